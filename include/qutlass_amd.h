@@ -1,0 +1,121 @@
+/*
+ * qutlass_amd.h -- C ABI of the MI355X (gfx950) microscaled low-bit GEMM library.
+ *
+ * This is the drop-in boundary for the qutlass hot path: every entry point replaces one host
+ * launcher that the reference's torch op bindings (qutlass/csrc/bindings.cpp) call, with plain
+ * device pointers, sizes and a HIP stream instead of torch::stable::Tensor.  A maintainer of the
+ * reference binds these from bindings.cpp (or from Python via ctypes) -- see INTEGRATION.md.
+ *
+ * Conventions
+ *   - all pointers are DEVICE pointers on the current HIP device; `stream` is a hipStream_t
+ *     (NULL = the legacy default stream).  Calls are asynchronous and never synchronise.
+ *   - return value: 0 = launched; QAMD_ERR_INVALID = argument rejected (nothing launched);
+ *     QAMD_ERR_HIP = the HIP runtime refused the launch.  qutlass_amd_last_error() returns a
+ *     thread-local message for the last non-zero return.
+ *   - no global state besides the two tuning options below; re-entrant; no allocation, no
+ *     workspace (the reference cudaMalloc's a CUTLASS workspace per call, gemm.cu:160-162).
+ */
+#ifndef QUTLASS_AMD_H_
+#define QUTLASS_AMD_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define QAMD_OK 0
+#define QAMD_ERR_INVALID 1
+#define QAMD_ERR_HIP 2
+
+#define QAMD_METHOD_QUEST 0
+#define QAMD_METHOD_ABSMAX 1
+
+/* ---- block-scaled GEMMs:  D[M,N] (bf16, row-major) = alpha[0] * (A.SFA) (B.SFB)^T ------------- */
+
+/*
+ * MXFP4.  A: (M, K/2) bytes, B: (N, K/2) bytes, two e2m1 per byte (element 2j = low nibble), K % 128 == 0.
+ * A_sf / B_sf: e8m0, one per 32 K-elements, in the to_blocked layout of a
+ * (ceil(M/128)*128, ceil(K/128)*4) matrix (resp. N).  alpha: device fp32[1].  N % 8 == 0.
+ * Replaces matmul_host_mxf4_bf16_tn (qutlass/csrc/gemm.cu:174-248; declared include/gemm.h:21-27;
+ * called from bindings.cpp:32-66).
+ */
+int qutlass_amd_matmul_mxf4_bf16_tn(const void* A, const void* B, const void* A_sf, const void* B_sf,
+                                    const float* alpha, void* D, int64_t M, int64_t N, int64_t K,
+                                    void* stream);
+
+/*
+ * NVFP4.  Same operand layout, scales are e4m3fn per 16 K-elements in the to_blocked layout of a
+ * (ceil(M/128)*128, ceil(K/64)*4) matrix; K % 32 == 0.
+ * Replaces matmul_host_nvf4_bf16_tn (gemm.cu:250-326; bindings.cpp:68-102).
+ */
+int qutlass_amd_matmul_nvf4_bf16_tn(const void* A, const void* B, const void* A_sf, const void* B_sf,
+                                    const float* alpha, void* D, int64_t M, int64_t N, int64_t K,
+                                    void* stream);
+
+/*
+ * MXFP8 (e4m3fn data, e8m0 per 32).  TN: A (M,K), B (N,K) row-major.  K % 32 == 0.
+ * Replaces matmul_host_mxf8_bf16_tn (gemm.cu:328-386; bindings.cpp:140-177).
+ */
+int qutlass_amd_matmul_mxf8_bf16_tn(const void* A, const void* B, const void* A_sf, const void* B_sf,
+                                    const float* alpha, void* D, int64_t M, int64_t N, int64_t K,
+                                    void* stream);
+
+/*
+ * MXFP8 NN: A is stored (K, M) row-major (the reference's ColumnMajor A), B (N, K).
+ * Replaces matmul_host_mxf8_bf16_nn (gemm.cu:388-434; bindings.cpp:179-216).
+ */
+int qutlass_amd_matmul_mxf8_bf16_nn(const void* A, const void* B, const void* A_sf, const void* B_sf,
+                                    const float* alpha, void* D, int64_t M, int64_t N, int64_t K,
+                                    void* stream);
+
+/* ---- fused rotate + quantize ------------------------------------------------------------------ */
+
+/*
+ * x: bf16[numel] viewed as (numel/rot, rot); h: bf16[rot*rot] row-major (runtime matrix, y = x_g . h);
+ * rot in {32, 64, 128}; numel % rot == 0.  method: QAMD_METHOD_QUEST / QAMD_METHOD_ABSMAX.
+ * out_e2m1: numel/2 bytes; out_e8m0: numel/32 bytes written FLAT in group order (the caller's
+ * (padded_rows, padded_cols) buffer keeps its padding untouched, as in the reference);
+ * out_mask: NULL, or numel/8 bytes (one u32 per 32-group; quest + rot 32 only).
+ * Replaces fusedQuantizeMx{Quest,AbsMax}{,Had64,Had128}_host (fused_quantize_mx.cu:107-207) and
+ * fusedQuantizeMxQuestWithMask_host (fused_quantize_mx_mask.cu:107-123); bindings.cpp:218-333.
+ */
+int qutlass_amd_fused_quantize_mx(const void* x, const void* h, int rot, int64_t numel, int method,
+                                  void* out_e2m1, void* out_e8m0, void* out_mask, void* stream);
+
+/*
+ * NVFP4 variant: rot in {16, 32, 64, 128}; out_e4m3: numel/16 bytes (e4m3fn), flat;
+ * global_scale: device fp32[1].
+ * Replaces fusedQuantizeNv{Quest,AbsMax}{,Had32,Had64,Had128}_host (fused_quantize_nv.cu:109-252;
+ * bindings.cpp:335-426).
+ */
+int qutlass_amd_fused_quantize_nv(const void* x, const void* h, int rot, int64_t numel, int method,
+                                  const float* global_scale, void* out_e2m1, void* out_e4m3,
+                                  void* stream);
+
+/* ---- block-scale swizzle ------------------------------------------------------------------------ */
+
+/*
+ * in: (rows, cols) row-major 1-byte elements; out: ceil(rows/128)*128 * ceil(cols/4)*4 bytes in the
+ * 128x4 tiled order, zero padded.  Replaces qutlass/utils.py:160-193 (to_blocked) incl. the Triton
+ * kernel at :16-133.
+ */
+int qutlass_amd_to_blocked(const void* in, int64_t rows, int64_t cols, void* out, void* stream);
+
+/* ---- misc ----------------------------------------------------------------------------------------- */
+
+const char* qutlass_amd_last_error(void);
+const char* qutlass_amd_version(void);
+
+/*
+ * Tuning / verification switches (process-wide, default in parentheses):
+ *   "hw_fp4_cvt"    use v_cvt_scalef32_pk_fp4_f32 for the final e2m1 rounding
+ *   "gemm_variant" (0 = auto) force a tile configuration of the MX GEMMs (bench sweeps)
+ * Returns the previous value, or -1 for an unknown key.
+ */
+int qutlass_amd_set_option(const char* key, int value);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* QUTLASS_AMD_H_ */

@@ -1,0 +1,253 @@
+// C ABI (include/qutlass_amd.h) -> kernel launches.  No torch types, no allocation, no sync.
+#include <hip/hip_runtime.h>
+
+#include <atomic>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+
+#include "../../include/qutlass_amd.h"
+#include "gemm_mx.hip.h"
+#include "gemm_nvf4.hip.h"
+#include "quantize.hip.h"
+#include "to_blocked.hip.h"
+
+using namespace qamd;
+
+namespace {
+
+thread_local char g_err[512] = "";
+std::atomic<int> g_hw_fp4_cvt{0};
+std::atomic<int> g_gemm_variant{0};
+std::atomic<int> g_pp_shift{2};
+std::atomic<int> g_pp_flags{1};
+std::atomic<uint32_t*> g_dbg{nullptr};
+
+int fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+int check_launch(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(QAMD_ERR_HIP, "%s: %s", what, hipGetErrorString(e));
+  return QAMD_OK;
+}
+
+inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+template <class C, int PP>
+int launch_gemm(GemmParams p, hipStream_t s) {
+  p.tiles_m = (int)cdiv(p.M, C::BM);
+  p.tiles_n = (int)cdiv(p.N, C::BN);
+  hipLaunchKernelGGL((gemm_mx_kernel<C, PP>), dim3(p.tiles_m * p.tiles_n), dim3(C::THREADS), 0, s, p);
+  return check_launch("gemm_mx_kernel");
+}
+
+// Tile/schedule variants ("gemm_variant" option; 0 = auto):
+//   1  256x256 ping-pong     5  256x256 lockstep     6..9  queue schedule (256x256, 128x128, 256x128, 128x256)
+//   2  128x128 lockstep (small M or N)                     3  256x128 lockstep    4  128x256 lockstep
+//   100+b / 200+b  ablations of variants 1 / 5 (bench only), b = OR of ABL_* bits
+template <int EBITS, bool SPLIT>
+int dispatch_variant(int v, const GemmParams& p, hipStream_t s, const char* name) {
+  switch (v) {
+    case 1: return launch_gemm<GemmCfg<256, 256, 2, 4, EBITS, SPLIT>, 1>(p, s);
+    case 2: return launch_gemm<GemmCfg<128, 128, 2, 2, EBITS, SPLIT>, 0>(p, s);
+    case 3: return launch_gemm<GemmCfg<256, 128, 4, 2, EBITS, SPLIT>, 0>(p, s);
+    case 4: return launch_gemm<GemmCfg<128, 256, 2, 4, EBITS, SPLIT>, 0>(p, s);
+    case 5: return launch_gemm<GemmCfg<256, 256, 2, 4, EBITS, SPLIT>, 0>(p, s);
+  }
+  if constexpr (EBITS == 4) {
+    switch (v) {
+      case 6: return launch_gemm<GemmCfg<256, 256, 2, 4, 4, false>, 2>(p, s);
+      case 7: return launch_gemm<GemmCfg<128, 128, 2, 2, 4, false>, 2>(p, s);
+      case 8: return launch_gemm<GemmCfg<256, 128, 4, 2, 4, false>, 2>(p, s);
+      case 9: return launch_gemm<GemmCfg<128, 256, 2, 4, 4, false>, 2>(p, s);
+    }
+  }
+  if constexpr (EBITS == 4 && !SPLIT) {
+    switch (v) {
+#define QAMD_ABL(b) \
+      case 100 + b: return launch_gemm<GemmCfg<256, 256, 2, 4, 4, false, b>, 1>(p, s); \
+      case 200 + b: return launch_gemm<GemmCfg<256, 256, 2, 4, 4, false, b>, 0>(p, s); \
+      case 300 + b: return launch_gemm<GemmCfg<256, 256, 2, 4, 4, false, b>, 2>(p, s);
+      QAMD_ABL(1) QAMD_ABL(2) QAMD_ABL(3) QAMD_ABL(4) QAMD_ABL(8) QAMD_ABL(9) QAMD_ABL(10) QAMD_ABL(11) QAMD_ABL(16) QAMD_ABL(17) QAMD_ABL(18)
+#undef QAMD_ABL
+    }
+  }
+  return fail(QAMD_ERR_INVALID, "%s: unknown gemm_variant %d", name, v);
+}
+
+// EBITS: 4 = MXFP4, 8 = MXFP8 (TN)
+template <int EBITS>
+int gemm_mx(const char* name, const void* A, const void* B, const void* A_sf, const void* B_sf,
+            const float* alpha, void* D, int64_t M, int64_t N, int64_t K, void* stream) {
+  if (!A || !B || !A_sf || !B_sf || !alpha || !D) return fail(QAMD_ERR_INVALID, "%s: null pointer argument", name);
+  if (M <= 0 || N <= 0) return fail(QAMD_ERR_INVALID, "%s: M and N must be positive (got M=%lld N=%lld)", name, (long long)M, (long long)N);
+  const int kalign = (EBITS == 4) ? 128 : 32;
+  if (K < 32 || K % kalign) return fail(QAMD_ERR_INVALID, "%s: K must be a positive multiple of %d (got %lld)", name, kalign, (long long)K);
+  if (N % 8) return fail(QAMD_ERR_INVALID, "%s: N must be a multiple of 8 (got %lld)", name, (long long)N);
+  const int64_t rowbytes = K * EBITS / 8;
+  const int64_t CB = cdiv(K / 32, 4);
+  const int64_t a_bytes = M * rowbytes, b_bytes = N * rowbytes;
+  const int64_t sfa_bytes = cdiv(M, 128) * CB * 512, sfb_bytes = cdiv(N, 128) * CB * 512;
+  if (a_bytes >= (1ll << 31) || b_bytes >= (1ll << 31) || M * N >= (1ll << 40))
+    return fail(QAMD_ERR_INVALID, "%s: operand larger than 2 GiB is not supported", name);
+  GemmParams p;
+  p.A = (const uint8_t*)A; p.B = (const uint8_t*)B; p.SFA = (const uint8_t*)A_sf; p.SFB = (const uint8_t*)B_sf;
+  p.alpha = alpha; p.D = (uint16_t*)D; p.M = (int)M; p.N = (int)N; p.K = (int)K;
+  p.a_bytes = (uint32_t)a_bytes; p.b_bytes = (uint32_t)b_bytes;
+  p.sfa_bytes = (uint32_t)sfa_bytes; p.sfb_bytes = (uint32_t)sfb_bytes;
+  p.pp_shift = g_pp_shift.load();
+  p.pp_flags = g_pp_flags.load();
+  p.dbg = g_dbg.load();
+  hipStream_t s = (hipStream_t)stream;
+  int variant = g_gemm_variant.load();
+  if (variant == 0) variant = (M <= 128 || N <= 128) ? 2 : 1;
+  return dispatch_variant<EBITS, EBITS == 8>(variant, p, s, name);
+}
+
+template <int R, bool NV, int METHOD, bool MASK>
+int launch_quant(const QuantParams& p, hipStream_t s, int grid) {
+  if (g_hw_fp4_cvt.load())
+    hipLaunchKernelGGL((fused_quantize_kernel<R, NV, METHOD, MASK, true>), dim3(grid), dim3(256), 0, s, p);
+  else
+    hipLaunchKernelGGL((fused_quantize_kernel<R, NV, METHOD, MASK, false>), dim3(grid), dim3(256), 0, s, p);
+  return check_launch("fused_quantize_kernel");
+}
+
+template <bool NV, int METHOD, bool MASK>
+int dispatch_rot(int rot, const QuantParams& p, hipStream_t s, int grid, const char* name) {
+  switch (rot) {
+    case 16:
+      if constexpr (NV) return launch_quant<16, NV, METHOD, false>(p, s, grid);
+      break;
+    case 32: return launch_quant<32, NV, METHOD, MASK>(p, s, grid);
+    case 64:
+      if constexpr (!MASK) return launch_quant<64, NV, METHOD, false>(p, s, grid);
+      break;
+    case 128:
+      if constexpr (!MASK) return launch_quant<128, NV, METHOD, false>(p, s, grid);
+      break;
+  }
+  if (MASK) return fail(QAMD_ERR_INVALID, "%s: Unsupported rotation size %d; expected 32.", name, rot);
+  return fail(QAMD_ERR_INVALID, "%s: Unsupported rotation size %d; expected %s32, 64, or 128.", name, rot, NV ? "16, " : "");
+}
+
+int quant_grid(int ntiles) {
+  // 4 waves per workgroup, one 32-row tile per wave per trip; cap at 8 workgroups per CU
+  int g = (ntiles + 3) / 4;
+  const int cap = 256 * 8;
+  return g < 1 ? 1 : (g > cap ? cap : g);
+}
+
+}  // namespace
+
+extern "C" {
+
+int qutlass_amd_matmul_mxf4_bf16_tn(const void* A, const void* B, const void* A_sf, const void* B_sf,
+                                    const float* alpha, void* D, int64_t M, int64_t N, int64_t K, void* stream) {
+  return gemm_mx<4>("matmul_mxf4_bf16_tn", A, B, A_sf, B_sf, alpha, D, M, N, K, stream);
+}
+
+int qutlass_amd_matmul_mxf8_bf16_tn(const void* A, const void* B, const void* A_sf, const void* B_sf,
+                                    const float* alpha, void* D, int64_t M, int64_t N, int64_t K, void* stream) {
+  return gemm_mx<8>("matmul_mxf8_bf16_tn", A, B, A_sf, B_sf, alpha, D, M, N, K, stream);
+}
+
+int qutlass_amd_matmul_mxf8_bf16_nn(const void*, const void*, const void*, const void*, const float*, void*,
+                                    int64_t, int64_t, int64_t, void*) {
+  return fail(QAMD_ERR_INVALID, "matmul_mxf8_bf16_nn: not implemented in this build");
+}
+
+int qutlass_amd_matmul_nvf4_bf16_tn(const void* A, const void* B, const void* A_sf, const void* B_sf,
+                                    const float* alpha, void* D, int64_t M, int64_t N, int64_t K, void* stream) {
+  const char* name = "matmul_nvf4_bf16_tn";
+  if (!A || !B || !A_sf || !B_sf || !alpha || !D) return fail(QAMD_ERR_INVALID, "%s: null pointer argument", name);
+  if (M <= 0 || N <= 0) return fail(QAMD_ERR_INVALID, "%s: M and N must be positive", name);
+  if (K < 16 || K % 32) return fail(QAMD_ERR_INVALID, "%s: K must be a positive multiple of 32 (got %lld)", name, (long long)K);
+  if (N % 8) return fail(QAMD_ERR_INVALID, "%s: N must be a multiple of 8 (got %lld)", name, (long long)N);
+  if (M * (K / 2) >= (1ll << 31) || N * (K / 2) >= (1ll << 31))
+    return fail(QAMD_ERR_INVALID, "%s: operand larger than 2 GiB is not supported", name);
+  NvGemmParams p;
+  p.A = (const uint8_t*)A; p.B = (const uint8_t*)B; p.SFA = (const uint8_t*)A_sf; p.SFB = (const uint8_t*)B_sf;
+  p.alpha = alpha; p.D = (uint16_t*)D; p.M = (int)M; p.N = (int)N; p.K = (int)K;
+  const int64_t CB = cdiv(K / 16, 4);
+  p.a_bytes = (uint32_t)(M * (K / 2)); p.b_bytes = (uint32_t)(N * (K / 2));
+  p.sfa_bytes = (uint32_t)(cdiv(M, 128) * CB * 512); p.sfb_bytes = (uint32_t)(cdiv(N, 128) * CB * 512);
+  return launch_nvf4_gemm(p, (hipStream_t)stream) == hipSuccess ? check_launch(name) : check_launch(name);
+}
+
+int qutlass_amd_fused_quantize_mx(const void* x, const void* h, int rot, int64_t numel, int method,
+                                  void* out_e2m1, void* out_e8m0, void* out_mask, void* stream) {
+  const char* name = "fusedQuantizeMx";
+  if (!x || !h || !out_e2m1 || !out_e8m0) return fail(QAMD_ERR_INVALID, "%s: null pointer argument", name);
+  if (rot != 32 && rot != 64 && rot != 128)
+    return fail(QAMD_ERR_INVALID, "%s: Unsupported rotation size %d; expected %s.", name, rot, out_mask ? "32" : "32, 64, or 128");
+  if (numel <= 0 || numel % rot) return fail(QAMD_ERR_INVALID, "%s: A must be divisible by %d", name, rot);
+  if (numel * 2 >= (1ll << 32)) return fail(QAMD_ERR_INVALID, "%s: more than 2^31 elements is not supported", name);
+  if (method != QAMD_METHOD_QUEST && method != QAMD_METHOD_ABSMAX) return fail(QAMD_ERR_INVALID, "%s: invalid method %d", name, method);
+  if (out_mask && method != QAMD_METHOD_QUEST) return fail(QAMD_ERR_INVALID, "%s: the clip mask is only defined for method quest", name);
+  QuantParams p;
+  p.x = (const uint16_t*)x; p.h = (const uint16_t*)h; p.out = (uint8_t*)out_e2m1; p.out_sf = (uint8_t*)out_e8m0;
+  p.out_mask = (uint32_t*)out_mask; p.global_scale = nullptr; p.numel = numel;
+  p.ntiles = (int)cdiv(numel, (int64_t)rot * 32);
+  const int grid = quant_grid(p.ntiles);
+  hipStream_t s = (hipStream_t)stream;
+  if (out_mask) return dispatch_rot<false, METHOD_QUEST, true>(rot, p, s, grid, name);
+  if (method == QAMD_METHOD_QUEST) return dispatch_rot<false, METHOD_QUEST, false>(rot, p, s, grid, name);
+  return dispatch_rot<false, METHOD_ABSMAX, false>(rot, p, s, grid, name);
+}
+
+int qutlass_amd_fused_quantize_nv(const void* x, const void* h, int rot, int64_t numel, int method,
+                                  const float* global_scale, void* out_e2m1, void* out_e4m3, void* stream) {
+  const char* name = "fusedQuantizeNv";
+  if (!x || !h || !out_e2m1 || !out_e4m3 || !global_scale) return fail(QAMD_ERR_INVALID, "%s: null pointer argument", name);
+  if (rot != 16 && rot != 32 && rot != 64 && rot != 128)
+    return fail(QAMD_ERR_INVALID, "%s: Unsupported rotation size %d; expected 16, 32, 64, or 128.", name, rot);
+  if (numel <= 0 || numel % rot) return fail(QAMD_ERR_INVALID, "%s: A must be divisible by %d", name, rot);
+  if (numel * 2 >= (1ll << 32)) return fail(QAMD_ERR_INVALID, "%s: more than 2^31 elements is not supported", name);
+  if (method != QAMD_METHOD_QUEST && method != QAMD_METHOD_ABSMAX) return fail(QAMD_ERR_INVALID, "%s: invalid method %d", name, method);
+  QuantParams p;
+  p.x = (const uint16_t*)x; p.h = (const uint16_t*)h; p.out = (uint8_t*)out_e2m1; p.out_sf = (uint8_t*)out_e4m3;
+  p.out_mask = nullptr; p.global_scale = global_scale; p.numel = numel;
+  const int rp = rot < 32 ? 32 : rot;
+  p.ntiles = (int)cdiv(numel, (int64_t)rp * 32);
+  const int grid = quant_grid(p.ntiles);
+  hipStream_t s = (hipStream_t)stream;
+  if (method == QAMD_METHOD_QUEST) return dispatch_rot<true, METHOD_QUEST, false>(rot, p, s, grid, name);
+  return dispatch_rot<true, METHOD_ABSMAX, false>(rot, p, s, grid, name);
+}
+
+int qutlass_amd_to_blocked(const void* in, int64_t rows, int64_t cols, void* out, void* stream) {
+  if (!in || !out) return fail(QAMD_ERR_INVALID, "to_blocked: null pointer argument");
+  if (rows <= 0 || cols <= 0 || rows >= (1ll << 31) || cols >= (1ll << 31))
+    return fail(QAMD_ERR_INVALID, "to_blocked: bad shape (%lld, %lld)", (long long)rows, (long long)cols);
+  BlockedParams p;
+  p.in = (const uint8_t*)in; p.out = (uint8_t*)out; p.rows = (int)rows; p.cols = (int)cols;
+  p.RB = (int)cdiv(rows, 128); p.CB = (int)cdiv(cols, 4);
+  const int64_t grid = (int64_t)p.RB * cdiv(p.CB, 32);
+  if (grid >= (1ll << 31)) return fail(QAMD_ERR_INVALID, "to_blocked: matrix too large");
+  hipLaunchKernelGGL(to_blocked_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, p);
+  return check_launch("to_blocked_kernel");
+}
+
+// bench/debug only (not declared in the public header): device buffer for ABL_TRACE builds
+void qutlass_amd_debug_set_trace_buffer(void* p) { g_dbg.store((uint32_t*)p); }
+
+const char* qutlass_amd_last_error(void) { return g_err; }
+const char* qutlass_amd_version(void) { return "qutlass_amd 0.1.0 (gfx950)"; }
+
+int qutlass_amd_set_option(const char* key, int value) {
+  if (!key) return -1;
+  if (!strcmp(key, "hw_fp4_cvt")) return g_hw_fp4_cvt.exchange(value);
+  if (!strcmp(key, "gemm_variant")) return g_gemm_variant.exchange(value);
+  if (!strcmp(key, "pp_shift")) return g_pp_shift.exchange(value);
+  if (!strcmp(key, "pp_flags")) return g_pp_flags.exchange(value);
+  return -1;
+}
+
+}  // extern "C"

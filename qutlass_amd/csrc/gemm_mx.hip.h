@@ -1,0 +1,594 @@
+// Block-scaled MX GEMM for gfx950:  D[M,N] (bf16) = alpha * (A . SFA) (B . SFB)^T
+//
+//   A: (M, K) row-major, B: (N, K) row-major ("TN"), elements e2m1 (EBITS=4, two per byte, MXFP4)
+//   or e4m3 (EBITS=8, MXFP8); SFA/SFB: e8m0 per 32 K-elements in the to_blocked 128x4 tiling.
+//   Replaces qutlass/csrc/gemm.cu:174-248 (matmul_host_mxf4_bf16_tn) and :328-386
+//   (matmul_host_mxf8_bf16_tn) of the reference, whose arithmetic lives in CUTLASS collectives.
+//
+// CDNA4 mapping:
+//   * v_mfma_scale_f32_32x32x64_f8f6f4.  FP4: one lane holds 32 consecutive K elements of one row,
+//     i.e. exactly one MX scale group, and the hardware applies the lane's e8m0 byte (selected from
+//     a 32-bit scale register by op_sel) to it (device-verified, tests/native/probe.hip P1).  The
+//     to_blocked layout puts the four K-block scales of a row in one dword and the four 32-row
+//     slabs of a 128-row tile in one 16-byte line, so a lane fetches all scales of its MT
+//     row-fragments x 4 K-blocks with ONE ds_read_b128.
+//   * K is walked in stages of 128 BYTES per row (256 fp4 / 128 fp8 elements).  Within a stage the
+//     two 32-lane halves of the wave take disjoint K-blocks (fp4: half g owns 16-byte chunks
+//     4g..4g+3), so the k-slice index j of an MFMA is both the chunk offset and the op_sel byte.
+//   * Stages are copied HBM/L2 -> LDS by LDS-DMA (buffer_load_dwordx4 ... lds), each wave
+//     instruction moving 8 rows x 128 B (full cache lines).  The LDS image is lane-linear, so the
+//     16-byte-chunk XOR swizzle (chunk ^= (row>>1)&7) that makes the ds_read_b128 fragment reads
+//     bank-conflict free is applied to the per-lane SOURCE address and to the read address.
+//   * Operand roles are swapped in the MFMA (srcA = B fragment, srcB = A fragment) so a lane ends
+//     up with 4 consecutive N for one M row: the bf16 epilogue packs 8-byte pieces, stages the
+//     tile through LDS and writes whole 128-byte lines.
+//   * blockIdx -> tile: XCD-contiguous remap + grouped raster so one XCD's L2 sees a compact
+//     rectangle of tiles.
+//   * Two schedules share all of the above: gemm_mx_lockstep (one barrier per stage, used for small
+//     tiles) and gemm_mx_pingpong (two wave groups ping-ponging load and MFMA blocks).
+#pragma once
+#include <type_traits>
+
+#include "common.hip.h"
+
+namespace qamd {
+
+struct GemmParams {
+  const uint8_t* A;
+  const uint8_t* B;
+  const uint8_t* SFA;
+  const uint8_t* SFB;
+  const float* alpha;
+  uint16_t* D;
+  int M, N, K;           // K in elements
+  int tiles_m, tiles_n;  // grid = tiles_m * tiles_n
+  uint32_t a_bytes, b_bytes, sfa_bytes, sfb_bytes;
+  int pp_shift;          // ping-pong: wave group = (wave >> pp_shift) & 1
+  int pp_flags;          // bit0: s_setprio around MFMA blocks
+  uint32_t* dbg;         // ABL_TRACE builds only: per-wave timestamp dump of workgroup 0
+};
+
+// ablation bits (bench-only instantiations; 0 in the product path)
+enum { ABL_NO_DMA = 1, ABL_NO_MFMA = 2, ABL_NO_STORE = 4, ABL_NO_EPILOGUE = 8, ABL_TRACE = 16 };
+
+template <int BM_, int BN_, int WAVES_M_, int WAVES_N_, int EBITS_, bool F8SPLIT_ = false, int ABL_ = 0>
+struct GemmCfg {
+  static constexpr int BM = BM_, BN = BN_, WAVES_M = WAVES_M_, WAVES_N = WAVES_N_, EBITS = EBITS_;
+  static constexpr bool F8SPLIT = F8SPLIT_;
+  static constexpr int ABL = ABL_;
+  static constexpr int NWAVES = WAVES_M * WAVES_N, THREADS = NWAVES * 64;
+  static constexpr int WTM = BM / WAVES_M, WTN = BN / WAVES_N, MT = WTM / 32, NT = WTN / 32;
+  static constexpr int ROWB = 128;                 // bytes of K per row per stage
+  static constexpr int BK = ROWB * 8 / EBITS;      // K elements per stage
+  static constexpr int KSL = BK / 64;              // MFMA k-slices per stage (4 fp4 / 2 fp8)
+  static constexpr int CPS = 16 * EBITS / 64;      // 16-byte chunks per lane per slice (1 / 2)
+  static constexpr int SCT = BK / 128;             // scale column tiles (4 K-blocks) per stage
+  static constexpr int SA_TILES = (BM + 127) / 128, SB_TILES = (BN + 127) / 128;
+  static constexpr int PA = SA_TILES * SCT, PB = SB_TILES * SCT;   // 512-byte scale pieces (128 rows x 4 K-blocks)
+  static constexpr int A_BYTES = BM * ROWB, B_BYTES = BN * ROWB;
+  // scale piece i is fetched by wave i into its own 1-KiB LDS slot (lanes 0-31 carry the 512 bytes,
+  // lanes 32-63 load out-of-range zeros into the slot's pad half): every wave issues the same
+  // instruction sequence, so the K loop needs no wave-dependent branch.
+  static constexpr int OFF_B = A_BYTES, OFF_S = A_BYTES + B_BYTES, S_BYTES = NWAVES * 1024;
+  static constexpr int STAGE_BYTES = OFF_S + S_BYTES;
+  static constexpr int NA = BM / 8 / NWAVES, NB = BN / 8 / NWAVES;  // 1-KiB DMA pieces per wave
+  static constexpr int SROW = BN * 2;   // epilogue staging row stride (8-byte granules XOR-swizzled by row)
+  static constexpr int LDS_MAIN = (2 * STAGE_BYTES > BM * SROW) ? 2 * STAGE_BYTES : BM * SROW;
+  static constexpr int TRACE_SLOTS = 96;
+  static constexpr int LDS_BYTES = LDS_MAIN + ((ABL_ & 16) ? NWAVES * TRACE_SLOTS * 4 : 0);
+  static_assert(BM % (8 * NWAVES) == 0 && BN % (8 * NWAVES) == 0, "DMA split");
+  static_assert(WTM % 32 == 0 && WTN % 32 == 0, "wave tile");
+  static_assert(PA + PB <= NWAVES, "one scale piece per wave");
+  static_assert(THREADS % (BN / 8) == 0, "epilogue split");
+};
+
+// Per-thread state + the building blocks shared by both schedules.
+template <class C>
+struct GemmCtx {
+  static constexpr int MT = C::MT, NT = C::NT, KSL = C::KSL, CPS = C::CPS;
+  char* smem;
+  const GemmParams& p;
+  int tid, lane, wave, wave_m, wave_n, i32, g;
+  int m0, n0, rowbytes, KT, CB;
+  bool ktail;
+  __amdgpu_buffer_rsrc_t rA, rB, rS;   // rS: the scale tensor (A's or B's) this wave fetches from
+  int voffAB[2];   // per-lane source offset of a 1-KiB DMA piece, for even / odd piece index (rows 8q..8q+7)
+  int voffT[2];    // the same for the last stage when K is not a multiple of the stage (chunks past K: out of range)
+  int rstep;       // 8 * rowbytes: byte distance between consecutive pieces
+  int voffS, colS; // scale piece of this wave
+  bool sIsB;
+  int rdA[KSL * CPS];   // fragment read address of chunk slot (j, u) for the A rows of this lane
+  int rdBd;             // wave-uniform: B fragment address = rdA[..] + rdBd
+  int rdSA[MT], rdSB[NT];
+  v16f acc[MT][NT];
+  v8i fa[KSL][MT], fb[KSL][NT];   // only the slices a schedule keeps live are materialised
+  int sa[MT], sb[NT];
+
+  __device__ __forceinline__ GemmCtx(char* smem_, const GemmParams& p_) : smem(smem_), p(p_) {
+    tid = threadIdx.x;
+    lane = tid & 63;
+    wave = uniform(tid >> 6);
+    wave_m = wave / C::WAVES_N;
+    wave_n = wave % C::WAVES_N;
+    i32 = lane & 31;
+    g = lane >> 5;
+
+    // ---- tile coordinates (XCD-contiguous, grouped raster) ----------------------------------
+    int tile_m, tile_n;
+    {
+      const int nb = p.tiles_m * p.tiles_n;
+      const int b2 = xcd_remap(blockIdx.x, nb);
+      constexpr int GM = 4;
+      const int group = GM * p.tiles_n;
+      const int gid = b2 / group;
+      const int first_m = gid * GM;
+      const int gsz = min(p.tiles_m - first_m, GM);
+      tile_m = first_m + (b2 % group) % gsz;
+      tile_n = (b2 % group) / gsz;
+    }
+    m0 = tile_m * C::BM;
+    n0 = tile_n * C::BN;
+    rowbytes = (p.K * C::EBITS) >> 3;
+    KT = (rowbytes + C::ROWB - 1) / C::ROWB;
+    CB = (p.K / 32 + 3) >> 2;
+    ktail = (rowbytes % C::ROWB) != 0;
+
+    // ---- DMA descriptors and per-lane source offsets ----------------------------------------
+    const uint32_t a_off = (uint32_t)m0 * rowbytes, b_off = (uint32_t)n0 * rowbytes;
+    rA = make_rsrc(p.A + a_off, p.a_bytes - a_off);
+    rB = make_rsrc(p.B + b_off, p.b_bytes - b_off);
+    const uint32_t sa_off = (uint32_t)(m0 >> 7) * CB * 512, sb_off = (uint32_t)(n0 >> 7) * CB * 512;
+
+    // piece q of an operand covers rows 8q..8q+7; lane L -> row 8q + (L>>3), physical chunk L&7,
+    // logical chunk (L&7) ^ ((row>>1)&7) = (L&7) ^ ((L>>4) + 4(q&1)): only the parity of q matters, so
+    // two per-lane offsets (relative to row 8q) serve every piece; the piece's row offset q*8*rowbytes
+    // and the K offset of the stage travel in the scalar soffset operand.
+    rstep = 8 * rowbytes;
+#pragma unroll
+    for (int par = 0; par < 2; ++par)
+    {
+      const int ch = (lane & 7) ^ (((lane >> 4) + 4 * par) & 7);
+      voffAB[par] = (lane >> 3) * rowbytes + (ch << 4);
+      voffT[par] = (ch * 16 < rowbytes - (KT - 1) * C::ROWB) ? voffAB[par] : 0x7fffffff;
+    }
+    // scale piece of this wave: pieces 0..PA-1 belong to A, PA..PA+PB-1 to B; piece -> (tile row, tile col)
+    {
+      sIsB = wave >= C::PA;
+      rS = sIsB ? make_rsrc(p.SFB + sb_off, p.sfb_bytes - sb_off) : make_rsrc(p.SFA + sa_off, p.sfa_bytes - sa_off);
+      const int idx = sIsB ? wave - C::PA : wave;
+      colS = idx % C::SCT;
+      voffS = (wave < C::PA + C::PB && g == 0) ? ((idx / C::SCT) * CB + colS) * 512 + i32 * 16 : 0x7fffffff;
+    }
+
+    // ---- LDS fragment read addresses --------------------------------------------------------
+    // fragment row r = wave_row0 + 32t + i32 ; phys chunk = logical chunk ^ ((r>>1)&7)
+    //   fp4              : slice j, lane half g        -> chunk 4g + j          (K-block 4g + j)
+    //   fp8 (contiguous) : slice j, register half u    -> chunk 4g + 2j + u     (K-block 2g + j)
+    //   fp8 (split)      : slice j, register half u    -> chunk 4j + 2u + g     (K-block 2j + u)
+    const int sw = (i32 >> 1) & 7;
+#pragma unroll
+    for (int j = 0; j < KSL; ++j)
+#pragma unroll
+      for (int u = 0; u < CPS; ++u) {
+        int c;
+        if (C::EBITS == 4) c = 4 * g + j;
+        else if (!C::F8SPLIT) c = 4 * g + 2 * j + u;
+        else c = 4 * j + 2 * u + g;
+        rdA[j * CPS + u] = (wave_m * C::WTM + i32) * C::ROWB + ((c ^ sw) << 4);
+      }
+    rdBd = C::OFF_B + (wave_n * C::WTN - wave_m * C::WTM) * C::ROWB;
+    // scale dwords: row r_abs = (m0 & 127) + wave_row0 + 32t (m0 & 127 only matters when BM < 128)
+    const int rbaseA = (C::BM >= 128) ? 0 : (m0 & 127), rbaseB = (C::BN >= 128) ? 0 : (n0 & 127);
+    const int scol = (C::SCT == 2) ? g : 0;   // fp4: half g owns column tile g of the stage
+#pragma unroll
+    for (int t = 0; t < MT; ++t) {
+      const int r = rbaseA + wave_m * C::WTM + 32 * t;
+      rdSA[t] = C::OFF_S + ((r >> 7) * C::SCT + scol) * 1024 + i32 * 16 + ((r & 127) >> 5) * 4;
+    }
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const int r = rbaseB + wave_n * C::WTN + 32 * t;
+      rdSB[t] = C::OFF_S + (C::PA + (r >> 7) * C::SCT + scol) * 1024 + i32 * 16 + ((r & 127) >> 5) * 4;
+    }
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int n = 0; n < NT; ++n)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+  }
+
+  int trace_n = 0;
+  __device__ __forceinline__ void trace() {
+    if (C::ABL & ABL_TRACE) {
+      if (blockIdx.x == 0 && trace_n < C::TRACE_SLOTS) {
+        const uint32_t t = (uint32_t)__builtin_readcyclecounter();
+        if (lane == 0) ((uint32_t*)(smem + C::LDS_MAIN))[wave * C::TRACE_SLOTS + trace_n] = t;
+      }
+      ++trace_n;
+    }
+  }
+  __device__ __forceinline__ void trace_dump() {
+    if (C::ABL & ABL_TRACE) {
+      __syncthreads();
+      if (blockIdx.x == 0 && p.dbg)
+        for (int i = tid; i < C::NWAVES * C::TRACE_SLOTS; i += C::THREADS) p.dbg[i] = ((uint32_t*)(smem + C::LDS_MAIN))[i];
+    }
+  }
+
+  // One operand's share of a stage for this wave: NP pieces q = wave*NP + t.  Branch-free: `valid == false`
+  // (no such stage) turns every lane's offset out of range, so the DMA writes zeros and the K loop stays one
+  // basic block.  The whole row offset stays in the per-lane voffset (one v_add per piece) so rows past the end
+  // of the tensor are out of range for the descriptor whatever the hardware does with soffset; soffset carries
+  // only the K offset of the stage.
+  __device__ __forceinline__ void issue_pieces(const int NP, __amdgpu_buffer_rsrc_t rsrc, char* dst, int kt, bool valid) {
+    const int soff = kt * C::ROWB;
+    // scalar masks made opaque to the optimiser: with plain selects LLVM threads the conditions into branches,
+    // which splits the K loop into several basic blocks and lets MachineSink pile every MFMA up at its end
+    int lastmask = (kt == KT - 1) ? -1 : 0;
+    int oob = valid ? 0 : 0x7f000000;
+    asm volatile("" : "+v"(lastmask), "+v"(oob));
+#pragma unroll
+    for (int t = 0; t < NP; ++t) {
+      const int q = wave * NP + t;
+      const int par = q & 1;
+      const int a = par ? voffAB[1] : voffAB[0], b = par ? voffT[1] : voffT[0];
+      const int base = (b & lastmask) | (a & ~lastmask);
+      const int v = base + q * rstep + oob;   // (unsigned) >= num_records when oob is set
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)(dst + q * 1024), 16, v, soff, 0, 0);
+    }
+  }
+  __device__ __forceinline__ void issue_scales(int kt, char* st, bool valid) {
+    int oob = (valid && kt * C::SCT + colS < CB) ? 0 : 0x7f000000;   // K tail: no such scale column tile
+    asm volatile("" : "+v"(oob));
+    const int ssoff = kt * C::SCT * 512;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rS, (lds_ptr_t)(st + C::OFF_S + wave * 1024), 16, voffS + oob, ssoff, 0, 0);
+  }
+  // half 0: the A pieces + the scale piece; half 1: the B pieces
+  __device__ __forceinline__ void issue_stage_part(int kt, int buf, int half, bool valid = true) {
+    char* st = smem + buf * C::STAGE_BYTES;
+    if (half == 0) {
+      issue_pieces(C::NA, rA, st, kt, valid);
+      issue_scales(kt, st, valid);
+    } else {
+      issue_pieces(C::NB, rB, st + C::OFF_B, kt, valid);
+    }
+  }
+  __device__ __forceinline__ void issue_stage(int kt, int buf) {
+    issue_stage_part(kt, buf, 0);
+    issue_stage_part(kt, buf, 1);
+  }
+
+  __device__ __forceinline__ void read_scales(int buf) {
+    const char* st = smem + buf * C::STAGE_BYTES;
+    // fp8: both halves read the same dword (4 K-blocks of the stage); bring "my" first byte down
+    const int shift = (C::EBITS == 4) ? 0 : (C::F8SPLIT ? 8 * g : 16 * g);
+#pragma unroll
+    for (int t = 0; t < MT; ++t) sa[t] = (int)((unsigned)(*(const int*)(st + rdSA[t])) >> shift);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) sb[t] = (int)((unsigned)(*(const int*)(st + rdSB[t])) >> shift);
+  }
+
+  __device__ __forceinline__ void read_frags(int buf, int j) {
+    const char* st = smem + buf * C::STAGE_BYTES;
+#pragma unroll
+    for (int t = 0; t < MT; ++t) {
+      const v4i lo = *(const v4i*)(st + rdA[j * CPS] + t * 32 * C::ROWB);
+      v4i hi = {0, 0, 0, 0};
+      if (CPS == 2) hi = *(const v4i*)(st + rdA[j * CPS + CPS - 1] + t * 32 * C::ROWB);
+      fa[j][t] = v8i{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    }
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const v4i lo = *(const v4i*)(st + rdBd + rdA[j * CPS] + t * 32 * C::ROWB);
+      v4i hi = {0, 0, 0, 0};
+      if (CPS == 2) hi = *(const v4i*)(st + rdBd + rdA[j * CPS + CPS - 1] + t * 32 * C::ROWB);
+      fb[j][t] = v8i{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    }
+  }
+
+  // op_sel byte of slice j:  fp4 -> j ; fp8 contiguous -> j ; fp8 split -> 2j.  `j` is always a literal
+  // at the call site; the branch chain folds after inlining (op_sel must be an immediate).
+  __device__ __forceinline__ void mfma_slice(const int j) {
+    constexpr int FMT = (C::EBITS == 4) ? 4 : 0;   // cbsz/blgp: 4 = e2m1, 0 = e4m3
+    const int ops = (C::EBITS == 8 && C::F8SPLIT) ? 2 * j : j;
+    if (C::ABL & ABL_NO_MFMA) {
+#pragma unroll
+      for (int t = 0; t < MT; ++t) asm volatile("" ::"v"(fa[j][t]));
+#pragma unroll
+      for (int t = 0; t < NT; ++t) asm volatile("" ::"v"(fb[j][t]));
+      return;
+    }
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int n = 0; n < NT; ++n) {
+        // srcA = B fragment (rows of the MFMA = n), srcB = A fragment (cols = m)
+        if (ops == 0) acc[m][n] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fb[j][n], fa[j][m], acc[m][n], FMT, FMT, 0, sb[n], 0, sa[m]);
+        if (ops == 1) acc[m][n] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fb[j][n], fa[j][m], acc[m][n], FMT, FMT, 1, sb[n], 1, sa[m]);
+        if (ops == 2) acc[m][n] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fb[j][n], fa[j][m], acc[m][n], FMT, FMT, 2, sb[n], 2, sa[m]);
+        if (ops == 3) acc[m][n] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fb[j][n], fa[j][m], acc[m][n], FMT, FMT, 3, sb[n], 3, sa[m]);
+      }
+  }
+
+  // ---- epilogue: alpha, bf16, stage through LDS, whole-line stores ---------------------------
+  __device__ __forceinline__ void epilogue() {
+    if (C::ABL & ABL_NO_EPILOGUE) {
+      float s = 0.f;
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) s += acc[m][n][r];
+      if (s == 123456.789f) p.D[tid] = 1;
+      return;
+    }
+    const float alpha = *p.alpha;
+    __syncthreads();
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int n = 0; n < NT; ++n)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int row = wave_m * C::WTM + 32 * m + i32;
+          const int cg = (wave_n * C::WTN + 32 * n + 8 * q + 4 * g) >> 2;   // 8-byte granule in the row
+          v2i w;
+          w[0] = pack_bf16x2(acc[m][n][4 * q + 0] * alpha, acc[m][n][4 * q + 1] * alpha);
+          w[1] = pack_bf16x2(acc[m][n][4 * q + 2] * alpha, acc[m][n][4 * q + 3] * alpha);
+          // granule ^ (row & 15): the 16 lanes of a ds_write_b64 group (16 consecutive rows) hit 32 banks
+          *(v2i*)(smem + row * C::SROW + ((cg ^ (row & 15)) << 3)) = w;
+        }
+    __syncthreads();
+    constexpr int CPR = C::BN / 8;               // 16-byte chunks per tile row
+    constexpr int RPP = C::THREADS / CPR;        // rows per pass
+    const int chunk = tid % CPR, r0 = tid / CPR;
+    const int gcol = n0 + chunk * 8;
+#pragma unroll 4
+    for (int pss = 0; pss < C::BM / RPP; ++pss) {
+      const int row = pss * RPP + r0;
+      const int grow = m0 + row;
+      if (grow < p.M && gcol < p.N) {
+        v4i v = *(const v4i*)(smem + row * C::SROW + ((((2 * chunk) ^ (row & 15)) & ~1) << 3));
+        if (row & 1) v = v4i{v[2], v[3], v[0], v[1]};   // odd rows hold the granule pair swapped
+        if (C::ABL & ABL_NO_STORE) {
+          if (v[0] == 0x12345678) p.D[(size_t)grow * p.N + gcol] = 1;
+        } else {
+          *(v4i*)(p.D + (size_t)grow * p.N + gcol) = v;
+        }
+      }
+    }
+  }
+};
+
+// -------------------------------------------------------------------------------------------------
+// Schedule 1: 2-stage ring, one barrier per stage (all waves in lockstep).
+// -------------------------------------------------------------------------------------------------
+template <class C>
+__device__ __forceinline__ void gemm_mx_lockstep(char* smem, const GemmParams& p) {
+  GemmCtx<C> cx(smem, p);
+  cx.issue_stage(0, 0);
+  for (int kt = 0; kt < cx.KT; ++kt) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();   // stage kt landed for every wave; everyone is done reading the other buffer
+    if (kt + 1 < cx.KT && !(C::ABL & ABL_NO_DMA)) cx.issue_stage(kt + 1, (kt + 1) & 1);
+    const int buf = kt & 1;
+    cx.read_scales(buf);
+    cx.read_frags(buf, 0);
+    cx.mfma_slice(0);
+    cx.read_frags(buf, 1);
+    cx.mfma_slice(1);
+    if (C::KSL == 4) {
+      cx.read_frags(buf, 2 % C::KSL);
+      cx.mfma_slice(2 % C::KSL);
+      cx.read_frags(buf, 3 % C::KSL);
+      cx.mfma_slice(3 % C::KSL);
+    }
+  }
+  cx.epilogue();
+}
+
+// -------------------------------------------------------------------------------------------------
+// Schedule 2: ping-pong.  The waves form two groups (wave < NWAVES/2 and the rest; waves w and
+// w + NWAVES/2 share a SIMD).  Every stage is four blocks separated by workgroup barriers:
+//     L0  ds_read scales + fragments of the first half of the k-slices, issue ALL LDS-DMA of stage kt+1
+//     M0  MFMAs of the first half
+//     L1  ds_read fragments of the second half; wait lgkmcnt(0) and vmcnt(0)
+//     M1  MFMAs of the second half
+// Group B runs one block behind group A (one extra barrier up front, one at the end for A), so on
+// every SIMD one wave is in an MFMA block while its partner is in a load block.
+// Hazards (barrier n of A pairs with barrier n of B, B's code being one block earlier):
+//   RAW  stage kt+1 is first read in A's L0(kt+1), entered through the barrier that closes A's M1(kt)
+//        and B's L1(kt); every wave executed vmcnt(0) for its own DMA at the end of its L1(kt).
+//   WAR  DMA of stage kt+1 is first issued in A's L0(kt), entered through the barrier that closes
+//        B's L1(kt-1), at whose end B waited lgkmcnt(0) for its last reads of that buffer.
+// -------------------------------------------------------------------------------------------------
+template <class C>
+__device__ __forceinline__ void gemm_mx_pingpong(char* smem, const GemmParams& p) {
+  GemmCtx<C> cx(smem, p);
+  const bool groupB = ((cx.wave >> p.pp_shift) & 1) != 0;
+  constexpr int H = C::KSL / 2;   // k-slices per half (2 fp4 / 1 fp8)
+
+  cx.issue_stage(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  if (groupB) __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_sched_barrier(0);
+
+  const bool prio = (p.pp_flags & 1) != 0;
+  cx.trace();
+  for (int kt = 0; kt < cx.KT; ++kt) {
+    const int buf = kt & 1;
+    // ---- L0 ----
+    cx.read_scales(buf);
+#pragma unroll
+    for (int j = 0; j < H; ++j) cx.read_frags(buf, j);
+    if (kt + 1 < cx.KT && !(C::ABL & ABL_NO_DMA)) cx.issue_stage(kt + 1, buf ^ 1);
+    __builtin_amdgcn_sched_barrier(0);
+    cx.trace();
+    __builtin_amdgcn_s_barrier();
+    cx.trace();
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- M0 ----
+    if (prio) __builtin_amdgcn_s_setprio(1);
+    cx.mfma_slice(0);
+    if (H == 2) cx.mfma_slice(1 % C::KSL);
+    if (prio) __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+    cx.trace();
+    __builtin_amdgcn_s_barrier();
+    cx.trace();
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- L1 ----
+#pragma unroll
+    for (int j = H; j < C::KSL; ++j) cx.read_frags(buf, j);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    cx.trace();
+    __builtin_amdgcn_s_barrier();
+    cx.trace();
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- M1 ----
+    if (prio) __builtin_amdgcn_s_setprio(1);
+    cx.mfma_slice(H);
+    if (H == 2) cx.mfma_slice(3 % C::KSL);
+    if (prio) __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+    cx.trace();
+    __builtin_amdgcn_s_barrier();
+    cx.trace();
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  if (!groupB) __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_sched_barrier(0);
+  cx.trace();
+  cx.epilogue();
+  cx.trace();
+  cx.trace_dump();
+}
+
+// -------------------------------------------------------------------------------------------------
+// Schedule 3 ("queue"): per-wave software pipeline that keeps the MFMA queue fed.
+//
+// Measured on MI355X (tests/native trace): a wave ISSUES an MFMA in ~12 cycles
+// and the matrix pipe works the queue off at 32 cycles per v_mfma_scale_f32_32x32x64 (fp4); but an
+// LDS read whose destination registers are still sources of a queued MFMA does not complete until
+// that MFMA has executed.  So the fragment registers are double-buffered per k-slice: slice s+1 is
+// read into the OTHER register set right after the MFMAs of slice s were queued, and an empty asm
+// keeps set s allocated across those reads so the compiler cannot reuse its registers.
+//
+// Per stage (4 k-slices, one workgroup barrier):
+//     M0 ; R1 ; DMA(kt+1) second half
+//     M1 ; R2
+//     M2 ; R3
+//     M3 ; wait own DMA(kt+1) + own reads ; BARRIER ; R0' (+ scales') ; DMA(kt+2) first half
+// RAW  R0' of stage kt+1 follows the barrier that every wave reaches after vmcnt(0) for its DMA(kt+1).
+// WAR  DMA(kt+2) overwrites the buffer of stage kt; it follows the barrier that every wave reaches
+//      after lgkmcnt(0) for its last reads (R3) of stage kt.
+// -------------------------------------------------------------------------------------------------
+template <class C>
+__device__ __forceinline__ void gemm_mx_queue(char* smem, const GemmParams& p) {
+  static_assert(C::EBITS == 4, "queue schedule is written for fp4 (4 k-slices of one 16-byte chunk)");
+  constexpr int MT = C::MT, NT = C::NT;
+  GemmCtx<C> cx(smem, p);
+  v4i fa[2][MT], fb[2][NT];
+  int sa[2][MT], sb[2][NT];
+
+  auto read_slice = [&](int buf, int j, int set) __attribute__((always_inline)) {
+    const char* st = smem + buf * C::STAGE_BYTES;
+#pragma unroll
+    for (int t = 0; t < MT; ++t) fa[set][t] = *(const v4i*)(st + cx.rdA[j] + t * 32 * C::ROWB);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) fb[set][t] = *(const v4i*)(st + cx.rdBd + cx.rdA[j] + t * 32 * C::ROWB);
+  };
+  auto read_scales = [&](int buf, int set) __attribute__((always_inline)) {
+    const char* st = smem + buf * C::STAGE_BYTES;
+#pragma unroll
+    for (int t = 0; t < MT; ++t) sa[set][t] = *(const int*)(st + cx.rdSA[t]);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) sb[set][t] = *(const int*)(st + cx.rdSB[t]);
+  };
+  auto keep = [&](int set) __attribute__((always_inline)) {   // pin the registers of a fragment set across the next slice's reads
+#pragma unroll
+    for (int t = 0; t < MT; ++t) asm volatile("" ::"v"(fa[set][t]));
+#pragma unroll
+    for (int t = 0; t < NT; ++t) asm volatile("" ::"v"(fb[set][t]));
+  };
+  auto mfma = [&](int j, int set, int sset) __attribute__((always_inline)) {
+    if (C::ABL & ABL_NO_MFMA) return;
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int n = 0; n < NT; ++n) {
+        const v4i a = fa[set][m], b = fb[set][n];
+        const v8i A8 = {a[0], a[1], a[2], a[3], 0, 0, 0, 0}, B8 = {b[0], b[1], b[2], b[3], 0, 0, 0, 0};
+        if (j == 0) cx.acc[m][n] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(B8, A8, cx.acc[m][n], 4, 4, 0, sb[sset][n], 0, sa[sset][m]);
+        if (j == 1) cx.acc[m][n] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(B8, A8, cx.acc[m][n], 4, 4, 1, sb[sset][n], 1, sa[sset][m]);
+        if (j == 2) cx.acc[m][n] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(B8, A8, cx.acc[m][n], 4, 4, 2, sb[sset][n], 2, sa[sset][m]);
+        if (j == 3) cx.acc[m][n] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(B8, A8, cx.acc[m][n], 4, 4, 3, sb[sset][n], 3, sa[sset][m]);
+      }
+  };
+  auto fence = [&]() __attribute__((always_inline)) { __builtin_amdgcn_sched_barrier(0); };
+  const bool dma_on = !(C::ABL & ABL_NO_DMA);
+
+  // one stage; BUF = kt & 1 is a compile-time constant so every register-array index is static
+  auto stage = [&](int kt, auto bufc) __attribute__((always_inline)) {
+    constexpr int BUF = decltype(bufc)::value;
+    const int KT = cx.KT;
+    // j = 0
+    mfma(0, 0, BUF); fence();
+    read_slice(BUF, 1, 1); keep(0); fence();
+    if (dma_on) cx.issue_stage_part(kt + 1, BUF ^ 1, 1, kt + 1 < KT);
+    fence();
+    // j = 1
+    mfma(1, 1, BUF); fence();
+    read_slice(BUF, 2, 0); keep(1); fence();
+    // j = 2
+    mfma(2, 0, BUF); fence();
+    read_slice(BUF, 3, 1); keep(0); fence();
+    // j = 3
+    mfma(3, 1, BUF); fence();
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    fence();
+    read_scales(BUF ^ 1, BUF ^ 1);   // (after the last stage these read stale LDS; the values are never used)
+    read_slice(BUF ^ 1, 0, 0);
+    keep(1); fence();
+    if (dma_on) cx.issue_stage_part(kt + 2, BUF, 0, kt + 2 < KT);
+    fence();
+  };
+
+  // prologue: stage 0 -> buffer 0 (all of it), first half of stage 1 -> buffer 1
+  cx.issue_stage_part(0, 0, 0);
+  cx.issue_stage_part(0, 0, 1);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  fence();
+  read_scales(0, 0);
+  read_slice(0, 0, 0);
+  fence();
+  if (dma_on) cx.issue_stage_part(1, 1, 0, 1 < cx.KT);
+  fence();
+
+  int kt = 0;
+  for (; kt + 1 < cx.KT; kt += 2) {
+    stage(kt, std::integral_constant<int, 0>{});
+    stage(kt + 1, std::integral_constant<int, 1>{});
+  }
+  if (kt < cx.KT) stage(kt, std::integral_constant<int, 0>{});
+  fence();
+  cx.epilogue();
+}
+
+// One __global__ entry per (config, schedule).
+enum { SCHED_LOCKSTEP = 0, SCHED_PINGPONG = 1, SCHED_QUEUE = 2 };
+template <class C, int SCHED>
+__global__ __launch_bounds__(C::THREADS) void gemm_mx_kernel(const GemmParams p) {
+  __shared__ __attribute__((aligned(16))) char smem[C::LDS_BYTES];
+  if constexpr (SCHED == SCHED_QUEUE) gemm_mx_queue<C>(smem, p);
+  else if constexpr (SCHED == SCHED_PINGPONG) gemm_mx_pingpong<C>(smem, p);
+  else gemm_mx_lockstep<C>(smem, p);
+}
+
+}  // namespace qamd

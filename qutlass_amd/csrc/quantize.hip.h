@@ -1,0 +1,274 @@
+// Fused rotate + quantize kernels for gfx950 (HBM-bound; 2 B/elem in, ~0.53-0.66 B/elem out).
+//
+//   fusedQuantizeMx : y = x_g . h (bf16 x bf16 -> fp32, x viewed as (numel/R, R), h a RUNTIME RxR
+//                     matrix), then per 32 values an e8m0 scale (abs-max or Quest) + 32 e2m1 codes
+//                     [+ 32 clip-mask bits].  Replaces qutlass/csrc/fused_quantize_mx.cu:64-207,
+//                     fused_quantize_mx_mask.cu:62-123 and the arithmetic of
+//                     cutlass_extensions/epilogue/threadblock/epilogue_quant.h:460-812, :1087-1230.
+//   fusedQuantizeNv : same rotation, per 16 values an e4m3 scale relative to a global scale.
+//                     Replaces fused_quantize_nv.cu:109-252 / epilogue_quant.h:1560-2128.
+//
+// CDNA4 mapping.  The rotation is computed TRANSPOSED on the bf16 MFMA:
+//   D^T (32 j x 32 rows) = H^T (32 j x 16 k) . X^T (16 k x 32 rows)   [v_mfma_f32_32x32x16_bf16]
+// so that after the MFMA lane (row = l&31, half = l>>5) holds 16 of the 32 values of ONE scale
+// group of ONE row (j = 8q + 4*half + e) in registers: the group reduction is 15 in-register ops
+// plus ONE wavefront exchange with lane l^32 (v_permlane32_swap), every lane of the wave is busy
+// (the reference leaves 3 of 4 threads idle and round-trips accumulators through shared memory),
+// and the X^T operand is exactly 16 contiguous bytes of the row per lane, loaded straight from
+// global memory (buffer_load_dwordx4, out-of-range rows read as zero).
+#pragma once
+#include "common.hip.h"
+
+namespace qamd {
+
+enum { METHOD_QUEST = 0, METHOD_ABSMAX = 1 };
+
+struct QuantParams {
+  const uint16_t* x;   // bf16, numel
+  const uint16_t* h;   // bf16, R x R row-major
+  uint8_t* out;        // packed e2m1, numel/2
+  uint8_t* out_sf;     // e8m0 (MX, numel/32) or e4m3 (NV, numel/16), flat group order
+  uint32_t* out_mask;  // MX quest-with-mask: one u32 per 32-group (may be null)
+  const float* global_scale;  // NV only
+  int64_t numel;
+  int ntiles;          // ceil(numel / (max(R,32) * 32)): tiles of 32 rows x max(R,32) elements
+};
+
+// --- e2m1 encoders -------------------------------------------------------------------------------
+// Software RTNE-satfinite encoder (semantics of PTX cvt.rn.satfinite.e2m1x2.f32; oracle:
+// orc_e2m1_encode).  Uses the fp32 adder as the rounder: adding 2^22 / 2^23 / 2^24 rounds |t| to a
+// multiple of 0.5 / 1 / 2 with ties-to-even, which is exactly the e2m1 grid in [0,2) / [2,4) / [4,6].
+__device__ __forceinline__ uint32_t e2m1_encode_sw(float t) {
+  const uint32_t sign = (__float_as_uint(t) >> 28) & 8u;
+  float a = fminf(fabsf(t), 6.0f);          // NaN -> 6 (fminf returns the non-NaN operand)
+  const bool ge2 = a >= 2.0f, ge4 = a >= 4.0f;
+  const float magic = ge4 ? 16777216.0f : (ge2 ? 8388608.0f : 4194304.0f);
+  const uint32_t k = __float_as_uint(a + magic) - __float_as_uint(magic);
+  return sign | (k + (ge4 ? 4u : (ge2 ? 2u : 0u)));
+}
+
+// Hardware converter v_cvt_scalef32_pk_fp4_f32 (scale operand 1.0): two fp32 -> one byte,
+// lo -> low nibble.  Enabled only after tools/probe verified it against the oracle on device.
+template <int BYTE>
+__device__ __forceinline__ uint32_t e2m1_pack2_hw(uint32_t old, float lo, float hi) {
+  return __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(old, lo, hi, 1.0f, BYTE);
+}
+
+template <bool HWCVT>
+__device__ __forceinline__ uint32_t e2m1_pack8(const float* t) {   // 8 values -> one dword
+  if (HWCVT) {
+    uint32_t r = 0;
+    r = e2m1_pack2_hw<0>(r, t[0], t[1]);
+    r = e2m1_pack2_hw<1>(r, t[2], t[3]);
+    r = e2m1_pack2_hw<2>(r, t[4], t[5]);
+    r = e2m1_pack2_hw<3>(r, t[6], t[7]);
+    return r;
+  } else {
+    uint32_t r = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) r |= e2m1_encode_sw(t[i]) << (4 * i);
+    return r;
+  }
+}
+
+// combine a per-lane partial with the partner lane l^32 (one v_permlane32_swap + one op)
+__device__ __forceinline__ float xhalf_max(float v) {
+  auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float xhalf_add(float v) {
+  auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ uint32_t xhalf_or(uint32_t v) {
+  auto r = __builtin_amdgcn_permlane32_swap(v, v, false, false);
+  return r[0] | r[1];
+}
+
+// OCP e4m3fn encode of a non-negative finite fp32, RNE, saturating at 448 (oracle: orc_e4m3_encode).
+__device__ __forceinline__ uint32_t e4m3_encode_pos(float a) {
+  if (!(a < 448.0f)) return (a != a) ? 0x7Fu : 0x7Eu;
+  // quantum 2^(max(e,-6)-3): add-magic rounding at that binade
+  uint32_t u = __float_as_uint(a);
+  int e = (int)(u >> 23) - 127;
+  e = e < -6 ? -6 : e;
+  const float magic = __uint_as_float((uint32_t)(e + 20 + 127) << 23);   // 2^(e+20): ulp = 2^(e-3)
+  const float r = (a + magic) - magic;                                   // RNE to the e4m3 grid
+  if (r < 0.015625f) return (uint32_t)(r * 512.0f);                      // subnormal: m * 2^-9
+  const uint32_t ru = __float_as_uint(r);
+  return (((ru >> 23) - 120u) << 3) | ((ru >> 20) & 7u);
+}
+__device__ __forceinline__ float e4m3_decode_pos(uint32_t b) {
+  const uint32_t e = b >> 3, m = b & 7;
+  return e ? __uint_as_float(((e + 120u) << 23) | (m << 20)) : (float)m * 0.001953125f;
+}
+
+// -------------------------------------------------------------------------------------------------
+// Kernel.  One wave owns one 32-row tile at a time (grid-stride over tiles).
+//   R      : rotation size (MX: 32/64/128, NV: 16/32/64/128)
+//   NV     : false = MX (e8m0 per 32), true = NV (e4m3 per 16)
+//   METHOD : METHOD_QUEST / METHOD_ABSMAX
+//   MASK   : MX quest only: also emit the clip mask
+//   HWCVT  : use v_cvt_scalef32_pk_fp4_f32 for the final RTNE
+// -------------------------------------------------------------------------------------------------
+template <int R, bool NV, int METHOD, bool MASK, bool HWCVT>
+__global__ __launch_bounds__(256) void fused_quantize_kernel(const QuantParams p) {
+  constexpr int RP = (R < 32) ? 32 : R;         // rotation padded to one MFMA j-tile (R=16: block-diag)
+  constexpr int KC = RP / 16;                   // 16-wide k chunks per row
+  constexpr int JT = RP / 32;                   // 32-wide j tiles per row = MX groups per row
+  constexpr int HROW = RP * 2 + 16;             // padded H^T row stride in LDS (bytes)
+  __shared__ __attribute__((aligned(16))) char hT[RP * HROW];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = uniform(tid >> 6);
+  const int row = lane & 31, half = lane >> 5;
+
+  // ---- H^T image in LDS: hT[j][k] = h[k][j]; R = 16 becomes blockdiag(h, h) so that one 32-wide
+  //      MFMA tile rotates two adjacent 16-element rows at once
+  for (int idx = tid; idx < RP * RP; idx += 256) {
+    const int k = idx / RP, j = idx % RP;
+    uint16_t v;
+    if (R < 32) v = ((k >> 4) == (j >> 4)) ? p.h[(k & 15) * R + (j & 15)] : (uint16_t)0;
+    else v = p.h[k * R + j];
+    *(uint16_t*)(hT + j * HROW + k * 2) = v;
+  }
+  __syncthreads();
+
+  // x as rows of RP elements (for R = 16 two rotation rows share one 32-element "row")
+  const int64_t ngroups = p.numel / (NV ? 16 : 32);
+  const __amdgpu_buffer_rsrc_t rx = make_rsrc(p.x, (uint32_t)(p.numel * 2));
+  const float gscale = NV ? *p.global_scale : 1.0f;
+
+  const int wave_global = blockIdx.x * 4 + wave, nwaves = gridDim.x * 4;
+  for (int tile = wave_global; tile < p.ntiles; tile += nwaves) {
+    const int64_t r_abs = (int64_t)tile * 32 + row;
+    // X^T operand: lane (row, half), chunk kc -> x[r_abs][16 kc + 8 half .. +8)  (16 bytes)
+    v8bf xf[KC];
+    const int xoff = (int)(r_abs * RP * 2) + half * 16;   // numel*2 < 2^31 checked on the host
+#pragma unroll
+    for (int kc = 0; kc < KC; ++kc) {
+      const v4i raw = __builtin_amdgcn_raw_buffer_load_b128(rx, xoff + kc * 32, 0, 0);
+      xf[kc] = __builtin_bit_cast(v8bf, raw);
+    }
+#pragma unroll
+    for (int jt = 0; jt < JT; ++jt) {
+      v16f acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+      for (int kc = 0; kc < KC; ++kc) {
+        const v8bf hf = *(const v8bf*)(hT + (jt * 32 + row) * HROW + (kc * 16 + half * 8) * 2);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(hf, xf[kc], acc, 0, 0, 0);
+      }
+      // acc[4q+e] = y[r_abs][32 jt + 8q + 4 half + e]
+      const int64_t grp32 = r_abs * JT + jt;   // 32-element group index in the flat output
+
+      if (!NV) {
+        // ------------------------------ MX: e8m0 per 32 ----------------------------------------
+        float scale;
+        if (METHOD == METHOD_ABSMAX) {
+          float m = 0.f;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) m = fmaxf(m, fabsf(acc[r]));
+          m = xhalf_max(m);
+          scale = m + 1e-8f;
+        } else {
+          float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            s1 += acc[r];
+            s2 = fmaf(acc[r], acc[r], s2);
+          }
+          s1 = xhalf_add(s1);
+          s2 = xhalf_add(s2);
+          const float mean = s1 * 0.03125f;
+          const float var = fmaf(-mean, mean, s2 * 0.03125f);
+          scale = 1.0f;
+          if (var >= 0.f) scale = (float)((double)sqrtf(var) * (2.92247856 / 6.) + 1e-8);
+        }
+        const uint32_t e8 = (__float_as_uint(scale) >> 23) & 0xffu;   // floor to 2^e, keep exponent
+        const int sh = 127 - (int)e8;                                 // y / 2^(e8-127) == ldexp(y, sh)
+        float t[16];
+        uint32_t mbits = 0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float v = ldexpf(acc[r], sh);
+          if (MASK) mbits |= (fabsf(v) < 6.0f ? 1u : 0u) << (8 * (r >> 2) + 4 * half + (r & 3));
+          if (METHOD == METHOD_ABSMAX) v = v * 3.0f;
+          t[r] = v;
+        }
+        // bytes: q-th group of 4 values -> group bytes 4q + 2 half, 4q + 2 half + 1
+        const uint32_t P = e2m1_pack8<HWCVT>(t);       // halfwords H[0+half], H[2+half]
+        const uint32_t Q = e2m1_pack8<HWCVT>(t + 8);   // halfwords H[4+half], H[6+half]
+        auto sw = __builtin_amdgcn_permlane32_swap(P, Q, false, false);
+        const uint32_t X = sw[0], Y = sw[1];
+        // half 0: X = own P, Y = partner P ; half 1: X = partner Q, Y = own Q
+        v2i o;
+        o[0] = (int)((X & 0xffffu) | (Y << 16));
+        o[1] = (int)((X >> 16) | (Y & 0xffff0000u));
+        const bool ok = grp32 < ngroups;
+        if (ok) {
+          *(v2i*)(p.out + grp32 * 16 + half * 8) = o;
+          if (half == 0) p.out_sf[grp32] = (uint8_t)e8;
+        }
+        if (MASK) {
+          const uint32_t mm = xhalf_or(mbits);
+          if (ok && half == 0) p.out_mask[grp32] = mm;
+        }
+      } else {
+        // ------------------------------ NV: e4m3 per 16 ----------------------------------------
+        // lane holds j = 8q + 4 half + e: q in {0,1} belong to 16-group 2*grp32, q in {2,3} to +1
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) {
+          float v8[8];
+#pragma unroll
+          for (int r = 0; r < 8; ++r) v8[r] = acc[sub * 8 + r];
+          float out_scale;
+          uint32_t sfb;
+          if (METHOD == METHOD_ABSMAX) {
+            float m = 0.f;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) m = fmaxf(m, fabsf(v8[r]));
+            m = xhalf_max(m);
+            float sf = gscale * (m * (1.0f / 6.0f));
+            sfb = e4m3_encode_pos(sf);
+            sf = e4m3_decode_pos(sfb);
+            out_scale = (sf != 0.f) ? __frcp_rn(sf * __frcp_rn(gscale)) : 0.0f;
+          } else {
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+              s1 += v8[r];
+              s2 = fmaf(v8[r], v8[r], s2);
+            }
+            s1 = xhalf_add(s1);
+            s2 = xhalf_add(s2);
+            const float mean = s1 * 0.0625f;
+            const float var = fmaf(-mean, mean, s2 * 0.0625f);
+            const float sc = (float)((double)sqrtf(var) * (2.92247856 / 6.) + 1e-8);
+            sfb = e4m3_encode_pos(sc);
+            const float sq = e4m3_decode_pos(sfb);
+            out_scale = (sq > 0.f) ? __frcp_rn(sq) : 0.0f;
+          }
+          float t[8];
+#pragma unroll
+          for (int r = 0; r < 8; ++r) t[r] = v8[r] * out_scale;
+          // 8 values = bytes {0,1,4,5} + 2*half of the 8-byte group: halfwords H[half], H[2+half]
+          const uint32_t P = e2m1_pack8<HWCVT>(t);
+          auto sw = __builtin_amdgcn_permlane32_swap(P, P, false, false);
+          // half 0: sw[0] = own P (H0,H2), sw[1] = partner P (H1,H3)
+          // half 1: sw[0] = partner P (H0,H2), sw[1] = own P (H1,H3)
+          const uint32_t X = sw[0], Y = sw[1];
+          const uint32_t d0 = (X & 0xffffu) | (Y << 16);          // bytes 0..3
+          const uint32_t d1 = (X >> 16) | (Y & 0xffff0000u);      // bytes 4..7
+          const int64_t grp16 = grp32 * 2 + sub;
+          if (grp16 < ngroups) {
+            *(uint32_t*)(p.out + grp16 * 8 + half * 4) = half ? d1 : d0;
+            if (half == 0) p.out_sf[grp16] = (uint8_t)sfb;
+          }
+        }
+      }
+    }
+  }
+}
+
+}  // namespace qamd

@@ -1,0 +1,525 @@
+// Native (no Python) on-device checker + micro-bench for libqutlass_amd.so.
+// TEST INFRASTRUCTURE: links the product library through its C ABI and the CPU oracle
+// (oracle/libqutlass_oracle.so) as the checker.  Built by tests/native/build.sh, run on the GPU box:
+//     tests/native/qamd_check [probe] [gemm] [quant] [blocked] [bench]      (default: everything)
+// Prints one line per check: "CHECK <name> ... OK|FAIL" and "BENCH <name> ... us ... TFLOP/s|GB/s".
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <random>
+#include <string>
+#include <vector>
+
+#include "../../include/qutlass_amd.h"
+
+extern "C" {
+float orc_e2m1_decode(uint8_t);
+uint8_t orc_e2m1_encode(float);
+float orc_e4m3_decode(uint8_t);
+uint8_t orc_e4m3_encode(float);
+void orc_to_blocked(const uint8_t*, int64_t, int64_t, uint8_t*);
+void orc_fused_quantize_mx(const uint16_t*, const uint16_t*, int, int64_t, int, int, uint8_t*, uint8_t*, uint32_t*);
+void orc_fused_quantize_nv(const uint16_t*, const uint16_t*, int, int64_t, int, int, float, uint8_t*, uint8_t*);
+void orc_gemm_blockscaled(int, const uint8_t*, const uint8_t*, const uint8_t*, const uint8_t*, float, int64_t,
+                          int64_t, int64_t, uint16_t*);
+}
+
+#define HIP_OK(x)                                                                     \
+  do {                                                                                \
+    hipError_t e_ = (x);                                                              \
+    if (e_ != hipSuccess) {                                                           \
+      printf("HIP ERROR %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__);   \
+      exit(2);                                                                        \
+    }                                                                                 \
+  } while (0)
+#define Q_OK(x)                                                              \
+  do {                                                                       \
+    int r_ = (x);                                                            \
+    if (r_ != 0) {                                                           \
+      printf("QAMD ERROR %d: %s (%s:%d)\n", r_, qutlass_amd_last_error(), __FILE__, __LINE__); \
+      exit(3);                                                               \
+    }                                                                        \
+  } while (0)
+
+static int g_fail = 0;
+static void report(const char* name, bool ok, const std::string& detail) {
+  printf("CHECK %-58s %s  %s\n", name, ok ? "OK  " : "FAIL", detail.c_str());
+  if (!ok) ++g_fail;
+  fflush(stdout);
+}
+
+template <class T>
+struct DBuf {
+  T* p = nullptr;
+  size_t n = 0;
+  explicit DBuf(size_t n_) : n(n_) { HIP_OK(hipMalloc(&p, std::max<size_t>(n * sizeof(T), 16))); }
+  ~DBuf() { hipFree(p); }
+  void up(const std::vector<T>& h) { HIP_OK(hipMemcpy(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice)); }
+  std::vector<T> down() {
+    std::vector<T> h(n);
+    HIP_OK(hipMemcpy(h.data(), p, n * sizeof(T), hipMemcpyDeviceToHost));
+    return h;
+  }
+};
+
+static uint16_t f2bf(float f) {
+  uint32_t u;
+  memcpy(&u, &f, 4);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+}
+static float bf2f(uint16_t b) {
+  uint32_t u = (uint32_t)b << 16;
+  float f;
+  memcpy(&f, &u, 4);
+  return f;
+}
+
+static std::vector<uint16_t> hadamard_bf16(int R) {
+  std::vector<uint16_t> h((size_t)R * R);
+  const float c = 1.0f / std::sqrt((float)R);
+  for (int i = 0; i < R; ++i)
+    for (int j = 0; j < R; ++j) h[(size_t)i * R + j] = f2bf((__builtin_popcount(i & j) & 1) ? -c : c);
+  return h;
+}
+
+template <class F>
+static double time_us(F&& launch, int warm, int iters) {
+  hipEvent_t a, b;
+  HIP_OK(hipEventCreate(&a));
+  HIP_OK(hipEventCreate(&b));
+  for (int i = 0; i < warm; ++i) launch();
+  HIP_OK(hipDeviceSynchronize());
+  HIP_OK(hipEventRecord(a, 0));
+  for (int i = 0; i < iters; ++i) launch();
+  HIP_OK(hipEventRecord(b, 0));
+  HIP_OK(hipEventSynchronize(b));
+  float ms = 0;
+  HIP_OK(hipEventElapsedTime(&ms, a, b));
+  hipEventDestroy(a);
+  hipEventDestroy(b);
+  return (double)ms * 1000.0 / iters;
+}
+
+// ================================================================================================
+// GEMM checks
+// ================================================================================================
+struct GemmData {
+  int kind;  // 0 mxfp4, 1 nvfp4, 2 mxfp8
+  int64_t M, N, K;
+  std::vector<uint8_t> A, B, sfa_rm, sfb_rm, sfa, sfb;  // rm = row-major (rows, K/gs)
+  float alpha;
+};
+
+static GemmData make_gemm(int kind, int64_t M, int64_t N, int64_t K, float alpha, uint32_t seed, int spread) {
+  GemmData g;
+  g.kind = kind; g.M = M; g.N = N; g.K = K; g.alpha = alpha;
+  std::mt19937 rng(seed);
+  const int gs = kind == 1 ? 16 : 32;
+  const int64_t rb = kind == 2 ? K : K / 2;
+  g.A.resize(M * rb);
+  g.B.resize(N * rb);
+  auto fill = [&](std::vector<uint8_t>& v) {
+    for (auto& x : v) {
+      uint8_t b = (uint8_t)(rng() & 0xff);
+      if (kind == 2 && (b & 0x7f) == 0x7f) b &= 0xfe;  // no e4m3 NaN
+      x = b;
+    }
+  };
+  fill(g.A);
+  fill(g.B);
+  auto fill_sf = [&](std::vector<uint8_t>& rm, int64_t rows) {
+    rm.resize(rows * (K / gs));
+    for (auto& x : rm) {
+      if (kind == 1) x = (uint8_t)(0x28 + rng() % (8 * spread + 1));  // e4m3 around 2^-2..: positive, finite
+      else x = (uint8_t)(127 - spread + rng() % (2 * spread + 1));
+    }
+  };
+  fill_sf(g.sfa_rm, M);
+  fill_sf(g.sfb_rm, N);
+  auto blocked = [&](const std::vector<uint8_t>& rm, int64_t rows) {
+    const int64_t cols = K / gs;
+    std::vector<uint8_t> out(((rows + 127) / 128) * 128 * ((cols + 3) / 4) * 4);
+    orc_to_blocked(rm.data(), rows, cols, out.data());
+    return out;
+  };
+  g.sfa = blocked(g.sfa_rm, M);
+  g.sfb = blocked(g.sfb_rm, N);
+  return g;
+}
+
+typedef int (*gemm_fn)(const void*, const void*, const void*, const void*, const float*, void*, int64_t, int64_t,
+                       int64_t, void*);
+static gemm_fn gemm_entry(int kind) {
+  return kind == 0 ? qutlass_amd_matmul_mxf4_bf16_tn : kind == 1 ? qutlass_amd_matmul_nvf4_bf16_tn : qutlass_amd_matmul_mxf8_bf16_tn;
+}
+
+// Full check for small problems, row-sampled (nsample rows of A against all of B) for large ones.
+static void check_gemm(const char* tag, int kind, int64_t M, int64_t N, int64_t K, float alpha, int spread,
+                       int nsample, int variant, bool tol_ok = false) {
+  GemmData g = make_gemm(kind, M, N, K, alpha, 1234 + (uint32_t)(M * 7 + N * 3 + K), spread);
+  DBuf<uint8_t> dA(g.A.size()), dB(g.B.size()), dSA(g.sfa.size()), dSB(g.sfb.size());
+  DBuf<float> dAl(1);
+  DBuf<uint16_t> dD((size_t)M * N);
+  dA.up(g.A); dB.up(g.B); dSA.up(g.sfa); dSB.up(g.sfb);
+  dAl.up({alpha});
+  HIP_OK(hipMemset(dD.p, 0xff, (size_t)M * N * 2));
+  qutlass_amd_set_option("gemm_variant", variant);
+  Q_OK(gemm_entry(kind)(dA.p, dB.p, dSA.p, dSB.p, dAl.p, dD.p, M, N, K, nullptr));
+  HIP_OK(hipDeviceSynchronize());
+  qutlass_amd_set_option("gemm_variant", 0);
+  std::vector<uint16_t> D = dD.down();
+
+  // oracle on a row subset
+  std::vector<int64_t> rows;
+  if (nsample <= 0 || nsample >= M) for (int64_t i = 0; i < M; ++i) rows.push_back(i);
+  else {
+    std::mt19937 rng(99);
+    rows.push_back(0); rows.push_back(M - 1);
+    while ((int)rows.size() < nsample) rows.push_back(rng() % M);
+  }
+  const int gs = kind == 1 ? 16 : 32;
+  const int64_t rb = kind == 2 ? K : K / 2, kb = K / gs, ns = rows.size();
+  std::vector<uint8_t> As(ns * rb), sf_rm(ns * kb);
+  for (int64_t i = 0; i < ns; ++i) {
+    memcpy(&As[i * rb], &g.A[rows[i] * rb], rb);
+    memcpy(&sf_rm[i * kb], &g.sfa_rm[rows[i] * kb], kb);
+  }
+  std::vector<uint8_t> sfs(((ns + 127) / 128) * 128 * ((kb + 3) / 4) * 4);
+  orc_to_blocked(sf_rm.data(), ns, kb, sfs.data());
+  std::vector<uint16_t> ref(ns * N);
+  orc_gemm_blockscaled(kind, As.data(), g.B.data(), sfs.data(), g.sfb.data(), alpha, ns, N, K, ref.data());
+  int64_t bad = 0;
+  double maxrel = 0, maxabs = 0, refmax = 0;
+  for (int64_t i = 0; i < ns; ++i)
+    for (int64_t n = 0; n < N; ++n) refmax = std::max(refmax, (double)std::fabs(bf2f(ref[i * N + n])));
+  int64_t tolbad = 0;
+  for (int64_t i = 0; i < ns; ++i)
+    for (int64_t n = 0; n < N; ++n) {
+      const uint16_t a = D[rows[i] * N + n], b = ref[i * N + n];
+      if (a != b) {
+        ++bad;
+        const double fa = bf2f(a), fb = bf2f(b);
+        const double rel = std::fabs(fa - fb) / std::max(1e-30, std::fabs(fb));
+        maxabs = std::max(maxabs, std::fabs(fa - fb));
+        if (!(std::fabs(fa - fb) <= std::fabs(fb) / 128.0 + 2e-5 * refmax)) ++tolbad;
+        if (rel > maxrel || std::isnan(fa)) maxrel = std::isnan(fa) ? 1e9 : rel;
+        if (bad <= 3 && kind != 2) printf("    mismatch row %lld col %lld: got %g (0x%04x) want %g (0x%04x)\n", (long long)rows[i], (long long)n, fa, a, fb, b);
+      }
+    }
+  char buf[256];
+  snprintf(buf, sizeof buf, "M=%lld N=%lld K=%lld alpha=%g var=%d rows=%lld bit-mismatch=%lld maxrel=%.3g", (long long)M,
+           (long long)N, (long long)K, alpha, variant, (long long)ns, (long long)bad, maxrel);
+  if (kind == 2) {
+    // MXFP8: e4m3 x e4m3 products carry 8 significant bits, so an fp32-accumulating kernel cannot be
+    // bit-identical to the fp64 oracle (the reference itself tests with rtol = atol = 1e-1,
+    // tests/mxfp8_test.py:75).  Bound: |err| <= |ref|/128 (1 bf16 ulp) + 2e-5 * max|ref|.
+    snprintf(buf, sizeof buf, "M=%lld N=%lld K=%lld var=%d rows=%lld bit-mismatch=%lld out-of-tolerance=%lld maxabs=%.3g (max|ref|=%.3g)",
+             (long long)M, (long long)N, (long long)K, variant, (long long)ns, (long long)bad, (long long)tolbad, maxabs, refmax);
+    report(tag, tolbad == 0, buf);
+    return;
+  }
+  report(tag, tol_ok ? maxrel <= 1e-2 : bad == 0, buf);
+}
+
+static void bench_gemm(const char* tag, int kind, int64_t M, int64_t N, int64_t K, int variant, int iters) {
+  GemmData g = make_gemm(kind, M, N, K, 1.0f, 77, 3);
+  DBuf<uint8_t> dA(g.A.size()), dB(g.B.size()), dSA(g.sfa.size()), dSB(g.sfb.size());
+  DBuf<float> dAl(1);
+  DBuf<uint16_t> dD((size_t)M * N);
+  dA.up(g.A); dB.up(g.B); dSA.up(g.sfa); dSB.up(g.sfb);
+  dAl.up({1.0f});
+  qutlass_amd_set_option("gemm_variant", variant);
+  gemm_fn fn = gemm_entry(kind);
+  const double us = time_us([&] { Q_OK(fn(dA.p, dB.p, dSA.p, dSB.p, dAl.p, dD.p, M, N, K, nullptr)); }, 10, iters);
+  qutlass_amd_set_option("gemm_variant", 0);
+  const double tf = 2.0 * M * N * K / us * 1e-6;
+  printf("BENCH %-40s M=%lld N=%lld K=%lld var=%d  %9.2f us  %9.1f TFLOP/s\n", tag, (long long)M, (long long)N, (long long)K,
+         variant, us, tf);
+  fflush(stdout);
+}
+
+// ================================================================================================
+// quantizer checks
+// ================================================================================================
+static std::vector<uint16_t> randn_bf16(size_t n, float scale, uint32_t seed, bool small_int) {
+  std::mt19937 rng(seed);
+  std::normal_distribution<float> nd(0.f, 1.f);
+  std::vector<uint16_t> v(n);
+  for (auto& x : v) x = small_int ? f2bf((float)((int)(rng() % 17) - 8)) : f2bf(nd(rng) * scale);
+  return v;
+}
+
+static void check_quant_mx(int R, int method, bool mask, int hwcvt, int64_t numel, int input_kind) {
+  // input_kind 0: randn*25 + hadamard ; 1: small integers + hadamard scaled to exact (+-0.25) ; 2: randn + identity
+  std::vector<uint16_t> x = randn_bf16(numel, 25.f, 5 + R + method, input_kind == 1);
+  std::vector<uint16_t> h = hadamard_bf16(R);
+  if (input_kind == 1) for (auto& e : h) e = f2bf(bf2f(e) > 0 ? 0.25f : -0.25f);
+  if (input_kind == 2) for (int i = 0; i < R; ++i) for (int j = 0; j < R; ++j) h[(size_t)i * R + j] = f2bf(i == j ? 1.f : 0.f);
+  DBuf<uint16_t> dx(numel), dh((size_t)R * R);
+  DBuf<uint8_t> dq(numel / 2), ds(numel / 32);
+  DBuf<uint32_t> dm(numel / 32);
+  dx.up(x); dh.up(h);
+  HIP_OK(hipMemset(dq.p, 0xEE, numel / 2));
+  HIP_OK(hipMemset(ds.p, 0xEE, numel / 32));
+  qutlass_amd_set_option("hw_fp4_cvt", hwcvt);
+  Q_OK(qutlass_amd_fused_quantize_mx(dx.p, dh.p, R, numel, method, dq.p, ds.p, mask ? dm.p : nullptr, nullptr));
+  HIP_OK(hipDeviceSynchronize());
+  auto q = dq.down();
+  auto s = ds.down();
+  auto m = dm.down();
+  int64_t best_bad = -1;
+  char buf[320];
+  std::string detail;
+  for (int acc_model = 0; acc_model < 2; ++acc_model) {
+    std::vector<uint8_t> rq(numel / 2), rs(numel / 32);
+    std::vector<uint32_t> rm(numel / 32);
+    orc_fused_quantize_mx(x.data(), h.data(), R, numel, method, acc_model, rq.data(), rs.data(), rm.data());
+    int64_t sbad = 0, cbad = 0, mbad = 0;
+    for (int64_t i = 0; i < numel / 32; ++i) {
+      sbad += s[i] != rs[i];
+      if (mask) mbad += m[i] != rm[i];
+    }
+    for (int64_t i = 0; i < numel / 2; ++i) {
+      if (q[i] == rq[i]) continue;
+      for (int nb = 0; nb < 2; ++nb) {
+        uint8_t a = (q[i] >> (4 * nb)) & 0xf, b = (rq[i] >> (4 * nb)) & 0xf;
+        if (a != b && !((a & 7) == 0 && (b & 7) == 0)) ++cbad;
+      }
+    }
+    snprintf(buf, sizeof buf, "[acc%d: e8m0 %lld/%lld codes %lld/%lld mask %lld] ", acc_model, (long long)sbad,
+             (long long)(numel / 32), (long long)cbad, (long long)numel, (long long)mbad);
+    detail += buf;
+    const int64_t bad = sbad + cbad + mbad;
+    if (best_bad < 0 || bad < best_bad) best_bad = bad;
+  }
+  snprintf(buf, sizeof buf, "quant_mx R=%d %s%s hw=%d in=%d n=%lld", R, method ? "absmax" : "quest", mask ? "+mask" : "",
+           hwcvt, input_kind, (long long)numel);
+  // exact-arithmetic inputs must match bit-for-bit; random inputs within the reference's own 1e-4 bound
+  const bool ok = input_kind == 0 ? (double)best_bad <= 1e-5 * numel : best_bad == 0;
+  report(buf, ok, detail);
+}
+
+static void check_quant_nv(int R, int method, int hwcvt, int64_t numel, float gs) {
+  std::vector<uint16_t> x = randn_bf16(numel, 25.f, 11 + R, false);
+  std::vector<uint16_t> h = hadamard_bf16(R);
+  DBuf<uint16_t> dx(numel), dh((size_t)R * R);
+  DBuf<uint8_t> dq(numel / 2), ds(numel / 16);
+  DBuf<float> dg(1);
+  dx.up(x); dh.up(h); dg.up({gs});
+  qutlass_amd_set_option("hw_fp4_cvt", hwcvt);
+  Q_OK(qutlass_amd_fused_quantize_nv(dx.p, dh.p, R, numel, method, dg.p, dq.p, ds.p, nullptr));
+  HIP_OK(hipDeviceSynchronize());
+  auto q = dq.down();
+  auto s = ds.down();
+  std::vector<uint8_t> rq(numel / 2), rs(numel / 16);
+  orc_fused_quantize_nv(x.data(), h.data(), R, numel, method, 1, gs, rq.data(), rs.data());
+  int64_t sbad = 0, cbad = 0;
+  for (int64_t i = 0; i < numel / 16; ++i) sbad += s[i] != rs[i];
+  for (int64_t i = 0; i < numel / 2; ++i) {
+    if (q[i] == rq[i] || s[i / 8] != rs[i / 8]) continue;
+    for (int nb = 0; nb < 2; ++nb) {
+      uint8_t a = (q[i] >> (4 * nb)) & 0xf, b = (rq[i] >> (4 * nb)) & 0xf;
+      if (a != b && !((a & 7) == 0 && (b & 7) == 0)) ++cbad;
+    }
+  }
+  char name[128], buf[256];
+  snprintf(name, sizeof name, "quant_nv R=%d %s hw=%d gs=%g n=%lld", R, method ? "absmax" : "quest", hwcvt, gs, (long long)numel);
+  snprintf(buf, sizeof buf, "e4m3 %lld/%lld codes(same-scale groups) %lld/%lld", (long long)sbad, (long long)(numel / 16),
+           (long long)cbad, (long long)numel);
+  report(name, (double)sbad <= 1e-3 * (numel / 16) && (double)cbad <= 1e-3 * numel, buf);
+}
+
+static void bench_quant(int R, int method, bool mask, int hwcvt, int64_t rows, int64_t cols, bool nv) {
+  const int64_t numel = rows * cols;
+  std::vector<uint16_t> x = randn_bf16(numel, 25.f, 3, false);
+  std::vector<uint16_t> h = hadamard_bf16(R);
+  DBuf<uint16_t> dx(numel), dh((size_t)R * R);
+  DBuf<uint8_t> dq(numel / 2), ds(numel / 16);
+  DBuf<uint32_t> dm(numel / 32);
+  DBuf<float> dg(1);
+  dx.up(x); dh.up(h); dg.up({1.0f});
+  qutlass_amd_set_option("hw_fp4_cvt", hwcvt);
+  double us;
+  if (nv) us = time_us([&] { Q_OK(qutlass_amd_fused_quantize_nv(dx.p, dh.p, R, numel, method, dg.p, dq.p, ds.p, nullptr)); }, 5, 50);
+  else us = time_us([&] { Q_OK(qutlass_amd_fused_quantize_mx(dx.p, dh.p, R, numel, method, dq.p, ds.p, mask ? dm.p : nullptr, nullptr)); }, 5, 50);
+  const double bytes = numel * (2.0 + 0.5 + (nv ? 1.0 / 16 : 1.0 / 32) + (mask ? 0.125 : 0.0));
+  printf("BENCH quant_%s R=%-3d %-6s%s hw=%d %lldx%lld  %8.2f us  %8.1f GB/s (algorithmic)\n", nv ? "nv" : "mx", R,
+         method ? "absmax" : "quest", mask ? "+mask" : "", hwcvt, (long long)rows, (long long)cols, us, bytes / us * 1e-3);
+  fflush(stdout);
+}
+
+// ================================================================================================
+static void check_blocked(int64_t rows, int64_t cols) {
+  std::mt19937 rng(7);
+  std::vector<uint8_t> in(rows * cols);
+  for (auto& b : in) b = (uint8_t)rng();
+  const size_t on = ((rows + 127) / 128) * 128 * ((cols + 3) / 4) * 4;
+  DBuf<uint8_t> di(in.size()), dout(on);
+  di.up(in);
+  HIP_OK(hipMemset(dout.p, 0xAA, on));
+  Q_OK(qutlass_amd_to_blocked(di.p, rows, cols, dout.p, nullptr));
+  HIP_OK(hipDeviceSynchronize());
+  auto o = dout.down();
+  std::vector<uint8_t> ref(on);
+  orc_to_blocked(in.data(), rows, cols, ref.data());
+  int64_t bad = 0;
+  for (size_t i = 0; i < on; ++i) bad += o[i] != ref[i];
+  char name[64], buf[64];
+  snprintf(name, sizeof name, "to_blocked %lldx%lld", (long long)rows, (long long)cols);
+  snprintf(buf, sizeof buf, "byte mismatches %lld/%zu", (long long)bad, on);
+  report(name, bad == 0, buf);
+}
+
+static void bench_blocked(int64_t rows, int64_t cols) {
+  std::vector<uint8_t> in(rows * cols, 1);
+  const size_t on = ((rows + 127) / 128) * 128 * ((cols + 3) / 4) * 4;
+  DBuf<uint8_t> di(in.size()), dout(on);
+  di.up(in);
+  const double us = time_us([&] { Q_OK(qutlass_amd_to_blocked(di.p, rows, cols, dout.p, nullptr)); }, 5, 100);
+  printf("BENCH to_blocked %lldx%lld  %8.2f us  %8.1f GB/s\n", (long long)rows, (long long)cols, us, 2.0 * rows * cols / us * 1e-3);
+}
+
+extern void run_probe();   // probe.hip
+extern "C" void qutlass_amd_debug_set_trace_buffer(void*);
+
+// Per-wave block timeline of workgroup 0 of the ping-pong kernel (ABL_TRACE builds, variants 116..118).
+static void trace_gemm(int variant, int flags) {
+  const int64_t M = 4096, N = 4096, K = 4096;
+  GemmData g = make_gemm(0, M, N, K, 1.0f, 77, 3);
+  DBuf<uint8_t> dA(g.A.size()), dB(g.B.size()), dSA(g.sfa.size()), dSB(g.sfb.size());
+  DBuf<float> dAl(1);
+  DBuf<uint16_t> dD((size_t)M * N);
+  DBuf<uint32_t> dT(8 * 96);
+  dA.up(g.A); dB.up(g.B); dSA.up(g.sfa); dSB.up(g.sfb); dAl.up({1.0f});
+  HIP_OK(hipMemset(dT.p, 0, 8 * 96 * 4));
+  qutlass_amd_debug_set_trace_buffer(dT.p);
+  qutlass_amd_set_option("gemm_variant", variant);
+  qutlass_amd_set_option("pp_flags", flags);
+  for (int i = 0; i < 3; ++i) Q_OK(qutlass_amd_matmul_mxf4_bf16_tn(dA.p, dB.p, dSA.p, dSB.p, dAl.p, dD.p, M, N, K, nullptr));
+  HIP_OK(hipDeviceSynchronize());
+  qutlass_amd_set_option("gemm_variant", 0);
+  qutlass_amd_set_option("pp_flags", 1);
+  qutlass_amd_debug_set_trace_buffer(nullptr);
+  auto t = dT.down();
+  // slots: 0 loop entry; per stage 8: [endL0, afterBar, endM0, afterBar, endL1, afterBar, endM1, afterBar]; last 2: epilogue begin/end
+  printf("TRACE variant=%d flags=%d (cycles, per wave: for stages 2..5 the 8 deltas  L0 bar M0 bar L1 bar M1 bar)\n", variant, flags);
+  for (int w : {0, 4, 1, 5}) {
+    const uint32_t* r = &t[w * 96];
+    printf("TRACE w%d loop=%u..%u (%u cyc for 11 stages)", w, r[0], r[88], r[88] - r[0]);
+    for (int st = 2; st < 6; ++st) {
+      printf(" |");
+      for (int k = 0; k < 8; ++k) printf(" %u", r[1 + st * 8 + k] - r[st * 8 + k]);
+    }
+    printf("\n");
+  }
+}
+
+
+int main(int argc, char** argv) {
+  auto want = [&](const char* k) {
+    if (argc <= 1) return true;
+    for (int i = 1; i < argc; ++i) if (!strcmp(argv[i], k)) return true;
+    return false;
+  };
+  hipDeviceProp_t prop;
+  HIP_OK(hipGetDeviceProperties(&prop, 0));
+  printf("DEVICE %s arch=%s CUs=%d clock=%d MHz memclk=%d MHz L2=%d MiB %s\n", prop.name, prop.gcnArchName,
+         prop.multiProcessorCount, prop.clockRate / 1000, prop.memoryClockRate / 1000, prop.l2CacheSize >> 20,
+         qutlass_amd_version());
+
+  if (want("probe")) run_probe();
+
+  if (want("blocked")) {
+    check_blocked(128, 4); check_blocked(256, 16); check_blocked(384, 12); check_blocked(4096, 128);
+    check_blocked(130, 5); check_blocked(16, 64); check_blocked(504, 128); check_blocked(8192, 512);
+  }
+  if (want("gemm")) {
+    for (int var : {2, 1, 3, 4, 5, 6, 7, 8, 9}) {
+      check_gemm("gemm_mxfp4 config1", 0, 256, 256, 512, 1.0f, 3, 0, var);
+      check_gemm("gemm_mxfp4 tiny-K", 0, 128, 128, 128, 1.0f, 3, 0, var);
+      check_gemm("gemm_mxfp4 ragged + K tail", 0, 72, 136, 640, 0.5f, 4, 0, var);
+      check_gemm("gemm_mxfp4 M=1", 0, 1, 504, 1024, 1.0f, 2, 0, var);
+      check_gemm("gemm_mxfp4 504x504x2048", 0, 504, 504, 2048, 1.0f, 3, 0, var);
+    }
+    check_gemm("gemm_mxfp4 4096^3 (64 sampled rows)", 0, 4096, 4096, 4096, 1.0f, 3, 64, 0);
+    check_gemm("gemm_mxfp4 4096^3 queue (64 sampled rows)", 0, 4096, 4096, 4096, 1.0f, 3, 64, 6);
+    check_gemm("gemm_mxfp4 1024x768x3200 queue", 0, 1024, 768, 3200, 1.0f, 3, 48, 6);
+    check_gemm("gemm_mxfp4 wide exponent spread (tol 1e-2)", 0, 256, 512, 1024, 1.0f, 12, 0, 0, true);
+    check_gemm("gemm_mxfp4 4096x14336x4096 (32 rows)", 0, 4096, 14336, 4096, 1.0f, 3, 32, 0);
+    for (int var : {2, 1, 5}) {
+      check_gemm("gemm_mxfp8 16x64x256", 2, 16, 64, 256, 1.0f, 3, 0, var);
+      check_gemm("gemm_mxfp8 ragged + K tail", 2, 72, 136, 352, 1.0f, 3, 0, var);
+      check_gemm("gemm_mxfp8 512x512x1024", 2, 512, 512, 1024, 1.0f, 3, 0, var);
+    }
+    check_gemm("gemm_mxfp8 4096^3 (32 rows)", 2, 4096, 4096, 4096, 1.0f, 3, 32, 1);
+    check_gemm("gemm_nvfp4 128^3", 1, 128, 128, 128, 1.0f, 3, 0, 0);
+    check_gemm("gemm_nvfp4 ragged + K tail", 1, 72, 136, 320, 0.5f, 3, 0, 0);
+    check_gemm("gemm_nvfp4 504x512x2048", 1, 504, 512, 2048, 1.0f, 3, 0, 0);
+    check_gemm("gemm_nvfp4 2048^3 (32 rows)", 1, 2048, 2048, 2048, 1.0f, 3, 32, 0);
+  }
+  if (want("quant")) {
+    for (int hw : {0, 1})
+      for (int R : {32, 64, 128})
+        for (int method : {0, 1}) {
+          check_quant_mx(R, method, false, hw, 1 << 20, 0);
+          check_quant_mx(R, method, false, hw, 96 * 1024, 1);
+        }
+    for (int hw : {0, 1}) {
+      check_quant_mx(32, 0, true, hw, 1 << 20, 0);
+      check_quant_mx(32, 0, true, hw, 1 << 16, 2);
+      check_quant_mx(32, 1, false, hw, 1 << 16, 2);
+      check_quant_mx(32, 1, false, hw, 3 * 32 * 33, 0);   // ragged tile count
+    }
+    for (int hw : {0, 1})
+      for (int R : {16, 32, 64, 128})
+        for (int method : {0, 1}) check_quant_nv(R, method, hw, 1 << 18, method ? 6.0f : 1.0f);
+    check_quant_nv(16, 1, 0, 16 * 33, 1.0f);
+  }
+  if (want("trace")) {
+    trace_gemm(116, 1);
+    trace_gemm(116, 0);
+    trace_gemm(117, 1);
+    trace_gemm(118, 1);
+  }
+  if (want("bench")) {
+    for (int fl : {0, 1}) {
+      qutlass_amd_set_option("pp_flags", fl);
+      printf("pp_flags=%d\n", fl);
+      bench_gemm("mxfp4 4096^3", 0, 4096, 4096, 4096, 1, 50);
+      bench_gemm("mxfp4 4096^3 no-epilogue", 0, 4096, 4096, 4096, 108, 50);
+      bench_gemm("mxfp4 4096^3 no-DMA", 0, 4096, 4096, 4096, 101, 50);
+    }
+    qutlass_amd_set_option("pp_flags", 1);
+    for (int var : {6, 1, 5, 8, 9, 7, 3, 4, 2}) bench_gemm("mxfp4 4096^3", 0, 4096, 4096, 4096, var, 50);
+    for (int var : {301, 302, 303, 304, 308, 309, 310, 311}) bench_gemm("mxfp4 4096^3 queue ablation", 0, 4096, 4096, 4096, var, 30);
+    for (int var : {101, 102, 103, 104, 108, 109, 110, 111, 201, 202, 208, 210}) bench_gemm("mxfp4 4096^3 ablation", 0, 4096, 4096, 4096, var, 30);
+    for (int var : {6, 1, 5, 308}) bench_gemm("mxfp4 8192^3", 0, 8192, 8192, 8192, var, 10);
+    bench_gemm("mxfp4 C3 4096x14336x4096 queue", 0, 4096, 14336, 4096, 6, 20);
+    for (int var : {1, 5}) bench_gemm("mxfp4 2048^3", 0, 2048, 2048, 2048, var, 50);
+    bench_gemm("mxfp4 C3 4096x14336x4096", 0, 4096, 14336, 4096, 1, 20);
+    bench_gemm("mxfp4 M=16 decode", 0, 16, 14336, 4096, 2, 50);
+    for (int var : {1, 5}) bench_gemm("mxfp8 4096^3", 2, 4096, 4096, 4096, var, 30);
+    bench_gemm("nvfp4 4096^3", 1, 4096, 4096, 4096, 0, 10);
+    bench_gemm("nvfp4 8192^3", 1, 8192, 8192, 8192, 0, 3);
+    for (int hw : {0, 1}) {
+      bench_quant(32, 1, false, hw, 4096, 4096, false);
+      bench_quant(32, 0, false, hw, 4096, 4096, false);
+      bench_quant(32, 0, true, hw, 4096, 4096, false);
+      bench_quant(64, 1, false, hw, 4096, 4096, false);
+      bench_quant(128, 1, false, hw, 4096, 4096, false);
+      bench_quant(16, 1, false, hw, 4096, 4096, true);
+      bench_quant(128, 1, false, hw, 4096, 4096, true);
+    }
+    bench_blocked(4096, 128);
+    bench_blocked(14336, 128);
+    bench_blocked(8192, 512);
+  }
+  printf("SUMMARY failures=%d\n", g_fail);
+  return g_fail ? 1 : 0;
+}
