@@ -109,8 +109,9 @@ const char* qutlass_amd_version(void);
 
 /*
  * Tuning / verification switches (process-wide, default in parentheses):
- *   "hw_fp4_cvt"    use v_cvt_scalef32_pk_fp4_f32 for the final e2m1 rounding
- *   "gemm_variant" (0 = auto) force a tile configuration of the MX GEMMs (bench sweeps)
+ *   "hw_fp4_cvt"   (1) use v_cvt_scalef32_pk_fp4_f32 for the final e2m1 rounding; 0 = software encoder
+ *                  (both are bit-identical on gfx950)
+ *   "gemm_variant" (0 = auto) force a tile configuration / schedule of the MX GEMMs (bench sweeps)
  * Returns the previous value, or -1 for an unknown key.
  */
 int qutlass_amd_set_option(const char* key, int value);

@@ -17,7 +17,7 @@ using namespace qamd;
 namespace {
 
 thread_local char g_err[512] = "";
-std::atomic<int> g_hw_fp4_cvt{0};
+std::atomic<int> g_hw_fp4_cvt{1};   // device-verified bit-identical to the software encoder (tests/native/probe.hip P2)
 std::atomic<int> g_gemm_variant{0};
 std::atomic<int> g_pp_shift{2};
 std::atomic<int> g_pp_flags{1};
@@ -106,7 +106,11 @@ int gemm_mx(const char* name, const void* A, const void* B, const void* A_sf, co
   p.dbg = g_dbg.load();
   hipStream_t s = (hipStream_t)stream;
   int variant = g_gemm_variant.load();
-  if (variant == 0) variant = (M <= 128 || N <= 128) ? 2 : 1;
+  if (variant == 0) {
+    // auto: fp4 -> queue schedule (256x256 tiles, 128x128 when one dimension is small); fp8 -> lockstep
+    if (EBITS == 4) variant = (M <= 128 || N <= 128) ? 7 : 6;
+    else variant = (M <= 128 || N <= 128) ? 2 : 5;
+  }
   return dispatch_variant<EBITS, EBITS == 8>(variant, p, s, name);
 }
 

@@ -3,7 +3,7 @@
 # oracle/libqutlass_oracle.so (built by __graft_entry__.build()).
 set -e
 cd "$(dirname "$0")"
-hipcc --offload-arch=gfx950 -O2 -w -std=c++17 -x hip qamd_check.cpp probe.hip -o qamd_check \
+hipcc --offload-arch=gfx950 -O2 -w -std=c++17 -x hip qamd_check.cpp probe.hip ubench.hip -o qamd_check \
   -L../../qutlass_amd -lqutlass_amd -L../../oracle -lqutlass_oracle \
   -Wl,-rpath,'$ORIGIN/../../qutlass_amd:$ORIGIN/../../oracle'
 echo built tests/native/qamd_check

@@ -386,6 +386,7 @@ static void bench_blocked(int64_t rows, int64_t cols) {
 }
 
 extern void run_probe();   // probe.hip
+extern void run_ubench();  // ubench.hip
 extern "C" void qutlass_amd_debug_set_trace_buffer(void*);
 
 // Per-wave block timeline of workgroup 0 of the ping-pong kernel (ABL_TRACE builds, variants 116..118).
@@ -433,6 +434,7 @@ int main(int argc, char** argv) {
          prop.multiProcessorCount, prop.clockRate / 1000, prop.memoryClockRate / 1000, prop.l2CacheSize >> 20,
          qutlass_amd_version());
 
+  if (argc > 1 && want("ubench")) run_ubench();
   if (want("probe")) run_probe();
 
   if (want("blocked")) {

@@ -1,0 +1,149 @@
+// Micro-benchmarks that establish how the gfx950 matrix pipe, LDS reads and LDS-DMA overlap inside one wave and
+// between the two waves of a SIMD -- the facts the GEMM schedules in qutlass_amd/csrc/gemm_mx.hip.h are built on.
+//   mode 0  MFMA only                (8 x v_mfma_scale_f32_32x32x64 fp4 per iteration, fixed operands)
+//   mode 1  LDS reads only           (6 x ds_read_b128 per iteration)
+//   mode 2  MFMA(cur) ; reads -> the OTHER fragment set (double buffered)          = "queue" schedule
+//   mode 3  reads ; wait ; MFMA on the same single set                              = serialised
+//   mode 4  mode 2 + 2 LDS-DMA (buffer_load_dwordx4 ... lds, 1 KiB each) per iteration
+//   mode 5  mode 2 with the reads issued BEFORE the MFMAs of the iteration
+//   mode 6  LDS-DMA only (2 per iteration)
+//   mode 7  mode 4 + s_waitcnt vmcnt(0) lgkmcnt(0) + s_barrier every 4 slices (the stage hand-off)
+// Reported: shader cycles per iteration (s_memtime, wave 0 of workgroup 0) with every CU busy.
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <vector>
+
+typedef int v8i __attribute__((ext_vector_type(8)));
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef float v16f __attribute__((ext_vector_type(16)));
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+#define HIP_OK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP ERROR %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(2);} } while (0)
+
+template <int MODE, int THREADS>
+__global__ __launch_bounds__(THREADS) void ub_kernel(const char* g, uint32_t gbytes, float* out, uint32_t* cyc, int iters) {
+  __shared__ __attribute__((aligned(16))) char smem[64 * 1024 + 16 * 1024];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  for (int i = tid; i < 64 * 1024 / 4; i += THREADS) ((int*)smem)[i] = 0x22222222;
+  __syncthreads();
+  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(g), 0, gbytes, 0x00020000);
+  v16f acc[8];
+  for (int a = 0; a < 8; ++a) for (int r = 0; r < 16; ++r) acc[a][r] = 0.f;
+  v4i fa[2][4], fb[2][2];
+  // conflict-free fragment addressing of the GEMM: row = lane&31, chunk c = 4*(lane>>5) + j, phys = c ^ ((row>>1)&7)
+  const int sw = ((lane & 31) >> 1) & 7;
+  auto addr = [&](int j) __attribute__((always_inline)) { return (lane & 31) * 128 + (((4 * (lane >> 5) + j) ^ sw) << 4); };
+  const int base = addr(0);
+  for (int s = 0; s < 2; ++s) {
+    for (int t = 0; t < 4; ++t) fa[s][t] = *(const v4i*)(smem + base + t * 4096);
+    for (int t = 0; t < 2; ++t) fb[s][t] = *(const v4i*)(smem + 32768 + base + t * 4096);
+  }
+  const int scale = 0x7f7f7f7f;
+  auto mfma8 = [&](int set) __attribute__((always_inline)) {
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+      for (int n = 0; n < 2; ++n) {
+        const v4i a = fa[set][m], b = fb[set][n];
+        acc[m * 2 + n] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(v8i{b[0], b[1], b[2], b[3], 0, 0, 0, 0}, v8i{a[0], a[1], a[2], a[3], 0, 0, 0, 0},
+                                                                      acc[m * 2 + n], 4, 4, 0, scale, 0, scale);
+      }
+  };
+  auto reads = [&](int set, int off) __attribute__((always_inline)) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) fa[set][t] = *(const v4i*)(smem + addr(off) + t * 4096);
+#pragma unroll
+    for (int t = 0; t < 2; ++t) fb[set][t] = *(const v4i*)(smem + 32768 + addr(off) + t * 4096);
+  };
+  auto keep = [&](int set) __attribute__((always_inline)) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) asm volatile("" ::"v"(fa[set][t]));
+#pragma unroll
+    for (int t = 0; t < 2; ++t) asm volatile("" ::"v"(fb[set][t]));
+  };
+  auto dma2 = [&](int it) __attribute__((always_inline)) {
+    const int v = lane * 16 + (it & 63) * 2048 + wave * 131072;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)(smem + 65536 + wave * 2048), 16, v, 0, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)(smem + 65536 + wave * 2048 + 1024), 16, v + 1024, 0, 0, 0);
+  };
+  auto fence = [&]() __attribute__((always_inline)) { __builtin_amdgcn_sched_barrier(0); };
+
+  __syncthreads();
+  const uint64_t t0 = __builtin_readcyclecounter();
+  for (int it = 0; it < iters; it += 2) {
+    const int off0 = (it >> 1) & 3, off1 = (off0 + 1) & 3;   // k-slice index j (runtime, like the stage loop)
+    if (MODE == 0) { mfma8(0); fence(); mfma8(1); fence(); }
+    if (MODE == 1) { reads(0, off0); keep(0); fence(); reads(1, off1); keep(1); fence(); }
+    if (MODE == 2 || MODE == 4) {
+      mfma8(0); fence(); reads(1, off0); keep(0); fence();
+      if (MODE == 4) { dma2(it); fence(); }
+      mfma8(1); fence(); reads(0, off1); keep(1); fence();
+      if (MODE == 4) { dma2(it + 1); fence(); }
+    }
+    if (MODE == 3) { reads(0, off0); fence(); mfma8(0); fence(); reads(0, off1); fence(); mfma8(0); fence(); }
+    if (MODE == 5) {
+      reads(1, off0); fence(); mfma8(0); fence();
+      reads(0, off1); fence(); mfma8(1); fence();
+    }
+    if (MODE == 6) { dma2(it); fence(); dma2(it + 1); fence(); }
+    if (MODE == 7) {
+      mfma8(0); fence(); reads(1, off0); keep(0); fence(); dma2(it); fence();
+      mfma8(1); fence(); reads(0, off1); keep(1); fence(); dma2(it + 1); fence();
+      if ((it & 2) == 2) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); fence(); }
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  const uint64_t t1 = __builtin_readcyclecounter();
+  float s = 0.f;
+  for (int a = 0; a < 8; ++a) for (int r = 0; r < 16; ++r) s += acc[a][r];
+  for (int st = 0; st < 2; ++st) { for (int t = 0; t < 4; ++t) s += (float)fa[st][t][0]; for (int t = 0; t < 2; ++t) s += (float)fb[st][t][1]; }
+  out[blockIdx.x * THREADS + tid] = s + ((float*)smem)[16384 + tid];
+  if (blockIdx.x == 0 && lane == 0) cyc[wave] = (uint32_t)(t1 - t0);
+}
+
+template <int MODE, int THREADS>
+static void run_one(const char* name, const char* g, uint32_t gbytes, float* out, uint32_t* cyc, int blocks) {
+  const int iters = 2000;
+  ub_kernel<MODE, THREADS><<<blocks, THREADS>>>(g, gbytes, out, cyc, iters);
+  HIP_OK(hipDeviceSynchronize());
+  hipEvent_t e0, e1;
+  HIP_OK(hipEventCreate(&e0)); HIP_OK(hipEventCreate(&e1));
+  HIP_OK(hipEventRecord(e0, 0));
+  ub_kernel<MODE, THREADS><<<blocks, THREADS>>>(g, gbytes, out, cyc, iters);
+  HIP_OK(hipEventRecord(e1, 0));
+  HIP_OK(hipEventSynchronize(e1));
+  float ms; HIP_OK(hipEventElapsedTime(&ms, e0, e1));
+  uint32_t h[8];
+  HIP_OK(hipMemcpy(h, cyc, sizeof h, hipMemcpyDeviceToHost));
+  printf("UBENCH mode %d %-44s waves/SIMD=%d blocks=%3d : %7.1f cycles/iter (wave0)  %7.1f ns/iter  -> clock %.2f GHz\n", MODE, name, THREADS / 256, blocks,
+         (double)h[0] / iters, ms * 1e6 / iters, (double)h[0] / (ms * 1e6));
+  hipEventDestroy(e0); hipEventDestroy(e1);
+}
+
+void run_ubench() {
+  const uint32_t gbytes = 64u << 20;
+  char* g; float* out; uint32_t* cyc;
+  HIP_OK(hipMalloc(&g, gbytes)); HIP_OK(hipMemset(g, 0x22, gbytes));
+  HIP_OK(hipMalloc(&out, 256 * 512 * 4)); HIP_OK(hipMalloc(&cyc, 64));
+  for (int blocks : {1, 256}) {
+    run_one<0, 256>("MFMA x8 only", g, gbytes, out, cyc, blocks);
+    run_one<0, 512>("MFMA x8 only", g, gbytes, out, cyc, blocks);
+    run_one<1, 256>("ds_read_b128 x6 only", g, gbytes, out, cyc, blocks);
+    run_one<1, 512>("ds_read_b128 x6 only", g, gbytes, out, cyc, blocks);
+    run_one<2, 256>("MFMA(cur) ; reads->other set", g, gbytes, out, cyc, blocks);
+    run_one<2, 512>("MFMA(cur) ; reads->other set", g, gbytes, out, cyc, blocks);
+    run_one<5, 256>("reads->other set ; MFMA(cur)", g, gbytes, out, cyc, blocks);
+    run_one<5, 512>("reads->other set ; MFMA(cur)", g, gbytes, out, cyc, blocks);
+    run_one<3, 256>("reads ; MFMA same set (serialised)", g, gbytes, out, cyc, blocks);
+    run_one<3, 512>("reads ; MFMA same set (serialised)", g, gbytes, out, cyc, blocks);
+    run_one<6, 256>("LDS-DMA x2 only", g, gbytes, out, cyc, blocks);
+    run_one<6, 512>("LDS-DMA x2 only", g, gbytes, out, cyc, blocks);
+    run_one<4, 256>("MFMA ; reads->other ; LDS-DMA x2", g, gbytes, out, cyc, blocks);
+    run_one<4, 512>("MFMA ; reads->other ; LDS-DMA x2", g, gbytes, out, cyc, blocks);
+    run_one<7, 256>("mode 4 + vmcnt(0)+barrier every 4 slices", g, gbytes, out, cyc, blocks);
+    run_one<7, 512>("mode 4 + vmcnt(0)+barrier every 4 slices", g, gbytes, out, cyc, blocks);
+  }
+  hipFree(g); hipFree(out); hipFree(cyc);
+}

@@ -1,0 +1,153 @@
+"""CPU tests (no GPU): the C-ABI library loads and exports every symbol include/qutlass_amd.h declares,
+argument validation of the C entry points (no launches), the Python host mirror of the reference
+interface (names, signatures, error behaviour), and the padded-shape helpers."""
+import ctypes
+import inspect
+import os
+import re
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from qutlass_amd import _lib, build
+
+    build.build()  # hipcc cross-compiles gfx950 without a GPU; no-op when up to date
+    return _lib.load()
+
+
+def test_header_symbols_are_exported(lib):
+    hdr = open(os.path.join(ROOT, "include", "qutlass_amd.h")).read()
+    declared = set(re.findall(r"\b(qutlass_amd_[a-z0-9_]+)\s*\(", hdr))
+    assert len(declared) >= 10
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"{name} declared in include/qutlass_amd.h but not exported"
+    from qutlass_amd._lib import SYMBOLS
+
+    assert declared == set(SYMBOLS), "ctypes table and header disagree"
+
+
+def test_c_abi_rejects_bad_arguments_without_launching(lib):
+    from qutlass_amd._lib import QAMD_ERR_INVALID
+
+    dummy = ctypes.c_void_p(0x1000)  # never dereferenced: validation fails first
+    err = lambda: lib.qutlass_amd_last_error().decode()
+    g = lib.qutlass_amd_matmul_mxf4_bf16_tn
+    assert g(None, dummy, dummy, dummy, dummy, dummy, 128, 128, 128, None) == QAMD_ERR_INVALID
+    assert "null pointer" in err()
+    assert g(dummy, dummy, dummy, dummy, dummy, dummy, 128, 128, 96, None) == QAMD_ERR_INVALID
+    assert "multiple of 128" in err()
+    assert g(dummy, dummy, dummy, dummy, dummy, dummy, 128, 130, 128, None) == QAMD_ERR_INVALID
+    assert "multiple of 8" in err()
+    assert lib.qutlass_amd_matmul_nvf4_bf16_tn(dummy, dummy, dummy, dummy, dummy, dummy, 8, 8, 48, None) == QAMD_ERR_INVALID
+    q = lib.qutlass_amd_fused_quantize_mx
+    assert q(dummy, dummy, 48, 4096, 0, dummy, dummy, None, None) == QAMD_ERR_INVALID
+    assert "Unsupported rotation size 48" in err()
+    assert q(dummy, dummy, 64, 4096, 0, dummy, dummy, dummy, None) == QAMD_ERR_INVALID  # mask: rot 32 only
+    assert q(dummy, dummy, 32, 100, 0, dummy, dummy, None, None) == QAMD_ERR_INVALID
+    assert "divisible" in err()
+    assert q(dummy, dummy, 32, 4096, 1, dummy, dummy, dummy, None) == QAMD_ERR_INVALID  # mask + abs_max
+    assert lib.qutlass_amd_fused_quantize_nv(dummy, dummy, 8, 4096, 1, dummy, dummy, dummy, None) == QAMD_ERR_INVALID
+    assert lib.qutlass_amd_to_blocked(dummy, 0, 4, dummy, None) == QAMD_ERR_INVALID
+    assert lib.qutlass_amd_set_option(b"no_such_option", 1) == -1
+    assert b"gfx950" in lib.qutlass_amd_version()
+
+
+def test_python_surface_matches_reference_signatures():
+    import qutlass
+    import qutlass_amd
+    from qutlass.utils import get_padded_shape_mx, get_padded_shape_nv, pad_to_block, to_blocked  # noqa: F401
+
+    # reference: qutlass/__init__.py:34-203 (parameter names, order, keyword-only markers, defaults)
+    want = {
+        "matmul_mxf4_bf16_tn": ["a", "b", "a_sf", "b_sf", "alpha", "backend"],
+        "matmul_nvf4_bf16_tn": ["a", "b", "a_sf", "b_sf", "alpha", "backend"],
+        "matmul_mxf8_bf16_tn": ["a", "b", "block_scale_a", "block_scale_b", "alpha"],
+        "matmul_mxf8_bf16_nn": ["a", "b", "block_scale_a", "block_scale_b", "alpha"],
+        "fusedQuantizeMx": ["a", "b", "method", "return_mask"],
+        "fusedQuantizeNv": ["a", "b", "global_scale", "method"],
+    }
+    for name, params in want.items():
+        f = getattr(qutlass_amd, name)
+        assert getattr(qutlass, name) is f
+        assert list(inspect.signature(f).parameters) == params, name
+    sig = inspect.signature(qutlass_amd.fusedQuantizeMx)
+    assert sig.parameters["method"].default == "quest" and sig.parameters["method"].kind is inspect.Parameter.KEYWORD_ONLY
+    assert sig.parameters["return_mask"].default is False
+    assert inspect.signature(qutlass_amd.fusedQuantizeNv).parameters["method"].default == "abs_max"
+    assert inspect.signature(qutlass_amd.matmul_mxf4_bf16_tn).parameters["backend"].default == "cutlass"
+    assert list(inspect.signature(to_blocked).parameters) == ["input_matrix", "use_triton_kernel"]
+
+
+def test_torch_ops_registered_with_reference_schemas():
+    import qutlass_amd  # noqa: F401
+    from qutlass_amd.ops import SCHEMAS
+
+    for name, schema in SCHEMAS.items():
+        op = getattr(torch.ops._qutlass_C, name)
+        got = str(op.default._schema)
+        assert got == f"_qutlass_C::{name}{schema}", got
+
+
+def test_python_level_error_behaviour():
+    import qutlass_amd
+
+    a = torch.zeros(4, 64, dtype=torch.bfloat16)
+    h = torch.eye(32, dtype=torch.bfloat16)
+    with pytest.raises(ValueError, match="invalid method"):
+        qutlass_amd.fusedQuantizeMx(a, h, method="nope")
+    with pytest.raises(ValueError, match="return_mask is only supported"):
+        qutlass_amd.fusedQuantizeMx(a, h, method="abs_max", return_mask=True)
+    with pytest.raises(ValueError, match="invalid method"):
+        qutlass_amd.fusedQuantizeNv(a, h, torch.ones(1), method="nope")
+    u8 = torch.zeros(4, 64, dtype=torch.uint8)
+    sf = torch.zeros(128, 4, dtype=torch.float8_e8m0fnu)
+    with pytest.raises(ValueError, match="invalid backend"):
+        qutlass_amd.matmul_mxf4_bf16_tn(u8, u8, sf, sf, torch.ones(1), backend="nope")
+    with pytest.raises(ImportError, match="flashinfer"):
+        qutlass_amd.matmul_mxf4_bf16_tn(u8, u8, sf, sf, torch.ones(1), backend="flashinfer")
+    with pytest.raises(AttributeError, match="hot path"):
+        qutlass_amd.backward_t_bf16
+
+
+def test_op_layer_validation_messages_follow_the_reference():
+    # bindings.cpp:38-57 / bindings_utils.h:67-136 -- checked on CPU tensors: validation runs before any launch
+    from qutlass_amd import ops
+
+    u8 = torch.zeros(4, 64, dtype=torch.uint8)
+    sf = torch.zeros(128, 4, dtype=torch.float8_e8m0fnu)
+    al = torch.ones(1)
+    with pytest.raises(RuntimeError, match="Expected tensor to have cuda DeviceType, but got tensor with cpu DeviceType"):
+        ops.matmul_mxf4_bf16_tn(u8, u8, sf, sf, al)
+    nc = torch.zeros(64, 8, dtype=torch.uint8).t()
+    with pytest.raises(RuntimeError, match=r"Expected contiguous tensor, but got non-contiguous tensor for argument #0 'A' \(while checking arguments for matmul_mxf4_bf16_tn\)"):
+        ops.matmul_mxf4_bf16_tn(nc, u8, sf, sf, al)
+    with pytest.raises(RuntimeError, match="to_blocked expects a 2-D matrix"):
+        ops.to_blocked(torch.zeros(8, dtype=torch.uint8))
+
+
+def test_padded_shapes_and_pad_to_block():
+    from qutlass_amd.utils import get_padded_shape_mx, get_padded_shape_nv, pad_to_block
+
+    assert get_padded_shape_mx(torch.empty(4096, 4096)) == (4096, 128)
+    assert get_padded_shape_mx(torch.empty(2, 504, 2048)) == (1024, 64)
+    assert get_padded_shape_mx(torch.empty(1, 4096)) == (128, 128)
+    assert get_padded_shape_mx(torch.empty(3, 96)) == (128, 4)
+    assert get_padded_shape_nv(torch.empty(504, 4096)) == (512, 256)
+    x = torch.arange(6.0).reshape(2, 3)
+    assert pad_to_block(x, [0], 128).shape == (128, 3) and pad_to_block(x, [0, 1], 4).shape == (4, 4)
+    assert pad_to_block(x, [0], 128)[:2].equal(x) and pad_to_block(x, [0], 128)[2:].abs().sum() == 0
+
+
+def test_no_oracle_in_product_path():
+    # the product package must never import the test oracle (or any CPU fallback)
+    pkg = os.path.join(ROOT, "qutlass_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "import oracle" not in src and "from oracle" not in src and "libqutlass_oracle" not in src, f

@@ -1,0 +1,321 @@
+"""GPU parity tests (pytest -m gpu, run on the MI355X box).
+
+Every test goes through the product path -- qutlass_amd's Python operator surface, which calls the C ABI
+of libqutlass_amd.so (hand-written HIP) -- and checks the result against
+  * the committed golden fixtures produced by the reference's own Python oracles (tests/golden/), and
+  * the CPU oracle (oracle/) on seeded inputs,
+with the pass rules of SURVEY.md section 8c:
+  bytes / indices (to_blocked, e8m0, clip mask, packed layout) bit-exact; MXFP4 / NVFP4 GEMM outputs
+  bit-equal in bf16 (every product and partial sum is exact); e2m1 codes equal modulo the sign of zero with
+  a mismatch fraction <= 1e-6 (reference's own bound: 1e-4) on random data and 0 on exactly-representable
+  data; MXFP8 GEMM within 1 bf16 ulp + 2e-5 * max|ref| (reference tests: rtol = atol = 1e-1).
+Nothing here reads /root/reference.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import oracle  # noqa: E402  (the checker)
+
+
+@pytest.fixture(scope="module")
+def q():
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    import qutlass_amd
+
+    return qutlass_amd
+
+
+DEV = "cuda:0"
+
+
+def _load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name))
+
+
+def _bf16(bits: np.ndarray) -> torch.Tensor:
+    return torch.from_numpy(bits.astype(np.int16)).view(torch.bfloat16).to(DEV)
+
+
+def _hadamard(n):
+    h = torch.ones(1, 1)
+    while h.shape[0] < n:
+        h = torch.cat([torch.cat([h, h], 1), torch.cat([h, -h], 1)], 0)
+    return (h * n ** -0.5).to(torch.bfloat16).to(DEV)
+
+
+def _np(t: torch.Tensor) -> np.ndarray:
+    t = t.detach().cpu().contiguous()
+    if t.dtype == torch.bfloat16:
+        return t.view(torch.uint16).numpy()
+    if t.element_size() == 1:
+        return t.view(torch.uint8).numpy()
+    return t.numpy()
+
+
+def _loaded_native_lib():
+    # the parity claims are void if the HIP library is not the thing that ran
+    with open("/proc/self/maps") as f:
+        return any("libqutlass_amd.so" in line for line in f)
+
+
+def test_native_library_is_loaded(q):
+    assert _loaded_native_lib()
+    assert b"gfx950" in q._lib.load().qutlass_amd_version()
+
+
+# ------------------------------------------------------------------------------------------------
+# to_blocked
+# ------------------------------------------------------------------------------------------------
+def test_to_blocked_golden_and_ragged(q, golden_dir):
+    from qutlass_amd.utils import to_blocked
+
+    g = _load(golden_dir, "to_blocked.npz")
+    for i in range(4):
+        x = torch.from_numpy(g[f"in{i}"]).to(DEV)
+        assert np.array_equal(_np(to_blocked(x)), g[f"out{i}"]), i
+        assert np.array_equal(_np(to_blocked(x.view(torch.float8_e8m0fnu), use_triton_kernel=True)), g[f"out{i}"])
+    rng = np.random.default_rng(0)
+    for rows, cols in [(1, 4), (16, 128), (130, 5), (504, 64), (4096, 128), (300, 131), (8192, 512)]:
+        a = rng.integers(0, 256, (rows, cols), dtype=np.uint8)
+        got = _np(to_blocked(torch.from_numpy(a).to(DEV)))
+        assert np.array_equal(got, oracle.to_blocked(a)), (rows, cols)
+    out = to_blocked(torch.zeros(128, 4, dtype=torch.float8_e4m3fn, device=DEV))
+    assert out.dtype == torch.float8_e4m3fn and out.dim() == 1  # same dtype, flat (utils.py:193)
+
+
+# ------------------------------------------------------------------------------------------------
+# fusedQuantizeMx
+# ------------------------------------------------------------------------------------------------
+def _check_mx(q, x, h, method, mask, exact):
+    out = q.fusedQuantizeMx(x, h, method=method, return_mask=mask)
+    e2m1, e8m0 = out[0], out[1]
+    assert e2m1.shape == (*x.shape[:-1], x.shape[-1] // 2) and e2m1.dtype == torch.uint8
+    assert e8m0.dtype == torch.float8_e8m0fnu
+    n = x.numel()
+    rq, rs, rm = oracle.fused_quantize_mx(_np(x), _np(h), oracle.QUEST if method == "quest" else oracle.ABS_MAX, with_mask=mask)
+    got_s = _np(e8m0).reshape(-1)[: n // 32]
+    assert np.array_equal(got_s, rs), f"e8m0 mismatches: {(got_s != rs).sum()}"
+    eq = oracle.codes_equal_mod_zero_sign(_np(e2m1), rq)
+    bad = int((~eq).sum())
+    assert bad == 0 if exact else bad <= max(1, int(1e-6 * n)), f"{bad} code mismatches of {n}"
+    if mask:
+        assert out[2].shape == (*x.shape[:-1], x.shape[-1] // 8)
+        assert np.array_equal(_np(out[2]).reshape(-1), rm)
+
+
+@pytest.mark.parametrize("hw", [0, 1])
+def test_fused_quantize_mx_golden(q, golden_dir, hw):
+    q._lib.set_option("hw_fp4_cvt", hw)
+    try:
+        g = _load(golden_dir, "quantize_mx.npz")
+        for c in range(int(g["ncases"])):
+            R, quest = g[f"meta{c}"]
+            x, h = _bf16(g[f"x{c}"]), _bf16(g[f"h{c}"])
+            e2m1, e8m0 = q.fusedQuantizeMx(x, h, method="quest" if quest else "abs_max")
+            n = x.numel()
+            assert np.array_equal(_np(e8m0).reshape(-1)[: n // 32], g[f"e8m0_{c}"].reshape(-1)), c
+            eq = oracle.codes_equal_mod_zero_sign(_np(e2m1), g[f"e2m1_{c}"])
+            assert eq.all(), (c, int((~eq).sum()))
+            if quest and R == 32:
+                _, _, m = q.fusedQuantizeMx(x, h, method="quest", return_mask=True)
+                assert np.array_equal(_np(m).reshape(-1), g[f"mask{c}"].reshape(-1)), c
+    finally:
+        q._lib.set_option("hw_fp4_cvt", 1)
+
+
+@pytest.mark.parametrize("rot", [32, 64, 128])
+@pytest.mark.parametrize("method", ["quest", "abs_max"])
+def test_fused_quantize_mx_random_vs_oracle(q, rot, method):
+    torch.manual_seed(0)
+    x = torch.randn(2, 512, 4096, dtype=torch.bfloat16, device=DEV) * 25.0
+    _check_mx(q, x, _hadamard(rot), method, mask=(rot == 32 and method == "quest"), exact=False)
+
+
+@pytest.mark.parametrize("shape", [(1, 32), (3, 96), (33, 7, 64), (1, 4096), (5, 1056)])
+def test_fused_quantize_mx_ragged_shapes_and_exact_inputs(q, shape):
+    torch.manual_seed(1)
+    # small integers x (+-0.25) Hadamard: every fp32 operation is exact -> bit-exact regardless of order
+    x = torch.randint(-8, 9, shape, device=DEV).to(torch.bfloat16)
+    h = (_hadamard(32).float().sign() * 0.25).to(torch.bfloat16)
+    for method in ("quest", "abs_max"):
+        _check_mx(q, x, h, method, mask=(method == "quest"), exact=True)
+    # identity rotation (quartet_test.py:380 passes torch.eye(32)); all-zero group -> e8m0 of 1e-8
+    xz = torch.zeros(4, 64, dtype=torch.bfloat16, device=DEV)
+    _check_mx(q, xz, torch.eye(32, dtype=torch.bfloat16, device=DEV), "abs_max", False, True)
+
+
+def test_fused_quantize_mx_leaves_scale_padding_untouched(q):
+    # reference contract: only the first numel/32 bytes of the (padded_rows, padded_cols) buffer are written
+    x = torch.randn(3, 96, dtype=torch.bfloat16, device=DEV)
+    _, s = q.fusedQuantizeMx(x, _hadamard(32), method="abs_max")
+    assert s.shape == (128, 4)
+
+
+# ------------------------------------------------------------------------------------------------
+# MXFP4 GEMM
+# ------------------------------------------------------------------------------------------------
+def _gemm_golden(q, g, c, fn, sf_dtype, kind):
+    from qutlass_amd.utils import to_blocked
+
+    m, n, k = (int(v) for v in g[f"meta{c}"])
+    a, b = torch.from_numpy(g[f"a{c}"]).to(DEV), torch.from_numpy(g[f"b{c}"]).to(DEV)
+    asf = to_blocked(torch.from_numpy(g[f"asf{c}"]).to(DEV).view(sf_dtype))
+    bsf = to_blocked(torch.from_numpy(g[f"bsf{c}"]).to(DEV).view(sf_dtype))
+    alpha = torch.tensor([float(g[f"alpha{c}"])] if f"alpha{c}" in g else [1.0], device=DEV)
+    if kind == oracle.KIND_MXFP8_TN:
+        a, b = a.view(torch.float8_e4m3fn), b.view(torch.float8_e4m3fn)
+    out = fn(a, b, asf, bsf, alpha)
+    assert out.shape == (m, n) and out.dtype == torch.bfloat16
+    return _np(out), g[f"out{c}"]
+
+
+@pytest.mark.parametrize("variant", [0, 1, 2, 5, 6, 7])
+def test_matmul_mxf4_golden_bit_exact(q, golden_dir, variant):
+    g = _load(golden_dir, "gemm_mxfp4.npz")
+    q._lib.set_option("gemm_variant", variant)
+    try:
+        for c in range(int(g["ncases"])):
+            got, want = _gemm_golden(q, g, c, q.matmul_mxf4_bf16_tn, torch.float8_e8m0fnu, oracle.KIND_MXFP4)
+            assert np.array_equal(got, want), (variant, c, int((got != want).sum()))
+    finally:
+        q._lib.set_option("gemm_variant", 0)
+
+
+def _pipeline(q, m, n, k, method, rot=32, seed=0):
+    from qutlass_amd.utils import to_blocked
+
+    torch.manual_seed(seed)
+    h = _hadamard(rot)
+    a = torch.randn(m, k, dtype=torch.bfloat16, device=DEV) * 25.0
+    b = torch.randn(n, k, dtype=torch.bfloat16, device=DEV) * 25.0
+    a_q, a_s = q.fusedQuantizeMx(a, h, method=method)
+    b_q, b_s = q.fusedQuantizeMx(b, h, method=method)
+    alpha = torch.tensor([1.0], device=DEV)
+    out = q.matmul_mxf4_bf16_tn(a_q, b_q, to_blocked(a_s), to_blocked(b_s), alpha)
+    return a_q, a_s, b_q, b_s, out
+
+
+@pytest.mark.parametrize("m,n,k,method", [(256, 256, 512, "abs_max"), (1, 504, 4096, "abs_max"), (504, 504, 2048, "quest"),
+                                           (16, 4096, 4096, "quest"), (300, 1032, 1152, "abs_max")])
+def test_pipeline_quantize_swizzle_gemm_vs_oracle(q, m, n, k, method):
+    """The reference's own end-to-end test shape list (tests/mxfp4_test.py:224-237, 257-269): quantise both
+    operands on the GPU, swizzle, multiply; compare with the CPU oracle's dequantise-matmul on the SAME packed
+    operands -> exact bf16 equality."""
+    a_q, a_s, b_q, b_s, out = _pipeline(q, m, n, k, method)
+    sfa = oracle.to_blocked(_np(a_s)[:, : k // 32] if a_s.shape[1] == k // 32 else _np(a_s))
+    sfb = oracle.to_blocked(_np(b_s)[:, : k // 32] if b_s.shape[1] == k // 32 else _np(b_s))
+    ref = oracle.gemm_blockscaled(oracle.KIND_MXFP4, _np(a_q), _np(b_q), sfa, sfb, 1.0, m, n, k)
+    got = _np(out)
+    assert np.array_equal(got, ref), int((got != ref).sum())
+
+
+def test_matmul_mxf4_full_size_properties(q):
+    """BASELINE.json configs[1] (4096^3) at full size: (i) a 96-row slab against the CPU oracle, bit-exact;
+    (ii) linearity in alpha (exact: power of two); (iii) row-permutation equivariance; (iv) every tile
+    schedule produces the identical matrix."""
+    from qutlass_amd.utils import to_blocked
+
+    m = n = k = 4096
+    a_q, a_s, b_q, b_s, out = _pipeline(q, m, n, k, "abs_max")
+    rows = torch.randperm(m)[:96].sort().values
+    sfa_rm = _np(a_s)[rows.numpy()]
+    ref = oracle.gemm_blockscaled(oracle.KIND_MXFP4, _np(a_q[rows.to(DEV)]), _np(b_q), oracle.to_blocked(sfa_rm),
+                                  oracle.to_blocked(_np(b_s)), 1.0, len(rows), n, k)
+    assert np.array_equal(_np(out[rows.to(DEV)]), ref)
+    asf, bsf = to_blocked(a_s), to_blocked(b_s)
+    half = q.matmul_mxf4_bf16_tn(a_q, b_q, asf, bsf, torch.tensor([0.5], device=DEV))
+    assert torch.equal(half, out * 0.5)
+    perm = torch.randperm(m, device=DEV)
+    outp = q.matmul_mxf4_bf16_tn(a_q[perm].contiguous(), b_q, to_blocked(a_s[perm].contiguous()), bsf, torch.tensor([1.0], device=DEV))
+    assert torch.equal(outp, out[perm])
+    for variant in (1, 5, 6, 3, 4, 8, 9):
+        q._lib.set_option("gemm_variant", variant)
+        try:
+            assert torch.equal(q.matmul_mxf4_bf16_tn(a_q, b_q, asf, bsf, torch.tensor([1.0], device=DEV)), out), variant
+        finally:
+            q._lib.set_option("gemm_variant", 0)
+
+
+def test_matmul_mxf4_errors(q):
+    u8 = torch.zeros(128, 64, dtype=torch.uint8, device=DEV)
+    sf = torch.zeros(128 * 4, dtype=torch.float8_e8m0fnu, device=DEV)
+    al = torch.ones(1, device=DEV)
+    with pytest.raises(RuntimeError, match="A_sf must be float8_e8m0fnu"):
+        q.matmul_mxf4_bf16_tn(u8, u8, sf.view(torch.uint8), sf, al)
+    with pytest.raises(RuntimeError, match="Inner dimensions must match"):
+        q.matmul_mxf4_bf16_tn(u8, u8[:, :32].contiguous(), sf, sf, al)
+    with pytest.raises(RuntimeError, match="K-dim must be >= 32"):
+        q.matmul_mxf4_bf16_tn(u8[:, :8].contiguous(), u8[:, :8].contiguous(), sf, sf, al)
+    with pytest.raises(RuntimeError, match="multiple of 128"):   # CUTLASS alignment in the reference (gemm.cu:187)
+        q.matmul_mxf4_bf16_tn(u8[:, :48].contiguous(), u8[:, :48].contiguous(), sf, sf, al)
+
+
+# ------------------------------------------------------------------------------------------------
+# NVFP4
+# ------------------------------------------------------------------------------------------------
+def test_matmul_nvf4_golden_bit_exact(q, golden_dir):
+    g = _load(golden_dir, "gemm_nvfp4.npz")
+    for c in range(int(g["ncases"])):
+        got, want = _gemm_golden(q, g, c, q.matmul_nvf4_bf16_tn, torch.float8_e4m3fn, oracle.KIND_NVFP4)
+        assert np.array_equal(got, want), (c, int((got != want).sum()))
+
+
+@pytest.mark.parametrize("rot", [16, 32, 64, 128])
+def test_fused_quantize_nv_and_gemm_vs_oracle(q, rot):
+    from qutlass_amd.utils import to_blocked
+
+    torch.manual_seed(2)
+    m, n, k = 504, 1024, 2048
+    h = _hadamard(rot)
+    gs = torch.tensor([6.0], device=DEV)
+    a = torch.randn(m, k, dtype=torch.bfloat16, device=DEV) * 25.0
+    b = torch.randn(n, k, dtype=torch.bfloat16, device=DEV) * 25.0
+    a_q, a_s = q.fusedQuantizeNv(a, h, gs)
+    b_q, b_s = q.fusedQuantizeNv(b, h, gs)
+    assert a_s.dtype == torch.float8_e4m3fn and a_s.shape == (512, k // 16)
+    rq, rs = oracle.fused_quantize_nv(_np(a), _np(h), 6.0, oracle.ABS_MAX, acc_model=1)
+    got_s = _np(a_s).reshape(-1)[: rs.size]
+    sbad = int((got_s != rs).sum())
+    assert sbad <= 1e-3 * rs.size, sbad   # rcp / MFMA-order differences only (reference bound: 1e-1)
+    same = (got_s == rs).repeat(16)
+    eq = oracle.codes_equal_mod_zero_sign(_np(a_q), rq)
+    assert int((~eq & same).sum()) <= 1e-3 * eq.size
+    out = q.matmul_nvf4_bf16_tn(a_q, b_q, to_blocked(a_s), to_blocked(b_s), torch.tensor([1.0], device=DEV))
+    ref = oracle.gemm_blockscaled(oracle.KIND_NVFP4, _np(a_q), _np(b_q), oracle.to_blocked(_np(a_s)[:, : k // 16]),
+                                  oracle.to_blocked(_np(b_s)[:, : k // 16]), 1.0, m, n, k)
+    assert np.array_equal(_np(out), ref)   # exact: the reference asserts out.equal(out_ref) (nvfp4_test.py:224)
+
+
+# ------------------------------------------------------------------------------------------------
+# MXFP8
+# ------------------------------------------------------------------------------------------------
+def _mxfp8_close(got_bits, want_bits):
+    got = oracle.bf16_bits_to_f32(got_bits).astype(np.float64)
+    want = oracle.bf16_bits_to_f32(want_bits).astype(np.float64)
+    tol = np.abs(want) / 128.0 + 2e-5 * np.abs(want).max()
+    return np.abs(got - want) <= tol
+
+
+def test_matmul_mxf8_tn_golden_and_random(q, golden_dir):
+    from qutlass_amd.utils import to_blocked
+
+    g = _load(golden_dir, "gemm_mxfp8.npz")
+    for c in range(int(g["ncases"])):
+        got, want = _gemm_golden(q, g, c, q.matmul_mxf8_bf16_tn, torch.float8_e8m0fnu, oracle.KIND_MXFP8_TN)
+        assert _mxfp8_close(got, want).all(), c
+    torch.manual_seed(3)
+    m, n, k = 16, 4096, 4096   # reference test shape family (batch 16 x Llama layers, mxfp8_test.py:126-130)
+    a = torch.rand(m, k, dtype=torch.bfloat16) * 25.0
+    b = torch.rand(n, k, dtype=torch.bfloat16) * 25.0
+    aq, asf = oracle.pseudoquant_mxfp8(_np(a))
+    bq, bsf = oracle.pseudoquant_mxfp8(_np(b))
+    out = q.matmul_mxf8_bf16_tn(torch.from_numpy(aq).to(DEV).view(torch.float8_e4m3fn), torch.from_numpy(bq).to(DEV).view(torch.float8_e4m3fn),
+                                to_blocked(torch.from_numpy(asf).to(DEV).view(torch.float8_e8m0fnu)),
+                                to_blocked(torch.from_numpy(bsf).to(DEV).view(torch.float8_e8m0fnu)), torch.tensor([1.0], device=DEV))
+    ref = oracle.gemm_blockscaled(oracle.KIND_MXFP8_TN, aq, bq, oracle.to_blocked(asf), oracle.to_blocked(bsf), 1.0, m, n, k)
+    assert _mxfp8_close(_np(out), ref).all()
