@@ -155,7 +155,7 @@ def main():
             "unit": "TFLOP/s",
             "frac": round(achieved / FP4_DENSE_PEAK_TFLOPS, 4),
             "traffic": None,
-            "kernel": "gemm_mx_kernel<GemmCfg<256,256,2,4,4>, SCHED_QUEUE>",
+            "kernel": "gemm_mx_kernel<GemmCfg<256,256,2,4,4>, SCHED_SIMPLE>",
             "kernel_us": round(kernel_ms * 1e3, 3),
             "algorithmic_flop_per_launch": flop_per_step,
         },

@@ -49,6 +49,7 @@ int launch_gemm(GemmParams p, hipStream_t s) {
 
 // Tile/schedule variants ("gemm_variant" option; 0 = auto):
 //   1  256x256 ping-pong     5  256x256 lockstep     6..9  queue schedule (256x256, 128x128, 256x128, 128x256)
+//   20 / 24 / 25 / 26  simple schedule (256x256, 128x128, 256x128, 128x256) -- 20 and 24 are what auto picks
 //   2  128x128 lockstep (small M or N)                     3  256x128 lockstep    4  128x256 lockstep
 //   100+b / 200+b  ablations of variants 1 / 5 (bench only), b = OR of ABL_* bits
 template <int EBITS, bool SPLIT>
@@ -59,6 +60,10 @@ int dispatch_variant(int v, const GemmParams& p, hipStream_t s, const char* name
     case 3: return launch_gemm<GemmCfg<256, 128, 4, 2, EBITS, SPLIT>, 0>(p, s);
     case 4: return launch_gemm<GemmCfg<128, 256, 2, 4, EBITS, SPLIT>, 0>(p, s);
     case 5: return launch_gemm<GemmCfg<256, 256, 2, 4, EBITS, SPLIT>, 0>(p, s);
+    case 20: return launch_gemm<GemmCfg<256, 256, 2, 4, EBITS, SPLIT>, 3>(p, s);   // simple schedule (default, large)
+    case 24: return launch_gemm<GemmCfg<128, 128, 2, 2, EBITS, SPLIT>, 3>(p, s);   // simple schedule (default, small)
+    case 25: return launch_gemm<GemmCfg<256, 128, 4, 2, EBITS, SPLIT>, 3>(p, s);
+    case 26: return launch_gemm<GemmCfg<128, 256, 2, 4, EBITS, SPLIT>, 3>(p, s);
   }
   if constexpr (EBITS == 4) {
     switch (v) {
@@ -66,6 +71,9 @@ int dispatch_variant(int v, const GemmParams& p, hipStream_t s, const char* name
       case 7: return launch_gemm<GemmCfg<128, 128, 2, 2, 4, false>, 2>(p, s);
       case 8: return launch_gemm<GemmCfg<256, 128, 4, 2, 4, false>, 2>(p, s);
       case 9: return launch_gemm<GemmCfg<128, 256, 2, 4, 4, false>, 2>(p, s);
+      case 21: return launch_gemm<GemmCfg<256, 256, 2, 4, 4, false, 8>, 3>(p, s);   //   no epilogue
+      case 22: return launch_gemm<GemmCfg<256, 256, 2, 4, 4, false, 9>, 3>(p, s);   //   no DMA, no epilogue
+      case 23: return launch_gemm<GemmCfg<256, 256, 2, 4, 4, false, 10>, 3>(p, s);  //   no MFMA, no epilogue
     }
   }
   if constexpr (EBITS == 4 && !SPLIT) {
@@ -74,7 +82,7 @@ int dispatch_variant(int v, const GemmParams& p, hipStream_t s, const char* name
       case 100 + b: return launch_gemm<GemmCfg<256, 256, 2, 4, 4, false, b>, 1>(p, s); \
       case 200 + b: return launch_gemm<GemmCfg<256, 256, 2, 4, 4, false, b>, 0>(p, s); \
       case 300 + b: return launch_gemm<GemmCfg<256, 256, 2, 4, 4, false, b>, 2>(p, s);
-      QAMD_ABL(1) QAMD_ABL(2) QAMD_ABL(3) QAMD_ABL(4) QAMD_ABL(8) QAMD_ABL(9) QAMD_ABL(10) QAMD_ABL(11) QAMD_ABL(16) QAMD_ABL(17) QAMD_ABL(18)
+      QAMD_ABL(1) QAMD_ABL(2) QAMD_ABL(3) QAMD_ABL(4) QAMD_ABL(8) QAMD_ABL(9) QAMD_ABL(10) QAMD_ABL(11) QAMD_ABL(16) QAMD_ABL(17) QAMD_ABL(18) QAMD_ABL(41) QAMD_ABL(40) QAMD_ABL(42)
 #undef QAMD_ABL
     }
   }
@@ -107,9 +115,8 @@ int gemm_mx(const char* name, const void* A, const void* B, const void* A_sf, co
   hipStream_t s = (hipStream_t)stream;
   int variant = g_gemm_variant.load();
   if (variant == 0) {
-    // auto: fp4 -> queue schedule (256x256 tiles, 128x128 when one dimension is small); fp8 -> lockstep
-    if (EBITS == 4) variant = (M <= 128 || N <= 128) ? 7 : 6;
-    else variant = (M <= 128 || N <= 128) ? 2 : 5;
+    // auto: simple schedule, 256x256 tiles (128x128 when one dimension is small)
+    variant = (M <= 128 || N <= 128) ? 24 : 20;
   }
   return dispatch_variant<EBITS, EBITS == 8>(variant, p, s, name);
 }

@@ -49,7 +49,7 @@ struct GemmParams {
 };
 
 // ablation bits (bench-only instantiations; 0 in the product path)
-enum { ABL_NO_DMA = 1, ABL_NO_MFMA = 2, ABL_NO_STORE = 4, ABL_NO_EPILOGUE = 8, ABL_TRACE = 16 };
+enum { ABL_NO_DMA = 1, ABL_NO_MFMA = 2, ABL_NO_STORE = 4, ABL_NO_EPILOGUE = 8, ABL_TRACE = 16, ABL_NO_READS = 32 };
 
 template <int BM_, int BN_, int WAVES_M_, int WAVES_N_, int EBITS_, bool F8SPLIT_ = false, int ABL_ = 0>
 struct GemmCfg {
@@ -69,6 +69,8 @@ struct GemmCfg {
   // scale piece i is fetched by wave i into its own 1-KiB LDS slot (lanes 0-31 carry the 512 bytes,
   // lanes 32-63 load out-of-range zeros into the slot's pad half): every wave issues the same
   // instruction sequence, so the K loop needs no wave-dependent branch.
+  // With more pieces than waves (4-wave configurations) a wave carries two pieces of the SAME tensor, one per lane half.
+  static constexpr int PPW = (PA + PB > NWAVES) ? 2 : 1;   // pieces per wave instruction
   static constexpr int OFF_B = A_BYTES, OFF_S = A_BYTES + B_BYTES, S_BYTES = NWAVES * 1024;
   static constexpr int STAGE_BYTES = OFF_S + S_BYTES;
   static constexpr int NA = BM / 8 / NWAVES, NB = BN / 8 / NWAVES;  // 1-KiB DMA pieces per wave
@@ -78,7 +80,7 @@ struct GemmCfg {
   static constexpr int LDS_BYTES = LDS_MAIN + ((ABL_ & 16) ? NWAVES * TRACE_SLOTS * 4 : 0);
   static_assert(BM % (8 * NWAVES) == 0 && BN % (8 * NWAVES) == 0, "DMA split");
   static_assert(WTM % 32 == 0 && WTN % 32 == 0, "wave tile");
-  static_assert(PA + PB <= NWAVES, "one scale piece per wave");
+  static_assert(PA + PB <= NWAVES * PPW && (PPW == 1 || (PA % 2 == 0 && PB % 2 == 0)), "scale pieces per wave");
   static_assert(THREADS % (BN / 8) == 0, "epilogue split");
 };
 
@@ -151,13 +153,17 @@ struct GemmCtx {
       voffAB[par] = (lane >> 3) * rowbytes + (ch << 4);
       voffT[par] = (ch * 16 < rowbytes - (KT - 1) * C::ROWB) ? voffAB[par] : 0x7fffffff;
     }
-    // scale piece of this wave: pieces 0..PA-1 belong to A, PA..PA+PB-1 to B; piece -> (tile row, tile col)
+    // scale piece of this lane: pieces 0..PA-1 belong to A, PA..PA+PB-1 to B; piece -> (tile row, tile col).
+    // PPW == 1: piece = wave, carried by lanes 0-31 (lanes 32-63 load zeros into the slot's pad half);
+    // PPW == 2: lanes 0-31 carry piece 2*wave, lanes 32-63 piece 2*wave+1 (same tensor: PA, PB even).
     {
-      sIsB = wave >= C::PA;
+      const int piece = (C::PPW == 2) ? 2 * wave + g : wave;
+      sIsB = (C::PPW * wave) >= C::PA;
       rS = sIsB ? make_rsrc(p.SFB + sb_off, p.sfb_bytes - sb_off) : make_rsrc(p.SFA + sa_off, p.sfa_bytes - sa_off);
-      const int idx = sIsB ? wave - C::PA : wave;
+      const int idx = sIsB ? piece - C::PA : piece;
       colS = idx % C::SCT;
-      voffS = (wave < C::PA + C::PB && g == 0) ? ((idx / C::SCT) * CB + colS) * 512 + i32 * 16 : 0x7fffffff;
+      const bool on = (piece < C::PA + C::PB) && (C::PPW == 2 || g == 0);
+      voffS = on ? ((idx / C::SCT) * CB + colS) * 512 + i32 * 16 : 0x7fffffff;
     }
 
     // ---- LDS fragment read addresses --------------------------------------------------------
@@ -183,12 +189,12 @@ struct GemmCtx {
 #pragma unroll
     for (int t = 0; t < MT; ++t) {
       const int r = rbaseA + wave_m * C::WTM + 32 * t;
-      rdSA[t] = C::OFF_S + ((r >> 7) * C::SCT + scol) * 1024 + i32 * 16 + ((r & 127) >> 5) * 4;
+      rdSA[t] = C::OFF_S + ((r >> 7) * C::SCT + scol) * (1024 / C::PPW) + i32 * 16 + ((r & 127) >> 5) * 4;
     }
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
       const int r = rbaseB + wave_n * C::WTN + 32 * t;
-      rdSB[t] = C::OFF_S + (C::PA + (r >> 7) * C::SCT + scol) * 1024 + i32 * 16 + ((r & 127) >> 5) * 4;
+      rdSB[t] = C::OFF_S + (C::PA + (r >> 7) * C::SCT + scol) * (1024 / C::PPW) + i32 * 16 + ((r & 127) >> 5) * 4;
     }
 #pragma unroll
     for (int m = 0; m < MT; ++m)
@@ -238,12 +244,42 @@ struct GemmCtx {
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)(dst + q * 1024), 16, v, soff, 0, 0);
     }
   }
+  __device__ __forceinline__ void issue_pieces_range(const int NP, __amdgpu_buffer_rsrc_t rsrc, char* dst, int kt, bool valid, const int t0, const int t1) {
+    const int soff = kt * C::ROWB;
+    int lastmask = (kt == KT - 1) ? -1 : 0;
+    int oob = valid ? 0 : 0x7f000000;
+    asm volatile("" : "+v"(lastmask), "+v"(oob));
+#pragma unroll
+    for (int t = t0; t < t1; ++t) {
+      const int q = wave * NP + t;
+      const int par = q & 1;
+      const int a = par ? voffAB[1] : voffAB[0], b = par ? voffT[1] : voffT[0];
+      const int v = ((b & lastmask) | (a & ~lastmask)) + q * rstep + oob;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)(dst + q * 1024), 16, v, soff, 0, 0);
+    }
+  }
   __device__ __forceinline__ void issue_scales(int kt, char* st, bool valid) {
-    int oob = (valid && kt * C::SCT + colS < CB) ? 0 : 0x7f000000;   // K tail: no such scale column tile
+    int oob = (valid && kt * C::SCT + colS < CB) ? 0 : 0x7f000000;   // K tail: no such scale column tile (per lane)
     asm volatile("" : "+v"(oob));
     const int ssoff = kt * C::SCT * 512;
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rS, (lds_ptr_t)(st + C::OFF_S + wave * 1024), 16, voffS + oob, ssoff, 0, 0);
   }
+  // L2 warm-up: one dword per 128-byte line of a future stage (rows of A for the first half of the waves, rows of B
+  // for the second half; 64 lanes = 64 rows).  The loaded value is never used; it only makes the later LDS-DMA of
+  // that stage an L2 hit instead of a MALL/HBM miss (the 2-deep LDS ring leaves the DMA a single stage to land).
+  __device__ __forceinline__ int prefetch_stage(int kt, bool valid) {
+    constexpr int HALFW = C::NWAVES / 2;
+    const bool isB = wave >= HALFW;
+    const int w = isB ? wave - HALFW : wave;
+    constexpr int ROWS_PER_WAVE_A = C::BM / HALFW, ROWS_PER_WAVE_B = C::BN / HALFW;
+    static_assert(ROWS_PER_WAVE_A <= 64 && ROWS_PER_WAVE_B <= 64, "one load covers a wave's rows (needs >= 8 waves for 256-row tiles)");
+    const int rows = isB ? ROWS_PER_WAVE_B : ROWS_PER_WAVE_A;
+    int oob = (valid && kt < KT) ? 0 : 0x7f000000;
+    asm volatile("" : "+v"(oob));
+    const int v = (w * rows + (lane % rows)) * rowbytes + oob;
+    return __builtin_amdgcn_raw_buffer_load_b32(isB ? rB : rA, v, kt * C::ROWB, 0);
+  }
+
   // half 0: the A pieces + the scale piece; half 1: the B pieces
   __device__ __forceinline__ void issue_stage_part(int kt, int buf, int half, bool valid = true) {
     char* st = smem + buf * C::STAGE_BYTES;
@@ -492,10 +528,17 @@ __device__ __forceinline__ void gemm_mx_queue(char* smem, const GemmParams& p) {
   static_assert(C::EBITS == 4, "queue schedule is written for fp4 (4 k-slices of one 16-byte chunk)");
   constexpr int MT = C::MT, NT = C::NT;
   GemmCtx<C> cx(smem, p);
-  v4i fa[2][MT], fb[2][NT];
+  v4i fa[2][MT] = {}, fb[2][NT] = {};
   int sa[2][MT], sb[2][NT];
 
   auto read_slice = [&](int buf, int j, int set) __attribute__((always_inline)) {
+    if ((C::ABL & ABL_NO_READS) && buf >= 0) {   // keep whatever the registers hold (opaque to the optimiser)
+#pragma unroll
+      for (int t = 0; t < MT; ++t) asm volatile("" : "+v"(fa[set][t]));
+#pragma unroll
+      for (int t = 0; t < NT; ++t) asm volatile("" : "+v"(fb[set][t]));
+      return;
+    }
     const char* st = smem + buf * C::STAGE_BYTES;
 #pragma unroll
     for (int t = 0; t < MT; ++t) fa[set][t] = *(const v4i*)(st + cx.rdA[j] + t * 32 * C::ROWB);
@@ -531,6 +574,8 @@ __device__ __forceinline__ void gemm_mx_queue(char* smem, const GemmParams& p) {
   };
   auto fence = [&]() __attribute__((always_inline)) { __builtin_amdgcn_sched_barrier(0); };
   const bool dma_on = !(C::ABL & ABL_NO_DMA);
+  const bool pf_on = (p.pp_flags & 2) != 0;   // L2 warm-up loads (uniform)
+  int pf = 0;
 
   // one stage; BUF = kt & 1 is a compile-time constant so every register-array index is static
   auto stage = [&](int kt, auto bufc) __attribute__((always_inline)) {
@@ -539,8 +584,10 @@ __device__ __forceinline__ void gemm_mx_queue(char* smem, const GemmParams& p) {
     // j = 0
     mfma(0, 0, BUF); fence();
     read_slice(BUF, 1, 1); keep(0); fence();
+    cx.trace();                                                     // t1: M0 issued, R1 issued
     if (dma_on) cx.issue_stage_part(kt + 1, BUF ^ 1, 1, kt + 1 < KT);
     fence();
+    cx.trace();                                                     // t2: second DMA half issued
     // j = 1
     mfma(1, 1, BUF); fence();
     read_slice(BUF, 2, 0); keep(1); fence();
@@ -549,14 +596,20 @@ __device__ __forceinline__ void gemm_mx_queue(char* smem, const GemmParams& p) {
     read_slice(BUF, 3, 1); keep(0); fence();
     // j = 3
     mfma(3, 1, BUF); fence();
+    cx.trace();                                                     // t3: M1..M3 issued (incl. operand waits)
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    cx.trace();                                                     // t4: own DMA landed
     __builtin_amdgcn_s_barrier();
+    cx.trace();                                                     // t5: barrier released
     fence();
     read_scales(BUF ^ 1, BUF ^ 1);   // (after the last stage these read stale LDS; the values are never used)
     read_slice(BUF ^ 1, 0, 0);
     keep(1); fence();
+    asm volatile("" ::"v"(pf));                                      // previous warm-up load retired (covered by the vmcnt(0) above)
     if (dma_on) cx.issue_stage_part(kt + 2, BUF, 0, kt + 2 < KT);
+    pf = cx.prefetch_stage(kt + 4, pf_on);
     fence();
+    cx.trace();                                                     // t6 (= t0 of the next stage): R0' + first DMA half issued
   };
 
   // prologue: stage 0 -> buffer 0 (all of it), first half of stage 1 -> buffer 1
@@ -579,14 +632,77 @@ __device__ __forceinline__ void gemm_mx_queue(char* smem, const GemmParams& p) {
   if (kt < cx.KT) stage(kt, std::integral_constant<int, 0>{});
   fence();
   cx.epilogue();
+  cx.trace_dump();
+}
+
+// -------------------------------------------------------------------------------------------------
+// Schedule 4 ("simple"): the structure of tests/native/ubench.hip mode 11 -- ONE fragment set per wave,
+// every k-slice is  R(j) ; M(j) ; a share of the LDS-DMA of stage kt+1 (3,3,2+scale,0 pieces), one
+// vmcnt(0)+barrier hand-off per stage.  The WAR stall of R(j+1) behind M(j) makes each wave alternate
+// read and MFMA phases, and the two waves of a SIMD fall into complementary phases by themselves.
+// -------------------------------------------------------------------------------------------------
+template <class C>
+__device__ __forceinline__ void gemm_mx_simple(char* smem, const GemmParams& p) {
+  constexpr int KSL = C::KSL;
+  GemmCtx<C> cx(smem, p);
+  const bool dma_on = !(C::ABL & ABL_NO_DMA);
+  auto fence = [&]() __attribute__((always_inline)) { __builtin_amdgcn_sched_barrier(0); };
+  auto slice = [&](int buf, int j) __attribute__((always_inline)) {
+    cx.read_frags(buf, j);   // single fragment set: cx.fa[j]/fb[j] of different j never live together
+    fence();
+    cx.mfma_slice(j);
+    fence();
+  };
+  cx.issue_stage(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  fence();
+  for (int kt = 0; kt < cx.KT; ++kt) {
+    const int buf = kt & 1;
+    const bool nxt = kt + 1 < cx.KT;
+    char* nb = smem + (buf ^ 1) * C::STAGE_BYTES;
+    cx.read_scales(buf);
+    if (KSL == 4) {
+      slice(buf, 0);
+      if (dma_on) cx.issue_pieces_range(C::NA, cx.rA, nb, kt + 1, nxt, 0, (C::NA * 3 + 3) / 4);
+      fence();
+      slice(buf, 1);
+      if (dma_on) {
+        cx.issue_pieces_range(C::NA, cx.rA, nb, kt + 1, nxt, (C::NA * 3 + 3) / 4, C::NA);
+        cx.issue_pieces_range(C::NB, cx.rB, nb + C::OFF_B, kt + 1, nxt, 0, C::NB / 2);
+      }
+      fence();
+      slice(buf, 2);
+      if (dma_on) {
+        cx.issue_pieces_range(C::NB, cx.rB, nb + C::OFF_B, kt + 1, nxt, C::NB / 2, C::NB);
+        cx.issue_scales(kt + 1, nb, nxt);
+      }
+      fence();
+      slice(buf, 3 % KSL);
+    } else {   // fp8: two slices of 8 x 64-cycle MFMAs
+      slice(buf, 0);
+      if (dma_on) {
+        cx.issue_pieces_range(C::NA, cx.rA, nb, kt + 1, nxt, 0, C::NA);
+        cx.issue_pieces_range(C::NB, cx.rB, nb + C::OFF_B, kt + 1, nxt, 0, C::NB);
+        cx.issue_scales(kt + 1, nb, nxt);
+      }
+      fence();
+      slice(buf, 1);
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    fence();
+  }
+  cx.epilogue();
 }
 
 // One __global__ entry per (config, schedule).
-enum { SCHED_LOCKSTEP = 0, SCHED_PINGPONG = 1, SCHED_QUEUE = 2 };
+enum { SCHED_LOCKSTEP = 0, SCHED_PINGPONG = 1, SCHED_QUEUE = 2, SCHED_SIMPLE = 3 };
 template <class C, int SCHED>
 __global__ __launch_bounds__(C::THREADS) void gemm_mx_kernel(const GemmParams p) {
   __shared__ __attribute__((aligned(16))) char smem[C::LDS_BYTES];
-  if constexpr (SCHED == SCHED_QUEUE) gemm_mx_queue<C>(smem, p);
+  if constexpr (SCHED == SCHED_SIMPLE) gemm_mx_simple<C>(smem, p);
+  else if constexpr (SCHED == SCHED_QUEUE) gemm_mx_queue<C>(smem, p);
   else if constexpr (SCHED == SCHED_PINGPONG) gemm_mx_pingpong<C>(smem, p);
   else gemm_mx_lockstep<C>(smem, p);
 }

@@ -23,10 +23,14 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
 #define HIP_OK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP ERROR %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(2);} } while (0)
 
 template <int MODE, int THREADS>
-__global__ __launch_bounds__(THREADS) void ub_kernel(const char* g, uint32_t gbytes, float* out, uint32_t* cyc, int iters) {
+__global__ __launch_bounds__(THREADS) void ub_kernel(const char* g, uint32_t gbytes, float* out, uint32_t* cyc, int iters, int random_fill) {
   __shared__ __attribute__((aligned(16))) char smem[64 * 1024 + 16 * 1024];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  for (int i = tid; i < 64 * 1024 / 4; i += THREADS) ((int*)smem)[i] = 0x22222222;
+  for (int i = tid; i < 64 * 1024 / 4; i += THREADS) {
+    uint32_t x = (uint32_t)i * 2654435761u + blockIdx.x * 40503u + 12345u;   // operand bits: constant (low toggle power) or pseudo-random
+    x ^= x >> 13; x *= 0x5bd1e995u; x ^= x >> 15;
+    ((uint32_t*)smem)[i] = random_fill ? x : 0x22222222u;
+  }
   __syncthreads();
   const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(g), 0, gbytes, 0x00020000);
   v16f acc[8];
@@ -68,6 +72,10 @@ __global__ __launch_bounds__(THREADS) void ub_kernel(const char* g, uint32_t gby
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)(smem + 65536 + wave * 2048), 16, v, 0, 0, 0);
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)(smem + 65536 + wave * 2048 + 1024), 16, v + 1024, 0, 0, 0);
   };
+  auto dma1 = [&](int it) __attribute__((always_inline)) {
+    const int v = lane * 16 + (it & 63) * 2048 + wave * 131072 + 65536;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)(smem + 65536 + wave * 2048), 16, v, 0, 0, 0);
+  };
   auto fence = [&]() __attribute__((always_inline)) { __builtin_amdgcn_sched_barrier(0); };
 
   __syncthreads();
@@ -88,6 +96,24 @@ __global__ __launch_bounds__(THREADS) void ub_kernel(const char* g, uint32_t gby
       reads(0, off1); fence(); mfma8(1); fence();
     }
     if (MODE == 6) { dma2(it); fence(); dma2(it + 1); fence(); }
+    if (MODE == 8 || MODE == 9 || MODE == 10) {   // mode 2 + stage hand-off every 4 slices: 8 = lgkmcnt(0)+barrier, 9 = lgkmcnt(0) only, 10 = barrier only
+      mfma8(0); fence(); reads(1, off0); keep(0); fence();
+      mfma8(1); fence();
+      if ((it & 2) == 2) {
+        if (MODE != 10) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (MODE != 9) __builtin_amdgcn_s_barrier();
+        fence();
+      }
+      reads(0, off1); keep(1); fence();
+    }
+    if (MODE == 11 || MODE == 12) {   // single fragment set, R -> M per slice; DMA 3,3,2,0 over the 4 slices of a "stage"; hand-off after slice 3
+      const int ph = it & 2;          // it advances by 2 slices: ph == 0 -> slices 0,1 ; ph == 2 -> slices 2,3
+      reads(0, off0); fence(); mfma8(0); fence();
+      if (MODE == 11) { if (ph == 0) { dma2(it); dma1(it); } else { dma2(it); } fence(); }
+      reads(0, off1); fence(); mfma8(0); fence();
+      if (MODE == 11 && ph == 0) { dma2(it + 1); dma1(it + 1); fence(); }
+      if (ph == 2) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); fence(); }
+    }
     if (MODE == 7) {
       mfma8(0); fence(); reads(1, off0); keep(0); fence(); dma2(it); fence();
       mfma8(1); fence(); reads(0, off1); keep(1); fence(); dma2(it + 1); fence();
@@ -103,31 +129,108 @@ __global__ __launch_bounds__(THREADS) void ub_kernel(const char* g, uint32_t gby
   if (blockIdx.x == 0 && lane == 0) cyc[wave] = (uint32_t)(t1 - t0);
 }
 
+static int g_random_fill = 0;
 template <int MODE, int THREADS>
 static void run_one(const char* name, const char* g, uint32_t gbytes, float* out, uint32_t* cyc, int blocks) {
   const int iters = 2000;
-  ub_kernel<MODE, THREADS><<<blocks, THREADS>>>(g, gbytes, out, cyc, iters);
+  ub_kernel<MODE, THREADS><<<blocks, THREADS>>>(g, gbytes, out, cyc, iters, g_random_fill);
   HIP_OK(hipDeviceSynchronize());
   hipEvent_t e0, e1;
   HIP_OK(hipEventCreate(&e0)); HIP_OK(hipEventCreate(&e1));
   HIP_OK(hipEventRecord(e0, 0));
-  ub_kernel<MODE, THREADS><<<blocks, THREADS>>>(g, gbytes, out, cyc, iters);
+  ub_kernel<MODE, THREADS><<<blocks, THREADS>>>(g, gbytes, out, cyc, iters, g_random_fill);
   HIP_OK(hipEventRecord(e1, 0));
   HIP_OK(hipEventSynchronize(e1));
   float ms; HIP_OK(hipEventElapsedTime(&ms, e0, e1));
   uint32_t h[8];
   HIP_OK(hipMemcpy(h, cyc, sizeof h, hipMemcpyDeviceToHost));
-  printf("UBENCH mode %d %-44s waves/SIMD=%d blocks=%3d : %7.1f cycles/iter (wave0)  %7.1f ns/iter  -> clock %.2f GHz\n", MODE, name, THREADS / 256, blocks,
+  printf("UBENCH %s mode %d %-44s waves/SIMD=%d blocks=%3d : %7.1f cycles/iter (wave0)  %7.1f ns/iter  -> clock %.2f GHz\n", g_random_fill ? "[random operands]" : "[const operands] ", MODE, name, THREADS / 256, blocks,
          (double)h[0] / iters, ms * 1e6 / iters, (double)h[0] / (ms * 1e6));
   hipEventDestroy(e0); hipEventDestroy(e1);
 }
 
+// DMA streaming patterns with the GEMM's real addressing (256 CUs, each streaming a 256-row A panel and a 256-row B
+// panel of a 4096 x 2048-byte operand, 16 CUs per panel):
+//   PAT 0: pieces of 8 rows x 128 B (whole cache lines), 64 KiB per stage = 8 pieces per wave
+//   PAT 1: pieces of 16 rows x 64 B (half lines; the other half is fetched one stage later), 32 KiB per stage
+template <int PAT>
+__global__ __launch_bounds__(512) void dma_pattern_kernel(const char* A, const char* B, uint32_t bytes, float* out, uint32_t* cyc, int sweeps) {
+  __shared__ __attribute__((aligned(16))) char smem[144 * 1024];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int rowbytes = 2048, tile_m = blockIdx.x / 16, tile_n = blockIdx.x % 16;
+  const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(A) + tile_m * 256 * rowbytes, 0, bytes - tile_m * 256 * rowbytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(B) + tile_n * 256 * rowbytes, 0, bytes - tile_n * 256 * rowbytes, 0x00020000);
+  __syncthreads();
+  const uint64_t t0 = __builtin_readcyclecounter();
+  for (int sw = 0; sw < sweeps; ++sw) {
+    if (PAT == 0) {
+      for (int kt = 0; kt < 16; ++kt) {
+        char* st = smem + (kt & 1) * 65536;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const int q = wave * 4 + t, v = (8 * q + (lane >> 3)) * rowbytes + (lane & 7) * 16;
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lds_ptr_t)(st + q * 1024), 16, v, kt * 128, 0, 0);
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, (lds_ptr_t)(st + 32768 + q * 1024), 16, v, kt * 128, 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      }
+    } else {
+      for (int kt = 0; kt < 32; ++kt) {
+        char* st = smem + (kt & 3) * 32768;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          const int q = wave * 2 + t, v = (16 * q + (lane >> 2)) * rowbytes + (lane & 3) * 16;
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lds_ptr_t)(st + q * 1024), 16, v, kt * 64, 0, 0);
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, (lds_ptr_t)(st + 16384 + q * 1024), 16, v, kt * 64, 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      }
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  const uint64_t t1 = __builtin_readcyclecounter();
+  __syncthreads();
+  out[blockIdx.x * 512 + tid] = ((float*)smem)[tid];
+  if (blockIdx.x == 0 && lane == 0) cyc[wave] = (uint32_t)(t1 - t0);
+}
+
+template <int PAT>
+static void run_dma_pattern(const char* name, const char* A, const char* B, uint32_t bytes, float* out, uint32_t* cyc) {
+  const int sweeps = 20;
+  dma_pattern_kernel<PAT><<<256, 512>>>(A, B, bytes, out, cyc, sweeps);
+  HIP_OK(hipDeviceSynchronize());
+  hipEvent_t e0, e1;
+  HIP_OK(hipEventCreate(&e0)); HIP_OK(hipEventCreate(&e1));
+  HIP_OK(hipEventRecord(e0, 0));
+  dma_pattern_kernel<PAT><<<256, 512>>>(A, B, bytes, out, cyc, sweeps);
+  HIP_OK(hipEventRecord(e1, 0));
+  HIP_OK(hipEventSynchronize(e1));
+  float ms; HIP_OK(hipEventElapsedTime(&ms, e0, e1));
+  const double per_sweep_us = ms * 1e3 / sweeps;   // one sweep = 1 MiB per CU = the whole K=4096 loop of one 256x256 fp4 tile
+  printf("UBENCH dma-pattern %-40s : %7.2f us per K-sweep (1 MiB/CU, 256 CUs) = %6.1f GB/s per CU, %5.2f TB/s aggregate L2->LDS\n", name, per_sweep_us,
+         1048576.0 / per_sweep_us * 1e-3, 256 * 1048576.0 / per_sweep_us * 1e-6);
+  hipEventDestroy(e0); hipEventDestroy(e1);
+}
+
 void run_ubench() {
+  {
+    const uint32_t bytes = 8u << 20;
+    char *A, *B; float* o; uint32_t* c;
+    HIP_OK(hipMalloc(&A, bytes)); HIP_OK(hipMalloc(&B, bytes)); HIP_OK(hipMemset(A, 1, bytes)); HIP_OK(hipMemset(B, 2, bytes));
+    HIP_OK(hipMalloc(&o, 256 * 512 * 4)); HIP_OK(hipMalloc(&c, 64));
+    run_dma_pattern<0>("8 rows x 128 B pieces, 2 x 64 KiB ring", A, B, bytes, o, c);
+    run_dma_pattern<1>("16 rows x 64 B pieces, 4 x 32 KiB ring", A, B, bytes, o, c);
+    run_dma_pattern<0>("8 rows x 128 B pieces, 2 x 64 KiB ring", A, B, bytes, o, c);
+    run_dma_pattern<1>("16 rows x 64 B pieces, 4 x 32 KiB ring", A, B, bytes, o, c);
+    hipFree(A); hipFree(B); hipFree(o); hipFree(c);
+  }
   const uint32_t gbytes = 64u << 20;
   char* g; float* out; uint32_t* cyc;
   HIP_OK(hipMalloc(&g, gbytes)); HIP_OK(hipMemset(g, 0x22, gbytes));
   HIP_OK(hipMalloc(&out, 256 * 512 * 4)); HIP_OK(hipMalloc(&cyc, 64));
-  for (int blocks : {1, 256}) {
+  for (int rf : {0, 1}) {
+   g_random_fill = rf;
+   for (int blocks : {256}) {
     run_one<0, 256>("MFMA x8 only", g, gbytes, out, cyc, blocks);
     run_one<0, 512>("MFMA x8 only", g, gbytes, out, cyc, blocks);
     run_one<1, 256>("ds_read_b128 x6 only", g, gbytes, out, cyc, blocks);
@@ -142,8 +245,15 @@ void run_ubench() {
     run_one<6, 512>("LDS-DMA x2 only", g, gbytes, out, cyc, blocks);
     run_one<4, 256>("MFMA ; reads->other ; LDS-DMA x2", g, gbytes, out, cyc, blocks);
     run_one<4, 512>("MFMA ; reads->other ; LDS-DMA x2", g, gbytes, out, cyc, blocks);
+    run_one<8, 256>("mode 2 + lgkmcnt(0)+barrier every 4 slices", g, gbytes, out, cyc, blocks);
+    run_one<8, 512>("mode 2 + lgkmcnt(0)+barrier every 4 slices", g, gbytes, out, cyc, blocks);
+    run_one<9, 512>("mode 2 + lgkmcnt(0) only every 4 slices", g, gbytes, out, cyc, blocks);
+    run_one<10, 512>("mode 2 + barrier only every 4 slices", g, gbytes, out, cyc, blocks);
+    run_one<11, 512>("single set R->M, DMA 3,3,2,0 + hand-off / 4 slices", g, gbytes, out, cyc, blocks);
+    run_one<12, 512>("single set R->M, no DMA, hand-off / 4 slices", g, gbytes, out, cyc, blocks);
     run_one<7, 256>("mode 4 + vmcnt(0)+barrier every 4 slices", g, gbytes, out, cyc, blocks);
     run_one<7, 512>("mode 4 + vmcnt(0)+barrier every 4 slices", g, gbytes, out, cyc, blocks);
+   }
   }
   hipFree(g); hipFree(out); hipFree(cyc);
 }
