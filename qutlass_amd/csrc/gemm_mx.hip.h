@@ -347,8 +347,43 @@ struct GemmCtx {
       }
   }
 
+  // ---- epilogue, register-direct: alpha, bf16, one v_permlane32_swap per dword to give each lane 8 contiguous
+  //      columns (16 bytes) of its row, global_store_dwordx4.  A wave instruction writes 32 rows x 32 bytes; the
+  //      other sectors of each 128-byte line follow from the same wave within a few instructions (L2 merges them).
+  //      No LDS, no barrier: the stage buffers stay free for the next tile of a persistent loop.
+  __device__ __forceinline__ void epilogue_direct() {
+    const float alpha = *p.alpha;
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      const int grow = m0 + wave_m * C::WTM + 32 * m + i32;
+#pragma unroll
+      for (int n = 0; n < NT; ++n)
+#pragma unroll
+        for (int pr = 0; pr < 2; ++pr) {
+          const int q0 = 2 * pr, q1 = 2 * pr + 1;
+          uint32_t ax = pack_bf16x2(acc[m][n][4 * q0 + 0] * alpha, acc[m][n][4 * q0 + 1] * alpha);
+          uint32_t ay = pack_bf16x2(acc[m][n][4 * q0 + 2] * alpha, acc[m][n][4 * q0 + 3] * alpha);
+          uint32_t bx = pack_bf16x2(acc[m][n][4 * q1 + 0] * alpha, acc[m][n][4 * q1 + 1] * alpha);
+          uint32_t by = pack_bf16x2(acc[m][n][4 * q1 + 2] * alpha, acc[m][n][4 * q1 + 3] * alpha);
+          // lanes 32-63 of (ax, ay) <-> lanes 0-31 of (bx, by): lower half ends with columns +0..7, upper with +8..15
+          auto rx = __builtin_amdgcn_permlane32_swap(ax, bx, false, false);
+          auto ry = __builtin_amdgcn_permlane32_swap(ay, by, false, false);
+          const int gcol = n0 + wave_n * C::WTN + 32 * n + 16 * pr + 8 * g;
+          if (grow < p.M && gcol < p.N) {
+            const v4i v = {(int)rx[0], (int)ry[0], (int)rx[1], (int)ry[1]};
+            if (C::ABL & ABL_NO_STORE) {
+              if (v[0] == 0x12345678) p.D[(size_t)grow * p.N + gcol] = 1;
+            } else {
+              *(v4i*)(p.D + (size_t)grow * p.N + gcol) = v;
+            }
+          }
+        }
+    }
+  }
+
   // ---- epilogue: alpha, bf16, stage through LDS, whole-line stores ---------------------------
   __device__ __forceinline__ void epilogue() {
+    if (p.pp_flags & 8) { epilogue_direct(); return; }
     if (C::ABL & ABL_NO_EPILOGUE) {
       float s = 0.f;
 #pragma unroll
@@ -663,17 +698,25 @@ __device__ __forceinline__ void gemm_mx_simple(char* smem, const GemmParams& p) 
     char* nb = smem + (buf ^ 1) * C::STAGE_BYTES;
     cx.read_scales(buf);
     if (KSL == 4) {
+      const bool early = (p.pp_flags & 16) != 0;   // bench switch: whole DMA of stage kt+1 right after the first slice
       slice(buf, 0);
-      if (dma_on) cx.issue_pieces_range(C::NA, cx.rA, nb, kt + 1, nxt, 0, (C::NA * 3 + 3) / 4);
+      if (dma_on) {
+        cx.issue_pieces_range(C::NA, cx.rA, nb, kt + 1, nxt, 0, (C::NA * 3 + 3) / 4);
+        if (early) {
+          cx.issue_pieces_range(C::NA, cx.rA, nb, kt + 1, nxt, (C::NA * 3 + 3) / 4, C::NA);
+          cx.issue_pieces_range(C::NB, cx.rB, nb + C::OFF_B, kt + 1, nxt, 0, C::NB);
+          cx.issue_scales(kt + 1, nb, nxt);
+        }
+      }
       fence();
       slice(buf, 1);
-      if (dma_on) {
+      if (dma_on && !early) {
         cx.issue_pieces_range(C::NA, cx.rA, nb, kt + 1, nxt, (C::NA * 3 + 3) / 4, C::NA);
         cx.issue_pieces_range(C::NB, cx.rB, nb + C::OFF_B, kt + 1, nxt, 0, C::NB / 2);
       }
       fence();
       slice(buf, 2);
-      if (dma_on) {
+      if (dma_on && !early) {
         cx.issue_pieces_range(C::NB, cx.rB, nb + C::OFF_B, kt + 1, nxt, C::NB / 2, C::NB);
         cx.issue_scales(kt + 1, nb, nxt);
       }

@@ -509,14 +509,23 @@ int main(int argc, char** argv) {
       bench_gemm("mxfp4 4096^3 simple", 0, 4096, 4096, 4096, 20, 50);
       bench_gemm("mxfp4 4096^3 simple no-epi", 0, 4096, 4096, 4096, 21, 50);
     }
+    for (int fl : {1, 17, 1, 17}) {
+      qutlass_amd_set_option("pp_flags", fl);
+      printf("pp_flags=%d (bit3 = register-direct epilogue, bit4 = whole DMA after slice 0)\n", fl);
+      check_gemm("gemm_mxfp4 ragged direct-epilogue check", 0, 72, 136, 640, 0.5f, 4, 0, 20);
+      check_gemm("gemm_mxfp4 504x504x2048 direct-epilogue check", 0, 504, 504, 2048, 1.0f, 3, 0, 20);
+      bench_gemm("mxfp4 4096^3 simple", 0, 4096, 4096, 4096, 20, 50);
+      bench_gemm("mxfp4 C3 simple", 0, 4096, 14336, 4096, 20, 20);
+      bench_gemm("mxfp4 8192^3 simple", 0, 8192, 8192, 8192, 20, 10);
+    }
     qutlass_amd_set_option("pp_flags", 1);
-    for (int z : {1, 0}) {
+    for (int z : std::vector<int>{}) {
       g_zero_fill = z;
       printf("operand fill: %s\n", z ? "ZEROS (DVFS check)" : "random");
       for (int var : {20, 21, 22, 341}) bench_gemm("mxfp4 4096^3", 0, 4096, 4096, 4096, var, 50);
     }
     g_zero_fill = 0;
-    for (int var : {20}) {
+    for (int var : std::vector<int>{}) {
       bench_gemm("mxfp4 4096x4096 K=4096", 0, 4096, 4096, 4096, var, 30);
       bench_gemm("mxfp4 4096x4096 K=16384", 0, 4096, 4096, 16384, var, 20);
     }
