@@ -27,7 +27,12 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 
 FP4_DENSE_PEAK_TFLOPS = 10066.0  # 256 CU x 4 SIMD x 2048 MAC/clk x 2 x 2.4 GHz (MI355X_MICROARCH.md: ~10 PF dense)
+# MFMA-only loop (no memory traffic) with RANDOM fp4 operands, measured on this part: the power limit holds the
+# clock near 1.6 GHz (profiles/ubench_r1f_const_vs_random_operands.log).  Informational only.
+FP4_SUSTAINED_RANDOM_TFLOPS = 6550.0
+PMC_TRAFFIC_JSON = os.path.join(ROOT, "profiles", "pmc_bench_r1.json")  # written by tools/pmc_bench.sh on the GPU box
 M = N = K = 4096
+CPU_ROWS = 4096  # cpu_baseline sample: the whole workload (measured 3.2 s per 1024 rows on the 256-thread host)
 
 
 def hadamard(n, device):
@@ -158,15 +163,27 @@ def main():
             "kernel": "gemm_mx_kernel<GemmCfg<256,256,2,4,4>, SCHED_SIMPLE>",
             "kernel_us": round(kernel_ms * 1e3, 3),
             "algorithmic_flop_per_launch": flop_per_step,
+            "algorithmic_bytes_per_launch": M * K // 2 + N * K // 2 + (M + N) * K // 32 + 2 * M * N,
+            "frac_of_sustained_random_operand_mfma_rate": round(achieved / FP4_SUSTAINED_RANDOM_TFLOPS, 4),
         },
     }
+    # HBM-side bytes per launch of this kernel from the PMC passes (rocprofv3 cannot wrap the process from inside;
+    # tools/pmc_bench.sh runs the two --pmc passes over this same command and leaves the corrected sum here)
+    try:
+        with open(PMC_TRAFFIC_JSON) as f:
+            tj = json.load(f)
+        if tj.get("traffic_bytes"):
+            result["roofline"]["traffic"] = tj["traffic_bytes"]
+            result["roofline"]["traffic_source"] = "profiles/pmc_bench_r1.json (FETCH_SIZE x2 + WRITE_SIZE, per launch)"
+    except (OSError, ValueError):
+        pass
 
     if rank == 0:
         if not args.no_cpu_baseline and world == 1:
-            cb, ref = cpu_baseline(a_q, a_s, b_q, b_s, rows=256)
+            cb, ref = cpu_baseline(a_q, a_s, b_q, b_s, rows=CPU_ROWS)
             result["cpu_baseline"] = cb
             # parity of the measured op against the same slab (exact bf16 equality, as the reference asserts)
-            got = out[:256].cpu()
+            got = out[:CPU_ROWS].cpu()
             result["config"]["parity_vs_cpu_oracle_slab"] = bool(torch.equal(got, ref))
         else:
             result["cpu_baseline"] = None

@@ -12,8 +12,9 @@
  *   - return value: 0 = launched; QAMD_ERR_INVALID = argument rejected (nothing launched);
  *     QAMD_ERR_HIP = the HIP runtime refused the launch.  qutlass_amd_last_error() returns a
  *     thread-local message for the last non-zero return.
- *   - no global state besides the two tuning options below; re-entrant; no allocation, no
- *     workspace (the reference cudaMalloc's a CUTLASS workspace per call, gemm.cu:160-162).
+ *   - no global state besides the tuning options below; re-entrant; the library never allocates
+ *     (the reference cudaMalloc's a CUTLASS workspace per call, gemm.cu:160-162); the one op that
+ *     needs scratch (mxf8 NN) takes it from the caller.
  */
 #ifndef QUTLASS_AMD_H_
 #define QUTLASS_AMD_H_
@@ -62,12 +63,18 @@ int qutlass_amd_matmul_mxf8_bf16_tn(const void* A, const void* B, const void* A_
                                     void* stream);
 
 /*
- * MXFP8 NN: A is stored (K, M) row-major (the reference's ColumnMajor A), B (N, K).
+ * MXFP8 NN: A is stored (K, M) row-major (the reference's ColumnMajor A), B (N, K); A_sf is still the
+ * to_blocked layout of the (M, K/32) scale matrix.  K % 32 == 0, M % 16 == 0 (the reference's
+ * AlignmentA = 16 on the contiguous M axis, gemm.cu:400).
+ * workspace: caller-owned device scratch of at least qutlass_amd_mxf8_nn_workspace_bytes(M, K) bytes,
+ * used on `stream` only for the duration of the call's kernels (A is re-laid (M, K) once by a byte
+ * transpose pre-pass, then the TN kernel runs; the library itself never allocates).
  * Replaces matmul_host_mxf8_bf16_nn (gemm.cu:388-434; bindings.cpp:179-216).
  */
+int64_t qutlass_amd_mxf8_nn_workspace_bytes(int64_t M, int64_t K);
 int qutlass_amd_matmul_mxf8_bf16_nn(const void* A, const void* B, const void* A_sf, const void* B_sf,
                                     const float* alpha, void* D, int64_t M, int64_t N, int64_t K,
-                                    void* stream);
+                                    void* workspace, int64_t workspace_bytes, void* stream);
 
 /* ---- fused rotate + quantize ------------------------------------------------------------------ */
 

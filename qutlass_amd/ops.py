@@ -79,8 +79,16 @@ def _gemm(op, fn_name, A, B, A_sf, B_sf, alpha, data_dtype, data_msg, sf_dtype, 
     out = A.new_empty((M, N), dtype=torch.bfloat16)
     lib = _lib.load()
     with torch.cuda.device(A.device):
-        rc = getattr(lib, fn_name)(A.data_ptr(), B.data_ptr(), A_sf.data_ptr(), B_sf.data_ptr(),
-                                   alpha.data_ptr(), out.data_ptr(), M, N, K, _stream(A))
+        if nn:
+            # scratch for the (K, M) -> (M, K) re-layout, from torch's stream-ordered caching allocator
+            ws_bytes = lib.qutlass_amd_mxf8_nn_workspace_bytes(M, K)
+            ws = torch.empty(ws_bytes, dtype=torch.uint8, device=A.device)
+            rc = getattr(lib, fn_name)(A.data_ptr(), B.data_ptr(), A_sf.data_ptr(), B_sf.data_ptr(),
+                                       alpha.data_ptr(), out.data_ptr(), M, N, K, ws.data_ptr(), ws_bytes,
+                                       _stream(A))
+        else:
+            rc = getattr(lib, fn_name)(A.data_ptr(), B.data_ptr(), A_sf.data_ptr(), B_sf.data_ptr(),
+                                       alpha.data_ptr(), out.data_ptr(), M, N, K, _stream(A))
     _lib.check(rc)
     return out
 

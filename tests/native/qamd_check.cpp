@@ -227,6 +227,38 @@ static void check_gemm(const char* tag, int kind, int64_t M, int64_t N, int64_t 
   report(tag, tol_ok ? maxrel <= 1e-2 : bad == 0, buf);
 }
 
+// MXFP8 NN: A handed over as (K, M); must equal the TN kernel on the same operands bit for bit.
+static void check_bench_nn(int64_t M, int64_t N, int64_t K, int iters) {
+  GemmData g = make_gemm(2, M, N, K, 1.0f, 4321, 3);
+  std::vector<uint8_t> At((size_t)K * M);
+  for (int64_t m = 0; m < M; ++m)
+    for (int64_t k = 0; k < K; ++k) At[k * M + m] = g.A[m * K + k];
+  DBuf<uint8_t> dA(g.A.size()), dAt(At.size()), dB(g.B.size()), dSA(g.sfa.size()), dSB(g.sfb.size()), dW((size_t)M * K);
+  DBuf<float> dAl(1);
+  DBuf<uint16_t> dD((size_t)M * N), dD2((size_t)M * N);
+  dA.up(g.A); dAt.up(At); dB.up(g.B); dSA.up(g.sfa); dSB.up(g.sfb);
+  dAl.up({1.0f});
+  HIP_OK(hipMemset(dD.p, 0xff, (size_t)M * N * 2));
+  HIP_OK(hipMemset(dW.p, 0xee, (size_t)M * K));
+  Q_OK(qutlass_amd_matmul_mxf8_bf16_tn(dA.p, dB.p, dSA.p, dSB.p, dAl.p, dD2.p, M, N, K, nullptr));
+  Q_OK(qutlass_amd_matmul_mxf8_bf16_nn(dAt.p, dB.p, dSA.p, dSB.p, dAl.p, dD.p, M, N, K, dW.p, M * K, nullptr));
+  HIP_OK(hipDeviceSynchronize());
+  std::vector<uint16_t> D = dD.down(), D2 = dD2.down();
+  std::vector<uint8_t> W = dW.down();
+  int64_t badw = 0, bad = 0;
+  for (size_t i = 0; i < W.size(); ++i) badw += W[i] != g.A[i];
+  for (size_t i = 0; i < D.size(); ++i) bad += D[i] != D2[i];
+  char buf[200];
+  snprintf(buf, sizeof buf, "M=%lld N=%lld K=%lld transpose-mismatch=%lld out-vs-TN-mismatch=%lld", (long long)M, (long long)N, (long long)K, (long long)badw, (long long)bad);
+  report("gemm_mxfp8 NN == TN", badw == 0 && bad == 0, buf);
+  if (iters > 0) {
+    const double us = time_us([&] { Q_OK(qutlass_amd_matmul_mxf8_bf16_nn(dAt.p, dB.p, dSA.p, dSB.p, dAl.p, dD.p, M, N, K, dW.p, M * K, nullptr)); }, 5, iters);
+    const double ut = time_us([&] { Q_OK(qutlass_amd_matmul_mxf8_bf16_tn(dA.p, dB.p, dSA.p, dSB.p, dAl.p, dD.p, M, N, K, nullptr)); }, 5, iters);
+    printf("BENCH mxfp8 NN (transpose pre-pass + TN)       M=%lld N=%lld K=%lld  %9.2f us  %9.1f TFLOP/s   (TN alone %9.2f us)\n", (long long)M, (long long)N,
+           (long long)K, us, 2.0 * M * N * K / us * 1e-6, ut);
+  }
+}
+
 static int g_zero_fill = 0;
 static void bench_gemm(const char* tag, int kind, int64_t M, int64_t N, int64_t K, int variant, int iters) {
   GemmData g = make_gemm(kind, M, N, K, 1.0f, 77, 3);
@@ -446,6 +478,12 @@ int main(int argc, char** argv) {
   if (want("blocked")) {
     check_blocked(128, 4); check_blocked(256, 16); check_blocked(384, 12); check_blocked(4096, 128);
     check_blocked(130, 5); check_blocked(16, 64); check_blocked(504, 128); check_blocked(8192, 512);
+  }
+  if (want("nn") || want("gemm")) {
+    check_bench_nn(16, 64, 256, 0);
+    check_bench_nn(272, 520, 1056, 0);
+    check_bench_nn(16, 4096, 4096, 20);
+    check_bench_nn(4096, 4096, 4096, 20);
   }
   if (want("gemm")) {
     for (int var : {2, 1, 3, 4, 5, 6, 7, 8, 9, 20, 24, 25, 26}) {

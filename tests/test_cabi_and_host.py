@@ -44,6 +44,14 @@ def test_c_abi_rejects_bad_arguments_without_launching(lib):
     assert g(dummy, dummy, dummy, dummy, dummy, dummy, 128, 130, 128, None) == QAMD_ERR_INVALID
     assert "multiple of 8" in err()
     assert lib.qutlass_amd_matmul_nvf4_bf16_tn(dummy, dummy, dummy, dummy, dummy, dummy, 8, 8, 48, None) == QAMD_ERR_INVALID
+    nn = lib.qutlass_amd_matmul_mxf8_bf16_nn
+    assert lib.qutlass_amd_mxf8_nn_workspace_bytes(4096, 4096) == 4096 * 4096
+    assert nn(dummy, dummy, dummy, dummy, dummy, dummy, 128, 128, 128, None, 0, None) == QAMD_ERR_INVALID
+    assert "null pointer" in err()
+    assert nn(dummy, dummy, dummy, dummy, dummy, dummy, 128, 128, 128, dummy, 100, None) == QAMD_ERR_INVALID
+    assert "workspace too small" in err()
+    assert nn(dummy, dummy, dummy, dummy, dummy, dummy, 24, 128, 128, dummy, 1 << 20, None) == QAMD_ERR_INVALID
+    assert "multiple of 16" in err()
     q = lib.qutlass_amd_fused_quantize_mx
     assert q(dummy, dummy, 48, 4096, 0, dummy, dummy, None, None) == QAMD_ERR_INVALID
     assert "Unsupported rotation size 48" in err()

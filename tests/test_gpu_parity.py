@@ -319,3 +319,34 @@ def test_matmul_mxf8_tn_golden_and_random(q, golden_dir):
                                 to_blocked(torch.from_numpy(bsf).to(DEV).view(torch.float8_e8m0fnu)), torch.tensor([1.0], device=DEV))
     ref = oracle.gemm_blockscaled(oracle.KIND_MXFP8_TN, aq, bq, oracle.to_blocked(asf), oracle.to_blocked(bsf), 1.0, m, n, k)
     assert _mxfp8_close(_np(out), ref).all()
+
+
+@pytest.mark.parametrize("m,n,k", [(16, 4096, 4096), (272, 520, 1056), (4096, 4096, 4096)])
+def test_matmul_mxf8_nn_equals_tn_and_oracle(q, golden_dir, m, n, k):
+    """matmul_mxf8_bf16_nn takes A stored (K, M) (mxfp8_test.py:77-96: a_e4m3.T.contiguous().view((k, m))):
+    the result must be bit-identical to the TN op on the same operands (same kernel after the re-layout)
+    and agree with the oracle's NN path within the fp8 tolerance."""
+    from qutlass_amd.utils import to_blocked
+
+    torch.manual_seed(5)
+    a = torch.randn(m, k, dtype=torch.bfloat16) * 25.0
+    b = torch.randn(n, k, dtype=torch.bfloat16) * 25.0
+    aq, asf = oracle.pseudoquant_mxfp8(_np(a))
+    bq, bsf = oracle.pseudoquant_mxfp8(_np(b))
+    a_t = torch.from_numpy(aq).to(DEV).view(torch.float8_e4m3fn)
+    b_t = torch.from_numpy(bq).to(DEV).view(torch.float8_e4m3fn)
+    sa = to_blocked(torch.from_numpy(asf).to(DEV).view(torch.float8_e8m0fnu))
+    sb = to_blocked(torch.from_numpy(bsf).to(DEV).view(torch.float8_e8m0fnu))
+    alpha = torch.tensor([1.0], device=DEV)
+    a_km = a_t.view(torch.uint8).T.contiguous().view(torch.float8_e4m3fn)
+    assert a_km.shape == (k, m)
+    out_nn = q.matmul_mxf8_bf16_nn(a_km, b_t, sa, sb, alpha)
+    out_tn = q.matmul_mxf8_bf16_tn(a_t, b_t, sa, sb, alpha)
+    assert out_nn.shape == (m, n) and out_nn.dtype == torch.bfloat16
+    assert torch.equal(out_nn.view(torch.int16), out_tn.view(torch.int16))
+    if m * n * k <= 1 << 28:
+        ref = oracle.gemm_blockscaled(oracle.KIND_MXFP8_NN, _np(a_km), bq, oracle.to_blocked(asf), oracle.to_blocked(bsf), 1.0, m, n, k)
+        assert _mxfp8_close(_np(out_nn), ref).all()
+    with pytest.raises(RuntimeError, match="Inner dimensions must match for A.T @ B.T"):
+        q.matmul_mxf8_bf16_nn(a_km, b_t[:, : k - 32].contiguous(), sa, sb, alpha)
+
