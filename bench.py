@@ -160,7 +160,7 @@ def main():
             "unit": "TFLOP/s",
             "frac": round(achieved / FP4_DENSE_PEAK_TFLOPS, 4),
             "traffic": None,
-            "kernel": "gemm_mx_kernel<GemmCfg<256,256,2,4,4>, SCHED_SIMPLE>",
+            "kernel": "gemm_mx_kernel<GemmCfg<256,256,2,2,4>, SCHED_DEEP>",
             "kernel_us": round(kernel_ms * 1e3, 3),
             "algorithmic_flop_per_launch": flop_per_step,
             "algorithmic_bytes_per_launch": M * K // 2 + N * K // 2 + (M + N) * K // 32 + 2 * M * N,

@@ -20,6 +20,7 @@ namespace {
 thread_local char g_err[512] = "";
 std::atomic<int> g_hw_fp4_cvt{1};   // device-verified bit-identical to the software encoder (tests/native/probe.hip P2)
 std::atomic<int> g_gemm_variant{0};
+std::atomic<int> g_nvf4_variant{0};
 std::atomic<int> g_pp_shift{2};
 std::atomic<int> g_pp_flags{1};
 std::atomic<uint32_t*> g_dbg{nullptr};
@@ -50,7 +51,9 @@ int launch_gemm(GemmParams p, hipStream_t s) {
 
 // Tile/schedule variants ("gemm_variant" option; 0 = auto):
 //   1  256x256 ping-pong     5  256x256 lockstep     6..9  queue schedule (256x256, 128x128, 256x128, 128x256)
-//   20 / 24 / 25 / 26  simple schedule (256x256, 128x128, 256x128, 128x256) -- 20 and 24 are what auto picks
+//   20 / 24 / 25 / 26  simple schedule (256x256, 128x128, 256x128, 128x256)
+//   30  deep schedule (fp4, 256x256, 4 waves of 128x128, LDS-DMA)      40  regstage (same tiling, copy through registers)
+//   31..36, 41..43, 50..56  ablations / traces / clock probes of those (bench only)
 //   2  128x128 lockstep (small M or N)                     3  256x128 lockstep    4  128x256 lockstep
 //   100+b / 200+b  ablations of variants 1 / 5 (bench only), b = OR of ABL_* bits
 template <int EBITS, bool SPLIT>
@@ -72,6 +75,24 @@ int dispatch_variant(int v, const GemmParams& p, hipStream_t s, const char* name
       case 7: return launch_gemm<GemmCfg<128, 128, 2, 2, 4, false>, 2>(p, s);
       case 8: return launch_gemm<GemmCfg<256, 128, 4, 2, 4, false>, 2>(p, s);
       case 9: return launch_gemm<GemmCfg<128, 256, 2, 4, 4, false>, 2>(p, s);
+      case 30: return launch_gemm<GemmCfg<256, 256, 2, 2, 4, false>, 4>(p, s);      // deep schedule: 4 waves x 128x128
+      case 31: return launch_gemm<GemmCfg<256, 256, 2, 2, 4, false, 8>, 4>(p, s);   //   no epilogue
+      case 32: return launch_gemm<GemmCfg<256, 256, 2, 2, 4, false, 9>, 4>(p, s);   //   no DMA, no epilogue
+      case 33: return launch_gemm<GemmCfg<256, 256, 2, 2, 4, false, 10>, 4>(p, s);  //   no MFMA, no epilogue
+      case 34: return launch_gemm<GemmCfg<256, 256, 2, 2, 4, false, 40>, 4>(p, s);  //   no reads, no epilogue
+      case 40: return launch_gemm<GemmCfg<256, 256, 2, 2, 4, false>, 5>(p, s);      // regstage schedule: 4 waves x 128x128, copy through registers
+      case 41: return launch_gemm<GemmCfg<256, 256, 2, 2, 4, false, 8>, 5>(p, s);   //   no epilogue
+      case 42: return launch_gemm<GemmCfg<256, 256, 2, 2, 4, false, 9>, 5>(p, s);   //   no copy, no epilogue
+      case 43: return launch_gemm<GemmCfg<256, 256, 2, 2, 4, false, 10>, 5>(p, s);  //   no MFMA, no epilogue
+      case 50: return launch_gemm<GemmCfg<256, 256, 2, 4, 4, false, 64>, 3>(p, s);      // clock probes of 20 / 30 / 40 and their no-epilogue / no-copy ablations
+      case 51: return launch_gemm<GemmCfg<256, 256, 2, 2, 4, false, 64>, 4>(p, s);
+      case 52: return launch_gemm<GemmCfg<256, 256, 2, 2, 4, false, 64>, 5>(p, s);
+      case 53: return launch_gemm<GemmCfg<256, 256, 2, 2, 4, false, 72>, 5>(p, s);
+      case 54: return launch_gemm<GemmCfg<256, 256, 2, 2, 4, false, 73>, 5>(p, s);
+      case 55: return launch_gemm<GemmCfg<256, 256, 2, 2, 4, false, 74>, 5>(p, s);
+      case 56: return launch_gemm<GemmCfg<256, 256, 2, 2, 4, false, 104>, 5>(p, s);
+      case 35: return launch_gemm<GemmCfg<256, 256, 2, 2, 4, false, 16>, 4>(p, s);  //   trace
+      case 36: return launch_gemm<GemmCfg<256, 256, 2, 2, 4, false, 17>, 4>(p, s);  //   trace, no DMA
       case 21: return launch_gemm<GemmCfg<256, 256, 2, 4, 4, false, 8>, 3>(p, s);   //   no epilogue
       case 22: return launch_gemm<GemmCfg<256, 256, 2, 4, 4, false, 9>, 3>(p, s);   //   no DMA, no epilogue
       case 23: return launch_gemm<GemmCfg<256, 256, 2, 4, 4, false, 10>, 3>(p, s);  //   no MFMA, no epilogue
@@ -116,9 +137,10 @@ int gemm_mx(const char* name, const void* A, const void* B, const void* A_sf, co
   hipStream_t s = (hipStream_t)stream;
   int variant = g_gemm_variant.load();
   if (variant == 0) {
-    // auto: simple schedule, 256x256 tiles; 128x128 when one dimension is small (lockstep for M or N <= 64:
-    // measured 13.2 vs 15.7 us at 16x4096x4096)
-    variant = (M <= 64 || N <= 64) ? 2 : (M <= 128 || N <= 128) ? 24 : 20;
+    // auto (measured, profiles/native_r1_schedules.log): fp4 256x256 tiles run the "deep" schedule (4 waves of
+    // 128x128, variant 30), fp8 the "simple" one (variant 20); 128x128 tiles (variant 24) when M or N <= 128, the
+    // 128x128 lockstep kernel (variant 2) when M or N <= 64 (13.2 vs 15.7 us at 16x4096x4096)
+    variant = (M <= 64 || N <= 64) ? 2 : (M <= 128 || N <= 128) ? 24 : (EBITS == 4 ? 30 : 20);
   }
   return dispatch_variant<EBITS, EBITS == 8>(variant, p, s, name);
 }
@@ -205,7 +227,9 @@ int qutlass_amd_matmul_nvf4_bf16_tn(const void* A, const void* B, const void* A_
   const int64_t CB = cdiv(K / 16, 4);
   p.a_bytes = (uint32_t)(M * (K / 2)); p.b_bytes = (uint32_t)(N * (K / 2));
   p.sfa_bytes = (uint32_t)(cdiv(M, 128) * CB * 512); p.sfb_bytes = (uint32_t)(cdiv(N, 128) * CB * 512);
-  return launch_nvf4_gemm(p, (hipStream_t)stream) == hipSuccess ? check_launch(name) : check_launch(name);
+  p.dbg = g_dbg.load();
+  launch_nvf4_gemm(p, (hipStream_t)stream, g_nvf4_variant.load());
+  return check_launch(name);
 }
 
 int qutlass_amd_fused_quantize_mx(const void* x, const void* h, int rot, int64_t numel, int method,
@@ -272,6 +296,7 @@ int qutlass_amd_set_option(const char* key, int value) {
   if (!key) return -1;
   if (!strcmp(key, "hw_fp4_cvt")) return g_hw_fp4_cvt.exchange(value);
   if (!strcmp(key, "gemm_variant")) return g_gemm_variant.exchange(value);
+  if (!strcmp(key, "nvf4_variant")) return g_nvf4_variant.exchange(value);
   if (!strcmp(key, "pp_shift")) return g_pp_shift.exchange(value);
   if (!strcmp(key, "pp_flags")) return g_pp_flags.exchange(value);
   return -1;

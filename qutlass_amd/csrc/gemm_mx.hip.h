@@ -49,7 +49,7 @@ struct GemmParams {
 };
 
 // ablation bits (bench-only instantiations; 0 in the product path)
-enum { ABL_NO_DMA = 1, ABL_NO_MFMA = 2, ABL_NO_STORE = 4, ABL_NO_EPILOGUE = 8, ABL_TRACE = 16, ABL_NO_READS = 32 };
+enum { ABL_NO_DMA = 1, ABL_NO_MFMA = 2, ABL_NO_STORE = 4, ABL_NO_EPILOGUE = 8, ABL_TRACE = 16, ABL_NO_READS = 32, ABL_CLOCK = 64 };
 
 template <int BM_, int BN_, int WAVES_M_, int WAVES_N_, int EBITS_, bool F8SPLIT_ = false, int ABL_ = 0>
 struct GemmCfg {
@@ -739,15 +739,333 @@ __device__ __forceinline__ void gemm_mx_simple(char* smem, const GemmParams& p) 
   cx.epilogue();
 }
 
+// -------------------------------------------------------------------------------------------------
+// Schedule 5 ("deep"): ONE wave per SIMD, 128x128 wave tile (4 waves, MT = NT = 4).
+//
+// Why: LDS feeds ds_read_b128 at ~128 B/clk/CU (measured: fragment reads alone take 1500 cycles per
+// 192 KiB, profiles/native_r1_nvfp4_ablation.log).  With 8 waves of 128x64 every k-slice reads
+// 8 x 6 KiB = 48 KiB for 64 MFMAs; a stage is 192 KiB of reads + 16 KiB of scales + 72 KiB of DMA
+// writes = 2200 LDS-cycles against 2048 MFMA-cycles: the 8-wave schedules are LDS-bandwidth bound.
+// 128x128 wave tiles read 8 KiB per 16 MFMAs (32 KiB per slice per CU, -33 %).
+//
+// One wave per SIMD has no partner to cover its waits, so the wave pipelines itself: four fragment
+// sets (one per k-slice), reads issued two slices ahead, and the stage hand-off (vmcnt + barrier) sits
+// in the MIDDLE of the stage, between M(1) and M(2), when nothing it waits for is younger than a slice:
+//     R(2) ; M(0)
+//     R(3) ; M(1)
+//     wait own DMA(kt+1) [issued one stage ago] + own reads ; BARRIER
+//     scales' ; R'(0) ; M(2) interleaved with the DMA of stage kt+2 (one piece per MFMA)
+//     R'(1) ; M(3)
+// RAW  R'(0) reads stage kt+1 after the barrier every wave reaches after vmcnt(0) for its DMA(kt+1).
+// WAR  DMA(kt+2) overwrites stage kt after the barrier every wave reaches after lgkmcnt(0) for R(3).
+// -------------------------------------------------------------------------------------------------
+template <class C>
+__device__ __forceinline__ void gemm_mx_deep(char* smem, const GemmParams& p) {
+  static_assert(C::EBITS == 4, "deep schedule is written for fp4 (4 k-slices of one 16-byte chunk)");
+  constexpr int MT = C::MT, NT = C::NT;
+  GemmCtx<C> cx(smem, p);
+  v4i fa[4][MT] = {}, fb[4][NT] = {};
+  int sa[2][MT], sb[2][NT];
+
+  auto read_slice = [&](int buf, int j) __attribute__((always_inline)) {
+    if (C::ABL & ABL_NO_READS) {
+#pragma unroll
+      for (int t = 0; t < MT; ++t) asm volatile("" : "+v"(fa[j][t]));
+#pragma unroll
+      for (int t = 0; t < NT; ++t) asm volatile("" : "+v"(fb[j][t]));
+      return;
+    }
+    const char* st = smem + buf * C::STAGE_BYTES;
+#pragma unroll
+    for (int t = 0; t < MT; ++t) fa[j][t] = *(const v4i*)(st + cx.rdA[j] + t * 32 * C::ROWB);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) fb[j][t] = *(const v4i*)(st + cx.rdBd + cx.rdA[j] + t * 32 * C::ROWB);
+  };
+  auto read_scales = [&](int buf, int set) __attribute__((always_inline)) {
+    const char* st = smem + buf * C::STAGE_BYTES;
+#pragma unroll
+    for (int t = 0; t < MT; ++t) sa[set][t] = *(const int*)(st + cx.rdSA[t]);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) sb[set][t] = *(const int*)(st + cx.rdSB[t]);
+  };
+  auto mfma1 = [&](int j, int sset, int m, int n) __attribute__((always_inline)) {
+    if (C::ABL & ABL_NO_MFMA) { asm volatile("" ::"v"(fa[j][m]), "v"(fb[j][n])); return; }
+    const v4i a = fa[j][m], b = fb[j][n];
+    const v8i A8 = {a[0], a[1], a[2], a[3], 0, 0, 0, 0}, B8 = {b[0], b[1], b[2], b[3], 0, 0, 0, 0};
+    if (j == 0) cx.acc[m][n] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(B8, A8, cx.acc[m][n], 4, 4, 0, sb[sset][n], 0, sa[sset][m]);
+    if (j == 1) cx.acc[m][n] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(B8, A8, cx.acc[m][n], 4, 4, 1, sb[sset][n], 1, sa[sset][m]);
+    if (j == 2) cx.acc[m][n] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(B8, A8, cx.acc[m][n], 4, 4, 2, sb[sset][n], 2, sa[sset][m]);
+    if (j == 3) cx.acc[m][n] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(B8, A8, cx.acc[m][n], 4, 4, 3, sb[sset][n], 3, sa[sset][m]);
+  };
+  auto mfma = [&](int j, int sset) __attribute__((always_inline)) {
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int n = 0; n < NT; ++n) mfma1(j, sset, m, n);
+  };
+  auto fence = [&]() __attribute__((always_inline)) { __builtin_amdgcn_sched_barrier(0); };
+  const bool dma_on = !(C::ABL & ABL_NO_DMA);
+  constexpr int NPIECE = C::NA + C::NB;   // + 1 scale instruction
+
+  // M(2) with the DMA of stage kt+2 threaded through it: one 1-KiB piece behind each MFMA
+  auto mfma_dma = [&](int j, int sset, int kt2, int buf2) __attribute__((always_inline)) {
+    char* st = smem + buf2 * C::STAGE_BYTES;
+    const bool valid = kt2 < cx.KT;
+    int idx = 0;
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int n = 0; n < NT; ++n) {
+        mfma1(j, sset, m, n);
+        if (dma_on) {
+          constexpr int PER = (NPIECE + MT * NT - 1) / (MT * NT);
+#pragma unroll
+          for (int e = 0; e < PER; ++e) {
+            const int t = idx * PER + e;
+            if (t < C::NA) cx.issue_pieces_range(C::NA, cx.rA, st, kt2, valid, t, t + 1);
+            else if (t < NPIECE) cx.issue_pieces_range(C::NB, cx.rB, st + C::OFF_B, kt2, valid, t - C::NA, t - C::NA + 1);
+          }
+          if (idx == 0) cx.issue_scales(kt2, st, valid);
+        }
+        fence();
+        ++idx;
+      }
+  };
+
+  auto stage = [&](int kt, auto bufc) __attribute__((always_inline)) {
+    constexpr int BUF = decltype(bufc)::value;
+    read_slice(BUF, 2); fence();
+    mfma(0, BUF); fence();
+    cx.trace();                                                     // t1: R(2) + M(0) issued
+    read_slice(BUF, 3); fence();
+    mfma(1, BUF); fence();
+    cx.trace();                                                     // t2: R(3) + M(1) issued
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    cx.trace();                                                     // t3: own DMA(kt+1) + reads landed
+    __builtin_amdgcn_s_barrier();
+    cx.trace();                                                     // t4: barrier released
+    fence();
+    read_scales(BUF ^ 1, BUF ^ 1);   // (after the last stage these read stale LDS; never used)
+    read_slice(BUF ^ 1, 0); fence();
+    mfma_dma(2, BUF, kt + 2, BUF);
+    cx.trace();                                                     // t5: R'(0) + M(2) + DMA(kt+2) issued
+    read_slice(BUF ^ 1, 1); fence();
+    mfma(3, BUF); fence();
+    cx.trace();                                                     // t6 (= t0 of the next stage): R'(1) + M(3) issued
+  };
+
+  // prologue: stages 0 and 1 in flight; stage 0 landed -> first two slices into registers
+  cx.issue_stage_part(0, 0, 0);
+  cx.issue_stage_part(0, 0, 1);
+  if (dma_on) {
+    cx.issue_stage_part(1, 1, 0, 1 < cx.KT);
+    cx.issue_stage_part(1, 1, 1, 1 < cx.KT);
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPIECE + 1) : "memory");
+  } else {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  __builtin_amdgcn_s_barrier();
+  fence();
+  read_scales(0, 0);
+  read_slice(0, 0);
+  read_slice(0, 1);
+  fence();
+  cx.trace();
+
+  int kt = 0;
+  for (; kt + 1 < cx.KT; kt += 2) {
+    stage(kt, std::integral_constant<int, 0>{});
+    stage(kt + 1, std::integral_constant<int, 1>{});
+  }
+  if (kt < cx.KT) stage(kt, std::integral_constant<int, 0>{});
+  fence();
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // zero-fill DMA of the stages past K must not race the epilogue's LDS staging
+  cx.epilogue();
+  cx.trace_dump();
+}
+
+// -------------------------------------------------------------------------------------------------
+// Schedule 6 ("regstage"): the deep schedule with the HBM/L2 -> LDS copy staged through REGISTERS.
+//
+// A 2-deep LDS ring (2 x 68 KiB of 160) gives LDS-DMA exactly one stage to land, and the DMA of a stage
+// can only be issued once the buffer it overwrites has been read: latency (~1 us) + streaming (68 KiB at
+// the 64 B/clk the TA delivers into LDS) exceed the 2048 MFMA-cycles of a stage, and issuing a stage's 17
+// pieces in one burst stalls the issuing wave -- and with it the wave's MFMAs -- on the full VMEM queue.
+// Registers are the third buffer: every wave owns 16 one-KiB pieces of the tile (8 of A, 8 of B, 16 bytes
+// per lane each) and keeps them in 64 VGPRs as ordinary global loads in flight for a whole stage.  Per
+// stage, spread one piece per four MFMAs:  ds_write_b128 piece i (loaded one stage ago) into the LDS stage
+// it belongs to, then reload register i for one stage later.  The loads need no LDS buffer to be free, so
+// they are never bursty and have a full stage to land; LDS sees 68 KiB of plain writes per stage.
+// Scales skip LDS altogether: the to_blocked line (r%32)*16 holds the scales of rows r, r+32, r+64, r+96,
+// i.e. of the lane's four 32-row fragments -- one 16-byte global load per operand per stage.
+// Arch-VGPR budget (the 256 accumulators live in AGPRs): 2 fragment sets 64 + staging 64 + scales 16.
+//
+//     stage kt, BUF = kt&1      reads threaded in     pieces written            reloaded for
+//       M(0)                    slice 1               4..7   of stage kt+1      stage kt+2
+//       M(1)                    slice 2               8..11  of stage kt+1      stage kt+2
+//       M(2)                    slice 3               12..15 of stage kt+1      stage kt+2
+//       lgkmcnt(0) ; BARRIER        (stage kt+1 complete in LDS[BUF^1]; LDS[BUF] no longer read)
+//       M(3)                    slice 0 of kt+1       0..3   of stage kt+2      stage kt+3
+// -------------------------------------------------------------------------------------------------
+template <class C>
+__device__ __forceinline__ void gemm_mx_regstage(char* smem, const GemmParams& p) {
+  static_assert(C::EBITS == 4 && C::NWAVES == 4 && C::MT == 4 && C::NT == 4 && C::BM == 256 && C::BN == 256,
+                "regstage schedule: fp4, 256x256 tile, 4 waves of 128x128");
+  constexpr int MT = C::MT, NT = C::NT, NA = C::NA, NB = C::NB, NP = NA + NB;
+  static_assert(NP == 16, "one piece per four MFMAs");
+  GemmCtx<C> cx(smem, p);
+  v4i fa[2][MT] = {}, fb[2][NT] = {};   // fragment set j&1
+  v4i sA[2], sB[2];     // scale words of the lane's 4 A / 4 B fragments, per stage parity
+  v4i stg[NP];          // staging registers: pieces 0..NA-1 of A, NA..NP-1 of B
+
+  const int lane = cx.lane, wave = cx.wave;
+  // global side: piece q covers rows 8q..8q+7 of the operand tile; lane -> row 8q + lane/8, 16-byte chunk lane%8
+  const int gl_off = (lane >> 3) * cx.rowbytes + ((lane & 7) << 4);
+  const int tail_bytes = cx.rowbytes - (cx.KT - 1) * C::ROWB;                       // valid bytes of the last stage
+  const int gl_tail = (((lane & 7) << 4) < tail_bytes) ? gl_off : 0x7f000000;       // K tail: chunks past K read 0
+  // LDS side: physical chunk = chunk ^ ((row>>1)&7), row = 8q + lane/8 -> depends on the parity of q only; the wave's
+  // first piece is folded into the per-lane base so every piece is base[parity] + a compile-time offset
+  int wofs[2];
+#pragma unroll
+  for (int par = 0; par < 2; ++par)
+    wofs[par] = wave * (NA * 1024) + (lane >> 3) * C::ROWB + ((((lane & 7) ^ ((4 * par + (lane >> 4)) & 7))) << 4);
+  // scales: 16-byte line of (row tile, column tile kt*2 + g), lane row i32
+  const __amdgpu_buffer_rsrc_t rSA = make_rsrc(p.SFA, p.sfa_bytes), rSB = make_rsrc(p.SFB, p.sfb_bytes);
+  const int sA_off = ((cx.m0 >> 7) + cx.wave_m) * cx.CB * 512 + cx.g * 512 + cx.i32 * 16;   // lane half g owns column tile g of the stage
+  const int sB_off = ((cx.n0 >> 7) + cx.wave_n) * cx.CB * 512 + cx.g * 512 + cx.i32 * 16;
+
+  auto load_piece = [&](int i, int kt) __attribute__((always_inline)) {
+    const bool isB = i >= NA;
+    const int t = isB ? i - NA : i;
+    const int q = wave * NA + t;          // NA == NB
+    int v = ((kt == cx.KT - 1) ? gl_tail : gl_off) + ((kt < cx.KT) ? 0 : 0x7f000000);
+    asm volatile("" : "+v"(v));                                      // keep the K loop one basic block
+    stg[i] = __builtin_amdgcn_raw_buffer_load_b128(isB ? cx.rB : cx.rA, v + q * cx.rstep, kt * C::ROWB, 0);
+  };
+  auto write_piece = [&](int i, int buf) __attribute__((always_inline)) {
+    const bool isB = i >= NA;
+    const int t = isB ? i - NA : i;       // parity of q = wave*NA + t is the parity of t (NA even)
+    char* dst = smem + ((t & 1) ? wofs[1] : wofs[0]) + (buf * C::STAGE_BYTES + (isB ? C::OFF_B : 0) + t * 1024);
+    *(v4i*)dst = stg[i];
+  };
+  auto load_scales = [&](int kt, int set) __attribute__((always_inline)) {
+    int oob = (kt * C::SCT + cx.g < cx.CB) ? 0 : 0x7f000000;        // K tail / stages past K: no such column tile -> 0
+    asm volatile("" : "+v"(oob));
+    sA[set] = __builtin_amdgcn_raw_buffer_load_b128(rSA, sA_off + oob, kt * C::SCT * 512, 0);   // soffset must be wave-uniform
+    sB[set] = __builtin_amdgcn_raw_buffer_load_b128(rSB, sB_off + oob, kt * C::SCT * 512, 0);
+  };
+  auto read_slice = [&](int buf, int j) __attribute__((always_inline)) {
+    const char* st = smem + buf * C::STAGE_BYTES;
+#pragma unroll
+    for (int t = 0; t < MT; ++t) fa[j & 1][t] = *(const v4i*)(st + cx.rdA[j] + t * 32 * C::ROWB);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) fb[j & 1][t] = *(const v4i*)(st + cx.rdBd + cx.rdA[j] + t * 32 * C::ROWB);
+  };
+  auto mfma1 = [&](int j, int sset, int m, int n) __attribute__((always_inline)) {
+    if (C::ABL & ABL_NO_MFMA) { asm volatile("" ::"v"(fa[j & 1][m]), "v"(fb[j & 1][n])); return; }
+    const v4i a = fa[j & 1][m], b = fb[j & 1][n];
+    const v8i A8 = {a[0], a[1], a[2], a[3], 0, 0, 0, 0}, B8 = {b[0], b[1], b[2], b[3], 0, 0, 0, 0};
+    const int sa = sA[sset][m], sb = sB[sset][n];
+    if (j == 0) cx.acc[m][n] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(B8, A8, cx.acc[m][n], 4, 4, 0, sb, 0, sa);
+    if (j == 1) cx.acc[m][n] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(B8, A8, cx.acc[m][n], 4, 4, 1, sb, 1, sa);
+    if (j == 2) cx.acc[m][n] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(B8, A8, cx.acc[m][n], 4, 4, 2, sb, 2, sa);
+    if (j == 3) cx.acc[m][n] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(B8, A8, cx.acc[m][n], 4, 4, 3, sb, 3, sa);
+  };
+  auto fence = [&]() __attribute__((always_inline)) { __builtin_amdgcn_sched_barrier(0); };
+  const bool copy_on = !(C::ABL & ABL_NO_DMA);
+
+  // One fragment read of slice j (set j&1): e = 0 -> B[0], 1 -> A[0], 2..4 -> B[1..3], 5..7 -> A[1..3]
+  // (the order the m-major MFMA loop consumes them in).
+  auto read_one = [&](int buf, int j, int e) __attribute__((always_inline)) {
+    const char* st = smem + buf * C::STAGE_BYTES;
+    const bool isA = (e == 1) || (e >= 5);
+    const int t = (e == 0) ? 0 : (e == 1) ? 0 : (e <= 4) ? e - 1 : e - 4;
+    if (isA) fa[j & 1][t] = *(const v4i*)(st + cx.rdA[j] + t * 32 * C::ROWB);
+    else fb[j & 1][t] = *(const v4i*)(st + cx.rdBd + cx.rdA[j] + t * 32 * C::ROWB);
+  };
+  // 16 MFMAs of slice j with ONE other instruction in the shadow of each (a wave can queue only ~1 MFMA ahead,
+  // so anything that does not hide behind the 32 cycles of the MFMA in front of it is lost matrix time):
+  //   k = 0..7    fragment read e = k of slice rj in LDS[rbuf]      (next slice; complete long before k = 15)
+  //   k = 8..11   ds_write_b128 of piece i0 + k-8 into LDS[wbuf]    (loaded one stage ago)
+  //   k = 12..15  reload of that register for stage lkt
+  auto slice = [&](int j, int sset, int rbuf, int rj, int i0, int wbuf, int lkt) __attribute__((always_inline)) {
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int n = 0; n < NT; ++n) {
+        const int k = m * NT + n;
+        mfma1(j, sset, m, n);
+        if (k < 8) {
+          if (!(C::ABL & ABL_NO_READS)) read_one(rbuf, rj, k);
+        } else if (copy_on) {
+          if (k < 12) write_piece(i0 + k - 8, wbuf);
+          else load_piece(i0 + k - 12, lkt);
+        }
+        fence();
+      }
+  };
+
+  auto stage = [&](int kt, auto bufc) __attribute__((always_inline)) {
+    constexpr int BUF = decltype(bufc)::value;
+    slice(0, BUF, BUF, 1, 4, BUF ^ 1, kt + 2);
+    slice(1, BUF, BUF, 2, 8, BUF ^ 1, kt + 2);
+    slice(2, BUF, BUF, 3, 12, BUF ^ 1, kt + 2);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    fence();
+    slice(3, BUF, BUF ^ 1, 0, 0, BUF, kt + 3);
+    load_scales(kt + 2, BUF);      // set BUF is free once M(3) of this stage has been issued
+    fence();
+  };
+
+  // ---- prologue: stage 0 by LDS-DMA (no registers), stage 1 into the staging registers in parallel ----------
+  cx.issue_pieces(NA, cx.rA, smem, 0, true);
+  cx.issue_pieces(NB, cx.rB, smem + C::OFF_B, 0, true);
+  load_scales(0, 0);
+  load_scales(1, 1);
+#pragma unroll
+  for (int i = 0; i < NP; ++i) load_piece(i, 1);
+  fence();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {     // pieces 0..3 of stage 1 -> LDS[1]; their registers go on to stage 2
+    write_piece(i, 1);
+    load_piece(i, 2);
+  }
+  asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");   // the DMA of stage 0 is older than everything still in flight (4 reloads)
+  __builtin_amdgcn_s_barrier();
+  fence();
+  read_slice(0, 0);
+  fence();
+
+  int kt = 0;
+  for (; kt + 1 < cx.KT; kt += 2) {
+    stage(kt, std::integral_constant<int, 0>{});
+    stage(kt + 1, std::integral_constant<int, 1>{});
+  }
+  if (kt < cx.KT) stage(kt, std::integral_constant<int, 0>{});
+  fence();
+  cx.epilogue();
+}
+
 // One __global__ entry per (config, schedule).
-enum { SCHED_LOCKSTEP = 0, SCHED_PINGPONG = 1, SCHED_QUEUE = 2, SCHED_SIMPLE = 3 };
+enum { SCHED_LOCKSTEP = 0, SCHED_PINGPONG = 1, SCHED_QUEUE = 2, SCHED_SIMPLE = 3, SCHED_DEEP = 4, SCHED_REGSTAGE = 5 };
 template <class C, int SCHED>
 __global__ __launch_bounds__(C::THREADS) void gemm_mx_kernel(const GemmParams p) {
   __shared__ __attribute__((aligned(16))) char smem[C::LDS_BYTES];
-  if constexpr (SCHED == SCHED_SIMPLE) gemm_mx_simple<C>(smem, p);
+  // ABL_CLOCK builds only (qutlass_amd_debug_set_trace_buffer): workgroup 0 reports its shader-cycle and
+  // 100 MHz wall-clock duration, i.e. the clock the chip actually ran at under this kernel's power draw
+  const bool clk = (C::ABL & ABL_CLOCK) && p.dbg && blockIdx.x == 0 && threadIdx.x == 0;
+  const uint64_t c0 = clk ? __builtin_readcyclecounter() : 0, r0 = clk ? __builtin_amdgcn_s_memrealtime() : 0;
+  if constexpr (SCHED == SCHED_REGSTAGE) gemm_mx_regstage<C>(smem, p);
+  else if constexpr (SCHED == SCHED_DEEP) gemm_mx_deep<C>(smem, p);
+  else if constexpr (SCHED == SCHED_SIMPLE) gemm_mx_simple<C>(smem, p);
   else if constexpr (SCHED == SCHED_QUEUE) gemm_mx_queue<C>(smem, p);
   else if constexpr (SCHED == SCHED_PINGPONG) gemm_mx_pingpong<C>(smem, p);
   else gemm_mx_lockstep<C>(smem, p);
+  if (clk) {
+    p.dbg[0] = (uint32_t)(__builtin_readcyclecounter() - c0);
+    p.dbg[1] = (uint32_t)(__builtin_amdgcn_s_memrealtime() - r0);
+  }
 }
 
 }  // namespace qamd

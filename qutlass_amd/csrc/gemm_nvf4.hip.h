@@ -27,6 +27,7 @@ struct NvGemmParams {
   int M, N, K;
   int tiles_m, tiles_n;
   uint32_t a_bytes, b_bytes, sfa_bytes, sfb_bytes;
+  uint32_t* dbg;   // bench only: block 0 writes {shader cycles, 100 MHz ticks} of its K loop
 };
 
 template <int BM_, int BN_, int WAVES_M_, int WAVES_N_>
@@ -265,17 +266,265 @@ __global__ __launch_bounds__(C::THREADS) void gemm_nvf4_kernel(const NvGemmParam
   }
 }
 
-inline hipError_t launch_nvf4_gemm(NvGemmParams p, hipStream_t s) {
-  if (p.M <= 128 || p.N <= 128) {
-    using C = NvCfg<128, 128, 2, 2>;
+// ================================================================================================
+// v2: dequantise ONCE per workgroup into f16 LDS tiles.
+//
+// The kernel above converts every fragment in the wave that consumes it, so an A chunk is converted by
+// all WAVES_N waves of its row block and a B chunk by all WAVES_M: 3x redundant VALU work, ~900 VALU
+// instructions per 128 MFMAs per wave -- the VALU and the matrix pipe are both saturated
+// (tests/native/ubench.hip "valu": cvt and pk_mul issue at full rate, 2 waves x (8 MFMA + 64 VALU) take
+// 1.3x the MFMA-only time).  Here each thread owns ONE operand row of the tile: per 64-element K stage it
+// loads the row's 32 packed bytes + its 4 e4m3 scales from global memory (two stages ahead, into
+// registers), converts them once (32 cvt + 32 pk_mul), and writes 128 bytes of f16 into the LDS stage
+// with the same chunk ^ ((row>>1)&7) swizzle the MX kernels use.  The MFMA side is then the plain f16
+// kernel: per K=16 step 6 ds_read_b128 feed 8 v_mfma_f32_32x32x16_f16 -- the same LDS bytes per MFMA cycle
+// as the FP4 kernel.  One barrier per stage; no LDS-DMA (the packed source is 16 KiB per stage).
+// ================================================================================================
+template <int BM_, int BN_, int WAVES_M_, int WAVES_N_, int ABL_ = 0>
+struct NvLdsCfg {
+  static constexpr int BM = BM_, BN = BN_, WAVES_M = WAVES_M_, WAVES_N = WAVES_N_;
+  static constexpr int ABL = ABL_;       // bench-only ablations: 1 no convert/ds_write, 2 no fragment reads, 4 no MFMA, 8 no barrier
+  static constexpr int NWAVES = WAVES_M * WAVES_N, THREADS = NWAVES * 64;
+  static constexpr int WTM = BM / WAVES_M, WTN = BN / WAVES_N, MT = WTM / 32, NT = WTN / 32;
+  static constexpr int KS = 64;          // K elements per stage = one scale column tile (4 groups of 16)
+  static constexpr int ROWB = 128;       // f16 bytes per row per stage
+  static constexpr int A_BYTES = BM * ROWB, B_BYTES = BN * ROWB, OFF_B = A_BYTES;
+  static constexpr int STAGE_BYTES = A_BYTES + B_BYTES;
+  static constexpr int SROW = BN * 2;
+  static constexpr int LDS_BYTES = (2 * STAGE_BYTES > BM * SROW) ? 2 * STAGE_BYTES : BM * SROW;
+  static_assert(BM + BN == THREADS, "one operand row per thread");
+  static_assert(BM % 64 == 0, "A/B producer split must be wave-uniform");
+};
+
+struct NvPacked {   // one row-stage in flight: 64 e2m1 + 4 e4m3
+  v4i d0, d1;
+  uint32_t s;
+};
+
+template <class C>
+__global__ __launch_bounds__(C::THREADS) void gemm_nvf4_lds_kernel(const NvGemmParams p) {
+  constexpr int BM = C::BM, BN = C::BN, MT = C::MT, NT = C::NT;
+  __shared__ __attribute__((aligned(16))) char smem[C::LDS_BYTES];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = uniform(tid >> 6);
+  const int wave_m = wave / C::WAVES_N, wave_n = wave % C::WAVES_N;
+  const int i32 = lane & 31, g = lane >> 5;
+
+  int tile_m, tile_n;
+  {
+    const int nb = p.tiles_m * p.tiles_n;
+    const int b2 = xcd_remap(blockIdx.x, nb);
+    constexpr int GM = 4;
+    const int group = GM * p.tiles_n;
+    const int gid = b2 / group;
+    const int first_m = gid * GM;
+    const int gsz = min(p.tiles_m - first_m, GM);
+    tile_m = first_m + (b2 % group) % gsz;
+    tile_n = (b2 % group) / gsz;
+  }
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int rowbytes = p.K >> 1;
+  const int KT = (p.K + C::KS - 1) / C::KS;   // == number of scale column tiles
+  const int CB = KT;
+
+  // ---- producer role: thread -> one operand row of the tile (waves 0..BM/64-1: A, the rest: B) -------
+  const bool prodB = wave >= BM / 64;
+  const int prow = prodB ? tid - BM : tid;
+  const uint32_t base_off = prodB ? (uint32_t)n0 * rowbytes : (uint32_t)m0 * rowbytes;
+  const uint32_t tot_bytes = prodB ? p.b_bytes : p.a_bytes;
+  const __amdgpu_buffer_rsrc_t rD = make_rsrc((prodB ? p.B : p.A) + base_off, tot_bytes - base_off);
+  const __amdgpu_buffer_rsrc_t rS = make_rsrc(prodB ? p.SFB : p.SFA, prodB ? p.sfb_bytes : p.sfa_bytes);
+  const int voffD = prow * rowbytes;                       // rows past M / N fall off the descriptor -> 0
+  const int grow = (prodB ? n0 : m0) + prow;               // scale row in the padded blocked matrix
+  const int voffS = (grow >> 7) * CB * 512 + (grow & 31) * 16 + ((grow & 127) >> 5) * 4;
+  const int wrow = (prodB ? C::OFF_B : 0) + prow * C::ROWB;   // LDS row base of this thread's row
+  const int wsw = (prow >> 1) & 7;
+  constexpr int OOB = 0x7fffffff;
+
+  auto load_stage = [&](int kt, NvPacked& P) __attribute__((always_inline)) {
+    const int soff = kt * 32;
+    int v0 = (soff < rowbytes) ? voffD : OOB;
+    int v1 = (soff + 16 < rowbytes) ? voffD + 16 : OOB;
+    int vs = (kt < KT) ? voffS : OOB;
+    asm volatile("" : "+v"(v0), "+v"(v1), "+v"(vs));       // keep the loop branch-free (see gemm_mx.hip.h)
+    P.d0 = __builtin_amdgcn_raw_buffer_load_b128(rD, v0, soff, 0);
+    P.d1 = __builtin_amdgcn_raw_buffer_load_b128(rD, v1, soff, 0);
+    P.s = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rS, vs, kt * 512, 0);
+  };
+  // convert dwords [u0, u1) of the row-stage and store them as f16 chunks of LDS stage `buf`
+  auto convert_part = [&](const NvPacked& P, int kt, int buf, const int u0, const int u1) __attribute__((always_inline)) {
+    // scale bytes of groups past K (K % 64 == 32 tail) are layout padding: force them to 0
+    const int valid = p.K / 16 - 4 * kt;                   // wave-uniform
+    const uint32_t smask = valid >= 4 ? 0xffffffffu : (valid <= 0 ? 0u : ((1u << (8 * valid)) - 1u));
+    h2_t s01, s23;
+    e4m3x4_to_f16(P.s & smask, s01, s23);
+    char* st = smem + buf * C::STAGE_BYTES + wrow;
+#pragma unroll
+    for (int u = u0; u < u1; ++u) {
+      const uint32_t w = (uint32_t)(u < 4 ? P.d0[u & 3] : P.d1[u & 3]);
+      const int grp = u >> 1;
+      const _Float16 s = grp == 0 ? s01[0] : grp == 1 ? s01[1] : grp == 2 ? s23[0] : s23[1];
+      const h8_t f = dq8(w, h2_t{s, s});
+      *(h8_t*)(st + ((u ^ wsw) << 4)) = f;
+    }
+  };
+
+  // ---- consumer role: fragment addresses (chunk 2s+g of K-step s) ---------------------------------
+  const int sw = (i32 >> 1) & 7;
+  int rdA[4], rdB[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    const int c = 2 * s + g;
+    rdA[s] = (wave_m * C::WTM + i32) * C::ROWB + ((c ^ sw) << 4);
+    rdB[s] = C::OFF_B + (wave_n * C::WTN + i32) * C::ROWB + ((c ^ sw) << 4);
+  }
+
+  v16f acc[MT][NT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+
+  auto read_frags = [&](int buf, int s, h8_t (&fa)[MT], h8_t (&fb)[NT]) __attribute__((always_inline)) {
+    const char* st = smem + buf * C::STAGE_BYTES;
+#pragma unroll
+    for (int t = 0; t < MT; ++t) fa[t] = *(const h8_t*)(st + rdA[s] + t * 32 * C::ROWB);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) fb[t] = *(const h8_t*)(st + rdB[s] + t * 32 * C::ROWB);
+  };
+  auto mfma_step = [&](const h8_t (&fa)[MT], const h8_t (&fb)[NT]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int n = 0; n < NT; ++n)
+        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb[n], fa[m], acc[m][n], 0, 0, 0);
+  };
+
+  // stage kt: MFMAs on LDS[kt&1]; the row-stage kt+1 (in Pn) is converted into LDS[(kt+1)&1] in four
+  // parts between the K-steps; then Pn is refilled with stage kt+3.
+  auto stage = [&](int kt, NvPacked& Pn) __attribute__((always_inline)) {
+    const int buf = kt & 1, nxt = buf ^ 1;
+    h8_t fa[2][MT], fb[2][NT];
+    if (C::ABL & 2) {
+#pragma unroll
+      for (int t = 0; t < MT; ++t) fa[0][t] = fa[1][t] = h8_t{(_Float16)1, (_Float16)2, (_Float16)0, (_Float16)1, (_Float16)3, (_Float16)1, (_Float16)2, (_Float16)1};
+#pragma unroll
+      for (int t = 0; t < NT; ++t) fb[0][t] = fb[1][t] = h8_t{(_Float16)1, (_Float16)1, (_Float16)2, (_Float16)1, (_Float16)0, (_Float16)1, (_Float16)2, (_Float16)3};
+    } else
+    read_frags(buf, 0, fa[0], fb[0]);
+    asm volatile("s_waitcnt vmcnt(3)" ::: "memory");       // Pn landed (the 3 loads of stage kt+2 may still fly)
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      if (s < 3 && !(C::ABL & 2)) read_frags(buf, s + 1, fa[(s + 1) & 1], fb[(s + 1) & 1]);
+      if (!(C::ABL & 1)) convert_part(Pn, kt + 1, nxt, 2 * s, 2 * s + 2);
+      else if (s == 0) asm volatile("" ::"v"(Pn.d0), "v"(Pn.d1), "v"(Pn.s));
+      if (!(C::ABL & 4)) mfma_step(fa[s & 1], fb[s & 1]);
+      else {
+#pragma unroll
+        for (int t = 0; t < MT; ++t) asm volatile("" ::"v"(fa[s & 1][t]));
+#pragma unroll
+        for (int t = 0; t < NT; ++t) asm volatile("" ::"v"(fb[s & 1][t]));
+      }
+    }
+    load_stage(kt + 3, Pn);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (!(C::ABL & 8)) __syncthreads();
+  };
+
+  NvPacked P0, P1;
+  load_stage(0, P0);
+  load_stage(1, P1);
+  asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+  convert_part(P0, 0, 0, 0, 8);
+  load_stage(2, P0);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __syncthreads();
+  // invariant at stage kt: LDS[kt&1] holds stage kt; stage kt+1 is in P[(kt+1)&1], stage kt+2 in P[kt&1]
+  const uint64_t dbg_c0 = p.dbg ? __builtin_readcyclecounter() : 0, dbg_r0 = p.dbg ? __builtin_amdgcn_s_memrealtime() : 0;
+  int kt = 0;
+  for (; kt + 1 < KT; kt += 2) {
+    stage(kt, P1);
+    stage(kt + 1, P0);
+  }
+  if (kt < KT) stage(kt, P1);
+  if (p.dbg && blockIdx.x == 0 && tid == 0) {
+    p.dbg[0] = (uint32_t)(__builtin_readcyclecounter() - dbg_c0);
+    p.dbg[1] = (uint32_t)(__builtin_amdgcn_s_memrealtime() - dbg_r0);
+    p.dbg[2] = (uint32_t)KT;
+  }
+
+  const float alpha = *p.alpha;
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int row = wave_m * C::WTM + 32 * m + i32;
+        const int cg = (wave_n * C::WTN + 32 * n + 8 * q + 4 * g) >> 2;
+        v2i w;
+        w[0] = pack_bf16x2(acc[m][n][4 * q + 0] * alpha, acc[m][n][4 * q + 1] * alpha);
+        w[1] = pack_bf16x2(acc[m][n][4 * q + 2] * alpha, acc[m][n][4 * q + 3] * alpha);
+        *(v2i*)(smem + row * C::SROW + ((cg ^ (row & 15)) << 3)) = w;
+      }
+  __syncthreads();
+  constexpr int CPR = BN / 8;
+  constexpr int RPP = C::THREADS / CPR;
+  const int chunk = tid % CPR, r0 = tid / CPR;
+  const int gcol = n0 + chunk * 8;
+#pragma unroll 4
+  for (int pss = 0; pss < BM / RPP; ++pss) {
+    const int row = pss * RPP + r0;
+    const int grow2 = m0 + row;
+    if (grow2 < p.M && gcol < p.N) {
+      v4i v = *(const v4i*)(smem + row * C::SROW + ((((2 * chunk) ^ (row & 15)) & ~1) << 3));
+      if (row & 1) v = v4i{v[2], v[3], v[0], v[1]};
+      *(v4i*)(p.D + (size_t)grow2 * p.N + gcol) = v;
+    }
+  }
+}
+
+// variant: 0 = auto (v2), 1 = v1 (per-wave dequant), 2 = v2
+inline hipError_t launch_nvf4_gemm(NvGemmParams p, hipStream_t s, int variant = 0) {
+  const bool small = p.M <= 128 || p.N <= 128;
+  if (variant == 1) {
+    if (small) {
+      using C = NvCfg<128, 128, 2, 2>;
+      p.tiles_m = (p.M + C::BM - 1) / C::BM;
+      p.tiles_n = (p.N + C::BN - 1) / C::BN;
+      hipLaunchKernelGGL((gemm_nvf4_kernel<C>), dim3(p.tiles_m * p.tiles_n), dim3(C::THREADS), 0, s, p);
+    } else {
+      using C = NvCfg<256, 256, 2, 4>;
+      p.tiles_m = (p.M + C::BM - 1) / C::BM;
+      p.tiles_n = (p.N + C::BN - 1) / C::BN;
+      hipLaunchKernelGGL((gemm_nvf4_kernel<C>), dim3(p.tiles_m * p.tiles_n), dim3(C::THREADS), 0, s, p);
+    }
+    return hipSuccess;
+  }
+#define QAMD_NV_ABL(b)                                                                                          \
+  if (variant == 10 + b) {                                                                                     \
+    using C = NvLdsCfg<256, 256, 2, 4, b>;                                                                     \
+    p.tiles_m = (p.M + C::BM - 1) / C::BM;                                                                     \
+    p.tiles_n = (p.N + C::BN - 1) / C::BN;                                                                     \
+    hipLaunchKernelGGL((gemm_nvf4_lds_kernel<C>), dim3(p.tiles_m * p.tiles_n), dim3(C::THREADS), 0, s, p);     \
+    return hipSuccess;                                                                                         \
+  }
+  QAMD_NV_ABL(1) QAMD_NV_ABL(2) QAMD_NV_ABL(3) QAMD_NV_ABL(4) QAMD_NV_ABL(5) QAMD_NV_ABL(6) QAMD_NV_ABL(8) QAMD_NV_ABL(9) QAMD_NV_ABL(11)
+#undef QAMD_NV_ABL
+  if (small) {
+    using C = NvLdsCfg<128, 128, 2, 2>;
     p.tiles_m = (p.M + C::BM - 1) / C::BM;
     p.tiles_n = (p.N + C::BN - 1) / C::BN;
-    hipLaunchKernelGGL((gemm_nvf4_kernel<C>), dim3(p.tiles_m * p.tiles_n), dim3(C::THREADS), 0, s, p);
+    hipLaunchKernelGGL((gemm_nvf4_lds_kernel<C>), dim3(p.tiles_m * p.tiles_n), dim3(C::THREADS), 0, s, p);
   } else {
-    using C = NvCfg<256, 256, 2, 4>;
+    using C = NvLdsCfg<256, 256, 2, 4>;
     p.tiles_m = (p.M + C::BM - 1) / C::BM;
     p.tiles_n = (p.N + C::BN - 1) / C::BN;
-    hipLaunchKernelGGL((gemm_nvf4_kernel<C>), dim3(p.tiles_m * p.tiles_n), dim3(C::THREADS), 0, s, p);
+    hipLaunchKernelGGL((gemm_nvf4_lds_kernel<C>), dim3(p.tiles_m * p.tiles_n), dim3(C::THREADS), 0, s, p);
   }
   return hipSuccess;
 }

@@ -421,6 +421,7 @@ static void bench_blocked(int64_t rows, int64_t cols) {
 
 extern void run_probe();   // probe.hip
 extern void run_ubench();  // ubench.hip
+extern void run_valu_rates();  // ubench.hip
 extern "C" void qutlass_amd_debug_set_trace_buffer(void*);
 
 // Per-wave block timeline of workgroup 0 of the ping-pong kernel (ABL_TRACE builds, variants 116..118).
@@ -443,11 +444,14 @@ static void trace_gemm(int variant, int flags) {
   qutlass_amd_debug_set_trace_buffer(nullptr);
   auto t = dT.down();
   // slots: 0 loop entry; per stage 8: [endL0, afterBar, endM0, afterBar, endL1, afterBar, endM1, afterBar]; last 2: epilogue begin/end
-  const bool queue = variant >= 300;
+  const bool queue = variant >= 300 || variant == 35 || variant == 36;
   const int per = queue ? 6 : 8;
   printf("TRACE variant=%d flags=%d (cycles per wave, stages 3..8; %s)\n", variant, flags,
          queue ? "queue: M0+R1 | DMA half2 | M1..M3+reads | wait own DMA | barrier | R0'+DMA half1" : "pingpong: L0 bar M0 bar L1 bar M1 bar");
+  const bool deep = variant == 35 || variant == 36;
+  if (deep) printf("TRACE deep: R(2)+M(0) | R(3)+M(1) | wait own DMA+reads | barrier | R'(0)+M(2)+DMA | R'(1)+M(3)\n");
   for (int w : {0, 4, 1, 5, 3, 7}) {
+    if (deep && w >= 4) continue;
     const uint32_t* r = &t[w * 96];
     printf("TRACE w%d stage-len", w);
     for (int st = 3; st < 9; ++st) printf(" %u", r[(st + 1) * per] - r[st * per]);
@@ -473,11 +477,69 @@ int main(int argc, char** argv) {
          qutlass_amd_version());
 
   if (argc > 1 && want("ubench")) run_ubench();
+  if (argc > 1 && want("valu")) run_valu_rates();
   if (want("probe")) run_probe();
 
   if (want("blocked")) {
     check_blocked(128, 4); check_blocked(256, 16); check_blocked(384, 12); check_blocked(4096, 128);
     check_blocked(130, 5); check_blocked(16, 64); check_blocked(504, 128); check_blocked(8192, 512);
+  }
+  if (want("deep")) {
+    for (int var : {30, 40}) {
+      check_gemm("gemm_mxfp4 128^3 (deep)", 0, 128, 128, 128, 1.0f, 3, 0, var);
+      check_gemm("gemm_mxfp4 ragged + K tail (deep)", 0, 72, 136, 640, 0.5f, 3, 0, var);
+      check_gemm("gemm_mxfp4 300x520x1152 (deep)", 0, 300, 520, 1152, 1.0f, 3, 0, var);
+      check_gemm("gemm_mxfp4 504x504x2048 (deep)", 0, 504, 504, 2048, 1.0f, 3, 0, var);
+      check_gemm("gemm_mxfp4 4096^3 (32 rows, deep)", 0, 4096, 4096, 4096, 1.0f, 3, 32, var);
+    }
+    for (int rep = 0; rep < 2; ++rep)
+      for (int var : {20, 30, 40}) {
+        bench_gemm("mxfp4 4096^3", 0, 4096, 4096, 4096, var, 30);
+        bench_gemm("mxfp4 C3", 0, 4096, 14336, 4096, var, 10);
+        bench_gemm("mxfp4 8192^3", 0, 8192, 8192, 8192, var, 5);
+      }
+    for (int var : {50, 51, 52, 53, 54, 55, 56}) {   // 50/51/52 = simple/deep/regstage; 53..56 = regstage -epilogue, -epilogue-copy, -epilogue-mfma, -epilogue-reads
+      DBuf<uint32_t> dT(16);
+      HIP_OK(hipMemset(dT.p, 0, 64));
+      qutlass_amd_debug_set_trace_buffer(dT.p);
+      bench_gemm("mxfp4 4096^3 (+clock probe)", 0, 4096, 4096, 4096, var, 20);
+      qutlass_amd_debug_set_trace_buffer(nullptr);
+      std::vector<uint32_t> t = dT.down();
+      printf("      workgroup 0: %u shader cycles in %.2f us -> clock %.2f GHz\n", t[0], t[1] * 0.01, t[0] / (t[1] * 10.0));
+    }
+  }
+  if (want("nv")) {
+    for (int nv : {2, 1}) {
+      qutlass_amd_set_option("nvf4_variant", nv);
+      printf("nvf4_variant=%d (1 = per-wave dequant, 2 = dequantise once into f16 LDS tiles)\n", nv);
+      check_gemm("gemm_nvfp4 128^3", 1, 128, 128, 128, 1.0f, 3, 0, 0);
+      check_gemm("gemm_nvfp4 16x64x32", 1, 16, 64, 32, 1.0f, 3, 0, 0);
+      check_gemm("gemm_nvfp4 ragged + K tail (K%64=32)", 1, 72, 136, 352, 0.5f, 3, 0, 0);
+      check_gemm("gemm_nvfp4 ragged 300x264x320", 1, 300, 264, 320, 1.0f, 3, 0, 0);
+      check_gemm("gemm_nvfp4 504x512x2048", 1, 504, 512, 2048, 1.0f, 3, 0, 0);
+      check_gemm("gemm_nvfp4 2048^3 (32 rows)", 1, 2048, 2048, 2048, 1.0f, 3, 32, 0);
+      bench_gemm("nvfp4 16x4096x4096", 1, 16, 4096, 4096, 0, 20);
+      bench_gemm("nvfp4 4096^3", 1, 4096, 4096, 4096, 0, 10);
+      bench_gemm("nvfp4 8192^3", 1, 8192, 8192, 8192, 0, 3);
+      g_zero_fill = 1;
+      bench_gemm("nvfp4 4096^3 ZERO-filled operands", 1, 4096, 4096, 4096, 0, 10);
+      bench_gemm("nvfp4 8192^3 ZERO-filled operands", 1, 8192, 8192, 8192, 0, 3);
+      g_zero_fill = 0;
+    }
+    for (int abl : {0, 1, 2, 3, 4, 5, 6, 8, 9, 11}) {
+      qutlass_amd_set_option("nvf4_variant", abl ? 10 + abl : 2);
+      char tag[96];
+      snprintf(tag, sizeof tag, "nvfp4 v2 8192^3 abl=%d%s%s%s%s", abl, abl & 1 ? " -convert" : "", abl & 2 ? " -reads" : "", abl & 4 ? " -mfma" : "", abl & 8 ? " -barrier" : "");
+      DBuf<uint32_t> dT(16);
+      HIP_OK(hipMemset(dT.p, 0, 64));
+      qutlass_amd_debug_set_trace_buffer(dT.p);
+      bench_gemm(tag, 1, 8192, 8192, 8192, 0, 3);
+      qutlass_amd_debug_set_trace_buffer(nullptr);
+      std::vector<uint32_t> t = dT.down();
+      printf("      block 0 K loop: %u shader cycles, %u x 10 ns  ->  %.0f cycles/stage, %.3f us/stage, clock %.2f GHz\n", t[0], t[1], (double)t[0] / t[2],
+             t[1] * 0.01 / t[2], t[0] / (t[1] * 10.0));
+    }
+    qutlass_amd_set_option("nvf4_variant", 0);
   }
   if (want("nn") || want("gemm")) {
     check_bench_nn(16, 64, 256, 0);
@@ -526,6 +588,10 @@ int main(int argc, char** argv) {
       for (int R : {16, 32, 64, 128})
         for (int method : {0, 1}) check_quant_nv(R, method, hw, 1 << 18, method ? 6.0f : 1.0f);
     check_quant_nv(16, 1, 0, 16 * 33, 1.0f);
+  }
+  if (want("dtrace")) {
+    trace_gemm(35, 1);
+    trace_gemm(36, 1);
   }
   if (want("trace")) {
     trace_gemm(316, 1);

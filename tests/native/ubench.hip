@@ -132,7 +132,7 @@ __global__ __launch_bounds__(THREADS) void ub_kernel(const char* g, uint32_t gby
 static int g_random_fill = 0;
 template <int MODE, int THREADS>
 static void run_one(const char* name, const char* g, uint32_t gbytes, float* out, uint32_t* cyc, int blocks) {
-  const int iters = 2000;
+  const int iters = 20000;
   ub_kernel<MODE, THREADS><<<blocks, THREADS>>>(g, gbytes, out, cyc, iters, g_random_fill);
   HIP_OK(hipDeviceSynchronize());
   hipEvent_t e0, e1;
@@ -256,4 +256,102 @@ void run_ubench() {
    }
   }
   hipFree(g); hipFree(out); hipFree(cyc);
+}
+
+// ------------------------------------------------------------------------------------------------
+// VALU issue rates of the NVFP4 dequant instructions (one wave per SIMD, s_memtime around an unrolled
+// run of independent instructions): decides whether the f16 path is cvt-bound.
+// ------------------------------------------------------------------------------------------------
+typedef _Float16 ub_h2 __attribute__((ext_vector_type(2)));
+typedef _Float16 ub_h8 __attribute__((ext_vector_type(8)));
+typedef float ub_f16v __attribute__((ext_vector_type(16)));
+
+template <int OP>
+__global__ __launch_bounds__(256) void valu_rate_kernel(uint32_t* outv, uint64_t* cyc, int iters, uint32_t seed) {
+  uint32_t w[8];
+  ub_h2 acc[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { w[i] = seed * (threadIdx.x + 1) * (i + 3); acc[i] = ub_h2{(_Float16)1.0f, (_Float16)1.0f}; }
+  ub_f16v c0 = {}, c1 = {};
+  ub_h8 fa = {(_Float16)1, (_Float16)2, (_Float16)3, (_Float16)4, (_Float16)1, (_Float16)2, (_Float16)3, (_Float16)4};
+  ub_h8 fb = fa;
+  if (OP == 6) {   // random finite f16 operands (sign + 5-bit exponent around 1 + random mantissa)
+    uint32_t x = seed ^ (threadIdx.x * 2654435761u) ^ (blockIdx.x * 40503u);
+    uint32_t r4[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      x = x * 1664525u + 1013904223u;
+      const uint32_t lo = (x & 0x83ffu) | (((x >> 10) % 5 + 13) << 10);
+      const uint32_t hi = ((x >> 16) & 0x83ffu) | ((((x >> 26) % 5) + 13) << 10);
+      r4[i] = lo | (hi << 16);
+    }
+    typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+    fa = __builtin_bit_cast(ub_h8, (u4){r4[0], r4[1], r4[2], r4[3]});
+    fb = __builtin_bit_cast(ub_h8, (u4){r4[4], r4[5], r4[6], r4[7]});
+  }
+  uint64_t t0 = __builtin_readcyclecounter();
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      if (OP == 6) {
+        c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa, fb, c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb, fa, c1, 0, 0, 0);
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        if (OP == 0) acc[i] = __builtin_amdgcn_cvt_scalef32_pk_f16_fp4(w[i], 1.0f, 0) ;           // 32 cvt
+        if (OP == 1) acc[i] = acc[i] * ub_h2{(_Float16)1.0f, (_Float16)1.0009765625f};           // 32 pk_mul (dependent per i, 8 chains)
+        if (OP == 2) w[i] = __builtin_amdgcn_perm(w[i], w[(i + 1) & 7], 0x05010400u + r);       // 32 perm
+        if (OP == 3) { acc[i] = __builtin_amdgcn_cvt_scalef32_pk_f16_fp4(w[i], 1.0f, 0) * acc[i]; }   // 32 cvt + 32 mul
+      }
+      if (OP == 4 || OP == 5) {   // 2 MFMAs (+ 32 cvt/mul pairs for OP 5) per r
+        c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa, fa, c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa, fa, c1, 0, 0, 0);
+        if (OP == 5) {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_cvt_scalef32_pk_f16_fp4(w[i], 1.0f, 0) * acc[i];
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) asm volatile("" : "+v"(w[i]), "+v"(acc[i]));
+    }
+  }
+  uint64_t t1 = __builtin_readcyclecounter();
+  uint32_t s = 0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) s += w[i] + __builtin_bit_cast(uint32_t, acc[i]);
+  outv[blockIdx.x * 256 + threadIdx.x] = s + (uint32_t)(c0[0] + c1[3]);
+  if (threadIdx.x == 0 && blockIdx.x == 0) cyc[0] = t1 - t0;
+}
+
+template <int OP>
+static void run_valu(const char* name, int per_iter, int waves_per_simd) {
+  uint32_t* o; uint64_t* c;
+  HIP_OK(hipMalloc(&o, 256 * 512 * 4)); HIP_OK(hipMalloc(&c, 8));
+  const int iters = 20000;
+  valu_rate_kernel<OP><<<256 * waves_per_simd, 256>>>(o, c, iters, 12345u);
+  HIP_OK(hipDeviceSynchronize());
+  hipEvent_t e0, e1;
+  HIP_OK(hipEventCreate(&e0)); HIP_OK(hipEventCreate(&e1));
+  HIP_OK(hipEventRecord(e0, 0));
+  valu_rate_kernel<OP><<<256 * waves_per_simd, 256>>>(o, c, iters, 12345u);
+  HIP_OK(hipEventRecord(e1, 0));
+  HIP_OK(hipEventSynchronize(e1));
+  float ms; HIP_OK(hipEventElapsedTime(&ms, e0, e1));
+  uint64_t cy; HIP_OK(hipMemcpy(&cy, c, 8, hipMemcpyDeviceToHost));
+  printf("UBENCH valu %-44s waves/SIMD=%d : %8.1f ns per iteration-group of %d, s_memtime ticks/group %.1f\n", name, waves_per_simd,
+         ms * 1e6 / iters, per_iter, (double)cy / iters);
+  hipFree(o); hipFree(c); hipEventDestroy(e0); hipEventDestroy(e1);
+}
+
+void run_valu_rates() {
+  for (int w : {1, 2}) {
+    run_valu<0>("32 x v_cvt_scalef32_pk_f16_fp4", 32, w);
+    run_valu<1>("32 x v_pk_mul_f16", 32, w);
+    run_valu<2>("32 x v_perm_b32", 32, w);
+    run_valu<3>("32 x (cvt + pk_mul)", 64, w);
+    run_valu<4>("8 x v_mfma_f32_32x32x16_f16", 8, w);
+    run_valu<5>("8 x MFMA f16 + 32 x (cvt + pk_mul)", 72, w);
+    run_valu<6>("8 x v_mfma_f32_32x32x16_f16, RANDOM operands", 8, w);
+  }
 }
