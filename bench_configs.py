@@ -1,0 +1,128 @@
+#!/usr/bin/env python3
+"""Secondary measurements: the other BASELINE.json configs (C3, C4, C5) on one MI355X, one JSON line each.
+
+    python bench_configs.py [--iters N]
+
+bench.py stays the headline (configs[1]); this script only records, with the same conventions (operands resident
+in HBM, HIP events on the launch stream, algorithmic bytes / FLOPs against the MI355X_MICROARCH.md peaks), what the
+remaining hot-path rows of SURVEY.md section 8 do at their BASELINE.json shapes.  Results go to profiles/.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+PEAK = {"fp4": 10066.0, "fp8": 5033.0, "f16": 2516.0}   # dense TFLOP/s (MI355X_MICROARCH.md)
+HBM_PEAK_GBS = 8000.0
+
+
+def hadamard(n, device):
+    h = torch.ones(1, 1)
+    while h.shape[0] < n:
+        h = torch.cat([torch.cat([h, h], 1), torch.cat([h, -h], 1)], 0)
+    return (h * n ** -0.5).to(torch.bfloat16).to(device)
+
+
+def time_us(fn, iters, warmup=5):
+    for _ in range(warmup):
+        fn()
+    s = torch.cuda.current_stream()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record(s)
+    for _ in range(iters):
+        fn()
+    e1.record(s)
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e3 / iters
+
+
+def line(name, us, flops=None, peak=None, bytes_=None, **extra):
+    d = {"config": name, "us": round(us, 2)}
+    if flops:
+        tf = flops / us * 1e-6
+        d.update({"TFLOP/s": round(tf, 1), "roofline": {"bound": "mfma", "achieved": round(tf, 1), "peak": peak, "unit": "TFLOP/s", "frac": round(tf / peak, 4)}})
+    if bytes_:
+        gbs = bytes_ / us * 1e-3
+        d.update({"GB/s": round(gbs, 1), "roofline": {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
+                                                     "algorithmic_bytes": bytes_}})
+    d.update(extra)
+    print(json.dumps(d), flush=True)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--iters", type=int, default=30)
+    args = ap.parse_args()
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    import qutlass_amd as q
+    from qutlass_amd.utils import to_blocked
+
+    torch.manual_seed(0)
+    alpha = torch.tensor([1.0], device=dev)
+    h32 = hadamard(32, dev)
+
+    # ---- C3: fusedQuantizeMx(H32, abs_max) + to_blocked + MXFP4 GEMM, Llama-3-8B FFN M=4096 N=14336 K=4096 ----
+    M, N, K = 4096, 14336, 4096
+    x = torch.randn(M, K, dtype=torch.bfloat16, device=dev) * 25.0
+    w = torch.randn(N, K, dtype=torch.bfloat16, device=dev) * 25.0
+    w_q, w_s = q.fusedQuantizeMx(w, h32, method="abs_max")
+    w_sf = to_blocked(w_s)
+    x_q, x_s = q.fusedQuantizeMx(x, h32, method="abs_max")
+    x_sf = to_blocked(x_s)
+    qbytes = M * K * 2 + M * K // 2 + M * K // 32
+    line("C3 fusedQuantizeMx(H32, abs_max) 4096x4096 activations", time_us(lambda: q.fusedQuantizeMx(x, h32, method="abs_max"), args.iters), bytes_=qbytes)
+    line("C3 to_blocked(e8m0 4096x128)", time_us(lambda: to_blocked(x_s), args.iters), bytes_=2 * M * K // 32)
+    gflops = 2.0 * M * N * K
+    line("C3 matmul_mxf4_bf16_tn 4096x14336x4096", time_us(lambda: q.matmul_mxf4_bf16_tn(x_q, w_q, x_sf, w_sf, alpha), args.iters), flops=gflops, peak=PEAK["fp4"])
+
+    def c3_step():
+        a_q, a_s = q.fusedQuantizeMx(x, h32, method="abs_max")
+        return q.matmul_mxf4_bf16_tn(a_q, w_q, to_blocked(a_s), w_sf, alpha)
+
+    line("C3 step: quantize + to_blocked + GEMM (weights pre-quantised)", time_us(c3_step, args.iters), flops=gflops, peak=PEAK["fp4"])
+    del x, w, w_q, w_s, x_q, x_s
+
+    # ---- C4: NVFP4 GEMM 8192^3 ----------------------------------------------------------------------------------
+    M = N = K = 8192
+    gs = torch.tensor([1.0], device=dev)
+    a = torch.randn(M, K, dtype=torch.bfloat16, device=dev) * 25.0
+    b = torch.randn(N, K, dtype=torch.bfloat16, device=dev) * 25.0
+    h16 = hadamard(16, dev)
+    a_q, a_s = q.fusedQuantizeNv(a, h16, gs)
+    b_q, b_s = q.fusedQuantizeNv(b, h16, gs)
+    a_sf, b_sf = to_blocked(a_s), to_blocked(b_s)
+    nvbytes = M * K * 2 + M * K // 2 + M * K // 16
+    line("C4 fusedQuantizeNv(H16, abs_max) 8192x8192", time_us(lambda: q.fusedQuantizeNv(a, h16, gs), max(5, args.iters // 3)), bytes_=nvbytes)
+    line("C4 matmul_nvf4_bf16_tn 8192^3 (exact semantics on the f16 MFMA)", time_us(lambda: q.matmul_nvf4_bf16_tn(a_q, b_q, a_sf, b_sf, alpha), max(3, args.iters // 6)),
+         flops=2.0 * M * N * K, peak=PEAK["f16"])
+    del a, b, a_q, b_q, a_s, b_s
+
+    # ---- C5: MXFP8 TN + NN 4096^3, Quest + clip-mask quantizer ---------------------------------------------------
+    M = N = K = 4096
+    a8 = (torch.randn(M, K, device=dev) * 4).to(torch.float8_e4m3fn)
+    b8 = (torch.randn(N, K, device=dev) * 4).to(torch.float8_e4m3fn)
+    s8a = to_blocked(torch.randint(120, 131, (M, K // 32), dtype=torch.uint8, device=dev).view(torch.float8_e8m0fnu))
+    s8b = to_blocked(torch.randint(120, 131, (N, K // 32), dtype=torch.uint8, device=dev).view(torch.float8_e8m0fnu))
+    a8t = a8.view(torch.uint8).T.contiguous().view(torch.float8_e4m3fn)
+    line("C5 matmul_mxf8_bf16_tn 4096^3", time_us(lambda: q.matmul_mxf8_bf16_tn(a8, b8, s8a, s8b, alpha), args.iters), flops=2.0 * M * N * K, peak=PEAK["fp8"])
+    line("C5 matmul_mxf8_bf16_nn 4096^3 (A stored (K, M))", time_us(lambda: q.matmul_mxf8_bf16_nn(a8t, b8, s8a, s8b, alpha), args.iters), flops=2.0 * M * N * K, peak=PEAK["fp8"])
+    x = torch.randn(M, K, dtype=torch.bfloat16, device=dev) * 25.0
+    qb = M * K * 2 + M * K // 2 + M * K // 32
+    line("C5 fusedQuantizeMx(H32, quest) 4096x4096", time_us(lambda: q.fusedQuantizeMx(x, h32, method="quest"), args.iters), bytes_=qb)
+    line("C5 fusedQuantizeMx(H32, quest, return_mask=True) 4096x4096", time_us(lambda: q.fusedQuantizeMx(x, h32, method="quest", return_mask=True), args.iters), bytes_=qb + M * K // 8)
+    for r in (64, 128):
+        hr = hadamard(r, dev)
+        line(f"fusedQuantizeMx(H{r}, abs_max) 4096x4096", time_us(lambda: q.fusedQuantizeMx(x, hr, method="abs_max"), args.iters), bytes_=qb)
+
+
+if __name__ == "__main__":
+    main()

@@ -119,6 +119,7 @@ const char* qutlass_amd_version(void);
  *   "hw_fp4_cvt"   (1) use v_cvt_scalef32_pk_fp4_f32 for the final e2m1 rounding; 0 = software encoder
  *                  (both are bit-identical on gfx950)
  *   "gemm_variant" (0 = auto) force a tile configuration / schedule of the MX GEMMs (bench sweeps)
+ *   "nvf4_variant" (0 = auto) 1 = per-wave dequant kernel, 2 = dequantise-once-into-LDS kernel
  * Returns the previous value, or -1 for an unknown key.
  */
 int qutlass_amd_set_option(const char* key, int value);

@@ -1,4 +1,9 @@
-"""Build libqutlass_amd.so in-tree with hipcc for gfx950 (no torch headers, no cmake)."""
+"""Build the two in-tree binaries (no cmake, no JIT cache):
+
+  libqutlass_amd.so   hipcc --offload-arch=gfx950: the hand-written HIP kernels behind the C ABI (no torch headers)
+  _C.so               g++: the PyTorch extension (csrc/torch_ext.cpp, LibTorch stable ABI, no device code) that
+                      registers torch.ops._qutlass_C.* over that C ABI
+"""
 from __future__ import annotations
 
 import os
@@ -8,29 +13,55 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(_HERE, "csrc", "capi.hip")
 OUT = os.path.join(_HERE, "libqutlass_amd.so")
+EXT_SRC = os.path.join(_HERE, "csrc", "torch_ext.cpp")
+EXT_OUT = os.path.join(_HERE, "_C.so")
+HEADER = os.path.join(os.path.dirname(_HERE), "include", "qutlass_amd.h")
 
 
-def _sources():
+def _kernel_sources():
     d = os.path.join(_HERE, "csrc")
-    return [os.path.join(d, f) for f in sorted(os.listdir(d))] + [
-        os.path.join(os.path.dirname(_HERE), "include", "qutlass_amd.h")]
+    return [os.path.join(d, f) for f in sorted(os.listdir(d)) if f != "torch_ext.cpp"] + [HEADER]
+
+
+def _stale(out, sources) -> bool:
+    if not os.path.exists(out):
+        return True
+    t = os.path.getmtime(out)
+    return any(os.path.getmtime(s) > t for s in sources)
 
 
 def needs_build() -> bool:
-    if not os.path.exists(OUT):
-        return True
-    t = os.path.getmtime(OUT)
-    return any(os.path.getmtime(s) > t for s in _sources())
+    return _stale(OUT, _kernel_sources()) or _stale(EXT_OUT, [EXT_SRC, HEADER, OUT])
+
+
+def build_kernels(force: bool = False, verbose: bool = False) -> str:
+    if force or _stale(OUT, _kernel_sources()):
+        hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+        cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", SRC, "-o", OUT]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+    return OUT
+
+
+def build_extension(force: bool = False, verbose: bool = False) -> str:
+    if force or _stale(EXT_OUT, [EXT_SRC, HEADER, OUT]):
+        import torch
+
+        tdir = os.path.dirname(torch.__file__)
+        inc, lib = os.path.join(tdir, "include"), os.path.join(tdir, "lib")
+        cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-DUSE_ROCM", "-DTORCH_TARGET_VERSION=0x020a000000000000",
+               EXT_SRC, "-I" + inc, "-o", EXT_OUT, "-L" + lib, "-ltorch", "-ltorch_cpu", "-lc10", "-ltorch_hip",
+               "-L" + _HERE, "-lqutlass_amd", "-Wl,-rpath,$ORIGIN", "-Wl,-rpath," + lib]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+    return EXT_OUT
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
-    if not force and not needs_build():
-        return OUT
-    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", SRC, "-o", OUT]
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd)
+    build_kernels(force, verbose)
+    build_extension(force, verbose)
     return OUT
 
 

@@ -488,10 +488,11 @@ __global__ __launch_bounds__(C::THREADS) void gemm_nvf4_lds_kernel(const NvGemmP
   }
 }
 
-// variant: 0 = auto (v2), 1 = v1 (per-wave dequant), 2 = v2
+// variant: 0 = auto = 1 (per-wave dequant; measured equal or slightly faster than v2 on every shape,
+// profiles/native_r1_nvfp4_ablation.log -- both are power-bound at the same wall time), 2 = v2 (LDS dequant)
 inline hipError_t launch_nvf4_gemm(NvGemmParams p, hipStream_t s, int variant = 0) {
   const bool small = p.M <= 128 || p.N <= 128;
-  if (variant == 1) {
+  if (variant <= 1) {
     if (small) {
       using C = NvCfg<128, 128, 2, 2>;
       p.tiles_m = (p.M + C::BM - 1) / C::BM;

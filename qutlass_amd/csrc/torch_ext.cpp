@@ -1,0 +1,269 @@
+// PyTorch (ROCm) extension: the `_qutlass_C` operator library of the reference, bound to the C ABI of
+// libqutlass_amd.so (include/qutlass_amd.h).  No device code here -- the kernels are the hand-written HIP in
+// gemm_*.hip.h / quantize.hip.h / to_blocked.hip.h behind the C ABI.
+//
+// Mirrors qutlass/csrc/bindings.cpp of the reference op for op: same op names and schema strings
+// (bindings.cpp:499-513), same argument validation order and messages (bindings.cpp:32-426,
+// include/bindings_utils.h:67-136), same ownership (GEMMs allocate and return the bf16 result, quantizers fill
+// caller-allocated outputs and return them), same stream rule (current stream of the tensor's device,
+// include/common.h:40-45).  Written against the LibTorch stable ABI, like the reference, so one build serves
+// every torch >= 2.10.  One extra op, qutlass_amd::to_blocked, replaces the Triton/torch swizzle of
+// qutlass/utils.py:160-193.
+#include <torch/csrc/inductor/aoti_torch/c/shim.h>
+#include <torch/csrc/stable/accelerator.h>
+#include <torch/csrc/stable/library.h>
+#include <torch/csrc/stable/ops.h>
+#include <torch/csrc/stable/tensor.h>
+#include <torch/headeronly/core/ScalarType.h>
+#include <torch/headeronly/util/Exception.h>
+
+#include <initializer_list>
+#include <string>
+#include <tuple>
+
+#include "../../include/qutlass_amd.h"
+
+namespace {
+
+using torch::headeronly::ScalarType;
+using torch::stable::Tensor;
+
+struct Named {
+  const Tensor& t;
+  const char* name;
+};
+
+std::string arg_desc(int pos, const char* name) { return "argument #" + std::to_string(pos) + " '" + name + "'"; }
+
+// ---- the three generic checks of include/bindings_utils.h, table-driven ------------------------------------------
+void require_contiguous(const char* op, std::initializer_list<Named> args) {
+  int pos = 0;
+  for (const Named& a : args) {
+    STD_TORCH_CHECK(a.t.is_contiguous(), "Expected contiguous tensor, but got non-contiguous tensor for ", arg_desc(pos, a.name),
+                    " (while checking arguments for ", op, ")");
+    ++pos;
+  }
+}
+
+void require_gpu(const char* op, std::initializer_list<Named> args) {
+  for (const Named& a : args)
+    STD_TORCH_CHECK(a.t.is_cuda(), "Expected tensor to have cuda DeviceType, but got tensor with ", a.t.is_cpu() ? "cpu" : "another",
+                    " DeviceType (while checking arguments for ", op, ")");
+}
+
+void require_same_gpu(const char* op, std::initializer_list<Named> args) {
+  const Named& first = *args.begin();
+  int pos = 0;
+  for (const Named& a : args) {
+    if (pos > 0)
+      STD_TORCH_CHECK(a.t.get_device_index() == first.t.get_device_index(), "Expected tensor for ", arg_desc(0, first.name),
+                      " to have the same device as tensor for ", arg_desc(pos, a.name), "; but device ", first.t.get_device_index(),
+                      " does not equal ", a.t.get_device_index(), " (while checking arguments for ", op, ")");
+    ++pos;
+  }
+}
+
+// dtype through the C shim: Tensor::scalar_type() goes through the stable IValue conversion, which in torch 2.10 does
+// not know Float8_e8m0fnu yet ("Not yet supported ScalarType 44")
+bool has_dtype(const Tensor& t, ScalarType want) {
+  int32_t code = -1;
+  TORCH_ERROR_CODE_CHECK(aoti_torch_get_dtype(t.get(), &code));
+  return code == static_cast<int32_t>(want);
+}
+
+void* current_stream(const Tensor& t) {   // include/common.h:40-45
+  void* s = nullptr;
+  TORCH_ERROR_CODE_CHECK(aoti_torch_get_current_cuda_stream(t.get_device_index(), &s));
+  return s;
+}
+
+void check_rc(int rc) { STD_TORCH_CHECK(rc == QAMD_OK, qutlass_amd_last_error()); }
+
+// ---- block-scaled GEMMs --------------------------------------------------------------------------------------------
+enum class Gemm { MXF4, NVF4, MXF8_TN, MXF8_NN };
+
+template <Gemm G>
+Tensor matmul(const Tensor& A, const Tensor& B, const Tensor& A_sf, const Tensor& B_sf, const Tensor& alpha) {
+  constexpr bool fp8 = G == Gemm::MXF8_TN || G == Gemm::MXF8_NN;
+  constexpr bool nn = G == Gemm::MXF8_NN;
+  const char* op = G == Gemm::MXF4 ? "matmul_mxf4_bf16_tn" : G == Gemm::NVF4 ? "matmul_nvf4_bf16_tn" : G == Gemm::MXF8_TN ? "matmul_mxf8_bf16_tn" : "matmul_mxf8_bf16_nn";
+  if (fp8) require_contiguous(op, {{A, "A"}, {B, "B"}, {A_sf, "A_sf"}, {B_sf, "B_sf"}, {alpha, "alpha"}});
+  else require_contiguous(op, {{A, "A"}, {B, "B"}, {A_sf, "A_sf"}, {B_sf, "B_sf"}});
+  require_gpu(op, {{A, "A"}, {B, "B"}, {A_sf, "A_sf"}, {B_sf, "B_sf"}, {alpha, "alpha"}});
+  require_same_gpu(op, {{A, "A"}, {B, "B"}, {A_sf, "A_sf"}, {B_sf, "B_sf"}, {alpha, "alpha"}});
+
+  const ScalarType data_t = fp8 ? ScalarType::Float8_e4m3fn : ScalarType::Byte;
+  const ScalarType sf_t = G == Gemm::NVF4 ? ScalarType::Float8_e4m3fn : ScalarType::Float8_e8m0fnu;
+  const char* data_n = fp8 ? "float8_e4m3fn" : "uint8";
+  const char* sf_n = G == Gemm::NVF4 ? "float8_e4m3fn" : "float8_e8m0fnu";
+  STD_TORCH_CHECK(has_dtype(A, data_t), "A must be ", data_n);
+  STD_TORCH_CHECK(has_dtype(B, data_t), "B must be ", data_n);
+  STD_TORCH_CHECK(has_dtype(A_sf, sf_t), "A_sf must be ", sf_n);
+  STD_TORCH_CHECK(has_dtype(B_sf, sf_t), "B_sf must be ", sf_n);
+  STD_TORCH_CHECK(A.dim() == 2 && B.dim() == 2, "A and B must be 2D");
+  const int64_t kmin = G == Gemm::NVF4 ? 16 : 32;
+  int64_t M;
+  if (nn) {
+    STD_TORCH_CHECK(A.size(0) == B.size(1), "Inner dimensions must match for A.T @ B.T");
+    STD_TORCH_CHECK(A.size(0) >= kmin, "A K-dim must be >= ", kmin);
+    M = A.size(1);
+  } else {
+    STD_TORCH_CHECK(A.size(1) == B.size(1), "Inner dimensions must match for A @ B.T");
+    STD_TORCH_CHECK(A.size(1) >= kmin, "A K-dim must be >= ", kmin);
+    M = A.size(0);
+  }
+  STD_TORCH_CHECK(B.size(1) >= kmin, "B K-dim must be >= ", kmin);
+  const int64_t N = B.size(0), K = B.size(1) * (fp8 ? 1 : 2);
+
+  Tensor out = torch::stable::new_empty(A, {M, N}, ScalarType::BFloat16);
+  const torch::stable::accelerator::DeviceGuard guard(A.get_device_index());
+  const float* al = static_cast<const float*>(alpha.data_ptr());
+  void* s = current_stream(A);
+  int rc;
+  if (G == Gemm::MXF4) rc = qutlass_amd_matmul_mxf4_bf16_tn(A.data_ptr(), B.data_ptr(), A_sf.data_ptr(), B_sf.data_ptr(), al, out.data_ptr(), M, N, K, s);
+  else if (G == Gemm::NVF4) rc = qutlass_amd_matmul_nvf4_bf16_tn(A.data_ptr(), B.data_ptr(), A_sf.data_ptr(), B_sf.data_ptr(), al, out.data_ptr(), M, N, K, s);
+  else if (G == Gemm::MXF8_TN) rc = qutlass_amd_matmul_mxf8_bf16_tn(A.data_ptr(), B.data_ptr(), A_sf.data_ptr(), B_sf.data_ptr(), al, out.data_ptr(), M, N, K, s);
+  else {
+    // scratch for the (K, M) -> (M, K) re-layout: from torch's stream-ordered caching allocator
+    const int64_t ws_bytes = qutlass_amd_mxf8_nn_workspace_bytes(M, K);
+    Tensor ws = torch::stable::new_empty(A, {ws_bytes}, ScalarType::Byte);
+    rc = qutlass_amd_matmul_mxf8_bf16_nn(A.data_ptr(), B.data_ptr(), A_sf.data_ptr(), B_sf.data_ptr(), al, out.data_ptr(), M, N, K, ws.data_ptr(), ws_bytes, s);
+  }
+  check_rc(rc);
+  return out;
+}
+
+Tensor matmul_mxf4_bf16_tn(const Tensor& A, const Tensor& B, const Tensor& A_sf, const Tensor& B_sf, const Tensor& alpha) { return matmul<Gemm::MXF4>(A, B, A_sf, B_sf, alpha); }
+Tensor matmul_nvf4_bf16_tn(const Tensor& A, const Tensor& B, const Tensor& A_sf, const Tensor& B_sf, const Tensor& alpha) { return matmul<Gemm::NVF4>(A, B, A_sf, B_sf, alpha); }
+Tensor matmul_mxf8_bf16_tn(const Tensor& A, const Tensor& B, const Tensor& A_sf, const Tensor& B_sf, const Tensor& alpha) { return matmul<Gemm::MXF8_TN>(A, B, A_sf, B_sf, alpha); }
+Tensor matmul_mxf8_bf16_nn(const Tensor& A, const Tensor& B, const Tensor& A_sf, const Tensor& B_sf, const Tensor& alpha) { return matmul<Gemm::MXF8_NN>(A, B, A_sf, B_sf, alpha); }
+
+// ---- fused rotate + quantize ---------------------------------------------------------------------------------------
+int64_t nbytes(const Tensor& t) { return t.numel() * (int64_t)t.element_size(); }
+
+void quant_prologue(const char* op, const Tensor& A, const Tensor& R) {
+  STD_TORCH_CHECK(has_dtype(A, ScalarType::BFloat16), "A must be bf16");
+  STD_TORCH_CHECK(has_dtype(R, ScalarType::BFloat16), "B must be bf16");
+  (void)op;
+}
+
+// mask == nullptr: plain variant (rotation 32 / 64 / 128); mask != nullptr: Quest with clip mask (rotation 32 only)
+void quantize_mx(const char* op, const Tensor& A, const Tensor& R, Tensor& OUT, Tensor& OUT_sf, Tensor* OUT_mask, int method) {
+  if (OUT_mask) {
+    require_contiguous(op, {{A, "A"}, {R, "B"}, {OUT, "OUT"}, {OUT_sf, "OUT_sf"}, {*OUT_mask, "OUT_mask"}});
+    require_gpu(op, {{A, "A"}, {R, "B"}, {OUT, "OUT"}, {OUT_sf, "OUT_sf"}, {*OUT_mask, "OUT_mask"}});
+    require_same_gpu(op, {{A, "A"}, {R, "B"}, {OUT, "OUT"}, {OUT_sf, "OUT_sf"}, {*OUT_mask, "OUT_mask"}});
+  } else {
+    require_contiguous(op, {{A, "A"}, {R, "B"}, {OUT, "OUT"}, {OUT_sf, "OUT_sf"}});
+    require_gpu(op, {{A, "A"}, {R, "B"}, {OUT, "OUT"}, {OUT_sf, "OUT_sf"}});
+    require_same_gpu(op, {{A, "A"}, {R, "B"}, {OUT, "OUT"}, {OUT_sf, "OUT_sf"}});
+  }
+  quant_prologue(op, A, R);
+  STD_TORCH_CHECK(R.dim() == 2 && R.size(0) == R.size(1), "Rotation matrix must be square");
+  const int64_t rot = R.size(0), numel = A.numel();
+  STD_TORCH_CHECK(numel % rot == 0, "A must be divisible by", rot);
+  if (OUT_mask) {
+    STD_TORCH_CHECK(rot == 32, "Unsupported rotation size ", rot, "; expected 32.");
+  } else {
+    STD_TORCH_CHECK(rot == 32 || rot == 64 || rot == 128, "Unsupported rotation size ", rot, "; expected 32, 64, or 128.");
+  }
+  // the C ABI writes numel/2, numel/32 (and numel/8) bytes: the caller's buffers must hold them
+  STD_TORCH_CHECK(nbytes(OUT) >= numel / 2, "OUT is too small");
+  STD_TORCH_CHECK(nbytes(OUT_sf) >= numel / 32, "OUT_sf is too small");
+  if (OUT_mask) {
+    STD_TORCH_CHECK(nbytes(*OUT_mask) >= numel / 8, "OUT_mask is too small");
+  }
+  const torch::stable::accelerator::DeviceGuard guard(A.get_device_index());
+  check_rc(qutlass_amd_fused_quantize_mx(A.data_ptr(), R.data_ptr(), (int)rot, numel, method, OUT.data_ptr(), OUT_sf.data_ptr(),
+                                         OUT_mask ? OUT_mask->data_ptr() : nullptr, current_stream(A)));
+}
+
+std::tuple<Tensor, Tensor> fusedQuantizeMxQuest(const Tensor& A, const Tensor& R, Tensor OUT, Tensor OUT_sf) {
+  quantize_mx("fusedQuantizeMxQuest", A, R, OUT, OUT_sf, nullptr, QAMD_METHOD_QUEST);
+  return {OUT, OUT_sf};
+}
+std::tuple<Tensor, Tensor> fusedQuantizeMxAbsMax(const Tensor& A, const Tensor& R, Tensor OUT, Tensor OUT_sf) {
+  quantize_mx("fusedQuantizeMxAbsMax", A, R, OUT, OUT_sf, nullptr, QAMD_METHOD_ABSMAX);
+  return {OUT, OUT_sf};
+}
+std::tuple<Tensor, Tensor, Tensor> fusedQuantizeMxQuestWithMask(const Tensor& A, const Tensor& R, Tensor OUT, Tensor OUT_sf, Tensor OUT_mask) {
+  quantize_mx("fusedQuantizeMxQuestWithMask", A, R, OUT, OUT_sf, &OUT_mask, QAMD_METHOD_QUEST);
+  return {OUT, OUT_sf, OUT_mask};
+}
+
+void quantize_nv(const char* op, const Tensor& A, const Tensor& R, Tensor& OUT, Tensor& OUT_sf, const Tensor& gscale, int method) {
+  require_contiguous(op, {{A, "A"}, {R, "B"}, {OUT, "OUT"}, {OUT_sf, "OUT_sf"}});
+  require_gpu(op, {{A, "A"}, {R, "B"}, {OUT, "OUT"}, {OUT_sf, "OUT_sf"}, {gscale, "global_scale"}});
+  require_same_gpu(op, {{A, "A"}, {R, "B"}, {OUT, "OUT"}, {OUT_sf, "OUT_sf"}, {gscale, "global_scale"}});
+  quant_prologue(op, A, R);
+  STD_TORCH_CHECK(has_dtype(gscale, ScalarType::Float), "global_scale must be float");
+  STD_TORCH_CHECK(gscale.dim() == 1 && gscale.size(0) == 1, "global_scale must be a scalar");
+  STD_TORCH_CHECK(R.dim() == 2 && R.size(0) == R.size(1), "Rotation matrix must be square");
+  const int64_t rot = R.size(0), numel = A.numel();
+  STD_TORCH_CHECK(numel % rot == 0, "A must be divisible by", rot);
+  STD_TORCH_CHECK(rot == 16 || rot == 32 || rot == 64 || rot == 128, "Unsupported rotation size ", rot, "; expected 16, 32, 64, or 128.");
+  STD_TORCH_CHECK(nbytes(OUT) >= numel / 2, "OUT is too small");
+  STD_TORCH_CHECK(nbytes(OUT_sf) >= numel / 16, "OUT_sf is too small");
+  const torch::stable::accelerator::DeviceGuard guard(A.get_device_index());
+  check_rc(qutlass_amd_fused_quantize_nv(A.data_ptr(), R.data_ptr(), (int)rot, numel, method, static_cast<const float*>(gscale.data_ptr()),
+                                         OUT.data_ptr(), OUT_sf.data_ptr(), current_stream(A)));
+}
+
+std::tuple<Tensor, Tensor> fusedQuantizeNvQuest(const Tensor& A, const Tensor& R, Tensor OUT, Tensor OUT_sf, const Tensor& global_scale) {
+  quantize_nv("fusedQuantizeNvQuest", A, R, OUT, OUT_sf, global_scale, QAMD_METHOD_QUEST);
+  return {OUT, OUT_sf};
+}
+std::tuple<Tensor, Tensor> fusedQuantizeNvAbsMax(const Tensor& A, const Tensor& R, Tensor OUT, Tensor OUT_sf, const Tensor& global_scale) {
+  quantize_nv("fusedQuantizeNvAbsMax", A, R, OUT, OUT_sf, global_scale, QAMD_METHOD_ABSMAX);
+  return {OUT, OUT_sf};
+}
+
+// ---- block-scale swizzle -------------------------------------------------------------------------------------------
+Tensor to_blocked(const Tensor& in) {
+  STD_TORCH_CHECK(in.dim() == 2, "to_blocked expects a 2-D matrix");
+  STD_TORCH_CHECK(in.element_size() == 1, "Expected element size to be 1 byte (8 bits)");
+  STD_TORCH_CHECK(in.is_contiguous(), "Input tensor must be contiguous");
+  STD_TORCH_CHECK(in.is_cuda(), "to_blocked: expected a GPU tensor (no CPU path in qutlass_amd)");
+  const int64_t rows = in.size(0), cols = in.size(1);
+  const int64_t pr = (rows + 127) / 128 * 128, pc = (cols + 3) / 4 * 4;
+  Tensor out = torch::stable::new_empty(in, {pr * pc});
+  const torch::stable::accelerator::DeviceGuard guard(in.get_device_index());
+  check_rc(qutlass_amd_to_blocked(in.data_ptr(), rows, cols, out.data_ptr(), current_stream(in)));
+  return out;
+}
+
+}  // namespace
+
+// Schema strings: bindings.cpp:499-513 (the ops this build provides).
+STABLE_TORCH_LIBRARY(_qutlass_C, m) {
+  m.def("matmul_mxf4_bf16_tn(Tensor A, Tensor B, Tensor A_sf, Tensor B_sf, Tensor alpha) -> Tensor");
+  m.def("matmul_nvf4_bf16_tn(Tensor A, Tensor B, Tensor A_sf, Tensor B_sf, Tensor alpha) -> Tensor");
+  m.def("matmul_mxf8_bf16_tn(Tensor A, Tensor B, Tensor A_sf, Tensor B_sf, Tensor alpha) -> Tensor");
+  m.def("matmul_mxf8_bf16_nn(Tensor A, Tensor B, Tensor A_sf, Tensor B_sf, Tensor alpha) -> Tensor");
+  m.def("fusedQuantizeMxQuest(Tensor A, Tensor R, Tensor OUT, Tensor OUT_sf) -> (Tensor, Tensor)");
+  m.def("fusedQuantizeMxAbsMax(Tensor A, Tensor R, Tensor OUT, Tensor OUT_sf) -> (Tensor, Tensor)");
+  m.def("fusedQuantizeMxQuestWithMask(Tensor A, Tensor R, Tensor OUT, Tensor OUT_sf, Tensor OUT_mask) -> (Tensor, Tensor, Tensor)");
+  m.def("fusedQuantizeNvQuest(Tensor A, Tensor R, Tensor OUT, Tensor OUT_sf, Tensor global_scale) -> (Tensor, Tensor)");
+  m.def("fusedQuantizeNvAbsMax(Tensor A, Tensor R, Tensor OUT, Tensor OUT_sf, Tensor global_scale) -> (Tensor, Tensor)");
+}
+
+STABLE_TORCH_LIBRARY(qutlass_amd, m) { m.def("to_blocked(Tensor input_matrix) -> Tensor"); }
+
+// The reference registers for CUDA only (bindings.cpp:516-535); the same functions are also registered for CPU so that
+// a CPU tensor reaches the reference's own "Expected tensor to have cuda DeviceType" check instead of a dispatcher
+// error -- there is no CPU compute path.
+#define QAMD_IMPLS(m)                                                            \
+  m.impl("matmul_mxf4_bf16_tn", TORCH_BOX(&matmul_mxf4_bf16_tn));                \
+  m.impl("matmul_nvf4_bf16_tn", TORCH_BOX(&matmul_nvf4_bf16_tn));                \
+  m.impl("matmul_mxf8_bf16_tn", TORCH_BOX(&matmul_mxf8_bf16_tn));                \
+  m.impl("matmul_mxf8_bf16_nn", TORCH_BOX(&matmul_mxf8_bf16_nn));                \
+  m.impl("fusedQuantizeMxQuest", TORCH_BOX(&fusedQuantizeMxQuest));              \
+  m.impl("fusedQuantizeMxAbsMax", TORCH_BOX(&fusedQuantizeMxAbsMax));            \
+  m.impl("fusedQuantizeMxQuestWithMask", TORCH_BOX(&fusedQuantizeMxQuestWithMask)); \
+  m.impl("fusedQuantizeNvQuest", TORCH_BOX(&fusedQuantizeNvQuest));              \
+  m.impl("fusedQuantizeNvAbsMax", TORCH_BOX(&fusedQuantizeNvAbsMax));
+
+STABLE_TORCH_LIBRARY_IMPL(_qutlass_C, CUDA, m) { QAMD_IMPLS(m) }
+STABLE_TORCH_LIBRARY_IMPL(_qutlass_C, CPU, m) { QAMD_IMPLS(m) }
+STABLE_TORCH_LIBRARY_IMPL(qutlass_amd, CUDA, m) { m.impl("to_blocked", TORCH_BOX(&to_blocked)); }
+STABLE_TORCH_LIBRARY_IMPL(qutlass_amd, CPU, m) { m.impl("to_blocked", TORCH_BOX(&to_blocked)); }

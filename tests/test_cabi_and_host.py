@@ -101,6 +101,24 @@ def test_torch_ops_registered_with_reference_schemas():
         assert got == f"_qutlass_C::{name}{schema}", got
 
 
+def test_ops_are_implemented_by_the_cpp_extension():
+    """torch.ops._qutlass_C.* must come from the in-tree C++ extension (qutlass_amd/_C.so, csrc/torch_ext.cpp), which
+    links libqutlass_amd.so -- not from a Python-registered stand-in."""
+    import qutlass_amd  # noqa: F401
+    from qutlass_amd import ops
+
+    assert os.path.exists(ops.EXT_PATH)
+    maps = open("/proc/self/maps").read()
+    assert ops.EXT_PATH in maps and "libqutlass_amd.so" in maps
+    # a C++ kernel registered through the stable ABI is not a Python callable: there is no torch.library python impl
+    assert "_qutlass_C::matmul_mxf4_bf16_tn" not in getattr(torch.library, "_impls", {})
+    assert torch.ops.qutlass_amd.to_blocked is not None
+    # validation lives in the extension: the message carries the C++ source location (STD_TORCH_CHECK)
+    with pytest.raises(RuntimeError, match=r"torch_ext\.cpp"):
+        torch.ops._qutlass_C.matmul_mxf4_bf16_tn(torch.zeros(4, 64, dtype=torch.uint8), torch.zeros(4, 64, dtype=torch.uint8),
+                                                 torch.zeros(128, 4, dtype=torch.float8_e8m0fnu), torch.zeros(128, 4, dtype=torch.float8_e8m0fnu), torch.ones(1))
+
+
 def test_python_level_error_behaviour():
     import qutlass_amd
 

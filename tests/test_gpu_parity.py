@@ -258,11 +258,16 @@ def test_matmul_mxf4_errors(q):
 # ------------------------------------------------------------------------------------------------
 # NVFP4
 # ------------------------------------------------------------------------------------------------
-def test_matmul_nvf4_golden_bit_exact(q, golden_dir):
+@pytest.mark.parametrize("nv_variant", [0, 1, 2])   # 1 = per-wave dequant, 2 = dequantise once into f16 LDS tiles
+def test_matmul_nvf4_golden_bit_exact(q, golden_dir, nv_variant):
     g = _load(golden_dir, "gemm_nvfp4.npz")
-    for c in range(int(g["ncases"])):
-        got, want = _gemm_golden(q, g, c, q.matmul_nvf4_bf16_tn, torch.float8_e4m3fn, oracle.KIND_NVFP4)
-        assert np.array_equal(got, want), (c, int((got != want).sum()))
+    q._lib.set_option("nvf4_variant", nv_variant)
+    try:
+        for c in range(int(g["ncases"])):
+            got, want = _gemm_golden(q, g, c, q.matmul_nvf4_bf16_tn, torch.float8_e4m3fn, oracle.KIND_NVFP4)
+            assert np.array_equal(got, want), (nv_variant, c, int((got != want).sum()))
+    finally:
+        q._lib.set_option("nvf4_variant", 0)
 
 
 @pytest.mark.parametrize("rot", [16, 32, 64, 128])
