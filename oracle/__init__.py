@@ -59,6 +59,14 @@ def lib() -> ctypes.CDLL:
         L.orc_pseudoquant_mxfp8.argtypes = [vp, i64, vp, vp]
         L.orc_dequant_fp4.restype = None
         L.orc_dequant_fp4.argtypes = [vp, vp, i32, i32, i64, f32, vp]
+        L.orc_backward_t_bf16.restype = None
+        L.orc_backward_t_bf16.argtypes = [vp, vp, i64, i64, i64, i32, vp, vp]
+        L.orc_backward_qt_bf16.restype = None
+        L.orc_backward_qt_bf16.argtypes = [vp, vp, vp, f32, i64, i64, i64, i32, vp, vp]
+        L.orc_backward_bf16_square_double_mxfp8.restype = None
+        L.orc_backward_bf16_square_double_mxfp8.argtypes = [vp, i64, i64, vp, vp, vp]
+        L.orc_mxfp4_transpose_mxfp8.restype = None
+        L.orc_mxfp4_transpose_mxfp8.argtypes = [vp, vp, i64, i64, vp, vp]
         _lib = L
     return _lib
 
@@ -181,3 +189,59 @@ def codes_equal_mod_zero_sign(a_packed: np.ndarray, b_packed: np.ndarray) -> np.
     al, ah, bl, bh = a & 0xF, a >> 4, b & 0xF, b >> 4
     z = lambda c: np.where((c & 7) == 0, 0, c)
     return np.stack([z(al) == z(bl), z(ah) == z(bh)], axis=-1).reshape(-1)
+
+
+# ---- QAT-backward data-prep kernels (quartet_bwd_sm120.cu) ------------------------------------
+def backward_t_bf16(x_bf16, h_bf16, acc_model: int = 0):
+    """x: (B, N, M) or (N, M) bf16 bits -> (e2m1 (B, M, N/2) u8, e8m0 (B, M, N/32) u8)."""
+    x = _u16(x_bf16)
+    if x.ndim == 2:
+        x = x[None]
+    B, N, M = x.shape
+    h = _u16(h_bf16)
+    assert h.shape == (32, 32) and N % 32 == 0
+    q = np.empty((B, M, N // 2), dtype=np.uint8)
+    s = np.empty((B, M, N // 32), dtype=np.uint8)
+    lib().orc_backward_t_bf16(_p(np.ascontiguousarray(x)), _p(h), B, N, M, acc_model, _p(q), _p(s))
+    return q, s
+
+
+def backward_qt_bf16(x_e2m1, x_e8m0, h_bf16, alpha: float, acc_model: int = 0):
+    """x_e2m1: (B, N, M/2), x_e8m0: (B, N, M/32) -> (e2m1 (B, M, N/2), e8m0 (B, M, N/32))."""
+    xq, xs = _u8(x_e2m1), _u8(x_e8m0)
+    if xq.ndim == 2:
+        xq, xs = xq[None], xs[None]
+    B, N, M2 = xq.shape
+    M = M2 * 2
+    h = _u16(h_bf16)
+    assert h.shape == (32, 32) and N % 32 == 0 and xs.shape == (B, N, M // 32)
+    q = np.empty((B, M, N // 2), dtype=np.uint8)
+    s = np.empty((B, M, N // 32), dtype=np.uint8)
+    lib().orc_backward_qt_bf16(_p(np.ascontiguousarray(xq)), _p(np.ascontiguousarray(xs)), _p(h), float(alpha), B, N, M,
+                               acc_model, _p(q), _p(s))
+    return q, s
+
+
+def backward_bf16_square_double_mxfp8(x_bf16):
+    """x: (m, n) bf16 bits, m % 32 == 0, n % 32 == 0 -> (e4m3 (m, n), row_scales (m, n/32), col_scales (n, m/32))."""
+    x = np.ascontiguousarray(_u16(x_bf16))
+    m, n = x.shape
+    assert m % 32 == 0 and n % 32 == 0
+    y = np.empty((m, n), dtype=np.uint8)
+    rs = np.empty((m, n // 32), dtype=np.uint8)
+    cs = np.empty((n, m // 32), dtype=np.uint8)
+    lib().orc_backward_bf16_square_double_mxfp8(_p(x), m, n, _p(y), _p(rs), _p(cs))
+    return y, rs, cs
+
+
+def mxfp4_transpose_mxfp8(x_fp4, scales):
+    """x_fp4: (m, n/2) packed e2m1, scales: (m, n/32) e8m0 -> (e4m3 (n, m), e8m0 (n, m/32))."""
+    xq, xs = np.ascontiguousarray(_u8(x_fp4)), np.ascontiguousarray(_u8(scales))
+    m, n2 = xq.shape
+    n = n2 * 2
+    assert m % 32 == 0 and xs.shape == (m, n // 32)
+    y = np.empty((n, m), dtype=np.uint8)
+    e = np.empty((n, m // 32), dtype=np.uint8)
+    lib().orc_mxfp4_transpose_mxfp8(_p(xq), _p(xs), m, n, _p(y), _p(e))
+    return y, e
+

@@ -411,3 +411,152 @@ void orc_dequant_fp4(const uint8_t* packed, const uint8_t* sf_flat, int gs, int 
     out[i] = (double)orc_e2m1_decode(code) * s / (double)alpha;
   }
 }
+
+/* ------------------------------------------------------------------------------------------ */
+/* QAT-backward data-prep kernels (qutlass/csrc/quartet_bwd_sm120.cu)       */
+/* ------------------------------------------------------------------------------------------ */
+
+/* shared tail of quantize_g32t / quantize_g32qt (quartet_bwd_sm120.cu:304-323, :407-426):
+ *   scale = amax|y| [ / alpha ] ; scale &= 0x7f800000 ; e8m0 = bits >> 23 ;
+ *   q = y * (3.f / scale)   [ y * (3.f / (scale * alpha)) ] ; e2m1(q)
+ * NO epsilon (unlike fusedQuantizeMx abs_max): an all-zero group gives scale 0, 3/0 = inf, 0*inf = NaN,
+ * and cvt.rn.satfinite.e2m1x2 maps NaN to +6 (code 7) -- restated as is. */
+static void bwd_group_tail(const float* y, int use_alpha, float alpha, uint8_t* out16, uint8_t* out_e8m0) {
+  float amax = 0.f;
+  for (int i = 0; i < 32; ++i) {
+    float a = fabsf(y[i]);
+    if (a > amax) amax = a;
+  }
+  float scale = use_alpha ? amax / alpha : amax;
+  uint32_t sb;
+  memcpy(&sb, &scale, 4);
+  sb &= 0x7f800000u;
+  memcpy(&scale, &sb, 4);
+  *out_e8m0 = (uint8_t)(sb >> 23);
+  const float mult = use_alpha ? 3.f / (scale * alpha) : 3.f / scale;
+  float q[32];
+  for (int i = 0; i < 32; ++i) q[i] = y[i] * mult;
+  pack32(q, out16);
+}
+
+/*
+ * backward_t_bf16 (quartet_bwd_sm120.cu:237-325; wrapper qutlass/__init__.py:206-243; test oracle
+ * tests/quartet_test.py:155-173 applied to x.transpose(-2,-1), :239-245).
+ * x: (B, N, M) bf16.  Output row (b, m), group g: y_j = sum_k x[b][32g+k][m] * h[k][j]  (x^T rotated per 32
+ * along N), abs-max quantised.  out_e2m1: (B, M, N/2) bytes, out_e8m0: (B, M, N/32).
+ */
+void orc_backward_t_bf16(const uint16_t* x, const uint16_t* h, int64_t B, int64_t N, int64_t M, int acc_model,
+                         uint8_t* out_e2m1, uint8_t* out_e8m0) {
+  float hf[32 * 32];
+  for (int i = 0; i < 1024; ++i) hf[i] = bf16_to_f32(h[i]);
+  const int64_t G = N / 32;
+#pragma omp parallel for schedule(static)
+  for (int64_t bm = 0; bm < B * M; ++bm) {
+    const int64_t b = bm / M, m = bm % M;
+    for (int64_t g = 0; g < G; ++g) {
+      uint16_t col[32];
+      for (int k = 0; k < 32; ++k) col[k] = x[(b * N + 32 * g + k) * M + m];
+      float y[32];
+      rotate_group(col, hf, 32, acc_model, y);
+      bwd_group_tail(y, 0, 1.f, out_e2m1 + (bm * G + g) * 16, out_e8m0 + bm * G + g);
+    }
+  }
+}
+
+/*
+ * backward_qt_bf16 (quartet_bwd_sm120.cu:327-428; wrapper __init__.py:246-286; test quartet_test.py:247-260).
+ * x_e2m1: (B, N, M/2), x_e8m0: (B, N, M/32).  Operand = bf16( e2m1 value * 2^(e8m0-127) ) (:369-375: bf16 product of
+ * the decoded code and a bf16 whose bits are e8m0 << 7 -- exact), NOT divided by alpha; alpha enters the scale only.
+ */
+void orc_backward_qt_bf16(const uint8_t* x_e2m1, const uint8_t* x_e8m0, const uint16_t* h, float alpha, int64_t B,
+                          int64_t N, int64_t M, int acc_model, uint8_t* out_e2m1, uint8_t* out_e8m0) {
+  float hf[32 * 32];
+  for (int i = 0; i < 1024; ++i) hf[i] = bf16_to_f32(h[i]);
+  const int64_t G = N / 32;
+#pragma omp parallel for schedule(static)
+  for (int64_t bm = 0; bm < B * M; ++bm) {
+    const int64_t b = bm / M, m = bm % M;
+    for (int64_t g = 0; g < G; ++g) {
+      uint16_t col[32];
+      for (int k = 0; k < 32; ++k) {
+        const int64_t row = b * N + 32 * g + k;
+        const uint8_t byte = x_e2m1[row * (M / 2) + m / 2];
+        const uint8_t code = (m & 1) ? (byte >> 4) : (byte & 0xF);
+        const float sc = bf16_to_f32((uint16_t)((uint16_t)x_e8m0[row * (M / 32) + m / 32] << 7));
+        col[k] = f32_to_bf16_rne(orc_e2m1_decode(code) * sc);
+      }
+      float y[32];
+      rotate_group(col, hf, 32, acc_model, y);
+      bwd_group_tail(y, 1, alpha, out_e2m1 + (bm * G + g) * 16, out_e8m0 + bm * G + g);
+    }
+  }
+}
+
+/* encode_e8m0_shiftm8 (quartet_bwd_sm120.cu:503-509): 0 -> 127, else (biased exponent of bf16_rn(amax)) - 7
+ * (e8m0 conversion with round-toward-zero = the exponent field), in uint8 arithmetic. */
+static uint8_t e8m0_shift7(float amax) {
+  if (amax == 0.0f) return 127;
+  const uint16_t b = f32_to_bf16_rne(amax);
+  return (uint8_t)(((b >> 7) & 0xFF) - 7);
+}
+
+/* x / 2^(e-127) -> bf16_rn -> e4m3 satfinite RN (quartet_bwd_sm120.cu:580-586, :695-701).  qscale is the bf16 with bits
+ * e << 7 (e = 0 gives bits 0x0040 = 2^-127, __nv_cvt_e8m0_to_bf16raw). */
+static uint8_t requant_e4m3(float v, uint8_t e) {
+  const float qscale = bf16_to_f32(e ? (uint16_t)((uint16_t)e << 7) : (uint16_t)0x0040);
+  const float q = bf16_to_f32(f32_to_bf16_rne(v / qscale));
+  return orc_e4m3_encode(q);
+}
+
+/*
+ * backward_bf16_square_double_mxfp8 (quartet_bwd_sm120.cu:511-621; wrapper __init__.py:288-297; test oracle
+ * quartet_test.py:284-307).  x: (m, n) bf16, m % 32 == 0, n % 128 == 0.  One shared exponent per 32x32 block.
+ * y: (m, n) e4m3; row_scales: (m, n/32); col_scales: (n, m/32).
+ */
+void orc_backward_bf16_square_double_mxfp8(const uint16_t* x, int64_t m, int64_t n, uint8_t* y, uint8_t* row_scales,
+                                           uint8_t* col_scales) {
+  const int64_t BM = m / 32, BN = n / 32;
+#pragma omp parallel for schedule(static)
+  for (int64_t blk = 0; blk < BM * BN; ++blk) {
+    const int64_t bi = blk / BN, bj = blk % BN;
+    float amax = 0.f;
+    for (int r = 0; r < 32; ++r)
+      for (int c = 0; c < 32; ++c) amax = fmaxf(amax, fabsf(bf16_to_f32(x[(bi * 32 + r) * n + bj * 32 + c])));
+    const uint8_t e = e8m0_shift7(amax);
+    for (int r = 0; r < 32; ++r) {
+      row_scales[(bi * 32 + r) * BN + bj] = e;
+      col_scales[(bj * 32 + r) * BM + bi] = e;
+      for (int c = 0; c < 32; ++c)
+        y[(bi * 32 + r) * n + bj * 32 + c] = requant_e4m3(bf16_to_f32(x[(bi * 32 + r) * n + bj * 32 + c]), e);
+    }
+  }
+}
+
+/*
+ * mxfp4_transpose_mxfp8 (quartet_bwd_sm120.cu:628-733; wrapper __init__.py:299-315; test oracle
+ * quartet_test.py:310-366).  x_fp4: (m, n/2) packed e2m1, scales: (m, n/32) e8m0.  Dequantise to bf16 (value * scale,
+ * bf16_rn), transpose, one shared exponent per 32 along m.  y: (n, m) e4m3; out_e8m0: (n, m/32).  m % 32 == 0.
+ */
+void orc_mxfp4_transpose_mxfp8(const uint8_t* x_fp4, const uint8_t* scales, int64_t m, int64_t n, uint8_t* y,
+                               uint8_t* out_e8m0) {
+  const int64_t GM = m / 32;
+#pragma omp parallel for schedule(static)
+  for (int64_t col = 0; col < n; ++col) {
+    for (int64_t g = 0; g < GM; ++g) {
+      float v[32];
+      float amax = 0.f;
+      for (int k = 0; k < 32; ++k) {
+        const int64_t row = g * 32 + k;
+        const uint8_t byte = x_fp4[row * (n / 2) + col / 2];
+        const uint8_t code = (col & 1) ? (byte >> 4) : (byte & 0xF);
+        const uint8_t se = scales[row * (n / 32) + col / 32];
+        const float s_in = bf16_to_f32(se ? (uint16_t)((uint16_t)se << 7) : (uint16_t)0x0040);
+        v[k] = bf16_to_f32(f32_to_bf16_rne(orc_e2m1_decode(code) * s_in));
+        amax = fmaxf(amax, fabsf(v[k]));
+      }
+      const uint8_t e = e8m0_shift7(amax);
+      out_e8m0[col * GM + g] = e;
+      for (int k = 0; k < 32; ++k) y[col * m + g * 32 + k] = requant_e4m3(v[k], e);
+    }
+  }
+}

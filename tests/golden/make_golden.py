@@ -39,7 +39,8 @@ def load_reference():
     # Stub the compiled package so the test modules import; neutralise the CUDA requirement.
     stub = types.ModuleType("qutlass")
     for n in ("matmul_mxf4_bf16_tn", "fusedQuantizeMx", "matmul_nvf4_bf16_tn", "fusedQuantizeNv",
-              "matmul_mxf8_bf16_tn", "matmul_mxf8_bf16_nn"):
+              "matmul_mxf8_bf16_tn", "matmul_mxf8_bf16_nn", "backward_t_bf16", "backward_qt_bf16",
+              "backward_bf16_square_double_mxfp8", "mxfp4_transpose_mxfp8"):
         setattr(stub, n, None)
     stub.utils = utils
     sys.modules["qutlass"] = stub
@@ -52,6 +53,8 @@ def load_reference():
         mx = _load(os.path.join(REF, "tests", "mxfp4_test.py"), "ref_mxfp4_test")
         nv = _load(os.path.join(REF, "tests", "nvfp4_test.py"), "ref_nvfp4_test")
         f8 = _load(os.path.join(REF, "tests", "mxfp8_test.py"), "ref_mxfp8_test")
+        global QT
+        QT = _load(os.path.join(REF, "tests", "quartet_test.py"), "ref_quartet_test")
     finally:
         torch.cuda.is_available, torch.device, torch.compile = real_avail, real_device, real_compile
     return utils, mx, nv, f8
@@ -192,6 +195,46 @@ def main():
         case += 1
     d["ncases"] = np.array(case)
     np.savez_compressed(os.path.join(OUT, "gemm_mxfp8.npz"), **d)
+
+    # ---- QAT-backward data-prep oracles (quartet_test.py:155-173, 239-260, 284-366) ---------
+    qt = QT
+    d = {}
+    h = had(32)
+    # backward_t_bf16: x (B, N, M) -> abs-max MXFP4 of x^T rotated per 32 along N
+    for case, shape in enumerate([(1, 64, 96), (2, 128, 64), (1, 32, 8)]):
+        x = torch.randn(*shape, dtype=torch.bfloat16) * 25.0
+        _, (e2m1, e8m0) = qt._backward_quantize_ref(x.transpose(-2, -1), h)
+        d[f"t_x{case}"], d[f"t_e2m1_{case}"], d[f"t_e8m0_{case}"] = bits16(x), u8(e2m1), u8(e8m0)
+    d["t_ncases"] = np.array(3)
+    # backward_qt_bf16: abs-max MXFP4 input (reference MX oracle) -> dequant / 3, transpose, requantise
+    for case, shape in enumerate([(1, 64, 128), (2, 96, 64)]):
+        x = torch.randn(*shape, dtype=torch.bfloat16) * 25.0
+        _, _, (xq, xs, _) = mx._forward_quantize_ref(x, h, 32, quest=False)
+        xs = xs.reshape(*shape[:-1], shape[-1] // 32)
+        x_dq = qt._dq_fp4(xq, xs, alpha=3.0)[0]
+        dq_ref, (e2m1, e8m0) = qt._backward_quantize_ref(x_dq.transpose(-2, -1), h)
+        d[f"qt_xq{case}"], d[f"qt_xs{case}"] = u8(xq), u8(xs)
+        d[f"qt_e2m1_{case}"], d[f"qt_e8m0_{case}"] = u8(e2m1), u8(e8m0)
+        d[f"qt_dq{case}"] = dq_ref.to(torch.float32).numpy()
+    d["qt_ncases"] = np.array(2)
+    d["h"] = bits16(h)
+    # backward_bf16_square_double_mxfp8 (the reference's own test input: arange rows, plus random and a zero block)
+    xs_ = [torch.arange(0, 256, dtype=torch.bfloat16)[None, :].repeat(160, 1),
+           torch.randn(128, 128, dtype=torch.bfloat16) * 25.0]
+    xs_[1][32:64, 64:96] = 0
+    for case, x in enumerate(xs_):
+        y, rs, cs = qt._backward_bf16_square_double_mxfp8(x)
+        d[f"sq_x{case}"], d[f"sq_y{case}"], d[f"sq_rs{case}"], d[f"sq_cs{case}"] = bits16(x), u8(y), u8(rs), u8(cs)
+    d["sq_ncases"] = np.array(2)
+    # mxfp4_transpose_mxfp8
+    for case, shape in enumerate([(256, 128), (512, 64)]):
+        x = torch.randn(*shape, dtype=torch.bfloat16) * 25.0
+        _, _, (xq, xs, _) = mx._forward_quantize_ref(x, torch.eye(32, dtype=torch.bfloat16), 32, quest=False)
+        xs = xs.reshape(shape[0], shape[1] // 32)
+        y, e = qt._mxfp4_transpose_mxfp8(xq.clone(), xs.clone().view(torch.uint8))
+        d[f"tr_xq{case}"], d[f"tr_xs{case}"], d[f"tr_y{case}"], d[f"tr_e{case}"] = u8(xq), u8(xs), u8(y), u8(e)
+    d["tr_ncases"] = np.array(2)
+    np.savez_compressed(os.path.join(OUT, "quartet_bwd.npz"), **d)
 
     for f in sorted(os.listdir(OUT)):
         if f.endswith(".npz"):

@@ -140,3 +140,55 @@ def test_mxfp8_pseudoquant_and_gemm(golden_dir):
         d2 = oracle.gemm_blockscaled(oracle.KIND_MXFP8_NN, a_t, g[f"b{c}"], _blocked(g[f"asf{c}"]),
                                      _blocked(g[f"bsf{c}"]), 1.0, m, n, k)
         assert np.array_equal(d2, d), c
+
+
+# ---- QAT-backward data-prep kernels -----------------------------------------------------------
+def _dq_mx(codes_u8, e8m0_u8, alpha):
+    """(.., K/2) packed e2m1 + (.., K/32) e8m0 -> float64 dequantised values / alpha (tests/quartet_test.py:76-104)."""
+    lut = np.array([0, .5, 1, 1.5, 2, 3, 4, 6, -0., -.5, -1, -1.5, -2, -3, -4, -6], dtype=np.float64)
+    c = codes_u8.astype(np.int32)
+    v = np.stack([lut[c & 0xF], lut[c >> 4]], axis=-1).reshape(*c.shape[:-1], -1)
+    s = np.ldexp(1.0, e8m0_u8.astype(np.int32) - 127)
+    return (v.reshape(*v.shape[:-1], -1, 32) * s[..., None]).reshape(v.shape) / alpha
+
+
+def test_backward_t_bf16_vs_reference_oracle(golden_dir):
+    g = _load(golden_dir, "quartet_bwd.npz")
+    for c in range(int(g["t_ncases"])):
+        for acc_model in (0, 1):
+            q, s = oracle.backward_t_bf16(g[f"t_x{c}"], g["h"], acc_model)
+            want_q, want_s = g[f"t_e2m1_{c}"], g[f"t_e8m0_{c}"]
+            assert np.array_equal(s.reshape(want_s.shape), want_s), (c, acc_model)          # e8m0: bit-exact
+            eq = oracle.codes_equal_mod_zero_sign(q.reshape(want_q.shape), want_q)
+            assert (~eq).sum() <= 2e-3 * eq.size, (c, acc_model, int((~eq).sum()))            # fp32 vs fp64 rotation ties
+
+
+def test_backward_qt_bf16_vs_reference_oracle(golden_dir):
+    g = _load(golden_dir, "quartet_bwd.npz")
+    for c in range(int(g["qt_ncases"])):
+        q, s = oracle.backward_qt_bf16(g[f"qt_xq{c}"], g[f"qt_xs{c}"], g["h"], 3.0, acc_model=1)
+        want_s, want_dq = g[f"qt_e8m0_{c}"], g[f"qt_dq{c}"]
+        assert np.array_equal(s.reshape(want_s.shape), want_s), c
+        # the reference asserts equality of the DEQUANTISED values (quartet_test.py:258-260)
+        got_dq = _dq_mx(q.reshape(want_s.shape[:-1] + (-1,)), s.reshape(want_s.shape), 3.0)
+        bad = (got_dq.astype(np.float32) != want_dq.reshape(got_dq.shape)).sum()
+        assert bad <= 2e-3 * got_dq.size, (c, int(bad))
+
+
+def test_backward_bf16_square_double_mxfp8_bit_exact(golden_dir):
+    g = _load(golden_dir, "quartet_bwd.npz")
+    for c in range(int(g["sq_ncases"])):
+        x = g[f"sq_x{c}"]
+        pad = (-x.shape[0]) % 128            # the reference wrapper / oracle pad rows to a multiple of 128
+        xp = np.concatenate([x, np.zeros((pad, x.shape[1]), dtype=x.dtype)]) if pad else x
+        y, rs, cs = oracle.backward_bf16_square_double_mxfp8(xp)
+        assert np.array_equal(rs, g[f"sq_rs{c}"]) and np.array_equal(cs, g[f"sq_cs{c}"]), c
+        assert np.array_equal(y, g[f"sq_y{c}"]), (c, int((y != g[f"sq_y{c}"]).sum()))
+
+
+def test_mxfp4_transpose_mxfp8_bit_exact(golden_dir):
+    g = _load(golden_dir, "quartet_bwd.npz")
+    for c in range(int(g["tr_ncases"])):
+        y, e = oracle.mxfp4_transpose_mxfp8(g[f"tr_xq{c}"], g[f"tr_xs{c}"])
+        assert np.array_equal(e, g[f"tr_e{c}"]), c
+        assert np.array_equal(y, g[f"tr_y{c}"]), (c, int((y != g[f"tr_y{c}"]).sum()))
