@@ -100,6 +100,44 @@ int qutlass_amd_fused_quantize_nv(const void* x, const void* h, int rot, int64_t
                                   const float* global_scale, void* out_e2m1, void* out_e4m3,
                                   void* stream);
 
+/* ---- QAT-backward data preparation ------------------------------------- */
+
+/*
+ * x: bf16 (B, N, M) row-major; h: bf16 32 x 32.  For every (b, m) and every 32-group g along N:
+ * y = x[b, 32g..32g+31, m] . h, abs-max MXFP4 (no epsilon, x3 before rounding).  out_e2m1: (B, M, N/2) bytes,
+ * out_e8m0: (B, M, N/32) bytes.  N % 32 == 0, M % 8 == 0.
+ * Replaces backward_t_bf16_cuda (qutlass/csrc/quartet_bwd_sm120.cu:237-325,430-454; include/backward_host.h:17-26;
+ * bindings.cpp:429-443).
+ */
+int qutlass_amd_backward_t_bf16(const void* x, const void* h, int64_t B, int64_t N, int64_t M, void* out_e2m1,
+                                void* out_e8m0, void* stream);
+
+/*
+ * The same on an MXFP4 operand: x_e2m1 (B, N, M/2) bytes, x_e8m0 (B, N, M/32); alpha: device fp32[1] (enters the
+ * scale only: e8m0 = floor_pow2(amax / alpha), q = y * 3 / (scale * alpha)).  N % 32 == 0, M % 32 == 0.
+ * Replaces backward_qt_bf16_cuda (quartet_bwd_sm120.cu:327-428,457-483; backward_host.h:4-15; bindings.cpp:445-464).
+ */
+int qutlass_amd_backward_qt_bf16(const void* x_e2m1, const void* x_e8m0, const void* h, const float* alpha, int64_t B,
+                                 int64_t N, int64_t M, void* out_e2m1, void* out_e8m0, void* stream);
+
+/*
+ * x: bf16 (m, n).  One shared exponent per 32 x 32 block (floor(log2 amax) - 7, 127 for an all-zero block);
+ * y: e4m3 (m, n); row_scales: e8m0 (m, n/32); col_scales: e8m0 (n, m/32).  m % 128 == 0 and n % 128 == 0 (the
+ * reference wrapper pads m to 128 and launches n/128 blocks, qutlass/__init__.py:288-297, quartet_bwd_sm120.cu:596).
+ * Replaces backward_bf16_square_double_mxfp8_cuda (quartet_bwd_sm120.cu:511-621; bindings.cpp:466-479).
+ */
+int qutlass_amd_backward_bf16_square_double_mxfp8(const void* x, int64_t m, int64_t n, void* y, void* row_scales,
+                                                  void* col_scales, void* stream);
+
+/*
+ * x_fp4: packed e2m1 (m, n/2), scales: e8m0 (m, n/32).  y: e4m3 (n, m) = requantised transpose with one shared
+ * exponent per 32 along m; out_e8m0: (n, m/32).  m % 128 == 0, n % 256 == 0 (the reference pads m to 256 and launches
+ * n/256 blocks, __init__.py:299-315, quartet_bwd_sm120.cu:716).
+ * Replaces mxfp4_transpose_mxfp8_cuda (quartet_bwd_sm120.cu:628-733; bindings.cpp:481-494).
+ */
+int qutlass_amd_mxfp4_transpose_mxfp8(const void* x_fp4, const void* scales, int64_t m, int64_t n, void* y,
+                                      void* out_e8m0, void* stream);
+
 /* ---- block-scale swizzle ------------------------------------------------------------------------ */
 
 /*

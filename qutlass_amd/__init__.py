@@ -5,6 +5,7 @@ meaning, defaults and Python-level error behaviour):
 
     fusedQuantizeMx, fusedQuantizeNv, matmul_mxf4_bf16_tn, matmul_nvf4_bf16_tn,
     matmul_mxf8_bf16_tn, matmul_mxf8_bf16_nn         (+ qutlass_amd.utils.to_blocked & friends)
+    backward_t_bf16, backward_qt_bf16, backward_bf16_square_double_mxfp8, mxfp4_transpose_mxfp8
 
 All compute is hand-written HIP behind the C ABI of ``include/qutlass_amd.h``
 (``libqutlass_amd.so``); importing this package loads that library and registers
@@ -109,8 +110,63 @@ def fusedQuantizeNv(a: torch.Tensor, b: torch.Tensor, global_scale: torch.Tensor
         raise ValueError(f"invalid method {method!r}, must be 'quest' or 'abs_max'")
 
 
-_OUT_OF_SCOPE = ("matmul_ada_mxf4_bf16_tn", "backward_t_bf16", "backward_qt_bf16",
-                 "backward_bf16_square_double_mxfp8", "mxfp4_transpose_mxfp8")
+def backward_t_bf16(x: torch.Tensor, h: torch.Tensor, xh_e2m1: torch.Tensor = None,
+                    xh_e8m0: torch.Tensor = None) -> tuple[torch.Tensor, torch.Tensor]:
+    """qutlass/__init__.py:206-243: abs-max MXFP4 of x^T (last two dims swapped) rotated per 32 along the old
+    second-to-last dim.  Outputs (.., M, N/2) float4_e2m1fn_x2 and (.., M, N/32) e8m0 for x of shape (.., N, M)."""
+    if xh_e2m1 is None:
+        xh_e2m1 = torch.empty(*x.shape[:-2], x.size(-1), x.size(-2) // 2, dtype=torch.float4_e2m1fn_x2, device=h.device)
+    if xh_e8m0 is None:
+        xh_e8m0 = torch.empty(*x.shape[:-2], x.size(-1), x.size(-2) // 32, dtype=torch.float8_e8m0fnu, device=h.device)
+    assert x.dtype == h.dtype == torch.bfloat16
+    assert xh_e2m1.dtype == torch.float4_e2m1fn_x2 and xh_e8m0.dtype == torch.float8_e8m0fnu
+    assert x.is_contiguous() and h.is_contiguous() and xh_e2m1.is_contiguous() and xh_e8m0.is_contiguous()
+    qutlass_CUDA.backward_t_bf16(x, h, xh_e2m1, xh_e8m0)
+    return xh_e2m1, xh_e8m0
+
+
+def backward_qt_bf16(x_e2m1: torch.Tensor, x_e8m0: torch.Tensor, h: torch.Tensor, alpha: torch.Tensor,
+                     xh_e2m1: torch.Tensor = None, xh_e8m0: torch.Tensor = None) -> tuple[torch.Tensor, torch.Tensor]:
+    """qutlass/__init__.py:246-286: the same on an MXFP4 operand (x_e2m1 (.., N, M/2), x_e8m0 (.., N, M/32))."""
+    if xh_e2m1 is None:
+        xh_e2m1 = torch.empty(*x_e2m1.shape[:-2], x_e2m1.size(-1) * 2, x_e2m1.size(-2) // 2,
+                              dtype=torch.float4_e2m1fn_x2, device=h.device)
+    if xh_e8m0 is None:
+        xh_e8m0 = torch.empty(*x_e8m0.shape[:-2], x_e8m0.size(-1) * 32, x_e8m0.size(-2) // 32,
+                              dtype=torch.float8_e8m0fnu, device=h.device)
+    assert (x_e2m1.is_contiguous() and x_e8m0.is_contiguous() and h.is_contiguous()
+            and xh_e2m1.is_contiguous() and xh_e8m0.is_contiguous())
+    qutlass_CUDA.backward_qt_bf16(x_e2m1, x_e8m0, h, alpha, xh_e2m1, xh_e8m0)
+    return xh_e2m1, xh_e8m0
+
+
+def backward_bf16_square_double_mxfp8(x_bf16: torch.Tensor) -> tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    """qutlass/__init__.py:288-297: e4m3 with one e8m0 per 32 x 32 block, returned row-wise (m, n/32) and column-wise
+    (n, m/32); rows are zero-padded to a multiple of 128 first, as in the reference."""
+    if x_bf16.size(0) % 128 != 0:
+        x_bf16 = pad_to_block(x_bf16, [0], 128)
+    x_fp8 = torch.empty_like(x_bf16, dtype=torch.float8_e4m3fn)
+    row_scales = torch.empty(x_bf16.shape[0], x_bf16.shape[1] // 32, device=x_bf16.device, dtype=torch.float8_e8m0fnu)
+    column_scales = torch.empty(x_bf16.shape[1], x_bf16.shape[0] // 32, device=x_bf16.device, dtype=torch.float8_e8m0fnu)
+    qutlass_CUDA.backward_bf16_square_double_mxfp8(x_bf16, x_fp8, row_scales, column_scales)
+    return x_fp8, row_scales, column_scales
+
+
+def mxfp4_transpose_mxfp8(x_fp4: torch.Tensor, scales: torch.Tensor) -> tuple[torch.Tensor, torch.Tensor]:
+    """qutlass/__init__.py:299-315: MXFP4 (m, n/2) + e8m0 (m, n/32) -> transposed e4m3 (n, m) + e8m0 (n, m/32).
+    Rows are padded to a multiple of 256 with zero codes and unit scales first, as in the reference."""
+    if x_fp4.size(0) % 256 != 0:
+        m = x_fp4.shape[0]
+        m_up = ((m - 1) // 256) * 256 + 256
+        x_fp4 = pad_to_block(x_fp4, [0], 256)
+        scales[m:m_up] = 1.0
+    x_fp8 = torch.empty(x_fp4.shape[1] * 2, x_fp4.shape[0], device=x_fp4.device, dtype=torch.float8_e4m3fn)
+    shared_exps = torch.empty(x_fp4.shape[1] * 2, x_fp4.shape[0] // 32, device=x_fp4.device, dtype=torch.float8_e8m0fnu)
+    qutlass_CUDA.mxfp4_transpose_mxfp8(x_fp4, scales, x_fp8, shared_exps)
+    return x_fp8, shared_exps
+
+
+_OUT_OF_SCOPE = ("matmul_ada_mxf4_bf16_tn",)
 
 
 def __getattr__(name):

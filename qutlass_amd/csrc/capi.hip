@@ -1,6 +1,7 @@
 // C ABI (include/qutlass_amd.h) -> kernel launches.  No torch types, no allocation, no sync.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <atomic>
 #include <cstdarg>
 #include <cstdio>
@@ -12,6 +13,7 @@
 #include "quantize.hip.h"
 #include "to_blocked.hip.h"
 #include "transpose_u8.hip.h"
+#include "quartet_bwd.hip.h"
 
 using namespace qamd;
 
@@ -271,6 +273,69 @@ int qutlass_amd_fused_quantize_nv(const void* x, const void* h, int rot, int64_t
   hipStream_t s = (hipStream_t)stream;
   if (method == QAMD_METHOD_QUEST) return dispatch_rot<true, METHOD_QUEST, false>(rot, p, s, grid, name);
   return dispatch_rot<true, METHOD_ABSMAX, false>(rot, p, s, grid, name);
+}
+
+int qutlass_amd_backward_t_bf16(const void* x, const void* h, int64_t B, int64_t N, int64_t M, void* out_e2m1,
+                                void* out_e8m0, void* stream) {
+  const char* name = "backward_t_bf16";
+  if (!x || !h || !out_e2m1 || !out_e8m0) return fail(QAMD_ERR_INVALID, "%s: null pointer argument", name);
+  if (B <= 0 || N <= 0 || M <= 0 || N % 32 || M % 8)
+    return fail(QAMD_ERR_INVALID, "%s: need N %% 32 == 0 and M %% 8 == 0 (got B=%lld N=%lld M=%lld)", name, (long long)B, (long long)N, (long long)M);
+  if (B * N * M >= (1ll << 40)) return fail(QAMD_ERR_INVALID, "%s: tensor too large", name);
+  BwdTParams p{};
+  p.x = (const uint16_t*)x; p.h = (const uint16_t*)h; p.out = (uint8_t*)out_e2m1; p.out_sf = (uint8_t*)out_e8m0;
+  p.B = (int)B; p.N = (int)N; p.M = (int)M; p.tiles_m = (int)cdiv(M, 64);
+  p.ntiles = B * (N / 32) * p.tiles_m;
+  const int grid = (int)std::min<int64_t>(cdiv(p.ntiles, 4), 256 * 16);
+  if (g_hw_fp4_cvt.load()) hipLaunchKernelGGL((bwd_quant_t_kernel<false, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
+  else hipLaunchKernelGGL((bwd_quant_t_kernel<false, false>), dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
+  return check_launch("bwd_quant_t_kernel");
+}
+
+int qutlass_amd_backward_qt_bf16(const void* x_e2m1, const void* x_e8m0, const void* h, const float* alpha, int64_t B,
+                                 int64_t N, int64_t M, void* out_e2m1, void* out_e8m0, void* stream) {
+  const char* name = "backward_qt_bf16";
+  if (!x_e2m1 || !x_e8m0 || !h || !alpha || !out_e2m1 || !out_e8m0) return fail(QAMD_ERR_INVALID, "%s: null pointer argument", name);
+  if (B <= 0 || N <= 0 || M <= 0 || N % 32 || M % 32)
+    return fail(QAMD_ERR_INVALID, "%s: need N %% 32 == 0 and M %% 32 == 0 (got B=%lld N=%lld M=%lld)", name, (long long)B, (long long)N, (long long)M);
+  if (B * N * M >= (1ll << 40)) return fail(QAMD_ERR_INVALID, "%s: tensor too large", name);
+  BwdTParams p{};
+  p.xq = (const uint8_t*)x_e2m1; p.xs = (const uint8_t*)x_e8m0; p.h = (const uint16_t*)h; p.alpha = alpha;
+  p.out = (uint8_t*)out_e2m1; p.out_sf = (uint8_t*)out_e8m0;
+  p.B = (int)B; p.N = (int)N; p.M = (int)M; p.tiles_m = (int)cdiv(M, 64);
+  p.ntiles = B * (N / 32) * p.tiles_m;
+  const int grid = (int)std::min<int64_t>(cdiv(p.ntiles, 4), 256 * 16);
+  if (g_hw_fp4_cvt.load()) hipLaunchKernelGGL((bwd_quant_t_kernel<true, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
+  else hipLaunchKernelGGL((bwd_quant_t_kernel<true, false>), dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
+  return check_launch("bwd_quant_t_kernel");
+}
+
+int qutlass_amd_backward_bf16_square_double_mxfp8(const void* x, int64_t m, int64_t n, void* y, void* row_scales,
+                                                  void* col_scales, void* stream) {
+  const char* name = "backward_bf16_square_double_mxfp8";
+  if (!x || !y || !row_scales || !col_scales) return fail(QAMD_ERR_INVALID, "%s: null pointer argument", name);
+  if (m <= 0 || n <= 0 || m % 128 || n % 128)
+    return fail(QAMD_ERR_INVALID, "%s: m and n must be positive multiples of 128 (got m=%lld n=%lld)", name, (long long)m, (long long)n);
+  if (m >= (1ll << 31) || n >= (1ll << 31) || (m / 128) * (n / 128) >= (1ll << 31)) return fail(QAMD_ERR_INVALID, "%s: tensor too large", name);
+  SqParams p;
+  p.x = (const uint16_t*)x; p.y = (uint8_t*)y; p.row_sf = (uint8_t*)row_scales; p.col_sf = (uint8_t*)col_scales;
+  p.m = (int)m; p.n = (int)n;
+  hipLaunchKernelGGL(bwd_square_double_mxfp8_kernel, dim3((unsigned)((m / 128) * (n / 128))), dim3(256), 0, (hipStream_t)stream, p);
+  return check_launch("bwd_square_double_mxfp8_kernel");
+}
+
+int qutlass_amd_mxfp4_transpose_mxfp8(const void* x_fp4, const void* scales, int64_t m, int64_t n, void* y,
+                                      void* out_e8m0, void* stream) {
+  const char* name = "mxfp4_transpose_mxfp8";
+  if (!x_fp4 || !scales || !y || !out_e8m0) return fail(QAMD_ERR_INVALID, "%s: null pointer argument", name);
+  if (m <= 0 || n <= 0 || m % 128 || n % 256)
+    return fail(QAMD_ERR_INVALID, "%s: need m %% 128 == 0 and n %% 256 == 0 (got m=%lld n=%lld)", name, (long long)m, (long long)n);
+  if (m >= (1ll << 31) || n >= (1ll << 31) || (m / 128) * (n / 256) >= (1ll << 31)) return fail(QAMD_ERR_INVALID, "%s: tensor too large", name);
+  TrParams p;
+  p.xq = (const uint8_t*)x_fp4; p.xs = (const uint8_t*)scales; p.y = (uint8_t*)y; p.out_sf = (uint8_t*)out_e8m0;
+  p.m = (int)m; p.n = (int)n;
+  hipLaunchKernelGGL(mxfp4_transpose_mxfp8_kernel, dim3((unsigned)((m / 128) * (n / 256))), dim3(256), 0, (hipStream_t)stream, p);
+  return check_launch("mxfp4_transpose_mxfp8_kernel");
 }
 
 int qutlass_amd_to_blocked(const void* in, int64_t rows, int64_t cols, void* out, void* stream) {

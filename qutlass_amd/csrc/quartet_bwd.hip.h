@@ -1,0 +1,297 @@
+// QAT-backward data-prep kernels for gfx950.  All four are HBM-bound byte movers
+// with a block reduction; they replace qutlass/csrc/quartet_bwd_sm120.cu:237-734 of the reference:
+//
+//   backward_t_bf16                    x (B,N,M) bf16          -> abs-max MXFP4 of x^T rotated per 32 along N
+//   backward_qt_bf16                   MXFP4 (B,N,M) + alpha   -> the same on the dequantised operand
+//   backward_bf16_square_double_mxfp8  x (m,n) bf16            -> e4m3 with ONE e8m0 per 32x32 block, emitted row- and column-wise
+//   mxfp4_transpose_mxfp8              MXFP4 (m,n)             -> transposed e4m3 (n,m) with e8m0 per 32 along m
+//
+// CDNA4 mapping: the transposing quantisers stage a [32 n][64 m] bf16 tile per wave in LDS (coalesced 16-byte
+// row loads in, 2-byte column reads out) so that the rotation runs on the same transposed bf16 MFMA as
+// quantize.hip.h (lane = one output row, 16 of the 32 group values in registers, one v_permlane32_swap per
+// reduction); format conversions are the hardware ones (v_cvt_scalef32_pk_bf16_fp4, v_cvt_scalef32_pk_fp8_bf16,
+// v_cvt_scalef32_pk_fp4_f32), whose power-of-two scale operand performs the block scaling for free.
+#pragma once
+#include "common.hip.h"
+#include "quantize.hip.h"
+
+namespace qamd {
+
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef short i16x2 __attribute__((ext_vector_type(2)));
+
+// ----------------------------------------------------------------------------------------------------------------
+// backward_t_bf16 / backward_qt_bf16
+// ----------------------------------------------------------------------------------------------------------------
+struct BwdTParams {
+  const uint16_t* x;        // T: bf16 (B, N, M)
+  const uint8_t* xq;        // QT: packed e2m1 (B, N, M/2)
+  const uint8_t* xs;        // QT: e8m0 (B, N, M/32)
+  const uint16_t* h;        // bf16 32 x 32, row-major
+  const float* alpha;       // QT only (device scalar)
+  uint8_t* out;             // e2m1 (B, M, N/2)
+  uint8_t* out_sf;          // e8m0 (B, M, N/32)
+  int B, N, M;
+  int tiles_m;              // ceil(M / 64)
+  int64_t ntiles;           // B * (N/32) * tiles_m : one wave-tile = 32 n x 64 m of one batch entry
+};
+
+// One wave = one [32 n][64 m] tile = one scale group for 64 output rows.
+template <bool QT, bool HWCVT>
+__global__ __launch_bounds__(256) void bwd_quant_t_kernel(const BwdTParams p) {
+  constexpr int LROW = 64 * 2 + 4;   // LDS row stride (bytes): 32 dwords + 1 -> column reads of 2 bytes stay conflict-free
+  constexpr int HROW = 32 * 2 + 16;
+  __shared__ __attribute__((aligned(16))) char tile_s[4][32 * LROW];
+  __shared__ __attribute__((aligned(16))) char hT[32 * HROW];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = uniform(tid >> 6);
+  const int row = lane & 31, half = lane >> 5;
+  for (int idx = tid; idx < 32 * 32; idx += 256) {   // hT[j][k] = h[k][j]
+    const int k = idx >> 5, j = idx & 31;
+    *(uint16_t*)(hT + j * HROW + k * 2) = p.h[k * 32 + j];
+  }
+  __syncthreads();
+  v8bf hf[2];   // H^T operand of the two K = 16 MFMAs (runtime matrix, loaded once)
+#pragma unroll
+  for (int kc = 0; kc < 2; ++kc) hf[kc] = *(const v8bf*)(hT + row * HROW + (kc * 16 + half * 8) * 2);
+
+  char* ts = tile_s[wave];
+  const float alpha = QT ? *p.alpha : 1.0f;
+  const int G = p.N >> 5;
+  const int64_t wave_global = (int64_t)blockIdx.x * 4 + wave, nwaves = (int64_t)gridDim.x * 4;
+  for (int64_t t = wave_global; t < p.ntiles; t += nwaves) {
+    const int tm = (int)(t % p.tiles_m);
+    const int g = (int)((t / p.tiles_m) % G);
+    const int b = (int)(t / ((int64_t)p.tiles_m * G));
+    const int m0 = tm * 64, n0 = g * 32;
+
+    // ---- stage the [32 n][64 m] bf16 tile in LDS ---------------------------------------------------------------
+    if (!QT) {
+      // lane -> row lane/8 (+8 per pass), 16-byte chunk lane%8 (8 m): one pass = 8 rows x 128 B
+#pragma unroll
+      for (int ps = 0; ps < 4; ++ps) {
+        const int r = ps * 8 + (lane >> 3), c = (lane & 7) * 8;
+        v4i v = {0, 0, 0, 0};
+        if (m0 + c < p.M) {   // M % 8 == 0 (host-checked): a chunk is in or out as a whole
+          const uint16_t* src = p.x + ((int64_t)b * p.N + n0 + r) * p.M + m0 + c;
+          v = *(const v4i*)src;
+        }
+        // LROW is not a multiple of 16: four dword stores
+        int* d = (int*)(ts + r * LROW + c * 2);
+        d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; d[3] = v[3];
+      }
+    } else {
+      // packed input: lane -> row lane/2, 16-byte half (32 codes = one input scale group)
+      const int r = lane >> 1, c = (lane & 1) * 32;
+      uint32_t w[4] = {0, 0, 0, 0};
+      float sc = 1.0f;
+      if (m0 + c < p.M) {     // M % 32 == 0 (host-checked)
+        const int64_t rowi = (int64_t)b * p.N + n0 + r;
+        const v4i v = *(const v4i*)(p.xq + rowi * (p.M >> 1) + ((m0 + c) >> 1));
+        w[0] = v[0]; w[1] = v[1]; w[2] = v[2]; w[3] = v[3];
+        const uint32_t e = p.xs[rowi * (p.M >> 5) + ((m0 + c) >> 5)];
+        sc = __uint_as_float(e ? (e << 23) : 0x00400000u);   // 2^(e-127); e = 0 -> 2^-127 (denormal)
+      }
+      int* d = (int*)(ts + r * LROW + c * 2);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+#pragma unroll
+        for (int bsel = 0; bsel < 4; ++bsel) {
+          bf16x2 v2;
+          if (bsel == 0) v2 = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp4(w[q], sc, 0);
+          if (bsel == 1) v2 = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp4(w[q], sc, 1);
+          if (bsel == 2) v2 = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp4(w[q], sc, 2);
+          if (bsel == 3) v2 = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp4(w[q], sc, 3);
+          d[q * 4 + bsel] = __builtin_bit_cast(int, v2);
+        }
+      }
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): the wave's own LDS writes landed (wave-private tile)
+    __builtin_amdgcn_wave_barrier();
+
+#pragma unroll
+    for (int mh = 0; mh < 2; ++mh) {
+      const int mloc = mh * 32 + row;
+      // X^T operand: lane (m, half), chunk kc -> x[n0 + 16 kc + 8 half + i][m], i = 0..7
+      v16f acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+      for (int kc = 0; kc < 2; ++kc) {
+        v8u16 xv;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) xv[i] = *(const uint16_t*)(ts + (kc * 16 + half * 8 + i) * LROW + mloc * 2);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(hf[kc], __builtin_bit_cast(v8bf, xv), acc, 0, 0, 0);
+      }
+      // acc[4q+e] = y[m][8q + 4 half + e]   (quartet_bwd_sm120.cu:304-323 / :407-426)
+      float amax = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) amax = fmaxf(amax, fabsf(acc[r]));
+      amax = xhalf_max(amax);
+      float scale = QT ? amax / alpha : amax;
+      const uint32_t sb = __float_as_uint(scale) & 0x7f800000u;
+      scale = __uint_as_float(sb);
+      const float mult = QT ? 3.0f / (scale * alpha) : 3.0f / scale;
+      float tq[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) tq[r] = acc[r] * mult;
+      const uint32_t P = e2m1_pack8<HWCVT>(tq);
+      const uint32_t Q = e2m1_pack8<HWCVT>(tq + 8);
+      auto sw = __builtin_amdgcn_permlane32_swap(P, Q, false, false);
+      const uint32_t X = sw[0], Y = sw[1];
+      v2i o;
+      o[0] = (int)((X & 0xffffu) | (Y << 16));
+      o[1] = (int)((X >> 16) | (Y & 0xffff0000u));
+      const int m = m0 + mloc;
+      if (m < p.M) {
+        const int64_t grp = ((int64_t)b * p.M + m) * G + g;
+        *(v2i*)(p.out + grp * 16 + half * 8) = o;
+        if (half == 0) p.out_sf[grp] = (uint8_t)(sb >> 23);
+      }
+    }
+    __builtin_amdgcn_wave_barrier();   // all column reads of this tile issued before the next tile's stores
+  }
+}
+
+// ----------------------------------------------------------------------------------------------------------------
+// backward_bf16_square_double_mxfp8: one workgroup = 128 x 128 elements = 4 x 4 blocks; wave w = rows 32w..32w+31.
+// ----------------------------------------------------------------------------------------------------------------
+struct SqParams {
+  const uint16_t* x;   // bf16 (m, n)
+  uint8_t* y;          // e4m3 (m, n)
+  uint8_t* row_sf;     // e8m0 (m, n/32)
+  uint8_t* col_sf;     // e8m0 (n, m/32)
+  int m, n;            // both multiples of 128 (host-checked)
+};
+
+// exponent byte of encode_e8m0_shiftm8 (quartet_bwd_sm120.cu:503-509): amax is a bf16 value held in fp32
+__device__ __forceinline__ uint32_t e8m0_shift7(float amax) {
+  return amax == 0.0f ? 127u : ((__float_as_uint(amax) >> 23) - 7u) & 0xffu;
+}
+__device__ __forceinline__ float e8m0_scale(uint32_t e) { return __uint_as_float(e ? (e << 23) : 0x00400000u); }
+
+__global__ __launch_bounds__(256) void bwd_square_double_mxfp8_kernel(const SqParams p) {
+  __shared__ uint8_t es[4][4];   // [wave = row block][column block]
+  const int tid = threadIdx.x, lane = tid & 63, wave = uniform(tid >> 6);
+  const int tiles_n = p.n >> 7;
+  const int ti = blockIdx.x / tiles_n, tj = blockIdx.x % tiles_n;
+  const int r0 = ti * 128 + wave * 32, c0 = tj * 128;
+  // lane -> row lane/16 (+4 per pass), 16-byte chunk lane%16 (8 columns); column block j = (lane%16)/4
+  const int lr = lane >> 4, lc = (lane & 15) * 8;
+  v4i v[8];
+  float amax = 0.f;
+#pragma unroll
+  for (int ps = 0; ps < 8; ++ps) {
+    v[ps] = *(const v4i*)(p.x + (int64_t)(r0 + ps * 4 + lr) * p.n + c0 + lc);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const uint32_t w = (uint32_t)v[ps][q];
+      amax = fmaxf(amax, fmaxf(fabsf(__uint_as_float(w << 16)), fabsf(__uint_as_float(w & 0xffff0000u))));
+    }
+  }
+  // reduce over the lanes of the same column block: lane = 16 a + 4 j + c  ->  xor 1, 2 (c) and 16, 32 (a)
+  amax = fmaxf(amax, __shfl_xor(amax, 1));
+  amax = fmaxf(amax, __shfl_xor(amax, 2));
+  amax = fmaxf(amax, __shfl_xor(amax, 16));
+  amax = xhalf_max(amax);
+  const uint32_t e = e8m0_shift7(amax);
+  const float qs = e8m0_scale(e);
+#pragma unroll
+  for (int ps = 0; ps < 8; ++ps) {
+    // (hipcc 7.2 folds the four conversions of one v4i into two when the sources are vector elements: it selects the
+    //  same source register for both halves -- keep the sources as opaque scalars)
+    int s0 = v[ps][0], s1 = v[ps][1], s2 = v[ps][2], s3 = v[ps][3];
+    asm volatile("" : "+v"(s0), "+v"(s1), "+v"(s2), "+v"(s3));
+    i16x2 lo = {0, 0}, hi = {0, 0};
+    lo = __builtin_amdgcn_cvt_scalef32_pk_fp8_bf16(lo, __builtin_bit_cast(bf16x2, s0), qs, false);
+    lo = __builtin_amdgcn_cvt_scalef32_pk_fp8_bf16(lo, __builtin_bit_cast(bf16x2, s1), qs, true);
+    hi = __builtin_amdgcn_cvt_scalef32_pk_fp8_bf16(hi, __builtin_bit_cast(bf16x2, s2), qs, false);
+    hi = __builtin_amdgcn_cvt_scalef32_pk_fp8_bf16(hi, __builtin_bit_cast(bf16x2, s3), qs, true);
+    const v2i o = {__builtin_bit_cast(int, lo), __builtin_bit_cast(int, hi)};
+    *(v2i*)(p.y + (int64_t)(r0 + ps * 4 + lr) * p.n + c0 + lc) = o;
+  }
+  // scales: lanes 0, 4, 8, 12 hold the exponents of column blocks 0..3 of this wave's row block
+  const uint32_t e0 = __shfl(e, 0), e1 = __shfl(e, 4), e2 = __shfl(e, 8), e3 = __shfl(e, 12);
+  const uint32_t packed = e0 | (e1 << 8) | (e2 << 16) | (e3 << 24);
+  if (lane < 32) *(uint32_t*)(p.row_sf + (int64_t)(r0 + lane) * (p.n >> 5) + tj * 4) = packed;
+  if (lane == 0) *(uint32_t*)&es[wave][0] = packed;
+  __syncthreads();
+  if (tid < 128) {   // column c0 + tid: the four row blocks of this workgroup are 4 consecutive bytes
+    const int j = tid >> 5;
+    const uint32_t col = es[0][j] | (es[1][j] << 8) | (es[2][j] << 16) | (es[3][j] << 24);
+    *(uint32_t*)(p.col_sf + (int64_t)(c0 + tid) * (p.m >> 5) + ti * 4) = col;
+  }
+}
+
+// ----------------------------------------------------------------------------------------------------------------
+// mxfp4_transpose_mxfp8: one workgroup = 128 m x 256 n; wave w dequantises rows 32w..32w+31 into LDS as bf16,
+// then every lane owns 4 columns: 32 strided 2-byte reads, amax, requantise, 32 contiguous output bytes.
+// ----------------------------------------------------------------------------------------------------------------
+struct TrParams {
+  const uint8_t* xq;   // packed e2m1 (m, n/2)
+  const uint8_t* xs;   // e8m0 (m, n/32)
+  uint8_t* y;          // e4m3 (n, m)
+  uint8_t* out_sf;     // e8m0 (n, m/32)
+  int m, n;            // m % 128 == 0, n % 256 == 0 (host-checked)
+};
+
+__global__ __launch_bounds__(256) void mxfp4_transpose_mxfp8_kernel(const TrParams p) {
+  constexpr int LROW = 256 * 2 + 16;   // bf16 row of 256 columns + pad
+  __shared__ __attribute__((aligned(16))) char ts_all[4][32 * LROW];
+  const int tid = threadIdx.x, lane = tid & 63, wave = uniform(tid >> 6);
+  const int tiles_n = p.n >> 8;
+  const int ti = blockIdx.x / tiles_n, tj = blockIdx.x % tiles_n;
+  const int r0 = ti * 128 + wave * 32, c0 = tj * 256;
+  char* ts = ts_all[wave];
+  // lane -> row lane/8 (+8 per pass), 16-byte chunk lane%8 = 32 codes = one input scale group
+#pragma unroll
+  for (int ps = 0; ps < 4; ++ps) {
+    const int r = ps * 8 + (lane >> 3), c = (lane & 7) * 32;
+    const int64_t rowi = r0 + r;
+    const v4i v = *(const v4i*)(p.xq + rowi * (p.n >> 1) + ((c0 + c) >> 1));
+    const float sc = e8m0_scale(p.xs[rowi * (p.n >> 5) + ((c0 + c) >> 5)]);
+    v4i* d = (v4i*)(ts + r * LROW + c * 2);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const uint32_t w = (uint32_t)v[q];
+      v4i o;
+      o[0] = __builtin_bit_cast(int, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp4(w, sc, 0));
+      o[1] = __builtin_bit_cast(int, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp4(w, sc, 1));
+      o[2] = __builtin_bit_cast(int, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp4(w, sc, 2));
+      o[3] = __builtin_bit_cast(int, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp4(w, sc, 3));
+      d[q] = o;
+    }
+  }
+  __builtin_amdgcn_s_waitcnt(0xc07f);
+  __builtin_amdgcn_wave_barrier();
+  // columns lane, lane + 64, lane + 128, lane + 192 (consecutive lanes = consecutive 2-byte LDS addresses)
+#pragma unroll
+  for (int cc = 0; cc < 4; ++cc) {
+    const int col = cc * 64 + lane;
+    uint32_t pr[16];   // pr[i] = bf16 of rows 2i (low half) and 2i+1 (high half)
+    float amax = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const uint32_t a = *(const uint16_t*)(ts + (2 * i) * LROW + col * 2);
+      const uint32_t b = *(const uint16_t*)(ts + (2 * i + 1) * LROW + col * 2);
+      pr[i] = a | (b << 16);
+      amax = fmaxf(amax, fmaxf(fabsf(__uint_as_float(a << 16)), fabsf(__uint_as_float(b << 16))));
+    }
+    const uint32_t e = e8m0_shift7(amax);
+    const float qs = e8m0_scale(e);
+    v4i o[2];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      i16x2 w = {0, 0};
+      w = __builtin_amdgcn_cvt_scalef32_pk_fp8_bf16(w, __builtin_bit_cast(bf16x2, pr[2 * q]), qs, false);
+      w = __builtin_amdgcn_cvt_scalef32_pk_fp8_bf16(w, __builtin_bit_cast(bf16x2, pr[2 * q + 1]), qs, true);
+      o[q >> 2][q & 3] = __builtin_bit_cast(int, w);
+    }
+    uint8_t* dst = p.y + (int64_t)(c0 + col) * p.m + r0;
+    *(v4i*)dst = o[0];
+    *(v4i*)(dst + 16) = o[1];
+    p.out_sf[(int64_t)(c0 + col) * (p.m >> 5) + (r0 >> 5)] = (uint8_t)e;
+  }
+}
+
+}  // namespace qamd

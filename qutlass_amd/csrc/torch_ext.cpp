@@ -218,6 +218,59 @@ std::tuple<Tensor, Tensor> fusedQuantizeNvAbsMax(const Tensor& A, const Tensor& 
   return {OUT, OUT_sf};
 }
 
+// ---- QAT-backward data preparation (bindings.cpp:429-494: no validation there; the Python wrappers assert dtypes and
+//      contiguity, qutlass/__init__.py:206-315 -- the C ABI checks the shape constraints) --------------------------------
+void backward_t_bf16(const Tensor& x, const Tensor& h, Tensor xh_e2m1, Tensor xh_e8m0) {
+  const char* op = "backward_t_bf16";
+  require_contiguous(op, {{x, "x"}, {h, "h"}, {xh_e2m1, "xh_e2m1"}, {xh_e8m0, "xh_e8m0"}});
+  require_gpu(op, {{x, "x"}, {h, "h"}, {xh_e2m1, "xh_e2m1"}, {xh_e8m0, "xh_e8m0"}});
+  STD_TORCH_CHECK(has_dtype(x, ScalarType::BFloat16) && has_dtype(h, ScalarType::BFloat16), "x and h must be bf16");
+  STD_TORCH_CHECK(x.dim() >= 2 && h.numel() == 32 * 32, "x must be at least 2-D and h 32 x 32");
+  const int64_t M = x.size(x.dim() - 1), N = x.size(x.dim() - 2), B = x.numel() / (M * N);
+  STD_TORCH_CHECK(nbytes(xh_e2m1) >= B * M * N / 2 && nbytes(xh_e8m0) >= B * M * N / 32, "output tensors are too small");
+  const torch::stable::accelerator::DeviceGuard guard(x.get_device_index());
+  check_rc(qutlass_amd_backward_t_bf16(x.data_ptr(), h.data_ptr(), B, N, M, xh_e2m1.data_ptr(), xh_e8m0.data_ptr(), current_stream(x)));
+}
+
+void backward_qt_bf16(const Tensor& x_e2m1, const Tensor& x_e8m0, const Tensor& h, const Tensor& alpha, Tensor xh_e2m1, Tensor xh_e8m0) {
+  const char* op = "backward_qt_bf16";
+  require_contiguous(op, {{x_e2m1, "x_e2m1"}, {x_e8m0, "x_e8m0"}, {h, "h"}, {xh_e2m1, "xh_e2m1"}, {xh_e8m0, "xh_e8m0"}});
+  require_gpu(op, {{x_e2m1, "x_e2m1"}, {x_e8m0, "x_e8m0"}, {h, "h"}, {alpha, "alpha"}, {xh_e2m1, "xh_e2m1"}, {xh_e8m0, "xh_e8m0"}});
+  STD_TORCH_CHECK(has_dtype(h, ScalarType::BFloat16) && has_dtype(alpha, ScalarType::Float), "h must be bf16 and alpha float");
+  STD_TORCH_CHECK(x_e2m1.dim() >= 2 && x_e2m1.element_size() == 1 && x_e8m0.element_size() == 1 && h.numel() == 32 * 32,
+                  "x_e2m1 / x_e8m0 must be 1-byte tensors of at least 2 dimensions and h 32 x 32");
+  const int64_t M = x_e2m1.size(x_e2m1.dim() - 1) * 2, N = x_e2m1.size(x_e2m1.dim() - 2), B = x_e2m1.numel() * 2 / (M * N);
+  STD_TORCH_CHECK(x_e8m0.numel() == B * N * M / 32, "x_e8m0 must hold one scale per 32 elements of x_e2m1");
+  STD_TORCH_CHECK(nbytes(xh_e2m1) >= B * M * N / 2 && nbytes(xh_e8m0) >= B * M * N / 32, "output tensors are too small");
+  const torch::stable::accelerator::DeviceGuard guard(h.get_device_index());
+  check_rc(qutlass_amd_backward_qt_bf16(x_e2m1.data_ptr(), x_e8m0.data_ptr(), h.data_ptr(), static_cast<const float*>(alpha.data_ptr()), B, N, M,
+                                        xh_e2m1.data_ptr(), xh_e8m0.data_ptr(), current_stream(h)));
+}
+
+void backward_bf16_square_double_mxfp8(const Tensor& x_bf16, Tensor x_fp8, Tensor row_scales, Tensor column_scales) {
+  const char* op = "backward_bf16_square_double_mxfp8";
+  require_contiguous(op, {{x_bf16, "x_bf16"}, {x_fp8, "x_fp8"}, {row_scales, "row_scales"}, {column_scales, "column_scales"}});
+  require_gpu(op, {{x_bf16, "x_bf16"}, {x_fp8, "x_fp8"}, {row_scales, "row_scales"}, {column_scales, "column_scales"}});
+  STD_TORCH_CHECK(has_dtype(x_bf16, ScalarType::BFloat16) && x_bf16.dim() == 2, "x_bf16 must be a 2-D bf16 tensor");
+  const int64_t m = x_bf16.size(0), n = x_bf16.size(1);
+  STD_TORCH_CHECK(nbytes(x_fp8) >= m * n && nbytes(row_scales) >= m * n / 32 && nbytes(column_scales) >= m * n / 32, "output tensors are too small");
+  const torch::stable::accelerator::DeviceGuard guard(x_bf16.get_device_index());
+  check_rc(qutlass_amd_backward_bf16_square_double_mxfp8(x_bf16.data_ptr(), m, n, x_fp8.data_ptr(), row_scales.data_ptr(), column_scales.data_ptr(),
+                                                         current_stream(x_bf16)));
+}
+
+void mxfp4_transpose_mxfp8(const Tensor& x_fp4, const Tensor& scales, Tensor x_fp8, Tensor shared_exps) {
+  const char* op = "mxfp4_transpose_mxfp8";
+  require_contiguous(op, {{x_fp4, "x_fp4"}, {scales, "scales"}, {x_fp8, "x_fp8"}, {shared_exps, "shared_exps"}});
+  require_gpu(op, {{x_fp4, "x_fp4"}, {scales, "scales"}, {x_fp8, "x_fp8"}, {shared_exps, "shared_exps"}});
+  STD_TORCH_CHECK(x_fp4.dim() == 2 && x_fp4.element_size() == 1 && scales.element_size() == 1, "x_fp4 must be a 2-D 1-byte tensor, scales 1-byte");
+  const int64_t m = x_fp4.size(0), n = x_fp4.size(1) * 2;
+  STD_TORCH_CHECK(scales.numel() >= m * n / 32, "scales must hold one e8m0 per 32 elements");
+  STD_TORCH_CHECK(nbytes(x_fp8) >= m * n && nbytes(shared_exps) >= m * n / 32, "output tensors are too small");
+  const torch::stable::accelerator::DeviceGuard guard(x_fp4.get_device_index());
+  check_rc(qutlass_amd_mxfp4_transpose_mxfp8(x_fp4.data_ptr(), scales.data_ptr(), m, n, x_fp8.data_ptr(), shared_exps.data_ptr(), current_stream(x_fp4)));
+}
+
 // ---- block-scale swizzle -------------------------------------------------------------------------------------------
 Tensor to_blocked(const Tensor& in) {
   STD_TORCH_CHECK(in.dim() == 2, "to_blocked expects a 2-D matrix");
@@ -245,6 +298,10 @@ STABLE_TORCH_LIBRARY(_qutlass_C, m) {
   m.def("fusedQuantizeMxQuestWithMask(Tensor A, Tensor R, Tensor OUT, Tensor OUT_sf, Tensor OUT_mask) -> (Tensor, Tensor, Tensor)");
   m.def("fusedQuantizeNvQuest(Tensor A, Tensor R, Tensor OUT, Tensor OUT_sf, Tensor global_scale) -> (Tensor, Tensor)");
   m.def("fusedQuantizeNvAbsMax(Tensor A, Tensor R, Tensor OUT, Tensor OUT_sf, Tensor global_scale) -> (Tensor, Tensor)");
+  m.def("backward_t_bf16(Tensor x, Tensor h, Tensor xh_e2m1, Tensor xh_e8m0) -> ()");
+  m.def("backward_qt_bf16(Tensor x_e2m1, Tensor x_e8m0, Tensor h, Tensor alpha, Tensor xh_e2m1, Tensor xh_e8m0) -> ()");
+  m.def("backward_bf16_square_double_mxfp8(Tensor x_bf16, Tensor x_fp8, Tensor row_scales, Tensor column_scales) -> ()");
+  m.def("mxfp4_transpose_mxfp8(Tensor x_fp4, Tensor scales, Tensor x_fp8, Tensor shared_exps) -> ()");
 }
 
 STABLE_TORCH_LIBRARY(qutlass_amd, m) { m.def("to_blocked(Tensor input_matrix) -> Tensor"); }
@@ -261,7 +318,11 @@ STABLE_TORCH_LIBRARY(qutlass_amd, m) { m.def("to_blocked(Tensor input_matrix) ->
   m.impl("fusedQuantizeMxAbsMax", TORCH_BOX(&fusedQuantizeMxAbsMax));            \
   m.impl("fusedQuantizeMxQuestWithMask", TORCH_BOX(&fusedQuantizeMxQuestWithMask)); \
   m.impl("fusedQuantizeNvQuest", TORCH_BOX(&fusedQuantizeNvQuest));              \
-  m.impl("fusedQuantizeNvAbsMax", TORCH_BOX(&fusedQuantizeNvAbsMax));
+  m.impl("fusedQuantizeNvAbsMax", TORCH_BOX(&fusedQuantizeNvAbsMax));            \
+  m.impl("backward_t_bf16", TORCH_BOX(&backward_t_bf16));                        \
+  m.impl("backward_qt_bf16", TORCH_BOX(&backward_qt_bf16));                      \
+  m.impl("backward_bf16_square_double_mxfp8", TORCH_BOX(&backward_bf16_square_double_mxfp8)); \
+  m.impl("mxfp4_transpose_mxfp8", TORCH_BOX(&mxfp4_transpose_mxfp8));
 
 STABLE_TORCH_LIBRARY_IMPL(_qutlass_C, CUDA, m) { QAMD_IMPLS(m) }
 STABLE_TORCH_LIBRARY_IMPL(_qutlass_C, CPU, m) { QAMD_IMPLS(m) }

@@ -30,6 +30,10 @@ SCHEMAS = {
     "fusedQuantizeMxQuestWithMask": "(Tensor A, Tensor R, Tensor OUT, Tensor OUT_sf, Tensor OUT_mask) -> (Tensor, Tensor, Tensor)",
     "fusedQuantizeNvQuest": "(Tensor A, Tensor R, Tensor OUT, Tensor OUT_sf, Tensor global_scale) -> (Tensor, Tensor)",
     "fusedQuantizeNvAbsMax": "(Tensor A, Tensor R, Tensor OUT, Tensor OUT_sf, Tensor global_scale) -> (Tensor, Tensor)",
+    "backward_t_bf16": "(Tensor x, Tensor h, Tensor xh_e2m1, Tensor xh_e8m0) -> ()",
+    "backward_qt_bf16": "(Tensor x_e2m1, Tensor x_e8m0, Tensor h, Tensor alpha, Tensor xh_e2m1, Tensor xh_e8m0) -> ()",
+    "backward_bf16_square_double_mxfp8": "(Tensor x_bf16, Tensor x_fp8, Tensor row_scales, Tensor column_scales) -> ()",
+    "mxfp4_transpose_mxfp8": "(Tensor x_fp4, Tensor scales, Tensor x_fp8, Tensor shared_exps) -> ()",
 }
 
 _registered = False
@@ -100,6 +104,26 @@ def fusedQuantizeNvQuest(A, B, OUT, OUT_sf, global_scale):
 def fusedQuantizeNvAbsMax(A, B, OUT, OUT_sf, global_scale):
     """bindings.cpp:380-426."""
     return _C().fusedQuantizeNvAbsMax(A, B, OUT, OUT_sf, global_scale)
+
+
+def backward_t_bf16(x, h, xh_e2m1, xh_e8m0):
+    """bindings.cpp:429-443."""
+    return _C().backward_t_bf16(x, h, xh_e2m1, xh_e8m0)
+
+
+def backward_qt_bf16(x_e2m1, x_e8m0, h, alpha, xh_e2m1, xh_e8m0):
+    """bindings.cpp:445-464."""
+    return _C().backward_qt_bf16(x_e2m1, x_e8m0, h, alpha, xh_e2m1, xh_e8m0)
+
+
+def backward_bf16_square_double_mxfp8(x_bf16, x_fp8, row_scales, column_scales):
+    """bindings.cpp:466-479."""
+    return _C().backward_bf16_square_double_mxfp8(x_bf16, x_fp8, row_scales, column_scales)
+
+
+def mxfp4_transpose_mxfp8(x_fp4, scales, x_fp8, shared_exps):
+    """bindings.cpp:481-494."""
+    return _C().mxfp4_transpose_mxfp8(x_fp4, scales, x_fp8, shared_exps)
 
 
 def to_blocked(input_matrix: torch.Tensor) -> torch.Tensor:

@@ -52,6 +52,13 @@ def test_c_abi_rejects_bad_arguments_without_launching(lib):
     assert "workspace too small" in err()
     assert nn(dummy, dummy, dummy, dummy, dummy, dummy, 24, 128, 128, dummy, 1 << 20, None) == QAMD_ERR_INVALID
     assert "multiple of 16" in err()
+    assert lib.qutlass_amd_backward_t_bf16(dummy, dummy, 1, 48, 64, dummy, dummy, None) == QAMD_ERR_INVALID
+    assert "N % 32" in err()
+    assert lib.qutlass_amd_backward_qt_bf16(dummy, dummy, dummy, dummy, 1, 64, 48, dummy, dummy, None) == QAMD_ERR_INVALID
+    assert lib.qutlass_amd_backward_bf16_square_double_mxfp8(dummy, 96, 128, dummy, dummy, dummy, None) == QAMD_ERR_INVALID
+    assert "multiples of 128" in err()
+    assert lib.qutlass_amd_mxfp4_transpose_mxfp8(dummy, dummy, 128, 128, dummy, dummy, None) == QAMD_ERR_INVALID
+    assert "n % 256" in err()
     q = lib.qutlass_amd_fused_quantize_mx
     assert q(dummy, dummy, 48, 4096, 0, dummy, dummy, None, None) == QAMD_ERR_INVALID
     assert "Unsupported rotation size 48" in err()
@@ -89,6 +96,11 @@ def test_python_surface_matches_reference_signatures():
     assert inspect.signature(qutlass_amd.fusedQuantizeNv).parameters["method"].default == "abs_max"
     assert inspect.signature(qutlass_amd.matmul_mxf4_bf16_tn).parameters["backend"].default == "cutlass"
     assert list(inspect.signature(to_blocked).parameters) == ["input_matrix", "use_triton_kernel"]
+    # QAT-backward wrappers (qutlass/__init__.py:206-315)
+    assert list(inspect.signature(qutlass_amd.backward_t_bf16).parameters) == ["x", "h", "xh_e2m1", "xh_e8m0"]
+    assert list(inspect.signature(qutlass_amd.backward_qt_bf16).parameters) == ["x_e2m1", "x_e8m0", "h", "alpha", "xh_e2m1", "xh_e8m0"]
+    assert list(inspect.signature(qutlass_amd.backward_bf16_square_double_mxfp8).parameters) == ["x_bf16"]
+    assert list(inspect.signature(qutlass_amd.mxfp4_transpose_mxfp8).parameters) == ["x_fp4", "scales"]
 
 
 def test_torch_ops_registered_with_reference_schemas():
@@ -137,7 +149,7 @@ def test_python_level_error_behaviour():
     with pytest.raises(ImportError, match="flashinfer"):
         qutlass_amd.matmul_mxf4_bf16_tn(u8, u8, sf, sf, torch.ones(1), backend="flashinfer")
     with pytest.raises(AttributeError, match="hot path"):
-        qutlass_amd.backward_t_bf16
+        qutlass_amd.matmul_ada_mxf4_bf16_tn
 
 
 def test_op_layer_validation_messages_follow_the_reference():

@@ -355,3 +355,94 @@ def test_matmul_mxf8_nn_equals_tn_and_oracle(q, golden_dir, m, n, k):
     with pytest.raises(RuntimeError, match="Inner dimensions must match for A.T @ B.T"):
         q.matmul_mxf8_bf16_nn(a_km, b_t[:, : k - 32].contiguous(), sa, sb, alpha)
 
+
+# ------------------------------------------------------------------------------------------------
+# QAT-backward data-prep ops (reference tests/quartet_test.py:239-260, 368-384)
+# ------------------------------------------------------------------------------------------------
+def _codes_close(got, want, frac=2e-3):
+    eq = oracle.codes_equal_mod_zero_sign(got.reshape(want.shape), want)
+    return int((~eq).sum()) <= frac * eq.size, int((~eq).sum())
+
+
+def test_backward_t_bf16_golden_and_oracle(q, golden_dir):
+    g = _load(golden_dir, "quartet_bwd.npz")
+    h = torch.from_numpy(g["h"]).view(torch.bfloat16).to(DEV)
+    for c in range(int(g["t_ncases"])):
+        x = torch.from_numpy(g[f"t_x{c}"]).view(torch.bfloat16).to(DEV)
+        e2m1, e8m0 = q.backward_t_bf16(x, h)
+        assert e2m1.dtype == torch.float4_e2m1fn_x2 and e8m0.dtype == torch.float8_e8m0fnu
+        assert e2m1.shape == (*x.shape[:-2], x.size(-1), x.size(-2) // 2)
+        assert np.array_equal(_np(e8m0), g[f"t_e8m0_{c}"]), c                    # reference: xh_e8m0.equal(ref)
+        ok, bad = _codes_close(_np(e2m1), g[f"t_e2m1_{c}"])
+        assert ok, (c, bad)
+    torch.manual_seed(11)
+    x = torch.randn(2, 512, 1000, dtype=torch.bfloat16, device=DEV) * 25.0     # ragged M (multiple of 8, not of 64)
+    e2m1, e8m0 = q.backward_t_bf16(x, h)
+    rq, rs = oracle.backward_t_bf16(_np(x), _np(h), acc_model=1)
+    assert np.array_equal(_np(e8m0), rs)
+    ok, bad = _codes_close(_np(e2m1), rq, 1e-4)
+    assert ok, bad
+    # equivalence with the forward quantiser on the explicit transpose, up to the epsilon the forward op adds (none matters here)
+    fq, fs = q.fusedQuantizeMx(x.transpose(-2, -1).contiguous(), h, method="abs_max")
+    assert np.array_equal(_np(fs).reshape(-1)[: rs.size], rs.reshape(-1))
+    assert np.array_equal(_np(fq), _np(e2m1).reshape(_np(fq).shape))
+
+
+def test_backward_qt_bf16_golden_and_oracle(q, golden_dir):
+    g = _load(golden_dir, "quartet_bwd.npz")
+    h = torch.from_numpy(g["h"]).view(torch.bfloat16).to(DEV)
+    alpha = torch.tensor([3.0], device=DEV)
+    for c in range(int(g["qt_ncases"])):
+        xq = torch.from_numpy(g[f"qt_xq{c}"]).to(DEV)
+        xs = torch.from_numpy(g[f"qt_xs{c}"]).to(DEV).view(torch.float8_e8m0fnu)
+        e2m1, e8m0 = q.backward_qt_bf16(xq, xs, h, alpha)
+        assert np.array_equal(_np(e8m0), g[f"qt_e8m0_{c}"]), c
+        ok, bad = _codes_close(_np(e2m1), g[f"qt_e2m1_{c}"])
+        assert ok, (c, bad)
+    torch.manual_seed(12)
+    x = torch.randn(1, 256, 1024, dtype=torch.bfloat16, device=DEV) * 25.0
+    xq, xs = q.fusedQuantizeMx(x, h, method="abs_max")
+    xs = xs.view(torch.uint8).reshape(-1)[: x.numel() // 32].reshape(1, 256, 32).view(torch.float8_e8m0fnu)
+    e2m1, e8m0 = q.backward_qt_bf16(xq, xs, h, alpha)
+    rq, rs = oracle.backward_qt_bf16(_np(xq), _np(xs), _np(h), 3.0, acc_model=1)
+    assert np.array_equal(_np(e8m0), rs)
+    ok, bad = _codes_close(_np(e2m1), rq, 1e-4)
+    assert ok, bad
+
+
+def test_backward_bf16_square_double_mxfp8_bit_exact(q, golden_dir):
+    g = _load(golden_dir, "quartet_bwd.npz")
+    for c in range(int(g["sq_ncases"])):
+        x = torch.from_numpy(g[f"sq_x{c}"]).view(torch.bfloat16).to(DEV)
+        y, rs, cs = q.backward_bf16_square_double_mxfp8(x)          # pads rows to 128 like the reference
+        assert y.dtype == torch.float8_e4m3fn and rs.dtype == torch.float8_e8m0fnu
+        assert np.array_equal(_np(y), g[f"sq_y{c}"]), (c, int((_np(y) != g[f"sq_y{c}"]).sum()))
+        assert np.array_equal(_np(rs), g[f"sq_rs{c}"]) and np.array_equal(_np(cs), g[f"sq_cs{c}"]), c
+    torch.manual_seed(13)
+    x = torch.randn(1024, 2048, dtype=torch.bfloat16, device=DEV) * torch.logspace(-3, 3, 2048, device=DEV).to(torch.bfloat16)
+    x[128:160, 256:288] = 0
+    y, rs, cs = q.backward_bf16_square_double_mxfp8(x)
+    ry, rrs, rcs = oracle.backward_bf16_square_double_mxfp8(_np(x))
+    assert np.array_equal(_np(rs), rrs) and np.array_equal(_np(cs), rcs)
+    assert np.array_equal(_np(y), ry), int((_np(y) != ry).sum())
+
+
+def test_mxfp4_transpose_mxfp8_bit_exact(q, golden_dir):
+    g = _load(golden_dir, "quartet_bwd.npz")
+    for c in range(int(g["tr_ncases"])):
+        xq = torch.from_numpy(g[f"tr_xq{c}"]).to(DEV)
+        xs = torch.from_numpy(g[f"tr_xs{c}"]).to(DEV).view(torch.float8_e8m0fnu)
+        if xq.shape[1] * 2 % 256:      # the kernel needs n % 256 == 0 (the reference launches n/256 blocks)
+            continue
+        y, e = q.mxfp4_transpose_mxfp8(xq, xs)
+        assert np.array_equal(_np(e), g[f"tr_e{c}"]) and np.array_equal(_np(y), g[f"tr_y{c}"]), c
+    torch.manual_seed(14)
+    x = torch.randn(1024, 768, dtype=torch.bfloat16, device=DEV) * 25.0
+    xq, xs = q.fusedQuantizeMx(x, torch.eye(32, dtype=torch.bfloat16, device=DEV), method="abs_max")
+    xs = xs.view(torch.uint8).reshape(-1)[: x.numel() // 32].reshape(1024, 24).contiguous().view(torch.float8_e8m0fnu)
+    y, e = q.mxfp4_transpose_mxfp8(xq, xs)
+    ry, re = oracle.mxfp4_transpose_mxfp8(_np(xq), _np(xs))
+    assert y.shape == (768, 1024) and e.shape == (768, 32)
+    assert np.array_equal(_np(e), re)
+    assert np.array_equal(_np(y), ry), int((_np(y) != ry).sum())
+
