@@ -119,6 +119,15 @@ def main():
     qb = M * K * 2 + M * K // 2 + M * K // 32
     line("C5 fusedQuantizeMx(H32, quest) 4096x4096", time_us(lambda: q.fusedQuantizeMx(x, h32, method="quest"), args.iters), bytes_=qb)
     line("C5 fusedQuantizeMx(H32, quest, return_mask=True) 4096x4096", time_us(lambda: q.fusedQuantizeMx(x, h32, method="quest", return_mask=True), args.iters), bytes_=qb + M * K // 8)
+    # ---- QAT-backward data-prep ops at the C5 shape -------------------------------
+    xq, xs = q.fusedQuantizeMx(x, h32, method="abs_max")
+    xs2 = xs.view(torch.uint8).reshape(-1)[: M * K // 32].reshape(M, K // 32).contiguous().view(torch.float8_e8m0fnu)
+    al3 = torch.tensor([3.0], device=dev)
+    line("backward_t_bf16 4096x4096 (transpose + H32 + abs_max MXFP4)", time_us(lambda: q.backward_t_bf16(x, h32), args.iters), bytes_=qb)
+    line("backward_qt_bf16 4096x4096 (MXFP4 in, transpose + H32 + abs_max MXFP4 out)", time_us(lambda: q.backward_qt_bf16(xq, xs2, h32, al3), args.iters),
+         bytes_=2 * (M * K // 2 + M * K // 32))
+    line("backward_bf16_square_double_mxfp8 4096x4096", time_us(lambda: q.backward_bf16_square_double_mxfp8(x), args.iters), bytes_=M * K * 3 + 2 * M * K // 32)
+    line("mxfp4_transpose_mxfp8 4096x4096", time_us(lambda: q.mxfp4_transpose_mxfp8(xq, xs2), args.iters), bytes_=M * K // 2 + M * K // 32 + M * K + M * K // 32)
     for r in (64, 128):
         hr = hadamard(r, dev)
         line(f"fusedQuantizeMx(H{r}, abs_max) 4096x4096", time_us(lambda: q.fusedQuantizeMx(x, hr, method="abs_max"), args.iters), bytes_=qb)
