@@ -46,6 +46,17 @@ int qutlass_amd_matmul_mxf4_bf16_tn(const void* A, const void* B, const void* A_
                                     void* stream);
 
 /*
+ * MXFP4, small-batch variant: same operands, but A_sf / B_sf are the UN-swizzled row-major (M, K/32) / (N, K/32) e8m0
+ * matrices (what fusedQuantizeMx writes, without to_blocked).  Any M is accepted; the kernel is built for M <= 32
+ * (weight-bandwidth bound split-K, no LDS staging).  K % 128 == 0, N % 8 == 0.
+ * Replaces matmul_host_ada_mxf4_bf16_tn (qutlass/csrc/gemm_ada.cu:30-135; bindings.cpp:104-138; scale addressing
+ * cutlass_extensions/gemm/threadblock/mx_mma_multistage.h:418-448).
+ */
+int qutlass_amd_matmul_ada_mxf4_bf16_tn(const void* A, const void* B, const void* A_sf, const void* B_sf,
+                                        const float* alpha, void* D, int64_t M, int64_t N, int64_t K,
+                                        void* stream);
+
+/*
  * NVFP4.  Same operand layout, scales are e4m3fn per 16 K-elements in the to_blocked layout of a
  * (ceil(M/128)*128, ceil(K/64)*4) matrix; K % 32 == 0.
  * Replaces matmul_host_nvf4_bf16_tn (gemm.cu:250-326; bindings.cpp:68-102).

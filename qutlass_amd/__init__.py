@@ -5,7 +5,7 @@ meaning, defaults and Python-level error behaviour):
 
     fusedQuantizeMx, fusedQuantizeNv, matmul_mxf4_bf16_tn, matmul_nvf4_bf16_tn,
     matmul_mxf8_bf16_tn, matmul_mxf8_bf16_nn         (+ qutlass_amd.utils.to_blocked & friends)
-    backward_t_bf16, backward_qt_bf16, backward_bf16_square_double_mxfp8, mxfp4_transpose_mxfp8
+    matmul_ada_mxf4_bf16_tn, backward_t_bf16, backward_qt_bf16, backward_bf16_square_double_mxfp8, mxfp4_transpose_mxfp8
 
 All compute is hand-written HIP behind the C ABI of ``include/qutlass_amd.h``
 (``libqutlass_amd.so``); importing this package loads that library and registers
@@ -46,6 +46,12 @@ def matmul_mxf4_bf16_tn(a: torch.Tensor, b: torch.Tensor, a_sf: torch.Tensor, b_
         raise ImportError(_FLASHINFER_MSG)
     else:
         raise ValueError(f"invalid backend {backend!r}; use 'cutlass' or 'flashinfer'")
+
+
+def matmul_ada_mxf4_bf16_tn(a: torch.Tensor, b: torch.Tensor, a_sf: torch.Tensor, b_sf: torch.Tensor,
+                            alpha: torch.Tensor) -> torch.Tensor:
+    """qutlass/__init__.py:79-86: small-batch MXFP4 GEMM taking the UN-swizzled (rows, K/32) scales."""
+    return qutlass_CUDA.matmul_ada_mxf4_bf16_tn(a, b, a_sf, b_sf, alpha)
 
 
 def matmul_nvf4_bf16_tn(a: torch.Tensor, b: torch.Tensor, a_sf: torch.Tensor, b_sf: torch.Tensor,
@@ -166,7 +172,7 @@ def mxfp4_transpose_mxfp8(x_fp4: torch.Tensor, scales: torch.Tensor) -> tuple[to
     return x_fp8, shared_exps
 
 
-_OUT_OF_SCOPE = ("matmul_ada_mxf4_bf16_tn",)
+_OUT_OF_SCOPE = ()
 
 
 def __getattr__(name):

@@ -20,6 +20,7 @@ _GEMM_ARGS = [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _vp]
 SYMBOLS = {
     "qutlass_amd_matmul_mxf4_bf16_tn": (_i32, _GEMM_ARGS),
     "qutlass_amd_matmul_nvf4_bf16_tn": (_i32, _GEMM_ARGS),
+    "qutlass_amd_matmul_ada_mxf4_bf16_tn": (_i32, _GEMM_ARGS),
     "qutlass_amd_matmul_mxf8_bf16_tn": (_i32, _GEMM_ARGS),
     "qutlass_amd_matmul_mxf8_bf16_nn": (_i32, _GEMM_ARGS[:-1] + [_vp, _i64, _vp]),
     "qutlass_amd_mxf8_nn_workspace_bytes": (_i64, [_i64, _i64]),

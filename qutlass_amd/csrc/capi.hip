@@ -9,6 +9,7 @@
 
 #include "../../include/qutlass_amd.h"
 #include "gemm_mx.hip.h"
+#include "gemm_mx_skinny.hip.h"
 #include "gemm_nvf4.hip.h"
 #include "quantize.hip.h"
 #include "to_blocked.hip.h"
@@ -54,6 +55,7 @@ int launch_gemm(GemmParams p, hipStream_t s) {
 // Tile/schedule variants ("gemm_variant" option; 0 = auto):
 //   1  256x256 ping-pong     5  256x256 lockstep     6..9  queue schedule (256x256, 128x128, 256x128, 128x256)
 //   20 / 24 / 25 / 26  simple schedule (256x256, 128x128, 256x128, 128x256)
+//   60  skinny split-K kernel (fp4, M <= 32 per tile, no LDS staging): auto for M <= 32
 //   30  deep schedule (fp4, 256x256, 4 waves of 128x128, LDS-DMA)      40  regstage (same tiling, copy through registers)
 //   31..36, 41..43, 50..56  ablations / traces / clock probes of those (bench only)
 //   2  128x128 lockstep (small M or N)                     3  256x128 lockstep    4  128x256 lockstep
@@ -138,6 +140,14 @@ int gemm_mx(const char* name, const void* A, const void* B, const void* A_sf, co
   p.dbg = g_dbg.load();
   hipStream_t s = (hipStream_t)stream;
   int variant = g_gemm_variant.load();
+  if (EBITS == 4 && (variant == 60 || (variant == 0 && M <= 32))) {
+    // small batch: weight-bandwidth bound -> split-K kernel without LDS staging (gemm_mx_skinny.hip.h)
+    SkinnyParams q;
+    q.A = p.A; q.B = p.B; q.SFA = p.SFA; q.SFB = p.SFB; q.alpha = alpha; q.D = p.D; q.M = p.M; q.N = p.N; q.K = p.K;
+    q.a_bytes = p.a_bytes; q.b_bytes = p.b_bytes; q.sfa_bytes = p.sfa_bytes; q.sfb_bytes = p.sfb_bytes;
+    launch_skinny<true>(q, s);
+    return check_launch("gemm_mx_skinny_kernel");
+  }
   if (variant == 0) {
     // auto (measured, profiles/native_r1_schedules.log): fp4 256x256 tiles run the "deep" schedule (4 waves of
     // 128x128, variant 30), fp8 the "simple" one (variant 20); 128x128 tiles (variant 24) when M or N <= 128, the
@@ -188,6 +198,23 @@ extern "C" {
 int qutlass_amd_matmul_mxf4_bf16_tn(const void* A, const void* B, const void* A_sf, const void* B_sf,
                                     const float* alpha, void* D, int64_t M, int64_t N, int64_t K, void* stream) {
   return gemm_mx<4>("matmul_mxf4_bf16_tn", A, B, A_sf, B_sf, alpha, D, M, N, K, stream);
+}
+
+int qutlass_amd_matmul_ada_mxf4_bf16_tn(const void* A, const void* B, const void* A_sf, const void* B_sf,
+                                        const float* alpha, void* D, int64_t M, int64_t N, int64_t K, void* stream) {
+  const char* name = "matmul_ada_mxf4_bf16_tn";
+  if (!A || !B || !A_sf || !B_sf || !alpha || !D) return fail(QAMD_ERR_INVALID, "%s: null pointer argument", name);
+  if (M <= 0 || N <= 0) return fail(QAMD_ERR_INVALID, "%s: M and N must be positive (got M=%lld N=%lld)", name, (long long)M, (long long)N);
+  if (K < 128 || K % 128) return fail(QAMD_ERR_INVALID, "%s: K must be a positive multiple of 128 (got %lld)", name, (long long)K);
+  if (N % 8) return fail(QAMD_ERR_INVALID, "%s: N must be a multiple of 8 (got %lld)", name, (long long)N);
+  if (M * (K / 2) >= (1ll << 31) || N * (K / 2) >= (1ll << 31)) return fail(QAMD_ERR_INVALID, "%s: operand larger than 2 GiB is not supported", name);
+  SkinnyParams q;
+  q.A = (const uint8_t*)A; q.B = (const uint8_t*)B; q.SFA = (const uint8_t*)A_sf; q.SFB = (const uint8_t*)B_sf;
+  q.alpha = alpha; q.D = (uint16_t*)D; q.M = (int)M; q.N = (int)N; q.K = (int)K;
+  q.a_bytes = (uint32_t)(M * (K / 2)); q.b_bytes = (uint32_t)(N * (K / 2));
+  q.sfa_bytes = (uint32_t)(M * (K / 32)); q.sfb_bytes = (uint32_t)(N * (K / 32));   // row-major (rows, K/32), un-swizzled
+  launch_skinny<false>(q, (hipStream_t)stream);
+  return check_launch("gemm_mx_skinny_kernel");
 }
 
 int qutlass_amd_matmul_mxf8_bf16_tn(const void* A, const void* B, const void* A_sf, const void* B_sf,

@@ -80,13 +80,13 @@ void* current_stream(const Tensor& t) {   // include/common.h:40-45
 void check_rc(int rc) { STD_TORCH_CHECK(rc == QAMD_OK, qutlass_amd_last_error()); }
 
 // ---- block-scaled GEMMs --------------------------------------------------------------------------------------------
-enum class Gemm { MXF4, NVF4, MXF8_TN, MXF8_NN };
+enum class Gemm { MXF4, NVF4, MXF8_TN, MXF8_NN, ADA_MXF4 };
 
 template <Gemm G>
 Tensor matmul(const Tensor& A, const Tensor& B, const Tensor& A_sf, const Tensor& B_sf, const Tensor& alpha) {
   constexpr bool fp8 = G == Gemm::MXF8_TN || G == Gemm::MXF8_NN;
   constexpr bool nn = G == Gemm::MXF8_NN;
-  const char* op = G == Gemm::MXF4 ? "matmul_mxf4_bf16_tn" : G == Gemm::NVF4 ? "matmul_nvf4_bf16_tn" : G == Gemm::MXF8_TN ? "matmul_mxf8_bf16_tn" : "matmul_mxf8_bf16_nn";
+  const char* op = G == Gemm::ADA_MXF4 ? "matmul_ada_mxf4_bf16_tn" : G == Gemm::MXF4 ? "matmul_mxf4_bf16_tn" : G == Gemm::NVF4 ? "matmul_nvf4_bf16_tn" : G == Gemm::MXF8_TN ? "matmul_mxf8_bf16_tn" : "matmul_mxf8_bf16_nn";
   if (fp8) require_contiguous(op, {{A, "A"}, {B, "B"}, {A_sf, "A_sf"}, {B_sf, "B_sf"}, {alpha, "alpha"}});
   else require_contiguous(op, {{A, "A"}, {B, "B"}, {A_sf, "A_sf"}, {B_sf, "B_sf"}});
   require_gpu(op, {{A, "A"}, {B, "B"}, {A_sf, "A_sf"}, {B_sf, "B_sf"}, {alpha, "alpha"}});
@@ -120,7 +120,8 @@ Tensor matmul(const Tensor& A, const Tensor& B, const Tensor& A_sf, const Tensor
   const float* al = static_cast<const float*>(alpha.data_ptr());
   void* s = current_stream(A);
   int rc;
-  if (G == Gemm::MXF4) rc = qutlass_amd_matmul_mxf4_bf16_tn(A.data_ptr(), B.data_ptr(), A_sf.data_ptr(), B_sf.data_ptr(), al, out.data_ptr(), M, N, K, s);
+  if (G == Gemm::ADA_MXF4) rc = qutlass_amd_matmul_ada_mxf4_bf16_tn(A.data_ptr(), B.data_ptr(), A_sf.data_ptr(), B_sf.data_ptr(), al, out.data_ptr(), M, N, K, s);
+  else if (G == Gemm::MXF4) rc = qutlass_amd_matmul_mxf4_bf16_tn(A.data_ptr(), B.data_ptr(), A_sf.data_ptr(), B_sf.data_ptr(), al, out.data_ptr(), M, N, K, s);
   else if (G == Gemm::NVF4) rc = qutlass_amd_matmul_nvf4_bf16_tn(A.data_ptr(), B.data_ptr(), A_sf.data_ptr(), B_sf.data_ptr(), al, out.data_ptr(), M, N, K, s);
   else if (G == Gemm::MXF8_TN) rc = qutlass_amd_matmul_mxf8_bf16_tn(A.data_ptr(), B.data_ptr(), A_sf.data_ptr(), B_sf.data_ptr(), al, out.data_ptr(), M, N, K, s);
   else {
@@ -134,6 +135,7 @@ Tensor matmul(const Tensor& A, const Tensor& B, const Tensor& A_sf, const Tensor
 }
 
 Tensor matmul_mxf4_bf16_tn(const Tensor& A, const Tensor& B, const Tensor& A_sf, const Tensor& B_sf, const Tensor& alpha) { return matmul<Gemm::MXF4>(A, B, A_sf, B_sf, alpha); }
+Tensor matmul_ada_mxf4_bf16_tn(const Tensor& A, const Tensor& B, const Tensor& A_sf, const Tensor& B_sf, const Tensor& alpha) { return matmul<Gemm::ADA_MXF4>(A, B, A_sf, B_sf, alpha); }
 Tensor matmul_nvf4_bf16_tn(const Tensor& A, const Tensor& B, const Tensor& A_sf, const Tensor& B_sf, const Tensor& alpha) { return matmul<Gemm::NVF4>(A, B, A_sf, B_sf, alpha); }
 Tensor matmul_mxf8_bf16_tn(const Tensor& A, const Tensor& B, const Tensor& A_sf, const Tensor& B_sf, const Tensor& alpha) { return matmul<Gemm::MXF8_TN>(A, B, A_sf, B_sf, alpha); }
 Tensor matmul_mxf8_bf16_nn(const Tensor& A, const Tensor& B, const Tensor& A_sf, const Tensor& B_sf, const Tensor& alpha) { return matmul<Gemm::MXF8_NN>(A, B, A_sf, B_sf, alpha); }
@@ -291,6 +293,7 @@ Tensor to_blocked(const Tensor& in) {
 STABLE_TORCH_LIBRARY(_qutlass_C, m) {
   m.def("matmul_mxf4_bf16_tn(Tensor A, Tensor B, Tensor A_sf, Tensor B_sf, Tensor alpha) -> Tensor");
   m.def("matmul_nvf4_bf16_tn(Tensor A, Tensor B, Tensor A_sf, Tensor B_sf, Tensor alpha) -> Tensor");
+  m.def("matmul_ada_mxf4_bf16_tn(Tensor A, Tensor B, Tensor A_sf, Tensor B_sf, Tensor alpha) -> Tensor");
   m.def("matmul_mxf8_bf16_tn(Tensor A, Tensor B, Tensor A_sf, Tensor B_sf, Tensor alpha) -> Tensor");
   m.def("matmul_mxf8_bf16_nn(Tensor A, Tensor B, Tensor A_sf, Tensor B_sf, Tensor alpha) -> Tensor");
   m.def("fusedQuantizeMxQuest(Tensor A, Tensor R, Tensor OUT, Tensor OUT_sf) -> (Tensor, Tensor)");
@@ -312,6 +315,7 @@ STABLE_TORCH_LIBRARY(qutlass_amd, m) { m.def("to_blocked(Tensor input_matrix) ->
 #define QAMD_IMPLS(m)                                                            \
   m.impl("matmul_mxf4_bf16_tn", TORCH_BOX(&matmul_mxf4_bf16_tn));                \
   m.impl("matmul_nvf4_bf16_tn", TORCH_BOX(&matmul_nvf4_bf16_tn));                \
+  m.impl("matmul_ada_mxf4_bf16_tn", TORCH_BOX(&matmul_ada_mxf4_bf16_tn));        \
   m.impl("matmul_mxf8_bf16_tn", TORCH_BOX(&matmul_mxf8_bf16_tn));                \
   m.impl("matmul_mxf8_bf16_nn", TORCH_BOX(&matmul_mxf8_bf16_nn));                \
   m.impl("fusedQuantizeMxQuest", TORCH_BOX(&fusedQuantizeMxQuest));              \

@@ -23,6 +23,7 @@ EXT_PATH = os.path.join(_HERE, "_C.so")
 SCHEMAS = {
     "matmul_mxf4_bf16_tn": "(Tensor A, Tensor B, Tensor A_sf, Tensor B_sf, Tensor alpha) -> Tensor",
     "matmul_nvf4_bf16_tn": "(Tensor A, Tensor B, Tensor A_sf, Tensor B_sf, Tensor alpha) -> Tensor",
+    "matmul_ada_mxf4_bf16_tn": "(Tensor A, Tensor B, Tensor A_sf, Tensor B_sf, Tensor alpha) -> Tensor",
     "matmul_mxf8_bf16_tn": "(Tensor A, Tensor B, Tensor A_sf, Tensor B_sf, Tensor alpha) -> Tensor",
     "matmul_mxf8_bf16_nn": "(Tensor A, Tensor B, Tensor A_sf, Tensor B_sf, Tensor alpha) -> Tensor",
     "fusedQuantizeMxQuest": "(Tensor A, Tensor R, Tensor OUT, Tensor OUT_sf) -> (Tensor, Tensor)",
@@ -64,6 +65,11 @@ def _C():
 def matmul_mxf4_bf16_tn(A, B, A_sf, B_sf, alpha):
     """bindings.cpp:32-66 -> qutlass_amd_matmul_mxf4_bf16_tn."""
     return _C().matmul_mxf4_bf16_tn(A, B, A_sf, B_sf, alpha)
+
+
+def matmul_ada_mxf4_bf16_tn(A, B, A_sf, B_sf, alpha):
+    """bindings.cpp:104-138 -> qutlass_amd_matmul_ada_mxf4_bf16_tn (row-major, un-swizzled scales)."""
+    return _C().matmul_ada_mxf4_bf16_tn(A, B, A_sf, B_sf, alpha)
 
 
 def matmul_nvf4_bf16_tn(A, B, A_sf, B_sf, alpha):

@@ -174,7 +174,7 @@ def _gemm_golden(q, g, c, fn, sf_dtype, kind):
     return _np(out), g[f"out{c}"]
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 5, 6, 7, 20, 24, 30, 40])
+@pytest.mark.parametrize("variant", [0, 1, 2, 5, 6, 7, 20, 24, 30, 40, 60])
 def test_matmul_mxf4_golden_bit_exact(q, golden_dir, variant):
     g = _load(golden_dir, "gemm_mxfp4.npz")
     q._lib.set_option("gemm_variant", variant)
@@ -445,4 +445,47 @@ def test_mxfp4_transpose_mxfp8_bit_exact(q, golden_dir):
     assert y.shape == (768, 1024) and e.shape == (768, 32)
     assert np.array_equal(_np(e), re)
     assert np.array_equal(_np(y), ry), int((_np(y) != ry).sum())
+
+
+# ------------------------------------------------------------------------------------------------
+# small-batch path: matmul_ada_mxf4_bf16_tn (un-swizzled scales) and the skinny kernel behind matmul_mxf4_bf16_tn
+# ------------------------------------------------------------------------------------------------
+def test_matmul_ada_mxf4_golden_bit_exact(q, golden_dir):
+    g = _load(golden_dir, "gemm_mxfp4.npz")
+    for c in range(int(g["ncases"])):
+        m, n, k = (int(v) for v in g[f"meta{c}"])
+        a, b = torch.from_numpy(g[f"a{c}"]).to(DEV), torch.from_numpy(g[f"b{c}"]).to(DEV)
+        asf = torch.from_numpy(g[f"asf{c}"]).to(DEV).view(torch.float8_e8m0fnu)      # row-major (m, k/32): NOT to_blocked
+        bsf = torch.from_numpy(g[f"bsf{c}"]).to(DEV).view(torch.float8_e8m0fnu)
+        alpha = torch.tensor([float(g[f"alpha{c}"])], device=DEV)
+        out = q.matmul_ada_mxf4_bf16_tn(a, b, asf, bsf, alpha)
+        assert out.shape == (m, n) and out.dtype == torch.bfloat16
+        assert np.array_equal(_np(out), g[f"out{c}"]), (c, int((_np(out) != g[f"out{c}"]).sum()))
+
+
+@pytest.mark.parametrize("m,n,k", [(1, 4096, 4096), (16, 4096, 4096), (32, 14336, 4096), (7, 504, 1152), (40, 1032, 2048)])
+def test_small_batch_paths_agree_with_tiled_kernel_and_oracle(q, m, n, k):
+    from qutlass_amd.utils import to_blocked
+
+    torch.manual_seed(21)
+    h = _hadamard(32)
+    a = torch.randn(m, k, dtype=torch.bfloat16, device=DEV) * 25.0
+    b = torch.randn(n, k, dtype=torch.bfloat16, device=DEV) * 25.0
+    a_q, a_s = q.fusedQuantizeMx(a, h, method="abs_max")
+    b_q, b_s = q.fusedQuantizeMx(b, h, method="abs_max")
+    alpha = torch.tensor([1.0 / 9.0], device=DEV)
+    rm = lambda s, rows: s.view(torch.uint8).reshape(-1)[: rows * k // 32].reshape(rows, k // 32).contiguous().view(torch.float8_e8m0fnu)
+    out_ada = q.matmul_ada_mxf4_bf16_tn(a_q, b_q, rm(a_s, m), rm(b_s, n), alpha)
+    out_auto = q.matmul_mxf4_bf16_tn(a_q, b_q, to_blocked(a_s), to_blocked(b_s), alpha)     # M <= 32 -> skinny kernel
+    q._lib.set_option("gemm_variant", 24)
+    try:
+        out_tiled = q.matmul_mxf4_bf16_tn(a_q, b_q, to_blocked(a_s), to_blocked(b_s), alpha)
+    finally:
+        q._lib.set_option("gemm_variant", 0)
+    assert torch.equal(out_ada.view(torch.int16), out_tiled.view(torch.int16))
+    assert torch.equal(out_auto.view(torch.int16), out_tiled.view(torch.int16))
+    if m * n * k <= 1 << 29:
+        ref = oracle.gemm_blockscaled(oracle.KIND_MXFP4, _np(a_q), _np(b_q), oracle.to_blocked(_np(rm(a_s, m))), oracle.to_blocked(_np(rm(b_s, n))),
+                                      1.0 / 9.0, m, n, k)
+        assert np.array_equal(_np(out_ada), ref)
 
