@@ -128,6 +128,21 @@ def main():
          bytes_=2 * (M * K // 2 + M * K // 32))
     line("backward_bf16_square_double_mxfp8 4096x4096", time_us(lambda: q.backward_bf16_square_double_mxfp8(x), args.iters), bytes_=M * K * 3 + 2 * M * K // 32)
     line("mxfp4_transpose_mxfp8 4096x4096", time_us(lambda: q.mxfp4_transpose_mxfp8(xq, xs2), args.iters), bytes_=M * K // 2 + M * K // 32 + M * K + M * K // 32)
+    # ---- small-batch (decode) shapes: skinny split-K kernel vs the tiled kernels ---------------------------------
+    w = torch.randn(14336, 4096, dtype=torch.bfloat16, device=dev) * 25.0
+    w_q, w_s = q.fusedQuantizeMx(w, h32, method="abs_max")
+    w_sf = to_blocked(w_s)
+    for (mm, nn) in ((1, 4096), (16, 4096), (32, 4096), (16, 14336), (32, 14336)):
+        xa = torch.randn(mm, 4096, dtype=torch.bfloat16, device=dev) * 25.0
+        xa_q, xa_s = q.fusedQuantizeMx(xa, h32, method="abs_max")
+        xa_sf = to_blocked(xa_s)
+        wq, wsf = w_q[:nn], to_blocked(w_s.view(torch.uint8).reshape(-1)[: nn * 128].reshape(nn, 128).view(torch.float8_e8m0fnu))
+        wbytes = nn * 4096 // 2 + nn * 128 + mm * 4096 // 2 + 2 * mm * nn
+        for var, tag in ((0, "auto = skinny split-K"), (2, "128x128 lockstep"), (24, "128x128 simple")):
+            q._lib.set_option("gemm_variant", var)
+            us = time_us(lambda: q.matmul_mxf4_bf16_tn(xa_q, wq, xa_sf, wsf, alpha), args.iters)
+            q._lib.set_option("gemm_variant", 0)
+            line(f"matmul_mxf4_bf16_tn {mm}x{nn}x4096 [{tag}]", us, bytes_=wbytes)
     for r in (64, 128):
         hr = hadamard(r, dev)
         line(f"fusedQuantizeMx(H{r}, abs_max) 4096x4096", time_us(lambda: q.fusedQuantizeMx(x, hr, method="abs_max"), args.iters), bytes_=qb)
