@@ -1,0 +1,132 @@
+#!/usr/bin/env python3
+"""Sweep harness in the shape of the reference's benchmarks/bench_mxfp4_sm100.py / bench_nvfp4_sm100.py: TFLOP/s of a
+quantised linear layer vs batch size for the layer shapes of a model, three providers
+
+    torch-bf16             torch.nn.functional.linear on bf16 operands (the library GEMM torch ships)
+    <fmt>-native           fusedQuantize(activations) + to_blocked + block-scaled GEMM   (weights pre-quantised)
+    <fmt>-native-noquant   the GEMM alone on pre-quantised activations ("ideal" provider of the reference)
+
+timed as HIP-graph replays (the reference uses triton.testing.do_bench_cudagraph; triton is not used here), median and
+20 / 80 % quantiles over `--reps` replays.  Prints one table per layer and writes CSVs under benchmarks_output/.
+
+    python benchmarks/bench_mxfp4_mi355x.py [--format mxfp4|nvfp4] [--model Llama-3.1-70B] [--had 32] [--quick]
+"""
+from __future__ import annotations
+
+import argparse
+import csv
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+MODELS = {   # (K, N) per linear layer, as in the reference harness
+    "Llama-3.1-70B": [(8192, 8192), (8192, 57344), (28672, 8192)],
+    "Llama-3-8B": [(4096, 6144), (4096, 4096), (4096, 28672), (14336, 4096)],
+    "Qwen3-32B": [(5120, 5120), (5120, 51200), (25600, 5120)],
+    "Qwen3-8B": [(4096, 4096), (4096, 24576), (12288, 4096)],
+}
+BATCHES = [1, 4, 8, 16, 32, 64, 128, 256, 512, 1024, 2048, 4096, 8192, 16384, 24576, 32768, 65536]
+
+
+def hadamard(n, device):
+    h = torch.ones(1, 1)
+    while h.shape[0] < n:
+        h = torch.cat([torch.cat([h, h], 1), torch.cat([h, -h], 1)], 0)
+    return (h * n ** -0.5).to(torch.bfloat16).to(device)
+
+
+def bench_graph(fn, reps):
+    """Median / q20 / q80 milliseconds of one call, measured as replays of a captured HIP graph."""
+    fn()
+    torch.cuda.synchronize()
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        for _ in range(3):
+            fn()
+    torch.cuda.current_stream().wait_stream(s)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        fn()
+    ts = []
+    for _ in range(reps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        g.replay()
+        e1.record()
+        e1.synchronize()
+        ts.append(e0.elapsed_time(e1))
+    t = torch.tensor(ts)
+    return t.median().item(), t.quantile(0.2).item(), t.quantile(0.8).item()
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--format", choices=["mxfp4", "nvfp4"], default="mxfp4")
+    ap.add_argument("--model", default="Llama-3.1-70B", choices=sorted(MODELS))
+    ap.add_argument("--had", type=int, default=32)
+    ap.add_argument("--reps", type=int, default=50)
+    ap.add_argument("--max-batch", type=int, default=65536)
+    ap.add_argument("--quick", action="store_true", help="batch sizes 1, 16, 256, 4096 only, first two layers")
+    args = ap.parse_args()
+
+    import qutlass_amd as q
+    from qutlass_amd.utils import to_blocked
+
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    h = hadamard(args.had, dev)
+    alpha = torch.tensor([1.0], device=dev)
+    gs = torch.tensor([1.0], device=dev)
+    nv = args.format == "nvfp4"
+    quant = (lambda t: q.fusedQuantizeNv(t, h, gs)) if nv else (lambda t: q.fusedQuantizeMx(t, h, method="abs_max"))
+    gemm = q.matmul_nvf4_bf16_tn if nv else q.matmul_mxf4_bf16_tn
+    providers = ["torch-bf16", f"{args.format}-native", f"{args.format}-native-noquant"]
+    layers = MODELS[args.model][:2] if args.quick else MODELS[args.model]
+    batches = [1, 16, 256, 4096] if args.quick else [b for b in BATCHES if b <= args.max_batch]
+    os.makedirs(os.path.join(ROOT, "benchmarks_output"), exist_ok=True)
+
+    for K, N in layers:
+        print(f"{args.model}, N={N} K={K}, HAD={args.had}, BF16 vs {args.format.upper()} GEMMs TFLOP/s (median [q20, q80]):")
+        w = torch.randn(N, K, device=dev, dtype=torch.bfloat16)
+        w_q, w_s = quant(w)
+        w_sf = to_blocked(w_s)
+        rows = []
+        print(f"{'batch':>8} " + " ".join(f"{p:>34}" for p in providers))
+        for M in batches:
+            if M * max(N, K) * 2 > 24 << 30:   # keep single tensors under 24 GiB
+                continue
+            a = torch.randn(M, K, device=dev, dtype=torch.bfloat16)
+            a_q, a_s = quant(a)
+            a_sf = to_blocked(a_s)
+            fns = {
+                providers[0]: lambda: torch.nn.functional.linear(a, w),
+                providers[1]: lambda: gemm(*(lambda aq, asf: (aq, w_q, to_blocked(asf), w_sf, alpha))(*quant(a))),
+                providers[2]: lambda: gemm(a_q, w_q, a_sf, w_sf, alpha),
+            }
+            row = {"batch": M}
+            cells = []
+            for pname in providers:
+                ms, lo, hi = bench_graph(fns[pname], args.reps)
+                tf = lambda t: 2.0 * M * N * K * 1e-12 / (t * 1e-3)
+                row[pname], row[pname + "_q20"], row[pname + "_q80"] = tf(ms), tf(hi), tf(lo)
+                cells.append(f"{tf(ms):10.1f} [{tf(hi):8.1f},{tf(lo):8.1f}]")
+            rows.append(row)
+            print(f"{M:8d} " + " ".join(f"{c:>34}" for c in cells), flush=True)
+            del a, a_q, a_s, a_sf
+        path = os.path.join(ROOT, "benchmarks_output", f"bench_{args.format}_res_n{N}_k{K}_had{args.had}_mi355x.csv")
+        with open(path, "w", newline="") as f:
+            wr = csv.DictWriter(f, fieldnames=list(rows[0].keys()))
+            wr.writeheader()
+            wr.writerows(rows)
+        print(f"  -> {os.path.relpath(path, ROOT)}\n")
+        del w, w_q, w_s, w_sf
+
+
+if __name__ == "__main__":
+    main()

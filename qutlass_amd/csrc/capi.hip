@@ -72,6 +72,9 @@ int dispatch_variant(int v, const GemmParams& p, hipStream_t s, const char* name
     case 24: return launch_gemm<GemmCfg<128, 128, 2, 2, EBITS, SPLIT>, 3>(p, s);   // simple schedule (default, small)
     case 25: return launch_gemm<GemmCfg<256, 128, 4, 2, EBITS, SPLIT>, 3>(p, s);
     case 26: return launch_gemm<GemmCfg<128, 256, 2, 4, EBITS, SPLIT>, 3>(p, s);
+    case 27: return launch_gemm<GemmCfg<128, 64, 2, 2, EBITS, SPLIT>, 3>(p, s);    // mid-size problems: more, smaller tiles
+    case 28: return launch_gemm<GemmCfg<64, 128, 2, 2, EBITS, SPLIT>, 3>(p, s);
+    case 29: return launch_gemm<GemmCfg<64, 64, 2, 2, EBITS, SPLIT>, 3>(p, s);
   }
   if constexpr (EBITS == 4) {
     switch (v) {
@@ -149,10 +152,17 @@ int gemm_mx(const char* name, const void* A, const void* B, const void* A_sf, co
     return check_launch("gemm_mx_skinny_kernel");
   }
   if (variant == 0) {
-    // auto (measured, profiles/native_r1_schedules.log): fp4 256x256 tiles run the "deep" schedule (4 waves of
-    // 128x128, variant 30), fp8 the "simple" one (variant 20); 128x128 tiles (variant 24) when M or N <= 128, the
-    // 128x128 lockstep kernel (variant 2) when M or N <= 64 (13.2 vs 15.7 us at 16x4096x4096)
-    variant = (M <= 64 || N <= 64) ? 2 : (M <= 128 || N <= 128) ? 24 : (EBITS == 4 ? 30 : 20);
+    // auto (measured, profiles/native_r1_schedules.log, profiles/bench_sweep_*.txt): the largest tile that still gives
+    // every CU work -- 256x256 ("deep" schedule for fp4, "simple" for fp8), then 128x128, 128x64 / 64x128, 64x64 (simple
+    // schedule, several workgroups per CU).  (fp4 with M <= 32 went to the split-K kernel above.)
+    auto tiles = [&](int bm, int bn) { return cdiv(M, bm) * cdiv(N, bn); };
+    const int64_t want = 192;   // 3/4 of the 256 CUs
+    if (M <= 64) variant = (tiles(64, 128) >= want) ? 28 : 29;          // no point in tiles taller than the problem
+    else if (N <= 64) variant = (tiles(128, 64) >= want) ? 27 : 29;
+    else if (tiles(256, 256) >= want) variant = (EBITS == 4) ? 30 : 20;
+    else if (tiles(128, 128) >= want) variant = 24;
+    else if (tiles(128, 64) >= want || tiles(64, 128) >= want) variant = (N >= M) ? 27 : 28;
+    else variant = 29;
   }
   return dispatch_variant<EBITS, EBITS == 8>(variant, p, s, name);
 }

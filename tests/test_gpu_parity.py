@@ -174,7 +174,7 @@ def _gemm_golden(q, g, c, fn, sf_dtype, kind):
     return _np(out), g[f"out{c}"]
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 5, 6, 7, 20, 24, 30, 40, 60])
+@pytest.mark.parametrize("variant", [0, 1, 2, 5, 6, 7, 20, 24, 27, 28, 29, 30, 40, 60])
 def test_matmul_mxf4_golden_bit_exact(q, golden_dir, variant):
     g = _load(golden_dir, "gemm_mxfp4.npz")
     q._lib.set_option("gemm_variant", variant)
@@ -233,7 +233,7 @@ def test_matmul_mxf4_full_size_properties(q):
     perm = torch.randperm(m, device=DEV)
     outp = q.matmul_mxf4_bf16_tn(a_q[perm].contiguous(), b_q, to_blocked(a_s[perm].contiguous()), bsf, torch.tensor([1.0], device=DEV))
     assert torch.equal(outp, out[perm])
-    for variant in (1, 5, 6, 3, 4, 8, 9, 20, 30, 40):
+    for variant in (1, 5, 6, 3, 4, 8, 9, 20, 27, 28, 29, 30, 40):
         q._lib.set_option("gemm_variant", variant)
         try:
             assert torch.equal(q.matmul_mxf4_bf16_tn(a_q, b_q, asf, bsf, torch.tensor([1.0], device=DEV)), out), variant
