@@ -64,6 +64,23 @@ def cpu_baseline(a_q, a_s, b_q, b_s, rows):
     }, out
 
 
+def max_over_ranks(wall: float, device=None) -> float:
+    """The job's step time is the slowest rank's (replicas: no data-path collective, only this MAX-reduce and the
+    barriers around the timed region go through torch.distributed -- RCCL on GPUs, gloo in the CPU test)."""
+    import torch.distributed as dist
+
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return wall
+    tw = torch.tensor([wall], dtype=torch.float64, device=device if device is not None else "cpu")
+    dist.all_reduce(tw, op=dist.ReduceOp.MAX)
+    return float(tw.item())
+
+
+def aggregate_value(flop_per_step: float, steps: int, world: int, wall: float) -> float:
+    """Whole-job TFLOP/s: every rank runs the same workload (weak scaling, independent replicas)."""
+    return flop_per_step * steps * world / wall / 1e12
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -123,15 +140,10 @@ def main():
     wall = time.perf_counter() - t0
     kernel_ms = ev0.elapsed_time(ev1) / args.steps  # average launch-to-launch duration of the GEMM kernel
 
-    if world > 1:
-        import torch.distributed as dist
-
-        tw = torch.tensor([wall], device=dev, dtype=torch.float64)
-        dist.all_reduce(tw, op=dist.ReduceOp.MAX)
-        wall = float(tw.item())
+    wall = max_over_ranks(wall, dev if world > 1 else None)
 
     flop_per_step = 2.0 * M * N * K
-    value = flop_per_step * args.steps * world / wall / 1e12
+    value = aggregate_value(flop_per_step, args.steps, world, wall)
     achieved = flop_per_step / (kernel_ms * 1e-3) / 1e12
 
     result = {
