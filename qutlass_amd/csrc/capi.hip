@@ -246,7 +246,7 @@ int qutlass_amd_matmul_mxf8_bf16_nn(const void* A, const void* B, const void* A_
   if (M * K >= (1ll << 31)) return fail(QAMD_ERR_INVALID, "%s: operand larger than 2 GiB is not supported", name);
   TransposeParams t;
   t.in = (const uint8_t*)A; t.out = (uint8_t*)workspace; t.K = (int)K; t.M = (int)M;
-  hipLaunchKernelGGL(transpose_u8_kernel, dim3((unsigned)cdiv(M, 256), (unsigned)cdiv(K, 64)), dim3(256), 0, (hipStream_t)stream, t);
+  hipLaunchKernelGGL(transpose_u8_kernel, dim3((unsigned)cdiv(M, 128), (unsigned)cdiv(K, 128)), dim3(256), 0, (hipStream_t)stream, t);
   if (int rc = check_launch("transpose_u8_kernel")) return rc;
   return gemm_mx<8>(name, workspace, B, A_sf, B_sf, alpha, D, M, N, K, stream);
 }

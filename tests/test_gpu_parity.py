@@ -489,3 +489,37 @@ def test_small_batch_paths_agree_with_tiled_kernel_and_oracle(q, m, n, k):
                                       1.0 / 9.0, m, n, k)
         assert np.array_equal(_np(out_ada), ref)
 
+
+
+def test_ops_are_hip_graph_capturable(q):
+    """The reference's benchmarks time the ops under CUDA graphs (benchmarks/bench_mxfp4_sm100.py:216); the whole
+    quantize -> swizzle -> GEMM chain (incl. the allocations inside the ops) must capture and replay."""
+    from qutlass_amd.utils import to_blocked
+
+    torch.manual_seed(31)
+    h = _hadamard(32)
+    a = torch.randn(512, 1024, dtype=torch.bfloat16, device=DEV) * 25.0
+    b = torch.randn(768, 1024, dtype=torch.bfloat16, device=DEV) * 25.0
+    alpha = torch.tensor([1.0], device=DEV)
+    b_q, b_s = q.fusedQuantizeMx(b, h, method="abs_max")
+    b_sf = to_blocked(b_s)
+
+    def chain():
+        a_q, a_s = q.fusedQuantizeMx(a, h, method="abs_max")
+        return q.matmul_mxf4_bf16_tn(a_q, b_q, to_blocked(a_s), b_sf, alpha)
+
+    want = chain()
+    torch.cuda.synchronize()
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        for _ in range(2):
+            chain()
+    torch.cuda.current_stream().wait_stream(s)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        got = chain()
+    a.mul_(-1.0)            # new input in the captured buffer: the replay must recompute
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(got.view(torch.int16), (-want).view(torch.int16))
