@@ -522,4 +522,4 @@ def test_ops_are_hip_graph_capturable(q):
     a.mul_(-1.0)            # new input in the captured buffer: the replay must recompute
     g.replay()
     torch.cuda.synchronize()
-    assert torch.equal(got.view(torch.int16), (-want).view(torch.int16))
+    assert torch.equal(got, -want)      # value equality: an exact 0 keeps its sign bit under negation of the input
