@@ -1,0 +1,160 @@
+"""GPU: randomised shape sweep of every op against the CPU oracle (seeded, small sizes so the oracle stays fast).
+Complements test_gpu_parity.py, which pins the golden fixtures and the reference's own test shapes: here ragged
+M / N, K tails, every auto-selected tile configuration and leading batch dimensions are drawn at random."""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device("cuda", 0)
+
+
+@pytest.fixture(scope="module")
+def q():
+    import qutlass_amd
+
+    return qutlass_amd
+
+
+def _np(t):
+    t = t.detach().cpu().contiguous()
+    if t.dtype == torch.bfloat16:
+        return t.view(torch.uint16).numpy()
+    if t.element_size() == 1:
+        return t.view(torch.uint8).numpy()
+    return t.numpy()
+
+
+def _hadamard(n):
+    h = torch.ones(1, 1)
+    while h.shape[0] < n:
+        h = torch.cat([torch.cat([h, h], 1), torch.cat([h, -h], 1)], 0)
+    return (h * n ** -0.5).to(torch.bfloat16).to(DEV)
+
+
+def _rand_codes(rng, rows, kbytes):
+    return torch.from_numpy(rng.integers(0, 256, size=(rows, kbytes), dtype=np.uint8)).to(DEV)
+
+
+def test_fuzz_matmul_mxf4(q):
+    from qutlass_amd.utils import to_blocked
+
+    rng = np.random.default_rng(101)
+    ms = [1, 2, 7, 16, 31, 32, 33, 48, 64, 65, 100, 128, 129, 200, 256, 300, 520]
+    for it in range(40):
+        m = int(rng.choice(ms))
+        n = int(rng.integers(1, 90)) * 8
+        k = int(rng.integers(1, 12)) * 128
+        a, b = _rand_codes(rng, m, k // 2), _rand_codes(rng, n, k // 2)
+        # scale exponents within 3 binades: every fp32 partial sum is exact (K * 144 * 2^(2*3) < 2^24 for K <= 1408), so
+        # any summation order must reproduce the fp64 oracle bit for bit; every 4th case draws 16 binades, where fp32
+        # accumulation may round and the bar is the north-star tolerance (<= 1e-2 relative to max|ref|)
+        wide = it % 4 == 3
+        lo, hi = (118, 134) if wide else (126, 129)
+        sa = torch.from_numpy(rng.integers(lo, hi, size=(m, k // 32), dtype=np.uint8)).to(DEV)
+        sb = torch.from_numpy(rng.integers(lo, hi, size=(n, k // 32), dtype=np.uint8)).to(DEV)
+        alpha = torch.tensor([float(rng.choice([1.0, 0.5, 0.25]))], device=DEV)
+        e8 = torch.float8_e8m0fnu
+        out = q.matmul_mxf4_bf16_tn(a, b, to_blocked(sa.view(e8)), to_blocked(sb.view(e8)), alpha)
+        out2 = q.matmul_ada_mxf4_bf16_tn(a, b, sa.view(e8), sb.view(e8), alpha)
+        ref = oracle.gemm_blockscaled(oracle.KIND_MXFP4, _np(a), _np(b), oracle.to_blocked(_np(sa)), oracle.to_blocked(_np(sb)),
+                                      float(alpha.item()), m, n, k)
+        if wide:
+            want = oracle.bf16_bits_to_f32(ref).astype(np.float64)
+            for o in (out, out2):
+                got = oracle.bf16_bits_to_f32(_np(o)).astype(np.float64)
+                assert np.abs(got - want).max() <= 1e-2 * np.abs(want).max(), (it, m, n, k)
+        else:
+            assert np.array_equal(_np(out), ref), (it, m, n, k, int((_np(out) != ref).sum()))
+            assert np.array_equal(_np(out2), ref), ("ada", it, m, n, k)
+
+
+def test_fuzz_matmul_nvf4_and_mxf8(q):
+    from qutlass_amd.utils import to_blocked
+
+    rng = np.random.default_rng(102)
+    for it in range(16):
+        m, n = int(rng.choice([1, 16, 40, 128, 136, 300])), int(rng.integers(1, 50)) * 8
+        k = int(rng.integers(1, 20)) * 32
+        a, b = _rand_codes(rng, m, k // 2), _rand_codes(rng, n, k // 2)
+        sa = torch.from_numpy(rng.integers(0x28, 0x48, size=(m, k // 16), dtype=np.uint8)).to(DEV)
+        sb = torch.from_numpy(rng.integers(0x28, 0x48, size=(n, k // 16), dtype=np.uint8)).to(DEV)
+        alpha = torch.tensor([1.0], device=DEV)
+        e4 = torch.float8_e4m3fn
+        out = q.matmul_nvf4_bf16_tn(a, b, to_blocked(sa.view(e4)), to_blocked(sb.view(e4)), alpha)
+        ref = oracle.gemm_blockscaled(oracle.KIND_NVFP4, _np(a), _np(b), oracle.to_blocked(_np(sa)), oracle.to_blocked(_np(sb)), 1.0, m, n, k)
+        assert np.array_equal(_np(out), ref), (it, m, n, k, int((_np(out) != ref).sum()))
+    for it in range(16):
+        m, n = int(rng.choice([16, 48, 128, 144, 272])), int(rng.integers(1, 50)) * 8
+        k = int(rng.integers(1, 20)) * 32
+        x = (torch.from_numpy(rng.standard_normal((m, k)).astype(np.float32)) * 4).to(torch.float8_e4m3fn).to(DEV)
+        y = (torch.from_numpy(rng.standard_normal((n, k)).astype(np.float32)) * 4).to(torch.float8_e4m3fn).to(DEV)
+        sa = torch.from_numpy(rng.integers(120, 131, size=(m, k // 32), dtype=np.uint8)).to(DEV)
+        sb = torch.from_numpy(rng.integers(120, 131, size=(n, k // 32), dtype=np.uint8)).to(DEV)
+        alpha = torch.tensor([1.0], device=DEV)
+        e8 = torch.float8_e8m0fnu
+        out = q.matmul_mxf8_bf16_tn(x, y, to_blocked(sa.view(e8)), to_blocked(sb.view(e8)), alpha)
+        ref = oracle.gemm_blockscaled(oracle.KIND_MXFP8_TN, _np(x), _np(y), oracle.to_blocked(_np(sa)), oracle.to_blocked(_np(sb)), 1.0, m, n, k)
+        got = oracle.bf16_bits_to_f32(_np(out)).astype(np.float64)
+        want = oracle.bf16_bits_to_f32(ref).astype(np.float64)
+        assert (np.abs(got - want) <= np.abs(want) / 128.0 + 2e-5 * np.abs(want).max()).all(), (it, m, n, k)
+        x_km = x.view(torch.uint8).T.contiguous().view(torch.float8_e4m3fn)
+        out_nn = q.matmul_mxf8_bf16_nn(x_km, y, to_blocked(sa.view(e8)), to_blocked(sb.view(e8)), alpha)
+        assert torch.equal(out_nn.view(torch.int16), out.view(torch.int16)), ("nn", it, m, n, k)
+
+
+def test_fuzz_quantizers_and_swizzle(q):
+    rng = np.random.default_rng(103)
+    for it in range(24):
+        R = int(rng.choice([32, 64, 128]))
+        lead = tuple(int(v) for v in rng.integers(1, 5, size=int(rng.integers(0, 3))))
+        rows, cols = int(rng.integers(1, 40)), int(rng.integers(1, 6)) * R
+        x = torch.from_numpy(rng.standard_normal(lead + (rows, cols)).astype(np.float32) * float(rng.choice([0.01, 1.0, 25.0, 3000.0]))).to(torch.bfloat16).to(DEV)
+        h = _hadamard(R) if rng.random() < 0.7 else (torch.randn(R, R) * 0.2).to(torch.bfloat16).to(DEV)
+        method = str(rng.choice(["quest", "abs_max"]))
+        mask = method == "quest" and R == 32 and rng.random() < 0.5
+        res = q.fusedQuantizeMx(x, h, method=method, return_mask=mask)
+        rq, rs, rm = oracle.fused_quantize_mx(_np(x), _np(h), oracle.QUEST if method == "quest" else oracle.ABS_MAX, with_mask=mask, acc_model=1)
+        got_s = _np(res[1]).reshape(-1)[: rs.size]
+        sbad = int((got_s != rs).sum())
+        assert sbad <= max(1, 2e-3 * rs.size), (it, R, method, sbad)        # MFMA vs exact-sum order: rare binade flips only
+        same_grp = got_s == rs                                                # groups whose scale agrees
+        eq = oracle.codes_equal_mod_zero_sign(_np(res[0]).reshape(-1), rq)     # one flag per code
+        assert int((~eq & same_grp.repeat(32)).sum()) <= max(2, 2e-3 * eq.size), (it, R, method)
+        if mask:
+            mm = _np(res[2]).reshape(-1)                                       # 4 mask bytes per group
+            assert int(((mm != rm) & same_grp.repeat(4)).sum()) <= max(1, 1e-3 * rm.size)
+    for it in range(12):
+        r, c = int(rng.integers(1, 700)), int(rng.integers(1, 70))
+        a = torch.from_numpy(rng.integers(0, 256, size=(r, c), dtype=np.uint8)).to(DEV)
+        from qutlass_amd.utils import to_blocked
+
+        assert np.array_equal(_np(to_blocked(a)), oracle.to_blocked(_np(a))), (it, r, c)
+
+
+def test_fuzz_backward_ops(q):
+    rng = np.random.default_rng(104)
+    h = _hadamard(32)
+    for it in range(10):
+        B, N, M = int(rng.integers(1, 4)), int(rng.integers(1, 9)) * 32, int(rng.integers(1, 40)) * 8
+        x = torch.from_numpy(rng.standard_normal((B, N, M)).astype(np.float32) * 25.0).to(torch.bfloat16).to(DEV)
+        e2m1, e8m0 = q.backward_t_bf16(x, h)
+        rq, rs = oracle.backward_t_bf16(_np(x), _np(h), acc_model=1)
+        assert np.array_equal(_np(e8m0), rs), (it, B, N, M)
+        eq = oracle.codes_equal_mod_zero_sign(_np(e2m1).reshape(rq.shape), rq)
+        assert int((~eq).sum()) <= max(2, 1e-3 * eq.size), (it, B, N, M)
+    for it in range(6):
+        m, n = int(rng.integers(1, 5)) * 128, int(rng.integers(1, 5)) * 128
+        x = torch.from_numpy(rng.standard_normal((m, n)).astype(np.float32) * float(rng.choice([1e-3, 1.0, 500.0]))).to(torch.bfloat16).to(DEV)
+        y, rs, cs = q.backward_bf16_square_double_mxfp8(x)
+        ry, rrs, rcs = oracle.backward_bf16_square_double_mxfp8(_np(x))
+        assert np.array_equal(_np(y), ry) and np.array_equal(_np(rs), rrs) and np.array_equal(_np(cs), rcs), (it, m, n)
+    for it in range(6):
+        m, n = int(rng.integers(1, 4)) * 256, int(rng.integers(1, 4)) * 256
+        xq = _rand_codes(rng, m, n // 2)
+        xs = torch.from_numpy(rng.integers(110, 140, size=(m, n // 32), dtype=np.uint8)).to(DEV)
+        y, e = q.mxfp4_transpose_mxfp8(xq, xs.view(torch.float8_e8m0fnu))
+        ry, re = oracle.mxfp4_transpose_mxfp8(_np(xq), _np(xs))
+        assert np.array_equal(_np(e), re) and np.array_equal(_np(y), ry), (it, m, n)
