@@ -76,6 +76,9 @@ int dispatch_variant(int v, const GemmParams& p, hipStream_t s, const char* name
     case 28: return launch_gemm<GemmCfg<64, 128, 2, 2, EBITS, SPLIT>, 3>(p, s);
     case 29: return launch_gemm<GemmCfg<64, 64, 2, 2, EBITS, SPLIT>, 3>(p, s);
   }
+  if constexpr (EBITS == 8) {
+    if (v == 30) return launch_gemm<GemmCfg<256, 256, 2, 2, 8, true>, 4>(p, s);   // fp8 deep schedule
+  }
   if constexpr (EBITS == 4) {
     switch (v) {
       case 6: return launch_gemm<GemmCfg<256, 256, 2, 4, 4, false>, 2>(p, s);
@@ -153,13 +156,13 @@ int gemm_mx(const char* name, const void* A, const void* B, const void* A_sf, co
   }
   if (variant == 0) {
     // auto (measured, profiles/native_r1_schedules.log, profiles/bench_sweep_*.txt): the largest tile that still gives
-    // every CU work -- 256x256 ("deep" schedule for fp4, "simple" for fp8), then 128x128, 128x64 / 64x128, 64x64 (simple
+    // every CU work -- 256x256 ("deep" schedule, 4 waves of 128x128), then 128x128, 128x64 / 64x128, 64x64 (simple
     // schedule, several workgroups per CU).  (fp4 with M <= 32 went to the split-K kernel above.)
     auto tiles = [&](int bm, int bn) { return cdiv(M, bm) * cdiv(N, bn); };
     const int64_t want = 192;   // 3/4 of the 256 CUs
     if (M <= 64) variant = (tiles(64, 128) >= want) ? 28 : 29;          // no point in tiles taller than the problem
     else if (N <= 64) variant = (tiles(128, 64) >= want) ? 27 : 29;
-    else if (tiles(256, 256) >= want) variant = (EBITS == 4) ? 30 : 20;
+    else if (tiles(256, 256) >= want) variant = 30;
     else if (tiles(128, 128) >= want) variant = 24;
     else if (tiles(128, 64) >= want || tiles(64, 128) >= want) variant = (N >= M) ? 27 : 28;
     else variant = 29;

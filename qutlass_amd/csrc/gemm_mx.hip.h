@@ -885,6 +885,109 @@ __device__ __forceinline__ void gemm_mx_deep(char* smem, const GemmParams& p) {
 }
 
 // -------------------------------------------------------------------------------------------------
+// Schedule 5b ("deep", fp8): the same 4-wave 128x128 organisation for MXFP8.  A stage has two k-slices of two
+// 16-byte chunks per fragment (register halves u = 0, 1; split layout: chunk 4j + 2u + g, op_sel 2j), so there
+// are two fragment sets and the hand-off sits between the slices:
+//     R(1) ; M(0)
+//     wait own DMA(kt+1) + reads ; BARRIER
+//     scales' ; R'(0) ; M(1) interleaved with the DMA of stage kt+2 (one piece per MFMA)
+// An MFMA is 64 cycles here, a slice 1024: reads and DMA have twice the shadow they have in the fp4 kernel.
+// -------------------------------------------------------------------------------------------------
+template <class C>
+__device__ __forceinline__ void gemm_mx_deep8(char* smem, const GemmParams& p) {
+  static_assert(C::EBITS == 8 && C::F8SPLIT && C::KSL == 2 && C::CPS == 2, "fp8 deep schedule: split register layout");
+  constexpr int MT = C::MT, NT = C::NT;
+  GemmCtx<C> cx(smem, p);
+  v8i fa[2][MT] = {}, fb[2][NT] = {};
+  int sa[2][MT], sb[2][NT];
+
+  auto read_slice = [&](int buf, int j) __attribute__((always_inline)) {
+    const char* st = smem + buf * C::STAGE_BYTES;
+#pragma unroll
+    for (int t = 0; t < MT; ++t) {
+      const v4i lo = *(const v4i*)(st + cx.rdA[2 * j] + t * 32 * C::ROWB);
+      const v4i hi = *(const v4i*)(st + cx.rdA[2 * j + 1] + t * 32 * C::ROWB);
+      fa[j][t] = v8i{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    }
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const v4i lo = *(const v4i*)(st + cx.rdBd + cx.rdA[2 * j] + t * 32 * C::ROWB);
+      const v4i hi = *(const v4i*)(st + cx.rdBd + cx.rdA[2 * j + 1] + t * 32 * C::ROWB);
+      fb[j][t] = v8i{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    }
+  };
+  auto read_scales = [&](int buf, int set) __attribute__((always_inline)) {
+    const char* st = smem + buf * C::STAGE_BYTES;
+    const int shift = 8 * cx.g;   // split layout: lanes 0-31 carry K-block 2j, lanes 32-63 K-block 2j+1
+#pragma unroll
+    for (int t = 0; t < MT; ++t) sa[set][t] = (int)((unsigned)(*(const int*)(st + cx.rdSA[t])) >> shift);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) sb[set][t] = (int)((unsigned)(*(const int*)(st + cx.rdSB[t])) >> shift);
+  };
+  auto mfma1 = [&](int j, int sset, int m, int n) __attribute__((always_inline)) {
+    if (j == 0) cx.acc[m][n] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fb[0][n], fa[0][m], cx.acc[m][n], 0, 0, 0, sb[sset][n], 0, sa[sset][m]);
+    if (j == 1) cx.acc[m][n] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fb[1][n], fa[1][m], cx.acc[m][n], 0, 0, 2, sb[sset][n], 2, sa[sset][m]);
+  };
+  auto fence = [&]() __attribute__((always_inline)) { __builtin_amdgcn_sched_barrier(0); };
+  constexpr int NPIECE = C::NA + C::NB;
+
+  auto stage = [&](int kt, auto bufc) __attribute__((always_inline)) {
+    constexpr int BUF = decltype(bufc)::value;
+    read_slice(BUF, 1); fence();
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int n = 0; n < NT; ++n) mfma1(0, BUF, m, n);
+    fence();
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    fence();
+    read_scales(BUF ^ 1, BUF ^ 1);   // (after the last stage these read stale LDS; never used)
+    read_slice(BUF ^ 1, 0); fence();
+    char* st = smem + BUF * C::STAGE_BYTES;
+    const bool valid = kt + 2 < cx.KT;
+    int idx = 0;
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int n = 0; n < NT; ++n) {
+        mfma1(1, BUF, m, n);
+        constexpr int PER = (NPIECE + MT * NT - 1) / (MT * NT);
+#pragma unroll
+        for (int e = 0; e < PER; ++e) {
+          const int t = idx * PER + e;
+          if (t < C::NA) cx.issue_pieces_range(C::NA, cx.rA, st, kt + 2, valid, t, t + 1);
+          else if (t < NPIECE) cx.issue_pieces_range(C::NB, cx.rB, st + C::OFF_B, kt + 2, valid, t - C::NA, t - C::NA + 1);
+        }
+        if (idx == 0) cx.issue_scales(kt + 2, st, valid);
+        fence();
+        ++idx;
+      }
+  };
+
+  cx.issue_stage_part(0, 0, 0);
+  cx.issue_stage_part(0, 0, 1);
+  cx.issue_stage_part(1, 1, 0, 1 < cx.KT);
+  cx.issue_stage_part(1, 1, 1, 1 < cx.KT);
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPIECE + 1) : "memory");
+  __builtin_amdgcn_s_barrier();
+  fence();
+  read_scales(0, 0);
+  read_slice(0, 0);
+  fence();
+
+  int kt = 0;
+  for (; kt + 1 < cx.KT; kt += 2) {
+    stage(kt, std::integral_constant<int, 0>{});
+    stage(kt + 1, std::integral_constant<int, 1>{});
+  }
+  if (kt < cx.KT) stage(kt, std::integral_constant<int, 0>{});
+  fence();
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  cx.epilogue();
+}
+
+// -------------------------------------------------------------------------------------------------
 // Schedule 6 ("regstage"): the deep schedule with the HBM/L2 -> LDS copy staged through REGISTERS.
 //
 // A 2-deep LDS ring (2 x 68 KiB of 160) gives LDS-DMA exactly one stage to land, and the DMA of a stage
@@ -1057,6 +1160,7 @@ __global__ __launch_bounds__(C::THREADS) void gemm_mx_kernel(const GemmParams p)
   const bool clk = (C::ABL & ABL_CLOCK) && p.dbg && blockIdx.x == 0 && threadIdx.x == 0;
   const uint64_t c0 = clk ? __builtin_readcyclecounter() : 0, r0 = clk ? __builtin_amdgcn_s_memrealtime() : 0;
   if constexpr (SCHED == SCHED_REGSTAGE) gemm_mx_regstage<C>(smem, p);
+  else if constexpr (SCHED == SCHED_DEEP && C::EBITS == 8) gemm_mx_deep8<C>(smem, p);
   else if constexpr (SCHED == SCHED_DEEP) gemm_mx_deep<C>(smem, p);
   else if constexpr (SCHED == SCHED_SIMPLE) gemm_mx_simple<C>(smem, p);
   else if constexpr (SCHED == SCHED_QUEUE) gemm_mx_queue<C>(smem, p);

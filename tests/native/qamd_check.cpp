@@ -484,6 +484,17 @@ int main(int argc, char** argv) {
     check_blocked(128, 4); check_blocked(256, 16); check_blocked(384, 12); check_blocked(4096, 128);
     check_blocked(130, 5); check_blocked(16, 64); check_blocked(504, 128); check_blocked(8192, 512);
   }
+  if (want("deep8")) {
+    check_gemm("gemm_mxfp8 16x64x256 (deep)", 2, 16, 64, 256, 1.0f, 3, 0, 30);
+    check_gemm("gemm_mxfp8 ragged + K tail (deep)", 2, 72, 136, 352, 1.0f, 3, 0, 30);
+    check_gemm("gemm_mxfp8 512x512x1024 (deep)", 2, 512, 512, 1024, 1.0f, 3, 0, 30);
+    check_gemm("gemm_mxfp8 4096^3 (32 rows, deep)", 2, 4096, 4096, 4096, 1.0f, 3, 32, 30);
+    for (int rep = 0; rep < 2; ++rep)
+      for (int var : {20, 30}) {
+        bench_gemm("mxfp8 4096^3", 2, 4096, 4096, 4096, var, 30);
+        bench_gemm("mxfp8 8192^3", 2, 8192, 8192, 8192, var, 5);
+      }
+  }
   if (want("deep")) {
     for (int var : {30, 40}) {
       check_gemm("gemm_mxfp4 128^3 (deep)", 0, 128, 128, 128, 1.0f, 3, 0, var);

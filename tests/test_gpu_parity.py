@@ -306,6 +306,28 @@ def _mxfp8_close(got_bits, want_bits):
     return np.abs(got - want) <= tol
 
 
+@pytest.mark.parametrize("variant", [0, 20, 30])   # auto, 8-wave simple, 4-wave deep
+def test_matmul_mxf8_large_tiles_vs_oracle(q, variant):
+    from qutlass_amd.utils import to_blocked
+
+    torch.manual_seed(6)
+    m, n, k = 520, 776, 1056
+    a = torch.randn(m, k, dtype=torch.bfloat16) * 25.0
+    b = torch.randn(n, k, dtype=torch.bfloat16) * 25.0
+    aq, asf = oracle.pseudoquant_mxfp8(_np(a))
+    bq, bsf = oracle.pseudoquant_mxfp8(_np(b))
+    e4, e8 = torch.float8_e4m3fn, torch.float8_e8m0fnu
+    q._lib.set_option("gemm_variant", variant)
+    try:
+        out = q.matmul_mxf8_bf16_tn(torch.from_numpy(aq).to(DEV).view(e4), torch.from_numpy(bq).to(DEV).view(e4),
+                                    to_blocked(torch.from_numpy(asf).to(DEV).view(e8)), to_blocked(torch.from_numpy(bsf).to(DEV).view(e8)),
+                                    torch.tensor([1.0], device=DEV))
+    finally:
+        q._lib.set_option("gemm_variant", 0)
+    ref = oracle.gemm_blockscaled(oracle.KIND_MXFP8_TN, aq, bq, oracle.to_blocked(asf), oracle.to_blocked(bsf), 1.0, m, n, k)
+    assert _mxfp8_close(_np(out), ref).all()
+
+
 def test_matmul_mxf8_tn_golden_and_random(q, golden_dir):
     from qutlass_amd.utils import to_blocked
 
