@@ -146,6 +146,7 @@ int gemm_mx(const char* name, const void* A, const void* B, const void* A_sf, co
   p.dbg = g_dbg.load();
   hipStream_t s = (hipStream_t)stream;
   int variant = g_gemm_variant.load();
+  if (variant == 61 || variant == 62) variant = 0;   // these select the NN operand path only (matmul_mxf8_bf16_nn)
   if (EBITS == 4 && (variant == 60 || (variant == 0 && M <= 32))) {
     // small batch: weight-bandwidth bound -> split-K kernel without LDS staging (gemm_mx_skinny.hip.h)
     SkinnyParams q;
@@ -247,6 +248,22 @@ int qutlass_amd_matmul_mxf8_bf16_nn(const void* A, const void* B, const void* A_
   if (M % 16) return fail(QAMD_ERR_INVALID, "%s: M must be a multiple of 16 for the (K, M) operand (got %lld)", name, (long long)M);
   if (workspace_bytes < M * K) return fail(QAMD_ERR_INVALID, "%s: workspace too small (%lld < %lld bytes)", name, (long long)workspace_bytes, (long long)(M * K));
   if (M * K >= (1ll << 31)) return fail(QAMD_ERR_INVALID, "%s: operand larger than 2 GiB is not supported", name);
+  // large problems: the fused kernel reads A^T directly (no pre-pass, workspace untouched); "gemm_variant" 61 forces it,
+  // 62 forces the pre-pass
+  const int forced = g_gemm_variant.load();
+  if (forced == 61 || (forced == 0 && cdiv(M, 256) * cdiv(N, 256) >= 192)) {
+    if (!B || !A_sf || !B_sf || !alpha || !D) return fail(QAMD_ERR_INVALID, "%s: null pointer argument", name);
+    if (N % 8) return fail(QAMD_ERR_INVALID, "%s: N must be a multiple of 8 (got %lld)", name, (long long)N);
+    const int64_t CB = cdiv(K / 32, 4);
+    if (N * K >= (1ll << 31)) return fail(QAMD_ERR_INVALID, "%s: operand larger than 2 GiB is not supported", name);
+    GemmParams p;
+    p.A = (const uint8_t*)A; p.B = (const uint8_t*)B; p.SFA = (const uint8_t*)A_sf; p.SFB = (const uint8_t*)B_sf;
+    p.alpha = alpha; p.D = (uint16_t*)D; p.M = (int)M; p.N = (int)N; p.K = (int)K;
+    p.a_bytes = (uint32_t)(M * K); p.b_bytes = (uint32_t)(N * K);
+    p.sfa_bytes = (uint32_t)(cdiv(M, 128) * CB * 512); p.sfb_bytes = (uint32_t)(cdiv(N, 128) * CB * 512);
+    p.pp_shift = g_pp_shift.load(); p.pp_flags = g_pp_flags.load(); p.dbg = g_dbg.load();
+    return launch_gemm<GemmCfg<256, 256, 2, 2, 8, true>, 6>(p, (hipStream_t)stream);
+  }
   TransposeParams t;
   t.in = (const uint8_t*)A; t.out = (uint8_t*)workspace; t.K = (int)K; t.M = (int)M;
   hipLaunchKernelGGL(transpose_u8_kernel, dim3((unsigned)cdiv(M, 128), (unsigned)cdiv(K, 128)), dim3(256), 0, (hipStream_t)stream, t);

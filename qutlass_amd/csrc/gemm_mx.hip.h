@@ -30,6 +30,7 @@
 #include <type_traits>
 
 #include "common.hip.h"
+#include "transpose_u8.hip.h"   // transpose4x4_u8 (fused NN operand path)
 
 namespace qamd {
 
@@ -205,6 +206,7 @@ struct GemmCtx {
   }
 
   int trace_n = 0;
+  bool perm_rows = false;   // fused NN: lane i32 of fragment t owns tile row 4*i32 + t instead of 32*t + i32
   __device__ __forceinline__ void trace() {
     if (C::ABL & ABL_TRACE) {
       if (blockIdx.x == 0 && trace_n < C::TRACE_SLOTS) {
@@ -403,7 +405,7 @@ struct GemmCtx {
       for (int n = 0; n < NT; ++n)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          const int row = wave_m * C::WTM + 32 * m + i32;
+          const int row = wave_m * C::WTM + (perm_rows ? 4 * i32 + m : 32 * m + i32);
           const int cg = (wave_n * C::WTN + 32 * n + 8 * q + 4 * g) >> 2;   // 8-byte granule in the row
           v2i w;
           w[0] = pack_bf16x2(acc[m][n][4 * q + 0] * alpha, acc[m][n][4 * q + 1] * alpha);
@@ -893,21 +895,102 @@ __device__ __forceinline__ void gemm_mx_deep(char* smem, const GemmParams& p) {
 //     scales' ; R'(0) ; M(1) interleaved with the DMA of stage kt+2 (one piece per MFMA)
 // An MFMA is 64 cycles here, a slice 1024: reads and DMA have twice the shadow they have in the fp4 kernel.
 // -------------------------------------------------------------------------------------------------
-template <class C>
+template <class C, bool NN>
 __device__ __forceinline__ void gemm_mx_deep8(char* smem, const GemmParams& p) {
   static_assert(C::EBITS == 8 && C::F8SPLIT && C::KSL == 2 && C::CPS == 2, "fp8 deep schedule: split register layout");
   constexpr int MT = C::MT, NT = C::NT;
+  static_assert(!NN || (MT == 4 && C::BM == 256 && C::NWAVES == 4), "fused NN: 4 row fragments per lane, 8 A^T pieces per wave");
   GemmCtx<C> cx(smem, p);
   v8i fa[2][MT] = {}, fb[2][NT] = {};
   int sa[2][MT], sb[2][NT];
 
-  auto read_slice = [&](int buf, int j) __attribute__((always_inline)) {
-    const char* st = smem + buf * C::STAGE_BYTES;
+  // ---- fused NN (A handed over as (K, M), matmul_host_mxf8_bf16_nn, gemm.cu:388-434) --------------------------------
+  // The A^T stage is DMAed as it lies in memory: [128 k][256 m] bytes, 256-byte rows (piece = 4 k-rows; 16-byte chunk
+  // c of row k stored at chunk c ^ 8*((k>>4)&1) so that the two lane halves, which read k-chunks of opposite parity,
+  // hit disjoint banks).  A lane then reads the DWORD (k, m = 4*i32 .. +3) for the 16 k of its chunk and transposes
+  // 4x4 byte blocks in registers (v_perm_b32): the four bytes of a dword belong to FOUR DIFFERENT row fragments, i.e.
+  // lane i32 of fragment t owns tile row 4*i32 + t -- a permutation of M inside the wave tile that only the scale
+  // addressing and the epilogue need to know about.
+  const __amdgpu_buffer_rsrc_t rAT = make_rsrc(p.A, p.a_bytes);
+  int nn_voff[2], nn_rd = 0, nn_rdS[MT];
+  if (NN) {
+    cx.perm_rows = true;
+    const int r = cx.lane >> 4, pc = cx.lane & 15;
+#pragma unroll
+    for (int par = 0; par < 2; ++par) {                       // parity of (piece >> 2) = (k >> 4) & 1
+      const int lc = pc ^ (8 * par);
+      nn_voff[par] = (cx.m0 + lc * 16 < p.M) ? r * p.M + cx.m0 + lc * 16 : 0x7f000000;   // columns past M read 0
+    }
+    const int lc = cx.wave_m * 8 + (cx.i32 >> 2);
+    nn_rd = (lc << 4) + ((cx.i32 & 3) << 2);                  // + k*256, chunk ^ 8 for odd k-chunks (applied per read)
 #pragma unroll
     for (int t = 0; t < MT; ++t) {
-      const v4i lo = *(const v4i*)(st + cx.rdA[2 * j] + t * 32 * C::ROWB);
-      const v4i hi = *(const v4i*)(st + cx.rdA[2 * j + 1] + t * 32 * C::ROWB);
-      fa[j][t] = v8i{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      const int row = cx.wave_m * C::WTM + 4 * cx.i32 + t;
+      nn_rdS[t] = C::OFF_S + ((row >> 7) * C::SCT) * (1024 / C::PPW) + (row & 31) * 16 + ((row & 127) >> 5) * 4;
+    }
+  }
+  auto issue_AT = [&](int kt, char* st, const int t0, const int t1) __attribute__((always_inline)) {
+#pragma unroll
+    for (int t = t0; t < t1; ++t) {
+      const int q = cx.wave * 8 + t;                          // piece = k-rows 4q .. 4q+3 of the stage
+      const int k = kt * 128 + 4 * q + (cx.lane >> 4);
+      int v = (k < p.K) ? (((q >> 2) & 1) ? nn_voff[1] : nn_voff[0]) + (kt * 128 + 4 * q) * p.M : 0x7f000000;   // rows past K read 0
+      asm volatile("" : "+v"(v));
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rAT, (lds_ptr_t)(st + q * 1024), 16, v, 0, 0, 0);
+    }
+  };
+  auto read_A_nn = [&](int buf, int j) __attribute__((always_inline)) {
+    const char* st = smem + buf * C::STAGE_BYTES;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int c16 = 4 * j + 2 * u + cx.g;                   // this lane's 16-byte k-chunk (split layout)
+      const char* base = st + c16 * 16 * 256 + (nn_rd ^ ((c16 & 1) << 7));
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {
+        uint32_t o[4];
+        transpose4x4_u8(*(const uint32_t*)(base + (4 * a + 0) * 256), *(const uint32_t*)(base + (4 * a + 1) * 256),
+                        *(const uint32_t*)(base + (4 * a + 2) * 256), *(const uint32_t*)(base + (4 * a + 3) * 256), o);
+#pragma unroll
+        for (int t = 0; t < MT; ++t) fa[j][t][4 * u + a] = (int)o[t];
+      }
+    }
+  };
+
+  // the same in two halves, so that the loads of group gi+1 can be issued before the v_perms of group gi (one group =
+  // 4 dwords = 4 k-rows x the lane's 4 row fragments; gi = 4u + a)
+  uint32_t nn_d[2][4];
+  auto nn_reads = [&](int buf, int j, int gi) __attribute__((always_inline)) {
+    const int u = gi >> 2, a = gi & 3;
+    const int c16 = 4 * j + 2 * u + cx.g;
+    const char* base = smem + buf * C::STAGE_BYTES + c16 * 16 * 256 + (nn_rd ^ ((c16 & 1) << 7)) + 4 * a * 256;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) nn_d[gi & 1][r] = *(const uint32_t*)(base + r * 256);
+  };
+  auto nn_perms = [&](int j, int gi) __attribute__((always_inline)) {
+    uint32_t o[4];
+    transpose4x4_u8(nn_d[gi & 1][0], nn_d[gi & 1][1], nn_d[gi & 1][2], nn_d[gi & 1][3], o);
+#pragma unroll
+    for (int t = 0; t < MT; ++t) fa[j][t][gi] = (int)o[t];
+  };
+  auto read_B = [&](int buf, int j) __attribute__((always_inline)) {
+    const char* st = smem + buf * C::STAGE_BYTES;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const v4i lo = *(const v4i*)(st + cx.rdBd + cx.rdA[2 * j] + t * 32 * C::ROWB);
+      const v4i hi = *(const v4i*)(st + cx.rdBd + cx.rdA[2 * j + 1] + t * 32 * C::ROWB);
+      fb[j][t] = v8i{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    }
+  };
+  auto read_slice = [&](int buf, int j) __attribute__((always_inline)) {
+    const char* st = smem + buf * C::STAGE_BYTES;
+    if (NN) read_A_nn(buf, j);
+    else {
+#pragma unroll
+      for (int t = 0; t < MT; ++t) {
+        const v4i lo = *(const v4i*)(st + cx.rdA[2 * j] + t * 32 * C::ROWB);
+        const v4i hi = *(const v4i*)(st + cx.rdA[2 * j + 1] + t * 32 * C::ROWB);
+        fa[j][t] = v8i{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      }
     }
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
@@ -920,7 +1003,7 @@ __device__ __forceinline__ void gemm_mx_deep8(char* smem, const GemmParams& p) {
     const char* st = smem + buf * C::STAGE_BYTES;
     const int shift = 8 * cx.g;   // split layout: lanes 0-31 carry K-block 2j, lanes 32-63 K-block 2j+1
 #pragma unroll
-    for (int t = 0; t < MT; ++t) sa[set][t] = (int)((unsigned)(*(const int*)(st + cx.rdSA[t])) >> shift);
+    for (int t = 0; t < MT; ++t) sa[set][t] = (int)((unsigned)(*(const int*)(st + (NN ? nn_rdS[t] : cx.rdSA[t]))) >> shift);
 #pragma unroll
     for (int t = 0; t < NT; ++t) sb[set][t] = (int)((unsigned)(*(const int*)(st + cx.rdSB[t])) >> shift);
   };
@@ -933,17 +1016,30 @@ __device__ __forceinline__ void gemm_mx_deep8(char* smem, const GemmParams& p) {
 
   auto stage = [&](int kt, auto bufc) __attribute__((always_inline)) {
     constexpr int BUF = decltype(bufc)::value;
-    read_slice(BUF, 1); fence();
+    if (NN) { read_B(BUF, 1); } else { read_slice(BUF, 1); }
+    fence();
+    {
+      int k = 0;
 #pragma unroll
-    for (int m = 0; m < MT; ++m)
+      for (int m = 0; m < MT; ++m)
 #pragma unroll
-      for (int n = 0; n < NT; ++n) mfma1(0, BUF, m, n);
+        for (int n = 0; n < NT; ++n) {
+          mfma1(0, BUF, m, n);
+          if (NN) {   // A fragments of slice 1, one group per MFMA shadow, loads one group ahead of the permutes
+            if (k < 8) nn_reads(BUF, 1, k);
+            if (k >= 1 && k <= 8) nn_perms(1, k - 1);
+            fence();
+          }
+          ++k;
+        }
+    }
     fence();
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     fence();
     read_scales(BUF ^ 1, BUF ^ 1);   // (after the last stage these read stale LDS; never used)
-    read_slice(BUF ^ 1, 0); fence();
+    if (NN) { read_B(BUF ^ 1, 0); } else { read_slice(BUF ^ 1, 0); }
+    fence();
     char* st = smem + BUF * C::STAGE_BYTES;
     const bool valid = kt + 2 < cx.KT;
     int idx = 0;
@@ -952,11 +1048,18 @@ __device__ __forceinline__ void gemm_mx_deep8(char* smem, const GemmParams& p) {
 #pragma unroll
       for (int n = 0; n < NT; ++n) {
         mfma1(1, BUF, m, n);
+        if (NN) {   // A fragments of slice 0 of the next stage
+          if (idx < 8) nn_reads(BUF ^ 1, 0, idx);
+          if (idx >= 1 && idx <= 8) nn_perms(0, idx - 1);
+        }
         constexpr int PER = (NPIECE + MT * NT - 1) / (MT * NT);
 #pragma unroll
         for (int e = 0; e < PER; ++e) {
           const int t = idx * PER + e;
-          if (t < C::NA) cx.issue_pieces_range(C::NA, cx.rA, st, kt + 2, valid, t, t + 1);
+          if (t < C::NA) {
+            if (NN) issue_AT(kt + 2, st, t, t + 1);
+            else cx.issue_pieces_range(C::NA, cx.rA, st, kt + 2, valid, t, t + 1);
+          }
           else if (t < NPIECE) cx.issue_pieces_range(C::NB, cx.rB, st + C::OFF_B, kt + 2, valid, t - C::NA, t - C::NA + 1);
         }
         if (idx == 0) cx.issue_scales(kt + 2, st, valid);
@@ -965,10 +1068,19 @@ __device__ __forceinline__ void gemm_mx_deep8(char* smem, const GemmParams& p) {
       }
   };
 
-  cx.issue_stage_part(0, 0, 0);
-  cx.issue_stage_part(0, 0, 1);
-  cx.issue_stage_part(1, 1, 0, 1 < cx.KT);
-  cx.issue_stage_part(1, 1, 1, 1 < cx.KT);
+  if (NN) {
+    issue_AT(0, smem, 0, C::NA);
+    cx.issue_scales(0, smem, true);
+    cx.issue_stage_part(0, 0, 1);
+    issue_AT(1, smem + C::STAGE_BYTES, 0, C::NA);
+    cx.issue_scales(1, smem + C::STAGE_BYTES, 1 < cx.KT);
+    cx.issue_stage_part(1, 1, 1, 1 < cx.KT);
+  } else {
+    cx.issue_stage_part(0, 0, 0);
+    cx.issue_stage_part(0, 0, 1);
+    cx.issue_stage_part(1, 1, 0, 1 < cx.KT);
+    cx.issue_stage_part(1, 1, 1, 1 < cx.KT);
+  }
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPIECE + 1) : "memory");
   __builtin_amdgcn_s_barrier();
   fence();
@@ -1151,7 +1263,7 @@ __device__ __forceinline__ void gemm_mx_regstage(char* smem, const GemmParams& p
 }
 
 // One __global__ entry per (config, schedule).
-enum { SCHED_LOCKSTEP = 0, SCHED_PINGPONG = 1, SCHED_QUEUE = 2, SCHED_SIMPLE = 3, SCHED_DEEP = 4, SCHED_REGSTAGE = 5 };
+enum { SCHED_LOCKSTEP = 0, SCHED_PINGPONG = 1, SCHED_QUEUE = 2, SCHED_SIMPLE = 3, SCHED_DEEP = 4, SCHED_REGSTAGE = 5, SCHED_DEEP_NN = 6 };
 template <class C, int SCHED>
 __global__ __launch_bounds__(C::THREADS) void gemm_mx_kernel(const GemmParams p) {
   __shared__ __attribute__((aligned(16))) char smem[C::LDS_BYTES];
@@ -1160,7 +1272,8 @@ __global__ __launch_bounds__(C::THREADS) void gemm_mx_kernel(const GemmParams p)
   const bool clk = (C::ABL & ABL_CLOCK) && p.dbg && blockIdx.x == 0 && threadIdx.x == 0;
   const uint64_t c0 = clk ? __builtin_readcyclecounter() : 0, r0 = clk ? __builtin_amdgcn_s_memrealtime() : 0;
   if constexpr (SCHED == SCHED_REGSTAGE) gemm_mx_regstage<C>(smem, p);
-  else if constexpr (SCHED == SCHED_DEEP && C::EBITS == 8) gemm_mx_deep8<C>(smem, p);
+  else if constexpr (SCHED == SCHED_DEEP_NN) gemm_mx_deep8<C, true>(smem, p);
+  else if constexpr (SCHED == SCHED_DEEP && C::EBITS == 8) gemm_mx_deep8<C, false>(smem, p);
   else if constexpr (SCHED == SCHED_DEEP) gemm_mx_deep<C>(smem, p);
   else if constexpr (SCHED == SCHED_SIMPLE) gemm_mx_simple<C>(smem, p);
   else if constexpr (SCHED == SCHED_QUEUE) gemm_mx_queue<C>(smem, p);

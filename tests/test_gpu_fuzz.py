@@ -101,8 +101,17 @@ def test_fuzz_matmul_nvf4_and_mxf8(q):
         want = oracle.bf16_bits_to_f32(ref).astype(np.float64)
         assert (np.abs(got - want) <= np.abs(want) / 128.0 + 2e-5 * np.abs(want).max()).all(), (it, m, n, k)
         x_km = x.view(torch.uint8).T.contiguous().view(torch.float8_e4m3fn)
-        out_nn = q.matmul_mxf8_bf16_nn(x_km, y, to_blocked(sa.view(e8)), to_blocked(sb.view(e8)), alpha)
-        assert torch.equal(out_nn.view(torch.int16), out.view(torch.int16)), ("nn", it, m, n, k)
+        for path in (0, 61, 62):
+            q._lib.set_option("gemm_variant", path)
+            try:
+                out_nn = q.matmul_mxf8_bf16_nn(x_km, y, to_blocked(sa.view(e8)), to_blocked(sb.view(e8)), alpha)
+            finally:
+                q._lib.set_option("gemm_variant", 0)
+            if path == 61:   # different tile configuration than the auto TN kernel: compare with the oracle tolerance
+                gnn = oracle.bf16_bits_to_f32(_np(out_nn)).astype(np.float64)
+                assert (np.abs(gnn - want) <= np.abs(want) / 128.0 + 2e-5 * np.abs(want).max()).all(), ("nn fused", it, m, n, k)
+            else:
+                assert torch.equal(out_nn.view(torch.int16), out.view(torch.int16)), ("nn", path, it, m, n, k)
 
 
 def test_fuzz_quantizers_and_swizzle(q):

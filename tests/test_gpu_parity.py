@@ -371,6 +371,14 @@ def test_matmul_mxf8_nn_equals_tn_and_oracle(q, golden_dir, m, n, k):
     out_tn = q.matmul_mxf8_bf16_tn(a_t, b_t, sa, sb, alpha)
     assert out_nn.shape == (m, n) and out_nn.dtype == torch.bfloat16
     assert torch.equal(out_nn.view(torch.int16), out_tn.view(torch.int16))
+    # both operand paths explicitly: 61 = fused (A^T tiles transposed on the LDS -> register path), 62 = byte-transpose pre-pass
+    for path in (61, 62):
+        q._lib.set_option("gemm_variant", path)
+        try:
+            o = q.matmul_mxf8_bf16_nn(a_km, b_t, sa, sb, alpha)
+        finally:
+            q._lib.set_option("gemm_variant", 0)
+        assert torch.equal(o.view(torch.int16), out_tn.view(torch.int16)), path
     if m * n * k <= 1 << 28:
         ref = oracle.gemm_blockscaled(oracle.KIND_MXFP8_NN, _np(a_km), bq, oracle.to_blocked(asf), oracle.to_blocked(bsf), 1.0, m, n, k)
         assert _mxfp8_close(_np(out_nn), ref).all()
