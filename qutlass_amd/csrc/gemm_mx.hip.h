@@ -428,7 +428,7 @@ struct GemmCtx {
         if (C::ABL & ABL_NO_STORE) {
           if (v[0] == 0x12345678) p.D[(size_t)grow * p.N + gcol] = 1;
         } else {
-          *(v4i*)(p.D + (size_t)grow * p.N + gcol) = v;
+          if (p.pp_flags & 32) __builtin_nontemporal_store(v, (v4i*)(p.D + (size_t)grow * p.N + gcol)); else *(v4i*)(p.D + (size_t)grow * p.N + gcol) = v;
         }
       }
     }

@@ -486,6 +486,17 @@ int main(int argc, char** argv) {
     check_blocked(128, 4); check_blocked(256, 16); check_blocked(384, 12); check_blocked(4096, 128);
     check_blocked(130, 5); check_blocked(16, 64); check_blocked(504, 128); check_blocked(8192, 512);
   }
+  if (want("ntstore")) {
+    for (int rep = 0; rep < 3; ++rep)
+      for (int fl : {1, 33}) {
+        qutlass_amd_set_option("pp_flags", fl);
+        printf("pp_flags=%d (bit5 = non-temporal output stores)\n", fl);
+        bench_gemm("mxfp4 4096^3", 0, 4096, 4096, 4096, 30, 50);
+        bench_gemm("mxfp4 C3", 0, 4096, 14336, 4096, 30, 10);
+        bench_gemm("mxfp4 8192^3", 0, 8192, 8192, 8192, 30, 5);
+      }
+    qutlass_amd_set_option("pp_flags", 1);
+  }
   if (want("deep8")) {
     check_gemm("gemm_mxfp8 16x64x256 (deep)", 2, 16, 64, 256, 1.0f, 3, 0, 30);
     check_gemm("gemm_mxfp8 ragged + K tail (deep)", 2, 72, 136, 352, 1.0f, 3, 0, 30);
