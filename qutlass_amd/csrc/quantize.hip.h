@@ -140,6 +140,11 @@ __global__ __launch_bounds__(256) void fused_quantize_kernel(const QuantParams p
 
   const int wave_global = blockIdx.x * 4 + wave, nwaves = gridDim.x * 4;
   for (int tile = wave_global; tile < p.ntiles; tile += nwaves) {
+    // R >= 64: keep H^T in LDS instead of letting the compiler hoist its R*R/256 fragments into registers across the
+    // tile loop (R = 128: 128 VGPRs, 204 in total -> 2 waves per SIMD and no latency hiding; re-reading 32 KiB of LDS
+    // per 8-KiB tile is nowhere near a limit).  The opaque offset makes the address loop-variant for the optimiser.
+    int hoist_guard = 0;
+    if (RP >= 64) asm volatile("" : "+v"(hoist_guard));
     const int64_t r_abs = (int64_t)tile * 32 + row;
     // X^T operand: lane (row, half), chunk kc -> x[r_abs][16 kc + 8 half .. +8)  (16 bytes)
     v8bf xf[KC];
@@ -156,7 +161,7 @@ __global__ __launch_bounds__(256) void fused_quantize_kernel(const QuantParams p
       for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 #pragma unroll
       for (int kc = 0; kc < KC; ++kc) {
-        const v8bf hf = *(const v8bf*)(hT + (jt * 32 + row) * HROW + (kc * 16 + half * 8) * 2);
+        const v8bf hf = *(const v8bf*)(hT + hoist_guard + (jt * 32 + row) * HROW + (kc * 16 + half * 8) * 2);
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(hf, xf[kc], acc, 0, 0, 0);
       }
       // acc[4q+e] = y[r_abs][32 jt + 8q + 4 half + e]
