@@ -138,7 +138,7 @@ int gemm_mx(const char* name, const void* A, const void* B, const void* A_sf, co
     return fail(QAMD_ERR_INVALID, "%s: operand larger than 2 GiB is not supported", name);
   GemmParams p;
   p.A = (const uint8_t*)A; p.B = (const uint8_t*)B; p.SFA = (const uint8_t*)A_sf; p.SFB = (const uint8_t*)B_sf;
-  p.alpha = alpha; p.D = (uint16_t*)D; p.M = (int)M; p.N = (int)N; p.K = (int)K;
+  p.alpha = alpha; p.D = (uint16_t*)D; p.M = (int)M; p.N = (int)N; p.K = (int)K; p.ldd = (int)N;
   p.a_bytes = (uint32_t)a_bytes; p.b_bytes = (uint32_t)b_bytes;
   p.sfa_bytes = (uint32_t)sfa_bytes; p.sfb_bytes = (uint32_t)sfb_bytes;
   p.pp_shift = g_pp_shift.load();
@@ -163,7 +163,30 @@ int gemm_mx(const char* name, const void* A, const void* B, const void* A_sf, co
     const int64_t want = 192;   // 3/4 of the 256 CUs
     if (M <= 64) variant = (tiles(64, 128) >= want) ? 28 : 29;          // no point in tiles taller than the problem
     else if (N <= 64) variant = (tiles(128, 64) >= want) ? 27 : 29;
-    else if (tiles(256, 256) >= want) variant = 30;
+    else if (tiles(256, 256) >= want) {
+      variant = 30;
+      // wave quantisation: T tiles on 256 CUs run ceil(T/256) rounds; when the last round is less than ~60 % full
+      // (C3 4096x14336x4096: 896 tiles = 3.5 rounds) the trailing tile columns go to a second launch with smaller
+      // tiles that fills the chip once more for a fraction of a round.  Both launches write column ranges of the same
+      // D (ldd = N); operands of the column range are plain pointer offsets (N-range starts on a 256 boundary).
+      const int64_t tm = cdiv(M, 256), tn = cdiv(N, 256), T = tm * tn, full = (T / 256) * 256;
+      const int64_t main_cols = (tm > 0) ? full / tm : 0;          // whole tile columns that fit the full rounds
+      if (!(g_pp_flags.load() & 64) && full >= 256 && main_cols >= 1 && main_cols < tn && (T - main_cols * tm) * 10 <= 256 * 6) {
+        const int64_t n1 = main_cols * 256;
+        GemmParams pm = p;
+        pm.N = (int)n1; pm.b_bytes = (uint32_t)(n1 * rowbytes); pm.sfb_bytes = (uint32_t)(cdiv(n1, 128) * CB * 512);
+        if (int rc = dispatch_variant<EBITS, EBITS == 8>(30, pm, s, name)) return rc;
+        GemmParams pt = p;
+        pt.N = (int)(N - n1);
+        pt.B = p.B + n1 * rowbytes; pt.b_bytes = (uint32_t)((N - n1) * rowbytes);
+        pt.SFB = p.SFB + (n1 / 128) * CB * 512; pt.sfb_bytes = (uint32_t)(cdiv(N - n1, 128) * CB * 512);
+        pt.D = p.D + n1;
+        const int64_t Nt = N - n1;
+        auto tt = [&](int bm, int bn) { return cdiv(M, bm) * cdiv(Nt, bn); };
+        const int vt = (tt(256, 128) >= want) ? 25 : (tt(128, 128) >= want) ? 24 : (tt(128, 64) >= want) ? 27 : 29;
+        return dispatch_variant<EBITS, EBITS == 8>(vt, pt, s, name);
+      }
+    }
     else if (tiles(128, 128) >= want) variant = 24;
     else if (tiles(128, 64) >= want || tiles(64, 128) >= want) variant = (N >= M) ? 27 : 28;
     else variant = 29;
@@ -258,7 +281,7 @@ int qutlass_amd_matmul_mxf8_bf16_nn(const void* A, const void* B, const void* A_
     if (N * K >= (1ll << 31)) return fail(QAMD_ERR_INVALID, "%s: operand larger than 2 GiB is not supported", name);
     GemmParams p;
     p.A = (const uint8_t*)A; p.B = (const uint8_t*)B; p.SFA = (const uint8_t*)A_sf; p.SFB = (const uint8_t*)B_sf;
-    p.alpha = alpha; p.D = (uint16_t*)D; p.M = (int)M; p.N = (int)N; p.K = (int)K;
+    p.alpha = alpha; p.D = (uint16_t*)D; p.M = (int)M; p.N = (int)N; p.K = (int)K; p.ldd = (int)N;
     p.a_bytes = (uint32_t)(M * K); p.b_bytes = (uint32_t)(N * K);
     p.sfa_bytes = (uint32_t)(cdiv(M, 128) * CB * 512); p.sfb_bytes = (uint32_t)(cdiv(N, 128) * CB * 512);
     p.pp_shift = g_pp_shift.load(); p.pp_flags = g_pp_flags.load(); p.dbg = g_dbg.load();

@@ -42,6 +42,7 @@ struct GemmParams {
   const float* alpha;
   uint16_t* D;
   int M, N, K;           // K in elements
+  int ldd;               // row stride of D in elements (= N unless the launch covers a column range of a wider D)
   int tiles_m, tiles_n;  // grid = tiles_m * tiles_n
   uint32_t a_bytes, b_bytes, sfa_bytes, sfb_bytes;
   int pp_shift;          // ping-pong: wave group = (wave >> pp_shift) & 1
@@ -374,9 +375,9 @@ struct GemmCtx {
           if (grow < p.M && gcol < p.N) {
             const v4i v = {(int)rx[0], (int)ry[0], (int)rx[1], (int)ry[1]};
             if (C::ABL & ABL_NO_STORE) {
-              if (v[0] == 0x12345678) p.D[(size_t)grow * p.N + gcol] = 1;
+              if (v[0] == 0x12345678) p.D[(size_t)grow * p.ldd + gcol] = 1;
             } else {
-              *(v4i*)(p.D + (size_t)grow * p.N + gcol) = v;
+              *(v4i*)(p.D + (size_t)grow * p.ldd + gcol) = v;
             }
           }
         }
@@ -426,9 +427,9 @@ struct GemmCtx {
         v4i v = *(const v4i*)(smem + row * C::SROW + ((((2 * chunk) ^ (row & 15)) & ~1) << 3));
         if (row & 1) v = v4i{v[2], v[3], v[0], v[1]};   // odd rows hold the granule pair swapped
         if (C::ABL & ABL_NO_STORE) {
-          if (v[0] == 0x12345678) p.D[(size_t)grow * p.N + gcol] = 1;
+          if (v[0] == 0x12345678) p.D[(size_t)grow * p.ldd + gcol] = 1;
         } else {
-          if (p.pp_flags & 32) __builtin_nontemporal_store(v, (v4i*)(p.D + (size_t)grow * p.N + gcol)); else *(v4i*)(p.D + (size_t)grow * p.N + gcol) = v;
+          if (p.pp_flags & 32) __builtin_nontemporal_store(v, (v4i*)(p.D + (size_t)grow * p.ldd + gcol)); else *(v4i*)(p.D + (size_t)grow * p.ldd + gcol) = v;
         }
       }
     }

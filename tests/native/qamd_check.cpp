@@ -486,6 +486,20 @@ int main(int argc, char** argv) {
     check_blocked(128, 4); check_blocked(256, 16); check_blocked(384, 12); check_blocked(4096, 128);
     check_blocked(130, 5); check_blocked(16, 64); check_blocked(504, 128); check_blocked(8192, 512);
   }
+  if (want("tail")) {
+    check_gemm("gemm_mxfp4 C3 4096x14336x4096 auto (tail split), 48 sampled rows", 0, 4096, 14336, 4096, 1.0f, 3, 48, 0);
+    check_gemm("gemm_mxfp4 2304x3592x1152 auto (ragged, tail split)", 0, 2304, 3592, 1152, 0.5f, 3, 24, 0);
+    check_gemm("gemm_mxfp8 4096x14336x1024 auto (tail split)", 2, 4096, 14336, 1024, 1.0f, 3, 24, 0);
+    for (int rep = 0; rep < 3; ++rep)
+      for (int fl : {1, 65}) {
+        qutlass_amd_set_option("pp_flags", fl);
+        printf("pp_flags=%d (bit6 = tail split OFF)\n", fl);
+        bench_gemm("mxfp4 C3 auto", 0, 4096, 14336, 4096, 0, 10);
+        bench_gemm("mxfp4 4096x11008x4096 auto", 0, 4096, 11008, 4096, 0, 10);
+        bench_gemm("mxfp8 C3-shape auto", 2, 4096, 14336, 4096, 0, 10);
+      }
+    qutlass_amd_set_option("pp_flags", 1);
+  }
   if (want("ntstore")) {
     for (int rep = 0; rep < 3; ++rep)
       for (int fl : {1, 33}) {

@@ -553,3 +553,31 @@ def test_ops_are_hip_graph_capturable(q):
     g.replay()
     torch.cuda.synchronize()
     assert torch.equal(got, -want)      # value equality: an exact 0 keeps its sign bit under negation of the input
+
+
+def test_tail_split_launch_matches_single_launch(q):
+    """320 tiles of 256x256 on 256 CUs = 1.25 rounds: auto runs the first 16 tile columns with the deep kernel and the
+    last 4 with smaller tiles in a second launch (column range of the same D); forcing a variant runs ONE launch."""
+    from qutlass_amd.utils import to_blocked
+
+    torch.manual_seed(41)
+    m, n, k = 4096, 5120, 512
+    h = _hadamard(32)
+    a = torch.randn(m, k, dtype=torch.bfloat16, device=DEV) * 25.0
+    b = torch.randn(n, k, dtype=torch.bfloat16, device=DEV) * 25.0
+    a_q, a_s = q.fusedQuantizeMx(a, h, method="abs_max")
+    b_q, b_s = q.fusedQuantizeMx(b, h, method="quest")
+    asf, bsf = to_blocked(a_s), to_blocked(b_s)
+    alpha = torch.tensor([0.5], device=DEV)
+    out_split = q.matmul_mxf4_bf16_tn(a_q, b_q, asf, bsf, alpha)
+    q._lib.set_option("gemm_variant", 30)
+    try:
+        out_one = q.matmul_mxf4_bf16_tn(a_q, b_q, asf, bsf, alpha)
+    finally:
+        q._lib.set_option("gemm_variant", 0)
+    assert torch.equal(out_split.view(torch.int16), out_one.view(torch.int16))
+    rows = [0, 255, 256, 2047, 4095]
+    sub = torch.tensor(rows, device=DEV)
+    ref = oracle.gemm_blockscaled(oracle.KIND_MXFP4, _np(a_q[sub]), _np(b_q), oracle.to_blocked(_np(a_s).reshape(-1)[: m * k // 32].reshape(m, k // 32)[rows]),
+                                  oracle.to_blocked(_np(b_s).reshape(-1)[: n * k // 32].reshape(n, k // 32)), 0.5, len(rows), n, k)
+    assert np.array_equal(_np(out_split[sub]), ref)
