@@ -488,10 +488,111 @@ __global__ __launch_bounds__(C::THREADS) void gemm_nvf4_lds_kernel(const NvGemmP
   }
 }
 
-// variant: 0 = auto = 1 (per-wave dequant; measured equal or slightly faster than v2 on every shape,
+// ================================================================================================
+// Small batch (M <= 32 per tile): split-K kernel without LDS staging, the NVFP4 twin of gemm_mx_skinny.hip.h.
+// One workgroup = 32 rows of B x 32 rows of A; the 8 waves split K in 128-byte row segments (256 elements); a wave
+// loads its packed operands and e4m3 scale dwords straight from global memory with all loads of its K range in
+// flight, dequantises to f16 exactly as the tiled kernel does (cvt + one pk_mul per pair) and feeds
+// v_mfma_f32_32x32x16_f16; partial 32x32 tiles are summed through LDS.  Weight-bandwidth bound.
+// ================================================================================================
+template <int NWAVES>
+__global__ __launch_bounds__(NWAVES * 64) void gemm_nvf4_skinny_kernel(const NvGemmParams p) {
+  __shared__ __attribute__((aligned(16))) float part[NWAVES][32][33];
+  const int tid = threadIdx.x, lane = tid & 63, wave = uniform(tid >> 6);
+  const int i32 = lane & 31, g = lane >> 5;
+  const int n0 = blockIdx.x * 32, m0 = blockIdx.y * 32;
+  const int rowbytes = p.K >> 1;
+  const int nseg = (rowbytes + 127) >> 7;
+  const int CB = (p.K / 16 + 3) >> 2;              // scale column tiles (4 groups of 16) per row
+
+  const uint32_t a_off = (uint32_t)m0 * rowbytes, b_off = (uint32_t)n0 * rowbytes;
+  const __amdgpu_buffer_rsrc_t rA = make_rsrc(p.A + a_off, p.a_bytes - a_off);
+  const __amdgpu_buffer_rsrc_t rB = make_rsrc(p.B + b_off, p.b_bytes - b_off);
+  const __amdgpu_buffer_rsrc_t rSA = make_rsrc(p.SFA, p.sfa_bytes), rSB = make_rsrc(p.SFB, p.sfb_bytes);
+  const int voff = i32 * rowbytes + g * 64;
+  const int ra = m0 + i32, rb = n0 + i32;
+  // scale dword of (row, column tile ct): to_blocked layout; lane half g uses tiles 4s + 2g and 4s + 2g + 1
+  const int soffA = (ra >> 7) * CB * 512 + (ra & 31) * 16 + ((ra & 127) >> 5) * 4;
+  const int soffB = (rb >> 7) * CB * 512 + (rb & 31) * 16 + ((rb & 127) >> 5) * 4;
+  constexpr int OOB = 0x7f000000;
+
+  v16f acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+
+  for (int s = wave; s < nseg; s += NWAVES) {
+    v4i ca[4], cb[4];
+    uint32_t da[2], db[2];
+    const int base = s * 128;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int v = (base + g * 64 + j * 16 < rowbytes) ? voff + j * 16 : OOB;   // K tail: chunks past the row read 0
+      ca[j] = __builtin_amdgcn_raw_buffer_load_b128(rA, v, base, 0);
+      cb[j] = __builtin_amdgcn_raw_buffer_load_b128(rB, v, base, 0);
+    }
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj) {
+      const int ct = 4 * s + 2 * g + jj;
+      const int so = (ct < CB) ? ct * 512 : OOB;   // scale tiles past K are layout padding: read 0 (0 x 0, never NaN)
+      da[jj] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rSA, soffA + so, 0, 0);
+      db[jj] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rSB, soffB + so, 0, 0);
+    }
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj) {
+      // groups past K inside the last tile (K % 64 == 32): mask their scale bytes
+      const int valid = p.K / 16 - 4 * (4 * s + 2 * g + jj);
+      const uint32_t smask = valid >= 4 ? 0xffffffffu : (valid <= 0 ? 0u : ((1u << (8 * valid)) - 1u));
+      h2_t sa[2], sb[2];
+      e4m3x4_to_f16(da[jj] & smask, sa[0], sa[1]);
+      e4m3x4_to_f16(db[jj] & smask, sb[0], sb[1]);
+#pragma unroll
+      for (int jl = 0; jl < 2; ++jl) {
+        const int j = 2 * jj + jl;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const _Float16 xa = sa[jl][u >> 1], xb = sb[jl][u >> 1];
+          const h8_t fa = dq8((uint32_t)ca[j][u], h2_t{xa, xa});
+          const h8_t fb = dq8((uint32_t)cb[j][u], h2_t{xb, xb});
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb, fa, acc, 0, 0, 0);
+        }
+      }
+    }
+  }
+
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) part[wave][i32][8 * q + 4 * g + e] = acc[4 * q + e];
+  __syncthreads();
+  const float alpha = *p.alpha;
+  for (int idx = tid; idx < 32 * 8; idx += NWAVES * 64) {
+    const int m = idx >> 3, nq = (idx & 7) * 4;
+    float sum[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int w = 0; w < NWAVES; ++w)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) sum[e] += part[w][m][nq + e];
+    if (m0 + m < p.M && n0 + nq < p.N) {
+      v2i o;
+      o[0] = (int)pack_bf16x2(sum[0] * alpha, sum[1] * alpha);
+      o[1] = (int)pack_bf16x2(sum[2] * alpha, sum[3] * alpha);
+      *(v2i*)(p.D + (size_t)(m0 + m) * p.N + n0 + nq) = o;
+    }
+  }
+}
+
+// variant: 3 = small-batch split-K kernel (auto for M <= 32); otherwise 0 = auto = 1 (per-wave dequant; measured equal or slightly faster than v2 on every shape,
 // profiles/native_r1_nvfp4_ablation.log -- both are power-bound at the same wall time), 2 = v2 (LDS dequant)
 inline hipError_t launch_nvf4_gemm(NvGemmParams p, hipStream_t s, int variant = 0) {
-  const bool small = p.M <= 128 || p.N <= 128;
+  // 128x128 tiles when a dimension is small OR when 256x256 tiles would leave most CUs without work
+  const bool small = p.M <= 128 || p.N <= 128 || (int64_t)((p.M + 255) / 256) * ((p.N + 255) / 256) < 192;
+  // small batch: split-K kernel for M <= 64, and up to M = 128 while 128x128 tiles would leave CUs idle (measured:
+  // M = 128, N = 4096: 184 vs 93 TFLOP/s; N = 28672: 380 vs 594, so large N stays tiled)
+  const int64_t tiles128 = (int64_t)((p.M + 127) / 128) * ((p.N + 127) / 128);
+  if (variant == 3 || (variant == 0 && (p.M <= 64 || (p.M <= 128 && tiles128 < 192)))) {
+    hipLaunchKernelGGL((gemm_nvf4_skinny_kernel<8>), dim3((p.N + 31) / 32, (p.M + 31) / 32), dim3(512), 0, s, p);
+    return hipSuccess;
+  }
   if (variant <= 1) {
     if (small) {
       using C = NvCfg<128, 128, 2, 2>;
