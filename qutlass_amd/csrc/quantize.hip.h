@@ -139,6 +139,13 @@ __global__ __launch_bounds__(256) void fused_quantize_kernel(const QuantParams p
   const float gscale = NV ? *p.global_scale : 1.0f;
 
   const int wave_global = blockIdx.x * 4 + wave, nwaves = gridDim.x * 4;
+  v4i xnext[RP / 16];
+  {
+    const int64_t r0 = (int64_t)wave_global * 32 + row;
+    const int xoff0 = (wave_global < p.ntiles) ? (int)(r0 * RP * 2) + half * 16 : 0x7f000000;
+#pragma unroll
+    for (int kc = 0; kc < RP / 16; ++kc) xnext[kc] = __builtin_amdgcn_raw_buffer_load_b128(rx, xoff0 + kc * 32, 0, 0);
+  }
   for (int tile = wave_global; tile < p.ntiles; tile += nwaves) {
     // R >= 64: keep H^T in LDS instead of letting the compiler hoist its R*R/256 fragments into registers across the
     // tile loop (R = 128: 128 VGPRs, 204 in total -> 2 waves per SIMD and no latency hiding; re-reading 32 KiB of LDS
@@ -146,13 +153,18 @@ __global__ __launch_bounds__(256) void fused_quantize_kernel(const QuantParams p
     int hoist_guard = 0;
     if (RP >= 64) asm volatile("" : "+v"(hoist_guard));
     const int64_t r_abs = (int64_t)tile * 32 + row;
-    // X^T operand: lane (row, half), chunk kc -> x[r_abs][16 kc + 8 half .. +8)  (16 bytes)
+    // X^T operand: lane (row, half), chunk kc -> x[r_abs][16 kc + 8 half .. +8)  (16 bytes).  Software pipeline: the
+    // loads of the wave's NEXT tile are issued before this tile is computed (tiles past the end fall off the buffer
+    // descriptor and read 0), so the HBM latency of tile i+1 hides behind the MFMAs / epilogue of tile i.
     v8bf xf[KC];
-    const int xoff = (int)(r_abs * RP * 2) + half * 16;   // numel*2 < 2^31 checked on the host
 #pragma unroll
-    for (int kc = 0; kc < KC; ++kc) {
-      const v4i raw = __builtin_amdgcn_raw_buffer_load_b128(rx, xoff + kc * 32, 0, 0);
-      xf[kc] = __builtin_bit_cast(v8bf, raw);
+    for (int kc = 0; kc < KC; ++kc) xf[kc] = __builtin_bit_cast(v8bf, xnext[kc]);
+    {
+      const int64_t rn = (int64_t)(tile + nwaves) * 32 + row;
+      const int64_t on = rn * RP * 2 + half * 16;
+      const int xoffn = (tile + nwaves < p.ntiles) ? (int)on : 0x7f000000;
+#pragma unroll
+      for (int kc = 0; kc < KC; ++kc) xnext[kc] = __builtin_amdgcn_raw_buffer_load_b128(rx, xoffn + kc * 32, 0, 0);
     }
 #pragma unroll
     for (int jt = 0; jt < JT; ++jt) {

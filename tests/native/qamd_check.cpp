@@ -486,6 +486,17 @@ int main(int argc, char** argv) {
     check_blocked(128, 4); check_blocked(256, 16); check_blocked(384, 12); check_blocked(4096, 128);
     check_blocked(130, 5); check_blocked(16, 64); check_blocked(504, 128); check_blocked(8192, 512);
   }
+  if (want("qgrid")) {   // quantizer: workgroups per CU (tiles per wave for the software pipeline)
+    for (int wg : {0, 8, 4, 2, 1}) {
+      qutlass_amd_set_option("quant_wg_per_cu", wg);
+      printf("quant_wg_per_cu=%d\n", wg);
+      bench_quant(32, 1, false, 1, 4096, 4096, false);
+      bench_quant(32, 0, true, 1, 4096, 4096, false);
+      bench_quant(128, 1, false, 1, 4096, 4096, false);
+      bench_quant(16, 1, false, 1, 8192, 8192, true);
+    }
+    qutlass_amd_set_option("quant_wg_per_cu", 0);
+  }
   if (want("tail")) {
     check_gemm("gemm_mxfp4 C3 4096x14336x4096 auto (tail split), 48 sampled rows", 0, 4096, 14336, 4096, 1.0f, 3, 48, 0);
     check_gemm("gemm_mxfp4 2304x3592x1152 auto (ragged, tail split)", 0, 2304, 3592, 1152, 0.5f, 3, 24, 0);
