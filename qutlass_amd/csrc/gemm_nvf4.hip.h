@@ -47,7 +47,7 @@ struct NvCfg {
   static constexpr int NA = BM / 8 / NWAVES, NB = BN / 8 / NWAVES;
   static constexpr int SROW = BN * 2;
   static constexpr int LDS_BYTES = (2 * STAGE_BYTES > BM * SROW) ? 2 * STAGE_BYTES : BM * SROW;
-  static_assert(NSIA + NSIB <= NWAVES, "scale DMA split");
+  static constexpr int SPW = (NSIA + NSIB + NWAVES - 1) / NWAVES;   // 1-KiB scale pieces per wave (2 for the 4-wave config)
 };
 
 // 4 e4m3 scale bytes (one dword of the blocked layout) -> two packed-f16 pairs, exact:
@@ -119,13 +119,19 @@ __global__ __launch_bounds__(C::THREADS) void gemm_nvf4_kernel(const NvGemmParam
     chB[t] = (lane & 7) ^ ((row >> 1) & 7);
     voffB[t] = row * rowbytes + chB[t] * 16;
   }
-  int voffS = 0x7fffffff, colS = 0;
-  if (wave < C::NSIA + C::NSIB) {
-    const bool isB = wave >= C::NSIA;
-    const int s = isB ? wave - C::NSIA : wave;
-    const int pp = 2 * s + g;
-    colS = pp % C::SCT;
-    voffS = ((pp / C::SCT) * CB + colS) * 512 + i32 * 16;
+  int voffS[C::SPW], colS[C::SPW];
+#pragma unroll
+  for (int e = 0; e < C::SPW; ++e) {
+    const int sp = wave + e * C::NWAVES;             // scale piece (1 KiB = two 512-byte tiles, one per lane half)
+    voffS[e] = 0x7fffffff;
+    colS[e] = 0;
+    if (sp < C::NSIA + C::NSIB) {
+      const bool isB = sp >= C::NSIA;
+      const int s = isB ? sp - C::NSIA : sp;
+      const int pp = 2 * s + g;
+      colS[e] = pp % C::SCT;
+      voffS[e] = ((pp / C::SCT) * CB + colS[e]) * 512 + i32 * 16;
+    }
   }
 
   auto issue_stage = [&](int kt, int buf) {
@@ -144,14 +150,18 @@ __global__ __launch_bounds__(C::THREADS) void gemm_nvf4_kernel(const NvGemmParam
       if (tail && (soff + chB[t] * 16 >= rowbytes)) v = 0x7fffffff;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, (lds_ptr_t)(st + C::OFF_B + (wave * C::NB + t) * 1024), 16, v, soff, 0, 0);
     }
-    if (wave < C::NSIA + C::NSIB) {
-      int v = voffS;
-      if (kt * C::SCT + colS >= CB) v = 0x7fffffff;
-      const int ssoff = kt * C::SCT * 512;
-      if (wave < C::NSIA)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rSA, (lds_ptr_t)(st + C::OFF_SA + wave * 1024), 16, v, ssoff, 0, 0);
-      else
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rSB, (lds_ptr_t)(st + C::OFF_SB + (wave - C::NSIA) * 1024), 16, v, ssoff, 0, 0);
+#pragma unroll
+    for (int e = 0; e < C::SPW; ++e) {
+      const int sp = wave + e * C::NWAVES;
+      if (sp < C::NSIA + C::NSIB) {
+        int v = voffS[e];
+        if (kt * C::SCT + colS[e] >= CB) v = 0x7fffffff;
+        const int ssoff = kt * C::SCT * 512;
+        if (sp < C::NSIA)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rSA, (lds_ptr_t)(st + C::OFF_SA + sp * 1024), 16, v, ssoff, 0, 0);
+        else
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rSB, (lds_ptr_t)(st + C::OFF_SB + (sp - C::NSIA) * 1024), 16, v, ssoff, 0, 0);
+      }
     }
   };
 
@@ -593,7 +603,14 @@ inline hipError_t launch_nvf4_gemm(NvGemmParams p, hipStream_t s, int variant = 
     hipLaunchKernelGGL((gemm_nvf4_skinny_kernel<8>), dim3((p.N + 31) / 32, (p.M + 31) / 32), dim3(512), 0, s, p);
     return hipSuccess;
   }
-  if (variant <= 1) {
+  if (variant == 4 && !small) {   // 4 waves of 128x128: each operand chunk is dequantised by 2 waves instead of 4 / 2
+    using C = NvCfg<256, 256, 2, 2>;
+    p.tiles_m = (p.M + C::BM - 1) / C::BM;
+    p.tiles_n = (p.N + C::BN - 1) / C::BN;
+    hipLaunchKernelGGL((gemm_nvf4_kernel<C>), dim3(p.tiles_m * p.tiles_n), dim3(C::THREADS), 0, s, p);
+    return hipSuccess;
+  }
+  if (variant <= 1 || variant == 4) {
     if (small) {
       using C = NvCfg<128, 128, 2, 2>;
       p.tiles_m = (p.M + C::BM - 1) / C::BM;
