@@ -262,6 +262,7 @@ static void check_bench_nn(int64_t M, int64_t N, int64_t K, int iters) {
 }
 
 static int g_zero_fill = 0;
+static int g_warm_override = 0, g_iters_override = 0;
 static void bench_gemm(const char* tag, int kind, int64_t M, int64_t N, int64_t K, int variant, int iters) {
   GemmData g = make_gemm(kind, M, N, K, 1.0f, 77, 3);
   if (g_zero_fill) { std::fill(g.A.begin(), g.A.end(), 0); std::fill(g.B.begin(), g.B.end(), 0); }
@@ -272,7 +273,8 @@ static void bench_gemm(const char* tag, int kind, int64_t M, int64_t N, int64_t 
   dAl.up({1.0f});
   qutlass_amd_set_option("gemm_variant", variant);
   gemm_fn fn = gemm_entry(kind);
-  const double us = time_us([&] { Q_OK(fn(dA.p, dB.p, dSA.p, dSB.p, dAl.p, dD.p, M, N, K, nullptr)); }, 10, iters);
+  const double us = time_us([&] { Q_OK(fn(dA.p, dB.p, dSA.p, dSB.p, dAl.p, dD.p, M, N, K, nullptr)); }, g_warm_override ? g_warm_override : 10,
+                            g_iters_override ? g_iters_override : iters);
   qutlass_amd_set_option("gemm_variant", 0);
   const double tf = 2.0 * M * N * K / us * 1e-6;
   printf("BENCH %-40s M=%lld N=%lld K=%lld var=%d  %9.2f us  %9.1f TFLOP/s\n", tag, (long long)M, (long long)N, (long long)K,
@@ -424,6 +426,7 @@ static void bench_blocked(int64_t rows, int64_t cols) {
 extern void run_probe();   // probe.hip
 extern void run_ubench();  // ubench.hip
 extern void run_valu_rates();  // ubench.hip
+extern void run_ubench_steady();  // ubench.hip
 extern "C" void qutlass_amd_debug_set_trace_buffer(void*);
 
 // Per-wave block timeline of workgroup 0 of the ping-pong kernel (ABL_TRACE builds, variants 116..118).
@@ -480,11 +483,26 @@ int main(int argc, char** argv) {
 
   if (argc > 1 && want("ubench")) run_ubench();
   if (argc > 1 && want("valu")) run_valu_rates();
+  if (argc > 1 && want("usteady")) run_ubench_steady();
   if (want("probe")) run_probe();
 
   if (want("blocked")) {
     check_blocked(128, 4); check_blocked(256, 16); check_blocked(384, 12); check_blocked(4096, 128);
     check_blocked(130, 5); check_blocked(16, 64); check_blocked(504, 128); check_blocked(8192, 512);
+  }
+  if (want("steady")) {   // steady-state clocks: the part needs ~50 ms of load to leave its ramp (tools/clock_ramp.py)
+    g_warm_override = 2500; g_iters_override = 2500;
+    for (int rep = 0; rep < 2; ++rep)
+      for (int var : {20, 30, 40, 6, 1, 5}) bench_gemm("mxfp4 4096^3 steady", 0, 4096, 4096, 4096, var, 0);
+    g_warm_override = 600; g_iters_override = 600;
+    for (int var : {20, 30, 0}) bench_gemm("mxfp4 C3 steady", 0, 4096, 14336, 4096, var, 0);
+    g_warm_override = 300; g_iters_override = 300;
+    for (int var : {20, 30}) bench_gemm("mxfp4 8192^3 steady", 0, 8192, 8192, 8192, var, 0);
+    g_warm_override = 1200; g_iters_override = 1200;
+    for (int var : {20, 30}) bench_gemm("mxfp8 4096^3 steady", 2, 4096, 4096, 4096, var, 0);
+    g_warm_override = 100; g_iters_override = 100;
+    bench_gemm("nvfp4 8192^3 steady", 1, 8192, 8192, 8192, 0, 0);
+    g_warm_override = 0; g_iters_override = 0;
   }
   if (want("qgrid")) {   // quantizer: workgroups per CU (tiles per wave for the software pipeline)
     for (int wg : {0, 8, 4, 2, 1}) {

@@ -130,10 +130,12 @@ __global__ __launch_bounds__(THREADS) void ub_kernel(const char* g, uint32_t gby
 }
 
 static int g_random_fill = 0;
+static int g_steady_warm = 0;
 template <int MODE, int THREADS>
 static void run_one(const char* name, const char* g, uint32_t gbytes, float* out, uint32_t* cyc, int blocks) {
   const int iters = 20000;
-  ub_kernel<MODE, THREADS><<<blocks, THREADS>>>(g, gbytes, out, cyc, iters, g_random_fill);
+  // g_steady_warm launches first: the part needs ~50 ms under load to leave its clock ramp (tools/clock_ramp.py)
+  for (int w = 0; w < (g_steady_warm ? g_steady_warm : 1); ++w) ub_kernel<MODE, THREADS><<<blocks, THREADS>>>(g, gbytes, out, cyc, iters, g_random_fill);
   HIP_OK(hipDeviceSynchronize());
   hipEvent_t e0, e1;
   HIP_OK(hipEventCreate(&e0)); HIP_OK(hipEventCreate(&e1));
@@ -342,6 +344,23 @@ static void run_valu(const char* name, int per_iter, int waves_per_simd) {
   printf("UBENCH valu %-44s waves/SIMD=%d : %8.1f ns per iteration-group of %d, s_memtime ticks/group %.1f\n", name, waves_per_simd,
          ms * 1e6 / iters, per_iter, (double)cy / iters);
   hipFree(o); hipFree(c); hipEventDestroy(e0); hipEventDestroy(e1);
+}
+
+void run_ubench_steady() {   // MFMA-only ceilings in the steady state (after ~100 ms under load)
+  const uint32_t gbytes = 64u << 20;
+  char* g; float* out; uint32_t* cyc;
+  HIP_OK(hipMalloc(&g, gbytes)); HIP_OK(hipMemset(g, 0x22, gbytes));
+  HIP_OK(hipMalloc(&out, 256 * 512 * 4)); HIP_OK(hipMalloc(&cyc, 64));
+  g_steady_warm = 40;
+  for (int rf : {0, 1, 0, 1}) {
+    g_random_fill = rf;
+    run_one<0, 256>("MFMA x8 only (steady)", g, gbytes, out, cyc, 256);
+    run_one<0, 512>("MFMA x8 only (steady)", g, gbytes, out, cyc, 256);
+    run_one<2, 512>("MFMA(cur) ; reads->other set (steady)", g, gbytes, out, cyc, 256);
+    run_one<4, 512>("MFMA ; reads->other ; LDS-DMA x2 (steady)", g, gbytes, out, cyc, 256);
+  }
+  g_steady_warm = 0;
+  hipFree(g); hipFree(out); hipFree(cyc);
 }
 
 void run_valu_rates() {

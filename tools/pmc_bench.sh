@@ -6,7 +6,7 @@
 # traffic.json is what bench.py reports as roofline.traffic (copy it to profiles/pmc_bench_<round>.json).
 OUT=${1:-gpurun_out/pmc_bench}; R=${GRAFT_REPO_ROOT:-$(pwd)}
 mkdir -p $R/$OUT; cd /tmp; export TMPDIR=/tmp
-CMD="python $R/bench.py --no-cpu-baseline"   # the default command (200 timed steps): durations must agree with the bench line
+CMD="python $R/bench.py --no-cpu-baseline"   # the default command: durations must agree with the bench line
 rocprofv3 --kernel-trace --stats -d $R/$OUT/trace -o p -- $CMD > $R/$OUT/trace.log 2>&1
 rocprofv3 --pmc FETCH_SIZE -d $R/$OUT/fetch -o p -- $CMD > $R/$OUT/fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE -d $R/$OUT/write -o p -- $CMD > $R/$OUT/write.log 2>&1
