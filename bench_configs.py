@@ -30,12 +30,22 @@ def hadamard(n, device):
     return (h * n ** -0.5).to(torch.bfloat16).to(device)
 
 
-def time_us(fn, iters, warmup=5):
+def time_us(fn, iters, warmup=5, ramp_ms=40.0):
+    """Average microseconds per call over `iters` back-to-back calls, after at least `ramp_ms` of the same load: an idle
+    MI355X needs ~40 ms to reach its steady clock (tools/clock_ramp.py), and the Python set-up between two measurements is
+    long enough for it to fall back."""
+    import time
+
     for _ in range(warmup):
         fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    while (time.perf_counter() - t0) * 1e3 < ramp_ms:
+        for _ in range(10):
+            fn()
+        torch.cuda.synchronize()
     s = torch.cuda.current_stream()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    torch.cuda.synchronize()
     e0.record(s)
     for _ in range(iters):
         fn()

@@ -40,19 +40,35 @@ def hadamard(n, device):
 
 
 def bench_graph(fn, reps):
-    """Median / q20 / q80 milliseconds of one call, measured as replays of a captured HIP graph."""
+    """Median / q20 / q80 milliseconds of one call.  `fn` is captured into a HIP graph `inner` times (so that one replay
+    lasts >= ~1 ms), the graph is replayed for >= 50 ms first (an idle MI355X needs ~40 ms under load to reach its steady
+    clock, tools/clock_ramp.py), then `reps` replays are timed individually."""
+    import time
+
     fn()
     torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(3):
+        fn()
+    e1.record()
+    e1.synchronize()
+    est_ms = max(e0.elapsed_time(e1) / 3, 1e-3)
+    inner = int(min(200, max(1, round(1.0 / est_ms))))
     s = torch.cuda.Stream()
     s.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(s):
-        for _ in range(3):
-            fn()
+        fn()
     torch.cuda.current_stream().wait_stream(s)
     torch.cuda.synchronize()
     g = torch.cuda.CUDAGraph()
     with torch.cuda.graph(g):
-        fn()
+        for _ in range(inner):
+            fn()
+    t0 = time.perf_counter()
+    while (time.perf_counter() - t0) < 0.05:
+        g.replay()
+        torch.cuda.synchronize()
     ts = []
     for _ in range(reps):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -60,7 +76,7 @@ def bench_graph(fn, reps):
         g.replay()
         e1.record()
         e1.synchronize()
-        ts.append(e0.elapsed_time(e1))
+        ts.append(e0.elapsed_time(e1) / inner)
     t = torch.tensor(ts)
     return t.median().item(), t.quantile(0.2).item(), t.quantile(0.8).item()
 
