@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -95,6 +96,16 @@ static double time_us(F&& launch, int warm, int iters) {
   HIP_OK(hipEventCreate(&b));
   for (int i = 0; i < warm; ++i) launch();
   HIP_OK(hipDeviceSynchronize());
+  // QAMD_STEADY_MS=<ms> (environment): keep launching for that long before the timed region -- an idle MI355X needs
+  // ~40 ms under load to leave its clock ramp (tools/clock_ramp.py); without it short runs read ~10 % slow
+  static const double steady_ms = getenv("QAMD_STEADY_MS") ? atof(getenv("QAMD_STEADY_MS")) : 0.0;
+  if (steady_ms > 0) {
+    const auto t0 = std::chrono::steady_clock::now();
+    while (std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() < steady_ms) {
+      for (int i = 0; i < 20; ++i) launch();
+      HIP_OK(hipDeviceSynchronize());
+    }
+  }
   HIP_OK(hipEventRecord(a, 0));
   for (int i = 0; i < iters; ++i) launch();
   HIP_OK(hipEventRecord(b, 0));
@@ -493,7 +504,7 @@ int main(int argc, char** argv) {
   if (want("steady")) {   // steady-state clocks: the part needs ~50 ms of load to leave its ramp (tools/clock_ramp.py)
     g_warm_override = 2500; g_iters_override = 2500;
     for (int rep = 0; rep < 2; ++rep)
-      for (int var : {20, 30, 40, 6, 1, 5}) bench_gemm("mxfp4 4096^3 steady", 0, 4096, 4096, 4096, var, 0);
+      for (int var : {20, 30, 40, 6, 1, 5, 24, 25, 2}) bench_gemm("mxfp4 4096^3 steady", 0, 4096, 4096, 4096, var, 0);
     g_warm_override = 600; g_iters_override = 600;
     for (int var : {20, 30, 0}) bench_gemm("mxfp4 C3 steady", 0, 4096, 14336, 4096, var, 0);
     g_warm_override = 300; g_iters_override = 300;
