@@ -46,7 +46,7 @@ def load() -> ctypes.CDLL:
         if not os.path.exists(LIB_PATH):
             raise ImportError(
                 f"{LIB_PATH} is missing: build the HIP extension first "
-                "(python -c 'import __graft_entry__ as g; g.build()' or python -m qutlass_amd.build). "
+                "(python -c 'import __graft_entry__ as g; g.build()' or python qutlass_amd/build.py). "
                 "qutlass_amd has no CPU fallback."
             )
         lib = ctypes.CDLL(LIB_PATH)

@@ -50,7 +50,7 @@ def register_torch_ops() -> None:
     if not os.path.exists(EXT_PATH):
         raise ImportError(
             f"{EXT_PATH} is missing: build the extension first "
-            "(python -c 'import __graft_entry__ as g; g.build()' or python -m qutlass_amd.build). "
+            "(python -c 'import __graft_entry__ as g; g.build()' or python qutlass_amd/build.py). "
             "qutlass_amd has no CPU / eager fallback."
         )
     torch.ops.load_library(EXT_PATH)
