@@ -84,8 +84,8 @@ def aggregate_value(flop_per_step: float, steps: int, world: int, wall: float) -
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=25)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--ramp-ms", type=float, default=250.0,
                     help="untimed load before the W warmup steps: an idle MI355X needs ~50 ms under load to leave its clock "
