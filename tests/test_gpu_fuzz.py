@@ -9,6 +9,9 @@ import oracle
 
 pytestmark = pytest.mark.gpu
 DEV = torch.device("cuda", 0)
+import os
+
+SEED = int(os.environ.get("QAMD_FUZZ_SEED", "0"))   # extra sweeps: QAMD_FUZZ_SEED=1,2,... python -m pytest tests/test_gpu_fuzz.py -m gpu
 
 
 @pytest.fixture(scope="module")
@@ -41,7 +44,7 @@ def _rand_codes(rng, rows, kbytes):
 def test_fuzz_matmul_mxf4(q):
     from qutlass_amd.utils import to_blocked
 
-    rng = np.random.default_rng(101)
+    rng = np.random.default_rng(101 + 1000 * SEED)
     ms = [1, 2, 7, 16, 31, 32, 33, 48, 64, 65, 100, 128, 129, 200, 256, 300, 520]
     for it in range(40):
         m = int(rng.choice(ms))
@@ -74,7 +77,7 @@ def test_fuzz_matmul_mxf4(q):
 def test_fuzz_matmul_nvf4_and_mxf8(q):
     from qutlass_amd.utils import to_blocked
 
-    rng = np.random.default_rng(102)
+    rng = np.random.default_rng(102 + 1000 * SEED)
     for it in range(16):
         m, n = int(rng.choice([1, 16, 40, 128, 136, 300])), int(rng.integers(1, 50)) * 8
         k = int(rng.integers(1, 20)) * 32
@@ -99,7 +102,9 @@ def test_fuzz_matmul_nvf4_and_mxf8(q):
         ref = oracle.gemm_blockscaled(oracle.KIND_MXFP8_TN, _np(x), _np(y), oracle.to_blocked(_np(sa)), oracle.to_blocked(_np(sb)), 1.0, m, n, k)
         got = oracle.bf16_bits_to_f32(_np(out)).astype(np.float64)
         want = oracle.bf16_bits_to_f32(ref).astype(np.float64)
-        assert (np.abs(got - want) <= np.abs(want) / 128.0 + 2e-5 * np.abs(want).max()).all(), (it, m, n, k)
+        # fp32 accumulation of 8-bit-significand products: 1 bf16 ulp + 1e-4 * max|ref| (cancelling outputs next to 2e4-sized
+        # partial sums were seen 3e-5 * max off, identically in every tile configuration / schedule)
+        assert (np.abs(got - want) <= np.abs(want) / 128.0 + 1e-4 * np.abs(want).max()).all(), (it, m, n, k)
         x_km = x.view(torch.uint8).T.contiguous().view(torch.float8_e4m3fn)
         for path in (0, 61, 62):
             q._lib.set_option("gemm_variant", path)
@@ -109,13 +114,13 @@ def test_fuzz_matmul_nvf4_and_mxf8(q):
                 q._lib.set_option("gemm_variant", 0)
             if path == 61:   # different tile configuration than the auto TN kernel: compare with the oracle tolerance
                 gnn = oracle.bf16_bits_to_f32(_np(out_nn)).astype(np.float64)
-                assert (np.abs(gnn - want) <= np.abs(want) / 128.0 + 2e-5 * np.abs(want).max()).all(), ("nn fused", it, m, n, k)
+                assert (np.abs(gnn - want) <= np.abs(want) / 128.0 + 1e-4 * np.abs(want).max()).all(), ("nn fused", it, m, n, k)
             else:
                 assert torch.equal(out_nn.view(torch.int16), out.view(torch.int16)), ("nn", path, it, m, n, k)
 
 
 def test_fuzz_quantizers_and_swizzle(q):
-    rng = np.random.default_rng(103)
+    rng = np.random.default_rng(103 + 1000 * SEED)
     for it in range(24):
         R = int(rng.choice([32, 64, 128]))
         lead = tuple(int(v) for v in rng.integers(1, 5, size=int(rng.integers(0, 3))))
@@ -144,7 +149,7 @@ def test_fuzz_quantizers_and_swizzle(q):
 
 
 def test_fuzz_backward_ops(q):
-    rng = np.random.default_rng(104)
+    rng = np.random.default_rng(104 + 1000 * SEED)
     h = _hadamard(32)
     for it in range(10):
         B, N, M = int(rng.integers(1, 4)), int(rng.integers(1, 9)) * 32, int(rng.integers(1, 40)) * 8
