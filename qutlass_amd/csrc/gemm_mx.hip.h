@@ -30,7 +30,13 @@
 #include <type_traits>
 
 #include "common.hip.h"
-#include "transpose_u8.hip.h"   // transpose4x4_u8 (fused NN operand path)
+#include "transpose_u8.hip.h"
+
+// cache policy of the operand LDS-DMA loads (buffer_load ... lds aux bits: 1 = sc0, 2 = nt, 16 = sc1); build-time
+// switch for experiments (tools: hipcc -DQAMD_DMA_AUX=2 ...)
+#ifndef QAMD_DMA_AUX
+#define QAMD_DMA_AUX 0
+#endif   // transpose4x4_u8 (fused NN operand path)
 
 namespace qamd {
 
@@ -244,7 +250,7 @@ struct GemmCtx {
       const int a = par ? voffAB[1] : voffAB[0], b = par ? voffT[1] : voffT[0];
       const int base = (b & lastmask) | (a & ~lastmask);
       const int v = base + q * rstep + oob;   // (unsigned) >= num_records when oob is set
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)(dst + q * 1024), 16, v, soff, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)(dst + q * 1024), 16, v, soff, 0, QAMD_DMA_AUX);
     }
   }
   __device__ __forceinline__ void issue_pieces_range(const int NP, __amdgpu_buffer_rsrc_t rsrc, char* dst, int kt, bool valid, const int t0, const int t1) {
@@ -258,7 +264,7 @@ struct GemmCtx {
       const int par = q & 1;
       const int a = par ? voffAB[1] : voffAB[0], b = par ? voffT[1] : voffT[0];
       const int v = ((b & lastmask) | (a & ~lastmask)) + q * rstep + oob;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)(dst + q * 1024), 16, v, soff, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)(dst + q * 1024), 16, v, soff, 0, QAMD_DMA_AUX);
     }
   }
   __device__ __forceinline__ void issue_scales(int kt, char* st, bool valid) {
@@ -937,7 +943,7 @@ __device__ __forceinline__ void gemm_mx_deep8(char* smem, const GemmParams& p) {
       const int k = kt * 128 + 4 * q + (cx.lane >> 4);
       int v = (k < p.K) ? (((q >> 2) & 1) ? nn_voff[1] : nn_voff[0]) + (kt * 128 + 4 * q) * p.M : 0x7f000000;   // rows past K read 0
       asm volatile("" : "+v"(v));
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rAT, (lds_ptr_t)(st + q * 1024), 16, v, 0, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rAT, (lds_ptr_t)(st + q * 1024), 16, v, 0, 0, QAMD_DMA_AUX);
     }
   };
   auto read_A_nn = [&](int buf, int j) __attribute__((always_inline)) {
