@@ -33,13 +33,14 @@ struct BwdTParams {
   uint8_t* out_sf;          // e8m0 (B, M, N/32)
   int B, N, M;
   int tiles_m;              // ceil(M / 64)
-  int64_t ntiles;           // B * (N/32) * tiles_m : one wave-tile = 32 n x 64 m of one batch entry
+  int ntiles;               // B * (N/32) * tiles_m (< 2^31, host-checked): one wave-tile = 32 n x 64 m of one batch entry
 };
 
 // One wave = one [32 n][64 m] tile = one scale group for 64 output rows.
 template <bool QT, bool HWCVT>
 __global__ __launch_bounds__(256) void bwd_quant_t_kernel(const BwdTParams p) {
-  constexpr int LROW = 64 * 2 + 4;   // LDS row stride (bytes): 32 dwords + 1 -> column reads of 2 bytes stay conflict-free
+  constexpr int LROW = 64 * 2 + 16;  // LDS row stride (bytes): 16-byte aligned rows (ds_write_b128); the two lane halves read rows
+                                     // 8 apart = 288 dwords = bank offset 32, so their 64-byte column runs never collide
   constexpr int HROW = 32 * 2 + 16;
   __shared__ __attribute__((aligned(16))) char tile_s[4][32 * LROW];
   __shared__ __attribute__((aligned(16))) char hT[32 * HROW];
@@ -58,54 +59,70 @@ __global__ __launch_bounds__(256) void bwd_quant_t_kernel(const BwdTParams p) {
   char* ts = tile_s[wave];
   const float alpha = QT ? *p.alpha : 1.0f;
   const int G = p.N >> 5;
-  const int64_t wave_global = (int64_t)blockIdx.x * 4 + wave, nwaves = (int64_t)gridDim.x * 4;
-  for (int64_t t = wave_global; t < p.ntiles; t += nwaves) {
-    const int tm = (int)(t % p.tiles_m);
-    const int g = (int)((t / p.tiles_m) % G);
-    const int b = (int)(t / ((int64_t)p.tiles_m * G));
-    const int m0 = tm * 64, n0 = g * 32;
+  const int wave_global = blockIdx.x * 4 + wave, nwaves = gridDim.x * 4;   // 32-bit tile arithmetic: 64-bit div/mod is ~100 SALU ops each
 
-    // ---- stage the [32 n][64 m] bf16 tile in LDS ---------------------------------------------------------------
+  // global -> registers for one tile (software pipeline: the next tile's loads are in flight while this one is
+  // rotated and quantised).  T: lane -> row lane/8 (+8 per pass), 16-byte chunk lane%8 (8 m): one pass = 8 rows x 128 B.
+  // QT: lane -> row lane/2, 16-byte half (32 codes = one input scale group) + its e8m0 byte.
+  v4i ld[QT ? 1 : 4];
+  uint32_t ld_e = 0;
+  auto load_tile = [&](int t) __attribute__((always_inline)) {
+    const bool live = t < p.ntiles;
+    const unsigned tq = (unsigned)t / (unsigned)p.tiles_m;
+    const int tm = (int)((unsigned)t - tq * (unsigned)p.tiles_m);
+    const int b = (int)(tq / (unsigned)G);
+    const int g = (int)(tq - (unsigned)b * (unsigned)G);
+    const int m0 = tm * 64, n0 = g * 32;
     if (!QT) {
-      // lane -> row lane/8 (+8 per pass), 16-byte chunk lane%8 (8 m): one pass = 8 rows x 128 B
 #pragma unroll
       for (int ps = 0; ps < 4; ++ps) {
         const int r = ps * 8 + (lane >> 3), c = (lane & 7) * 8;
-        v4i v = {0, 0, 0, 0};
-        if (m0 + c < p.M) {   // M % 8 == 0 (host-checked): a chunk is in or out as a whole
-          const uint16_t* src = p.x + ((int64_t)b * p.N + n0 + r) * p.M + m0 + c;
-          v = *(const v4i*)src;
-        }
-        // LROW is not a multiple of 16: four dword stores
-        int* d = (int*)(ts + r * LROW + c * 2);
-        d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; d[3] = v[3];
+        ld[ps] = v4i{0, 0, 0, 0};
+        if (live && m0 + c < p.M)   // M % 8 == 0 (host-checked): a chunk is in or out as a whole
+          ld[ps] = *(const v4i*)(p.x + ((int64_t)b * p.N + n0 + r) * p.M + m0 + c);
       }
     } else {
-      // packed input: lane -> row lane/2, 16-byte half (32 codes = one input scale group)
       const int r = lane >> 1, c = (lane & 1) * 32;
-      uint32_t w[4] = {0, 0, 0, 0};
-      float sc = 1.0f;
-      if (m0 + c < p.M) {     // M % 32 == 0 (host-checked)
+      ld[0] = v4i{0, 0, 0, 0};
+      ld_e = 127;
+      if (live && m0 + c < p.M) {     // M % 32 == 0 (host-checked)
         const int64_t rowi = (int64_t)b * p.N + n0 + r;
-        const v4i v = *(const v4i*)(p.xq + rowi * (p.M >> 1) + ((m0 + c) >> 1));
-        w[0] = v[0]; w[1] = v[1]; w[2] = v[2]; w[3] = v[3];
-        const uint32_t e = p.xs[rowi * (p.M >> 5) + ((m0 + c) >> 5)];
-        sc = __uint_as_float(e ? (e << 23) : 0x00400000u);   // 2^(e-127); e = 0 -> 2^-127 (denormal)
-      }
-      int* d = (int*)(ts + r * LROW + c * 2);
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-#pragma unroll
-        for (int bsel = 0; bsel < 4; ++bsel) {
-          bf16x2 v2;
-          if (bsel == 0) v2 = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp4(w[q], sc, 0);
-          if (bsel == 1) v2 = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp4(w[q], sc, 1);
-          if (bsel == 2) v2 = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp4(w[q], sc, 2);
-          if (bsel == 3) v2 = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp4(w[q], sc, 3);
-          d[q * 4 + bsel] = __builtin_bit_cast(int, v2);
-        }
+        ld[0] = *(const v4i*)(p.xq + rowi * (p.M >> 1) + ((m0 + c) >> 1));
+        ld_e = p.xs[rowi * (p.M >> 5) + ((m0 + c) >> 5)];
       }
     }
+  };
+  load_tile(wave_global);
+  for (int t = wave_global; t < p.ntiles; t += nwaves) {
+    const unsigned tq = (unsigned)t / (unsigned)p.tiles_m;
+    const int tm = (int)((unsigned)t - tq * (unsigned)p.tiles_m);
+    const int b = (int)(tq / (unsigned)G);
+    const int g = (int)(tq - (unsigned)b * (unsigned)G);
+    const int m0 = tm * 64;
+
+    // ---- stage the [32 n][64 m] bf16 tile in LDS ---------------------------------------------------------------
+    if (!QT) {
+#pragma unroll
+      for (int ps = 0; ps < 4; ++ps) {
+        const int r = ps * 8 + (lane >> 3), c = (lane & 7) * 8;
+        *(v4i*)(ts + r * LROW + c * 2) = ld[ps];
+      }
+    } else {
+      const int r = lane >> 1, c = (lane & 1) * 32;
+      const float sc = __uint_as_float(ld_e ? (ld_e << 23) : 0x00400000u);   // 2^(e-127); e = 0 -> 2^-127 (denormal)
+      v4i* d = (v4i*)(ts + r * LROW + c * 2);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const uint32_t w = (uint32_t)ld[0][q];
+        v4i o;
+        o[0] = __builtin_bit_cast(int, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp4(w, sc, 0));
+        o[1] = __builtin_bit_cast(int, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp4(w, sc, 1));
+        o[2] = __builtin_bit_cast(int, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp4(w, sc, 2));
+        o[3] = __builtin_bit_cast(int, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp4(w, sc, 3));
+        d[q] = o;
+      }
+    }
+    load_tile(t + nwaves);   // next tile's rows: in flight during the rotation / quantisation below
     __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): the wave's own LDS writes landed (wave-private tile)
     __builtin_amdgcn_wave_barrier();
 
