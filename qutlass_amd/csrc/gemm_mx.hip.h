@@ -24,8 +24,13 @@
 //     tile through LDS and writes whole 128-byte lines.
 //   * blockIdx -> tile: XCD-contiguous remap + grouped raster so one XCD's L2 sees a compact
 //     rectangle of tiles.
-//   * Two schedules share all of the above: gemm_mx_lockstep (one barrier per stage, used for small
-//     tiles) and gemm_mx_pingpong (two wave groups ping-ponging load and MFMA blocks).
+//   * Schedules (all share the tiling / DMA / epilogue code in GemmCtx; DESIGN.md section 3.3-3.4 has the measurements):
+//       gemm_mx_deep / gemm_mx_deep8   4 waves of 128x128, self-pipelined, hand-off in mid-stage  -- DEFAULT for 256x256 tiles
+//                                      (gemm_mx_deep8<C, NN = true>: fused (K, M) operand path of matmul_mxf8_bf16_nn)
+//       gemm_mx_simple                 8 waves (or 4 for small tiles), R(j);M(j) per slice             -- DEFAULT for smaller tiles
+//       gemm_mx_lockstep / _pingpong / _queue / _regstage   earlier or alternative schedules kept selectable ("gemm_variant")
+//                                      because their measurements are part of the design record; none is faster in the
+//                                      steady state -- the kernels run at the power cap.
 #pragma once
 #include <type_traits>
 
