@@ -596,10 +596,10 @@ __global__ __launch_bounds__(NWAVES * 64) void gemm_nvf4_skinny_kernel(const NvG
 inline hipError_t launch_nvf4_gemm(NvGemmParams p, hipStream_t s, int variant = 0) {
   // 128x128 tiles when a dimension is small OR when 256x256 tiles would leave most CUs without work
   const bool small = p.M <= 128 || p.N <= 128 || (int64_t)((p.M + 255) / 256) * ((p.N + 255) / 256) < 192;
-  // small batch: split-K kernel for M <= 64, and up to M = 128 while 128x128 tiles would leave CUs idle (measured:
-  // M = 128, N = 4096: 184 vs 93 TFLOP/s; N = 28672: 380 vs 594, so large N stays tiled)
-  const int64_t tiles128 = (int64_t)((p.M + 127) / 128) * ((p.N + 127) / 128);
-  if (variant == 3 || (variant == 0 && (p.M <= 64 || (p.M <= 128 && tiles128 < 192)))) {
+  // small batch: split-K kernel for M <= 64, and up to M = 128 while even 64x64 tiles would leave CUs idle (measured,
+  // M = 128, K = 4096: N = 4096 11.8 us vs 17.3 us for 64x64 tiles; N = 14336 35.6 us vs 25.2 us for 128x64 tiles)
+  const int64_t tiles64 = (int64_t)((p.M + 63) / 64) * ((p.N + 63) / 64);
+  if (variant == 3 || (variant == 0 && (p.M <= 64 || (p.M <= 128 && tiles64 < 192)))) {
     hipLaunchKernelGGL((gemm_nvf4_skinny_kernel<8>), dim3((p.N + 31) / 32, (p.M + 31) / 32), dim3(512), 0, s, p);
     return hipSuccess;
   }
@@ -610,19 +610,29 @@ inline hipError_t launch_nvf4_gemm(NvGemmParams p, hipStream_t s, int variant = 
     hipLaunchKernelGGL((gemm_nvf4_kernel<C>), dim3(p.tiles_m * p.tiles_n), dim3(C::THREADS), 0, s, p);
     return hipSuccess;
   }
-  if (variant <= 1 || variant == 4) {
-    if (small) {
-      using C = NvCfg<128, 128, 2, 2>;
-      p.tiles_m = (p.M + C::BM - 1) / C::BM;
-      p.tiles_n = (p.N + C::BN - 1) / C::BN;
-      hipLaunchKernelGGL((gemm_nvf4_kernel<C>), dim3(p.tiles_m * p.tiles_n), dim3(C::THREADS), 0, s, p);
-    } else {
-      using C = NvCfg<256, 256, 2, 4>;
-      p.tiles_m = (p.M + C::BM - 1) / C::BM;
-      p.tiles_n = (p.N + C::BN - 1) / C::BN;
-      hipLaunchKernelGGL((gemm_nvf4_kernel<C>), dim3(p.tiles_m * p.tiles_n), dim3(C::THREADS), 0, s, p);
+  if (variant <= 1 || variant == 4 || (variant >= 5 && variant <= 7)) {
+    // tile choice by occupancy (as for the MX kernels): the largest tile that gives >= 192 workgroups
+    auto tiles = [&](int bm, int bn) { return (int64_t)((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn); };
+    int cfg = small ? 1 : 0;                                  // 0: 256x256, 1: 128x128, 2: 128x64, 3: 64x64
+    if (variant == 0 || variant == 1) {
+      if (cfg == 1 && tiles(128, 128) < 192) cfg = (tiles(128, 64) >= 192) ? 2 : 3;
     }
-    return hipSuccess;
+    if (variant == 5) cfg = 1;
+    if (variant == 6) cfg = 2;
+    if (variant == 7) cfg = 3;
+#define QAMD_NV_LAUNCH(BM_, BN_, WM_, WN_)                                                                     \
+    {                                                                                                          \
+      using C = NvCfg<BM_, BN_, WM_, WN_>;                                                                     \
+      p.tiles_m = (p.M + C::BM - 1) / C::BM;                                                                   \
+      p.tiles_n = (p.N + C::BN - 1) / C::BN;                                                                   \
+      hipLaunchKernelGGL((gemm_nvf4_kernel<C>), dim3(p.tiles_m * p.tiles_n), dim3(C::THREADS), 0, s, p);       \
+      return hipSuccess;                                                                                       \
+    }
+    if (cfg == 0) QAMD_NV_LAUNCH(256, 256, 2, 4)
+    if (cfg == 1) QAMD_NV_LAUNCH(128, 128, 2, 2)
+    if (cfg == 2) QAMD_NV_LAUNCH(128, 64, 2, 2)
+    QAMD_NV_LAUNCH(64, 64, 2, 2)
+#undef QAMD_NV_LAUNCH
   }
 #define QAMD_NV_ABL(b)                                                                                          \
   if (variant == 10 + b) {                                                                                     \

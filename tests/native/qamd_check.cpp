@@ -619,6 +619,27 @@ int main(int argc, char** argv) {
     }
     qutlass_amd_set_option("nvf4_variant", 0);
   }
+  if (want("nvtile")) {   // NVFP4 tile configs (5: 128x128, 6: 128x64, 7: 64x64, 3: split-K, 0: auto) over mid-batch shapes
+    for (int nv : {5, 6, 7}) {
+      qutlass_amd_set_option("nvf4_variant", nv);
+      printf("nvf4_variant=%d\n", nv);
+      check_gemm("gemm_nvfp4 16x64x32", 1, 16, 64, 32, 1.0f, 3, 0, 0);
+      check_gemm("gemm_nvfp4 ragged + K tail (K%64=32)", 1, 72, 136, 352, 0.5f, 3, 0, 0);
+      check_gemm("gemm_nvfp4 ragged 300x264x320", 1, 300, 264, 320, 1.0f, 3, 0, 0);
+      check_gemm("gemm_nvfp4 504x512x2048", 1, 504, 512, 2048, 1.0f, 3, 0, 0);
+    }
+    for (int64_t M : {128, 256, 512, 1024, 2048})
+      for (int64_t N : {4096, 14336}) {
+        for (int nv : {0, 3, 5, 6, 7}) {
+          if (nv == 3 && M > 256) continue;
+          qutlass_amd_set_option("nvf4_variant", nv);
+          char tag[96];
+          snprintf(tag, sizeof tag, "nvfp4 var=%d %lldx%lldx4096", nv, (long long)M, (long long)N);
+          bench_gemm(tag, 1, M, N, 4096, 0, 50);
+        }
+      }
+    qutlass_amd_set_option("nvf4_variant", 0);
+  }
   if (want("nn") || want("gemm")) {
     for (int force : {61, 62}) {   // 61 = fused A^T operand path, 62 = byte-transpose pre-pass + TN
       qutlass_amd_set_option("gemm_variant", force);

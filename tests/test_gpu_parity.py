@@ -258,7 +258,7 @@ def test_matmul_mxf4_errors(q):
 # ------------------------------------------------------------------------------------------------
 # NVFP4
 # ------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("nv_variant", [0, 1, 2, 3, 4])   # 1 / 4 = per-wave dequant (8 / 4 waves), 2 = dequantise once into f16 LDS tiles, 3 = small-batch split-K
+@pytest.mark.parametrize("nv_variant", [0, 1, 2, 3, 4, 5, 6, 7])   # 5 / 6 / 7 = 128x128 / 128x64 / 64x64 tiles, 1 / 4 = per-wave dequant (8 / 4 waves), 2 = dequantise once into f16 LDS tiles, 3 = small-batch split-K
 def test_matmul_nvf4_golden_bit_exact(q, golden_dir, nv_variant):
     g = _load(golden_dir, "gemm_nvfp4.npz")
     q._lib.set_option("nvf4_variant", nv_variant)
