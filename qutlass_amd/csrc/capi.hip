@@ -147,12 +147,23 @@ int gemm_mx(const char* name, const void* A, const void* B, const void* A_sf, co
   hipStream_t s = (hipStream_t)stream;
   int variant = g_gemm_variant.load();
   if (variant == 61 || variant == 62) variant = 0;   // these select the NN operand path only (matmul_mxf8_bf16_nn)
-  if (EBITS == 4 && (variant == 60 || (variant == 0 && M <= 32))) {
-    // small batch: weight-bandwidth bound -> split-K kernel without LDS staging (gemm_mx_skinny.hip.h)
+  // small batch: weight-bandwidth bound.  While the weight has fewer than 256 64-row tiles (N < 16384) the split-K kernel
+  // without LDS staging wins (gemm_mx_skinny.hip.h: N = K = 4096, M = 16: 5.5 us vs 7.9 us); with more tiles than CUs the
+  // 64x64-tile kernel streams the weight at 6.3 TB/s through full-line LDS-DMA and wins (N = 57344, K = 8192: 36 us vs
+  // 58-74 us; profiles/native_r1_skinny_shapes.log)
+  if (EBITS == 4 && (variant == 60 || (variant >= 44 && variant <= 49) || (variant == 0 && M <= 32 && cdiv(N, 64) < 256))) {
     SkinnyParams q;
     q.A = p.A; q.B = p.B; q.SFA = p.SFA; q.SFB = p.SFB; q.alpha = alpha; q.D = p.D; q.M = p.M; q.N = p.N; q.K = p.K;
     q.a_bytes = p.a_bytes; q.b_bytes = p.b_bytes; q.sfa_bytes = p.sfa_bytes; q.sfb_bytes = p.sfb_bytes;
-    launch_skinny<true>(q, s);
+    switch (variant) {   // 44..49: bench-only shapes of the split-K kernel (waves, segments per trip, chunk mapping)
+      case 44: launch_skinny<true, 8, 2, true>(q, s); break;
+      case 45: launch_skinny<true, 4, 2, false>(q, s); break;
+      case 46: launch_skinny<true, 4, 2, true>(q, s); break;
+      case 47: launch_skinny<true, 8, 2, false>(q, s); break;
+      case 48: launch_skinny<true, 8, 1, true>(q, s); break;
+      case 49: launch_skinny<true, 4, 4, true>(q, s); break;
+      default: launch_skinny<true, 8, 4, false>(q, s);   // 4 segments per wave per trip: 32 b128 loads in flight per wave
+    }
     return check_launch("gemm_mx_skinny_kernel");
   }
   if (variant == 0) {
@@ -161,7 +172,9 @@ int gemm_mx(const char* name, const void* A, const void* B, const void* A_sf, co
     // schedule, several workgroups per CU).  (fp4 with M <= 32 went to the split-K kernel above.)
     auto tiles = [&](int bm, int bn) { return cdiv(M, bm) * cdiv(N, bn); };
     const int64_t want = 192;   // 3/4 of the 256 CUs
-    if (M <= 64) variant = (tiles(64, 128) >= want) ? 28 : 29;          // no point in tiles taller than the problem
+    // no point in tiles taller than the problem; 64x64 until 64x128 tiles fill the chip 1.5 times (weight-bandwidth
+    // bound: N = 28672, K = 4096, M = 32: 12.6 us with 448 tiles of 64x64 vs 14.3 us with 224 of 64x128)
+    if (M <= 64) variant = (tiles(64, 128) >= 384) ? 28 : 29;
     else if (N <= 64) variant = (tiles(128, 64) >= want) ? 27 : 29;
     else if (tiles(256, 256) >= want) {
       variant = 30;
@@ -256,7 +269,7 @@ int qutlass_amd_matmul_ada_mxf4_bf16_tn(const void* A, const void* B, const void
   q.alpha = alpha; q.D = (uint16_t*)D; q.M = (int)M; q.N = (int)N; q.K = (int)K;
   q.a_bytes = (uint32_t)(M * (K / 2)); q.b_bytes = (uint32_t)(N * (K / 2));
   q.sfa_bytes = (uint32_t)(M * (K / 32)); q.sfb_bytes = (uint32_t)(N * (K / 32));   // row-major (rows, K/32), un-swizzled
-  launch_skinny<false>(q, (hipStream_t)stream);
+  launch_skinny<false, 8, 4, false>(q, (hipStream_t)stream);
   return check_launch("gemm_mx_skinny_kernel");
 }
 
@@ -316,7 +329,7 @@ int qutlass_amd_matmul_nvf4_bf16_tn(const void* A, const void* B, const void* A_
   p.a_bytes = (uint32_t)(M * (K / 2)); p.b_bytes = (uint32_t)(N * (K / 2));
   p.sfa_bytes = (uint32_t)(cdiv(M, 128) * CB * 512); p.sfb_bytes = (uint32_t)(cdiv(N, 128) * CB * 512);
   p.dbg = g_dbg.load();
-  launch_nvf4_gemm(p, (hipStream_t)stream, g_nvf4_variant.load());
+  (void)launch_nvf4_gemm(p, (hipStream_t)stream, g_nvf4_variant.load());
   return check_launch(name);
 }
 

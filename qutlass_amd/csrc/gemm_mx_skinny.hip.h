@@ -27,9 +27,10 @@ struct SkinnyParams {
   uint32_t a_bytes, b_bytes, sfa_bytes, sfb_bytes;
 };
 
-template <bool SWZ, int NWAVES>
+// MAP2 = false: lane (row, half g) takes chunk 4g + j for k-slice j (two separate 16-byte pieces of a line per load);
+// MAP2 = true : chunk 2j + g, so one load instruction reads 32 contiguous bytes of each of its 32 lines.
+template <bool SWZ, int NWAVES, int SEG = 2, bool MAP2 = false>   // SEG: 128-byte row segments (256 K elements) per wave per trip
 __global__ __launch_bounds__(NWAVES * 64) void gemm_mx_skinny_kernel(const SkinnyParams p) {
-  constexpr int SEG = 2;   // 128-byte row segments (256 K elements) per wave per trip
   __shared__ __attribute__((aligned(16))) float part[NWAVES][32][33];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = uniform(tid >> 6);
@@ -44,17 +45,19 @@ __global__ __launch_bounds__(NWAVES * 64) void gemm_mx_skinny_kernel(const Skinn
   const __amdgpu_buffer_rsrc_t rA = make_rsrc(p.A + a_off, p.a_bytes - a_off);   // rows past M / N fall off the end -> 0
   const __amdgpu_buffer_rsrc_t rB = make_rsrc(p.B + b_off, p.b_bytes - b_off);
   const __amdgpu_buffer_rsrc_t rSA = make_rsrc(p.SFA, p.sfa_bytes), rSB = make_rsrc(p.SFB, p.sfb_bytes);
-  const int voff = i32 * rowbytes + g * 64;        // row i32, chunk 4g (+ 16 j)
-  // scale dword of (row, segment s, half g): K-blocks 8s + 4g .. +3
+  constexpr int CSTEP = MAP2 ? 32 : 16;            // byte step between the chunks of k-slices j, j + 1
+  const int voff = i32 * rowbytes + g * (MAP2 ? 16 : 64);   // row i32, chunk 4g (+ j)  |  chunk g (+ 2j)
+  // scale dword of (row, segment s, half g): K-blocks 8s + 4g .. +3   (MAP2: both dwords of the segment, h = 0 / 1)
   int soffA, soffB;
   {
     const int ra = m0 + i32, rb = n0 + i32;
+    const int gg = MAP2 ? 0 : g;
     if (SWZ) {
-      soffA = (ra >> 7) * CB * 512 + (ra & 31) * 16 + ((ra & 127) >> 5) * 4 + g * 512;   // + s * 1024: column tile 2s + g
-      soffB = (rb >> 7) * CB * 512 + (rb & 31) * 16 + ((rb & 127) >> 5) * 4 + g * 512;
+      soffA = (ra >> 7) * CB * 512 + (ra & 31) * 16 + ((ra & 127) >> 5) * 4 + gg * 512;  // + s * 1024: column tile 2s + g
+      soffB = (rb >> 7) * CB * 512 + (rb & 31) * 16 + ((rb & 127) >> 5) * 4 + gg * 512;
     } else {
-      soffA = ra * KB + g * 4;                                                           // + s * 8
-      soffB = rb * KB + g * 4;
+      soffA = ra * KB + gg * 4;                                                          // + s * 8
+      soffB = rb * KB + gg * 4;
     }
   }
   constexpr int OOB = 0x7f000000;
@@ -67,7 +70,7 @@ __global__ __launch_bounds__(NWAVES * 64) void gemm_mx_skinny_kernel(const Skinn
 
   for (int s0 = wave * SEG; s0 < nseg; s0 += NWAVES * SEG) {
     v4i fa[SEG][4], fb[SEG][4];
-    int sa[SEG], sb[SEG];
+    int sa[SEG][2], sb[SEG][2];
 #pragma unroll
     for (int u = 0; u < SEG; ++u) {
       const int s = s0 + u;
@@ -75,14 +78,29 @@ __global__ __launch_bounds__(NWAVES * 64) void gemm_mx_skinny_kernel(const Skinn
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         // chunks past the end of the row (K tail / segment past K) must read 0, not the next row
-        const int v = (s < nseg && base + g * 64 + j * 16 < rowbytes) ? voff + j * 16 : OOB;
+        const int cbyte = MAP2 ? g * 16 + j * 32 : g * 64 + j * 16;
+        const int v = (s < nseg && base + cbyte < rowbytes) ? voff + j * CSTEP : OOB;
         fa[u][j] = __builtin_amdgcn_raw_buffer_load_b128(rA, v, base, 0);
         fb[u][j] = __builtin_amdgcn_raw_buffer_load_b128(rB, v, base, 0);
       }
-      const bool col_ok = (8 * s + 4 * g) < KB;          // K % 128 == 0: a scale dword is in or out as a whole
       const int step = SWZ ? s * 1024 : s * 8;
-      sa[u] = __builtin_amdgcn_raw_buffer_load_b32(rSA, (col_ok && rowA_ok) ? soffA + step : OOB, 0, 0);
-      sb[u] = __builtin_amdgcn_raw_buffer_load_b32(rSB, (col_ok && rowB_ok) ? soffB + step : OOB, 0, 0);
+      if (MAP2) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {                      // dword h = K-blocks 8s + 4h .. +3; the lane uses bytes g, 2 + g
+          const bool col_ok = (8 * s + 4 * h) < KB;
+          const int hoff = SWZ ? h * 512 : h * 4;
+          const int da = __builtin_amdgcn_raw_buffer_load_b32(rSA, (col_ok && rowA_ok) ? soffA + step + hoff : OOB, 0, 0);
+          const int db = __builtin_amdgcn_raw_buffer_load_b32(rSB, (col_ok && rowB_ok) ? soffB + step + hoff : OOB, 0, 0);
+          sa[u][h] = (int)((uint32_t)da >> (8 * g));
+          sb[u][h] = (int)((uint32_t)db >> (8 * g));
+        }
+      } else {
+        const bool col_ok = (8 * s + 4 * g) < KB;          // K % 128 == 0: a scale dword is in or out as a whole
+        sa[u][0] = __builtin_amdgcn_raw_buffer_load_b32(rSA, (col_ok && rowA_ok) ? soffA + step : OOB, 0, 0);
+        sb[u][0] = __builtin_amdgcn_raw_buffer_load_b32(rSB, (col_ok && rowB_ok) ? soffB + step : OOB, 0, 0);
+        sa[u][1] = sa[u][0];
+        sb[u][1] = sb[u][0];
+      }
     }
 #pragma unroll
     for (int u = 0; u < SEG; ++u) {
@@ -91,10 +109,17 @@ __global__ __launch_bounds__(NWAVES * 64) void gemm_mx_skinny_kernel(const Skinn
         const v4i a = fa[u][j], b = fb[u][j];
         const v8i A8 = {a[0], a[1], a[2], a[3], 0, 0, 0, 0}, B8 = {b[0], b[1], b[2], b[3], 0, 0, 0, 0};
         // srcA = B fragment, srcB = A fragment (as in gemm_mx.hip.h): acc[4q+e] = D[m = i32][n = 8q + 4g + e]
-        if (j == 0) acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(B8, A8, acc, 4, 4, 0, sb[u], 0, sa[u]);
-        if (j == 1) acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(B8, A8, acc, 4, 4, 1, sb[u], 1, sa[u]);
-        if (j == 2) acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(B8, A8, acc, 4, 4, 2, sb[u], 2, sa[u]);
-        if (j == 3) acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(B8, A8, acc, 4, 4, 3, sb[u], 3, sa[u]);
+        if (MAP2) {     // slice j = K-block 2j + g: byte (2j & 3) of the lane's shifted dword j >> 1
+          if (j == 0) acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(B8, A8, acc, 4, 4, 0, sb[u][0], 0, sa[u][0]);
+          if (j == 1) acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(B8, A8, acc, 4, 4, 2, sb[u][0], 2, sa[u][0]);
+          if (j == 2) acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(B8, A8, acc, 4, 4, 0, sb[u][1], 0, sa[u][1]);
+          if (j == 3) acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(B8, A8, acc, 4, 4, 2, sb[u][1], 2, sa[u][1]);
+        } else {
+          if (j == 0) acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(B8, A8, acc, 4, 4, 0, sb[u][0], 0, sa[u][0]);
+          if (j == 1) acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(B8, A8, acc, 4, 4, 1, sb[u][0], 1, sa[u][0]);
+          if (j == 2) acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(B8, A8, acc, 4, 4, 2, sb[u][0], 2, sa[u][0]);
+          if (j == 3) acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(B8, A8, acc, 4, 4, 3, sb[u][0], 3, sa[u][0]);
+        }
       }
     }
   }
@@ -122,10 +147,9 @@ __global__ __launch_bounds__(NWAVES * 64) void gemm_mx_skinny_kernel(const Skinn
   }
 }
 
-template <bool SWZ>
+template <bool SWZ, int NW = 8, int SEG = 2, bool MAP2 = false>
 inline void launch_skinny(const SkinnyParams& p, hipStream_t s) {
-  constexpr int NW = 8;
-  hipLaunchKernelGGL((gemm_mx_skinny_kernel<SWZ, NW>), dim3((p.N + 31) / 32, (p.M + 31) / 32), dim3(NW * 64), 0, s, p);
+  hipLaunchKernelGGL((gemm_mx_skinny_kernel<SWZ, NW, SEG, MAP2>), dim3((p.N + 31) / 32, (p.M + 31) / 32), dim3(NW * 64), 0, s, p);
 }
 
 }  // namespace qamd

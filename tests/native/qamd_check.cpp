@@ -619,6 +619,23 @@ int main(int argc, char** argv) {
     }
     qutlass_amd_set_option("nvf4_variant", 0);
   }
+  if (want("skinny")) {   // split-K kernel shapes (60: 8 waves x 4 segments, 47: x 2, 44..49 see capi.hip) vs 64-row tiles (28: 64x128, 29: 64x64)
+    for (int var : {60, 44, 45, 46, 47, 48, 49}) {
+      check_gemm("gemm_mxfp4 skinny M=1", 0, 1, 504, 1024, 1.0f, 2, 0, var);
+      check_gemm("gemm_mxfp4 skinny ragged + K tail", 0, 24, 136, 640, 0.5f, 4, 0, var);
+      check_gemm("gemm_mxfp4 skinny 32x512x4096", 0, 32, 512, 4096, 1.0f, 3, 0, var);
+      check_gemm("gemm_mxfp4 skinny 7x264x1152", 0, 7, 264, 1152, 1.0f, 3, 0, var);
+    }
+    const int64_t shapes[][2] = {{4096, 4096}, {14336, 4096}, {28672, 4096}, {8192, 8192}, {57344, 8192}, {8192, 28672}};
+    for (auto& sh : shapes)
+      for (int64_t M : {1, 16, 32}) {
+        for (int var : {60, 44, 45, 46, 47, 48, 49, 28, 29}) {
+          char tag[96];
+          snprintf(tag, sizeof tag, "mxfp4 M=%lld N=%lld K=%lld var=%d", (long long)M, (long long)sh[0], (long long)sh[1], var);
+          bench_gemm(tag, 0, M, sh[0], sh[1], var, 50);
+        }
+      }
+  }
   if (want("nvtile")) {   // NVFP4 tile configs (5: 128x128, 6: 128x64, 7: 64x64, 3: split-K, 0: auto) over mid-batch shapes
     for (int nv : {5, 6, 7}) {
       qutlass_amd_set_option("nvf4_variant", nv);

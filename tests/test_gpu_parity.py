@@ -296,6 +296,39 @@ def test_fused_quantize_nv_and_gemm_vs_oracle(q, rot):
     assert np.array_equal(_np(out), ref)   # exact: the reference asserts out.equal(out_ref) (nvfp4_test.py:224)
 
 
+@pytest.mark.parametrize("m,n,k", [(256, 4096, 1024), (512, 4096, 1024), (128, 14336, 512), (96, 4096, 1024), (1000, 2056, 544)])
+def test_matmul_nvf4_occupancy_tile_choice_is_bit_identical(q, m, n, k):
+    """The auto rule picks 64x64 / 128x64 / split-K / 128x128 tiles on these shapes; every configuration accumulates K in
+    the same order, so the result must equal the forced 128x128 launch bit for bit, and the oracle on sampled rows."""
+    g = torch.Generator(device="cpu").manual_seed(m + n + k)
+    a = torch.randint(0, 256, (m, k // 2), dtype=torch.uint8, generator=g).to(DEV)
+    b = torch.randint(0, 256, (n, k // 2), dtype=torch.uint8, generator=g).to(DEV)
+    # e4m3 scales in [1, 4), all mantissas: every partial sum stays exact in fp32, so the oracle comparison is bit-exact
+    sa = torch.randint(0x38, 0x48, (-(-m // 128) * 128, k // 16), dtype=torch.uint8, generator=g)
+    sb = torch.randint(0x38, 0x48, (-(-n // 128) * 128, k // 16), dtype=torch.uint8, generator=g)
+    from qutlass_amd.utils import to_blocked
+
+    sa_b = to_blocked(sa.to(DEV).view(torch.float8_e4m3fn))
+    sb_b = to_blocked(sb.to(DEV).view(torch.float8_e4m3fn))
+    al = torch.tensor([0.25], device=DEV)
+    outs = {}
+    try:
+        for v in (0, 5, 6, 7):
+            q._lib.set_option("nvf4_variant", v)
+            outs[v] = q.matmul_nvf4_bf16_tn(a, b, sa_b, sb_b, al).view(torch.int16).cpu()
+    finally:
+        q._lib.set_option("nvf4_variant", 0)
+    for v in (0, 6, 7):
+        assert torch.equal(outs[v], outs[5]), v
+    rows = sorted({0, m // 2, m - 1})
+    a_s = np.ascontiguousarray(_np(a)[rows])
+    sa_s = np.ascontiguousarray(sa.numpy()[rows])
+    pad = np.zeros((128 - len(rows), k // 16), np.uint8)
+    ref = oracle.gemm_blockscaled(oracle.KIND_NVFP4, a_s, _np(b), oracle.to_blocked(np.concatenate([sa_s, pad])),
+                                  oracle.to_blocked(sb.numpy()), 0.25, len(rows), n, k)
+    assert np.array_equal(outs[0].numpy()[rows].view(np.uint16), ref.view(np.uint16))
+
+
 # ------------------------------------------------------------------------------------------------
 # MXFP8
 # ------------------------------------------------------------------------------------------------
