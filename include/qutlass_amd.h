@@ -13,8 +13,8 @@
  *     QAMD_ERR_HIP = the HIP runtime refused the launch.  qutlass_amd_last_error() returns a
  *     thread-local message for the last non-zero return.
  *   - no global state besides the tuning options below; re-entrant; the library never allocates
- *     (the reference cudaMalloc's a CUTLASS workspace per call, gemm.cu:160-162); the one op that
- *     needs scratch (mxf8 NN) takes it from the caller.
+ *     (the reference cudaMalloc's a CUTLASS workspace per call, gemm.cu:160-162); ops that use
+ *     scratch (mxf8 NN pre-pass, split-K of the *_ws GEMMs) take it from the caller.
  */
 #ifndef QUTLASS_AMD_H_
 #define QUTLASS_AMD_H_
@@ -72,6 +72,24 @@ int qutlass_amd_matmul_nvf4_bf16_tn(const void* A, const void* B, const void* A_
 int qutlass_amd_matmul_mxf8_bf16_tn(const void* A, const void* B, const void* A_sf, const void* B_sf,
                                     const float* alpha, void* D, int64_t M, int64_t N, int64_t K,
                                     void* stream);
+
+/*
+ * The same two GEMMs with caller-owned scratch, which unlocks split-K for small outputs with a long K (fewer than 256
+ * tiles of 64x64 and K >= 16 stages of 128 bytes: e.g. M = 64, N = 4096, K = 14336 runs 64 workgroups without it).
+ * Each K split writes its fp32 partial to workspace[z][M][N]; a second kernel sums the splits in fixed order, applies
+ * alpha and rounds to bf16 (deterministic; identical to the single-pass result whenever the fp32 partial sums are
+ * exact, which is the regime the reference's equality tests run in).  qutlass_amd_gemm_splitk_workspace_bytes(ebits = 4
+ * or 8, M, N, K) returns the bytes the split needs, 0 when the shape does not split; a NULL or smaller workspace
+ * silently runs the single-pass kernel.  The workspace is used on `stream` for the duration of the call's kernels.
+ * (The reference allocates and frees a CUTLASS workspace inside every call, gemm.cu:160-162.)
+ */
+int64_t qutlass_amd_gemm_splitk_workspace_bytes(int ebits, int64_t M, int64_t N, int64_t K);
+int qutlass_amd_matmul_mxf4_bf16_tn_ws(const void* A, const void* B, const void* A_sf, const void* B_sf,
+                                       const float* alpha, void* D, int64_t M, int64_t N, int64_t K,
+                                       void* workspace, int64_t workspace_bytes, void* stream);
+int qutlass_amd_matmul_mxf8_bf16_tn_ws(const void* A, const void* B, const void* A_sf, const void* B_sf,
+                                       const float* alpha, void* D, int64_t M, int64_t N, int64_t K,
+                                       void* workspace, int64_t workspace_bytes, void* stream);
 
 /*
  * MXFP8 NN: A is stored (K, M) row-major (the reference's ColumnMajor A), B (N, K); A_sf is still the

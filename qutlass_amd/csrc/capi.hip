@@ -48,7 +48,8 @@ template <class C, int PP>
 int launch_gemm(GemmParams p, hipStream_t s) {
   p.tiles_m = (int)cdiv(p.M, C::BM);
   p.tiles_n = (int)cdiv(p.N, C::BN);
-  hipLaunchKernelGGL((gemm_mx_kernel<C, PP>), dim3(p.tiles_m * p.tiles_n), dim3(C::THREADS), 0, s, p);
+  if (PP != 7) { p.ws = nullptr; p.splits = 1; }   // only the ring schedule knows about split-K
+  hipLaunchKernelGGL((gemm_mx_kernel<C, PP>), dim3(p.tiles_m * p.tiles_n, p.splits), dim3(C::THREADS), 0, s, p);
   return check_launch("gemm_mx_kernel");
 }
 
@@ -75,6 +76,12 @@ int dispatch_variant(int v, const GemmParams& p, hipStream_t s, const char* name
     case 27: return launch_gemm<GemmCfg<128, 64, 2, 2, EBITS, SPLIT>, 3>(p, s);    // mid-size problems: more, smaller tiles
     case 28: return launch_gemm<GemmCfg<64, 128, 2, 2, EBITS, SPLIT>, 3>(p, s);
     case 29: return launch_gemm<GemmCfg<64, 64, 2, 2, EBITS, SPLIT>, 3>(p, s);
+    case 70: return launch_gemm<GemmCfg<64, 64, 2, 2, EBITS, SPLIT, 0, 3>, 7>(p, s);     // ring schedule: NSTAGE-deep LDS ring, NSTAGE-1 stages in flight
+    case 71: return launch_gemm<GemmCfg<128, 64, 2, 2, EBITS, SPLIT, 0, 3>, 7>(p, s);
+    case 72: return launch_gemm<GemmCfg<64, 128, 2, 2, EBITS, SPLIT, 0, 3>, 7>(p, s);
+    case 73: return launch_gemm<GemmCfg<128, 128, 2, 2, EBITS, SPLIT, 0, 3>, 7>(p, s);
+    case 74: return launch_gemm<GemmCfg<64, 64, 2, 2, EBITS, SPLIT, 0, 4>, 7>(p, s);
+    case 75: return launch_gemm<GemmCfg<64, 64, 2, 2, EBITS, SPLIT, 0, 6>, 7>(p, s);
   }
   if constexpr (EBITS == 8) {
     if (v == 30) return launch_gemm<GemmCfg<256, 256, 2, 2, 8, true>, 4>(p, s);   // fp8 deep schedule
@@ -122,9 +129,32 @@ int dispatch_variant(int v, const GemmParams& p, hipStream_t s, const char* name
 }
 
 // EBITS: 4 = MXFP4, 8 = MXFP8 (TN)
+// Small-output regime: ring schedule (one workgroup per CU with several stages in flight beats the 2-stage simple schedule
+// whenever the tiles do not fill the chip twice), plus split-K over grid.y when 64x64 tiles leave CUs idle and K is long
+// enough to pay for the second pass.  One function so that the launcher and qutlass_amd_gemm_splitk_workspace_bytes
+// agree.  Measured: profiles/native_r1_ring.log.
+struct SmallPlan { int variant; int splits; };   // variant 0: not this regime
+template <int EBITS>
+SmallPlan plan_small(int64_t M, int64_t N, int64_t K) {
+  const int64_t T64 = cdiv(M, 64) * cdiv(N, 64), T128 = cdiv(M, 128) * cdiv(N, 128);
+  if (T64 <= 256) {
+    const int64_t KT = cdiv(K * EBITS / 8, 128);
+    int64_t S = 1;
+    if (T64 < 256 && KT >= 48) {                                       // shorter K: the reduce pass costs more than it saves
+      S = std::min<int64_t>(std::min<int64_t>(8, 512 / T64), KT / 8);   // up to 2 workgroups per CU, >= 8 stages per split
+      const int64_t per = cdiv(KT, S);
+      S = cdiv(KT, per);                                                // every split non-empty
+    }
+    return {70, (int)S};
+  }
+  if (T64 <= 512) return {N >= M ? 72 : 71, 1};
+  if (M > 64 && N > 64 && T128 <= 256) return {73, 1};
+  return {0, 1};
+}
+
 template <int EBITS>
 int gemm_mx(const char* name, const void* A, const void* B, const void* A_sf, const void* B_sf,
-            const float* alpha, void* D, int64_t M, int64_t N, int64_t K, void* stream) {
+            const float* alpha, void* D, int64_t M, int64_t N, int64_t K, void* stream, void* ws = nullptr, int64_t ws_bytes = 0) {
   if (!A || !B || !A_sf || !B_sf || !alpha || !D) return fail(QAMD_ERR_INVALID, "%s: null pointer argument", name);
   if (M <= 0 || N <= 0) return fail(QAMD_ERR_INVALID, "%s: M and N must be positive (got M=%lld N=%lld)", name, (long long)M, (long long)N);
   const int kalign = (EBITS == 4) ? 128 : 32;
@@ -144,14 +174,32 @@ int gemm_mx(const char* name, const void* A, const void* B, const void* A_sf, co
   p.pp_shift = g_pp_shift.load();
   p.pp_flags = g_pp_flags.load();
   p.dbg = g_dbg.load();
+  p.ws = nullptr; p.splits = 1;
   hipStream_t s = (hipStream_t)stream;
   int variant = g_gemm_variant.load();
   if (variant == 61 || variant == 62) variant = 0;   // these select the NN operand path only (matmul_mxf8_bf16_nn)
-  // small batch: weight-bandwidth bound.  While the weight has fewer than 256 64-row tiles (N < 16384) the split-K kernel
-  // without LDS staging wins (gemm_mx_skinny.hip.h: N = K = 4096, M = 16: 5.5 us vs 7.9 us); with more tiles than CUs the
-  // 64x64-tile kernel streams the weight at 6.3 TB/s through full-line LDS-DMA and wins (N = 57344, K = 8192: 36 us vs
-  // 58-74 us; profiles/native_r1_skinny_shapes.log)
-  if (EBITS == 4 && (variant == 60 || (variant >= 44 && variant <= 49) || (variant == 0 && M <= 32 && cdiv(N, 64) < 256))) {
+  // ring schedule + optional split-K (needs caller scratch; "pp_flags" bit 7 turns split-K off, bit 8 the ring rule)
+  const SmallPlan pl = plan_small<EBITS>(M, N, K);
+  auto ring_launch = [&](int v, int splits) -> int {
+    const int64_t need = (int64_t)splits * M * N * 4;
+    if (splits > 1 && ws && ws_bytes >= need && !(p.pp_flags & 128)) {
+      p.ws = (float*)ws; p.splits = splits;
+      if (int rc = dispatch_variant<EBITS, EBITS == 8>(v, p, s, name)) return rc;
+      const int64_t quads = M * (N / 4);
+      const int grid = (int)std::min<int64_t>(cdiv(quads, 256), 2048);
+      hipLaunchKernelGGL(splitk_reduce_kernel, dim3(grid), dim3(256), 0, s, (const float*)ws, p.D, alpha, (int)M, (int)N, p.ldd, splits);
+      return check_launch("splitk_reduce_kernel");
+    }
+    return dispatch_variant<EBITS, EBITS == 8>(v, p, s, name);
+  };
+  const bool can_split = pl.variant == 70 && pl.splits > 1 && ws && ws_bytes >= (int64_t)pl.splits * M * N * 4 && !(p.pp_flags & 128);
+  if (variant == 77) return ring_launch(70, pl.variant == 70 ? pl.splits : 1);   // bench: 64x64 ring (+ split-K) whatever M
+  // small batch (M <= 32): weight-bandwidth bound.  With fewer than 128 64-row tiles (N < 8192) the split-K kernel without
+  // LDS staging wins (gemm_mx_skinny.hip.h: N = K = 4096, M = 16: 5.9 us vs 7.1 us for the ring kernel on 64 CUs); from
+  // 128 tiles on, the 64x64 ring kernel streams the weight through full-line LDS-DMA and wins (N = 14336, K = 4096: 6.9 us
+  // vs 9.7 us; N = 57344, K = 8192: 36 us vs 58-74 us), as does ring + split-K over caller scratch for a long K
+  // (N = 4096, K = 14336, M = 16: 11.6 us vs 14.8 us).  profiles/native_r1_skinny_shapes.log, native_r1_ring.log
+  if (EBITS == 4 && (variant == 60 || (variant >= 44 && variant <= 49) || (variant == 0 && M <= 32 && cdiv(N, 64) < 128 && !can_split))) {
     SkinnyParams q;
     q.A = p.A; q.B = p.B; q.SFA = p.SFA; q.SFB = p.SFB; q.alpha = alpha; q.D = p.D; q.M = p.M; q.N = p.N; q.K = p.K;
     q.a_bytes = p.a_bytes; q.b_bytes = p.b_bytes; q.sfa_bytes = p.sfa_bytes; q.sfb_bytes = p.sfb_bytes;
@@ -166,6 +214,7 @@ int gemm_mx(const char* name, const void* A, const void* B, const void* A_sf, co
     }
     return check_launch("gemm_mx_skinny_kernel");
   }
+  if (variant == 0 && !(p.pp_flags & 256) && pl.variant) return ring_launch(pl.variant, pl.splits);
   if (variant == 0) {
     // auto (measured, profiles/native_r1_schedules.log, profiles/bench_sweep_*.txt): the largest tile that still gives
     // every CU work -- 256x256 ("deep" schedule, 4 waves of 128x128), then 128x128, 128x64 / 64x128, 64x64 (simple
@@ -254,6 +303,22 @@ extern "C" {
 int qutlass_amd_matmul_mxf4_bf16_tn(const void* A, const void* B, const void* A_sf, const void* B_sf,
                                     const float* alpha, void* D, int64_t M, int64_t N, int64_t K, void* stream) {
   return gemm_mx<4>("matmul_mxf4_bf16_tn", A, B, A_sf, B_sf, alpha, D, M, N, K, stream);
+}
+
+int64_t qutlass_amd_gemm_splitk_workspace_bytes(int ebits, int64_t M, int64_t N, int64_t K) {
+  if (M <= 0 || N <= 0 || K <= 0 || (ebits != 4 && ebits != 8)) return 0;
+  const SmallPlan pl = (ebits == 4) ? plan_small<4>(M, N, K) : plan_small<8>(M, N, K);
+  return (pl.variant == 70 && pl.splits > 1) ? (int64_t)pl.splits * M * N * 4 : 0;
+}
+
+int qutlass_amd_matmul_mxf4_bf16_tn_ws(const void* A, const void* B, const void* A_sf, const void* B_sf, const float* alpha, void* D,
+                                       int64_t M, int64_t N, int64_t K, void* workspace, int64_t workspace_bytes, void* stream) {
+  return gemm_mx<4>("matmul_mxf4_bf16_tn", A, B, A_sf, B_sf, alpha, D, M, N, K, stream, workspace, workspace_bytes);
+}
+
+int qutlass_amd_matmul_mxf8_bf16_tn_ws(const void* A, const void* B, const void* A_sf, const void* B_sf, const float* alpha, void* D,
+                                       int64_t M, int64_t N, int64_t K, void* workspace, int64_t workspace_bytes, void* stream) {
+  return gemm_mx<8>("matmul_mxf8_bf16_tn", A, B, A_sf, B_sf, alpha, D, M, N, K, stream, workspace, workspace_bytes);
 }
 
 int qutlass_amd_matmul_ada_mxf4_bf16_tn(const void* A, const void* B, const void* A_sf, const void* B_sf,

@@ -27,7 +27,9 @@
 //   * Schedules (all share the tiling / DMA / epilogue code in GemmCtx; DESIGN.md section 3.3-3.4 has the measurements):
 //       gemm_mx_deep / gemm_mx_deep8   4 waves of 128x128, self-pipelined, hand-off in mid-stage  -- DEFAULT for 256x256 tiles
 //                                      (gemm_mx_deep8<C, NN = true>: fused (K, M) operand path of matmul_mxf8_bf16_nn)
-//       gemm_mx_simple                 8 waves (or 4 for small tiles), R(j);M(j) per slice             -- DEFAULT for smaller tiles
+//       gemm_mx_simple                 8 waves (or 4 for small tiles), R(j);M(j) per slice             -- DEFAULT for mid-size tile counts
+//       gemm_mx_ring                   4 waves, 64x64 .. 128x128 tiles, 3-deep LDS ring, optional split-K  -- DEFAULT when the tiles fill the
+//                                      chip at most once or twice (capi.hip plan_small)
 //       gemm_mx_lockstep / _pingpong / _queue / _regstage   earlier or alternative schedules kept selectable ("gemm_variant")
 //                                      because their measurements are part of the design record; none is faster in the
 //                                      steady state -- the kernels run at the power cap.
@@ -59,13 +61,16 @@ struct GemmParams {
   int pp_shift;          // ping-pong: wave group = (wave >> pp_shift) & 1
   int pp_flags;          // bit0: s_setprio around MFMA blocks
   uint32_t* dbg;         // ABL_TRACE builds only: per-wave timestamp dump of workgroup 0
+  float* ws;             // split-K (ring schedule only): fp32 partial tiles, [splits][M][N]; NULL = no split
+  int splits;            // grid.y; split z covers K stages [z * ceil(KT / splits), ...)
 };
 
 // ablation bits (bench-only instantiations; 0 in the product path)
 enum { ABL_NO_DMA = 1, ABL_NO_MFMA = 2, ABL_NO_STORE = 4, ABL_NO_EPILOGUE = 8, ABL_TRACE = 16, ABL_NO_READS = 32, ABL_CLOCK = 64 };
 
-template <int BM_, int BN_, int WAVES_M_, int WAVES_N_, int EBITS_, bool F8SPLIT_ = false, int ABL_ = 0>
+template <int BM_, int BN_, int WAVES_M_, int WAVES_N_, int EBITS_, bool F8SPLIT_ = false, int ABL_ = 0, int NSTAGE_ = 2>
 struct GemmCfg {
+  static constexpr int NSTAGE = NSTAGE_;           // depth of the LDS stage ring (2 except for the ring schedule)
   static constexpr int BM = BM_, BN = BN_, WAVES_M = WAVES_M_, WAVES_N = WAVES_N_, EBITS = EBITS_;
   static constexpr bool F8SPLIT = F8SPLIT_;
   static constexpr int ABL = ABL_;
@@ -88,7 +93,7 @@ struct GemmCfg {
   static constexpr int STAGE_BYTES = OFF_S + S_BYTES;
   static constexpr int NA = BM / 8 / NWAVES, NB = BN / 8 / NWAVES;  // 1-KiB DMA pieces per wave
   static constexpr int SROW = BN * 2;   // epilogue staging row stride (8-byte granules XOR-swizzled by row)
-  static constexpr int LDS_MAIN = (2 * STAGE_BYTES > BM * SROW) ? 2 * STAGE_BYTES : BM * SROW;
+  static constexpr int LDS_MAIN = (NSTAGE * STAGE_BYTES > BM * SROW) ? NSTAGE * STAGE_BYTES : BM * SROW;
   static constexpr int TRACE_SLOTS = 96;
   static constexpr int LDS_BYTES = LDS_MAIN + ((ABL_ & 16) ? NWAVES * TRACE_SLOTS * 4 : 0);
   static_assert(BM % (8 * NWAVES) == 0 && BN % (8 * NWAVES) == 0, "DMA split");
@@ -390,6 +395,26 @@ struct GemmCtx {
             } else {
               *(v4i*)(p.D + (size_t)grow * p.ldd + gcol) = v;
             }
+          }
+        }
+    }
+  }
+
+  // ---- split-K partial: raw fp32 accumulators of this K range to ws[z][M][N] (alpha and the bf16 rounding happen in
+  //      splitk_reduce_kernel); a lane owns 4 consecutive columns per q -> 16-byte stores
+  __device__ __forceinline__ void epilogue_partial(int z) {
+    float* base = p.ws + (size_t)z * p.M * p.N;
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      const int grow = m0 + wave_m * C::WTM + 32 * m + i32;
+#pragma unroll
+      for (int n = 0; n < NT; ++n)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int gcol = n0 + wave_n * C::WTN + 32 * n + 8 * q + 4 * g;
+          if (grow < p.M && gcol < p.N) {
+            const v4f v = {acc[m][n][4 * q + 0], acc[m][n][4 * q + 1], acc[m][n][4 * q + 2], acc[m][n][4 * q + 3]};
+            *(v4f*)(base + (size_t)grow * p.N + gcol) = v;
           }
         }
     }
@@ -1274,8 +1299,115 @@ __device__ __forceinline__ void gemm_mx_regstage(char* smem, const GemmParams& p
   cx.epilogue();
 }
 
+// ================================================================================================
+// Ring schedule for SMALL tiles (64x64 .. 128x128): the simple schedule keeps one stage in flight, so a K stage costs a
+// full memory round trip (0.58 us measured, whatever the tile does: 64x64 tiles hold 4 MFMAs per wave per stage) and
+// a problem with few tiles and a long K is latency bound (M = 64..256, N = 4096, K = 14336: 33 us flat).  Here the LDS
+// ring is NSTAGE deep and NSTAGE-1 stages are in flight: at the top of stage kt a wave waits until its own pieces of
+// stage kt have landed (vmcnt = (NSTAGE-2) x loads per stage: DMA loads retire in order), the barrier makes every
+// wave's pieces visible and proves everyone is done with stage kt-1, whose slot then takes stage kt+NSTAGE-1.
+// Stages past K are issued with out-of-range offsets (zero fill), which keeps the vmcnt arithmetic uniform.
+// Same K order per output as every other schedule -> bit-identical results.
+// ================================================================================================
+template <class C>
+__device__ __forceinline__ void gemm_mx_ring(char* smem, const GemmParams& p) {
+  constexpr int KSL = C::KSL, D = C::NSTAGE;
+  constexpr int LPS = C::NA + C::NB + 1;            // DMA instructions per wave per stage
+  static_assert(D >= 3 && (D - 2) * LPS <= 63, "vmcnt immediate");
+  GemmCtx<C> cx(smem, p);
+  auto fence = [&]() __attribute__((always_inline)) { __builtin_amdgcn_sched_barrier(0); };
+  // K range of this workgroup (split-K: grid.y = splits, every split non-empty by construction on the host)
+  int kt0 = 0, kt1 = cx.KT;
+  if (p.splits > 1) {
+    const int per = (cx.KT + p.splits - 1) / p.splits;
+    kt0 = uniform((int)blockIdx.y * per);
+    kt1 = min(cx.KT, kt0 + per);
+  }
+  // With one wave per SIMD the stage cost is instruction issue, so everything that does not depend on the stage is
+  // hoisted: per-piece source offsets (normal / K-tail flavour), and the ring is unrolled D times so that LDS slot
+  // addresses are immediates.
+  int vA[C::NA], vAT[C::NA], vB[C::NB], vBT[C::NB];
+#pragma unroll
+  for (int t = 0; t < C::NA; ++t) {
+    const int q = cx.wave * C::NA + t;
+    vA[t] = cx.voffAB[q & 1] + q * cx.rstep;
+    vAT[t] = cx.voffT[q & 1] == 0x7fffffff ? 0x7fffffff : cx.voffT[q & 1] + q * cx.rstep;
+  }
+#pragma unroll
+  for (int t = 0; t < C::NB; ++t) {
+    const int q = cx.wave * C::NB + t;
+    vB[t] = cx.voffAB[q & 1] + q * cx.rstep;
+    vBT[t] = cx.voffT[q & 1] == 0x7fffffff ? 0x7fffffff : cx.voffT[q & 1] + q * cx.rstep;
+  }
+  // stages past the range re-load the last one into a free slot that is never read: keeps the vmcnt arithmetic uniform
+  // without any out-of-range bookkeeping
+  auto issue = [&](int kt, const int slot) __attribute__((always_inline)) {
+    char* st = smem + slot * C::STAGE_BYTES;
+    const int ktc = min(kt, kt1 - 1);
+    const int soff = ktc * C::ROWB;
+    int lastmask = (cx.ktail && ktc == cx.KT - 1) ? -1 : 0;
+    asm volatile("" : "+v"(lastmask));
+#pragma unroll
+    for (int t = 0; t < C::NA; ++t) {
+      const int v = (vAT[t] & lastmask) | (vA[t] & ~lastmask);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(cx.rA, (lds_ptr_t)(st + (cx.wave * C::NA + t) * 1024), 16, v, soff, 0, QAMD_DMA_AUX);
+    }
+#pragma unroll
+    for (int t = 0; t < C::NB; ++t) {
+      const int v = (vBT[t] & lastmask) | (vB[t] & ~lastmask);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(cx.rB, (lds_ptr_t)(st + C::OFF_B + (cx.wave * C::NB + t) * 1024), 16, v, soff, 0, QAMD_DMA_AUX);
+    }
+    const int vs = (ktc * C::SCT + cx.colS < cx.CB) ? cx.voffS : 0x7fffffff;   // K tail: no such scale column tile
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(cx.rS, (lds_ptr_t)(st + C::OFF_S + cx.wave * 1024), 16, vs, ktc * C::SCT * 512, 0, 0);
+  };
+  auto stage = [&](int kt, const int slot) __attribute__((always_inline)) {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 2) * LPS) : "memory");
+    __builtin_amdgcn_s_barrier();
+    fence();
+    issue(kt + D - 1, (slot + D - 1) % D);
+    fence();
+    // all fragments of the stage up front (<= 64 VGPRs): ONE LDS latency per stage instead of one per slice
+    cx.read_scales(slot);
+#pragma unroll
+    for (int j = 0; j < KSL; ++j) cx.read_frags(slot, j);
+    fence();
+#pragma unroll
+    for (int j = 0; j < KSL; ++j) cx.mfma_slice(j);
+    fence();
+  };
+#pragma unroll
+  for (int s = 0; s < D - 1; ++s) issue(kt0 + s, s);
+  for (int kt = kt0; kt < kt1; kt += D) {
+#pragma unroll
+    for (int u = 0; u < D; ++u)
+      if (u == 0 || kt + u < kt1) stage(kt + u, u);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the trailing re-loads must land before the epilogue reuses the LDS
+  if (p.splits > 1) cx.epilogue_partial(blockIdx.y);
+  else cx.epilogue();
+}
+
+// split-K second pass: D = bf16(alpha * sum_z ws[z]) in fixed z order (deterministic); 4 columns per thread
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, uint16_t* __restrict__ D, const float* __restrict__ alpha_p,
+                                                            int M, int N, int ldd, int splits) {
+  const int64_t quads = (int64_t)M * (N >> 2);
+  const float alpha = *alpha_p;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < quads; i += (int64_t)gridDim.x * 256) {
+    const int row = (int)(i / (N >> 2)), c4 = (int)(i % (N >> 2)) * 4;
+    v4f s = *(const v4f*)(ws + (size_t)row * N + c4);
+    for (int z = 1; z < splits; ++z) {
+      const v4f t = *(const v4f*)(ws + ((size_t)z * M + row) * N + c4);
+      s[0] += t[0]; s[1] += t[1]; s[2] += t[2]; s[3] += t[3];
+    }
+    v2i o;
+    o[0] = (int)pack_bf16x2(s[0] * alpha, s[1] * alpha);
+    o[1] = (int)pack_bf16x2(s[2] * alpha, s[3] * alpha);
+    *(v2i*)(D + (size_t)row * ldd + c4) = o;
+  }
+}
+
 // One __global__ entry per (config, schedule).
-enum { SCHED_LOCKSTEP = 0, SCHED_PINGPONG = 1, SCHED_QUEUE = 2, SCHED_SIMPLE = 3, SCHED_DEEP = 4, SCHED_REGSTAGE = 5, SCHED_DEEP_NN = 6 };
+enum { SCHED_LOCKSTEP = 0, SCHED_PINGPONG = 1, SCHED_QUEUE = 2, SCHED_SIMPLE = 3, SCHED_DEEP = 4, SCHED_REGSTAGE = 5, SCHED_DEEP_NN = 6, SCHED_RING = 7 };
 template <class C, int SCHED>
 __global__ __launch_bounds__(C::THREADS) void gemm_mx_kernel(const GemmParams p) {
   __shared__ __attribute__((aligned(16))) char smem[C::LDS_BYTES];
@@ -1283,7 +1415,8 @@ __global__ __launch_bounds__(C::THREADS) void gemm_mx_kernel(const GemmParams p)
   // 100 MHz wall-clock duration, i.e. the clock the chip actually ran at under this kernel's power draw
   const bool clk = (C::ABL & ABL_CLOCK) && p.dbg && blockIdx.x == 0 && threadIdx.x == 0;
   const uint64_t c0 = clk ? __builtin_readcyclecounter() : 0, r0 = clk ? __builtin_amdgcn_s_memrealtime() : 0;
-  if constexpr (SCHED == SCHED_REGSTAGE) gemm_mx_regstage<C>(smem, p);
+  if constexpr (SCHED == SCHED_RING) gemm_mx_ring<C>(smem, p);
+  else if constexpr (SCHED == SCHED_REGSTAGE) gemm_mx_regstage<C>(smem, p);
   else if constexpr (SCHED == SCHED_DEEP_NN) gemm_mx_deep8<C, true>(smem, p);
   else if constexpr (SCHED == SCHED_DEEP && C::EBITS == 8) gemm_mx_deep8<C, false>(smem, p);
   else if constexpr (SCHED == SCHED_DEEP) gemm_mx_deep<C>(smem, p);

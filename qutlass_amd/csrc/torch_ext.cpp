@@ -121,9 +121,16 @@ Tensor matmul(const Tensor& A, const Tensor& B, const Tensor& A_sf, const Tensor
   void* s = current_stream(A);
   int rc;
   if (G == Gemm::ADA_MXF4) rc = qutlass_amd_matmul_ada_mxf4_bf16_tn(A.data_ptr(), B.data_ptr(), A_sf.data_ptr(), B_sf.data_ptr(), al, out.data_ptr(), M, N, K, s);
-  else if (G == Gemm::MXF4) rc = qutlass_amd_matmul_mxf4_bf16_tn(A.data_ptr(), B.data_ptr(), A_sf.data_ptr(), B_sf.data_ptr(), al, out.data_ptr(), M, N, K, s);
+  else if (G == Gemm::MXF4 || G == Gemm::MXF8_TN) {
+    // small outputs with a long K split K over scratch from torch's stream-ordered caching allocator (the reference
+    // allocates its CUTLASS workspace per call as well, gemm.cu:160-162); 0 bytes = the shape does not split
+    const int64_t ws_bytes = qutlass_amd_gemm_splitk_workspace_bytes(fp8 ? 8 : 4, M, N, K);
+    Tensor ws = ws_bytes > 0 ? torch::stable::new_empty(A, {ws_bytes}, ScalarType::Byte) : Tensor();
+    void* wp = ws_bytes > 0 ? ws.data_ptr() : nullptr;
+    rc = fp8 ? qutlass_amd_matmul_mxf8_bf16_tn_ws(A.data_ptr(), B.data_ptr(), A_sf.data_ptr(), B_sf.data_ptr(), al, out.data_ptr(), M, N, K, wp, ws_bytes, s)
+             : qutlass_amd_matmul_mxf4_bf16_tn_ws(A.data_ptr(), B.data_ptr(), A_sf.data_ptr(), B_sf.data_ptr(), al, out.data_ptr(), M, N, K, wp, ws_bytes, s);
+  }
   else if (G == Gemm::NVF4) rc = qutlass_amd_matmul_nvf4_bf16_tn(A.data_ptr(), B.data_ptr(), A_sf.data_ptr(), B_sf.data_ptr(), al, out.data_ptr(), M, N, K, s);
-  else if (G == Gemm::MXF8_TN) rc = qutlass_amd_matmul_mxf8_bf16_tn(A.data_ptr(), B.data_ptr(), A_sf.data_ptr(), B_sf.data_ptr(), al, out.data_ptr(), M, N, K, s);
   else {
     // scratch for the (K, M) -> (M, K) re-layout: from torch's stream-ordered caching allocator
     const int64_t ws_bytes = qutlass_amd_mxf8_nn_workspace_bytes(M, K);

@@ -166,7 +166,17 @@ static GemmData make_gemm(int kind, int64_t M, int64_t N, int64_t K, float alpha
 
 typedef int (*gemm_fn)(const void*, const void*, const void*, const void*, const float*, void*, int64_t, int64_t,
                        int64_t, void*);
+// split-K scratch for the _ws entries (QAMD_NO_WS=1 in the environment: plain entries, no split-K)
+static void* g_ws = nullptr;
+static int64_t g_ws_bytes = 0;
+static int mxf4_ws(const void* A, const void* B, const void* SA, const void* SB, const float* al, void* D, int64_t M, int64_t N, int64_t K, void* st) {
+  return qutlass_amd_matmul_mxf4_bf16_tn_ws(A, B, SA, SB, al, D, M, N, K, g_ws, g_ws_bytes, st);
+}
+static int mxf8_ws(const void* A, const void* B, const void* SA, const void* SB, const float* al, void* D, int64_t M, int64_t N, int64_t K, void* st) {
+  return qutlass_amd_matmul_mxf8_bf16_tn_ws(A, B, SA, SB, al, D, M, N, K, g_ws, g_ws_bytes, st);
+}
 static gemm_fn gemm_entry(int kind) {
+  if (g_ws) return kind == 0 ? mxf4_ws : kind == 1 ? qutlass_amd_matmul_nvf4_bf16_tn : mxf8_ws;
   return kind == 0 ? qutlass_amd_matmul_mxf4_bf16_tn : kind == 1 ? qutlass_amd_matmul_nvf4_bf16_tn : qutlass_amd_matmul_mxf8_bf16_tn;
 }
 
@@ -492,6 +502,10 @@ int main(int argc, char** argv) {
          prop.multiProcessorCount, prop.clockRate / 1000, prop.memoryClockRate / 1000, prop.l2CacheSize >> 20,
          qutlass_amd_version());
 
+  if (!getenv("QAMD_NO_WS")) {
+    g_ws_bytes = 64ll << 20;
+    HIP_OK(hipMalloc(&g_ws, g_ws_bytes));
+  }
   if (argc > 1 && want("ubench")) run_ubench();
   if (argc > 1 && want("valu")) run_valu_rates();
   if (argc > 1 && want("usteady")) run_ubench_steady();
@@ -635,6 +649,38 @@ int main(int argc, char** argv) {
           bench_gemm(tag, 0, M, sh[0], sh[1], var, 50);
         }
       }
+  }
+  if (want("ring")) {   // ring schedule (70: 64x64 x6, 71: 128x64 x5, 72: 64x128 x5, 73: 128x128 x4, 74: 64x64 x3) vs the 2-stage simple schedule
+    for (int var : {70, 71, 72, 73, 74, 75, 77, 0}) {
+      for (int kind : {0, 2}) {
+        const bool tol = kind == 2;
+        check_gemm("ring config1", kind, 256, 256, 512, 1.0f, 3, 0, var, tol);
+        check_gemm("ring tiny-K (1 stage)", kind, 128, 128, 128, 1.0f, 3, 0, var, tol);
+        check_gemm("ring ragged + K tail", kind, 72, 136, 640, 0.5f, 4, 0, var, tol);
+        check_gemm("ring M=1", kind, 1, 504, 1024, 1.0f, 2, 0, var, tol);
+        check_gemm("ring 504x504x2048", kind, 504, 504, 2048, 1.0f, 3, 0, var, tol);
+        check_gemm("ring 200x264x7168", kind, 200, 264, 7168, 1.0f, 3, 0, var, tol);
+        check_gemm("ring 64x512x14336 (split-K when auto / 77)", kind, 64, 512, 14336, 0.5f, 3, 0, var, tol);
+        check_gemm("ring 40x1032x4224 (split-K, K tail)", kind, 40, 1032, kind == 2 ? 4256 : 4224, 1.0f, 3, 0, var, tol);
+      }
+    }
+    const int64_t shapes[][2] = {{4096, 4096}, {4096, 14336}, {14336, 4096}, {8192, 8192}};
+    for (auto& sh : shapes)
+      for (int64_t M : {16, 32, 64, 128, 256, 512, 1024, 2048}) {
+        for (int var : {0, 29, 27, 24, 70, 74, 75, 71, 72, 73, 77}) {
+          if (M <= 64 && (var == 27 || var == 24 || var == 71 || var == 73)) continue;
+          char tag[96];
+          snprintf(tag, sizeof tag, "mxfp4 M=%lld N=%lld K=%lld var=%d", (long long)M, (long long)sh[0], (long long)sh[1], var);
+          bench_gemm(tag, 0, M, sh[0], sh[1], var, 30);
+        }
+      }
+    for (int64_t M : {64, 256, 1024}) {
+      for (int var : {0, 29, 24, 70, 74, 73, 77}) {
+        char tag[96];
+        snprintf(tag, sizeof tag, "mxfp8 M=%lld N=4096 K=4096 var=%d", (long long)M, var);
+        bench_gemm(tag, 2, M, 4096, 4096, var, 30);
+      }
+    }
   }
   if (want("nvtile")) {   // NVFP4 tile configs (5: 128x128, 6: 128x64, 7: 64x64, 3: split-K, 0: auto) over mid-batch shapes
     for (int nv : {5, 6, 7}) {

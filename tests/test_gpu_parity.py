@@ -174,7 +174,7 @@ def _gemm_golden(q, g, c, fn, sf_dtype, kind):
     return _np(out), g[f"out{c}"]
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 5, 6, 7, 20, 24, 27, 28, 29, 30, 40, 60])
+@pytest.mark.parametrize("variant", [0, 1, 2, 5, 6, 7, 20, 24, 27, 28, 29, 30, 40, 60, 70, 71, 72, 73, 74, 75, 77])
 def test_matmul_mxf4_golden_bit_exact(q, golden_dir, variant):
     g = _load(golden_dir, "gemm_mxfp4.npz")
     q._lib.set_option("gemm_variant", variant)
@@ -233,12 +233,41 @@ def test_matmul_mxf4_full_size_properties(q):
     perm = torch.randperm(m, device=DEV)
     outp = q.matmul_mxf4_bf16_tn(a_q[perm].contiguous(), b_q, to_blocked(a_s[perm].contiguous()), bsf, torch.tensor([1.0], device=DEV))
     assert torch.equal(outp, out[perm])
-    for variant in (1, 5, 6, 3, 4, 8, 9, 20, 27, 28, 29, 30, 40):
+    for variant in (1, 5, 6, 3, 4, 8, 9, 20, 27, 28, 29, 30, 40, 70, 73):
         q._lib.set_option("gemm_variant", variant)
         try:
             assert torch.equal(q.matmul_mxf4_bf16_tn(a_q, b_q, asf, bsf, torch.tensor([1.0], device=DEV)), out), variant
         finally:
             q._lib.set_option("gemm_variant", 0)
+
+
+@pytest.mark.parametrize("m,n,k", [(64, 4096, 14336), (16, 512, 8192), (200, 264, 7168), (128, 4096, 6144), (40, 1032, 14464)])
+def test_split_k_small_output_long_k(q, m, n, k):
+    """Small outputs with a long K run the ring kernel with K split over grid.y and a second pass that sums the fp32
+    partials (qutlass_amd_matmul_mxf4_bf16_tn_ws; the torch op takes the scratch from the caching allocator).  On
+    quantised test data every partial sum is exact, so the result must equal the single-pass kernel (split-K off,
+    "pp_flags" bit 7), the 2-stage simple schedule, and the CPU oracle, bit for bit."""
+    from qutlass_amd.utils import to_blocked
+
+    a_q, a_s, b_q, b_s, out = _pipeline(q, m, n, k, "abs_max", seed=m + k)
+    expect_split = q._lib.load().qutlass_amd_gemm_splitk_workspace_bytes(4, m, n, k)
+    assert (expect_split > 0) == (k >= 48 * 256 and -(-m // 64) * -(-n // 64) < 256)
+    asf, bsf, al = to_blocked(a_s), to_blocked(b_s), torch.tensor([1.0], device=DEV)
+    old = q._lib.set_option("pp_flags", 1 | 128)
+    try:
+        single = q.matmul_mxf4_bf16_tn(a_q, b_q, asf, bsf, al)
+    finally:
+        q._lib.set_option("pp_flags", old)
+    q._lib.set_option("gemm_variant", 29)
+    try:
+        simple = q.matmul_mxf4_bf16_tn(a_q, b_q, asf, bsf, al)
+    finally:
+        q._lib.set_option("gemm_variant", 0)
+    assert torch.equal(out, single) and torch.equal(out, simple)
+    rows = sorted({0, m // 3, m - 1})
+    sfa = oracle.to_blocked(np.ascontiguousarray(np.concatenate([_np(a_s)[rows], np.zeros((128 - len(rows), k // 32), np.uint8)])))
+    ref = oracle.gemm_blockscaled(oracle.KIND_MXFP4, np.ascontiguousarray(_np(a_q)[rows]), _np(b_q), sfa, oracle.to_blocked(_np(b_s)), 1.0, len(rows), n, k)
+    assert np.array_equal(_np(out)[rows], ref)
 
 
 def test_matmul_mxf4_errors(q):
@@ -339,7 +368,7 @@ def _mxfp8_close(got_bits, want_bits):
     return np.abs(got - want) <= tol
 
 
-@pytest.mark.parametrize("variant", [0, 20, 30])   # auto, 8-wave simple, 4-wave deep
+@pytest.mark.parametrize("variant", [0, 20, 30, 70, 73])   # auto, 8-wave simple, 4-wave deep, ring 64x64 / 128x128
 def test_matmul_mxf8_large_tiles_vs_oracle(q, variant):
     from qutlass_amd.utils import to_blocked
 
