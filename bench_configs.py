@@ -148,11 +148,25 @@ def main():
         xa_sf = to_blocked(xa_s)
         wq, wsf = w_q[:nn], to_blocked(w_s.view(torch.uint8).reshape(-1)[: nn * 128].reshape(nn, 128).view(torch.float8_e8m0fnu))
         wbytes = nn * 4096 // 2 + nn * 128 + mm * 4096 // 2 + 2 * mm * nn
-        for var, tag in ((0, "auto = skinny split-K"), (2, "128x128 lockstep"), (24, "128x128 simple")):
+        for var, tag in ((0, "auto: LDS-free split-K (N < 8192) / 64x64 ring"), (2, "128x128 lockstep"), (24, "128x128 simple")):
             q._lib.set_option("gemm_variant", var)
             us = time_us(lambda: q.matmul_mxf4_bf16_tn(xa_q, wq, xa_sf, wsf, alpha), args.iters)
             q._lib.set_option("gemm_variant", 0)
             line(f"matmul_mxf4_bf16_tn {mm}x{nn}x4096 [{tag}]", us, bytes_=wbytes)
+    # ---- mid batch against a long-K layer (Llama-3-8B down-proj 4096 x 14336): ring schedule (+ split-K) vs the 2-stage tiles
+    w2 = torch.randn(4096, 14336, dtype=torch.bfloat16, device=dev) * 25.0
+    w2_q, w2_s = q.fusedQuantizeMx(w2, h32, method="abs_max")
+    w2_sf = to_blocked(w2_s)
+    for mm in (16, 64, 256, 512):
+        xa = torch.randn(mm, 14336, dtype=torch.bfloat16, device=dev) * 25.0
+        xa_q, xa_s = q.fusedQuantizeMx(xa, h32, method="abs_max")
+        xa_sf = to_blocked(xa_s)
+        wbytes = 4096 * 14336 // 2 + 4096 * 448 + mm * 14336 // 2 + 2 * mm * 4096
+        for var, tag in ((0, "auto: ring, split-K when < 256 tiles"), (29, "64x64 simple (2-stage)")):
+            q._lib.set_option("gemm_variant", var)
+            us = time_us(lambda: q.matmul_mxf4_bf16_tn(xa_q, w2_q, xa_sf, w2_sf, alpha), args.iters)
+            q._lib.set_option("gemm_variant", 0)
+            line(f"matmul_mxf4_bf16_tn {mm}x4096x14336 [{tag}]", us, bytes_=wbytes)
     for r in (64, 128):
         hr = hadamard(r, dev)
         line(f"fusedQuantizeMx(H{r}, abs_max) 4096x4096", time_us(lambda: q.fusedQuantizeMx(x, hr, method="abs_max"), args.iters), bytes_=qb)

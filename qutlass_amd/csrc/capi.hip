@@ -187,7 +187,12 @@ int gemm_mx(const char* name, const void* A, const void* B, const void* A_sf, co
       if (int rc = dispatch_variant<EBITS, EBITS == 8>(v, p, s, name)) return rc;
       const int64_t quads = M * (N / 4);
       const int grid = (int)std::min<int64_t>(cdiv(quads, 256), 2048);
-      hipLaunchKernelGGL(splitk_reduce_kernel, dim3(grid), dim3(256), 0, s, (const float*)ws, p.D, alpha, (int)M, (int)N, p.ldd, splits);
+      switch (splits) {
+#define QAMD_RED(S_) case S_: hipLaunchKernelGGL(splitk_reduce_kernel<S_>, dim3(grid), dim3(256), 0, s, (const float*)ws, p.D, alpha, (int)M, (int)N, p.ldd); break;
+        QAMD_RED(2) QAMD_RED(3) QAMD_RED(4) QAMD_RED(5) QAMD_RED(6) QAMD_RED(7) QAMD_RED(8)
+#undef QAMD_RED
+        default: return fail(QAMD_ERR_INVALID, "%s: unsupported split count %d", name, splits);
+      }
       return check_launch("splitk_reduce_kernel");
     }
     return dispatch_variant<EBITS, EBITS == 8>(v, p, s, name);

@@ -583,15 +583,16 @@ def test_small_batch_paths_agree_with_tiled_kernel_and_oracle(q, m, n, k):
 
 
 
-def test_ops_are_hip_graph_capturable(q):
+@pytest.mark.parametrize("m,n,k", [(512, 768, 1024), (48, 512, 14336)])   # second shape: split-K with scratch from the caching allocator
+def test_ops_are_hip_graph_capturable(q, m, n, k):
     """The reference's benchmarks time the ops under CUDA graphs (benchmarks/bench_mxfp4_sm100.py:216); the whole
     quantize -> swizzle -> GEMM chain (incl. the allocations inside the ops) must capture and replay."""
     from qutlass_amd.utils import to_blocked
 
     torch.manual_seed(31)
     h = _hadamard(32)
-    a = torch.randn(512, 1024, dtype=torch.bfloat16, device=DEV) * 25.0
-    b = torch.randn(768, 1024, dtype=torch.bfloat16, device=DEV) * 25.0
+    a = torch.randn(m, k, dtype=torch.bfloat16, device=DEV) * 25.0
+    b = torch.randn(n, k, dtype=torch.bfloat16, device=DEV) * 25.0
     alpha = torch.tensor([1.0], device=DEV)
     b_q, b_s = q.fusedQuantizeMx(b, h, method="abs_max")
     b_sf = to_blocked(b_s)
