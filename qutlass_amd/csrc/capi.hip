@@ -82,6 +82,12 @@ int dispatch_variant(int v, const GemmParams& p, hipStream_t s, const char* name
     case 73: return launch_gemm<GemmCfg<128, 128, 2, 2, EBITS, SPLIT, 0, 3>, 7>(p, s);
     case 74: return launch_gemm<GemmCfg<64, 64, 2, 2, EBITS, SPLIT, 0, 4>, 7>(p, s);
     case 75: return launch_gemm<GemmCfg<64, 64, 2, 2, EBITS, SPLIT, 0, 6>, 7>(p, s);
+    case 80: return launch_gemm<GemmCfg<64, 64, 2, 2, EBITS, SPLIT, 1, 3>, 7>(p, s);     //   ring ablations (bench only): no DMA
+    case 81: return launch_gemm<GemmCfg<64, 64, 2, 2, EBITS, SPLIT, 2, 3>, 7>(p, s);     //   no MFMA
+    case 82: return launch_gemm<GemmCfg<64, 64, 2, 2, EBITS, SPLIT, 32, 3>, 7>(p, s);    //   no fragment reads
+    case 83: return launch_gemm<GemmCfg<64, 64, 2, 2, EBITS, SPLIT, 34, 3>, 7>(p, s);    //   DMA + barriers only
+    case 84: return launch_gemm<GemmCfg<64, 64, 2, 2, EBITS, SPLIT, 35, 3>, 7>(p, s);    //   barriers only
+    case 78: return launch_gemm<GemmCfg<64, 64, 2, 2, EBITS, SPLIT, 16, 3>, 7>(p, s);    //   per-wave timeline of workgroup 0 (bench only)
   }
   if constexpr (EBITS == 8) {
     if (v == 30) return launch_gemm<GemmCfg<256, 256, 2, 2, 8, true>, 4>(p, s);   // fp8 deep schedule

@@ -1361,30 +1361,44 @@ __device__ __forceinline__ void gemm_mx_ring(char* smem, const GemmParams& p) {
     __builtin_amdgcn_raw_ptr_buffer_load_lds(cx.rS, (lds_ptr_t)(st + C::OFF_S + cx.wave * 1024), 16, vs, ktc * C::SCT * 512, 0, 0);
   };
   auto stage = [&](int kt, const int slot) __attribute__((always_inline)) {
+    cx.trace();   // (ABL_TRACE builds only) 0: stage begin
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 2) * LPS) : "memory");
+    cx.trace();   // 1: own pieces landed
     __builtin_amdgcn_s_barrier();
     fence();
-    issue(kt + D - 1, (slot + D - 1) % D);
-    fence();
-    // all fragments of the stage up front (<= 64 VGPRs): ONE LDS latency per stage instead of one per slice
-    cx.read_scales(slot);
+    cx.trace();   // 2: barrier passed
+    // all fragments of the stage up front (<= 64 VGPRs): ONE LDS latency per stage instead of one per slice -- and the
+    // reads go first, so the ~230 cycles of DMA issue below run while the LDS serves them (rtrace: reads 450 cycles)
+    if (!(C::ABL & ABL_NO_READS)) {
+      cx.read_scales(slot);
 #pragma unroll
-    for (int j = 0; j < KSL; ++j) cx.read_frags(slot, j);
+      for (int j = 0; j < KSL; ++j) cx.read_frags(slot, j);
+    }
     fence();
+    cx.trace();   // 3: reads issued
+    if (!(C::ABL & ABL_NO_DMA)) issue(kt + D - 1, (slot + D - 1) % D);
+    fence();
+    if (C::ABL & ABL_TRACE) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    cx.trace();   // 4: DMA issued, fragments in registers
 #pragma unroll
     for (int j = 0; j < KSL; ++j) cx.mfma_slice(j);
     fence();
+    cx.trace();   // 5: MFMAs issued
   };
 #pragma unroll
-  for (int s = 0; s < D - 1; ++s) issue(kt0 + s, s);
+  for (int s = 0; s < D - 1; ++s)
+    if (!(C::ABL & ABL_NO_DMA)) issue(kt0 + s, s);
   for (int kt = kt0; kt < kt1; kt += D) {
 #pragma unroll
     for (int u = 0; u < D; ++u)
       if (u == 0 || kt + u < kt1) stage(kt + u, u);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the trailing re-loads must land before the epilogue reuses the LDS
+  cx.trace();
   if (p.splits > 1) cx.epilogue_partial(blockIdx.y);
   else cx.epilogue();
+  cx.trace();
+  cx.trace_dump();
 }
 
 // split-K second pass: D = bf16(alpha * sum_z ws[z]) in fixed z order (deterministic); 4 columns per thread.  S is a

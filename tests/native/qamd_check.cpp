@@ -667,7 +667,7 @@ int main(int argc, char** argv) {
     const int64_t shapes[][2] = {{4096, 4096}, {4096, 14336}, {14336, 4096}, {8192, 8192}};
     for (auto& sh : shapes)
       for (int64_t M : {16, 32, 64, 128, 256, 512, 1024, 2048}) {
-        for (int var : {0, 29, 27, 24, 70, 74, 75, 71, 72, 73, 77}) {
+        for (int var : {0, 29, 27, 24, 70, 74, 71, 72, 73, 77}) {
           if (M <= 64 && (var == 27 || var == 24 || var == 71 || var == 73)) continue;
           char tag[96];
           snprintf(tag, sizeof tag, "mxfp4 M=%lld N=%lld K=%lld var=%d", (long long)M, (long long)sh[0], (long long)sh[1], var);
@@ -675,7 +675,7 @@ int main(int argc, char** argv) {
         }
       }
     for (int64_t M : {64, 256, 1024}) {
-      for (int var : {0, 29, 24, 70, 74, 73, 77}) {
+      for (int var : {0, 29, 24, 70, 73, 77}) {
         char tag[96];
         snprintf(tag, sizeof tag, "mxfp8 M=%lld N=4096 K=4096 var=%d", (long long)M, var);
         bench_gemm(tag, 2, M, 4096, 4096, var, 30);
@@ -759,6 +759,35 @@ int main(int argc, char** argv) {
       for (int R : {16, 32, 64, 128})
         for (int method : {0, 1}) check_quant_nv(R, method, hw, 1 << 18, method ? 6.0f : 1.0f);
     check_quant_nv(16, 1, 0, 16 * 33, 1.0f);
+  }
+  if (want("rtrace")) {   // ring schedule timeline, workgroup 0: per stage [wait own DMA | barrier | issue DMA | fragment reads | MFMA issue]
+    for (int64_t M : {64, 256}) {
+      const int64_t N = 4096, K = 4096;
+      GemmData g = make_gemm(0, M, N, K, 1.0f, 77, 3);
+      DBuf<uint8_t> dA(g.A.size()), dB(g.B.size()), dSA(g.sfa.size()), dSB(g.sfb.size());
+      DBuf<float> dAl(1);
+      DBuf<uint16_t> dD((size_t)M * N);
+      DBuf<uint32_t> dT(8 * 96);
+      dA.up(g.A); dB.up(g.B); dSA.up(g.sfa); dSB.up(g.sfb); dAl.up({1.0f});
+      HIP_OK(hipMemset(dT.p, 0, 8 * 96 * 4));
+      qutlass_amd_debug_set_trace_buffer(dT.p);
+      qutlass_amd_set_option("gemm_variant", 78);
+      for (int i = 0; i < 3; ++i) Q_OK(qutlass_amd_matmul_mxf4_bf16_tn(dA.p, dB.p, dSA.p, dSB.p, dAl.p, dD.p, M, N, K, nullptr));
+      HIP_OK(hipDeviceSynchronize());
+      qutlass_amd_set_option("gemm_variant", 0);
+      qutlass_amd_debug_set_trace_buffer(nullptr);
+      auto t = dT.down();
+      printf("RTRACE M=%lld: cycles (s_memtime, 100 MHz x?) per wave; stages 2..13: [wait|barrier|issue|reads|mfma|loop]\n", (long long)M);
+      for (int w = 0; w < 4; ++w) {
+        const uint32_t* r = &t[w * 96];
+        printf("RTRACE w%d 16 stages=%u cycles :", w, r[95] - r[0]);
+        for (int st = 2; st < 14; ++st) {
+          printf(" |");
+          for (int k = 0; k < 6; ++k) printf(" %u", r[st * 6 + k + 1] - r[st * 6 + k]);
+        }
+        printf("\n");
+      }
+    }
   }
   if (want("dtrace")) {
     trace_gemm(35, 1);
