@@ -83,6 +83,20 @@ __global__ __launch_bounds__(THREADS) void ub_kernel(const char* g, uint32_t gby
   for (int it = 0; it < iters; it += 2) {
     const int off0 = (it >> 1) & 3, off1 = (off0 + 1) & 3;   // k-slice index j (runtime, like the stage loop)
     if (MODE == 0) { mfma8(0); fence(); mfma8(1); fence(); }
+    if (MODE >= 20 && MODE <= 23) {   // accumulator-stationary orders: CH back-to-back MFMAs into the SAME accumulator (8 / 4 / 2), 23 = operand-stationary A
+      constexpr int CH = MODE == 20 ? 8 : MODE == 21 ? 4 : 2;
+#pragma unroll
+      for (int set = 0; set < 2; ++set)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const int a_i = (MODE == 23) ? (i >> 1) : (i & 3), b_i = (MODE == 23) ? (i & 1) : ((i >> 2) & 1);
+          const int acc_i = (MODE == 23) ? i : (i / CH) * CH % 8;
+          const v4i a = fa[set][a_i], b = fb[set][b_i];
+          acc[acc_i] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(v8i{b[0], b[1], b[2], b[3], 0, 0, 0, 0}, v8i{a[0], a[1], a[2], a[3], 0, 0, 0, 0},
+                                                                        acc[acc_i], 4, 4, 0, scale, 0, scale);
+        }
+      fence();
+    }
     if (MODE == 1) { reads(0, off0); keep(0); fence(); reads(1, off1); keep(1); fence(); }
     if (MODE == 2 || MODE == 4) {
       mfma8(0); fence(); reads(1, off0); keep(0); fence();
@@ -356,6 +370,12 @@ void run_ubench_steady() {   // MFMA-only ceilings in the steady state (after ~1
     g_random_fill = rf;
     run_one<0, 256>("MFMA x8 only (steady)", g, gbytes, out, cyc, 256);
     run_one<0, 512>("MFMA x8 only (steady)", g, gbytes, out, cyc, 256);
+    run_one<20, 256>("MFMA x8, ONE accumulator (chain 8)", g, gbytes, out, cyc, 256);
+    run_one<20, 512>("MFMA x8, ONE accumulator (chain 8)", g, gbytes, out, cyc, 256);
+    run_one<21, 256>("MFMA x8, chains of 4 on one accumulator", g, gbytes, out, cyc, 256);
+    run_one<21, 512>("MFMA x8, chains of 4 on one accumulator", g, gbytes, out, cyc, 256);
+    run_one<22, 256>("MFMA x8, chains of 2 on one accumulator", g, gbytes, out, cyc, 256);
+    run_one<22, 512>("MFMA x8, chains of 2 on one accumulator", g, gbytes, out, cyc, 256);
     run_one<2, 512>("MFMA(cur) ; reads->other set (steady)", g, gbytes, out, cyc, 256);
     run_one<4, 512>("MFMA ; reads->other ; LDS-DMA x2 (steady)", g, gbytes, out, cyc, 256);
   }
