@@ -186,7 +186,11 @@ const char* qutlass_amd_version(void);
  *   "hw_fp4_cvt"   (1) use v_cvt_scalef32_pk_fp4_f32 for the final e2m1 rounding; 0 = software encoder
  *                  (both are bit-identical on gfx950)
  *   "gemm_variant" (0 = auto) force a tile configuration / schedule of the MX GEMMs (bench sweeps)
- *   "nvf4_variant" (0 = auto) 1 = per-wave dequant kernel, 2 = dequantise-once-into-LDS kernel
+ *   "nvf4_variant" (0 = auto) 1 = per-wave dequant kernel, 2 = dequantise-once-into-LDS kernel, 3 = small-batch split-K,
+ *                  5 / 6 / 7 = 128x128 / 128x64 / 64x64 tiles
+ *   "pp_flags"     (1) bit field of schedule experiments; bit 6 = no tail split, bit 7 = no split-K, bit 8 = no ring rule
+ *   "transpose_nc" (128) n columns per workgroup of mxfp4_transpose_mxfp8 (128 or 256)
+ *   "quant_wg_per_cu" (0 = auto) grid cap of the fused quantizers
  * Returns the previous value, or -1 for an unknown key.
  */
 int qutlass_amd_set_option(const char* key, int value);

@@ -24,6 +24,7 @@ thread_local char g_err[512] = "";
 std::atomic<int> g_hw_fp4_cvt{1};   // device-verified bit-identical to the software encoder (tests/native/probe.hip P2)
 std::atomic<int> g_gemm_variant{0};
 std::atomic<int> g_nvf4_variant{0};
+std::atomic<int> g_transpose_nc{128};   // mxfp4_transpose_mxfp8: n columns per workgroup (128 or 256)
 std::atomic<int> g_pp_shift{2};
 std::atomic<int> g_pp_flags{1};
 std::atomic<uint32_t*> g_dbg{nullptr};
@@ -511,7 +512,10 @@ int qutlass_amd_mxfp4_transpose_mxfp8(const void* x_fp4, const void* scales, int
   TrParams p;
   p.xq = (const uint8_t*)x_fp4; p.xs = (const uint8_t*)scales; p.y = (uint8_t*)y; p.out_sf = (uint8_t*)out_e8m0;
   p.m = (int)m; p.n = (int)n;
-  hipLaunchKernelGGL(mxfp4_transpose_mxfp8_kernel, dim3((unsigned)((m / 128) * (n / 256))), dim3(256), 0, (hipStream_t)stream, p);
+  if (g_transpose_nc.load() == 256)
+    hipLaunchKernelGGL(mxfp4_transpose_mxfp8_kernel<256>, dim3((unsigned)((m / 128) * (n / 256))), dim3(256), 0, (hipStream_t)stream, p);
+  else
+    hipLaunchKernelGGL(mxfp4_transpose_mxfp8_kernel<128>, dim3((unsigned)((m / 128) * (n / 128))), dim3(256), 0, (hipStream_t)stream, p);
   return check_launch("mxfp4_transpose_mxfp8_kernel");
 }
 
@@ -539,6 +543,7 @@ int qutlass_amd_set_option(const char* key, int value) {
   if (!strcmp(key, "hw_fp4_cvt")) return g_hw_fp4_cvt.exchange(value);
   if (!strcmp(key, "gemm_variant")) return g_gemm_variant.exchange(value);
   if (!strcmp(key, "nvf4_variant")) return g_nvf4_variant.exchange(value);
+  if (!strcmp(key, "transpose_nc")) return g_transpose_nc.exchange(value);
   if (!strcmp(key, "quant_wg_per_cu")) return g_quant_wg_per_cu.exchange(value);
   if (!strcmp(key, "pp_shift")) return g_pp_shift.exchange(value);
   if (!strcmp(key, "pp_flags")) return g_pp_flags.exchange(value);

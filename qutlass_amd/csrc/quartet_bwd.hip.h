@@ -252,18 +252,23 @@ struct TrParams {
   int m, n;            // m % 128 == 0, n % 256 == 0 (host-checked)
 };
 
+// NC = columns (n) per workgroup: 256, or 128 (half the LDS, 4 workgroups per CU: the kernel is one round of workgroups,
+// so its duration is ONE workgroup's load -> transpose -> store latency chain, and smaller tiles shorten it)
+template <int NC>
 __global__ __launch_bounds__(256) void mxfp4_transpose_mxfp8_kernel(const TrParams p) {
-  constexpr int LROW = 256 * 2 + 16;   // bf16 row of 256 columns + pad
+  constexpr int LROW = NC * 2 + 16;    // bf16 row of NC columns + pad
+  constexpr int LPR = NC / 32;         // lanes per input row (16 bytes = 32 codes = one input scale group each)
+  constexpr int RPP = 64 / LPR;        // rows per load pass
+  constexpr int CPL = NC / 64;         // columns per lane
   __shared__ __attribute__((aligned(16))) char ts_all[4][32 * LROW];
   const int tid = threadIdx.x, lane = tid & 63, wave = uniform(tid >> 6);
-  const int tiles_n = p.n >> 8;
+  const int tiles_n = p.n / NC;
   const int ti = blockIdx.x / tiles_n, tj = blockIdx.x % tiles_n;
-  const int r0 = ti * 128 + wave * 32, c0 = tj * 256;
+  const int r0 = ti * 128 + wave * 32, c0 = tj * NC;
   char* ts = ts_all[wave];
-  // lane -> row lane/8 (+8 per pass), 16-byte chunk lane%8 = 32 codes = one input scale group
 #pragma unroll
-  for (int ps = 0; ps < 4; ++ps) {
-    const int r = ps * 8 + (lane >> 3), c = (lane & 7) * 32;
+  for (int ps = 0; ps < 32 / RPP; ++ps) {
+    const int r = ps * RPP + lane / LPR, c = (lane % LPR) * 32;
     const int64_t rowi = r0 + r;
     const v4i v = *(const v4i*)(p.xq + rowi * (p.n >> 1) + ((c0 + c) >> 1));
     const float sc = e8m0_scale(p.xs[rowi * (p.n >> 5) + ((c0 + c) >> 5)]);
@@ -281,9 +286,11 @@ __global__ __launch_bounds__(256) void mxfp4_transpose_mxfp8_kernel(const TrPara
   }
   __builtin_amdgcn_s_waitcnt(0xc07f);
   __builtin_amdgcn_wave_barrier();
-  // columns lane, lane + 64, lane + 128, lane + 192 (consecutive lanes = consecutive 2-byte LDS addresses)
+  // columns lane, lane + 64, ... (consecutive lanes = consecutive 2-byte LDS addresses)
+  v4i oq[CPL][2];
+  uint8_t oe[CPL];
 #pragma unroll
-  for (int cc = 0; cc < 4; ++cc) {
+  for (int cc = 0; cc < CPL; ++cc) {
     const int col = cc * 64 + lane;
     uint32_t pr[16];   // pr[i] = bf16 of rows 2i (low half) and 2i+1 (high half)
     float amax = 0.f;
@@ -304,11 +311,36 @@ __global__ __launch_bounds__(256) void mxfp4_transpose_mxfp8_kernel(const TrPara
       w = __builtin_amdgcn_cvt_scalef32_pk_fp8_bf16(w, __builtin_bit_cast(bf16x2, pr[2 * q + 1]), qs, true);
       o[q >> 2][q & 3] = __builtin_bit_cast(int, w);
     }
-    uint8_t* dst = p.y + (int64_t)(c0 + col) * p.m + r0;
-    *(v4i*)dst = o[0];
-    *(v4i*)(dst + 16) = o[1];
-    p.out_sf[(int64_t)(c0 + col) * (p.m >> 5) + (r0 >> 5)] = (uint8_t)e;
+    oq[cc][0] = o[0];
+    oq[cc][1] = o[1];
+    oe[cc] = (uint8_t)e;
   }
+  // The lane's 32 output bytes per column are a quarter of a 128-byte output line (the other three quarters belong to
+  // the other waves) and its scale byte sits 128 bytes from its neighbour's: written straight from here that is 64
+  // partial lines per store instruction (14.2 us for 4096^2, 23 % of the HBM roofline).  Stage the workgroup's
+  // [NC n][128 m] fp8 tile and its [NC][4] scale bytes in LDS (the bf16 staging area is dead by now) and write whole
+  // lines / one dword of scales per output row.
+  __syncthreads();
+  constexpr int OROW = 128 + 16;                       // staged output row: 128 m bytes + pad
+  char* os = &ts_all[0][0];
+  uint8_t* es = (uint8_t*)os + NC * OROW;              // [NC][4]
+  static_assert(NC * OROW + NC * 4 <= 4 * 32 * LROW, "output staging fits the bf16 staging area");
+#pragma unroll
+  for (int cc = 0; cc < CPL; ++cc) {
+    const int col = cc * 64 + lane;
+    *(v4i*)(os + col * OROW + wave * 32) = oq[cc][0];
+    *(v4i*)(os + col * OROW + wave * 32 + 16) = oq[cc][1];
+    es[col * 4 + wave] = oe[cc];
+  }
+  __syncthreads();
+  const int m0 = ti * 128;
+#pragma unroll
+  for (int ps = 0; ps < NC / 32; ++ps) {               // NC * 8 16-byte pieces: row = piece / 8, chunk = piece % 8
+    const int piece = ps * 256 + tid, row = piece >> 3, ch = piece & 7;
+    const v4i v = *(const v4i*)(os + row * OROW + ch * 16);
+    *(v4i*)(p.y + (int64_t)(c0 + row) * p.m + m0 + ch * 16) = v;
+  }
+  if (tid < NC) *(uint32_t*)(p.out_sf + (int64_t)(c0 + tid) * (p.m >> 5) + (m0 >> 5)) = *(const uint32_t*)(es + tid * 4);
 }
 
 }  // namespace qamd
