@@ -36,18 +36,24 @@ struct BwdTParams {
   int ntiles;               // B * (N/32) * tiles_m (< 2^31, host-checked): one wave-tile = 32 n x 64 m of one batch entry
 };
 
-// One wave = one [32 n][64 m] tile = one scale group for 64 output rows.
+// One wave = one [32 n][64 m] tile = one scale group for 64 output rows; the 8 waves of a workgroup take 8 consecutive
+// scale groups (n0 .. n0 + 255) of the SAME 64 rows m, so the workgroup's output is one whole 128-byte line of e2m1 and
+// 8 scale bytes per row: staged through LDS and stored as full lines (written per wave it was 16 bytes of each of 32
+// lines per store instruction, and single scale bytes 128 bytes apart).
 template <bool QT, bool HWCVT>
-__global__ __launch_bounds__(256) void bwd_quant_t_kernel(const BwdTParams p) {
+__global__ __launch_bounds__(512) void bwd_quant_t_kernel(const BwdTParams p) {
   constexpr int LROW = 64 * 2 + 16;  // LDS row stride (bytes): 16-byte aligned rows (ds_write_b128); the two lane halves read rows
                                      // 8 apart = 288 dwords = bank offset 32, so their 64-byte column runs never collide
   constexpr int HROW = 32 * 2 + 16;
-  __shared__ __attribute__((aligned(16))) char tile_s[4][32 * LROW];
+  constexpr int OROW = 128 + 16;     // staged output row: 8 groups x 16 bytes + pad
+  __shared__ __attribute__((aligned(16))) char tile_s[8][32 * LROW];
   __shared__ __attribute__((aligned(16))) char hT[32 * HROW];
+  __shared__ __attribute__((aligned(16))) char out_s[64 * OROW];
+  __shared__ __attribute__((aligned(16))) uint8_t sf_s[64 * 8];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = uniform(tid >> 6);
   const int row = lane & 31, half = lane >> 5;
-  for (int idx = tid; idx < 32 * 32; idx += 256) {   // hT[j][k] = h[k][j]
+  for (int idx = tid; idx < 32 * 32; idx += 512) {   // hT[j][k] = h[k][j]
     const int k = idx >> 5, j = idx & 31;
     *(uint16_t*)(hT + j * HROW + k * 2) = p.h[k * 32 + j];
   }
@@ -59,20 +65,27 @@ __global__ __launch_bounds__(256) void bwd_quant_t_kernel(const BwdTParams p) {
   char* ts = tile_s[wave];
   const float alpha = QT ? *p.alpha : 1.0f;
   const int G = p.N >> 5;
-  const int wave_global = blockIdx.x * 4 + wave, nwaves = gridDim.x * 4;   // 32-bit tile arithmetic: 64-bit div/mod is ~100 SALU ops each
+  const int ngb = (G + 7) >> 3;                       // blocks of 8 scale groups
+  const int ntw = p.B * p.tiles_m * ngb;              // workgroup tiles (host-checked < 2^31)
+  // workgroup tile tw -> (b, tm, gb), gb fastest; 32-bit arithmetic: 64-bit div/mod is ~100 SALU ops each
+  auto decode = [&](int tw, int& b, int& m0, int& g0) __attribute__((always_inline)) {
+    const unsigned q1 = (unsigned)tw / (unsigned)ngb;
+    g0 = (int)((unsigned)tw - q1 * (unsigned)ngb) * 8;
+    b = (int)(q1 / (unsigned)p.tiles_m);
+    m0 = (int)(q1 - (unsigned)b * (unsigned)p.tiles_m) * 64;
+  };
 
   // global -> registers for one tile (software pipeline: the next tile's loads are in flight while this one is
   // rotated and quantised).  T: lane -> row lane/8 (+8 per pass), 16-byte chunk lane%8 (8 m): one pass = 8 rows x 128 B.
   // QT: lane -> row lane/2, 16-byte half (32 codes = one input scale group) + its e8m0 byte.
   v4i ld[QT ? 1 : 4];
   uint32_t ld_e = 0;
-  auto load_tile = [&](int t) __attribute__((always_inline)) {
-    const bool live = t < p.ntiles;
-    const unsigned tq = (unsigned)t / (unsigned)p.tiles_m;
-    const int tm = (int)((unsigned)t - tq * (unsigned)p.tiles_m);
-    const int b = (int)(tq / (unsigned)G);
-    const int g = (int)(tq - (unsigned)b * (unsigned)G);
-    const int m0 = tm * 64, n0 = g * 32;
+  auto load_tile = [&](int tw) __attribute__((always_inline)) {
+    int b, m0, g0;
+    decode(tw, b, m0, g0);
+    const int g = g0 + wave;
+    const bool live = tw < ntw && g < G;
+    const int n0 = g * 32;
     if (!QT) {
 #pragma unroll
       for (int ps = 0; ps < 4; ++ps) {
@@ -92,13 +105,10 @@ __global__ __launch_bounds__(256) void bwd_quant_t_kernel(const BwdTParams p) {
       }
     }
   };
-  load_tile(wave_global);
-  for (int t = wave_global; t < p.ntiles; t += nwaves) {
-    const unsigned tq = (unsigned)t / (unsigned)p.tiles_m;
-    const int tm = (int)((unsigned)t - tq * (unsigned)p.tiles_m);
-    const int b = (int)(tq / (unsigned)G);
-    const int g = (int)(tq - (unsigned)b * (unsigned)G);
-    const int m0 = tm * 64;
+  load_tile(blockIdx.x);
+  for (int tw = blockIdx.x; tw < ntw; tw += gridDim.x) {   // uniform over the workgroup: barriers inside are safe
+    int b, m0, g0;
+    decode(tw, b, m0, g0);
 
     // ---- stage the [32 n][64 m] bf16 tile in LDS ---------------------------------------------------------------
     if (!QT) {
@@ -122,7 +132,7 @@ __global__ __launch_bounds__(256) void bwd_quant_t_kernel(const BwdTParams p) {
         d[q] = o;
       }
     }
-    load_tile(t + nwaves);   // next tile's rows: in flight during the rotation / quantisation below
+    load_tile(tw + gridDim.x);   // next tile's rows: in flight during the rotation / quantisation below
     __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): the wave's own LDS writes landed (wave-private tile)
     __builtin_amdgcn_wave_barrier();
 
@@ -159,14 +169,27 @@ __global__ __launch_bounds__(256) void bwd_quant_t_kernel(const BwdTParams p) {
       v2i o;
       o[0] = (int)((X & 0xffffu) | (Y << 16));
       o[1] = (int)((X >> 16) | (Y & 0xffff0000u));
-      const int m = m0 + mloc;
-      if (m < p.M) {
+      *(v2i*)(out_s + mloc * OROW + wave * 16 + half * 8) = o;
+      if (half == 0) sf_s[mloc * 8 + wave] = (uint8_t)(sb >> 23);
+    }
+    __syncthreads();   // the workgroup's [64 m][8 groups] output tile is staged (and every wave is done with its bf16 tile)
+    {
+      const int r = tid >> 3, pc = tid & 7;            // 512 pieces of 16 bytes: row r, group g0 + pc
+      const int m = m0 + r, g = g0 + pc;
+      if (m < p.M && g < G) {
         const int64_t grp = ((int64_t)b * p.M + m) * G + g;
-        *(v2i*)(p.out + grp * 16 + half * 8) = o;
-        if (half == 0) p.out_sf[grp] = (uint8_t)(sb >> 23);
+        *(v4i*)(p.out + grp * 16) = *(const v4i*)(out_s + r * OROW + pc * 16);
+      }
+      if (tid < 64 && m0 + tid < p.M) {
+        uint8_t* dst = p.out_sf + ((int64_t)b * p.M + m0 + tid) * G + g0;
+        if ((G & 7) == 0) {
+          *(v2i*)dst = *(const v2i*)(sf_s + tid * 8);   // 8-byte aligned: G % 8 == 0 and g0 % 8 == 0
+        } else {
+          for (int k = 0; k < 8 && g0 + k < G; ++k) dst[k] = sf_s[tid * 8 + k];
+        }
       }
     }
-    __builtin_amdgcn_wave_barrier();   // all column reads of this tile issued before the next tile's stores
+    __syncthreads();   // staging area free for the next tile
   }
 }
 
