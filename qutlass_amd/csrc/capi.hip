@@ -528,9 +528,17 @@ int qutlass_amd_to_blocked(const void* in, int64_t rows, int64_t cols, void* out
   BlockedParams p;
   p.in = (const uint8_t*)in; p.out = (uint8_t*)out; p.rows = (int)rows; p.cols = (int)cols;
   p.RB = (int)cdiv(rows, 128); p.CB = (int)cdiv(cols, 4);
-  const int64_t grid = (int64_t)p.RB * cdiv(p.CB, 32);
+  // columns per workgroup: the widest slab that still gives every CU a workgroup
+  int tc = 128;
+  while (tc > 16 && (int64_t)p.RB * cdiv(p.CB, tc / 4) < 256) tc >>= 1;
+  const int64_t grid = (int64_t)p.RB * cdiv(p.CB, tc / 4);
   if (grid >= (1ll << 31)) return fail(QAMD_ERR_INVALID, "to_blocked: matrix too large");
-  hipLaunchKernelGGL(to_blocked_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, p);
+  switch (tc) {
+    case 128: hipLaunchKernelGGL(to_blocked_kernel<128>, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, p); break;
+    case 64: hipLaunchKernelGGL(to_blocked_kernel<64>, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, p); break;
+    case 32: hipLaunchKernelGGL(to_blocked_kernel<32>, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, p); break;
+    default: hipLaunchKernelGGL(to_blocked_kernel<16>, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, p); break;
+  }
   return check_launch("to_blocked_kernel");
 }
 

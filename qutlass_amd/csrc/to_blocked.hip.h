@@ -3,11 +3,12 @@
 // Replaces qutlass/utils.py:160-193 (torch path) and :16-133 (Triton kernel).  Pure byte
 // permutation, HBM-bound (2 B per scale byte).
 //
-// One workgroup = one 128-row tile x up to 32 column tiles (128 input columns).  The 128 x 128-byte
-// slab is read with whole-line coalesced 16-byte loads into LDS (out-of-range -> 0 through the buffer
-// descriptor / explicit column masks), then every thread assembles 16-byte output lines
-// (4 x ds_read_b32 from the rows r, r+32, r+64, r+96) and stores them fully coalesced:
-// consecutive lanes write consecutive 16 bytes of the output tile stream.
+// One workgroup = one 128-row tile x TC/4 column tiles (TC input columns; TC = 128 for large matrices, down to 16 so
+// that small ones -- a 4096 x 128 activation scale matrix is 512 KiB -- still spread over the chip: 32 workgroups of
+// 16 KiB each took 4.5 us, launch latency plus 20 serial iterations per thread).  The 128 x TC-byte slab is read with
+// dword loads into LDS (out-of-range -> 0), then every thread assembles 16-byte output lines (4 x ds_read_b32 from the
+// rows r, r+32, r+64, r+96) and stores them fully coalesced: consecutive lanes write consecutive 16 bytes of the
+// output tile stream.
 #pragma once
 #include "common.hip.h"
 
@@ -20,13 +21,14 @@ struct BlockedParams {
   int RB, CB;       // ceil(rows/128), ceil(cols/4)
 };
 
+template <int TC>   // input columns (bytes) per workgroup = TC / 4 column tiles
 __global__ __launch_bounds__(256) void to_blocked_kernel(const BlockedParams p) {
-  constexpr int TC = 128;                 // input columns (bytes) per workgroup = 32 column tiles
+  constexpr int CT = TC / 4;              // column tiles per workgroup
   constexpr int LROW = TC + 4;            // LDS row stride (bytes), +4 breaks the 32-row bank pattern
   __shared__ __attribute__((aligned(16))) uint8_t slab[128 * LROW];
 
   const int tid = threadIdx.x;
-  const int cgroups = (p.CB + 31) / 32;
+  const int cgroups = (p.CB + CT - 1) / CT;
   const int rb = blockIdx.x / cgroups, cg = blockIdx.x % cgroups;
   const int r0 = rb * 128, c0 = cg * TC;
   const bool vec_ok = (p.cols % 4) == 0;   // dword loads stay inside a row and are 4-byte aligned
@@ -50,10 +52,10 @@ __global__ __launch_bounds__(256) void to_blocked_kernel(const BlockedParams p) 
   }
   __syncthreads();
 
-  // ---- emit: 32 column tiles x 32 lines of 16 bytes ------------------------------------------
-  for (int it = tid; it < 32 * 32; it += 256) {
+  // ---- emit: CT column tiles x 32 lines of 16 bytes ------------------------------------------
+  for (int it = tid; it < CT * 32; it += 256) {
     const int ct = it / 32, i = it % 32;
-    const int cb = cg * 32 + ct;
+    const int cb = cg * CT + ct;
     if (cb >= p.CB) continue;
     v4i o;
 #pragma unroll

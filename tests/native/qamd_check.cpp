@@ -514,6 +514,8 @@ int main(int argc, char** argv) {
   if (want("blocked")) {
     check_blocked(128, 4); check_blocked(256, 16); check_blocked(384, 12); check_blocked(4096, 128);
     check_blocked(130, 5); check_blocked(16, 64); check_blocked(504, 128); check_blocked(8192, 512);
+    check_blocked(16, 128); check_blocked(1024, 448); check_blocked(2048, 36); check_blocked(57344, 256);
+    bench_blocked(16, 128); bench_blocked(4096, 128); bench_blocked(14336, 128); bench_blocked(8192, 512);
   }
   if (want("steady")) {   // steady-state clocks: the part needs ~50 ms of load to leave its ramp (tools/clock_ramp.py)
     g_warm_override = 2500; g_iters_override = 2500;
