@@ -72,6 +72,38 @@ def test_c_abi_rejects_bad_arguments_without_launching(lib):
     assert b"gfx950" in lib.qutlass_amd_version()
 
 
+def test_split_k_workspace_plan_is_a_pure_host_function(lib):
+    """qutlass_amd_gemm_splitk_workspace_bytes is the contract between a caller that owns the scratch and the launcher:
+    fp32 partials [splits][M][N] for small outputs (< 256 tiles of 64x64) with a long K (>= 48 stages of 128 bytes),
+    0 otherwise; the *_ws entries validate like the plain ones."""
+    from qutlass_amd._lib import QAMD_ERR_INVALID
+
+    ws = lib.qutlass_amd_gemm_splitk_workspace_bytes
+    def splits(ebits, m, n, k):   # the documented rule (DESIGN.md section 3.8)
+        t, kt = -(-m // 64) * -(-n // 64), -(-(k * ebits // 8) // 128)
+        if t >= 256 or kt < 48:
+            return 0
+        s = min(8, 512 // t, kt // 8)
+        return -(-kt // -(-kt // s))
+
+    # Llama-3-8B down-proj, batch 64: 64 tiles, KT = 56 stages -> 7 splits of 8 stages
+    assert splits(4, 64, 4096, 14336) == 7 and ws(4, 64, 4096, 14336) == 7 * 64 * 4096 * 4
+    assert ws(4, 16, 4096, 14336) == splits(4, 16, 4096, 14336) * 16 * 4096 * 4
+    assert ws(4, 128, 4096, 14336) == 4 * 128 * 4096 * 4   # 128 tiles: 4 splits keep two workgroups per CU
+    assert ws(4, 256, 4096, 14336) == 0          # 256 tiles fill the chip: no split
+    assert ws(4, 64, 4096, 8192) == 0            # K too short to pay for the second pass
+    assert ws(8, 64, 4096, 8192) == splits(8, 64, 4096, 8192) * 64 * 4096 * 4 > 0   # fp8: the same K is 64 stages
+    assert ws(4, 4096, 4096, 4096) == 0 and ws(4, 0, 4096, 4096) == 0 and ws(5, 64, 4096, 14336) == 0
+    for m, n, k in [(8, 512, 28672), (40, 1032, 14464), (128, 2048, 57344), (1, 64, 12288)]:
+        b = ws(4, m, n, k)
+        assert b == splits(4, m, n, k) * m * n * 4 and 2 <= b // (m * n * 4) <= 8, (m, n, k, b)
+    dummy = ctypes.c_void_p(0x1000)
+    g = lib.qutlass_amd_matmul_mxf4_bf16_tn_ws
+    assert g(dummy, dummy, dummy, dummy, dummy, dummy, 128, 128, 96, None, 0, None) == QAMD_ERR_INVALID
+    assert "multiple of 128" in lib.qutlass_amd_last_error().decode()
+    assert lib.qutlass_amd_matmul_mxf8_bf16_tn_ws(None, dummy, dummy, dummy, dummy, dummy, 128, 128, 128, None, 0, None) == QAMD_ERR_INVALID
+
+
 def test_python_surface_matches_reference_signatures():
     import qutlass
     import qutlass_amd
