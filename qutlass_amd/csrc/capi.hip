@@ -24,6 +24,7 @@ thread_local char g_err[512] = "";
 std::atomic<int> g_hw_fp4_cvt{1};   // device-verified bit-identical to the software encoder (tests/native/probe.hip P2)
 std::atomic<int> g_gemm_variant{0};
 std::atomic<int> g_nvf4_variant{0};
+std::atomic<int> g_splitk_wg{256};      // split-K: target workgroup count ("splitk_wg"; one per CU measured best, profiles/native_r1_splitk_wg.log)
 std::atomic<int> g_transpose_nc{128};   // mxfp4_transpose_mxfp8: n columns per workgroup (128 or 256)
 std::atomic<int> g_pp_shift{2};
 std::atomic<int> g_pp_flags{1};
@@ -148,7 +149,8 @@ SmallPlan plan_small(int64_t M, int64_t N, int64_t K) {
     const int64_t KT = cdiv(K * EBITS / 8, 128);
     int64_t S = 1;
     if (T64 < 256 && KT >= 48) {                                       // shorter K: the reduce pass costs more than it saves
-      S = std::min<int64_t>(std::min<int64_t>(8, 512 / T64), KT / 8);   // up to 2 workgroups per CU, >= 8 stages per split
+      S = std::min<int64_t>(std::min<int64_t>(8, g_splitk_wg.load() / T64), KT / 8);   // up to one workgroup per CU, >= 8 stages per split
+      if (S < 1) S = 1;
       const int64_t per = cdiv(KT, S);
       S = cdiv(KT, per);                                                // every split non-empty
     }
@@ -554,6 +556,7 @@ int qutlass_amd_set_option(const char* key, int value) {
   if (!strcmp(key, "gemm_variant")) return g_gemm_variant.exchange(value);
   if (!strcmp(key, "nvf4_variant")) return g_nvf4_variant.exchange(value);
   if (!strcmp(key, "transpose_nc")) return g_transpose_nc.exchange(value);
+  if (!strcmp(key, "splitk_wg")) return g_splitk_wg.exchange(value);
   if (!strcmp(key, "quant_wg_per_cu")) return g_quant_wg_per_cu.exchange(value);
   if (!strcmp(key, "pp_shift")) return g_pp_shift.exchange(value);
   if (!strcmp(key, "pp_flags")) return g_pp_flags.exchange(value);

@@ -762,6 +762,19 @@ int main(int argc, char** argv) {
         for (int method : {0, 1}) check_quant_nv(R, method, hw, 1 << 18, method ? 6.0f : 1.0f);
     check_quant_nv(16, 1, 0, 16 * 33, 1.0f);
   }
+  if (want("splitk")) {   // split-K workgroup target: 512 (two per CU) vs 256 vs 128
+    for (int wg : {512, 384, 256, 128}) {
+      qutlass_amd_set_option("splitk_wg", wg);
+      for (int64_t M : {16, 64, 128, 192}) {
+        for (auto nk : {std::pair<int64_t, int64_t>{4096, 14336}, {8192, 28672}, {2048, 16384}}) {
+          char tag[96];
+          snprintf(tag, sizeof tag, "splitk_wg=%d M=%lld N=%lld K=%lld", wg, (long long)M, (long long)nk.first, (long long)nk.second);
+          bench_gemm(tag, 0, M, nk.first, nk.second, 0, 50);
+        }
+      }
+    }
+    qutlass_amd_set_option("splitk_wg", 256);
+  }
   if (want("rtrace")) {   // ring schedule timeline, workgroup 0: per stage [wait own DMA | barrier | issue DMA | fragment reads | MFMA issue]
     for (int64_t M : {64, 256}) {
       const int64_t N = 4096, K = 4096;

@@ -83,14 +83,14 @@ def test_split_k_workspace_plan_is_a_pure_host_function(lib):
         t, kt = -(-m // 64) * -(-n // 64), -(-(k * ebits // 8) // 128)
         if t >= 256 or kt < 48:
             return 0
-        s = min(8, 512 // t, kt // 8)
-        return -(-kt // -(-kt // s))
+        s = min(8, 256 // t, kt // 8)
+        return -(-kt // -(-kt // s)) if s >= 2 else 0
 
-    # Llama-3-8B down-proj, batch 64: 64 tiles, KT = 56 stages -> 7 splits of 8 stages
-    assert splits(4, 64, 4096, 14336) == 7 and ws(4, 64, 4096, 14336) == 7 * 64 * 4096 * 4
+    # Llama-3-8B down-proj, batch 64: 64 tiles, KT = 56 stages -> 4 splits of 14 stages (one workgroup per CU)
+    assert splits(4, 64, 4096, 14336) == 4 and ws(4, 64, 4096, 14336) == 4 * 64 * 4096 * 4
     assert ws(4, 16, 4096, 14336) == splits(4, 16, 4096, 14336) * 16 * 4096 * 4
-    assert ws(4, 128, 4096, 14336) == 4 * 128 * 4096 * 4   # 128 tiles: 4 splits keep two workgroups per CU
-    assert ws(4, 256, 4096, 14336) == 0          # 256 tiles fill the chip: no split
+    assert ws(4, 128, 4096, 14336) == 2 * 128 * 4096 * 4   # 128 tiles: 2 splits
+    assert ws(4, 256, 4096, 14336) == 0 and ws(4, 192, 4096, 14336) == 0   # more than 128 tiles: no split
     assert ws(4, 64, 4096, 8192) == 0            # K too short to pay for the second pass
     assert ws(8, 64, 4096, 8192) == splits(8, 64, 4096, 8192) * 64 * 4096 * 4 > 0   # fp8: the same K is 64 stages
     assert ws(4, 4096, 4096, 4096) == 0 and ws(4, 0, 4096, 4096) == 0 and ws(5, 64, 4096, 14336) == 0
