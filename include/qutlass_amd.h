@@ -75,7 +75,7 @@ int qutlass_amd_matmul_mxf8_bf16_tn(const void* A, const void* B, const void* A_
 
 /*
  * The same two GEMMs with caller-owned scratch, which unlocks split-K for small outputs with a long K (fewer than 256
- * tiles of 64x64 -- at most 128 of them -- and K >= 48 stages of 128 bytes: e.g. M = 64, N = 4096, K = 14336 runs 64
+ * tiles of 64x64 -- at most 128 of them -- and K >= 32 stages of 128 bytes: e.g. M = 64, N = 4096, K = 14336 runs 64
  * workgroups without it).
  * Each K split writes its fp32 partial to workspace[z][M][N]; a second kernel sums the splits in fixed order, applies
  * alpha and rounds to bf16 (deterministic; identical to the single-pass result whenever the fp32 partial sums are

@@ -25,6 +25,7 @@ std::atomic<int> g_hw_fp4_cvt{1};   // device-verified bit-identical to the soft
 std::atomic<int> g_gemm_variant{0};
 std::atomic<int> g_nvf4_variant{0};
 std::atomic<int> g_splitk_wg{256};      // split-K: target workgroup count ("splitk_wg"; one per CU measured best, profiles/native_r1_splitk_wg.log)
+std::atomic<int> g_splitk_min_kt{32};   // split-K: minimum number of 128-byte K stages ("splitk_min_kt"; 16 loses at K = 4096, 48 leaves K = 8192 .. 11008 unsplit)
 std::atomic<int> g_transpose_nc{128};   // mxfp4_transpose_mxfp8: n columns per workgroup (128 or 256)
 std::atomic<int> g_pp_shift{2};
 std::atomic<int> g_pp_flags{1};
@@ -139,7 +140,7 @@ int dispatch_variant(int v, const GemmParams& p, hipStream_t s, const char* name
 // EBITS: 4 = MXFP4, 8 = MXFP8 (TN)
 // Small-output regime: ring schedule (one workgroup per CU with several stages in flight beats the 2-stage simple schedule
 // whenever the tiles do not fill the chip twice), plus split-K over grid.y when 64x64 tiles leave CUs idle and K is long
-// enough to pay for the second pass.  One function so that the launcher and qutlass_amd_gemm_splitk_workspace_bytes
+// enough to pay for the second pass (>= 32 stages: fp4 K >= 8192).  One function so that the launcher and qutlass_amd_gemm_splitk_workspace_bytes
 // agree.  Measured: profiles/native_r1_ring.log.
 struct SmallPlan { int variant; int splits; };   // variant 0: not this regime
 template <int EBITS>
@@ -148,7 +149,7 @@ SmallPlan plan_small(int64_t M, int64_t N, int64_t K) {
   if (T64 <= 256) {
     const int64_t KT = cdiv(K * EBITS / 8, 128);
     int64_t S = 1;
-    if (T64 < 256 && KT >= 48) {                                       // shorter K: the reduce pass costs more than it saves
+    if (T64 < 256 && KT >= g_splitk_min_kt.load()) {                                       // shorter K: the reduce pass costs more than it saves
       S = std::min<int64_t>(std::min<int64_t>(8, g_splitk_wg.load() / T64), KT / 8);   // up to one workgroup per CU, >= 8 stages per split
       if (S < 1) S = 1;
       const int64_t per = cdiv(KT, S);
@@ -557,6 +558,7 @@ int qutlass_amd_set_option(const char* key, int value) {
   if (!strcmp(key, "nvf4_variant")) return g_nvf4_variant.exchange(value);
   if (!strcmp(key, "transpose_nc")) return g_transpose_nc.exchange(value);
   if (!strcmp(key, "splitk_wg")) return g_splitk_wg.exchange(value);
+  if (!strcmp(key, "splitk_min_kt")) return g_splitk_min_kt.exchange(value);
   if (!strcmp(key, "quant_wg_per_cu")) return g_quant_wg_per_cu.exchange(value);
   if (!strcmp(key, "pp_shift")) return g_pp_shift.exchange(value);
   if (!strcmp(key, "pp_flags")) return g_pp_flags.exchange(value);

@@ -775,6 +775,19 @@ int main(int argc, char** argv) {
     }
     qutlass_amd_set_option("splitk_wg", 256);
   }
+  if (want("splitkt")) {   // split-K threshold on the number of K stages: 48 vs 32 (default) vs 16
+    for (int kt : {48, 32, 16}) {
+      qutlass_amd_set_option("splitk_min_kt", kt);
+      for (int64_t M : {16, 64, 128}) {
+        for (auto nk : {std::pair<int64_t, int64_t>{4096, 4096}, {4096, 8192}, {8192, 8192}, {2048, 8192}, {4096, 11008}}) {
+          char tag[96];
+          snprintf(tag, sizeof tag, "min_kt=%d M=%lld N=%lld K=%lld", kt, (long long)M, (long long)nk.first, (long long)nk.second);
+          bench_gemm(tag, 0, M, nk.first, nk.second, 0, 50);
+        }
+      }
+    }
+    qutlass_amd_set_option("splitk_min_kt", 32);
+  }
   if (want("rtrace")) {   // ring schedule timeline, workgroup 0: per stage [wait own DMA | barrier | issue DMA | fragment reads | MFMA issue]
     for (int64_t M : {64, 256}) {
       const int64_t N = 4096, K = 4096;

@@ -74,14 +74,14 @@ def test_c_abi_rejects_bad_arguments_without_launching(lib):
 
 def test_split_k_workspace_plan_is_a_pure_host_function(lib):
     """qutlass_amd_gemm_splitk_workspace_bytes is the contract between a caller that owns the scratch and the launcher:
-    fp32 partials [splits][M][N] for small outputs (< 256 tiles of 64x64) with a long K (>= 48 stages of 128 bytes),
+    fp32 partials [splits][M][N] for small outputs (<= 128 tiles of 64x64) with a long K (>= 32 stages of 128 bytes),
     0 otherwise; the *_ws entries validate like the plain ones."""
     from qutlass_amd._lib import QAMD_ERR_INVALID
 
     ws = lib.qutlass_amd_gemm_splitk_workspace_bytes
     def splits(ebits, m, n, k):   # the documented rule (DESIGN.md section 3.8)
         t, kt = -(-m // 64) * -(-n // 64), -(-(k * ebits // 8) // 128)
-        if t >= 256 or kt < 48:
+        if t >= 256 or kt < 32:
             return 0
         s = min(8, 256 // t, kt // 8)
         return -(-kt // -(-kt // s)) if s >= 2 else 0
@@ -91,8 +91,8 @@ def test_split_k_workspace_plan_is_a_pure_host_function(lib):
     assert ws(4, 16, 4096, 14336) == splits(4, 16, 4096, 14336) * 16 * 4096 * 4
     assert ws(4, 128, 4096, 14336) == 2 * 128 * 4096 * 4   # 128 tiles: 2 splits
     assert ws(4, 256, 4096, 14336) == 0 and ws(4, 192, 4096, 14336) == 0   # more than 128 tiles: no split
-    assert ws(4, 64, 4096, 8192) == 0            # K too short to pay for the second pass
-    assert ws(8, 64, 4096, 8192) == splits(8, 64, 4096, 8192) * 64 * 4096 * 4 > 0   # fp8: the same K is 64 stages
+    assert ws(4, 64, 4096, 4096) == 0            # 16 stages: too short to pay for the second pass
+    assert ws(4, 64, 4096, 8192) == 4 * 64 * 4096 * 4 and ws(8, 64, 4096, 4096) == 4 * 64 * 4096 * 4   # 32 stages (fp8: K = 4096)
     assert ws(4, 4096, 4096, 4096) == 0 and ws(4, 0, 4096, 4096) == 0 and ws(5, 64, 4096, 14336) == 0
     for m, n, k in [(8, 512, 28672), (40, 1032, 14464), (128, 2048, 57344), (1, 64, 12288)]:
         b = ws(4, m, n, k)

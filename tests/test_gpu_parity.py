@@ -251,7 +251,7 @@ def test_split_k_small_output_long_k(q, m, n, k):
 
     a_q, a_s, b_q, b_s, out = _pipeline(q, m, n, k, "abs_max", seed=m + k)
     expect_split = q._lib.load().qutlass_amd_gemm_splitk_workspace_bytes(4, m, n, k)
-    assert (expect_split > 0) == (k >= 48 * 256 and -(-m // 64) * -(-n // 64) <= 128)
+    assert (expect_split > 0) == (k >= 32 * 256 and -(-m // 64) * -(-n // 64) <= 128)
     asf, bsf, al = to_blocked(a_s), to_blocked(b_s), torch.tensor([1.0], device=DEV)
     old = q._lib.set_option("pp_flags", 1 | 128)
     try:
