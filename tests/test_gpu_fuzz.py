@@ -74,6 +74,31 @@ def test_fuzz_matmul_mxf4(q):
             assert np.array_equal(_np(out2), ref), ("ada", it, m, n, k)
 
 
+def test_fuzz_matmul_mxf4_long_k_split(q):
+    """Long K with a small output: the ring kernel splits K over grid.y (scratch from the caching allocator) and a
+    second kernel sums the partials.  Scale exponents within 2 binades keep every fp32 partial sum exact for K <= 12288
+    (K * 144 * 2^2 < 2^24), so the split result must equal the fp64 oracle bit for bit."""
+    from qutlass_amd.utils import to_blocked
+
+    rng = np.random.default_rng(105 + 1000 * SEED)
+    e8 = torch.float8_e8m0fnu
+    nsplit = 0
+    for it in range(8):
+        m = int(rng.choice([1, 16, 33, 40, 64, 100, 128]))
+        n = int(rng.integers(1, 64)) * 8
+        k = int(rng.choice([8192, 8320, 9216, 11008 // 128 * 128, 12288]))
+        a, b = _rand_codes(rng, m, k // 2), _rand_codes(rng, n, k // 2)
+        sa = torch.from_numpy(rng.integers(127, 129, size=(m, k // 32), dtype=np.uint8)).to(DEV)
+        sb = torch.from_numpy(rng.integers(127, 129, size=(n, k // 32), dtype=np.uint8)).to(DEV)
+        alpha = torch.tensor([float(rng.choice([1.0, 0.5]))], device=DEV)
+        nsplit += q._lib.load().qutlass_amd_gemm_splitk_workspace_bytes(4, m, n, k) > 0
+        out = q.matmul_mxf4_bf16_tn(a, b, to_blocked(sa.view(e8)), to_blocked(sb.view(e8)), alpha)
+        ref = oracle.gemm_blockscaled(oracle.KIND_MXFP4, _np(a), _np(b), oracle.to_blocked(_np(sa)), oracle.to_blocked(_np(sb)),
+                                      float(alpha.item()), m, n, k)
+        assert np.array_equal(_np(out), ref), (it, m, n, k, int((_np(out) != ref).sum()))
+    assert nsplit >= 6   # these shapes are in the split-K regime (<= 128 tiles, >= 32 stages)
+
+
 def test_fuzz_matmul_nvf4_and_mxf8(q):
     from qutlass_amd.utils import to_blocked
 
