@@ -196,41 +196,64 @@ __global__ __launch_bounds__(C::THREADS) void gemm_nvf4_kernel(const NvGemmParam
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
 
+  // A stage is 16 k-steps of 16 elements: step s = (j, u) with chunk j = s / 4 (scale column tile jj = j / 2, byte pair
+  // jl = j % 2) and dword u = s % 4.  Software pipeline with TWO fragment register sets: the converts of step s + 1 write
+  // set (s + 1) & 1 while the MFMAs of step s read set s & 1, and the sched_group_barrier pattern asks for "1 MFMA, then
+  // its share of the next step's converts", so a single wave keeps the matrix pipe fed.  Measured: 8192^3 with
+  // zero-filled operands (not power limited) 762 -> 691 us; random operands unchanged (power cap); small tiles unchanged --
+  // they are bound by the VALU itself (8 packed-f16 converts / multiplies per 8 elements at ~6 cycles each,
+  // tests/native/ubench.hip "valu": 512 of them per stage and wave of a 128x128 tile = 1.6 us).
   auto compute_stage = [&](int buf) {
     const char* st = smem + buf * C::STAGE_BYTES;
+    h2_t sa[2][MT][2], sb[2][NT][2];     // [jj & 1][.][jl]
+    v4i ca[2][MT], cb[2][NT];            // [j & 1]
+    h8_t fa[2][MT], fb[2][NT];           // [s & 1]
+    auto load_scales = [&](const int jj) __attribute__((always_inline)) {
 #pragma unroll
-    for (int jj = 0; jj < 2; ++jj) {           // scale column tile 2g + jj  <->  chunks j = 2jj, 2jj+1
-      h2_t sa[MT][2], sb[NT][2];               // [.][0] = groups of chunk 2jj, [.][1] = chunk 2jj+1
+      for (int t = 0; t < MT; ++t) e4m3x4_to_f16(*(const uint32_t*)(st + rdSA[t] + jj * 512), sa[jj & 1][t][0], sa[jj & 1][t][1]);
 #pragma unroll
-      for (int t = 0; t < MT; ++t) e4m3x4_to_f16(*(const uint32_t*)(st + rdSA[t] + jj * 512), sa[t][0], sa[t][1]);
+      for (int t = 0; t < NT; ++t) e4m3x4_to_f16(*(const uint32_t*)(st + rdSB[t] + jj * 512), sb[jj & 1][t][0], sb[jj & 1][t][1]);
+    };
+    auto load_chunks = [&](const int j) __attribute__((always_inline)) {
 #pragma unroll
-      for (int t = 0; t < NT; ++t) e4m3x4_to_f16(*(const uint32_t*)(st + rdSB[t] + jj * 512), sb[t][0], sb[t][1]);
+      for (int t = 0; t < MT; ++t) ca[j & 1][t] = *(const v4i*)(st + rdA[j] + t * 32 * C::ROWB);
 #pragma unroll
-      for (int jl = 0; jl < 2; ++jl) {
-        const int j = 2 * jj + jl;
-        v4i ca[MT], cb[NT];
+      for (int t = 0; t < NT; ++t) cb[j & 1][t] = *(const v4i*)(st + rdB[j] + t * 32 * C::ROWB);
+    };
+    auto dq_step = [&](const int s) __attribute__((always_inline)) {
+      const int j = s >> 2, u = s & 3, jj = j >> 1, jl = j & 1;
 #pragma unroll
-        for (int t = 0; t < MT; ++t) ca[t] = *(const v4i*)(st + rdA[j] + t * 32 * C::ROWB);
+      for (int t = 0; t < MT; ++t) {
+        const _Float16 sc = sa[jj & 1][t][jl][u >> 1];
+        fa[s & 1][t] = dq8((uint32_t)ca[j & 1][t][u], h2_t{sc, sc});
+      }
 #pragma unroll
-        for (int t = 0; t < NT; ++t) cb[t] = *(const v4i*)(st + rdB[j] + t * 32 * C::ROWB);
+      for (int t = 0; t < NT; ++t) {
+        const _Float16 sc = sb[jj & 1][t][jl][u >> 1];
+        fb[s & 1][t] = dq8((uint32_t)cb[j & 1][t][u], h2_t{sc, sc});
+      }
+    };
+    load_scales(0);
+    load_chunks(0);
+    dq_step(0);
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {          // dword u = elements 8u..8u+7, 16-group (u >> 1)
-          h8_t fa[MT], fb[NT];
+    for (int s = 0; s < 16; ++s) {
+      if (s + 1 < 16) {
+        if (s == 1) load_scales(1);                                        // second scale column tile: used from step 8
+        if ((s & 3) == 0 && (s >> 2) + 1 < 4) load_chunks((s >> 2) + 1);   // raw chunk of j + 1: one chunk (4 steps) ahead
+        dq_step(s + 1);
+      }
 #pragma unroll
-          for (int t = 0; t < MT; ++t) {
-            const _Float16 s = sa[t][jl][u >> 1];
-            fa[t] = dq8((uint32_t)ca[t][u], h2_t{s, s});
-          }
+      for (int m = 0; m < MT; ++m)
 #pragma unroll
-          for (int t = 0; t < NT; ++t) {
-            const _Float16 s = sb[t][jl][u >> 1];
-            fb[t] = dq8((uint32_t)cb[t][u], h2_t{s, s});
-          }
+        for (int n = 0; n < NT; ++n)
+          acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb[s & 1][n], fa[s & 1][m], acc[m][n], 0, 0, 0);
+      if (s + 1 < 16) {
+        constexpr int VPM = ((MT + NT) * 8 + MT * NT - 1) / (MT * NT);   // converts of the next step per MFMA of this one
 #pragma unroll
-          for (int m = 0; m < MT; ++m)
-#pragma unroll
-            for (int n = 0; n < NT; ++n)
-              acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb[n], fa[m], acc[m][n], 0, 0, 0);
+        for (int i = 0; i < MT * NT; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);     // 1 MFMA
+          __builtin_amdgcn_sched_group_barrier(0x002, VPM, 0);   // VPM VALU
         }
       }
     }
