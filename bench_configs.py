@@ -31,27 +31,53 @@ def hadamard(n, device):
 
 
 def time_us(fn, iters, warmup=5, ramp_ms=40.0):
-    """Average microseconds per call over `iters` back-to-back calls, after at least `ramp_ms` of the same load: an idle
-    MI355X needs ~40 ms to reach its steady clock (tools/clock_ramp.py), and the Python set-up between two measurements is
-    long enough for it to fall back."""
+    """Average microseconds per call on the DEVICE: `fn` is captured into a HIP graph (`inner` calls, so that one replay
+    lasts >= ~0.5 ms and the 8 us of host work per Python op call does not bound short kernels), the graph is replayed for
+    at least `ramp_ms` first -- an idle MI355X needs ~40 ms under load to reach its steady clock (tools/clock_ramp.py) --
+    and then timed over enough replays to cover `iters` calls.  Falls back to eager launches if capture fails."""
     import time
 
     for _ in range(warmup):
         fn()
     torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(3):
+        fn()
+    e1.record()
+    e1.synchronize()
+    est_us = max(e0.elapsed_time(e1) * 1e3 / 3, 1.0)
+    inner = int(min(100, max(1, round(500.0 / est_us))))
+    try:
+        st = torch.cuda.Stream()
+        st.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(st):
+            fn()
+        torch.cuda.current_stream().wait_stream(st)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            for _ in range(inner):
+                fn()
+        run = g.replay
+    except Exception:   # pragma: no cover - capture is expected to work (tests/test_gpu_parity.py)
+        torch.cuda.synchronize()
+
+        def run():
+            for _ in range(inner):
+                fn()
     t0 = time.perf_counter()
     while (time.perf_counter() - t0) * 1e3 < ramp_ms:
-        for _ in range(10):
-            fn()
+        run()
         torch.cuda.synchronize()
-    s = torch.cuda.current_stream()
+    reps = max(3, -(-iters // inner))
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record(s)
-    for _ in range(iters):
-        fn()
-    e1.record(s)
+    e0.record()
+    for _ in range(reps):
+        run()
+    e1.record()
     torch.cuda.synchronize()
-    return e0.elapsed_time(e1) * 1e3 / iters
+    return e0.elapsed_time(e1) * 1e3 / (reps * inner)
 
 
 def line(name, us, flops=None, peak=None, bytes_=None, **extra):
