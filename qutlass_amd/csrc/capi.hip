@@ -64,8 +64,21 @@ int launch_gemm(GemmParams p, hipStream_t s) {
 //   31..36, 41..43, 50..56  ablations / traces / clock probes of those (bench only)
 //   2  128x128 lockstep (small M or N)                     3  256x128 lockstep    4  128x256 lockstep
 //   100+b / 200+b  ablations of variants 1 / 5 (bench only), b = OR of ABL_* bits
+// Dry run (qutlass_amd_debug_gemm_plan): the dispatch code below runs unchanged, but instead of launching it records
+// which kernels it WOULD launch -- {variant, N of the launch, K splits} per launch -- so the auto rules are testable on a
+// machine without a GPU (tests/test_cabi_and_host.py).
+struct DryRun { bool on = false; int n = 0; int rec[8][3]; };
+thread_local DryRun t_dry;
+inline bool dry_record(int variant, int n_cols, int splits) {
+  if (!t_dry.on) return false;
+  if (t_dry.n < 8) { t_dry.rec[t_dry.n][0] = variant; t_dry.rec[t_dry.n][1] = n_cols; t_dry.rec[t_dry.n][2] = splits; }
+  ++t_dry.n;
+  return true;
+}
+
 template <int EBITS, bool SPLIT>
 int dispatch_variant(int v, const GemmParams& p, hipStream_t s, const char* name) {
+  if (dry_record(v, p.N, (v >= 70 && v <= 78) ? p.splits : 1)) return 0;
   switch (v) {
     case 1: return launch_gemm<GemmCfg<256, 256, 2, 4, EBITS, SPLIT>, 1>(p, s);
     case 2: return launch_gemm<GemmCfg<128, 128, 2, 2, EBITS, SPLIT>, 0>(p, s);
@@ -195,6 +208,7 @@ int gemm_mx(const char* name, const void* A, const void* B, const void* A_sf, co
     if (splits > 1 && ws && ws_bytes >= need && !(p.pp_flags & 128)) {
       p.ws = (float*)ws; p.splits = splits;
       if (int rc = dispatch_variant<EBITS, EBITS == 8>(v, p, s, name)) return rc;
+      if (t_dry.on) return 0;
       const int64_t quads = M * (N / 4);
       const int grid = (int)std::min<int64_t>(cdiv(quads, 256), 2048);
       switch (splits) {
@@ -215,6 +229,7 @@ int gemm_mx(const char* name, const void* A, const void* B, const void* A_sf, co
   // vs 9.7 us; N = 57344, K = 8192: 36 us vs 58-74 us), as does ring + split-K over caller scratch for a long K
   // (N = 4096, K = 14336, M = 16: 11.6 us vs 14.8 us).  profiles/native_r1_skinny_shapes.log, native_r1_ring.log
   if (EBITS == 4 && (variant == 60 || (variant >= 44 && variant <= 49) || (variant == 0 && M <= 32 && cdiv(N, 64) < 128 && !can_split))) {
+    if (dry_record(variant ? variant : 60, p.N, 1)) return 0;
     SkinnyParams q;
     q.A = p.A; q.B = p.B; q.SFA = p.SFA; q.SFB = p.SFB; q.alpha = alpha; q.D = p.D; q.M = p.M; q.N = p.N; q.K = p.K;
     q.a_bytes = p.a_bytes; q.b_bytes = p.b_bytes; q.sfa_bytes = p.sfa_bytes; q.sfb_bytes = p.sfb_bytes;
@@ -543,6 +558,23 @@ int qutlass_amd_to_blocked(const void* in, int64_t rows, int64_t cols, void* out
     default: hipLaunchKernelGGL(to_blocked_kernel<16>, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, p); break;
   }
   return check_launch("to_blocked_kernel");
+}
+
+// debug only (not declared in the public header): which kernels would matmul_mx{f4,f8}_bf16_tn(_ws) launch for this shape?
+// out[3 * i + {0, 1, 2}] = {gemm_variant, N of the launch, K splits} of launch i; returns the number of launches (the split-K
+// reduce pass is implied by splits > 1), or -1 when the arguments are rejected.  No GPU is touched.
+int qutlass_amd_debug_gemm_plan(int ebits, int64_t M, int64_t N, int64_t K, int64_t workspace_bytes, int* out, int cap) {
+  static char dummy[16];
+  t_dry = DryRun{};
+  t_dry.on = true;
+  void* ws = workspace_bytes > 0 ? (void*)dummy : nullptr;
+  const int rc = (ebits == 4) ? gemm_mx<4>("debug_gemm_plan", dummy, dummy, dummy, dummy, (const float*)dummy, dummy, M, N, K, nullptr, ws, workspace_bytes)
+               : (ebits == 8) ? gemm_mx<8>("debug_gemm_plan", dummy, dummy, dummy, dummy, (const float*)dummy, dummy, M, N, K, nullptr, ws, workspace_bytes)
+                              : QAMD_ERR_INVALID;
+  const int n = t_dry.n;
+  for (int i = 0; i < n && i < 8 && i < cap; ++i) { out[3 * i] = t_dry.rec[i][0]; out[3 * i + 1] = t_dry.rec[i][1]; out[3 * i + 2] = t_dry.rec[i][2]; }
+  t_dry = DryRun{};
+  return rc == QAMD_OK ? n : -1;
 }
 
 // bench/debug only (not declared in the public header): device buffer for ABL_TRACE builds

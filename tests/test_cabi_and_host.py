@@ -104,6 +104,46 @@ def test_split_k_workspace_plan_is_a_pure_host_function(lib):
     assert lib.qutlass_amd_matmul_mxf8_bf16_tn_ws(None, dummy, dummy, dummy, dummy, dummy, 128, 128, 128, None, 0, None) == QAMD_ERR_INVALID
 
 
+def test_auto_dispatch_rules_dry_run(lib):
+    """The tile / schedule choice of the MX GEMMs (DESIGN.md sections 3.3, 3.7, 3.8) through the library's dry-run hook:
+    the real dispatch code runs, launches are recorded instead of issued.  (variant, N of the launch, K splits)."""
+    f = lib.qutlass_amd_debug_gemm_plan   # debug entry, deliberately not in the public header
+    f.restype = ctypes.c_int
+    f.argtypes = [ctypes.c_int] + [ctypes.c_int64] * 4 + [ctypes.POINTER(ctypes.c_int), ctypes.c_int]
+
+    def plan(ebits, m, n, k, ws=0):
+        out = (ctypes.c_int * 24)()
+        cnt = f(ebits, m, n, k, ws, out, 8)
+        return None if cnt < 0 else [(out[3 * i], out[3 * i + 1], out[3 * i + 2]) for i in range(cnt)]
+
+    DEEP, SKINNY, RING64, RING64x128, RING128 = 30, 60, 70, 72, 73
+    big = 1 << 30
+    # headline and the other BASELINE configs: 256x256 deep tiles; C3 = 3.5 rounds of tiles -> tail split (2048 columns on 256x128)
+    assert plan(4, 4096, 4096, 4096) == [(DEEP, 4096, 1)]
+    assert plan(4, 8192, 8192, 8192) == [(DEEP, 8192, 1)]
+    assert plan(4, 4096, 14336, 4096) == [(DEEP, 12288, 1), (25, 2048, 1)]
+    assert plan(8, 4096, 4096, 4096) == [(DEEP, 4096, 1)]
+    # decode: LDS-free split-K kernel while the weight has fewer than 128 64-row tiles, ring kernel beyond, 64x128 tiles for huge N
+    assert plan(4, 1, 4096, 4096) == [(SKINNY, 4096, 1)] and plan(4, 32, 4096, 4096) == [(SKINNY, 4096, 1)]
+    assert plan(4, 16, 14336, 4096) == [(RING64, 14336, 1)]
+    assert plan(4, 16, 57344, 8192) == [(28, 57344, 1)]
+    assert plan(8, 16, 4096, 4096) == [(RING64, 4096, 1)]            # no fp8 skinny kernel
+    # small outputs: ring schedule; split-K only with caller scratch, <= 128 tiles and >= 32 K stages
+    assert plan(4, 64, 4096, 4096) == [(RING64, 4096, 1)] == plan(4, 64, 4096, 4096, big)
+    assert plan(4, 64, 4096, 14336) == [(RING64, 4096, 1)]
+    assert plan(4, 64, 4096, 14336, big) == [(RING64, 4096, 4)]
+    assert plan(4, 64, 4096, 14336, 64 * 4096 * 4 * 4 - 1) == [(RING64, 4096, 1)]   # scratch one byte short: single pass
+    assert plan(4, 16, 4096, 14336, big) == [(RING64, 4096, 4)]       # beats the skinny kernel when it may split
+    assert plan(4, 128, 4096, 14336, big) == [(RING64, 4096, 2)]
+    assert plan(4, 256, 4096, 14336, big) == [(RING64, 4096, 1)]
+    assert plan(8, 64, 4096, 4096, big) == [(RING64, 4096, 4)]
+    assert plan(4, 512, 4096, 4096) == [(RING64x128, 4096, 1)]
+    assert plan(4, 1024, 4096, 4096) == [(RING128, 4096, 1)] and plan(4, 256, 14336, 4096) == [(RING128, 14336, 1)]
+    assert plan(4, 2048, 4096, 4096) == [(24, 4096, 1)]               # 512 tiles of 128x128: two workgroups per CU, simple schedule
+    # rejected arguments never reach the dispatch
+    assert plan(4, 128, 128, 96) is None and plan(5, 128, 128, 128) is None
+
+
 def test_python_surface_matches_reference_signatures():
     import qutlass
     import qutlass_amd
