@@ -4,6 +4,7 @@ duration (the `--kernel-trace --stats` view) and, when the run collected PMC cou
 
     python tools/rocprof_summary.py gpurun_out/prof_r1/bench_results.db [more.db ...] > profiles/xxx.txt
 """
+import os
 import sqlite3
 import sys
 
@@ -55,7 +56,13 @@ def traffic_json(kernel_substr, paths):
 def main():
     if len(sys.argv) > 2 and sys.argv[1] == "--traffic-json":
         return traffic_json(sys.argv[2], sys.argv[3:])
+    if len(sys.argv) < 2 or sys.argv[1] in ("-h", "--help"):
+        print(__doc__ or "usage: rocprof_summary.py [--traffic-json <kernel substring>] <rocprofv3 results .db> ...")
+        return
     for path in sys.argv[1:]:
+        if not os.path.exists(path):   # sqlite3.connect would silently create an empty database
+            print(f"== {path}: no such file")
+            continue
         c = sqlite3.connect(path)
         print(f"== {path}")
         rows = list(c.execute("select name, total_calls, total_duration, average, percentage from top_kernels"))
