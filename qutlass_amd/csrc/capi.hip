@@ -480,7 +480,6 @@ int qutlass_amd_backward_t_bf16(const void* x, const void* h, int64_t B, int64_t
   p.x = (const uint16_t*)x; p.h = (const uint16_t*)h; p.out = (uint8_t*)out_e2m1; p.out_sf = (uint8_t*)out_e8m0;
   p.B = (int)B; p.N = (int)N; p.M = (int)M; p.tiles_m = (int)cdiv(M, 64);
   if (B * (N / 32) * p.tiles_m >= (1ll << 31) - 65536) return fail(QAMD_ERR_INVALID, "%s: tensor too large", name);
-  p.ntiles = (int)(B * (N / 32) * p.tiles_m);
   const int64_t ntw = B * p.tiles_m * cdiv(N / 32, 8);   // workgroup tiles: 8 scale groups (256 n) x 64 m
   const int grid = (int)std::min<int64_t>(ntw, 256 * 2);   // several tiles per workgroup: the kernel prefetches the next tile
   if (g_hw_fp4_cvt.load()) hipLaunchKernelGGL((bwd_quant_t_kernel<false, true>), dim3(grid), dim3(512), 0, (hipStream_t)stream, p);
@@ -500,7 +499,6 @@ int qutlass_amd_backward_qt_bf16(const void* x_e2m1, const void* x_e8m0, const v
   p.out = (uint8_t*)out_e2m1; p.out_sf = (uint8_t*)out_e8m0;
   p.B = (int)B; p.N = (int)N; p.M = (int)M; p.tiles_m = (int)cdiv(M, 64);
   if (B * (N / 32) * p.tiles_m >= (1ll << 31) - 65536) return fail(QAMD_ERR_INVALID, "%s: tensor too large", name);
-  p.ntiles = (int)(B * (N / 32) * p.tiles_m);
   const int64_t ntw = B * p.tiles_m * cdiv(N / 32, 8);
   const int grid = (int)std::min<int64_t>(ntw, 256 * 2);
   if (g_hw_fp4_cvt.load()) hipLaunchKernelGGL((bwd_quant_t_kernel<true, true>), dim3(grid), dim3(512), 0, (hipStream_t)stream, p);

@@ -32,8 +32,7 @@ struct BwdTParams {
   uint8_t* out;             // e2m1 (B, M, N/2)
   uint8_t* out_sf;          // e8m0 (B, M, N/32)
   int B, N, M;
-  int tiles_m;              // ceil(M / 64)
-  int ntiles;               // B * (N/32) * tiles_m (< 2^31, host-checked): one wave-tile = 32 n x 64 m of one batch entry
+  int tiles_m;              // ceil(M / 64); B * (N/32) * tiles_m < 2^31 (host-checked): the kernel indexes tiles in 32 bits
 };
 
 // One wave = one [32 n][64 m] tile = one scale group for 64 output rows; the 8 waves of a workgroup take 8 consecutive
