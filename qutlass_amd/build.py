@@ -34,13 +34,37 @@ def needs_build() -> bool:
     return _stale(OUT, _kernel_sources()) or _stale(EXT_OUT, [EXT_SRC, HEADER, OUT])
 
 
+NUM_TU = 7   # translation units of csrc/capi.hip (QAMD_TU = 1..NUM_TU; see the comment at the top of that file)
+
+
 def build_kernels(force: bool = False, verbose: bool = False) -> str:
+    """csrc/capi.hip is compiled once per QAMD_TU value, in parallel (each unit instantiates one kernel family), and the
+    objects are linked into libqutlass_amd.so.  QAMD_SINGLE_TU=1 in the environment compiles it as one unit instead."""
     if force or _stale(OUT, _kernel_sources()):
         hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
-        cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", SRC, "-o", OUT]
-        if verbose:
-            print(" ".join(cmd))
-        subprocess.check_call(cmd)
+        base = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
+        if os.environ.get("QAMD_SINGLE_TU"):
+            cmd = base + ["-shared", SRC, "-o", OUT]
+            if verbose:
+                print(" ".join(cmd))
+            subprocess.check_call(cmd)
+            return OUT
+        import tempfile
+        from concurrent.futures import ThreadPoolExecutor
+
+        with tempfile.TemporaryDirectory(prefix="qamd_build_") as tmp:
+            objs = [os.path.join(tmp, f"capi_tu{i}.o") for i in range(1, NUM_TU + 1)]
+            cmds = [base + [f"-DQAMD_TU={i}", "-c", SRC, "-o", o] for i, o in zip(range(1, NUM_TU + 1), objs)]
+            if verbose:
+                print(" ".join(cmds[0]), f"   (x{NUM_TU}: QAMD_TU=1..{NUM_TU}, in parallel)")
+            with ThreadPoolExecutor(max_workers=min(NUM_TU, os.cpu_count() or 1)) as ex:
+                for rc, cmd in zip(ex.map(lambda c: subprocess.run(c).returncode, cmds), cmds):
+                    if rc != 0:
+                        raise subprocess.CalledProcessError(rc, cmd)
+            link = base + ["-shared"] + objs + ["-o", OUT]
+            if verbose:
+                print(" ".join(link[:6]), "... -o", OUT)
+            subprocess.check_call(link)
     return OUT
 
 

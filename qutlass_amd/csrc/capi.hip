@@ -18,8 +18,22 @@
 
 using namespace qamd;
 
-namespace {
+// One source, several translation units.  The library has ~200 kernel instantiations (most of them bench-only schedule
+// variants and ablations kept selectable because their measurements are part of the design record); compiled as one
+// unit that is 3.5 minutes of hipcc.  build.py compiles this file once per QAMD_TU value in parallel: every heavy
+// template family is instantiated in exactly one unit (explicit instantiation) and only declared (`extern template`) in
+// the others.  QAMD_TU = 0 (a plain `hipcc capi.hip`) still gives the whole library in one unit.
+//   1  C entry points, dispatch rules, small kernels      2  MXFP4 tile / schedule variants      3  MXFP8 variants
+//   4  NVFP4 kernels                                      5  fused quantizers                    6  MXFP4 ablations (100+, 200+, 300+)
+//   7  NVFP4 v2 ablations (gemm_nvf4.hip.h)
+#ifndef QAMD_TU
+#define QAMD_TU 0
+#endif
+#define QAMD_DEF(n) (QAMD_TU == 0 || QAMD_TU == (n))
 
+namespace qamd_host {
+
+#if QAMD_DEF(1)
 thread_local char g_err[512] = "";
 std::atomic<int> g_hw_fp4_cvt{1};   // device-verified bit-identical to the software encoder (tests/native/probe.hip P2)
 std::atomic<int> g_gemm_variant{0};
@@ -44,6 +58,11 @@ int check_launch(const char* what) {
   if (e != hipSuccess) return fail(QAMD_ERR_HIP, "%s: %s", what, hipGetErrorString(e));
   return QAMD_OK;
 }
+#else
+extern std::atomic<int> g_hw_fp4_cvt;
+int fail(int code, const char* fmt, ...);
+int check_launch(const char* what);
+#endif
 
 inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
@@ -68,13 +87,35 @@ int launch_gemm(GemmParams p, hipStream_t s) {
 // which kernels it WOULD launch -- {variant, N of the launch, K splits} per launch -- so the auto rules are testable on a
 // machine without a GPU (tests/test_cabi_and_host.py).
 struct DryRun { bool on = false; int n = 0; int rec[8][3]; };
+#if QAMD_DEF(1)
 thread_local DryRun t_dry;
+#else
+extern thread_local DryRun t_dry;
+#endif
 inline bool dry_record(int variant, int n_cols, int splits) {
   if (!t_dry.on) return false;
   if (t_dry.n < 8) { t_dry.rec[t_dry.n][0] = variant; t_dry.rec[t_dry.n][1] = n_cols; t_dry.rec[t_dry.n][2] = splits; }
   ++t_dry.n;
   return true;
 }
+
+// bench-only ablations of the 8-wave 256x256 MXFP4 schedules: 100 + b ping-pong, 200 + b lockstep, 300 + b queue, b = OR
+// of ABL_* bits.  Returns -1 for any other variant.
+#if QAMD_DEF(6)
+int dispatch_ablation_mx4(int v, const GemmParams& p, hipStream_t s) {
+  switch (v) {
+#define QAMD_ABL(b) \
+    case 100 + b: return launch_gemm<GemmCfg<256, 256, 2, 4, 4, false, b>, 1>(p, s); \
+    case 200 + b: return launch_gemm<GemmCfg<256, 256, 2, 4, 4, false, b>, 0>(p, s); \
+    case 300 + b: return launch_gemm<GemmCfg<256, 256, 2, 4, 4, false, b>, 2>(p, s);
+    QAMD_ABL(1) QAMD_ABL(2) QAMD_ABL(3) QAMD_ABL(4) QAMD_ABL(8) QAMD_ABL(9) QAMD_ABL(10) QAMD_ABL(11) QAMD_ABL(16) QAMD_ABL(17) QAMD_ABL(18) QAMD_ABL(41) QAMD_ABL(40) QAMD_ABL(42)
+#undef QAMD_ABL
+  }
+  return -1;
+}
+#else
+int dispatch_ablation_mx4(int v, const GemmParams& p, hipStream_t s);
+#endif
 
 template <int EBITS, bool SPLIT>
 int dispatch_variant(int v, const GemmParams& p, hipStream_t s, const char* name) {
@@ -138,18 +179,38 @@ int dispatch_variant(int v, const GemmParams& p, hipStream_t s, const char* name
     }
   }
   if constexpr (EBITS == 4 && !SPLIT) {
-    switch (v) {
-#define QAMD_ABL(b) \
-      case 100 + b: return launch_gemm<GemmCfg<256, 256, 2, 4, 4, false, b>, 1>(p, s); \
-      case 200 + b: return launch_gemm<GemmCfg<256, 256, 2, 4, 4, false, b>, 0>(p, s); \
-      case 300 + b: return launch_gemm<GemmCfg<256, 256, 2, 4, 4, false, b>, 2>(p, s);
-      QAMD_ABL(1) QAMD_ABL(2) QAMD_ABL(3) QAMD_ABL(4) QAMD_ABL(8) QAMD_ABL(9) QAMD_ABL(10) QAMD_ABL(11) QAMD_ABL(16) QAMD_ABL(17) QAMD_ABL(18) QAMD_ABL(41) QAMD_ABL(40) QAMD_ABL(42)
-#undef QAMD_ABL
-    }
+    const int rc = dispatch_ablation_mx4(v, p, s);
+    if (rc >= 0) return rc;
   }
   return fail(QAMD_ERR_INVALID, "%s: unknown gemm_variant %d", name, v);
 }
 
+#if QAMD_TU != 0
+#if QAMD_TU == 2
+template int dispatch_variant<4, false>(int, const GemmParams&, hipStream_t, const char*);
+#else
+extern template int dispatch_variant<4, false>(int, const GemmParams&, hipStream_t, const char*);
+#endif
+#if QAMD_TU == 3
+template int dispatch_variant<8, true>(int, const GemmParams&, hipStream_t, const char*);
+template int launch_gemm<GemmCfg<256, 256, 2, 2, 8, true>, 6>(GemmParams, hipStream_t);   // fused (K, M) operand path of matmul_mxf8_bf16_nn
+#else
+extern template int dispatch_variant<8, true>(int, const GemmParams&, hipStream_t, const char*);
+extern template int launch_gemm<GemmCfg<256, 256, 2, 2, 8, true>, 6>(GemmParams, hipStream_t);
+#endif
+#endif
+
+// NVFP4 launches live in their own unit
+#if QAMD_DEF(4)
+int launch_nvf4_host(const NvGemmParams& p, hipStream_t s, int variant) {
+  (void)launch_nvf4_gemm(p, s, variant);
+  return 0;
+}
+#else
+int launch_nvf4_host(const NvGemmParams& p, hipStream_t s, int variant);
+#endif
+
+#if QAMD_DEF(1)
 // EBITS: 4 = MXFP4, 8 = MXFP8 (TN)
 // Small-output regime: ring schedule (one workgroup per CU with several stages in flight beats the 2-stage simple schedule
 // whenever the tiles do not fill the chip twice), plus split-K over grid.y when 64x64 tiles leave CUs idle and K is long
@@ -286,6 +347,8 @@ int gemm_mx(const char* name, const void* A, const void* B, const void* A_sf, co
   return dispatch_variant<EBITS, EBITS == 8>(variant, p, s, name);
 }
 
+#endif   // QAMD_DEF(1)
+
 template <int R, bool NV, int METHOD, bool MASK>
 int launch_quant(const QuantParams& p, hipStream_t s, int grid) {
   if (g_hw_fp4_cvt.load())
@@ -313,6 +376,21 @@ int dispatch_rot(int rot, const QuantParams& p, hipStream_t s, int grid, const c
   return fail(QAMD_ERR_INVALID, "%s: Unsupported rotation size %d; expected %s32, 64, or 128.", name, rot, NV ? "16, " : "");
 }
 
+#if QAMD_TU != 0
+#if QAMD_TU == 5
+#define QAMD_ROT_INST template
+#else
+#define QAMD_ROT_INST extern template
+#endif
+QAMD_ROT_INST int dispatch_rot<false, METHOD_QUEST, true>(int, const QuantParams&, hipStream_t, int, const char*);
+QAMD_ROT_INST int dispatch_rot<false, METHOD_QUEST, false>(int, const QuantParams&, hipStream_t, int, const char*);
+QAMD_ROT_INST int dispatch_rot<false, METHOD_ABSMAX, false>(int, const QuantParams&, hipStream_t, int, const char*);
+QAMD_ROT_INST int dispatch_rot<true, METHOD_QUEST, false>(int, const QuantParams&, hipStream_t, int, const char*);
+QAMD_ROT_INST int dispatch_rot<true, METHOD_ABSMAX, false>(int, const QuantParams&, hipStream_t, int, const char*);
+#undef QAMD_ROT_INST
+#endif
+
+#if QAMD_DEF(1)
 std::atomic<int> g_quant_wg_per_cu{0};   // 0 = auto
 
 int quant_grid(int ntiles, int rot) {
@@ -326,8 +404,13 @@ int quant_grid(int ntiles, int rot) {
   return g < 1 ? 1 : (g > cap ? cap : g);
 }
 
-}  // namespace
+#endif   // QAMD_DEF(1)
 
+}  // namespace qamd_host
+
+using namespace qamd_host;
+
+#if QAMD_DEF(1)
 extern "C" {
 
 int qutlass_amd_matmul_mxf4_bf16_tn(const void* A, const void* B, const void* A_sf, const void* B_sf,
@@ -403,7 +486,7 @@ int qutlass_amd_matmul_mxf8_bf16_nn(const void* A, const void* B, const void* A_
   }
   TransposeParams t;
   t.in = (const uint8_t*)A; t.out = (uint8_t*)workspace; t.K = (int)K; t.M = (int)M;
-  hipLaunchKernelGGL(transpose_u8_kernel, dim3((unsigned)cdiv(M, 128), (unsigned)cdiv(K, 128)), dim3(256), 0, (hipStream_t)stream, t);
+  hipLaunchKernelGGL(transpose_u8_kernel<>, dim3((unsigned)cdiv(M, 128), (unsigned)cdiv(K, 128)), dim3(256), 0, (hipStream_t)stream, t);
   if (int rc = check_launch("transpose_u8_kernel")) return rc;
   return gemm_mx<8>(name, workspace, B, A_sf, B_sf, alpha, D, M, N, K, stream);
 }
@@ -424,7 +507,7 @@ int qutlass_amd_matmul_nvf4_bf16_tn(const void* A, const void* B, const void* A_
   p.a_bytes = (uint32_t)(M * (K / 2)); p.b_bytes = (uint32_t)(N * (K / 2));
   p.sfa_bytes = (uint32_t)(cdiv(M, 128) * CB * 512); p.sfb_bytes = (uint32_t)(cdiv(N, 128) * CB * 512);
   p.dbg = g_dbg.load();
-  (void)launch_nvf4_gemm(p, (hipStream_t)stream, g_nvf4_variant.load());
+  launch_nvf4_host(p, (hipStream_t)stream, g_nvf4_variant.load());
   return check_launch(name);
 }
 
@@ -516,7 +599,7 @@ int qutlass_amd_backward_bf16_square_double_mxfp8(const void* x, int64_t m, int6
   SqParams p;
   p.x = (const uint16_t*)x; p.y = (uint8_t*)y; p.row_sf = (uint8_t*)row_scales; p.col_sf = (uint8_t*)col_scales;
   p.m = (int)m; p.n = (int)n;
-  hipLaunchKernelGGL(bwd_square_double_mxfp8_kernel, dim3((unsigned)((m / 128) * (n / 128))), dim3(256), 0, (hipStream_t)stream, p);
+  hipLaunchKernelGGL(bwd_square_double_mxfp8_kernel<>, dim3((unsigned)((m / 128) * (n / 128))), dim3(256), 0, (hipStream_t)stream, p);
   return check_launch("bwd_square_double_mxfp8_kernel");
 }
 
@@ -596,3 +679,4 @@ int qutlass_amd_set_option(const char* key, int value) {
 }
 
 }  // extern "C"
+#endif   // QAMD_DEF(1)

@@ -198,11 +198,12 @@ __global__ __launch_bounds__(C::THREADS) void gemm_nvf4_kernel(const NvGemmParam
 
   // A stage is 16 k-steps of 16 elements: step s = (j, u) with chunk j = s / 4 (scale column tile jj = j / 2, byte pair
   // jl = j % 2) and dword u = s % 4.  Software pipeline with TWO fragment register sets: the converts of step s + 1 write
-  // set (s + 1) & 1 while the MFMAs of step s read set s & 1, and the sched_group_barrier pattern asks for "1 MFMA, then
-  // its share of the next step's converts", so a single wave keeps the matrix pipe fed.  Measured: 8192^3 with
-  // zero-filled operands (not power limited) 762 -> 691 us; random operands unchanged (power cap); small tiles unchanged --
-  // they are bound by the VALU itself (8 packed-f16 converts / multiplies per 8 elements at ~6 cycles each,
-  // tests/native/ubench.hip "valu": 512 of them per stage and wave of a 128x128 tile = 1.6 us).
+  // set (s + 1) & 1 while the MFMAs of step s read set s & 1, so the scheduler is free to run one step's MFMAs under the
+  // next step's converts.  (An explicit "1 MFMA : n VALU" sched_group_barrier pattern gave the same ISA shape but cost
+  // 150 s of compile time for the five tile configurations; not kept.)  Measured: 8192^3 with zero-filled operands (not
+  // power limited) 762 -> 691 us; random operands unchanged (power cap); small tiles unchanged -- they are bound by the
+  // VALU itself (8 packed-f16 converts / multiplies per 8 elements at ~6 cycles each, tests/native/ubench.hip "valu": 512
+  // of them per stage and wave of a 128x128 tile = 1.6 us).
   auto compute_stage = [&](int buf) {
     const char* st = smem + buf * C::STAGE_BYTES;
     h2_t sa[2][MT][2], sb[2][NT][2];     // [jj & 1][.][jl]
@@ -248,14 +249,6 @@ __global__ __launch_bounds__(C::THREADS) void gemm_nvf4_kernel(const NvGemmParam
 #pragma unroll
         for (int n = 0; n < NT; ++n)
           acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb[s & 1][n], fa[s & 1][m], acc[m][n], 0, 0, 0);
-      if (s + 1 < 16) {
-        constexpr int VPM = ((MT + NT) * 8 + MT * NT - 1) / (MT * NT);   // converts of the next step per MFMA of this one
-#pragma unroll
-        for (int i = 0; i < MT * NT; ++i) {
-          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);     // 1 MFMA
-          __builtin_amdgcn_sched_group_barrier(0x002, VPM, 0);   // VPM VALU
-        }
-      }
     }
   };
 
@@ -616,6 +609,32 @@ __global__ __launch_bounds__(NWAVES * 64) void gemm_nvf4_skinny_kernel(const NvG
 
 // variant: 3 = small-batch split-K kernel (auto for M <= 32); otherwise 0 = auto = 1 (per-wave dequant; measured equal or slightly faster than v2 on every shape,
 // profiles/native_r1_nvfp4_ablation.log -- both are power-bound at the same wall time), 2 = v2 (LDS dequant)
+// (Host launchers are compiled only into the translation unit that owns them -- capi.hip, QAMD_TU: a kernel template that
+// an inline launcher merely MENTIONS is instantiated by the device pass of every unit that sees the launcher.)
+#ifndef QAMD_TU
+#define QAMD_TU 0
+#endif
+#if QAMD_TU == 0 || QAMD_TU == 7
+// bench-only ablations of the v2 kernel (variant 10 + b); returns false for any other variant.  (Not inline: the unit that
+// owns it must emit it.)
+bool launch_nvf4_ablation(NvGemmParams p, hipStream_t s, int variant) {
+#define QAMD_NV_ABL(b)                                                                                          \
+  if (variant == 10 + b) {                                                                                     \
+    using C = NvLdsCfg<256, 256, 2, 4, b>;                                                                     \
+    p.tiles_m = (p.M + C::BM - 1) / C::BM;                                                                     \
+    p.tiles_n = (p.N + C::BN - 1) / C::BN;                                                                     \
+    hipLaunchKernelGGL((gemm_nvf4_lds_kernel<C>), dim3(p.tiles_m * p.tiles_n), dim3(C::THREADS), 0, s, p);     \
+    return true;                                                                                               \
+  }
+  QAMD_NV_ABL(1) QAMD_NV_ABL(2) QAMD_NV_ABL(3) QAMD_NV_ABL(4) QAMD_NV_ABL(5) QAMD_NV_ABL(6) QAMD_NV_ABL(8) QAMD_NV_ABL(9) QAMD_NV_ABL(11)
+#undef QAMD_NV_ABL
+  return false;
+}
+#else
+bool launch_nvf4_ablation(NvGemmParams p, hipStream_t s, int variant);
+#endif
+
+#if QAMD_TU == 0 || QAMD_TU == 4
 inline hipError_t launch_nvf4_gemm(NvGemmParams p, hipStream_t s, int variant = 0) {
   // 128x128 tiles when a dimension is small OR when 256x256 tiles would leave most CUs without work
   const bool small = p.M <= 128 || p.N <= 128 || (int64_t)((p.M + 255) / 256) * ((p.N + 255) / 256) < 192;
@@ -657,16 +676,7 @@ inline hipError_t launch_nvf4_gemm(NvGemmParams p, hipStream_t s, int variant = 
     QAMD_NV_LAUNCH(64, 64, 2, 2)
 #undef QAMD_NV_LAUNCH
   }
-#define QAMD_NV_ABL(b)                                                                                          \
-  if (variant == 10 + b) {                                                                                     \
-    using C = NvLdsCfg<256, 256, 2, 4, b>;                                                                     \
-    p.tiles_m = (p.M + C::BM - 1) / C::BM;                                                                     \
-    p.tiles_n = (p.N + C::BN - 1) / C::BN;                                                                     \
-    hipLaunchKernelGGL((gemm_nvf4_lds_kernel<C>), dim3(p.tiles_m * p.tiles_n), dim3(C::THREADS), 0, s, p);     \
-    return hipSuccess;                                                                                         \
-  }
-  QAMD_NV_ABL(1) QAMD_NV_ABL(2) QAMD_NV_ABL(3) QAMD_NV_ABL(4) QAMD_NV_ABL(5) QAMD_NV_ABL(6) QAMD_NV_ABL(8) QAMD_NV_ABL(9) QAMD_NV_ABL(11)
-#undef QAMD_NV_ABL
+  if (variant >= 10 && launch_nvf4_ablation(p, s, variant)) return hipSuccess;
   if (small) {
     using C = NvLdsCfg<128, 128, 2, 2>;
     p.tiles_m = (p.M + C::BM - 1) / C::BM;
@@ -680,5 +690,6 @@ inline hipError_t launch_nvf4_gemm(NvGemmParams p, hipStream_t s, int variant = 
   }
   return hipSuccess;
 }
+#endif   // QAMD_TU == 0 || QAMD_TU == 4
 
 }  // namespace qamd

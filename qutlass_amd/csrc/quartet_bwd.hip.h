@@ -209,6 +209,7 @@ __device__ __forceinline__ uint32_t e8m0_shift7(float amax) {
 }
 __device__ __forceinline__ float e8m0_scale(uint32_t e) { return __uint_as_float(e ? (e << 23) : 0x00400000u); }
 
+template <int UNIT = 0>   // (a template only so that the kernel is emitted by the one translation unit that launches it)
 __global__ __launch_bounds__(256) void bwd_square_double_mxfp8_kernel(const SqParams p) {
   __shared__ uint8_t es[4][4];   // [wave = row block][column block]
   const int tid = threadIdx.x, lane = tid & 63, wave = uniform(tid >> 6);

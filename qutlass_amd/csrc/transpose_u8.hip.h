@@ -33,6 +33,7 @@ __device__ __forceinline__ void transpose4x4_u8(const uint32_t r0, const uint32_
   c[3] = __builtin_amdgcn_perm(u1, t1, 0x07060302u);
 }
 
+template <int UNIT = 0>   // (a template only so that the kernel is emitted by the one translation unit that launches it)
 __global__ __launch_bounds__(256) void transpose_u8_kernel(const TransposeParams p) {
   constexpr int LROW = 128 + 4;   // bytes per LDS row (33 dwords)
   __shared__ __attribute__((aligned(16))) uint8_t tile[128 * LROW];
