@@ -42,7 +42,7 @@ def build_kernels(force: bool = False, verbose: bool = False) -> str:
     objects are linked into libqutlass_amd.so.  QAMD_SINGLE_TU=1 in the environment compiles it as one unit instead."""
     if force or _stale(OUT, _kernel_sources()):
         hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
-        base = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
+        base = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden"]
         if os.environ.get("QAMD_SINGLE_TU"):
             cmd = base + ["-shared", SRC, "-o", OUT]
             if verbose:

@@ -411,6 +411,8 @@ int quant_grid(int ntiles, int rot) {
 using namespace qamd_host;
 
 #if QAMD_DEF(1)
+// the library is built with -fvisibility=hidden: only the C ABI below is exported
+#pragma GCC visibility push(default)
 extern "C" {
 
 int qutlass_amd_matmul_mxf4_bf16_tn(const void* A, const void* B, const void* A_sf, const void* B_sf,
@@ -679,4 +681,5 @@ int qutlass_amd_set_option(const char* key, int value) {
 }
 
 }  // extern "C"
+#pragma GCC visibility pop
 #endif   // QAMD_DEF(1)
