@@ -788,6 +788,15 @@ int main(int argc, char** argv) {
     }
     qutlass_amd_set_option("splitk_min_kt", 32);
   }
+  if (want("big")) {   // the largest shapes of the reference's benchmark sweep (M up to 65536): 32-bit offset arithmetic, sampled rows vs the oracle
+    check_gemm("gemm_mxfp4 65536x4096x4096 (48 sampled rows)", 0, 65536, 4096, 4096, 1.0f, 3, 48, 0);
+    check_gemm("gemm_mxfp4 32768x8192x8192 (32 sampled rows)", 0, 32768, 8192, 8192, 0.5f, 3, 32, 0);
+    check_gemm("gemm_mxfp4 8x57344x8192 (all rows)", 0, 8, 57344, 8192, 1.0f, 3, 0, 0);
+    check_gemm("gemm_mxfp8 32768x4096x4096 (32 sampled rows)", 2, 32768, 4096, 4096, 1.0f, 3, 32, 0, true);
+    check_gemm("gemm_nvfp4 32768x4096x4096 (32 sampled rows)", 1, 32768, 4096, 4096, 1.0f, 3, 32, 0);
+    bench_gemm("mxfp4 65536x4096x4096", 0, 65536, 4096, 4096, 0, 5);
+    bench_gemm("mxfp4 32768x8192x8192", 0, 32768, 8192, 8192, 0, 3);
+  }
   if (want("rtrace")) {   // ring schedule timeline, workgroup 0: per stage [wait own DMA | barrier | issue DMA | fragment reads | MFMA issue]
     for (int64_t M : {64, 256}) {
       const int64_t N = 4096, K = 4096;

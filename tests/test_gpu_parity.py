@@ -270,6 +270,27 @@ def test_split_k_small_output_long_k(q, m, n, k):
     assert np.array_equal(_np(out)[rows], ref)
 
 
+def test_matmul_mxf4_largest_sweep_shape_row_samples(q):
+    """M = 65536 is the top of the reference's benchmark sweep (benchmarks/bench_mxfp4_sm100.py:176-194): tile offsets
+    approach 2^31 bytes.  Random codes, scales within 3 binades (exact regime) -> sampled rows must match the oracle bit
+    for bit, including the last row."""
+    from qutlass_amd.utils import to_blocked
+
+    m, n, k = 65536, 4096, 4096
+    g = torch.Generator(device="cpu").manual_seed(7)
+    a = torch.randint(0, 256, (m, k // 2), dtype=torch.uint8, generator=g).to(DEV)
+    b = torch.randint(0, 256, (n, k // 2), dtype=torch.uint8, generator=g).to(DEV)
+    sa = torch.randint(126, 129, (m, k // 32), dtype=torch.uint8, generator=g)
+    sb = torch.randint(126, 129, (n, k // 32), dtype=torch.uint8, generator=g)
+    e8 = torch.float8_e8m0fnu
+    out = q.matmul_mxf4_bf16_tn(a, b, to_blocked(sa.to(DEV).view(e8)), to_blocked(sb.to(DEV).view(e8)), torch.tensor([1.0], device=DEV))
+    rows = [0, 1, 255, 256, 32767, 32768, 40001, 65279, 65280, 65534, 65535]
+    a_s = np.ascontiguousarray(_np(a[rows]))
+    sa_s = np.concatenate([sa.numpy()[rows], np.zeros((128 - len(rows), k // 32), np.uint8)])
+    ref = oracle.gemm_blockscaled(oracle.KIND_MXFP4, a_s, _np(b), oracle.to_blocked(sa_s), oracle.to_blocked(sb.numpy()), 1.0, len(rows), n, k)
+    assert np.array_equal(_np(out[rows]), ref)
+
+
 def test_matmul_mxf4_errors(q):
     u8 = torch.zeros(128, 64, dtype=torch.uint8, device=DEV)
     sf = torch.zeros(128 * 4, dtype=torch.float8_e8m0fnu, device=DEV)
