@@ -116,6 +116,7 @@ Tensor matmul(const Tensor& A, const Tensor& B, const Tensor& A_sf, const Tensor
   const int64_t N = B.size(0), K = B.size(1) * (fp8 ? 1 : 2);
 
   Tensor out = torch::stable::new_empty(A, {M, N}, ScalarType::BFloat16);
+  if (M == 0 || N == 0) return out;   // empty batch / empty weight: nothing to launch (the C ABI requires positive extents)
   const torch::stable::accelerator::DeviceGuard guard(A.get_device_index());
   const float* al = static_cast<const float*>(alpha.data_ptr());
   void* s = current_stream(A);

@@ -291,6 +291,21 @@ def test_matmul_mxf4_largest_sweep_shape_row_samples(q):
     assert np.array_equal(_np(out[rows]), ref)
 
 
+def test_matmul_empty_batch_returns_empty_output(q):
+    """An empty batch (M = 0) is a valid call at the op level: (0, N) bf16, nothing launched."""
+    e8 = torch.float8_e8m0fnu
+    b = torch.zeros(64, 64, dtype=torch.uint8, device=DEV)
+    bsf = torch.zeros(128 * 4, dtype=torch.uint8, device=DEV).view(e8)
+    a = torch.zeros(0, 64, dtype=torch.uint8, device=DEV)
+    asf = torch.zeros(0, dtype=torch.uint8, device=DEV).view(e8)
+    al = torch.tensor([1.0], device=DEV)
+    for fn in (q.matmul_mxf4_bf16_tn, q.matmul_ada_mxf4_bf16_tn):
+        out = fn(a, b, asf, bsf, al)
+        assert out.shape == (0, 64) and out.dtype == torch.bfloat16
+    out = q.matmul_nvf4_bf16_tn(a, b, asf.view(torch.uint8).view(torch.float8_e4m3fn), bsf.view(torch.uint8).view(torch.float8_e4m3fn), al)
+    assert out.shape == (0, 64)
+
+
 def test_matmul_mxf4_errors(q):
     u8 = torch.zeros(128, 64, dtype=torch.uint8, device=DEV)
     sf = torch.zeros(128 * 4, dtype=torch.float8_e8m0fnu, device=DEV)
