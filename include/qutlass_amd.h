@@ -47,8 +47,9 @@ int qutlass_amd_matmul_mxf4_bf16_tn(const void* A, const void* B, const void* A_
 
 /*
  * MXFP4, small-batch variant: same operands, but A_sf / B_sf are the UN-swizzled row-major (M, K/32) / (N, K/32) e8m0
- * matrices (what fusedQuantizeMx writes, without to_blocked).  Any M is accepted; the kernel is built for M <= 32
- * (weight-bandwidth bound split-K, no LDS staging).  K % 128 == 0, N % 8 == 0.
+ * matrices (what fusedQuantizeMx writes, without to_blocked).  Any M is accepted; built for small batches: an LDS-free
+ * split-K kernel for M <= 32 against a small weight, the 64x64 ring kernel with row-major scale fetch for N >= 8192 or
+ * M > 32 (both weight-bandwidth bound).  K % 128 == 0, N % 8 == 0.
  * Replaces matmul_host_ada_mxf4_bf16_tn (qutlass/csrc/gemm_ada.cu:30-135; bindings.cpp:104-138; scale addressing
  * cutlass_extensions/gemm/threadblock/mx_mma_multistage.h:418-448).
  */

@@ -70,7 +70,7 @@ template <class C, int PP>
 int launch_gemm(GemmParams p, hipStream_t s) {
   p.tiles_m = (int)cdiv(p.M, C::BM);
   p.tiles_n = (int)cdiv(p.N, C::BN);
-  if (PP != 7) { p.ws = nullptr; p.splits = 1; }   // only the ring schedule knows about split-K
+  if (PP != 7) { p.ws = nullptr; p.splits = 1; }   // only the (blocked-scale) ring schedule knows about split-K
   hipLaunchKernelGGL((gemm_mx_kernel<C, PP>), dim3(p.tiles_m * p.tiles_n, p.splits), dim3(C::THREADS), 0, s, p);
   return check_launch("gemm_mx_kernel");
 }
@@ -444,6 +444,24 @@ int qutlass_amd_matmul_ada_mxf4_bf16_tn(const void* A, const void* B, const void
   if (K < 128 || K % 128) return fail(QAMD_ERR_INVALID, "%s: K must be a positive multiple of 128 (got %lld)", name, (long long)K);
   if (N % 8) return fail(QAMD_ERR_INVALID, "%s: N must be a multiple of 8 (got %lld)", name, (long long)N);
   if (M * (K / 2) >= (1ll << 31) || N * (K / 2) >= (1ll << 31)) return fail(QAMD_ERR_INVALID, "%s: operand larger than 2 GiB is not supported", name);
+  // Same regimes as matmul_mxf4_bf16_tn: the LDS-free split-K kernel while the weight has fewer than 128 64-row tiles;
+  // from 128 tiles on (N >= 8192) the 64x64 ring kernel with row-major scale fetch streams the weight through full-line
+  // LDS-DMA (M = 16: N = 14336, K = 4096 9.7 -> 6.9 us; N = 57344, K = 8192 62.6 -> 39.9 us), and any M > 32 goes there
+  // too ("gemm_variant" 60 / 70 force either).
+  const int forced = g_gemm_variant.load();
+  const int64_t T64 = cdiv(N, 64);   // (no split-K here -- the op has no scratch argument -- so a long K on few tiles stays with the split-K kernel:
+                                     //  8 x 8192 x 28672: 27.9 us vs 34.2 us on 128 workgroups of the ring kernel)
+  const bool ring = forced == 70 || (forced != 60 && (M > 32 || T64 >= 256 || (T64 >= 128 && K < 16384)));
+  if (ring) {
+    GemmParams p;
+    p.A = (const uint8_t*)A; p.B = (const uint8_t*)B; p.SFA = (const uint8_t*)A_sf; p.SFB = (const uint8_t*)B_sf;
+    p.alpha = alpha; p.D = (uint16_t*)D; p.M = (int)M; p.N = (int)N; p.K = (int)K; p.ldd = (int)N;
+    p.a_bytes = (uint32_t)(M * (K / 2)); p.b_bytes = (uint32_t)(N * (K / 2));
+    p.sfa_bytes = (uint32_t)(M * (K / 32)); p.sfb_bytes = (uint32_t)(N * (K / 32));   // row-major (rows, K/32), un-swizzled
+    p.pp_shift = g_pp_shift.load(); p.pp_flags = g_pp_flags.load(); p.dbg = g_dbg.load();
+    p.ws = nullptr; p.splits = 1;
+    return launch_gemm<GemmCfg<64, 64, 2, 2, 4, false, 0, 3>, 8>(p, (hipStream_t)stream);
+  }
   SkinnyParams q;
   q.A = (const uint8_t*)A; q.B = (const uint8_t*)B; q.SFA = (const uint8_t*)A_sf; q.SFB = (const uint8_t*)B_sf;
   q.alpha = alpha; q.D = (uint16_t*)D; q.M = (int)M; q.N = (int)N; q.K = (int)K;

@@ -1309,12 +1309,31 @@ __device__ __forceinline__ void gemm_mx_regstage(char* smem, const GemmParams& p
 // Stages past K are issued with out-of-range offsets (zero fill), which keeps the vmcnt arithmetic uniform.
 // Same K order per output as every other schedule -> bit-identical results.
 // ================================================================================================
-template <class C>
+// RM = true: SFA / SFB are the UN-swizzled row-major (rows, K/32) scale matrices of matmul_ada_mxf4_bf16_tn (64x64 fp4
+// tiles only): per stage wave w fetches dword (w & 1) of the 8 scale bytes of the 64 rows of operand (w >> 1) -- lane =
+// row, 4 bytes each -- into [operand][dword][row] in the stage's scale area, and a lane's scale dword for its K-blocks
+// 4g .. 4g+3 is [operand][g][row].
+template <class C, bool RM = false>
 __device__ __forceinline__ void gemm_mx_ring(char* smem, const GemmParams& p) {
   constexpr int KSL = C::KSL, D = C::NSTAGE;
   constexpr int LPS = C::NA + C::NB + 1;            // DMA instructions per wave per stage
   static_assert(D >= 3 && (D - 2) * LPS <= 63, "vmcnt immediate");
+  static_assert(!RM || (C::EBITS == 4 && C::BM == 64 && C::BN == 64 && C::NWAVES == 4), "row-major scales: 64x64 fp4 tiles");
   GemmCtx<C> cx(smem, p);
+  __amdgpu_buffer_rsrc_t rSrm = cx.rS;
+  int vSrm = 0x7fffffff;
+  const int KBr = p.K >> 5;                         // scale bytes per row (row-major)
+  if (RM) {
+    const int opB = cx.wave >> 1, dw = cx.wave & 1;
+    const uint32_t row0 = opB ? (uint32_t)cx.n0 : (uint32_t)cx.m0;
+    const uint32_t total = opB ? p.sfb_bytes : p.sfa_bytes, off = row0 * (uint32_t)KBr;
+    rSrm = make_rsrc((opB ? p.SFB : p.SFA) + off, total > off ? total - off : 0);   // rows past M / N fall off the end -> 0
+    vSrm = cx.lane * KBr + dw * 4;
+#pragma unroll
+    for (int t = 0; t < C::MT; ++t) cx.rdSA[t] = C::OFF_S + cx.g * 256 + (cx.wave_m * C::WTM + 32 * t + cx.i32) * 4;
+#pragma unroll
+    for (int t = 0; t < C::NT; ++t) cx.rdSB[t] = C::OFF_S + 512 + cx.g * 256 + (cx.wave_n * C::WTN + 32 * t + cx.i32) * 4;
+  }
   auto fence = [&]() __attribute__((always_inline)) { __builtin_amdgcn_sched_barrier(0); };
   // K range of this workgroup (split-K: grid.y = splits, every split non-empty by construction on the host)
   int kt0 = 0, kt1 = cx.KT;
@@ -1357,8 +1376,13 @@ __device__ __forceinline__ void gemm_mx_ring(char* smem, const GemmParams& p) {
       const int v = (vBT[t] & lastmask) | (vB[t] & ~lastmask);
       __builtin_amdgcn_raw_ptr_buffer_load_lds(cx.rB, (lds_ptr_t)(st + C::OFF_B + (cx.wave * C::NB + t) * 1024), 16, v, soff, 0, QAMD_DMA_AUX);
     }
-    const int vs = (ktc * C::SCT + cx.colS < cx.CB) ? cx.voffS : 0x7fffffff;   // K tail: no such scale column tile
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(cx.rS, (lds_ptr_t)(st + C::OFF_S + cx.wave * 1024), 16, vs, ktc * C::SCT * 512, 0, 0);
+    if (RM) {
+      const int vs = (ktc * 8 + (cx.wave & 1) * 4 < KBr) ? vSrm : 0x7fffffff;   // K tail: the stage's second scale dword does not exist
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rSrm, (lds_ptr_t)(st + C::OFF_S + cx.wave * 256), 4, vs, ktc * 8, 0, 0);
+    } else {
+      const int vs = (ktc * C::SCT + cx.colS < cx.CB) ? cx.voffS : 0x7fffffff;   // K tail: no such scale column tile
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(cx.rS, (lds_ptr_t)(st + C::OFF_S + cx.wave * 1024), 16, vs, ktc * C::SCT * 512, 0, 0);
+    }
   };
   auto stage = [&](int kt, const int slot) __attribute__((always_inline)) {
     cx.trace();   // (ABL_TRACE builds only) 0: stage begin
@@ -1427,7 +1451,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 }
 
 // One __global__ entry per (config, schedule).
-enum { SCHED_LOCKSTEP = 0, SCHED_PINGPONG = 1, SCHED_QUEUE = 2, SCHED_SIMPLE = 3, SCHED_DEEP = 4, SCHED_REGSTAGE = 5, SCHED_DEEP_NN = 6, SCHED_RING = 7 };
+enum { SCHED_LOCKSTEP = 0, SCHED_PINGPONG = 1, SCHED_QUEUE = 2, SCHED_SIMPLE = 3, SCHED_DEEP = 4, SCHED_REGSTAGE = 5, SCHED_DEEP_NN = 6, SCHED_RING = 7, SCHED_RING_RM = 8 };
 template <class C, int SCHED>
 __global__ __launch_bounds__(C::THREADS) void gemm_mx_kernel(const GemmParams p) {
   __shared__ __attribute__((aligned(16))) char smem[C::LDS_BYTES];
@@ -1435,7 +1459,8 @@ __global__ __launch_bounds__(C::THREADS) void gemm_mx_kernel(const GemmParams p)
   // 100 MHz wall-clock duration, i.e. the clock the chip actually ran at under this kernel's power draw
   const bool clk = (C::ABL & ABL_CLOCK) && p.dbg && blockIdx.x == 0 && threadIdx.x == 0;
   const uint64_t c0 = clk ? __builtin_readcyclecounter() : 0, r0 = clk ? __builtin_amdgcn_s_memrealtime() : 0;
-  if constexpr (SCHED == SCHED_RING) gemm_mx_ring<C>(smem, p);
+  if constexpr (SCHED == SCHED_RING_RM) gemm_mx_ring<C, true>(smem, p);
+  else if constexpr (SCHED == SCHED_RING) gemm_mx_ring<C>(smem, p);
   else if constexpr (SCHED == SCHED_REGSTAGE) gemm_mx_regstage<C>(smem, p);
   else if constexpr (SCHED == SCHED_DEEP_NN) gemm_mx_deep8<C, true>(smem, p);
   else if constexpr (SCHED == SCHED_DEEP && C::EBITS == 8) gemm_mx_deep8<C, false>(smem, p);
