@@ -118,6 +118,14 @@ __global__ __launch_bounds__(256) void fused_quantize_kernel(const QuantParams p
   constexpr int JT = RP / 32;                   // 32-wide j tiles per row = MX groups per row
   constexpr int HROW = RP * 2 + 16;             // padded H^T row stride in LDS (bytes)
   __shared__ __attribute__((aligned(16))) char hT[RP * HROW];
+  // R >= 64: a tile's rows are 128 / 256 bytes apart, and a load in MFMA layout (lane = row, 16 bytes) touches 32 lines
+  // for 32 bytes each -- every line four to eight times over the tile's loads, from an L1 that the other waves' tiles
+  // have long flushed (R = 128: 11.6 us for 4096^2 against 6.9 us at R = 32).  Those sizes load their tile as ONE
+  // contiguous run (64 lanes x 16 bytes = 1 KiB per instruction), stage it in a wave-private LDS area and read the MFMA
+  // fragments from there.
+  constexpr bool STAGED = RP >= 64;
+  constexpr int XROW = RP * 2 + 16;              // staged row stride (bytes)
+  __shared__ __attribute__((aligned(16))) char xs_all[STAGED ? 4 * 32 * XROW : 16];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = uniform(tid >> 6);
   const int row = lane & 31, half = lane >> 5;
@@ -155,11 +163,15 @@ __global__ __launch_bounds__(256) void fused_quantize_kernel(const QuantParams p
 
   const int wave_global = blockIdx.x * 4 + wave, nwaves = gridDim.x * 4;
   v4i xnext[RP / 16];
+  // per-lane byte offset inside a tile and the step between a lane's loads: MFMA layout (row, half; 32 bytes apart) or,
+  // staged, chunk lane + 64 i of the tile's contiguous 32 * RP * 2 bytes
+  const int lane_off = STAGED ? lane * 16 : row * RP * 2 + half * 16;
+  constexpr int LSTEP = STAGED ? 1024 : 32;
+  char* xs = xs_all + (STAGED ? wave * 32 * XROW : 0);
   {
-    const int64_t r0 = (int64_t)wave_global * 32 + row;
-    const int xoff0 = (wave_global < p.ntiles) ? (int)(r0 * RP * 2) + half * 16 : 0x7f000000;
+    const int xoff0 = (wave_global < p.ntiles) ? (int)((int64_t)wave_global * 32 * RP * 2) + lane_off : 0x7f000000;
 #pragma unroll
-    for (int kc = 0; kc < RP / 16; ++kc) xnext[kc] = __builtin_amdgcn_raw_buffer_load_b128(rx, xoff0 + kc * 32, 0, 0);
+    for (int kc = 0; kc < RP / 16; ++kc) xnext[kc] = __builtin_amdgcn_raw_buffer_load_b128(rx, xoff0 + kc * LSTEP, 0, 0);
   }
   for (int tile = wave_global; tile < p.ntiles; tile += nwaves) {
     // R >= 64: keep H^T in LDS instead of letting the compiler hoist its R*R/256 fragments into registers across the
@@ -172,14 +184,26 @@ __global__ __launch_bounds__(256) void fused_quantize_kernel(const QuantParams p
     // loads of the wave's NEXT tile are issued before this tile is computed (tiles past the end fall off the buffer
     // descriptor and read 0), so the HBM latency of tile i+1 hides behind the MFMAs / epilogue of tile i.
     v8bf xf[KC];
+    if (STAGED) {
+      constexpr int CPR = RP / 8;                // 16-byte chunks per row
 #pragma unroll
-    for (int kc = 0; kc < KC; ++kc) xf[kc] = __builtin_bit_cast(v8bf, xnext[kc]);
+      for (int i = 0; i < KC; ++i) {
+        const int q = i * 64 + lane;             // chunk of the tile held in xnext[i]
+        *(v4i*)(xs + (q / CPR) * XROW + (q % CPR) * 16) = xnext[i];
+      }
+      __builtin_amdgcn_s_waitcnt(0xc07f);        // lgkmcnt(0): the wave's own writes landed (wave-private area)
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int kc = 0; kc < KC; ++kc) xf[kc] = *(const v8bf*)(xs + row * XROW + (2 * kc + half) * 16);
+    } else {
+#pragma unroll
+      for (int kc = 0; kc < KC; ++kc) xf[kc] = __builtin_bit_cast(v8bf, xnext[kc]);
+    }
     {
-      const int64_t rn = (int64_t)(tile + nwaves) * 32 + row;
-      const int64_t on = rn * RP * 2 + half * 16;
+      const int64_t on = (int64_t)(tile + nwaves) * 32 * RP * 2 + lane_off;
       const int xoffn = (tile + nwaves < p.ntiles) ? (int)on : 0x7f000000;
 #pragma unroll
-      for (int kc = 0; kc < KC; ++kc) xnext[kc] = __builtin_amdgcn_raw_buffer_load_b128(rx, xoffn + kc * 32, 0, 0);
+      for (int kc = 0; kc < KC; ++kc) xnext[kc] = __builtin_amdgcn_raw_buffer_load_b128(rx, xoffn + kc * LSTEP, 0, 0);
     }
 #pragma unroll
     for (int jt = 0; jt < JT; ++jt) {
