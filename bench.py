@@ -212,12 +212,12 @@ def main():
             result["config"]["parity_vs_cpu_oracle_slab"] = bool(torch.equal(got, ref))
         else:
             result["cpu_baseline"] = None
-        print(json.dumps(result))
-
-    if world > 1:
+        print(json.dumps(result), flush=True)
+    if world > 1 or args.gpus > 1:
         import torch.distributed as dist
 
-        dist.destroy_process_group()
+        if dist.is_initialized():
+            dist.destroy_process_group()
 
 
 if __name__ == "__main__":
