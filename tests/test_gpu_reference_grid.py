@@ -1,0 +1,143 @@
+"""GPU: the reference's own end-to-end shape grids (tests/mxfp4_test.py:272-299 `test_llama_shapes`, tests/nvfp4_test.py:227-262,
+tests/mxfp8_test.py:98-130): LLaMA 7B / 13B / 33B / 70B layer shapes x batch {1, 16} x every rotation size, quantise both
+operands with the fused quantizer, swizzle the scales, multiply, and require what the reference requires --
+`out.equal(out_ref)` for MXFP4 / NVFP4 against the fp64 dequantise-matmul of the SAME packed operands, assert_close
+(1e-1) for MXFP8 TN and NN.  The fp64 reference here is plain torch on the GPU (test-side restatement, no product code)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device("cuda", 0)
+
+# (k, n) per linear layer, as listed in the reference's tests (data, not code)
+LLAMA_MODELS = {
+    "7B": [(4096, 3 * 4096), (4096, 4096), (4096, 2 * 10752), (10752, 4096)],
+    "13B": [(5120, 3 * 5120), (5120, 5120), (5120, 2 * 13568), (13568, 5120)],
+    "33B": [(6656, 3 * 6656), (6656, 6656), (6656, 2 * 17664), (17664, 6656)],
+    "70B": [(8192, 3 * 8192), (8192, 8192), (8192, 2 * 21760), (21760, 8192)],
+}
+_E2M1 = [0.0, 0.5, 1.0, 1.5, 2.0, 3.0, 4.0, 6.0, -0.0, -0.5, -1.0, -1.5, -2.0, -3.0, -4.0, -6.0]
+
+
+@pytest.fixture(scope="module")
+def q():
+    import qutlass_amd
+
+    return qutlass_amd
+
+
+def _hadamard(n):
+    h = torch.ones(1, 1)
+    while h.shape[0] < n:
+        h = torch.cat([torch.cat([h, h], 1), torch.cat([h, -h], 1)], 0)
+    return (h * n ** -0.5).to(torch.bfloat16).to(DEV)
+
+
+def _dequant_fp64(codes, scales, rows, group):
+    """packed e2m1 (rows, k/2) + per-group scales (>= rows, k/group) -> (rows, k) float64; element 2j = low nibble of byte j."""
+    lut = torch.tensor(_E2M1, dtype=torch.float64, device=codes.device)
+    c = codes.view(torch.uint8)
+    vals = torch.stack([lut[(c & 0xF).long()], lut[(c >> 4).long()]], dim=-1).reshape(rows, -1)
+    s = scales[:rows]
+    if s.dtype == torch.float8_e8m0fnu:
+        s = torch.pow(2.0, s.view(torch.uint8).to(torch.float64) - 127.0)
+    else:
+        s = s.to(torch.float32).to(torch.float64)
+    return (vals.reshape(rows, -1, group) * s[:, : vals.shape[1] // group, None]).reshape(rows, -1)
+
+
+_weights = {}
+
+
+def _weight(key, n, k, make):
+    """quantised weight of a layer, shared by the batch sizes of the same (format, rotation) case"""
+    if key not in _weights:
+        _weights.clear()   # one resident weight at a time (up to 43520 x 8192)
+        _weights[key] = make()
+    return _weights[key]
+
+
+@pytest.mark.parametrize("had_size", [32, 64, 128])
+@pytest.mark.parametrize("layer_idx", [0, 1, 2, 3])
+@pytest.mark.parametrize("model", list(LLAMA_MODELS))
+def test_mxfp4_llama_shapes_exact(q, model, layer_idx, had_size):
+    from qutlass_amd.utils import to_blocked
+
+    k, n = LLAMA_MODELS[model][layer_idx]
+    h = _hadamard(had_size)
+    alpha = torch.tensor([1.0], device=DEV)
+    torch.manual_seed(0)
+    b = torch.rand(n, k, dtype=torch.bfloat16, device=DEV) * 25.0
+    b_q, b_s = q.fusedQuantizeMx(b, h, method="quest")
+    b_dq = _dequant_fp64(b_q, b_s, n, 32)
+    b_sf = to_blocked(b_s)
+    for m in (1, 16):
+        a = torch.rand(m, k, dtype=torch.bfloat16, device=DEV) * 25.0
+        a_q, a_s = q.fusedQuantizeMx(a, h, method="quest")
+        ref = (_dequant_fp64(a_q, a_s, m, 32) @ b_dq.T).to(torch.bfloat16)
+        out = q.matmul_mxf4_bf16_tn(a_q, b_q, to_blocked(a_s), b_sf, alpha)
+        assert out.equal(ref), (model, layer_idx, m, had_size, int((out != ref).sum()))
+        out2 = q.matmul_ada_mxf4_bf16_tn(a_q, b_q, a_s[:m].contiguous(), b_s[:n].contiguous(), alpha)
+        assert out2.equal(ref), ("ada", model, layer_idx, m, had_size)
+
+
+@pytest.mark.parametrize("rot_size", [16, 32, 64, 128])
+@pytest.mark.parametrize("layer_idx", [0, 1, 2, 3])
+@pytest.mark.parametrize("model", list(LLAMA_MODELS))
+def test_nvfp4_llama_shapes_exact(q, model, layer_idx, rot_size):
+    from qutlass_amd.utils import to_blocked
+
+    k, n = LLAMA_MODELS[model][layer_idx]
+    h = _hadamard(rot_size)
+    alpha = torch.tensor([1.0], device=DEV)
+    gs = torch.tensor([1.0], device=DEV)
+    torch.manual_seed(0)
+    b = torch.randn(n, k, dtype=torch.bfloat16, device=DEV) * 25.0
+    b_q, b_s = q.fusedQuantizeNv(b, h, gs)
+    b_dq = _dequant_fp64(b_q, b_s, n, 16)
+    b_sf = to_blocked(b_s)
+    for m in (1, 16):
+        a = torch.randn(m, k, dtype=torch.bfloat16, device=DEV) * 25.0
+        a_q, a_s = q.fusedQuantizeNv(a, h, gs)
+        ref = (_dequant_fp64(a_q, a_s, m, 16) @ b_dq.T).to(torch.bfloat16)
+        out = q.matmul_nvf4_bf16_tn(a_q, b_q, to_blocked(a_s), b_sf, alpha)
+        assert out.equal(ref), (model, layer_idx, m, rot_size, int((out != ref).sum()))
+
+
+def _pseudoquant_mxfp8(x):
+    """e8m0 per 32 = floor(log2 amax) - 8 + 1 ... restated from the reference's producer semantics: scale = 2^(floor(log2(amax)) - 8),
+    values rounded to e4m3fn.  Only used to produce operands; the check itself dequantises the produced bytes."""
+    xr = x.float().reshape(x.shape[0], -1, 32)
+    amax = xr.abs().amax(dim=-1, keepdim=True).clamp_min(2.0 ** -120)
+    e = torch.floor(torch.log2(amax)) - 8.0
+    scale = torch.pow(2.0, e)
+    q8 = (xr / scale).clamp(-448.0, 448.0).to(torch.float8_e4m3fn)
+    e8 = (e + 127.0).clamp(0, 254).to(torch.uint8).reshape(x.shape[0], -1).view(torch.float8_e8m0fnu)
+    return q8.reshape(x.shape), e8
+
+
+@pytest.mark.parametrize("layer_idx", [0, 1, 2, 3])
+@pytest.mark.parametrize("model", list(LLAMA_MODELS))
+def test_mxfp8_llama_shapes_tn_nn_close(q, model, layer_idx):
+    from qutlass_amd.utils import to_blocked
+
+    k, n = LLAMA_MODELS[model][layer_idx]
+    m = 16
+    torch.manual_seed(0)
+    a = torch.rand(m, k, dtype=torch.bfloat16, device=DEV) * 25.0
+    b = torch.rand(n, k, dtype=torch.bfloat16, device=DEV) * 25.0
+    a8, a_s = _pseudoquant_mxfp8(a)
+    b8, b_s = _pseudoquant_mxfp8(b)
+    deq = lambda v, s: (v.to(torch.float32).to(torch.float64).reshape(v.shape[0], -1, 32)
+                        * torch.pow(2.0, s.view(torch.uint8).to(torch.float64) - 127.0)[:, :, None]).reshape(v.shape[0], -1)
+    ref = (deq(a8, a_s) @ deq(b8, b_s).T).to(torch.bfloat16)
+    alpha = torch.tensor([1.0], device=DEV)
+    pad = lambda s, rows: torch.cat([s.view(torch.uint8), torch.zeros(-(-rows // 128) * 128 - rows, s.shape[1], dtype=torch.uint8, device=DEV)]).view(torch.float8_e8m0fnu)
+    a_sf, b_sf = to_blocked(pad(a_s, m)), to_blocked(pad(b_s, n))
+    out = q.matmul_mxf8_bf16_tn(a8, b8, a_sf, b_sf, alpha)
+    torch.testing.assert_close(out, ref, atol=1e-1, rtol=1e-1)
+    a8t = a8.view(torch.uint8).T.contiguous().view(torch.float8_e4m3fn)
+    out_nn = q.matmul_mxf8_bf16_nn(a8t, b8, a_sf, b_sf, alpha)
+    torch.testing.assert_close(out_nn, ref, atol=1e-1, rtol=1e-1)
+    # (TN may take the split-K path for these small outputs, NN never does: same values up to fp32 summation order)
+    torch.testing.assert_close(out_nn, out, atol=0.0, rtol=2.0 ** -7)
