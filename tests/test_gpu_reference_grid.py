@@ -141,3 +141,63 @@ def test_mxfp8_llama_shapes_tn_nn_close(q, model, layer_idx):
     torch.testing.assert_close(out_nn, ref, atol=1e-1, rtol=1e-1)
     # (TN may take the split-K path for these small outputs, NN never does: same values up to fp32 summation order)
     torch.testing.assert_close(out_nn, out, atol=0.0, rtol=2.0 ** -7)
+
+
+def test_quartet_forward_gemm_exact(q):
+    """tests/quartet_test.py:241-258: 12288 x 8192 x 4096, both operands Quest-quantised WITH the clip mask, exact equality."""
+    from qutlass_amd.utils import to_blocked
+
+    m, n, k = 4096 * 3, 4096 * 2, 4096
+    h = _hadamard(32)
+    torch.manual_seed(0)
+    a = torch.randn(m, k, dtype=torch.bfloat16, device=DEV) * 25.0
+    b = torch.randn(n, k, dtype=torch.bfloat16, device=DEV) * 25.0
+    a_q, a_s, a_mask = q.fusedQuantizeMx(a, h, method="quest", return_mask=True)
+    b_q, b_s, _ = q.fusedQuantizeMx(b, h, method="quest", return_mask=True)
+    assert a_mask.shape == (m, k // 8) and a_mask.dtype == torch.uint8
+    ref = (_dequant_fp64(a_q, a_s, m, 32) @ _dequant_fp64(b_q, b_s, n, 32).T).to(torch.bfloat16)
+    out = q.matmul_mxf4_bf16_tn(a_q, b_q, to_blocked(a_s), to_blocked(b_s), torch.tensor([1.0], device=DEV))
+    assert out.equal(ref), int((out != ref).sum())
+
+
+def test_quartet_fp8_requant_chain(q):
+    """tests/quartet_test.py `_fp8_requant_test` (m, n = 2694, 256; rows are padded by the wrappers as in the reference):
+    backward_bf16_square_double_mxfp8 and mxfp4_transpose_mxfp8 bit-exact against the CPU oracle, then their outputs feed
+    matmul_mxf8_bf16_nn, whose result matches the fp64 product of the dequantised operands within the reference's 1e-1."""
+    import numpy as np
+
+    import oracle
+    from qutlass_amd.utils import to_blocked
+
+    def npu8(t):
+        return t.detach().cpu().contiguous().view(torch.uint8).numpy()
+
+    m, n = 2694, 256
+    bf16 = torch.arange(0, n, dtype=torch.bfloat16, device=DEV)[None, :].repeat(m, 1)
+    a8, a_rs, a_cs = q.backward_bf16_square_double_mxfp8(bf16)
+    mp = -(-m // 128) * 128
+    assert a8.shape == (mp, n) and a_rs.shape == (mp, n // 32) and a_cs.shape == (n, mp // 32)
+    xpad = torch.cat([bf16, torch.zeros(mp - m, n, dtype=torch.bfloat16, device=DEV)])
+    oy, ors, ocs = oracle.backward_bf16_square_double_mxfp8(xpad.cpu().view(torch.uint16).numpy())
+    assert np.array_equal(npu8(a8), oy) and np.array_equal(npu8(a_rs), ors) and np.array_equal(npu8(a_cs), ocs)
+
+    fp4, scales = q.fusedQuantizeMx(bf16, torch.eye(32, dtype=torch.bfloat16, device=DEV), method="abs_max")
+    sc = scales.clone()
+    b8, b_e = q.mxfp4_transpose_mxfp8(fp4, sc)
+    mp2 = -(-m // 256) * 256
+    assert b8.shape == (n, mp2) and b_e.shape == (n, mp2 // 32) and mp2 == mp
+    fp4_pad = torch.cat([fp4.view(torch.uint8), torch.zeros(mp2 - m, n // 2, dtype=torch.uint8, device=DEV)])
+    sc_pad = npu8(sc)[:mp2, : n // 32].copy()
+    sc_pad[m:] = 127   # the wrapper sets the scales of the padded rows to 1.0
+    oy2, oe2 = oracle.mxfp4_transpose_mxfp8(npu8(fp4_pad), sc_pad)
+    assert np.array_equal(npu8(b8), oy2) and np.array_equal(npu8(b_e), oe2)
+
+    # the chain: A stored (K, M) = a8 (mp, n), scales (M, K/32) = column scales; B (N, K) = b8, scales (N, K/32) = b_e
+    al = torch.tensor([1.0], device=DEV)
+    out = q.matmul_mxf8_bf16_nn(a8, b8, to_blocked(a_cs), to_blocked(b_e), al)
+    deq = lambda v, s: (v.to(torch.float32).to(torch.float64).reshape(v.shape[0], -1, 32)
+                        * torch.pow(2.0, s.view(torch.uint8).to(torch.float64) - 127.0)[:, :, None]).reshape(v.shape[0], -1)
+    a_dq = deq(a8.view(torch.uint8).T.contiguous().view(torch.float8_e4m3fn), a_cs)      # (M = n, K = mp)
+    ref = (a_dq @ deq(b8, b_e).T).to(torch.bfloat16)
+    assert out.shape == (n, n)
+    torch.testing.assert_close(out, ref, atol=1e-1, rtol=1e-1)
