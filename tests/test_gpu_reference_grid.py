@@ -201,3 +201,72 @@ def test_quartet_fp8_requant_chain(q):
     ref = (a_dq @ deq(b8, b_e).T).to(torch.bfloat16)
     assert out.shape == (n, n)
     torch.testing.assert_close(out, ref, atol=1e-1, rtol=1e-1)
+
+
+def _rtne_e2m1(v):
+    """fp64 values -> nearest e2m1 grid value, ties to the even mantissa, saturating at 6 (SURVEY.md 8a KATs)."""
+    a = v.abs()
+    q = torch.full_like(a, 6.0)
+    for bound, val, tie_low in ((5.0, 4.0, True), (3.5, 3.0, False), (2.5, 2.0, True), (1.75, 1.5, False), (1.25, 1.0, True), (0.75, 0.5, False), (0.25, 0.0, True)):
+        q = torch.where((a <= bound) if tie_low else (a < bound), torch.full_like(a, val), q)
+    return torch.copysign(q, v)
+
+
+@pytest.mark.parametrize("rot_size", [32, 64, 128])
+@pytest.mark.parametrize("method", ["abs_max", "quest"])
+def test_mx_quantizer_full_size_within_the_references_bound(q, rot_size, method):
+    """tests/mxfp4_test.py:208-222 / :240-254 at the reference's size (2, 4096, 4096): dequantised GPU output vs an fp64
+    restatement of the quantiser; the reference's own bar is <= 1e-4 mismatching elements (fp32 vs fp64 rotation ties)."""
+    torch.manual_seed(0)
+    h = _hadamard(rot_size)
+    x = torch.randn(2, 4096, 4096, dtype=torch.bfloat16, device=DEV) * 25.0
+    xq, xs = q.fusedQuantizeMx(x, h, method=method)
+    rows = 2 * 4096
+    alpha = 3.0 if method == "abs_max" else 1.0
+    got = _dequant_fp64(xq.reshape(rows, -1), xs.view(torch.uint8).reshape(-1)[: rows * 128].reshape(rows, 128).view(torch.float8_e8m0fnu), rows, 32) / alpha
+    bad = 0
+    for r0 in range(0, rows, 2048):   # fp64 in slabs of 2048 rows
+        xh = (x.reshape(rows, -1)[r0 : r0 + 2048].to(torch.float64).reshape(-1, rot_size) @ h.to(torch.float64)).reshape(-1, 32)
+        if method == "abs_max":
+            s = xh.abs().amax(dim=-1, keepdim=True) + 1e-8
+        else:
+            mean = xh.mean(dim=-1, keepdim=True)
+            var = (xh * xh).mean(dim=-1, keepdim=True) - mean * mean
+            s = torch.sqrt(var.clamp_min(0.0)) * (2.92247856 / 6.0) + 1e-8
+        scale = torch.pow(2.0, torch.floor(torch.log2(s)))
+        ref = _rtne_e2m1(xh / scale * alpha) * scale / alpha
+        bad += int((got[r0 : r0 + 2048].reshape(-1, 32) != ref).sum())
+    assert bad / x.numel() <= 1e-4, bad
+
+
+@pytest.mark.parametrize("rot_size", [16, 32, 64, 128])
+def test_nv_quantizer_full_size_and_gemm_exact(q, rot_size):
+    """tests/nvfp4_test.py:190-224: (2, 4096, 4096) with global_scale 6 -> dequantised output vs an fp64 restatement within
+    the reference's bound (<= 1e-1 mismatching elements), then 504 x 8192 x 4096 quantise -> swizzle -> GEMM, exact."""
+    from qutlass_amd.utils import to_blocked
+
+    torch.manual_seed(0)
+    h = _hadamard(rot_size)
+    gs = torch.tensor([6.0], device=DEV)
+    x = torch.randn(2, 4096, 4096, dtype=torch.bfloat16, device=DEV) * 25.0
+    xq, xs = q.fusedQuantizeNv(x, h, gs)
+    rows = 2 * 4096
+    s2d = xs.view(torch.uint8).reshape(-1)[: rows * 256].reshape(rows, 256).view(torch.float8_e4m3fn)
+    got = _dequant_fp64(xq.reshape(rows, -1), s2d, rows, 16) / 6.0
+    bad = 0
+    for r0 in range(0, rows, 2048):
+        xh = (x.reshape(rows, -1)[r0 : r0 + 2048].to(torch.float64).reshape(-1, rot_size) @ h.to(torch.float64)).reshape(-1, 16)
+        sf = (xh.abs().amax(dim=-1, keepdim=True) * (6.0 / 6.0)).to(torch.float32).to(torch.float8_e4m3fn).to(torch.float32).to(torch.float64)
+        step = sf / 6.0
+        ref = torch.where(sf > 0, _rtne_e2m1(xh / step.clamp_min(1e-300)) * step, torch.zeros_like(xh))
+        bad += int((got[r0 : r0 + 2048].reshape(-1, 16) != ref).sum())
+    assert bad / x.numel() <= 1e-1, bad
+
+    m, n, k = 504, 4096 * 2, 4096
+    a = torch.randn(m, k, dtype=torch.bfloat16, device=DEV) * 25.0
+    b = torch.randn(n, k, dtype=torch.bfloat16, device=DEV) * 25.0
+    a_q, a_s = q.fusedQuantizeNv(a, h, gs)
+    b_q, b_s = q.fusedQuantizeNv(b, h, gs)
+    ref = (_dequant_fp64(a_q, a_s, m, 16) @ _dequant_fp64(b_q, b_s, n, 16).T).to(torch.bfloat16)
+    out = q.matmul_nvf4_bf16_tn(a_q, b_q, to_blocked(a_s), to_blocked(b_s), torch.tensor([1.0], device=DEV))
+    assert out.equal(ref), int((out != ref).sum())
