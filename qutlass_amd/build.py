@@ -1,6 +1,10 @@
-"""Build the two in-tree binaries (no cmake, no JIT cache):
+"""Build the in-tree binaries (no cmake, no JIT cache):
 
-  libqutlass_amd.so   hipcc --offload-arch=gfx950: the hand-written HIP kernels behind the C ABI (no torch headers)
+  libqutlass_amd.so        hipcc --offload-arch=gfx950: the hand-written HIP kernels behind the C ABI (no torch headers).
+                           The PRODUCT: only the kernels the dispatch rules can reach, no kernel-selecting options.
+  libqutlass_amd_bench.so  the same source with -DQAMD_BENCH=1: the LAB build with every schedule variant / ablation /
+                           trace instantiation and the "gemm_variant"-style options.  Test and bench infrastructure
+                           only (tests/native, tests/_benchlib.py, tools/); nothing under qutlass_amd/ loads it.
   _C.so               g++: the PyTorch extension (csrc/torch_ext.cpp, LibTorch stable ABI, no device code) that
                       registers torch.ops._qutlass_C.* over that C ABI
 """
@@ -13,6 +17,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(_HERE, "csrc", "capi.hip")
 OUT = os.path.join(_HERE, "libqutlass_amd.so")
+BENCH_OUT = os.path.join(_HERE, "libqutlass_amd_bench.so")
 EXT_SRC = os.path.join(_HERE, "csrc", "torch_ext.cpp")
 EXT_OUT = os.path.join(_HERE, "_C.so")
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "qutlass_amd.h")
@@ -34,38 +39,51 @@ def needs_build() -> bool:
     return _stale(OUT, _kernel_sources()) or _stale(EXT_OUT, [EXT_SRC, HEADER, OUT])
 
 
-NUM_TU = 7   # translation units of csrc/capi.hip (QAMD_TU = 1..NUM_TU; see the comment at the top of that file)
+NUM_TU = 5         # translation units of csrc/capi.hip in the product build (QAMD_TU = 1..5; see the top of that file)
+NUM_TU_BENCH = 7   # the lab build adds the ablation units 6 and 7
+
+
+def _compile_units(out: str, num_tu: int, extra: list, verbose: bool) -> None:
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    base = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden"] + extra
+    if os.environ.get("QAMD_SINGLE_TU"):
+        cmd = base + ["-shared", "-Wl,-Bsymbolic", SRC, "-o", out]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+        return
+    import tempfile
+    from concurrent.futures import ThreadPoolExecutor
+
+    with tempfile.TemporaryDirectory(prefix="qamd_build_") as tmp:
+        objs = [os.path.join(tmp, f"capi_tu{i}.o") for i in range(1, num_tu + 1)]
+        cmds = [base + [f"-DQAMD_TU={i}", "-c", SRC, "-o", o] for i, o in zip(range(1, num_tu + 1), objs)]
+        if verbose:
+            print(" ".join(cmds[0]), f"   (x{num_tu}: QAMD_TU=1..{num_tu}, in parallel)")
+        with ThreadPoolExecutor(max_workers=min(num_tu, os.cpu_count() or 1)) as ex:
+            for rc, cmd in zip(ex.map(lambda c: subprocess.run(c).returncode, cmds), cmds):
+                if rc != 0:
+                    raise subprocess.CalledProcessError(rc, cmd)
+        # -Bsymbolic: the product and the lab library export the same C names and may live in one process
+        link = base + ["-shared", "-Wl,-Bsymbolic"] + objs + ["-o", out]
+        if verbose:
+            print(" ".join(link[:6]), "... -o", out)
+        subprocess.check_call(link)
 
 
 def build_kernels(force: bool = False, verbose: bool = False) -> str:
     """csrc/capi.hip is compiled once per QAMD_TU value, in parallel (each unit instantiates one kernel family), and the
     objects are linked into libqutlass_amd.so.  QAMD_SINGLE_TU=1 in the environment compiles it as one unit instead."""
     if force or _stale(OUT, _kernel_sources()):
-        hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
-        base = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden"]
-        if os.environ.get("QAMD_SINGLE_TU"):
-            cmd = base + ["-shared", SRC, "-o", OUT]
-            if verbose:
-                print(" ".join(cmd))
-            subprocess.check_call(cmd)
-            return OUT
-        import tempfile
-        from concurrent.futures import ThreadPoolExecutor
-
-        with tempfile.TemporaryDirectory(prefix="qamd_build_") as tmp:
-            objs = [os.path.join(tmp, f"capi_tu{i}.o") for i in range(1, NUM_TU + 1)]
-            cmds = [base + [f"-DQAMD_TU={i}", "-c", SRC, "-o", o] for i, o in zip(range(1, NUM_TU + 1), objs)]
-            if verbose:
-                print(" ".join(cmds[0]), f"   (x{NUM_TU}: QAMD_TU=1..{NUM_TU}, in parallel)")
-            with ThreadPoolExecutor(max_workers=min(NUM_TU, os.cpu_count() or 1)) as ex:
-                for rc, cmd in zip(ex.map(lambda c: subprocess.run(c).returncode, cmds), cmds):
-                    if rc != 0:
-                        raise subprocess.CalledProcessError(rc, cmd)
-            link = base + ["-shared"] + objs + ["-o", OUT]
-            if verbose:
-                print(" ".join(link[:6]), "... -o", OUT)
-            subprocess.check_call(link)
+        _compile_units(OUT, NUM_TU, [], verbose)
     return OUT
+
+
+def build_bench_lib(force: bool = False, verbose: bool = False) -> str:
+    """The lab library (test / bench infrastructure, see the module docstring)."""
+    if force or _stale(BENCH_OUT, _kernel_sources()):
+        _compile_units(BENCH_OUT, NUM_TU_BENCH, ["-DQAMD_BENCH=1"], verbose)
+    return BENCH_OUT
 
 
 def build_extension(force: bool = False, verbose: bool = False) -> str:

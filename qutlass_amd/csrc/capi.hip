@@ -9,6 +9,7 @@
 
 #include "../../include/qutlass_amd.h"
 #include "gemm_mx.hip.h"
+#include "gemm_mx_deepp.hip.h"
 #include "gemm_mx_skinny.hip.h"
 #include "gemm_nvf4.hip.h"
 #include "quantize.hip.h"
@@ -18,24 +19,34 @@
 
 using namespace qamd;
 
-// One source, several translation units.  The library has ~200 kernel instantiations (most of them bench-only schedule
-// variants and ablations kept selectable because their measurements are part of the design record); compiled as one
-// unit that is 3.5 minutes of hipcc.  build.py compiles this file once per QAMD_TU value in parallel: every heavy
-// template family is instantiated in exactly one unit (explicit instantiation) and only declared (`extern template`) in
-// the others.  QAMD_TU = 0 (a plain `hipcc capi.hip`) still gives the whole library in one unit.
+// One source, several translation units, two libraries.
+//   libqutlass_amd.so        the PRODUCT: the C ABI of include/qutlass_amd.h and exactly the kernels its dispatch rules can
+//                            reach.  No process-wide switch can change which kernel runs or what it computes; the only
+//                            option is "hw_fp4_cvt" (two encoders that are tested to the same bits).
+//   libqutlass_amd_bench.so  the LAB (-DQAMD_BENCH=1): the same entry points plus every schedule variant, ablation, trace
+//                            and clock-probe instantiation the design record cites, selectable through
+//                            qutlass_amd_set_option("gemm_variant" / "nvf4_variant" / "pp_flags" / ...).  Only
+//                            tests/native, the sweeps under tools/ and the forced-tile parity tests load it.
+// build.py compiles this file once per QAMD_TU value in parallel: every heavy template family is instantiated in exactly
+// one unit (explicit instantiation) and only declared (`extern template`) in the others.  QAMD_TU = 0 (a plain
+// `hipcc capi.hip`) still gives a whole library in one unit.
 //   1  C entry points, dispatch rules, small kernels      2  MXFP4 tile / schedule variants      3  MXFP8 variants
-//   4  NVFP4 kernels                                      5  fused quantizers                    6  MXFP4 ablations (100+, 200+, 300+)
-//   7  NVFP4 v2 ablations (gemm_nvf4.hip.h)
+//   4  NVFP4 kernels                                      5  fused quantizers
+//   6  MXFP4 ablations (100+, 200+, 300+; lab only)       7  NVFP4 v2 ablations (gemm_nvf4.hip.h; lab only)
 #ifndef QAMD_TU
 #define QAMD_TU 0
 #endif
 #define QAMD_DEF(n) (QAMD_TU == 0 || QAMD_TU == (n))
+#ifndef QAMD_BENCH
+#define QAMD_BENCH 0
+#endif
 
 namespace qamd_host {
 
 #if QAMD_DEF(1)
 thread_local char g_err[512] = "";
 std::atomic<int> g_hw_fp4_cvt{1};   // device-verified bit-identical to the software encoder (tests/native/probe.hip P2)
+#if QAMD_BENCH
 std::atomic<int> g_gemm_variant{0};
 std::atomic<int> g_nvf4_variant{0};
 std::atomic<int> g_splitk_wg{256};      // split-K: target workgroup count ("splitk_wg"; one per CU measured best, profiles/native_r1_splitk_wg.log)
@@ -43,7 +54,9 @@ std::atomic<int> g_splitk_min_kt{32};   // split-K: minimum number of 128-byte K
 std::atomic<int> g_transpose_nc{128};   // mxfp4_transpose_mxfp8: n columns per workgroup (128 or 256)
 std::atomic<int> g_pp_shift{2};
 std::atomic<int> g_pp_flags{1};
+std::atomic<int> g_quant_wg_per_cu{0};  // 0 = auto
 std::atomic<uint32_t*> g_dbg{nullptr};
+#endif
 
 int fail(int code, const char* fmt, ...) {
   va_list ap;
@@ -60,8 +73,36 @@ int check_launch(const char* what) {
 }
 #else
 extern std::atomic<int> g_hw_fp4_cvt;
+#if QAMD_BENCH
+extern std::atomic<int> g_gemm_variant, g_nvf4_variant, g_splitk_wg, g_splitk_min_kt, g_transpose_nc, g_pp_shift, g_pp_flags, g_quant_wg_per_cu;
+extern std::atomic<uint32_t*> g_dbg;
+#endif
 int fail(int code, const char* fmt, ...);
 int check_launch(const char* what);
+#endif
+
+// Tuning state.  In the product library these are compile-time constants: nothing a caller (or another thread) does can
+// change which kernel a shape gets.  The lab library reads them from qutlass_amd_set_option().
+#if QAMD_BENCH
+inline int opt_gemm_variant() { return g_gemm_variant.load(); }
+inline int opt_nvf4_variant() { return g_nvf4_variant.load(); }
+inline int opt_splitk_wg() { return g_splitk_wg.load(); }
+inline int opt_splitk_min_kt() { return g_splitk_min_kt.load(); }
+inline int opt_transpose_nc() { return g_transpose_nc.load(); }
+inline int opt_pp_shift() { return g_pp_shift.load(); }
+inline int opt_pp_flags() { return g_pp_flags.load(); }
+inline int opt_quant_wg_per_cu() { return g_quant_wg_per_cu.load(); }
+inline uint32_t* opt_dbg() { return g_dbg.load(); }
+#else
+constexpr int opt_gemm_variant() { return 0; }
+constexpr int opt_nvf4_variant() { return 0; }
+constexpr int opt_splitk_wg() { return 256; }
+constexpr int opt_splitk_min_kt() { return 32; }
+constexpr int opt_transpose_nc() { return 128; }
+constexpr int opt_pp_shift() { return 2; }
+constexpr int opt_pp_flags() { return 1; }
+constexpr int opt_quant_wg_per_cu() { return 0; }
+constexpr uint32_t* opt_dbg() { return nullptr; }
 #endif
 
 inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
@@ -75,7 +116,23 @@ int launch_gemm(GemmParams p, hipStream_t s) {
   return check_launch("gemm_mx_kernel");
 }
 
-// Tile/schedule variants ("gemm_variant" option; 0 = auto):
+// persistent deep schedule (gemm_mx_deepp.hip.h): one workgroup per CU walks the tiles; 160 KiB of static LDS
+template <class C, bool TRACE = false>
+int launch_gemm_deepp(GemmParams p, hipStream_t s) {
+  p.tiles_m = (int)cdiv(p.M, C::BM);
+  p.tiles_n = (int)cdiv(p.N, C::BN);
+  p.ws = nullptr; p.splits = 1;
+  const int grid = std::min(p.tiles_m * p.tiles_n, 256);   // MI355X: 256 CUs, one 512-register workgroup each
+  hipLaunchKernelGGL((gemm_mx_deepp_kernel<C, TRACE>), dim3(grid), dim3(C::THREADS), 0, s, p);
+  return check_launch("gemm_mx_deepp_kernel");
+}
+
+// Tile/schedule variants (0 = auto; the lab library can force one through the "gemm_variant" option):
+//   PRODUCT (what the auto rules below can pick):
+//     90  persistent deep schedule, fp4, 256x256      30  deep schedule, fp8, 256x256 (lab: also fp4, the per-tile predecessor of 90)
+//     24 / 25 / 27 / 28 / 29  simple schedule 128x128, 256x128, 128x64, 64x128, 64x64
+//     70..73  ring schedule 64x64, 128x64, 64x128, 128x128 (+ split-K)          60  skinny split-K kernel (fp4, M <= 32)
+//   LAB only:
 //   1  256x256 ping-pong     5  256x256 lockstep     6..9  queue schedule (256x256, 128x128, 256x128, 128x256)
 //   20 / 24 / 25 / 26  simple schedule (256x256, 128x128, 256x128, 128x256)
 //   60  skinny split-K kernel (fp4, M <= 32 per tile, no LDS staging): auto for M <= 32
@@ -101,6 +158,7 @@ inline bool dry_record(int variant, int n_cols, int splits) {
 
 // bench-only ablations of the 8-wave 256x256 MXFP4 schedules: 100 + b ping-pong, 200 + b lockstep, 300 + b queue, b = OR
 // of ABL_* bits.  Returns -1 for any other variant.
+#if QAMD_BENCH
 #if QAMD_DEF(6)
 int dispatch_ablation_mx4(int v, const GemmParams& p, hipStream_t s) {
   switch (v) {
@@ -116,20 +174,14 @@ int dispatch_ablation_mx4(int v, const GemmParams& p, hipStream_t s) {
 #else
 int dispatch_ablation_mx4(int v, const GemmParams& p, hipStream_t s);
 #endif
+#endif   // QAMD_BENCH
 
 template <int EBITS, bool SPLIT>
 int dispatch_variant(int v, const GemmParams& p, hipStream_t s, const char* name) {
   if (dry_record(v, p.N, (v >= 70 && v <= 78) ? p.splits : 1)) return 0;
   switch (v) {
-    case 1: return launch_gemm<GemmCfg<256, 256, 2, 4, EBITS, SPLIT>, 1>(p, s);
-    case 2: return launch_gemm<GemmCfg<128, 128, 2, 2, EBITS, SPLIT>, 0>(p, s);
-    case 3: return launch_gemm<GemmCfg<256, 128, 4, 2, EBITS, SPLIT>, 0>(p, s);
-    case 4: return launch_gemm<GemmCfg<128, 256, 2, 4, EBITS, SPLIT>, 0>(p, s);
-    case 5: return launch_gemm<GemmCfg<256, 256, 2, 4, EBITS, SPLIT>, 0>(p, s);
-    case 20: return launch_gemm<GemmCfg<256, 256, 2, 4, EBITS, SPLIT>, 3>(p, s);   // simple schedule (default, large)
-    case 24: return launch_gemm<GemmCfg<128, 128, 2, 2, EBITS, SPLIT>, 3>(p, s);   // simple schedule (default, small)
+    case 24: return launch_gemm<GemmCfg<128, 128, 2, 2, EBITS, SPLIT>, 3>(p, s);   // simple schedule
     case 25: return launch_gemm<GemmCfg<256, 128, 4, 2, EBITS, SPLIT>, 3>(p, s);
-    case 26: return launch_gemm<GemmCfg<128, 256, 2, 4, EBITS, SPLIT>, 3>(p, s);
     case 27: return launch_gemm<GemmCfg<128, 64, 2, 2, EBITS, SPLIT>, 3>(p, s);    // mid-size problems: more, smaller tiles
     case 28: return launch_gemm<GemmCfg<64, 128, 2, 2, EBITS, SPLIT>, 3>(p, s);
     case 29: return launch_gemm<GemmCfg<64, 64, 2, 2, EBITS, SPLIT>, 3>(p, s);
@@ -137,25 +189,37 @@ int dispatch_variant(int v, const GemmParams& p, hipStream_t s, const char* name
     case 71: return launch_gemm<GemmCfg<128, 64, 2, 2, EBITS, SPLIT, 0, 3>, 7>(p, s);
     case 72: return launch_gemm<GemmCfg<64, 128, 2, 2, EBITS, SPLIT, 0, 3>, 7>(p, s);
     case 73: return launch_gemm<GemmCfg<128, 128, 2, 2, EBITS, SPLIT, 0, 3>, 7>(p, s);
+#if QAMD_BENCH
+    case 1: return launch_gemm<GemmCfg<256, 256, 2, 4, EBITS, SPLIT>, 1>(p, s);
+    case 2: return launch_gemm<GemmCfg<128, 128, 2, 2, EBITS, SPLIT>, 0>(p, s);
+    case 3: return launch_gemm<GemmCfg<256, 128, 4, 2, EBITS, SPLIT>, 0>(p, s);
+    case 4: return launch_gemm<GemmCfg<128, 256, 2, 4, EBITS, SPLIT>, 0>(p, s);
+    case 5: return launch_gemm<GemmCfg<256, 256, 2, 4, EBITS, SPLIT>, 0>(p, s);
+    case 20: return launch_gemm<GemmCfg<256, 256, 2, 4, EBITS, SPLIT>, 3>(p, s);   // simple schedule, 256x256
+    case 26: return launch_gemm<GemmCfg<128, 256, 2, 4, EBITS, SPLIT>, 3>(p, s);
     case 74: return launch_gemm<GemmCfg<64, 64, 2, 2, EBITS, SPLIT, 0, 4>, 7>(p, s);
     case 75: return launch_gemm<GemmCfg<64, 64, 2, 2, EBITS, SPLIT, 0, 6>, 7>(p, s);
-    case 80: return launch_gemm<GemmCfg<64, 64, 2, 2, EBITS, SPLIT, 1, 3>, 7>(p, s);     //   ring ablations (bench only): no DMA
+    case 80: return launch_gemm<GemmCfg<64, 64, 2, 2, EBITS, SPLIT, 1, 3>, 7>(p, s);     //   ring ablations: no DMA
     case 81: return launch_gemm<GemmCfg<64, 64, 2, 2, EBITS, SPLIT, 2, 3>, 7>(p, s);     //   no MFMA
     case 82: return launch_gemm<GemmCfg<64, 64, 2, 2, EBITS, SPLIT, 32, 3>, 7>(p, s);    //   no fragment reads
     case 83: return launch_gemm<GemmCfg<64, 64, 2, 2, EBITS, SPLIT, 34, 3>, 7>(p, s);    //   DMA + barriers only
     case 84: return launch_gemm<GemmCfg<64, 64, 2, 2, EBITS, SPLIT, 35, 3>, 7>(p, s);    //   barriers only
-    case 78: return launch_gemm<GemmCfg<64, 64, 2, 2, EBITS, SPLIT, 16, 3>, 7>(p, s);    //   per-wave timeline of workgroup 0 (bench only)
+    case 78: return launch_gemm<GemmCfg<64, 64, 2, 2, EBITS, SPLIT, 16, 3>, 7>(p, s);    //   per-wave timeline of workgroup 0
+#endif
   }
   if constexpr (EBITS == 8) {
     if (v == 30) return launch_gemm<GemmCfg<256, 256, 2, 2, 8, true>, 4>(p, s);   // fp8 deep schedule
   }
   if constexpr (EBITS == 4) {
+    if (v == 90) return launch_gemm_deepp<GemmCfg<256, 256, 2, 2, 4, false>>(p, s);   // persistent deep schedule
+#if QAMD_BENCH
+    if (v == 91) return launch_gemm_deepp<GemmCfg<256, 256, 2, 2, 4, false>, true>(p, s);   //   + phase timestamps of workgroup 0 (qutlass_amd_debug_set_trace_buffer)
     switch (v) {
       case 6: return launch_gemm<GemmCfg<256, 256, 2, 4, 4, false>, 2>(p, s);
       case 7: return launch_gemm<GemmCfg<128, 128, 2, 2, 4, false>, 2>(p, s);
       case 8: return launch_gemm<GemmCfg<256, 128, 4, 2, 4, false>, 2>(p, s);
       case 9: return launch_gemm<GemmCfg<128, 256, 2, 4, 4, false>, 2>(p, s);
-      case 30: return launch_gemm<GemmCfg<256, 256, 2, 2, 4, false>, 4>(p, s);      // deep schedule: 4 waves x 128x128
+      case 30: return launch_gemm<GemmCfg<256, 256, 2, 2, 4, false>, 4>(p, s);      // deep schedule: 4 waves x 128x128, one tile per workgroup
       case 31: return launch_gemm<GemmCfg<256, 256, 2, 2, 4, false, 8>, 4>(p, s);   //   no epilogue
       case 32: return launch_gemm<GemmCfg<256, 256, 2, 2, 4, false, 9>, 4>(p, s);   //   no DMA, no epilogue
       case 33: return launch_gemm<GemmCfg<256, 256, 2, 2, 4, false, 10>, 4>(p, s);  //   no MFMA, no epilogue
@@ -177,11 +241,14 @@ int dispatch_variant(int v, const GemmParams& p, hipStream_t s, const char* name
       case 22: return launch_gemm<GemmCfg<256, 256, 2, 4, 4, false, 9>, 3>(p, s);   //   no DMA, no epilogue
       case 23: return launch_gemm<GemmCfg<256, 256, 2, 4, 4, false, 10>, 3>(p, s);  //   no MFMA, no epilogue
     }
+#endif
   }
+#if QAMD_BENCH
   if constexpr (EBITS == 4 && !SPLIT) {
     const int rc = dispatch_ablation_mx4(v, p, s);
     if (rc >= 0) return rc;
   }
+#endif
   return fail(QAMD_ERR_INVALID, "%s: unknown gemm_variant %d", name, v);
 }
 
@@ -203,8 +270,7 @@ extern template int launch_gemm<GemmCfg<256, 256, 2, 2, 8, true>, 6>(GemmParams,
 // NVFP4 launches live in their own unit
 #if QAMD_DEF(4)
 int launch_nvf4_host(const NvGemmParams& p, hipStream_t s, int variant) {
-  (void)launch_nvf4_gemm(p, s, variant);
-  return 0;
+  return launch_nvf4_gemm(p, s, variant) == hipSuccess ? 0 : 1;
 }
 #else
 int launch_nvf4_host(const NvGemmParams& p, hipStream_t s, int variant);
@@ -223,8 +289,8 @@ SmallPlan plan_small(int64_t M, int64_t N, int64_t K) {
   if (T64 <= 256) {
     const int64_t KT = cdiv(K * EBITS / 8, 128);
     int64_t S = 1;
-    if (T64 < 256 && KT >= g_splitk_min_kt.load()) {                                       // shorter K: the reduce pass costs more than it saves
-      S = std::min<int64_t>(std::min<int64_t>(8, g_splitk_wg.load() / T64), KT / 8);   // up to one workgroup per CU, >= 8 stages per split
+    if (T64 < 256 && KT >= opt_splitk_min_kt()) {                                       // shorter K: the reduce pass costs more than it saves
+      S = std::min<int64_t>(std::min<int64_t>(8, opt_splitk_wg() / T64), KT / 8);   // up to one workgroup per CU, >= 8 stages per split
       if (S < 1) S = 1;
       const int64_t per = cdiv(KT, S);
       S = cdiv(KT, per);                                                // every split non-empty
@@ -255,12 +321,12 @@ int gemm_mx(const char* name, const void* A, const void* B, const void* A_sf, co
   p.alpha = alpha; p.D = (uint16_t*)D; p.M = (int)M; p.N = (int)N; p.K = (int)K; p.ldd = (int)N;
   p.a_bytes = (uint32_t)a_bytes; p.b_bytes = (uint32_t)b_bytes;
   p.sfa_bytes = (uint32_t)sfa_bytes; p.sfb_bytes = (uint32_t)sfb_bytes;
-  p.pp_shift = g_pp_shift.load();
-  p.pp_flags = g_pp_flags.load();
-  p.dbg = g_dbg.load();
+  p.pp_shift = opt_pp_shift();
+  p.pp_flags = opt_pp_flags();
+  p.dbg = opt_dbg();
   p.ws = nullptr; p.splits = 1;
   hipStream_t s = (hipStream_t)stream;
-  int variant = g_gemm_variant.load();
+  int variant = opt_gemm_variant();
   if (variant == 61 || variant == 62) variant = 0;   // these select the NN operand path only (matmul_mxf8_bf16_nn)
   // ring schedule + optional split-K (needs caller scratch; "pp_flags" bit 7 turns split-K off, bit 8 the ring rule)
   const SmallPlan pl = plan_small<EBITS>(M, N, K);
@@ -294,13 +360,15 @@ int gemm_mx(const char* name, const void* A, const void* B, const void* A_sf, co
     SkinnyParams q;
     q.A = p.A; q.B = p.B; q.SFA = p.SFA; q.SFB = p.SFB; q.alpha = alpha; q.D = p.D; q.M = p.M; q.N = p.N; q.K = p.K;
     q.a_bytes = p.a_bytes; q.b_bytes = p.b_bytes; q.sfa_bytes = p.sfa_bytes; q.sfb_bytes = p.sfb_bytes;
-    switch (variant) {   // 44..49: bench-only shapes of the split-K kernel (waves, segments per trip, chunk mapping)
+    switch (variant) {   // 44..49: lab-only shapes of the split-K kernel (waves, segments per trip, chunk mapping)
+#if QAMD_BENCH
       case 44: launch_skinny<true, 8, 2, true>(q, s); break;
       case 45: launch_skinny<true, 4, 2, false>(q, s); break;
       case 46: launch_skinny<true, 4, 2, true>(q, s); break;
       case 47: launch_skinny<true, 8, 2, false>(q, s); break;
       case 48: launch_skinny<true, 8, 1, true>(q, s); break;
       case 49: launch_skinny<true, 4, 4, true>(q, s); break;
+#endif
       default: launch_skinny<true, 8, 4, false>(q, s);   // 4 segments per wave per trip: 32 b128 loads in flight per wave
     }
     return check_launch("gemm_mx_skinny_kernel");
@@ -317,18 +385,21 @@ int gemm_mx(const char* name, const void* A, const void* B, const void* A_sf, co
     if (M <= 64) variant = (tiles(64, 128) >= 384) ? 28 : 29;
     else if (N <= 64) variant = (tiles(128, 64) >= want) ? 27 : 29;
     else if (tiles(256, 256) >= want) {
-      variant = 30;
+      // fp4: the persistent deep schedule (one workgroup per CU walks the tiles, epilogue folded into the last K stage);
+      // its epilogue addresses a tile with 32-bit byte offsets, so absurdly wide outputs stay with 256x128 simple tiles
+      const int big = (EBITS == 8) ? 30 : (N < (1ll << 22) ? 90 : 25);
+      variant = big;
       // wave quantisation: T tiles on 256 CUs run ceil(T/256) rounds; when the last round is less than ~60 % full
       // (C3 4096x14336x4096: 896 tiles = 3.5 rounds) the trailing tile columns go to a second launch with smaller
       // tiles that fills the chip once more for a fraction of a round.  Both launches write column ranges of the same
       // D (ldd = N); operands of the column range are plain pointer offsets (N-range starts on a 256 boundary).
       const int64_t tm = cdiv(M, 256), tn = cdiv(N, 256), T = tm * tn, full = (T / 256) * 256;
       const int64_t main_cols = (tm > 0) ? full / tm : 0;          // whole tile columns that fit the full rounds
-      if (!(g_pp_flags.load() & 64) && full >= 256 && main_cols >= 1 && main_cols < tn && (T - main_cols * tm) * 10 <= 256 * 6) {
+      if (!(opt_pp_flags() & 64) && full >= 256 && main_cols >= 1 && main_cols < tn && (T - main_cols * tm) * 10 <= 256 * 6) {
         const int64_t n1 = main_cols * 256;
         GemmParams pm = p;
         pm.N = (int)n1; pm.b_bytes = (uint32_t)(n1 * rowbytes); pm.sfb_bytes = (uint32_t)(cdiv(n1, 128) * CB * 512);
-        if (int rc = dispatch_variant<EBITS, EBITS == 8>(30, pm, s, name)) return rc;
+        if (int rc = dispatch_variant<EBITS, EBITS == 8>(big, pm, s, name)) return rc;
         GemmParams pt = p;
         pt.N = (int)(N - n1);
         pt.B = p.B + n1 * rowbytes; pt.b_bytes = (uint32_t)((N - n1) * rowbytes);
@@ -391,13 +462,11 @@ QAMD_ROT_INST int dispatch_rot<true, METHOD_ABSMAX, false>(int, const QuantParam
 #endif
 
 #if QAMD_DEF(1)
-std::atomic<int> g_quant_wg_per_cu{0};   // 0 = auto
-
 int quant_grid(int ntiles, int rot) {
   // 4 waves per workgroup, one 32-row tile per wave per trip.  Small rotations are pure streaming: as many waves as
   // fit (8 workgroups per CU; 8192^2 NV runs at 6.26 TB/s).  R = 128 tiles are 8 KiB with 32 MFMAs each: fewer, longer
   // waves let the software pipeline (next tile's loads in flight during this tile's MFMAs) overlap (13.2 vs 14.6 us).
-  int per_cu = g_quant_wg_per_cu.load();
+  int per_cu = opt_quant_wg_per_cu();
   if (per_cu <= 0) per_cu = rot >= 128 ? 2 : (rot >= 64 ? 4 : 8);
   int g = (ntiles + 3) / 4;
   const int cap = 256 * per_cu;
@@ -448,7 +517,7 @@ int qutlass_amd_matmul_ada_mxf4_bf16_tn(const void* A, const void* B, const void
   // from 128 tiles on (N >= 8192) the 64x64 ring kernel with row-major scale fetch streams the weight through full-line
   // LDS-DMA (M = 16: N = 14336, K = 4096 9.7 -> 6.9 us; N = 57344, K = 8192 62.6 -> 39.9 us), and any M > 32 goes there
   // too ("gemm_variant" 60 / 70 force either).
-  const int forced = g_gemm_variant.load();
+  const int forced = opt_gemm_variant();
   const int64_t T64 = cdiv(N, 64);   // (no split-K here -- the op has no scratch argument -- so a long K on few tiles stays with the split-K kernel:
                                      //  8 x 8192 x 28672: 27.9 us vs 34.2 us on 128 workgroups of the ring kernel)
   const bool ring = forced == 70 || (forced != 60 && (M > 32 || T64 >= 256 || (T64 >= 128 && K < 16384)));
@@ -458,7 +527,7 @@ int qutlass_amd_matmul_ada_mxf4_bf16_tn(const void* A, const void* B, const void
     p.alpha = alpha; p.D = (uint16_t*)D; p.M = (int)M; p.N = (int)N; p.K = (int)K; p.ldd = (int)N;
     p.a_bytes = (uint32_t)(M * (K / 2)); p.b_bytes = (uint32_t)(N * (K / 2));
     p.sfa_bytes = (uint32_t)(M * (K / 32)); p.sfb_bytes = (uint32_t)(N * (K / 32));   // row-major (rows, K/32), un-swizzled
-    p.pp_shift = g_pp_shift.load(); p.pp_flags = g_pp_flags.load(); p.dbg = g_dbg.load();
+    p.pp_shift = opt_pp_shift(); p.pp_flags = opt_pp_flags(); p.dbg = opt_dbg();
     p.ws = nullptr; p.splits = 1;
     return launch_gemm<GemmCfg<64, 64, 2, 2, 4, false, 0, 3>, 8>(p, (hipStream_t)stream);
   }
@@ -490,7 +559,7 @@ int qutlass_amd_matmul_mxf8_bf16_nn(const void* A, const void* B, const void* A_
   if (M * K >= (1ll << 31)) return fail(QAMD_ERR_INVALID, "%s: operand larger than 2 GiB is not supported", name);
   // large problems: the fused kernel reads A^T directly (no pre-pass, workspace untouched); "gemm_variant" 61 forces it,
   // 62 forces the pre-pass
-  const int forced = g_gemm_variant.load();
+  const int forced = opt_gemm_variant();
   if (forced == 61 || (forced == 0 && cdiv(M, 256) * cdiv(N, 256) >= 192)) {
     if (!B || !A_sf || !B_sf || !alpha || !D) return fail(QAMD_ERR_INVALID, "%s: null pointer argument", name);
     if (N % 8) return fail(QAMD_ERR_INVALID, "%s: N must be a multiple of 8 (got %lld)", name, (long long)N);
@@ -501,7 +570,7 @@ int qutlass_amd_matmul_mxf8_bf16_nn(const void* A, const void* B, const void* A_
     p.alpha = alpha; p.D = (uint16_t*)D; p.M = (int)M; p.N = (int)N; p.K = (int)K; p.ldd = (int)N;
     p.a_bytes = (uint32_t)(M * K); p.b_bytes = (uint32_t)(N * K);
     p.sfa_bytes = (uint32_t)(cdiv(M, 128) * CB * 512); p.sfb_bytes = (uint32_t)(cdiv(N, 128) * CB * 512);
-    p.pp_shift = g_pp_shift.load(); p.pp_flags = g_pp_flags.load(); p.dbg = g_dbg.load();
+    p.pp_shift = opt_pp_shift(); p.pp_flags = opt_pp_flags(); p.dbg = opt_dbg();
     return launch_gemm<GemmCfg<256, 256, 2, 2, 8, true>, 6>(p, (hipStream_t)stream);
   }
   TransposeParams t;
@@ -526,8 +595,8 @@ int qutlass_amd_matmul_nvf4_bf16_tn(const void* A, const void* B, const void* A_
   const int64_t CB = cdiv(K / 16, 4);
   p.a_bytes = (uint32_t)(M * (K / 2)); p.b_bytes = (uint32_t)(N * (K / 2));
   p.sfa_bytes = (uint32_t)(cdiv(M, 128) * CB * 512); p.sfb_bytes = (uint32_t)(cdiv(N, 128) * CB * 512);
-  p.dbg = g_dbg.load();
-  launch_nvf4_host(p, (hipStream_t)stream, g_nvf4_variant.load());
+  p.dbg = opt_dbg();
+  if (launch_nvf4_host(p, (hipStream_t)stream, opt_nvf4_variant())) return fail(QAMD_ERR_INVALID, "%s: unknown nvf4_variant %d", name, opt_nvf4_variant());
   return check_launch(name);
 }
 
@@ -633,9 +702,11 @@ int qutlass_amd_mxfp4_transpose_mxfp8(const void* x_fp4, const void* scales, int
   TrParams p;
   p.xq = (const uint8_t*)x_fp4; p.xs = (const uint8_t*)scales; p.y = (uint8_t*)y; p.out_sf = (uint8_t*)out_e8m0;
   p.m = (int)m; p.n = (int)n;
-  if (g_transpose_nc.load() == 256)
+#if QAMD_BENCH
+  if (opt_transpose_nc() == 256)
     hipLaunchKernelGGL(mxfp4_transpose_mxfp8_kernel<256>, dim3((unsigned)((m / 128) * (n / 256))), dim3(256), 0, (hipStream_t)stream, p);
   else
+#endif
     hipLaunchKernelGGL(mxfp4_transpose_mxfp8_kernel<128>, dim3((unsigned)((m / 128) * (n / 128))), dim3(256), 0, (hipStream_t)stream, p);
   return check_launch("mxfp4_transpose_mxfp8_kernel");
 }
@@ -678,15 +749,25 @@ int qutlass_amd_debug_gemm_plan(int ebits, int64_t M, int64_t N, int64_t K, int6
   return rc == QAMD_OK ? n : -1;
 }
 
-// bench/debug only (not declared in the public header): device buffer for ABL_TRACE builds
+#if QAMD_BENCH
+// lab library only: device buffer for ABL_TRACE / ABL_CLOCK builds
 void qutlass_amd_debug_set_trace_buffer(void* p) { g_dbg.store((uint32_t*)p); }
+#endif
 
 const char* qutlass_amd_last_error(void) { return g_err; }
-const char* qutlass_amd_version(void) { return "qutlass_amd 0.1.0 (gfx950)"; }
+#if QAMD_BENCH
+const char* qutlass_amd_version(void) { return "qutlass_amd 0.2.0 (gfx950, lab build)"; }
+#else
+const char* qutlass_amd_version(void) { return "qutlass_amd 0.2.0 (gfx950)"; }
+#endif
 
+// Product library: the only option is "hw_fp4_cvt" (hardware v_cvt_scalef32_pk_fp4_f32 vs the software encoder; both
+// produce the same bits, tests/test_gpu_parity.py).  Every other key -- in particular anything that would select a
+// kernel -- returns -1.  The lab library accepts the tuning / variant keys its benches use.
 int qutlass_amd_set_option(const char* key, int value) {
   if (!key) return -1;
   if (!strcmp(key, "hw_fp4_cvt")) return g_hw_fp4_cvt.exchange(value);
+#if QAMD_BENCH
   if (!strcmp(key, "gemm_variant")) return g_gemm_variant.exchange(value);
   if (!strcmp(key, "nvf4_variant")) return g_nvf4_variant.exchange(value);
   if (!strcmp(key, "transpose_nc")) return g_transpose_nc.exchange(value);
@@ -695,6 +776,7 @@ int qutlass_amd_set_option(const char* key, int value) {
   if (!strcmp(key, "quant_wg_per_cu")) return g_quant_wg_per_cu.exchange(value);
   if (!strcmp(key, "pp_shift")) return g_pp_shift.exchange(value);
   if (!strcmp(key, "pp_flags")) return g_pp_flags.exchange(value);
+#endif
   return -1;
 }
 

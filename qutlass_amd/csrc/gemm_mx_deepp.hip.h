@@ -1,0 +1,357 @@
+// Persistent "deep" MXFP4 GEMM for gfx950: the 4-wave 128x128-per-wave schedule of gemm_mx_deep (gemm_mx.hip.h) as a
+// tile LOOP with the epilogue folded into the last K stage.  Replaces the per-tile launch of
+// qutlass/csrc/gemm.cu:174-248 (matmul_host_mxf4_bf16_tn) for outputs of >= 192 tiles of 256x256.
+//
+// What changes against gemm_mx_deep (DESIGN.md section 3.4b has the measurements):
+//   * One workgroup per CU walks tiles t = wg, wg + G, ... (G = grid size).  The LDS-DMA stream never stops at a tile
+//     boundary: stage kt of a tile issues the DMA of stage kt + 2, and for the last two stages of a tile that is stage
+//     0 / 1 of the NEXT tile (descriptor selected with scalar selects -- the K loop stays branch-free).  The ~2 us a
+//     fresh workgroup spends waiting for its first two stages is paid once per launch, not once per tile.
+//   * The LAST K stage of a tile runs accumulator-stationary: all four k-slices are in registers, so the MFMA order is
+//     (m, n)-major and an accumulator tile is final after 4 MFMAs.  Each retired 32x32 tile goes through a WAVE-PRIVATE
+//     4-KiB LDS scratch (ds_write_b128 straight from the accumulator registers, 16-byte chunks XOR-swizzled by row) and
+//     comes back row-major: 8 fp32 per lane -> alpha, v_cvt_pk_bf16_f32 -> one 16-byte store, 16 rows x 64 B per wave
+//     instruction.  No workgroup barrier, no second pass over the tile: the stores of tile (m, n) issue in the MFMA
+//     shadows of tile (m, n + 1), and the DMA of the next tile's stage 1 + the fragment reads of its stage 0 are threaded
+//     through the same stage.
+//   * The first stage of a tile starts its accumulators from the inline constant 0 (no zeroing pass).
+//   * KT (K stages of 256 elements) is rounded up to even with an all-zero stage (out-of-range DMA offsets load zeros),
+//     so every tile starts in LDS buffer 0 and the stage code is unrolled by parity exactly once.
+// Same products, same K order per output as every other schedule: bit-identical results.
+#pragma once
+#include "gemm_mx.hip.h"
+
+namespace qamd {
+
+template <class C>
+struct DeepPCfg {
+  static constexpr int STAGE = C::STAGE_BYTES;
+  static constexpr int OFF_SCR = 2 * C::STAGE_BYTES;          // wave-private epilogue scratch: 4 KiB per wave
+  static constexpr int LDS_BYTES = OFF_SCR + C::NWAVES * 4096;
+  static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
+};
+
+// post-hand-off MFMA index at which accumulator tile T of the last stage is final: e(T) = 1, 3, 4T - 1; inverse (-1: none)
+constexpr int deepp_tile_done_at(int s) { return s == 1 ? 0 : s == 3 ? 1 : (s >= 7 && s <= 59 && (s + 1) % 4 == 0) ? (s + 1) / 4 : -1; }
+
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<I + 1, N>(f);
+  }
+}
+
+// TRACE (lab build only): workgroup 0, wave 0 writes {shader cycles, 100 MHz wall ticks} pairs to p.dbg at: kernel entry,
+// first stage landed, entry of the last stage of every tile, end of that stage, kernel exit (after the last store ack).
+template <class C, bool TRACE = false>
+__device__ __forceinline__ void gemm_mx_deepp(char* smem, const GemmParams& p) {
+  static_assert(C::EBITS == 4 && C::BM == 256 && C::BN == 256 && C::WAVES_M == 2 && C::WAVES_N == 2 && C::NSTAGE == 2 && C::PPW == 2,
+                "persistent deep schedule: fp4, 256x256 tiles, 4 waves of 128x128");
+  constexpr int MT = 4, NT = 4;
+  constexpr int STAGE = C::STAGE_BYTES, OFF_SCR = DeepPCfg<C>::OFF_SCR;
+  GemmCtx<C> cx(smem, p);   // per-lane offsets / LDS addresses; its tile coordinates and descriptors are NOT used here
+  const int lane = cx.lane, wave = cx.wave, i32 = cx.i32, g = cx.g;
+  const int KT = cx.KT, KTe = (KT + 1) & ~1, CB = cx.CB, rowbytes = cx.rowbytes;
+  const int ntiles = p.tiles_m * p.tiles_n, G = (int)gridDim.x;
+  const int wg = xcd_remap((int)blockIdx.x, G);
+
+  auto fence = [&]() __attribute__((always_inline)) { __builtin_amdgcn_sched_barrier(0); };
+  int trace_n = 0;
+  auto trace = [&]() __attribute__((always_inline)) {
+    if constexpr (TRACE) {
+      if (blockIdx.x == 0 && wave == 0 && p.dbg && trace_n < 30) {
+        const uint32_t c = (uint32_t)__builtin_readcyclecounter(), r = (uint32_t)__builtin_amdgcn_s_memrealtime();
+        if (lane == 0) { p.dbg[2 + 2 * trace_n] = c; p.dbg[3 + 2 * trace_n] = r; }
+      }
+      ++trace_n;
+    }
+  };
+  trace();
+
+  // ---- tile -> (m0, n0): rounds of G tiles, each round XCD-contiguous, grouped raster of 4 tile rows --------------------
+  auto decode = [&](int t, int& m0, int& n0) __attribute__((always_inline)) {
+    constexpr int GM = 4;
+    const int group = GM * p.tiles_n;
+    const int gid = t / group, first_m = gid * GM;
+    const int gsz = min(p.tiles_m - first_m, GM);
+    const int rem = t - gid * group;
+    m0 = uniform((first_m + rem % gsz) * C::BM);
+    n0 = uniform((rem / gsz) * C::BN);
+  };
+  struct Desc { __amdgpu_buffer_rsrc_t a, b, s; };
+  // operand descriptors of tile t (t >= ntiles: empty descriptors -> every DMA of that "tile" loads zeros)
+  auto make_desc = [&](int t) __attribute__((always_inline)) {
+    const bool valid = t < ntiles;
+    int m0, n0;
+    decode(valid ? t : ntiles - 1, m0, n0);
+    const uint32_t a_off = (uint32_t)m0 * rowbytes, b_off = (uint32_t)n0 * rowbytes;
+    const uint32_t sa_off = (uint32_t)(m0 >> 7) * CB * 512, sb_off = (uint32_t)(n0 >> 7) * CB * 512;
+    Desc d;
+    d.a = make_rsrc(p.A + a_off, valid ? p.a_bytes - a_off : 0u);
+    d.b = make_rsrc(p.B + b_off, valid ? p.b_bytes - b_off : 0u);
+    d.s = cx.sIsB ? make_rsrc(p.SFB + sb_off, valid ? p.sfb_bytes - sb_off : 0u) : make_rsrc(p.SFA + sa_off, valid ? p.sfa_bytes - sa_off : 0u);
+    return d;
+  };
+
+  // ---- registers -------------------------------------------------------------------------------------------------------
+  v16f acc[MT][NT];
+  v4i fa[4][MT] = {}, fb[4][NT] = {};
+  int sa[2][MT], sb[2][NT];
+
+  auto read_slice = [&](const int buf, const int j) __attribute__((always_inline)) {
+    const char* st = smem + buf * STAGE;
+#pragma unroll
+    for (int t = 0; t < MT; ++t) fa[j][t] = *(const v4i*)(st + cx.rdA[j] + t * 32 * C::ROWB);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) fb[j][t] = *(const v4i*)(st + cx.rdBd + cx.rdA[j] + t * 32 * C::ROWB);
+  };
+  auto read_fa = [&](const int buf, const int j, const int t) __attribute__((always_inline)) {
+    fa[j][t] = *(const v4i*)(smem + buf * STAGE + cx.rdA[j] + t * 32 * C::ROWB);
+  };
+  auto read_fb = [&](const int buf, const int j, const int t) __attribute__((always_inline)) {
+    fb[j][t] = *(const v4i*)(smem + buf * STAGE + cx.rdBd + cx.rdA[j] + t * 32 * C::ROWB);
+  };
+  auto read_scales = [&](const int buf, const int set) __attribute__((always_inline)) {
+    const char* st = smem + buf * STAGE;
+#pragma unroll
+    for (int t = 0; t < MT; ++t) sa[set][t] = *(const int*)(st + cx.rdSA[t]);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) sb[set][t] = *(const int*)(st + cx.rdSB[t]);
+  };
+  // one scaled FP4 MFMA: acc[m][n] (+)= B-fragment n x A-fragment m of k-slice j (op_sel byte j of the scale dwords of set sset)
+  auto mfma1 = [&](const int j, const int sset, const int m, const int n, const bool zero_c) __attribute__((always_inline)) {
+    const v4i a = fa[j][m], b = fb[j][n];
+    const v8i A8 = {a[0], a[1], a[2], a[3], 0, 0, 0, 0}, B8 = {b[0], b[1], b[2], b[3], 0, 0, 0, 0};
+    v16f c = acc[m][n];
+    if (zero_c) c = v16f{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (j == 0) acc[m][n] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(B8, A8, c, 4, 4, 0, sb[sset][n], 0, sa[sset][m]);
+    if (j == 1) acc[m][n] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(B8, A8, c, 4, 4, 1, sb[sset][n], 1, sa[sset][m]);
+    if (j == 2) acc[m][n] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(B8, A8, c, 4, 4, 2, sb[sset][n], 2, sa[sset][m]);
+    if (j == 3) acc[m][n] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(B8, A8, c, 4, 4, 3, sb[sset][n], 3, sa[sset][m]);
+  };
+  auto mfma_all = [&](const int j, const int sset, const bool zero_c) __attribute__((always_inline)) {
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int n = 0; n < NT; ++n) mfma1(j, sset, m, n, zero_c);
+  };
+
+  // ---- LDS-DMA of one stage, one instruction at a time (item 0..7: A pieces, 8..15: B pieces, 16: the scale piece) ------
+  // vb[par]: per-lane source offset of an even / odd piece for THIS stage (K-tail flavour, out-of-range when the stage
+  // does not exist), computed once per stage by dma_prep -- opaque to the optimiser so the selects stay arithmetic.
+  int vb0 = 0, vb1 = 0, vbS = 0;
+  auto dma_prep = [&](int kt, bool valid) __attribute__((always_inline)) {
+    int lastmask = (kt == KT - 1) ? -1 : 0;
+    int oobm = (valid && kt < KT) ? 0 : -1;
+    int oobs = (valid && kt * C::SCT + cx.colS < CB) ? 0 : -1;
+    asm volatile("" : "+v"(lastmask), "+v"(oobm), "+v"(oobs));
+    // out of range = 0x80000000: stays >= any descriptor range (< 2^31) after q * rstep (< 2^31) is added, never wraps
+    vb0 = (((cx.voffT[0] & lastmask) | (cx.voffAB[0] & ~lastmask)) & ~oobm) | ((int)0x80000000 & oobm);
+    vb1 = (((cx.voffT[1] & lastmask) | (cx.voffAB[1] & ~lastmask)) & ~oobm) | ((int)0x80000000 & oobm);
+    vbS = (cx.voffS & ~oobs) | ((int)0x80000000 & oobs);
+  };
+  auto dma_item = [&](const Desc& d, int kt, const int buf, const int item) __attribute__((always_inline)) {
+    char* st = smem + buf * STAGE;
+    if (item < 16) {
+      const int t = item & 7, q = wave * 8 + t;
+      const int v = ((t & 1) ? vb1 : vb0) + q * cx.rstep;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(item < 8 ? d.a : d.b, (lds_ptr_t)(st + (item < 8 ? 0 : C::OFF_B) + q * 1024), 16, v, kt * C::ROWB, 0, QAMD_DMA_AUX);
+    } else {
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(d.s, (lds_ptr_t)(st + C::OFF_S + wave * 1024), 16, vbS, kt * C::SCT * 512, 0, 0);
+    }
+  };
+  auto dma_stage = [&](const Desc& d, int kt, bool valid, const int buf) __attribute__((always_inline)) {
+    dma_prep(kt, valid);
+#pragma unroll
+    for (int i = 0; i < 17; ++i) dma_item(d, kt, buf, i);
+  };
+
+  // The first stage of a tile sits outside the K loop; without a use of its results in its own block LLVM's MachineSink
+  // moves all 64 MFMAs behind the DMA issue, into the loop pre-header.  pin_acc() "uses" the accumulators in place.
+  auto pin_acc = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int n = 0; n < NT; ++n) asm volatile("" : "+a"(acc[m][n]));
+  };
+
+  // ---- one K stage (not the last of its tile).  Entry: fragment sets 0, 1 and scale set BUF hold slices 0, 1 of this
+  //      stage; exit: the same for the next stage (other buffer).  The DMA threaded through M(2) is stage (d, ktl).
+  auto stage = [&](auto bufc, auto firstc, const Desc& d, int ktl, bool dvalid) __attribute__((always_inline)) {
+    constexpr int BUF = decltype(bufc)::value;
+    constexpr bool FIRST = decltype(firstc)::value;
+    read_slice(BUF, 2); fence();
+    mfma_all(0, BUF, FIRST); fence();
+    read_slice(BUF, 3); fence();
+    mfma_all(1, BUF, false); fence();
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // own DMA of the next stage landed; own reads of this buffer done
+    __builtin_amdgcn_s_barrier();
+    fence();
+    read_scales(BUF ^ 1, BUF ^ 1);
+    read_slice(BUF ^ 1, 0);
+    dma_prep(ktl, dvalid);
+    fence();
+    int idx = 0;
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int n = 0; n < NT; ++n) {
+        mfma1(2, BUF, m, n, false);
+        dma_item(d, ktl, BUF, idx);
+        if (idx == 0) dma_item(d, ktl, BUF, 16);
+        fence();
+        ++idx;
+      }
+    read_slice(BUF ^ 1, 1); fence();
+    mfma_all(3, BUF, false); fence();
+    if constexpr (FIRST) pin_acc();
+  };
+
+  // ---- epilogue pieces: one retired 32x32 accumulator tile through the wave-private scratch -----------------------------
+  char* scr = smem + OFF_SCR + wave * 4096;
+  const int scrW = i32 * 128 + ((((i32 & 6) << 4)) | ((g ^ (i32 & 1)) << 4));   // chunk (2q + g) ^ (row & 7) = this ^ (q << 5)
+  const int rrl = lane >> 2, ccl = lane & 3;                                     // read-back: row rrl (+16 per pass), columns 8 ccl .. +7
+  const int scrR = rrl * 128 + (((2 * ccl) ^ (rrl & 7)) << 4);                   // chunk 2 ccl of that row; chunk 2 ccl + 1 = this ^ 16
+  const float alpha = *p.alpha;
+  __amdgpu_buffer_rsrc_t rD = make_rsrc(p.D, 0);
+  int stLane = 0, colLim = 0;
+  // output descriptor of the tile at (m0, n0): base = its first element, range = what is left of D from there (capped at
+  // 2 GiB: a tile spans < 2^31 bytes, launch code rejects wider rows), so rows >= M fall out of range by themselves;
+  // columns >= N are pushed out of range per lane.
+  auto set_out_tile = [&](int m0, int n0) __attribute__((always_inline)) {
+    const int64_t left = ((int64_t)(p.M - m0) * p.ldd - n0) * 2;
+    rD = make_rsrc(p.D + ((int64_t)m0 * p.ldd + n0), (uint32_t)(left > 0x7fffffffll ? 0x7fffffffll : left));
+    stLane = ((cx.wave_m * C::WTM + rrl) * p.ldd + cx.wave_n * C::WTN + 8 * ccl) * 2;
+    colLim = p.N - n0 - cx.wave_n * C::WTN - 8 * ccl;   // column 32 n + 8 ccl of the wave tile exists iff 32 n < colLim
+  };
+  auto retire_write = [&](const int m, const int n) __attribute__((always_inline)) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      *(v4f*)(scr + (scrW ^ (q << 5))) = v4f{acc[m][n][4 * q + 0], acc[m][n][4 * q + 1], acc[m][n][4 * q + 2], acc[m][n][4 * q + 3]};
+  };
+  v4f rb[2][2];
+  auto retire_read = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int ps = 0; ps < 2; ++ps) {
+      rb[ps][0] = *(const v4f*)(scr + scrR + ps * 2048);
+      rb[ps][1] = *(const v4f*)(scr + (scrR ^ 16) + ps * 2048);
+    }
+  };
+  auto retire_store = [&](const int m, const int n, const int ps) __attribute__((always_inline)) {
+    const v4f lo = rb[ps][0], hi = rb[ps][1];
+    v4i o;
+    o[0] = (int)pack_bf16x2(lo[0] * alpha, lo[1] * alpha);
+    o[1] = (int)pack_bf16x2(lo[2] * alpha, lo[3] * alpha);
+    o[2] = (int)pack_bf16x2(hi[0] * alpha, hi[1] * alpha);
+    o[3] = (int)pack_bf16x2(hi[2] * alpha, hi[3] * alpha);
+    const int off = stLane + ((32 * m + 16 * ps) * p.ldd + 32 * n) * 2;
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, o), rD, (32 * n < colLim) ? off : (int)0x80000000, 0, 0);
+  };
+
+  // ---- the LAST stage of a tile (buffer 1), accumulator-stationary, with the tile's epilogue, the DMA of the next tile's
+  //      stage 1 (d) and the fragment / scale reads of the next tile's stage 0 (buffer 0, scale set 0) threaded through.
+  // MFMA sequence after the hand-off: tiles T = 0..15 in (m, n) row-major order, T0 and T1 with slices 2, 3 only (their
+  // slices 0, 1 ran before the hand-off to cover the latency of R(2), R(3)), every later tile with slices 0..3.  Tile T is
+  // final after post-hand-off MFMA e(T) = 1, 3, 4T - 1; its retirement is four items in the shadows of later MFMAs:
+  //   write (slot e+1)   read-back (e+4)   convert + store rows 0-15 (e+6)   rows 16-31 (e+7)        (tile 0: 2, 3, 5, 6)
+  auto final_stage = [&](const Desc& d, bool dvalid) __attribute__((always_inline)) {
+    read_slice(1, 2);
+    read_slice(1, 3);
+    fence();
+    mfma1(0, 1, 0, 0, false); mfma1(1, 1, 0, 0, false); mfma1(0, 1, 0, 1, false); mfma1(1, 1, 0, 1, false);
+    fence();
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // next tile's stage 0 landed (buffer 0); all reads of buffer 1 done
+    __builtin_amdgcn_s_barrier();
+    fence();
+    dma_prep(1, dvalid);
+    fence();
+    static_for<0, 68>([&](auto sc) __attribute__((always_inline)) {
+      constexpr int s = decltype(sc)::value;
+      if constexpr (s < 60) {
+        constexpr int T = s < 2 ? 0 : s < 4 ? 1 : 2 + (s - 4) / 4;
+        constexpr int j = s < 4 ? 2 + (s & 1) : (s - 4) % 4;
+        mfma1(j, 1, T / 4, T % 4, false);
+      }
+      // DMA of the next tile's stage 1 into buffer 1: one instruction every third slot
+      if constexpr (s % 3 == 0 && s / 3 < 17) dma_item(d, 1, 1, s / 3);
+      if constexpr (s == 1) read_scales(0, 0);
+      // fragments of the next tile's stage 0, as their registers die: A rows of m after tile (m, 3), B rows of n after (3, n)
+      if constexpr (s == 12 || s == 28 || s == 44) { read_fa(0, 0, (s - 12) / 16); read_fa(0, 1, (s - 12) / 16); }
+      if constexpr (s == 48 || s == 52 || s == 56) { read_fb(0, 0, (s - 48) / 4); read_fb(0, 1, (s - 48) / 4); }
+      if constexpr (s == 60) { read_fa(0, 0, 3); read_fa(0, 1, 3); read_fb(0, 0, 3); read_fb(0, 1, 3); }
+      // retirement items due in this slot.  One scratch tile and one read-back register set per wave, so for consecutive
+      // tiles Ta, Tb: write(Tb) after read(Ta), read(Tb) after the last store of Ta.  Tile 0 (final at e = 1):
+      // write 2, read 3, stores 5, 6.  Tile T >= 1 (final at e): write e + 1, read e + 4, stores e + 6, e + 7 -- with
+      // e(T + 1) = e(T) + 4 every constraint holds with one slot to spare (stores first: they use the previous read-back).
+      constexpr int Tw = deepp_tile_done_at(s - 1);
+      constexpr int Tr = s == 3 ? 0 : (deepp_tile_done_at(s - 4) >= 1 ? deepp_tile_done_at(s - 4) : -1);
+      constexpr int Ts0 = s == 5 ? 0 : (deepp_tile_done_at(s - 6) >= 1 ? deepp_tile_done_at(s - 6) : -1);
+      constexpr int Ts1 = s == 6 ? 0 : (deepp_tile_done_at(s - 7) >= 1 ? deepp_tile_done_at(s - 7) : -1);
+      if constexpr (Ts0 >= 0) retire_store(Ts0 / 4, Ts0 % 4, 0);
+      if constexpr (Ts1 >= 0) retire_store(Ts1 / 4, Ts1 % 4, 1);
+      if constexpr (Tw >= 0) retire_write(Tw / 4, Tw % 4);
+      if constexpr (Tr >= 0) retire_read();
+      fence();
+    });
+  };
+
+  // ---- prologue: first tile's stages 0 and 1 in flight; stage 0 landed -> first two slices into registers ---------------
+  int tile = wg;
+  Desc cur = make_desc(tile);
+  dma_stage(cur, 0, true, 0);
+  dma_stage(cur, 1, true, 1);
+  asm volatile("s_waitcnt vmcnt(17)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  fence();
+  read_scales(0, 0);
+  read_slice(0, 0);
+  read_slice(0, 1);
+  fence();
+  trace();
+
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+  using BT = std::integral_constant<bool, true>;
+  using BF = std::integral_constant<bool, false>;
+  while (tile < ntiles) {
+    int m0, n0;
+    decode(tile, m0, n0);
+    set_out_tile(m0, n0);
+    const int tnext = tile + G;
+    const Desc nxt = make_desc(tnext);
+    const bool nvalid = tnext < ntiles;
+    // stage 0 (accumulators start from 0); its DMA is stage 2 of this tile, or stage 0 of the next tile when KTe == 2
+    {
+      const bool tonext = KTe == 2;
+      Desc d;
+      d.a = tonext ? nxt.a : cur.a; d.b = tonext ? nxt.b : cur.b; d.s = tonext ? nxt.s : cur.s;
+      stage(I0{}, BT{}, d, tonext ? 0 : 2, tonext ? nvalid : true);
+    }
+    for (int kt = 1; kt + 2 < KTe; kt += 2) {
+      stage(I1{}, BF{}, cur, kt + 2, true);
+      const bool tonext = kt + 3 == KTe;
+      Desc d;
+      d.a = tonext ? nxt.a : cur.a; d.b = tonext ? nxt.b : cur.b; d.s = tonext ? nxt.s : cur.s;
+      stage(I0{}, BF{}, d, tonext ? 0 : kt + 3, tonext ? nvalid : true);
+    }
+    trace();
+    final_stage(nxt, nvalid);
+    trace();
+    cur = nxt;
+    tile = tnext;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  trace();
+  if constexpr (TRACE) {
+    if (blockIdx.x == 0 && wave == 0 && lane == 0 && p.dbg) p.dbg[0] = (uint32_t)trace_n;
+  }
+}
+
+template <class C, bool TRACE = false>
+__global__ __launch_bounds__(C::THREADS) void gemm_mx_deepp_kernel(const GemmParams p) {
+  __shared__ __attribute__((aligned(16))) char smem[DeepPCfg<C>::LDS_BYTES];
+  gemm_mx_deepp<C, TRACE>(smem, p);
+}
+
+}  // namespace qamd

@@ -614,6 +614,10 @@ __global__ __launch_bounds__(NWAVES * 64) void gemm_nvf4_skinny_kernel(const NvG
 #ifndef QAMD_TU
 #define QAMD_TU 0
 #endif
+#ifndef QAMD_BENCH
+#define QAMD_BENCH 0
+#endif
+#if QAMD_BENCH
 #if QAMD_TU == 0 || QAMD_TU == 7
 // bench-only ablations of the v2 kernel (variant 10 + b); returns false for any other variant.  (Not inline: the unit that
 // owns it must emit it.)
@@ -633,9 +637,14 @@ bool launch_nvf4_ablation(NvGemmParams p, hipStream_t s, int variant) {
 #else
 bool launch_nvf4_ablation(NvGemmParams p, hipStream_t s, int variant);
 #endif
+#endif   // QAMD_BENCH
 
 #if QAMD_TU == 0 || QAMD_TU == 4
+// Returns hipErrorInvalidValue for a variant this build does not know (the product library knows only 0 = auto).
 inline hipError_t launch_nvf4_gemm(NvGemmParams p, hipStream_t s, int variant = 0) {
+#if !QAMD_BENCH
+  if (variant != 0) return hipErrorInvalidValue;
+#endif
   // 128x128 tiles when a dimension is small OR when 256x256 tiles would leave most CUs without work
   const bool small = p.M <= 128 || p.N <= 128 || (int64_t)((p.M + 255) / 256) * ((p.N + 255) / 256) < 192;
   // small batch: split-K kernel for M <= 64, and up to M = 128 while even 64x64 tiles would leave CUs idle (measured,
@@ -645,6 +654,7 @@ inline hipError_t launch_nvf4_gemm(NvGemmParams p, hipStream_t s, int variant = 
     hipLaunchKernelGGL((gemm_nvf4_skinny_kernel<8>), dim3((p.N + 31) / 32, (p.M + 31) / 32), dim3(512), 0, s, p);
     return hipSuccess;
   }
+#if QAMD_BENCH
   if (variant == 4 && !small) {   // 4 waves of 128x128: each operand chunk is dequantised by 2 waves instead of 4 / 2
     using C = NvCfg<256, 256, 2, 2>;
     p.tiles_m = (p.M + C::BM - 1) / C::BM;
@@ -652,6 +662,7 @@ inline hipError_t launch_nvf4_gemm(NvGemmParams p, hipStream_t s, int variant = 
     hipLaunchKernelGGL((gemm_nvf4_kernel<C>), dim3(p.tiles_m * p.tiles_n), dim3(C::THREADS), 0, s, p);
     return hipSuccess;
   }
+#endif
   if (variant <= 1 || variant == 4 || (variant >= 5 && variant <= 7)) {
     // tile choice by occupancy (as for the MX kernels): the largest tile that gives >= 192 workgroups
     auto tiles = [&](int bm, int bn) { return (int64_t)((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn); };
@@ -676,7 +687,9 @@ inline hipError_t launch_nvf4_gemm(NvGemmParams p, hipStream_t s, int variant = 
     QAMD_NV_LAUNCH(64, 64, 2, 2)
 #undef QAMD_NV_LAUNCH
   }
+#if QAMD_BENCH
   if (variant >= 10 && launch_nvf4_ablation(p, s, variant)) return hipSuccess;
+  if (variant != 2) return hipErrorInvalidValue;
   if (small) {
     using C = NvLdsCfg<128, 128, 2, 2>;
     p.tiles_m = (p.M + C::BM - 1) / C::BM;
@@ -689,6 +702,9 @@ inline hipError_t launch_nvf4_gemm(NvGemmParams p, hipStream_t s, int variant = 
     hipLaunchKernelGGL((gemm_nvf4_lds_kernel<C>), dim3(p.tiles_m * p.tiles_n), dim3(C::THREADS), 0, s, p);
   }
   return hipSuccess;
+#else
+  return hipErrorInvalidValue;
+#endif
 }
 #endif   // QAMD_TU == 0 || QAMD_TU == 4
 

@@ -11,10 +11,11 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 
 def _ensure_built():
-    """The test session needs the in-tree binaries (product .so files + the oracle).  They are git-ignored, so on a
-    fresh checkout build them once here (hipcc cross-compiles gfx950 without a GPU); an existing build is left alone."""
+    """The test session needs the in-tree binaries (product .so files, the lab build the forced-variant tests use, and
+    the oracle).  They are git-ignored, so on a fresh checkout build them once here (hipcc cross-compiles gfx950 without
+    a GPU); an existing build is left alone."""
     need = [os.path.join(ROOT, "qutlass_amd", "libqutlass_amd.so"), os.path.join(ROOT, "qutlass_amd", "_C.so"),
-            os.path.join(ROOT, "oracle", "libqutlass_oracle.so")]
+            os.path.join(ROOT, "qutlass_amd", "libqutlass_amd_bench.so"), os.path.join(ROOT, "oracle", "libqutlass_oracle.so")]
     if all(os.path.exists(f) for f in need):
         return
     import importlib.util
@@ -23,6 +24,7 @@ def _ensure_built():
     b = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(b)
     b.build(verbose=True)
+    b.build_bench_lib(verbose=True)
     import oracle
 
     oracle.build()

@@ -17,6 +17,8 @@
 #include <vector>
 
 #include "../../include/qutlass_amd.h"
+#include "smi_sampler.h"
+extern std::vector<uint32_t> gaussian_e2m1_image(size_t bytes, uint32_t seed);  // ubench.hip
 
 extern "C" {
 float orc_e2m1_decode(uint8_t);
@@ -283,10 +285,15 @@ static void check_bench_nn(int64_t M, int64_t N, int64_t K, int iters) {
 }
 
 static int g_zero_fill = 0;
+static int g_gauss_fill = 0;   // fp4 operands = e2m1 codes of quantised N(0,1) data (what fusedQuantizeMx produces) instead of uniformly random bytes
 static int g_warm_override = 0, g_iters_override = 0;
 static void bench_gemm(const char* tag, int kind, int64_t M, int64_t N, int64_t K, int variant, int iters) {
   GemmData g = make_gemm(kind, M, N, K, 1.0f, 77, 3);
   if (g_zero_fill) { std::fill(g.A.begin(), g.A.end(), 0); std::fill(g.B.begin(), g.B.end(), 0); }
+  if (g_gauss_fill && kind == 0) {
+    std::vector<uint32_t> ia = gaussian_e2m1_image(g.A.size(), 11), ib = gaussian_e2m1_image(g.B.size(), 12);
+    memcpy(g.A.data(), ia.data(), g.A.size()); memcpy(g.B.data(), ib.data(), g.B.size());
+  }
   DBuf<uint8_t> dA(g.A.size()), dB(g.B.size()), dSA(g.sfa.size()), dSB(g.sfb.size());
   DBuf<float> dAl(1);
   DBuf<uint16_t> dD((size_t)M * N);
@@ -448,6 +455,7 @@ extern void run_probe();   // probe.hip
 extern void run_ubench();  // ubench.hip
 extern void run_valu_rates();  // ubench.hip
 extern void run_ubench_steady();  // ubench.hip
+extern void run_ubench_power(const char* csv_path);  // ubench.hip
 extern "C" void qutlass_amd_debug_set_trace_buffer(void*);
 
 // Per-wave block timeline of workgroup 0 of the ping-pong kernel (ABL_TRACE builds, variants 116..118).
@@ -510,6 +518,109 @@ int main(int argc, char** argv) {
   if (argc > 1 && want("valu")) run_valu_rates();
   if (argc > 1 && want("usteady")) run_ubench_steady();
   if (want("probe")) run_probe();
+  if (argc > 1 && want("power")) run_ubench_power("gpurun_out/power_trace_ubench_r2.csv");
+  if (argc > 1 && want("gpower")) {   // socket power + sclk trace of the headline GEMM: kernel variants x operand classes, ~1 s each
+    SmiSampler smi;
+    std::vector<std::pair<double, std::string>> marks;
+    smi.start();
+    struct Cls { const char* name; int zero, gauss; };
+    const Cls classes[] = {{"zero", 1, 0}, {"uniform", 0, 0}, {"gaussian", 0, 1}};
+    const int64_t M = 4096, N = 4096, K = 4096;
+    for (const Cls& c : classes) {
+      g_zero_fill = c.zero; g_gauss_fill = c.gauss;
+      GemmData g = make_gemm(0, M, N, K, 1.0f, 77, 3);
+      if (c.zero) { std::fill(g.A.begin(), g.A.end(), 0); std::fill(g.B.begin(), g.B.end(), 0); }
+      if (c.gauss) {
+        std::vector<uint32_t> ia = gaussian_e2m1_image(g.A.size(), 11), ib = gaussian_e2m1_image(g.B.size(), 12);
+        memcpy(g.A.data(), ia.data(), g.A.size()); memcpy(g.B.data(), ib.data(), g.B.size());
+      }
+      DBuf<uint8_t> dA(g.A.size()), dB(g.B.size()), dSA(g.sfa.size()), dSB(g.sfb.size());
+      DBuf<float> dAl(1);
+      DBuf<uint16_t> dD((size_t)M * N);
+      dA.up(g.A); dB.up(g.B); dSA.up(g.sfa); dSB.up(g.sfb); dAl.up({1.0f});
+      for (int var : {30, 90, 31, 32}) {   // deep (per-tile), persistent deep, deep without epilogue, deep without DMA and epilogue (MFMA + reads)
+        qutlass_amd_set_option("gemm_variant", var);
+        char tag[96];
+        snprintf(tag, sizeof tag, "gemm %s var %d", c.name, var);
+        marks.push_back({smi.now_ms(), tag});
+        const auto t0 = std::chrono::steady_clock::now();
+        auto el = [&] { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); };
+        while (el() < 0.35) { for (int i = 0; i < 200; ++i) Q_OK(qutlass_amd_matmul_mxf4_bf16_tn(dA.p, dB.p, dSA.p, dSB.p, dAl.p, dD.p, M, N, K, nullptr)); HIP_OK(hipDeviceSynchronize()); }
+        hipEvent_t e0, e1; HIP_OK(hipEventCreate(&e0)); HIP_OK(hipEventCreate(&e1));
+        const double a_ms = smi.now_ms();
+        HIP_OK(hipEventRecord(e0, 0));
+        long n = 0;
+        while (el() < 1.2) { for (int i = 0; i < 500; ++i) Q_OK(qutlass_amd_matmul_mxf4_bf16_tn(dA.p, dB.p, dSA.p, dSB.p, dAl.p, dD.p, M, N, K, nullptr)); n += 500; HIP_OK(hipStreamSynchronize(0)); }
+        HIP_OK(hipEventRecord(e1, 0)); HIP_OK(hipEventSynchronize(e1));
+        const double b_ms = smi.now_ms();
+        float ms; HIP_OK(hipEventElapsedTime(&ms, e0, e1));
+        double w, mhz; int ns; smi.mean(a_ms + 20, b_ms, w, mhz, ns);
+        const double us = ms * 1e3 / n;
+        printf("GPOWER %-9s var %3d  %7.2f us/launch  %7.1f TFLOP/s  socket %6.0f W  sclk(smi) %5.0f MHz  energy/launch %5.1f mJ  (%d samples)\n", c.name, var, us, 2.0 * M * N * K / us * 1e-6, w, mhz,
+               w * us * 1e-3, ns);
+        fflush(stdout);
+        hipEventDestroy(e0); hipEventDestroy(e1);
+      }
+      qutlass_amd_set_option("gemm_variant", 0);
+    }
+    g_zero_fill = 0; g_gauss_fill = 0;
+    smi.finish();
+    smi.dump("gpurun_out/power_trace_gemm_r2.csv", marks);
+  }
+  if (want("deepp")) {   // persistent deep schedule (variant 90) against the oracle and against the per-tile deep schedule (30)
+    for (int var : {90}) {
+      check_gemm("deepp 256x256x512 (one tile)", 0, 256, 256, 512, 1.0f, 3, 0, var);
+      check_gemm("deepp 128^3 (partial tile, KT = 1)", 0, 128, 128, 128, 1.0f, 3, 0, var);
+      check_gemm("deepp 256x256x256 (KT = 1 + zero stage)", 0, 256, 256, 256, 0.5f, 3, 0, var);
+      check_gemm("deepp 200x264x384 (KT = 2 with K tail)", 0, 200, 264, 384, 1.0f, 3, 0, var);
+      check_gemm("deepp ragged + K tail 72x136x640", 0, 72, 136, 640, 0.5f, 4, 0, var);
+      check_gemm("deepp 300x520x1152 (6 tiles, KT = 5 -> 6)", 0, 300, 520, 1152, 1.0f, 3, 0, var);
+      check_gemm("deepp 504x504x2048", 0, 504, 504, 2048, 1.0f, 3, 0, var);
+      check_gemm("deepp 1x8x128", 0, 1, 8, 128, 1.0f, 2, 0, var);
+      check_gemm("deepp 2304x3592x1152 (135 ragged tiles)", 0, 2304, 3592, 1152, 0.5f, 3, 48, var);
+      check_gemm("deepp 4100x4360x768 (306 ragged tiles: 2 rounds)", 0, 4100, 4360, 768, 0.5f, 3, 64, var);
+      check_gemm("deepp 5000x8200x512 (660 tiles: 3 rounds, KTe = 2)", 0, 5000, 8200, 512, 1.0f, 3, 64, var);
+      check_gemm("deepp 4096^3 (64 rows)", 0, 4096, 4096, 4096, 1.0f, 3, 64, var);
+      check_gemm("deepp 4096x12288x4096 (C3 main part, 48 rows)", 0, 4096, 12288, 4096, 1.0f, 3, 48, var);
+      check_gemm("deepp 8192x8192x1024 (4 rounds, 48 rows)", 0, 8192, 8192, 1024, 1.0f, 3, 48, var);
+    }
+    check_gemm("auto C3 4096x14336x4096 (deepp + tail, 64 rows)", 0, 4096, 14336, 4096, 1.0f, 3, 64, 0);
+    check_gemm("auto 4096x11008x4096 (64 rows)", 0, 4096, 11008, 4096, 0.5f, 3, 64, 0);
+  }
+  if (want("deepptrace")) {   // phase timeline of workgroup 0 of the persistent deep kernel (variant 91), in the steady state
+    struct Sh { int64_t M, N, K; };
+    for (const Sh& sh : {Sh{4096, 4096, 4096}, Sh{4096, 12288, 4096}, Sh{8192, 8192, 8192}}) {
+      DBuf<uint32_t> dT(64);
+      HIP_OK(hipMemset(dT.p, 0, 256));
+      qutlass_amd_debug_set_trace_buffer(dT.p);
+      g_gauss_fill = 1; g_warm_override = 1500; g_iters_override = 500;
+      bench_gemm("mxfp4 persistent deep + timestamps", 0, sh.M, sh.N, sh.K, 91, 0);
+      g_gauss_fill = 0; g_warm_override = 0; g_iters_override = 0;
+      qutlass_amd_debug_set_trace_buffer(nullptr);
+      std::vector<uint32_t> t = dT.down();
+      const int n = (int)t[0];
+      printf("  TRACE wg 0 / wave 0, %d marks (entry, first stage landed, [last-stage entry, last-stage exit] per tile, exit):\n", n);
+      for (int i = 0; i < n && i < 30; ++i)
+        printf("    mark %2d  +%8u cycles  +%7.2f us   (since previous: %7u cycles, %6.2f us -> %.2f GHz)\n", i, t[2 + 2 * i] - t[2], (t[3 + 2 * i] - t[3]) * 0.01,
+               i ? t[2 + 2 * i] - t[2 * i] : 0, i ? (t[3 + 2 * i] - t[1 + 2 * i]) * 0.01 : 0.0, i && t[3 + 2 * i] != t[1 + 2 * i] ? (t[2 + 2 * i] - t[2 * i]) / ((t[3 + 2 * i] - t[1 + 2 * i]) * 10.0) : 0.0);
+    }
+  }
+  if (want("deeppbench")) {
+    g_gauss_fill = 1;
+    g_warm_override = 2500; g_iters_override = 2500;
+    for (int rep = 0; rep < 2; ++rep)
+      for (int var : {30, 90, 31}) bench_gemm("mxfp4 4096^3 steady (gaussian codes)", 0, 4096, 4096, 4096, var, 0);
+    g_warm_override = 600; g_iters_override = 600;
+    for (int rep = 0; rep < 2; ++rep) {
+      for (int var : {30, 90}) bench_gemm("mxfp4 4096x12288x4096 steady (gaussian codes)", 0, 4096, 12288, 4096, var, 0);
+      bench_gemm("mxfp4 C3 auto steady (gaussian codes)", 0, 4096, 14336, 4096, 0, 0);
+    }
+    g_warm_override = 300; g_iters_override = 300;
+    for (int rep = 0; rep < 2; ++rep)
+      for (int var : {30, 90}) bench_gemm("mxfp4 8192^3 steady (gaussian codes)", 0, 8192, 8192, 8192, var, 0);
+    g_warm_override = 0; g_iters_override = 0;
+    g_gauss_fill = 0;
+  }
 
   if (want("blocked")) {
     check_blocked(128, 4); check_blocked(256, 16); check_blocked(384, 12); check_blocked(4096, 128);

@@ -11,9 +11,18 @@
 // Reported: shader cycles per iteration (s_memtime, wave 0 of workgroup 0) with every CU busy.
 #include <hip/hip_runtime.h>
 
+#include <atomic>
+#include <chrono>
+#include <cmath>
 #include <cstdint>
 #include <cstdio>
+#include <cstring>
+#include <random>
+#include <string>
+#include <thread>
 #include <vector>
+
+#include "smi_sampler.h"
 
 typedef int v8i __attribute__((ext_vector_type(8)));
 typedef int v4i __attribute__((ext_vector_type(4)));
@@ -23,18 +32,21 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
 #define HIP_OK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP ERROR %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(2);} } while (0)
 
 template <int MODE, int THREADS>
-__global__ __launch_bounds__(THREADS) void ub_kernel(const char* g, uint32_t gbytes, float* out, uint32_t* cyc, int iters, int random_fill) {
+__global__ __launch_bounds__(THREADS) void ub_kernel(const char* g, uint32_t gbytes, float* out, uint32_t* cyc, int iters, int random_fill, const uint32_t* fill = nullptr) {
   __shared__ __attribute__((aligned(16))) char smem[64 * 1024 + 16 * 1024];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   for (int i = tid; i < 64 * 1024 / 4; i += THREADS) {
     uint32_t x = (uint32_t)i * 2654435761u + blockIdx.x * 40503u + 12345u;   // operand bits: constant (low toggle power) or pseudo-random
     x ^= x >> 13; x *= 0x5bd1e995u; x ^= x >> 15;
-    ((uint32_t*)smem)[i] = random_fill ? x : 0x22222222u;
+    ((uint32_t*)smem)[i] = fill ? fill[i] : (random_fill ? x : 0x22222222u);   // fill: 64 KiB operand image prepared by the host (e.g. quantised Gaussian codes)
   }
   __syncthreads();
   const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(g), 0, gbytes, 0x00020000);
   v16f acc[8];
   for (int a = 0; a < 8; ++a) for (int r = 0; r < 16; ++r) acc[a][r] = 0.f;
+  typedef float v4f_ __attribute__((ext_vector_type(4)));
+  v4f_ acc4[32];   // MODE 26 only (16x16x128 MFMAs)
+  for (int a = 0; a < 32; ++a) acc4[a] = v4f_{0.f, 0.f, 0.f, 0.f};
   v4i fa[2][4], fb[2][2];
   // conflict-free fragment addressing of the GEMM: row = lane&31, chunk c = 4*(lane>>5) + j, phys = c ^ ((row>>1)&7)
   const int sw = ((lane & 31) >> 1) & 7;
@@ -83,7 +95,7 @@ __global__ __launch_bounds__(THREADS) void ub_kernel(const char* g, uint32_t gby
   for (int it = 0; it < iters; it += 2) {
     const int off0 = (it >> 1) & 3, off1 = (off0 + 1) & 3;   // k-slice index j (runtime, like the stage loop)
     if (MODE == 0) { mfma8(0); fence(); mfma8(1); fence(); }
-    if (MODE >= 20 && MODE <= 23) {   // accumulator-stationary orders: CH back-to-back MFMAs into the SAME accumulator (8 / 4 / 2), 23 = operand-stationary A
+    if (MODE >= 20 && MODE <= 23) {     // accumulator-stationary orders: CH back-to-back MFMAs into the SAME accumulator (8 / 4 / 2), 23 = operand-stationary A
       constexpr int CH = MODE == 20 ? 8 : MODE == 21 ? 4 : 2;
 #pragma unroll
       for (int set = 0; set < 2; ++set)
@@ -94,6 +106,28 @@ __global__ __launch_bounds__(THREADS) void ub_kernel(const char* g, uint32_t gby
           const v4i a = fa[set][a_i], b = fb[set][b_i];
           acc[acc_i] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(v8i{b[0], b[1], b[2], b[3], 0, 0, 0, 0}, v8i{a[0], a[1], a[2], a[3], 0, 0, 0, 0},
                                                                         acc[acc_i], 4, 4, 0, scale, 0, scale);
+        }
+      fence();
+    }
+    if (MODE == 24 || MODE == 25) {   // 24: every MFMA the SAME two operands (nothing toggles between MFMAs); 25: both operands change on every MFMA
+      auto frag = [&](const int k) __attribute__((always_inline)) { return k < 8 ? fa[k >> 2][k & 3] : fb[(k - 8) >> 1][(k - 8) & 1]; };
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const v4i a = (MODE == 24) ? fa[0][0] : frag((2 * i) % 12);
+        const v4i b = (MODE == 24) ? fb[0][0] : frag((2 * i + 1) % 12);
+        acc[i & 7] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(v8i{b[0], b[1], b[2], b[3], 0, 0, 0, 0}, v8i{a[0], a[1], a[2], a[3], 0, 0, 0, 0},
+                                                                     acc[i & 7], 4, 4, 0, scale, 0, scale);
+      }
+      fence();
+    }
+    if (MODE == 26) {   // the same FLOPs on v_mfma_scale_f32_16x16x128_f8f6f4: 32 MFMAs of 16x16x128 = 16 of 32x32x64
+#pragma unroll
+      for (int set = 0; set < 2; ++set)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const v4i a = fa[set][i & 3], b = fb[set][(i >> 2) & 1];
+          acc4[set * 16 + i] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(v8i{b[0], b[1], b[2], b[3], 0, 0, 0, 0}, v8i{a[0], a[1], a[2], a[3], 0, 0, 0, 0},
+                                                                                acc4[set * 16 + i], 4, 4, 0, scale, 0, scale);
         }
       fence();
     }
@@ -138,6 +172,7 @@ __global__ __launch_bounds__(THREADS) void ub_kernel(const char* g, uint32_t gby
   const uint64_t t1 = __builtin_readcyclecounter();
   float s = 0.f;
   for (int a = 0; a < 8; ++a) for (int r = 0; r < 16; ++r) s += acc[a][r];
+  if (MODE == 26) for (int a = 0; a < 32; ++a) s += acc4[a][0] + acc4[a][1] + acc4[a][2] + acc4[a][3];
   for (int st = 0; st < 2; ++st) { for (int t = 0; t < 4; ++t) s += (float)fa[st][t][0]; for (int t = 0; t < 2; ++t) s += (float)fb[st][t][1]; }
   out[blockIdx.x * THREADS + tid] = s + ((float*)smem)[16384 + tid];
   if (blockIdx.x == 0 && lane == 0) cyc[wave] = (uint32_t)(t1 - t0);
@@ -145,22 +180,24 @@ __global__ __launch_bounds__(THREADS) void ub_kernel(const char* g, uint32_t gby
 
 static int g_random_fill = 0;
 static int g_steady_warm = 0;
+static const uint32_t* g_fill = nullptr;   // device pointer: 64 KiB operand image (overrides g_random_fill)
+static const char* g_fill_name = nullptr;
 template <int MODE, int THREADS>
 static void run_one(const char* name, const char* g, uint32_t gbytes, float* out, uint32_t* cyc, int blocks) {
   const int iters = 20000;
   // g_steady_warm launches first: the part needs ~50 ms under load to leave its clock ramp (tools/clock_ramp.py)
-  for (int w = 0; w < (g_steady_warm ? g_steady_warm : 1); ++w) ub_kernel<MODE, THREADS><<<blocks, THREADS>>>(g, gbytes, out, cyc, iters, g_random_fill);
+  for (int w = 0; w < (g_steady_warm ? g_steady_warm : 1); ++w) ub_kernel<MODE, THREADS><<<blocks, THREADS>>>(g, gbytes, out, cyc, iters, g_random_fill, g_fill);
   HIP_OK(hipDeviceSynchronize());
   hipEvent_t e0, e1;
   HIP_OK(hipEventCreate(&e0)); HIP_OK(hipEventCreate(&e1));
   HIP_OK(hipEventRecord(e0, 0));
-  ub_kernel<MODE, THREADS><<<blocks, THREADS>>>(g, gbytes, out, cyc, iters, g_random_fill);
+  ub_kernel<MODE, THREADS><<<blocks, THREADS>>>(g, gbytes, out, cyc, iters, g_random_fill, g_fill);
   HIP_OK(hipEventRecord(e1, 0));
   HIP_OK(hipEventSynchronize(e1));
   float ms; HIP_OK(hipEventElapsedTime(&ms, e0, e1));
   uint32_t h[8];
   HIP_OK(hipMemcpy(h, cyc, sizeof h, hipMemcpyDeviceToHost));
-  printf("UBENCH %s mode %d %-44s waves/SIMD=%d blocks=%3d : %7.1f cycles/iter (wave0)  %7.1f ns/iter  -> clock %.2f GHz\n", g_random_fill ? "[random operands]" : "[const operands] ", MODE, name, THREADS / 256, blocks,
+  printf("UBENCH %s mode %d %-44s waves/SIMD=%d blocks=%3d : %7.1f cycles/iter (wave0)  %7.1f ns/iter  -> clock %.2f GHz\n", g_fill_name ? g_fill_name : g_random_fill ? "[random operands]" : "[const operands] ", MODE, name, THREADS / 256, blocks,
          (double)h[0] / iters, ms * 1e6 / iters, (double)h[0] / (ms * 1e6));
   hipEventDestroy(e0); hipEventDestroy(e1);
 }
@@ -393,4 +430,108 @@ void run_valu_rates() {
     run_valu<5>("8 x MFMA f16 + 32 x (cvt + pk_mul)", 72, w);
     run_valu<6>("8 x v_mfma_f32_32x32x16_f16, RANDOM operands", 8, w);
   }
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// Power / clock traces: socket power and shader clock sampled through librocm_smi64 from a host
+// thread (>= 100 Hz) while one kernel runs back to back for a fixed wall time.  Operand classes of the FP4 MFMA loop:
+//   const      every nibble 0x2 (= 1.0): the data class micro-benchmarks that quote ~9 PF use
+//   uniform    uniformly random bytes (worst-case toggling)
+//   gaussian   e2m1 codes of N(0,1) data quantised per 32 with the abs-max rule of fusedQuantizeMx (what the GEMM sees)
+// ------------------------------------------------------------------------------------------------
+// 64 KiB image of e2m1 codes: N(0,1) values, groups of 32, scale = 2^floor(log2(amax)), q = RTNE_e2m1(3 x / scale)
+std::vector<uint32_t> gaussian_e2m1_image(size_t bytes, uint32_t seed) {
+  std::mt19937 rng(seed);
+  std::normal_distribution<float> nd(0.f, 1.f);
+  std::vector<uint8_t> out(bytes);
+  const float grid[8] = {0.f, 0.5f, 1.f, 1.5f, 2.f, 3.f, 4.f, 6.f};
+  for (size_t g0 = 0; g0 < bytes * 2; g0 += 32) {
+    float x[32], amax = 0.f;
+    for (int i = 0; i < 32; ++i) { x[i] = nd(rng); amax = std::max(amax, std::fabs(x[i])); }
+    const float sc = std::exp2(std::floor(std::log2(amax)));
+    for (int i = 0; i < 32; ++i) {
+      const float v = std::fabs(x[i]) / sc * 3.0f;
+      int best = 0;
+      for (int c = 1; c < 8; ++c) if (std::fabs(v - grid[c]) < std::fabs(v - grid[best]) || (std::fabs(v - grid[c]) == std::fabs(v - grid[best]) && !(c & 1))) best = c;
+      const uint8_t code = (uint8_t)(best | (x[i] < 0 ? 8 : 0));
+      const size_t e = g0 + i;
+      if (e & 1) out[e >> 1] |= (uint8_t)(code << 4); else out[e >> 1] = code;
+    }
+  }
+  std::vector<uint32_t> w(bytes / 4);
+  memcpy(w.data(), out.data(), bytes);
+  return w;
+}
+
+template <int MODE, int THREADS>
+static void power_run(SmiSampler& smi, std::vector<std::pair<double, std::string>>& marks, const char* cls, const char* name, const char* g, uint32_t gbytes, float* out,
+                      uint32_t* cyc, double seconds, double flop_per_iter) {
+  const int iters = 20000;
+  char tag[160];
+  snprintf(tag, sizeof tag, "%s mode %d %s", cls, MODE, name);
+  marks.push_back({smi.now_ms(), tag});
+  hipEvent_t e0, e1;
+  HIP_OK(hipEventCreate(&e0)); HIP_OK(hipEventCreate(&e1));
+  const auto t_begin = std::chrono::steady_clock::now();
+  auto el = [&] { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count(); };
+  while (el() < seconds * 0.35) {   // ramp
+    for (int i = 0; i < 4; ++i) ub_kernel<MODE, THREADS><<<256, THREADS>>>(g, gbytes, out, cyc, iters, g_random_fill, g_fill);
+    HIP_OK(hipDeviceSynchronize());
+  }
+  const double a_ms = smi.now_ms();
+  HIP_OK(hipEventRecord(e0, 0));
+  int n = 0;
+  while (el() < seconds) {
+    for (int i = 0; i < 4; ++i) ub_kernel<MODE, THREADS><<<256, THREADS>>>(g, gbytes, out, cyc, iters, g_random_fill, g_fill);
+    n += 4;
+    HIP_OK(hipStreamSynchronize(0));
+  }
+  HIP_OK(hipEventRecord(e1, 0));
+  HIP_OK(hipEventSynchronize(e1));
+  const double b_ms = smi.now_ms();
+  float ms; HIP_OK(hipEventElapsedTime(&ms, e0, e1));
+  uint32_t h[8];
+  HIP_OK(hipMemcpy(h, cyc, sizeof h, hipMemcpyDeviceToHost));
+  double w, mhz; int ns;
+  smi.mean(a_ms + 20, b_ms, w, mhz, ns);
+  const double ns_iter = ms * 1e6 / ((double)n * iters);
+  printf("POWER %-10s mode %2d %-46s %7.1f ns/iter  %6.0f TFLOP/s  cycles/iter %6.1f -> %4.2f GHz (s_memtime)   socket %6.0f W  sclk(smi) %5.0f MHz  (%d samples)\n", cls, MODE, name, ns_iter,
+         flop_per_iter * 256 * (THREADS / 64) / ns_iter * 1e-3, (double)h[0] / iters, (double)h[0] / iters / ns_iter, w, mhz, ns);
+  fflush(stdout);
+  hipEventDestroy(e0); hipEventDestroy(e1);
+}
+
+void run_ubench_power(const char* csv_path) {
+  const uint32_t gbytes = 64u << 20;
+  char* g; float* out; uint32_t* cyc; uint32_t* fill;
+  HIP_OK(hipMalloc(&g, gbytes)); HIP_OK(hipMemset(g, 0x22, gbytes));
+  HIP_OK(hipMalloc(&out, 256 * 512 * 4)); HIP_OK(hipMalloc(&cyc, 64)); HIP_OK(hipMalloc(&fill, 65536));
+  std::vector<uint32_t> gauss = gaussian_e2m1_image(65536, 7);
+  SmiSampler smi;
+  std::vector<std::pair<double, std::string>> marks;
+  smi.start();
+  std::this_thread::sleep_for(std::chrono::milliseconds(500));
+  marks.push_back({0.0, "idle"});
+  const double sec = 0.8;
+  const double F = 8.0 * 2 * 32 * 32 * 64;   // flop per wave per "iteration" (8 MFMAs of 32x32x64)
+  for (int cls = 0; cls < 3; ++cls) {
+    const char* cn = cls == 0 ? "const" : cls == 1 ? "uniform" : "gaussian";
+    g_random_fill = cls == 1;
+    g_fill = nullptr;
+    if (cls == 2) { HIP_OK(hipMemcpy(fill, gauss.data(), 65536, hipMemcpyHostToDevice)); g_fill = fill; }
+    g_fill_name = cls == 2 ? "[gaussian codes]  " : nullptr;
+    power_run<0, 256>(smi, marks, cn, "MFMA x8, A held for 2, B alternates (GEMM order)", g, gbytes, out, cyc, sec, F);
+    power_run<24, 256>(smi, marks, cn, "MFMA, SAME A and B every time", g, gbytes, out, cyc, sec, F);
+    power_run<25, 256>(smi, marks, cn, "MFMA, A and B both change every time", g, gbytes, out, cyc, sec, F);
+    power_run<20, 256>(smi, marks, cn, "MFMA x8 into ONE accumulator", g, gbytes, out, cyc, sec, F);
+    power_run<26, 256>(smi, marks, cn, "32 x v_mfma_scale 16x16x128 (same FLOPs)", g, gbytes, out, cyc, sec, F);
+    power_run<2, 256>(smi, marks, cn, "MFMA + fragment reads", g, gbytes, out, cyc, sec, F);
+    power_run<4, 256>(smi, marks, cn, "MFMA + fragment reads + LDS-DMA", g, gbytes, out, cyc, sec, F);
+  }
+  g_fill = nullptr; g_fill_name = nullptr; g_random_fill = 0;
+  std::this_thread::sleep_for(std::chrono::milliseconds(300));
+  smi.finish();
+  if (csv_path) smi.dump(csv_path, marks);
+  hipFree(g); hipFree(out); hipFree(cyc); hipFree(fill);
 }

@@ -1,0 +1,160 @@
+"""BASELINE.json configs[2..4] at FULL size through the product path, against the pinned CPU oracle (oracle/) on sampled rows.
+
+  C3  fusedQuantizeMx (Hadamard-32, abs_max) + to_blocked + matmul_mxf4_bf16_tn, Llama-3-8B FFN shape M=4096 N=14336 K=4096
+      (reference: tests/mxfp4_test.py:224-237 at the benchmark's size, benchmarks/bench_mxfp4_sm120.py:40-83)
+  C4  matmul_nvf4_bf16_tn 8192 x 8192 x 8192                       (reference: tests/nvfp4_test.py:214-224: out.equal(ref))
+  C5  matmul_mxf8_bf16_tn and _nn 4096^3                             (reference: tests/mxfp8_test.py:60-96)
+
+The oracle is a scalar C restatement, so a full 4096 x 14336 x 4096 product is out of reach in a test; every test takes
+>= 64 rows of A (first / last / tile-boundary rows plus a random draw), runs the oracle's dequantise-matmul on exactly
+those rows against ALL of B, and requires the GPU's rows to match: bit for bit for the FP4 formats (every partial sum is
+exact in fp32), within 1 bf16 ulp + 2e-5 max|ref| for MXFP8 (8-bit significands: fp32 accumulation order shows).
+Nothing here reads /root/reference.
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import oracle  # noqa: E402  (the checker)
+
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def q():
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    import qutlass_amd
+
+    return qutlass_amd
+
+
+def _np(t: torch.Tensor) -> np.ndarray:
+    t = t.detach().cpu().contiguous()
+    if t.dtype == torch.bfloat16:
+        return t.view(torch.uint16).numpy()
+    if t.element_size() == 1:
+        return t.view(torch.uint8).numpy()
+    return t.numpy()
+
+
+def _hadamard(n):
+    h = torch.ones(1, 1)
+    while h.shape[0] < n:
+        h = torch.cat([torch.cat([h, h], 1), torch.cat([h, -h], 1)], 0)
+    return (h * n ** -0.5).to(torch.bfloat16).to(DEV)
+
+
+def _sample_rows(m: int, count: int, seed: int):
+    """first / last rows, both sides of every 256-row tile boundary near the start, middle and end, plus a random draw"""
+    fixed = {0, 1, 255, 256, 257, m // 2 - 1, m // 2, m - 257, m - 256, m - 1}
+    rng = np.random.default_rng(seed)
+    rows = set(r for r in fixed if 0 <= r < m)
+    while len(rows) < count:
+        rows.add(int(rng.integers(0, m)))
+    return sorted(rows)
+
+
+def _mxfp8_close(got_bits, want_bits):
+    got = oracle.bf16_bits_to_f32(got_bits).astype(np.float64)
+    want = oracle.bf16_bits_to_f32(want_bits).astype(np.float64)
+    return np.abs(got - want) <= np.abs(want) / 128.0 + 2e-5 * np.abs(want).max()
+
+
+def test_c3_quantize_swizzle_gemm_llama3_ffn_vs_oracle(q):
+    """configs[2]: both operands quantised on the GPU (Hadamard-32, abs_max), scales swizzled on the GPU, GEMM 4096 x 14336 x
+    4096 (auto dispatch: persistent deep kernel over the first 12288 columns + a 256x128-tile launch over the last 2048, so
+    every compared row crosses the launch boundary).  Checks, all against the oracle on the same bytes:
+      * quantiser: e8m0 bytes exact and e2m1 codes exact (mod sign of zero, <= 1e-6 mismatching) on the sampled rows of A and
+        on 256 sampled rows of B;  * to_blocked of the full scale matrices exact;  * 96 output rows bit-exact."""
+    from qutlass_amd.utils import to_blocked
+
+    m, n, k = 4096, 14336, 4096
+    torch.manual_seed(1234)
+    h = _hadamard(32)
+    a = torch.randn(m, k, dtype=torch.bfloat16, device=DEV) * 25.0
+    b = torch.randn(n, k, dtype=torch.bfloat16, device=DEV) * 25.0
+    a_q, a_s = q.fusedQuantizeMx(a, h, method="abs_max")
+    b_q, b_s = q.fusedQuantizeMx(b, h, method="abs_max")
+    asf, bsf = to_blocked(a_s), to_blocked(b_s)
+    out = q.matmul_mxf4_bf16_tn(a_q, b_q, asf, bsf, torch.tensor([1.0], device=DEV))
+    assert out.shape == (m, n) and out.dtype == torch.bfloat16
+
+    rows = _sample_rows(m, 96, 3)
+    ridx = torch.tensor(rows, device=DEV)
+    hb = _np(h)
+    a_s_rm = _np(a_s).reshape(-1)[: m * k // 32].reshape(m, k // 32)
+    b_s_rm = _np(b_s).reshape(-1)[: n * k // 32].reshape(n, k // 32)
+    # quantiser on sampled rows (each row is k/32 independent groups, so a row subset is a valid quantiser input)
+    for x, xq, xs, rr in ((a, a_q, a_s_rm, rows), (b, b_q, b_s_rm, _sample_rows(n, 256, 4))):
+        ri = torch.tensor(rr, device=DEV)
+        rq, rs, _ = oracle.fused_quantize_mx(_np(x[ri]), hb, oracle.ABS_MAX)
+        assert np.array_equal(xs[rr].reshape(-1), rs.reshape(-1)), "e8m0 scales differ from the oracle"
+        eq = oracle.codes_equal_mod_zero_sign(_np(xq[ri]).reshape(-1), rq)
+        assert (~eq).mean() <= 1e-6, float((~eq).mean())
+    assert np.array_equal(_np(asf).reshape(-1), oracle.to_blocked(a_s_rm).reshape(-1))
+    assert np.array_equal(_np(bsf).reshape(-1), oracle.to_blocked(b_s_rm).reshape(-1))
+    ref = oracle.gemm_blockscaled(oracle.KIND_MXFP4, _np(a_q[ridx]), _np(b_q), oracle.to_blocked(np.ascontiguousarray(a_s_rm[rows])),
+                                  oracle.to_blocked(b_s_rm), 1.0, len(rows), n, k)
+    got = _np(out[ridx])
+    assert np.array_equal(got, ref), f"{int((got != ref).sum())} of {got.size} sampled outputs differ (first bad column {int(np.argwhere(got != ref)[0][1])})"
+
+
+def test_c4_nvfp4_8192_cubed_vs_oracle(q):
+    """configs[3]: NVFP4 (e2m1 codes, e4m3 scale per 16) 8192^3 through fusedQuantizeNv (rotation 16, abs_max) + to_blocked +
+    matmul_nvf4_bf16_tn; the 256x256-tile auto configuration at 4 rounds of tiles.  64 sampled rows, exact equality (the
+    reference asserts out.equal(out_ref), nvfp4_test.py:224)."""
+    from qutlass_amd.utils import to_blocked
+
+    m = n = k = 8192
+    torch.manual_seed(77)
+    h = _hadamard(16)
+    gs = torch.tensor([1.0], device=DEV)
+    a = torch.randn(m, k, dtype=torch.bfloat16, device=DEV) * 3.0
+    b = torch.randn(n, k, dtype=torch.bfloat16, device=DEV) * 3.0
+    a_q, a_s = q.fusedQuantizeNv(a, h, gs, method="abs_max")
+    b_q, b_s = q.fusedQuantizeNv(b, h, gs, method="abs_max")
+    del a, b
+    out = q.matmul_nvf4_bf16_tn(a_q, b_q, to_blocked(a_s), to_blocked(b_s), torch.tensor([1.0], device=DEV))
+    rows = _sample_rows(m, 64, 5)
+    ridx = torch.tensor(rows, device=DEV)
+    a_s_rm = _np(a_s).reshape(-1)[: m * k // 16].reshape(m, k // 16)
+    b_s_rm = _np(b_s).reshape(-1)[: n * k // 16].reshape(n, k // 16)
+    ref = oracle.gemm_blockscaled(oracle.KIND_NVFP4, _np(a_q[ridx]), _np(b_q), oracle.to_blocked(np.ascontiguousarray(a_s_rm[rows])),
+                                  oracle.to_blocked(b_s_rm), 1.0, len(rows), n, k)
+    got = _np(out[ridx])
+    assert np.array_equal(got, ref), f"{int((got != ref).sum())} of {got.size} sampled outputs differ"
+
+
+@pytest.mark.parametrize("layout", ["tn", "nn"])
+def test_c5_mxfp8_4096_cubed_vs_oracle(q, layout):
+    """configs[4] (the e4m3 x e4m3 leg the reference implements): 4096^3 TN and NN against oracle.gemm_blockscaled on 64
+    sampled rows -- the oracle, not a TN/NN self-comparison.  Operands from the oracle's _pseudoquant_mxfp8 restatement
+    (mxfp8_test.py:26-46)."""
+    from qutlass_amd.utils import to_blocked
+
+    m = n = k = 4096
+    torch.manual_seed(5)
+    a = torch.randn(m, k, dtype=torch.bfloat16) * 25.0
+    b = torch.randn(n, k, dtype=torch.bfloat16) * 25.0
+    aq, asf = oracle.pseudoquant_mxfp8(_np(a))
+    bq, bsf = oracle.pseudoquant_mxfp8(_np(b))
+    e4, e8 = torch.float8_e4m3fn, torch.float8_e8m0fnu
+    a_t, b_t = torch.from_numpy(aq).to(DEV).view(e4), torch.from_numpy(bq).to(DEV).view(e4)
+    sa, sb = to_blocked(torch.from_numpy(asf).to(DEV).view(e8)), to_blocked(torch.from_numpy(bsf).to(DEV).view(e8))
+    alpha = torch.tensor([1.0], device=DEV)
+    rows = _sample_rows(m, 64, 6)
+    if layout == "tn":
+        out = q.matmul_mxf8_bf16_tn(a_t, b_t, sa, sb, alpha)
+        ref = oracle.gemm_blockscaled(oracle.KIND_MXFP8_TN, np.ascontiguousarray(aq[rows]), bq, oracle.to_blocked(np.ascontiguousarray(asf[rows])),
+                                      oracle.to_blocked(bsf), 1.0, len(rows), n, k)
+    else:
+        a_km = a_t.view(torch.uint8).T.contiguous().view(e4)       # (K, M), the reference's ColumnMajor A (mxfp8_test.py:77-96)
+        out = q.matmul_mxf8_bf16_nn(a_km, b_t, sa, sb, alpha)
+        a_km_rows = np.ascontiguousarray(aq.T[:, rows])              # (K, rows): the oracle's NN path on the sampled columns of A^T
+        ref = oracle.gemm_blockscaled(oracle.KIND_MXFP8_NN, a_km_rows, bq, oracle.to_blocked(np.ascontiguousarray(asf[rows])),
+                                      oracle.to_blocked(bsf), 1.0, len(rows), n, k)
+    got = _np(out[torch.tensor(rows, device=DEV)])
+    ok = _mxfp8_close(got, ref)
+    assert ok.all(), f"{int((~ok).sum())} of {ok.size} sampled outputs out of tolerance"

@@ -6,6 +6,7 @@ import pytest
 import torch
 
 import oracle
+import _benchlib as lab  # the LAB build of the library (forced operand paths), tests/_benchlib.py
 
 pytestmark = pytest.mark.gpu
 DEV = torch.device("cuda", 0)
@@ -132,11 +133,9 @@ def test_fuzz_matmul_nvf4_and_mxf8(q):
         assert (np.abs(got - want) <= np.abs(want) / 128.0 + 1e-4 * np.abs(want).max()).all(), (it, m, n, k)
         x_km = x.view(torch.uint8).T.contiguous().view(torch.float8_e4m3fn)
         for path in (0, 61, 62):
-            q._lib.set_option("gemm_variant", path)
-            try:
-                out_nn = q.matmul_mxf8_bf16_nn(x_km, y, to_blocked(sa.view(e8)), to_blocked(sb.view(e8)), alpha)
-            finally:
-                q._lib.set_option("gemm_variant", 0)
+            impl = q if path == 0 else lab
+            with lab.forced(gemm_variant=path):
+                out_nn = impl.matmul_mxf8_bf16_nn(x_km, y, to_blocked(sa.view(e8)), to_blocked(sb.view(e8)), alpha)
             if path == 61:   # different tile configuration than the auto TN kernel: compare with the oracle tolerance
                 gnn = oracle.bf16_bits_to_f32(_np(out_nn)).astype(np.float64)
                 assert (np.abs(gnn - want) <= np.abs(want) / 128.0 + 1e-4 * np.abs(want).max()).all(), ("nn fused", it, m, n, k)

@@ -20,6 +20,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 import oracle  # noqa: E402  (the checker)
+import _benchlib as lab  # noqa: E402  (the LAB build of the library: forced tiles / schedules, see tests/_benchlib.py)
 
 
 @pytest.fixture(scope="module")
@@ -174,16 +175,14 @@ def _gemm_golden(q, g, c, fn, sf_dtype, kind):
     return _np(out), g[f"out{c}"]
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 5, 6, 7, 20, 24, 27, 28, 29, 30, 40, 60, 70, 71, 72, 73, 74, 75, 77])
+@pytest.mark.parametrize("variant", [0, 1, 2, 5, 6, 7, 20, 24, 27, 28, 29, 30, 40, 60, 70, 71, 72, 73, 74, 75, 77, 90])
 def test_matmul_mxf4_golden_bit_exact(q, golden_dir, variant):
     g = _load(golden_dir, "gemm_mxfp4.npz")
-    q._lib.set_option("gemm_variant", variant)
-    try:
+    impl = q if variant == 0 else lab   # 0: the product library's own dispatch; otherwise the lab build with that variant forced
+    with lab.forced(gemm_variant=variant):
         for c in range(int(g["ncases"])):
-            got, want = _gemm_golden(q, g, c, q.matmul_mxf4_bf16_tn, torch.float8_e8m0fnu, oracle.KIND_MXFP4)
+            got, want = _gemm_golden(q, g, c, impl.matmul_mxf4_bf16_tn, torch.float8_e8m0fnu, oracle.KIND_MXFP4)
             assert np.array_equal(got, want), (variant, c, int((got != want).sum()))
-    finally:
-        q._lib.set_option("gemm_variant", 0)
 
 
 def _pipeline(q, m, n, k, method, rot=32, seed=0):
@@ -233,12 +232,9 @@ def test_matmul_mxf4_full_size_properties(q):
     perm = torch.randperm(m, device=DEV)
     outp = q.matmul_mxf4_bf16_tn(a_q[perm].contiguous(), b_q, to_blocked(a_s[perm].contiguous()), bsf, torch.tensor([1.0], device=DEV))
     assert torch.equal(outp, out[perm])
-    for variant in (1, 5, 6, 3, 4, 8, 9, 20, 27, 28, 29, 30, 40, 70, 73):
-        q._lib.set_option("gemm_variant", variant)
-        try:
-            assert torch.equal(q.matmul_mxf4_bf16_tn(a_q, b_q, asf, bsf, torch.tensor([1.0], device=DEV)), out), variant
-        finally:
-            q._lib.set_option("gemm_variant", 0)
+    for variant in (1, 5, 6, 3, 4, 8, 9, 20, 27, 28, 29, 30, 40, 70, 73, 90):
+        with lab.forced(gemm_variant=variant):
+            assert torch.equal(lab.matmul_mxf4_bf16_tn(a_q, b_q, asf, bsf, torch.tensor([1.0], device=DEV)), out), variant
 
 
 @pytest.mark.parametrize("m,n,k", [(64, 4096, 14336), (16, 512, 8192), (200, 264, 7168), (128, 4096, 6144), (40, 1032, 14464)])
@@ -253,16 +249,10 @@ def test_split_k_small_output_long_k(q, m, n, k):
     expect_split = q._lib.load().qutlass_amd_gemm_splitk_workspace_bytes(4, m, n, k)
     assert (expect_split > 0) == (k >= 32 * 256 and -(-m // 64) * -(-n // 64) <= 128)
     asf, bsf, al = to_blocked(a_s), to_blocked(b_s), torch.tensor([1.0], device=DEV)
-    old = q._lib.set_option("pp_flags", 1 | 128)
-    try:
-        single = q.matmul_mxf4_bf16_tn(a_q, b_q, asf, bsf, al)
-    finally:
-        q._lib.set_option("pp_flags", old)
-    q._lib.set_option("gemm_variant", 29)
-    try:
-        simple = q.matmul_mxf4_bf16_tn(a_q, b_q, asf, bsf, al)
-    finally:
-        q._lib.set_option("gemm_variant", 0)
+    with lab.forced(pp_flags=1 | 128):
+        single = lab.matmul_mxf4_bf16_tn(a_q, b_q, asf, bsf, al)
+    with lab.forced(gemm_variant=29):
+        simple = lab.matmul_mxf4_bf16_tn(a_q, b_q, asf, bsf, al)
     assert torch.equal(out, single) and torch.equal(out, simple)
     rows = sorted({0, m // 3, m - 1})
     sfa = oracle.to_blocked(np.ascontiguousarray(np.concatenate([_np(a_s)[rows], np.zeros((128 - len(rows), k // 32), np.uint8)])))
@@ -326,13 +316,11 @@ def test_matmul_mxf4_errors(q):
 @pytest.mark.parametrize("nv_variant", [0, 1, 2, 3, 4, 5, 6, 7])   # 5 / 6 / 7 = 128x128 / 128x64 / 64x64 tiles, 1 / 4 = per-wave dequant (8 / 4 waves), 2 = dequantise once into f16 LDS tiles, 3 = small-batch split-K
 def test_matmul_nvf4_golden_bit_exact(q, golden_dir, nv_variant):
     g = _load(golden_dir, "gemm_nvfp4.npz")
-    q._lib.set_option("nvf4_variant", nv_variant)
-    try:
+    impl = q if nv_variant == 0 else lab
+    with lab.forced(nvf4_variant=nv_variant):
         for c in range(int(g["ncases"])):
-            got, want = _gemm_golden(q, g, c, q.matmul_nvf4_bf16_tn, torch.float8_e4m3fn, oracle.KIND_NVFP4)
+            got, want = _gemm_golden(q, g, c, impl.matmul_nvf4_bf16_tn, torch.float8_e4m3fn, oracle.KIND_NVFP4)
             assert np.array_equal(got, want), (nv_variant, c, int((got != want).sum()))
-    finally:
-        q._lib.set_option("nvf4_variant", 0)
 
 
 @pytest.mark.parametrize("rot", [16, 32, 64, 128])
@@ -376,13 +364,10 @@ def test_matmul_nvf4_occupancy_tile_choice_is_bit_identical(q, m, n, k):
     sa_b = to_blocked(sa.to(DEV).view(torch.float8_e4m3fn))
     sb_b = to_blocked(sb.to(DEV).view(torch.float8_e4m3fn))
     al = torch.tensor([0.25], device=DEV)
-    outs = {}
-    try:
-        for v in (0, 5, 6, 7):
-            q._lib.set_option("nvf4_variant", v)
-            outs[v] = q.matmul_nvf4_bf16_tn(a, b, sa_b, sb_b, al).view(torch.int16).cpu()
-    finally:
-        q._lib.set_option("nvf4_variant", 0)
+    outs = {0: q.matmul_nvf4_bf16_tn(a, b, sa_b, sb_b, al).view(torch.int16).cpu()}
+    for v in (5, 6, 7):
+        with lab.forced(nvf4_variant=v):
+            outs[v] = lab.matmul_nvf4_bf16_tn(a, b, sa_b, sb_b, al).view(torch.int16).cpu()
     for v in (0, 6, 7):
         assert torch.equal(outs[v], outs[5]), v
     rows = sorted({0, m // 2, m - 1})
@@ -415,13 +400,11 @@ def test_matmul_mxf8_large_tiles_vs_oracle(q, variant):
     aq, asf = oracle.pseudoquant_mxfp8(_np(a))
     bq, bsf = oracle.pseudoquant_mxfp8(_np(b))
     e4, e8 = torch.float8_e4m3fn, torch.float8_e8m0fnu
-    q._lib.set_option("gemm_variant", variant)
-    try:
-        out = q.matmul_mxf8_bf16_tn(torch.from_numpy(aq).to(DEV).view(e4), torch.from_numpy(bq).to(DEV).view(e4),
-                                    to_blocked(torch.from_numpy(asf).to(DEV).view(e8)), to_blocked(torch.from_numpy(bsf).to(DEV).view(e8)),
-                                    torch.tensor([1.0], device=DEV))
-    finally:
-        q._lib.set_option("gemm_variant", 0)
+    impl = q if variant == 0 else lab
+    with lab.forced(gemm_variant=variant):
+        out = impl.matmul_mxf8_bf16_tn(torch.from_numpy(aq).to(DEV).view(e4), torch.from_numpy(bq).to(DEV).view(e4),
+                                       to_blocked(torch.from_numpy(asf).to(DEV).view(e8)), to_blocked(torch.from_numpy(bsf).to(DEV).view(e8)),
+                                       torch.tensor([1.0], device=DEV))
     ref = oracle.gemm_blockscaled(oracle.KIND_MXFP8_TN, aq, bq, oracle.to_blocked(asf), oracle.to_blocked(bsf), 1.0, m, n, k)
     assert _mxfp8_close(_np(out), ref).all()
 
@@ -471,11 +454,8 @@ def test_matmul_mxf8_nn_equals_tn_and_oracle(q, golden_dir, m, n, k):
     assert torch.equal(out_nn.view(torch.int16), out_tn.view(torch.int16))
     # both operand paths explicitly: 61 = fused (A^T tiles transposed on the LDS -> register path), 62 = byte-transpose pre-pass
     for path in (61, 62):
-        q._lib.set_option("gemm_variant", path)
-        try:
-            o = q.matmul_mxf8_bf16_nn(a_km, b_t, sa, sb, alpha)
-        finally:
-            q._lib.set_option("gemm_variant", 0)
+        with lab.forced(gemm_variant=path):
+            o = lab.matmul_mxf8_bf16_nn(a_km, b_t, sa, sb, alpha)
         assert torch.equal(o.view(torch.int16), out_tn.view(torch.int16)), path
     if m * n * k <= 1 << 28:
         ref = oracle.gemm_blockscaled(oracle.KIND_MXFP8_NN, _np(a_km), bq, oracle.to_blocked(asf), oracle.to_blocked(bsf), 1.0, m, n, k)
@@ -605,11 +585,8 @@ def test_small_batch_paths_agree_with_tiled_kernel_and_oracle(q, m, n, k):
     rm = lambda s, rows: s.view(torch.uint8).reshape(-1)[: rows * k // 32].reshape(rows, k // 32).contiguous().view(torch.float8_e8m0fnu)
     out_ada = q.matmul_ada_mxf4_bf16_tn(a_q, b_q, rm(a_s, m), rm(b_s, n), alpha)
     out_auto = q.matmul_mxf4_bf16_tn(a_q, b_q, to_blocked(a_s), to_blocked(b_s), alpha)     # M <= 32 -> skinny kernel
-    q._lib.set_option("gemm_variant", 24)
-    try:
-        out_tiled = q.matmul_mxf4_bf16_tn(a_q, b_q, to_blocked(a_s), to_blocked(b_s), alpha)
-    finally:
-        q._lib.set_option("gemm_variant", 0)
+    with lab.forced(gemm_variant=24):
+        out_tiled = lab.matmul_mxf4_bf16_tn(a_q, b_q, to_blocked(a_s), to_blocked(b_s), alpha)
     assert torch.equal(out_ada.view(torch.int16), out_tiled.view(torch.int16))
     assert torch.equal(out_auto.view(torch.int16), out_tiled.view(torch.int16))
     if m * n * k <= 1 << 29:
@@ -669,11 +646,8 @@ def test_tail_split_launch_matches_single_launch(q):
     asf, bsf = to_blocked(a_s), to_blocked(b_s)
     alpha = torch.tensor([0.5], device=DEV)
     out_split = q.matmul_mxf4_bf16_tn(a_q, b_q, asf, bsf, alpha)
-    q._lib.set_option("gemm_variant", 30)
-    try:
-        out_one = q.matmul_mxf4_bf16_tn(a_q, b_q, asf, bsf, alpha)
-    finally:
-        q._lib.set_option("gemm_variant", 0)
+    with lab.forced(gemm_variant=30):   # the per-tile deep schedule over the whole output, one launch
+        out_one = lab.matmul_mxf4_bf16_tn(a_q, b_q, asf, bsf, alpha)
     assert torch.equal(out_split.view(torch.int16), out_one.view(torch.int16))
     rows = [0, 255, 256, 2047, 4095]
     sub = torch.tensor(rows, device=DEV)
