@@ -187,6 +187,11 @@ def main():
     a8t = a8.view(torch.uint8).T.contiguous().view(torch.float8_e4m3fn)
     line("C5 matmul_mxf8_bf16_tn 4096^3", time_us(lambda: q.matmul_mxf8_bf16_tn(a8, b8, s8a, s8b, alpha), args.iters), flops=2.0 * M * N * K, peak=PEAK["fp8"])
     line("C5 matmul_mxf8_bf16_nn 4096^3 (A stored (K, M))", time_us(lambda: q.matmul_mxf8_bf16_nn(a8t, b8, s8a, s8b, alpha), args.iters), flops=2.0 * M * N * K, peak=PEAK["fp8"])
+    # configs[4] as BASELINE.json words it: e5m2 gradient x e4m3 activation (extension; the reference rejects e5m2)
+    g5 = (torch.randn(M, K, device=dev) * 4 * torch.exp2(torch.randint(-8, 9, (M, 1), device=dev).float())).to(torch.float8_e5m2)
+    g5t = g5.view(torch.uint8).T.contiguous().view(torch.float8_e5m2)
+    line("C5 matmul_mxf8_bf16_tn 4096^3, A = e5m2 gradient", time_us(lambda: q.matmul_mxf8_bf16_tn(g5, b8, s8a, s8b, alpha), args.iters), flops=2.0 * M * N * K, peak=PEAK["fp8"])
+    line("C5 matmul_mxf8_bf16_nn 4096^3, A = e5m2 gradient stored (K, M)", time_us(lambda: q.matmul_mxf8_bf16_nn(g5t, b8, s8a, s8b, alpha), args.iters), flops=2.0 * M * N * K, peak=PEAK["fp8"])
     x = torch.randn(M, K, dtype=torch.bfloat16, device=dev) * 25.0
     qb = M * K * 2 + M * K // 2 + M * K // 32
     line("C5 fusedQuantizeMx(H32, quest) 4096x4096", time_us(lambda: q.fusedQuantizeMx(x, h32, method="quest"), args.iters), bytes_=qb)

@@ -97,15 +97,36 @@ int qutlass_amd_matmul_mxf8_bf16_tn_ws(const void* A, const void* B, const void*
  * MXFP8 NN: A is stored (K, M) row-major (the reference's ColumnMajor A), B (N, K); A_sf is still the
  * to_blocked layout of the (M, K/32) scale matrix.  K % 32 == 0, M % 16 == 0 (the reference's
  * AlignmentA = 16 on the contiguous M axis, gemm.cu:400).
- * workspace: caller-owned device scratch of at least qutlass_amd_mxf8_nn_workspace_bytes(M, K) bytes,
- * used on `stream` only for the duration of the call's kernels (A is re-laid (M, K) once by a byte
- * transpose pre-pass, then the TN kernel runs; the library itself never allocates).
+ * workspace: caller-owned device scratch, used on `stream` only for the duration of the call's kernels (the library
+ * itself never allocates).  Small problems re-lay A as (M, K) with a byte-transpose pre-pass and then run the TN kernel:
+ * they need M * K bytes.  Problems whose 256x256 tiles fill the chip read the (K, M) operand directly and need NONE.
+ * qutlass_amd_mxf8_nn_workspace_bytes_for(M, N, K) returns what THIS shape needs (0 for the fused path: workspace may be
+ * NULL); qutlass_amd_mxf8_nn_workspace_bytes(M, K) is the shape-independent upper bound M * K.
  * Replaces matmul_host_mxf8_bf16_nn (gemm.cu:388-434; bindings.cpp:179-216).
  */
 int64_t qutlass_amd_mxf8_nn_workspace_bytes(int64_t M, int64_t K);
+int64_t qutlass_amd_mxf8_nn_workspace_bytes_for(int64_t M, int64_t N, int64_t K);
 int qutlass_amd_matmul_mxf8_bf16_nn(const void* A, const void* B, const void* A_sf, const void* B_sf,
                                     const float* alpha, void* D, int64_t M, int64_t N, int64_t K,
                                     void* workspace, int64_t workspace_bytes, void* stream);
+
+/*
+ * EXTENSION (no reference counterpart): MXFP8 with an e5m2 A operand -- the gradient x activation GEMMs of a QAT
+ * backward pass (BASELINE.json configs[4]).  The reference's entry points reject every element type but e4m3
+ * (bindings.cpp:157-160, 196-199; gemm.cu:339-345, 399-403); CDNA4's scaled MFMA takes the format per operand.
+ * a_format / b_format: QAMD_FP8_E4M3 or QAMD_FP8_E5M2; b_format must be QAMD_FP8_E4M3.  Everything else (layouts, scales,
+ * alignment, workspace rules, return codes) as the entry of the same name without `_fmt`: the TN entry takes the optional
+ * split-K scratch of qutlass_amd_matmul_mxf8_bf16_tn_ws (NULL / 0 = never split), the NN entry the mandatory re-layout
+ * scratch of qutlass_amd_matmul_mxf8_bf16_nn.  With both formats E4M3 they ARE those entries.
+ */
+#define QAMD_FP8_E4M3 0
+#define QAMD_FP8_E5M2 1
+int qutlass_amd_matmul_mxf8_bf16_tn_fmt(const void* A, const void* B, const void* A_sf, const void* B_sf,
+                                        const float* alpha, void* D, int64_t M, int64_t N, int64_t K,
+                                        int a_format, int b_format, void* workspace, int64_t workspace_bytes, void* stream);
+int qutlass_amd_matmul_mxf8_bf16_nn_fmt(const void* A, const void* B, const void* A_sf, const void* B_sf,
+                                        const float* alpha, void* D, int64_t M, int64_t N, int64_t K,
+                                        int a_format, int b_format, void* workspace, int64_t workspace_bytes, void* stream);
 
 /* ---- fused rotate + quantize ------------------------------------------------------------------ */
 

@@ -20,6 +20,7 @@ _LIB_PATH = os.path.join(_HERE, "libqutlass_oracle.so")
 
 QUEST, ABS_MAX = 0, 1
 KIND_MXFP4, KIND_NVFP4, KIND_MXFP8_TN, KIND_MXFP8_NN = 0, 1, 2, 3
+KIND_MXFP8_TN_A5, KIND_MXFP8_NN_A5 = 4, 5   # e5m2 A operand x e4m3 B operand (extension; see qutlass_oracle.c orc_e5m2_decode)
 
 
 def build(force: bool = False) -> str:
@@ -57,6 +58,12 @@ def lib() -> ctypes.CDLL:
         L.orc_gemm_blockscaled.argtypes = [i32, vp, vp, vp, vp, f32, i64, i64, i64, vp]
         L.orc_pseudoquant_mxfp8.restype = None
         L.orc_pseudoquant_mxfp8.argtypes = [vp, i64, vp, vp]
+        L.orc_pseudoquant_mxfp8_e5m2.restype = None
+        L.orc_pseudoquant_mxfp8_e5m2.argtypes = [vp, i64, vp, vp]
+        L.orc_e5m2_decode.restype = f32
+        L.orc_e5m2_decode.argtypes = [ctypes.c_uint8]
+        L.orc_e5m2_encode.restype = ctypes.c_uint8
+        L.orc_e5m2_encode.argtypes = [f32]
         L.orc_dequant_fp4.restype = None
         L.orc_dequant_fp4.argtypes = [vp, vp, i32, i32, i64, f32, vp]
         L.orc_backward_t_bf16.restype = None
@@ -161,12 +168,21 @@ def gemm_blockscaled(kind: int, a, b, sfa_blocked, sfb_blocked, alpha: float, m:
     return d
 
 
-def pseudoquant_mxfp8(x_bf16):
+def pseudoquant_mxfp8(x_bf16, e5m2: bool = False):
+    """tests/mxfp8_test.py:26-46; e5m2=True: the same expression with the e5m2 constants (extension, see the C source)."""
     x = _u16(x_bf16)
     q = np.empty(x.shape, dtype=np.uint8)
     s = np.empty(x.size // 32, dtype=np.uint8)
-    lib().orc_pseudoquant_mxfp8(_p(x.reshape(-1)), x.size, _p(q), _p(s))
+    (lib().orc_pseudoquant_mxfp8_e5m2 if e5m2 else lib().orc_pseudoquant_mxfp8)(_p(x.reshape(-1)), x.size, _p(q), _p(s))
     return q, s.reshape(x.shape[:-1] + (x.shape[-1] // 32,))
+
+
+def e5m2_encode(x: float) -> int:
+    return int(lib().orc_e5m2_encode(float(x)))
+
+
+def e5m2_decode(b: int) -> float:
+    return float(lib().orc_e5m2_decode(int(b) & 0xFF))
 
 
 def dequant_fp4(packed, sf_flat, gs: int = 32, is_e4m3: bool = False, alpha: float = 1.0) -> np.ndarray:

@@ -117,6 +117,44 @@ uint8_t orc_e4m3_encode(float x) {
   return sign | (uint8_t)(((ue + 7) << 3) | m);
 }
 
+/*
+ * OCP e5m2 (IEEE-like: 5 exponent bits, bias 15, 2 mantissa bits, max finite 57344, inf 0x7C, NaN 0x7D..0x7F).
+ * EXTENSION: the reference's MXFP8 GEMMs reject every element type but e4m3 (bindings.cpp:157-160, 196-199;
+ * gemm.cu:339-345, 399-403).  BASELINE.json configs[4] names an e5m2-gradient x e4m3-activation leg, which CDNA4's
+ * scaled MFMA supports natively (cbsz / blgp select the format per operand), so the oracle restates the format here.
+ * The conversion is pinned by tests/golden/gemm_mxfp8_e5m2.npz, generated with torch's own float8_e5m2 cast
+ * (tests/golden/make_golden.py), NOT by anything in the reference.
+ */
+float orc_e5m2_decode(uint8_t b) {
+  int s = b >> 7, e = (b >> 2) & 0x1F, m = b & 3;
+  float v;
+  if (e == 0x1F) v = m ? NAN : INFINITY;
+  else if (e == 0) v = ldexpf((float)m, -16);
+  else v = ldexpf(1.0f + (float)m / 4.0f, e - 15);
+  return s ? -v : v;
+}
+
+/* fp32 -> e5m2, RNE, saturate-to-finite (+-57344), NaN -> 0x7F (the satfinite convention used for e4m3 above). */
+uint8_t orc_e5m2_encode(float x) {
+  if (x != x) return 0x7F;
+  uint8_t sign = signbit(x) ? 0x80 : 0;
+  float a = fabsf(x);
+  if (a >= 57344.0f) return sign | 0x7B;
+  if (a <= ldexpf(1.0f, -17)) return sign;   /* at most half the smallest subnormal (2^-16): tie -> even (0) */
+  int e;
+  (void)frexpf(a, &e);
+  int ue = e - 1;
+  if (ue < -14) ue = -14;
+  float q = ldexpf(1.0f, ue - 2);
+  float v = nearbyintf(a / q) * q;
+  if (v >= 57344.0f) return sign | 0x7B;
+  if (v < ldexpf(1.0f, -14)) return sign | (uint8_t)(int)(v * 65536.0f);
+  (void)frexpf(v, &e);
+  ue = e - 1;
+  int m = (int)(ldexpf(v, -ue) * 4.0f) - 4;
+  return sign | (uint8_t)(((ue + 15) << 2) | m);
+}
+
 /* ------------------------------------------------------------------------------------------ */
 /* a8: to_blocked  (qutlass/utils.py:160-193 torch path; :16-133 Triton path = same map + 0-pad) */
 /* ------------------------------------------------------------------------------------------ */
@@ -311,6 +349,7 @@ void orc_fused_quantize_nv(const uint16_t* x, const uint16_t* h, int R, int64_t 
  * kernel produces whenever its partial sums are exact.
  * kind: 0 = MXFP4 (e2m1, e8m0/32)   1 = NVFP4 (e2m1, e4m3/16)   2 = MXFP8 TN (e4m3, e8m0/32)
  *       3 = MXFP8 NN (A stored (K,M) row-major)
+ *       4 / 5 = kinds 2 / 3 with an e5m2 A operand (extension, see orc_e5m2_decode; B stays e4m3)
  */
 static void dequant_row_fp4(const uint8_t* row, int64_t K, double* out) {
   for (int64_t j = 0; j < K / 2; ++j) {
@@ -331,7 +370,9 @@ void orc_gemm_blockscaled(int kind, const uint8_t* A, const uint8_t* B, const ui
     double* o = Ad + m * K;
     if (kind <= 1) dequant_row_fp4(A + m * (K / 2), K, o);
     else if (kind == 2) for (int64_t k = 0; k < K; ++k) o[k] = orc_e4m3_decode(A[m * K + k]);
-    else for (int64_t k = 0; k < K; ++k) o[k] = orc_e4m3_decode(A[k * M + m]);
+    else if (kind == 3) for (int64_t k = 0; k < K; ++k) o[k] = orc_e4m3_decode(A[k * M + m]);
+    else if (kind == 4) for (int64_t k = 0; k < K; ++k) o[k] = orc_e5m2_decode(A[m * K + k]);
+    else for (int64_t k = 0; k < K; ++k) o[k] = orc_e5m2_decode(A[k * M + m]);
     for (int64_t kb = 0; kb < KB; ++kb) {
       uint8_t sb = blocked_sf(SFA, CB, m, kb);
       double s = (kind == 1) ? (double)orc_e4m3_decode(sb) : e8m0_to_f64(sb);
@@ -394,6 +435,34 @@ void orc_pseudoquant_mxfp8(const uint16_t* x, int64_t numel, uint8_t* out_e4m3, 
       if (q > 448.f) q = 448.f;
       if (q < -448.f) q = -448.f;
       out_e4m3[g * 32 + i] = orc_e4m3_encode(q);
+    }
+  }
+}
+
+/*
+ * The same pseudo-quantiser with an e5m2 payload (extension): the expression of tests/mxfp8_test.py:26-46 with the
+ * format constants swapped -- shared exponent floor(log2 amax) - 15 + 128 (e5m2: emax = 15, e4m3: 8), clamp +-57344.
+ */
+void orc_pseudoquant_mxfp8_e5m2(const uint16_t* x, int64_t numel, uint8_t* out_e5m2, uint8_t* out_e8m0) {
+#pragma omp parallel for schedule(static)
+  for (int64_t g = 0; g < numel / 32; ++g) {
+    float amax = 0.f;
+    for (int i = 0; i < 32; ++i) {
+      float a = fabsf(bf16_to_f32(x[g * 32 + i]));
+      if (a > amax) amax = a;
+    }
+    uint8_t e = 128;
+    if (amax > 0) {
+      float l = bf16_to_f32(f32_to_bf16_rne(log2f(amax)));
+      e = (uint8_t)((uint8_t)(int)floorf(l) - 15 + 128);
+    }
+    out_e8m0[g] = e;
+    float s = (float)e8m0_to_f64(e);
+    for (int i = 0; i < 32; ++i) {
+      float q = bf16_to_f32(f32_to_bf16_rne(bf16_to_f32(x[g * 32 + i]) / s));
+      if (q > 57344.f) q = 57344.f;
+      if (q < -57344.f) q = -57344.f;
+      out_e5m2[g * 32 + i] = orc_e5m2_encode(q);
     }
   }
 }

@@ -24,6 +24,9 @@ SYMBOLS = {
     "qutlass_amd_matmul_mxf8_bf16_tn": (_i32, _GEMM_ARGS),
     "qutlass_amd_matmul_mxf8_bf16_nn": (_i32, _GEMM_ARGS[:-1] + [_vp, _i64, _vp]),
     "qutlass_amd_mxf8_nn_workspace_bytes": (_i64, [_i64, _i64]),
+    "qutlass_amd_mxf8_nn_workspace_bytes_for": (_i64, [_i64, _i64, _i64]),
+    "qutlass_amd_matmul_mxf8_bf16_tn_fmt": (_i32, _GEMM_ARGS[:-1] + [_i32, _i32, _vp, _i64, _vp]),
+    "qutlass_amd_matmul_mxf8_bf16_nn_fmt": (_i32, _GEMM_ARGS[:-1] + [_i32, _i32, _vp, _i64, _vp]),
     "qutlass_amd_gemm_splitk_workspace_bytes": (_i64, [_i32, _i64, _i64, _i64]),
     "qutlass_amd_matmul_mxf4_bf16_tn_ws": (_i32, _GEMM_ARGS[:-1] + [_vp, _i64, _vp]),
     "qutlass_amd_matmul_mxf8_bf16_tn_ws": (_i32, _GEMM_ARGS[:-1] + [_vp, _i64, _vp]),

@@ -5,8 +5,9 @@
   libqutlass_amd_bench.so  the same source with -DQAMD_BENCH=1: the LAB build with every schedule variant / ablation /
                            trace instantiation and the "gemm_variant"-style options.  Test and bench infrastructure
                            only (tests/native, tests/_benchlib.py, tools/); nothing under qutlass_amd/ loads it.
-  _C.so               g++: the PyTorch extension (csrc/torch_ext.cpp, LibTorch stable ABI, no device code) that
-                      registers torch.ops._qutlass_C.* over that C ABI
+  qutlass/_CUDA.abi3.so    g++: the PyTorch extension (csrc/torch_ext.cpp, LibTorch stable ABI, no device code) that registers
+                           torch.ops._qutlass_C.* over that C ABI -- same module name and entry point (PyInit__CUDA) as the
+                           reference's op library (qutlass/csrc/bindings.cpp:537-540)
 """
 from __future__ import annotations
 
@@ -19,7 +20,7 @@ SRC = os.path.join(_HERE, "csrc", "capi.hip")
 OUT = os.path.join(_HERE, "libqutlass_amd.so")
 BENCH_OUT = os.path.join(_HERE, "libqutlass_amd_bench.so")
 EXT_SRC = os.path.join(_HERE, "csrc", "torch_ext.cpp")
-EXT_OUT = os.path.join(_HERE, "_C.so")
+EXT_OUT = os.path.join(os.path.dirname(_HERE), "qutlass", "_CUDA.abi3.so")
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "qutlass_amd.h")
 
 
@@ -88,16 +89,23 @@ def build_bench_lib(force: bool = False, verbose: bool = False) -> str:
 
 def build_extension(force: bool = False, verbose: bool = False) -> str:
     if force or _stale(EXT_OUT, [EXT_SRC, HEADER, OUT]):
+        import sysconfig
+
         import torch
 
         tdir = os.path.dirname(torch.__file__)
         inc, lib = os.path.join(tdir, "include"), os.path.join(tdir, "lib")
-        cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-DUSE_ROCM", "-DTORCH_TARGET_VERSION=0x020a000000000000",
-               EXT_SRC, "-I" + inc, "-o", EXT_OUT, "-L" + lib, "-ltorch", "-ltorch_cpu", "-lc10", "-ltorch_hip",
-               "-L" + _HERE, "-lqutlass_amd", "-Wl,-rpath,$ORIGIN", "-Wl,-rpath," + lib]
+        # Py_LIMITED_API: the module only needs PyModule_Create (abi3); the ops themselves use the LibTorch stable ABI
+        cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden", "-DUSE_ROCM", "-DTORCH_TARGET_VERSION=0x020a000000000000",
+               "-DPy_LIMITED_API=0x03090000", EXT_SRC, "-I" + inc, "-I" + sysconfig.get_paths()["include"], "-o", EXT_OUT,
+               "-L" + lib, "-ltorch", "-ltorch_cpu", "-lc10", "-ltorch_hip",
+               "-L" + _HERE, "-lqutlass_amd", "-Wl,-rpath,$ORIGIN/../qutlass_amd", "-Wl,-rpath," + lib]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)
+        stale = os.path.join(_HERE, "_C.so")   # the round-1 name of the extension
+        if os.path.exists(stale):
+            os.remove(stale)
     return EXT_OUT
 
 

@@ -117,13 +117,13 @@ int launch_gemm(GemmParams p, hipStream_t s) {
 }
 
 // persistent deep schedule (gemm_mx_deepp.hip.h): one workgroup per CU walks the tiles; 160 KiB of static LDS
-template <class C, bool TRACE = false>
+template <class C, bool TRACE = false, int ST_AUX = 0>
 int launch_gemm_deepp(GemmParams p, hipStream_t s) {
   p.tiles_m = (int)cdiv(p.M, C::BM);
   p.tiles_n = (int)cdiv(p.N, C::BN);
   p.ws = nullptr; p.splits = 1;
   const int grid = std::min(p.tiles_m * p.tiles_n, 256);   // MI355X: 256 CUs, one 512-register workgroup each
-  hipLaunchKernelGGL((gemm_mx_deepp_kernel<C, TRACE>), dim3(grid), dim3(C::THREADS), 0, s, p);
+  hipLaunchKernelGGL((gemm_mx_deepp_kernel<C, TRACE, ST_AUX>), dim3(grid), dim3(C::THREADS), 0, s, p);
   return check_launch("gemm_mx_deepp_kernel");
 }
 
@@ -211,9 +211,16 @@ int dispatch_variant(int v, const GemmParams& p, hipStream_t s, const char* name
     if (v == 30) return launch_gemm<GemmCfg<256, 256, 2, 2, 8, true>, 4>(p, s);   // fp8 deep schedule
   }
   if constexpr (EBITS == 4) {
-    if (v == 90) return launch_gemm_deepp<GemmCfg<256, 256, 2, 2, 4, false>>(p, s);   // persistent deep schedule
+    // persistent deep schedule; output stores write through (sc0 sc1): nothing dirty is left for the end-of-kernel L2
+    // write-back (4096^3: 34.6 -> 33.4 .. 34.4 us, never slower; profiles/native_r2_store_policy.log)
+    if (v == 90) return launch_gemm_deepp<GemmCfg<256, 256, 2, 2, 4, false>, false, 17>(p, s);
 #if QAMD_BENCH
-    if (v == 91) return launch_gemm_deepp<GemmCfg<256, 256, 2, 2, 4, false>, true>(p, s);   //   + phase timestamps of workgroup 0 (qutlass_amd_debug_set_trace_buffer)
+    if (v == 91) return launch_gemm_deepp<GemmCfg<256, 256, 2, 2, 4, false>, true, 17>(p, s);   //   + phase timestamps of workgroup 0 (qutlass_amd_debug_set_trace_buffer)
+    if (v == 92) return launch_gemm_deepp<GemmCfg<256, 256, 2, 2, 4, false>, false, 2>(p, s);       //   output stores nt
+    if (v == 93) return launch_gemm_deepp<GemmCfg<256, 256, 2, 2, 4, false>, false, 16>(p, s);      //   sc1
+    if (v == 94) return launch_gemm_deepp<GemmCfg<256, 256, 2, 2, 4, false>, false, 0>(p, s);       //   default (write-back) policy
+    if (v == 95) return launch_gemm_deepp<GemmCfg<256, 256, 2, 2, 4, false>, false, 19>(p, s);      //   sc0 sc1 nt
+    if (v == 96) return launch_gemm_deepp<GemmCfg<256, 256, 2, 2, 4, false>, false, 1>(p, s);       //   sc0
     switch (v) {
       case 6: return launch_gemm<GemmCfg<256, 256, 2, 4, 4, false>, 2>(p, s);
       case 7: return launch_gemm<GemmCfg<128, 128, 2, 2, 4, false>, 2>(p, s);
@@ -251,6 +258,32 @@ int dispatch_variant(int v, const GemmParams& p, hipStream_t s, const char* name
 #endif
   return fail(QAMD_ERR_INVALID, "%s: unknown gemm_variant %d", name, v);
 }
+
+// MXFP8 with an e5m2 A operand (extension, include/qutlass_amd.h qutlass_amd_matmul_mxf8_bf16_{tn,nn}_fmt): the variants the
+// auto rules can pick, nothing else.
+int dispatch_variant_a5(int v, const GemmParams& p, hipStream_t s, const char* name)
+#if QAMD_DEF(3)
+{
+  if (dry_record(v, p.N, (v >= 70 && v <= 78) ? p.splits : 1)) return 0;
+  switch (v) {
+    case 24: return launch_gemm<GemmCfg<128, 128, 2, 2, 8, true, 0, 2, 1>, 3>(p, s);
+    case 25: return launch_gemm<GemmCfg<256, 128, 4, 2, 8, true, 0, 2, 1>, 3>(p, s);
+    case 27: return launch_gemm<GemmCfg<128, 64, 2, 2, 8, true, 0, 2, 1>, 3>(p, s);
+    case 28: return launch_gemm<GemmCfg<64, 128, 2, 2, 8, true, 0, 2, 1>, 3>(p, s);
+    case 29: return launch_gemm<GemmCfg<64, 64, 2, 2, 8, true, 0, 2, 1>, 3>(p, s);
+    case 30: return launch_gemm<GemmCfg<256, 256, 2, 2, 8, true, 0, 2, 1>, 4>(p, s);
+    case 70: return launch_gemm<GemmCfg<64, 64, 2, 2, 8, true, 0, 3, 1>, 7>(p, s);
+    case 71: return launch_gemm<GemmCfg<128, 64, 2, 2, 8, true, 0, 3, 1>, 7>(p, s);
+    case 72: return launch_gemm<GemmCfg<64, 128, 2, 2, 8, true, 0, 3, 1>, 7>(p, s);
+    case 73: return launch_gemm<GemmCfg<128, 128, 2, 2, 8, true, 0, 3, 1>, 7>(p, s);
+  }
+  return fail(QAMD_ERR_INVALID, "%s: gemm_variant %d has no e5m2-operand instantiation", name, v);
+}
+int launch_nn_fused_a5(const GemmParams& p, hipStream_t s) { return launch_gemm<GemmCfg<256, 256, 2, 2, 8, true, 0, 2, 1>, 6>(p, s); }
+#else
+;
+int launch_nn_fused_a5(const GemmParams& p, hipStream_t s);
+#endif
 
 #if QAMD_TU != 0
 #if QAMD_TU == 2
@@ -302,9 +335,15 @@ SmallPlan plan_small(int64_t M, int64_t N, int64_t K) {
   return {0, 1};
 }
 
+// a_fmt (MXFP8 only): QAMD_FP8_E4M3 / QAMD_FP8_E5M2 element format of A
 template <int EBITS>
 int gemm_mx(const char* name, const void* A, const void* B, const void* A_sf, const void* B_sf,
-            const float* alpha, void* D, int64_t M, int64_t N, int64_t K, void* stream, void* ws = nullptr, int64_t ws_bytes = 0) {
+            const float* alpha, void* D, int64_t M, int64_t N, int64_t K, void* stream, void* ws = nullptr, int64_t ws_bytes = 0, int a_fmt = 0) {
+  // one place decides which instantiation family a variant number is looked up in
+  auto dispatch = [&](int v, const GemmParams& q, hipStream_t st) -> int {
+    if (EBITS == 8 && a_fmt == 1) return dispatch_variant_a5(v, q, st, name);
+    return dispatch_variant<EBITS, EBITS == 8>(v, q, st, name);
+  };
   if (!A || !B || !A_sf || !B_sf || !alpha || !D) return fail(QAMD_ERR_INVALID, "%s: null pointer argument", name);
   if (M <= 0 || N <= 0) return fail(QAMD_ERR_INVALID, "%s: M and N must be positive (got M=%lld N=%lld)", name, (long long)M, (long long)N);
   const int kalign = (EBITS == 4) ? 128 : 32;
@@ -334,7 +373,7 @@ int gemm_mx(const char* name, const void* A, const void* B, const void* A_sf, co
     const int64_t need = (int64_t)splits * M * N * 4;
     if (splits > 1 && ws && ws_bytes >= need && !(p.pp_flags & 128)) {
       p.ws = (float*)ws; p.splits = splits;
-      if (int rc = dispatch_variant<EBITS, EBITS == 8>(v, p, s, name)) return rc;
+      if (int rc = dispatch(v, p, s)) return rc;
       if (t_dry.on) return 0;
       const int64_t quads = M * (N / 4);
       const int grid = (int)std::min<int64_t>(cdiv(quads, 256), 2048);
@@ -346,7 +385,7 @@ int gemm_mx(const char* name, const void* A, const void* B, const void* A_sf, co
       }
       return check_launch("splitk_reduce_kernel");
     }
-    return dispatch_variant<EBITS, EBITS == 8>(v, p, s, name);
+    return dispatch(v, p, s);
   };
   const bool can_split = pl.variant == 70 && pl.splits > 1 && ws && ws_bytes >= (int64_t)pl.splits * M * N * 4 && !(p.pp_flags & 128);
   if (variant == 77) return ring_launch(70, pl.variant == 70 ? pl.splits : 1);   // bench: 64x64 ring (+ split-K) whatever M
@@ -399,7 +438,7 @@ int gemm_mx(const char* name, const void* A, const void* B, const void* A_sf, co
         const int64_t n1 = main_cols * 256;
         GemmParams pm = p;
         pm.N = (int)n1; pm.b_bytes = (uint32_t)(n1 * rowbytes); pm.sfb_bytes = (uint32_t)(cdiv(n1, 128) * CB * 512);
-        if (int rc = dispatch_variant<EBITS, EBITS == 8>(big, pm, s, name)) return rc;
+        if (int rc = dispatch(big, pm, s)) return rc;
         GemmParams pt = p;
         pt.N = (int)(N - n1);
         pt.B = p.B + n1 * rowbytes; pt.b_bytes = (uint32_t)((N - n1) * rowbytes);
@@ -408,14 +447,14 @@ int gemm_mx(const char* name, const void* A, const void* B, const void* A_sf, co
         const int64_t Nt = N - n1;
         auto tt = [&](int bm, int bn) { return cdiv(M, bm) * cdiv(Nt, bn); };
         const int vt = (tt(256, 128) >= want) ? 25 : (tt(128, 128) >= want) ? 24 : (tt(128, 64) >= want) ? 27 : 29;
-        return dispatch_variant<EBITS, EBITS == 8>(vt, pt, s, name);
+        return dispatch(vt, pt, s);
       }
     }
     else if (tiles(128, 128) >= want) variant = 24;
     else if (tiles(128, 64) >= want || tiles(64, 128) >= want) variant = (N >= M) ? 27 : 28;
     else variant = 29;
   }
-  return dispatch_variant<EBITS, EBITS == 8>(variant, p, s, name);
+  return dispatch(variant, p, s);
 }
 
 #endif   // QAMD_DEF(1)
@@ -545,22 +584,32 @@ int qutlass_amd_matmul_mxf8_bf16_tn(const void* A, const void* B, const void* A_
   return gemm_mx<8>("matmul_mxf8_bf16_tn", A, B, A_sf, B_sf, alpha, D, M, N, K, stream);
 }
 
-int64_t qutlass_amd_mxf8_nn_workspace_bytes(int64_t M, int64_t K) { return (M > 0 && K > 0) ? M * K : 0; }
+// one rule for the launcher and the workspace query: the fused (K, M) operand path needs the 256x256 tiles to fill the chip
+static bool mxf8_nn_is_fused(int64_t M, int64_t N) { return cdiv(M, 256) * cdiv(N, 256) >= 192; }
 
-int qutlass_amd_matmul_mxf8_bf16_nn(const void* A, const void* B, const void* A_sf, const void* B_sf,
-                                    const float* alpha, void* D, int64_t M, int64_t N, int64_t K,
-                                    void* workspace, int64_t workspace_bytes, void* stream) {
+int64_t qutlass_amd_mxf8_nn_workspace_bytes(int64_t M, int64_t K) { return (M > 0 && K > 0) ? M * K : 0; }
+int64_t qutlass_amd_mxf8_nn_workspace_bytes_for(int64_t M, int64_t N, int64_t K) {
+  if (M <= 0 || N <= 0 || K <= 0) return 0;
+  return (opt_gemm_variant() == 0 && mxf8_nn_is_fused(M, N)) ? 0 : M * K;
+}
+
+static int mxf8_nn_impl(const void* A, const void* B, const void* A_sf, const void* B_sf, const float* alpha, void* D, int64_t M, int64_t N,
+                        int64_t K, int a_fmt, void* workspace, int64_t workspace_bytes, void* stream) {
   const char* name = "matmul_mxf8_bf16_nn";
-  if (!A || !workspace) return fail(QAMD_ERR_INVALID, "%s: null pointer argument", name);
+  if (!A) return fail(QAMD_ERR_INVALID, "%s: null pointer argument", name);
   if (M <= 0 || N <= 0) return fail(QAMD_ERR_INVALID, "%s: M and N must be positive (got M=%lld N=%lld)", name, (long long)M, (long long)N);
   if (K < 32 || K % 32) return fail(QAMD_ERR_INVALID, "%s: K must be a positive multiple of 32 (got %lld)", name, (long long)K);
   if (M % 16) return fail(QAMD_ERR_INVALID, "%s: M must be a multiple of 16 for the (K, M) operand (got %lld)", name, (long long)M);
-  if (workspace_bytes < M * K) return fail(QAMD_ERR_INVALID, "%s: workspace too small (%lld < %lld bytes)", name, (long long)workspace_bytes, (long long)(M * K));
   if (M * K >= (1ll << 31)) return fail(QAMD_ERR_INVALID, "%s: operand larger than 2 GiB is not supported", name);
-  // large problems: the fused kernel reads A^T directly (no pre-pass, workspace untouched); "gemm_variant" 61 forces it,
-  // 62 forces the pre-pass
+  // large problems: the fused kernel reads A^T directly (no pre-pass, no workspace); "gemm_variant" 61 forces it, 62 forces
+  // the pre-pass (lab library only)
   const int forced = opt_gemm_variant();
-  if (forced == 61 || (forced == 0 && cdiv(M, 256) * cdiv(N, 256) >= 192)) {
+  const bool fused = forced == 61 || (forced == 0 && mxf8_nn_is_fused(M, N));
+  if (!fused) {
+    if (!workspace) return fail(QAMD_ERR_INVALID, "%s: null pointer argument", name);
+    if (workspace_bytes < M * K) return fail(QAMD_ERR_INVALID, "%s: workspace too small (%lld < %lld bytes)", name, (long long)workspace_bytes, (long long)(M * K));
+  }
+  if (fused) {
     if (!B || !A_sf || !B_sf || !alpha || !D) return fail(QAMD_ERR_INVALID, "%s: null pointer argument", name);
     if (N % 8) return fail(QAMD_ERR_INVALID, "%s: N must be a multiple of 8 (got %lld)", name, (long long)N);
     const int64_t CB = cdiv(K / 32, 4);
@@ -571,13 +620,38 @@ int qutlass_amd_matmul_mxf8_bf16_nn(const void* A, const void* B, const void* A_
     p.a_bytes = (uint32_t)(M * K); p.b_bytes = (uint32_t)(N * K);
     p.sfa_bytes = (uint32_t)(cdiv(M, 128) * CB * 512); p.sfb_bytes = (uint32_t)(cdiv(N, 128) * CB * 512);
     p.pp_shift = opt_pp_shift(); p.pp_flags = opt_pp_flags(); p.dbg = opt_dbg();
+    if (a_fmt == 1) return launch_nn_fused_a5(p, (hipStream_t)stream);
     return launch_gemm<GemmCfg<256, 256, 2, 2, 8, true>, 6>(p, (hipStream_t)stream);
   }
   TransposeParams t;
   t.in = (const uint8_t*)A; t.out = (uint8_t*)workspace; t.K = (int)K; t.M = (int)M;
   hipLaunchKernelGGL(transpose_u8_kernel<>, dim3((unsigned)cdiv(M, 128), (unsigned)cdiv(K, 128)), dim3(256), 0, (hipStream_t)stream, t);
   if (int rc = check_launch("transpose_u8_kernel")) return rc;
-  return gemm_mx<8>(name, workspace, B, A_sf, B_sf, alpha, D, M, N, K, stream);
+  return gemm_mx<8>(name, workspace, B, A_sf, B_sf, alpha, D, M, N, K, stream, nullptr, 0, a_fmt);
+}
+
+int qutlass_amd_matmul_mxf8_bf16_nn(const void* A, const void* B, const void* A_sf, const void* B_sf,
+                                    const float* alpha, void* D, int64_t M, int64_t N, int64_t K,
+                                    void* workspace, int64_t workspace_bytes, void* stream) {
+  return mxf8_nn_impl(A, B, A_sf, B_sf, alpha, D, M, N, K, QAMD_FP8_E4M3, workspace, workspace_bytes, stream);
+}
+
+static int check_fp8_formats(const char* name, int a_format, int b_format) {
+  if (a_format != QAMD_FP8_E4M3 && a_format != QAMD_FP8_E5M2) return fail(QAMD_ERR_INVALID, "%s: invalid a_format %d", name, a_format);
+  if (b_format != QAMD_FP8_E4M3) return fail(QAMD_ERR_INVALID, "%s: b_format must be QAMD_FP8_E4M3 (got %d)", name, b_format);
+  return QAMD_OK;
+}
+
+int qutlass_amd_matmul_mxf8_bf16_tn_fmt(const void* A, const void* B, const void* A_sf, const void* B_sf, const float* alpha, void* D, int64_t M,
+                                        int64_t N, int64_t K, int a_format, int b_format, void* workspace, int64_t workspace_bytes, void* stream) {
+  if (int rc = check_fp8_formats("matmul_mxf8_bf16_tn", a_format, b_format)) return rc;
+  return gemm_mx<8>("matmul_mxf8_bf16_tn", A, B, A_sf, B_sf, alpha, D, M, N, K, stream, workspace, workspace_bytes, a_format);
+}
+
+int qutlass_amd_matmul_mxf8_bf16_nn_fmt(const void* A, const void* B, const void* A_sf, const void* B_sf, const float* alpha, void* D, int64_t M,
+                                        int64_t N, int64_t K, int a_format, int b_format, void* workspace, int64_t workspace_bytes, void* stream) {
+  if (int rc = check_fp8_formats("matmul_mxf8_bf16_nn", a_format, b_format)) return rc;
+  return mxf8_nn_impl(A, B, A_sf, B_sf, alpha, D, M, N, K, a_format, workspace, workspace_bytes, stream);
 }
 
 int qutlass_amd_matmul_nvf4_bf16_tn(const void* A, const void* B, const void* A_sf, const void* B_sf,

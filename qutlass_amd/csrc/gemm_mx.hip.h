@@ -68,8 +68,12 @@ struct GemmParams {
 // ablation bits (bench-only instantiations; 0 in the product path)
 enum { ABL_NO_DMA = 1, ABL_NO_MFMA = 2, ABL_NO_STORE = 4, ABL_NO_EPILOGUE = 8, ABL_TRACE = 16, ABL_NO_READS = 32, ABL_CLOCK = 64 };
 
-template <int BM_, int BN_, int WAVES_M_, int WAVES_N_, int EBITS_, bool F8SPLIT_ = false, int ABL_ = 0, int NSTAGE_ = 2>
+// AFMT_: element format of the A operand of an MXFP8 GEMM, 0 = e4m3 (the reference's only format), 1 = e5m2 (extension:
+// gradient operand of BASELINE.json configs[4]; the scaled MFMA takes the format per operand in cbsz / blgp).  B is e4m3.
+template <int BM_, int BN_, int WAVES_M_, int WAVES_N_, int EBITS_, bool F8SPLIT_ = false, int ABL_ = 0, int NSTAGE_ = 2, int AFMT_ = 0>
 struct GemmCfg {
+  static constexpr int AFMT = AFMT_;
+  static_assert(AFMT_ == 0 || (AFMT_ == 1 && EBITS_ == 8), "A format: 0 = e4m3 / e2m1, 1 = e5m2 (MXFP8 only)");
   static constexpr int NSTAGE = NSTAGE_;           // depth of the LDS stage ring (2 except for the ring schedule)
   static constexpr int BM = BM_, BN = BN_, WAVES_M = WAVES_M_, WAVES_N = WAVES_N_, EBITS = EBITS_;
   static constexpr bool F8SPLIT = F8SPLIT_;
@@ -345,7 +349,8 @@ struct GemmCtx {
   // op_sel byte of slice j:  fp4 -> j ; fp8 contiguous -> j ; fp8 split -> 2j.  `j` is always a literal
   // at the call site; the branch chain folds after inlining (op_sel must be an immediate).
   __device__ __forceinline__ void mfma_slice(const int j) {
-    constexpr int FMT = (C::EBITS == 4) ? 4 : 0;   // cbsz/blgp: 4 = e2m1, 0 = e4m3
+    // cbsz = format of srcA (the B fragments), blgp = format of srcB (the A fragments): 4 = e2m1, 0 = e4m3, 1 = e5m2
+    constexpr int FMT = (C::EBITS == 4) ? 4 : 0, FMTA = (C::EBITS == 4) ? 4 : C::AFMT;
     const int ops = (C::EBITS == 8 && C::F8SPLIT) ? 2 * j : j;
     if (C::ABL & ABL_NO_MFMA) {
 #pragma unroll
@@ -359,10 +364,10 @@ struct GemmCtx {
 #pragma unroll
       for (int n = 0; n < NT; ++n) {
         // srcA = B fragment (rows of the MFMA = n), srcB = A fragment (cols = m)
-        if (ops == 0) acc[m][n] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fb[j][n], fa[j][m], acc[m][n], FMT, FMT, 0, sb[n], 0, sa[m]);
-        if (ops == 1) acc[m][n] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fb[j][n], fa[j][m], acc[m][n], FMT, FMT, 1, sb[n], 1, sa[m]);
-        if (ops == 2) acc[m][n] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fb[j][n], fa[j][m], acc[m][n], FMT, FMT, 2, sb[n], 2, sa[m]);
-        if (ops == 3) acc[m][n] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fb[j][n], fa[j][m], acc[m][n], FMT, FMT, 3, sb[n], 3, sa[m]);
+        if (ops == 0) acc[m][n] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fb[j][n], fa[j][m], acc[m][n], FMT, FMTA, 0, sb[n], 0, sa[m]);
+        if (ops == 1) acc[m][n] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fb[j][n], fa[j][m], acc[m][n], FMT, FMTA, 1, sb[n], 1, sa[m]);
+        if (ops == 2) acc[m][n] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fb[j][n], fa[j][m], acc[m][n], FMT, FMTA, 2, sb[n], 2, sa[m]);
+        if (ops == 3) acc[m][n] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fb[j][n], fa[j][m], acc[m][n], FMT, FMTA, 3, sb[n], 3, sa[m]);
       }
   }
 
@@ -1045,8 +1050,8 @@ __device__ __forceinline__ void gemm_mx_deep8(char* smem, const GemmParams& p) {
     for (int t = 0; t < NT; ++t) sb[set][t] = (int)((unsigned)(*(const int*)(st + cx.rdSB[t])) >> shift);
   };
   auto mfma1 = [&](int j, int sset, int m, int n) __attribute__((always_inline)) {
-    if (j == 0) cx.acc[m][n] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fb[0][n], fa[0][m], cx.acc[m][n], 0, 0, 0, sb[sset][n], 0, sa[sset][m]);
-    if (j == 1) cx.acc[m][n] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fb[1][n], fa[1][m], cx.acc[m][n], 0, 0, 2, sb[sset][n], 2, sa[sset][m]);
+    if (j == 0) cx.acc[m][n] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fb[0][n], fa[0][m], cx.acc[m][n], 0, C::AFMT, 0, sb[sset][n], 0, sa[sset][m]);
+    if (j == 1) cx.acc[m][n] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fb[1][n], fa[1][m], cx.acc[m][n], 0, C::AFMT, 2, sb[sset][n], 2, sa[sset][m]);
   };
   auto fence = [&]() __attribute__((always_inline)) { __builtin_amdgcn_sched_barrier(0); };
   constexpr int NPIECE = C::NA + C::NB;

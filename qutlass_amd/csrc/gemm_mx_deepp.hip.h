@@ -44,7 +44,8 @@ __device__ __forceinline__ void static_for(F&& f) {
 
 // TRACE (lab build only): workgroup 0, wave 0 writes {shader cycles, 100 MHz wall ticks} pairs to p.dbg at: kernel entry,
 // first stage landed, entry of the last stage of every tile, end of that stage, kernel exit (after the last store ack).
-template <class C, bool TRACE = false>
+// ST_AUX: cache-policy bits of the output stores (buffer_store aux: 1 = sc0, 2 = nt, 16 = sc1; lab variants only, product = 0).
+template <class C, bool TRACE = false, int ST_AUX = 0>
 __device__ __forceinline__ void gemm_mx_deepp(char* smem, const GemmParams& p) {
   static_assert(C::EBITS == 4 && C::BM == 256 && C::BN == 256 && C::WAVES_M == 2 && C::WAVES_N == 2 && C::NSTAGE == 2 && C::PPW == 2,
                 "persistent deep schedule: fp4, 256x256 tiles, 4 waves of 128x128");
@@ -68,6 +69,8 @@ __device__ __forceinline__ void gemm_mx_deepp(char* smem, const GemmParams& p) {
     }
   };
   trace();
+  uint32_t wg_t0 = 0;
+  if constexpr (TRACE) wg_t0 = (uint32_t)__builtin_amdgcn_s_memrealtime();
 
   // ---- tile -> (m0, n0): rounds of G tiles, each round XCD-contiguous, grouped raster of 4 tile rows --------------------
   auto decode = [&](int t, int& m0, int& n0) __attribute__((always_inline)) {
@@ -246,7 +249,7 @@ __device__ __forceinline__ void gemm_mx_deepp(char* smem, const GemmParams& p) {
     o[2] = (int)pack_bf16x2(hi[0] * alpha, hi[1] * alpha);
     o[3] = (int)pack_bf16x2(hi[2] * alpha, hi[3] * alpha);
     const int off = stLane + ((32 * m + 16 * ps) * p.ldd + 32 * n) * 2;
-    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, o), rD, (32 * n < colLim) ? off : (int)0x80000000, 0, 0);
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, o), rD, (32 * n < colLim) ? off : (int)0x80000000, 0, ST_AUX);
   };
 
   // ---- the LAST stage of a tile (buffer 1), accumulator-stationary, with the tile's epilogue, the DMA of the next tile's
@@ -345,13 +348,18 @@ __device__ __forceinline__ void gemm_mx_deepp(char* smem, const GemmParams& p) {
   trace();
   if constexpr (TRACE) {
     if (blockIdx.x == 0 && wave == 0 && lane == 0 && p.dbg) p.dbg[0] = (uint32_t)trace_n;
+    // every workgroup: wall-clock entry / exit ticks (100 MHz) -> dispatch ramp and finish skew across the chip
+    if (wave == 0 && lane == 0 && p.dbg && blockIdx.x < 256) {
+      p.dbg[64 + 2 * blockIdx.x] = wg_t0;
+      p.dbg[65 + 2 * blockIdx.x] = (uint32_t)__builtin_amdgcn_s_memrealtime();
+    }
   }
 }
 
-template <class C, bool TRACE = false>
+template <class C, bool TRACE = false, int ST_AUX = 0>
 __global__ __launch_bounds__(C::THREADS) void gemm_mx_deepp_kernel(const GemmParams p) {
   __shared__ __attribute__((aligned(16))) char smem[DeepPCfg<C>::LDS_BYTES];
-  gemm_mx_deepp<C, TRACE>(smem, p);
+  gemm_mx_deepp<C, TRACE, ST_AUX>(smem, p);
 }
 
 }  // namespace qamd

@@ -9,6 +9,13 @@
 // include/common.h:40-45).  Written against the LibTorch stable ABI, like the reference, so one build serves
 // every torch >= 2.10.  One extra op, qutlass_amd::to_blocked, replaces the Triton/torch swizzle of
 // qutlass/utils.py:160-193.
+//
+// Built as qutlass/_CUDA.abi3.so: like the reference's op library it is a Python extension module (PyInit__CUDA,
+// include/registration.h + bindings.cpp:537-540) whose import -- or a plain dlopen through torch.ops.load_library --
+// runs the static registrations; `_qutlass_C` is opened as a FRAGMENT and implemented for the CUDA dispatch key only
+// (bindings.cpp:498, :516), so a CPU tensor gets the dispatcher's own "not implemented for the CPU backend" error.
+#include <Python.h>
+
 #include <torch/csrc/inductor/aoti_torch/c/shim.h>
 #include <torch/csrc/stable/accelerator.h>
 #include <torch/csrc/stable/library.h>
@@ -96,7 +103,10 @@ Tensor matmul(const Tensor& A, const Tensor& B, const Tensor& A_sf, const Tensor
   const ScalarType sf_t = G == Gemm::NVF4 ? ScalarType::Float8_e4m3fn : ScalarType::Float8_e8m0fnu;
   const char* data_n = fp8 ? "float8_e4m3fn" : "uint8";
   const char* sf_n = G == Gemm::NVF4 ? "float8_e4m3fn" : "float8_e8m0fnu";
-  STD_TORCH_CHECK(has_dtype(A, data_t), "A must be ", data_n);
+  // EXTENSION over the reference (which accepts e4m3 only, bindings.cpp:157-160, 196-199): the A operand of the MXFP8 GEMMs
+  // may be float8_e5m2 -- the gradient operand of a QAT backward GEMM (BASELINE.json configs[4]); B stays e4m3.
+  const bool a_e5m2 = fp8 && has_dtype(A, ScalarType::Float8_e5m2);
+  STD_TORCH_CHECK(has_dtype(A, data_t) || a_e5m2, "A must be ", data_n, fp8 ? " (or float8_e5m2)" : "");
   STD_TORCH_CHECK(has_dtype(B, data_t), "B must be ", data_n);
   STD_TORCH_CHECK(has_dtype(A_sf, sf_t), "A_sf must be ", sf_n);
   STD_TORCH_CHECK(has_dtype(B_sf, sf_t), "B_sf must be ", sf_n);
@@ -114,6 +124,17 @@ Tensor matmul(const Tensor& A, const Tensor& B, const Tensor& A_sf, const Tensor
   }
   STD_TORCH_CHECK(B.size(1) >= kmin, "B K-dim must be >= ", kmin);
   const int64_t N = B.size(0), K = B.size(1) * (fp8 ? 1 : 2);
+  // the kernels read alpha as one fp32 and the scale operands through descriptors sized from M / N / K: make sure the
+  // tensors are at least that large (the reference leaves both to CUTLASS' can_implement / the caller)
+  STD_TORCH_CHECK(has_dtype(alpha, ScalarType::Float) && alpha.numel() >= 1, "alpha must be a float32 tensor with at least one element");
+  {
+    const int64_t gs = G == Gemm::NVF4 ? 16 : 32, kb = K / gs;
+    const bool row_major_sf = G == Gemm::ADA_MXF4;   // un-swizzled (rows, K/32); every other op: to_blocked layout of the padded matrix
+    const int64_t need_a = row_major_sf ? M * kb : (M + 127) / 128 * 128 * ((kb + 3) / 4 * 4);
+    const int64_t need_b = row_major_sf ? N * kb : (N + 127) / 128 * 128 * ((kb + 3) / 4 * 4);
+    STD_TORCH_CHECK(A_sf.numel() >= need_a, "A_sf has ", A_sf.numel(), " elements, the ", row_major_sf ? "row-major" : "blocked", " scale layout of A needs ", need_a);
+    STD_TORCH_CHECK(B_sf.numel() >= need_b, "B_sf has ", B_sf.numel(), " elements, the ", row_major_sf ? "row-major" : "blocked", " scale layout of B needs ", need_b);
+  }
 
   Tensor out = torch::stable::new_empty(A, {M, N}, ScalarType::BFloat16);
   if (M == 0 || N == 0) return out;   // empty batch / empty weight: nothing to launch (the C ABI requires positive extents)
@@ -128,15 +149,18 @@ Tensor matmul(const Tensor& A, const Tensor& B, const Tensor& A_sf, const Tensor
     const int64_t ws_bytes = qutlass_amd_gemm_splitk_workspace_bytes(fp8 ? 8 : 4, M, N, K);
     Tensor ws = ws_bytes > 0 ? torch::stable::new_empty(A, {ws_bytes}, ScalarType::Byte) : Tensor();
     void* wp = ws_bytes > 0 ? ws.data_ptr() : nullptr;
-    rc = fp8 ? qutlass_amd_matmul_mxf8_bf16_tn_ws(A.data_ptr(), B.data_ptr(), A_sf.data_ptr(), B_sf.data_ptr(), al, out.data_ptr(), M, N, K, wp, ws_bytes, s)
+    rc = fp8 ? qutlass_amd_matmul_mxf8_bf16_tn_fmt(A.data_ptr(), B.data_ptr(), A_sf.data_ptr(), B_sf.data_ptr(), al, out.data_ptr(), M, N, K,
+                                                   a_e5m2 ? QAMD_FP8_E5M2 : QAMD_FP8_E4M3, QAMD_FP8_E4M3, wp, ws_bytes, s)
              : qutlass_amd_matmul_mxf4_bf16_tn_ws(A.data_ptr(), B.data_ptr(), A_sf.data_ptr(), B_sf.data_ptr(), al, out.data_ptr(), M, N, K, wp, ws_bytes, s);
   }
   else if (G == Gemm::NVF4) rc = qutlass_amd_matmul_nvf4_bf16_tn(A.data_ptr(), B.data_ptr(), A_sf.data_ptr(), B_sf.data_ptr(), al, out.data_ptr(), M, N, K, s);
   else {
-    // scratch for the (K, M) -> (M, K) re-layout: from torch's stream-ordered caching allocator
-    const int64_t ws_bytes = qutlass_amd_mxf8_nn_workspace_bytes(M, K);
-    Tensor ws = torch::stable::new_empty(A, {ws_bytes}, ScalarType::Byte);
-    rc = qutlass_amd_matmul_mxf8_bf16_nn(A.data_ptr(), B.data_ptr(), A_sf.data_ptr(), B_sf.data_ptr(), al, out.data_ptr(), M, N, K, ws.data_ptr(), ws_bytes, s);
+    // scratch for the (K, M) -> (M, K) re-layout of small problems, from torch's stream-ordered caching allocator; shapes
+    // that take the fused operand path need none (0 bytes: nothing is allocated)
+    const int64_t ws_bytes = qutlass_amd_mxf8_nn_workspace_bytes_for(M, N, K);
+    Tensor ws = ws_bytes > 0 ? torch::stable::new_empty(A, {ws_bytes}, ScalarType::Byte) : Tensor();
+    rc = qutlass_amd_matmul_mxf8_bf16_nn_fmt(A.data_ptr(), B.data_ptr(), A_sf.data_ptr(), B_sf.data_ptr(), al, out.data_ptr(), M, N, K,
+                                             a_e5m2 ? QAMD_FP8_E5M2 : QAMD_FP8_E4M3, QAMD_FP8_E4M3, ws_bytes > 0 ? ws.data_ptr() : nullptr, ws_bytes, s);
   }
   check_rc(rc);
   return out;
@@ -297,8 +321,8 @@ Tensor to_blocked(const Tensor& in) {
 
 }  // namespace
 
-// Schema strings: bindings.cpp:499-513 (the ops this build provides).
-STABLE_TORCH_LIBRARY(_qutlass_C, m) {
+// Schema strings: bindings.cpp:499-513.  FRAGMENT, as in the reference (bindings.cpp:498): another library may add to `_qutlass_C`.
+STABLE_TORCH_LIBRARY_FRAGMENT(_qutlass_C, m) {
   m.def("matmul_mxf4_bf16_tn(Tensor A, Tensor B, Tensor A_sf, Tensor B_sf, Tensor alpha) -> Tensor");
   m.def("matmul_nvf4_bf16_tn(Tensor A, Tensor B, Tensor A_sf, Tensor B_sf, Tensor alpha) -> Tensor");
   m.def("matmul_ada_mxf4_bf16_tn(Tensor A, Tensor B, Tensor A_sf, Tensor B_sf, Tensor alpha) -> Tensor");
@@ -315,28 +339,30 @@ STABLE_TORCH_LIBRARY(_qutlass_C, m) {
   m.def("mxfp4_transpose_mxfp8(Tensor x_fp4, Tensor scales, Tensor x_fp8, Tensor shared_exps) -> ()");
 }
 
-STABLE_TORCH_LIBRARY(qutlass_amd, m) { m.def("to_blocked(Tensor input_matrix) -> Tensor"); }
+STABLE_TORCH_LIBRARY_FRAGMENT(qutlass_amd, m) { m.def("to_blocked(Tensor input_matrix) -> Tensor"); }
 
-// The reference registers for CUDA only (bindings.cpp:516-535); the same functions are also registered for CPU so that
-// a CPU tensor reaches the reference's own "Expected tensor to have cuda DeviceType" check instead of a dispatcher
-// error -- there is no CPU compute path.
-#define QAMD_IMPLS(m)                                                            \
-  m.impl("matmul_mxf4_bf16_tn", TORCH_BOX(&matmul_mxf4_bf16_tn));                \
-  m.impl("matmul_nvf4_bf16_tn", TORCH_BOX(&matmul_nvf4_bf16_tn));                \
-  m.impl("matmul_ada_mxf4_bf16_tn", TORCH_BOX(&matmul_ada_mxf4_bf16_tn));        \
-  m.impl("matmul_mxf8_bf16_tn", TORCH_BOX(&matmul_mxf8_bf16_tn));                \
-  m.impl("matmul_mxf8_bf16_nn", TORCH_BOX(&matmul_mxf8_bf16_nn));                \
-  m.impl("fusedQuantizeMxQuest", TORCH_BOX(&fusedQuantizeMxQuest));              \
-  m.impl("fusedQuantizeMxAbsMax", TORCH_BOX(&fusedQuantizeMxAbsMax));            \
-  m.impl("fusedQuantizeMxQuestWithMask", TORCH_BOX(&fusedQuantizeMxQuestWithMask)); \
-  m.impl("fusedQuantizeNvQuest", TORCH_BOX(&fusedQuantizeNvQuest));              \
-  m.impl("fusedQuantizeNvAbsMax", TORCH_BOX(&fusedQuantizeNvAbsMax));            \
-  m.impl("backward_t_bf16", TORCH_BOX(&backward_t_bf16));                        \
-  m.impl("backward_qt_bf16", TORCH_BOX(&backward_qt_bf16));                      \
-  m.impl("backward_bf16_square_double_mxfp8", TORCH_BOX(&backward_bf16_square_double_mxfp8)); \
+// CUDA dispatch key only, as the reference (bindings.cpp:516-535); there is no CPU compute path.
+STABLE_TORCH_LIBRARY_IMPL(_qutlass_C, CUDA, m) {
+  m.impl("matmul_mxf4_bf16_tn", TORCH_BOX(&matmul_mxf4_bf16_tn));
+  m.impl("matmul_nvf4_bf16_tn", TORCH_BOX(&matmul_nvf4_bf16_tn));
+  m.impl("matmul_ada_mxf4_bf16_tn", TORCH_BOX(&matmul_ada_mxf4_bf16_tn));
+  m.impl("matmul_mxf8_bf16_tn", TORCH_BOX(&matmul_mxf8_bf16_tn));
+  m.impl("matmul_mxf8_bf16_nn", TORCH_BOX(&matmul_mxf8_bf16_nn));
+  m.impl("fusedQuantizeMxQuest", TORCH_BOX(&fusedQuantizeMxQuest));
+  m.impl("fusedQuantizeMxAbsMax", TORCH_BOX(&fusedQuantizeMxAbsMax));
+  m.impl("fusedQuantizeMxQuestWithMask", TORCH_BOX(&fusedQuantizeMxQuestWithMask));
+  m.impl("fusedQuantizeNvQuest", TORCH_BOX(&fusedQuantizeNvQuest));
+  m.impl("fusedQuantizeNvAbsMax", TORCH_BOX(&fusedQuantizeNvAbsMax));
+  m.impl("backward_t_bf16", TORCH_BOX(&backward_t_bf16));
+  m.impl("backward_qt_bf16", TORCH_BOX(&backward_qt_bf16));
+  m.impl("backward_bf16_square_double_mxfp8", TORCH_BOX(&backward_bf16_square_double_mxfp8));
   m.impl("mxfp4_transpose_mxfp8", TORCH_BOX(&mxfp4_transpose_mxfp8));
-
-STABLE_TORCH_LIBRARY_IMPL(_qutlass_C, CUDA, m) { QAMD_IMPLS(m) }
-STABLE_TORCH_LIBRARY_IMPL(_qutlass_C, CPU, m) { QAMD_IMPLS(m) }
+}
 STABLE_TORCH_LIBRARY_IMPL(qutlass_amd, CUDA, m) { m.impl("to_blocked", TORCH_BOX(&to_blocked)); }
-STABLE_TORCH_LIBRARY_IMPL(qutlass_amd, CPU, m) { m.impl("to_blocked", TORCH_BOX(&to_blocked)); }
+
+// `import qutlass._CUDA` (reference: include/registration.h REGISTER_EXTENSION(_CUDA), bindings.cpp:537-540): an empty module
+// whose only purpose is that loading it runs the registrations above.
+extern "C" __attribute__((visibility("default"))) PyObject* PyInit__CUDA(void) {
+  static struct PyModuleDef module = {PyModuleDef_HEAD_INIT, "_CUDA", nullptr, 0, nullptr};
+  return PyModule_Create(&module);
+}

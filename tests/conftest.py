@@ -14,7 +14,7 @@ def _ensure_built():
     """The test session needs the in-tree binaries (product .so files, the lab build the forced-variant tests use, and
     the oracle).  They are git-ignored, so on a fresh checkout build them once here (hipcc cross-compiles gfx950 without
     a GPU); an existing build is left alone."""
-    need = [os.path.join(ROOT, "qutlass_amd", "libqutlass_amd.so"), os.path.join(ROOT, "qutlass_amd", "_C.so"),
+    need = [os.path.join(ROOT, "qutlass_amd", "libqutlass_amd.so"), os.path.join(ROOT, "qutlass", "_CUDA.abi3.so"),
             os.path.join(ROOT, "qutlass_amd", "libqutlass_amd_bench.so"), os.path.join(ROOT, "oracle", "libqutlass_oracle.so")]
     if all(os.path.exists(f) for f in need):
         return

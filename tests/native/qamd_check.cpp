@@ -456,6 +456,7 @@ extern void run_ubench();  // ubench.hip
 extern void run_valu_rates();  // ubench.hip
 extern void run_ubench_steady();  // ubench.hip
 extern void run_ubench_power(const char* csv_path);  // ubench.hip
+extern void run_store_patterns();  // ubench.hip
 extern "C" void qutlass_amd_debug_set_trace_buffer(void*);
 
 // Per-wave block timeline of workgroup 0 of the ping-pong kernel (ABL_TRACE builds, variants 116..118).
@@ -518,6 +519,7 @@ int main(int argc, char** argv) {
   if (argc > 1 && want("valu")) run_valu_rates();
   if (argc > 1 && want("usteady")) run_ubench_steady();
   if (want("probe")) run_probe();
+  if (argc > 1 && want("stores")) run_store_patterns();
   if (argc > 1 && want("power")) run_ubench_power("gpurun_out/power_trace_ubench_r2.csv");
   if (argc > 1 && want("gpower")) {   // socket power + sclk trace of the headline GEMM: kernel variants x operand classes, ~1 s each
     SmiSampler smi;
@@ -590,8 +592,8 @@ int main(int argc, char** argv) {
   if (want("deepptrace")) {   // phase timeline of workgroup 0 of the persistent deep kernel (variant 91), in the steady state
     struct Sh { int64_t M, N, K; };
     for (const Sh& sh : {Sh{4096, 4096, 4096}, Sh{4096, 12288, 4096}, Sh{8192, 8192, 8192}}) {
-      DBuf<uint32_t> dT(64);
-      HIP_OK(hipMemset(dT.p, 0, 256));
+      DBuf<uint32_t> dT(64 + 512);
+      HIP_OK(hipMemset(dT.p, 0, (64 + 512) * 4));
       qutlass_amd_debug_set_trace_buffer(dT.p);
       g_gauss_fill = 1; g_warm_override = 1500; g_iters_override = 500;
       bench_gemm("mxfp4 persistent deep + timestamps", 0, sh.M, sh.N, sh.K, 91, 0);
@@ -603,7 +605,23 @@ int main(int argc, char** argv) {
       for (int i = 0; i < n && i < 30; ++i)
         printf("    mark %2d  +%8u cycles  +%7.2f us   (since previous: %7u cycles, %6.2f us -> %.2f GHz)\n", i, t[2 + 2 * i] - t[2], (t[3 + 2 * i] - t[3]) * 0.01,
                i ? t[2 + 2 * i] - t[2 * i] : 0, i ? (t[3 + 2 * i] - t[1 + 2 * i]) * 0.01 : 0.0, i && t[3 + 2 * i] != t[1 + 2 * i] ? (t[2 + 2 * i] - t[2 * i]) / ((t[3 + 2 * i] - t[1 + 2 * i]) * 10.0) : 0.0);
+      // all workgroups of the LAST launch: entry / exit wall ticks relative to the earliest entry
+      uint32_t first = 0xffffffffu, last_in = 0, first_out = 0xffffffffu, last_out = 0;
+      for (int w = 0; w < 256; ++w) { first = std::min(first, t[64 + 2 * w]); }
+      std::vector<double> ins, outs;
+      for (int w = 0; w < 256; ++w) { ins.push_back((t[64 + 2 * w] - first) * 0.01); outs.push_back((t[65 + 2 * w] - first) * 0.01); }
+      std::sort(ins.begin(), ins.end()); std::sort(outs.begin(), outs.end());
+      printf("  WG entry (us after the first): p0 %.2f p25 %.2f p50 %.2f p75 %.2f p100 %.2f   WG exit: p0 %.2f p25 %.2f p50 %.2f p75 %.2f p100 %.2f\n", ins[0], ins[64], ins[128], ins[192], ins[255],
+             outs[0], outs[64], outs[128], outs[192], outs[255]);
     }
+  }
+  if (want("staux")) {   // cache policy of the output stores of the persistent deep kernel (lab variants 92..96), steady state, interleaved
+    g_gauss_fill = 1; g_warm_override = 2500; g_iters_override = 2500;
+    for (int rep = 0; rep < 3; ++rep)
+      for (int var : {90, 92, 93, 94, 95, 96}) bench_gemm("mxfp4 4096^3 steady: store policy 90 = sc0|sc1 (product), 92 nt, 93 sc1, 94 write-back default, 95 sc0|sc1|nt, 96 sc0", 0, 4096, 4096, 4096, var, 0);
+    g_warm_override = 600; g_iters_override = 600;
+    for (int var : {90, 92, 94}) bench_gemm("mxfp4 4096x12288x4096 steady: store policy", 0, 4096, 12288, 4096, var, 0);
+    g_gauss_fill = 0; g_warm_override = 0; g_iters_override = 0;
   }
   if (want("deeppbench")) {
     g_gauss_fill = 1;

@@ -535,3 +535,91 @@ void run_ubench_power(const char* csv_path) {
   if (csv_path) smi.dump(csv_path, marks);
   hipFree(g); hipFree(out); hipFree(cyc); hipFree(fill);
 }
+
+
+// ------------------------------------------------------------------------------------------------
+// Output-store burst of the 4096^3 GEMM in isolation: 256 workgroups x 4 waves, every wave writes its 128 x 128 bf16
+// quadrant of a 256 x 256 tile (32 MiB in total) from registers, as 32-row x 32-column pieces in the order the GEMM retires them.
+//   PAT 0: 16 rows x 64 B per wave instruction (what gemm_mx_deepp does)    PAT 1: 8 rows x 128 B (pairs of pieces, whole lines)
+//   PAT 2: 32 rows x 32 B (the register-direct epilogue's pattern)          AUX: cache policy bits (1 sc0, 2 nt, 16 sc1)
+// ------------------------------------------------------------------------------------------------
+template <int PAT, int AUX>
+__global__ __launch_bounds__(256) void store_pattern_kernel(uint16_t* D, int ldd, uint32_t seed) {
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int tile_m = blockIdx.x / 16, tile_n = blockIdx.x % 16, wave_m = wave >> 1, wave_n = wave & 1;
+  const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(D + ((size_t)(tile_m * 256) * ldd + tile_n * 256), 0, 0x7fffffff, 0x00020000);
+  typedef unsigned int v4u_ __attribute__((ext_vector_type(4)));
+  v4u_ v = {seed ^ (uint32_t)threadIdx.x, seed * 3u, seed * 5u + blockIdx.x, seed * 7u};
+  for (int m = 0; m < 4; ++m)
+    for (int n = 0; n < 4; ++n) {
+      if (PAT == 0) {
+        const int rr = lane >> 2, cc = lane & 3;
+        for (int ps = 0; ps < 2; ++ps) {
+          const int off = ((wave_m * 128 + 32 * m + 16 * ps + rr) * ldd + wave_n * 128 + 32 * n + 8 * cc) * 2;
+          __builtin_amdgcn_raw_buffer_store_b128(v, r, off, 0, AUX);
+          v[0] += 1;
+        }
+      } else if (PAT == 1) {
+        if (n & 1) continue;   // a pair of pieces (n, n + 1) = 32 rows x 128 B: 4 instructions of 8 rows x 128 B
+        const int rr = lane >> 3, cc = lane & 7;
+        for (int ps = 0; ps < 4; ++ps) {
+          const int off = ((wave_m * 128 + 32 * m + 8 * ps + rr) * ldd + wave_n * 128 + 32 * n + 8 * cc) * 2;
+          __builtin_amdgcn_raw_buffer_store_b128(v, r, off, 0, AUX);
+          v[0] += 1;
+        }
+      } else {
+        const int rr = lane & 31, cc = lane >> 5;
+        for (int ps = 0; ps < 2; ++ps) {
+          const int off = ((wave_m * 128 + 32 * m + rr) * ldd + wave_n * 128 + 32 * n + 16 * ps + 8 * cc) * 2;
+          __builtin_amdgcn_raw_buffer_store_b128(v, r, off, 0, AUX);
+          v[0] += 1;
+        }
+      }
+    }
+}
+
+template <int PAT, int AUX>
+static void run_store_pattern(const char* name, uint16_t* D) {
+  auto go = [&](int n) { for (int i = 0; i < n; ++i) store_pattern_kernel<PAT, AUX><<<256, 256>>>(D, 4096, 17u + i); };
+  go(3000);
+  HIP_OK(hipDeviceSynchronize());
+  hipEvent_t e0, e1;
+  HIP_OK(hipEventCreate(&e0)); HIP_OK(hipEventCreate(&e1));
+  HIP_OK(hipEventRecord(e0, 0));
+  go(3000);
+  HIP_OK(hipEventRecord(e1, 0));
+  HIP_OK(hipEventSynchronize(e1));
+  float ms; HIP_OK(hipEventElapsedTime(&ms, e0, e1));
+  const double us = ms * 1e3 / 3000;
+  printf("UBENCH stores %-58s aux %2d : %6.2f us per 32 MiB launch = %5.2f TB/s (launch-to-launch, incl. dispatch + end-of-kernel write-back)\n", name, AUX, us, 33.554432 / us);
+  hipEventDestroy(e0); hipEventDestroy(e1);
+}
+
+__global__ void empty_kernel_256(uint32_t* p) { if (p == nullptr && threadIdx.x == 1234567) *p = 1; }
+
+void run_store_patterns() {
+  uint16_t* D;
+  HIP_OK(hipMalloc(&D, 4096ull * 4096 * 2));
+  {
+    for (int i = 0; i < 3000; ++i) empty_kernel_256<<<256, 256>>>((uint32_t*)D);
+    HIP_OK(hipDeviceSynchronize());
+    hipEvent_t e0, e1; HIP_OK(hipEventCreate(&e0)); HIP_OK(hipEventCreate(&e1));
+    HIP_OK(hipEventRecord(e0, 0));
+    for (int i = 0; i < 3000; ++i) empty_kernel_256<<<256, 256>>>((uint32_t*)D);
+    HIP_OK(hipEventRecord(e1, 0)); HIP_OK(hipEventSynchronize(e1));
+    float ms; HIP_OK(hipEventElapsedTime(&ms, e0, e1));
+    printf("UBENCH empty kernel, 256 workgroups x 256 threads: %6.2f us launch-to-launch\n", ms * 1e3 / 3000);
+  }
+  for (int rep = 0; rep < 2; ++rep) {
+    run_store_pattern<0, 0>("16 rows x 64 B per instruction (gemm_mx_deepp)", D);
+    run_store_pattern<1, 0>("8 rows x 128 B per instruction (whole lines)", D);
+    run_store_pattern<2, 0>("32 rows x 32 B per instruction (register-direct)", D);
+    run_store_pattern<0, 2>("16 rows x 64 B", D);
+    run_store_pattern<0, 16>("16 rows x 64 B", D);
+    run_store_pattern<0, 17>("16 rows x 64 B", D);
+    run_store_pattern<0, 19>("16 rows x 64 B", D);
+    run_store_pattern<1, 2>("8 rows x 128 B", D);
+    run_store_pattern<1, 17>("8 rows x 128 B", D);
+  }
+  hipFree(D);
+}

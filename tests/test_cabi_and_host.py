@@ -69,6 +69,9 @@ def test_c_abi_rejects_bad_arguments_without_launching(lib):
     assert lib.qutlass_amd_fused_quantize_nv(dummy, dummy, 8, 4096, 1, dummy, dummy, dummy, None) == QAMD_ERR_INVALID
     assert lib.qutlass_amd_to_blocked(dummy, 0, 4, dummy, None) == QAMD_ERR_INVALID
     assert lib.qutlass_amd_set_option(b"no_such_option", 1) == -1
+    # the PRODUCT library has no kernel-selecting state: these keys exist only in the lab build (libqutlass_amd_bench.so)
+    for key in (b"gemm_variant", b"nvf4_variant", b"pp_flags", b"splitk_wg", b"quant_wg_per_cu"):
+        assert lib.qutlass_amd_set_option(key, 31) == -1, key
     assert b"gfx950" in lib.qutlass_amd_version()
 
 
@@ -177,30 +180,56 @@ def test_python_surface_matches_reference_signatures():
     assert list(inspect.signature(qutlass_amd.mxfp4_transpose_mxfp8).parameters) == ["x_fp4", "scales"]
 
 
+# exact schema strings of the reference's op library (qutlass/csrc/bindings.cpp:499-513)
+REFERENCE_SCHEMAS = {
+    "matmul_mxf4_bf16_tn": "(Tensor A, Tensor B, Tensor A_sf, Tensor B_sf, Tensor alpha) -> Tensor",
+    "matmul_nvf4_bf16_tn": "(Tensor A, Tensor B, Tensor A_sf, Tensor B_sf, Tensor alpha) -> Tensor",
+    "matmul_ada_mxf4_bf16_tn": "(Tensor A, Tensor B, Tensor A_sf, Tensor B_sf, Tensor alpha) -> Tensor",
+    "matmul_mxf8_bf16_tn": "(Tensor A, Tensor B, Tensor A_sf, Tensor B_sf, Tensor alpha) -> Tensor",
+    "matmul_mxf8_bf16_nn": "(Tensor A, Tensor B, Tensor A_sf, Tensor B_sf, Tensor alpha) -> Tensor",
+    "fusedQuantizeMxQuest": "(Tensor A, Tensor R, Tensor OUT, Tensor OUT_sf) -> (Tensor, Tensor)",
+    "fusedQuantizeMxAbsMax": "(Tensor A, Tensor R, Tensor OUT, Tensor OUT_sf) -> (Tensor, Tensor)",
+    "fusedQuantizeMxQuestWithMask": "(Tensor A, Tensor R, Tensor OUT, Tensor OUT_sf, Tensor OUT_mask) -> (Tensor, Tensor, Tensor)",
+    "fusedQuantizeNvQuest": "(Tensor A, Tensor R, Tensor OUT, Tensor OUT_sf, Tensor global_scale) -> (Tensor, Tensor)",
+    "fusedQuantizeNvAbsMax": "(Tensor A, Tensor R, Tensor OUT, Tensor OUT_sf, Tensor global_scale) -> (Tensor, Tensor)",
+    "backward_t_bf16": "(Tensor x, Tensor h, Tensor xh_e2m1, Tensor xh_e8m0) -> ()",
+    "backward_qt_bf16": "(Tensor x_e2m1, Tensor x_e8m0, Tensor h, Tensor alpha, Tensor xh_e2m1, Tensor xh_e8m0) -> ()",
+    "backward_bf16_square_double_mxfp8": "(Tensor x_bf16, Tensor x_fp8, Tensor row_scales, Tensor column_scales) -> ()",
+    "mxfp4_transpose_mxfp8": "(Tensor x_fp4, Tensor scales, Tensor x_fp8, Tensor shared_exps) -> ()",
+}
+
+
 def test_torch_ops_registered_with_reference_schemas():
     import qutlass_amd  # noqa: F401
-    from qutlass_amd.ops import SCHEMAS
 
-    for name, schema in SCHEMAS.items():
+    for name, schema in REFERENCE_SCHEMAS.items():
         op = getattr(torch.ops._qutlass_C, name)
         got = str(op.default._schema)
         assert got == f"_qutlass_C::{name}{schema}", got
 
 
 def test_ops_are_implemented_by_the_cpp_extension():
-    """torch.ops._qutlass_C.* must come from the in-tree C++ extension (qutlass_amd/_C.so, csrc/torch_ext.cpp), which
-    links libqutlass_amd.so -- not from a Python-registered stand-in."""
+    """torch.ops._qutlass_C.* must come from the in-tree C++ extension (qutlass/_CUDA.abi3.so, csrc/torch_ext.cpp), which
+    links libqutlass_amd.so -- not from a Python-registered stand-in -- and it must be the reference's module:
+    `import qutlass._CUDA` succeeds (PyInit__CUDA, bindings.cpp:537-540) and is the same mapped file."""
+    import importlib
+
     import qutlass_amd  # noqa: F401
     from qutlass_amd import ops
 
-    assert os.path.exists(ops.EXT_PATH)
+    assert os.path.exists(ops.EXT_PATH) and ops.EXT_PATH.endswith(os.path.join("qutlass", "_CUDA.abi3.so"))
     maps = open("/proc/self/maps").read()
     assert ops.EXT_PATH in maps and "libqutlass_amd.so" in maps
+    mod = importlib.import_module("qutlass._CUDA")
+    assert os.path.samefile(mod.__file__, ops.EXT_PATH)
     # a C++ kernel registered through the stable ABI is not a Python callable: there is no torch.library python impl
     assert "_qutlass_C::matmul_mxf4_bf16_tn" not in getattr(torch.library, "_impls", {})
     assert torch.ops.qutlass_amd.to_blocked is not None
-    # validation lives in the extension: the message carries the C++ source location (STD_TORCH_CHECK)
-    with pytest.raises(RuntimeError, match=r"torch_ext\.cpp"):
+    # registered for the CUDA dispatch key ONLY, as in the reference (bindings.cpp:516): a CPU tensor never reaches the
+    # kernels -- the dispatcher itself refuses
+    assert torch._C._dispatch_has_kernel_for_dispatch_key("_qutlass_C::matmul_mxf4_bf16_tn", "CUDA")
+    assert not torch._C._dispatch_has_kernel_for_dispatch_key("_qutlass_C::matmul_mxf4_bf16_tn", "CPU")
+    with pytest.raises(NotImplementedError, match="CPU"):
         torch.ops._qutlass_C.matmul_mxf4_bf16_tn(torch.zeros(4, 64, dtype=torch.uint8), torch.zeros(4, 64, dtype=torch.uint8),
                                                  torch.zeros(128, 4, dtype=torch.float8_e8m0fnu), torch.zeros(128, 4, dtype=torch.float8_e8m0fnu), torch.ones(1))
 
@@ -224,22 +253,6 @@ def test_python_level_error_behaviour():
         qutlass_amd.matmul_mxf4_bf16_tn(u8, u8, sf, sf, torch.ones(1), backend="flashinfer")
     with pytest.raises(AttributeError):
         qutlass_amd.no_such_function
-
-
-def test_op_layer_validation_messages_follow_the_reference():
-    # bindings.cpp:38-57 / bindings_utils.h:67-136 -- checked on CPU tensors: validation runs before any launch
-    from qutlass_amd import ops
-
-    u8 = torch.zeros(4, 64, dtype=torch.uint8)
-    sf = torch.zeros(128, 4, dtype=torch.float8_e8m0fnu)
-    al = torch.ones(1)
-    with pytest.raises(RuntimeError, match="Expected tensor to have cuda DeviceType, but got tensor with cpu DeviceType"):
-        ops.matmul_mxf4_bf16_tn(u8, u8, sf, sf, al)
-    nc = torch.zeros(64, 8, dtype=torch.uint8).t()
-    with pytest.raises(RuntimeError, match=r"Expected contiguous tensor, but got non-contiguous tensor for argument #0 'A' \(while checking arguments for matmul_mxf4_bf16_tn\)"):
-        ops.matmul_mxf4_bf16_tn(nc, u8, sf, sf, al)
-    with pytest.raises(RuntimeError, match="to_blocked expects a 2-D matrix"):
-        ops.to_blocked(torch.zeros(8, dtype=torch.uint8))
 
 
 def test_padded_shapes_and_pad_to_block():

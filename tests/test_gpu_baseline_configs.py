@@ -127,33 +127,41 @@ def test_c4_nvfp4_8192_cubed_vs_oracle(q):
     assert np.array_equal(got, ref), f"{int((got != ref).sum())} of {got.size} sampled outputs differ"
 
 
+@pytest.mark.parametrize("a_format", ["e4m3", "e5m2"])
 @pytest.mark.parametrize("layout", ["tn", "nn"])
-def test_c5_mxfp8_4096_cubed_vs_oracle(q, layout):
-    """configs[4] (the e4m3 x e4m3 leg the reference implements): 4096^3 TN and NN against oracle.gemm_blockscaled on 64
-    sampled rows -- the oracle, not a TN/NN self-comparison.  Operands from the oracle's _pseudoquant_mxfp8 restatement
-    (mxfp8_test.py:26-46)."""
+def test_c5_mxfp8_4096_cubed_vs_oracle(q, layout, a_format):
+    """configs[4] at 4096^3, TN and NN, against oracle.gemm_blockscaled on 64 sampled rows -- the oracle, not a TN/NN
+    self-comparison.  a_format e4m3: the leg the reference implements, operands from the oracle's _pseudoquant_mxfp8
+    restatement (mxfp8_test.py:26-46).  a_format e5m2: configs[4] as BASELINE.json words it (e5m2 gradient x e4m3
+    activation) -- an extension the reference rejects (bindings.cpp:157-160); A gets a gradient-like dynamic range
+    (rows scaled by 2^U(-8, 8)) and the e5m2 pseudo-quantiser pinned by tests/golden/gemm_mxfp8_e5m2.npz."""
     from qutlass_amd.utils import to_blocked
 
     m = n = k = 4096
     torch.manual_seed(5)
     a = torch.randn(m, k, dtype=torch.bfloat16) * 25.0
     b = torch.randn(n, k, dtype=torch.bfloat16) * 25.0
-    aq, asf = oracle.pseudoquant_mxfp8(_np(a))
+    a5 = a_format == "e5m2"
+    if a5:
+        a = a * torch.exp2(torch.randint(-8, 9, (m, 1)).float()).to(torch.bfloat16)
+    aq, asf = oracle.pseudoquant_mxfp8(_np(a), e5m2=a5)
     bq, bsf = oracle.pseudoquant_mxfp8(_np(b))
     e4, e8 = torch.float8_e4m3fn, torch.float8_e8m0fnu
-    a_t, b_t = torch.from_numpy(aq).to(DEV).view(e4), torch.from_numpy(bq).to(DEV).view(e4)
+    ea = torch.float8_e5m2 if a5 else e4
+    kind_tn, kind_nn = (oracle.KIND_MXFP8_TN_A5, oracle.KIND_MXFP8_NN_A5) if a5 else (oracle.KIND_MXFP8_TN, oracle.KIND_MXFP8_NN)
+    a_t, b_t = torch.from_numpy(aq).to(DEV).view(ea), torch.from_numpy(bq).to(DEV).view(e4)
     sa, sb = to_blocked(torch.from_numpy(asf).to(DEV).view(e8)), to_blocked(torch.from_numpy(bsf).to(DEV).view(e8))
     alpha = torch.tensor([1.0], device=DEV)
     rows = _sample_rows(m, 64, 6)
     if layout == "tn":
         out = q.matmul_mxf8_bf16_tn(a_t, b_t, sa, sb, alpha)
-        ref = oracle.gemm_blockscaled(oracle.KIND_MXFP8_TN, np.ascontiguousarray(aq[rows]), bq, oracle.to_blocked(np.ascontiguousarray(asf[rows])),
+        ref = oracle.gemm_blockscaled(kind_tn, np.ascontiguousarray(aq[rows]), bq, oracle.to_blocked(np.ascontiguousarray(asf[rows])),
                                       oracle.to_blocked(bsf), 1.0, len(rows), n, k)
     else:
-        a_km = a_t.view(torch.uint8).T.contiguous().view(e4)       # (K, M), the reference's ColumnMajor A (mxfp8_test.py:77-96)
+        a_km = a_t.view(torch.uint8).T.contiguous().view(ea)       # (K, M), the reference's ColumnMajor A (mxfp8_test.py:77-96)
         out = q.matmul_mxf8_bf16_nn(a_km, b_t, sa, sb, alpha)
         a_km_rows = np.ascontiguousarray(aq.T[:, rows])              # (K, rows): the oracle's NN path on the sampled columns of A^T
-        ref = oracle.gemm_blockscaled(oracle.KIND_MXFP8_NN, a_km_rows, bq, oracle.to_blocked(np.ascontiguousarray(asf[rows])),
+        ref = oracle.gemm_blockscaled(kind_nn, a_km_rows, bq, oracle.to_blocked(np.ascontiguousarray(asf[rows])),
                                       oracle.to_blocked(bsf), 1.0, len(rows), n, k)
     got = _np(out[torch.tensor(rows, device=DEV)])
     ok = _mxfp8_close(got, ref)

@@ -310,6 +310,30 @@ def test_matmul_mxf4_errors(q):
         q.matmul_mxf4_bf16_tn(u8[:, :48].contiguous(), u8[:, :48].contiguous(), sf, sf, al)
 
 
+def test_op_layer_validation_messages_follow_the_reference(q):
+    """bindings.cpp:38-57 / bindings_utils.h:67-136: contiguity, device and dtype checks with the reference's wording,
+    raised by the C++ extension (the message carries its source location) before anything is launched."""
+    u8 = torch.zeros(4, 64, dtype=torch.uint8, device=DEV)
+    sf = torch.zeros(128, 4, dtype=torch.float8_e8m0fnu, device=DEV)
+    al = torch.ones(1, device=DEV)
+    C = torch.ops._qutlass_C
+    with pytest.raises(RuntimeError, match="Expected tensor to have cuda DeviceType, but got tensor with cpu DeviceType"):
+        C.matmul_mxf4_bf16_tn(u8, u8.cpu(), sf, sf, al)
+    nc = torch.zeros(64, 8, dtype=torch.uint8, device=DEV).t()
+    with pytest.raises(RuntimeError, match=r"Expected contiguous tensor, but got non-contiguous tensor for argument #0 'A' \(while checking arguments for matmul_mxf4_bf16_tn\)"):
+        C.matmul_mxf4_bf16_tn(nc, u8, sf, sf, al)
+    with pytest.raises(RuntimeError, match=r"torch_ext\.cpp"):
+        C.matmul_mxf4_bf16_tn(u8, u8, sf.view(torch.uint8), sf, al)
+    with pytest.raises(RuntimeError, match="A_sf has 4 elements"):      # scale tensor smaller than the blocked layout the kernel reads
+        C.matmul_mxf4_bf16_tn(u8, u8, sf.reshape(-1)[:4].contiguous(), sf, al)
+    with pytest.raises(RuntimeError, match="alpha must be a float32 tensor"):
+        C.matmul_mxf4_bf16_tn(u8, u8, sf, sf, al.to(torch.float64))
+    with pytest.raises(RuntimeError, match="to_blocked expects a 2-D matrix"):
+        torch.ops.qutlass_amd.to_blocked(torch.zeros(8, dtype=torch.uint8, device=DEV))
+    with pytest.raises(NotImplementedError):                               # CUDA dispatch key only, as the reference registers
+        C.matmul_mxf4_bf16_tn(u8.cpu(), u8.cpu(), sf.cpu(), sf.cpu(), al.cpu())
+
+
 # ------------------------------------------------------------------------------------------------
 # NVFP4
 # ------------------------------------------------------------------------------------------------
@@ -427,6 +451,51 @@ def test_matmul_mxf8_tn_golden_and_random(q, golden_dir):
                                 to_blocked(torch.from_numpy(bsf).to(DEV).view(torch.float8_e8m0fnu)), torch.tensor([1.0], device=DEV))
     ref = oracle.gemm_blockscaled(oracle.KIND_MXFP8_TN, aq, bq, oracle.to_blocked(asf), oracle.to_blocked(bsf), 1.0, m, n, k)
     assert _mxfp8_close(_np(out), ref).all()
+
+
+def test_matmul_mxf8_e5m2_operand_golden(q, golden_dir):
+    """Extension: A may be float8_e5m2 (gradient operand, BASELINE.json configs[4]); fixtures from torch's own e5m2 cast
+    (tests/golden/make_golden_e5m2.py).  TN and NN through the Python surface, within the MXFP8 tolerance."""
+    from qutlass_amd.utils import to_blocked
+
+    g = _load(golden_dir, "gemm_mxfp8_e5m2.npz")
+    e5, e4, e8 = torch.float8_e5m2, torch.float8_e4m3fn, torch.float8_e8m0fnu
+    for c in range(int(g["ncases"])):
+        m, n, k = (int(v) for v in g[f"meta{c}"])
+        a = torch.from_numpy(g[f"a{c}"]).to(DEV).view(e5)
+        b = torch.from_numpy(g[f"b{c}"]).to(DEV).view(e4)
+        asf = to_blocked(torch.from_numpy(g[f"asf{c}"]).to(DEV).view(e8))
+        bsf = to_blocked(torch.from_numpy(g[f"bsf{c}"]).to(DEV).view(e8))
+        alpha = torch.tensor([1.0], device=DEV)
+        out = q.matmul_mxf8_bf16_tn(a, b, asf, bsf, alpha)
+        assert out.shape == (m, n) and _mxfp8_close(_np(out), g[f"out{c}"]).all(), c
+        if m % 16 == 0:
+            a_km = a.view(torch.uint8).T.contiguous().view(e5)
+            out_nn = q.matmul_mxf8_bf16_nn(a_km, b, asf, bsf, alpha)
+            assert torch.equal(out_nn.view(torch.int16), out.view(torch.int16)), c
+    with pytest.raises(RuntimeError, match="B must be float8_e4m3fn"):      # only A may be e5m2
+        q.matmul_mxf8_bf16_tn(a, b.view(e5), asf, bsf, alpha)
+
+
+@pytest.mark.parametrize("m,n,k", [(16, 4096, 1024), (200, 264, 7168), (520, 776, 1056), (1024, 4096, 512), (2048, 4096, 256), (4096, 4096, 128)])
+def test_matmul_mxf8_e5m2_operand_every_tile_vs_oracle(q, m, n, k):
+    """The shapes walk the auto dispatch through ring 64x64 (+ split-K), ring 128x128, simple 128x128 and the 256x256 deep
+    kernel, each in its e5m2-A instantiation, against oracle.gemm_blockscaled(KIND_MXFP8_TN_A5)."""
+    from qutlass_amd.utils import to_blocked
+
+    torch.manual_seed(m + n + k)
+    a = torch.randn(m, k, dtype=torch.bfloat16) * 25.0 * torch.exp2(torch.randint(-6, 7, (m, 1)).float()).to(torch.bfloat16)
+    b = torch.randn(n, k, dtype=torch.bfloat16) * 25.0
+    aq, asf = oracle.pseudoquant_mxfp8(_np(a), e5m2=True)
+    bq, bsf = oracle.pseudoquant_mxfp8(_np(b))
+    e8 = torch.float8_e8m0fnu
+    out = q.matmul_mxf8_bf16_tn(torch.from_numpy(aq).to(DEV).view(torch.float8_e5m2), torch.from_numpy(bq).to(DEV).view(torch.float8_e4m3fn),
+                                to_blocked(torch.from_numpy(asf).to(DEV).view(e8)), to_blocked(torch.from_numpy(bsf).to(DEV).view(e8)),
+                                torch.tensor([0.5], device=DEV))
+    rows = sorted({0, 1, m // 2, m - 1} | set(np.random.default_rng(m).integers(0, m, 28).tolist()))
+    ref = oracle.gemm_blockscaled(oracle.KIND_MXFP8_TN_A5, np.ascontiguousarray(aq[rows]), bq, oracle.to_blocked(np.ascontiguousarray(asf[rows])),
+                                  oracle.to_blocked(bsf), 0.5, len(rows), n, k)
+    assert _mxfp8_close(_np(out)[rows], ref).all()
 
 
 @pytest.mark.parametrize("m,n,k", [(16, 4096, 4096), (272, 520, 1056), (4096, 4096, 4096)])

@@ -142,6 +142,29 @@ def test_mxfp8_pseudoquant_and_gemm(golden_dir):
         assert np.array_equal(d2, d), c
 
 
+def test_mxfp8_e5m2_operand_extension(golden_dir):
+    """BASELINE.json configs[4]'s e5m2-gradient leg (extension: the reference rejects it, so the fixture is built from torch's
+    own float8_e5m2 cast + the reference's e4m3 pseudo-quantiser, tests/golden/make_golden_e5m2.py).  Pins the oracle's e5m2
+    decode / encode on the whole code space and on 4k values, the e5m2 pseudo-quantiser, and the TN / NN GEMM kinds."""
+    g = _load(golden_dir, "gemm_mxfp8_e5m2.npz")
+    dec = np.array([oracle.e5m2_decode(b) for b in range(256)], dtype=np.float32)
+    want = g["e5m2_decode_f32"]
+    assert np.array_equal(np.isnan(dec), np.isnan(want)) and np.array_equal(dec[~np.isnan(dec)], want[~np.isnan(want)])
+    enc = np.array([oracle.e5m2_encode(float(v)) for v in g["e5m2_encode_in"]], dtype=np.uint8)
+    assert np.array_equal(enc, g["e5m2_encode_out"])
+    for c in range(int(g["ncases"])):
+        m, n, k = g[f"meta{c}"]
+        oq, os_ = oracle.pseudoquant_mxfp8(g[f"xa{c}"], e5m2=True)
+        assert np.array_equal(os_, g[f"asf{c}"]) and np.array_equal(oq, g[f"a{c}"]), c
+        oq, os_ = oracle.pseudoquant_mxfp8(g[f"xb{c}"])
+        assert np.array_equal(os_, g[f"bsf{c}"]) and np.array_equal(oq, g[f"b{c}"]), c
+        d = oracle.gemm_blockscaled(oracle.KIND_MXFP8_TN_A5, g[f"a{c}"], g[f"b{c}"], _blocked(g[f"asf{c}"]), _blocked(g[f"bsf{c}"]), 1.0, m, n, k)
+        assert np.array_equal(d, g[f"out{c}"]), c
+        d2 = oracle.gemm_blockscaled(oracle.KIND_MXFP8_NN_A5, np.ascontiguousarray(g[f"a{c}"].T), g[f"b{c}"], _blocked(g[f"asf{c}"]),
+                                     _blocked(g[f"bsf{c}"]), 1.0, m, n, k)
+        assert np.array_equal(d2, d), c
+
+
 # ---- SURVEY 8(f) rank 1: QAT-backward data-prep kernels -----------------------------------------------------------
 def _dq_mx(codes_u8, e8m0_u8, alpha):
     """(.., K/2) packed e2m1 + (.., K/32) e8m0 -> float64 dequantised values / alpha (tests/quartet_test.py:76-104)."""
