@@ -253,6 +253,16 @@ def main():
     cold("fusedQuantizeNv(H16, abs_max) 4096x4096", lambda j: q.fusedQuantizeNv(xs_c[j], h16, gs), M * K * 2 + M * K // 2 + M * K // 16)
     cold("backward_t_bf16 4096x4096", lambda j: q.backward_t_bf16(xs_c[j], h32), qb)
     cold("backward_bf16_square_double_mxfp8 4096x4096", lambda j: q.backward_bf16_square_double_mxfp8(xs_c[j]), M * K * 3 + 2 * M * K // 32)
+    # the same op on a tensor large enough to amortise launch + ramp (~2 us of a 9 us call at 4096^2): 16384 x 8192 bf16 = 256 MiB
+    # per input, 5 inputs rotated
+    big = [torch.randn(16384, 8192, dtype=torch.bfloat16, device=dev) * 25.0 for _ in range(5)]
+    bigb = 16384 * 8192 * 2 + 16384 * 8192 // 2 + 16384 * 8192 // 32
+    line("fusedQuantizeMx(H32, abs_max) 16384x8192 [cold: 5 x 256 MiB inputs rotated]", time_us_cold(lambda j: q.fusedQuantizeMx(big[j], h32, method="abs_max"), 5, 20), bytes_=bigb, cache="cold")
+    line("fusedQuantizeMx(H32, quest, return_mask=True) 16384x8192 [cold: 5 x 256 MiB inputs rotated]",
+         time_us_cold(lambda j: q.fusedQuantizeMx(big[j], h32, method="quest", return_mask=True), 5, 20), bytes_=bigb + 16384 * 8192 // 8, cache="cold")
+    h128 = hadamard(128, dev)
+    line("fusedQuantizeMx(H128, abs_max) 16384x8192 [cold: 5 x 256 MiB inputs rotated]", time_us_cold(lambda j: q.fusedQuantizeMx(big[j], h128, method="abs_max"), 5, 20), bytes_=bigb, cache="cold")
+    del big
     # packed-input ops: 9 MiB per input, so rotate 40 of them as well (360 MiB > MALL) -- quantise the cold inputs once
     packed = [q.fusedQuantizeMx(t, h32, method="abs_max") for t in xs_c]
     packed = [(pq, ps.view(torch.uint8).reshape(-1)[: M * K // 32].reshape(M, K // 32).contiguous().view(torch.float8_e8m0fnu)) for pq, ps in packed]

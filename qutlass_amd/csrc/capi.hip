@@ -3,6 +3,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -55,6 +56,7 @@ std::atomic<int> g_transpose_nc{128};   // mxfp4_transpose_mxfp8: n columns per 
 std::atomic<int> g_pp_shift{2};
 std::atomic<int> g_pp_flags{1};
 std::atomic<int> g_quant_wg_per_cu{0};  // 0 = auto
+std::atomic<int> g_splitk_force{0};     // lab: K splits for a FORCED ring variant ("gemm_variant" 70..73); 0 = the plan's
 std::atomic<uint32_t*> g_dbg{nullptr};
 #endif
 
@@ -71,10 +73,22 @@ int check_launch(const char* what) {
   if (e != hipSuccess) return fail(QAMD_ERR_HIP, "%s: %s", what, hipGetErrorString(e));
   return QAMD_OK;
 }
+
+// Per-launch number of the fused split-K kernels (host state only; no device memory behind it): starts at a value drawn
+// from the clock and the process, then counts up.  56 bits of it tag the arrival slots of one launch.
+unsigned long long next_launch_tag() {
+  static std::atomic<unsigned long long> tag{[] {
+    unsigned long long x = (unsigned long long)std::chrono::steady_clock::now().time_since_epoch().count() ^ ((unsigned long long)(uintptr_t)&g_err << 17);
+    x ^= x >> 31; x *= 0x9e3779b97f4a7c15ull; x ^= x >> 29;
+    return x | 1ull;
+  }()};
+  return tag.fetch_add(1, std::memory_order_relaxed) + 1;
+}
 #else
+unsigned long long next_launch_tag();
 extern std::atomic<int> g_hw_fp4_cvt;
 #if QAMD_BENCH
-extern std::atomic<int> g_gemm_variant, g_nvf4_variant, g_splitk_wg, g_splitk_min_kt, g_transpose_nc, g_pp_shift, g_pp_flags, g_quant_wg_per_cu;
+extern std::atomic<int> g_gemm_variant, g_nvf4_variant, g_splitk_wg, g_splitk_min_kt, g_transpose_nc, g_pp_shift, g_pp_flags, g_quant_wg_per_cu, g_splitk_force;
 extern std::atomic<uint32_t*> g_dbg;
 #endif
 int fail(int code, const char* fmt, ...);
@@ -92,6 +106,7 @@ inline int opt_transpose_nc() { return g_transpose_nc.load(); }
 inline int opt_pp_shift() { return g_pp_shift.load(); }
 inline int opt_pp_flags() { return g_pp_flags.load(); }
 inline int opt_quant_wg_per_cu() { return g_quant_wg_per_cu.load(); }
+inline int opt_splitk_force() { return g_splitk_force.load(); }
 inline uint32_t* opt_dbg() { return g_dbg.load(); }
 #else
 constexpr int opt_gemm_variant() { return 0; }
@@ -102,6 +117,7 @@ constexpr int opt_transpose_nc() { return 128; }
 constexpr int opt_pp_shift() { return 2; }
 constexpr int opt_pp_flags() { return 1; }
 constexpr int opt_quant_wg_per_cu() { return 0; }
+constexpr int opt_splitk_force() { return 0; }
 constexpr uint32_t* opt_dbg() { return nullptr; }
 #endif
 
@@ -111,7 +127,7 @@ template <class C, int PP>
 int launch_gemm(GemmParams p, hipStream_t s) {
   p.tiles_m = (int)cdiv(p.M, C::BM);
   p.tiles_n = (int)cdiv(p.N, C::BN);
-  if (PP != 7) { p.ws = nullptr; p.splits = 1; }   // only the (blocked-scale) ring schedule knows about split-K
+  if (PP != 7) { p.ws = nullptr; p.splits = 1; p.ctr = nullptr; p.tag = 0; }   // only the (blocked-scale) ring schedule knows about split-K
   hipLaunchKernelGGL((gemm_mx_kernel<C, PP>), dim3(p.tiles_m * p.tiles_n, p.splits), dim3(C::THREADS), 0, s, p);
   return check_launch("gemm_mx_kernel");
 }
@@ -121,7 +137,7 @@ template <class C, bool TRACE = false, int ST_AUX = 0>
 int launch_gemm_deepp(GemmParams p, hipStream_t s) {
   p.tiles_m = (int)cdiv(p.M, C::BM);
   p.tiles_n = (int)cdiv(p.N, C::BN);
-  p.ws = nullptr; p.splits = 1;
+  p.ws = nullptr; p.splits = 1; p.ctr = nullptr; p.tag = 0;
   const int grid = std::min(p.tiles_m * p.tiles_n, 256);   // MI355X: 256 CUs, one 512-register workgroup each
   hipLaunchKernelGGL((gemm_mx_deepp_kernel<C, TRACE, ST_AUX>), dim3(grid), dim3(C::THREADS), 0, s, p);
   return check_launch("gemm_mx_deepp_kernel");
@@ -316,6 +332,25 @@ int launch_nvf4_host(const NvGemmParams& p, hipStream_t s, int variant);
 // enough to pay for the second pass (>= 32 stages: fp4 K >= 8192).  One function so that the launcher and qutlass_amd_gemm_splitk_workspace_bytes
 // agree.  Measured: profiles/native_r1_ring.log.
 struct SmallPlan { int variant; int splits; };   // variant 0: not this regime
+// tile of a ring variant (70: 64x64, 71: 128x64, 72: 64x128, 73: 128x128)
+inline void ring_tile(int variant, int& bm, int& bn) {
+  bm = (variant == 71 || variant == 73) ? 128 : 64;
+  bn = (variant == 72 || variant == 73) ? 128 : 64;
+}
+// split-K scratch: [splits][M][N] fp32 partials (lab library: then, 256-byte aligned, one 64-bit arrival slot per output tile
+// for the fused-reduction experiment)
+inline int64_t splitk_partial_bytes(int64_t M, int64_t N, int splits) { return (int64_t)splits * M * N * 4; }
+inline int64_t splitk_ctr_offset(int64_t M, int64_t N, int splits) { return (splitk_partial_bytes(M, N, splits) + 255) / 256 * 256; }
+inline int64_t splitk_ws_bytes(int variant, int64_t M, int64_t N, int splits) {
+#if QAMD_BENCH
+  int bm, bn;
+  ring_tile(variant, bm, bn);
+  return splitk_ctr_offset(M, N, splits) + cdiv(M, bm) * cdiv(N, bn) * 8;
+#else
+  (void)variant;
+  return splitk_partial_bytes(M, N, splits);
+#endif
+}
 template <int EBITS>
 SmallPlan plan_small(int64_t M, int64_t N, int64_t K) {
   const int64_t T64 = cdiv(M, 64) * cdiv(N, 64), T128 = cdiv(M, 128) * cdiv(N, 128);
@@ -363,16 +398,29 @@ int gemm_mx(const char* name, const void* A, const void* B, const void* A_sf, co
   p.pp_shift = opt_pp_shift();
   p.pp_flags = opt_pp_flags();
   p.dbg = opt_dbg();
-  p.ws = nullptr; p.splits = 1;
+  p.ws = nullptr; p.splits = 1; p.ctr = nullptr; p.tag = 0;
   hipStream_t s = (hipStream_t)stream;
   int variant = opt_gemm_variant();
   if (variant == 61 || variant == 62) variant = 0;   // these select the NN operand path only (matmul_mxf8_bf16_nn)
   // ring schedule + optional split-K (needs caller scratch; "pp_flags" bit 7 turns split-K off, bit 8 the ring rule)
   const SmallPlan pl = plan_small<EBITS>(M, N, K);
   auto ring_launch = [&](int v, int splits) -> int {
-    const int64_t need = (int64_t)splits * M * N * 4;
-    if (splits > 1 && ws && ws_bytes >= need && !(p.pp_flags & 128)) {
-      p.ws = (float*)ws; p.splits = splits;
+    {   // every split non-empty (a forced count may not divide the K stages)
+      const int64_t KT = cdiv(K * EBITS / 8, 128);
+      splits = (int)std::min<int64_t>(std::max(splits, 1), std::min<int64_t>(KT, 8));
+      splits = (int)cdiv(KT, cdiv(KT, splits));
+    }
+    if (splits > 1 && ws && ws_bytes >= splitk_ws_bytes(v, M, N, splits) && !(p.pp_flags & 128)) {
+      p.ws = (float*)ws; p.splits = splits; p.ctr = nullptr; p.tag = 0;
+#if QAMD_BENCH
+      if (p.pp_flags & 512) {   // lab: ONE launch, the last split to arrive for a tile reduces it (gemm_mx.hip.h epilogue_splitk_fused);
+                                // measured slower than the reduce kernel below, see there
+        p.ctr = (unsigned long long*)((char*)ws + splitk_ctr_offset(M, N, splits));
+        p.tag = (next_launch_tag() & ((1ull << 56) - 1)) << 8;
+        return dispatch(v, p, s);
+      }
+#endif
+      // second launch: sum the partials in fixed z order, alpha, bf16 (deterministic)
       if (int rc = dispatch(v, p, s)) return rc;
       if (t_dry.on) return 0;
       const int64_t quads = M * (N / 4);
@@ -385,10 +433,12 @@ int gemm_mx(const char* name, const void* A, const void* B, const void* A_sf, co
       }
       return check_launch("splitk_reduce_kernel");
     }
+    p.ws = nullptr; p.splits = 1; p.ctr = nullptr; p.tag = 0;
     return dispatch(v, p, s);
   };
-  const bool can_split = pl.variant == 70 && pl.splits > 1 && ws && ws_bytes >= (int64_t)pl.splits * M * N * 4 && !(p.pp_flags & 128);
-  if (variant == 77) return ring_launch(70, pl.variant == 70 ? pl.splits : 1);   // bench: 64x64 ring (+ split-K) whatever M
+  const bool can_split = pl.variant && pl.splits > 1 && ws && ws_bytes >= splitk_ws_bytes(pl.variant, M, N, pl.splits) && !(p.pp_flags & 128);
+  if (variant == 77) return ring_launch(70, pl.variant == 70 ? pl.splits : 1);   // lab: 64x64 ring (+ split-K) whatever M
+  if (variant >= 70 && variant <= 73 && opt_splitk_force() > 0) return ring_launch(variant, opt_splitk_force());   // lab: forced tile x forced split
   // small batch (M <= 32): weight-bandwidth bound.  With fewer than 128 64-row tiles (N < 8192) the split-K kernel without
   // LDS staging wins (gemm_mx_skinny.hip.h: N = K = 4096, M = 16: 5.9 us vs 7.1 us for the ring kernel on 64 CUs); from
   // 128 tiles on, the 64x64 ring kernel streams the weight through full-line LDS-DMA and wins (N = 14336, K = 4096: 6.9 us
@@ -531,7 +581,11 @@ int qutlass_amd_matmul_mxf4_bf16_tn(const void* A, const void* B, const void* A_
 int64_t qutlass_amd_gemm_splitk_workspace_bytes(int ebits, int64_t M, int64_t N, int64_t K) {
   if (M <= 0 || N <= 0 || K <= 0 || (ebits != 4 && ebits != 8)) return 0;
   const SmallPlan pl = (ebits == 4) ? plan_small<4>(M, N, K) : plan_small<8>(M, N, K);
-  return (pl.variant == 70 && pl.splits > 1) ? (int64_t)pl.splits * M * N * 4 : 0;
+  int64_t need = (pl.variant && pl.splits > 1) ? splitk_ws_bytes(pl.variant, M, N, pl.splits) : 0;
+#if QAMD_BENCH
+  if (opt_splitk_force() > 1) need = std::max<int64_t>(need, splitk_ws_bytes(70, M, N, 8));   // lab: room for any forced tile x split
+#endif
+  return need;
 }
 
 int qutlass_amd_matmul_mxf4_bf16_tn_ws(const void* A, const void* B, const void* A_sf, const void* B_sf, const float* alpha, void* D,
@@ -567,7 +621,7 @@ int qutlass_amd_matmul_ada_mxf4_bf16_tn(const void* A, const void* B, const void
     p.a_bytes = (uint32_t)(M * (K / 2)); p.b_bytes = (uint32_t)(N * (K / 2));
     p.sfa_bytes = (uint32_t)(M * (K / 32)); p.sfb_bytes = (uint32_t)(N * (K / 32));   // row-major (rows, K/32), un-swizzled
     p.pp_shift = opt_pp_shift(); p.pp_flags = opt_pp_flags(); p.dbg = opt_dbg();
-    p.ws = nullptr; p.splits = 1;
+    p.ws = nullptr; p.splits = 1; p.ctr = nullptr; p.tag = 0;
     return launch_gemm<GemmCfg<64, 64, 2, 2, 4, false, 0, 3>, 8>(p, (hipStream_t)stream);
   }
   SkinnyParams q;
@@ -620,6 +674,7 @@ static int mxf8_nn_impl(const void* A, const void* B, const void* A_sf, const vo
     p.a_bytes = (uint32_t)(M * K); p.b_bytes = (uint32_t)(N * K);
     p.sfa_bytes = (uint32_t)(cdiv(M, 128) * CB * 512); p.sfb_bytes = (uint32_t)(cdiv(N, 128) * CB * 512);
     p.pp_shift = opt_pp_shift(); p.pp_flags = opt_pp_flags(); p.dbg = opt_dbg();
+    p.ws = nullptr; p.splits = 1; p.ctr = nullptr; p.tag = 0;
     if (a_fmt == 1) return launch_nn_fused_a5(p, (hipStream_t)stream);
     return launch_gemm<GemmCfg<256, 256, 2, 2, 8, true>, 6>(p, (hipStream_t)stream);
   }
@@ -847,6 +902,7 @@ int qutlass_amd_set_option(const char* key, int value) {
   if (!strcmp(key, "transpose_nc")) return g_transpose_nc.exchange(value);
   if (!strcmp(key, "splitk_wg")) return g_splitk_wg.exchange(value);
   if (!strcmp(key, "splitk_min_kt")) return g_splitk_min_kt.exchange(value);
+  if (!strcmp(key, "splitk_force")) return g_splitk_force.exchange(value);
   if (!strcmp(key, "quant_wg_per_cu")) return g_quant_wg_per_cu.exchange(value);
   if (!strcmp(key, "pp_shift")) return g_pp_shift.exchange(value);
   if (!strcmp(key, "pp_flags")) return g_pp_flags.exchange(value);

@@ -43,6 +43,9 @@
 // switch for experiments (tools: hipcc -DQAMD_DMA_AUX=2 ...)
 #ifndef QAMD_DMA_AUX
 #define QAMD_DMA_AUX 0
+#endif
+#ifndef QAMD_BENCH
+#define QAMD_BENCH 0   // 1: lab library (libqutlass_amd_bench.so) -- experimental code paths that lost their measurement stay compiled there
 #endif   // transpose4x4_u8 (fused NN operand path)
 
 namespace qamd {
@@ -63,6 +66,11 @@ struct GemmParams {
   uint32_t* dbg;         // ABL_TRACE builds only: per-wave timestamp dump of workgroup 0
   float* ws;             // split-K (ring schedule only): fp32 partial tiles, [splits][M][N]; NULL = no split
   int splits;            // grid.y; split z covers K stages [z * ceil(KT / splits), ...)
+  // fused split-K reduction (ctr != NULL): one 64-bit arrival slot per output tile, {launch tag : 56, count : 8}; the last
+  // split to arrive for a tile sums the partials and writes D.  tag = a per-launch number from the host, so slots need no
+  // initialisation (whatever the memory held counts as "0 arrivals" unless it carries this launch's 56-bit tag).
+  unsigned long long* ctr;
+  unsigned long long tag;    // (launch number & (2^56 - 1)) << 8
 };
 
 // ablation bits (bench-only instantiations; 0 in the product path)
@@ -424,6 +432,92 @@ struct GemmCtx {
         }
     }
   }
+
+#if QAMD_BENCH
+  // LAB ONLY.  Measured on MI355X (profiles/native_r2_splitk_fused.log): 1.5 - 2.7 us SLOWER than the two-launch form at
+  // M = 16 / 64 (10.8 / 13.6 vs 9.1 / 10.9 us at N = 4096, K = 14336) -- the reducing workgroup pays two memory round trips
+  // (write-through acknowledgements, then the read-back across XCDs) plus the slot update in series, which costs more than
+  // the ~3 us launch of a separate, fully parallel reduce kernel.  Kept selectable ("pp_flags" bit 9) so the number can be
+  // reproduced; the product library does not contain it.
+  // ---- split-K, ONE launch: every split stores its raw fp32 tile, the LAST split to arrive for the tile (arrival slot
+  //      p.ctr[tile]) sums all S partials in z order -- deterministic, whichever split arrives last -- applies alpha, rounds
+  //      to bf16 and writes D.  Cross-XCD visibility without cache flushes: the partials are stored write-through (sc0 sc1)
+  //      and read back with sc0 sc1 loads, i.e. both sides meet at the memory-side coherence point; the only ordering
+  //      needed is "my stores are acknowledged before I bump the slot" (s_waitcnt vmcnt(0) + workgroup barrier) -- the
+  //      slot itself is a device-scope compare-and-swap.  The slot is reset to 0 by the reducing workgroup, so a replayed
+  //      graph (same tag, same scratch) starts clean.
+  __device__ __forceinline__ void epilogue_splitk_fused(int z) {
+    const uint32_t plane = (uint32_t)p.M * (uint32_t)p.N * 4u;   // bytes of one partial matrix (< 2^28 by the host's tile limits)
+    const __amdgpu_buffer_rsrc_t rW = make_rsrc(p.ws, plane * (uint32_t)p.splits);
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      const int grow = m0 + wave_m * C::WTM + 32 * m + i32;
+#pragma unroll
+      for (int n = 0; n < NT; ++n)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int gcol = n0 + wave_n * C::WTN + 32 * n + 8 * q + 4 * g;
+          const v4f v = {acc[m][n][4 * q + 0], acc[m][n][4 * q + 1], acc[m][n][4 * q + 2], acc[m][n][4 * q + 3]};
+          const int off = (grow < p.M && gcol < p.N) ? (grow * p.N + gcol) * 4 : (int)0x80000000;
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, v), rW, off, (int)(plane * (uint32_t)z), 17);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's partial stores are acknowledged by the coherence point
+    __syncthreads();                                    // ... and every wave's (also: nobody reads the stage buffers any more)
+    if (tid == 0) {
+      unsigned long long* slot = p.ctr + blockIdx.x;
+      unsigned long long cur = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      int cnt;
+      for (;;) {
+        cnt = ((cur & ~0xffull) == p.tag) ? (int)(cur & 0xffull) : 0;
+        const unsigned long long want = p.tag | (unsigned long long)(cnt + 1);
+        if (__hip_atomic_compare_exchange_strong(slot, &cur, want, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+      }
+      *(volatile int*)smem = cnt + 1;
+    }
+    __syncthreads();
+    const int arrived = uniform(*(volatile int*)smem);
+    if (arrived != p.splits) return;
+    // ---- last arrival: D tile = bf16(alpha * sum_z partial[z]) ----------------------------------------------------------
+    const float alpha = *p.alpha;
+    constexpr int QPR = C::BN / 4;                 // float4 per tile row
+    constexpr int RPP = C::THREADS / QPR;          // rows per pass
+    constexpr int NPASS = C::BM / RPP;
+    constexpr int GP = NPASS < 4 ? NPASS : 4;      // passes whose loads are in flight together (GP x 8 float4 per thread)
+    const int c4 = (tid % QPR) * 4, r0 = tid / QPR;
+#pragma unroll 1
+    for (int pg = 0; pg < NPASS; pg += GP) {
+      v4u t[GP][8];
+#pragma unroll
+      for (int u = 0; u < GP; ++u) {
+        const int grow = m0 + (pg + u) * RPP + r0, gcol = n0 + c4;
+        const int off = (grow < p.M && gcol < p.N) ? (grow * p.N + gcol) * 4 : (int)0x80000000;
+#pragma unroll
+        for (int zz = 0; zz < 8; ++zz)
+          t[u][zz] = (zz < p.splits) ? __builtin_amdgcn_raw_buffer_load_b128(rW, off, (int)(plane * (uint32_t)zz), 17) : v4u{0u, 0u, 0u, 0u};
+      }
+#pragma unroll
+      for (int u = 0; u < GP; ++u) {
+        const int grow = m0 + (pg + u) * RPP + r0, gcol = n0 + c4;
+        v4f sum = __builtin_bit_cast(v4f, t[u][0]);
+#pragma unroll
+        for (int zz = 1; zz < 8; ++zz)
+          if (zz < p.splits) {
+            const v4f x = __builtin_bit_cast(v4f, t[u][zz]);
+            sum[0] += x[0]; sum[1] += x[1]; sum[2] += x[2]; sum[3] += x[3];
+          }
+        if (grow < p.M && gcol < p.N) {
+          v2i o;
+          o[0] = (int)pack_bf16x2(sum[0] * alpha, sum[1] * alpha);
+          o[1] = (int)pack_bf16x2(sum[2] * alpha, sum[3] * alpha);
+          *(v2i*)(p.D + (size_t)grow * p.ldd + gcol) = o;
+        }
+      }
+    }
+    if (tid == 0) __hip_atomic_store(p.ctr + blockIdx.x, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // leave the slot clean
+  }
+
+#endif   // QAMD_BENCH
 
   // ---- epilogue: alpha, bf16, stage through LDS, whole-line stores ---------------------------
   __device__ __forceinline__ void epilogue() {
@@ -1424,6 +1518,10 @@ __device__ __forceinline__ void gemm_mx_ring(char* smem, const GemmParams& p) {
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the trailing re-loads must land before the epilogue reuses the LDS
   cx.trace();
+#if QAMD_BENCH
+  if (p.splits > 1 && p.ctr) cx.epilogue_splitk_fused(blockIdx.y);
+  else
+#endif
   if (p.splits > 1) cx.epilogue_partial(blockIdx.y);
   else cx.epilogue();
   cx.trace();

@@ -124,6 +124,8 @@ Tensor matmul(const Tensor& A, const Tensor& B, const Tensor& A_sf, const Tensor
   }
   STD_TORCH_CHECK(B.size(1) >= kmin, "B K-dim must be >= ", kmin);
   const int64_t N = B.size(0), K = B.size(1) * (fp8 ? 1 : 2);
+  Tensor out = torch::stable::new_empty(A, {M, N}, ScalarType::BFloat16);
+  if (M == 0 || N == 0) return out;   // empty batch / empty weight: nothing to launch (the C ABI requires positive extents)
   // the kernels read alpha as one fp32 and the scale operands through descriptors sized from M / N / K: make sure the
   // tensors are at least that large (the reference leaves both to CUTLASS' can_implement / the caller)
   STD_TORCH_CHECK(has_dtype(alpha, ScalarType::Float) && alpha.numel() >= 1, "alpha must be a float32 tensor with at least one element");
@@ -136,8 +138,6 @@ Tensor matmul(const Tensor& A, const Tensor& B, const Tensor& A_sf, const Tensor
     STD_TORCH_CHECK(B_sf.numel() >= need_b, "B_sf has ", B_sf.numel(), " elements, the ", row_major_sf ? "row-major" : "blocked", " scale layout of B needs ", need_b);
   }
 
-  Tensor out = torch::stable::new_empty(A, {M, N}, ScalarType::BFloat16);
-  if (M == 0 || N == 0) return out;   // empty batch / empty weight: nothing to launch (the C ABI requires positive extents)
   const torch::stable::accelerator::DeviceGuard guard(A.get_device_index());
   const float* al = static_cast<const float*>(alpha.data_ptr());
   void* s = current_stream(A);

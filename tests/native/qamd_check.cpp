@@ -623,6 +623,61 @@ int main(int argc, char** argv) {
     for (int var : {90, 92, 94}) bench_gemm("mxfp4 4096x12288x4096 steady: store policy", 0, 4096, 12288, 4096, var, 0);
     g_gauss_fill = 0; g_warm_override = 0; g_iters_override = 0;
   }
+  if (want("splitk")) {   // fused split-K (one launch, last-arriving workgroup reduces) vs the two-launch form, and tile x split choices
+    // correctness first: ragged shapes, K tails, every ring tile with forced splits, against the oracle (bit-exact); both forms
+    for (int form : {1 | 512, 1})
+    for (int var : {70, 71, 72, 73}) {
+      qutlass_amd_set_option("pp_flags", form);
+      for (int S : {2, 3, 8}) {
+        qutlass_amd_set_option("splitk_force", S);
+        for (int kind : {0, 2}) {
+          const bool tol = kind == 2;
+          check_gemm("fused split-K 64x512x14336", kind, 64, 512, 14336, 0.5f, 3, 0, var, tol);
+          check_gemm("fused split-K 200x264x7168 (ragged)", kind, 200, 264, 7168, 1.0f, 3, 0, var, tol);
+          check_gemm("fused split-K 40x1032x4224 (K tail)", kind, 40, 1032, kind == 2 ? 4256 : 4224, 1.0f, 3, 0, var, tol);
+        }
+      }
+    }
+    qutlass_amd_set_option("splitk_force", 0);
+    qutlass_amd_set_option("pp_flags", 1 | 512);
+    check_gemm("fused split-K auto 64x4096x14336", 0, 64, 4096, 14336, 1.0f, 3, 16, 0);
+    check_gemm("fused split-K auto 16x4096x14336", 0, 16, 4096, 14336, 1.0f, 3, 0, 0);
+    // repeated launches into the same scratch (slots must come back clean): run the check twice more
+    check_gemm("fused split-K auto 128x4096x14336 (rerun 1)", 0, 128, 4096, 14336, 1.0f, 3, 16, 0);
+    check_gemm("fused split-K auto 128x4096x14336 (rerun 2)", 0, 128, 4096, 14336, 1.0f, 3, 16, 0);
+    qutlass_amd_set_option("pp_flags", 1);
+    g_gauss_fill = 1;
+    const int64_t shapes[][2] = {{4096, 14336}, {8192, 8192}, {4096, 8192}, {14336, 4096}};
+    for (auto& sh : shapes)
+      for (int64_t M : {16, 64, 128, 256, 512, 1024}) {
+        char tag[128];
+        qutlass_amd_set_option("pp_flags", 1 | 512);
+        snprintf(tag, sizeof tag, "auto fused (lab)      M=%lld N=%lld K=%lld", (long long)M, (long long)sh[0], (long long)sh[1]);
+        bench_gemm(tag, 0, M, sh[0], sh[1], 0, 200);
+        qutlass_amd_set_option("pp_flags", 1);
+        snprintf(tag, sizeof tag, "auto two-launch       M=%lld N=%lld K=%lld", (long long)M, (long long)sh[0], (long long)sh[1]);
+        bench_gemm(tag, 0, M, sh[0], sh[1], 0, 200);
+        for (int var : {74, 75}) {   // 64x64 ring with 4 / 6 stages (3 / 5 in flight)
+          snprintf(tag, sizeof tag, "64x64 ring depth %d    M=%lld N=%lld K=%lld", var == 74 ? 4 : 6, (long long)M, (long long)sh[0], (long long)sh[1]);
+          if (((M + 63) / 64) * ((sh[0] + 63) / 64) <= 512) bench_gemm(tag, 0, M, sh[0], sh[1], var, 200);
+        }
+        qutlass_amd_set_option("pp_flags", 1 | 512);   // the forced tile x split rows below use the fused form
+        for (int var : {70, 71, 72, 73}) {
+          int bm = (var == 71 || var == 73) ? 128 : 64, bn = (var == 72 || var == 73) ? 128 : 64;
+          const int64_t tiles = ((M + bm - 1) / bm) * ((sh[0] + bn - 1) / bn);
+          if (tiles > 256) continue;
+          for (int S : {1, 2, 4, 8}) {
+            if (tiles * S > 256 || (S > 1 && sh[1] / 256 / S < 4)) continue;
+            qutlass_amd_set_option("splitk_force", S);
+            snprintf(tag, sizeof tag, "forced tile %dx%d S=%d  M=%lld N=%lld K=%lld", bm, bn, S, (long long)M, (long long)sh[0], (long long)sh[1]);
+            bench_gemm(tag, 0, M, sh[0], sh[1], var, 200);
+          }
+          qutlass_amd_set_option("splitk_force", 0);
+        }
+        qutlass_amd_set_option("pp_flags", 1);
+      }
+    g_gauss_fill = 0;
+  }
   if (want("deeppbench")) {
     g_gauss_fill = 1;
     g_warm_override = 2500; g_iters_override = 2500;

@@ -89,17 +89,20 @@ def test_split_k_workspace_plan_is_a_pure_host_function(lib):
         s = min(8, 256 // t, kt // 8)
         return -(-kt // -(-kt // s)) if s >= 2 else 0
 
+    def layout(m, n, s):   # [s][m][n] fp32 partials
+        return s * m * n * 4
+
     # Llama-3-8B down-proj, batch 64: 64 tiles, KT = 56 stages -> 4 splits of 14 stages (one workgroup per CU)
-    assert splits(4, 64, 4096, 14336) == 4 and ws(4, 64, 4096, 14336) == 4 * 64 * 4096 * 4
-    assert ws(4, 16, 4096, 14336) == splits(4, 16, 4096, 14336) * 16 * 4096 * 4
-    assert ws(4, 128, 4096, 14336) == 2 * 128 * 4096 * 4   # 128 tiles: 2 splits
+    assert splits(4, 64, 4096, 14336) == 4 and ws(4, 64, 4096, 14336) == layout(64, 4096, 4) == 4 * 64 * 4096 * 4
+    assert ws(4, 16, 4096, 14336) == layout(16, 4096, splits(4, 16, 4096, 14336))
+    assert ws(4, 128, 4096, 14336) == layout(128, 4096, 2)   # 128 tiles: 2 splits
     assert ws(4, 256, 4096, 14336) == 0 and ws(4, 192, 4096, 14336) == 0   # more than 128 tiles: no split
-    assert ws(4, 64, 4096, 4096) == 0            # 16 stages: too short to pay for the second pass
-    assert ws(4, 64, 4096, 8192) == 4 * 64 * 4096 * 4 and ws(8, 64, 4096, 4096) == 4 * 64 * 4096 * 4   # 32 stages (fp8: K = 4096)
+    assert ws(4, 64, 4096, 4096) == 0            # 16 stages: too short to pay for the reduction
+    assert ws(4, 64, 4096, 8192) == layout(64, 4096, 4) and ws(8, 64, 4096, 4096) == layout(64, 4096, 4)   # 32 stages (fp8: K = 4096)
     assert ws(4, 4096, 4096, 4096) == 0 and ws(4, 0, 4096, 4096) == 0 and ws(5, 64, 4096, 14336) == 0
     for m, n, k in [(8, 512, 28672), (40, 1032, 14464), (128, 2048, 57344), (1, 64, 12288)]:
         b = ws(4, m, n, k)
-        assert b == splits(4, m, n, k) * m * n * 4 and 2 <= b // (m * n * 4) <= 8, (m, n, k, b)
+        assert b == layout(m, n, splits(4, m, n, k)) and 2 <= splits(4, m, n, k) <= 8, (m, n, k, b)
     dummy = ctypes.c_void_p(0x1000)
     g = lib.qutlass_amd_matmul_mxf4_bf16_tn_ws
     assert g(dummy, dummy, dummy, dummy, dummy, dummy, 128, 128, 96, None, 0, None) == QAMD_ERR_INVALID
