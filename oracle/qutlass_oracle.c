@@ -312,6 +312,7 @@ void orc_fused_quantize_nv(const uint16_t* x, const uint16_t* h, int R, int64_t 
         float r16 = 1.0f / 16.0f;
         float mean = s1 * r16;
         float var = fmaf(-mean, mean, s2 * r16);
+        if (var < 0.f) var = 0.f; /* fp32 rounding on a constant group: the reference propagates NaN here; clamped */
         float scale = (float)((double)sqrtf(var) * (2.92247856 / 6.) + 1e-8);
         sfb = orc_e4m3_encode(scale);
         float sq = orc_e4m3_decode(sfb);

@@ -308,7 +308,10 @@ __global__ __launch_bounds__(256) void fused_quantize_kernel(const QuantParams p
             s1 = xhalf_add(s1);
             s2 = xhalf_add(s2);
             const float mean = s1 * 0.0625f;
-            const float var = fmaf(-mean, mean, s2 * 0.0625f);
+            // var < 0 can only come from fp32 rounding on a (nearly) constant group; the reference takes sqrt of it and
+            // carries a NaN scale (epilogue_quant.h:1631-1680 has no guard).  Clamped here, as the MX path does: the group
+            // quantises to scale 0 / zero codes instead of a NaN scale byte.  (Deviation noted in DESIGN.md section 4.)
+            const float var = fmaxf(fmaf(-mean, mean, s2 * 0.0625f), 0.f);
             const float sc = (float)((double)sqrtf(var) * (2.92247856 / 6.) + 1e-8);
             sfb = e4m3_encode_pos(sc);
             const float sq = e4m3_decode_pos(sfb);

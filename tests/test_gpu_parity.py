@@ -363,10 +363,10 @@ def test_fused_quantize_nv_and_gemm_vs_oracle(q, rot):
     rq, rs = oracle.fused_quantize_nv(_np(a), _np(h), 6.0, oracle.ABS_MAX, acc_model=1)
     got_s = _np(a_s).reshape(-1)[: rs.size]
     sbad = int((got_s != rs).sum())
-    assert sbad <= 1e-3 * rs.size, sbad   # rcp / MFMA-order differences only (reference bound: 1e-1)
+    assert sbad <= 2e-4 * rs.size, sbad   # rcp / MFMA-order differences only (reference bound: 1e-1)
     same = (got_s == rs).repeat(16)
     eq = oracle.codes_equal_mod_zero_sign(_np(a_q), rq)
-    assert int((~eq & same).sum()) <= 1e-3 * eq.size
+    assert int((~eq & same).sum()) <= 2e-4 * eq.size
     out = q.matmul_nvf4_bf16_tn(a_q, b_q, to_blocked(a_s), to_blocked(b_s), torch.tensor([1.0], device=DEV))
     ref = oracle.gemm_blockscaled(oracle.KIND_NVFP4, _np(a_q), _np(b_q), oracle.to_blocked(_np(a_s)[:, : k // 16]),
                                   oracle.to_blocked(_np(b_s)[:, : k // 16]), 1.0, m, n, k)
@@ -536,7 +536,7 @@ def test_matmul_mxf8_nn_equals_tn_and_oracle(q, golden_dir, m, n, k):
 # ------------------------------------------------------------------------------------------------
 # QAT-backward data-prep ops (reference tests/quartet_test.py:239-260, 368-384)
 # ------------------------------------------------------------------------------------------------
-def _codes_close(got, want, frac=2e-3):
+def _codes_close(got, want, frac=1e-4):   # observed: 0 mismatching codes against the fp64 goldens and against the fp32 oracle
     eq = oracle.codes_equal_mod_zero_sign(got.reshape(want.shape), want)
     return int((~eq).sum()) <= frac * eq.size, int((~eq).sum())
 

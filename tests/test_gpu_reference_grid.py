@@ -2,9 +2,14 @@
 tests/mxfp8_test.py:98-130): LLaMA 7B / 13B / 33B / 70B layer shapes x batch {1, 16} x every rotation size, quantise both
 operands with the fused quantizer, swizzle the scales, multiply, and require what the reference requires --
 `out.equal(out_ref)` for MXFP4 / NVFP4 against the fp64 dequantise-matmul of the SAME packed operands, assert_close
-(1e-1) for MXFP8 TN and NN.  The fp64 reference here is plain torch on the GPU (test-side restatement, no product code)."""
+(1e-1) for MXFP8 TN and NN.  Two references per case: (i) the fp64 dequantise-matmul in plain torch on the GPU over the WHOLE
+output (a test-side restatement, pinned to nothing by itself) and (ii) the pinned CPU oracle (oracle/, golden-vector checked)
+on 192 sampled output columns -- so every case of the grid carries the pinned-oracle guarantee."""
+import numpy as np
 import pytest
 import torch
+
+import oracle  # the checker
 
 pytestmark = pytest.mark.gpu
 DEV = torch.device("cuda", 0)
@@ -46,6 +51,22 @@ def _dequant_fp64(codes, scales, rows, group):
     return (vals.reshape(rows, -1, group) * s[:, : vals.shape[1] // group, None]).reshape(rows, -1)
 
 
+def _np(t):
+    t = t.detach().cpu().contiguous()
+    return t.view(torch.uint16).numpy() if t.dtype == torch.bfloat16 else (t.view(torch.uint8).numpy() if t.element_size() == 1 else t.numpy())
+
+
+def _oracle_columns(kind, a_q, a_s, b_q, b_s, out, m, n, k, group, seed):
+    """oracle.gemm_blockscaled on all rows of A x 192 sampled rows of B (= output columns), bit-exact against `out`."""
+    cols = sorted({0, 1, n // 2, n - 2, n - 1} | set(np.random.default_rng(seed).integers(0, n, 187).tolist()))
+    ci = torch.tensor(cols, device=out.device)
+    rm = lambda s_, rows: _np(s_).reshape(-1)[: rows * (k // group)].reshape(rows, k // group)
+    ref = oracle.gemm_blockscaled(kind, _np(a_q), _np(b_q[ci]), oracle.to_blocked(rm(a_s, m)), oracle.to_blocked(np.ascontiguousarray(rm(b_s, n)[cols])),
+                                  1.0, m, len(cols), k)
+    got = _np(out[:, ci])
+    assert np.array_equal(got, ref), f"{int((got != ref).sum())} of {got.size} sampled outputs differ from the pinned oracle"
+
+
 _weights = {}
 
 
@@ -77,6 +98,7 @@ def test_mxfp4_llama_shapes_exact(q, model, layer_idx, had_size):
         ref = (_dequant_fp64(a_q, a_s, m, 32) @ b_dq.T).to(torch.bfloat16)
         out = q.matmul_mxf4_bf16_tn(a_q, b_q, to_blocked(a_s), b_sf, alpha)
         assert out.equal(ref), (model, layer_idx, m, had_size, int((out != ref).sum()))
+        _oracle_columns(oracle.KIND_MXFP4, a_q, a_s, b_q, b_s, out, m, n, k, 32, layer_idx * 7 + m)
         out2 = q.matmul_ada_mxf4_bf16_tn(a_q, b_q, a_s[:m].contiguous(), b_s[:n].contiguous(), alpha)
         assert out2.equal(ref), ("ada", model, layer_idx, m, had_size)
 
@@ -102,6 +124,7 @@ def test_nvfp4_llama_shapes_exact(q, model, layer_idx, rot_size):
         ref = (_dequant_fp64(a_q, a_s, m, 16) @ b_dq.T).to(torch.bfloat16)
         out = q.matmul_nvf4_bf16_tn(a_q, b_q, to_blocked(a_s), b_sf, alpha)
         assert out.equal(ref), (model, layer_idx, m, rot_size, int((out != ref).sum()))
+        _oracle_columns(oracle.KIND_NVFP4, a_q, a_s, b_q, b_s, out, m, n, k, 16, layer_idx * 7 + m)
 
 
 def _pseudoquant_mxfp8(x):
@@ -141,6 +164,14 @@ def test_mxfp8_llama_shapes_tn_nn_close(q, model, layer_idx):
     torch.testing.assert_close(out_nn, ref, atol=1e-1, rtol=1e-1)
     # (TN may take the split-K path for these small outputs, NN never does: same values up to fp32 summation order)
     torch.testing.assert_close(out_nn, out, atol=0.0, rtol=2.0 ** -7)
+    # pinned oracle on 192 sampled columns, 1 bf16 ulp + 2e-5 max|ref| (fp32 accumulation of 8-bit-significand products)
+    cols = sorted({0, n - 1} | set(np.random.default_rng(layer_idx).integers(0, n, 190).tolist()))
+    ci = torch.tensor(cols, device=DEV)
+    oref = oracle.gemm_blockscaled(oracle.KIND_MXFP8_TN, _np(a8), _np(b8[ci]), oracle.to_blocked(_np(a_s)), oracle.to_blocked(_np(b_s[ci])), 1.0, m, len(cols), k)
+    want = oracle.bf16_bits_to_f32(oref).astype(np.float64)
+    for o in (out, out_nn):
+        got = oracle.bf16_bits_to_f32(_np(o[:, ci])).astype(np.float64)
+        assert (np.abs(got - want) <= np.abs(want) / 128.0 + 2e-5 * np.abs(want).max()).all()
 
 
 def test_quartet_forward_gemm_exact(q):
