@@ -12,7 +12,7 @@
  *   - return value: 0 = launched; QAMD_ERR_INVALID = argument rejected (nothing launched);
  *     QAMD_ERR_HIP = the HIP runtime refused the launch.  qutlass_amd_last_error() returns a
  *     thread-local message for the last non-zero return.
- *   - no global state besides the tuning options below; re-entrant; the library never allocates
+ *   - no global state besides the one verification switch at the end of this file; re-entrant; the library never allocates
  *     (the reference cudaMalloc's a CUTLASS workspace per call, gemm.cu:160-162); ops that use
  *     scratch (mxf8 NN pre-pass, split-K of the *_ws GEMMs) take it from the caller.
  */
@@ -205,16 +205,14 @@ const char* qutlass_amd_last_error(void);
 const char* qutlass_amd_version(void);
 
 /*
- * Tuning / verification switches (process-wide, default in parentheses):
- *   "hw_fp4_cvt"   (1) use v_cvt_scalef32_pk_fp4_f32 for the final e2m1 rounding; 0 = software encoder
- *                  (both are bit-identical on gfx950)
- *   "gemm_variant" (0 = auto) force a tile configuration / schedule of the MX GEMMs (bench sweeps)
- *   "nvf4_variant" (0 = auto) 1 = per-wave dequant kernel, 2 = dequantise-once-into-LDS kernel, 3 = small-batch split-K,
- *                  5 / 6 / 7 = 128x128 / 128x64 / 64x64 tiles
- *   "pp_flags"     (1) bit field of schedule experiments; bit 6 = no tail split, bit 7 = no split-K, bit 8 = no ring rule
- *   "transpose_nc" (128) n columns per workgroup of mxfp4_transpose_mxfp8 (128 or 256)
- *   "quant_wg_per_cu" (0 = auto) grid cap of the fused quantizers
- * Returns the previous value, or -1 for an unknown key.
+ * The one verification switch of the library (process-wide):
+ *   "hw_fp4_cvt"   (default 1) use v_cvt_scalef32_pk_fp4_f32 for the final e2m1 rounding; 0 = software encoder.  Both
+ *                  produce the same bits on gfx950 (tests/test_gpu_parity.py runs every quantizer test
+ *                  under both values).
+ * Returns the previous value, or -1 for an unknown key.  libqutlass_amd.so knows no other key: nothing a caller or another
+ * thread does can change which kernel a shape gets.  (The lab build of the same sources, libqutlass_amd_bench.so -- test and
+ * bench infrastructure, see INTEGRATION.md -- additionally accepts "gemm_variant", "nvf4_variant", "pp_flags",
+ * "splitk_wg", "splitk_min_kt", "splitk_force", "transpose_nc", "quant_wg_per_cu", "pp_shift".)
  */
 int qutlass_amd_set_option(const char* key, int value);
 

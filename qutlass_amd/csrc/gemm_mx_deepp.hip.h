@@ -26,13 +26,19 @@ namespace qamd {
 template <class C>
 struct DeepPCfg {
   static constexpr int STAGE = C::STAGE_BYTES;
-  static constexpr int OFF_SCR = 2 * C::STAGE_BYTES;          // wave-private epilogue scratch: 4 KiB per wave
-  static constexpr int LDS_BYTES = OFF_SCR + C::NWAVES * 4096;
+  // Epilogue scratch: none of its own.  In the last K stage of a tile, after the hand-off barrier nobody reads buffer 1 any
+  // more and the only writer of rows [64 w, 64 w + 64) of its A area -- 8 KiB -- is wave w itself (its own LDS-DMA pieces of
+  // the next tile's stage 1).  Wave w uses that slice as its private scratch and issues those 8 pieces when it is done.
+  static constexpr int OFF_SCR = C::STAGE_BYTES;              // buffer 1, A area
+  static constexpr int SCR_PER_WAVE = 8192;
+  static constexpr int LDS_BYTES = 2 * C::STAGE_BYTES;
+  static_assert(C::NA * 1024 == SCR_PER_WAVE, "a wave's A pieces of one stage are its scratch");
   static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
 };
 
-// post-hand-off MFMA index at which accumulator tile T of the last stage is final: e(T) = 1, 3, 4T - 1; inverse (-1: none)
-constexpr int deepp_tile_done_at(int s) { return s == 1 ? 0 : s == 3 ? 1 : (s >= 7 && s <= 59 && (s + 1) % 4 == 0) ? (s + 1) / 4 : -1; }
+// post-hand-off MFMA index at which accumulator-tile PAIR P (tiles 2P, 2P + 1 in (m, n) row-major order) of the last stage is
+// final: e(P) = 8 P + 3; inverse (-1: none)
+constexpr int deepp_pair_done_at(int s) { return (s >= 3 && s <= 59 && (s - 3) % 8 == 0) ? (s - 3) / 8 : -1; }
 
 template <int I, int N, class F>
 __device__ __forceinline__ void static_for(F&& f) {
@@ -211,11 +217,15 @@ __device__ __forceinline__ void gemm_mx_deepp(char* smem, const GemmParams& p) {
     if constexpr (FIRST) pin_acc();
   };
 
-  // ---- epilogue pieces: one retired 32x32 accumulator tile through the wave-private scratch -----------------------------
-  char* scr = smem + OFF_SCR + wave * 4096;
-  const int scrW = i32 * 128 + ((((i32 & 6) << 4)) | ((g ^ (i32 & 1)) << 4));   // chunk (2q + g) ^ (row & 7) = this ^ (q << 5)
-  const int rrl = lane >> 2, ccl = lane & 3;                                     // read-back: row rrl (+16 per pass), columns 8 ccl .. +7
-  const int scrR = rrl * 128 + (((2 * ccl) ^ (rrl & 7)) << 4);                   // chunk 2 ccl of that row; chunk 2 ccl + 1 = this ^ 16
+  // ---- epilogue pieces: a retired PAIR of accumulator tiles (m, 2h), (m, 2h + 1) = 32 rows x 64 columns through the
+  //      wave-private scratch (fp32, 32 rows x 256 B; 16-byte chunk c = 8 n' + 2 q + g of row r stored at chunk
+  //      (c & 8) | ((c & 7) ^ (r & 7)): the 8 lanes of a ds_write_b128 group hit 8 different chunks, the 16 lanes of a
+  //      ds_read_b128 group 16 different ones).  Read-back is row-major: lane -> row 8 p + l / 8, columns 8 (l % 8) .. + 7, so
+  //      8 lanes cover one whole 128-byte line of D and a wave instruction stores 8 rows x 128 B.
+  char* scr = smem + OFF_SCR + wave * DeepPCfg<C>::SCR_PER_WAVE;
+  const int scrW = i32 * 256 + ((((i32 & 6) << 4)) | ((g ^ (i32 & 1)) << 4));   // chunk (2q + g) ^ (row & 7) = this ^ (q << 5); + 128 n'
+  const int rrl = lane >> 3, ccl = lane & 7;                                     // read-back: row rrl (+ 8 per pass), columns 8 ccl .. + 7
+  const int scrR = rrl * 256 + (ccl >> 2) * 128 + ((((2 * ccl) & 7) ^ (rrl & 7)) << 4);   // chunk 2 ccl of that row; chunk 2 ccl + 1 = this ^ 16
   const float alpha = *p.alpha;
   __amdgpu_buffer_rsrc_t rD = make_rsrc(p.D, 0);
   int stLane = 0, colLim = 0;
@@ -226,38 +236,43 @@ __device__ __forceinline__ void gemm_mx_deepp(char* smem, const GemmParams& p) {
     const int64_t left = ((int64_t)(p.M - m0) * p.ldd - n0) * 2;
     rD = make_rsrc(p.D + ((int64_t)m0 * p.ldd + n0), (uint32_t)(left > 0x7fffffffll ? 0x7fffffffll : left));
     stLane = ((cx.wave_m * C::WTM + rrl) * p.ldd + cx.wave_n * C::WTN + 8 * ccl) * 2;
-    colLim = p.N - n0 - cx.wave_n * C::WTN - 8 * ccl;   // column 32 n + 8 ccl of the wave tile exists iff 32 n < colLim
+    colLim = p.N - n0 - cx.wave_n * C::WTN - 8 * ccl;   // column 64 h + 8 ccl of the wave tile exists iff 64 h < colLim
   };
-  auto retire_write = [&](const int m, const int n) __attribute__((always_inline)) {
+  auto retire_write = [&](const int m, const int h) __attribute__((always_inline)) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q)
-      *(v4f*)(scr + (scrW ^ (q << 5))) = v4f{acc[m][n][4 * q + 0], acc[m][n][4 * q + 1], acc[m][n][4 * q + 2], acc[m][n][4 * q + 3]};
+    for (int nn = 0; nn < 2; ++nn)
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        *(v4f*)(scr + (scrW ^ (q << 5)) + nn * 128) =
+            v4f{acc[m][2 * h + nn][4 * q + 0], acc[m][2 * h + nn][4 * q + 1], acc[m][2 * h + nn][4 * q + 2], acc[m][2 * h + nn][4 * q + 3]};
   };
   v4f rb[2][2];
-  auto retire_read = [&]() __attribute__((always_inline)) {
+  auto retire_read = [&](const int half) __attribute__((always_inline)) {   // rows 16 half .. + 15: passes 2 half, 2 half + 1
 #pragma unroll
     for (int ps = 0; ps < 2; ++ps) {
-      rb[ps][0] = *(const v4f*)(scr + scrR + ps * 2048);
-      rb[ps][1] = *(const v4f*)(scr + (scrR ^ 16) + ps * 2048);
+      rb[ps][0] = *(const v4f*)(scr + scrR + (2 * half + ps) * 2048);
+      rb[ps][1] = *(const v4f*)(scr + (scrR ^ 16) + (2 * half + ps) * 2048);
     }
   };
-  auto retire_store = [&](const int m, const int n, const int ps) __attribute__((always_inline)) {
-    const v4f lo = rb[ps][0], hi = rb[ps][1];
+  auto retire_store = [&](const int m, const int h, const int pass) __attribute__((always_inline)) {
+    const v4f lo = rb[pass & 1][0], hi = rb[pass & 1][1];
     v4i o;
     o[0] = (int)pack_bf16x2(lo[0] * alpha, lo[1] * alpha);
     o[1] = (int)pack_bf16x2(lo[2] * alpha, lo[3] * alpha);
     o[2] = (int)pack_bf16x2(hi[0] * alpha, hi[1] * alpha);
     o[3] = (int)pack_bf16x2(hi[2] * alpha, hi[3] * alpha);
-    const int off = stLane + ((32 * m + 16 * ps) * p.ldd + 32 * n) * 2;
-    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, o), rD, (32 * n < colLim) ? off : (int)0x80000000, 0, ST_AUX);
+    const int off = stLane + ((32 * m + 8 * pass) * p.ldd + 64 * h) * 2;
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, o), rD, (64 * h < colLim) ? off : (int)0x80000000, 0, ST_AUX);
   };
 
   // ---- the LAST stage of a tile (buffer 1), accumulator-stationary, with the tile's epilogue, the DMA of the next tile's
   //      stage 1 (d) and the fragment / scale reads of the next tile's stage 0 (buffer 0, scale set 0) threaded through.
   // MFMA sequence after the hand-off: tiles T = 0..15 in (m, n) row-major order, T0 and T1 with slices 2, 3 only (their
-  // slices 0, 1 ran before the hand-off to cover the latency of R(2), R(3)), every later tile with slices 0..3.  Tile T is
-  // final after post-hand-off MFMA e(T) = 1, 3, 4T - 1; its retirement is four items in the shadows of later MFMAs:
-  //   write (slot e+1)   read-back (e+4)   convert + store rows 0-15 (e+6)   rows 16-31 (e+7)        (tile 0: 2, 3, 5, 6)
+  // slices 0, 1 ran before the hand-off to cover the latency of R(2), R(3)), every later tile with slices 0..3.  Pair
+  // P = 0..7 (tiles 2P, 2P + 1) is final after post-hand-off MFMA e = 8 P + 3; its retirement in the shadows of later MFMAs:
+  //   write e+1 | read rows 0-15 e+3 | stores e+5, e+6 | read rows 16-31 e+7 | stores e+9, e+10
+  // One scratch and one read-back register set per wave: write(P + 1) at e + 9 follows read(P) at e + 7, read(P + 1) at
+  // e + 11 follows the last store of P at e + 10 (within a slot: stores, then write, then read).
   auto final_stage = [&](const Desc& d, bool dvalid) __attribute__((always_inline)) {
     read_slice(1, 2);
     read_slice(1, 3);
@@ -269,34 +284,37 @@ __device__ __forceinline__ void gemm_mx_deepp(char* smem, const GemmParams& p) {
     fence();
     dma_prep(1, dvalid);
     fence();
-    static_for<0, 68>([&](auto sc) __attribute__((always_inline)) {
+    static_for<0, 71>([&](auto sc) __attribute__((always_inline)) {
       constexpr int s = decltype(sc)::value;
       if constexpr (s < 60) {
         constexpr int T = s < 2 ? 0 : s < 4 ? 1 : 2 + (s - 4) / 4;
         constexpr int j = s < 4 ? 2 + (s & 1) : (s - 4) % 4;
         mfma1(j, 1, T / 4, T % 4, false);
       }
-      // DMA of the next tile's stage 1 into buffer 1: one instruction every third slot
-      if constexpr (s % 3 == 0 && s / 3 < 17) dma_item(d, 1, 1, s / 3);
+      // DMA of the next tile's stage 1 into buffer 1: the B pieces and the scale piece now, one instruction every third
+      // slot; the wave's 8 A pieces land in its own scratch area, so they wait until the last read-back (after the loop)
+      if constexpr (s % 3 == 0 && s / 3 < 9) dma_item(d, 1, 1, 8 + s / 3);
       if constexpr (s == 1) read_scales(0, 0);
       // fragments of the next tile's stage 0, as their registers die: A rows of m after tile (m, 3), B rows of n after (3, n)
       if constexpr (s == 12 || s == 28 || s == 44) { read_fa(0, 0, (s - 12) / 16); read_fa(0, 1, (s - 12) / 16); }
       if constexpr (s == 48 || s == 52 || s == 56) { read_fb(0, 0, (s - 48) / 4); read_fb(0, 1, (s - 48) / 4); }
       if constexpr (s == 60) { read_fa(0, 0, 3); read_fa(0, 1, 3); read_fb(0, 0, 3); read_fb(0, 1, 3); }
-      // retirement items due in this slot.  One scratch tile and one read-back register set per wave, so for consecutive
-      // tiles Ta, Tb: write(Tb) after read(Ta), read(Tb) after the last store of Ta.  Tile 0 (final at e = 1):
-      // write 2, read 3, stores 5, 6.  Tile T >= 1 (final at e): write e + 1, read e + 4, stores e + 6, e + 7 -- with
-      // e(T + 1) = e(T) + 4 every constraint holds with one slot to spare (stores first: they use the previous read-back).
-      constexpr int Tw = deepp_tile_done_at(s - 1);
-      constexpr int Tr = s == 3 ? 0 : (deepp_tile_done_at(s - 4) >= 1 ? deepp_tile_done_at(s - 4) : -1);
-      constexpr int Ts0 = s == 5 ? 0 : (deepp_tile_done_at(s - 6) >= 1 ? deepp_tile_done_at(s - 6) : -1);
-      constexpr int Ts1 = s == 6 ? 0 : (deepp_tile_done_at(s - 7) >= 1 ? deepp_tile_done_at(s - 7) : -1);
-      if constexpr (Ts0 >= 0) retire_store(Ts0 / 4, Ts0 % 4, 0);
-      if constexpr (Ts1 >= 0) retire_store(Ts1 / 4, Ts1 % 4, 1);
-      if constexpr (Tw >= 0) retire_write(Tw / 4, Tw % 4);
-      if constexpr (Tr >= 0) retire_read();
+      // retirement items due in this slot (pair P final at e = 8 P + 3)
+      constexpr int d1 = s - 1, d3 = s - 3, d5 = s - 5, d6 = s - 6, d7 = s - 7, d9 = s - 9, d10 = s - 10;
+      if constexpr (deepp_pair_done_at(d5) >= 0) retire_store(deepp_pair_done_at(d5) / 2, deepp_pair_done_at(d5) % 2, 0);
+      if constexpr (deepp_pair_done_at(d6) >= 0) retire_store(deepp_pair_done_at(d6) / 2, deepp_pair_done_at(d6) % 2, 1);
+      if constexpr (deepp_pair_done_at(d9) >= 0) retire_store(deepp_pair_done_at(d9) / 2, deepp_pair_done_at(d9) % 2, 2);
+      if constexpr (deepp_pair_done_at(d10) >= 0) retire_store(deepp_pair_done_at(d10) / 2, deepp_pair_done_at(d10) % 2, 3);
+      if constexpr (deepp_pair_done_at(d1) >= 0) retire_write(deepp_pair_done_at(d1) / 2, deepp_pair_done_at(d1) % 2);
+      if constexpr (deepp_pair_done_at(d3) >= 0) retire_read(0);
+      if constexpr (deepp_pair_done_at(d7) >= 0) retire_read(1);
       fence();
     });
+    // the wave's own A pieces of the next tile's stage 1 overwrite its scratch: its read-backs must have returned first
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int i = 0; i < 8; ++i) dma_item(d, 1, 1, i);
+    fence();
   };
 
   // ---- prologue: first tile's stages 0 and 1 in flight; stage 0 landed -> first two slices into registers ---------------
