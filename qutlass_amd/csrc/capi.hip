@@ -143,9 +143,19 @@ int launch_gemm_deepp(GemmParams p, hipStream_t s) {
   return check_launch("gemm_mx_deepp_kernel");
 }
 
+template <class C>
+int launch_gemm_deepp8(GemmParams p, hipStream_t s) {   // the fp8 twin (gemm_mx_deepp8), write-through output stores
+  p.tiles_m = (int)cdiv(p.M, C::BM);
+  p.tiles_n = (int)cdiv(p.N, C::BN);
+  p.ws = nullptr; p.splits = 1; p.ctr = nullptr; p.tag = 0;
+  const int grid = std::min(p.tiles_m * p.tiles_n, 256);
+  hipLaunchKernelGGL((gemm_mx_deepp8_kernel<C, 17>), dim3(grid), dim3(C::THREADS), 0, s, p);
+  return check_launch("gemm_mx_deepp8_kernel");
+}
+
 // Tile/schedule variants (0 = auto; the lab library can force one through the "gemm_variant" option):
 //   PRODUCT (what the auto rules below can pick):
-//     90  persistent deep schedule, fp4, 256x256      30  deep schedule, fp8, 256x256 (lab: also fp4, the per-tile predecessor of 90)
+//     90  persistent deep schedule, 256x256 (fp4: gemm_mx_deepp, fp8: gemm_mx_deepp8)      lab: 30 = the per-tile deep schedule of round 1
 //     24 / 25 / 27 / 28 / 29  simple schedule 128x128, 256x128, 128x64, 64x128, 64x64
 //     70..73  ring schedule 64x64, 128x64, 64x128, 128x128 (+ split-K)          60  skinny split-K kernel (fp4, M <= 32)
 //   LAB only:
@@ -224,7 +234,10 @@ int dispatch_variant(int v, const GemmParams& p, hipStream_t s, const char* name
 #endif
   }
   if constexpr (EBITS == 8) {
-    if (v == 30) return launch_gemm<GemmCfg<256, 256, 2, 2, 8, true>, 4>(p, s);   // fp8 deep schedule
+    if (v == 90) return launch_gemm_deepp8<GemmCfg<256, 256, 2, 2, 8, true>>(p, s);   // persistent deep schedule, fp8
+#if QAMD_BENCH
+    if (v == 30) return launch_gemm<GemmCfg<256, 256, 2, 2, 8, true>, 4>(p, s);   // per-tile deep schedule (round 1)
+#endif
   }
   if constexpr (EBITS == 4) {
     // persistent deep schedule; output stores write through (sc0 sc1): nothing dirty is left for the end-of-kernel L2
@@ -287,7 +300,7 @@ int dispatch_variant_a5(int v, const GemmParams& p, hipStream_t s, const char* n
     case 27: return launch_gemm<GemmCfg<128, 64, 2, 2, 8, true, 0, 2, 1>, 3>(p, s);
     case 28: return launch_gemm<GemmCfg<64, 128, 2, 2, 8, true, 0, 2, 1>, 3>(p, s);
     case 29: return launch_gemm<GemmCfg<64, 64, 2, 2, 8, true, 0, 2, 1>, 3>(p, s);
-    case 30: return launch_gemm<GemmCfg<256, 256, 2, 2, 8, true, 0, 2, 1>, 4>(p, s);
+    case 90: return launch_gemm_deepp8<GemmCfg<256, 256, 2, 2, 8, true, 0, 2, 1>>(p, s);
     case 70: return launch_gemm<GemmCfg<64, 64, 2, 2, 8, true, 0, 3, 1>, 7>(p, s);
     case 71: return launch_gemm<GemmCfg<128, 64, 2, 2, 8, true, 0, 3, 1>, 7>(p, s);
     case 72: return launch_gemm<GemmCfg<64, 128, 2, 2, 8, true, 0, 3, 1>, 7>(p, s);
@@ -474,9 +487,9 @@ int gemm_mx(const char* name, const void* A, const void* B, const void* A_sf, co
     if (M <= 64) variant = (tiles(64, 128) >= 384) ? 28 : 29;
     else if (N <= 64) variant = (tiles(128, 64) >= want) ? 27 : 29;
     else if (tiles(256, 256) >= want) {
-      // fp4: the persistent deep schedule (one workgroup per CU walks the tiles, epilogue folded into the last K stage);
-      // its epilogue addresses a tile with 32-bit byte offsets, so absurdly wide outputs stay with 256x128 simple tiles
-      const int big = (EBITS == 8) ? 30 : (N < (1ll << 22) ? 90 : 25);
+      // the persistent deep schedule (one workgroup per CU walks the tiles, epilogue folded into the last K stage), fp4 and
+      // fp8; its epilogue addresses a tile with 32-bit byte offsets, so absurdly wide outputs stay with 256x128 simple tiles
+      const int big = N < (1ll << 22) ? 90 : 25;
       variant = big;
       // wave quantisation: T tiles on 256 CUs run ceil(T/256) rounds; when the last round is less than ~60 % full
       // (C3 4096x14336x4096: 896 tiles = 3.5 rounds) the trailing tile columns go to a second launch with smaller

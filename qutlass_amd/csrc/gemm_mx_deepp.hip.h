@@ -374,6 +374,278 @@ __device__ __forceinline__ void gemm_mx_deepp(char* smem, const GemmParams& p) {
   }
 }
 
+// -------------------------------------------------------------------------------------------------------------------------
+// The same structure for MXFP8 (matmul_mxf8_bf16_tn; A e4m3 or e5m2 via C::AFMT, B e4m3).  A stage is 128 K-elements = two
+// k-slices of two 16-byte chunks per fragment (split register layout of gemm_mx_deep8: chunk 4j + 2u + g, op_sel 2j), two
+// fragment sets, an MFMA is 64 cycles:
+//     R(1) ; M(0) ; hand-off ; scales' ; R'(0) ; M(1) with the DMA of stage kt + 2 threaded through
+// Last stage of a tile: accumulator-stationary with 2 MFMAs per 32x32 tile; a pair of tiles is final after post-hand-off MFMA
+// e = 4 P + 1 (30 MFMAs after the hand-off) and retires through the wave's own 8-KiB slice of buffer 1 exactly as in the fp4
+// kernel:  write e+1 | read rows 0-15 e+2 | stores + read rows 16-31 e+4 | stores e+6.
+// -------------------------------------------------------------------------------------------------------------------------
+constexpr int deepp8_pair_done_at(int s) { return (s >= 1 && s <= 29 && (s - 1) % 4 == 0) ? (s - 1) / 4 : -1; }
+
+template <class C, int ST_AUX = 0>
+__device__ __forceinline__ void gemm_mx_deepp8(char* smem, const GemmParams& p) {
+  static_assert(C::EBITS == 8 && C::F8SPLIT && C::BM == 256 && C::BN == 256 && C::WAVES_M == 2 && C::WAVES_N == 2 && C::NSTAGE == 2 && C::PPW == 1,
+                "persistent deep schedule (fp8): 256x256 tiles, 4 waves of 128x128, split register layout");
+  constexpr int MT = 4, NT = 4;
+  constexpr int STAGE = C::STAGE_BYTES, OFF_SCR = DeepPCfg<C>::OFF_SCR;
+  GemmCtx<C> cx(smem, p);   // per-lane offsets / LDS addresses; its tile coordinates and descriptors are NOT used here
+  const int lane = cx.lane, wave = cx.wave, i32 = cx.i32, g = cx.g;
+  const int KT = cx.KT, KTe = (KT + 1) & ~1, CB = cx.CB, rowbytes = cx.rowbytes;
+  const int ntiles = p.tiles_m * p.tiles_n, G = (int)gridDim.x;
+  const int wg = xcd_remap((int)blockIdx.x, G);
+  auto fence = [&]() __attribute__((always_inline)) { __builtin_amdgcn_sched_barrier(0); };
+
+  auto decode = [&](int t, int& m0, int& n0) __attribute__((always_inline)) {
+    constexpr int GM = 4;
+    const int group = GM * p.tiles_n;
+    const int gid = t / group, first_m = gid * GM;
+    const int gsz = min(p.tiles_m - first_m, GM);
+    const int rem = t - gid * group;
+    m0 = uniform((first_m + rem % gsz) * C::BM);
+    n0 = uniform((rem / gsz) * C::BN);
+  };
+  struct Desc { __amdgpu_buffer_rsrc_t a, b, s; };
+  auto make_desc = [&](int t) __attribute__((always_inline)) {
+    const bool valid = t < ntiles;
+    int m0, n0;
+    decode(valid ? t : ntiles - 1, m0, n0);
+    const uint32_t a_off = (uint32_t)m0 * rowbytes, b_off = (uint32_t)n0 * rowbytes;
+    const uint32_t sa_off = (uint32_t)(m0 >> 7) * CB * 512, sb_off = (uint32_t)(n0 >> 7) * CB * 512;
+    Desc d;
+    d.a = make_rsrc(p.A + a_off, valid ? p.a_bytes - a_off : 0u);
+    d.b = make_rsrc(p.B + b_off, valid ? p.b_bytes - b_off : 0u);
+    d.s = cx.sIsB ? make_rsrc(p.SFB + sb_off, valid ? p.sfb_bytes - sb_off : 0u) : make_rsrc(p.SFA + sa_off, valid ? p.sfa_bytes - sa_off : 0u);
+    return d;
+  };
+
+  v16f acc[MT][NT];
+  v8i fa[2][MT] = {}, fb[2][NT] = {};
+  int sa[2][MT], sb[2][NT];
+
+  auto read_fa = [&](const int buf, const int j, const int t) __attribute__((always_inline)) {
+    const char* st = smem + buf * STAGE;
+    const v4i lo = *(const v4i*)(st + cx.rdA[2 * j] + t * 32 * C::ROWB);
+    const v4i hi = *(const v4i*)(st + cx.rdA[2 * j + 1] + t * 32 * C::ROWB);
+    fa[j][t] = v8i{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  };
+  auto read_fb = [&](const int buf, const int j, const int t) __attribute__((always_inline)) {
+    const char* st = smem + buf * STAGE;
+    const v4i lo = *(const v4i*)(st + cx.rdBd + cx.rdA[2 * j] + t * 32 * C::ROWB);
+    const v4i hi = *(const v4i*)(st + cx.rdBd + cx.rdA[2 * j + 1] + t * 32 * C::ROWB);
+    fb[j][t] = v8i{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  };
+  auto read_slice = [&](const int buf, const int j) __attribute__((always_inline)) {
+#pragma unroll
+    for (int t = 0; t < MT; ++t) read_fa(buf, j, t);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) read_fb(buf, j, t);
+  };
+  auto read_scales = [&](const int buf, const int set) __attribute__((always_inline)) {
+    const char* st = smem + buf * STAGE;
+    const int shift = 8 * g;   // split layout: lanes 0-31 carry K-block 2j, lanes 32-63 K-block 2j + 1
+#pragma unroll
+    for (int t = 0; t < MT; ++t) sa[set][t] = (int)((unsigned)(*(const int*)(st + cx.rdSA[t])) >> shift);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) sb[set][t] = (int)((unsigned)(*(const int*)(st + cx.rdSB[t])) >> shift);
+  };
+  auto mfma1 = [&](const int j, const int sset, const int m, const int n, const bool zero_c) __attribute__((always_inline)) {
+    v16f c = acc[m][n];
+    if (zero_c) c = v16f{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (j == 0) acc[m][n] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fb[0][n], fa[0][m], c, 0, C::AFMT, 0, sb[sset][n], 0, sa[sset][m]);
+    if (j == 1) acc[m][n] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fb[1][n], fa[1][m], c, 0, C::AFMT, 2, sb[sset][n], 2, sa[sset][m]);
+  };
+
+  int vb0 = 0, vb1 = 0, vbS = 0;
+  auto dma_prep = [&](int kt, bool valid) __attribute__((always_inline)) {
+    int lastmask = (kt == KT - 1) ? -1 : 0;
+    int oobm = (valid && kt < KT) ? 0 : -1;
+    int oobs = (valid && kt * C::SCT + cx.colS < CB) ? 0 : -1;
+    asm volatile("" : "+v"(lastmask), "+v"(oobm), "+v"(oobs));
+    vb0 = (((cx.voffT[0] & lastmask) | (cx.voffAB[0] & ~lastmask)) & ~oobm) | ((int)0x80000000 & oobm);
+    vb1 = (((cx.voffT[1] & lastmask) | (cx.voffAB[1] & ~lastmask)) & ~oobm) | ((int)0x80000000 & oobm);
+    vbS = (cx.voffS & ~oobs) | ((int)0x80000000 & oobs);
+  };
+  auto dma_item = [&](const Desc& d, int kt, const int buf, const int item) __attribute__((always_inline)) {
+    char* st = smem + buf * STAGE;
+    if (item < 16) {
+      const int t = item & 7, q = wave * 8 + t;
+      const int v = ((t & 1) ? vb1 : vb0) + q * cx.rstep;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(item < 8 ? d.a : d.b, (lds_ptr_t)(st + (item < 8 ? 0 : C::OFF_B) + q * 1024), 16, v, kt * C::ROWB, 0, QAMD_DMA_AUX);
+    } else {
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(d.s, (lds_ptr_t)(st + C::OFF_S + wave * 1024), 16, vbS, kt * C::SCT * 512, 0, 0);
+    }
+  };
+  auto dma_stage = [&](const Desc& d, int kt, bool valid, const int buf) __attribute__((always_inline)) {
+    dma_prep(kt, valid);
+#pragma unroll
+    for (int i = 0; i < 17; ++i) dma_item(d, kt, buf, i);
+  };
+  auto pin_acc = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int n = 0; n < NT; ++n) asm volatile("" : "+a"(acc[m][n]));
+  };
+
+  // one K stage (not the last of its tile).  Entry: fragment set 0 and scale set BUF hold slice 0 of this stage.
+  auto stage = [&](auto bufc, auto firstc, const Desc& d, int ktl, bool dvalid) __attribute__((always_inline)) {
+    constexpr int BUF = decltype(bufc)::value;
+    constexpr bool FIRST = decltype(firstc)::value;
+    read_slice(BUF, 1); fence();
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int n = 0; n < NT; ++n) mfma1(0, BUF, m, n, FIRST);
+    fence();
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    fence();
+    read_scales(BUF ^ 1, BUF ^ 1);
+    read_slice(BUF ^ 1, 0);
+    dma_prep(ktl, dvalid);
+    fence();
+    int idx = 0;
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int n = 0; n < NT; ++n) {
+        mfma1(1, BUF, m, n, false);
+        dma_item(d, ktl, BUF, idx);
+        if (idx == 0) dma_item(d, ktl, BUF, 16);
+        fence();
+        ++idx;
+      }
+    if constexpr (FIRST) pin_acc();
+  };
+
+  // epilogue pieces: identical to the fp4 kernel (pairs of 32x32 tiles through the wave's 8-KiB slice of buffer 1's A area)
+  char* scr = smem + OFF_SCR + wave * DeepPCfg<C>::SCR_PER_WAVE;
+  const int scrW = i32 * 256 + ((((i32 & 6) << 4)) | ((g ^ (i32 & 1)) << 4));
+  const int rrl = lane >> 3, ccl = lane & 7;
+  const int scrR = rrl * 256 + (ccl >> 2) * 128 + ((((2 * ccl) & 7) ^ (rrl & 7)) << 4);
+  const float alpha = *p.alpha;
+  __amdgpu_buffer_rsrc_t rD = make_rsrc(p.D, 0);
+  int stLane = 0, colLim = 0;
+  auto set_out_tile = [&](int m0, int n0) __attribute__((always_inline)) {
+    const int64_t left = ((int64_t)(p.M - m0) * p.ldd - n0) * 2;
+    rD = make_rsrc(p.D + ((int64_t)m0 * p.ldd + n0), (uint32_t)(left > 0x7fffffffll ? 0x7fffffffll : left));
+    stLane = ((cx.wave_m * C::WTM + rrl) * p.ldd + cx.wave_n * C::WTN + 8 * ccl) * 2;
+    colLim = p.N - n0 - cx.wave_n * C::WTN - 8 * ccl;
+  };
+  auto retire_write = [&](const int m, const int h) __attribute__((always_inline)) {
+#pragma unroll
+    for (int nn = 0; nn < 2; ++nn)
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        *(v4f*)(scr + (scrW ^ (q << 5)) + nn * 128) =
+            v4f{acc[m][2 * h + nn][4 * q + 0], acc[m][2 * h + nn][4 * q + 1], acc[m][2 * h + nn][4 * q + 2], acc[m][2 * h + nn][4 * q + 3]};
+  };
+  v4f rb[2][2];
+  auto retire_read = [&](const int half) __attribute__((always_inline)) {
+#pragma unroll
+    for (int ps = 0; ps < 2; ++ps) {
+      rb[ps][0] = *(const v4f*)(scr + scrR + (2 * half + ps) * 2048);
+      rb[ps][1] = *(const v4f*)(scr + (scrR ^ 16) + (2 * half + ps) * 2048);
+    }
+  };
+  auto retire_store = [&](const int m, const int h, const int pass) __attribute__((always_inline)) {
+    const v4f lo = rb[pass & 1][0], hi = rb[pass & 1][1];
+    v4i o;
+    o[0] = (int)pack_bf16x2(lo[0] * alpha, lo[1] * alpha);
+    o[1] = (int)pack_bf16x2(lo[2] * alpha, lo[3] * alpha);
+    o[2] = (int)pack_bf16x2(hi[0] * alpha, hi[1] * alpha);
+    o[3] = (int)pack_bf16x2(hi[2] * alpha, hi[3] * alpha);
+    const int off = stLane + ((32 * m + 8 * pass) * p.ldd + 64 * h) * 2;
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, o), rD, (64 * h < colLim) ? off : (int)0x80000000, 0, ST_AUX);
+  };
+
+  auto final_stage = [&](const Desc& d, bool dvalid) __attribute__((always_inline)) {
+    read_slice(1, 1);
+    fence();
+    mfma1(0, 1, 0, 0, false); mfma1(0, 1, 0, 1, false);   // slice 0 of tiles 0, 1: covers the latency of R(1)
+    fence();
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    fence();
+    dma_prep(1, dvalid);
+    fence();
+    static_for<0, 37>([&](auto sc) __attribute__((always_inline)) {
+      constexpr int s = decltype(sc)::value;
+      if constexpr (s < 30) {
+        constexpr int T = s < 2 ? s : 2 + (s - 2) / 2;
+        constexpr int j = s < 2 ? 1 : (s - 2) % 2;
+        mfma1(j, 1, T / 4, T % 4, false);
+      }
+      if constexpr (s % 2 == 0 && s / 2 < 9) dma_item(d, 1, 1, 8 + s / 2);
+      if constexpr (s == 1) read_scales(0, 0);
+      // slice 0 of the next tile's stage 0, as the registers die: A rows of m after tile (m, 3) (MFMA 8 m + 5), B rows of n after (3, n) (MFMA 23 + 2 n)
+      if constexpr (s == 6 || s == 14 || s == 22) read_fa(0, 0, (s - 6) / 8);
+      if constexpr (s == 24 || s == 26 || s == 28) read_fb(0, 0, (s - 24) / 2);
+      if constexpr (s == 30) { read_fa(0, 0, 3); read_fb(0, 0, 3); }
+      constexpr int P4 = deepp8_pair_done_at(s - 4), P6 = deepp8_pair_done_at(s - 6), P1 = deepp8_pair_done_at(s - 1), P2 = deepp8_pair_done_at(s - 2);
+      if constexpr (P6 >= 0) { retire_store(P6 / 2, P6 % 2, 2); retire_store(P6 / 2, P6 % 2, 3); }
+      if constexpr (P4 >= 0) { retire_store(P4 / 2, P4 % 2, 0); retire_store(P4 / 2, P4 % 2, 1); retire_read(1); }
+      if constexpr (P1 >= 0) retire_write(P1 / 2, P1 % 2);
+      if constexpr (P2 >= 0) retire_read(0);
+      fence();
+    });
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int i = 0; i < 8; ++i) dma_item(d, 1, 1, i);
+    fence();
+  };
+
+  int tile = wg;
+  Desc cur = make_desc(tile);
+  dma_stage(cur, 0, true, 0);
+  dma_stage(cur, 1, true, 1);
+  asm volatile("s_waitcnt vmcnt(17)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  fence();
+  read_scales(0, 0);
+  read_slice(0, 0);
+  fence();
+
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+  using BT = std::integral_constant<bool, true>;
+  using BF = std::integral_constant<bool, false>;
+  while (tile < ntiles) {
+    int m0, n0;
+    decode(tile, m0, n0);
+    set_out_tile(m0, n0);
+    const int tnext = tile + G;
+    const Desc nxt = make_desc(tnext);
+    const bool nvalid = tnext < ntiles;
+    {
+      const bool tonext = KTe == 2;
+      Desc d;
+      d.a = tonext ? nxt.a : cur.a; d.b = tonext ? nxt.b : cur.b; d.s = tonext ? nxt.s : cur.s;
+      stage(I0{}, BT{}, d, tonext ? 0 : 2, tonext ? nvalid : true);
+    }
+    for (int kt = 1; kt + 2 < KTe; kt += 2) {
+      stage(I1{}, BF{}, cur, kt + 2, true);
+      const bool tonext = kt + 3 == KTe;
+      Desc d;
+      d.a = tonext ? nxt.a : cur.a; d.b = tonext ? nxt.b : cur.b; d.s = tonext ? nxt.s : cur.s;
+      stage(I0{}, BF{}, d, tonext ? 0 : kt + 3, tonext ? nvalid : true);
+    }
+    final_stage(nxt, nvalid);
+    cur = nxt;
+    tile = tnext;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+template <class C, int ST_AUX = 0>
+__global__ __launch_bounds__(C::THREADS) void gemm_mx_deepp8_kernel(const GemmParams p) {
+  __shared__ __attribute__((aligned(16))) char smem[DeepPCfg<C>::LDS_BYTES];
+  gemm_mx_deepp8<C, ST_AUX>(smem, p);
+}
+
 template <class C, bool TRACE = false, int ST_AUX = 0>
 __global__ __launch_bounds__(C::THREADS) void gemm_mx_deepp_kernel(const GemmParams p) {
   __shared__ __attribute__((aligned(16))) char smem[DeepPCfg<C>::LDS_BYTES];

@@ -678,6 +678,26 @@ int main(int argc, char** argv) {
       }
     g_gauss_fill = 0;
   }
+  if (want("deepp8")) {   // persistent deep schedule, fp8 (variant 90) against the oracle and the per-tile deep schedule (30)
+    check_gemm("deepp8 256x256x256 (one tile)", 2, 256, 256, 256, 1.0f, 3, 0, 90);
+    check_gemm("deepp8 128x128x32 (partial tile, KT = 1)", 2, 128, 128, 32, 1.0f, 3, 0, 90);
+    check_gemm("deepp8 200x264x160 (KT = 2 with K tail)", 2, 200, 264, 160, 0.5f, 3, 0, 90);
+    check_gemm("deepp8 72x136x352 (ragged, K tail, KT = 3 -> 4)", 2, 72, 136, 352, 0.5f, 4, 0, 90);
+    check_gemm("deepp8 300x520x1152 (6 tiles)", 2, 300, 520, 1152, 1.0f, 3, 0, 90);
+    check_gemm("deepp8 504x504x2048", 2, 504, 504, 2048, 1.0f, 3, 0, 90);
+    check_gemm("deepp8 4100x4360x384 (306 ragged tiles: 2 rounds)", 2, 4100, 4360, 384, 0.5f, 3, 48, 90);
+    check_gemm("deepp8 5000x8200x256 (660 tiles: 3 rounds, KTe = 2)", 2, 5000, 8200, 256, 1.0f, 3, 48, 90);
+    check_gemm("deepp8 4096^3 (48 rows)", 2, 4096, 4096, 4096, 1.0f, 3, 48, 90);
+    check_gemm("auto fp8 4096x14336x1024 (deepp8 + tail)", 2, 4096, 14336, 1024, 1.0f, 3, 24, 0);
+    g_warm_override = 1500; g_iters_override = 1500;
+    for (int rep = 0; rep < 2; ++rep)
+      for (int var : {30, 90}) bench_gemm("mxfp8 4096^3 steady", 2, 4096, 4096, 4096, var, 0);
+    g_warm_override = 300; g_iters_override = 300;
+    for (int var : {30, 90}) bench_gemm("mxfp8 4096x12288x4096 steady", 2, 4096, 12288, 4096, var, 0);
+    g_warm_override = 150; g_iters_override = 150;
+    for (int var : {30, 90}) bench_gemm("mxfp8 8192^3 steady", 2, 8192, 8192, 8192, var, 0);
+    g_warm_override = 0; g_iters_override = 0;
+  }
   if (want("deeppbench")) {
     g_gauss_fill = 1;
     g_warm_override = 2500; g_iters_override = 2500;

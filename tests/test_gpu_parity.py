@@ -413,7 +413,7 @@ def _mxfp8_close(got_bits, want_bits):
     return np.abs(got - want) <= tol
 
 
-@pytest.mark.parametrize("variant", [0, 20, 30, 70, 73])   # auto, 8-wave simple, 4-wave deep, ring 64x64 / 128x128
+@pytest.mark.parametrize("variant", [0, 20, 30, 70, 73, 90])   # auto, 8-wave simple, 4-wave deep (per tile), ring 64x64 / 128x128, persistent deep
 def test_matmul_mxf8_large_tiles_vs_oracle(q, variant):
     from qutlass_amd.utils import to_blocked
 
