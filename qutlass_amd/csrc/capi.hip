@@ -56,6 +56,7 @@ std::atomic<int> g_transpose_nc{128};   // mxfp4_transpose_mxfp8: n columns per 
 std::atomic<int> g_pp_shift{2};
 std::atomic<int> g_pp_flags{1};
 std::atomic<int> g_quant_wg_per_cu{0};  // 0 = auto
+std::atomic<int> g_deepp_grid{0};       // lab: workgroups of the persistent deep kernels (0 = the balanced-rounds rule)
 std::atomic<int> g_splitk_force{0};     // lab: K splits for a FORCED ring variant ("gemm_variant" 70..73); 0 = the plan's
 std::atomic<uint32_t*> g_dbg{nullptr};
 #endif
@@ -88,7 +89,7 @@ unsigned long long next_launch_tag() {
 unsigned long long next_launch_tag();
 extern std::atomic<int> g_hw_fp4_cvt;
 #if QAMD_BENCH
-extern std::atomic<int> g_gemm_variant, g_nvf4_variant, g_splitk_wg, g_splitk_min_kt, g_transpose_nc, g_pp_shift, g_pp_flags, g_quant_wg_per_cu, g_splitk_force;
+extern std::atomic<int> g_gemm_variant, g_nvf4_variant, g_splitk_wg, g_splitk_min_kt, g_transpose_nc, g_pp_shift, g_pp_flags, g_quant_wg_per_cu, g_splitk_force, g_deepp_grid;
 extern std::atomic<uint32_t*> g_dbg;
 #endif
 int fail(int code, const char* fmt, ...);
@@ -107,6 +108,7 @@ inline int opt_pp_shift() { return g_pp_shift.load(); }
 inline int opt_pp_flags() { return g_pp_flags.load(); }
 inline int opt_quant_wg_per_cu() { return g_quant_wg_per_cu.load(); }
 inline int opt_splitk_force() { return g_splitk_force.load(); }
+inline int opt_deepp_grid() { return g_deepp_grid.load(); }
 inline uint32_t* opt_dbg() { return g_dbg.load(); }
 #else
 constexpr int opt_gemm_variant() { return 0; }
@@ -118,6 +120,7 @@ constexpr int opt_pp_shift() { return 2; }
 constexpr int opt_pp_flags() { return 1; }
 constexpr int opt_quant_wg_per_cu() { return 0; }
 constexpr int opt_splitk_force() { return 0; }
+constexpr int opt_deepp_grid() { return 0; }
 constexpr uint32_t* opt_dbg() { return nullptr; }
 #endif
 
@@ -132,13 +135,26 @@ int launch_gemm(GemmParams p, hipStream_t s) {
   return check_launch("gemm_mx_kernel");
 }
 
-// persistent deep schedule (gemm_mx_deepp.hip.h): one workgroup per CU walks the tiles; 160 KiB of static LDS
+// Workgroups of a persistent deep launch over T tiles of 256x256 on the 256 CUs of an MI355X (one 512-register workgroup per
+// CU): BALANCED rounds -- R = ceil(T / 256) tiles per workgroup, G = ceil(T / R) workgroups rounded up to a multiple of 8 (one
+// share per XCD) -- instead of 256 workgroups with a ragged last round.  The kernels run at the socket power limit, so the CUs
+// a smaller grid leaves idle are not lost: the others clock higher (896 tiles: 224 workgroups x 4 tiles beat 256 workgroups
+// x 3.5 rounds, profiles/native_r2_deepp_grid.log).
+inline int deepp_grid(int tiles) {
+  const int forced = opt_deepp_grid();
+  if (forced > 0) return std::min(forced, tiles);
+  const int rounds = (tiles + 255) / 256;
+  const int g = ((tiles + rounds - 1) / rounds + 7) / 8 * 8;
+  return std::min(std::min(g, 256), tiles);
+}
+
+// persistent deep schedule (gemm_mx_deepp.hip.h): one workgroup per CU walks the tiles; 136 KiB of static LDS
 template <class C, bool TRACE = false, int ST_AUX = 0>
 int launch_gemm_deepp(GemmParams p, hipStream_t s) {
   p.tiles_m = (int)cdiv(p.M, C::BM);
   p.tiles_n = (int)cdiv(p.N, C::BN);
   p.ws = nullptr; p.splits = 1; p.ctr = nullptr; p.tag = 0;
-  const int grid = std::min(p.tiles_m * p.tiles_n, 256);   // MI355X: 256 CUs, one 512-register workgroup each
+  const int grid = deepp_grid(p.tiles_m * p.tiles_n);
   hipLaunchKernelGGL((gemm_mx_deepp_kernel<C, TRACE, ST_AUX>), dim3(grid), dim3(C::THREADS), 0, s, p);
   return check_launch("gemm_mx_deepp_kernel");
 }
@@ -148,7 +164,7 @@ int launch_gemm_deepp8(GemmParams p, hipStream_t s) {   // the fp8 twin (gemm_mx
   p.tiles_m = (int)cdiv(p.M, C::BM);
   p.tiles_n = (int)cdiv(p.N, C::BN);
   p.ws = nullptr; p.splits = 1; p.ctr = nullptr; p.tag = 0;
-  const int grid = std::min(p.tiles_m * p.tiles_n, 256);
+  const int grid = deepp_grid(p.tiles_m * p.tiles_n);
   hipLaunchKernelGGL((gemm_mx_deepp8_kernel<C, 17>), dim3(grid), dim3(C::THREADS), 0, s, p);
   return check_launch("gemm_mx_deepp8_kernel");
 }
@@ -497,7 +513,9 @@ int gemm_mx(const char* name, const void* A, const void* B, const void* A_sf, co
       // D (ldd = N); operands of the column range are plain pointer offsets (N-range starts on a 256 boundary).
       const int64_t tm = cdiv(M, 256), tn = cdiv(N, 256), T = tm * tn, full = (T / 256) * 256;
       const int64_t main_cols = (tm > 0) ? full / tm : 0;          // whole tile columns that fit the full rounds
-      if (!(opt_pp_flags() & 64) && full >= 256 && main_cols >= 1 && main_cols < tn && (T - main_cols * tm) * 10 <= 256 * 6) {
+      // From three full rounds on, ONE persistent launch with balanced rounds (deepp_grid) is at least as good (C3: 118.0-119.4
+      // vs 120.2-120.7 us); with one or two full rounds the split wins or ties (4096 x 5120: 50.6 vs 51.0 us).
+      if (!(opt_pp_flags() & 64) && full >= 256 && full < 768 && main_cols >= 1 && main_cols < tn && (T - main_cols * tm) * 10 <= 256 * 6) {
         const int64_t n1 = main_cols * 256;
         GemmParams pm = p;
         pm.N = (int)n1; pm.b_bytes = (uint32_t)(n1 * rowbytes); pm.sfb_bytes = (uint32_t)(cdiv(n1, 128) * CB * 512);
@@ -916,6 +934,7 @@ int qutlass_amd_set_option(const char* key, int value) {
   if (!strcmp(key, "splitk_wg")) return g_splitk_wg.exchange(value);
   if (!strcmp(key, "splitk_min_kt")) return g_splitk_min_kt.exchange(value);
   if (!strcmp(key, "splitk_force")) return g_splitk_force.exchange(value);
+  if (!strcmp(key, "deepp_grid")) return g_deepp_grid.exchange(value);
   if (!strcmp(key, "quant_wg_per_cu")) return g_quant_wg_per_cu.exchange(value);
   if (!strcmp(key, "pp_shift")) return g_pp_shift.exchange(value);
   if (!strcmp(key, "pp_flags")) return g_pp_flags.exchange(value);

@@ -698,6 +698,32 @@ int main(int argc, char** argv) {
     for (int var : {30, 90}) bench_gemm("mxfp8 8192^3 steady", 2, 8192, 8192, 8192, var, 0);
     g_warm_override = 0; g_iters_override = 0;
   }
+  if (want("deeppgrid")) {   // C3 and other ragged tile counts: tail split vs one persistent launch with 256 / balanced workgroups
+    g_gauss_fill = 1; g_warm_override = 600; g_iters_override = 600;
+    struct Sh { int64_t M, N, K; };
+    for (const Sh& sh : {Sh{4096, 14336, 4096}, Sh{4096, 11008, 4096}, Sh{8192, 10240, 4096}, Sh{4096, 5120, 4096}}) {
+      for (int rep = 0; rep < 2; ++rep) {
+        qutlass_amd_set_option("pp_flags", 1); qutlass_amd_set_option("deepp_grid", 256);
+        bench_gemm("mxfp4 auto: tail split, 256 workgroups", 0, sh.M, sh.N, sh.K, 0, 0);
+        qutlass_amd_set_option("pp_flags", 1 | 64);
+        bench_gemm("mxfp4 one launch, 256 workgroups", 0, sh.M, sh.N, sh.K, 0, 0);
+        qutlass_amd_set_option("deepp_grid", 0);
+        bench_gemm("mxfp4 one launch, balanced rounds", 0, sh.M, sh.N, sh.K, 0, 0);
+        qutlass_amd_set_option("pp_flags", 1);
+        bench_gemm("mxfp4 tail split + balanced main", 0, sh.M, sh.N, sh.K, 0, 0);
+      }
+    }
+    for (int gr : {256, 240, 224, 192, 128}) {   // 768 tiles (3 per CU at 256): does a smaller grid cost anything when rounds are balanced either way?
+      qutlass_amd_set_option("deepp_grid", gr);
+      char tag[64]; snprintf(tag, sizeof tag, "mxfp4 4096x12288x4096, %d workgroups", gr);
+      bench_gemm(tag, 0, 4096, 12288, 4096, 90, 0);
+    }
+    qutlass_amd_set_option("deepp_grid", 0);
+    check_gemm("balanced grid C3 (one launch, 224 workgroups x 4 tiles)", 0, 4096, 14336, 4096, 1.0f, 3, 32, 90);
+    check_gemm("balanced grid 2304x3592x1152", 0, 2304, 3592, 1152, 0.5f, 3, 24, 90);
+    check_gemm("balanced grid 5000x8200x512", 0, 5000, 8200, 512, 1.0f, 3, 32, 90);
+    g_gauss_fill = 0; g_warm_override = 0; g_iters_override = 0;
+  }
   if (want("deeppbench")) {
     g_gauss_fill = 1;
     g_warm_override = 2500; g_iters_override = 2500;

@@ -125,10 +125,12 @@ def test_auto_dispatch_rules_dry_run(lib):
     DEEPP, DEEP, SKINNY, RING64, RING64x128, RING128 = 90, 30, 60, 70, 72, 73
     big = 1 << 30
     # headline and the other BASELINE configs: 256x256 tiles, the persistent deep schedule (fp4 and fp8);
-    # C3 = 3.5 rounds of tiles -> tail split (2048 columns on 256x128)
+    # C3 = 3.5 rounds of tiles -> one persistent launch with balanced rounds (224 workgroups x 4 tiles); 1.25 rounds -> tail
+    # split (the last 1024 columns on 128x128 tiles)
     assert plan(4, 4096, 4096, 4096) == [(DEEPP, 4096, 1)]
     assert plan(4, 8192, 8192, 8192) == [(DEEPP, 8192, 1)]
-    assert plan(4, 4096, 14336, 4096) == [(DEEPP, 12288, 1), (25, 2048, 1)]
+    assert plan(4, 4096, 14336, 4096) == [(DEEPP, 14336, 1)]
+    assert plan(4, 4096, 5120, 4096) == [(DEEPP, 4096, 1), (24, 1024, 1)]
     assert plan(8, 4096, 4096, 4096) == [(DEEPP, 4096, 1)]
     assert plan(4, 256, 1 << 22, 128) == [(25, 1 << 22, 1)]          # absurdly wide output: 32-bit tile offsets of the persistent epilogue do not reach
     # decode: LDS-free split-K kernel while the weight has fewer than 128 64-row tiles, ring kernel beyond, 64x128 tiles for huge N

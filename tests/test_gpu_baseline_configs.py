@@ -64,8 +64,7 @@ def _mxfp8_close(got_bits, want_bits):
 
 def test_c3_quantize_swizzle_gemm_llama3_ffn_vs_oracle(q):
     """configs[2]: both operands quantised on the GPU (Hadamard-32, abs_max), scales swizzled on the GPU, GEMM 4096 x 14336 x
-    4096 (auto dispatch: persistent deep kernel over the first 12288 columns + a 256x128-tile launch over the last 2048, so
-    every compared row crosses the launch boundary).  Checks, all against the oracle on the same bytes:
+    4096 (auto dispatch: one persistent launch, 224 workgroups x 4 tiles of 256x256).  Checks, all against the oracle on the same bytes:
       * quantiser: e8m0 bytes exact and e2m1 codes exact (mod sign of zero, <= 1e-6 mismatching) on the sampled rows of A and
         on 256 sampled rows of B;  * to_blocked of the full scale matrices exact;  * 96 output rows bit-exact."""
     from qutlass_amd.utils import to_blocked
