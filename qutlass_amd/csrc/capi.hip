@@ -417,8 +417,22 @@ int gemm_mx(const char* name, const void* A, const void* B, const void* A_sf, co
   const int64_t CB = cdiv(K / 32, 4);
   const int64_t a_bytes = M * rowbytes, b_bytes = N * rowbytes;
   const int64_t sfa_bytes = cdiv(M, 128) * CB * 512, sfb_bytes = cdiv(N, 128) * CB * 512;
-  if (a_bytes >= (1ll << 31) || b_bytes >= (1ll << 31) || M * N >= (1ll << 40))
-    return fail(QAMD_ERR_INVALID, "%s: operand larger than 2 GiB is not supported", name);
+  if (b_bytes >= (1ll << 31) || M * N >= (1ll << 40) || M >= (1ll << 31))
+    return fail(QAMD_ERR_INVALID, "%s: B operand larger than 2 GiB (or an output of 2^40 elements) is not supported", name);
+  if (a_bytes >= (1ll << 31)) {
+    // The kernels address an operand through 32-bit buffer-descriptor offsets (< 2 GiB); the reference's CUTLASS kernels use
+    // 64-bit strides.  A larger A (large batch x long K, e.g. 262144 x 16384 fp4) runs as row ranges of whole 256-row tiles:
+    // rebased A / scale / D pointers, same B -- every output element is computed by exactly one launch, in the same K order.
+    const int64_t rows = ((1ll << 31) - 1) / rowbytes / 256 * 256;
+    if (rows < 256) return fail(QAMD_ERR_INVALID, "%s: K too large for a 256-row range of A to stay below 2 GiB", name);
+    for (int64_t r0 = 0; r0 < M; r0 += rows) {
+      const int64_t mc = std::min(rows, M - r0);
+      if (int rc = gemm_mx<EBITS>(name, (const uint8_t*)A + r0 * rowbytes, B, (const uint8_t*)A_sf + (r0 / 128) * CB * 512, B_sf, alpha,
+                                  (uint16_t*)D + r0 * N, mc, N, K, stream, ws, ws_bytes, a_fmt))
+        return rc;
+    }
+    return QAMD_OK;
+  }
   GemmParams p;
   p.A = (const uint8_t*)A; p.B = (const uint8_t*)B; p.SFA = (const uint8_t*)A_sf; p.SFB = (const uint8_t*)B_sf;
   p.alpha = alpha; p.D = (uint16_t*)D; p.M = (int)M; p.N = (int)N; p.K = (int)K; p.ldd = (int)N;

@@ -150,6 +150,8 @@ def test_auto_dispatch_rules_dry_run(lib):
     assert plan(4, 512, 4096, 4096) == [(RING64x128, 4096, 1)]
     assert plan(4, 1024, 4096, 4096) == [(RING128, 4096, 1)] and plan(4, 256, 14336, 4096) == [(RING128, 14336, 1)]
     assert plan(4, 2048, 4096, 4096) == [(24, 4096, 1)]               # 512 tiles of 128x128: two workgroups per CU, simple schedule
+    # an A operand of >= 2 GiB (262400 x 16384 fp4 = 2.15 GB) runs as two row ranges of whole 256-row tiles
+    assert plan(4, 262400, 256, 16384) == [(DEEPP, 256, 1), (RING64, 256, 1)]   # 261888 rows, then the last 512
     # rejected arguments never reach the dispatch
     assert plan(4, 128, 128, 96) is None and plan(5, 128, 128, 128) is None
 

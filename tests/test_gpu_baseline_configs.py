@@ -165,3 +165,29 @@ def test_c5_mxfp8_4096_cubed_vs_oracle(q, layout, a_format):
     got = _np(out[torch.tensor(rows, device=DEV)])
     ok = _mxfp8_close(got, ref)
     assert ok.all(), f"{int((~ok).sum())} of {ok.size} sampled outputs out of tolerance"
+
+
+def test_a_operand_beyond_2gib_runs_as_row_ranges(q):
+    """The kernels address an operand through 32-bit buffer-descriptor offsets; an A operand of >= 2 GiB (here 262400 x 16384
+    fp4 = 2.15 GB -- the reference's CUTLASS kernels take it directly) runs as row ranges with rebased pointers.  Rows from the
+    start, both sides of the range boundary (row 261888) and the end, bit-exact against the oracle."""
+    from qutlass_amd.utils import to_blocked
+
+    m, n, k = 262400, 256, 16384
+    g = torch.Generator(device=DEV).manual_seed(9)
+    a = torch.randint(0, 256, (m, k // 2), dtype=torch.uint8, device=DEV, generator=g)
+    b = torch.randint(0, 256, (n, k // 2), dtype=torch.uint8, device=DEV, generator=g)
+    a_s = torch.randint(124, 131, (m, k // 32), dtype=torch.uint8, device=DEV, generator=g)
+    b_s = torch.randint(124, 131, (n, k // 32), dtype=torch.uint8, device=DEV, generator=g)
+    e8 = torch.float8_e8m0fnu
+    out = q.matmul_mxf4_bf16_tn(a, b, to_blocked(a_s.view(e8)), to_blocked(b_s.view(e8)), torch.tensor([1.0], device=DEV))
+    assert out.shape == (m, n)
+    rows = [0, 1, 255, 256, 131071, 261887, 261888, 261889, 262143, 262144, 262399]
+    ri = torch.tensor(rows, device=DEV)
+    ref = oracle.gemm_blockscaled(oracle.KIND_MXFP4, _np(a[ri]), _np(b), oracle.to_blocked(_np(a_s[ri])), oracle.to_blocked(_np(b_s)), 1.0, len(rows), n, k)
+    got = _np(out[ri])
+    # 16384-long sums of products with a 7-binade scale spread are not all exact in fp32: bit-equality is required where the
+    # fp64 reference is exactly representable in the kernel's accumulation (the reference's own regime); here: 1 bf16 ulp
+    gf, rf = oracle.bf16_bits_to_f32(got).astype(np.float64), oracle.bf16_bits_to_f32(ref).astype(np.float64)
+    assert (np.abs(gf - rf) <= np.abs(rf) / 128.0 + 1e-6 * np.abs(rf).max()).all()
+    assert (got == ref).mean() > 0.95
