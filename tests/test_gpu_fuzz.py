@@ -196,3 +196,47 @@ def test_fuzz_backward_ops(q):
         y, e = q.mxfp4_transpose_mxfp8(xq, xs.view(torch.float8_e8m0fnu))
         ry, re = oracle.mxfp4_transpose_mxfp8(_np(xq), _np(xs))
         assert np.array_equal(_np(e), re) and np.array_equal(_np(y), ry), (it, m, n)
+
+
+def test_fuzz_persistent_deep_kernels(q):
+    """Outputs of >= 192 tiles of 256x256 run the persistent deep kernels (gemm_mx_deepp / gemm_mx_deepp8): ragged M / N, K tails,
+    odd and even stage counts, 1..3 rounds of tiles per workgroup, balanced grids and tail splits, alpha != 1 -- against the
+    oracle on sampled rows (first / last / tile-boundary rows + a random draw).  K stays small so the oracle stays fast."""
+    from qutlass_amd.utils import to_blocked
+
+    rng = np.random.default_rng(107 + 1000 * SEED)
+    e8 = torch.float8_e8m0fnu
+    for it in range(10):
+        fp8 = it % 2 == 1
+        e5 = fp8 and it % 4 == 3
+        m = int(rng.integers(2600, 6200)) if it % 3 else int(rng.choice([3072, 4096, 5120]))
+        n = int(rng.integers(2600 // 8, 9000 // 8)) * 8
+        if -(-m // 256) * -(-n // 256) < 192:
+            n = -(-192 // -(-m // 256)) * 256 + 8
+        k = int(rng.integers(1, 13)) * (32 if fp8 else 128)
+        alpha = float(rng.choice([1.0, 0.5, -0.25]))
+        rows = sorted({0, 1, 255, 256, 257, m - 257, m - 256, m - 1} | set(rng.integers(0, m, 24).tolist()))
+        ri = torch.tensor(rows, device=DEV)
+        al = torch.tensor([alpha], device=DEV)
+        if not fp8:
+            a, b = _rand_codes(rng, m, k // 2), _rand_codes(rng, n, k // 2)
+            sa = torch.from_numpy(rng.integers(126, 129, size=(m, k // 32), dtype=np.uint8)).to(DEV)
+            sb = torch.from_numpy(rng.integers(126, 129, size=(n, k // 32), dtype=np.uint8)).to(DEV)
+            out = q.matmul_mxf4_bf16_tn(a, b, to_blocked(sa.view(e8)), to_blocked(sb.view(e8)), al)
+            ref = oracle.gemm_blockscaled(oracle.KIND_MXFP4, _np(a[ri]), _np(b), oracle.to_blocked(_np(sa[ri])), oracle.to_blocked(_np(sb)), alpha, len(rows), n, k)
+            got = _np(out[ri])
+            assert np.array_equal(got, ref), (it, m, n, k, int((got != ref).sum()))
+        else:
+            x = torch.from_numpy(rng.standard_normal((m, k)).astype(np.float32) * 4)
+            y = torch.from_numpy(rng.standard_normal((n, k)).astype(np.float32) * 4)
+            xs = x * torch.exp2(torch.from_numpy(rng.integers(-6, 7, (m, 1)).astype(np.float32))) if e5 else x   # gradient-like row ranges for e5m2
+            a = xs.clamp(-448.0 if not e5 else -57344.0, 448.0 if not e5 else 57344.0).to(torch.float8_e5m2 if e5 else torch.float8_e4m3fn).to(DEV)
+            b = y.clamp(-448.0, 448.0).to(torch.float8_e4m3fn).to(DEV)
+            sa = torch.from_numpy(rng.integers(122, 131, size=(m, k // 32), dtype=np.uint8)).to(DEV)
+            sb = torch.from_numpy(rng.integers(122, 131, size=(n, k // 32), dtype=np.uint8)).to(DEV)
+            out = q.matmul_mxf8_bf16_tn(a, b, to_blocked(sa.view(e8)), to_blocked(sb.view(e8)), al)
+            kind = oracle.KIND_MXFP8_TN_A5 if e5 else oracle.KIND_MXFP8_TN
+            ref = oracle.gemm_blockscaled(kind, _np(a[ri]), _np(b), oracle.to_blocked(_np(sa[ri])), oracle.to_blocked(_np(sb)), alpha, len(rows), n, k)
+            got = oracle.bf16_bits_to_f32(_np(out[ri])).astype(np.float64)
+            want = oracle.bf16_bits_to_f32(ref).astype(np.float64)
+            assert (np.abs(got - want) <= np.abs(want) / 128.0 + 1e-4 * np.abs(want).max()).all(), (it, m, n, k, e5)
