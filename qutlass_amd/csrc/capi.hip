@@ -159,13 +159,13 @@ int launch_gemm_deepp(GemmParams p, hipStream_t s) {
   return check_launch("gemm_mx_deepp_kernel");
 }
 
-template <class C>
-int launch_gemm_deepp8(GemmParams p, hipStream_t s) {   // the fp8 twin (gemm_mx_deepp8), write-through output stores
+template <class C, bool NN = false, int NNABL = 0>
+int launch_gemm_deepp8(GemmParams p, hipStream_t s) {   // the fp8 twin (gemm_mx_deepp8), write-through output stores; NN: A is (K, M)
   p.tiles_m = (int)cdiv(p.M, C::BM);
   p.tiles_n = (int)cdiv(p.N, C::BN);
   p.ws = nullptr; p.splits = 1; p.ctr = nullptr; p.tag = 0;
   const int grid = deepp_grid(p.tiles_m * p.tiles_n);
-  hipLaunchKernelGGL((gemm_mx_deepp8_kernel<C, 17>), dim3(grid), dim3(C::THREADS), 0, s, p);
+  hipLaunchKernelGGL((gemm_mx_deepp8_kernel<C, 17, NN, NNABL>), dim3(grid), dim3(C::THREADS), 0, s, p);
   return check_launch("gemm_mx_deepp8_kernel");
 }
 
@@ -324,10 +324,16 @@ int dispatch_variant_a5(int v, const GemmParams& p, hipStream_t s, const char* n
   }
   return fail(QAMD_ERR_INVALID, "%s: gemm_variant %d has no e5m2-operand instantiation", name, v);
 }
-int launch_nn_fused_a5(const GemmParams& p, hipStream_t s) { return launch_gemm<GemmCfg<256, 256, 2, 2, 8, true, 0, 2, 1>, 6>(p, s); }
+int launch_nn_fused_a5(const GemmParams& p, hipStream_t s, bool per_tile) {
+#if QAMD_BENCH
+  if (per_tile) return launch_gemm<GemmCfg<256, 256, 2, 2, 8, true, 0, 2, 1>, 6>(p, s);
+#endif
+  (void)per_tile;
+  return launch_gemm_deepp8<GemmCfg<256, 256, 2, 2, 8, true, 0, 2, 1>, true>(p, s);
+}
 #else
 ;
-int launch_nn_fused_a5(const GemmParams& p, hipStream_t s);
+int launch_nn_fused_a5(const GemmParams& p, hipStream_t s, bool per_tile);
 #endif
 
 #if QAMD_TU != 0
@@ -338,10 +344,14 @@ extern template int dispatch_variant<4, false>(int, const GemmParams&, hipStream
 #endif
 #if QAMD_TU == 3
 template int dispatch_variant<8, true>(int, const GemmParams&, hipStream_t, const char*);
-template int launch_gemm<GemmCfg<256, 256, 2, 2, 8, true>, 6>(GemmParams, hipStream_t);   // fused (K, M) operand path of matmul_mxf8_bf16_nn
+#if QAMD_BENCH
+template int launch_gemm<GemmCfg<256, 256, 2, 2, 8, true>, 6>(GemmParams, hipStream_t);   // lab: per-tile kernel on the (K, M) operand (round 1)
+#endif
 #else
 extern template int dispatch_variant<8, true>(int, const GemmParams&, hipStream_t, const char*);
+#if QAMD_BENCH
 extern template int launch_gemm<GemmCfg<256, 256, 2, 2, 8, true>, 6>(GemmParams, hipStream_t);
+#endif
 #endif
 #endif
 
@@ -444,7 +454,7 @@ int gemm_mx(const char* name, const void* A, const void* B, const void* A_sf, co
   p.ws = nullptr; p.splits = 1; p.ctr = nullptr; p.tag = 0;
   hipStream_t s = (hipStream_t)stream;
   int variant = opt_gemm_variant();
-  if (variant == 61 || variant == 62) variant = 0;   // these select the NN operand path only (matmul_mxf8_bf16_nn)
+  if (variant >= 61 && variant <= 66) variant = 0;   // these select the NN operand path only (matmul_mxf8_bf16_nn)
   // ring schedule + optional split-K (needs caller scratch; "pp_flags" bit 7 turns split-K off, bit 8 the ring rule)
   const SmallPlan pl = plan_small<EBITS>(M, N, K);
   auto ring_launch = [&](int v, int splits) -> int {
@@ -683,8 +693,10 @@ int qutlass_amd_matmul_mxf8_bf16_tn(const void* A, const void* B, const void* A_
   return gemm_mx<8>("matmul_mxf8_bf16_tn", A, B, A_sf, B_sf, alpha, D, M, N, K, stream);
 }
 
-// one rule for the launcher and the workspace query: the fused (K, M) operand path needs the 256x256 tiles to fill the chip
-static bool mxf8_nn_is_fused(int64_t M, int64_t N) { return cdiv(M, 256) * cdiv(N, 256) >= 192; }
+// one rule for the launcher and the workspace query: the persistent kernel on the (K, M) operand wherever the TN op would
+// pick the persistent 256x256 kernel for the whole problem (gemm_mx auto rule); everything smaller goes through the
+// byte-transpose pre-pass and the TN dispatch with its smaller tiles / split-K
+static bool mxf8_nn_is_fused(int64_t M, int64_t N) { return M > 64 && N > 64 && N < (1ll << 22) && cdiv(M, 256) * cdiv(N, 256) >= 192; }
 
 int64_t qutlass_amd_mxf8_nn_workspace_bytes(int64_t M, int64_t K) { return (M > 0 && K > 0) ? M * K : 0; }
 int64_t qutlass_amd_mxf8_nn_workspace_bytes_for(int64_t M, int64_t N, int64_t K) {
@@ -700,10 +712,10 @@ static int mxf8_nn_impl(const void* A, const void* B, const void* A_sf, const vo
   if (K < 32 || K % 32) return fail(QAMD_ERR_INVALID, "%s: K must be a positive multiple of 32 (got %lld)", name, (long long)K);
   if (M % 16) return fail(QAMD_ERR_INVALID, "%s: M must be a multiple of 16 for the (K, M) operand (got %lld)", name, (long long)M);
   if (M * K >= (1ll << 31)) return fail(QAMD_ERR_INVALID, "%s: operand larger than 2 GiB is not supported", name);
-  // large problems: the fused kernel reads A^T directly (no pre-pass, no workspace); "gemm_variant" 61 forces it, 62 forces
-  // the pre-pass (lab library only)
+  // large problems: the persistent kernel reads A^T directly (no pre-pass, no workspace).  Lab library only: "gemm_variant"
+  // 63 forces it, 61 forces the per-tile fused kernel of round 1 (dword reads + v_perm byte transposes), 62 the pre-pass
   const int forced = opt_gemm_variant();
-  const bool fused = forced == 61 || (forced == 0 && mxf8_nn_is_fused(M, N));
+  const bool fused = forced == 61 || (forced >= 63 && forced <= 66) || (forced == 0 && mxf8_nn_is_fused(M, N));
   if (!fused) {
     if (!workspace) return fail(QAMD_ERR_INVALID, "%s: null pointer argument", name);
     if (workspace_bytes < M * K) return fail(QAMD_ERR_INVALID, "%s: workspace too small (%lld < %lld bytes)", name, (long long)workspace_bytes, (long long)(M * K));
@@ -720,8 +732,16 @@ static int mxf8_nn_impl(const void* A, const void* B, const void* A_sf, const vo
     p.sfa_bytes = (uint32_t)(cdiv(M, 128) * CB * 512); p.sfb_bytes = (uint32_t)(cdiv(N, 128) * CB * 512);
     p.pp_shift = opt_pp_shift(); p.pp_flags = opt_pp_flags(); p.dbg = opt_dbg();
     p.ws = nullptr; p.splits = 1; p.ctr = nullptr; p.tag = 0;
-    if (a_fmt == 1) return launch_nn_fused_a5(p, (hipStream_t)stream);
-    return launch_gemm<GemmCfg<256, 256, 2, 2, 8, true>, 6>(p, (hipStream_t)stream);
+    if (dry_record(forced == 61 ? 61 : 63, p.N, 1)) return 0;
+    if (a_fmt == 1) return launch_nn_fused_a5(p, (hipStream_t)stream, forced == 61);
+#if QAMD_BENCH
+    if (forced == 61) return launch_gemm<GemmCfg<256, 256, 2, 2, 8, true>, 6>(p, (hipStream_t)stream);
+    // timing-only ablations (wrong results): 64 = A fetched with the TN addresses, 65 = A fragments read the TN way, 66 = both
+    if (forced == 64) return launch_gemm_deepp8<GemmCfg<256, 256, 2, 2, 8, true>, true, 1>(p, (hipStream_t)stream);
+    if (forced == 65) return launch_gemm_deepp8<GemmCfg<256, 256, 2, 2, 8, true>, true, 2>(p, (hipStream_t)stream);
+    if (forced == 66) return launch_gemm_deepp8<GemmCfg<256, 256, 2, 2, 8, true>, true, 3>(p, (hipStream_t)stream);
+#endif
+    return launch_gemm_deepp8<GemmCfg<256, 256, 2, 2, 8, true>, true>(p, (hipStream_t)stream);
   }
   TransposeParams t;
   t.in = (const uint8_t*)A; t.out = (uint8_t*)workspace; t.K = (int)K; t.M = (int)M;

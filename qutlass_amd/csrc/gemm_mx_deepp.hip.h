@@ -385,7 +385,7 @@ __device__ __forceinline__ void gemm_mx_deepp(char* smem, const GemmParams& p) {
 // -------------------------------------------------------------------------------------------------------------------------
 constexpr int deepp8_pair_done_at(int s) { return (s >= 1 && s <= 29 && (s - 1) % 4 == 0) ? (s - 1) / 4 : -1; }
 
-template <class C, int ST_AUX = 0>
+template <class C, int ST_AUX = 0, bool NN = false, int NNABL = 0>
 __device__ __forceinline__ void gemm_mx_deepp8(char* smem, const GemmParams& p) {
   static_assert(C::EBITS == 8 && C::F8SPLIT && C::BM == 256 && C::BN == 256 && C::WAVES_M == 2 && C::WAVES_N == 2 && C::NSTAGE == 2 && C::PPW == 1,
                 "persistent deep schedule (fp8): 256x256 tiles, 4 waves of 128x128, split register layout");
@@ -407,14 +407,34 @@ __device__ __forceinline__ void gemm_mx_deepp8(char* smem, const GemmParams& p) 
     m0 = uniform((first_m + rem % gsz) * C::BM);
     n0 = uniform((rem / gsz) * C::BN);
   };
-  struct Desc { __amdgpu_buffer_rsrc_t a, b, s; };
+  // ---- NN: A handed over as (K, M) row-major (matmul_host_mxf8_bf16_nn, gemm.cu:388-434) ---------------------------------
+  // The A stage is DMAed as it lies in memory: [128 k][256 m] bytes (piece q = k-rows 4q .. 4q+3 = 1 KiB, lane = row l/16,
+  // 16-byte chunk l%16), and the row fragments are read with ds_read_b64_tr_b8: per 16 lanes it takes an [8 k][16 m] byte
+  // block (lane i supplies the 8 bytes at row i/2, columns 8 (i%2) ..) and hands lane c column c -- 8 consecutive k of one
+  // m, i.e. a quarter of a K-contiguous fragment row, in the natural row order (tests/native/tr_probe.hip,
+  // profiles/native_r2_tr_probe.txt).  Four of them per fragment replace the two ds_read_b128 of the TN kernel at the same
+  // LDS cycles.  Bank-conflict freedom: a 32-lane pass covers 8 k-rows x 32 bytes; 16-byte chunk c of row k is stored at
+  // chunk c ^ 2 (k & 7), which spreads those 8 rows over all 64 banks.
+  int nn_col0 = 0, nn_v[2] = {0, 0}, nnA0 = 0;
+  if constexpr (NN) {
+    const int kk = lane >> 4, pos = lane & 15;
+#pragma unroll
+    for (int par = 0; par < 2; ++par)   // par = piece parity: k & 7 = 4 par + kk; the parities' chunks differ by ^ 8 (128 bytes)
+      nn_v[par] = kk * p.M + ((pos ^ (2 * (4 * par + kk))) << 4);
+    nn_col0 = (pos ^ (2 * kk)) << 4;
+    // fragment t of this lane: chunk (wave_m * 8 + 2 t + b) ^ 2 r = ((wave_m * 8 + b) ^ 2 r) ^ 2 t  ->  address nnA0 ^ 32 t
+    const int idx = lane & 15, r = idx >> 1, b = (lane >> 4) & 1;
+    nnA0 = (16 * g + r) * 256 + (((cx.wave_m * 8 + b) ^ (2 * r)) << 4) + 8 * (idx & 1);
+  }
+  struct Desc { __amdgpu_buffer_rsrc_t a, b, s; int mrem; };
   auto make_desc = [&](int t) __attribute__((always_inline)) {
     const bool valid = t < ntiles;
     int m0, n0;
     decode(valid ? t : ntiles - 1, m0, n0);
-    const uint32_t a_off = (uint32_t)m0 * rowbytes, b_off = (uint32_t)n0 * rowbytes;
+    const uint32_t a_off = NN ? (uint32_t)m0 : (uint32_t)m0 * rowbytes, b_off = (uint32_t)n0 * rowbytes;
     const uint32_t sa_off = (uint32_t)(m0 >> 7) * CB * 512, sb_off = (uint32_t)(n0 >> 7) * CB * 512;
     Desc d;
+    d.mrem = p.M - m0;   // NN: columns past M would read the next k-row: those lanes fetch out of range (zeros) instead
     d.a = make_rsrc(p.A + a_off, valid ? p.a_bytes - a_off : 0u);
     d.b = make_rsrc(p.B + b_off, valid ? p.b_bytes - b_off : 0u);
     d.s = cx.sIsB ? make_rsrc(p.SFB + sb_off, valid ? p.sfb_bytes - sb_off : 0u) : make_rsrc(p.SFA + sa_off, valid ? p.sfa_bytes - sa_off : 0u);
@@ -427,9 +447,24 @@ __device__ __forceinline__ void gemm_mx_deepp8(char* smem, const GemmParams& p) 
 
   auto read_fa = [&](const int buf, const int j, const int t) __attribute__((always_inline)) {
     const char* st = smem + buf * STAGE;
-    const v4i lo = *(const v4i*)(st + cx.rdA[2 * j] + t * 32 * C::ROWB);
-    const v4i hi = *(const v4i*)(st + cx.rdA[2 * j + 1] + t * 32 * C::ROWB);
-    fa[j][t] = v8i{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    if constexpr (NN && !(NNABL & 2)) {   // (lab: NNABL bit 1 = TN-style fragment reads, timing only)
+      // Inline asm, not __builtin_amdgcn_ds_read_tr8_b64_v2i32: the builtin carries no memory operand, so the compiler's
+      // wait-count pass assumes it may read what an outstanding LDS-DMA is writing and puts s_waitcnt vmcnt(0) in front of
+      // every one of them -- the K loop then waits for the DMA of the NEXT stage before reading this one (65 us against
+      // 58 us for 4096^3, profiles/native_r2_nn_steady.log).  The price: the compiler does not count these reads in
+      // lgkmcnt, so every consumer sits behind an explicit s_waitcnt lgkmcnt(0) (nn_wait below; LDS returns in order, so the
+      // compiler's own lgkmcnt(n) for its tracked reads can only wait longer than it needs, never shorter).
+      const uint32_t a = (uint32_t)(uintptr_t)(lds_ptr_t)(st + (nnA0 ^ (32 * t)));
+      v2i q[4];   // (u, h): k = 64 j + 32 u + 16 g + 8 h .. +7 of row wave_m * 128 + 32 t + i32
+#pragma unroll
+      for (int uh = 0; uh < 4; ++uh)
+        asm volatile("ds_read_b64_tr_b8 %0, %1 offset:%2" : "=v"(q[uh]) : "v"(a), "n"((64 * j + 32 * (uh >> 1) + 8 * (uh & 1)) * 256) : "memory");
+      fa[j][t] = v8i{q[0][0], q[0][1], q[1][0], q[1][1], q[2][0], q[2][1], q[3][0], q[3][1]};
+    } else {
+      const v4i lo = *(const v4i*)(st + cx.rdA[2 * j] + t * 32 * C::ROWB);
+      const v4i hi = *(const v4i*)(st + cx.rdA[2 * j + 1] + t * 32 * C::ROWB);
+      fa[j][t] = v8i{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    }
   };
   auto read_fb = [&](const int buf, const int j, const int t) __attribute__((always_inline)) {
     const char* st = smem + buf * STAGE;
@@ -443,13 +478,31 @@ __device__ __forceinline__ void gemm_mx_deepp8(char* smem, const GemmParams& p) 
 #pragma unroll
     for (int t = 0; t < NT; ++t) read_fb(buf, j, t);
   };
-  auto read_scales = [&](const int buf, const int set) __attribute__((always_inline)) {
+  auto nn_wait = [&]() __attribute__((always_inline)) {   // the asm fragment reads above have landed (see read_fa)
+    if constexpr (NN && !(NNABL & 2)) {
+      __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0), as a builtin: the compiler's scoreboard is cleared with it
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);    // no consumer is scheduled above the wait
+    }
+  };
+  // scale dwords of a stage: loaded raw (the four row fragments' dwords are consecutive: one 16-byte read per operand) and
+  // shifted into place a few MFMAs later, so that no instruction waits on the load right after it was issued
+  v4i sraw[2];
+  auto scales_load = [&](const int buf) __attribute__((always_inline)) {
     const char* st = smem + buf * STAGE;
+    sraw[0] = *(const v4i*)(st + cx.rdSA[0]);
+    sraw[1] = *(const v4i*)(st + cx.rdSB[0]);
+  };
+  auto scales_fin = [&](const int set) __attribute__((always_inline)) {
     const int shift = 8 * g;   // split layout: lanes 0-31 carry K-block 2j, lanes 32-63 K-block 2j + 1
 #pragma unroll
-    for (int t = 0; t < MT; ++t) sa[set][t] = (int)((unsigned)(*(const int*)(st + cx.rdSA[t])) >> shift);
+    for (int t = 0; t < MT; ++t) sa[set][t] = (int)((unsigned)sraw[0][t] >> shift);
 #pragma unroll
-    for (int t = 0; t < NT; ++t) sb[set][t] = (int)((unsigned)(*(const int*)(st + cx.rdSB[t])) >> shift);
+    for (int t = 0; t < NT; ++t) sb[set][t] = (int)((unsigned)sraw[1][t] >> shift);
+  };
+  auto read_scales = [&](const int buf, const int set) __attribute__((always_inline)) {
+    scales_load(buf);
+    scales_fin(set);
   };
   auto mfma1 = [&](const int j, const int sset, const int m, const int n, const bool zero_c) __attribute__((always_inline)) {
     v16f c = acc[m][n];
@@ -458,8 +511,9 @@ __device__ __forceinline__ void gemm_mx_deepp8(char* smem, const GemmParams& p) 
     if (j == 1) acc[m][n] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fb[1][n], fa[1][m], c, 0, C::AFMT, 2, sb[sset][n], 2, sa[sset][m]);
   };
 
-  int vb0 = 0, vb1 = 0, vbS = 0;
-  auto dma_prep = [&](int kt, bool valid) __attribute__((always_inline)) {
+  int vb0 = 0, vb1 = 0, vbS = 0, va0 = 0, va1 = 0;
+  const int nn_rstep = 4 * p.M, nn_kstep = 128 * p.M;   // NN: bytes between consecutive A pieces / K stages
+  auto dma_prep = [&](const Desc& d, int kt, bool valid) __attribute__((always_inline)) {
     int lastmask = (kt == KT - 1) ? -1 : 0;
     int oobm = (valid && kt < KT) ? 0 : -1;
     int oobs = (valid && kt * C::SCT + cx.colS < CB) ? 0 : -1;
@@ -467,10 +521,19 @@ __device__ __forceinline__ void gemm_mx_deepp8(char* smem, const GemmParams& p) 
     vb0 = (((cx.voffT[0] & lastmask) | (cx.voffAB[0] & ~lastmask)) & ~oobm) | ((int)0x80000000 & oobm);
     vb1 = (((cx.voffT[1] & lastmask) | (cx.voffAB[1] & ~lastmask)) & ~oobm) | ((int)0x80000000 & oobm);
     vbS = (cx.voffS & ~oobs) | ((int)0x80000000 & oobs);
+    if constexpr (NN) {   // k-rows past K lie past the end of the tensor (out of range = zeros): no tail variant
+      const int o0 = oobm | (nn_col0 < d.mrem ? 0 : -1), o1 = oobm | ((nn_col0 ^ 128) < d.mrem ? 0 : -1);
+      va0 = (nn_v[0] & ~o0) | ((int)0x80000000 & o0);
+      va1 = (nn_v[1] & ~o1) | ((int)0x80000000 & o1);
+    }
   };
   auto dma_item = [&](const Desc& d, int kt, const int buf, const int item) __attribute__((always_inline)) {
     char* st = smem + buf * STAGE;
-    if (item < 16) {
+    if (NN && !(NNABL & 1) && item < 8) {   // (lab: NNABL bit 0 = TN-style A addresses, timing only)
+      const int q = wave * 8 + item;
+      const int v = ((item & 1) ? va1 : va0) + q * nn_rstep;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(d.a, (lds_ptr_t)(st + q * 1024), 16, v, kt * nn_kstep, 0, QAMD_DMA_AUX);
+    } else if (item < 16) {
       const int t = item & 7, q = wave * 8 + t;
       const int v = ((t & 1) ? vb1 : vb0) + q * cx.rstep;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(item < 8 ? d.a : d.b, (lds_ptr_t)(st + (item < 8 ? 0 : C::OFF_B) + q * 1024), 16, v, kt * C::ROWB, 0, QAMD_DMA_AUX);
@@ -479,7 +542,7 @@ __device__ __forceinline__ void gemm_mx_deepp8(char* smem, const GemmParams& p) 
     }
   };
   auto dma_stage = [&](const Desc& d, int kt, bool valid, const int buf) __attribute__((always_inline)) {
-    dma_prep(kt, valid);
+    dma_prep(d, kt, valid);
 #pragma unroll
     for (int i = 0; i < 17; ++i) dma_item(d, kt, buf, i);
   };
@@ -494,20 +557,27 @@ __device__ __forceinline__ void gemm_mx_deepp8(char* smem, const GemmParams& p) 
   auto stage = [&](auto bufc, auto firstc, const Desc& d, int ktl, bool dvalid) __attribute__((always_inline)) {
     constexpr int BUF = decltype(bufc)::value;
     constexpr bool FIRST = decltype(firstc)::value;
-    read_slice(BUF, 1); fence();
+    // M(0) with R(1) threaded through (one fragment per MFMA: a burst of 16 -- NN: 24 -- LDS reads in front of the MFMAs
+    // overflows the 4-bit lgkmcnt, and the compiler then has to wait for the burst itself before the first MFMA)
+    int idx = 0;
 #pragma unroll
     for (int m = 0; m < MT; ++m)
 #pragma unroll
-      for (int n = 0; n < NT; ++n) mfma1(0, BUF, m, n, FIRST);
-    fence();
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      for (int n = 0; n < NT; ++n) {
+        mfma1(0, BUF, m, n, FIRST);
+        if (idx < 4) read_fa(BUF, 1, idx);
+        else if (idx < 8) read_fb(BUF, 1, idx - 4);
+        fence();
+        ++idx;
+      }
+    __builtin_amdgcn_s_waitcnt(0x0070);   // vmcnt(0) lgkmcnt(0), as a builtin: the compiler's wait-count scoreboard sees it
+    asm volatile("" ::: "memory");
     __builtin_amdgcn_s_barrier();
     fence();
-    read_scales(BUF ^ 1, BUF ^ 1);
-    read_slice(BUF ^ 1, 0);
-    dma_prep(ktl, dvalid);
+    scales_load(BUF ^ 1);
+    dma_prep(d, ktl, dvalid);
     fence();
-    int idx = 0;
+    idx = 0;
 #pragma unroll
     for (int m = 0; m < MT; ++m)
 #pragma unroll
@@ -515,9 +585,13 @@ __device__ __forceinline__ void gemm_mx_deepp8(char* smem, const GemmParams& p) 
         mfma1(1, BUF, m, n, false);
         dma_item(d, ktl, BUF, idx);
         if (idx == 0) dma_item(d, ktl, BUF, 16);
+        if (idx < 4) read_fa(BUF ^ 1, 0, idx);
+        else if (idx < 8) read_fb(BUF ^ 1, 0, idx - 4);
+        if (idx == 8) scales_fin(BUF ^ 1);
         fence();
         ++idx;
       }
+    nn_wait();   // R'(0) was issued 12+ MFMAs ago
     if constexpr (FIRST) pin_acc();
   };
 
@@ -533,6 +607,9 @@ __device__ __forceinline__ void gemm_mx_deepp8(char* smem, const GemmParams& p) 
     const int64_t left = ((int64_t)(p.M - m0) * p.ldd - n0) * 2;
     rD = make_rsrc(p.D + ((int64_t)m0 * p.ldd + n0), (uint32_t)(left > 0x7fffffffll ? 0x7fffffffll : left));
     stLane = ((cx.wave_m * C::WTM + rrl) * p.ldd + cx.wave_n * C::WTN + 8 * ccl) * 2;
+    // opaque: the 32 store offsets stLane + const * ldd are tile-invariant, and the compiler otherwise keeps all of them in
+    // VGPRs across the tile loop (NN: 16 dwords of scratch spills); one v_add per store instead
+    asm volatile("" : "+v"(stLane));
     colLim = p.N - n0 - cx.wave_n * C::WTN - 8 * ccl;
   };
   auto retire_write = [&](const int m, const int h) __attribute__((always_inline)) {
@@ -567,10 +644,11 @@ __device__ __forceinline__ void gemm_mx_deepp8(char* smem, const GemmParams& p) 
     fence();
     mfma1(0, 1, 0, 0, false); mfma1(0, 1, 0, 1, false);   // slice 0 of tiles 0, 1: covers the latency of R(1)
     fence();
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_waitcnt(0x0070);   // vmcnt(0) lgkmcnt(0), as a builtin: the compiler's wait-count scoreboard sees it
+    asm volatile("" ::: "memory");
     __builtin_amdgcn_s_barrier();
     fence();
-    dma_prep(1, dvalid);
+    dma_prep(d, 1, dvalid);
     fence();
     static_for<0, 37>([&](auto sc) __attribute__((always_inline)) {
       constexpr int s = decltype(sc)::value;
@@ -580,7 +658,8 @@ __device__ __forceinline__ void gemm_mx_deepp8(char* smem, const GemmParams& p) 
         mfma1(j, 1, T / 4, T % 4, false);
       }
       if constexpr (s % 2 == 0 && s / 2 < 9) dma_item(d, 1, 1, 8 + s / 2);
-      if constexpr (s == 1) read_scales(0, 0);
+      if constexpr (s == 1) scales_load(0);
+      if constexpr (s == 4) scales_fin(0);
       // slice 0 of the next tile's stage 0, as the registers die: A rows of m after tile (m, 3) (MFMA 8 m + 5), B rows of n after (3, n) (MFMA 23 + 2 n)
       if constexpr (s == 6 || s == 14 || s == 22) read_fa(0, 0, (s - 6) / 8);
       if constexpr (s == 24 || s == 26 || s == 28) read_fb(0, 0, (s - 24) / 2);
@@ -592,7 +671,8 @@ __device__ __forceinline__ void gemm_mx_deepp8(char* smem, const GemmParams& p) 
       if constexpr (P2 >= 0) retire_read(0);
       fence();
     });
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): the retirement reads of the scratch slice (and NN: the asm fragment reads)
+    asm volatile("" ::: "memory");
 #pragma unroll
     for (int i = 0; i < 8; ++i) dma_item(d, 1, 1, i);
     fence();
@@ -607,6 +687,7 @@ __device__ __forceinline__ void gemm_mx_deepp8(char* smem, const GemmParams& p) 
   fence();
   read_scales(0, 0);
   read_slice(0, 0);
+  nn_wait();
   fence();
 
   using I0 = std::integral_constant<int, 0>;
@@ -624,6 +705,7 @@ __device__ __forceinline__ void gemm_mx_deepp8(char* smem, const GemmParams& p) 
       const bool tonext = KTe == 2;
       Desc d;
       d.a = tonext ? nxt.a : cur.a; d.b = tonext ? nxt.b : cur.b; d.s = tonext ? nxt.s : cur.s;
+      d.mrem = tonext ? nxt.mrem : cur.mrem;
       stage(I0{}, BT{}, d, tonext ? 0 : 2, tonext ? nvalid : true);
     }
     for (int kt = 1; kt + 2 < KTe; kt += 2) {
@@ -631,6 +713,7 @@ __device__ __forceinline__ void gemm_mx_deepp8(char* smem, const GemmParams& p) 
       const bool tonext = kt + 3 == KTe;
       Desc d;
       d.a = tonext ? nxt.a : cur.a; d.b = tonext ? nxt.b : cur.b; d.s = tonext ? nxt.s : cur.s;
+      d.mrem = tonext ? nxt.mrem : cur.mrem;
       stage(I0{}, BF{}, d, tonext ? 0 : kt + 3, tonext ? nvalid : true);
     }
     final_stage(nxt, nvalid);
@@ -640,10 +723,10 @@ __device__ __forceinline__ void gemm_mx_deepp8(char* smem, const GemmParams& p) 
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
-template <class C, int ST_AUX = 0>
+template <class C, int ST_AUX = 0, bool NN = false, int NNABL = 0>
 __global__ __launch_bounds__(C::THREADS) void gemm_mx_deepp8_kernel(const GemmParams p) {
   __shared__ __attribute__((aligned(16))) char smem[DeepPCfg<C>::LDS_BYTES];
-  gemm_mx_deepp8<C, ST_AUX>(smem, p);
+  gemm_mx_deepp8<C, ST_AUX, NN, NNABL>(smem, p);
 }
 
 template <class C, bool TRACE = false, int ST_AUX = 0>

@@ -936,19 +936,41 @@ int main(int argc, char** argv) {
     qutlass_amd_set_option("nvf4_variant", 0);
   }
   if (want("nn") || want("gemm")) {
-    for (int force : {61, 62}) {   // 61 = fused A^T operand path, 62 = byte-transpose pre-pass + TN
+    for (int force : {63, 61, 62}) {   // 63 = persistent kernel on the (K, M) operand (tr8 fragment reads), 61 = per-tile fused kernel (v_perm), 62 = byte-transpose pre-pass + TN
       qutlass_amd_set_option("gemm_variant", force);
       printf("matmul_mxf8_bf16_nn path %d\n", force);
       check_bench_nn(16, 64, 256, 0);
       check_bench_nn(272, 520, 1056, 0);
       check_bench_nn(1040, 776, 2080, 0);
       check_bench_nn(4096, 4096, 4096, 20);
+      if (force != 62) { check_bench_nn(4112, 4360, 4128, 20); check_bench_nn(8192, 8192, 8192, 10); }
       qutlass_amd_set_option("gemm_variant", 0);
     }
     check_bench_nn(16, 64, 256, 0);
     check_bench_nn(272, 520, 1056, 0);
     check_bench_nn(16, 4096, 4096, 20);
     check_bench_nn(4096, 4096, 4096, 20);
+  }
+  if (want("nnsteady")) {   // run with QAMD_STEADY_MS=60: (K, M) operand kernels against TN in the steady state, strides M = 4096 / 8192 / non-power-of-two
+    for (int force : {63, 61}) {
+      qutlass_amd_set_option("gemm_variant", force);
+      printf("matmul_mxf8_bf16_nn path %d\n", force);
+      check_bench_nn(4096, 4096, 4096, 100);
+      check_bench_nn(4096, 4096, 8192, 50);
+      check_bench_nn(8192, 4096, 4096, 50);
+      check_bench_nn(8192, 8192, 8192, 20);
+      check_bench_nn(8448, 8192, 8192, 20);
+      check_bench_nn(4096, 14336, 4096, 50);
+      qutlass_amd_set_option("gemm_variant", 0);
+    }
+    // where the difference to TN comes from (results are wrong with these flags: timing only)
+    for (int v : {63, 64, 65, 66, 63}) {
+      qutlass_amd_set_option("gemm_variant", v);
+      printf("persistent NN kernel, variant %d (64: A fetched with TN addresses, 65: A fragments read as TN, 66: both)\n", v);
+      check_bench_nn(4096, 4096, 4096, 100);
+    }
+    qutlass_amd_set_option("pp_flags", 0);
+    qutlass_amd_set_option("gemm_variant", 0);
   }
   if (want("gemm")) {
     for (int var : {2, 1, 3, 4, 5, 6, 7, 8, 9, 20, 24, 25, 26}) {

@@ -521,8 +521,10 @@ def test_matmul_mxf8_nn_equals_tn_and_oracle(q, golden_dir, m, n, k):
     out_tn = q.matmul_mxf8_bf16_tn(a_t, b_t, sa, sb, alpha)
     assert out_nn.shape == (m, n) and out_nn.dtype == torch.bfloat16
     assert torch.equal(out_nn.view(torch.int16), out_tn.view(torch.int16))
-    # both operand paths explicitly: 61 = fused (A^T tiles transposed on the LDS -> register path), 62 = byte-transpose pre-pass
-    for path in (61, 62):
+    # every operand path explicitly: 63 = persistent kernel on the (K, M) operand (ds_read_b64_tr_b8 fragment reads; the
+    # product's choice for large problems), 61 = per-tile fused kernel of round 1 (v_perm byte transposes; lab only),
+    # 62 = byte-transpose pre-pass + TN
+    for path in (63, 61, 62):
         with lab.forced(gemm_variant=path):
             o = lab.matmul_mxf8_bf16_nn(a_km, b_t, sa, sb, alpha)
         assert torch.equal(o.view(torch.int16), out_tn.view(torch.int16)), path
