@@ -100,7 +100,7 @@ int qutlass_amd_matmul_mxf8_bf16_tn_ws(const void* A, const void* B, const void*
  * workspace: caller-owned device scratch, used on `stream` only for the duration of the call's kernels (the library
  * itself never allocates).  Small problems re-lay A as (M, K) with a byte-transpose pre-pass and then run the TN kernel:
  * they need M * K bytes.  Problems whose 256x256 tiles fill the chip read the (K, M) operand directly and need NONE.
- * qutlass_amd_mxf8_nn_workspace_bytes_for(M, N, K) returns what THIS shape needs (0 for the fused path: workspace may be
+ * qutlass_amd_mxf8_nn_workspace_bytes_for(M, N, K) returns what THIS shape needs (0 for the in-place path: workspace may be
  * NULL); qutlass_amd_mxf8_nn_workspace_bytes(M, K) is the shape-independent upper bound M * K.
  * Replaces matmul_host_mxf8_bf16_nn (gemm.cu:388-434; bindings.cpp:179-216).
  */

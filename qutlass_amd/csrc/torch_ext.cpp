@@ -156,7 +156,7 @@ Tensor matmul(const Tensor& A, const Tensor& B, const Tensor& A_sf, const Tensor
   else if (G == Gemm::NVF4) rc = qutlass_amd_matmul_nvf4_bf16_tn(A.data_ptr(), B.data_ptr(), A_sf.data_ptr(), B_sf.data_ptr(), al, out.data_ptr(), M, N, K, s);
   else {
     // scratch for the (K, M) -> (M, K) re-layout of small problems, from torch's stream-ordered caching allocator; shapes
-    // that take the fused operand path need none (0 bytes: nothing is allocated)
+    // that read the (K, M) operand in place need none (0 bytes: nothing is allocated)
     const int64_t ws_bytes = qutlass_amd_mxf8_nn_workspace_bytes_for(M, N, K);
     Tensor ws = ws_bytes > 0 ? torch::stable::new_empty(A, {ws_bytes}, ScalarType::Byte) : Tensor();
     rc = qutlass_amd_matmul_mxf8_bf16_nn_fmt(A.data_ptr(), B.data_ptr(), A_sf.data_ptr(), B_sf.data_ptr(), al, out.data_ptr(), M, N, K,
