@@ -130,7 +130,7 @@ template <class C, int PP>
 int launch_gemm(GemmParams p, hipStream_t s) {
   p.tiles_m = (int)cdiv(p.M, C::BM);
   p.tiles_n = (int)cdiv(p.N, C::BN);
-  if (PP != 7) { p.ws = nullptr; p.splits = 1; p.ctr = nullptr; p.tag = 0; }   // only the (blocked-scale) ring schedule knows about split-K
+  if (PP != 7 && PP != 9) { p.ws = nullptr; p.splits = 1; p.ctr = nullptr; p.tag = 0; }   // only the (blocked-scale) ring schedules know about split-K
   hipLaunchKernelGGL((gemm_mx_kernel<C, PP>), dim3(p.tiles_m * p.tiles_n, p.splits), dim3(C::THREADS), 0, s, p);
   return check_launch("gemm_mx_kernel");
 }
@@ -220,18 +220,25 @@ int dispatch_ablation_mx4(int v, const GemmParams& p, hipStream_t s);
 
 template <int EBITS, bool SPLIT>
 int dispatch_variant(int v, const GemmParams& p, hipStream_t s, const char* name) {
-  if (dry_record(v, p.N, (v >= 70 && v <= 78) ? p.splits : 1)) return 0;
+#if QAMD_BENCH
+  if ((p.pp_flags & 4096) && v >= 70 && v <= 73) v += 100;   // lab: "pp_flags" bit 12 = the round-1 ring schedule wherever a ring kernel is picked
+#endif
+  if (dry_record(v, p.N, ((v >= 70 && v <= 78) || (v >= 170 && v <= 173)) ? p.splits : 1)) return 0;
   switch (v) {
     case 24: return launch_gemm<GemmCfg<128, 128, 2, 2, EBITS, SPLIT>, 3>(p, s);   // simple schedule
     case 25: return launch_gemm<GemmCfg<256, 128, 4, 2, EBITS, SPLIT>, 3>(p, s);
     case 27: return launch_gemm<GemmCfg<128, 64, 2, 2, EBITS, SPLIT>, 3>(p, s);    // mid-size problems: more, smaller tiles
     case 28: return launch_gemm<GemmCfg<64, 128, 2, 2, EBITS, SPLIT>, 3>(p, s);
     case 29: return launch_gemm<GemmCfg<64, 64, 2, 2, EBITS, SPLIT>, 3>(p, s);
-    case 70: return launch_gemm<GemmCfg<64, 64, 2, 2, EBITS, SPLIT, 0, 3>, 7>(p, s);     // ring schedule: NSTAGE-deep LDS ring, NSTAGE-1 stages in flight
-    case 71: return launch_gemm<GemmCfg<128, 64, 2, 2, EBITS, SPLIT, 0, 3>, 7>(p, s);
-    case 72: return launch_gemm<GemmCfg<64, 128, 2, 2, EBITS, SPLIT, 0, 3>, 7>(p, s);
-    case 73: return launch_gemm<GemmCfg<128, 128, 2, 2, EBITS, SPLIT, 0, 3>, 7>(p, s);
+    case 70: return launch_gemm<GemmCfg<64, 64, 2, 2, EBITS, SPLIT, 0, 3>, 9>(p, s);     // pipelined ring schedule: NSTAGE-deep LDS ring, NSTAGE-1 stages in flight,
+    case 71: return launch_gemm<GemmCfg<128, 64, 2, 2, EBITS, SPLIT, 0, 3>, 9>(p, s);    //   fragments of the next stage read during this stage's MFMAs
+    case 72: return launch_gemm<GemmCfg<64, 128, 2, 2, EBITS, SPLIT, 0, 3>, 9>(p, s);
+    case 73: return launch_gemm<GemmCfg<128, 128, 2, 2, EBITS, SPLIT, 0, 3>, 9>(p, s);
 #if QAMD_BENCH
+    case 170: return launch_gemm<GemmCfg<64, 64, 2, 2, EBITS, SPLIT, 0, 3>, 7>(p, s);    // the round-1 ring schedule (whole-stage reads after the barrier, then the MFMAs)
+    case 171: return launch_gemm<GemmCfg<128, 64, 2, 2, EBITS, SPLIT, 0, 3>, 7>(p, s);
+    case 172: return launch_gemm<GemmCfg<64, 128, 2, 2, EBITS, SPLIT, 0, 3>, 7>(p, s);
+    case 173: return launch_gemm<GemmCfg<128, 128, 2, 2, EBITS, SPLIT, 0, 3>, 7>(p, s);
     case 1: return launch_gemm<GemmCfg<256, 256, 2, 4, EBITS, SPLIT>, 1>(p, s);
     case 2: return launch_gemm<GemmCfg<128, 128, 2, 2, EBITS, SPLIT>, 0>(p, s);
     case 3: return launch_gemm<GemmCfg<256, 128, 4, 2, EBITS, SPLIT>, 0>(p, s);
@@ -317,10 +324,10 @@ int dispatch_variant_a5(int v, const GemmParams& p, hipStream_t s, const char* n
     case 28: return launch_gemm<GemmCfg<64, 128, 2, 2, 8, true, 0, 2, 1>, 3>(p, s);
     case 29: return launch_gemm<GemmCfg<64, 64, 2, 2, 8, true, 0, 2, 1>, 3>(p, s);
     case 90: return launch_gemm_deepp8<GemmCfg<256, 256, 2, 2, 8, true, 0, 2, 1>>(p, s);
-    case 70: return launch_gemm<GemmCfg<64, 64, 2, 2, 8, true, 0, 3, 1>, 7>(p, s);
-    case 71: return launch_gemm<GemmCfg<128, 64, 2, 2, 8, true, 0, 3, 1>, 7>(p, s);
-    case 72: return launch_gemm<GemmCfg<64, 128, 2, 2, 8, true, 0, 3, 1>, 7>(p, s);
-    case 73: return launch_gemm<GemmCfg<128, 128, 2, 2, 8, true, 0, 3, 1>, 7>(p, s);
+    case 70: return launch_gemm<GemmCfg<64, 64, 2, 2, 8, true, 0, 3, 1>, 9>(p, s);
+    case 71: return launch_gemm<GemmCfg<128, 64, 2, 2, 8, true, 0, 3, 1>, 9>(p, s);
+    case 72: return launch_gemm<GemmCfg<64, 128, 2, 2, 8, true, 0, 3, 1>, 9>(p, s);
+    case 73: return launch_gemm<GemmCfg<128, 128, 2, 2, 8, true, 0, 3, 1>, 9>(p, s);
   }
   return fail(QAMD_ERR_INVALID, "%s: gemm_variant %d has no e5m2-operand instantiation", name, v);
 }
@@ -677,7 +684,10 @@ int qutlass_amd_matmul_ada_mxf4_bf16_tn(const void* A, const void* B, const void
     p.sfa_bytes = (uint32_t)(M * (K / 32)); p.sfb_bytes = (uint32_t)(N * (K / 32));   // row-major (rows, K/32), un-swizzled
     p.pp_shift = opt_pp_shift(); p.pp_flags = opt_pp_flags(); p.dbg = opt_dbg();
     p.ws = nullptr; p.splits = 1; p.ctr = nullptr; p.tag = 0;
-    return launch_gemm<GemmCfg<64, 64, 2, 2, 4, false, 0, 3>, 8>(p, (hipStream_t)stream);
+#if QAMD_BENCH
+    if (opt_gemm_variant() == 178) return launch_gemm<GemmCfg<64, 64, 2, 2, 4, false, 0, 3>, 8>(p, (hipStream_t)stream);   // round-1 ring schedule
+#endif
+    return launch_gemm<GemmCfg<64, 64, 2, 2, 4, false, 0, 3>, 10>(p, (hipStream_t)stream);
   }
   SkinnyParams q;
   q.A = (const uint8_t*)A; q.B = (const uint8_t*)B; q.SFA = (const uint8_t*)A_sf; q.SFB = (const uint8_t*)B_sf;

@@ -1528,6 +1528,197 @@ __device__ __forceinline__ void gemm_mx_ring(char* smem, const GemmParams& p) {
   cx.trace_dump();
 }
 
+// ================================================================================================
+// Pipelined ring schedule (product: ring variants 70..73 and the row-major-scale kernel of matmul_ada_mxf4_bf16_tn).
+// Same LDS ring, same DMA stream, same K order -> bit-identical results.  What changes is WHEN a wave reads its fragments:
+// gemm_mx_ring reads the whole stage after the barrier and waits for it before the first MFMA -- with one workgroup of
+// four waves per CU (the ring fills the LDS) nothing else runs in the meantime: ~450 cycles of exposed LDS latency per
+// stage against 128 (64x64 tiles) .. 512 (128x128) cycles of MFMAs.  Here the fragments live in TWO register sets: while
+// the MFMAs of stage kt issue from one set, the reads of stage kt+1 into the other set and the DMA of stage kt+D are
+// threaded between them, one or two per MFMA.  Per stage:
+//     lgkmcnt(0) [stage kt in registers] ; own DMA of stage kt+1 landed ; BARRIER
+//     MFMAs(kt) interleaved with  reads(kt+1 -> other set)  and  DMA(kt+D -> the slot of stage kt, free since the barrier)
+// The ring is unrolled lcm(D, 2) times so that slot addresses are immediates and register sets alternate statically.
+// ================================================================================================
+// order of the auxiliary instructions of a pipelined-ring stage: position a of nr + nd -> read unit (>= 0) or DMA item (-1 - index);
+// a DMA item after every second read unit, whatever is left of either kind at the end
+constexpr int ringp_aux_item(int a, int nr, int nd) {
+  int r = 0, d = 0, last = 0;
+  for (int pos = 0; pos <= a; ++pos) {
+    const bool dma = (r >= nr) || (d < nd && pos % 3 == 2);
+    if (dma) last = -1 - d++;
+    else last = r++;
+  }
+  return last;
+}
+
+template <class C, bool RM = false>
+__device__ __forceinline__ void gemm_mx_ringp(char* smem, const GemmParams& p) {
+  constexpr int KSL = C::KSL, D = C::NSTAGE, MT = C::MT, NT = C::NT, CPS = C::CPS;
+  constexpr int LPS = C::NA + C::NB + 1;            // DMA instructions per wave per stage
+  constexpr int U = (D % 2 == 0) ? D : 2 * D;       // unroll: slot = u % D, register set = u & 1
+  static_assert(D >= 3 && (D - 2) * LPS <= 63, "vmcnt immediate");
+  static_assert(!RM || (C::EBITS == 4 && C::BM == 64 && C::BN == 64 && C::NWAVES == 4), "row-major scales: 64x64 fp4 tiles");
+  static_assert(C::ABL == 0, "no ablation builds of this schedule");
+  GemmCtx<C> cx(smem, p);
+  __amdgpu_buffer_rsrc_t rSrm = cx.rS;
+  int vSrm = 0x7fffffff;
+  const int KBr = p.K >> 5;                         // scale bytes per row (row-major)
+  if (RM) {
+    const int opB = cx.wave >> 1, dw = cx.wave & 1;
+    const uint32_t row0 = opB ? (uint32_t)cx.n0 : (uint32_t)cx.m0;
+    const uint32_t total = opB ? p.sfb_bytes : p.sfa_bytes, off = row0 * (uint32_t)KBr;
+    rSrm = make_rsrc((opB ? p.SFB : p.SFA) + off, total > off ? total - off : 0);   // rows past M / N fall off the end -> 0
+    vSrm = cx.lane * KBr + dw * 4;
+#pragma unroll
+    for (int t = 0; t < MT; ++t) cx.rdSA[t] = C::OFF_S + cx.g * 256 + (cx.wave_m * C::WTM + 32 * t + cx.i32) * 4;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) cx.rdSB[t] = C::OFF_S + 512 + cx.g * 256 + (cx.wave_n * C::WTN + 32 * t + cx.i32) * 4;
+  }
+  auto fence = [&]() __attribute__((always_inline)) { __builtin_amdgcn_sched_barrier(0); };
+  int kt0 = 0, kt1 = cx.KT;
+  if (p.splits > 1) {
+    const int per = (cx.KT + p.splits - 1) / p.splits;
+    kt0 = uniform((int)blockIdx.y * per);
+    kt1 = min(cx.KT, kt0 + per);
+  }
+  int vA[C::NA], vAT[C::NA], vB[C::NB], vBT[C::NB];
+#pragma unroll
+  for (int t = 0; t < C::NA; ++t) {
+    const int q = cx.wave * C::NA + t;
+    vA[t] = cx.voffAB[q & 1] + q * cx.rstep;
+    vAT[t] = cx.voffT[q & 1] == 0x7fffffff ? 0x7fffffff : cx.voffT[q & 1] + q * cx.rstep;
+  }
+#pragma unroll
+  for (int t = 0; t < C::NB; ++t) {
+    const int q = cx.wave * C::NB + t;
+    vB[t] = cx.voffAB[q & 1] + q * cx.rstep;
+    vBT[t] = cx.voffT[q & 1] == 0x7fffffff ? 0x7fffffff : cx.voffT[q & 1] + q * cx.rstep;
+  }
+  // one DMA instruction of stage kt (item 0 .. LPS-1: A pieces, B pieces, the scale piece); stages past the range re-load
+  // the last one into a free slot that is never used: keeps the vmcnt arithmetic uniform
+  int d_soff = 0, d_last = 0, d_ktc = 0;
+  auto dma_prep = [&](int kt) __attribute__((always_inline)) {
+    d_ktc = min(kt, kt1 - 1);
+    d_soff = d_ktc * C::ROWB;
+    d_last = (cx.ktail && d_ktc == cx.KT - 1) ? -1 : 0;
+    asm volatile("" : "+v"(d_last));
+  };
+  auto dma_item = [&](const int slot, const int item) __attribute__((always_inline)) {
+    char* st = smem + slot * C::STAGE_BYTES;
+    if (item < C::NA) {
+      const int t = item, v = (vAT[t] & d_last) | (vA[t] & ~d_last);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(cx.rA, (lds_ptr_t)(st + (cx.wave * C::NA + t) * 1024), 16, v, d_soff, 0, QAMD_DMA_AUX);
+    } else if (item < C::NA + C::NB) {
+      const int t = item - C::NA, v = (vBT[t] & d_last) | (vB[t] & ~d_last);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(cx.rB, (lds_ptr_t)(st + C::OFF_B + (cx.wave * C::NB + t) * 1024), 16, v, d_soff, 0, QAMD_DMA_AUX);
+    } else if (RM) {
+      const int vs = (d_ktc * 8 + (cx.wave & 1) * 4 < KBr) ? vSrm : 0x7fffffff;   // K tail: the stage's second scale dword does not exist
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rSrm, (lds_ptr_t)(st + C::OFF_S + cx.wave * 256), 4, vs, d_ktc * 8, 0, 0);
+    } else {
+      const int vs = (d_ktc * C::SCT + cx.colS < cx.CB) ? cx.voffS : 0x7fffffff;   // K tail: no such scale column tile
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(cx.rS, (lds_ptr_t)(st + C::OFF_S + cx.wave * 1024), 16, vs, d_ktc * C::SCT * 512, 0, 0);
+    }
+  };
+  auto issue = [&](int kt, const int slot) __attribute__((always_inline)) {
+    dma_prep(kt);
+#pragma unroll
+    for (int i = 0; i < LPS; ++i) dma_item(slot, i);
+  };
+
+  // two register sets: fragments of a whole stage + its raw scale dwords
+  v8i fa[2][KSL][MT], fb[2][KSL][NT];
+  int sa[2][MT], sb[2][NT];
+  // read unit r of a stage: 0 = the A scale dwords, 1 = the B scale dwords, then per slice the MT A fragments and NT B fragments
+  constexpr int NRU = 2 + KSL * (MT + NT);
+  auto read_unit = [&](const int slot, const int set, const int r) __attribute__((always_inline)) {
+    const char* st = smem + slot * C::STAGE_BYTES;
+    if (r == 0) {
+#pragma unroll
+      for (int t = 0; t < MT; ++t) sa[set][t] = *(const int*)(st + cx.rdSA[t]);
+    } else if (r == 1) {
+#pragma unroll
+      for (int t = 0; t < NT; ++t) sb[set][t] = *(const int*)(st + cx.rdSB[t]);
+    } else {
+      const int j = (r - 2) / (MT + NT), t = (r - 2) % (MT + NT);
+      const int boff = (t < MT) ? t * 32 * C::ROWB : cx.rdBd + (t - MT) * 32 * C::ROWB;
+      const v4i lo = *(const v4i*)(st + boff + cx.rdA[j * CPS]);
+      v4i hi = {0, 0, 0, 0};
+      if (CPS == 2) hi = *(const v4i*)(st + boff + cx.rdA[j * CPS + CPS - 1]);
+      const v8i v = v8i{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      if (t < MT) fa[set][j][t] = v; else fb[set][j][t - MT] = v;
+    }
+  };
+  constexpr int FMT = (C::EBITS == 4) ? 4 : 0, FMTA = (C::EBITS == 4) ? 4 : C::AFMT;
+  auto mfma1 = [&](const int set, const int j, const int m, const int n) __attribute__((always_inline)) {
+    const int ops = (C::EBITS == 8 && C::F8SPLIT) ? 2 * j : j;
+    v16f& c = cx.acc[m][n];
+    if (ops == 0) c = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fb[set][j][n], fa[set][j][m], c, FMT, FMTA, 0, sb[set][n], 0, sa[set][m]);
+    if (ops == 1) c = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fb[set][j][n], fa[set][j][m], c, FMT, FMTA, 1, sb[set][n], 1, sa[set][m]);
+    if (ops == 2) c = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fb[set][j][n], fa[set][j][m], c, FMT, FMTA, 2, sb[set][n], 2, sa[set][m]);
+    if (ops == 3) c = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fb[set][j][n], fa[set][j][m], c, FMT, FMTA, 3, sb[set][n], 3, sa[set][m]);
+  };
+  const int sshift = (C::EBITS == 4) ? 0 : (C::F8SPLIT ? 8 * cx.g : 16 * cx.g);   // fp8: bring "my" first scale byte down
+  auto top = [&](const int set) __attribute__((always_inline)) {
+    __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0), as a builtin (the compiler's scoreboard sees it): this stage's fragments are in registers
+    if (C::EBITS == 8) {
+#pragma unroll
+      for (int t = 0; t < MT; ++t) sa[set][t] = (int)((unsigned)sa[set][t] >> sshift);
+#pragma unroll
+      for (int t = 0; t < NT; ++t) sb[set][t] = (int)((unsigned)sb[set][t] >> sshift);
+    }
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 2) * LPS) : "memory");   // own pieces of the NEXT stage landed (DMA retires in order)
+    __builtin_amdgcn_s_barrier();
+    fence();
+  };
+  // MFMAs of stage kt (set `set`) with the reads of stage kt+1 (slot `nslot` -> the other set) and the DMA of stage kt+D (-> `slot`)
+  // threaded through; auxiliary item i of NAUX goes after MFMA floor(i * NM / NAUX)
+  constexpr int NM = KSL * MT * NT, NAUX = NRU + LPS;
+  auto stage = [&](int kt, auto slotc, auto setc) __attribute__((always_inline)) {
+    constexpr int slot = decltype(slotc)::value, set = decltype(setc)::value, nslot = (slot + 1) % D;
+    top(set);
+    dma_prep(kt + D);
+    fence();
+    static_for<0, NM>([&](auto ic) __attribute__((always_inline)) {
+      constexpr int i = decltype(ic)::value;
+      constexpr int j = i / (MT * NT), m = (i / NT) % MT, n = i % NT;
+      mfma1(set, j, m, n);
+      // auxiliary items [i * NAUX / NM, (i + 1) * NAUX / NM): reads first-come, a DMA item after every second read unit
+      static_for<i * NAUX / NM, (i + 1) * NAUX / NM>([&](auto ac) __attribute__((always_inline)) {
+        constexpr int a = decltype(ac)::value;
+        constexpr int code = ringp_aux_item(a, NRU, LPS);   // >= 0: read unit, < 0: DMA item -1 - code
+        if constexpr (code >= 0) read_unit(nslot, set ^ 1, code);
+        else dma_item(slot, -1 - code);
+      });
+      fence();
+    });
+  };
+
+#pragma unroll
+  for (int s = 0; s < D - 1; ++s) issue(kt0 + s, s);
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 2) * LPS) : "memory");   // stage kt0 landed
+  __builtin_amdgcn_s_barrier();
+  fence();
+#pragma unroll
+  for (int r = 0; r < NRU; ++r) read_unit(0, 0, r);
+  issue(kt0 + D - 1, D - 1);
+  fence();
+  for (int kt = kt0; kt < kt1; kt += U) {
+    static_for<0, U>([&](auto uc) __attribute__((always_inline)) {
+      constexpr int u = decltype(uc)::value;
+      if (u == 0 || kt + u < kt1) stage(kt + u, std::integral_constant<int, u % D>{}, std::integral_constant<int, u & 1>{});
+    });
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the trailing re-loads must land before the epilogue reuses the LDS
+  __builtin_amdgcn_s_waitcnt(0xc07f);                // and the look-ahead reads of the stage past the end
+#if QAMD_BENCH
+  if (p.splits > 1 && p.ctr) cx.epilogue_splitk_fused(blockIdx.y);
+  else
+#endif
+  if (p.splits > 1) cx.epilogue_partial(blockIdx.y);
+  else cx.epilogue();
+}
+
 // split-K second pass: D = bf16(alpha * sum_z ws[z]) in fixed z order (deterministic); 4 columns per thread.  S is a
 // template parameter so that all S loads of a thread are in flight together (a runtime loop serialises S memory round
 // trips: 4.8 us for a 1 MB output).
@@ -1554,7 +1745,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 }
 
 // One __global__ entry per (config, schedule).
-enum { SCHED_LOCKSTEP = 0, SCHED_PINGPONG = 1, SCHED_QUEUE = 2, SCHED_SIMPLE = 3, SCHED_DEEP = 4, SCHED_REGSTAGE = 5, SCHED_DEEP_NN = 6, SCHED_RING = 7, SCHED_RING_RM = 8 };
+enum { SCHED_LOCKSTEP = 0, SCHED_PINGPONG = 1, SCHED_QUEUE = 2, SCHED_SIMPLE = 3, SCHED_DEEP = 4, SCHED_REGSTAGE = 5, SCHED_DEEP_NN = 6, SCHED_RING = 7, SCHED_RING_RM = 8, SCHED_RINGP = 9, SCHED_RINGP_RM = 10 };
 template <class C, int SCHED>
 __global__ __launch_bounds__(C::THREADS) void gemm_mx_kernel(const GemmParams p) {
   __shared__ __attribute__((aligned(16))) char smem[C::LDS_BYTES];
@@ -1562,7 +1753,9 @@ __global__ __launch_bounds__(C::THREADS) void gemm_mx_kernel(const GemmParams p)
   // 100 MHz wall-clock duration, i.e. the clock the chip actually ran at under this kernel's power draw
   const bool clk = (C::ABL & ABL_CLOCK) && p.dbg && blockIdx.x == 0 && threadIdx.x == 0;
   const uint64_t c0 = clk ? __builtin_readcyclecounter() : 0, r0 = clk ? __builtin_amdgcn_s_memrealtime() : 0;
-  if constexpr (SCHED == SCHED_RING_RM) gemm_mx_ring<C, true>(smem, p);
+  if constexpr (SCHED == SCHED_RINGP_RM) gemm_mx_ringp<C, true>(smem, p);
+  else if constexpr (SCHED == SCHED_RINGP) gemm_mx_ringp<C>(smem, p);
+  else if constexpr (SCHED == SCHED_RING_RM) gemm_mx_ring<C, true>(smem, p);
   else if constexpr (SCHED == SCHED_RING) gemm_mx_ring<C>(smem, p);
   else if constexpr (SCHED == SCHED_REGSTAGE) gemm_mx_regstage<C>(smem, p);
   else if constexpr (SCHED == SCHED_DEEP_NN) gemm_mx_deep8<C, true>(smem, p);

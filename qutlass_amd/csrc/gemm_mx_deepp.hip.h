@@ -40,13 +40,6 @@ struct DeepPCfg {
 // final: e(P) = 8 P + 3; inverse (-1: none)
 constexpr int deepp_pair_done_at(int s) { return (s >= 3 && s <= 59 && (s - 3) % 8 == 0) ? (s - 3) / 8 : -1; }
 
-template <int I, int N, class F>
-__device__ __forceinline__ void static_for(F&& f) {
-  if constexpr (I < N) {
-    f(std::integral_constant<int, I>{});
-    static_for<I + 1, N>(f);
-  }
-}
 
 // TRACE (lab build only): workgroup 0, wave 0 writes {shader cycles, 100 MHz wall ticks} pairs to p.dbg at: kernel entry,
 // first stage landed, entry of the last stage of every tile, end of that stage, kernel exit (after the last store ack).

@@ -882,6 +882,43 @@ int main(int argc, char** argv) {
         }
       }
   }
+  if (want("ringp")) {   // pipelined ring schedule (product 70..73 + the row-major-scale kernel) vs the oracle, and vs the round-1 ring ("pp_flags" bit 12) on the auto rules
+    for (int var : {70, 71, 72, 73, 77, 0}) {
+      for (int kind : {0, 2}) {
+        const bool tol = kind == 2;
+        check_gemm("ringp config1", kind, 256, 256, 512, 1.0f, 3, 0, var, tol);
+        check_gemm("ringp tiny-K (1 stage)", kind, 128, 128, 128, 1.0f, 3, 0, var, tol);
+        check_gemm("ringp 2 stages", kind, 128, 192, kind == 2 ? 256 : 512, 1.0f, 3, 0, var, tol);
+        check_gemm("ringp 5 stages", kind, 136, 200, kind == 2 ? 640 : 1280, 1.0f, 3, 0, var, tol);
+        check_gemm("ringp 7 stages + K tail", kind, 72, 136, kind == 2 ? 800 : 1664, 0.5f, 4, 0, var, tol);
+        check_gemm("ringp ragged + K tail", kind, 72, 136, 640, 0.5f, 4, 0, var, tol);
+        check_gemm("ringp M=1", kind, 1, 504, 1024, 1.0f, 2, 0, var, tol);
+        check_gemm("ringp 504x504x2048", kind, 504, 504, 2048, 1.0f, 3, 0, var, tol);
+        check_gemm("ringp 200x264x7168", kind, 200, 264, 7168, 1.0f, 3, 0, var, tol);
+        check_gemm("ringp 64x512x14336 (split-K when auto / 77)", kind, 64, 512, 14336, 0.5f, 3, 0, var, tol);
+        check_gemm("ringp 40x1032x4224 (split-K, K tail)", kind, 40, 1032, kind == 2 ? 4256 : 4224, 1.0f, 3, 0, var, tol);
+      }
+    }
+    const int64_t shapes[][2] = {{4096, 14336}, {4096, 4096}, {14336, 4096}, {8192, 8192}};
+    for (auto& sh : shapes)
+      for (int64_t M : {16, 64, 128, 256, 512, 1024}) {
+        for (int fl : {0, 4096}) {
+          qutlass_amd_set_option("pp_flags", fl);
+          char tag[96];
+          snprintf(tag, sizeof tag, "mxfp4 M=%lld N=%lld K=%lld auto, %s", (long long)M, (long long)sh[0], (long long)sh[1], fl ? "round-1 ring" : "pipelined ring");
+          bench_gemm(tag, 0, M, sh[0], sh[1], 0, 100);
+        }
+        qutlass_amd_set_option("pp_flags", 0);
+      }
+    for (int64_t M : {64, 256, 1024})
+      for (int fl : {0, 4096}) {
+        qutlass_amd_set_option("pp_flags", fl);
+        char tag[96];
+        snprintf(tag, sizeof tag, "mxfp8 M=%lld N=4096 K=4096 auto, %s", (long long)M, fl ? "round-1 ring" : "pipelined ring");
+        bench_gemm(tag, 2, M, 4096, 4096, 0, 100);
+        qutlass_amd_set_option("pp_flags", 0);
+      }
+  }
   if (want("ring")) {   // ring schedule (70: 64x64 x6, 71: 128x64 x5, 72: 64x128 x5, 73: 128x128 x4, 74: 64x64 x3) vs the 2-stage simple schedule
     for (int var : {70, 71, 72, 73, 74, 75, 77, 0}) {
       for (int kind : {0, 2}) {
