@@ -130,6 +130,25 @@ __global__ __launch_bounds__(256) void fused_quantize_kernel(const QuantParams p
   const int tid = threadIdx.x, lane = tid & 63, wave = uniform(tid >> 6);
   const int row = lane & 31, half = lane >> 5;
 
+  // x as rows of RP elements (for R = 16 two rotation rows share one 32-element "row")
+  const int64_t ngroups = p.numel / (NV ? 16 : 32);
+  const __amdgpu_buffer_rsrc_t rx = make_rsrc(p.x, (uint32_t)(p.numel * 2));
+
+  const int wave_global = blockIdx.x * 4 + wave, nwaves = gridDim.x * 4;
+  v4i xnext[RP / 16];
+  // per-lane byte offset inside a tile and the step between a lane's loads: MFMA layout (row, half; 32 bytes apart) or,
+  // staged, chunk lane + 64 i of the tile's contiguous 32 * RP * 2 bytes
+  const int lane_off = STAGED ? lane * 16 : row * RP * 2 + half * 16;
+  constexpr int LSTEP = STAGED ? 1024 : 32;
+  char* xs = xs_all + (STAGED ? wave * 32 * XROW : 0);
+  {   // [r2] the first tile's loads go out BEFORE H is staged: the two memory round trips overlap (4096^2 cold: 9.03 -> 8.46 us at
+      // R = 32, 10.08 -> 9.31 at R = 64, 13.18 -> 12.54 at R = 128; profiles/ab_stream_ops_r2.txt)
+    const int xoff0 = (wave_global < p.ntiles) ? (int)((int64_t)wave_global * 32 * RP * 2) + lane_off : 0x7f000000;
+#pragma unroll
+    for (int kc = 0; kc < RP / 16; ++kc) xnext[kc] = __builtin_amdgcn_raw_buffer_load_b128(rx, xoff0 + kc * LSTEP, 0, 0);
+  }
+  const float gscale = NV ? *p.global_scale : 1.0f;
+
   // ---- H^T image in LDS: hT[j][k] = h[k][j]; R = 16 becomes blockdiag(h, h) so that one 32-wide
   //      MFMA tile rotates two adjacent 16-element rows at once
   if (R < 32) {
@@ -156,23 +175,6 @@ __global__ __launch_bounds__(256) void fused_quantize_kernel(const QuantParams p
   }
   __syncthreads();
 
-  // x as rows of RP elements (for R = 16 two rotation rows share one 32-element "row")
-  const int64_t ngroups = p.numel / (NV ? 16 : 32);
-  const __amdgpu_buffer_rsrc_t rx = make_rsrc(p.x, (uint32_t)(p.numel * 2));
-  const float gscale = NV ? *p.global_scale : 1.0f;
-
-  const int wave_global = blockIdx.x * 4 + wave, nwaves = gridDim.x * 4;
-  v4i xnext[RP / 16];
-  // per-lane byte offset inside a tile and the step between a lane's loads: MFMA layout (row, half; 32 bytes apart) or,
-  // staged, chunk lane + 64 i of the tile's contiguous 32 * RP * 2 bytes
-  const int lane_off = STAGED ? lane * 16 : row * RP * 2 + half * 16;
-  constexpr int LSTEP = STAGED ? 1024 : 32;
-  char* xs = xs_all + (STAGED ? wave * 32 * XROW : 0);
-  {
-    const int xoff0 = (wave_global < p.ntiles) ? (int)((int64_t)wave_global * 32 * RP * 2) + lane_off : 0x7f000000;
-#pragma unroll
-    for (int kc = 0; kc < RP / 16; ++kc) xnext[kc] = __builtin_amdgcn_raw_buffer_load_b128(rx, xoff0 + kc * LSTEP, 0, 0);
-  }
   for (int tile = wave_global; tile < p.ntiles; tile += nwaves) {
     // R >= 64: keep H^T in LDS instead of letting the compiler hoist its R*R/256 fragments into registers across the
     // tile loop (R = 128: 128 VGPRs, 204 in total -> 2 waves per SIMD and no latency hiding; re-reading 32 KiB of LDS
