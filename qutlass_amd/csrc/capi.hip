@@ -32,7 +32,7 @@ using namespace qamd;
 // one unit (explicit instantiation) and only declared (`extern template`) in the others.  QAMD_TU = 0 (a plain
 // `hipcc capi.hip`) still gives a whole library in one unit.
 //   1  C entry points, dispatch rules, small kernels      2  MXFP4 tile / schedule variants      3  MXFP8 variants
-//   4  NVFP4 kernels                                      5  fused quantizers
+//   4  NVFP4 kernels + MXFP8 with an e5m2 A operand        5  fused quantizers
 //   6  MXFP4 ablations (100+, 200+, 300+; lab only)       7  NVFP4 v2 ablations (gemm_nvf4.hip.h; lab only)
 #ifndef QAMD_TU
 #define QAMD_TU 0
@@ -221,20 +221,31 @@ int dispatch_ablation_mx4(int v, const GemmParams& p, hipStream_t s);
 template <int EBITS, bool SPLIT>
 int dispatch_variant(int v, const GemmParams& p, hipStream_t s, const char* name) {
 #if QAMD_BENCH
-  if ((p.pp_flags & 4096) && v >= 70 && v <= 73) v += 100;   // lab: "pp_flags" bit 12 = the round-1 ring schedule wherever a ring kernel is picked
+  if (p.pp_flags & 4096) {   // lab: "pp_flags" bit 12 = the round-1 ring / simple schedules wherever their pipelined successors are picked
+    if (v >= 70 && v <= 73) v += 100;
+    else if (v == 24 || v == 25 || (v >= 27 && v <= 29)) v += 200;
+  }
 #endif
   if (dry_record(v, p.N, ((v >= 70 && v <= 78) || (v >= 170 && v <= 173)) ? p.splits : 1)) return 0;
   switch (v) {
-    case 24: return launch_gemm<GemmCfg<128, 128, 2, 2, EBITS, SPLIT>, 3>(p, s);   // simple schedule
-    case 25: return launch_gemm<GemmCfg<256, 128, 4, 2, EBITS, SPLIT>, 3>(p, s);
-    case 27: return launch_gemm<GemmCfg<128, 64, 2, 2, EBITS, SPLIT>, 3>(p, s);    // mid-size problems: more, smaller tiles
-    case 28: return launch_gemm<GemmCfg<64, 128, 2, 2, EBITS, SPLIT>, 3>(p, s);
-    case 29: return launch_gemm<GemmCfg<64, 64, 2, 2, EBITS, SPLIT>, 3>(p, s);
+    // pipelined schedule on a 2-deep LDS ring (gemm_mx_ringp with NSTAGE = 2: the LDS footprint of the round-1 "simple" schedule,
+    // two workgroups per CU, but the next stage's fragments are read during this stage's MFMAs): -3 .. -13 % against the
+    // simple schedule on every mid-size shape measured (profiles/native_r2_midtile2.log)
+    case 24: return launch_gemm<GemmCfg<128, 128, 2, 2, EBITS, SPLIT, 0, 2>, 9>(p, s);
+    case 25: return launch_gemm<GemmCfg<256, 128, 4, 2, EBITS, SPLIT, 0, 2>, 9>(p, s);
+    case 27: return launch_gemm<GemmCfg<128, 64, 2, 2, EBITS, SPLIT, 0, 2>, 9>(p, s);    // mid-size problems: more, smaller tiles
+    case 28: return launch_gemm<GemmCfg<64, 128, 2, 2, EBITS, SPLIT, 0, 2>, 9>(p, s);
+    case 29: return launch_gemm<GemmCfg<64, 64, 2, 2, EBITS, SPLIT, 0, 2>, 9>(p, s);
     case 70: return launch_gemm<GemmCfg<64, 64, 2, 2, EBITS, SPLIT, 0, 3>, 9>(p, s);     // pipelined ring schedule: NSTAGE-deep LDS ring, NSTAGE-1 stages in flight,
     case 71: return launch_gemm<GemmCfg<128, 64, 2, 2, EBITS, SPLIT, 0, 3>, 9>(p, s);    //   fragments of the next stage read during this stage's MFMAs
     case 72: return launch_gemm<GemmCfg<64, 128, 2, 2, EBITS, SPLIT, 0, 3>, 9>(p, s);
     case 73: return launch_gemm<GemmCfg<128, 128, 2, 2, EBITS, SPLIT, 0, 3>, 9>(p, s);
 #if QAMD_BENCH
+    case 224: return launch_gemm<GemmCfg<128, 128, 2, 2, EBITS, SPLIT>, 3>(p, s);   // the round-1 simple schedule (2 stages, reads after the barrier, then MFMAs)
+    case 225: return launch_gemm<GemmCfg<256, 128, 4, 2, EBITS, SPLIT>, 3>(p, s);
+    case 227: return launch_gemm<GemmCfg<128, 64, 2, 2, EBITS, SPLIT>, 3>(p, s);
+    case 228: return launch_gemm<GemmCfg<64, 128, 2, 2, EBITS, SPLIT>, 3>(p, s);
+    case 229: return launch_gemm<GemmCfg<64, 64, 2, 2, EBITS, SPLIT>, 3>(p, s);
     case 170: return launch_gemm<GemmCfg<64, 64, 2, 2, EBITS, SPLIT, 0, 3>, 7>(p, s);    // the round-1 ring schedule (whole-stage reads after the barrier, then the MFMAs)
     case 171: return launch_gemm<GemmCfg<128, 64, 2, 2, EBITS, SPLIT, 0, 3>, 7>(p, s);
     case 172: return launch_gemm<GemmCfg<64, 128, 2, 2, EBITS, SPLIT, 0, 3>, 7>(p, s);
@@ -314,15 +325,15 @@ int dispatch_variant(int v, const GemmParams& p, hipStream_t s, const char* name
 // MXFP8 with an e5m2 A operand (extension, include/qutlass_amd.h qutlass_amd_matmul_mxf8_bf16_{tn,nn}_fmt): the variants the
 // auto rules can pick, nothing else.
 int dispatch_variant_a5(int v, const GemmParams& p, hipStream_t s, const char* name)
-#if QAMD_DEF(3)
+#if QAMD_DEF(4)   // (the e5m2-operand MXFP8 kernels ride with the NVFP4 unit: balances the parallel build)
 {
   if (dry_record(v, p.N, (v >= 70 && v <= 78) ? p.splits : 1)) return 0;
   switch (v) {
-    case 24: return launch_gemm<GemmCfg<128, 128, 2, 2, 8, true, 0, 2, 1>, 3>(p, s);
-    case 25: return launch_gemm<GemmCfg<256, 128, 4, 2, 8, true, 0, 2, 1>, 3>(p, s);
-    case 27: return launch_gemm<GemmCfg<128, 64, 2, 2, 8, true, 0, 2, 1>, 3>(p, s);
-    case 28: return launch_gemm<GemmCfg<64, 128, 2, 2, 8, true, 0, 2, 1>, 3>(p, s);
-    case 29: return launch_gemm<GemmCfg<64, 64, 2, 2, 8, true, 0, 2, 1>, 3>(p, s);
+    case 24: return launch_gemm<GemmCfg<128, 128, 2, 2, 8, true, 0, 2, 1>, 9>(p, s);
+    case 25: return launch_gemm<GemmCfg<256, 128, 4, 2, 8, true, 0, 2, 1>, 9>(p, s);
+    case 27: return launch_gemm<GemmCfg<128, 64, 2, 2, 8, true, 0, 2, 1>, 9>(p, s);
+    case 28: return launch_gemm<GemmCfg<64, 128, 2, 2, 8, true, 0, 2, 1>, 9>(p, s);
+    case 29: return launch_gemm<GemmCfg<64, 64, 2, 2, 8, true, 0, 2, 1>, 9>(p, s);
     case 90: return launch_gemm_deepp8<GemmCfg<256, 256, 2, 2, 8, true, 0, 2, 1>>(p, s);
     case 70: return launch_gemm<GemmCfg<64, 64, 2, 2, 8, true, 0, 3, 1>, 9>(p, s);
     case 71: return launch_gemm<GemmCfg<128, 64, 2, 2, 8, true, 0, 3, 1>, 9>(p, s);

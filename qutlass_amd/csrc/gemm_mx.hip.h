@@ -1557,7 +1557,7 @@ __device__ __forceinline__ void gemm_mx_ringp(char* smem, const GemmParams& p) {
   constexpr int KSL = C::KSL, D = C::NSTAGE, MT = C::MT, NT = C::NT, CPS = C::CPS;
   constexpr int LPS = C::NA + C::NB + 1;            // DMA instructions per wave per stage
   constexpr int U = (D % 2 == 0) ? D : 2 * D;       // unroll: slot = u % D, register set = u & 1
-  static_assert(D >= 3 && (D - 2) * LPS <= 63, "vmcnt immediate");
+  static_assert(D >= 2 && (D - 2) * LPS <= 63, "vmcnt immediate");   // D = 2: one stage in flight, LDS of the simple schedule (two workgroups per CU)
   static_assert(!RM || (C::EBITS == 4 && C::BM == 64 && C::BN == 64 && C::NWAVES == 4), "row-major scales: 64x64 fp4 tiles");
   static_assert(C::ABL == 0, "no ablation builds of this schedule");
   GemmCtx<C> cx(smem, p);
@@ -1746,8 +1746,11 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 
 // One __global__ entry per (config, schedule).
 enum { SCHED_LOCKSTEP = 0, SCHED_PINGPONG = 1, SCHED_QUEUE = 2, SCHED_SIMPLE = 3, SCHED_DEEP = 4, SCHED_REGSTAGE = 5, SCHED_DEEP_NN = 6, SCHED_RING = 7, SCHED_RING_RM = 8, SCHED_RINGP = 9, SCHED_RINGP_RM = 10 };
+// pipelined schedule on a 2-deep ring: sized for two workgroups per CU, i.e. (4-wave configurations) two waves per SIMD = 256 registers
 template <class C, int SCHED>
-__global__ __launch_bounds__(C::THREADS) void gemm_mx_kernel(const GemmParams p) {
+constexpr int gemm_min_waves_per_eu() { return ((SCHED == 9 || SCHED == 10) && C::NSTAGE == 2 && C::NWAVES == 4) ? 2 : 1; }
+template <class C, int SCHED>
+__global__ __launch_bounds__(C::THREADS, (gemm_min_waves_per_eu<C, SCHED>())) void gemm_mx_kernel(const GemmParams p) {
   __shared__ __attribute__((aligned(16))) char smem[C::LDS_BYTES];
   // ABL_CLOCK builds only (qutlass_amd_debug_set_trace_buffer): workgroup 0 reports its shader-cycle and
   // 100 MHz wall-clock duration, i.e. the clock the chip actually ran at under this kernel's power draw

@@ -886,20 +886,20 @@ int main(int argc, char** argv) {
     const int64_t shapes[][3] = {{1024, 4096, 4096}, {2048, 4096, 4096}, {3072, 4096, 4096}, {1024, 14336, 4096}, {2048, 14336, 4096}, {2048, 4096, 14336},
                                  {1536, 8192, 8192}, {2048, 8192, 8192}, {3072, 5120, 5120}, {4096, 2048, 4096}};
     for (auto& sh : shapes)
-      for (int var : {0, 24, 25, 27, 73, 71, 72, 90}) {
+      for (int var : {0, 224, 24, 225, 25, 227, 27, 228, 28, 73, 90}) {
         char tag[96];
         snprintf(tag, sizeof tag, "mxfp4 %lldx%lldx%lld var=%d", (long long)sh[0], (long long)sh[1], (long long)sh[2], var);
         bench_gemm(tag, 0, sh[0], sh[1], sh[2], var, 100);
       }
     for (auto& sh : shapes)
-      for (int var : {0, 24, 25, 73, 90}) {
+      for (int var : {0, 224, 24, 225, 25, 73, 90}) {
         char tag[96];
         snprintf(tag, sizeof tag, "mxfp8 %lldx%lldx%lld var=%d", (long long)sh[0], (long long)sh[1], (long long)sh[2], var);
         bench_gemm(tag, 2, sh[0], sh[1], sh[2], var, 100);
       }
   }
   if (want("ringp")) {   // pipelined ring schedule (product 70..73 + the row-major-scale kernel) vs the oracle, and vs the round-1 ring ("pp_flags" bit 12) on the auto rules
-    for (int var : {70, 71, 72, 73, 77, 0}) {
+    for (int var : {70, 71, 72, 73, 77, 0, 24, 25, 27, 28, 29}) {
       for (int kind : {0, 2}) {
         const bool tol = kind == 2;
         check_gemm("ringp config1", kind, 256, 256, 512, 1.0f, 3, 0, var, tol);
