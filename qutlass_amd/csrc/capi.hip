@@ -430,7 +430,8 @@ SmallPlan plan_small(int64_t M, int64_t N, int64_t K) {
 // a_fmt (MXFP8 only): QAMD_FP8_E4M3 / QAMD_FP8_E5M2 element format of A
 template <int EBITS>
 int gemm_mx(const char* name, const void* A, const void* B, const void* A_sf, const void* B_sf,
-            const float* alpha, void* D, int64_t M, int64_t N, int64_t K, void* stream, void* ws = nullptr, int64_t ws_bytes = 0, int a_fmt = 0) {
+            const float* alpha, void* D, int64_t M, int64_t N, int64_t K, void* stream, void* ws = nullptr, int64_t ws_bytes = 0, int a_fmt = 0,
+            int64_t ldd = 0) {   // ldd: row stride of D in elements when this call covers a column range of a wider output (0 = N)
   // one place decides which instantiation family a variant number is looked up in
   auto dispatch = [&](int v, const GemmParams& q, hipStream_t st) -> int {
     if (EBITS == 8 && a_fmt == 1) return dispatch_variant_a5(v, q, st, name);
@@ -445,8 +446,21 @@ int gemm_mx(const char* name, const void* A, const void* B, const void* A_sf, co
   const int64_t CB = cdiv(K / 32, 4);
   const int64_t a_bytes = M * rowbytes, b_bytes = N * rowbytes;
   const int64_t sfa_bytes = cdiv(M, 128) * CB * 512, sfb_bytes = cdiv(N, 128) * CB * 512;
-  if (b_bytes >= (1ll << 31) || M * N >= (1ll << 40) || M >= (1ll << 31))
-    return fail(QAMD_ERR_INVALID, "%s: B operand larger than 2 GiB (or an output of 2^40 elements) is not supported", name);
+  if (M * N >= (1ll << 40) || M >= (1ll << 31) || N >= (1ll << 31)) return fail(QAMD_ERR_INVALID, "%s: an output of 2^40 elements is not supported", name);
+  if (ldd == 0) ldd = N;
+  if (b_bytes >= (1ll << 31)) {
+    // B of >= 2 GiB (e.g. a 262400 x 16384 fp4 weight): column ranges of whole 256-column tiles, each writing its columns of the
+    // same D (row stride ldd); A is shared.  Every output element is computed by exactly one launch, in the same K order.
+    const int64_t cols = ((1ll << 31) - 1) / rowbytes / 256 * 256;
+    if (cols < 256) return fail(QAMD_ERR_INVALID, "%s: K too large for a 256-column range of B to stay below 2 GiB", name);
+    for (int64_t c0 = 0; c0 < N; c0 += cols) {
+      const int64_t nc = std::min(cols, N - c0);
+      if (int rc = gemm_mx<EBITS>(name, A, (const uint8_t*)B + c0 * rowbytes, A_sf, (const uint8_t*)B_sf + (c0 / 128) * CB * 512, alpha,
+                                  (uint16_t*)D + c0, M, nc, K, stream, ws, ws_bytes, a_fmt, ldd))
+        return rc;
+    }
+    return QAMD_OK;
+  }
   if (a_bytes >= (1ll << 31)) {
     // The kernels address an operand through 32-bit buffer-descriptor offsets (< 2 GiB); the reference's CUTLASS kernels use
     // 64-bit strides.  A larger A (large batch x long K, e.g. 262144 x 16384 fp4) runs as row ranges of whole 256-row tiles:
@@ -456,14 +470,14 @@ int gemm_mx(const char* name, const void* A, const void* B, const void* A_sf, co
     for (int64_t r0 = 0; r0 < M; r0 += rows) {
       const int64_t mc = std::min(rows, M - r0);
       if (int rc = gemm_mx<EBITS>(name, (const uint8_t*)A + r0 * rowbytes, B, (const uint8_t*)A_sf + (r0 / 128) * CB * 512, B_sf, alpha,
-                                  (uint16_t*)D + r0 * N, mc, N, K, stream, ws, ws_bytes, a_fmt))
+                                  (uint16_t*)D + r0 * ldd, mc, N, K, stream, ws, ws_bytes, a_fmt, ldd))
         return rc;
     }
     return QAMD_OK;
   }
   GemmParams p;
   p.A = (const uint8_t*)A; p.B = (const uint8_t*)B; p.SFA = (const uint8_t*)A_sf; p.SFB = (const uint8_t*)B_sf;
-  p.alpha = alpha; p.D = (uint16_t*)D; p.M = (int)M; p.N = (int)N; p.K = (int)K; p.ldd = (int)N;
+  p.alpha = alpha; p.D = (uint16_t*)D; p.M = (int)M; p.N = (int)N; p.K = (int)K; p.ldd = (int)ldd;
   p.a_bytes = (uint32_t)a_bytes; p.b_bytes = (uint32_t)b_bytes;
   p.sfa_bytes = (uint32_t)sfa_bytes; p.sfb_bytes = (uint32_t)sfb_bytes;
   p.pp_shift = opt_pp_shift();
@@ -515,7 +529,7 @@ int gemm_mx(const char* name, const void* A, const void* B, const void* A_sf, co
   // 128 tiles on, the 64x64 ring kernel streams the weight through full-line LDS-DMA and wins (N = 14336, K = 4096: 6.9 us
   // vs 9.7 us; N = 57344, K = 8192: 36 us vs 58-74 us), as does ring + split-K over caller scratch for a long K
   // (N = 4096, K = 14336, M = 16: 11.6 us vs 14.8 us).  profiles/native_r1_skinny_shapes.log, native_r1_ring.log
-  if (EBITS == 4 && (variant == 60 || (variant >= 44 && variant <= 49) || (variant == 0 && M <= 32 && cdiv(N, 64) < 128 && !can_split))) {
+  if (EBITS == 4 && ldd == N && (variant == 60 || (variant >= 44 && variant <= 49) || (variant == 0 && M <= 32 && cdiv(N, 64) < 128 && !can_split))) {   // (the skinny kernel writes a dense D)
     if (dry_record(variant ? variant : 60, p.N, 1)) return 0;
     SkinnyParams q;
     q.A = p.A; q.B = p.B; q.SFA = p.SFA; q.SFB = p.SFB; q.alpha = alpha; q.D = p.D; q.M = p.M; q.N = p.N; q.K = p.K;
@@ -547,7 +561,7 @@ int gemm_mx(const char* name, const void* A, const void* B, const void* A_sf, co
     else if (tiles(256, 256) >= want) {
       // the persistent deep schedule (one workgroup per CU walks the tiles, epilogue folded into the last K stage), fp4 and
       // fp8; its epilogue addresses a tile with 32-bit byte offsets, so absurdly wide outputs stay with 256x128 simple tiles
-      const int big = N < (1ll << 22) ? 90 : 25;
+      const int big = ldd < (1ll << 22) ? 90 : 25;
       variant = big;
       // wave quantisation: T tiles on 256 CUs run ceil(T/256) rounds; when the last round is less than ~60 % full
       // (C3 4096x14336x4096: 896 tiles = 3.5 rounds) the trailing tile columns go to a second launch with smaller

@@ -191,3 +191,27 @@ def test_a_operand_beyond_2gib_runs_as_row_ranges(q):
     gf, rf = oracle.bf16_bits_to_f32(got).astype(np.float64), oracle.bf16_bits_to_f32(ref).astype(np.float64)
     assert (np.abs(gf - rf) <= np.abs(rf) / 128.0 + 1e-6 * np.abs(rf).max()).all()
     assert (got == ref).mean() > 0.95
+
+
+def test_b_operand_beyond_2gib_runs_as_column_ranges(q):
+    """The mirror case: a weight of >= 2 GiB (262400 x 16384 fp4) runs as column ranges of whole 256-column tiles that write
+    their columns of one D (row stride = the full N).  Columns from the start, both sides of the range boundary (column 261888)
+    and the end against the oracle."""
+    from qutlass_amd.utils import to_blocked
+
+    m, n, k = 48, 262400, 16384
+    g = torch.Generator(device=DEV).manual_seed(10)
+    a = torch.randint(0, 256, (m, k // 2), dtype=torch.uint8, device=DEV, generator=g)
+    b = torch.randint(0, 256, (n, k // 2), dtype=torch.uint8, device=DEV, generator=g)
+    a_s = torch.randint(124, 131, (m, k // 32), dtype=torch.uint8, device=DEV, generator=g)
+    b_s = torch.randint(124, 131, (n, k // 32), dtype=torch.uint8, device=DEV, generator=g)
+    e8 = torch.float8_e8m0fnu
+    out = q.matmul_mxf4_bf16_tn(a, b, to_blocked(a_s.view(e8)), to_blocked(b_s.view(e8)), torch.tensor([1.0], device=DEV))
+    assert out.shape == (m, n)
+    cols = [0, 1, 255, 256, 131071, 261887, 261888, 261889, 262143, 262144, 262399]
+    ci = torch.tensor(cols, device=DEV)
+    ref = oracle.gemm_blockscaled(oracle.KIND_MXFP4, _np(a), _np(b[ci]), oracle.to_blocked(_np(a_s)), oracle.to_blocked(_np(b_s[ci])), 1.0, m, len(cols), k)
+    got = _np(out[:, ci])
+    gf, rf = oracle.bf16_bits_to_f32(got).astype(np.float64), oracle.bf16_bits_to_f32(ref).astype(np.float64)
+    assert (np.abs(gf - rf) <= np.abs(rf) / 128.0 + 1e-6 * np.abs(rf).max()).all()
+    assert (got == ref).mean() > 0.95
