@@ -419,6 +419,10 @@ SmallPlan plan_small(int64_t M, int64_t N, int64_t K) {
       if (S < 1) S = 1;
       const int64_t per = cdiv(KT, S);
       S = cdiv(KT, per);                                                // every split non-empty
+      // a two-way split (more than 64 tiles) halves the K loop at best and pays a second launch + the reduce pass (~3.5 us): it
+      // needs ~48 stages to win (M = 128, N = 4096: K = 8192 7.6 us unsplit vs 9.8 us split; K = 14336 17.3 vs 14.0 us;
+      // profiles/native_r2_tilesplit.log)
+      if (S == 2 && KT < 48) S = 1;
     }
     return {70, (int)S};
   }

@@ -882,6 +882,29 @@ int main(int argc, char** argv) {
         }
       }
   }
+  if (want("tilesplit")) {   // pipelined ring: tile x split-K choices (two-launch form) against the auto rule, mid-batch shapes
+    g_gauss_fill = 1;
+    const int64_t shapes[][2] = {{4096, 14336}, {8192, 8192}, {4096, 8192}, {14336, 4096}, {4096, 4096}};
+    for (auto& sh : shapes)
+      for (int64_t M : {64, 128, 256, 512, 1024}) {
+        char tag[128];
+        snprintf(tag, sizeof tag, "auto                    M=%lld N=%lld K=%lld", (long long)M, (long long)sh[0], (long long)sh[1]);
+        bench_gemm(tag, 0, M, sh[0], sh[1], 0, 100);
+        for (int var : {70, 71, 72, 73}) {
+          int bm = (var == 71 || var == 73) ? 128 : 64, bn = (var == 72 || var == 73) ? 128 : 64;
+          if (M <= 64 && bm == 128) continue;
+          const int64_t tiles = ((M + bm - 1) / bm) * ((sh[0] + bn - 1) / bn);
+          for (int S : {1, 2, 4, 8}) {
+            if (tiles * S > 512 || tiles * S < 128 || (S > 1 && sh[1] / 256 / S < 4)) continue;
+            qutlass_amd_set_option("splitk_force", S);
+            snprintf(tag, sizeof tag, "forced tile %dx%d S=%d  M=%lld N=%lld K=%lld", bm, bn, S, (long long)M, (long long)sh[0], (long long)sh[1]);
+            bench_gemm(tag, 0, M, sh[0], sh[1], var, 100);
+          }
+          qutlass_amd_set_option("splitk_force", 0);
+        }
+      }
+    g_gauss_fill = 0;
+  }
   if (want("midtile")) {   // mid-size outputs (too few 256x256 tiles for the persistent kernel): simple 2-stage schedule vs pipelined ring vs 256x256
     const int64_t shapes[][3] = {{1024, 4096, 4096}, {2048, 4096, 4096}, {3072, 4096, 4096}, {1024, 14336, 4096}, {2048, 14336, 4096}, {2048, 4096, 14336},
                                  {1536, 8192, 8192}, {2048, 8192, 8192}, {3072, 5120, 5120}, {4096, 2048, 4096}};

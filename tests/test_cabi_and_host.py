@@ -145,6 +145,7 @@ def test_auto_dispatch_rules_dry_run(lib):
     assert plan(4, 64, 4096, 14336, 64 * 4096 * 4 * 4 - 1) == [(RING64, 4096, 1)]   # scratch one byte short: single pass
     assert plan(4, 16, 4096, 14336, big) == [(RING64, 4096, 4)]       # beats the skinny kernel when it may split
     assert plan(4, 128, 4096, 14336, big) == [(RING64, 4096, 2)]
+    assert plan(4, 128, 4096, 8192, big) == [(RING64, 4096, 1)]       # a two-way split needs >= 48 K stages to pay for its reduce pass
     assert plan(4, 256, 4096, 14336, big) == [(RING64, 4096, 1)]
     assert plan(8, 64, 4096, 4096, big) == [(RING64, 4096, 4)]
     assert plan(4, 512, 4096, 4096) == [(RING64x128, 4096, 1)]
