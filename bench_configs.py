@@ -263,6 +263,13 @@ def main():
     h128 = hadamard(128, dev)
     line("fusedQuantizeMx(H128, abs_max) 16384x8192 [cold: 5 x 256 MiB inputs rotated]", time_us_cold(lambda j: q.fusedQuantizeMx(big[j], h128, method="abs_max"), 5, 20), bytes_=bigb, cache="cold")
     del big
+    # ... and in between: 8192 x 8192 = 128 MiB per input, 10 inputs rotated (1.25 GiB per cycle)
+    mid = [torch.randn(8192, 8192, dtype=torch.bfloat16, device=dev) * 25.0 for _ in range(10)]
+    midb = 8192 * 8192 * 2 + 8192 * 8192 // 2 + 8192 * 8192 // 32
+    line("fusedQuantizeMx(H32, abs_max) 8192x8192 [cold: 10 x 128 MiB inputs rotated]", time_us_cold(lambda j: q.fusedQuantizeMx(mid[j], h32, method="abs_max"), 10, 20), bytes_=midb, cache="cold")
+    h64 = hadamard(64, dev)
+    line("fusedQuantizeMx(H64, abs_max) 8192x8192 [cold: 10 x 128 MiB inputs rotated]", time_us_cold(lambda j: q.fusedQuantizeMx(mid[j], h64, method="abs_max"), 10, 20), bytes_=midb, cache="cold")
+    del mid
     # packed-input ops: 9 MiB per input, so rotate 40 of them as well (360 MiB > MALL) -- quantise the cold inputs once
     packed = [q.fusedQuantizeMx(t, h32, method="abs_max") for t in xs_c]
     packed = [(pq, ps.view(torch.uint8).reshape(-1)[: M * K // 32].reshape(M, K // 32).contiguous().view(torch.float8_e8m0fnu)) for pq, ps in packed]
