@@ -287,3 +287,12 @@ def test_no_oracle_in_product_path():
             if f.endswith((".py", ".hip", ".h", ".cpp")):
                 src = open(os.path.join(dirpath, f)).read()
                 assert "import oracle" not in src and "from oracle" not in src and "libqutlass_oracle" not in src, f
+
+
+def test_in_tree_binaries_are_not_older_than_their_sources():
+    """The .so files are git-ignored build products that travel to the GPU box as they are: a library built before the last
+    source edit would make every GPU result describe other code than the tree.  (`__graft_entry__.build()` rebuilds stale ones.)"""
+    from qutlass_amd import build
+
+    assert not build.needs_build(), "libqutlass_amd.so / qutlass/_CUDA.abi3.so are older than their sources: run __graft_entry__.build()"
+    assert not build._stale(build.BENCH_OUT, build._kernel_sources()), "libqutlass_amd_bench.so is older than its sources"
