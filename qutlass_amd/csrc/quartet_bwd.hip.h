@@ -52,14 +52,6 @@ __global__ __launch_bounds__(512) void bwd_quant_t_kernel(const BwdTParams p) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = uniform(tid >> 6);
   const int row = lane & 31, half = lane >> 5;
-  for (int idx = tid; idx < 32 * 32; idx += 512) {   // hT[j][k] = h[k][j]
-    const int k = idx >> 5, j = idx & 31;
-    *(uint16_t*)(hT + j * HROW + k * 2) = p.h[k * 32 + j];
-  }
-  __syncthreads();
-  v8bf hf[2];   // H^T operand of the two K = 16 MFMAs (runtime matrix, loaded once)
-#pragma unroll
-  for (int kc = 0; kc < 2; ++kc) hf[kc] = *(const v8bf*)(hT + row * HROW + (kc * 16 + half * 8) * 2);
 
   char* ts = tile_s[wave];
   const float alpha = QT ? *p.alpha : 1.0f;
@@ -104,7 +96,24 @@ __global__ __launch_bounds__(512) void bwd_quant_t_kernel(const BwdTParams p) {
       }
     }
   };
-  load_tile(blockIdx.x);
+  // [r2] T: the first tile's loads are issued BEFORE the rotation matrix is staged (the two memory round trips overlap: 13.7 -> 12.9 us
+  // cold at 4096^2).  QT keeps them after it: its tile is 1/4 of the bytes and hoisting measured +4 % warm (profiles/ab_stream_ops_r2.txt)
+  if (!QT) load_tile(blockIdx.x);
+  {   // hT[j][k] = h[k][j]; [r2] both loads of a thread before the first LDS write (the loop form waited for each load in turn)
+    uint16_t hv[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) hv[i] = p.h[i * 512 + tid];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int idx = i * 512 + tid, k = idx >> 5, j = idx & 31;
+      *(uint16_t*)(hT + j * HROW + k * 2) = hv[i];
+    }
+  }
+  __syncthreads();
+  v8bf hf[2];   // H^T operand of the two K = 16 MFMAs (runtime matrix, loaded once)
+#pragma unroll
+  for (int kc = 0; kc < 2; ++kc) hf[kc] = *(const v8bf*)(hT + row * HROW + (kc * 16 + half * 8) * 2);
+  if (QT) load_tile(blockIdx.x);
   for (int tw = blockIdx.x; tw < ntw; tw += gridDim.x) {   // uniform over the workgroup: barriers inside are safe
     int b, m0, g0;
     decode(tw, b, m0, g0);
