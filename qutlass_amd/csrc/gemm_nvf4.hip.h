@@ -655,8 +655,8 @@ inline hipError_t launch_nvf4_gemm(NvGemmParams p, hipStream_t s, int variant = 
     return hipSuccess;
   }
 #if QAMD_BENCH
-  if (variant == 4 && !small) {   // 4 waves of 128x128: each operand chunk is dequantised by 2 waves instead of 4 / 2
-    using C = NvCfg<256, 256, 2, 2>;
+  if (variant == 1 && !small) {   // lab: the round-1 choice for 256x256 tiles, 8 waves of 128x64 (each A chunk dequantised by 4 waves, each B chunk by 2)
+    using C = NvCfg<256, 256, 2, 4>;
     p.tiles_m = (p.M + C::BM - 1) / C::BM;
     p.tiles_n = (p.N + C::BN - 1) / C::BN;
     hipLaunchKernelGGL((gemm_nvf4_kernel<C>), dim3(p.tiles_m * p.tiles_n), dim3(C::THREADS), 0, s, p);
@@ -681,7 +681,10 @@ inline hipError_t launch_nvf4_gemm(NvGemmParams p, hipStream_t s, int variant = 
       hipLaunchKernelGGL((gemm_nvf4_kernel<C>), dim3(p.tiles_m * p.tiles_n), dim3(C::THREADS), 0, s, p);       \
       return hipSuccess;                                                                                       \
     }
-    if (cfg == 0) QAMD_NV_LAUNCH(256, 256, 2, 4)
+    // [r2] 256x256 tiles: 4 waves of 128x128 -- every operand chunk is dequantised by 2 waves (8 waves of 128x64: A by 4, B by 2),
+    // 64 converts / multiplies per 16 MFMAs instead of 48 per 8: +1.7 % (4096^3) .. +3.3 % (8192^3) in the steady state
+    // (profiles/native_r2_nvsteady.log)
+    if (cfg == 0) QAMD_NV_LAUNCH(256, 256, 2, 2)
     if (cfg == 1) QAMD_NV_LAUNCH(128, 128, 2, 2)
     if (cfg == 2) QAMD_NV_LAUNCH(128, 64, 2, 2)
     QAMD_NV_LAUNCH(64, 64, 2, 2)

@@ -990,6 +990,17 @@ int main(int argc, char** argv) {
       }
     }
   }
+  if (want("nvsteady")) {   // run with QAMD_STEADY_MS=60: NVFP4 256x256 kernels in the steady state: 1 = 8 waves (product), 4 = 4 waves of 128x128, 2 = dequantise once into f16 LDS tiles
+    for (int rep = 0; rep < 2; ++rep)
+      for (int nv : {1, 4, 2}) {
+        qutlass_amd_set_option("nvf4_variant", nv);
+        char tag[64];
+        snprintf(tag, sizeof tag, "nvfp4 variant %d 4096^3", nv); bench_gemm(tag, 1, 4096, 4096, 4096, 0, 60);
+        snprintf(tag, sizeof tag, "nvfp4 variant %d 8192^3", nv); bench_gemm(tag, 1, 8192, 8192, 8192, 0, 20);
+        snprintf(tag, sizeof tag, "nvfp4 variant %d 8192x8192x4096", nv); bench_gemm(tag, 1, 8192, 8192, 4096, 0, 30);
+      }
+    qutlass_amd_set_option("nvf4_variant", 0);
+  }
   if (want("nvtile")) {   // NVFP4 tile configs (5: 128x128, 6: 128x64, 7: 64x64, 3: split-K, 0: auto) over mid-batch shapes
     for (int nv : {5, 6, 7}) {
       qutlass_amd_set_option("nvf4_variant", nv);
