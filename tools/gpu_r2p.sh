@@ -1,7 +1,7 @@
 #!/bin/bash
-# Round-2 GPU session O: full GPU suite + smoke + bench + bench_configs on the current build.
+# Round-2 GPU session P: full GPU suite + smoke + bench + bench_configs on the current build.
 cd ${GRAFT_REPO_ROOT:-.}
-O=gpurun_out/r2o; mkdir -p $O
+O=gpurun_out/r2p; mkdir -p $O
 timeout 1800 python -m pytest tests -m gpu -q > $O/pytest_gpu.log 2>&1; echo "pytest rc=$?"
 tail -6 $O/pytest_gpu.log
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; echo "smoke rc=$?"; tail -1 $O/smoke.log
@@ -13,7 +13,7 @@ print(d['value'], d['ms_per_step'], r['frac'], r['per_launch_us']['median'], d['
 timeout 900 python bench_configs.py > $O/bench_configs.jsonl 2> $O/bench_configs.err; echo "bench_configs rc=$?"
 python - <<'PY'
 import json
-for l in open('gpurun_out/r2o/bench_configs.jsonl'):
+for l in open('gpurun_out/r2p/bench_configs.jsonl'):
     d=json.loads(l); r=d.get('roofline',{})
     if d['config'].startswith('C') : print(f"{d['config'][:80]:80s} {d['us']:9.2f} us frac={r.get('frac','')}")
 PY
