@@ -663,7 +663,7 @@ inline hipError_t launch_nvf4_gemm(NvGemmParams p, hipStream_t s, int variant = 
     return hipSuccess;
   }
 #endif
-  if (variant <= 1 || variant == 4 || (variant >= 5 && variant <= 7)) {
+  if (variant <= 1 || variant == 4 || (variant >= 5 && variant <= 9)) {
     // tile choice by occupancy (as for the MX kernels): the largest tile that gives >= 192 workgroups
     auto tiles = [&](int bm, int bn) { return (int64_t)((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn); };
     int cfg = small ? 1 : 0;                                  // 0: 256x256, 1: 128x128, 2: 128x64, 3: 64x64
@@ -673,6 +673,10 @@ inline hipError_t launch_nvf4_gemm(NvGemmParams p, hipStream_t s, int variant = 
     if (variant == 5) cfg = 1;
     if (variant == 6) cfg = 2;
     if (variant == 7) cfg = 3;
+#if QAMD_BENCH
+    if (variant == 8) cfg = 8;    // lab: 128x128 tile on 2 waves of 128x64 (A dequantised by 2 waves, B by 1)
+    if (variant == 9) cfg = 9;    //      128x128 tile on 2 waves of 64x128
+#endif
 #define QAMD_NV_LAUNCH(BM_, BN_, WM_, WN_)                                                                     \
     {                                                                                                          \
       using C = NvCfg<BM_, BN_, WM_, WN_>;                                                                     \
@@ -685,6 +689,10 @@ inline hipError_t launch_nvf4_gemm(NvGemmParams p, hipStream_t s, int variant = 
     // 64 converts / multiplies per 16 MFMAs instead of 48 per 8: +1.7 % (4096^3) .. +3.3 % (8192^3) in the steady state
     // (profiles/native_r2_nvsteady.log)
     if (cfg == 0) QAMD_NV_LAUNCH(256, 256, 2, 2)
+#if QAMD_BENCH
+    if (cfg == 8) QAMD_NV_LAUNCH(128, 128, 1, 2)
+    if (cfg == 9) QAMD_NV_LAUNCH(128, 128, 2, 1)
+#endif
     if (cfg == 1) QAMD_NV_LAUNCH(128, 128, 2, 2)
     if (cfg == 2) QAMD_NV_LAUNCH(128, 64, 2, 2)
     QAMD_NV_LAUNCH(64, 64, 2, 2)

@@ -999,6 +999,22 @@ int main(int argc, char** argv) {
         snprintf(tag, sizeof tag, "nvfp4 variant %d 8192^3", nv); bench_gemm(tag, 1, 8192, 8192, 8192, 0, 20);
         snprintf(tag, sizeof tag, "nvfp4 variant %d 8192x8192x4096", nv); bench_gemm(tag, 1, 8192, 8192, 4096, 0, 30);
       }
+    // 128x128 tiles: 4 waves of 64x64 (5, product) vs 2 waves of 128x64 (8) / 64x128 (9)
+    for (int nv : {8, 9}) {
+      qutlass_amd_set_option("nvf4_variant", nv);
+      check_gemm("gemm_nvfp4 2-wave 128x128: 16x64x32", 1, 16, 64, 32, 1.0f, 3, 0, 0);
+      check_gemm("gemm_nvfp4 2-wave 128x128: ragged + K tail", 1, 72, 136, 352, 0.5f, 3, 0, 0);
+      check_gemm("gemm_nvfp4 2-wave 128x128: 300x264x320", 1, 300, 264, 320, 1.0f, 3, 0, 0);
+      check_gemm("gemm_nvfp4 2-wave 128x128: 504x512x2048", 1, 504, 512, 2048, 1.0f, 3, 0, 0);
+    }
+    for (int rep = 0; rep < 2; ++rep)
+      for (int nv : {5, 8, 9}) {
+        qutlass_amd_set_option("nvf4_variant", nv);
+        char tag[64];
+        snprintf(tag, sizeof tag, "nvfp4 variant %d 2048x4096x4096", nv); bench_gemm(tag, 1, 2048, 4096, 4096, 0, 60);
+        snprintf(tag, sizeof tag, "nvfp4 variant %d 1024x14336x4096", nv); bench_gemm(tag, 1, 1024, 14336, 4096, 0, 60);
+        snprintf(tag, sizeof tag, "nvfp4 variant %d 2048x8192x8192", nv); bench_gemm(tag, 1, 2048, 8192, 8192, 0, 30);
+      }
     qutlass_amd_set_option("nvf4_variant", 0);
   }
   if (want("nvtile")) {   // NVFP4 tile configs (5: 128x128, 6: 128x64, 7: 64x64, 3: split-K, 0: auto) over mid-batch shapes
