@@ -1190,6 +1190,11 @@ int main(int argc, char** argv) {
     trace_gemm(317, 1);
     trace_gemm(318, 1);
   }
+  if (argc >= 2 && !strcmp(argv[1], "onefp8")) {   // qamd_check onefp8 [nn] : MXFP8 4096^3 on the persistent kernel, TN or the (K, M) operand, for rocprofv3 --pmc passes
+    if (argc >= 3 && !strcmp(argv[2], "nn")) check_bench_nn(4096, 4096, 4096, 20);
+    else bench_gemm("onefp8", 2, 4096, 4096, 4096, 0, 20);
+    return 0;
+  }
   if (argc >= 3 && !strcmp(argv[1], "one")) {   // qamd_check one <variant> [M N K] : a single config, for rocprofv3 --pmc passes
     const int var = atoi(argv[2]);
     const int64_t M = argc > 3 ? atoll(argv[3]) : 4096, N = argc > 4 ? atoll(argv[4]) : 4096, K = argc > 5 ? atoll(argv[5]) : 4096;
