@@ -535,6 +535,30 @@ def test_matmul_mxf8_nn_equals_tn_and_oracle(q, golden_dir, m, n, k):
         q.matmul_mxf8_bf16_nn(a_km, b_t[:, : k - 32].contiguous(), sa, sb, alpha)
 
 
+def test_matmul_mxf8_nn_k_tail_does_not_read_past_the_operand(q):
+    """(K, M) operand on the persistent kernel with K % 128 != 0: the last K stage holds k-rows that do not exist.  The operand is
+    a view into a larger buffer whose tail is filled with fp8 NaN bytes -- a kernel that fetched those rows (instead of zeros)
+    would turn whole output columns into NaN.  Bit-equal to the TN op on the same operands."""
+    from qutlass_amd.utils import to_blocked
+
+    m, n, k = 4096, 4096, 1056                      # 256 tiles of 256x256 -> the in-place path; 1056 = 8 * 128 + 32
+    g = torch.Generator(device=DEV).manual_seed(21)
+    a = torch.randint(0, 0x78, (m, k), dtype=torch.uint8, device=DEV, generator=g)      # finite e4m3 codes
+    b = torch.randint(0, 0x78, (n, k), dtype=torch.uint8, device=DEV, generator=g)
+    a_s = torch.randint(124, 131, (m, k // 32), dtype=torch.uint8, device=DEV, generator=g)
+    b_s = torch.randint(124, 131, (n, k // 32), dtype=torch.uint8, device=DEV, generator=g)
+    e8, f8 = torch.float8_e8m0fnu, torch.float8_e4m3fn
+    sa, sb = to_blocked(a_s.view(e8)), to_blocked(b_s.view(e8))
+    alpha = torch.tensor([1.0], device=DEV)
+    buf = torch.full((k * m + 256 * m,), 0x7F, dtype=torch.uint8, device=DEV)           # 0x7F = NaN in e4m3fn
+    buf[: k * m] = a.T.contiguous().reshape(-1)
+    a_km = buf[: k * m].view(k, m).view(f8)
+    out_nn = q.matmul_mxf8_bf16_nn(a_km, b.view(f8), sa, sb, alpha)
+    out_tn = q.matmul_mxf8_bf16_tn(a.view(f8), b.view(f8), sa, sb, alpha)
+    assert not torch.isnan(out_nn.float()).any()
+    assert torch.equal(out_nn.view(torch.int16), out_tn.view(torch.int16))
+
+
 # ------------------------------------------------------------------------------------------------
 # QAT-backward data-prep ops (SURVEY.md section 8f rank 1; reference tests/quartet_test.py:239-260, 368-384)
 # ------------------------------------------------------------------------------------------------
