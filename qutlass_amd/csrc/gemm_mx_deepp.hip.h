@@ -514,7 +514,7 @@ __device__ __forceinline__ void gemm_mx_deepp8(char* smem, const GemmParams& p) 
     vb0 = (((cx.voffT[0] & lastmask) | (cx.voffAB[0] & ~lastmask)) & ~oobm) | ((int)0x80000000 & oobm);
     vb1 = (((cx.voffT[1] & lastmask) | (cx.voffAB[1] & ~lastmask)) & ~oobm) | ((int)0x80000000 & oobm);
     vbS = (cx.voffS & ~oobs) | ((int)0x80000000 & oobs);
-    if constexpr (NN) {   // no K-tail variant of the offsets: whole k-rows are in or out (checked per piece in dma_item)
+    if constexpr (NN) {
       const int o0 = oobm | (nn_col0 < d.mrem ? 0 : -1), o1 = oobm | ((nn_col0 ^ 128) < d.mrem ? 0 : -1);
       va0 = (nn_v[0] & ~o0) | ((int)0x80000000 & o0);
       va1 = (nn_v[1] & ~o1) | ((int)0x80000000 & o1);
@@ -524,10 +524,11 @@ __device__ __forceinline__ void gemm_mx_deepp8(char* smem, const GemmParams& p) 
     char* st = smem + buf * STAGE;
     if (NN && !(NNABL & 1) && item < 8) {   // (lab: NNABL bit 0 = TN-style A addresses, timing only)
       const int q = wave * 8 + item;
-      // k-rows past K (last stage of a K that is not a multiple of 128) fetch out of range explicitly: the stage offset travels in
-      // soffset, which the descriptor's range check does not have to include, so "past the end of the tensor" is not relied upon
-      const int v = ((lane >> 4) < p.K - kt * 128 - 4 * q) ? ((item & 1) ? va1 : va0) + q * nn_rstep : (int)0x80000000;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(d.a, (lds_ptr_t)(st + q * 1024), 16, v, kt * nn_kstep, 0, QAMD_DMA_AUX);
+      // the K offset of the stage rides in voffset (one scalar sum, the same single v_add per piece), not in soffset: k-rows past
+      // K (last stage of a K that is not a multiple of 128) are then past the descriptor's end by their voffset alone, whatever
+      // the range check does with soffset.  (A sentinel offset 0x80000000 plus at most 2^31 - 1 stays out of range.)
+      const int v = ((item & 1) ? va1 : va0) + (q * nn_rstep + kt * nn_kstep);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(d.a, (lds_ptr_t)(st + q * 1024), 16, v, 0, 0, QAMD_DMA_AUX);
     } else if (item < 16) {
       const int t = item & 7, q = wave * 8 + t;
       const int v = ((t & 1) ? vb1 : vb0) + q * cx.rstep;
