@@ -524,11 +524,11 @@ __device__ __forceinline__ void gemm_mx_deepp8(char* smem, const GemmParams& p) 
     char* st = smem + buf * STAGE;
     if (NN && !(NNABL & 1) && item < 8) {   // (lab: NNABL bit 0 = TN-style A addresses, timing only)
       const int q = wave * 8 + item;
-      // the K offset of the stage rides in voffset (one scalar sum, the same single v_add per piece), not in soffset: k-rows past
-      // K (last stage of a K that is not a multiple of 128) are then past the descriptor's end by their voffset alone, whatever
-      // the range check does with soffset.  (A sentinel offset 0x80000000 plus at most 2^31 - 1 stays out of range.)
-      const int v = ((item & 1) ? va1 : va0) + (q * nn_rstep + kt * nn_kstep);
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(d.a, (lds_ptr_t)(st + q * 1024), 16, v, 0, 0, QAMD_DMA_AUX);
+      // k-rows past K (last stage of a K that is not a multiple of 128) lie past the end of the descriptor and read zeros: on gfx950
+      // the range check of a raw buffer covers voffset + soffset (tests/native/soffset_probe.hip, profiles/native_r2_soffset_probe.txt;
+      // tests/test_gpu_parity.py puts fp8 NaN bytes behind the operand)
+      const int v = ((item & 1) ? va1 : va0) + q * nn_rstep;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(d.a, (lds_ptr_t)(st + q * 1024), 16, v, kt * nn_kstep, 0, QAMD_DMA_AUX);
     } else if (item < 16) {
       const int t = item & 7, q = wave * 8 + t;
       const int v = ((t & 1) ? vb1 : vb0) + q * cx.rstep;
