@@ -668,6 +668,15 @@ inline hipError_t launch_nvf4_gemm(NvGemmParams p, hipStream_t s, int variant = 
     auto tiles = [&](int bm, int bn) { return (int64_t)((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn); };
     int cfg = small ? 1 : 0;                                  // 0: 256x256, 1: 128x128, 2: 128x64, 3: 64x64
     if (variant == 0 || variant == 1) {
+      // [r2] wave quantisation of the 256x256 grid (one workgroup per CU, 256 slots per round): 288 tiles run two rounds at 56 %
+      // occupancy.  128x128 tiles (two per CU, 512 slots) sustain 0.85 of the big tile's rate (2048 x 8192 x 8192: 249 vs 213 us)
+      // but quantise four times finer: take them when that more than pays (3072 x 6144 x 4096: 197 -> 152 us;
+      // profiles/native_r2_nvwave.log)
+      if (cfg == 0) {
+        const int64_t t256 = tiles(256, 256), t128 = tiles(128, 128);
+        const double e256 = (double)t256 / (double)((t256 + 255) / 256 * 256), e128 = (double)t128 / (double)((t128 + 511) / 512 * 512);
+        if (e256 < 0.85 * e128) cfg = 1;
+      }
       if (cfg == 1 && tiles(128, 128) < 192) cfg = (tiles(128, 64) >= 192) ? 2 : 3;
     }
     if (variant == 5) cfg = 1;

@@ -1017,6 +1017,19 @@ int main(int argc, char** argv) {
       }
     qutlass_amd_set_option("nvf4_variant", 0);
   }
+  if (want("nvwave")) {   // NVFP4 tile choice against wave quantisation: auto (0) vs forced 128x128 tiles (5), run with QAMD_STEADY_MS=30
+    const int64_t nk[][2] = {{4096, 4096}, {14336, 4096}, {4096, 14336}, {8192, 8192}, {6144, 4096}};
+    for (auto& s2 : nk)
+      for (int64_t M : {1024, 2048, 3072, 4096}) {
+        for (int nv : {0, 5}) {
+          qutlass_amd_set_option("nvf4_variant", nv);
+          char tag[96];
+          snprintf(tag, sizeof tag, "nvfp4 variant %d %lldx%lldx%lld", nv, (long long)M, (long long)s2[0], (long long)s2[1]);
+          bench_gemm(tag, 1, M, s2[0], s2[1], 0, 40);
+        }
+      }
+    qutlass_amd_set_option("nvf4_variant", 0);
+  }
   if (want("nvtile")) {   // NVFP4 tile configs (5: 128x128, 6: 128x64, 7: 64x64, 3: split-K, 0: auto) over mid-batch shapes
     for (int nv : {5, 6, 7}) {
       qutlass_amd_set_option("nvf4_variant", nv);
