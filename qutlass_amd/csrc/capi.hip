@@ -575,7 +575,11 @@ int gemm_mx(const char* name, const void* A, const void* B, const void* A_sf, co
       const int64_t main_cols = (tm > 0) ? full / tm : 0;          // whole tile columns that fit the full rounds
       // From three full rounds on, ONE persistent launch with balanced rounds (deepp_grid) is at least as good (C3: 118.0-119.4
       // vs 120.2-120.7 us); with one or two full rounds the split wins or ties (4096 x 5120: 50.6 vs 51.0 us).
-      if (!(opt_pp_flags() & 64) && full >= 256 && full < 768 && main_cols >= 1 && main_cols < tn && (T - main_cols * tm) * 10 <= 256 * 6) {
+      // [r2] ... and only for a SMALL tail (<= 80 tiles): a tail of half a round runs as a second, serialised launch of 256x128 tiles
+      // that quantises badly itself (3072 x 8192: 71.4 us split vs 54.6 us as one balanced launch; 5120 x 8192: 101 vs 86;
+      // 6144 x 4096: 70 vs 56), while a small tail still wins (3072 x 6144: 47.0 vs 51.4; 4096 x 5120: 50.5 vs 52.9).
+      // profiles/native_r2_mxwave.log
+      if (!(opt_pp_flags() & 64) && full >= 256 && full < 768 && main_cols >= 1 && main_cols < tn && (T - main_cols * tm) <= 80) {
         const int64_t n1 = main_cols * 256;
         GemmParams pm = p;
         pm.N = (int)n1; pm.b_bytes = (uint32_t)(n1 * rowbytes); pm.sfb_bytes = (uint32_t)(cdiv(n1, 128) * CB * 512);

@@ -1017,6 +1017,22 @@ int main(int argc, char** argv) {
       }
     qutlass_amd_set_option("nvf4_variant", 0);
   }
+  if (want("mxwave")) {   // MXFP4 large outputs: the auto rule (persistent kernel, balanced rounds / tail split) vs one forced persistent launch vs 128x128 tiles, QAMD_STEADY_MS=30
+    g_gauss_fill = 1;
+    const bool quick = getenv("QAMD_MXWAVE_QUICK") != nullptr;   // only the shapes whose tails are half a round
+    for (int64_t M : {3072, 4096, 5120, 6144, 8192})
+      for (int64_t N : {4096, 5120, 6144, 8192, 11008, 14336}) {
+        if (quick && !((M == 3072 && N == 8192) || (M == 5120 && N == 8192) || (M == 6144 && N == 4096) || (M == 4096 && N == 6144) || (M == 3072 && N == 6144))) continue;
+        char tag[96];
+        qutlass_amd_set_option("pp_flags", 0);
+        snprintf(tag, sizeof tag, "mxfp4 auto %lldx%lldx4096", (long long)M, (long long)N); bench_gemm(tag, 0, M, N, 4096, 0, 40);
+        qutlass_amd_set_option("pp_flags", 64);
+        snprintf(tag, sizeof tag, "mxfp4 one-launch %lldx%lldx4096", (long long)M, (long long)N); bench_gemm(tag, 0, M, N, 4096, 90, 40);
+        qutlass_amd_set_option("pp_flags", 0);
+        snprintf(tag, sizeof tag, "mxfp4 128x128 %lldx%lldx4096", (long long)M, (long long)N); bench_gemm(tag, 0, M, N, 4096, 24, 40);
+      }
+    g_gauss_fill = 0;
+  }
   if (want("nvwave")) {   // NVFP4 tile choice against wave quantisation: auto (0) vs forced 128x128 tiles (5), run with QAMD_STEADY_MS=30
     const int64_t nk[][2] = {{4096, 4096}, {14336, 4096}, {4096, 14336}, {8192, 8192}, {6144, 4096}};
     for (auto& s2 : nk)
