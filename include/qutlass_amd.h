@@ -116,8 +116,9 @@ int qutlass_amd_matmul_mxf8_bf16_nn(const void* A, const void* B, const void* A_
  * (bindings.cpp:157-160, 196-199; gemm.cu:339-345, 399-403); CDNA4's scaled MFMA takes the format per operand.
  * a_format / b_format: QAMD_FP8_E4M3 or QAMD_FP8_E5M2; b_format must be QAMD_FP8_E4M3.  Everything else (layouts, scales,
  * alignment, workspace rules, return codes) as the entry of the same name without `_fmt`: the TN entry takes the optional
- * split-K scratch of qutlass_amd_matmul_mxf8_bf16_tn_ws (NULL / 0 = never split), the NN entry the mandatory re-layout
- * scratch of qutlass_amd_matmul_mxf8_bf16_nn.  With both formats E4M3 they ARE those entries.
+ * split-K scratch of qutlass_amd_matmul_mxf8_bf16_tn_ws (NULL / 0 = never split), the NN entry the re-layout scratch reported by
+ * qutlass_amd_mxf8_nn_workspace_bytes_for(M, N, K) (may be NULL when that returns 0: the in-place operand path).  With both
+ * formats E4M3 they ARE those entries.
  */
 #define QAMD_FP8_E4M3 0
 #define QAMD_FP8_E5M2 1
@@ -151,6 +152,19 @@ int qutlass_amd_fused_quantize_mx(const void* x, const void* h, int rot, int64_t
 int qutlass_amd_fused_quantize_nv(const void* x, const void* h, int rot, int64_t numel, int method,
                                   const float* global_scale, void* out_e2m1, void* out_e4m3,
                                   void* stream);
+
+/*
+ * EXTENSION (no reference counterpart; the reference's activation path is fusedQuantizeMx -> to_blocked -> matmul, three launches,
+ * qutlass/__init__.py:149-180 + qutlass/utils.py:160-193): the same quantizers, but the scale bytes are written DIRECTLY in the
+ * to_blocked() layout the GEMMs consume -- one launch instead of two.  x is a (rows, k) bf16 matrix (k % max(rot, 32) == 0);
+ * out_*_blocked: ceil(rows/128)*128 * ceil(k/gs/4)*4 bytes (gs = 32 MX / 16 NV), padding zero-filled; byte for byte what
+ * qutlass_amd_to_blocked() makes of the flat scales of the entry above (tests/test_gpu_parity.py).  Everything else as above.
+ */
+int qutlass_amd_fused_quantize_mx_blocked(const void* x, const void* h, int rot, int64_t rows, int64_t k, int method,
+                                          void* out_e2m1, void* out_e8m0_blocked, void* out_mask, void* stream);
+int qutlass_amd_fused_quantize_nv_blocked(const void* x, const void* h, int rot, int64_t rows, int64_t k, int method,
+                                          const float* global_scale, void* out_e2m1, void* out_e4m3_blocked,
+                                          void* stream);
 
 /* ---- QAT-backward data preparation ------------------------------------- */
 

@@ -242,6 +242,22 @@ void orc_fused_quantize_mx(const uint16_t* x, const uint16_t* h, int R, int64_t 
       float scale;
       if (method == 0) {
         float s1 = 0.f, s2 = 0.f;
+        if (acc_model == 2) {
+          /* the HIP kernel's order (qutlass_amd/csrc/quantize.hip.h: lane half h holds j = 8q + 4h + e, q, e = 0..3, summed in
+           * register order, then ONE cross-lane add): same terms, different fp32 association than the reference's sequential
+           * loop -- tests/test_gpu_round3.py uses it to show that a scale byte which differs from the sequential sum differs
+           * by the summation order alone */
+          float p1[2] = {0.f, 0.f}, p2[2] = {0.f, 0.f};
+          for (int hh = 0; hh < 2; ++hh)
+            for (int qq = 0; qq < 4; ++qq)
+              for (int e = 0; e < 4; ++e) {
+                const float t = v[8 * qq + 4 * hh + e];
+                p1[hh] = p1[hh] + t;
+                p2[hh] = fmaf(t, t, p2[hh]);
+              }
+          s1 = p1[0] + p1[1];
+          s2 = p2[0] + p2[1];
+        } else
         for (int i = 0; i < 32; ++i) {
           s1 = s1 + v[i];
           s2 = fmaf(v[i], v[i], s2);

@@ -116,6 +116,32 @@ def fusedQuantizeNv(a: torch.Tensor, b: torch.Tensor, global_scale: torch.Tensor
         raise ValueError(f"invalid method {method!r}, must be 'quest' or 'abs_max'")
 
 
+_METHOD_CODE = {"quest": 0, "abs_max": 1}
+
+
+def fusedQuantizeMxBlocked(a: torch.Tensor, b: torch.Tensor, *, method: Literal["quest", "abs_max"] = "quest") -> tuple[torch.Tensor, torch.Tensor]:
+    """EXTENSION (no reference counterpart): ``fusedQuantizeMx`` whose scales come out GEMM-ready -- the second tensor is
+    byte for byte ``to_blocked(fusedQuantizeMx(a, b, method=method)[1])`` (flat, zero padded), written by the quantizer itself:
+    one launch instead of two on the activation path (qutlass/__init__.py:149-180 + qutlass/utils.py:160-193)."""
+    if method not in _METHOD_CODE:
+        raise ValueError(f"invalid method {method!r}, must be 'quest' or 'abs_max'")
+    padded_rows, padded_cols = get_padded_shape_mx(a)
+    xh_e2m1 = torch.empty(*a.shape[:-1], a.size(-1) // 2, dtype=torch.uint8, device=a.device)
+    xh_e8m0 = torch.empty(padded_rows * padded_cols, dtype=torch.float8_e8m0fnu, device=a.device)
+    return torch.ops.qutlass_amd.fusedQuantizeMxBlocked(a, b, xh_e2m1, xh_e8m0, _METHOD_CODE[method])
+
+
+def fusedQuantizeNvBlocked(a: torch.Tensor, b: torch.Tensor, global_scale: torch.Tensor, *,
+                           method: Literal["quest", "abs_max"] = "abs_max") -> tuple[torch.Tensor, torch.Tensor]:
+    """EXTENSION: ``fusedQuantizeNv`` with the e4m3 scales written directly in the ``to_blocked`` layout (see fusedQuantizeMxBlocked)."""
+    if method not in _METHOD_CODE:
+        raise ValueError(f"invalid method {method!r}, must be 'quest' or 'abs_max'")
+    padded_rows, padded_cols = get_padded_shape_nv(a)
+    xh_e2m1 = torch.empty(*a.shape[:-1], a.size(-1) // 2, dtype=torch.uint8, device=a.device)
+    xh_e4m3 = torch.empty(padded_rows * padded_cols, dtype=torch.float8_e4m3fn, device=a.device)
+    return torch.ops.qutlass_amd.fusedQuantizeNvBlocked(a, b, xh_e2m1, xh_e4m3, global_scale, _METHOD_CODE[method])
+
+
 def backward_t_bf16(x: torch.Tensor, h: torch.Tensor, xh_e2m1: torch.Tensor = None,
                     xh_e8m0: torch.Tensor = None) -> tuple[torch.Tensor, torch.Tensor]:
     """qutlass/__init__.py:206-243: abs-max MXFP4 of x^T (last two dims swapped) rotated per 32 along the old

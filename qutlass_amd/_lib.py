@@ -32,6 +32,8 @@ SYMBOLS = {
     "qutlass_amd_matmul_mxf8_bf16_tn_ws": (_i32, _GEMM_ARGS[:-1] + [_vp, _i64, _vp]),
     "qutlass_amd_fused_quantize_mx": (_i32, [_vp, _vp, _i32, _i64, _i32, _vp, _vp, _vp, _vp]),
     "qutlass_amd_fused_quantize_nv": (_i32, [_vp, _vp, _i32, _i64, _i32, _vp, _vp, _vp, _vp]),
+    "qutlass_amd_fused_quantize_mx_blocked": (_i32, [_vp, _vp, _i32, _i64, _i64, _i32, _vp, _vp, _vp, _vp]),
+    "qutlass_amd_fused_quantize_nv_blocked": (_i32, [_vp, _vp, _i32, _i64, _i64, _i32, _vp, _vp, _vp, _vp]),
     "qutlass_amd_to_blocked": (_i32, [_vp, _i64, _i64, _vp, _vp]),
     "qutlass_amd_backward_t_bf16": (_i32, [_vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp]),
     "qutlass_amd_backward_qt_bf16": (_i32, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp]),

@@ -50,7 +50,7 @@ std::atomic<int> g_hw_fp4_cvt{1};   // device-verified bit-identical to the soft
 #if QAMD_BENCH
 std::atomic<int> g_gemm_variant{0};
 std::atomic<int> g_nvf4_variant{0};
-std::atomic<int> g_splitk_wg{256};      // split-K: target workgroup count ("splitk_wg"; one per CU measured best, profiles/native_r1_splitk_wg.log)
+std::atomic<int> g_splitk_wg{0};        // split-K: target workgroup count ("splitk_wg"; one per CU measured best, profiles/native_r1_splitk_wg.log)
 std::atomic<int> g_splitk_min_kt{32};   // split-K: minimum number of 128-byte K stages ("splitk_min_kt"; 16 loses at K = 4096, 48 leaves K = 8192 .. 11008 unsplit)
 std::atomic<int> g_transpose_nc{128};   // mxfp4_transpose_mxfp8: n columns per workgroup (128 or 256)
 std::atomic<int> g_pp_shift{2};
@@ -101,7 +101,7 @@ int check_launch(const char* what);
 #if QAMD_BENCH
 inline int opt_gemm_variant() { return g_gemm_variant.load(); }
 inline int opt_nvf4_variant() { return g_nvf4_variant.load(); }
-inline int opt_splitk_wg() { return g_splitk_wg.load(); }
+inline int opt_splitk_wg() { return g_splitk_wg.load(); }   // 0 = one workgroup per CU
 inline int opt_splitk_min_kt() { return g_splitk_min_kt.load(); }
 inline int opt_transpose_nc() { return g_transpose_nc.load(); }
 inline int opt_pp_shift() { return g_pp_shift.load(); }
@@ -113,7 +113,7 @@ inline uint32_t* opt_dbg() { return g_dbg.load(); }
 #else
 constexpr int opt_gemm_variant() { return 0; }
 constexpr int opt_nvf4_variant() { return 0; }
-constexpr int opt_splitk_wg() { return 256; }
+constexpr int opt_splitk_wg() { return 0; }
 constexpr int opt_splitk_min_kt() { return 32; }
 constexpr int opt_transpose_nc() { return 128; }
 constexpr int opt_pp_shift() { return 2; }
@@ -125,6 +125,46 @@ constexpr uint32_t* opt_dbg() { return nullptr; }
 #endif
 
 inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// Dry run (qutlass_amd_debug_gemm_plan): the dispatch code below runs unchanged, but instead of launching it records
+// which kernels it WOULD launch -- {variant, N of the launch, K splits} per launch -- so the auto rules are testable on a
+// machine without a GPU (tests/test_cabi_and_host.py).
+struct DryRun { bool on = false; int n = 0; int rec[8][3]; };
+#if QAMD_DEF(1)
+thread_local DryRun t_dry;
+#else
+extern thread_local DryRun t_dry;
+#endif
+// Compute units of the current device, asked once per device (hipDeviceAttributeMultiprocessorCount: 256 on an MI355X in SPX
+// mode; fewer in a partitioned / CU-masked configuration).  Every grid size and occupancy threshold below derives from it.
+// (The kernels' blockIdx -> XCD remap assumes the dispatcher's round-robin over 8 XCDs; it is a bijection for any grid, so
+// on another XCD count it only costs L2 locality.)  The dry-run hook describes a full MI355X whatever the machine.
+#if QAMD_DEF(1)
+int chip_cus() {
+  if (t_dry.on) return 256;
+  static std::atomic<int> cache[64];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+  int v = cache[dev].load(std::memory_order_relaxed);
+  if (v <= 0) {
+    int n = 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    cache[dev].store(n, std::memory_order_relaxed);
+    v = n;
+  }
+  return v;
+}
+#else
+int chip_cus();
+#endif
+
+inline bool dry_record(int variant, int n_cols, int splits) {
+  if (!t_dry.on) return false;
+  if (t_dry.n < 8) { t_dry.rec[t_dry.n][0] = variant; t_dry.rec[t_dry.n][1] = n_cols; t_dry.rec[t_dry.n][2] = splits; }
+  ++t_dry.n;
+  return true;
+}
+
 
 template <class C, int PP>
 int launch_gemm(GemmParams p, hipStream_t s) {
@@ -143,9 +183,10 @@ int launch_gemm(GemmParams p, hipStream_t s) {
 inline int deepp_grid(int tiles) {
   const int forced = opt_deepp_grid();
   if (forced > 0) return std::min(forced, tiles);
-  const int rounds = (tiles + 255) / 256;
+  const int cus = chip_cus();
+  const int rounds = (tiles + cus - 1) / cus;
   const int g = ((tiles + rounds - 1) / rounds + 7) / 8 * 8;
-  return std::min(std::min(g, 256), tiles);
+  return std::min(std::min(g, cus), tiles);
 }
 
 // persistent deep schedule (gemm_mx_deepp.hip.h): one workgroup per CU walks the tiles; 136 KiB of static LDS
@@ -169,9 +210,45 @@ int launch_gemm_deepp8(GemmParams p, hipStream_t s) {   // the fp8 twin (gemm_mx
   return check_launch("gemm_mx_deepp8_kernel");
 }
 
+// Heterogeneous launch (gemm_mx_hetero_kernel): the persistent 256x256 kernel over the full rounds of `cus` tiles + the residual
+// tiles as 128x128 quarter tiles on extra workgroups of the SAME grid, dispatched CU by CU as the persistent workgroups retire.
+template <class CB, class CT, int ST_AUX>
+int launch_gemm_hetero(GemmParams p, hipStream_t s) {
+  p.tiles_m = (int)cdiv(p.M, CB::BM);
+  p.tiles_n = (int)cdiv(p.N, CB::BN);
+  p.ws = nullptr; p.splits = 1; p.ctr = nullptr; p.tag = 0;
+  const int T = p.tiles_m * p.tiles_n;
+  const int forced = opt_deepp_grid();
+  const int g_big = std::min(forced > 0 ? forced : chip_cus(), T);
+  const int t_main = T / g_big * g_big;
+  const int nsmall = 4 * (T - t_main);
+  if (nsmall == 0) {   // a whole number of rounds: nothing residual, the plain persistent kernel
+    if constexpr (CB::EBITS == 4) return launch_gemm_deepp<CB, false, ST_AUX>(p, s);
+    else return launch_gemm_deepp8<CB>(p, s);
+  }
+  hipLaunchKernelGGL((gemm_mx_hetero_kernel<CB, CT, ST_AUX>), dim3(g_big + nsmall), dim3(256), 0, s, p, g_big, t_main);
+  return check_launch("gemm_mx_hetero_kernel");
+}
+
+// Persistent launch or heterogeneous launch for T tiles of 256x256?  Cost in units of one full round of `cus` tiles, fitted to the
+// steady-state sweeps (profiles/native_r2_mxwave.log, native_r3_hetero.log):
+//   balanced rounds   R = ceil(T / cus) rounds at occupancy o = T / (R cus): the kernels run at the socket power limit, so a round that
+//                     leaves CUs idle is cheaper -- f(o) = 0.36 + 0.64 o (768 tiles: 192 x 4 take 109.3 us against 97.9 us for 256 x 3)
+//   heterogeneous     the full rounds + waves of quarter tiles: a 128x128 tile walks K at ~0.6 us per stage against 1.79 us for the
+//                     256x256 tile, plus its own prologue / epilogue -> 0.05 + 0.38 per wave of `cus` quarter tiles
+inline bool hetero_wins(int64_t T, int cus) {
+  const int64_t r = T / cus, rem = T % cus;
+  if (r < 1 || rem == 0) return false;
+  const int64_t R = r + 1;
+  const double a = (double)R * (0.36 + 0.64 * (double)T / (double)(R * cus));
+  const double b = (double)r + 0.05 + 0.38 * (double)cdiv(4 * rem, cus);
+  return b < a;
+}
+
 // Tile/schedule variants (0 = auto; the lab library can force one through the "gemm_variant" option):
 //   PRODUCT (what the auto rules below can pick):
 //     90  persistent deep schedule, 256x256 (fp4: gemm_mx_deepp, fp8: gemm_mx_deepp8)      lab: 30 = the per-tile deep schedule of round 1
+//     98  heterogeneous launch: 90 over the full rounds + the residual tiles as 128x128 tiles in the same grid     lab: 99 = 3-deep ring for those
 //     24 / 25 / 27 / 28 / 29  simple schedule 128x128, 256x128, 128x64, 64x128, 64x64
 //     70..73  ring schedule 64x64, 128x64, 64x128, 128x128 (+ split-K)          60  skinny split-K kernel (fp4, M <= 32)
 //   LAB only:
@@ -182,22 +259,6 @@ int launch_gemm_deepp8(GemmParams p, hipStream_t s) {   // the fp8 twin (gemm_mx
 //   31..36, 41..43, 50..56  ablations / traces / clock probes of those (bench only)
 //   2  128x128 lockstep (small M or N)                     3  256x128 lockstep    4  128x256 lockstep
 //   100+b / 200+b  ablations of variants 1 / 5 (bench only), b = OR of ABL_* bits
-// Dry run (qutlass_amd_debug_gemm_plan): the dispatch code below runs unchanged, but instead of launching it records
-// which kernels it WOULD launch -- {variant, N of the launch, K splits} per launch -- so the auto rules are testable on a
-// machine without a GPU (tests/test_cabi_and_host.py).
-struct DryRun { bool on = false; int n = 0; int rec[8][3]; };
-#if QAMD_DEF(1)
-thread_local DryRun t_dry;
-#else
-extern thread_local DryRun t_dry;
-#endif
-inline bool dry_record(int variant, int n_cols, int splits) {
-  if (!t_dry.on) return false;
-  if (t_dry.n < 8) { t_dry.rec[t_dry.n][0] = variant; t_dry.rec[t_dry.n][1] = n_cols; t_dry.rec[t_dry.n][2] = splits; }
-  ++t_dry.n;
-  return true;
-}
-
 // bench-only ablations of the 8-wave 256x256 MXFP4 schedules: 100 + b ping-pong, 200 + b lockstep, 300 + b queue, b = OR
 // of ABL_* bits.  Returns -1 for any other variant.
 #if QAMD_BENCH
@@ -269,6 +330,7 @@ int dispatch_variant(int v, const GemmParams& p, hipStream_t s, const char* name
   }
   if constexpr (EBITS == 8) {
     if (v == 90) return launch_gemm_deepp8<GemmCfg<256, 256, 2, 2, 8, true>>(p, s);   // persistent deep schedule, fp8
+    if (v == 98) return launch_gemm_hetero<GemmCfg<256, 256, 2, 2, 8, true>, GemmCfg<128, 128, 2, 2, 8, true, 0, 4>, 17>(p, s);
 #if QAMD_BENCH
     if (v == 30) return launch_gemm<GemmCfg<256, 256, 2, 2, 8, true>, 4>(p, s);   // per-tile deep schedule (round 1)
 #endif
@@ -277,7 +339,9 @@ int dispatch_variant(int v, const GemmParams& p, hipStream_t s, const char* name
     // persistent deep schedule; output stores write through (sc0 sc1): nothing dirty is left for the end-of-kernel L2
     // write-back (4096^3: 34.6 -> 33.4 .. 34.4 us, never slower; profiles/native_r2_store_policy.log)
     if (v == 90) return launch_gemm_deepp<GemmCfg<256, 256, 2, 2, 4, false>, false, 17>(p, s);
+    if (v == 98) return launch_gemm_hetero<GemmCfg<256, 256, 2, 2, 4, false>, GemmCfg<128, 128, 2, 2, 4, false, 0, 4>, 17>(p, s);
 #if QAMD_BENCH
+    if (v == 99) return launch_gemm_hetero<GemmCfg<256, 256, 2, 2, 4, false>, GemmCfg<128, 128, 2, 2, 4, false, 0, 3>, 17>(p, s);
     if (v == 91) return launch_gemm_deepp<GemmCfg<256, 256, 2, 2, 4, false>, true, 17>(p, s);   //   + phase timestamps of workgroup 0 (qutlass_amd_debug_set_trace_buffer)
     if (v == 92) return launch_gemm_deepp<GemmCfg<256, 256, 2, 2, 4, false>, false, 2>(p, s);       //   output stores nt
     if (v == 93) return launch_gemm_deepp<GemmCfg<256, 256, 2, 2, 4, false>, false, 16>(p, s);      //   sc1
@@ -335,6 +399,7 @@ int dispatch_variant_a5(int v, const GemmParams& p, hipStream_t s, const char* n
     case 28: return launch_gemm<GemmCfg<64, 128, 2, 2, 8, true, 0, 2, 1>, 9>(p, s);
     case 29: return launch_gemm<GemmCfg<64, 64, 2, 2, 8, true, 0, 2, 1>, 9>(p, s);
     case 90: return launch_gemm_deepp8<GemmCfg<256, 256, 2, 2, 8, true, 0, 2, 1>>(p, s);
+    case 98: return launch_gemm_hetero<GemmCfg<256, 256, 2, 2, 8, true, 0, 2, 1>, GemmCfg<128, 128, 2, 2, 8, true, 0, 4, 1>, 17>(p, s);
     case 70: return launch_gemm<GemmCfg<64, 64, 2, 2, 8, true, 0, 3, 1>, 9>(p, s);
     case 71: return launch_gemm<GemmCfg<128, 64, 2, 2, 8, true, 0, 3, 1>, 9>(p, s);
     case 72: return launch_gemm<GemmCfg<64, 128, 2, 2, 8, true, 0, 3, 1>, 9>(p, s);
@@ -376,7 +441,7 @@ extern template int launch_gemm<GemmCfg<256, 256, 2, 2, 8, true>, 6>(GemmParams,
 // NVFP4 launches live in their own unit
 #if QAMD_DEF(4)
 int launch_nvf4_host(const NvGemmParams& p, hipStream_t s, int variant) {
-  return launch_nvf4_gemm(p, s, variant) == hipSuccess ? 0 : 1;
+  return launch_nvf4_gemm(p, s, variant, chip_cus()) == hipSuccess ? 0 : 1;
 }
 #else
 int launch_nvf4_host(const NvGemmParams& p, hipStream_t s, int variant);
@@ -410,12 +475,14 @@ inline int64_t splitk_ws_bytes(int variant, int64_t M, int64_t N, int splits) {
 }
 template <int EBITS>
 SmallPlan plan_small(int64_t M, int64_t N, int64_t K) {
+  const int64_t cus = chip_cus();
   const int64_t T64 = cdiv(M, 64) * cdiv(N, 64), T128 = cdiv(M, 128) * cdiv(N, 128);
-  if (T64 <= 256) {
+  if (T64 <= cus) {
     const int64_t KT = cdiv(K * EBITS / 8, 128);
     int64_t S = 1;
-    if (T64 < 256 && KT >= opt_splitk_min_kt()) {                                       // shorter K: the reduce pass costs more than it saves
-      S = std::min<int64_t>(std::min<int64_t>(8, opt_splitk_wg() / T64), KT / 8);   // up to one workgroup per CU, >= 8 stages per split
+    if (T64 < cus && KT >= opt_splitk_min_kt()) {                                       // shorter K: the reduce pass costs more than it saves
+      const int64_t wg = opt_splitk_wg() > 0 ? opt_splitk_wg() : cus;
+      S = std::min<int64_t>(std::min<int64_t>(8, wg / T64), KT / 8);   // up to one workgroup per CU, >= 8 stages per split
       if (S < 1) S = 1;
       const int64_t per = cdiv(KT, S);
       S = cdiv(KT, per);                                                // every split non-empty
@@ -426,8 +493,8 @@ SmallPlan plan_small(int64_t M, int64_t N, int64_t K) {
     }
     return {70, (int)S};
   }
-  if (T64 <= 512) return {N >= M ? 72 : 71, 1};
-  if (M > 64 && N > 64 && T128 <= 256) return {73, 1};
+  if (T64 <= 2 * cus) return {N >= M ? 72 : 71, 1};
+  if (M > 64 && N > 64 && T128 <= cus) return {73, 1};
   return {0, 1};
 }
 
@@ -533,7 +600,7 @@ int gemm_mx(const char* name, const void* A, const void* B, const void* A_sf, co
   // 128 tiles on, the 64x64 ring kernel streams the weight through full-line LDS-DMA and wins (N = 14336, K = 4096: 6.9 us
   // vs 9.7 us; N = 57344, K = 8192: 36 us vs 58-74 us), as does ring + split-K over caller scratch for a long K
   // (N = 4096, K = 14336, M = 16: 11.6 us vs 14.8 us).  profiles/native_r1_skinny_shapes.log, native_r1_ring.log
-  if (EBITS == 4 && ldd == N && (variant == 60 || (variant >= 44 && variant <= 49) || (variant == 0 && M <= 32 && cdiv(N, 64) < 128 && !can_split))) {   // (the skinny kernel writes a dense D)
+  if (EBITS == 4 && ldd == N && (variant == 60 || (variant >= 44 && variant <= 49) || (variant == 0 && M <= 32 && cdiv(N, 64) < chip_cus() / 2 && !can_split))) {   // (the skinny kernel writes a dense D)
     if (dry_record(variant ? variant : 60, p.N, 1)) return 0;
     SkinnyParams q;
     q.A = p.A; q.B = p.B; q.SFA = p.SFA; q.SFB = p.SFB; q.alpha = alpha; q.D = p.D; q.M = p.M; q.N = p.N; q.K = p.K;
@@ -557,29 +624,28 @@ int gemm_mx(const char* name, const void* A, const void* B, const void* A_sf, co
     // every CU work -- 256x256 ("deep" schedule, 4 waves of 128x128), then 128x128, 128x64 / 64x128, 64x64 (simple
     // schedule, several workgroups per CU).  (fp4 with M <= 32 went to the split-K kernel above.)
     auto tiles = [&](int bm, int bn) { return cdiv(M, bm) * cdiv(N, bn); };
-    const int64_t want = 192;   // 3/4 of the 256 CUs
+    const int cus = chip_cus();
+    const int64_t want = cus * 3 / 4;   // 3/4 of the CUs
     // no point in tiles taller than the problem; 64x64 until 64x128 tiles fill the chip 1.5 times (weight-bandwidth
     // bound: N = 28672, K = 4096, M = 32: 12.6 us with 448 tiles of 64x64 vs 14.3 us with 224 of 64x128)
-    if (M <= 64) variant = (tiles(64, 128) >= 384) ? 28 : 29;
+    if (M <= 64) variant = (tiles(64, 128) >= cus * 3 / 2) ? 28 : 29;
     else if (N <= 64) variant = (tiles(128, 64) >= want) ? 27 : 29;
     else if (tiles(256, 256) >= want) {
       // the persistent deep schedule (one workgroup per CU walks the tiles, epilogue folded into the last K stage), fp4 and
       // fp8; its epilogue addresses a tile with 32-bit byte offsets, so absurdly wide outputs stay with 256x128 simple tiles
       const int big = ldd < (1ll << 22) ? 90 : 25;
       variant = big;
-      // wave quantisation: T tiles on 256 CUs run ceil(T/256) rounds; when the last round is less than ~60 % full
-      // (C3 4096x14336x4096: 896 tiles = 3.5 rounds) the trailing tile columns go to a second launch with smaller
-      // tiles that fills the chip once more for a fraction of a round.  Both launches write column ranges of the same
-      // D (ldd = N); operands of the column range are plain pointer offsets (N-range starts on a 256 boundary).
-      const int64_t tm = cdiv(M, 256), tn = cdiv(N, 256), T = tm * tn, full = (T / 256) * 256;
-      const int64_t main_cols = (tm > 0) ? full / tm : 0;          // whole tile columns that fit the full rounds
-      // From three full rounds on, ONE persistent launch with balanced rounds (deepp_grid) is at least as good (C3: 118.0-119.4
-      // vs 120.2-120.7 us); with one or two full rounds the split wins or ties (4096 x 5120: 50.6 vs 51.0 us).
-      // [r2] ... and only for a SMALL tail (<= 80 tiles): a tail of half a round runs as a second, serialised launch of 256x128 tiles
-      // that quantises badly itself (3072 x 8192: 71.4 us split vs 54.6 us as one balanced launch; 5120 x 8192: 101 vs 86;
-      // 6144 x 4096: 70 vs 56), while a small tail still wins (3072 x 6144: 47.0 vs 51.4; 4096 x 5120: 50.5 vs 52.9).
-      // profiles/native_r2_mxwave.log
-      if (!(opt_pp_flags() & 64) && full >= 256 && full < 768 && main_cols >= 1 && main_cols < tn && (T - main_cols * tm) <= 80) {
+      // Wave quantisation: T tiles on `cus` CUs run ceil(T / cus) rounds, the last one part-filled (4096 x 5120: 320 tiles =
+      // 1.25 rounds).  [r3] The residual tiles run as 128x128 quarter tiles on extra workgroups of the SAME launch
+      // (gemm_mx_hetero_kernel: dispatched CU by CU as the persistent workgroups retire) whenever the cost model says so;
+      // otherwise ONE persistent launch with balanced rounds (deepp_grid).
+      const int64_t tm = cdiv(M, 256), tn = cdiv(N, 256), T = tm * tn;
+      const bool hetero_ok = big == 90 && !(opt_pp_flags() & 64);
+#if QAMD_BENCH
+      // lab, "pp_flags" bit 13: the round-1/2 form of the same idea -- the trailing tile columns as a SECOND launch of smaller tiles
+      // (kept for the A/B in profiles/native_r3_hetero.log); bit 6: neither (balanced rounds only)
+      const int64_t full = (T / cus) * cus, main_cols = (tm > 0) ? full / tm : 0;
+      if ((opt_pp_flags() & 8192) && hetero_ok && full >= cus && full < 3 * cus && main_cols >= 1 && main_cols < tn && (T - main_cols * tm) <= 80) {
         const int64_t n1 = main_cols * 256;
         GemmParams pm = p;
         pm.N = (int)n1; pm.b_bytes = (uint32_t)(n1 * rowbytes); pm.sfb_bytes = (uint32_t)(cdiv(n1, 128) * CB * 512);
@@ -594,6 +660,9 @@ int gemm_mx(const char* name, const void* A, const void* B, const void* A_sf, co
         const int vt = (tt(256, 128) >= want) ? 25 : (tt(128, 128) >= want) ? 24 : (tt(128, 64) >= want) ? 27 : 29;
         return dispatch(vt, pt, s);
       }
+      if (opt_pp_flags() & 8192) {} else
+#endif
+      if (hetero_ok && hetero_wins(T, cus)) variant = 98;
     }
     else if (tiles(128, 128) >= want) variant = 24;
     else if (tiles(128, 64) >= want || tiles(64, 128) >= want) variant = (N >= M) ? 27 : 28;
@@ -604,27 +673,28 @@ int gemm_mx(const char* name, const void* A, const void* B, const void* A_sf, co
 
 #endif   // QAMD_DEF(1)
 
-template <int R, bool NV, int METHOD, bool MASK>
+template <int R, bool NV, int METHOD, bool MASK, bool BLK>
 int launch_quant(const QuantParams& p, hipStream_t s, int grid) {
   if (g_hw_fp4_cvt.load())
-    hipLaunchKernelGGL((fused_quantize_kernel<R, NV, METHOD, MASK, true>), dim3(grid), dim3(256), 0, s, p);
+    hipLaunchKernelGGL((fused_quantize_kernel<R, NV, METHOD, MASK, true, BLK>), dim3(grid), dim3(256), 0, s, p);
   else
-    hipLaunchKernelGGL((fused_quantize_kernel<R, NV, METHOD, MASK, false>), dim3(grid), dim3(256), 0, s, p);
+    hipLaunchKernelGGL((fused_quantize_kernel<R, NV, METHOD, MASK, false, BLK>), dim3(grid), dim3(256), 0, s, p);
   return check_launch("fused_quantize_kernel");
 }
 
-template <bool NV, int METHOD, bool MASK>
+// BLK: scales written in the to_blocked() layout (qutlass_amd_fused_quantize_{mx,nv}_blocked)
+template <bool NV, int METHOD, bool MASK, bool BLK = false>
 int dispatch_rot(int rot, const QuantParams& p, hipStream_t s, int grid, const char* name) {
   switch (rot) {
     case 16:
-      if constexpr (NV) return launch_quant<16, NV, METHOD, false>(p, s, grid);
+      if constexpr (NV) return launch_quant<16, NV, METHOD, false, BLK>(p, s, grid);
       break;
-    case 32: return launch_quant<32, NV, METHOD, MASK>(p, s, grid);
+    case 32: return launch_quant<32, NV, METHOD, MASK, BLK>(p, s, grid);
     case 64:
-      if constexpr (!MASK) return launch_quant<64, NV, METHOD, false>(p, s, grid);
+      if constexpr (!MASK) return launch_quant<64, NV, METHOD, false, BLK>(p, s, grid);
       break;
     case 128:
-      if constexpr (!MASK) return launch_quant<128, NV, METHOD, false>(p, s, grid);
+      if constexpr (!MASK) return launch_quant<128, NV, METHOD, false, BLK>(p, s, grid);
       break;
   }
   if (MASK) return fail(QAMD_ERR_INVALID, "%s: Unsupported rotation size %d; expected 32.", name, rot);
@@ -637,11 +707,15 @@ int dispatch_rot(int rot, const QuantParams& p, hipStream_t s, int grid, const c
 #else
 #define QAMD_ROT_INST extern template
 #endif
-QAMD_ROT_INST int dispatch_rot<false, METHOD_QUEST, true>(int, const QuantParams&, hipStream_t, int, const char*);
-QAMD_ROT_INST int dispatch_rot<false, METHOD_QUEST, false>(int, const QuantParams&, hipStream_t, int, const char*);
-QAMD_ROT_INST int dispatch_rot<false, METHOD_ABSMAX, false>(int, const QuantParams&, hipStream_t, int, const char*);
-QAMD_ROT_INST int dispatch_rot<true, METHOD_QUEST, false>(int, const QuantParams&, hipStream_t, int, const char*);
-QAMD_ROT_INST int dispatch_rot<true, METHOD_ABSMAX, false>(int, const QuantParams&, hipStream_t, int, const char*);
+#define QAMD_ROT_BOTH(NV_, M_, K_) \
+  QAMD_ROT_INST int dispatch_rot<NV_, M_, K_, false>(int, const QuantParams&, hipStream_t, int, const char*); \
+  QAMD_ROT_INST int dispatch_rot<NV_, M_, K_, true>(int, const QuantParams&, hipStream_t, int, const char*);
+QAMD_ROT_BOTH(false, METHOD_QUEST, true)
+QAMD_ROT_BOTH(false, METHOD_QUEST, false)
+QAMD_ROT_BOTH(false, METHOD_ABSMAX, false)
+QAMD_ROT_BOTH(true, METHOD_QUEST, false)
+QAMD_ROT_BOTH(true, METHOD_ABSMAX, false)
+#undef QAMD_ROT_BOTH
 #undef QAMD_ROT_INST
 #endif
 
@@ -653,7 +727,7 @@ int quant_grid(int ntiles, int rot) {
   int per_cu = opt_quant_wg_per_cu();
   if (per_cu <= 0) per_cu = rot >= 128 ? 2 : (rot >= 64 ? 4 : 8);
   int g = (ntiles + 3) / 4;
-  const int cap = 256 * per_cu;
+  const int cap = chip_cus() * per_cu;
   return g < 1 ? 1 : (g > cap ? cap : g);
 }
 
@@ -708,7 +782,8 @@ int qutlass_amd_matmul_ada_mxf4_bf16_tn(const void* A, const void* B, const void
   const int forced = opt_gemm_variant();
   const int64_t T64 = cdiv(N, 64);   // (no split-K here -- the op has no scratch argument -- so a long K on few tiles stays with the split-K kernel:
                                      //  8 x 8192 x 28672: 27.9 us vs 34.2 us on 128 workgroups of the ring kernel)
-  const bool ring = forced == 70 || (forced != 60 && (M > 32 || T64 >= 256 || (T64 >= 128 && K < 16384)));
+  const int cus = chip_cus();
+  const bool ring = forced == 70 || (forced != 60 && (M > 32 || T64 >= cus || (T64 >= cus / 2 && K < 16384)));
   if (ring) {
     GemmParams p;
     p.A = (const uint8_t*)A; p.B = (const uint8_t*)B; p.SFA = (const uint8_t*)A_sf; p.SFB = (const uint8_t*)B_sf;
@@ -739,7 +814,7 @@ int qutlass_amd_matmul_mxf8_bf16_tn(const void* A, const void* B, const void* A_
 // one rule for the launcher and the workspace query: the persistent kernel on the (K, M) operand wherever the TN op would
 // pick the persistent 256x256 kernel for the whole problem (gemm_mx auto rule); everything smaller goes through the
 // byte-transpose pre-pass and the TN dispatch with its smaller tiles / split-K
-static bool mxf8_nn_is_fused(int64_t M, int64_t N) { return M > 64 && N > 64 && N < (1ll << 22) && cdiv(M, 256) * cdiv(N, 256) >= 192; }
+static bool mxf8_nn_is_fused(int64_t M, int64_t N) { return M > 64 && N > 64 && N < (1ll << 22) && cdiv(M, 256) * cdiv(N, 256) >= chip_cus() * 3 / 4; }
 
 int64_t qutlass_amd_mxf8_nn_workspace_bytes(int64_t M, int64_t K) { return (M > 0 && K > 0) ? M * K : 0; }
 int64_t qutlass_amd_mxf8_nn_workspace_bytes_for(int64_t M, int64_t N, int64_t K) {
@@ -837,9 +912,9 @@ int qutlass_amd_matmul_nvf4_bf16_tn(const void* A, const void* B, const void* A_
   return check_launch(name);
 }
 
-int qutlass_amd_fused_quantize_mx(const void* x, const void* h, int rot, int64_t numel, int method,
+// sf_rows / k: logical 2-D shape of x (rows of k elements) for the blocked-scale variants; k == 0: flat scales (the reference's contract)
+static int fused_quantize_mx_impl(const char* name, const void* x, const void* h, int rot, int64_t numel, int64_t k, int method,
                                   void* out_e2m1, void* out_e8m0, void* out_mask, void* stream) {
-  const char* name = "fusedQuantizeMx";
   if (!x || !h || !out_e2m1 || !out_e8m0) return fail(QAMD_ERR_INVALID, "%s: null pointer argument", name);
   if (rot != 32 && rot != 64 && rot != 128)
     return fail(QAMD_ERR_INVALID, "%s: Unsupported rotation size %d; expected %s.", name, rot, out_mask ? "32" : "32, 64, or 128");
@@ -847,35 +922,71 @@ int qutlass_amd_fused_quantize_mx(const void* x, const void* h, int rot, int64_t
   if (numel * 2 >= (1ll << 32)) return fail(QAMD_ERR_INVALID, "%s: more than 2^31 elements is not supported", name);
   if (method != QAMD_METHOD_QUEST && method != QAMD_METHOD_ABSMAX) return fail(QAMD_ERR_INVALID, "%s: invalid method %d", name, method);
   if (out_mask && method != QAMD_METHOD_QUEST) return fail(QAMD_ERR_INVALID, "%s: the clip mask is only defined for method quest", name);
+  if (k && (k % rot || numel % k)) return fail(QAMD_ERR_INVALID, "%s: the row length %lld must be a multiple of the rotation size %d and divide numel", name, (long long)k, rot);
   QuantParams p;
   p.x = (const uint16_t*)x; p.h = (const uint16_t*)h; p.out = (uint8_t*)out_e2m1; p.out_sf = (uint8_t*)out_e8m0;
   p.out_mask = (uint32_t*)out_mask; p.global_scale = nullptr; p.numel = numel;
   p.ntiles = (int)cdiv(numel, (int64_t)rot * 32);
+  p.sf_rows = k ? (int)(numel / k) : 0; p.sf_cols = k ? (int)(k / 32) : 0;
   const int grid = quant_grid(p.ntiles, rot);
   hipStream_t s = (hipStream_t)stream;
+  if (k) {
+    if (out_mask) return dispatch_rot<false, METHOD_QUEST, true, true>(rot, p, s, grid, name);
+    if (method == QAMD_METHOD_QUEST) return dispatch_rot<false, METHOD_QUEST, false, true>(rot, p, s, grid, name);
+    return dispatch_rot<false, METHOD_ABSMAX, false, true>(rot, p, s, grid, name);
+  }
   if (out_mask) return dispatch_rot<false, METHOD_QUEST, true>(rot, p, s, grid, name);
   if (method == QAMD_METHOD_QUEST) return dispatch_rot<false, METHOD_QUEST, false>(rot, p, s, grid, name);
   return dispatch_rot<false, METHOD_ABSMAX, false>(rot, p, s, grid, name);
 }
 
-int qutlass_amd_fused_quantize_nv(const void* x, const void* h, int rot, int64_t numel, int method,
+int qutlass_amd_fused_quantize_mx(const void* x, const void* h, int rot, int64_t numel, int method,
+                                  void* out_e2m1, void* out_e8m0, void* out_mask, void* stream) {
+  return fused_quantize_mx_impl("fusedQuantizeMx", x, h, rot, numel, 0, method, out_e2m1, out_e8m0, out_mask, stream);
+}
+
+int qutlass_amd_fused_quantize_mx_blocked(const void* x, const void* h, int rot, int64_t rows, int64_t k, int method,
+                                          void* out_e2m1, void* out_e8m0_blocked, void* out_mask, void* stream) {
+  const char* name = "fusedQuantizeMxBlocked";
+  if (rows <= 0 || k <= 0 || rows >= (1ll << 31) || k >= (1ll << 31)) return fail(QAMD_ERR_INVALID, "%s: bad shape (%lld, %lld)", name, (long long)rows, (long long)k);
+  return fused_quantize_mx_impl(name, x, h, rot, rows * k, k, method, out_e2m1, out_e8m0_blocked, out_mask, stream);
+}
+
+static int fused_quantize_nv_impl(const char* name, const void* x, const void* h, int rot, int64_t numel, int64_t k, int method,
                                   const float* global_scale, void* out_e2m1, void* out_e4m3, void* stream) {
-  const char* name = "fusedQuantizeNv";
   if (!x || !h || !out_e2m1 || !out_e4m3 || !global_scale) return fail(QAMD_ERR_INVALID, "%s: null pointer argument", name);
   if (rot != 16 && rot != 32 && rot != 64 && rot != 128)
     return fail(QAMD_ERR_INVALID, "%s: Unsupported rotation size %d; expected 16, 32, 64, or 128.", name, rot);
   if (numel <= 0 || numel % rot) return fail(QAMD_ERR_INVALID, "%s: A must be divisible by %d", name, rot);
   if (numel * 2 >= (1ll << 32)) return fail(QAMD_ERR_INVALID, "%s: more than 2^31 elements is not supported", name);
   if (method != QAMD_METHOD_QUEST && method != QAMD_METHOD_ABSMAX) return fail(QAMD_ERR_INVALID, "%s: invalid method %d", name, method);
+  const int rp = rot < 32 ? 32 : rot;
+  if (k && (k % rp || numel % k)) return fail(QAMD_ERR_INVALID, "%s: the row length %lld must be a multiple of %d and divide numel", name, (long long)k, rp);
   QuantParams p;
   p.x = (const uint16_t*)x; p.h = (const uint16_t*)h; p.out = (uint8_t*)out_e2m1; p.out_sf = (uint8_t*)out_e4m3;
   p.out_mask = nullptr; p.global_scale = global_scale; p.numel = numel;
-  const int rp = rot < 32 ? 32 : rot;
   p.ntiles = (int)cdiv(numel, (int64_t)rp * 32);
+  p.sf_rows = k ? (int)(numel / k) : 0; p.sf_cols = k ? (int)(k / 16) : 0;
   const int grid = quant_grid(p.ntiles, rot);
   hipStream_t s = (hipStream_t)stream;
+  if (k) {
+    if (method == QAMD_METHOD_QUEST) return dispatch_rot<true, METHOD_QUEST, false, true>(rot, p, s, grid, name);
+    return dispatch_rot<true, METHOD_ABSMAX, false, true>(rot, p, s, grid, name);
+  }
   if (method == QAMD_METHOD_QUEST) return dispatch_rot<true, METHOD_QUEST, false>(rot, p, s, grid, name);
   return dispatch_rot<true, METHOD_ABSMAX, false>(rot, p, s, grid, name);
+}
+
+int qutlass_amd_fused_quantize_nv(const void* x, const void* h, int rot, int64_t numel, int method,
+                                  const float* global_scale, void* out_e2m1, void* out_e4m3, void* stream) {
+  return fused_quantize_nv_impl("fusedQuantizeNv", x, h, rot, numel, 0, method, global_scale, out_e2m1, out_e4m3, stream);
+}
+
+int qutlass_amd_fused_quantize_nv_blocked(const void* x, const void* h, int rot, int64_t rows, int64_t k, int method,
+                                          const float* global_scale, void* out_e2m1, void* out_e4m3_blocked, void* stream) {
+  const char* name = "fusedQuantizeNvBlocked";
+  if (rows <= 0 || k <= 0 || rows >= (1ll << 31) || k >= (1ll << 31)) return fail(QAMD_ERR_INVALID, "%s: bad shape (%lld, %lld)", name, (long long)rows, (long long)k);
+  return fused_quantize_nv_impl(name, x, h, rot, rows * k, k, method, global_scale, out_e2m1, out_e4m3_blocked, stream);
 }
 
 int qutlass_amd_backward_t_bf16(const void* x, const void* h, int64_t B, int64_t N, int64_t M, void* out_e2m1,
@@ -890,7 +1001,7 @@ int qutlass_amd_backward_t_bf16(const void* x, const void* h, int64_t B, int64_t
   p.B = (int)B; p.N = (int)N; p.M = (int)M; p.tiles_m = (int)cdiv(M, 64);
   if (B * (N / 32) * p.tiles_m >= (1ll << 31) - 65536) return fail(QAMD_ERR_INVALID, "%s: tensor too large", name);
   const int64_t ntw = B * p.tiles_m * cdiv(N / 32, 8);   // workgroup tiles: 8 scale groups (256 n) x 64 m
-  const int grid = (int)std::min<int64_t>(ntw, 256 * 2);   // several tiles per workgroup: the kernel prefetches the next tile
+  const int grid = (int)std::min<int64_t>(ntw, chip_cus() * 2);   // several tiles per workgroup: the kernel prefetches the next tile
   if (g_hw_fp4_cvt.load()) hipLaunchKernelGGL((bwd_quant_t_kernel<false, true>), dim3(grid), dim3(512), 0, (hipStream_t)stream, p);
   else hipLaunchKernelGGL((bwd_quant_t_kernel<false, false>), dim3(grid), dim3(512), 0, (hipStream_t)stream, p);
   return check_launch("bwd_quant_t_kernel");
@@ -909,7 +1020,7 @@ int qutlass_amd_backward_qt_bf16(const void* x_e2m1, const void* x_e8m0, const v
   p.B = (int)B; p.N = (int)N; p.M = (int)M; p.tiles_m = (int)cdiv(M, 64);
   if (B * (N / 32) * p.tiles_m >= (1ll << 31) - 65536) return fail(QAMD_ERR_INVALID, "%s: tensor too large", name);
   const int64_t ntw = B * p.tiles_m * cdiv(N / 32, 8);
-  const int grid = (int)std::min<int64_t>(ntw, 256 * 2);
+  const int grid = (int)std::min<int64_t>(ntw, chip_cus() * 2);
   if (g_hw_fp4_cvt.load()) hipLaunchKernelGGL((bwd_quant_t_kernel<true, true>), dim3(grid), dim3(512), 0, (hipStream_t)stream, p);
   else hipLaunchKernelGGL((bwd_quant_t_kernel<true, false>), dim3(grid), dim3(512), 0, (hipStream_t)stream, p);
   return check_launch("bwd_quant_t_kernel");
@@ -957,7 +1068,7 @@ int qutlass_amd_to_blocked(const void* in, int64_t rows, int64_t cols, void* out
   p.RB = (int)cdiv(rows, 128); p.CB = (int)cdiv(cols, 4);
   // columns per workgroup: the widest slab that still gives every CU a workgroup
   int tc = 128;
-  while (tc > 16 && (int64_t)p.RB * cdiv(p.CB, tc / 4) < 256) tc >>= 1;
+  while (tc > 16 && (int64_t)p.RB * cdiv(p.CB, tc / 4) < chip_cus()) tc >>= 1;
   const int64_t grid = (int64_t)p.RB * cdiv(p.CB, tc / 4);
   if (grid >= (1ll << 31)) return fail(QAMD_ERR_INVALID, "to_blocked: matrix too large");
   switch (tc) {

@@ -136,7 +136,9 @@ struct GemmCtx {
   v8i fa[KSL][MT], fb[KSL][NT];   // only the slices a schedule keeps live are materialised
   int sa[MT], sb[NT];
 
-  __device__ __forceinline__ GemmCtx(char* smem_, const GemmParams& p_) : smem(smem_), p(p_) {
+  // bid: linear tile id (the workgroup id of a plain launch).  fm0 / fn0 >= 0: the tile's origin is given instead (residual
+  // tiles of a heterogeneous launch, gemm_mx_deepp.hip.h: any 128-aligned origin inside the output).
+  __device__ __forceinline__ GemmCtx(char* smem_, const GemmParams& p_, int bid = (int)blockIdx.x, int fm0 = -1, int fn0 = -1) : smem(smem_), p(p_) {
     tid = threadIdx.x;
     lane = tid & 63;
     wave = uniform(tid >> 6);
@@ -149,7 +151,7 @@ struct GemmCtx {
     int tile_m, tile_n;
     {
       const int nb = p.tiles_m * p.tiles_n;
-      const int b2 = xcd_remap(blockIdx.x, nb);
+      const int b2 = xcd_remap(bid, nb);
       constexpr int GM = 4;
       const int group = GM * p.tiles_n;
       const int gid = b2 / group;
@@ -160,6 +162,7 @@ struct GemmCtx {
     }
     m0 = tile_m * C::BM;
     n0 = tile_n * C::BN;
+    if (fm0 >= 0) { m0 = fm0; n0 = fn0; }
     rowbytes = (p.K * C::EBITS) >> 3;
     KT = (rowbytes + C::ROWB - 1) / C::ROWB;
     CB = (p.K / 32 + 3) >> 2;
@@ -1553,14 +1556,14 @@ constexpr int ringp_aux_item(int a, int nr, int nd) {
 }
 
 template <class C, bool RM = false>
-__device__ __forceinline__ void gemm_mx_ringp(char* smem, const GemmParams& p) {
+__device__ __forceinline__ void gemm_mx_ringp(char* smem, const GemmParams& p, int bid = (int)blockIdx.x, int fm0 = -1, int fn0 = -1) {
   constexpr int KSL = C::KSL, D = C::NSTAGE, MT = C::MT, NT = C::NT, CPS = C::CPS;
   constexpr int LPS = C::NA + C::NB + 1;            // DMA instructions per wave per stage
   constexpr int U = (D % 2 == 0) ? D : 2 * D;       // unroll: slot = u % D, register set = u & 1
   static_assert(D >= 2 && (D - 2) * LPS <= 63, "vmcnt immediate");   // D = 2: one stage in flight, LDS of the simple schedule (two workgroups per CU)
   static_assert(!RM || (C::EBITS == 4 && C::BM == 64 && C::BN == 64 && C::NWAVES == 4), "row-major scales: 64x64 fp4 tiles");
   static_assert(C::ABL == 0, "no ablation builds of this schedule");
-  GemmCtx<C> cx(smem, p);
+  GemmCtx<C> cx(smem, p, bid, fm0, fn0);
   __amdgpu_buffer_rsrc_t rSrm = cx.rS;
   int vSrm = 0x7fffffff;
   const int KBr = p.K >> 5;                         // scale bytes per row (row-major)

@@ -44,8 +44,11 @@ constexpr int deepp_pair_done_at(int s) { return (s >= 3 && s <= 59 && (s - 3) %
 // TRACE (lab build only): workgroup 0, wave 0 writes {shader cycles, 100 MHz wall ticks} pairs to p.dbg at: kernel entry,
 // first stage landed, entry of the last stage of every tile, end of that stage, kernel exit (after the last store ack).
 // ST_AUX: cache-policy bits of the output stores (buffer_store aux: 1 = sc0, 2 = nt, 16 = sc1; lab variants only, product = 0).
+// bid / G: this workgroup's id among the G persistent workgroups; ntiles: the tiles they walk (tiles 0 .. ntiles-1 of the grouped
+// raster).  A plain launch passes blockIdx.x / gridDim.x / all tiles; the heterogeneous launch (gemm_mx_hetero_kernel, end of this
+// file) gives the persistent workgroups the full rounds and runs the residual tiles as 128x128 tiles on other workgroups.
 template <class C, bool TRACE = false, int ST_AUX = 0>
-__device__ __forceinline__ void gemm_mx_deepp(char* smem, const GemmParams& p) {
+__device__ __forceinline__ void gemm_mx_deepp(char* smem, const GemmParams& p, const int bid, const int G, const int ntiles) {
   static_assert(C::EBITS == 4 && C::BM == 256 && C::BN == 256 && C::WAVES_M == 2 && C::WAVES_N == 2 && C::NSTAGE == 2 && C::PPW == 2,
                 "persistent deep schedule: fp4, 256x256 tiles, 4 waves of 128x128");
   constexpr int MT = 4, NT = 4;
@@ -53,8 +56,7 @@ __device__ __forceinline__ void gemm_mx_deepp(char* smem, const GemmParams& p) {
   GemmCtx<C> cx(smem, p);   // per-lane offsets / LDS addresses; its tile coordinates and descriptors are NOT used here
   const int lane = cx.lane, wave = cx.wave, i32 = cx.i32, g = cx.g;
   const int KT = cx.KT, KTe = (KT + 1) & ~1, CB = cx.CB, rowbytes = cx.rowbytes;
-  const int ntiles = p.tiles_m * p.tiles_n, G = (int)gridDim.x;
-  const int wg = xcd_remap((int)blockIdx.x, G);
+  const int wg = xcd_remap(bid, G);
 
   auto fence = [&]() __attribute__((always_inline)) { __builtin_amdgcn_sched_barrier(0); };
   int trace_n = 0;
@@ -379,7 +381,7 @@ __device__ __forceinline__ void gemm_mx_deepp(char* smem, const GemmParams& p) {
 constexpr int deepp8_pair_done_at(int s) { return (s >= 1 && s <= 29 && (s - 1) % 4 == 0) ? (s - 1) / 4 : -1; }
 
 template <class C, int ST_AUX = 0, bool NN = false, int NNABL = 0>
-__device__ __forceinline__ void gemm_mx_deepp8(char* smem, const GemmParams& p) {
+__device__ __forceinline__ void gemm_mx_deepp8(char* smem, const GemmParams& p, const int bid, const int G, const int ntiles) {
   static_assert(C::EBITS == 8 && C::F8SPLIT && C::BM == 256 && C::BN == 256 && C::WAVES_M == 2 && C::WAVES_N == 2 && C::NSTAGE == 2 && C::PPW == 1,
                 "persistent deep schedule (fp8): 256x256 tiles, 4 waves of 128x128, split register layout");
   constexpr int MT = 4, NT = 4;
@@ -387,8 +389,7 @@ __device__ __forceinline__ void gemm_mx_deepp8(char* smem, const GemmParams& p) 
   GemmCtx<C> cx(smem, p);   // per-lane offsets / LDS addresses; its tile coordinates and descriptors are NOT used here
   const int lane = cx.lane, wave = cx.wave, i32 = cx.i32, g = cx.g;
   const int KT = cx.KT, KTe = (KT + 1) & ~1, CB = cx.CB, rowbytes = cx.rowbytes;
-  const int ntiles = p.tiles_m * p.tiles_n, G = (int)gridDim.x;
-  const int wg = xcd_remap((int)blockIdx.x, G);
+  const int wg = xcd_remap(bid, G);
   auto fence = [&]() __attribute__((always_inline)) { __builtin_amdgcn_sched_barrier(0); };
 
   auto decode = [&](int t, int& m0, int& n0) __attribute__((always_inline)) {
@@ -722,13 +723,56 @@ __device__ __forceinline__ void gemm_mx_deepp8(char* smem, const GemmParams& p) 
 template <class C, int ST_AUX = 0, bool NN = false, int NNABL = 0>
 __global__ __launch_bounds__(C::THREADS) void gemm_mx_deepp8_kernel(const GemmParams p) {
   __shared__ __attribute__((aligned(16))) char smem[DeepPCfg<C>::LDS_BYTES];
-  gemm_mx_deepp8<C, ST_AUX, NN, NNABL>(smem, p);
+  gemm_mx_deepp8<C, ST_AUX, NN, NNABL>(smem, p, (int)blockIdx.x, (int)gridDim.x, p.tiles_m * p.tiles_n);
 }
 
 template <class C, bool TRACE = false, int ST_AUX = 0>
 __global__ __launch_bounds__(C::THREADS) void gemm_mx_deepp_kernel(const GemmParams p) {
   __shared__ __attribute__((aligned(16))) char smem[DeepPCfg<C>::LDS_BYTES];
-  gemm_mx_deepp<C, TRACE, ST_AUX>(smem, p);
+  gemm_mx_deepp<C, TRACE, ST_AUX>(smem, p, (int)blockIdx.x, (int)gridDim.x, p.tiles_m * p.tiles_n);
+}
+
+// -------------------------------------------------------------------------------------------------------------------------
+// Heterogeneous launch ("residual-round scheduler"): ONE grid, two kinds of workgroups.
+//   blockIdx.x <  g_big : the persistent 256x256 kernel above over the first t_main tiles of the grouped raster (t_main = a whole
+//                         number of rounds of g_big tiles: every persistent workgroup walks the same number of tiles)
+//   blockIdx.x >= g_big : one 128x128 tile each (pipelined ring schedule, gemm_mx_ringp) of the RESIDUAL 256x256 tiles
+//                         t_main .. T-1, four per residual tile
+// Every workgroup claims the kernel's whole static LDS (one per CU), so the residual workgroups are dispatched CU by CU as the
+// persistent ones retire: the part-filled last round of a ragged tile count (320 tiles on 256 CUs = 1.25 rounds) turns into a short
+// wave of quarter tiles that starts as soon as the first CUs are free -- no second launch (its launch gap and the serialisation
+// behind the slowest persistent workgroup), no K split, no partial sums, no scratch: every output element is still computed by
+// exactly one workgroup in the same K order, so the result is bit-identical to every other schedule.
+// Reference counterpart: the M-bucketed tile choice + CUTLASS tile scheduler of qutlass/csrc/gemm.cu:195-222.
+// -------------------------------------------------------------------------------------------------------------------------
+template <class CB, class CT, int ST_AUX = 0>
+__global__ __launch_bounds__(256) void gemm_mx_hetero_kernel(const GemmParams p, const int g_big, const int t_main) {
+  static_assert(CB::THREADS == 256 && CT::THREADS == 256 && CT::BM == 128 && CT::BN == 128 && CB::EBITS == CT::EBITS && CB::AFMT == CT::AFMT, "tile pair");
+  constexpr int LDS = DeepPCfg<CB>::LDS_BYTES > CT::LDS_BYTES ? DeepPCfg<CB>::LDS_BYTES : CT::LDS_BYTES;
+  static_assert(LDS <= 160 * 1024, "LDS budget");
+  // (device pass only: the host pass has already instantiated the same gemm_mx_deepp specialisation for the plain kernel, and clang
+  // marks a __device__ specialisation whose body holds target builtins as invalid for every later host-side reference)
+#if defined(__HIP_DEVICE_COMPILE__)
+  __shared__ __attribute__((aligned(16))) char smem[LDS];
+  const int b = (int)blockIdx.x;
+  if (b < g_big) {
+    if constexpr (CB::EBITS == 4) gemm_mx_deepp<CB, false, ST_AUX>(smem, p, b, g_big, t_main);
+    else gemm_mx_deepp8<CB, ST_AUX>(smem, p, b, g_big, t_main);
+    return;
+  }
+  // residual quarter tile j: the dispatcher hands workgroup b to XCD b % 8, so ids are shifted by g_big % 8 (mod the count) before
+  // the XCD-contiguous remap -- each XCD then works on a contiguous run of residual tiles (shared operand panels in its L2)
+  const int nsmall = 4 * (p.tiles_m * p.tiles_n - t_main);
+  int j = (b - g_big + (g_big & 7)) % nsmall;
+  j = xcd_remap(j, nsmall);
+  const int t = t_main + (j >> 2);
+  constexpr int GM = 4;   // the grouped raster of the persistent kernel (decode)
+  const int group = GM * p.tiles_n, gid = t / group, first_m = gid * GM, gsz = min(p.tiles_m - first_m, GM), rem = t - gid * group;
+  const int m0 = uniform((first_m + rem % gsz) * CB::BM + ((j >> 1) & 1) * 128);
+  const int n0 = uniform((rem / gsz) * CB::BN + (j & 1) * 128);
+  if (m0 >= p.M || n0 >= p.N) return;   // quarter of a partial edge tile that lies outside the output
+  gemm_mx_ringp<CT>(smem, p, 0, m0, n0);
+#endif
 }
 
 }  // namespace qamd

@@ -262,14 +262,18 @@ __global__ __launch_bounds__(C::THREADS) void gemm_nvf4_kernel(const NvGemmParam
 
   const float alpha = *p.alpha;
   __syncthreads();
+  // the epilogue re-derives lane / thread id (v_mbcnt) instead of keeping them live across the K loop: with 256 accumulators
+  // + two fragment sets the 256x256 tile is at the 256-VGPR limit and the three id registers were spilled to scratch
+  const int elane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+  const int etid = wave * 64 + elane, ei32 = elane & 31, eg = elane >> 5;
 #pragma unroll
   for (int m = 0; m < MT; ++m)
 #pragma unroll
     for (int n = 0; n < NT; ++n)
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const int row = wave_m * C::WTM + 32 * m + i32;
-        const int cg = (wave_n * C::WTN + 32 * n + 8 * q + 4 * g) >> 2;
+        const int row = wave_m * C::WTM + 32 * m + ei32;
+        const int cg = (wave_n * C::WTN + 32 * n + 8 * q + 4 * eg) >> 2;
         v2i w;
         w[0] = pack_bf16x2(acc[m][n][4 * q + 0] * alpha, acc[m][n][4 * q + 1] * alpha);
         w[1] = pack_bf16x2(acc[m][n][4 * q + 2] * alpha, acc[m][n][4 * q + 3] * alpha);
@@ -278,7 +282,7 @@ __global__ __launch_bounds__(C::THREADS) void gemm_nvf4_kernel(const NvGemmParam
   __syncthreads();
   constexpr int CPR = BN / 8;
   constexpr int RPP = C::THREADS / CPR;
-  const int chunk = tid % CPR, r0 = tid / CPR;
+  const int chunk = etid % CPR, r0 = etid / CPR;
   const int gcol = n0 + chunk * 8;
 #pragma unroll 4
   for (int pss = 0; pss < BM / RPP; ++pss) {
@@ -641,16 +645,18 @@ bool launch_nvf4_ablation(NvGemmParams p, hipStream_t s, int variant);
 
 #if QAMD_TU == 0 || QAMD_TU == 4
 // Returns hipErrorInvalidValue for a variant this build does not know (the product library knows only 0 = auto).
-inline hipError_t launch_nvf4_gemm(NvGemmParams p, hipStream_t s, int variant = 0) {
+// cus: compute units of the device (capi.hip chip_cus): every occupancy threshold below derives from it
+inline hipError_t launch_nvf4_gemm(NvGemmParams p, hipStream_t s, int variant = 0, int cus = 256) {
+  const int64_t want = cus * 3 / 4;
 #if !QAMD_BENCH
   if (variant != 0) return hipErrorInvalidValue;
 #endif
   // 128x128 tiles when a dimension is small OR when 256x256 tiles would leave most CUs without work
-  const bool small = p.M <= 128 || p.N <= 128 || (int64_t)((p.M + 255) / 256) * ((p.N + 255) / 256) < 192;
+  const bool small = p.M <= 128 || p.N <= 128 || (int64_t)((p.M + 255) / 256) * ((p.N + 255) / 256) < want;
   // small batch: split-K kernel for M <= 64, and up to M = 128 while even 64x64 tiles would leave CUs idle (measured,
   // M = 128, K = 4096: N = 4096 11.8 us vs 17.3 us for 64x64 tiles; N = 14336 35.6 us vs 25.2 us for 128x64 tiles)
   const int64_t tiles64 = (int64_t)((p.M + 63) / 64) * ((p.N + 63) / 64);
-  if (variant == 3 || (variant == 0 && (p.M <= 64 || (p.M <= 128 && tiles64 < 192)))) {
+  if (variant == 3 || (variant == 0 && (p.M <= 64 || (p.M <= 128 && tiles64 < want)))) {
     hipLaunchKernelGGL((gemm_nvf4_skinny_kernel<8>), dim3((p.N + 31) / 32, (p.M + 31) / 32), dim3(512), 0, s, p);
     return hipSuccess;
   }
@@ -674,10 +680,10 @@ inline hipError_t launch_nvf4_gemm(NvGemmParams p, hipStream_t s, int variant = 
       // profiles/native_r2_nvwave.log)
       if (cfg == 0) {
         const int64_t t256 = tiles(256, 256), t128 = tiles(128, 128);
-        const double e256 = (double)t256 / (double)((t256 + 255) / 256 * 256), e128 = (double)t128 / (double)((t128 + 511) / 512 * 512);
+        const double e256 = (double)t256 / (double)((t256 + cus - 1) / cus * cus), e128 = (double)t128 / (double)((t128 + 2 * cus - 1) / (2 * cus) * (2 * cus));
         if (e256 < 0.85 * e128) cfg = 1;
       }
-      if (cfg == 1 && tiles(128, 128) < 192) cfg = (tiles(128, 64) >= 192) ? 2 : 3;
+      if (cfg == 1 && tiles(128, 128) < want) cfg = (tiles(128, 64) >= want) ? 2 : 3;
     }
     if (variant == 5) cfg = 1;
     if (variant == 6) cfg = 2;

@@ -32,7 +32,15 @@ struct QuantParams {
   const float* global_scale;  // NV only
   int64_t numel;
   int ntiles;          // ceil(numel / (max(R,32) * 32)): tiles of 32 rows x max(R,32) elements
+  // BLK kernels only (fusedQuantize{Mx,Nv}Blocked): the scales go straight into the to_blocked() layout of the logical
+  // (sf_rows, sf_cols) scale matrix -- sf_rows = numel / K, sf_cols = K / 32 (MX) or K / 16 (NV) -- padding zero-filled
+  int sf_rows, sf_cols;
 };
+
+// byte offset of scale (row, col) in the 128x4-tiled block-scale layout (qutlass/utils.py:60-64, :190-193); CB = ceil(cols / 4)
+__device__ __forceinline__ uint32_t blocked_sf_offset(uint32_t row, uint32_t col, uint32_t CB) {
+  return ((row >> 7) * CB + (col >> 2)) * 512u + (row & 31u) * 16u + ((row & 127u) >> 5) * 4u + (col & 3u);
+}
 
 // --- e2m1 encoders -------------------------------------------------------------------------------
 // Software RTNE-satfinite encoder (semantics of PTX cvt.rn.satfinite.e2m1x2.f32; oracle:
@@ -110,8 +118,9 @@ __device__ __forceinline__ float e4m3_decode_pos(uint32_t b) {
 //   METHOD : METHOD_QUEST / METHOD_ABSMAX
 //   MASK   : MX quest only: also emit the clip mask
 //   HWCVT  : use v_cvt_scalef32_pk_fp4_f32 for the final RTNE
+//   BLK    : scale bytes are written in the to_blocked() layout (GEMM-ready: no separate swizzle launch) instead of flat
 // -------------------------------------------------------------------------------------------------
-template <int R, bool NV, int METHOD, bool MASK, bool HWCVT>
+template <int R, bool NV, int METHOD, bool MASK, bool HWCVT, bool BLK = false>
 __global__ __launch_bounds__(256) void fused_quantize_kernel(const QuantParams p) {
   constexpr int RP = (R < 32) ? 32 : R;         // rotation padded to one MFMA j-tile (R=16: block-diag)
   constexpr int KC = RP / 16;                   // 16-wide k chunks per row
@@ -148,6 +157,18 @@ __global__ __launch_bounds__(256) void fused_quantize_kernel(const QuantParams p
     for (int kc = 0; kc < RP / 16; ++kc) xnext[kc] = __builtin_amdgcn_raw_buffer_load_b128(rx, xoff0 + kc * LSTEP, 0, 0);
   }
   const float gscale = NV ? *p.global_scale : 1.0f;
+  const uint32_t sfCB = BLK ? ((uint32_t)p.sf_cols + 3u) >> 2 : 0u;
+  if (BLK) {
+    // zero padding of the blocked layout (rows up to a multiple of 128, columns up to a multiple of 4), as to_blocked writes it
+    const uint32_t prow = ((uint32_t)p.sf_rows + 127u) & ~127u, pcol = sfCB * 4u;
+    const uint32_t n1 = (prow - (uint32_t)p.sf_rows) * pcol, cpad = pcol - (uint32_t)p.sf_cols, n2 = (uint32_t)p.sf_rows * cpad;
+    for (uint32_t i = blockIdx.x * 256u + tid; i < n1 + n2; i += gridDim.x * 256u) {
+      uint32_t r, c;
+      if (i < n1) { r = (uint32_t)p.sf_rows + i / pcol; c = i % pcol; }
+      else { const uint32_t j = i - n1; r = j / cpad; c = (uint32_t)p.sf_cols + j % cpad; }
+      p.out_sf[blocked_sf_offset(r, c, sfCB)] = 0;
+    }
+  }
 
   // ---- H^T image in LDS: hT[j][k] = h[k][j]; R = 16 becomes blockdiag(h, h) so that one 32-wide
   //      MFMA tile rotates two adjacent 16-element rows at once
@@ -182,6 +203,14 @@ __global__ __launch_bounds__(256) void fused_quantize_kernel(const QuantParams p
     int hoist_guard = 0;
     if (RP >= 64) asm volatile("" : "+v"(hoist_guard));
     const int64_t r_abs = (int64_t)tile * 32 + row;
+    // BLK: position of this lane's RP-element row in the logical scale matrix (one division per tile, not per group)
+    uint32_t sf_row = 0, sf_col0 = 0;
+    if (BLK) {
+      const uint32_t gpr = NV ? 2 * JT : JT;                        // scale groups per RP-element row
+      const uint32_t rpr = (uint32_t)p.sf_cols / gpr;               // RP-element rows per logical row (K / RP)
+      sf_row = (uint32_t)r_abs / rpr;
+      sf_col0 = ((uint32_t)r_abs - sf_row * rpr) * gpr;
+    }
     // X^T operand: lane (row, half), chunk kc -> x[r_abs][16 kc + 8 half .. +8)  (16 bytes).  Software pipeline: the
     // loads of the wave's NEXT tile are issued before this tile is computed (tiles past the end fall off the buffer
     // descriptor and read 0), so the HBM latency of tile i+1 hides behind the MFMAs / epilogue of tile i.
@@ -275,7 +304,7 @@ __global__ __launch_bounds__(256) void fused_quantize_kernel(const QuantParams p
         const bool ok = grp32 < ngroups;
         if (ok) {
           *(v2i*)(p.out + grp32 * 16 + half * 8) = o;
-          if (half == 0) p.out_sf[grp32] = (uint8_t)e8;
+          if (half == 0) p.out_sf[BLK ? (int64_t)blocked_sf_offset(sf_row, sf_col0 + jt, sfCB) : grp32] = (uint8_t)e8;
         }
         if (MASK) {
           const uint32_t mm = xhalf_or(mbits);
@@ -333,7 +362,7 @@ __global__ __launch_bounds__(256) void fused_quantize_kernel(const QuantParams p
           const int64_t grp16 = grp32 * 2 + sub;
           if (grp16 < ngroups) {
             *(uint32_t*)(p.out + grp16 * 8 + half * 4) = half ? d1 : d0;
-            if (half == 0) p.out_sf[grp16] = (uint8_t)sfb;
+            if (half == 0) p.out_sf[BLK ? (int64_t)blocked_sf_offset(sf_row, sf_col0 + 2 * jt + sub, sfCB) : grp16] = (uint8_t)sfb;
           }
         }
       }

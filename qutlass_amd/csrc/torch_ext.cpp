@@ -124,10 +124,9 @@ Tensor matmul(const Tensor& A, const Tensor& B, const Tensor& A_sf, const Tensor
   }
   STD_TORCH_CHECK(B.size(1) >= kmin, "B K-dim must be >= ", kmin);
   const int64_t N = B.size(0), K = B.size(1) * (fp8 ? 1 : 2);
-  Tensor out = torch::stable::new_empty(A, {M, N}, ScalarType::BFloat16);
-  if (M == 0 || N == 0) return out;   // empty batch / empty weight: nothing to launch (the C ABI requires positive extents)
   // the kernels read alpha as one fp32 and the scale operands through descriptors sized from M / N / K: make sure the
-  // tensors are at least that large (the reference leaves both to CUTLASS' can_implement / the caller)
+  // tensors are at least that large (the reference leaves both to CUTLASS' can_implement / the caller); checked before the
+  // empty-shape return so that a malformed argument fails whatever the batch size
   STD_TORCH_CHECK(has_dtype(alpha, ScalarType::Float) && alpha.numel() >= 1, "alpha must be a float32 tensor with at least one element");
   {
     const int64_t gs = G == Gemm::NVF4 ? 16 : 32, kb = K / gs;
@@ -137,6 +136,8 @@ Tensor matmul(const Tensor& A, const Tensor& B, const Tensor& A_sf, const Tensor
     STD_TORCH_CHECK(A_sf.numel() >= need_a, "A_sf has ", A_sf.numel(), " elements, the ", row_major_sf ? "row-major" : "blocked", " scale layout of A needs ", need_a);
     STD_TORCH_CHECK(B_sf.numel() >= need_b, "B_sf has ", B_sf.numel(), " elements, the ", row_major_sf ? "row-major" : "blocked", " scale layout of B needs ", need_b);
   }
+  Tensor out = torch::stable::new_empty(A, {M, N}, ScalarType::BFloat16);
+  if (M == 0 || N == 0) return out;   // empty batch / empty weight: nothing to launch (the C ABI requires positive extents)
 
   const torch::stable::accelerator::DeviceGuard guard(A.get_device_index());
   const float* al = static_cast<const float*>(alpha.data_ptr());
@@ -252,6 +253,48 @@ std::tuple<Tensor, Tensor> fusedQuantizeNvAbsMax(const Tensor& A, const Tensor& 
   return {OUT, OUT_sf};
 }
 
+// ---- EXTENSION: quantizers that emit GEMM-ready (to_blocked-layout) scales: one launch instead of quantize + to_blocked ----------
+// A is (.., K); OUT_sf must hold the padded blocked matrix of the (numel / K, K / gs) scales.  method: 0 quest, 1 abs_max.
+std::tuple<Tensor, Tensor> fusedQuantizeMxBlocked(const Tensor& A, const Tensor& R, Tensor OUT, Tensor OUT_sf, int64_t method) {
+  const char* op = "fusedQuantizeMxBlocked";
+  require_contiguous(op, {{A, "A"}, {R, "B"}, {OUT, "OUT"}, {OUT_sf, "OUT_sf"}});
+  require_gpu(op, {{A, "A"}, {R, "B"}, {OUT, "OUT"}, {OUT_sf, "OUT_sf"}});
+  require_same_gpu(op, {{A, "A"}, {R, "B"}, {OUT, "OUT"}, {OUT_sf, "OUT_sf"}});
+  quant_prologue(op, A, R);
+  STD_TORCH_CHECK(R.dim() == 2 && R.size(0) == R.size(1), "Rotation matrix must be square");
+  STD_TORCH_CHECK(A.dim() >= 1 && A.numel() > 0, "A must be a non-empty tensor");
+  const int64_t rot = R.size(0), numel = A.numel(), k = A.size(A.dim() - 1), rows = numel / k;
+  STD_TORCH_CHECK(rot == 32 || rot == 64 || rot == 128, "Unsupported rotation size ", rot, "; expected 32, 64, or 128.");
+  STD_TORCH_CHECK(k % rot == 0, "the last dimension of A must be divisible by", rot);
+  STD_TORCH_CHECK(nbytes(OUT) >= numel / 2, "OUT is too small");
+  STD_TORCH_CHECK(nbytes(OUT_sf) >= (rows + 127) / 128 * 128 * ((k / 32 + 3) / 4 * 4), "OUT_sf is too small for the blocked scale layout");
+  const torch::stable::accelerator::DeviceGuard guard(A.get_device_index());
+  check_rc(qutlass_amd_fused_quantize_mx_blocked(A.data_ptr(), R.data_ptr(), (int)rot, rows, k, (int)method, OUT.data_ptr(), OUT_sf.data_ptr(), nullptr,
+                                                 current_stream(A)));
+  return {OUT, OUT_sf};
+}
+
+std::tuple<Tensor, Tensor> fusedQuantizeNvBlocked(const Tensor& A, const Tensor& R, Tensor OUT, Tensor OUT_sf, const Tensor& gscale, int64_t method) {
+  const char* op = "fusedQuantizeNvBlocked";
+  require_contiguous(op, {{A, "A"}, {R, "B"}, {OUT, "OUT"}, {OUT_sf, "OUT_sf"}});
+  require_gpu(op, {{A, "A"}, {R, "B"}, {OUT, "OUT"}, {OUT_sf, "OUT_sf"}, {gscale, "global_scale"}});
+  require_same_gpu(op, {{A, "A"}, {R, "B"}, {OUT, "OUT"}, {OUT_sf, "OUT_sf"}, {gscale, "global_scale"}});
+  quant_prologue(op, A, R);
+  STD_TORCH_CHECK(has_dtype(gscale, ScalarType::Float), "global_scale must be float");
+  STD_TORCH_CHECK(gscale.dim() == 1 && gscale.size(0) == 1, "global_scale must be a scalar");
+  STD_TORCH_CHECK(R.dim() == 2 && R.size(0) == R.size(1), "Rotation matrix must be square");
+  STD_TORCH_CHECK(A.dim() >= 1 && A.numel() > 0, "A must be a non-empty tensor");
+  const int64_t rot = R.size(0), numel = A.numel(), k = A.size(A.dim() - 1), rows = numel / k;
+  STD_TORCH_CHECK(rot == 16 || rot == 32 || rot == 64 || rot == 128, "Unsupported rotation size ", rot, "; expected 16, 32, 64, or 128.");
+  STD_TORCH_CHECK(k % (rot < 32 ? 32 : rot) == 0, "the last dimension of A must be divisible by", rot < 32 ? 32 : rot);
+  STD_TORCH_CHECK(nbytes(OUT) >= numel / 2, "OUT is too small");
+  STD_TORCH_CHECK(nbytes(OUT_sf) >= (rows + 127) / 128 * 128 * ((k / 16 + 3) / 4 * 4), "OUT_sf is too small for the blocked scale layout");
+  const torch::stable::accelerator::DeviceGuard guard(A.get_device_index());
+  check_rc(qutlass_amd_fused_quantize_nv_blocked(A.data_ptr(), R.data_ptr(), (int)rot, rows, k, (int)method, static_cast<const float*>(gscale.data_ptr()),
+                                                 OUT.data_ptr(), OUT_sf.data_ptr(), current_stream(A)));
+  return {OUT, OUT_sf};
+}
+
 // ---- QAT-backward data preparation (bindings.cpp:429-494: no validation there; the Python wrappers assert dtypes and
 //      contiguity, qutlass/__init__.py:206-315 -- the C ABI checks the shape constraints) --------------------------------
 void backward_t_bf16(const Tensor& x, const Tensor& h, Tensor xh_e2m1, Tensor xh_e8m0) {
@@ -339,7 +382,11 @@ STABLE_TORCH_LIBRARY_FRAGMENT(_qutlass_C, m) {
   m.def("mxfp4_transpose_mxfp8(Tensor x_fp4, Tensor scales, Tensor x_fp8, Tensor shared_exps) -> ()");
 }
 
-STABLE_TORCH_LIBRARY_FRAGMENT(qutlass_amd, m) { m.def("to_blocked(Tensor input_matrix) -> Tensor"); }
+STABLE_TORCH_LIBRARY_FRAGMENT(qutlass_amd, m) {
+  m.def("to_blocked(Tensor input_matrix) -> Tensor");
+  m.def("fusedQuantizeMxBlocked(Tensor A, Tensor R, Tensor OUT, Tensor OUT_sf, int method) -> (Tensor, Tensor)");
+  m.def("fusedQuantizeNvBlocked(Tensor A, Tensor R, Tensor OUT, Tensor OUT_sf, Tensor global_scale, int method) -> (Tensor, Tensor)");
+}
 
 // CUDA dispatch key only, as the reference (bindings.cpp:516-535); there is no CPU compute path.
 STABLE_TORCH_LIBRARY_IMPL(_qutlass_C, CUDA, m) {
@@ -358,7 +405,11 @@ STABLE_TORCH_LIBRARY_IMPL(_qutlass_C, CUDA, m) {
   m.impl("backward_bf16_square_double_mxfp8", TORCH_BOX(&backward_bf16_square_double_mxfp8));
   m.impl("mxfp4_transpose_mxfp8", TORCH_BOX(&mxfp4_transpose_mxfp8));
 }
-STABLE_TORCH_LIBRARY_IMPL(qutlass_amd, CUDA, m) { m.impl("to_blocked", TORCH_BOX(&to_blocked)); }
+STABLE_TORCH_LIBRARY_IMPL(qutlass_amd, CUDA, m) {
+  m.impl("to_blocked", TORCH_BOX(&to_blocked));
+  m.impl("fusedQuantizeMxBlocked", TORCH_BOX(&fusedQuantizeMxBlocked));
+  m.impl("fusedQuantizeNvBlocked", TORCH_BOX(&fusedQuantizeNvBlocked));
+}
 
 // `import qutlass._CUDA` (reference: include/registration.h REGISTER_EXTENSION(_CUDA), bindings.cpp:537-540): an empty module
 // whose only purpose is that loading it runs the registrations above.

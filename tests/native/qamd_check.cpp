@@ -589,6 +589,51 @@ int main(int argc, char** argv) {
     check_gemm("auto C3 4096x14336x4096 (deepp + tail, 64 rows)", 0, 4096, 14336, 4096, 1.0f, 3, 64, 0);
     check_gemm("auto 4096x11008x4096 (64 rows)", 0, 4096, 11008, 4096, 0.5f, 3, 64, 0);
   }
+  if (want("hetero")) {   // [r3] heterogeneous launch (variant 98: persistent 256x256 over the full rounds + residual tiles as 128x128 tiles of the same grid)
+    // parity against the oracle: ragged edge tiles (quarter tiles partly / wholly outside), K tails, 1..3 rounds, fp4 exact / fp8 in tolerance
+    for (int var : {98, 99}) {
+      check_gemm("hetero 4096x5120x512 (320 tiles = 1 round + 64 residual)", 0, 4096, 5120, 512, 1.0f, 3, 64, var);
+      check_gemm("hetero 4000x5000x640 (ragged edges, K tail, KT = 3 -> 4)", 0, 4000, 5000, 640, 0.5f, 3, 64, var);
+      check_gemm("hetero 4100x4360x768 (306 tiles, last tile row 4 rows tall)", 0, 4100, 4360, 768, 0.5f, 3, 64, var);
+      check_gemm("hetero 8192x5120x256 (640 tiles = 2 rounds + 128 residual, KT = 1)", 0, 8192, 5120, 256, 1.0f, 3, 48, var);
+      check_gemm("hetero 300x520x1152 (6 tiles < one round: plain persistent)", 0, 300, 520, 1152, 1.0f, 3, 0, var);
+    }
+    check_gemm("hetero 4096x5120x4096 (64 rows)", 0, 4096, 5120, 4096, 1.0f, 3, 64, 98);
+    check_gemm("hetero 5120x4096x4096 (64 rows)", 0, 5120, 4096, 4096, 1.0f, 3, 64, 98);
+    check_gemm("auto 4096x5120x4096 (64 rows)", 0, 4096, 5120, 4096, 1.0f, 3, 64, 0);
+    check_gemm("auto 3072x6144x4096 (64 rows)", 0, 3072, 6144, 4096, 1.0f, 3, 64, 0);
+    check_gemm("hetero fp8 4096x5120x1024 (64 rows)", 2, 4096, 5120, 1024, 1.0f, 3, 64, 98);
+    check_gemm("hetero fp8 4000x5000x672 (ragged, K tail; 64 rows)", 2, 4000, 5000, 672, 0.5f, 3, 64, 98);
+    check_gemm("auto fp8 4096x5120x4096 (48 rows)", 2, 4096, 5120, 4096, 1.0f, 3, 48, 0);
+  }
+  if (want("heterobench")) {   // steady state (QAMD_STEADY_MS=30): auto vs balanced persistent (90, pp_flags 64) vs heterogeneous (98) vs the round-2 two-launch tail split (pp_flags 8192)
+    g_gauss_fill = 1;
+    struct Sh { int64_t M, N, K; };
+    for (const Sh& sh : {Sh{4096, 4096, 4096}, Sh{4096, 4352, 4096}, Sh{4096, 4608, 4096}, Sh{4096, 5120, 4096}, Sh{5120, 4096, 4096}, Sh{3072, 6144, 4096}, Sh{4096, 6144, 4096}, Sh{3072, 8192, 4096},
+                         Sh{4096, 7168, 4096}, Sh{4096, 8192, 4096}, Sh{4096, 9216, 4096}, Sh{4096, 11008, 4096}, Sh{4096, 14336, 4096}, Sh{6144, 4096, 4096}, Sh{5120, 8192, 4096}, Sh{8192, 8192, 8192},
+                         Sh{4096, 5120, 14336}, Sh{4096, 5120, 1024}}) {
+      char tag[96];
+      qutlass_amd_set_option("pp_flags", 1);
+      snprintf(tag, sizeof tag, "mxfp4 auto %lldx%lldx%lld", (long long)sh.M, (long long)sh.N, (long long)sh.K); bench_gemm(tag, 0, sh.M, sh.N, sh.K, 0, 40);
+      qutlass_amd_set_option("pp_flags", 1 | 64);
+      snprintf(tag, sizeof tag, "mxfp4 balanced %lldx%lldx%lld", (long long)sh.M, (long long)sh.N, (long long)sh.K); bench_gemm(tag, 0, sh.M, sh.N, sh.K, 90, 40);
+      qutlass_amd_set_option("pp_flags", 1);
+      snprintf(tag, sizeof tag, "mxfp4 hetero(4-deep) %lldx%lldx%lld", (long long)sh.M, (long long)sh.N, (long long)sh.K); bench_gemm(tag, 0, sh.M, sh.N, sh.K, 98, 40);
+      snprintf(tag, sizeof tag, "mxfp4 hetero(3-deep) %lldx%lldx%lld", (long long)sh.M, (long long)sh.N, (long long)sh.K); bench_gemm(tag, 0, sh.M, sh.N, sh.K, 99, 40);
+      qutlass_amd_set_option("pp_flags", 1 | 8192);
+      snprintf(tag, sizeof tag, "mxfp4 two-launch %lldx%lldx%lld", (long long)sh.M, (long long)sh.N, (long long)sh.K); bench_gemm(tag, 0, sh.M, sh.N, sh.K, 0, 40);
+      qutlass_amd_set_option("pp_flags", 1);
+    }
+    g_gauss_fill = 0;
+    for (const Sh& sh : {Sh{4096, 4096, 4096}, Sh{4096, 5120, 4096}, Sh{5120, 4096, 4096}, Sh{3072, 6144, 4096}, Sh{4096, 14336, 4096}}) {
+      char tag[96];
+      snprintf(tag, sizeof tag, "mxfp8 auto %lldx%lldx%lld", (long long)sh.M, (long long)sh.N, (long long)sh.K); bench_gemm(tag, 2, sh.M, sh.N, sh.K, 0, 40);
+      qutlass_amd_set_option("pp_flags", 1 | 64);
+      snprintf(tag, sizeof tag, "mxfp8 balanced %lldx%lldx%lld", (long long)sh.M, (long long)sh.N, (long long)sh.K); bench_gemm(tag, 2, sh.M, sh.N, sh.K, 90, 40);
+      qutlass_amd_set_option("pp_flags", 1);
+      snprintf(tag, sizeof tag, "mxfp8 hetero %lldx%lldx%lld", (long long)sh.M, (long long)sh.N, (long long)sh.K); bench_gemm(tag, 2, sh.M, sh.N, sh.K, 98, 40);
+    }
+  }
   if (want("deepptrace")) {   // phase timeline of workgroup 0 of the persistent deep kernel (variant 91), in the steady state
     struct Sh { int64_t M, N, K; };
     for (const Sh& sh : {Sh{4096, 4096, 4096}, Sh{4096, 12288, 4096}, Sh{8192, 8192, 8192}}) {

@@ -125,12 +125,16 @@ def test_auto_dispatch_rules_dry_run(lib):
     DEEPP, DEEP, SKINNY, RING64, RING64x128, RING128 = 90, 30, 60, 70, 72, 73
     big = 1 << 30
     # headline and the other BASELINE configs: 256x256 tiles, the persistent deep schedule (fp4 and fp8);
-    # C3 = 3.5 rounds of tiles -> one persistent launch with balanced rounds (224 workgroups x 4 tiles); 1.25 rounds -> tail
-    # split (the last 1024 columns on 128x128 tiles)
+    # C3 = 3.5 rounds of tiles -> one persistent launch with balanced rounds (224 workgroups x 4 tiles); 1.25 rounds (320 tiles) ->
+    # the heterogeneous launch: 256 persistent workgroups x 1 tile + the 64 residual tiles as 256 quarter tiles in the same grid;
+    # 1.5 rounds (384 tiles) stay with balanced rounds (the cost model of capi.hip: hetero_wins)
     assert plan(4, 4096, 4096, 4096) == [(DEEPP, 4096, 1)]
     assert plan(4, 8192, 8192, 8192) == [(DEEPP, 8192, 1)]
     assert plan(4, 4096, 14336, 4096) == [(DEEPP, 14336, 1)]
-    assert plan(4, 4096, 5120, 4096) == [(DEEPP, 4096, 1), (24, 1024, 1)]
+    HETERO = 98
+    assert plan(4, 4096, 5120, 4096) == [(HETERO, 5120, 1)] and plan(4, 5120, 4096, 4096) == [(HETERO, 4096, 1)]
+    assert plan(8, 4096, 5120, 4096) == [(HETERO, 5120, 1)]
+    assert plan(4, 3072, 8192, 4096) == [(DEEPP, 8192, 1)]
     assert plan(8, 4096, 4096, 4096) == [(DEEPP, 4096, 1)]
     assert plan(4, 256, 1 << 22, 128) == [(25, 1 << 22, 1)]          # absurdly wide output: 32-bit tile offsets of the persistent epilogue do not reach
     # decode: LDS-free split-K kernel while the weight has fewer than 128 64-row tiles, ring kernel beyond, 64x128 tiles for huge N
@@ -158,6 +162,21 @@ def test_auto_dispatch_rules_dry_run(lib):
     assert plan(4, 4096, 262400, 16384) == [(DEEPP, 261888, 1), (71, 512, 1)]
     # rejected arguments never reach the dispatch
     assert plan(4, 128, 128, 96) is None and plan(5, 128, 128, 128) is None
+
+
+def test_product_kernels_use_no_scratch():
+    """a register spill in one of the hand-scheduled kernels is silent and slow; the compiler's own resource report
+    (-Rpass-analysis=kernel-resource-usage, device pass of every translation unit) must show 0 bytes of scratch and no VGPR
+    spills for every kernel of the product library."""
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("_kres", os.path.join(ROOT, "tools", "kernel_resources.py"))
+    kres = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(kres)
+    ks = kres.collect(lab=False)
+    assert len(ks) > 100
+    spilled = {k: v for k, v in ks.items() if v.get("scratch", 0) or v.get("vgpr_spill", 0)}
+    assert not spilled, spilled
 
 
 def test_python_surface_matches_reference_signatures():

@@ -1,0 +1,289 @@
+"""Round-3 GPU parity tests (through the Python surface -> torch ops -> C ABI -> HIP kernels), against the pinned CPU oracle.
+
+  * fusedQuantize{Mx,Nv}Blocked: the quantizer that writes its scales straight into the to_blocked() layout must produce, byte
+    for byte, what the reference's two-step path produces (qutlass/__init__.py:149-203 followed by qutlass/utils.py:160-193).
+  * the heterogeneous launch (persistent 256x256 tiles over the full rounds + the residual tiles as 128x128 tiles of the same
+    grid; reference counterpart: the tile scheduler behind qutlass/csrc/gemm.cu:195-222): bit-identical to the single-schedule
+    launches and to the oracle, on ragged edges, K tails and several rounds, fp4 and fp8.
+  * Quest scales at binade boundaries (cutlass_extensions/epilogue/threadblock/epilogue_quant.h:521-539): adversarial groups
+    whose sqrt(var) * c + 1e-8 sits within an ulp of a power of two -- the place where a different fp32 summation order
+    could flip an e8m0 byte.
+  * the C ABI's re-entrancy claim (include/qutlass_amd.h: "no global state ... re-entrant"; reference: include/common.h:40-45
+    launches on the caller's current stream): a GEMM on one stream while the quantizer runs on another, both checked.
+Nothing here reads /root/reference.
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import oracle  # noqa: E402  (the checker)
+import _benchlib as lab  # noqa: E402  (LAB build: forced schedules)
+
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def q():
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    import qutlass_amd
+
+    return qutlass_amd
+
+
+def _np(t: torch.Tensor) -> np.ndarray:
+    t = t.detach().cpu().contiguous()
+    if t.dtype == torch.bfloat16:
+        return t.view(torch.uint16).numpy()
+    if t.element_size() == 1:
+        return t.view(torch.uint8).numpy()
+    return t.numpy()
+
+
+def _hadamard(n):
+    h = torch.ones(1, 1)
+    while h.shape[0] < n:
+        h = torch.cat([torch.cat([h, h], 1), torch.cat([h, -h], 1)], 0)
+    return (h * n ** -0.5).to(torch.bfloat16).to(DEV)
+
+
+# ------------------------------------------------------------------------------------------------
+# quantizers with GEMM-ready scales
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("shape", [(4096, 4096), (3, 100, 512), (1, 4096), (33, 1024), (130, 128), (2, 512, 1152)])
+@pytest.mark.parametrize("rot", [32, 64, 128])
+@pytest.mark.parametrize("method", ["quest", "abs_max"])
+def test_fused_quantize_mx_blocked_equals_two_step_path(q, shape, rot, method):
+    from qutlass_amd.utils import to_blocked
+
+    if shape[-1] % rot:
+        pytest.skip("row length not a multiple of the rotation size")
+    torch.manual_seed(hash((shape, rot)) % 1000)
+    x = torch.randn(*shape, dtype=torch.bfloat16, device=DEV) * 25.0
+    h = _hadamard(rot)
+    rows, k = x.numel() // shape[-1], shape[-1]
+    c_flat, s_flat = q.fusedQuantizeMx(x, h, method=method)
+    c_blk, s_blk = q.fusedQuantizeMxBlocked(x, h, method=method)
+    assert torch.equal(c_flat, c_blk)
+    want = to_blocked(s_flat.view(torch.uint8).reshape(-1)[: rows * (k // 32)].reshape(rows, k // 32))
+    assert s_blk.dtype == torch.float8_e8m0fnu and s_blk.dim() == 1 and s_blk.numel() == want.numel()
+    assert torch.equal(s_blk.view(torch.uint8), want.view(torch.uint8))
+    # ... and against the oracle's own two steps on the same input
+    _, rs, _ = oracle.fused_quantize_mx(_np(x), _np(h), oracle.QUEST if method == "quest" else oracle.ABS_MAX)
+    assert np.array_equal(_np(s_blk), oracle.to_blocked(rs.reshape(rows, k // 32)))
+
+
+@pytest.mark.parametrize("shape", [(2048, 2048), (5, 96), (3, 100, 512), (1, 4096), (130, 160)])
+@pytest.mark.parametrize("rot", [16, 32, 64, 128])
+@pytest.mark.parametrize("method", ["quest", "abs_max"])
+def test_fused_quantize_nv_blocked_equals_two_step_path(q, shape, rot, method):
+    from qutlass_amd.utils import to_blocked
+
+    if shape[-1] % max(rot, 32):
+        pytest.skip("row length not a multiple of the rotation tile")
+    torch.manual_seed(hash((shape, rot)) % 1000)
+    x = torch.randn(*shape, dtype=torch.bfloat16, device=DEV) * 3.0
+    h = _hadamard(rot)
+    gs = torch.tensor([6.0], device=DEV)
+    rows, k = x.numel() // shape[-1], shape[-1]
+    c_flat, s_flat = q.fusedQuantizeNv(x, h, gs, method=method)
+    c_blk, s_blk = q.fusedQuantizeNvBlocked(x, h, gs, method=method)
+    assert torch.equal(c_flat, c_blk)
+    want = to_blocked(s_flat.view(torch.uint8).reshape(-1)[: rows * (k // 16)].reshape(rows, k // 16))   # zero-pads ragged shapes (K/16 % 4 != 0)
+    assert s_blk.dtype == torch.float8_e4m3fn and s_blk.numel() == want.numel()
+    assert torch.equal(s_blk.view(torch.uint8), want.view(torch.uint8))
+
+
+def test_blocked_quantizer_feeds_the_gemm_directly(q):
+    """quantize (blocked scales) -> GEMM, two launches per operand pair instead of three, same bf16 bits as the reference flow and
+    the oracle; M = 100 rows: the scale rows 100..127 of the last 128-row tile are zero padding written by the quantizer itself."""
+    from qutlass_amd.utils import to_blocked
+
+    torch.manual_seed(7)
+    m, n, k = 100, 384, 1024
+    h = _hadamard(32)
+    a = torch.randn(m, k, dtype=torch.bfloat16, device=DEV) * 25.0
+    b = torch.randn(n, k, dtype=torch.bfloat16, device=DEV) * 25.0
+    alpha = torch.tensor([1.0 / 9.0], device=DEV)
+    a_q, a_s = q.fusedQuantizeMx(a, h, method="abs_max")
+    b_q, b_s = q.fusedQuantizeMx(b, h, method="abs_max")
+    want = q.matmul_mxf4_bf16_tn(a_q, b_q, to_blocked(a_s), to_blocked(b_s), alpha)
+    a_q2, a_sb = q.fusedQuantizeMxBlocked(a, h, method="abs_max")
+    b_q2, b_sb = q.fusedQuantizeMxBlocked(b, h, method="abs_max")
+    got = q.matmul_mxf4_bf16_tn(a_q2, b_q2, a_sb, b_sb, alpha)
+    assert torch.equal(got.view(torch.int16), want.view(torch.int16))
+    ref = oracle.gemm_blockscaled(oracle.KIND_MXFP4, _np(a_q2), _np(b_q2), _np(a_sb), _np(b_sb), float(alpha.item()), m, n, k)
+    assert np.array_equal(_np(got), ref)
+
+
+def test_blocked_quantizer_rejects_bad_arguments(q):
+    h = _hadamard(64)
+    with pytest.raises(RuntimeError):   # row length 96 is not a multiple of the rotation size 64
+        q.fusedQuantizeMxBlocked(torch.zeros(4, 96, dtype=torch.bfloat16, device=DEV), h)
+    with pytest.raises(ValueError):
+        q.fusedQuantizeMxBlocked(torch.zeros(4, 128, dtype=torch.bfloat16, device=DEV), h, method="nope")
+    with pytest.raises(RuntimeError):   # OUT_sf too small for the padded blocked layout
+        torch.ops.qutlass_amd.fusedQuantizeMxBlocked(torch.zeros(4, 128, dtype=torch.bfloat16, device=DEV), h,
+                                                     torch.empty(4, 64, dtype=torch.uint8, device=DEV),
+                                                     torch.empty(16, dtype=torch.float8_e8m0fnu, device=DEV), 1)
+
+
+# ------------------------------------------------------------------------------------------------
+# heterogeneous launch
+# ------------------------------------------------------------------------------------------------
+def _rand_mx(m, n, k, seed, fp8=False, e5m2=False):
+    """random operands in the exact regime (block exponents within +-3): any K order gives the same fp32 sums for fp4"""
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    if fp8:
+        a = torch.randint(0, 256, (m, k), dtype=torch.uint8, generator=g)
+        b = torch.randint(0, 256, (n, k), dtype=torch.uint8, generator=g)
+        nan_a = (a & 0x7f) > (0x7b if e5m2 else 0x7e)      # e5m2: inf / nan codes 0x7c..0x7f ; e4m3fn: nan 0x7f
+        a = torch.where(nan_a, a & 0x80, a)
+        b = torch.where((b & 0x7f) == 0x7f, b & 0x80, b)
+    else:
+        a = torch.randint(0, 256, (m, k // 2), dtype=torch.uint8, generator=g)
+        b = torch.randint(0, 256, (n, k // 2), dtype=torch.uint8, generator=g)
+    sa = torch.randint(124, 131, (m, k // 32), dtype=torch.uint8, generator=g)
+    sb = torch.randint(124, 131, (n, k // 32), dtype=torch.uint8, generator=g)
+    return a, b, sa, sb
+
+
+def _oracle_rows(kind, a, b, sa, sb, alpha, rows, n, k):
+    rows = list(rows)
+    return oracle.gemm_blockscaled(kind, a[rows].numpy(), b.numpy(), oracle.to_blocked(sa[rows].numpy()), oracle.to_blocked(sb.numpy()), alpha, len(rows), n, k)
+
+
+def _sample(m, count, seed):
+    rng = np.random.default_rng(seed)
+    rows = {0, 1, 127, 128, 255, 256, m - 1, m - 128, m - 129, m // 2}
+    rows = {r for r in rows if 0 <= r < m}
+    while len(rows) < count:
+        rows.add(int(rng.integers(0, m)))
+    return sorted(rows)
+
+
+@pytest.mark.parametrize("m,n,k,forced", [
+    (4096, 5120, 1024, 0),       # the product's own choice: 320 tiles -> 256 persistent workgroups + 256 quarter tiles
+    (5120, 4096, 1024, 0),
+    (4000, 5000, 640, 98),       # ragged edges: quarter tiles partly and wholly outside the output; K tail (KT = 3 -> 4)
+    (4100, 4360, 768, 98),       # 306 tiles; the last tile row is 4 rows tall
+    (8192, 5120, 256, 98),       # two full rounds + 128 residual tiles, KT = 1
+])
+def test_hetero_launch_mxfp4_bit_exact(q, m, n, k, forced):
+    from qutlass_amd.utils import to_blocked
+
+    a, b, sa, sb = _rand_mx(m, n, k, seed=m + n + k)
+    ad, bd = a.to(DEV), b.to(DEV)
+    asf = to_blocked(sa.to(DEV).view(torch.float8_e8m0fnu))
+    bsf = to_blocked(sb.to(DEV).view(torch.float8_e8m0fnu))
+    alpha = torch.tensor([0.5], device=DEV)
+    if forced:
+        with lab.forced(gemm_variant=forced):
+            got = lab.matmul_mxf4_bf16_tn(ad, bd, asf, bsf, alpha)
+    else:
+        got = q.matmul_mxf4_bf16_tn(ad, bd, asf, bsf, alpha)
+    with lab.forced(gemm_variant=90, pp_flags=1 | 64):   # ONE persistent launch over all tiles (balanced rounds)
+        one = lab.matmul_mxf4_bf16_tn(ad, bd, asf, bsf, alpha)
+    assert torch.equal(got.view(torch.int16), one.view(torch.int16))
+    rows = _sample(m, 40, seed=1)
+    ref = _oracle_rows(oracle.KIND_MXFP4, a, b, sa, sb, 0.5, rows, n, k)
+    assert np.array_equal(_np(got[torch.tensor(rows, device=DEV)]), ref)
+
+
+@pytest.mark.parametrize("e5m2", [False, True])
+def test_hetero_launch_mxfp8_matches_persistent_and_oracle(q, e5m2):
+    from qutlass_amd.utils import to_blocked
+
+    m, n, k = 4096, 5120, 1024
+    a, b, sa, sb = _rand_mx(m, n, k, seed=5, fp8=True, e5m2=e5m2)
+    ad = a.to(DEV).view(torch.float8_e5m2 if e5m2 else torch.float8_e4m3fn)
+    bd = b.to(DEV).view(torch.float8_e4m3fn)
+    asf = to_blocked(sa.to(DEV).view(torch.float8_e8m0fnu))
+    bsf = to_blocked(sb.to(DEV).view(torch.float8_e8m0fnu))
+    alpha = torch.tensor([1.0], device=DEV)
+    got = q.matmul_mxf8_bf16_tn(ad, bd, asf, bsf, alpha)          # auto: the heterogeneous launch (tests/test_cabi_and_host.py pins the plan)
+    rows = _sample(m, 32, seed=2)
+    kind = 4 if e5m2 else oracle.KIND_MXFP8
+    ref = _oracle_rows(kind, a, b, sa, sb, 1.0, rows, n, k)
+    g = oracle.bf16_bits_to_f32(_np(got[torch.tensor(rows, device=DEV)])).astype(np.float64)
+    w = oracle.bf16_bits_to_f32(ref).astype(np.float64)
+    assert (np.abs(g - w) <= np.abs(w) / 128.0 + 1e-4 * np.abs(w).max()).all()
+    if not e5m2:
+        with lab.forced(gemm_variant=90, pp_flags=1 | 64):
+            one = lab.matmul_mxf8_bf16_tn(ad, bd, asf, bsf, alpha)
+        assert torch.equal(got.view(torch.int16), one.view(torch.int16))   # same K order, same MFMA: bit-identical schedules
+
+
+# ------------------------------------------------------------------------------------------------
+# Quest scales at binade boundaries
+# ------------------------------------------------------------------------------------------------
+def test_quest_scale_bytes_at_binade_boundaries(q):
+    """Groups constructed so that sqrt(var) * (2.92247856 / 6) + 1e-8 lands within ~1 ulp of a power of two: the e8m0 byte is
+    floor(log2(scale)), so this is where the kernel's summation order (16 values per lane + one cross-lane add) could differ
+    from a sequential 32-term sum.  Identity rotation, so the group statistics are those of the input.  The oracle follows the
+    kernel's order (acc_model 0) and must agree on EVERY byte; the sequential order (acc_model 1) is reported, not required."""
+    rng = np.random.default_rng(0)
+    c = 2.92247856 / 6.0
+    ngroups = 1 << 16
+    base = rng.standard_normal((ngroups, 32))
+    base -= base.mean(axis=1, keepdims=True)
+    std = np.sqrt((base ** 2).mean(axis=1, keepdims=True))
+    e = rng.integers(-6, 7, (ngroups, 1))
+    jitter = 1.0 + rng.integers(-3, 4, (ngroups, 1)) * 2.0 ** -9          # bf16 rounding of the inputs adds ~2^-9 relative noise per value
+    x = base / std * (2.0 ** e / c) * jitter
+    xt = torch.from_numpy(x.reshape(-1, 4096)).to(torch.bfloat16).to(DEV)
+    eye = torch.eye(32, dtype=torch.bfloat16, device=DEV)
+    _, s = q.fusedQuantizeMx(xt, eye, method="quest")
+    got = _np(s).reshape(-1)[:ngroups]
+    _, want, _ = oracle.fused_quantize_mx(_np(xt), _np(eye), oracle.QUEST, acc_model=2)
+    # how adversarial the data is: fraction of groups whose scale lies within 2^-10 of a power of two
+    xs = xt.float().cpu().numpy().reshape(ngroups, 32).astype(np.float64)
+    sc = np.sqrt(np.maximum((xs ** 2).mean(1) - xs.mean(1) ** 2, 0)) * c + 1e-8
+    frac = np.abs(sc / 2.0 ** np.round(np.log2(sc)) - 1.0)
+    near = float((frac < 2.0 ** -10).mean())
+    assert near > 0.2, near
+    assert np.array_equal(got, want), f"{int((got != want).sum())} of {ngroups} e8m0 bytes differ from the oracle (kernel summation order)"
+    _, seq, _ = oracle.fused_quantize_mx(_np(xt), _np(eye), oracle.QUEST, acc_model=0)
+    rate = float((got != seq).mean())
+    print(f"QUEST_BINADE groups={ngroups} near_boundary_frac={near:.3f} bytes_differing_from_sequential_sum={int((got != seq).sum())} rate={rate:.3e}")
+    assert rate <= 2e-2, rate   # an ulp-level difference in sqrt(var) can only flip a byte when the scale is within ~1 ulp of 2^e
+    assert (np.abs(got.astype(np.int32) - seq.astype(np.int32)) <= 1).all()   # ... and then by exactly one binade
+
+
+# ------------------------------------------------------------------------------------------------
+# re-entrancy: two streams
+# ------------------------------------------------------------------------------------------------
+def test_two_streams_run_gemm_and_quantizer_concurrently(q):
+    from qutlass_amd.utils import to_blocked
+
+    torch.manual_seed(3)
+    m, n, k = 2048, 4096, 4096
+    h = _hadamard(32)
+    a = torch.randn(m, k, dtype=torch.bfloat16, device=DEV) * 25.0
+    b = torch.randn(n, k, dtype=torch.bfloat16, device=DEV) * 25.0
+    x2 = torch.randn(8192, 4096, dtype=torch.bfloat16, device=DEV) * 25.0
+    a_q, a_s = q.fusedQuantizeMx(a, h, method="abs_max")
+    b_q, b_s = q.fusedQuantizeMx(b, h, method="abs_max")
+    asf, bsf = to_blocked(a_s), to_blocked(b_s)
+    alpha = torch.tensor([1.0], device=DEV)
+    want_out = q.matmul_mxf4_bf16_tn(a_q, b_q, asf, bsf, alpha)
+    want_q, want_s = q.fusedQuantizeMx(x2, h, method="quest")
+    torch.cuda.synchronize()
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    outs, quants = [], []
+    for _ in range(20):
+        with torch.cuda.stream(s1):
+            outs.append(q.matmul_mxf4_bf16_tn(a_q, b_q, asf, bsf, alpha))
+        with torch.cuda.stream(s2):
+            quants.append(q.fusedQuantizeMx(x2, h, method="quest"))
+    s1.synchronize()
+    s2.synchronize()
+    for o in outs:
+        assert torch.equal(o.view(torch.int16), want_out.view(torch.int16))
+    for cq, cs in quants:
+        assert torch.equal(cq, want_q) and torch.equal(cs.view(torch.uint8), want_s.view(torch.uint8))   # (8192, 128): no padding
+    rows = [0, 777, 2047]
+    ref = oracle.gemm_blockscaled(oracle.KIND_MXFP4, _np(a_q)[rows], _np(b_q), oracle.to_blocked(_np(a_s).reshape(m, k // 32)[rows]),
+                                  oracle.to_blocked(_np(b_s).reshape(n, k // 32)), 1.0, len(rows), n, k)
+    assert np.array_equal(_np(outs[-1][torch.tensor(rows, device=DEV)]), ref)
