@@ -13,6 +13,14 @@ Prints ONE JSON line on rank 0 with `roofline` (MFMA-bound: FLOP/s of the domina
 events on the launch stream vs the FP4 dense peak of MI355X_MICROARCH.md) and `cpu_baseline` (the
 reference's dequantise + torch.matmul oracle path timed on this host's cores, bounded sample).
 
+Round 3: the same line also carries (i) `configs` -- the other BASELINE.json configs (C3 GEMM / C3 step / C4 / C5 TN / C5 NN), each
+timed with HIP events on the launch stream after the headline's timed region, with its own roofline fraction; (ii) `power` -- socket
+power and shader clock sampled through librocm_smi64 on a host thread WHILE the timed region runs (the headline kernel sits at the
+socket power limit: the clock it gets is part of the result); (iii) `roofline.traffic` measured FRESH: after the timed region the
+script runs its own hot loop twice more under `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (separate passes, as
+MI355X_MICROARCH.md prescribes; child processes of this run, same box, same build) -- null with the reason if rocprofv3 is missing or
+fails, never a replay of an earlier run.
+
 Timing protocol.  `value` / `ms_per_step` follow the driver's contract: EXACTLY K back-to-back steps between two
 barrier + synchronize pairs, wall clock, max over ranks.  Next to it the reference's own protocol
 (benchmarks/bench_mxfp4_sm120.py:109-125: warm-up, >= 200 individually timed repetitions, median with the 20th / 80th
@@ -22,6 +30,7 @@ percentile) runs as a SECOND, separate pass after the timed region -- one HIP ev
 from __future__ import annotations
 
 import argparse
+import ctypes
 import json
 import os
 import sys
@@ -36,10 +45,9 @@ FP4_DENSE_PEAK_TFLOPS = 10066.0  # 256 CU x 4 SIMD x 2048 MAC/clk x 2 x 2.4 GHz 
 # MFMA-only loop (no memory traffic) with RANDOM fp4 operands, measured on this part: the power limit holds the
 # clock near 1.6 GHz (profiles/ubench_r1f_const_vs_random_operands.log).  Informational only.
 FP4_SUSTAINED_RANDOM_TFLOPS = 6550.0
-# HBM-side bytes per launch from the two --pmc passes of tools/pmc_bench.sh (rocprofv3 wraps the process, so the counters
-# cannot be read from inside this run).  QAMD_PMC_TRAFFIC_JSON (set by pmc_bench.sh for its final, un-profiled run) points
-# at the file measured minutes earlier on the SAME box and build; otherwise the newest committed profiles/pmc_bench_r*.json
-# is quoted and marked as a replay of an earlier run ("traffic_stale": true).
+# HBM-side bytes per launch come from two rocprofv3 --pmc child runs of this script's own hot loop (fresh_traffic below).
+# QAMD_PMC_TRAFFIC_JSON (set by tools/pmc_bench.sh for its final, un-profiled run) may point at counters that script took
+# minutes earlier on the same box and build instead; a committed file of an earlier run is never quoted.
 PMC_TRAFFIC_ENV = "QAMD_PMC_TRAFFIC_JSON"
 M = N = K = 4096
 CPU_ROWS = 4096  # cpu_baseline sample: the whole workload (measured 3.2 s per 1024 rows on the 256-thread host)
@@ -91,6 +99,184 @@ def cpu_baseline(a_q, a_s, b_q, b_s, rows):
     }, out64
 
 
+# ---- socket power / shader clock while the timed region runs (librocm_smi64 through ctypes, host thread) ------------------------
+class _RsmiFreq(ctypes.Structure):   # rsmi_frequencies_t (rocm_smi.h)
+    _fields_ = [("has_deep_sleep", ctypes.c_bool), ("num_supported", ctypes.c_uint32), ("current", ctypes.c_uint32), ("frequency", ctypes.c_uint64 * 33)]
+
+
+class PowerSampler:
+    """rsmi_dev_power_get + rsmi_dev_gpu_clk_freq_get(RSMI_CLK_TYPE_SYS) every ~2 ms on a daemon thread (the firmware refreshes its
+    table every ~12 ms).  `mark()` timestamps phase boundaries; `window(a, b)` averages the samples between two marks."""
+
+    def __init__(self, dev_index: int = 0):
+        import threading
+
+        self.ok, self.samples, self.marks, self._stop, self._dev = False, [], {}, threading.Event(), dev_index
+        self.t0 = time.perf_counter()
+        try:
+            self.lib = ctypes.CDLL("librocm_smi64.so")
+            self.ok = self.lib.rsmi_init(ctypes.c_uint64(0)) == 0
+        except OSError:
+            self.lib = None
+        if self.ok:
+            self._th = threading.Thread(target=self._run, daemon=True)
+            self._th.start()
+
+    def _run(self):
+        uw, pt, fr = ctypes.c_uint64(0), ctypes.c_int(0), _RsmiFreq()
+        while not self._stop.is_set():
+            w = mhz = None
+            try:
+                if self.lib.rsmi_dev_power_get(ctypes.c_uint32(self._dev), ctypes.byref(uw), ctypes.byref(pt)) == 0:
+                    w = uw.value * 1e-6
+            except AttributeError:   # older librocm_smi64: average socket power
+                if self.lib.rsmi_dev_power_ave_get(ctypes.c_uint32(self._dev), ctypes.c_uint32(0), ctypes.byref(uw)) == 0:
+                    w = uw.value * 1e-6
+            if self.lib.rsmi_dev_gpu_clk_freq_get(ctypes.c_uint32(self._dev), ctypes.c_int(0), ctypes.byref(fr)) == 0 and fr.current < 33:
+                mhz = fr.frequency[fr.current] * 1e-6
+            self.samples.append((time.perf_counter() - self.t0, w, mhz))
+            time.sleep(0.002)
+
+    def mark(self, name):
+        self.marks[name] = time.perf_counter() - self.t0
+
+    def window(self, a, b):
+        ta, tb = self.marks[a], self.marks[b]
+        ws = [w for t, w, _ in self.samples if ta <= t <= tb and w]
+        fs = [f for t, _, f in self.samples if ta <= t <= tb and f]
+        return {"power_w": round(sum(ws) / len(ws), 1) if ws else None, "sclk_mhz": round(sum(fs) / len(fs), 0) if fs else None,
+                "power_w_max": round(max(ws), 1) if ws else None, "samples": len(ws), "window_ms": round((tb - ta) * 1e3, 1)}
+
+    def stop(self):
+        self._stop.set()
+        if self.ok:
+            self._th.join(timeout=1.0)
+            try:
+                self.lib.rsmi_shut_down()
+            except Exception:
+                pass
+
+
+def event_us(fn, iters, warm=5, min_ms=30.0):
+    """average device microseconds per call: back-to-back launches bracketed by HIP events on the current stream, after `warm` calls
+    and at least `min_ms` of the same load (clock ramp)"""
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    while (time.perf_counter() - t0) * 1e3 < min_ms:
+        for _ in range(10):
+            fn()
+        torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e3 / iters
+
+
+def side_configs(q, dev, h32, alpha):
+    """BASELINE.json configs[2..4] at full size (synthetic operands, resident in HBM; parity of every one of them is what
+    tests/test_gpu_baseline_configs.py checks).  Peaks: MI355X_MICROARCH.md dense figures for the MFMA the path computes on --
+    FP4 10066, FP8 5033, f16 2516 TFLOP/s (NVFP4 keeps the reference's exact e4m3-per-16 semantics on the f16 MFMA)."""
+    from qutlass_amd.utils import to_blocked
+
+    out = {}
+
+    def put(name, us, flops, peak, **extra):
+        tf = flops / us * 1e-6
+        out[name] = {"us": round(us, 2), "TFLOP/s": round(tf, 1), "roofline": {"bound": "mfma", "achieved": round(tf, 1), "peak": peak, "unit": "TFLOP/s",
+                                                                              "frac": round(tf / peak, 4)}, **extra}
+
+    # C3: fusedQuantizeMx(H32, abs_max) + MXFP4 GEMM, Llama-3-8B FFN M=4096 N=14336 K=4096
+    m, n, k = 4096, 14336, 4096
+    x = torch.randn(m, k, dtype=torch.bfloat16, device=dev) * 25.0
+    w = torch.randn(n, k, dtype=torch.bfloat16, device=dev) * 25.0
+    w_q, w_s = q.fusedQuantizeMx(w, h32, method="abs_max")
+    w_sf = to_blocked(w_s)
+    x_q, x_s = q.fusedQuantizeMx(x, h32, method="abs_max")
+    x_sf = to_blocked(x_s)
+    fl = 2.0 * m * n * k
+    put("C3_gemm", event_us(lambda: q.matmul_mxf4_bf16_tn(x_q, w_q, x_sf, w_sf, alpha), 100), fl, FP4_DENSE_PEAK_TFLOPS, workload="matmul_mxf4_bf16_tn 4096x14336x4096")
+
+    def step3():   # the reference's activation path: three launches (qutlass/__init__.py:149-180, utils.py:160-193)
+        a_q, a_s = q.fusedQuantizeMx(x, h32, method="abs_max")
+        return q.matmul_mxf4_bf16_tn(a_q, w_q, to_blocked(a_s), w_sf, alpha)
+
+    def step2():   # quantizer with GEMM-ready scales: two launches
+        a_q, a_sb = q.fusedQuantizeMxBlocked(x, h32, method="abs_max")
+        return q.matmul_mxf4_bf16_tn(a_q, w_q, a_sb, w_sf, alpha)
+
+    put("C3_step", event_us(step3, 100), fl, FP4_DENSE_PEAK_TFLOPS, workload="fusedQuantizeMx(H32, abs_max) + to_blocked + GEMM, weights pre-quantised (3 launches)")
+    put("C3_step_blocked", event_us(step2, 100), fl, FP4_DENSE_PEAK_TFLOPS, workload="fusedQuantizeMxBlocked(H32, abs_max) + GEMM (2 launches; extension)")
+    del x, w, w_q, w_s, x_q, x_s, w_sf, x_sf
+    # C4: NVFP4 8192^3
+    m = n = k = 8192
+    gs = torch.tensor([1.0], device=dev)
+    h16 = hadamard(16, dev)
+    a = torch.randn(m, k, dtype=torch.bfloat16, device=dev) * 25.0
+    a_q, a_s = q.fusedQuantizeNv(a, h16, gs)
+    a.normal_()
+    a *= 25.0
+    b_q, b_s = q.fusedQuantizeNv(a, h16, gs)
+    del a
+    a_sf, b_sf = to_blocked(a_s), to_blocked(b_s)
+    put("C4", event_us(lambda: q.matmul_nvf4_bf16_tn(a_q, b_q, a_sf, b_sf, alpha), 40, warm=3), 2.0 * m * n * k, 2516.0,
+        workload="matmul_nvf4_bf16_tn 8192^3 (exact e4m3-per-16 semantics on the f16 MFMA: peak = the 16-bit dense peak)")
+    del a_q, b_q, a_s, b_s, a_sf, b_sf
+    # C5: MXFP8 4096^3 TN and NN
+    m = n = k = 4096
+    a8 = (torch.randn(m, k, device=dev) * 4).to(torch.float8_e4m3fn)
+    b8 = (torch.randn(n, k, device=dev) * 4).to(torch.float8_e4m3fn)
+    s8a = to_blocked(torch.randint(120, 131, (m, k // 32), dtype=torch.uint8, device=dev).view(torch.float8_e8m0fnu))
+    s8b = to_blocked(torch.randint(120, 131, (n, k // 32), dtype=torch.uint8, device=dev).view(torch.float8_e8m0fnu))
+    a8t = a8.view(torch.uint8).T.contiguous().view(torch.float8_e4m3fn)
+    put("C5_tn", event_us(lambda: q.matmul_mxf8_bf16_tn(a8, b8, s8a, s8b, alpha), 200), 2.0 * m * n * k, 5033.0, workload="matmul_mxf8_bf16_tn 4096^3")
+    put("C5_nn", event_us(lambda: q.matmul_mxf8_bf16_nn(a8t, b8, s8a, s8b, alpha), 200), 2.0 * m * n * k, 5033.0, workload="matmul_mxf8_bf16_nn 4096^3 (A stored (K, M))")
+    return out
+
+
+def fresh_traffic():
+    """HBM-side bytes per launch of the headline kernel: two `rocprofv3 --pmc` child runs (FETCH_SIZE, WRITE_SIZE: separate passes)
+    of this script's own hot loop (`--pmc-child`), on this box, right now.  Returns (dict | None, note)."""
+    import glob
+    import importlib.util
+    import shutil
+    import sqlite3
+    import subprocess
+    import tempfile
+
+    rocprof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(rocprof):
+        return None, "rocprofv3 not found"
+    spec = importlib.util.spec_from_file_location("_rps", os.path.join(ROOT, "tools", "rocprof_summary.py"))
+    rps = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(rps)
+    tmp = tempfile.mkdtemp(prefix="qamd_pmc_", dir="/tmp")
+    vals = {}
+    try:
+        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+            cmd = [rocprof, "--pmc", ctr, "-d", os.path.join(tmp, ctr), "-o", "p", "--", sys.executable, os.path.abspath(__file__), "--pmc-child", "30"]
+            r = subprocess.run(cmd, cwd="/tmp", env={**os.environ, "TMPDIR": "/tmp"}, capture_output=True, text=True, timeout=240)
+            dbs = glob.glob(os.path.join(tmp, ctr, "**", "*results.db"), recursive=True)
+            if r.returncode != 0 or not dbs:
+                return None, f"rocprofv3 --pmc {ctr} failed (rc {r.returncode}): {(r.stderr or r.stdout)[-300:]}"
+            for kname, cname, cnt, avg in rps.pmc_rows(sqlite3.connect(dbs[0])):
+                if "gemm_mx_" in kname and cname == ctr:
+                    vals[ctr] = (avg * 1024.0, cnt, kname)
+        if len(vals) != 2:
+            return None, f"counters missing from the rocprofv3 output ({sorted(vals)})"
+        f, w = vals["FETCH_SIZE"][0], vals["WRITE_SIZE"][0]
+        return {"traffic_bytes": 2 * f + w, "fetch_size_raw_bytes": f, "fetch_bytes_corrected_x2": 2 * f, "write_bytes": w,
+                "kernel": vals["FETCH_SIZE"][2], "dispatches": vals["FETCH_SIZE"][1]}, "ok"
+    except Exception as e:   # noqa: BLE001 -- the profile is optional evidence, never a reason to lose the bench line
+        return None, f"{type(e).__name__}: {e}"
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 def dominant_kernel_name():
     """The kernel the product library's dispatch picks for the headline shape, from its dry-run hook (no GPU touched)."""
     import ctypes
@@ -137,6 +323,10 @@ def main():
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-configs", action="store_true", help="skip the C3 / C4 / C5 side measurements")
+    ap.add_argument("--no-pmc", action="store_true", help="skip the two rocprofv3 --pmc child runs (roofline.traffic = null)")
+    ap.add_argument("--pmc-child", type=int, default=0, metavar="N",
+                    help="internal: set the headline operands up, launch the headline op N times and exit (the command the --pmc passes profile)")
     ap.add_argument("--ramp-ms", type=float, default=250.0,
                     help="untimed load before the W warmup steps: an idle MI355X needs ~50 ms under load to leave its clock "
                          "ramp (tools/clock_ramp.py: 54 -> 42 -> 38 -> 36.7 us/step over the first 40 ms)")
@@ -169,6 +359,13 @@ def main():
     def step():
         return qutlass_amd.matmul_mxf4_bf16_tn(a_q, b_q, a_sf, b_sf, alpha)
 
+    if args.pmc_child > 0:   # profiled child of fresh_traffic(): the hot loop only
+        for _ in range(args.pmc_child):
+            step()
+        torch.cuda.synchronize()
+        return
+    sampler = PowerSampler(local_rank) if rank == 0 else None
+
     # ---- clock ramp (untimed, not part of the W warmup steps): bring the part to its steady clock / power state ----
     ramp_steps = 0
     t_ramp = time.perf_counter()
@@ -193,6 +390,8 @@ def main():
     stream = torch.cuda.current_stream(dev)
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     barrier()
+    if sampler:
+        sampler.mark("timed_start")
     t0 = time.perf_counter()
     ev0.record(stream)  # the ops launch on torch's current stream, so these events bracket the kernels
     for _ in range(args.steps):
@@ -200,6 +399,8 @@ def main():
     ev1.record(stream)
     barrier()
     wall = time.perf_counter() - t0
+    if sampler:
+        sampler.mark("timed_end")
     kernel_ms = ev0.elapsed_time(ev1) / args.steps  # average launch-to-launch duration of the GEMM kernel
 
     wall = max_over_ranks(wall, dev if world > 1 else None)
@@ -215,6 +416,8 @@ def main():
         evs[i + 1].record(stream)
     torch.cuda.synchronize()
     per = sorted(evs[i].elapsed_time(evs[i + 1]) * 1e3 for i in range(nrep))
+    if sampler:
+        sampler.mark("per_launch_end")
     per_launch = {"n": nrep, "median": round(percentile(per, 0.5), 3), "p20": round(percentile(per, 0.2), 3), "p80": round(percentile(per, 0.8), 3),
                   "min": round(per[0], 3), "note": "one HIP event pair per launch, after the timed region (bench_mxfp4_sm120.py:109-125 protocol)"}
 
@@ -259,23 +462,41 @@ def main():
             "frac_of_sustained_random_operand_mfma_rate": round(achieved / FP4_SUSTAINED_RANDOM_TFLOPS, 4),
         },
     }
-    # HBM-side bytes per launch of this kernel from the PMC passes (see PMC_TRAFFIC_ENV above)
-    import glob
-
-    fresh = os.environ.get(PMC_TRAFFIC_ENV)
-    cands = [fresh] if fresh else sorted(glob.glob(os.path.join(ROOT, "profiles", "pmc_bench_r*.json")), reverse=True)
-    for path in cands:
-        try:
-            with open(path) as f:
-                tj = json.load(f)
-        except (OSError, ValueError):
-            continue
-        if tj.get("traffic_bytes"):
+    # socket power / shader clock during the timed region (and over the longer window that also holds the per-launch pass: the
+    # firmware refreshes its table every ~12 ms, the K-step region of the default run lasts ~70 ms)
+    if sampler:
+        sampler.stop()
+        if sampler.ok and sampler.samples:
+            result["power"] = {"timed_region": sampler.window("timed_start", "timed_end"), "timed_region_plus_per_launch_pass": sampler.window("timed_start", "per_launch_end"),
+                               "source": "librocm_smi64 rsmi_dev_power_get / rsmi_dev_gpu_clk_freq_get(SYS), host thread, 2 ms period"}
+        else:
+            result["power"] = None
+    # HBM-side bytes per launch of this kernel: fresh PMC passes (see fresh_traffic), rank 0 of a single-GPU run only
+    if rank == 0 and world == 1:
+        tj, note = None, "skipped (--no-pmc)"
+        fresh = os.environ.get(PMC_TRAFFIC_ENV)
+        if fresh:
+            try:
+                with open(fresh) as f:
+                    tj = json.load(f)
+                note = "counters taken by tools/pmc_bench.sh minutes earlier on this box: " + os.path.relpath(fresh, ROOT)
+            except (OSError, ValueError) as e:
+                tj, note = None, f"{fresh}: {e}"
+        elif not args.no_pmc:
+            tj, note = fresh_traffic()
+            if tj:
+                note = "2 rocprofv3 --pmc child runs (FETCH_SIZE, WRITE_SIZE) of this script's hot loop, this box, after the timed region"
+        if tj and tj.get("traffic_bytes"):
             result["roofline"]["traffic"] = tj["traffic_bytes"]
-            result["roofline"]["traffic_source"] = os.path.relpath(path, ROOT) + " (FETCH_SIZE x2 + WRITE_SIZE per launch, tools/pmc_bench.sh)"
-            result["roofline"]["traffic_stale"] = not fresh   # True: counters of an EARLIER run (other box, possibly other build) replayed here
+            result["roofline"]["traffic_detail"] = {k_: tj.get(k_) for k_ in ("fetch_size_raw_bytes", "fetch_bytes_corrected_x2", "write_bytes", "dispatches")}
             result["roofline"]["traffic_kernel"] = tj.get("kernel")
-            break
+            result["roofline"]["traffic_over_algorithmic"] = round(tj["traffic_bytes"] / result["roofline"]["algorithmic_bytes_per_launch"], 3)
+        result["roofline"]["traffic_source"] = note
+        if not args.no_configs:
+            try:
+                result["configs"] = side_configs(qutlass_amd, dev, h, alpha)
+            except Exception as e:   # noqa: BLE001 -- side measurements must not cost the headline line
+                result["configs"] = {"error": f"{type(e).__name__}: {e}"}
 
     if rank == 0:
         if not args.no_cpu_baseline and world == 1:
