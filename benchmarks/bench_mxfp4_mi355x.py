@@ -3,7 +3,9 @@
 quantised linear layer vs batch size for the layer shapes of a model, three providers
 
     torch-bf16             torch.nn.functional.linear on bf16 operands (the library GEMM torch ships)
-    <fmt>-native           fusedQuantize(activations) + to_blocked + block-scaled GEMM   (weights pre-quantised)
+    <fmt>-native           fusedQuantize(activations) + to_blocked + block-scaled GEMM   (weights pre-quantised; the reference's three launches)
+    <fmt>-native-fused     [r3, --fused] the same result in fewer launches: fusedQuantize*Blocked + GEMM (two launches), and for MXFP4
+                           batches of at most 32 rows ONE launch in which the small-batch GEMM quantises its own A operand
     <fmt>-native-noquant   the GEMM alone on pre-quantised activations ("ideal" provider of the reference)
 
 timed as HIP-graph replays (the reference uses triton.testing.do_bench_cudagraph; triton is not used here), median and
@@ -89,6 +91,8 @@ def main():
     ap.add_argument("--reps", type=int, default=50)
     ap.add_argument("--max-batch", type=int, default=65536)
     ap.add_argument("--quick", action="store_true", help="batch sizes 1, 16, 256, 4096 only, first two layers")
+    ap.add_argument("--fused", action="store_true", help="add the <fmt>-native-fused provider (blocked-scale quantizer / one-launch decode path)")
+    ap.add_argument("--layers", type=int, default=0, help="only the first N layers of the model")
     args = ap.parse_args()
 
     import qutlass_amd as q
@@ -102,8 +106,14 @@ def main():
     nv = args.format == "nvfp4"
     quant = (lambda t: q.fusedQuantizeNv(t, h, gs)) if nv else (lambda t: q.fusedQuantizeMx(t, h, method="abs_max"))
     gemm = q.matmul_nvf4_bf16_tn if nv else q.matmul_mxf4_bf16_tn
-    providers = ["torch-bf16", f"{args.format}-native", f"{args.format}-native-noquant"]
+    providers = ["torch-bf16", f"{args.format}-native"] + ([f"{args.format}-native-fused"] if args.fused else []) + [f"{args.format}-native-noquant"]
+    if nv:
+        fused = lambda t, wq, wsf: gemm(*(lambda aq, asf: (aq, wq, asf, wsf, alpha))(*q.fusedQuantizeNvBlocked(t, h, gs)))
+    else:
+        fused = lambda t, wq, wsf: q.fused_quantize_matmul_mxf4_bf16_tn(t, h, wq, wsf, alpha, method="abs_max")
     layers = MODELS[args.model][:2] if args.quick else MODELS[args.model]
+    if args.layers > 0:
+        layers = layers[: args.layers]
     batches = [1, 16, 256, 4096] if args.quick else [b for b in BATCHES if b <= args.max_batch]
     os.makedirs(os.path.join(ROOT, "benchmarks_output"), exist_ok=True)
 
@@ -123,8 +133,10 @@ def main():
             fns = {
                 providers[0]: lambda: torch.nn.functional.linear(a, w),
                 providers[1]: lambda: gemm(*(lambda aq, asf: (aq, w_q, to_blocked(asf), w_sf, alpha))(*quant(a))),
-                providers[2]: lambda: gemm(a_q, w_q, a_sf, w_sf, alpha),
+                providers[-1]: lambda: gemm(a_q, w_q, a_sf, w_sf, alpha),
             }
+            if args.fused:
+                fns[providers[2]] = lambda: fused(a, w_q, w_sf)
             row = {"batch": M}
             cells = []
             for pname in providers:

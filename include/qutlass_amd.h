@@ -166,6 +166,18 @@ int qutlass_amd_fused_quantize_nv_blocked(const void* x, const void* h, int rot,
                                           const float* global_scale, void* out_e2m1, void* out_e4m3_blocked,
                                           void* stream);
 
+/*
+ * EXTENSION: the whole decode-time activation path in ONE launch, for batches of at most 32 rows:
+ *     D[M,N] (bf16) = alpha[0] * Q(x . h) (B . SFB)^T
+ * x: (M, K) bf16 activations, h: 32 x 32 bf16 rotation (rot must be 32), method as above; B / B_sf: the MXFP4 weight and its
+ * to_blocked e8m0 scales exactly as qutlass_amd_matmul_mxf4_bf16_tn takes them.  K % 128 == 0, N % 8 == 0, 1 <= M <= 32.
+ * Bit-identical to qutlass_amd_fused_quantize_mx + qutlass_amd_to_blocked + qutlass_amd_matmul_mxf4_bf16_tn on the same
+ * inputs (the three launches of qutlass/__init__.py:149-180, qutlass/utils.py:160-193, qutlass/__init__.py:34-76).
+ */
+int qutlass_amd_fused_quantize_matmul_mxf4_bf16_tn(const void* x, const void* h, int rot, int method, const void* B,
+                                                   const void* B_sf, const float* alpha, void* D, int64_t M, int64_t N,
+                                                   int64_t K, void* stream);
+
 /* ---- QAT-backward data preparation ------------------------------------- */
 
 /*
@@ -203,6 +215,20 @@ int qutlass_amd_backward_bf16_square_double_mxfp8(const void* x, int64_t m, int6
  */
 int qutlass_amd_mxfp4_transpose_mxfp8(const void* x_fp4, const void* scales, int64_t m, int64_t n, void* y,
                                       void* out_e8m0, void* stream);
+
+/*
+ * The same two ops for ANY row count m: the outputs are laid out for m_pad rows (a multiple of 128 >= m; the reference's
+ * wrappers use ceil(m / 128) * 128 resp. ceil(m / 256) * 256) and rows m .. m_pad-1 of the input are treated as zeros (zero codes
+ * with unit scales for the MXFP4 input) INSIDE the kernel.  The reference materialises that padding with
+ * torch.nn.functional.pad -- a full extra copy of the operand -- and, for mxfp4_transpose_mxfp8, by writing 1.0 into rows
+ * m .. m_pad-1 of the CALLER's scale tensor (qutlass/__init__.py:288-307, its own "TODO: padding in kernel"); here x / x_fp4 /
+ * scales are read-only and only need their m real rows.  With m_pad == m these ARE the entries above.
+ * y: (m_pad, n) resp. (n, m_pad); row_scales (m_pad, n/32), col_scales (n, m_pad/32); out_e8m0 (n, m_pad/32).
+ */
+int qutlass_amd_backward_bf16_square_double_mxfp8_rows(const void* x, int64_t m, int64_t m_pad, int64_t n, void* y,
+                                                       void* row_scales, void* col_scales, void* stream);
+int qutlass_amd_mxfp4_transpose_mxfp8_rows(const void* x_fp4, const void* scales, int64_t m, int64_t m_pad, int64_t n,
+                                           void* y, void* out_e8m0, void* stream);
 
 /* ---- block-scale swizzle ------------------------------------------------------------------------ */
 

@@ -19,7 +19,7 @@ from typing import Literal
 import torch
 
 from . import _lib, ops
-from .utils import get_padded_shape_mx, get_padded_shape_nv, pad_to_block, to_blocked  # noqa: F401
+from .utils import ceil_div, get_padded_shape_mx, get_padded_shape_nv, pad_to_block, to_blocked  # noqa: F401
 
 __version__ = "0.1.0"
 
@@ -142,6 +142,23 @@ def fusedQuantizeNvBlocked(a: torch.Tensor, b: torch.Tensor, global_scale: torch
     return torch.ops.qutlass_amd.fusedQuantizeNvBlocked(a, b, xh_e2m1, xh_e4m3, global_scale, _METHOD_CODE[method])
 
 
+def fused_quantize_matmul_mxf4_bf16_tn(x: torch.Tensor, h: torch.Tensor, b: torch.Tensor, b_sf: torch.Tensor, alpha: torch.Tensor, *,
+                                       method: Literal["quest", "abs_max"] = "abs_max") -> torch.Tensor:
+    """EXTENSION: ``matmul_mxf4_bf16_tn(*fusedQuantizeMxBlocked(x, h, method=method), b, b_sf, alpha)`` -- the activation path of one
+    linear layer (qutlass/__init__.py:149-180 -> qutlass/utils.py:160-193 -> qutlass/__init__.py:34-76).  Decode batches (at most
+    32 rows, 32 x 32 rotation) run as ONE launch in which the small-batch GEMM quantises its own A operand
+    (csrc/gemm_mx_fusedq.hip.h); everything else takes the two-launch path.  Same bits either way."""
+    if method not in _METHOD_CODE:
+        raise ValueError(f"invalid method {method!r}, must be 'quest' or 'abs_max'")
+    k = x.size(-1)
+    m = x.numel() // k if k else 0
+    if 0 < m <= 32 and h.size(0) == 32 and b.size(0) < 8192:
+        out = torch.ops.qutlass_amd.fusedQuantizeMatmulMxf4(x, h, b, b_sf, alpha, _METHOD_CODE[method])
+        return out.view(*x.shape[:-1], b.size(0))
+    a_q, a_sf = fusedQuantizeMxBlocked(x, h, method=method)
+    return qutlass_CUDA.matmul_mxf4_bf16_tn(a_q.view(-1, k // 2), b, a_sf, b_sf, alpha).view(*x.shape[:-1], b.size(0))
+
+
 def backward_t_bf16(x: torch.Tensor, h: torch.Tensor, xh_e2m1: torch.Tensor = None,
                     xh_e8m0: torch.Tensor = None) -> tuple[torch.Tensor, torch.Tensor]:
     """qutlass/__init__.py:206-243: abs-max MXFP4 of x^T (last two dims swapped) rotated per 32 along the old
@@ -173,27 +190,25 @@ def backward_qt_bf16(x_e2m1: torch.Tensor, x_e8m0: torch.Tensor, h: torch.Tensor
 
 
 def backward_bf16_square_double_mxfp8(x_bf16: torch.Tensor) -> tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
-    """qutlass/__init__.py:288-297: e4m3 with one e8m0 per 32 x 32 block, returned row-wise (m, n/32) and column-wise
-    (n, m/32); rows are zero-padded to a multiple of 128 first, as in the reference."""
-    if x_bf16.size(0) % 128 != 0:
-        x_bf16 = pad_to_block(x_bf16, [0], 128)
-    x_fp8 = torch.empty_like(x_bf16, dtype=torch.float8_e4m3fn)
-    row_scales = torch.empty(x_bf16.shape[0], x_bf16.shape[1] // 32, device=x_bf16.device, dtype=torch.float8_e8m0fnu)
-    column_scales = torch.empty(x_bf16.shape[1], x_bf16.shape[0] // 32, device=x_bf16.device, dtype=torch.float8_e8m0fnu)
+    """qutlass/__init__.py:288-297: e4m3 with one e8m0 per 32 x 32 block, returned row-wise (m_pad, n/32) and column-wise
+    (n, m_pad/32), m_pad = rows rounded up to 128.  The missing rows are zeros INSIDE the kernel: no padded copy of x."""
+    m, n = x_bf16.shape
+    m_pad = ceil_div(m, 128) * 128
+    x_fp8 = torch.empty(m_pad, n, device=x_bf16.device, dtype=torch.float8_e4m3fn)
+    row_scales = torch.empty(m_pad, n // 32, device=x_bf16.device, dtype=torch.float8_e8m0fnu)
+    column_scales = torch.empty(n, m_pad // 32, device=x_bf16.device, dtype=torch.float8_e8m0fnu)
     qutlass_CUDA.backward_bf16_square_double_mxfp8(x_bf16, x_fp8, row_scales, column_scales)
     return x_fp8, row_scales, column_scales
 
 
 def mxfp4_transpose_mxfp8(x_fp4: torch.Tensor, scales: torch.Tensor) -> tuple[torch.Tensor, torch.Tensor]:
-    """qutlass/__init__.py:299-315: MXFP4 (m, n/2) + e8m0 (m, n/32) -> transposed e4m3 (n, m) + e8m0 (n, m/32).
-    Rows are padded to a multiple of 256 with zero codes and unit scales first, as in the reference."""
-    if x_fp4.size(0) % 256 != 0:
-        m = x_fp4.shape[0]
-        m_up = ((m - 1) // 256) * 256 + 256
-        x_fp4 = pad_to_block(x_fp4, [0], 256)
-        scales[m:m_up] = 1.0
-    x_fp8 = torch.empty(x_fp4.shape[1] * 2, x_fp4.shape[0], device=x_fp4.device, dtype=torch.float8_e4m3fn)
-    shared_exps = torch.empty(x_fp4.shape[1] * 2, x_fp4.shape[0] // 32, device=x_fp4.device, dtype=torch.float8_e8m0fnu)
+    """qutlass/__init__.py:299-315: MXFP4 (m, n/2) + e8m0 (m, n/32) -> transposed e4m3 (n, m_pad) + e8m0 (n, m_pad/32), m_pad = rows
+    rounded up to 256 as in the reference.  The padding rows (zero codes, unit scales) exist only inside the kernel: x_fp4 is
+    not copied and `scales` is not written (the reference's own "TODO: padding in kernel")."""
+    m = x_fp4.shape[0]
+    m_pad = ceil_div(m, 256) * 256
+    x_fp8 = torch.empty(x_fp4.shape[1] * 2, m_pad, device=x_fp4.device, dtype=torch.float8_e4m3fn)
+    shared_exps = torch.empty(x_fp4.shape[1] * 2, m_pad // 32, device=x_fp4.device, dtype=torch.float8_e8m0fnu)
     qutlass_CUDA.mxfp4_transpose_mxfp8(x_fp4, scales, x_fp8, shared_exps)
     return x_fp8, shared_exps
 

@@ -34,11 +34,14 @@ SYMBOLS = {
     "qutlass_amd_fused_quantize_nv": (_i32, [_vp, _vp, _i32, _i64, _i32, _vp, _vp, _vp, _vp]),
     "qutlass_amd_fused_quantize_mx_blocked": (_i32, [_vp, _vp, _i32, _i64, _i64, _i32, _vp, _vp, _vp, _vp]),
     "qutlass_amd_fused_quantize_nv_blocked": (_i32, [_vp, _vp, _i32, _i64, _i64, _i32, _vp, _vp, _vp, _vp]),
+    "qutlass_amd_fused_quantize_matmul_mxf4_bf16_tn": (_i32, [_vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _vp]),
     "qutlass_amd_to_blocked": (_i32, [_vp, _i64, _i64, _vp, _vp]),
     "qutlass_amd_backward_t_bf16": (_i32, [_vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp]),
     "qutlass_amd_backward_qt_bf16": (_i32, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp]),
     "qutlass_amd_backward_bf16_square_double_mxfp8": (_i32, [_vp, _i64, _i64, _vp, _vp, _vp, _vp]),
     "qutlass_amd_mxfp4_transpose_mxfp8": (_i32, [_vp, _vp, _i64, _i64, _vp, _vp, _vp]),
+    "qutlass_amd_backward_bf16_square_double_mxfp8_rows": (_i32, [_vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp]),
+    "qutlass_amd_mxfp4_transpose_mxfp8_rows": (_i32, [_vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp]),
     "qutlass_amd_last_error": (ctypes.c_char_p, []),
     "qutlass_amd_version": (ctypes.c_char_p, []),
     "qutlass_amd_set_option": (_i32, [ctypes.c_char_p, _i32]),

@@ -12,6 +12,7 @@
 #include "gemm_mx.hip.h"
 #include "gemm_mx_deepp.hip.h"
 #include "gemm_mx_skinny.hip.h"
+#include "gemm_mx_fusedq.hip.h"
 #include "gemm_nvf4.hip.h"
 #include "quantize.hip.h"
 #include "to_blocked.hip.h"
@@ -230,18 +231,23 @@ int launch_gemm_hetero(GemmParams p, hipStream_t s) {
   return check_launch("gemm_mx_hetero_kernel");
 }
 
-// Persistent launch or heterogeneous launch for T tiles of 256x256?  Cost in units of one full round of `cus` tiles, fitted to the
-// steady-state sweeps (profiles/native_r2_mxwave.log, native_r3_hetero.log):
-//   balanced rounds   R = ceil(T / cus) rounds at occupancy o = T / (R cus): the kernels run at the socket power limit, so a round that
-//                     leaves CUs idle is cheaper -- f(o) = 0.36 + 0.64 o (768 tiles: 192 x 4 take 109.3 us against 97.9 us for 256 x 3)
-//   heterogeneous     the full rounds + waves of quarter tiles: a 128x128 tile walks K at ~0.6 us per stage against 1.79 us for the
-//                     256x256 tile, plus its own prologue / epilogue -> 0.05 + 0.38 per wave of `cus` quarter tiles
+// Persistent launch or heterogeneous launch for T tiles of 256x256?  Cost in units of one full-chip round of `cus` tiles, fitted to the
+// steady-state A/B of 18 shapes, K = 1024 .. 14336 (tests/native/qamd_check heterobench, profiles/native_r3_heterobench.log):
+//   balanced rounds   R = ceil(T / cus) rounds at occupancy o = T / (R cus).  The kernels run at the socket power limit, so a round that
+//                     leaves CUs idle is cheaper -- but never cheaper than the clock ceiling allows: f(o) = max(0.45 + 0.55 o, 0.78)
+//                     (measured: 272 / 320 / 384 / 448 / 576 tiles = 1.56 / 1.62 / 1.77 / 1.90 / 2.62 rounds)
+//   heterogeneous     the full rounds + waves of 128x128 quarter tiles: 0.05 once, then 0.25 + 0.13 x fill per wave of `cus` quarter tiles
+//                     (a quarter tile walks K at ~0.6 us per stage against 1.79 us for the 256x256 tile, plus its own prologue /
+//                     epilogue; measured: 272 / 288 / 320 / 384 / 448 / 576 tiles = 1.30 / 1.32 / 1.43 / 1.87 / 2.25 / 2.43 rounds)
+// 4096 x 5120 x 4096: 52.3 us balanced, 49.9 us as two launches (round 2), 46.8 us heterogeneous; 3072 x 6144: 51.5 / 47.4 / 43.3.
 inline bool hetero_wins(int64_t T, int cus) {
   const int64_t r = T / cus, rem = T % cus;
   if (r < 1 || rem == 0) return false;
   const int64_t R = r + 1;
-  const double a = (double)R * (0.36 + 0.64 * (double)T / (double)(R * cus));
-  const double b = (double)r + 0.05 + 0.38 * (double)cdiv(4 * rem, cus);
+  const double a = (double)R * std::max(0.45 + 0.55 * (double)T / (double)(R * cus), 0.78);
+  const int64_t nsmall = 4 * rem, waves = nsmall / cus;
+  const double last = (double)(nsmall % cus) / (double)cus;
+  const double b = (double)r + 0.05 + 0.38 * (double)waves + (last > 0 ? 0.25 + 0.13 * last : 0.0);
   return b < a;
 }
 
@@ -989,6 +995,34 @@ int qutlass_amd_fused_quantize_nv_blocked(const void* x, const void* h, int rot,
   return fused_quantize_nv_impl(name, x, h, rot, rows * k, k, method, global_scale, out_e2m1, out_e4m3_blocked, stream);
 }
 
+// decode-time activation path in one launch (gemm_mx_fusedq.hip.h): D = alpha * Q(x . h) (B . SFB)^T for M <= 32
+int qutlass_amd_fused_quantize_matmul_mxf4_bf16_tn(const void* x, const void* h, int rot, int method, const void* B, const void* B_sf,
+                                                   const float* alpha, void* D, int64_t M, int64_t N, int64_t K, void* stream) {
+  const char* name = "fusedQuantizeMatmulMxf4";
+  if (!x || !h || !B || !B_sf || !alpha || !D) return fail(QAMD_ERR_INVALID, "%s: null pointer argument", name);
+  if (rot != 32) return fail(QAMD_ERR_INVALID, "%s: Unsupported rotation size %d; expected 32.", name, rot);
+  if (method != QAMD_METHOD_QUEST && method != QAMD_METHOD_ABSMAX) return fail(QAMD_ERR_INVALID, "%s: invalid method %d", name, method);
+  if (M <= 0 || M > 32) return fail(QAMD_ERR_INVALID, "%s: M must be in 1..32 (got %lld); larger batches take fusedQuantizeMxBlocked + matmul_mxf4_bf16_tn", name, (long long)M);
+  if (N <= 0 || N % 8) return fail(QAMD_ERR_INVALID, "%s: N must be a positive multiple of 8 (got %lld)", name, (long long)N);
+  if (K < 128 || K % 128) return fail(QAMD_ERR_INVALID, "%s: K must be a positive multiple of 128 (got %lld)", name, (long long)K);
+  if (N * (K / 2) >= (1ll << 31) || M * K * 2 >= (1ll << 31) || cdiv(N, 32) >= (1ll << 31)) return fail(QAMD_ERR_INVALID, "%s: operand larger than 2 GiB is not supported", name);
+  FusedQParams p;
+  p.x = (const uint16_t*)x; p.h = (const uint16_t*)h; p.B = (const uint8_t*)B; p.SFB = (const uint8_t*)B_sf; p.alpha = alpha; p.D = (uint16_t*)D;
+  p.M = (int)M; p.N = (int)N; p.K = (int)K;
+  p.x_bytes = (uint32_t)(M * K * 2); p.b_bytes = (uint32_t)(N * (K / 2)); p.sfb_bytes = (uint32_t)(cdiv(N, 128) * cdiv(K / 32, 4) * 512);
+  const dim3 grid((unsigned)cdiv(N, 32), 1), block(512);
+  hipStream_t s = (hipStream_t)stream;
+  const bool hw = g_hw_fp4_cvt.load() != 0;
+  if (method == QAMD_METHOD_ABSMAX) {
+    if (hw) hipLaunchKernelGGL((gemm_mx_fusedq_kernel<METHOD_ABSMAX, true>), grid, block, 0, s, p);
+    else hipLaunchKernelGGL((gemm_mx_fusedq_kernel<METHOD_ABSMAX, false>), grid, block, 0, s, p);
+  } else {
+    if (hw) hipLaunchKernelGGL((gemm_mx_fusedq_kernel<METHOD_QUEST, true>), grid, block, 0, s, p);
+    else hipLaunchKernelGGL((gemm_mx_fusedq_kernel<METHOD_QUEST, false>), grid, block, 0, s, p);
+  }
+  return check_launch("gemm_mx_fusedq_kernel");
+}
+
 int qutlass_amd_backward_t_bf16(const void* x, const void* h, int64_t B, int64_t N, int64_t M, void* out_e2m1,
                                 void* out_e8m0, void* stream) {
   const char* name = "backward_t_bf16";
@@ -1026,37 +1060,51 @@ int qutlass_amd_backward_qt_bf16(const void* x_e2m1, const void* x_e8m0, const v
   return check_launch("bwd_quant_t_kernel");
 }
 
-int qutlass_amd_backward_bf16_square_double_mxfp8(const void* x, int64_t m, int64_t n, void* y, void* row_scales,
-                                                  void* col_scales, void* stream) {
+int qutlass_amd_backward_bf16_square_double_mxfp8_rows(const void* x, int64_t m, int64_t m_pad, int64_t n, void* y, void* row_scales,
+                                                       void* col_scales, void* stream) {
   const char* name = "backward_bf16_square_double_mxfp8";
   if (!x || !y || !row_scales || !col_scales) return fail(QAMD_ERR_INVALID, "%s: null pointer argument", name);
-  if (m <= 0 || n <= 0 || m % 128 || n % 128)
-    return fail(QAMD_ERR_INVALID, "%s: m and n must be positive multiples of 128 (got m=%lld n=%lld)", name, (long long)m, (long long)n);
-  if (m >= (1ll << 31) || n >= (1ll << 31) || (m / 128) * (n / 128) >= (1ll << 31)) return fail(QAMD_ERR_INVALID, "%s: tensor too large", name);
+  if (m <= 0 || n <= 0 || n % 128 || m_pad < m || m_pad % 128)
+    return fail(QAMD_ERR_INVALID, "%s: need m > 0, n a positive multiple of 128 and the output row extent a multiple of 128 >= m (got m=%lld m_pad=%lld n=%lld)", name,
+                (long long)m, (long long)m_pad, (long long)n);
+  if (m_pad >= (1ll << 31) || n >= (1ll << 31) || (m_pad / 128) * (n / 128) >= (1ll << 31)) return fail(QAMD_ERR_INVALID, "%s: tensor too large", name);
   SqParams p;
   p.x = (const uint16_t*)x; p.y = (uint8_t*)y; p.row_sf = (uint8_t*)row_scales; p.col_sf = (uint8_t*)col_scales;
-  p.m = (int)m; p.n = (int)n;
-  hipLaunchKernelGGL(bwd_square_double_mxfp8_kernel<>, dim3((unsigned)((m / 128) * (n / 128))), dim3(256), 0, (hipStream_t)stream, p);
+  p.m = (int)m; p.n = (int)n; p.m_pad = (int)m_pad;
+  hipLaunchKernelGGL(bwd_square_double_mxfp8_kernel<>, dim3((unsigned)((m_pad / 128) * (n / 128))), dim3(256), 0, (hipStream_t)stream, p);
   return check_launch("bwd_square_double_mxfp8_kernel");
+}
+
+int qutlass_amd_backward_bf16_square_double_mxfp8(const void* x, int64_t m, int64_t n, void* y, void* row_scales,
+                                                  void* col_scales, void* stream) {
+  if (m > 0 && m % 128) return fail(QAMD_ERR_INVALID, "backward_bf16_square_double_mxfp8: m and n must be positive multiples of 128 (got m=%lld n=%lld)", (long long)m, (long long)n);
+  return qutlass_amd_backward_bf16_square_double_mxfp8_rows(x, m, m, n, y, row_scales, col_scales, stream);
+}
+
+int qutlass_amd_mxfp4_transpose_mxfp8_rows(const void* x_fp4, const void* scales, int64_t m, int64_t m_pad, int64_t n, void* y,
+                                           void* out_e8m0, void* stream) {
+  const char* name = "mxfp4_transpose_mxfp8";
+  if (!x_fp4 || !scales || !y || !out_e8m0) return fail(QAMD_ERR_INVALID, "%s: null pointer argument", name);
+  if (m <= 0 || n <= 0 || n % 256 || m_pad < m || m_pad % 128)
+    return fail(QAMD_ERR_INVALID, "%s: need m > 0, n %% 256 == 0 and the output row extent a multiple of 128 >= m (got m=%lld m_pad=%lld n=%lld)", name, (long long)m,
+                (long long)m_pad, (long long)n);
+  if (m_pad >= (1ll << 31) || n >= (1ll << 31) || (m_pad / 128) * (n / 128) >= (1ll << 31)) return fail(QAMD_ERR_INVALID, "%s: tensor too large", name);
+  TrParams p;
+  p.xq = (const uint8_t*)x_fp4; p.xs = (const uint8_t*)scales; p.y = (uint8_t*)y; p.out_sf = (uint8_t*)out_e8m0;
+  p.m = (int)m; p.n = (int)n; p.m_pad = (int)m_pad;
+#if QAMD_BENCH
+  if (opt_transpose_nc() == 256)
+    hipLaunchKernelGGL(mxfp4_transpose_mxfp8_kernel<256>, dim3((unsigned)((m_pad / 128) * (n / 256))), dim3(256), 0, (hipStream_t)stream, p);
+  else
+#endif
+    hipLaunchKernelGGL(mxfp4_transpose_mxfp8_kernel<128>, dim3((unsigned)((m_pad / 128) * (n / 128))), dim3(256), 0, (hipStream_t)stream, p);
+  return check_launch("mxfp4_transpose_mxfp8_kernel");
 }
 
 int qutlass_amd_mxfp4_transpose_mxfp8(const void* x_fp4, const void* scales, int64_t m, int64_t n, void* y,
                                       void* out_e8m0, void* stream) {
-  const char* name = "mxfp4_transpose_mxfp8";
-  if (!x_fp4 || !scales || !y || !out_e8m0) return fail(QAMD_ERR_INVALID, "%s: null pointer argument", name);
-  if (m <= 0 || n <= 0 || m % 128 || n % 256)
-    return fail(QAMD_ERR_INVALID, "%s: need m %% 128 == 0 and n %% 256 == 0 (got m=%lld n=%lld)", name, (long long)m, (long long)n);
-  if (m >= (1ll << 31) || n >= (1ll << 31) || (m / 128) * (n / 256) >= (1ll << 31)) return fail(QAMD_ERR_INVALID, "%s: tensor too large", name);
-  TrParams p;
-  p.xq = (const uint8_t*)x_fp4; p.xs = (const uint8_t*)scales; p.y = (uint8_t*)y; p.out_sf = (uint8_t*)out_e8m0;
-  p.m = (int)m; p.n = (int)n;
-#if QAMD_BENCH
-  if (opt_transpose_nc() == 256)
-    hipLaunchKernelGGL(mxfp4_transpose_mxfp8_kernel<256>, dim3((unsigned)((m / 128) * (n / 256))), dim3(256), 0, (hipStream_t)stream, p);
-  else
-#endif
-    hipLaunchKernelGGL(mxfp4_transpose_mxfp8_kernel<128>, dim3((unsigned)((m / 128) * (n / 128))), dim3(256), 0, (hipStream_t)stream, p);
-  return check_launch("mxfp4_transpose_mxfp8_kernel");
+  if (m > 0 && m % 128) return fail(QAMD_ERR_INVALID, "mxfp4_transpose_mxfp8: need m %% 128 == 0 and n %% 256 == 0 (got m=%lld n=%lld)", (long long)m, (long long)n);
+  return qutlass_amd_mxfp4_transpose_mxfp8_rows(x_fp4, scales, m, m, n, y, out_e8m0, stream);
 }
 
 int qutlass_amd_to_blocked(const void* in, int64_t rows, int64_t cols, void* out, void* stream) {

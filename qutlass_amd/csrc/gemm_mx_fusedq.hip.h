@@ -1,0 +1,207 @@
+// Decode-time activation path in ONE launch (M <= 32):  D[M,N] (bf16) = alpha * Q(x . h) (B . SFB)^T
+//
+// The reference runs three launches per linear layer -- fusedQuantizeMx (qutlass/__init__.py:149-180), to_blocked
+// (qutlass/utils.py:160-193), matmul_mxf4_bf16_tn (qutlass/__init__.py:34-76) -- and at batch sizes 1..32 each of them is
+// nothing but launch latency (README.md:136-148: "Actual" vs "Ideal").  Here the small-batch GEMM of gemm_mx_skinny.hip.h
+// quantises its own A operand: a workgroup owns 32 rows of the weight B and splits K over its 8 waves, exactly as there; but
+// instead of loading packed e2m1 + e8m0 for A, each wave loads the bf16 activations of its K range, rotates them per 32-element
+// group on the bf16 MFMA (transposed, as quantize.hip.h does), derives the e8m0 scale (abs-max or Quest), rounds to e2m1 and
+// hands the codes to the scaled FP4 MFMA in registers.  Every workgroup repeats the quantisation of the (tiny) activation
+// matrix -- 32 x K bf16 -- which costs nothing against a launch; the weight loads of a wave are issued BEFORE the
+// quantisation starts, so the HBM latency of the weight stream hides behind it.
+//
+// Arithmetic = fused_quantize_kernel<32, false, METHOD, false, HWCVT> (same MFMA, same operand layout, same reduction order)
+// followed by gemm_mx_skinny_kernel (same K split, same reduction): the output is bit-identical to the three-launch path
+// (tests/test_gpu_round3.py).
+#pragma once
+#include "gemm_mx_skinny.hip.h"
+#include "quantize.hip.h"
+
+namespace qamd {
+
+struct FusedQParams {
+  const uint16_t* x;     // (M, K) bf16 activations
+  const uint16_t* h;     // (32, 32) bf16 rotation, row-major (y = x_g . h)
+  const uint8_t* B;      // (N, K/2) packed e2m1
+  const uint8_t* SFB;    // to_blocked e8m0 scales of B
+  const float* alpha;
+  uint16_t* D;           // (M, N) bf16
+  int M, N, K;
+  uint32_t x_bytes, b_bytes, sfb_bytes;
+};
+
+template <int METHOD, bool HWCVT, int NWAVES = 8>
+__global__ __launch_bounds__(NWAVES * 64) void gemm_mx_fusedq_kernel(const FusedQParams p) {
+  __shared__ __attribute__((aligned(16))) float part[NWAVES][32][33];
+  constexpr int HROW = 32 * 2 + 16;   // padded H^T row stride (bytes), as in quantize.hip.h
+  __shared__ __attribute__((aligned(16))) char hT[32 * HROW];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = uniform(tid >> 6);
+  const int i32 = lane & 31, g = lane >> 5;
+  const int n0 = blockIdx.x * 32, m0 = blockIdx.y * 32;
+  const int rowbytes = p.K >> 1;                   // packed B row
+  const int nseg = (rowbytes + 127) >> 7;          // 256-element K segments (K % 128 == 0: the last may be half)
+  const int KB = p.K >> 5, CB = (KB + 3) >> 2;
+
+  const uint32_t b_off = (uint32_t)n0 * rowbytes, x_off = (uint32_t)m0 * (uint32_t)p.K * 2u;
+  const __amdgpu_buffer_rsrc_t rB = make_rsrc(p.B + b_off, p.b_bytes - b_off);    // rows past N fall off the end -> 0
+  const __amdgpu_buffer_rsrc_t rX = make_rsrc((const uint8_t*)p.x + x_off, p.x_bytes - x_off);   // rows past M -> 0
+  const __amdgpu_buffer_rsrc_t rSB = make_rsrc(p.SFB, p.sfb_bytes);
+  const int voffB = i32 * rowbytes + g * 64;       // row i32, chunk 4g (+ j)
+  const int voffX = i32 * p.K * 2 + g * 16;        // row i32 of x, bytes 32 kc' + 16 g .. (+ 64 per group)
+  const int rb = n0 + i32;
+  const int soffB = (rb >> 7) * CB * 512 + (rb & 31) * 16 + ((rb & 127) >> 5) * 4 + g * 512;   // + s * 1024: column tile 2s + g
+  constexpr int OOB = 0x7f000000;
+
+  // ---- weight loads of this wave's FIRST segment go out before anything else ------------------------------------------------
+  v4i fb[4];
+  int sb = 0;
+  auto load_b = [&](int s) __attribute__((always_inline)) {
+    const int base = s * 128;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int v = (s < nseg && base + g * 64 + j * 16 < rowbytes) ? voffB + j * 16 : OOB;
+      fb[j] = __builtin_amdgcn_raw_buffer_load_b128(rB, v, base, 0);
+    }
+    sb = __builtin_amdgcn_raw_buffer_load_b32(rSB, (s < nseg && (8 * s + 4 * g) < KB) ? soffB + s * 1024 : OOB, 0, 0);
+  };
+  // x of segment s: group G = 0..7 (32 elements = 64 bytes of the row), chunk kc = 0, 1: lane (row, half) takes bytes 32 kc + 16 half .. +16
+  v4i xr[8][2];
+  auto load_x = [&](int s) __attribute__((always_inline)) {
+#pragma unroll
+    for (int G = 0; G < 8; ++G)
+#pragma unroll
+      for (int kc = 0; kc < 2; ++kc) {
+        const int k0 = s * 256 + G * 32;           // first element of the group
+        const int v = (s < nseg && k0 < p.K) ? voffX + G * 64 + kc * 32 : OOB;
+        xr[G][kc] = __builtin_amdgcn_raw_buffer_load_b128(rX, v, s * 512, 0);
+      }
+  };
+  int s = wave;
+  load_b(s);
+  load_x(s);
+
+  // ---- H^T image in LDS (hT[j][k] = h[k][j]), then this lane's two MFMA fragments into registers -----------------------------
+  if (tid < 256) {
+    uint16_t hv[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) hv[i] = p.h[i * 256 + tid];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int idx = i * 256 + tid, k = idx >> 5, j = idx & 31;
+      *(uint16_t*)(hT + j * HROW + k * 2) = hv[i];
+    }
+  }
+  __syncthreads();
+  v8bf hf[2];
+#pragma unroll
+  for (int kc = 0; kc < 2; ++kc) hf[kc] = *(const v8bf*)(hT + i32 * HROW + (kc * 16 + g * 8) * 2);
+
+  v16f acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+
+  for (; s < nseg; s += NWAVES) {
+    // ---- quantise the 8 groups of this segment: codes o[G] = 8 bytes (bytes 8 g .. 8 g + 7 of the group's 16), scale byte e8[G] ----
+    v2i o[8];
+    uint32_t e8s[8];
+#pragma unroll
+    for (int G = 0; G < 8; ++G) {
+      v16f y;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) y[r] = 0.f;
+#pragma unroll
+      for (int kc = 0; kc < 2; ++kc) y = __builtin_amdgcn_mfma_f32_32x32x16_bf16(hf[kc], __builtin_bit_cast(v8bf, xr[G][kc]), y, 0, 0, 0);
+      // y[4q+e] = (x_g . h)[row i32][8q + 4 g + e]       (quantize.hip.h, same operand layout)
+      float scale;
+      if (METHOD == METHOD_ABSMAX) {
+        float m = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) m = fmaxf(m, fabsf(y[r]));
+        m = xhalf_max(m);
+        scale = m + 1e-8f;
+      } else {
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          s1 += y[r];
+          s2 = fmaf(y[r], y[r], s2);
+        }
+        s1 = xhalf_add(s1);
+        s2 = xhalf_add(s2);
+        const float mean = s1 * 0.03125f;
+        const float var = fmaf(-mean, mean, s2 * 0.03125f);
+        scale = 1.0f;
+        if (var >= 0.f) scale = (float)((double)sqrtf(var) * (2.92247856 / 6.) + 1e-8);
+      }
+      const uint32_t e8 = (__float_as_uint(scale) >> 23) & 0xffu;
+      const int sh = 127 - (int)e8;
+      float t[16];
+      if (METHOD == METHOD_ABSMAX) {
+        const float f3 = ldexpf(3.0f, sh);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) t[r] = y[r] * f3;
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) t[r] = ldexpf(y[r], sh);
+      }
+      const uint32_t P = e2m1_pack8<HWCVT>(t), Q = e2m1_pack8<HWCVT>(t + 8);
+      auto sw = __builtin_amdgcn_permlane32_swap(P, Q, false, false);
+      const uint32_t X = sw[0], Y = sw[1];
+      o[G][0] = (int)((X & 0xffffu) | (Y << 16));
+      o[G][1] = (int)((X >> 16) | (Y & 0xffff0000u));
+      e8s[G] = e8;
+    }
+    // the next segment's activations can be fetched now (xr is dead)
+    const int snext = s + NWAVES;
+    // ---- MFMA operands: lane (row, g) of k-slice j needs all 16 code bytes of group 4 g + j.  Half 0 holds bytes 0..7 of every
+    //      group, half 1 bytes 8..15.  v_permlane32_swap(a, b) exchanges a's lanes 32-63 with b's lanes 0-31:
+    //        new a: lanes 0-31 keep a, lanes 32-63 receive half 0's b        new b: lanes 0-31 receive half 1's a, lanes 32-63 keep b
+    //      with a = o[j], b = o[4 + j]:   g = 0 -> {own bytes 0..7 of j, half 1's bytes 8..15 of j}
+    //                                     g = 1 -> {half 0's bytes 0..7 of 4 + j, own bytes 8..15 of 4 + j}
+    v4i fa[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      auto a0 = __builtin_amdgcn_permlane32_swap((uint32_t)o[j][0], (uint32_t)o[4 + j][0], false, false);
+      auto a1 = __builtin_amdgcn_permlane32_swap((uint32_t)o[j][1], (uint32_t)o[4 + j][1], false, false);
+      fa[j] = v4i{(int)a0[0], (int)a1[0], (int)a0[1], (int)a1[1]};   // bytes 0..7 (new a), bytes 8..15 (new b)
+    }
+    // scale dword of this lane: K-blocks 4 g .. 4 g + 3 of the segment
+    const uint32_t sa = g ? (e8s[4] | (e8s[5] << 8) | (e8s[6] << 16) | (e8s[7] << 24)) : (e8s[0] | (e8s[1] << 8) | (e8s[2] << 16) | (e8s[3] << 24));
+    load_x(snext);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const v4i a = fa[j], b = fb[j];
+      const v8i A8 = {a[0], a[1], a[2], a[3], 0, 0, 0, 0}, B8 = {b[0], b[1], b[2], b[3], 0, 0, 0, 0};
+      if (j == 0) acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(B8, A8, acc, 4, 4, 0, sb, 0, (int)sa);
+      if (j == 1) acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(B8, A8, acc, 4, 4, 1, sb, 1, (int)sa);
+      if (j == 2) acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(B8, A8, acc, 4, 4, 2, sb, 2, (int)sa);
+      if (j == 3) acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(B8, A8, acc, 4, 4, 3, sb, 3, (int)sa);
+    }
+    load_b(snext);
+  }
+
+  // ---- cross-wave reduction and epilogue: gemm_mx_skinny_kernel's --------------------------------------------------------------
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) part[wave][i32][8 * q + 4 * g + e] = acc[4 * q + e];
+  __syncthreads();
+  const float alpha = *p.alpha;
+  for (int idx = tid; idx < 32 * 8; idx += NWAVES * 64) {
+    const int m = idx >> 3, nq = (idx & 7) * 4;
+    float sm[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int w = 0; w < NWAVES; ++w)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) sm[e] += part[w][m][nq + e];
+    if (m0 + m < p.M && n0 + nq < p.N) {
+      v2i ov;
+      ov[0] = (int)pack_bf16x2(sm[0] * alpha, sm[1] * alpha);
+      ov[1] = (int)pack_bf16x2(sm[2] * alpha, sm[3] * alpha);
+      *(v2i*)(p.D + (size_t)(m0 + m) * p.N + n0 + nq) = ov;
+    }
+  }
+}
+
+}  // namespace qamd

@@ -196,6 +196,18 @@ __global__ __launch_bounds__(256) void fused_quantize_kernel(const QuantParams p
   }
   __syncthreads();
 
+  // BLK: (sf_row, sf_rem) = this lane's RP-element row r_abs = tile * 32 + row as (logical row, RP-row within it); one division
+  // here, then a carry-propagating add per tile
+  constexpr uint32_t SF_GPR = NV ? 2 * JT : JT;                       // scale groups per RP-element row
+  uint32_t sf_row = 0, sf_rem = 0, sf_qstep = 0, sf_rstep = 0, sf_rpr = 1;
+  if (BLK) {
+    sf_rpr = (uint32_t)p.sf_cols / SF_GPR;                            // RP-element rows per logical row (K / RP)
+    const uint32_t r0 = (uint32_t)wave_global * 32u + (uint32_t)row, step = (uint32_t)nwaves * 32u;
+    sf_row = r0 / sf_rpr;
+    sf_rem = r0 - sf_row * sf_rpr;
+    sf_qstep = step / sf_rpr;
+    sf_rstep = step - sf_qstep * sf_rpr;
+  }
   for (int tile = wave_global; tile < p.ntiles; tile += nwaves) {
     // R >= 64: keep H^T in LDS instead of letting the compiler hoist its R*R/256 fragments into registers across the
     // tile loop (R = 128: 128 VGPRs, 204 in total -> 2 waves per SIMD and no latency hiding; re-reading 32 KiB of LDS
@@ -203,14 +215,9 @@ __global__ __launch_bounds__(256) void fused_quantize_kernel(const QuantParams p
     int hoist_guard = 0;
     if (RP >= 64) asm volatile("" : "+v"(hoist_guard));
     const int64_t r_abs = (int64_t)tile * 32 + row;
-    // BLK: position of this lane's RP-element row in the logical scale matrix (one division per tile, not per group)
-    uint32_t sf_row = 0, sf_col0 = 0;
-    if (BLK) {
-      const uint32_t gpr = NV ? 2 * JT : JT;                        // scale groups per RP-element row
-      const uint32_t rpr = (uint32_t)p.sf_cols / gpr;               // RP-element rows per logical row (K / RP)
-      sf_row = (uint32_t)r_abs / rpr;
-      sf_col0 = ((uint32_t)r_abs - sf_row * rpr) * gpr;
-    }
+    // BLK: position of this lane's RP-element row in the logical scale matrix; advanced incrementally at the end of the loop body
+    // (a division per tile cost a third more VALU instructions in a kernel that is issue-bound at small R)
+    const uint32_t sf_col0 = BLK ? sf_rem * SF_GPR : 0u;
     // X^T operand: lane (row, half), chunk kc -> x[r_abs][16 kc + 8 half .. +8)  (16 bytes).  Software pipeline: the
     // loads of the wave's NEXT tile are issued before this tile is computed (tiles past the end fall off the buffer
     // descriptor and read 0), so the HBM latency of tile i+1 hides behind the MFMAs / epilogue of tile i.
@@ -366,6 +373,12 @@ __global__ __launch_bounds__(256) void fused_quantize_kernel(const QuantParams p
           }
         }
       }
+    }
+    if (BLK) {   // next tile of this wave: r_abs += nwaves * 32
+      sf_rem += sf_rstep;
+      const uint32_t carry = sf_rem >= sf_rpr ? 1u : 0u;
+      sf_rem -= carry ? sf_rpr : 0u;
+      sf_row += sf_qstep + carry;
     }
   }
 }

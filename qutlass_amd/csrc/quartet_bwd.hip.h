@@ -208,8 +208,10 @@ struct SqParams {
   const uint16_t* x;   // bf16 (m, n)
   uint8_t* y;          // e4m3 (m, n)
   uint8_t* row_sf;     // e8m0 (m, n/32)
-  uint8_t* col_sf;     // e8m0 (n, m/32)
-  int m, n;            // both multiples of 128 (host-checked)
+  uint8_t* col_sf;     // e8m0 (n, m_pad/32)
+  int m, n;            // m: rows of x that exist; n a multiple of 128 (host-checked)
+  int m_pad;           // rows of the outputs, a multiple of 128 >= m: rows m .. m_pad-1 are treated as zeros IN the kernel ([r3]: the
+                       // reference pads x with torch.nn.functional.pad first, qutlass/__init__.py:288-290 -- a full extra copy of the operand)
 };
 
 // exponent byte of encode_e8m0_shiftm8 (quartet_bwd_sm120.cu:503-509): amax is a bf16 value held in fp32
@@ -231,7 +233,8 @@ __global__ __launch_bounds__(256) void bwd_square_double_mxfp8_kernel(const SqPa
   float amax = 0.f;
 #pragma unroll
   for (int ps = 0; ps < 8; ++ps) {
-    v[ps] = *(const v4i*)(p.x + (int64_t)(r0 + ps * 4 + lr) * p.n + c0 + lc);
+    const int row = r0 + ps * 4 + lr;
+    v[ps] = row < p.m ? *(const v4i*)(p.x + (int64_t)row * p.n + c0 + lc) : v4i{0, 0, 0, 0};
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const uint32_t w = (uint32_t)v[ps][q];
@@ -268,7 +271,7 @@ __global__ __launch_bounds__(256) void bwd_square_double_mxfp8_kernel(const SqPa
   if (tid < 128) {   // column c0 + tid: the four row blocks of this workgroup are 4 consecutive bytes
     const int j = tid >> 5;
     const uint32_t col = es[0][j] | (es[1][j] << 8) | (es[2][j] << 16) | (es[3][j] << 24);
-    *(uint32_t*)(p.col_sf + (int64_t)(c0 + tid) * (p.m >> 5) + ti * 4) = col;
+    *(uint32_t*)(p.col_sf + (int64_t)(c0 + tid) * (p.m_pad >> 5) + ti * 4) = col;
   }
 }
 
@@ -280,8 +283,11 @@ struct TrParams {
   const uint8_t* xq;   // packed e2m1 (m, n/2)
   const uint8_t* xs;   // e8m0 (m, n/32)
   uint8_t* y;          // e4m3 (n, m)
-  uint8_t* out_sf;     // e8m0 (n, m/32)
-  int m, n;            // m % 128 == 0, n % 256 == 0 (host-checked)
+  uint8_t* out_sf;     // e8m0 (n, m_pad/32)
+  int m, n;            // m: rows of x_fp4 / scales that exist; n % 256 == 0 (host-checked)
+  int m_pad;           // row extent of the outputs (y is (n, m_pad)), a multiple of 128 >= m: rows m .. m_pad-1 count as zero codes with
+                       // unit scales IN the kernel ([r3]: the reference pads x_fp4 with a copy and writes 1.0 into the caller's scale
+                       // tensor first, qutlass/__init__.py:299-307 "TODO: padding in kernel")
 };
 
 // NC = columns (n) per workgroup: 256, or 128 (half the LDS, 4 workgroups per CU: the kernel is one round of workgroups,
@@ -302,8 +308,9 @@ __global__ __launch_bounds__(256) void mxfp4_transpose_mxfp8_kernel(const TrPara
   for (int ps = 0; ps < 32 / RPP; ++ps) {
     const int r = ps * RPP + lane / LPR, c = (lane % LPR) * 32;
     const int64_t rowi = r0 + r;
-    const v4i v = *(const v4i*)(p.xq + rowi * (p.n >> 1) + ((c0 + c) >> 1));
-    const float sc = e8m0_scale(p.xs[rowi * (p.n >> 5) + ((c0 + c) >> 5)]);
+    const bool live = rowi < p.m;
+    const v4i v = live ? *(const v4i*)(p.xq + rowi * (p.n >> 1) + ((c0 + c) >> 1)) : v4i{0, 0, 0, 0};
+    const float sc = live ? e8m0_scale(p.xs[rowi * (p.n >> 5) + ((c0 + c) >> 5)]) : 1.0f;
     v4i* d = (v4i*)(ts + r * LROW + c * 2);
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -370,9 +377,9 @@ __global__ __launch_bounds__(256) void mxfp4_transpose_mxfp8_kernel(const TrPara
   for (int ps = 0; ps < NC / 32; ++ps) {               // NC * 8 16-byte pieces: row = piece / 8, chunk = piece % 8
     const int piece = ps * 256 + tid, row = piece >> 3, ch = piece & 7;
     const v4i v = *(const v4i*)(os + row * OROW + ch * 16);
-    *(v4i*)(p.y + (int64_t)(c0 + row) * p.m + m0 + ch * 16) = v;
+    *(v4i*)(p.y + (int64_t)(c0 + row) * p.m_pad + m0 + ch * 16) = v;
   }
-  if (tid < NC) *(uint32_t*)(p.out_sf + (int64_t)(c0 + tid) * (p.m >> 5) + (m0 >> 5)) = *(const uint32_t*)(es + tid * 4);
+  if (tid < NC) *(uint32_t*)(p.out_sf + (int64_t)(c0 + tid) * (p.m_pad >> 5) + (m0 >> 5)) = *(const uint32_t*)(es + tid * 4);
 }
 
 }  // namespace qamd

@@ -295,6 +295,29 @@ std::tuple<Tensor, Tensor> fusedQuantizeNvBlocked(const Tensor& A, const Tensor&
   return {OUT, OUT_sf};
 }
 
+// ---- EXTENSION: rotate + quantize + MXFP4 GEMM in one launch for decode batches (M <= 32) ---------------------------------------
+Tensor fusedQuantizeMatmulMxf4(const Tensor& X, const Tensor& R, const Tensor& B, const Tensor& B_sf, const Tensor& alpha, int64_t method) {
+  const char* op = "fusedQuantizeMatmulMxf4";
+  require_contiguous(op, {{X, "X"}, {R, "R"}, {B, "B"}, {B_sf, "B_sf"}});
+  require_gpu(op, {{X, "X"}, {R, "R"}, {B, "B"}, {B_sf, "B_sf"}, {alpha, "alpha"}});
+  require_same_gpu(op, {{X, "X"}, {R, "R"}, {B, "B"}, {B_sf, "B_sf"}, {alpha, "alpha"}});
+  STD_TORCH_CHECK(has_dtype(X, ScalarType::BFloat16) && has_dtype(R, ScalarType::BFloat16), "X and R must be bf16");
+  STD_TORCH_CHECK(has_dtype(B, ScalarType::Byte), "B must be uint8");
+  STD_TORCH_CHECK(has_dtype(B_sf, ScalarType::Float8_e8m0fnu), "B_sf must be float8_e8m0fnu");
+  STD_TORCH_CHECK(has_dtype(alpha, ScalarType::Float) && alpha.numel() >= 1, "alpha must be a float32 tensor with at least one element");
+  STD_TORCH_CHECK(X.dim() >= 1 && B.dim() == 2, "X must be at least 1-D and B 2-D");
+  STD_TORCH_CHECK(R.dim() == 2 && R.size(0) == R.size(1), "Rotation matrix must be square");
+  const int64_t K = X.size(X.dim() - 1), M = K > 0 ? X.numel() / K : 0, N = B.size(0);
+  STD_TORCH_CHECK(B.size(1) * 2 == K, "Inner dimensions must match for Q(X) @ B.T");
+  STD_TORCH_CHECK(B_sf.numel() >= (N + 127) / 128 * 128 * ((K / 32 + 3) / 4 * 4), "B_sf is too small for the blocked scale layout of B");
+  Tensor out = torch::stable::new_empty(X, {M, N}, ScalarType::BFloat16);
+  if (M == 0 || N == 0) return out;
+  const torch::stable::accelerator::DeviceGuard guard(X.get_device_index());
+  check_rc(qutlass_amd_fused_quantize_matmul_mxf4_bf16_tn(X.data_ptr(), R.data_ptr(), (int)R.size(0), (int)method, B.data_ptr(), B_sf.data_ptr(),
+                                                          static_cast<const float*>(alpha.data_ptr()), out.data_ptr(), M, N, K, current_stream(X)));
+  return out;
+}
+
 // ---- QAT-backward data preparation (bindings.cpp:429-494: no validation there; the Python wrappers assert dtypes and
 //      contiguity, qutlass/__init__.py:206-315 -- the C ABI checks the shape constraints) --------------------------------
 void backward_t_bf16(const Tensor& x, const Tensor& h, Tensor xh_e2m1, Tensor xh_e8m0) {
@@ -329,11 +352,15 @@ void backward_bf16_square_double_mxfp8(const Tensor& x_bf16, Tensor x_fp8, Tenso
   require_contiguous(op, {{x_bf16, "x_bf16"}, {x_fp8, "x_fp8"}, {row_scales, "row_scales"}, {column_scales, "column_scales"}});
   require_gpu(op, {{x_bf16, "x_bf16"}, {x_fp8, "x_fp8"}, {row_scales, "row_scales"}, {column_scales, "column_scales"}});
   STD_TORCH_CHECK(has_dtype(x_bf16, ScalarType::BFloat16) && x_bf16.dim() == 2, "x_bf16 must be a 2-D bf16 tensor");
-  const int64_t m = x_bf16.size(0), n = x_bf16.size(1);
-  STD_TORCH_CHECK(nbytes(x_fp8) >= m * n && nbytes(row_scales) >= m * n / 32 && nbytes(column_scales) >= m * n / 32, "output tensors are too small");
+  // x_bf16 may have any row count m: the outputs carry the padded extent m_pad = x_fp8.size(0) (a multiple of 128 >= m) and the kernel
+  // treats the missing rows as zeros (the reference pads x_bf16 with a copy before the call, qutlass/__init__.py:288-290)
+  STD_TORCH_CHECK(x_fp8.dim() == 2 && x_fp8.size(1) == x_bf16.size(1), "x_fp8 must be (m_pad, n)");
+  const int64_t m = x_bf16.size(0), n = x_bf16.size(1), m_pad = x_fp8.size(0);
+  STD_TORCH_CHECK(m_pad >= m && m_pad % 128 == 0, "x_fp8 must have a multiple of 128 rows, at least as many as x_bf16");
+  STD_TORCH_CHECK(nbytes(row_scales) >= m_pad * n / 32 && nbytes(column_scales) >= m_pad * n / 32, "output tensors are too small");
   const torch::stable::accelerator::DeviceGuard guard(x_bf16.get_device_index());
-  check_rc(qutlass_amd_backward_bf16_square_double_mxfp8(x_bf16.data_ptr(), m, n, x_fp8.data_ptr(), row_scales.data_ptr(), column_scales.data_ptr(),
-                                                         current_stream(x_bf16)));
+  check_rc(qutlass_amd_backward_bf16_square_double_mxfp8_rows(x_bf16.data_ptr(), m, m_pad, n, x_fp8.data_ptr(), row_scales.data_ptr(), column_scales.data_ptr(),
+                                                              current_stream(x_bf16)));
 }
 
 void mxfp4_transpose_mxfp8(const Tensor& x_fp4, const Tensor& scales, Tensor x_fp8, Tensor shared_exps) {
@@ -341,11 +368,17 @@ void mxfp4_transpose_mxfp8(const Tensor& x_fp4, const Tensor& scales, Tensor x_f
   require_contiguous(op, {{x_fp4, "x_fp4"}, {scales, "scales"}, {x_fp8, "x_fp8"}, {shared_exps, "shared_exps"}});
   require_gpu(op, {{x_fp4, "x_fp4"}, {scales, "scales"}, {x_fp8, "x_fp8"}, {shared_exps, "shared_exps"}});
   STD_TORCH_CHECK(x_fp4.dim() == 2 && x_fp4.element_size() == 1 && scales.element_size() == 1, "x_fp4 must be a 2-D 1-byte tensor, scales 1-byte");
+  // any row count m: x_fp8 is (n, m_pad) with m_pad a multiple of 128 >= m; rows m .. m_pad-1 count as zero codes with unit scales
+  // inside the kernel -- `scales` is read-only and needs only its m real rows (the reference pads x_fp4 with a copy and writes 1.0 into
+  // the caller's scale tensor, qutlass/__init__.py:299-307)
   const int64_t m = x_fp4.size(0), n = x_fp4.size(1) * 2;
+  STD_TORCH_CHECK(x_fp8.dim() == 2 && x_fp8.size(0) == n, "x_fp8 must be (n, m_pad)");
+  const int64_t m_pad = x_fp8.size(1);
+  STD_TORCH_CHECK(m_pad >= m && m_pad % 128 == 0, "x_fp8 must have a multiple of 128 columns, at least as many as x_fp4 has rows");
   STD_TORCH_CHECK(scales.numel() >= m * n / 32, "scales must hold one e8m0 per 32 elements");
-  STD_TORCH_CHECK(nbytes(x_fp8) >= m * n && nbytes(shared_exps) >= m * n / 32, "output tensors are too small");
+  STD_TORCH_CHECK(nbytes(shared_exps) >= m_pad * n / 32, "output tensors are too small");
   const torch::stable::accelerator::DeviceGuard guard(x_fp4.get_device_index());
-  check_rc(qutlass_amd_mxfp4_transpose_mxfp8(x_fp4.data_ptr(), scales.data_ptr(), m, n, x_fp8.data_ptr(), shared_exps.data_ptr(), current_stream(x_fp4)));
+  check_rc(qutlass_amd_mxfp4_transpose_mxfp8_rows(x_fp4.data_ptr(), scales.data_ptr(), m, m_pad, n, x_fp8.data_ptr(), shared_exps.data_ptr(), current_stream(x_fp4)));
 }
 
 // ---- block-scale swizzle -------------------------------------------------------------------------------------------
@@ -386,6 +419,7 @@ STABLE_TORCH_LIBRARY_FRAGMENT(qutlass_amd, m) {
   m.def("to_blocked(Tensor input_matrix) -> Tensor");
   m.def("fusedQuantizeMxBlocked(Tensor A, Tensor R, Tensor OUT, Tensor OUT_sf, int method) -> (Tensor, Tensor)");
   m.def("fusedQuantizeNvBlocked(Tensor A, Tensor R, Tensor OUT, Tensor OUT_sf, Tensor global_scale, int method) -> (Tensor, Tensor)");
+  m.def("fusedQuantizeMatmulMxf4(Tensor X, Tensor R, Tensor B, Tensor B_sf, Tensor alpha, int method) -> Tensor");
 }
 
 // CUDA dispatch key only, as the reference (bindings.cpp:516-535); there is no CPU compute path.
@@ -409,6 +443,7 @@ STABLE_TORCH_LIBRARY_IMPL(qutlass_amd, CUDA, m) {
   m.impl("to_blocked", TORCH_BOX(&to_blocked));
   m.impl("fusedQuantizeMxBlocked", TORCH_BOX(&fusedQuantizeMxBlocked));
   m.impl("fusedQuantizeNvBlocked", TORCH_BOX(&fusedQuantizeNvBlocked));
+  m.impl("fusedQuantizeMatmulMxf4", TORCH_BOX(&fusedQuantizeMatmulMxf4));
 }
 
 // `import qutlass._CUDA` (reference: include/registration.h REGISTER_EXTENSION(_CUDA), bindings.cpp:537-540): an empty module

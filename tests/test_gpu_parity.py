@@ -292,8 +292,16 @@ def test_matmul_empty_batch_returns_empty_output(q):
     for fn in (q.matmul_mxf4_bf16_tn, q.matmul_ada_mxf4_bf16_tn):
         out = fn(a, b, asf, bsf, al)
         assert out.shape == (0, 64) and out.dtype == torch.bfloat16
-    out = q.matmul_nvf4_bf16_tn(a, b, asf.view(torch.uint8).view(torch.float8_e4m3fn), bsf.view(torch.uint8).view(torch.float8_e4m3fn), al)
+    e4 = torch.float8_e4m3fn
+    bsf_nv = torch.zeros(128 * 8, dtype=torch.uint8, device=DEV).view(e4)   # K = 128: 8 groups of 16 per row
+    out = q.matmul_nvf4_bf16_tn(a, b, asf.view(torch.uint8).view(e4), bsf_nv, al)
     assert out.shape == (0, 64)
+    # [r3, ADVICE r2] a malformed scale / alpha tensor is rejected whatever the batch size (the checks used to sit behind the
+    # empty-shape return)
+    with pytest.raises(RuntimeError, match="scale layout of B needs 1024"):
+        q.matmul_nvf4_bf16_tn(a, b, asf.view(torch.uint8).view(e4), bsf.view(torch.uint8).view(e4), al)
+    with pytest.raises(RuntimeError, match="alpha must be a float32"):
+        q.matmul_mxf4_bf16_tn(a, b, asf, bsf, al.double())
 
 
 def test_matmul_mxf4_errors(q):
@@ -727,8 +735,8 @@ def test_ops_are_hip_graph_capturable(q, m, n, k):
 
 
 def test_tail_split_launch_matches_single_launch(q):
-    """320 tiles of 256x256 on 256 CUs = 1.25 rounds: auto runs the first 16 tile columns with the deep kernel and the
-    last 4 with smaller tiles in a second launch (column range of the same D); forcing a variant runs ONE launch."""
+    """320 tiles of 256x256 on 256 CUs = 1.25 rounds: auto runs the heterogeneous launch ([r3]; rounds 1-2: a second launch of smaller
+    tiles over the last 4 tile columns) -- 256 persistent workgroups + 256 quarter tiles; forcing the per-tile kernel runs ONE schedule."""
     from qutlass_amd.utils import to_blocked
 
     torch.manual_seed(41)

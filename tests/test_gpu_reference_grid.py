@@ -219,9 +219,14 @@ def test_quartet_fp8_requant_chain(q):
     assert b8.shape == (n, mp2) and b_e.shape == (n, mp2 // 32) and mp2 == mp
     fp4_pad = torch.cat([fp4.view(torch.uint8), torch.zeros(mp2 - m, n // 2, dtype=torch.uint8, device=DEV)])
     sc_pad = npu8(sc)[:mp2, : n // 32].copy()
-    sc_pad[m:] = 127   # the wrapper sets the scales of the padded rows to 1.0
+    sc_pad[m:] = 127   # the padded rows carry unit scales (the reference's wrapper writes 1.0 into the caller's tensor; here the kernel assumes it)
     oy2, oe2 = oracle.mxfp4_transpose_mxfp8(npu8(fp4_pad), sc_pad)
     assert np.array_equal(npu8(b8), oy2) and np.array_equal(npu8(b_e), oe2)
+    # [r3] padding lives in the kernel: the caller's scale tensor is untouched, and a scale tensor of exactly m rows is enough
+    assert torch.equal(sc.view(torch.uint8), scales.view(torch.uint8))
+    sc_exact = scales.view(torch.uint8).reshape(-1)[: m * n // 32].reshape(m, n // 32).clone().view(torch.float8_e8m0fnu)
+    b8x, b_ex = q.mxfp4_transpose_mxfp8(fp4, sc_exact)
+    assert torch.equal(b8x.view(torch.uint8), b8.view(torch.uint8)) and torch.equal(b_ex.view(torch.uint8), b_e.view(torch.uint8))
 
     # the chain: A stored (K, M) = a8 (mp, n), scales (M, K/32) = column scales; B (N, K) = b8, scales (N, K/32) = b_e
     al = torch.tensor([1.0], device=DEV)
