@@ -606,11 +606,11 @@ int gemm_mx(const char* name, const void* A, const void* B, const void* A_sf, co
   // 128 tiles on, the 64x64 ring kernel streams the weight through full-line LDS-DMA and wins (N = 14336, K = 4096: 6.9 us
   // vs 9.7 us; N = 57344, K = 8192: 36 us vs 58-74 us), as does ring + split-K over caller scratch for a long K
   // (N = 4096, K = 14336, M = 16: 11.6 us vs 14.8 us).  profiles/native_r1_skinny_shapes.log, native_r1_ring.log
-  if (EBITS == 4 && ldd == N && (variant == 60 || (variant >= 44 && variant <= 49) || (variant == 0 && M <= 32 && cdiv(N, 64) < chip_cus() / 2 && !can_split))) {   // (the skinny kernel writes a dense D)
+  if (EBITS == 4 && (variant == 60 || (variant >= 44 && variant <= 49) || (variant == 0 && M <= 32 && cdiv(N, 64) < chip_cus() / 2 && !can_split))) {
     if (dry_record(variant ? variant : 60, p.N, 1)) return 0;
     SkinnyParams q;
     q.A = p.A; q.B = p.B; q.SFA = p.SFA; q.SFB = p.SFB; q.alpha = alpha; q.D = p.D; q.M = p.M; q.N = p.N; q.K = p.K;
-    q.a_bytes = p.a_bytes; q.b_bytes = p.b_bytes; q.sfa_bytes = p.sfa_bytes; q.sfb_bytes = p.sfb_bytes;
+    q.a_bytes = p.a_bytes; q.b_bytes = p.b_bytes; q.sfa_bytes = p.sfa_bytes; q.sfb_bytes = p.sfb_bytes; q.ldd = p.ldd;
     switch (variant) {   // 44..49: lab-only shapes of the split-K kernel (waves, segments per trip, chunk mapping)
 #if QAMD_BENCH
       case 44: launch_skinny<true, 8, 2, true>(q, s); break;
@@ -773,14 +773,32 @@ int qutlass_amd_matmul_mxf8_bf16_tn_ws(const void* A, const void* B, const void*
   return gemm_mx<8>("matmul_mxf8_bf16_tn", A, B, A_sf, B_sf, alpha, D, M, N, K, stream, workspace, workspace_bytes);
 }
 
-int qutlass_amd_matmul_ada_mxf4_bf16_tn(const void* A, const void* B, const void* A_sf, const void* B_sf,
-                                        const float* alpha, void* D, int64_t M, int64_t N, int64_t K, void* stream) {
+static int ada_impl(const void* A, const void* B, const void* A_sf, const void* B_sf, const float* alpha, void* D, int64_t M, int64_t N, int64_t K,
+                    int64_t ldd, void* stream) {
   const char* name = "matmul_ada_mxf4_bf16_tn";
   if (!A || !B || !A_sf || !B_sf || !alpha || !D) return fail(QAMD_ERR_INVALID, "%s: null pointer argument", name);
   if (M <= 0 || N <= 0) return fail(QAMD_ERR_INVALID, "%s: M and N must be positive (got M=%lld N=%lld)", name, (long long)M, (long long)N);
   if (K < 128 || K % 128) return fail(QAMD_ERR_INVALID, "%s: K must be a positive multiple of 128 (got %lld)", name, (long long)K);
   if (N % 8) return fail(QAMD_ERR_INVALID, "%s: N must be a multiple of 8 (got %lld)", name, (long long)N);
-  if (M * (K / 2) >= (1ll << 31) || N * (K / 2) >= (1ll << 31)) return fail(QAMD_ERR_INVALID, "%s: operand larger than 2 GiB is not supported", name);
+  if (M >= (1ll << 31) || N >= (1ll << 31) || M * N >= (1ll << 40)) return fail(QAMD_ERR_INVALID, "%s: an output of 2^40 elements is not supported", name);
+  if (ldd == 0) ldd = N;
+  const int64_t rowbytes = K / 2, KB = K / 32;
+  // operands of >= 2 GiB (32-bit buffer-descriptor offsets; the reference hands 64-bit strides to CUTLASS): ranges of whole 64-row
+  // tiles with rebased operand / row-major scale / D pointers -- every output element is computed by exactly one launch
+  if (N * rowbytes >= (1ll << 31)) {
+    const int64_t cols = ((1ll << 31) - 1) / rowbytes / 64 * 64;
+    if (cols < 64) return fail(QAMD_ERR_INVALID, "%s: K too large for a 64-column range of B to stay below 2 GiB", name);
+    for (int64_t c0 = 0; c0 < N; c0 += cols)
+      if (int rc = ada_impl(A, (const uint8_t*)B + c0 * rowbytes, A_sf, (const uint8_t*)B_sf + c0 * KB, alpha, (uint16_t*)D + c0, M, std::min(cols, N - c0), K, ldd, stream)) return rc;
+    return QAMD_OK;
+  }
+  if (M * rowbytes >= (1ll << 31)) {
+    const int64_t rows = ((1ll << 31) - 1) / rowbytes / 64 * 64;
+    if (rows < 64) return fail(QAMD_ERR_INVALID, "%s: K too large for a 64-row range of A to stay below 2 GiB", name);
+    for (int64_t r0 = 0; r0 < M; r0 += rows)
+      if (int rc = ada_impl((const uint8_t*)A + r0 * rowbytes, B, (const uint8_t*)A_sf + r0 * KB, B_sf, alpha, (uint16_t*)D + r0 * ldd, std::min(rows, M - r0), N, K, ldd, stream)) return rc;
+    return QAMD_OK;
+  }
   // Same regimes as matmul_mxf4_bf16_tn: the LDS-free split-K kernel while the weight has fewer than 128 64-row tiles;
   // from 128 tiles on (N >= 8192) the 64x64 ring kernel with row-major scale fetch streams the weight through full-line
   // LDS-DMA (M = 16: N = 14336, K = 4096 9.7 -> 6.9 us; N = 57344, K = 8192 62.6 -> 39.9 us), and any M > 32 goes there
@@ -793,9 +811,9 @@ int qutlass_amd_matmul_ada_mxf4_bf16_tn(const void* A, const void* B, const void
   if (ring) {
     GemmParams p;
     p.A = (const uint8_t*)A; p.B = (const uint8_t*)B; p.SFA = (const uint8_t*)A_sf; p.SFB = (const uint8_t*)B_sf;
-    p.alpha = alpha; p.D = (uint16_t*)D; p.M = (int)M; p.N = (int)N; p.K = (int)K; p.ldd = (int)N;
-    p.a_bytes = (uint32_t)(M * (K / 2)); p.b_bytes = (uint32_t)(N * (K / 2));
-    p.sfa_bytes = (uint32_t)(M * (K / 32)); p.sfb_bytes = (uint32_t)(N * (K / 32));   // row-major (rows, K/32), un-swizzled
+    p.alpha = alpha; p.D = (uint16_t*)D; p.M = (int)M; p.N = (int)N; p.K = (int)K; p.ldd = (int)ldd;
+    p.a_bytes = (uint32_t)(M * rowbytes); p.b_bytes = (uint32_t)(N * rowbytes);
+    p.sfa_bytes = (uint32_t)(M * KB); p.sfb_bytes = (uint32_t)(N * KB);   // row-major (rows, K/32), un-swizzled
     p.pp_shift = opt_pp_shift(); p.pp_flags = opt_pp_flags(); p.dbg = opt_dbg();
     p.ws = nullptr; p.splits = 1; p.ctr = nullptr; p.tag = 0;
 #if QAMD_BENCH
@@ -805,11 +823,16 @@ int qutlass_amd_matmul_ada_mxf4_bf16_tn(const void* A, const void* B, const void
   }
   SkinnyParams q;
   q.A = (const uint8_t*)A; q.B = (const uint8_t*)B; q.SFA = (const uint8_t*)A_sf; q.SFB = (const uint8_t*)B_sf;
-  q.alpha = alpha; q.D = (uint16_t*)D; q.M = (int)M; q.N = (int)N; q.K = (int)K;
-  q.a_bytes = (uint32_t)(M * (K / 2)); q.b_bytes = (uint32_t)(N * (K / 2));
-  q.sfa_bytes = (uint32_t)(M * (K / 32)); q.sfb_bytes = (uint32_t)(N * (K / 32));   // row-major (rows, K/32), un-swizzled
+  q.alpha = alpha; q.D = (uint16_t*)D; q.M = (int)M; q.N = (int)N; q.K = (int)K; q.ldd = (int)ldd;
+  q.a_bytes = (uint32_t)(M * rowbytes); q.b_bytes = (uint32_t)(N * rowbytes);
+  q.sfa_bytes = (uint32_t)(M * KB); q.sfb_bytes = (uint32_t)(N * KB);   // row-major (rows, K/32), un-swizzled
   launch_skinny<false, 8, 4, false>(q, (hipStream_t)stream);
   return check_launch("gemm_mx_skinny_kernel");
+}
+
+int qutlass_amd_matmul_ada_mxf4_bf16_tn(const void* A, const void* B, const void* A_sf, const void* B_sf,
+                                        const float* alpha, void* D, int64_t M, int64_t N, int64_t K, void* stream) {
+  return ada_impl(A, B, A_sf, B_sf, alpha, D, M, N, K, 0, stream);
 }
 
 int qutlass_amd_matmul_mxf8_bf16_tn(const void* A, const void* B, const void* A_sf, const void* B_sf,
@@ -820,12 +843,16 @@ int qutlass_amd_matmul_mxf8_bf16_tn(const void* A, const void* B, const void* A_
 // one rule for the launcher and the workspace query: the persistent kernel on the (K, M) operand wherever the TN op would
 // pick the persistent 256x256 kernel for the whole problem (gemm_mx auto rule); everything smaller goes through the
 // byte-transpose pre-pass and the TN dispatch with its smaller tiles / split-K
-static bool mxf8_nn_is_fused(int64_t M, int64_t N) { return M > 64 && N > 64 && N < (1ll << 22) && cdiv(M, 256) * cdiv(N, 256) >= chip_cus() * 3 / 4; }
+// (operands of >= 2 GiB also take the pre-pass: the in-place path walks the (K, M) operand with 32-bit offsets k * M + m, which only a
+//  per-K-chunk descriptor could extend; the (M, K) copy in the workspace then runs as row ranges of the TN dispatch, gemm_mx)
+static bool mxf8_nn_is_fused(int64_t M, int64_t N, int64_t K) {
+  return M > 64 && N > 64 && N < (1ll << 22) && cdiv(M, 256) * cdiv(N, 256) >= chip_cus() * 3 / 4 && M * K < (1ll << 31) && N * K < (1ll << 31);
+}
 
 int64_t qutlass_amd_mxf8_nn_workspace_bytes(int64_t M, int64_t K) { return (M > 0 && K > 0) ? M * K : 0; }
 int64_t qutlass_amd_mxf8_nn_workspace_bytes_for(int64_t M, int64_t N, int64_t K) {
   if (M <= 0 || N <= 0 || K <= 0) return 0;
-  return (opt_gemm_variant() == 0 && mxf8_nn_is_fused(M, N)) ? 0 : M * K;
+  return (opt_gemm_variant() == 0 && mxf8_nn_is_fused(M, N, K)) ? 0 : M * K;
 }
 
 static int mxf8_nn_impl(const void* A, const void* B, const void* A_sf, const void* B_sf, const float* alpha, void* D, int64_t M, int64_t N,
@@ -835,11 +862,11 @@ static int mxf8_nn_impl(const void* A, const void* B, const void* A_sf, const vo
   if (M <= 0 || N <= 0) return fail(QAMD_ERR_INVALID, "%s: M and N must be positive (got M=%lld N=%lld)", name, (long long)M, (long long)N);
   if (K < 32 || K % 32) return fail(QAMD_ERR_INVALID, "%s: K must be a positive multiple of 32 (got %lld)", name, (long long)K);
   if (M % 16) return fail(QAMD_ERR_INVALID, "%s: M must be a multiple of 16 for the (K, M) operand (got %lld)", name, (long long)M);
-  if (M * K >= (1ll << 31)) return fail(QAMD_ERR_INVALID, "%s: operand larger than 2 GiB is not supported", name);
+  if (M >= (1ll << 31) || K >= (1ll << 31)) return fail(QAMD_ERR_INVALID, "%s: tensor too large", name);
   // large problems: the persistent kernel reads A^T directly (no pre-pass, no workspace).  Lab library only: "gemm_variant"
   // 63 forces it, 61 forces the per-tile fused kernel of round 1 (dword reads + v_perm byte transposes), 62 the pre-pass
   const int forced = opt_gemm_variant();
-  const bool fused = forced == 61 || (forced >= 63 && forced <= 66) || (forced == 0 && mxf8_nn_is_fused(M, N));
+  const bool fused = (M * K < (1ll << 31) && N * K < (1ll << 31)) && (forced == 61 || (forced >= 63 && forced <= 66) || (forced == 0 && mxf8_nn_is_fused(M, N, K)));
   if (!fused) {
     if (!workspace) return fail(QAMD_ERR_INVALID, "%s: null pointer argument", name);
     if (workspace_bytes < M * K) return fail(QAMD_ERR_INVALID, "%s: workspace too small (%lld < %lld bytes)", name, (long long)workspace_bytes, (long long)(M * K));
@@ -848,7 +875,6 @@ static int mxf8_nn_impl(const void* A, const void* B, const void* A_sf, const vo
     if (!B || !A_sf || !B_sf || !alpha || !D) return fail(QAMD_ERR_INVALID, "%s: null pointer argument", name);
     if (N % 8) return fail(QAMD_ERR_INVALID, "%s: N must be a multiple of 8 (got %lld)", name, (long long)N);
     const int64_t CB = cdiv(K / 32, 4);
-    if (N * K >= (1ll << 31)) return fail(QAMD_ERR_INVALID, "%s: operand larger than 2 GiB is not supported", name);
     GemmParams p;
     p.A = (const uint8_t*)A; p.B = (const uint8_t*)B; p.SFA = (const uint8_t*)A_sf; p.SFB = (const uint8_t*)B_sf;
     p.alpha = alpha; p.D = (uint16_t*)D; p.M = (int)M; p.N = (int)N; p.K = (int)K; p.ldd = (int)N;
@@ -898,24 +924,51 @@ int qutlass_amd_matmul_mxf8_bf16_nn_fmt(const void* A, const void* B, const void
   return mxf8_nn_impl(A, B, A_sf, B_sf, alpha, D, M, N, K, a_format, workspace, workspace_bytes, stream);
 }
 
-int qutlass_amd_matmul_nvf4_bf16_tn(const void* A, const void* B, const void* A_sf, const void* B_sf,
-                                    const float* alpha, void* D, int64_t M, int64_t N, int64_t K, void* stream) {
+// ldd: row stride of D in elements when the call covers a column range of a wider output (0 = N)
+static int nvf4_impl(const void* A, const void* B, const void* A_sf, const void* B_sf, const float* alpha, void* D, int64_t M, int64_t N,
+                     int64_t K, int64_t ldd, void* stream) {
   const char* name = "matmul_nvf4_bf16_tn";
   if (!A || !B || !A_sf || !B_sf || !alpha || !D) return fail(QAMD_ERR_INVALID, "%s: null pointer argument", name);
   if (M <= 0 || N <= 0) return fail(QAMD_ERR_INVALID, "%s: M and N must be positive", name);
   if (K < 16 || K % 32) return fail(QAMD_ERR_INVALID, "%s: K must be a positive multiple of 32 (got %lld)", name, (long long)K);
   if (N % 8) return fail(QAMD_ERR_INVALID, "%s: N must be a multiple of 8 (got %lld)", name, (long long)N);
-  if (M * (K / 2) >= (1ll << 31) || N * (K / 2) >= (1ll << 31))
-    return fail(QAMD_ERR_INVALID, "%s: operand larger than 2 GiB is not supported", name);
+  if (M >= (1ll << 31) || N >= (1ll << 31) || M * N >= (1ll << 40)) return fail(QAMD_ERR_INVALID, "%s: an output of 2^40 elements is not supported", name);
+  if (ldd == 0) ldd = N;
+  const int64_t rowbytes = K / 2, CB = cdiv(K / 16, 4);
+  // The kernels address an operand through 32-bit buffer-descriptor offsets (< 2 GiB); the reference hands 64-bit strides to CUTLASS
+  // (qutlass/csrc/gemm.cu:90-143).  A larger operand runs as ranges of whole 256-row tiles with rebased operand / scale / D pointers
+  // (gemm_mx does the same): every output element is computed by exactly one launch, in the same K order.
+  if (N * rowbytes >= (1ll << 31)) {
+    const int64_t cols = ((1ll << 31) - 1) / rowbytes / 256 * 256;
+    if (cols < 256) return fail(QAMD_ERR_INVALID, "%s: K too large for a 256-column range of B to stay below 2 GiB", name);
+    for (int64_t c0 = 0; c0 < N; c0 += cols)
+      if (int rc = nvf4_impl(A, (const uint8_t*)B + c0 * rowbytes, A_sf, (const uint8_t*)B_sf + (c0 / 128) * CB * 512, alpha, (uint16_t*)D + c0, M,
+                             std::min(cols, N - c0), K, ldd, stream))
+        return rc;
+    return QAMD_OK;
+  }
+  if (M * rowbytes >= (1ll << 31)) {
+    const int64_t rows = ((1ll << 31) - 1) / rowbytes / 256 * 256;
+    if (rows < 256) return fail(QAMD_ERR_INVALID, "%s: K too large for a 256-row range of A to stay below 2 GiB", name);
+    for (int64_t r0 = 0; r0 < M; r0 += rows)
+      if (int rc = nvf4_impl((const uint8_t*)A + r0 * rowbytes, B, (const uint8_t*)A_sf + (r0 / 128) * CB * 512, B_sf, alpha, (uint16_t*)D + r0 * ldd,
+                             std::min(rows, M - r0), N, K, ldd, stream))
+        return rc;
+    return QAMD_OK;
+  }
   NvGemmParams p;
   p.A = (const uint8_t*)A; p.B = (const uint8_t*)B; p.SFA = (const uint8_t*)A_sf; p.SFB = (const uint8_t*)B_sf;
-  p.alpha = alpha; p.D = (uint16_t*)D; p.M = (int)M; p.N = (int)N; p.K = (int)K;
-  const int64_t CB = cdiv(K / 16, 4);
-  p.a_bytes = (uint32_t)(M * (K / 2)); p.b_bytes = (uint32_t)(N * (K / 2));
+  p.alpha = alpha; p.D = (uint16_t*)D; p.M = (int)M; p.N = (int)N; p.K = (int)K; p.ldd = (int)ldd;
+  p.a_bytes = (uint32_t)(M * rowbytes); p.b_bytes = (uint32_t)(N * rowbytes);
   p.sfa_bytes = (uint32_t)(cdiv(M, 128) * CB * 512); p.sfb_bytes = (uint32_t)(cdiv(N, 128) * CB * 512);
   p.dbg = opt_dbg();
   if (launch_nvf4_host(p, (hipStream_t)stream, opt_nvf4_variant())) return fail(QAMD_ERR_INVALID, "%s: unknown nvf4_variant %d", name, opt_nvf4_variant());
   return check_launch(name);
+}
+
+int qutlass_amd_matmul_nvf4_bf16_tn(const void* A, const void* B, const void* A_sf, const void* B_sf,
+                                    const float* alpha, void* D, int64_t M, int64_t N, int64_t K, void* stream) {
+  return nvf4_impl(A, B, A_sf, B_sf, alpha, D, M, N, K, 0, stream);
 }
 
 // sf_rows / k: logical 2-D shape of x (rows of k elements) for the blocked-scale variants; k == 0: flat scales (the reference's contract)

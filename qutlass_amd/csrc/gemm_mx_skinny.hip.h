@@ -25,6 +25,7 @@ struct SkinnyParams {
   uint16_t* D;           // (M, N) bf16
   int M, N, K;
   uint32_t a_bytes, b_bytes, sfa_bytes, sfb_bytes;
+  int ldd;               // row stride of D in elements (= N unless the launch covers a column range of a wider D)
 };
 
 // MAP2 = false: lane (row, half g) takes chunk 4g + j for k-slice j (two separate 16-byte pieces of a line per load);
@@ -142,7 +143,7 @@ __global__ __launch_bounds__(NWAVES * 64) void gemm_mx_skinny_kernel(const Skinn
       v2i o;
       o[0] = (int)pack_bf16x2(s[0] * alpha, s[1] * alpha);
       o[1] = (int)pack_bf16x2(s[2] * alpha, s[3] * alpha);
-      *(v2i*)(p.D + (size_t)(m0 + m) * p.N + n0 + nq) = o;
+      *(v2i*)(p.D + (size_t)(m0 + m) * p.ldd + n0 + nq) = o;
     }
   }
 }

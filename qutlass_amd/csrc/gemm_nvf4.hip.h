@@ -25,6 +25,7 @@ struct NvGemmParams {
   const float* alpha;
   uint16_t* D;
   int M, N, K;
+  int ldd;         // row stride of D in elements (= N unless the launch covers a column range of a wider D: operands >= 2 GiB, capi.hip)
   int tiles_m, tiles_n;
   uint32_t a_bytes, b_bytes, sfa_bytes, sfb_bytes;
   uint32_t* dbg;   // bench only: block 0 writes {shader cycles, 100 MHz ticks} of its K loop
@@ -291,7 +292,7 @@ __global__ __launch_bounds__(C::THREADS) void gemm_nvf4_kernel(const NvGemmParam
     if (grow < p.M && gcol < p.N) {
       v4i v = *(const v4i*)(smem + row * C::SROW + ((((2 * chunk) ^ (row & 15)) & ~1) << 3));
       if (row & 1) v = v4i{v[2], v[3], v[0], v[1]};
-      *(v4i*)(p.D + (size_t)grow * p.N + gcol) = v;
+      *(v4i*)(p.D + (size_t)grow * p.ldd + gcol) = v;
     }
   }
 }
@@ -513,7 +514,7 @@ __global__ __launch_bounds__(C::THREADS) void gemm_nvf4_lds_kernel(const NvGemmP
     if (grow2 < p.M && gcol < p.N) {
       v4i v = *(const v4i*)(smem + row * C::SROW + ((((2 * chunk) ^ (row & 15)) & ~1) << 3));
       if (row & 1) v = v4i{v[2], v[3], v[0], v[1]};
-      *(v4i*)(p.D + (size_t)grow2 * p.N + gcol) = v;
+      *(v4i*)(p.D + (size_t)grow2 * p.ldd + gcol) = v;
     }
   }
 }
@@ -606,7 +607,7 @@ __global__ __launch_bounds__(NWAVES * 64) void gemm_nvf4_skinny_kernel(const NvG
       v2i o;
       o[0] = (int)pack_bf16x2(sum[0] * alpha, sum[1] * alpha);
       o[1] = (int)pack_bf16x2(sum[2] * alpha, sum[3] * alpha);
-      *(v2i*)(p.D + (size_t)(m0 + m) * p.N + n0 + nq) = o;
+      *(v2i*)(p.D + (size_t)(m0 + m) * p.ldd + n0 + nq) = o;
     }
   }
 }

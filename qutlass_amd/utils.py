@@ -35,10 +35,12 @@ def to_blocked(input_matrix: torch.Tensor, use_triton_kernel: bool = False) -> t
 
 
 def pad_to_block(tensor, dims, blocksize):
-    """qutlass/utils.py:196-204."""
-    pad_dims = [0 for _ in range(2 * len(tensor.shape))]
-    for dim in dims:
-        size = tensor.shape[dim]
-        next_multiple_of_block = ((size - 1) // blocksize + 1) * blocksize
-        pad_dims[-2 * dim - 1] = next_multiple_of_block - size
-    return torch.nn.functional.pad(tensor, pad_dims, "constant", 0.0)
+    """qutlass/utils.py:196-204 (public helper of the reference; nothing in this package calls it any more -- the ops that needed
+    row padding do it inside their kernels): zero-extend `tensor` at the end of every dimension in `dims` to a multiple of
+    `blocksize`."""
+    shape = list(tensor.shape)
+    for d in dims:
+        shape[d] = -(-shape[d] // blocksize) * blocksize
+    out = tensor.new_zeros(shape)
+    out[tuple(slice(0, n) for n in tensor.shape)] = tensor
+    return out

@@ -634,6 +634,21 @@ int main(int argc, char** argv) {
       snprintf(tag, sizeof tag, "mxfp8 hetero %lldx%lldx%lld", (long long)sh.M, (long long)sh.N, (long long)sh.K); bench_gemm(tag, 2, sh.M, sh.N, sh.K, 98, 40);
     }
   }
+  if (want("heterobench2")) {   // spot checks of the refitted cost model (capi.hip hetero_wins) on tile counts the first sweep did not hold: auto must equal the better of the two
+    g_gauss_fill = 1;
+    struct Sh { int64_t M, N, K; };
+    for (const Sh& sh : {Sh{4096, 4352, 4096}, Sh{4096, 5632, 4096}, Sh{4096, 6656, 4096}, Sh{4096, 9728, 4096}, Sh{4096, 10240, 4096}, Sh{4096, 13312, 4096}, Sh{8192, 4352, 4096}, Sh{2048, 8704, 4096},
+                         Sh{4096, 5120, 8192}, Sh{5120, 4096, 2048}}) {
+      char tag[96];
+      qutlass_amd_set_option("pp_flags", 1);
+      snprintf(tag, sizeof tag, "mxfp4 auto %lldx%lldx%lld", (long long)sh.M, (long long)sh.N, (long long)sh.K); bench_gemm(tag, 0, sh.M, sh.N, sh.K, 0, 40);
+      qutlass_amd_set_option("pp_flags", 1 | 64);
+      snprintf(tag, sizeof tag, "mxfp4 balanced %lldx%lldx%lld", (long long)sh.M, (long long)sh.N, (long long)sh.K); bench_gemm(tag, 0, sh.M, sh.N, sh.K, 90, 40);
+      qutlass_amd_set_option("pp_flags", 1);
+      snprintf(tag, sizeof tag, "mxfp4 hetero %lldx%lldx%lld", (long long)sh.M, (long long)sh.N, (long long)sh.K); bench_gemm(tag, 0, sh.M, sh.N, sh.K, 98, 40);
+    }
+    g_gauss_fill = 0;
+  }
   if (want("deepptrace")) {   // phase timeline of workgroup 0 of the persistent deep kernel (variant 91), in the steady state
     struct Sh { int64_t M, N, K; };
     for (const Sh& sh : {Sh{4096, 4096, 4096}, Sh{4096, 12288, 4096}, Sh{8192, 8192, 8192}}) {

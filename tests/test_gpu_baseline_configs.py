@@ -215,3 +215,59 @@ def test_b_operand_beyond_2gib_runs_as_column_ranges(q):
     gf, rf = oracle.bf16_bits_to_f32(got).astype(np.float64), oracle.bf16_bits_to_f32(ref).astype(np.float64)
     assert (np.abs(gf - rf) <= np.abs(rf) / 128.0 + 1e-6 * np.abs(rf).max()).all()
     assert (got == ref).mean() > 0.95
+
+
+def test_nvfp4_operands_beyond_2gib_run_as_ranges(q):
+    """[r3] matmul_nvf4_bf16_tn with an A operand (then a B operand) of >= 2 GiB: 262400 x 16384 fp4 = 2.15 GB, e4m3 scales per
+    16.  The reference passes 64-bit strides to CUTLASS (qutlass/csrc/gemm.cu:90-143); here the operand runs as ranges of whole
+    256-row tiles.  Rows / columns at the start, on both sides of the range boundary (261888) and at the end, against the oracle."""
+    from qutlass_amd.utils import to_blocked
+
+    e4 = torch.float8_e4m3fn
+    edge = [0, 1, 255, 256, 131071, 261887, 261888, 261889, 262143, 262144, 262399]
+    for big_a in (True, False):
+        m, n, k = (262400, 256, 16384) if big_a else (48, 262400, 16384)
+        g = torch.Generator(device=DEV).manual_seed(21 + int(big_a))
+        a = torch.randint(0, 256, (m, k // 2), dtype=torch.uint8, device=DEV, generator=g)
+        b = torch.randint(0, 256, (n, k // 2), dtype=torch.uint8, device=DEV, generator=g)
+        a_s = torch.randint(0x30, 0x40, (m, k // 16), dtype=torch.uint8, device=DEV, generator=g)   # e4m3 0.5 .. 1.875
+        b_s = torch.randint(0x30, 0x40, (n, k // 16), dtype=torch.uint8, device=DEV, generator=g)
+        out = q.matmul_nvf4_bf16_tn(a, b, to_blocked(a_s.view(e4)), to_blocked(b_s.view(e4)), torch.tensor([1.0], device=DEV))
+        assert out.shape == (m, n)
+        idx = torch.tensor(edge, device=DEV)
+        if big_a:
+            ref = oracle.gemm_blockscaled(oracle.KIND_NVFP4, _np(a[idx]), _np(b), oracle.to_blocked(_np(a_s[idx])), oracle.to_blocked(_np(b_s)), 1.0, len(edge), n, k)
+            got = _np(out[idx])
+        else:
+            ref = oracle.gemm_blockscaled(oracle.KIND_NVFP4, _np(a), _np(b[idx]), oracle.to_blocked(_np(a_s)), oracle.to_blocked(_np(b_s[idx])), 1.0, m, len(edge), k)
+            got = _np(out[:, idx])
+        gf, rf = oracle.bf16_bits_to_f32(got).astype(np.float64), oracle.bf16_bits_to_f32(ref).astype(np.float64)
+        assert (np.abs(gf - rf) <= np.abs(rf) / 128.0 + 1e-6 * np.abs(rf).max()).all(), big_a
+        assert (got == ref).mean() > 0.95, big_a
+        del a, b, a_s, b_s, out
+
+
+def test_mxf8_nn_operand_beyond_2gib_takes_the_relayout_path(q):
+    """[r3] matmul_mxf8_bf16_nn with a (K, M) operand of >= 2 GiB (16384 x 131328 e4m3 = 2.15 GB): the in-place path addresses it with
+    32-bit offsets, so the op re-lays it as (M, K) into scratch and runs the TN dispatch as row ranges.  Must equal the TN op on
+    the transposed copy bit for bit, and the oracle on sampled rows."""
+    from qutlass_amd.utils import to_blocked
+
+    m, n, k = 131328, 256, 16384
+    g = torch.Generator(device=DEV).manual_seed(31)
+    at = torch.randint(0, 256, (k, m), dtype=torch.uint8, device=DEV, generator=g)
+    at = torch.where((at & 0x7f) == 0x7f, at & 0x80, at)                      # no e4m3 NaN
+    b = torch.randint(0, 256, (n, k), dtype=torch.uint8, device=DEV, generator=g)
+    b = torch.where((b & 0x7f) == 0x7f, b & 0x80, b)
+    a_s = torch.randint(124, 131, (m, k // 32), dtype=torch.uint8, device=DEV, generator=g)
+    b_s = torch.randint(124, 131, (n, k // 32), dtype=torch.uint8, device=DEV, generator=g)
+    e8, e4 = torch.float8_e8m0fnu, torch.float8_e4m3fn
+    asf, bsf, al = to_blocked(a_s.view(e8)), to_blocked(b_s.view(e8)), torch.tensor([1.0], device=DEV)
+    out_nn = q.matmul_mxf8_bf16_nn(at.view(e4), b.view(e4), asf, bsf, al)
+    a = at.T.contiguous()
+    out_tn = q.matmul_mxf8_bf16_tn(a.view(e4), b.view(e4), asf, bsf, al)
+    assert out_nn.shape == (m, n) and torch.equal(out_nn.view(torch.int16), out_tn.view(torch.int16))
+    rows = [0, 255, 256, 65535, 131071, 131072, 131327]
+    ri = torch.tensor(rows, device=DEV)
+    ref = oracle.gemm_blockscaled(oracle.KIND_MXFP8_TN, _np(a[ri]), _np(b), oracle.to_blocked(_np(a_s[ri])), oracle.to_blocked(_np(b_s)), 1.0, len(rows), n, k)
+    assert _mxfp8_close(_np(out_nn[ri]), ref).all()
