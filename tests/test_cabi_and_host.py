@@ -158,7 +158,7 @@ def test_auto_dispatch_rules_dry_run(lib):
     # an A operand of >= 2 GiB (262400 x 16384 fp4 = 2.15 GB) runs as two row ranges of whole 256-row tiles
     assert plan(4, 262400, 256, 16384) == [(DEEPP, 256, 1), (RING64, 256, 1)]   # 261888 rows, then the last 512
     # ... and a B operand of >= 2 GiB (262400 x 16384 fp4 weight) as two column ranges of whole 256-column tiles writing one D
-    assert plan(4, 16, 262400, 16384) == [(28, 261888, 1), (RING64, 512, 1)]
+    assert plan(4, 16, 262400, 16384) == [(28, 261888, 1), (SKINNY, 512, 1)]   # [r3] the split-K kernel writes a column range too (row stride ldd)
     assert plan(4, 4096, 262400, 16384) == [(DEEPP, 261888, 1), (71, 512, 1)]
     # rejected arguments never reach the dispatch
     assert plan(4, 128, 128, 96) is None and plan(5, 128, 128, 128) is None
