@@ -115,9 +115,14 @@ __global__ __launch_bounds__(NWAVES * 64) void gemm_mx_fusedq_kernel(const Fused
       // y[4q+e] = (x_g . h)[row i32][8q + 4 g + e]       (quantize.hip.h, same operand layout)
       float scale;
       if (METHOD == METHOD_ABSMAX) {
-        float m = 0.f;
+        // max is order-independent: a depth-4 tree instead of a 16-long dependent chain (this kernel runs two waves per SIMD, so
+        // nothing else hides the chain's latency)
+        float t8[8], t4[4];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) m = fmaxf(m, fabsf(y[r]));
+        for (int r = 0; r < 8; ++r) t8[r] = fmaxf(fabsf(y[2 * r]), fabsf(y[2 * r + 1]));
+#pragma unroll
+        for (int r = 0; r < 4; ++r) t4[r] = fmaxf(t8[2 * r], t8[2 * r + 1]);
+        float m = fmaxf(fmaxf(t4[0], t4[1]), fmaxf(t4[2], t4[3]));
         m = xhalf_max(m);
         scale = m + 1e-8f;
       } else {

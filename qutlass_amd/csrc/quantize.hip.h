@@ -162,11 +162,16 @@ __global__ __launch_bounds__(256) void fused_quantize_kernel(const QuantParams p
     // zero padding of the blocked layout (rows up to a multiple of 128, columns up to a multiple of 4), as to_blocked writes it
     const uint32_t prow = ((uint32_t)p.sf_rows + 127u) & ~127u, pcol = sfCB * 4u;
     const uint32_t n1 = (prow - (uint32_t)p.sf_rows) * pcol, cpad = pcol - (uint32_t)p.sf_cols, n2 = (uint32_t)p.sf_rows * cpad;
-    for (uint32_t i = blockIdx.x * 256u + tid; i < n1 + n2; i += gridDim.x * 256u) {
-      uint32_t r, c;
-      if (i < n1) { r = (uint32_t)p.sf_rows + i / pcol; c = i % pcol; }
-      else { const uint32_t j = i - n1; r = j / cpad; c = (uint32_t)p.sf_cols + j % cpad; }
-      p.out_sf[blocked_sf_offset(r, c, sfCB)] = 0;
+    // padding rows: one dword (the four columns of a column tile) per store; padding columns of real rows: bytes
+    const uint32_t nd = n1 >> 2;
+    for (uint32_t i = blockIdx.x * 256u + tid; i < nd + n2; i += gridDim.x * 256u) {
+      if (i < nd) {
+        const uint32_t r = (uint32_t)p.sf_rows + i / sfCB, cb = i % sfCB;
+        *(uint32_t*)(p.out_sf + blocked_sf_offset(r, 4u * cb, sfCB)) = 0u;
+      } else {
+        const uint32_t j = i - nd, r = j / cpad, c = (uint32_t)p.sf_cols + j % cpad;
+        p.out_sf[blocked_sf_offset(r, c, sfCB)] = 0;
+      }
     }
   }
 

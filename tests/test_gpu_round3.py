@@ -69,8 +69,9 @@ def test_fused_quantize_mx_blocked_equals_two_step_path(q, shape, rot, method):
     want = to_blocked(s_flat.view(torch.uint8).reshape(-1)[: rows * (k // 32)].reshape(rows, k // 32))
     assert s_blk.dtype == torch.float8_e8m0fnu and s_blk.dim() == 1 and s_blk.numel() == want.numel()
     assert torch.equal(s_blk.view(torch.uint8), want.view(torch.uint8))
-    # ... and against the oracle's own two steps on the same input
-    _, rs, _ = oracle.fused_quantize_mx(_np(x), _np(h), oracle.QUEST if method == "quest" else oracle.ABS_MAX)
+    # ... and against the oracle's own two steps on the same input (Quest statistics in the kernel's summation order, acc_model 2: on 16 M
+    # elements the reference's sequential 32-term sum differs in a handful of scale bytes -- test_quest_scale_bytes_at_binade_boundaries)
+    _, rs, _ = oracle.fused_quantize_mx(_np(x), _np(h), oracle.QUEST if method == "quest" else oracle.ABS_MAX, acc_model=2)
     assert np.array_equal(_np(s_blk), oracle.to_blocked(rs.reshape(rows, k // 32)))
 
 
@@ -204,7 +205,7 @@ def test_hetero_launch_mxfp8_matches_persistent_and_oracle(q, e5m2):
     alpha = torch.tensor([1.0], device=DEV)
     got = q.matmul_mxf8_bf16_tn(ad, bd, asf, bsf, alpha)          # auto: the heterogeneous launch (tests/test_cabi_and_host.py pins the plan)
     rows = _sample(m, 32, seed=2)
-    kind = 4 if e5m2 else oracle.KIND_MXFP8
+    kind = oracle.KIND_MXFP8_TN_A5 if e5m2 else oracle.KIND_MXFP8_TN
     ref = _oracle_rows(kind, a, b, sa, sb, 1.0, rows, n, k)
     g = oracle.bf16_bits_to_f32(_np(got[torch.tensor(rows, device=DEV)])).astype(np.float64)
     w = oracle.bf16_bits_to_f32(ref).astype(np.float64)
@@ -242,7 +243,7 @@ def test_quest_scale_bytes_at_binade_boundaries(q):
     sc = np.sqrt(np.maximum((xs ** 2).mean(1) - xs.mean(1) ** 2, 0)) * c + 1e-8
     frac = np.abs(sc / 2.0 ** np.round(np.log2(sc)) - 1.0)
     near = float((frac < 2.0 ** -10).mean())
-    assert near > 0.2, near
+    assert near > 0.1, near   # (one in seven groups by construction: jitter 0 of -3 .. 3 steps of 2^-9)
     assert np.array_equal(got, want), f"{int((got != want).sum())} of {ngroups} e8m0 bytes differ from the oracle (kernel summation order)"
     _, seq, _ = oracle.fused_quantize_mx(_np(xt), _np(eye), oracle.QUEST, acc_model=0)
     rate = float((got != seq).mean())
