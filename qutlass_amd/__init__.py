@@ -143,16 +143,17 @@ def fusedQuantizeNvBlocked(a: torch.Tensor, b: torch.Tensor, global_scale: torch
 
 
 def fused_quantize_matmul_mxf4_bf16_tn(x: torch.Tensor, h: torch.Tensor, b: torch.Tensor, b_sf: torch.Tensor, alpha: torch.Tensor, *,
-                                       method: Literal["quest", "abs_max"] = "abs_max") -> torch.Tensor:
+                                       method: Literal["quest", "abs_max"] = "abs_max", single_launch: bool = False) -> torch.Tensor:
     """EXTENSION: ``matmul_mxf4_bf16_tn(*fusedQuantizeMxBlocked(x, h, method=method), b, b_sf, alpha)`` -- the activation path of one
-    linear layer (qutlass/__init__.py:149-180 -> qutlass/utils.py:160-193 -> qutlass/__init__.py:34-76).  Decode batches (at most
-    32 rows, 32 x 32 rotation) run as ONE launch in which the small-batch GEMM quantises its own A operand
-    (csrc/gemm_mx_fusedq.hip.h); everything else takes the two-launch path.  Same bits either way."""
+    linear layer (qutlass/__init__.py:149-180 -> qutlass/utils.py:160-193 -> qutlass/__init__.py:34-76) in TWO launches instead of
+    three: the quantizer writes GEMM-ready scales (M = 16, N = K = 4096: 8.2 us against 10.1 us, GEMM alone 5.3 us;
+    profiles/ab_blocked_quant_r3.txt).  ``single_launch=True`` (at most 32 rows, 32 x 32 rotation) runs the one-launch kernel in
+    which the small-batch GEMM quantises its own A operand (csrc/gemm_mx_fusedq.hip.h) -- same bits, but measured SLOWER than the
+    two launches (10.9 us at M = 16: every workgroup repeats the rotate + quantize chain of its K slices), so it is not the default."""
     if method not in _METHOD_CODE:
         raise ValueError(f"invalid method {method!r}, must be 'quest' or 'abs_max'")
     k = x.size(-1)
-    m = x.numel() // k if k else 0
-    if 0 < m <= 32 and h.size(0) == 32 and b.size(0) < 8192:
+    if single_launch:
         out = torch.ops.qutlass_amd.fusedQuantizeMatmulMxf4(x, h, b, b_sf, alpha, _METHOD_CODE[method])
         return out.view(*x.shape[:-1], b.size(0))
     a_q, a_sf = fusedQuantizeMxBlocked(x, h, method=method)

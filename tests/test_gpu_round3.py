@@ -311,7 +311,9 @@ def test_fused_quantize_matmul_decode_equals_three_launch_path(q, m, n, k, metho
     for hw in (1, 0):
         q._lib.set_option("hw_fp4_cvt", hw)
         try:
-            got = q.fused_quantize_matmul_mxf4_bf16_tn(x, h, w_q, w_sf, alpha, method=method)
+            got = q.fused_quantize_matmul_mxf4_bf16_tn(x, h, w_q, w_sf, alpha, method=method, single_launch=True)
+            two = q.fused_quantize_matmul_mxf4_bf16_tn(x, h, w_q, w_sf, alpha, method=method)   # default: blocked quantizer + GEMM
+            assert torch.equal(two.view(torch.int16), want.view(torch.int16))
         finally:
             q._lib.set_option("hw_fp4_cvt", 1)
         assert got.shape == (m, n) and got.dtype == torch.bfloat16
@@ -331,13 +333,14 @@ def test_fused_quantize_matmul_wrapper_dispatch_and_errors(q):
     w_q, w_s = q.fusedQuantizeMx(w, h, method="abs_max")
     w_sf = to_blocked(w_s)
     alpha = torch.tensor([1.0], device=DEV)
-    # leading batch dimensions are flattened; M = 2 * 8 = 16 -> one launch
+    # leading batch dimensions are flattened; M = 2 * 8 = 16
     x = torch.randn(2, 8, k, dtype=torch.bfloat16, device=DEV)
-    got = q.fused_quantize_matmul_mxf4_bf16_tn(x, h, w_q, w_sf, alpha)
+    got = q.fused_quantize_matmul_mxf4_bf16_tn(x, h, w_q, w_sf, alpha, single_launch=True)
+    assert torch.equal(got, q.fused_quantize_matmul_mxf4_bf16_tn(x, h, w_q, w_sf, alpha))
     a_q, a_sf = q.fusedQuantizeMxBlocked(x, h, method="abs_max")
     want = q.matmul_mxf4_bf16_tn(a_q.view(-1, k // 2), w_q, a_sf, w_sf, alpha)
     assert got.shape == (2, 8, n) and torch.equal(got.view(-1, n).view(torch.int16), want.view(torch.int16))
-    # M = 48 > 32: the wrapper takes the two-launch path, same bits as the reference flow
+    # M = 48: the default two-launch path, same bits as the reference flow (the one-launch kernel rejects M > 32, below)
     x2 = torch.randn(48, k, dtype=torch.bfloat16, device=DEV)
     got2 = q.fused_quantize_matmul_mxf4_bf16_tn(x2, h, w_q, w_sf, alpha, method="quest")
     b_q, b_s = q.fusedQuantizeMx(x2, h, method="quest")
