@@ -191,13 +191,13 @@ inline int deepp_grid(int tiles) {
 }
 
 // persistent deep schedule (gemm_mx_deepp.hip.h): one workgroup per CU walks the tiles; 136 KiB of static LDS
-template <class C, bool TRACE = false, int ST_AUX = 0>
+template <class C, bool TRACE = false, int ST_AUX = 0, int LAB = 0>
 int launch_gemm_deepp(GemmParams p, hipStream_t s) {
   p.tiles_m = (int)cdiv(p.M, C::BM);
   p.tiles_n = (int)cdiv(p.N, C::BN);
   p.ws = nullptr; p.splits = 1; p.ctr = nullptr; p.tag = 0;
   const int grid = deepp_grid(p.tiles_m * p.tiles_n);
-  hipLaunchKernelGGL((gemm_mx_deepp_kernel<C, TRACE, ST_AUX>), dim3(grid), dim3(C::THREADS), 0, s, p);
+  hipLaunchKernelGGL((gemm_mx_deepp_kernel<C, TRACE, ST_AUX, LAB>), dim3(grid), dim3(C::THREADS), 0, s, p);
   return check_launch("gemm_mx_deepp_kernel");
 }
 
@@ -354,6 +354,11 @@ int dispatch_variant(int v, const GemmParams& p, hipStream_t s, const char* name
     if (v == 94) return launch_gemm_deepp<GemmCfg<256, 256, 2, 2, 4, false>, false, 0>(p, s);       //   default (write-back) policy
     if (v == 95) return launch_gemm_deepp<GemmCfg<256, 256, 2, 2, 4, false>, false, 19>(p, s);      //   sc0 sc1 nt
     if (v == 96) return launch_gemm_deepp<GemmCfg<256, 256, 2, 2, 4, false>, false, 1>(p, s);       //   sc0
+    // timing experiments that change the result (gemm_mx_deepp.hip.h LAB): 97 = no alpha multiply, 197 = half of the stores one stage early, 297 = both
+    if (v == 97) return launch_gemm_deepp<GemmCfg<256, 256, 2, 2, 4, false>, false, 17, 1>(p, s);
+    if (v == 197) return launch_gemm_deepp<GemmCfg<256, 256, 2, 2, 4, false>, false, 17, 2>(p, s);
+    if (v == 297) return launch_gemm_deepp<GemmCfg<256, 256, 2, 2, 4, false>, false, 17, 3>(p, s);
+    if (v == 397) return launch_gemm_deepp<GemmCfg<256, 256, 2, 2, 4, false>, false, 17, 4>(p, s);   //   half of the tile is never stored (accumulators kept alive)
     switch (v) {
       case 6: return launch_gemm<GemmCfg<256, 256, 2, 4, 4, false>, 2>(p, s);
       case 7: return launch_gemm<GemmCfg<128, 128, 2, 2, 4, false>, 2>(p, s);

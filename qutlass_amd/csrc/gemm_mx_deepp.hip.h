@@ -47,7 +47,14 @@ constexpr int deepp_pair_done_at(int s) { return (s >= 3 && s <= 59 && (s - 3) %
 // bid / G: this workgroup's id among the G persistent workgroups; ntiles: the tiles they walk (tiles 0 .. ntiles-1 of the grouped
 // raster).  A plain launch passes blockIdx.x / gridDim.x / all tiles; the heterogeneous launch (gemm_mx_hetero_kernel, end of this
 // file) gives the persistent workgroups the full rounds and runs the residual tiles as 128x128 tiles on other workgroups.
-template <class C, bool TRACE = false, int ST_AUX = 0>
+// LAB (lab build only; 0 in the product): timing experiments that change the RESULT and exist to price an idea before it is built --
+//   bit 0: no alpha multiply in the retirement (an alpha == 1 specialisation would save 4 v_pk_mul_f32 per store)
+//   bit 2: the last stage retires only HALF of the tile (the pairs of m = 2, 3); the other accumulators are kept alive but never stored:
+//          prices the store burst itself (time of the kernel with 16 MiB instead of 32 MiB of output at 4096^3)
+//   bit 1: "spread" ablation (needs two copies of the stage code and spills -- 1.5 KB of scratch, 183 us: not usable, kept for the record): half of the tile's output stores (the pairs of m = 0, 1, zero data) are issued one stage EARLY, threaded
+//          through the second half of stage KTe-2, and the last stage retires only the other half -- what a two-stage
+//          accumulator-stationary window could gain at best by overlapping the 32 MiB store burst with more MFMA work
+template <class C, bool TRACE = false, int ST_AUX = 0, int LAB = 0>
 __device__ __forceinline__ void gemm_mx_deepp(char* smem, const GemmParams& p, const int bid, const int G, const int ntiles) {
   static_assert(C::EBITS == 4 && C::BM == 256 && C::BN == 256 && C::WAVES_M == 2 && C::WAVES_N == 2 && C::NSTAGE == 2 && C::PPW == 2,
                 "persistent deep schedule: fp4, 256x256 tiles, 4 waves of 128x128");
@@ -102,6 +109,9 @@ __device__ __forceinline__ void gemm_mx_deepp(char* smem, const GemmParams& p, c
   v16f acc[MT][NT];
   v4i fa[4][MT] = {}, fb[4][NT] = {};
   int sa[2][MT], sb[2][NT];
+  // output addressing of the current tile, mirrored for the spread ablation (set_out_tile keeps both in step)
+  __amdgpu_buffer_rsrc_t est_rD = make_rsrc(p.D, 0);
+  int est_lane = 0, est_colLim = 0;
 
   auto read_slice = [&](const int buf, const int j) __attribute__((always_inline)) {
     const char* st = smem + buf * STAGE;
@@ -182,9 +192,15 @@ __device__ __forceinline__ void gemm_mx_deepp(char* smem, const GemmParams& p, c
 
   // ---- one K stage (not the last of its tile).  Entry: fragment sets 0, 1 and scale set BUF hold slices 0, 1 of this
   //      stage; exit: the same for the next stage (other buffer).  The DMA threaded through M(2) is stage (d, ktl).
-  auto stage = [&](auto bufc, auto firstc, const Desc& d, int ktl, bool dvalid) __attribute__((always_inline)) {
+  // (defined below; the spread ablation calls it from the stage before the last)
+  auto early_store = [&](const int m, const int h, const int pass) __attribute__((always_inline)) {
+    const int off = est_lane + ((32 * m + 8 * pass) * p.ldd + 64 * h) * 2;
+    __builtin_amdgcn_raw_buffer_store_b128(v4u{0u, 0u, 0u, 0u}, est_rD, (64 * h < est_colLim) ? off : (int)0x80000000, 0, ST_AUX);
+  };
+  auto stage = [&](auto bufc, auto firstc, const Desc& d, int ktl, bool dvalid, auto earlyc) __attribute__((always_inline)) {
     constexpr int BUF = decltype(bufc)::value;
     constexpr bool FIRST = decltype(firstc)::value;
+    constexpr bool EARLY = decltype(earlyc)::value;
     read_slice(BUF, 2); fence();
     mfma_all(0, BUF, FIRST); fence();
     read_slice(BUF, 3); fence();
@@ -208,7 +224,20 @@ __device__ __forceinline__ void gemm_mx_deepp(char* smem, const GemmParams& p, c
         ++idx;
       }
     read_slice(BUF ^ 1, 1); fence();
-    mfma_all(3, BUF, false); fence();
+    if constexpr (EARLY) {
+      int e = 0;
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+          mfma1(3, BUF, m, n, false);
+          early_store(e / 8, (e / 4) % 2, e % 4);   // pairs (m = 0, 1) x (h = 0, 1), four passes each
+          fence();
+          ++e;
+        }
+    } else {
+      mfma_all(3, BUF, false); fence();
+    }
     if constexpr (FIRST) pin_acc();
   };
 
@@ -232,6 +261,7 @@ __device__ __forceinline__ void gemm_mx_deepp(char* smem, const GemmParams& p, c
     rD = make_rsrc(p.D + ((int64_t)m0 * p.ldd + n0), (uint32_t)(left > 0x7fffffffll ? 0x7fffffffll : left));
     stLane = ((cx.wave_m * C::WTM + rrl) * p.ldd + cx.wave_n * C::WTN + 8 * ccl) * 2;
     colLim = p.N - n0 - cx.wave_n * C::WTN - 8 * ccl;   // column 64 h + 8 ccl of the wave tile exists iff 64 h < colLim
+    if constexpr (LAB & 2) { est_rD = rD; est_lane = stLane; est_colLim = colLim; }
   };
   auto retire_write = [&](const int m, const int h) __attribute__((always_inline)) {
 #pragma unroll
@@ -252,10 +282,14 @@ __device__ __forceinline__ void gemm_mx_deepp(char* smem, const GemmParams& p, c
   auto retire_store = [&](const int m, const int h, const int pass) __attribute__((always_inline)) {
     const v4f lo = rb[pass & 1][0], hi = rb[pass & 1][1];
     v4i o;
+    if constexpr (LAB & 1) {
+      o[0] = (int)pack_bf16x2(lo[0], lo[1]); o[1] = (int)pack_bf16x2(lo[2], lo[3]); o[2] = (int)pack_bf16x2(hi[0], hi[1]); o[3] = (int)pack_bf16x2(hi[2], hi[3]);
+    } else {
     o[0] = (int)pack_bf16x2(lo[0] * alpha, lo[1] * alpha);
     o[1] = (int)pack_bf16x2(lo[2] * alpha, lo[3] * alpha);
     o[2] = (int)pack_bf16x2(hi[0] * alpha, hi[1] * alpha);
     o[3] = (int)pack_bf16x2(hi[2] * alpha, hi[3] * alpha);
+    }
     const int off = stLane + ((32 * m + 8 * pass) * p.ldd + 64 * h) * 2;
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, o), rD, (64 * h < colLim) ? off : (int)0x80000000, 0, ST_AUX);
   };
@@ -296,13 +330,17 @@ __device__ __forceinline__ void gemm_mx_deepp(char* smem, const GemmParams& p, c
       if constexpr (s == 60) { read_fa(0, 0, 3); read_fa(0, 1, 3); read_fb(0, 0, 3); read_fb(0, 1, 3); }
       // retirement items due in this slot (pair P final at e = 8 P + 3)
       constexpr int d1 = s - 1, d3 = s - 3, d5 = s - 5, d6 = s - 6, d7 = s - 7, d9 = s - 9, d10 = s - 10;
-      if constexpr (deepp_pair_done_at(d5) >= 0) retire_store(deepp_pair_done_at(d5) / 2, deepp_pair_done_at(d5) % 2, 0);
-      if constexpr (deepp_pair_done_at(d6) >= 0) retire_store(deepp_pair_done_at(d6) / 2, deepp_pair_done_at(d6) % 2, 1);
-      if constexpr (deepp_pair_done_at(d9) >= 0) retire_store(deepp_pair_done_at(d9) / 2, deepp_pair_done_at(d9) % 2, 2);
-      if constexpr (deepp_pair_done_at(d10) >= 0) retire_store(deepp_pair_done_at(d10) / 2, deepp_pair_done_at(d10) % 2, 3);
-      if constexpr (deepp_pair_done_at(d1) >= 0) retire_write(deepp_pair_done_at(d1) / 2, deepp_pair_done_at(d1) % 2);
-      if constexpr (deepp_pair_done_at(d3) >= 0) retire_read(0);
-      if constexpr (deepp_pair_done_at(d7) >= 0) retire_read(1);
+      constexpr int PMIN = (LAB & 6) ? 4 : 0;   // ablations: the pairs of m = 0, 1 are not retired here (bit 1: "stored" one stage earlier; bit 2: never)
+      if constexpr ((LAB & 4) && deepp_pair_done_at(d1) >= 0 && deepp_pair_done_at(d1) < 4) {   // ... but their accumulators (and MFMAs) stay alive
+        asm volatile("" ::"a"(acc[deepp_pair_done_at(d1) / 2][2 * (deepp_pair_done_at(d1) % 2)]), "a"(acc[deepp_pair_done_at(d1) / 2][2 * (deepp_pair_done_at(d1) % 2) + 1]));
+      }
+      if constexpr (deepp_pair_done_at(d5) >= PMIN) retire_store(deepp_pair_done_at(d5) / 2, deepp_pair_done_at(d5) % 2, 0);
+      if constexpr (deepp_pair_done_at(d6) >= PMIN) retire_store(deepp_pair_done_at(d6) / 2, deepp_pair_done_at(d6) % 2, 1);
+      if constexpr (deepp_pair_done_at(d9) >= PMIN) retire_store(deepp_pair_done_at(d9) / 2, deepp_pair_done_at(d9) % 2, 2);
+      if constexpr (deepp_pair_done_at(d10) >= PMIN) retire_store(deepp_pair_done_at(d10) / 2, deepp_pair_done_at(d10) % 2, 3);
+      if constexpr (deepp_pair_done_at(d1) >= PMIN) retire_write(deepp_pair_done_at(d1) / 2, deepp_pair_done_at(d1) % 2);
+      if constexpr (deepp_pair_done_at(d3) >= PMIN) retire_read(0);
+      if constexpr (deepp_pair_done_at(d7) >= PMIN) retire_read(1);
       fence();
     });
     // the wave's own A pieces of the next tile's stage 1 overwrite its scratch: its read-backs must have returned first
@@ -310,6 +348,7 @@ __device__ __forceinline__ void gemm_mx_deepp(char* smem, const GemmParams& p, c
 #pragma unroll
     for (int i = 0; i < 8; ++i) dma_item(d, 1, 1, i);
     fence();
+    if constexpr (LAB & 2) pin_acc();   // the accumulators the ablation does not retire must stay live, or their MFMAs are eliminated
   };
 
   // ---- prologue: first tile's stages 0 and 1 in flight; stage 0 landed -> first two slices into registers ---------------
@@ -342,14 +381,19 @@ __device__ __forceinline__ void gemm_mx_deepp(char* smem, const GemmParams& p, c
       const bool tonext = KTe == 2;
       Desc d;
       d.a = tonext ? nxt.a : cur.a; d.b = tonext ? nxt.b : cur.b; d.s = tonext ? nxt.s : cur.s;
-      stage(I0{}, BT{}, d, tonext ? 0 : 2, tonext ? nvalid : true);
+      stage(I0{}, BT{}, d, tonext ? 0 : 2, tonext ? nvalid : true, BF{});
     }
     for (int kt = 1; kt + 2 < KTe; kt += 2) {
-      stage(I1{}, BF{}, cur, kt + 2, true);
+      stage(I1{}, BF{}, cur, kt + 2, true, BF{});
       const bool tonext = kt + 3 == KTe;
       Desc d;
       d.a = tonext ? nxt.a : cur.a; d.b = tonext ? nxt.b : cur.b; d.s = tonext ? nxt.s : cur.s;
-      stage(I0{}, BF{}, d, tonext ? 0 : kt + 3, tonext ? nvalid : true);
+      if constexpr (LAB & 2) {
+        if (tonext) stage(I0{}, BF{}, d, 0, nvalid, BT{});
+        else stage(I0{}, BF{}, d, kt + 3, true, BF{});
+      } else {
+        stage(I0{}, BF{}, d, tonext ? 0 : kt + 3, tonext ? nvalid : true, BF{});
+      }
     }
     trace();
     final_stage(nxt, nvalid);
@@ -726,10 +770,10 @@ __global__ __launch_bounds__(C::THREADS) void gemm_mx_deepp8_kernel(const GemmPa
   gemm_mx_deepp8<C, ST_AUX, NN, NNABL>(smem, p, (int)blockIdx.x, (int)gridDim.x, p.tiles_m * p.tiles_n);
 }
 
-template <class C, bool TRACE = false, int ST_AUX = 0>
+template <class C, bool TRACE = false, int ST_AUX = 0, int LAB = 0>
 __global__ __launch_bounds__(C::THREADS) void gemm_mx_deepp_kernel(const GemmParams p) {
   __shared__ __attribute__((aligned(16))) char smem[DeepPCfg<C>::LDS_BYTES];
-  gemm_mx_deepp<C, TRACE, ST_AUX>(smem, p, (int)blockIdx.x, (int)gridDim.x, p.tiles_m * p.tiles_n);
+  gemm_mx_deepp<C, TRACE, ST_AUX, LAB>(smem, p, (int)blockIdx.x, (int)gridDim.x, p.tiles_m * p.tiles_n);
 }
 
 // -------------------------------------------------------------------------------------------------------------------------

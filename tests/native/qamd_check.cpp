@@ -649,6 +649,19 @@ int main(int argc, char** argv) {
     }
     g_gauss_fill = 0;
   }
+  if (want("spread")) {   // [r3] timing-only ablations of the persistent kernel (results wrong by construction): 97 = no alpha multiply, 197 = half of the output
+                           // stores issued one stage early (what a two-stage accumulator-stationary window could gain at best), 297 = both; QAMD_STEADY_MS=30
+    g_gauss_fill = 1;
+    struct Sh { int64_t M, N, K; };
+    for (int rep = 0; rep < 3; ++rep)
+      for (const Sh& sh : {Sh{4096, 4096, 4096}, Sh{4096, 14336, 4096}, Sh{8192, 8192, 8192}})
+        for (int var : {90, 97, 397}) {
+          char tag[96];
+          snprintf(tag, sizeof tag, "mxfp4 variant %d %lldx%lldx%lld", var, (long long)sh.M, (long long)sh.N, (long long)sh.K);
+          bench_gemm(tag, 0, sh.M, sh.N, sh.K, var, 60);
+        }
+    g_gauss_fill = 0;
+  }
   if (want("deepptrace")) {   // phase timeline of workgroup 0 of the persistent deep kernel (variant 91), in the steady state
     struct Sh { int64_t M, N, K; };
     for (const Sh& sh : {Sh{4096, 4096, 4096}, Sh{4096, 12288, 4096}, Sh{8192, 8192, 8192}}) {
