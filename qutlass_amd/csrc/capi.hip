@@ -1082,13 +1082,19 @@ int qutlass_amd_fused_quantize_matmul_mxf4_bf16_tn(const void* x, const void* h,
   const dim3 grid((unsigned)cdiv(N, 32), 1), block(512);
   hipStream_t s = (hipStream_t)stream;
   const bool hw = g_hw_fp4_cvt.load() != 0;
+  // rows per rotation tile: the smallest of 4 / 8 / 16 / 32 that holds the batch (fewer rows = more scale groups per tile = fewer
+  // rotate + quantize chains per K segment, gemm_mx_fusedq.hip.h)
+  const int vr = M <= 4 ? 4 : M <= 8 ? 8 : M <= 16 ? 16 : 32;
+#define QAMD_FQ(METH_, HW_, VR_) hipLaunchKernelGGL((gemm_mx_fusedq_kernel<METH_, HW_, VR_>), grid, block, 0, s, p)
+#define QAMD_FQ_VR(METH_, HW_) \
+  switch (vr) { case 4: QAMD_FQ(METH_, HW_, 4); break; case 8: QAMD_FQ(METH_, HW_, 8); break; case 16: QAMD_FQ(METH_, HW_, 16); break; default: QAMD_FQ(METH_, HW_, 32); }
   if (method == QAMD_METHOD_ABSMAX) {
-    if (hw) hipLaunchKernelGGL((gemm_mx_fusedq_kernel<METHOD_ABSMAX, true>), grid, block, 0, s, p);
-    else hipLaunchKernelGGL((gemm_mx_fusedq_kernel<METHOD_ABSMAX, false>), grid, block, 0, s, p);
+    if (hw) { QAMD_FQ_VR(METHOD_ABSMAX, true) } else { QAMD_FQ_VR(METHOD_ABSMAX, false) }
   } else {
-    if (hw) hipLaunchKernelGGL((gemm_mx_fusedq_kernel<METHOD_QUEST, true>), grid, block, 0, s, p);
-    else hipLaunchKernelGGL((gemm_mx_fusedq_kernel<METHOD_QUEST, false>), grid, block, 0, s, p);
+    if (hw) { QAMD_FQ_VR(METHOD_QUEST, true) } else { QAMD_FQ_VR(METHOD_QUEST, false) }
   }
+#undef QAMD_FQ_VR
+#undef QAMD_FQ
   return check_launch("gemm_mx_fusedq_kernel");
 }
 

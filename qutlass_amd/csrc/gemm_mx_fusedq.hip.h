@@ -10,9 +10,9 @@
 // matrix -- 32 x K bf16 -- which costs nothing against a launch; the weight loads of a wave are issued BEFORE the
 // quantisation starts, so the HBM latency of the weight stream hides behind it.
 //
-// Arithmetic = fused_quantize_kernel<32, false, METHOD, false, HWCVT> (same MFMA, same operand layout, same reduction order)
-// followed by gemm_mx_skinny_kernel (same K split, same reduction): the output is bit-identical to the three-launch path
-// (tests/test_gpu_round3.py).
+// Arithmetic = fused_quantize_kernel<32, false, METHOD, false, HWCVT> (same MFMA, same operand layout per (row, group), same
+// reduction order) followed by gemm_mx_skinny_kernel (same K split, same reduction): the output is bit-identical to the
+// three-launch path (tests/test_gpu_round3.py).
 #pragma once
 #include "gemm_mx_skinny.hip.h"
 #include "quantize.hip.h"
@@ -30,11 +30,25 @@ struct FusedQParams {
   uint32_t x_bytes, b_bytes, sfb_bytes;
 };
 
-template <int METHOD, bool HWCVT, int NWAVES = 8>
+// VR = activation rows per rotation tile (4, 8, 16 or 32 >= M).  The bf16 MFMA that rotates the activations always works on 32
+// "rows"; with fewer real rows a tile takes 32 / VR scale groups of each row instead (virtual row v = r * (32 / VR) + G'), so a
+// 256-element K segment of the activations costs 8 / (32 / VR) rotate + quantize chains instead of 8 -- at M <= 4 ONE chain per
+// segment.  (The chain, ~250 VALU instructions that every workgroup repeats, is what the first version of this kernel -- lane = row,
+// 8 chains per segment whatever M -- lost against two separate launches: 10.9 vs 8.2 us at M = 16, profiles/ab_blocked_quant_r3.txt.)
+// The codes and scale bytes of a segment go through a wave-private LDS tile [row][group][16 bytes] and come back in the operand
+// layout of the scaled FP4 MFMA: lane (row, g) reads the 16 code bytes of group 4 g + j for k-slice j and the scale dword of
+// groups 4 g .. 4 g + 3; rows >= VR read zeros.
+template <int METHOD, bool HWCVT, int VR, int NWAVES = 8>
 __global__ __launch_bounds__(NWAVES * 64) void gemm_mx_fusedq_kernel(const FusedQParams p) {
+  static_assert(VR == 4 || VR == 8 || VR == 16 || VR == 32, "rows per rotation tile");
+  constexpr int GPS = 32 / VR;          // scale groups of one row per rotation tile
+  constexpr int NPASS = 8 / GPS;        // rotation tiles per 256-element segment
+  constexpr int CROW = 8 * 16 + 16;     // staged code row: 8 groups x 16 bytes + pad
   __shared__ __attribute__((aligned(16))) float part[NWAVES][32][33];
   constexpr int HROW = 32 * 2 + 16;   // padded H^T row stride (bytes), as in quantize.hip.h
   __shared__ __attribute__((aligned(16))) char hT[32 * HROW];
+  __shared__ __attribute__((aligned(16))) char cs_all[NWAVES][VR * CROW];      // codes of one segment: [row][group][16]
+  __shared__ __attribute__((aligned(16))) uint8_t ss_all[NWAVES][VR * 8];      // scale bytes: [row][group]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = uniform(tid >> 6);
   const int i32 = lane & 31, g = lane >> 5;
@@ -42,13 +56,17 @@ __global__ __launch_bounds__(NWAVES * 64) void gemm_mx_fusedq_kernel(const Fused
   const int rowbytes = p.K >> 1;                   // packed B row
   const int nseg = (rowbytes + 127) >> 7;          // 256-element K segments (K % 128 == 0: the last may be half)
   const int KB = p.K >> 5, CB = (KB + 3) >> 2;
+  char* cs = cs_all[wave];
+  uint8_t* ss = ss_all[wave];
 
   const uint32_t b_off = (uint32_t)n0 * rowbytes, x_off = (uint32_t)m0 * (uint32_t)p.K * 2u;
   const __amdgpu_buffer_rsrc_t rB = make_rsrc(p.B + b_off, p.b_bytes - b_off);    // rows past N fall off the end -> 0
   const __amdgpu_buffer_rsrc_t rX = make_rsrc((const uint8_t*)p.x + x_off, p.x_bytes - x_off);   // rows past M -> 0
   const __amdgpu_buffer_rsrc_t rSB = make_rsrc(p.SFB, p.sfb_bytes);
   const int voffB = i32 * rowbytes + g * 64;       // row i32, chunk 4g (+ j)
-  const int voffX = i32 * p.K * 2 + g * 16;        // row i32 of x, bytes 32 kc' + 16 g .. (+ 64 per group)
+  // rotation tile: virtual row i32 = (activation row vr, local group vg); pass ps covers groups ps * GPS + vg
+  const int vr = i32 / GPS, vg = i32 % GPS;
+  const int voffX = vr * p.K * 2 + vg * 64 + g * 16;   // bytes: row vr, group vg, half g (+ 32 per kc, + GPS * 64 per pass, + 512 per segment)
   const int rb = n0 + i32;
   const int soffB = (rb >> 7) * CB * 512 + (rb & 31) * 16 + ((rb & 127) >> 5) * 4 + g * 512;   // + s * 1024: column tile 2s + g
   constexpr int OOB = 0x7f000000;
@@ -65,16 +83,16 @@ __global__ __launch_bounds__(NWAVES * 64) void gemm_mx_fusedq_kernel(const Fused
     }
     sb = __builtin_amdgcn_raw_buffer_load_b32(rSB, (s < nseg && (8 * s + 4 * g) < KB) ? soffB + s * 1024 : OOB, 0, 0);
   };
-  // x of segment s: group G = 0..7 (32 elements = 64 bytes of the row), chunk kc = 0, 1: lane (row, half) takes bytes 32 kc + 16 half .. +16
-  v4i xr[8][2];
+  // activations of segment s: pass ps, chunk kc -> 16 bytes per lane (the X^T operand layout of quantize.hip.h)
+  v4i xr[NPASS][2];
   auto load_x = [&](int s) __attribute__((always_inline)) {
 #pragma unroll
-    for (int G = 0; G < 8; ++G)
+    for (int ps = 0; ps < NPASS; ++ps)
 #pragma unroll
       for (int kc = 0; kc < 2; ++kc) {
-        const int k0 = s * 256 + G * 32;           // first element of the group
-        const int v = (s < nseg && k0 < p.K) ? voffX + G * 64 + kc * 32 : OOB;
-        xr[G][kc] = __builtin_amdgcn_raw_buffer_load_b128(rX, v, s * 512, 0);
+        const int k0 = s * 256 + (ps * GPS + vg) * 32;   // first element of the lane's group
+        const int v = (s < nseg && k0 < p.K) ? voffX + ps * GPS * 64 + kc * 32 : OOB;
+        xr[ps][kc] = __builtin_amdgcn_raw_buffer_load_b128(rX, v, s * 512, 0);
       }
   };
   int s = wave;
@@ -102,21 +120,18 @@ __global__ __launch_bounds__(NWAVES * 64) void gemm_mx_fusedq_kernel(const Fused
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 
   for (; s < nseg; s += NWAVES) {
-    // ---- quantise the 8 groups of this segment: codes o[G] = 8 bytes (bytes 8 g .. 8 g + 7 of the group's 16), scale byte e8[G] ----
-    v2i o[8];
-    uint32_t e8s[8];
+    // ---- rotate + quantise the segment: NPASS tiles of 32 virtual rows; codes (8 bytes per lane) and scale bytes -> LDS ----------
 #pragma unroll
-    for (int G = 0; G < 8; ++G) {
+    for (int ps = 0; ps < NPASS; ++ps) {
       v16f y;
 #pragma unroll
       for (int r = 0; r < 16; ++r) y[r] = 0.f;
 #pragma unroll
-      for (int kc = 0; kc < 2; ++kc) y = __builtin_amdgcn_mfma_f32_32x32x16_bf16(hf[kc], __builtin_bit_cast(v8bf, xr[G][kc]), y, 0, 0, 0);
-      // y[4q+e] = (x_g . h)[row i32][8q + 4 g + e]       (quantize.hip.h, same operand layout)
+      for (int kc = 0; kc < 2; ++kc) y = __builtin_amdgcn_mfma_f32_32x32x16_bf16(hf[kc], __builtin_bit_cast(v8bf, xr[ps][kc]), y, 0, 0, 0);
+      // y[4q+e] = (x_g . h)[virtual row i32][8q + 4 g + e]       (quantize.hip.h, same operand layout)
       float scale;
       if (METHOD == METHOD_ABSMAX) {
-        // max is order-independent: a depth-4 tree instead of a 16-long dependent chain (this kernel runs two waves per SIMD, so
-        // nothing else hides the chain's latency)
+        // max is order-independent: a depth-4 tree instead of a 16-long dependent chain (two waves per SIMD hide little latency)
         float t8[8], t4[4];
 #pragma unroll
         for (int r = 0; r < 8; ++r) t8[r] = fmaxf(fabsf(y[2 * r]), fabsf(y[2 * r + 1]));
@@ -153,27 +168,28 @@ __global__ __launch_bounds__(NWAVES * 64) void gemm_mx_fusedq_kernel(const Fused
       const uint32_t P = e2m1_pack8<HWCVT>(t), Q = e2m1_pack8<HWCVT>(t + 8);
       auto sw = __builtin_amdgcn_permlane32_swap(P, Q, false, false);
       const uint32_t X = sw[0], Y = sw[1];
-      o[G][0] = (int)((X & 0xffffu) | (Y << 16));
-      o[G][1] = (int)((X >> 16) | (Y & 0xffff0000u));
-      e8s[G] = e8;
+      v2i o;   // bytes 8 g .. 8 g + 7 of the group's 16 code bytes
+      o[0] = (int)((X & 0xffffu) | (Y << 16));
+      o[1] = (int)((X >> 16) | (Y & 0xffff0000u));
+      const int G = ps * GPS + vg;
+      *(v2i*)(cs + vr * CROW + G * 16 + g * 8) = o;
+      if (g == 0) ss[vr * 8 + G] = (uint8_t)e8;
     }
-    // the next segment's activations can be fetched now (xr is dead)
     const int snext = s + NWAVES;
-    // ---- MFMA operands: lane (row, g) of k-slice j needs all 16 code bytes of group 4 g + j.  Half 0 holds bytes 0..7 of every
-    //      group, half 1 bytes 8..15.  v_permlane32_swap(a, b) exchanges a's lanes 32-63 with b's lanes 0-31:
-    //        new a: lanes 0-31 keep a, lanes 32-63 receive half 0's b        new b: lanes 0-31 receive half 1's a, lanes 32-63 keep b
-    //      with a = o[j], b = o[4 + j]:   g = 0 -> {own bytes 0..7 of j, half 1's bytes 8..15 of j}
-    //                                     g = 1 -> {half 0's bytes 0..7 of 4 + j, own bytes 8..15 of 4 + j}
+    load_x(snext);                          // xr is dead: the next segment's activations
+    __builtin_amdgcn_s_waitcnt(0xc07f);     // lgkmcnt(0): the wave's own LDS writes landed (wave-private tile)
+    __builtin_amdgcn_wave_barrier();
+    // ---- MFMA operands: lane (row i32, g), k-slice j <- the 16 code bytes of group 4 g + j, the scale dword of groups 4 g .. 4 g + 3 ----
     v4i fa[4];
+    uint32_t sa = 0;
+    if (i32 < VR) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      auto a0 = __builtin_amdgcn_permlane32_swap((uint32_t)o[j][0], (uint32_t)o[4 + j][0], false, false);
-      auto a1 = __builtin_amdgcn_permlane32_swap((uint32_t)o[j][1], (uint32_t)o[4 + j][1], false, false);
-      fa[j] = v4i{(int)a0[0], (int)a1[0], (int)a0[1], (int)a1[1]};   // bytes 0..7 (new a), bytes 8..15 (new b)
+      for (int j = 0; j < 4; ++j) fa[j] = *(const v4i*)(cs + i32 * CROW + (4 * g + j) * 16);
+      sa = *(const uint32_t*)(ss + i32 * 8 + 4 * g);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) fa[j] = v4i{0, 0, 0, 0};
     }
-    // scale dword of this lane: K-blocks 4 g .. 4 g + 3 of the segment
-    const uint32_t sa = g ? (e8s[4] | (e8s[5] << 8) | (e8s[6] << 16) | (e8s[7] << 24)) : (e8s[0] | (e8s[1] << 8) | (e8s[2] << 16) | (e8s[3] << 24));
-    load_x(snext);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const v4i a = fa[j], b = fb[j];
@@ -184,6 +200,7 @@ __global__ __launch_bounds__(NWAVES * 64) void gemm_mx_fusedq_kernel(const Fused
       if (j == 3) acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(B8, A8, acc, 4, 4, 3, sb, 3, (int)sa);
     }
     load_b(snext);
+    __builtin_amdgcn_wave_barrier();        // (LDS is in order per wave: the reads above precede the next segment's writes)
   }
 
   // ---- cross-wave reduction and epilogue: gemm_mx_skinny_kernel's --------------------------------------------------------------
