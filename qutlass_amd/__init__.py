@@ -142,17 +142,30 @@ def fusedQuantizeNvBlocked(a: torch.Tensor, b: torch.Tensor, global_scale: torch
     return torch.ops.qutlass_amd.fusedQuantizeNvBlocked(a, b, xh_e2m1, xh_e4m3, global_scale, _METHOD_CODE[method])
 
 
+def _decode_single_launch_wins(m: int, n: int, k: int, rot: int) -> bool:
+    """Measured rule (profiles/ab_blocked_quant_r3.txt, N = 4096 / 6144 / 14336, K = 4096 / 14336): the one-launch kernel repeats the
+    rotate + quantize chain of its K slices in every workgroup -- ceil(K / 2048) x (1, 2, 4, 8 for M <= 4, 8, 16, 32) chains per wave --
+    and wins while that is at most 8 chains against a weight the small-batch GEMM handles (N < 8192, K <= 8192):
+    M = 1 / 8 / 16 at N = K = 4096: 5.0 / 6.1 / 7.6 us against 7.2 / 7.9 / 8.3 us for two launches (GEMM alone 4.6 / 5.0 / 5.3 us)."""
+    if not (0 < m <= 16 and rot == 32 and n < 8192 and k <= 8192):
+        return False
+    npass = 1 if m <= 4 else 2 if m <= 8 else 4
+    return -(-k // 2048) * npass <= 8
+
+
 def fused_quantize_matmul_mxf4_bf16_tn(x: torch.Tensor, h: torch.Tensor, b: torch.Tensor, b_sf: torch.Tensor, alpha: torch.Tensor, *,
-                                       method: Literal["quest", "abs_max"] = "abs_max", single_launch: bool = False) -> torch.Tensor:
-    """EXTENSION: ``matmul_mxf4_bf16_tn(*fusedQuantizeMxBlocked(x, h, method=method), b, b_sf, alpha)`` -- the activation path of one
-    linear layer (qutlass/__init__.py:149-180 -> qutlass/utils.py:160-193 -> qutlass/__init__.py:34-76) in TWO launches instead of
-    three: the quantizer writes GEMM-ready scales (M = 16, N = K = 4096: 8.2 us against 10.1 us, GEMM alone 5.3 us;
-    profiles/ab_blocked_quant_r3.txt).  ``single_launch=True`` (at most 32 rows, 32 x 32 rotation) runs the one-launch kernel in
-    which the small-batch GEMM quantises its own A operand (csrc/gemm_mx_fusedq.hip.h) -- same bits, but measured SLOWER than the
-    two launches (10.9 us at M = 16: every workgroup repeats the rotate + quantize chain of its K slices), so it is not the default."""
+                                       method: Literal["quest", "abs_max"] = "abs_max", single_launch: bool | None = None) -> torch.Tensor:
+    """EXTENSION: ``matmul_mxf4_bf16_tn(*fusedQuantizeMx(x, h, method=method) -> to_blocked, b, b_sf, alpha)`` -- the activation path of
+    one linear layer (qutlass/__init__.py:149-180 -> qutlass/utils.py:160-193 -> qutlass/__init__.py:34-76) in fewer launches, same bits:
+      * TWO launches: the quantizer writes GEMM-ready scales (``fusedQuantizeMxBlocked``), then the GEMM;
+      * ONE launch for decode batches (csrc/gemm_mx_fusedq.hip.h: the small-batch GEMM rotates and quantises its own A operand),
+        chosen where it measured faster (``_decode_single_launch_wins``); ``single_launch=True / False`` forces either."""
     if method not in _METHOD_CODE:
         raise ValueError(f"invalid method {method!r}, must be 'quest' or 'abs_max'")
     k = x.size(-1)
+    m = x.numel() // k if k else 0
+    if single_launch is None:
+        single_launch = _decode_single_launch_wins(m, b.size(0), k, h.size(0))
     if single_launch:
         out = torch.ops.qutlass_amd.fusedQuantizeMatmulMxf4(x, h, b, b_sf, alpha, _METHOD_CODE[method])
         return out.view(*x.shape[:-1], b.size(0))

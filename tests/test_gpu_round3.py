@@ -312,8 +312,9 @@ def test_fused_quantize_matmul_decode_equals_three_launch_path(q, m, n, k, metho
         q._lib.set_option("hw_fp4_cvt", hw)
         try:
             got = q.fused_quantize_matmul_mxf4_bf16_tn(x, h, w_q, w_sf, alpha, method=method, single_launch=True)
-            two = q.fused_quantize_matmul_mxf4_bf16_tn(x, h, w_q, w_sf, alpha, method=method)   # default: blocked quantizer + GEMM
-            assert torch.equal(two.view(torch.int16), want.view(torch.int16))
+            two = q.fused_quantize_matmul_mxf4_bf16_tn(x, h, w_q, w_sf, alpha, method=method, single_launch=False)   # blocked quantizer + GEMM
+            auto = q.fused_quantize_matmul_mxf4_bf16_tn(x, h, w_q, w_sf, alpha, method=method)                      # the measured rule picks one
+            assert torch.equal(two.view(torch.int16), want.view(torch.int16)) and torch.equal(auto.view(torch.int16), want.view(torch.int16))
         finally:
             q._lib.set_option("hw_fp4_cvt", 1)
         assert got.shape == (m, n) and got.dtype == torch.bfloat16

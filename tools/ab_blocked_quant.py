@@ -34,7 +34,7 @@ def main():
             print(f"{rows:>6}x{k:<7} {method:>8} {t_q:9.2f} {t_b:10.2f} {t_qb:14.2f} {t_f:10.2f}", flush=True)
     print("# linear layer y = Q(x h) W^T, weights pre-quantised: device us per call")
     print(f"{'M x N x K':>20} {'3 launches':>11} {'2 launches':>11} {'1 launch':>9} {'GEMM alone':>11}")
-    for n, k in ((4096, 4096), (6144, 4096), (4096, 14336), (14336, 4096)):
+    for n, k in ((4096, 4096), (6144, 4096), (4096, 8192), (2048, 2048), (4096, 14336), (14336, 4096)):
         w = torch.randn(n, k, dtype=torch.bfloat16, device=dev) * 25.0
         w_q, w_s = q.fusedQuantizeMx(w, h, method="abs_max")
         w_sf = to_blocked(w_s)
