@@ -270,6 +270,21 @@ def main():
     h64 = hadamard(64, dev)
     line("fusedQuantizeMx(H64, abs_max) 8192x8192 [cold: 10 x 128 MiB inputs rotated]", time_us_cold(lambda j: q.fusedQuantizeMx(mid[j], h64, method="abs_max"), 10, 20), bytes_=midb, cache="cold")
     del mid
+    # [r3] the four QAT-backward data-prep ops at 8192 x 8192 (a 4096^2 call of these ops is 18 - 51 MB, i.e. 3 - 8 us of
+    # streaming behind a ~2 us launch floor; the size that shows the kernels themselves is the next one up), 10 inputs rotated
+    big8 = [torch.randn(8192, 8192, dtype=torch.bfloat16, device=dev) * 25.0 for _ in range(10)]
+    b8 = 8192 * 8192
+    line("backward_t_bf16 8192x8192 [cold: 10 x 128 MiB inputs rotated]", time_us_cold(lambda j: q.backward_t_bf16(big8[j], h32), 10, 20), bytes_=b8 * 2 + b8 // 2 + b8 // 32, cache="cold")
+    line("backward_bf16_square_double_mxfp8 8192x8192 [cold: 10 x 128 MiB inputs rotated]", time_us_cold(lambda j: q.backward_bf16_square_double_mxfp8(big8[j]), 10, 20),
+         bytes_=b8 * 3 + 2 * b8 // 32, cache="cold")
+    pk8 = [q.fusedQuantizeMx(t, h32, method="abs_max") for t in big8]
+    pk8 = [(pq, ps.view(torch.uint8).reshape(-1)[: b8 // 32].reshape(8192, 8192 // 32).contiguous().view(torch.float8_e8m0fnu)) for pq, ps in pk8]
+    del big8
+    line("backward_qt_bf16 8192x8192 [cold: 10 x 36 MiB inputs rotated]", time_us_cold(lambda j: q.backward_qt_bf16(pk8[j][0], pk8[j][1], h32, al3), 10, 20),
+         bytes_=2 * (b8 // 2 + b8 // 32), cache="cold")
+    line("mxfp4_transpose_mxfp8 8192x8192 [cold: 10 x 36 MiB inputs rotated]", time_us_cold(lambda j: q.mxfp4_transpose_mxfp8(pk8[j][0], pk8[j][1]), 10, 20),
+         bytes_=b8 // 2 + b8 // 32 + b8 + b8 // 32, cache="cold")
+    del pk8
     # packed-input ops: 9 MiB per input, so rotate 40 of them as well (360 MiB > MALL) -- quantise the cold inputs once
     packed = [q.fusedQuantizeMx(t, h32, method="abs_max") for t in xs_c]
     packed = [(pq, ps.view(torch.uint8).reshape(-1)[: M * K // 32].reshape(M, K // 32).contiguous().view(torch.float8_e8m0fnu)) for pq, ps in packed]

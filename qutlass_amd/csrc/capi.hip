@@ -308,6 +308,8 @@ int dispatch_variant(int v, const GemmParams& p, hipStream_t s, const char* name
     case 72: return launch_gemm<GemmCfg<64, 128, 2, 2, EBITS, SPLIT, 0, 3>, 9>(p, s);
     case 73: return launch_gemm<GemmCfg<128, 128, 2, 2, EBITS, SPLIT, 0, 3>, 9>(p, s);
 #if QAMD_BENCH
+    case 76: return launch_gemm<GemmCfg<128, 128, 2, 2, EBITS, SPLIT, 0, 4>, 9>(p, s);   // lab: 73 with a 4-deep ring (144 KiB of LDS: one workgroup per CU, which 73's regime is anyway)
+    case 79: return launch_gemm<GemmCfg<64, 128, 2, 2, EBITS, SPLIT, 0, 4>, 9>(p, s);    //      72 with a 4-deep ring
     case 224: return launch_gemm<GemmCfg<128, 128, 2, 2, EBITS, SPLIT>, 3>(p, s);   // the round-1 simple schedule (2 stages, reads after the barrier, then MFMAs)
     case 225: return launch_gemm<GemmCfg<256, 128, 4, 2, EBITS, SPLIT>, 3>(p, s);
     case 227: return launch_gemm<GemmCfg<128, 64, 2, 2, EBITS, SPLIT>, 3>(p, s);

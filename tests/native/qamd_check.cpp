@@ -662,6 +662,26 @@ int main(int argc, char** argv) {
         }
     g_gauss_fill = 0;
   }
+  if (want("ring4")) {   // [r3] mid-size outputs: the 3-deep pipelined ring the auto rule picks (128x128: 73, 64x128: 72) against a 4-deep ring (76, 79); QAMD_STEADY_MS=30
+    g_gauss_fill = 1;
+    struct Sh { int64_t M, N, K; };
+    for (int rep = 0; rep < 2; ++rep)
+      for (const Sh& sh : {Sh{1024, 4096, 4096}, Sh{768, 4096, 4096}, Sh{256, 14336, 4096}, Sh{1024, 4096, 14336}, Sh{1024, 4096, 8192}, Sh{512, 8192, 8192}, Sh{1024, 2048, 4096}})
+        for (int var : {0, 73, 76}) {
+          char tag[96];
+          snprintf(tag, sizeof tag, "mxfp4 variant %d %lldx%lldx%lld", var, (long long)sh.M, (long long)sh.N, (long long)sh.K);
+          bench_gemm(tag, 0, sh.M, sh.N, sh.K, var, 100);
+        }
+    for (const Sh& sh : {Sh{512, 4096, 4096}, Sh{256, 8192, 8192}, Sh{512, 4096, 14336}})
+      for (int var : {0, 72, 79}) {
+        char tag[96];
+        snprintf(tag, sizeof tag, "mxfp4 variant %d %lldx%lldx%lld", var, (long long)sh.M, (long long)sh.N, (long long)sh.K);
+        bench_gemm(tag, 0, sh.M, sh.N, sh.K, var, 100);
+      }
+    g_gauss_fill = 0;
+    check_gemm("ring 128x128 4-deep 1000x520x1152", 0, 1000, 520, 1152, 0.5f, 3, 0, 76);
+    check_gemm("ring 64x128 4-deep 300x520x640 (K tail)", 0, 300, 520, 640, 1.0f, 3, 0, 79);
+  }
   if (want("deepptrace")) {   // phase timeline of workgroup 0 of the persistent deep kernel (variant 91), in the steady state
     struct Sh { int64_t M, N, K; };
     for (const Sh& sh : {Sh{4096, 4096, 4096}, Sh{4096, 12288, 4096}, Sh{8192, 8192, 8192}}) {
