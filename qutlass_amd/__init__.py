@@ -143,14 +143,15 @@ def fusedQuantizeNvBlocked(a: torch.Tensor, b: torch.Tensor, global_scale: torch
 
 
 def _decode_single_launch_wins(m: int, n: int, k: int, rot: int) -> bool:
-    """Measured rule (profiles/ab_blocked_quant_r3.txt, N = 4096 / 6144 / 14336, K = 4096 / 14336): the one-launch kernel repeats the
-    rotate + quantize chain of its K slices in every workgroup -- ceil(K / 2048) x (1, 2, 4, 8 for M <= 4, 8, 16, 32) chains per wave --
-    and wins while that is at most 8 chains against a weight the small-batch GEMM handles (N < 8192, K <= 8192):
-    M = 1 / 8 / 16 at N = K = 4096: 5.0 / 6.1 / 7.6 us against 7.2 / 7.9 / 8.3 us for two launches (GEMM alone 4.6 / 5.0 / 5.3 us)."""
-    if not (0 < m <= 16 and rot == 32 and n < 8192 and k <= 8192):
+    """Measured rule (profiles/ab_blocked_quant_r3.txt: N x K = 4096^2, 6144 x 4096, 4096 x 8192, 2048^2, 4096 x 14336, 14336 x 4096).  The
+    one-launch kernel repeats the rotate + quantize chains of its K slices in every workgroup -- ceil(K / 2048) x (1, 2, 4 for
+    M <= 4, 8, 16) chains per wave -- and beats the two launches (which cost ~3 us over the GEMM alone) while that stays short:
+        M <= 4: K <= 8192      M <= 8: K <= 6144      M <= 16: K <= 4096      (and a weight the small-batch GEMM handles: N < 8192)
+    M = 1 / 8 / 16 at N = K = 4096: 5.0 / 6.0 / 7.6 us against 7.2 / 7.9 / 8.3 us for two launches and 9.0 / 9.6 / 10.0 us for the
+    reference's three (GEMM alone 4.6 / 4.9 / 5.3 us); M = 32, or K = 14336, lose (14.2 vs 9.0 us, 12.7 vs 10.7 us)."""
+    if not (0 < m <= 16 and rot == 32 and n < 8192):
         return False
-    npass = 1 if m <= 4 else 2 if m <= 8 else 4
-    return -(-k // 2048) * npass <= 8
+    return k <= (8192 if m <= 4 else 6144 if m <= 8 else 4096)
 
 
 def fused_quantize_matmul_mxf4_bf16_tn(x: torch.Tensor, h: torch.Tensor, b: torch.Tensor, b_sf: torch.Tensor, alpha: torch.Tensor, *,
