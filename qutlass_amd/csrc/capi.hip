@@ -308,6 +308,12 @@ int dispatch_variant(int v, const GemmParams& p, hipStream_t s, const char* name
     case 72: return launch_gemm<GemmCfg<64, 128, 2, 2, EBITS, SPLIT, 0, 3>, 9>(p, s);
     case 73: return launch_gemm<GemmCfg<128, 128, 2, 2, EBITS, SPLIT, 0, 3>, 9>(p, s);
 #if QAMD_BENCH
+    case 273: return launch_gemm<GemmCfg<128, 128, 2, 2, EBITS, SPLIT, 128, 3>, 9>(p, s);   // lab: 73 with the next stage's reads packed into the first MFMAs (ABL_READS_FIRST)
+    case 272: return launch_gemm<GemmCfg<64, 128, 2, 2, EBITS, SPLIT, 128, 3>, 9>(p, s);
+    case 270: return launch_gemm<GemmCfg<64, 64, 2, 2, EBITS, SPLIT, 128, 3>, 9>(p, s);
+    case 224 + 1000: return launch_gemm<GemmCfg<128, 128, 2, 2, EBITS, SPLIT, 128, 2>, 9>(p, s);   //      24 (2-deep, two workgroups per CU) likewise
+    case 373: return launch_gemm<GemmCfg<128, 128, 2, 4, EBITS, SPLIT, 0, 3>, 9>(p, s);    //      128x128 on EIGHT waves of 64x32 (two per SIMD cover each other's stage-top bubble)
+    case 374: return launch_gemm<GemmCfg<128, 128, 4, 2, EBITS, SPLIT, 0, 3>, 9>(p, s);    //      ... of 32x64
     case 76: return launch_gemm<GemmCfg<128, 128, 2, 2, EBITS, SPLIT, 0, 4>, 9>(p, s);   // lab: 73 with a 4-deep ring (144 KiB of LDS: one workgroup per CU, which 73's regime is anyway)
     case 79: return launch_gemm<GemmCfg<64, 128, 2, 2, EBITS, SPLIT, 0, 4>, 9>(p, s);    //      72 with a 4-deep ring
     case 224: return launch_gemm<GemmCfg<128, 128, 2, 2, EBITS, SPLIT>, 3>(p, s);   // the round-1 simple schedule (2 stages, reads after the barrier, then MFMAs)
@@ -350,6 +356,7 @@ int dispatch_variant(int v, const GemmParams& p, hipStream_t s, const char* name
     if (v == 98) return launch_gemm_hetero<GemmCfg<256, 256, 2, 2, 4, false>, GemmCfg<128, 128, 2, 2, 4, false, 0, 4>, 17>(p, s);
 #if QAMD_BENCH
     if (v == 99) return launch_gemm_hetero<GemmCfg<256, 256, 2, 2, 4, false>, GemmCfg<128, 128, 2, 2, 4, false, 0, 3>, 17>(p, s);
+    if (v == 298) return launch_gemm_hetero<GemmCfg<256, 256, 2, 2, 4, false>, GemmCfg<128, 128, 2, 2, 4, false, 128, 4>, 17>(p, s);   // residual tiles with ABL_READS_FIRST
     if (v == 91) return launch_gemm_deepp<GemmCfg<256, 256, 2, 2, 4, false>, true, 17>(p, s);   //   + phase timestamps of workgroup 0 (qutlass_amd_debug_set_trace_buffer)
     if (v == 92) return launch_gemm_deepp<GemmCfg<256, 256, 2, 2, 4, false>, false, 2>(p, s);       //   output stores nt
     if (v == 93) return launch_gemm_deepp<GemmCfg<256, 256, 2, 2, 4, false>, false, 16>(p, s);      //   sc1

@@ -73,7 +73,8 @@ struct GemmParams {
 };
 
 // ablation bits (bench-only instantiations; 0 in the product path)
-enum { ABL_NO_DMA = 1, ABL_NO_MFMA = 2, ABL_NO_STORE = 4, ABL_NO_EPILOGUE = 8, ABL_TRACE = 16, ABL_NO_READS = 32, ABL_CLOCK = 64 };
+enum { ABL_NO_DMA = 1, ABL_NO_MFMA = 2, ABL_NO_STORE = 4, ABL_NO_EPILOGUE = 8, ABL_TRACE = 16, ABL_NO_READS = 32, ABL_CLOCK = 64,
+       ABL_READS_FIRST = 128 };   // (not an ablation: pipelined ring with the next stage's fragment reads packed into the first MFMAs of the stage; lab A/B)
 
 // AFMT_: element format of the A operand of an MXFP8 GEMM, 0 = e4m3 (the reference's only format), 1 = e5m2 (extension:
 // gradient operand of BASELINE.json configs[4]; the scaled MFMA takes the format per operand in cbsz / blgp).  B is e4m3.
@@ -593,10 +594,12 @@ struct GemmCtx {
 // ================================================================================================
 // order of the auxiliary instructions of a pipelined-ring stage: position a of nr + nd -> read unit (>= 0) or DMA item (-1 - index);
 // a DMA item after every second read unit, whatever is left of either kind at the end
-constexpr int ringp_aux_item(int a, int nr, int nd) {
+// (reads_first: all read units before the first DMA item -- with ONE workgroup per CU nothing else covers the LDS latency of the last
+//  reads at the top of the next stage, so they should not be the last instructions of this one)
+constexpr int ringp_aux_item(int a, int nr, int nd, bool reads_first = false) {
   int r = 0, d = 0, last = 0;
   for (int pos = 0; pos <= a; ++pos) {
-    const bool dma = (r >= nr) || (d < nd && pos % 3 == 2);
+    const bool dma = (r >= nr) || (!reads_first && d < nd && pos % 3 == 2);
     if (dma) last = -1 - d++;
     else last = r++;
   }
@@ -610,7 +613,7 @@ __device__ __forceinline__ void gemm_mx_ringp(char* smem, const GemmParams& p, i
   constexpr int U = (D % 2 == 0) ? D : 2 * D;       // unroll: slot = u % D, register set = u & 1
   static_assert(D >= 2 && (D - 2) * LPS <= 63, "vmcnt immediate");   // D = 2: one stage in flight, LDS of the simple schedule (two workgroups per CU)
   static_assert(!RM || (C::EBITS == 4 && C::BM == 64 && C::BN == 64 && C::NWAVES == 4), "row-major scales: 64x64 fp4 tiles");
-  static_assert(C::ABL == 0, "no ablation builds of this schedule");
+  static_assert((C::ABL & ~ABL_READS_FIRST) == 0, "no ablation builds of this schedule");
   GemmCtx<C> cx(smem, p, bid, fm0, fn0);
   __amdgpu_buffer_rsrc_t rSrm = cx.rS;
   int vSrm = 0x7fffffff;
@@ -737,7 +740,7 @@ __device__ __forceinline__ void gemm_mx_ringp(char* smem, const GemmParams& p, i
       // auxiliary items [i * NAUX / NM, (i + 1) * NAUX / NM): reads first-come, a DMA item after every second read unit
       static_for<i * NAUX / NM, (i + 1) * NAUX / NM>([&](auto ac) __attribute__((always_inline)) {
         constexpr int a = decltype(ac)::value;
-        constexpr int code = ringp_aux_item(a, NRU, LPS);   // >= 0: read unit, < 0: DMA item -1 - code
+        constexpr int code = ringp_aux_item(a, NRU, LPS, (C::ABL & ABL_READS_FIRST) != 0);   // >= 0: read unit, < 0: DMA item -1 - code
         if constexpr (code >= 0) read_unit(nslot, set ^ 1, code);
         else dma_item(slot, -1 - code);
       });

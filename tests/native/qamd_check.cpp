@@ -682,6 +682,33 @@ int main(int argc, char** argv) {
     check_gemm("ring 128x128 4-deep 1000x520x1152", 0, 1000, 520, 1152, 0.5f, 3, 0, 76);
     check_gemm("ring 64x128 4-deep 300x520x640 (K tail)", 0, 300, 520, 640, 1.0f, 3, 0, 79);
   }
+  if (want("readsfirst")) {   // [r3] pipelined ring: next-stage fragment reads packed into the first MFMAs of a stage (273 / 272 / 270 / 1224 / hetero 298) vs the product order; QAMD_STEADY_MS=30
+    check_gemm("ringp reads-first 128x128 1000x520x1152", 0, 1000, 520, 1152, 0.5f, 3, 0, 273);
+    check_gemm("ringp reads-first 64x128 300x520x640 (K tail)", 0, 300, 520, 640, 1.0f, 3, 0, 272);
+    check_gemm("ringp reads-first 64x64 72x136x640", 0, 72, 136, 640, 1.0f, 3, 0, 270);
+    check_gemm("ringp reads-first 128x128 2-deep 504x504x2048", 0, 504, 504, 2048, 1.0f, 3, 0, 1224);
+    check_gemm("hetero reads-first 4000x5000x640", 0, 4000, 5000, 640, 0.5f, 3, 64, 298);
+    check_gemm("ringp reads-first fp8 128x128 520x1000x1056", 2, 520, 1000, 1056, 1.0f, 3, 0, 273);
+    check_gemm("ringp 128x128 on 8 waves (2x4) 1000x520x1152", 0, 1000, 520, 1152, 0.5f, 3, 0, 373);
+    check_gemm("ringp 128x128 on 8 waves (4x2) 1000x520x1152", 0, 1000, 520, 1152, 0.5f, 3, 0, 374);
+    g_gauss_fill = 1;
+    struct Sh { int64_t M, N, K; int a, b; };
+    for (int rep = 0; rep < 2; ++rep)
+      for (const Sh& sh : {Sh{1024, 4096, 4096, 73, 273}, Sh{768, 4096, 4096, 73, 273}, Sh{256, 14336, 4096, 73, 273}, Sh{1024, 4096, 14336, 73, 273}, Sh{512, 4096, 4096, 72, 272},
+                           Sh{256, 4096, 4096, 70, 270}, Sh{64, 4096, 4096, 70, 270}, Sh{2048, 4096, 4096, 24, 1224}, Sh{4096, 5120, 4096, 98, 298}, Sh{3072, 6144, 4096, 98, 298}, Sh{4096, 4352, 4096, 98, 298}})
+        for (int var : {sh.a, sh.b}) {
+          char tag[96];
+          snprintf(tag, sizeof tag, "mxfp4 variant %d %lldx%lldx%lld", var, (long long)sh.M, (long long)sh.N, (long long)sh.K);
+          bench_gemm(tag, 0, sh.M, sh.N, sh.K, var, 100);
+        }
+    for (const Sh& sh : {Sh{1024, 4096, 4096, 373, 374}, Sh{768, 4096, 4096, 373, 374}, Sh{256, 14336, 4096, 373, 374}, Sh{1024, 4096, 14336, 373, 374}})
+      for (int var : {sh.a, sh.b}) {
+        char tag[96];
+        snprintf(tag, sizeof tag, "mxfp4 variant %d %lldx%lldx%lld", var, (long long)sh.M, (long long)sh.N, (long long)sh.K);
+        bench_gemm(tag, 0, sh.M, sh.N, sh.K, var, 100);
+      }
+    g_gauss_fill = 0;
+  }
   if (want("deepptrace")) {   // phase timeline of workgroup 0 of the persistent deep kernel (variant 91), in the steady state
     struct Sh { int64_t M, N, K; };
     for (const Sh& sh : {Sh{4096, 4096, 4096}, Sh{4096, 12288, 4096}, Sh{8192, 8192, 8192}}) {
