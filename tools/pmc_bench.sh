@@ -7,7 +7,8 @@
 # re-runs bench.py un-profiled with these fresh counters attached (traffic_stale: false).
 OUT=${1:-gpurun_out/pmc_bench}; R=${GRAFT_REPO_ROOT:-$(pwd)}
 mkdir -p $R/$OUT; cd /tmp; export TMPDIR=/tmp
-CMD="python $R/bench.py --no-cpu-baseline"   # the default command: durations must agree with the bench line
+CMD="python $R/bench.py --no-cpu-baseline --no-configs --no-pmc"   # the headline hot loop of the default command (durations must agree with the bench line);
+# [r3] the side configs and the nested rocprofv3 --pmc child runs of a plain `bench.py` stay out of the profiled command
 rocprofv3 --kernel-trace --stats -d $R/$OUT/trace -o p -- $CMD > $R/$OUT/trace.log 2>&1
 rocprofv3 --pmc FETCH_SIZE -d $R/$OUT/fetch -o p -- $CMD > $R/$OUT/fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE -d $R/$OUT/write -o p -- $CMD > $R/$OUT/write.log 2>&1
@@ -16,5 +17,5 @@ python tools/rocprof_summary.py $OUT/*/p_results.db > $OUT/summary.txt 2>&1
 python tools/rocprof_summary.py --traffic-json gemm_mx_ $OUT/fetch/p_results.db $OUT/write/p_results.db > $OUT/traffic.json
 cat $OUT/traffic.json
 # final, un-profiled run of the same command on the same box: its JSON line carries THIS session's counters (traffic_stale: false)
-QAMD_PMC_TRAFFIC_JSON=$R/$OUT/traffic.json python $R/bench.py > $R/$OUT/bench_with_fresh_traffic.json 2> $R/$OUT/bench_with_fresh_traffic.err
+QAMD_PMC_TRAFFIC_JSON=$R/$OUT/traffic.json python $R/bench.py --no-configs > $R/$OUT/bench_with_fresh_traffic.json 2> $R/$OUT/bench_with_fresh_traffic.err
 tail -1 $R/$OUT/bench_with_fresh_traffic.json
