@@ -135,6 +135,12 @@ def test_auto_dispatch_rules_dry_run(lib):
     assert plan(4, 4096, 5120, 4096) == [(HETERO, 5120, 1)] and plan(4, 5120, 4096, 4096) == [(HETERO, 4096, 1)]
     assert plan(8, 4096, 5120, 4096) == [(HETERO, 5120, 1)]
     assert plan(4, 3072, 8192, 4096) == [(DEEPP, 8192, 1)]
+    # the cost model of capi.hip (hetero_wins), tile counts on both sides of each switch: 272 / 288 / 320 tiles heterogeneous, 352 … 512 balanced,
+    # 544 / 576 heterogeneous, 608 … 768 balanced, 832 heterogeneous, 896 (C3) balanced; a (K, M) operand never (matmul_mxf8_bf16_nn keeps balanced rounds)
+    for n_cols, want in ((4352, HETERO), (4608, HETERO), (5632, DEEPP), (6144, DEEPP), (7168, DEEPP), (8192, DEEPP), (8704, HETERO), (9216, HETERO), (9728, DEEPP),
+                         (11008, DEEPP), (12288, DEEPP), (13312, HETERO), (14336, DEEPP)):
+        assert plan(4, 4096, n_cols, 4096) == [(want, n_cols, 1)], n_cols
+    assert plan(4, 4096, 5120, 1024) == [(HETERO, 5120, 1)] and plan(4, 4096, 5120, 14336) == [(HETERO, 5120, 1)]   # the rule does not depend on K
     assert plan(8, 4096, 4096, 4096) == [(DEEPP, 4096, 1)]
     assert plan(4, 256, 1 << 22, 128) == [(25, 1 << 22, 1)]          # absurdly wide output: 32-bit tile offsets of the persistent epilogue do not reach
     # decode: LDS-free split-K kernel while the weight has fewer than 128 64-row tiles, ring kernel beyond, 64x128 tiles for huge N
@@ -162,6 +168,41 @@ def test_auto_dispatch_rules_dry_run(lib):
     assert plan(4, 4096, 262400, 16384) == [(DEEPP, 261888, 1), (71, 512, 1)]
     # rejected arguments never reach the dispatch
     assert plan(4, 128, 128, 96) is None and plan(5, 128, 128, 128) is None
+
+
+def test_new_round3_entry_points_validate_their_arguments(lib):
+    """C-ABI checks of the round-3 entries (no launch: every call is rejected before it reaches the GPU)."""
+    from qutlass_amd._lib import QAMD_ERR_INVALID
+
+    dummy = ctypes.c_void_p(0x1000)
+    err = lambda: lib.qutlass_amd_last_error().decode()
+    qb = lib.qutlass_amd_fused_quantize_mx_blocked
+    assert qb(dummy, dummy, 64, 4, 96, 1, dummy, dummy, None, None) == QAMD_ERR_INVALID and "multiple of the rotation size 64" in err()
+    assert qb(dummy, dummy, 32, 0, 128, 1, dummy, dummy, None, None) == QAMD_ERR_INVALID and "bad shape" in err()
+    assert qb(dummy, dummy, 32, 4, 128, 1, dummy, dummy, dummy, None) == QAMD_ERR_INVALID and "clip mask" in err()   # mask needs quest
+    nb = lib.qutlass_amd_fused_quantize_nv_blocked
+    assert nb(dummy, dummy, 16, 4, 48, 1, dummy, dummy, dummy, None) == QAMD_ERR_INVALID and "multiple of 32" in err()
+    assert nb(dummy, dummy, 16, 4, 64, 1, None, dummy, dummy, None) == QAMD_ERR_INVALID and "null pointer" in err()
+    fq = lib.qutlass_amd_fused_quantize_matmul_mxf4_bf16_tn
+    assert fq(dummy, dummy, 32, 1, dummy, dummy, dummy, dummy, 33, 128, 128, None) == QAMD_ERR_INVALID and "M must be in 1..32" in err()
+    assert fq(dummy, dummy, 64, 1, dummy, dummy, dummy, dummy, 8, 128, 128, None) == QAMD_ERR_INVALID and "Unsupported rotation size 64" in err()
+    assert fq(dummy, dummy, 32, 1, dummy, dummy, dummy, dummy, 8, 128, 96, None) == QAMD_ERR_INVALID and "multiple of 128" in err()
+    assert fq(dummy, dummy, 32, 7, dummy, dummy, dummy, dummy, 8, 128, 128, None) == QAMD_ERR_INVALID and "invalid method" in err()
+    sq = lib.qutlass_amd_backward_bf16_square_double_mxfp8_rows
+    assert sq(dummy, 100, 100, 128, dummy, dummy, dummy, None) == QAMD_ERR_INVALID and "multiple of 128 >= m" in err()   # m_pad not a multiple of 128
+    assert sq(dummy, 200, 128, 128, dummy, dummy, dummy, None) == QAMD_ERR_INVALID                                        # m_pad < m
+    tr = lib.qutlass_amd_mxfp4_transpose_mxfp8_rows
+    assert tr(dummy, dummy, 100, 128, 128, dummy, dummy, None) == QAMD_ERR_INVALID and "n % 256" in err()
+    assert tr(dummy, dummy, 100, 64, 256, dummy, dummy, None) == QAMD_ERR_INVALID
+
+
+def test_decode_launch_rule():
+    """qutlass_amd._decode_single_launch_wins: the measured one-launch / two-launch rule of fused_quantize_matmul_mxf4_bf16_tn."""
+    from qutlass_amd import _decode_single_launch_wins as w
+
+    assert w(1, 4096, 4096, 32) and w(4, 4096, 8192, 32) and w(8, 6144, 4096, 32) and w(16, 4096, 4096, 32) and w(16, 2048, 2048, 32)
+    assert not w(1, 4096, 14336, 32) and not w(8, 4096, 8192, 32) and not w(16, 4096, 8192, 32) and not w(32, 4096, 4096, 32)
+    assert not w(1, 14336, 4096, 32) and not w(1, 4096, 4096, 64) and not w(0, 4096, 4096, 32)
 
 
 def test_product_kernels_use_no_scratch():
