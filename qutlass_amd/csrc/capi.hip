@@ -660,12 +660,13 @@ int gemm_mx(const char* name, const void* A, const void* B, const void* A_sf, co
       // (gemm_mx_hetero_kernel: dispatched CU by CU as the persistent workgroups retire) whenever the cost model says so;
       // otherwise ONE persistent launch with balanced rounds (deepp_grid).
       const int64_t tm = cdiv(M, 256), tn = cdiv(N, 256), T = tm * tn;
-      const bool hetero_ok = big == 90 && !(opt_pp_flags() & 64);
+      bool hetero_ok = big == 90 && !(opt_pp_flags() & 64);   // (lab, "pp_flags" bit 6: balanced rounds only)
 #if QAMD_BENCH
-      // lab, "pp_flags" bit 13: the round-1/2 form of the same idea -- the trailing tile columns as a SECOND launch of smaller tiles
-      // (kept for the A/B in profiles/native_r3_hetero.log); bit 6: neither (balanced rounds only)
+      // lab, "pp_flags" bit 13: the round-1/2 form of the same idea INSTEAD -- the trailing tile columns as a SECOND launch of smaller
+      // tiles (kept for the A/B in profiles/native_r3_heterobench.log)
       const int64_t full = (T / cus) * cus, main_cols = (tm > 0) ? full / tm : 0;
-      if ((opt_pp_flags() & 8192) && hetero_ok && full >= cus && full < 3 * cus && main_cols >= 1 && main_cols < tn && (T - main_cols * tm) <= 80) {
+      const bool two_launch = (opt_pp_flags() & 8192) != 0;
+      if (two_launch && hetero_ok && full >= cus && full < 3 * cus && main_cols >= 1 && main_cols < tn && (T - main_cols * tm) <= 80) {
         const int64_t n1 = main_cols * 256;
         GemmParams pm = p;
         pm.N = (int)n1; pm.b_bytes = (uint32_t)(n1 * rowbytes); pm.sfb_bytes = (uint32_t)(cdiv(n1, 128) * CB * 512);
@@ -680,7 +681,7 @@ int gemm_mx(const char* name, const void* A, const void* B, const void* A_sf, co
         const int vt = (tt(256, 128) >= want) ? 25 : (tt(128, 128) >= want) ? 24 : (tt(128, 64) >= want) ? 27 : 29;
         return dispatch(vt, pt, s);
       }
-      if (opt_pp_flags() & 8192) {} else
+      if (two_launch) hetero_ok = false;
 #endif
       if (hetero_ok && hetero_wins(T, cus)) variant = 98;
     }
