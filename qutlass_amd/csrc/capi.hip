@@ -255,7 +255,7 @@ inline bool hetero_wins(int64_t T, int cus) {
 //   PRODUCT (what the auto rules below can pick):
 //     90  persistent deep schedule, 256x256 (fp4: gemm_mx_deepp, fp8: gemm_mx_deepp8)      lab: 30 = the per-tile deep schedule of round 1
 //     98  heterogeneous launch: 90 over the full rounds + the residual tiles as 128x128 tiles in the same grid     lab: 99 = 3-deep ring for those
-//     24 / 25 / 27 / 28 / 29  simple schedule 128x128, 256x128, 128x64, 64x128, 64x64
+//     24 / 25 / 27 / 28 / 29  pipelined schedule on a 2-deep ring: 128x128, 256x128 (8 waves), 128x64, 64x128, 64x64      58  256x128 on four waves, 3-deep ring
 //     70..73  ring schedule 64x64, 128x64, 64x128, 128x128 (+ split-K)          60  skinny split-K kernel (fp4, M <= 32)
 //   LAB only:
 //   1  256x256 ping-pong     5  256x256 lockstep     6..9  queue schedule (256x256, 128x128, 256x128, 128x256)
@@ -301,6 +301,9 @@ int dispatch_variant(int v, const GemmParams& p, hipStream_t s, const char* name
     case 24: return launch_gemm<GemmCfg<128, 128, 2, 2, EBITS, SPLIT, 0, 2>, 9>(p, s);
     case 25: return launch_gemm<GemmCfg<256, 128, 4, 2, EBITS, SPLIT, 0, 2>, 9>(p, s);
     case 27: return launch_gemm<GemmCfg<128, 64, 2, 2, EBITS, SPLIT, 0, 2>, 9>(p, s);    // mid-size problems: more, smaller tiles
+    // [r3] 256x128 on FOUR waves of 128x64, 3-deep ring, one workgroup per CU: 0.75 KiB of LDS fragment reads per MFMA against 1 KiB for the 64x64 wave
+    // tiles of 24 / 25 -- half-chip outputs with a long K (2048 x 4096 x 8192: 36.9 -> 35.4 us, x 14336: 60.6 -> 57.1; profiles/native_r3_halftile.log)
+    case 58: return launch_gemm<GemmCfg<256, 128, 2, 2, EBITS, SPLIT, 0, 3>, 9>(p, s);
     case 28: return launch_gemm<GemmCfg<64, 128, 2, 2, EBITS, SPLIT, 0, 2>, 9>(p, s);
     case 29: return launch_gemm<GemmCfg<64, 64, 2, 2, EBITS, SPLIT, 0, 2>, 9>(p, s);
     case 70: return launch_gemm<GemmCfg<64, 64, 2, 2, EBITS, SPLIT, 0, 3>, 9>(p, s);     // pipelined ring schedule: NSTAGE-deep LDS ring, NSTAGE-1 stages in flight,
@@ -314,6 +317,9 @@ int dispatch_variant(int v, const GemmParams& p, hipStream_t s, const char* name
     case 224 + 1000: return launch_gemm<GemmCfg<128, 128, 2, 2, EBITS, SPLIT, 128, 2>, 9>(p, s);   //      24 (2-deep, two workgroups per CU) likewise
     case 373: return launch_gemm<GemmCfg<128, 128, 2, 4, EBITS, SPLIT, 0, 3>, 9>(p, s);    //      128x128 on EIGHT waves of 64x32 (two per SIMD cover each other's stage-top bubble)
     case 374: return launch_gemm<GemmCfg<128, 128, 4, 2, EBITS, SPLIT, 0, 3>, 9>(p, s);    //      ... of 32x64
+    case 325: return launch_gemm<GemmCfg<256, 128, 2, 2, EBITS, SPLIT, 0, 3>, 9>(p, s);   //      = product variant 58
+    case 326: return launch_gemm<GemmCfg<128, 256, 2, 2, EBITS, SPLIT, 0, 3>, 9>(p, s);   //      128x256 on four waves of 64x128
+    case 327: return launch_gemm<GemmCfg<256, 128, 2, 2, EBITS, SPLIT, 0, 2>, 9>(p, s);   //      ... 2-deep
     case 76: return launch_gemm<GemmCfg<128, 128, 2, 2, EBITS, SPLIT, 0, 4>, 9>(p, s);   // lab: 73 with a 4-deep ring (144 KiB of LDS: one workgroup per CU, which 73's regime is anyway)
     case 79: return launch_gemm<GemmCfg<64, 128, 2, 2, EBITS, SPLIT, 0, 4>, 9>(p, s);    //      72 with a 4-deep ring
     case 224: return launch_gemm<GemmCfg<128, 128, 2, 2, EBITS, SPLIT>, 3>(p, s);   // the round-1 simple schedule (2 stages, reads after the barrier, then MFMAs)
@@ -416,6 +422,7 @@ int dispatch_variant_a5(int v, const GemmParams& p, hipStream_t s, const char* n
     case 24: return launch_gemm<GemmCfg<128, 128, 2, 2, 8, true, 0, 2, 1>, 9>(p, s);
     case 25: return launch_gemm<GemmCfg<256, 128, 4, 2, 8, true, 0, 2, 1>, 9>(p, s);
     case 27: return launch_gemm<GemmCfg<128, 64, 2, 2, 8, true, 0, 2, 1>, 9>(p, s);
+    case 58: return launch_gemm<GemmCfg<256, 128, 2, 2, 8, true, 0, 3, 1>, 9>(p, s);
     case 28: return launch_gemm<GemmCfg<64, 128, 2, 2, 8, true, 0, 2, 1>, 9>(p, s);
     case 29: return launch_gemm<GemmCfg<64, 64, 2, 2, 8, true, 0, 2, 1>, 9>(p, s);
     case 90: return launch_gemm_deepp8<GemmCfg<256, 256, 2, 2, 8, true, 0, 2, 1>>(p, s);
@@ -685,7 +692,13 @@ int gemm_mx(const char* name, const void* A, const void* B, const void* A_sf, co
 #endif
       if (hetero_ok && hetero_wins(T, cus)) variant = 98;
     }
-    else if (tiles(128, 128) >= want) variant = 24;
+    else if (tiles(128, 128) >= want) {
+      // [r3] half-chip outputs (fewer than `want` tiles of 256x256): with a long K (>= 32 stages) the 256x128 tile on four waves wins 5-6 %
+      // over 128x128 tiles on two workgroups per CU; with K = 4096 the two tie (22.97 vs 22.95 us at 2048 x 4096 x 4096) and 128x128 stays
+      const int64_t KTs = cdiv(K * EBITS / 8, 128);
+      // (MXFP8 likewise: 2048 x 4096 x 4096 34.9 -> 32.7 us, x 8192 63.2 -> 57.1 us; K = 2048 = 16 stages: -2 %, stays)
+      variant = (M >= 256 && KTs >= 32 && tiles(256, 128) >= want) ? 58 : 24;
+    }
     else if (tiles(128, 64) >= want || tiles(64, 128) >= want) variant = (N >= M) ? 27 : 28;
     else variant = 29;
   }

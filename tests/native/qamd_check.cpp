@@ -709,6 +709,29 @@ int main(int argc, char** argv) {
       }
     g_gauss_fill = 0;
   }
+  if (want("halftile")) {   // [r3] half-chip outputs (M = 2048 against a 4096-wide weight: 128 tiles of 256x256): 256x128 / 128x256 tiles on four waves (325 / 326 / 327) vs the product's choice
+    check_gemm("ringp 256x128 4 waves 1000x520x1152", 0, 1000, 520, 1152, 0.5f, 3, 0, 325);
+    check_gemm("ringp 128x256 4 waves 520x1000x640 (K tail)", 0, 520, 1000, 640, 1.0f, 3, 0, 326);
+    check_gemm("ringp 256x128 4 waves 2-deep 504x504x2048", 0, 504, 504, 2048, 1.0f, 3, 0, 327);
+    check_gemm("ringp 256x128 4 waves fp8 520x1000x1056", 2, 520, 1000, 1056, 1.0f, 3, 0, 325);
+    g_gauss_fill = 1;
+    struct Sh { int64_t M, N, K; };
+    for (int rep = 0; rep < 2; ++rep)
+      for (const Sh& sh : {Sh{2048, 4096, 4096}, Sh{4096, 2048, 4096}, Sh{1536, 4096, 4096}, Sh{2560, 4096, 4096}, Sh{2048, 6144, 4096}, Sh{2048, 4096, 14336}, Sh{2048, 4096, 8192}, Sh{1024, 8192, 8192}, Sh{1024, 14336, 4096}})
+        for (int var : {0, 24, 325, 326, 327}) {
+          char tag[96];
+          snprintf(tag, sizeof tag, "mxfp4 variant %d %lldx%lldx%lld", var, (long long)sh.M, (long long)sh.N, (long long)sh.K);
+          bench_gemm(tag, 0, sh.M, sh.N, sh.K, var, 100);
+        }
+    // MXFP8, same question (KT = K / 128 stages): variant 24 vs 58 (= 325)
+    for (const Sh& sh : {Sh{2048, 4096, 4096}, Sh{2048, 4096, 8192}, Sh{1024, 8192, 4096}, Sh{2048, 4096, 2048}})
+      for (int var : {0, 24, 58})  {
+        char tag[96];
+        snprintf(tag, sizeof tag, "mxfp8 variant %d %lldx%lldx%lld", var, (long long)sh.M, (long long)sh.N, (long long)sh.K);
+        bench_gemm(tag, 2, sh.M, sh.N, sh.K, var, 100);
+      }
+    g_gauss_fill = 0;
+  }
   if (want("deepptrace")) {   // phase timeline of workgroup 0 of the persistent deep kernel (variant 91), in the steady state
     struct Sh { int64_t M, N, K; };
     for (const Sh& sh : {Sh{4096, 4096, 4096}, Sh{4096, 12288, 4096}, Sh{8192, 8192, 8192}}) {

@@ -160,7 +160,10 @@ def test_auto_dispatch_rules_dry_run(lib):
     assert plan(8, 64, 4096, 4096, big) == [(RING64, 4096, 4)]
     assert plan(4, 512, 4096, 4096) == [(RING64x128, 4096, 1)]
     assert plan(4, 1024, 4096, 4096) == [(RING128, 4096, 1)] and plan(4, 256, 14336, 4096) == [(RING128, 14336, 1)]
-    assert plan(4, 2048, 4096, 4096) == [(24, 4096, 1)]               # 512 tiles of 128x128: two workgroups per CU, simple schedule
+    assert plan(4, 2048, 4096, 4096) == [(24, 4096, 1)]               # 512 tiles of 128x128: two workgroups per CU, pipelined schedule on a 2-deep ring
+    # [r3] half-chip outputs with a long K (>= 32 stages of 128 bytes): 256x128 tiles on four waves of 128x64 (3-deep ring), fp4 and fp8, M >= 256
+    assert plan(4, 2048, 4096, 8192) == [(58, 4096, 1)] and plan(4, 1024, 8192, 14336) == [(58, 8192, 1)]
+    assert plan(8, 2048, 4096, 4096) == [(58, 4096, 1)] and plan(8, 2048, 4096, 2048) == [(24, 4096, 1)] and plan(4, 2048, 4096, 7168) == [(24, 4096, 1)]
     # an A operand of >= 2 GiB (262400 x 16384 fp4 = 2.15 GB) runs as two row ranges of whole 256-row tiles
     assert plan(4, 262400, 256, 16384) == [(DEEPP, 256, 1), (RING64, 256, 1)]   # 261888 rows, then the last 512
     # ... and a B operand of >= 2 GiB (262400 x 16384 fp4 weight) as two column ranges of whole 256-column tiles writing one D
