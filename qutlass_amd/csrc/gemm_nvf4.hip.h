@@ -670,7 +670,7 @@ inline hipError_t launch_nvf4_gemm(NvGemmParams p, hipStream_t s, int variant = 
     return hipSuccess;
   }
 #endif
-  if (variant <= 1 || variant == 4 || (variant >= 5 && variant <= 9)) {
+  if (variant <= 1 || variant == 4 || (variant >= 5 && variant <= 9) || variant == 40) {
     // tile choice by occupancy (as for the MX kernels): the largest tile that gives >= 192 workgroups
     auto tiles = [&](int bm, int bn) { return (int64_t)((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn); };
     int cfg = small ? 1 : 0;                                  // 0: 256x256, 1: 128x128, 2: 128x64, 3: 64x64
@@ -685,11 +685,21 @@ inline hipError_t launch_nvf4_gemm(NvGemmParams p, hipStream_t s, int variant = 
         if (e256 < 0.85 * e128) cfg = 1;
       }
       if (cfg == 1 && tiles(128, 128) < want) cfg = (tiles(128, 64) >= want) ? 2 : 3;
+      // [r3] where 128x128 tiles would run, the 256x128 tile on FOUR waves of 128x64 (one workgroup per CU) dequantises 0.75 fragments per MFMA
+      // instead of 1 and runs 5-6.5 % faster when its rounds are as full (2048 x 4096 x 4096: 66.4 -> 63.1 us, x 8192: 128.2 -> 120.2, x 14336:
+      // 221.1 -> 207.7, 1536 x 4096 x 4096: 59.1 -> 56.2; profiles/native_r3_nvhalf.log) -- take it when 1.06 x its round occupancy beats that
+      // of the 128x128 grid (two workgroups per CU: 2 cus slots per round)
+      if (cfg == 1 && p.M >= 256) {
+        const int64_t t4 = tiles(256, 128), t128 = tiles(128, 128);
+        const double e4 = (double)t4 / (double)((t4 + cus - 1) / cus * cus), e128 = (double)t128 / (double)((t128 + 2 * cus - 1) / (2 * cus) * (2 * cus));
+        if (1.06 * e4 > e128) cfg = 4;
+      }
     }
     if (variant == 5) cfg = 1;
     if (variant == 6) cfg = 2;
     if (variant == 7) cfg = 3;
 #if QAMD_BENCH
+    if (variant == 40) cfg = 4;   // lab: force the 256x128 tile on four waves of 128x64
     if (variant == 8) cfg = 8;    // lab: 128x128 tile on 2 waves of 128x64 (A dequantised by 2 waves, B by 1)
     if (variant == 9) cfg = 9;    //      128x128 tile on 2 waves of 64x128
 #endif
@@ -705,6 +715,8 @@ inline hipError_t launch_nvf4_gemm(NvGemmParams p, hipStream_t s, int variant = 
     // 64 converts / multiplies per 16 MFMAs instead of 48 per 8: +1.7 % (4096^3) .. +3.3 % (8192^3) in the steady state
     // (profiles/native_r2_nvsteady.log)
     if (cfg == 0) QAMD_NV_LAUNCH(256, 256, 2, 2)
+    // [r3] 256x128 on four waves of 128x64: 6 fragment dequantisations per 8 MFMAs (0.75 per MFMA) against 4 per 4 for the 64x64 wave tiles of the 128x128 tile
+    if (cfg == 4) QAMD_NV_LAUNCH(256, 128, 2, 2)
 #if QAMD_BENCH
     if (cfg == 8) QAMD_NV_LAUNCH(128, 128, 1, 2)
     if (cfg == 9) QAMD_NV_LAUNCH(128, 128, 2, 1)

@@ -732,6 +732,21 @@ int main(int argc, char** argv) {
       }
     g_gauss_fill = 0;
   }
+  if (want("nvhalf")) {   // [r3] NVFP4 half-chip outputs: auto (0) vs 128x128 tiles (5) vs 256x128 on four waves (40); QAMD_STEADY_MS=30
+    qutlass_amd_set_option("nvf4_variant", 40);
+    check_gemm("gemm_nvfp4 256x128 tile 1000x520x1152", 1, 1000, 520, 1152, 0.5f, 3, 0, 0);
+    check_gemm("gemm_nvfp4 256x128 tile ragged + K tail 300x264x352", 1, 300, 264, 352, 1.0f, 3, 0, 0);
+    struct Sh { int64_t M, N, K; };
+    for (int rep = 0; rep < 2; ++rep)
+      for (const Sh& sh : {Sh{2048, 4096, 4096}, Sh{2048, 4096, 8192}, Sh{1024, 8192, 8192}, Sh{2048, 4096, 14336}, Sh{1536, 4096, 4096}, Sh{2048, 6144, 4096}})
+        for (int nv : {0, 5, 40}) {
+          qutlass_amd_set_option("nvf4_variant", nv);
+          char tag[96];
+          snprintf(tag, sizeof tag, "nvfp4 variant %d %lldx%lldx%lld", nv, (long long)sh.M, (long long)sh.N, (long long)sh.K);
+          bench_gemm(tag, 1, sh.M, sh.N, sh.K, 0, 40);
+        }
+    qutlass_amd_set_option("nvf4_variant", 0);
+  }
   if (want("deepptrace")) {   // phase timeline of workgroup 0 of the persistent deep kernel (variant 91), in the steady state
     struct Sh { int64_t M, N, K; };
     for (const Sh& sh : {Sh{4096, 4096, 4096}, Sh{4096, 12288, 4096}, Sh{8192, 8192, 8192}}) {

@@ -381,10 +381,11 @@ def test_fused_quantize_nv_and_gemm_vs_oracle(q, rot):
     assert np.array_equal(_np(out), ref)   # exact: the reference asserts out.equal(out_ref) (nvfp4_test.py:224)
 
 
-@pytest.mark.parametrize("m,n,k", [(256, 4096, 1024), (512, 4096, 1024), (128, 14336, 512), (96, 4096, 1024), (1000, 2056, 544)])
+@pytest.mark.parametrize("m,n,k", [(256, 4096, 1024), (512, 4096, 1024), (128, 14336, 512), (96, 4096, 1024), (1000, 2056, 544), (2048, 4096, 1024), (1536, 4096, 512)])
 def test_matmul_nvf4_occupancy_tile_choice_is_bit_identical(q, m, n, k):
-    """The auto rule picks 64x64 / 128x64 / split-K / 128x128 tiles on these shapes; every configuration accumulates K in
-    the same order, so the result must equal the forced 128x128 launch bit for bit, and the oracle on sampled rows."""
+    """The auto rule picks 64x64 / 128x64 / split-K / 128x128 tiles -- [r3] and, on the last two (half-chip) shapes, the 256x128 tile on
+    four waves -- on these shapes; every configuration accumulates K in the same order, so the result must equal the forced 128x128
+    launch bit for bit, and the oracle on sampled rows."""
     g = torch.Generator(device="cpu").manual_seed(m + n + k)
     a = torch.randint(0, 256, (m, k // 2), dtype=torch.uint8, generator=g).to(DEV)
     b = torch.randint(0, 256, (n, k // 2), dtype=torch.uint8, generator=g).to(DEV)
@@ -397,10 +398,10 @@ def test_matmul_nvf4_occupancy_tile_choice_is_bit_identical(q, m, n, k):
     sb_b = to_blocked(sb.to(DEV).view(torch.float8_e4m3fn))
     al = torch.tensor([0.25], device=DEV)
     outs = {0: q.matmul_nvf4_bf16_tn(a, b, sa_b, sb_b, al).view(torch.int16).cpu()}
-    for v in (5, 6, 7):
+    for v in (5, 6, 7, 40):   # 40: the 256x128 tile forced (lab)
         with lab.forced(nvf4_variant=v):
             outs[v] = lab.matmul_nvf4_bf16_tn(a, b, sa_b, sb_b, al).view(torch.int16).cpu()
-    for v in (0, 6, 7):
+    for v in (0, 6, 7, 40):
         assert torch.equal(outs[v], outs[5]), v
     rows = sorted({0, m // 2, m - 1})
     a_s = np.ascontiguousarray(_np(a)[rows])
