@@ -42,6 +42,11 @@ def needs_build() -> bool:
 
 NUM_TU = 5         # translation units of csrc/capi.hip in the product build (QAMD_TU = 1..5; see the top of that file)
 NUM_TU_BENCH = 7   # the lab build adds the ablation units 6 and 7
+# Per-unit compiler flags.  Unit 5 holds the fused_quantize_kernel family and nothing else: its rotation MFMAs take their
+# accumulators in VGPRs -- LLVM's default put them in AGPRs and copied all 16 back with v_accvgpr_read_b32 per 1024-element tile,
+# a fifth of the VALU instructions of a kernel that is VALU-issue-bound at R = 32.  The GEMM units must keep
+# the AGPR form (256 accumulator registers per lane), so this is not a global flag; a QAMD_SINGLE_TU build goes without it.
+TU_FLAGS = {5: ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
 
 
 def _compile_units(out: str, num_tu: int, extra: list, verbose: bool) -> None:
@@ -58,7 +63,7 @@ def _compile_units(out: str, num_tu: int, extra: list, verbose: bool) -> None:
 
     with tempfile.TemporaryDirectory(prefix="qamd_build_") as tmp:
         objs = [os.path.join(tmp, f"capi_tu{i}.o") for i in range(1, num_tu + 1)]
-        cmds = [base + [f"-DQAMD_TU={i}", "-c", SRC, "-o", o] for i, o in zip(range(1, num_tu + 1), objs)]
+        cmds = [base + TU_FLAGS.get(i, []) + [f"-DQAMD_TU={i}", "-c", SRC, "-o", o] for i, o in zip(range(1, num_tu + 1), objs)]
         if verbose:
             print(" ".join(cmds[0]), f"   (x{num_tu}: QAMD_TU=1..{num_tu}, in parallel)")
         with ThreadPoolExecutor(max_workers=min(num_tu, os.cpu_count() or 1)) as ex:

@@ -55,27 +55,44 @@ __device__ __forceinline__ uint32_t e2m1_encode_sw(float t) {
   return sign | (k + (ge4 ? 4u : (ge2 ? 2u : 0u)));
 }
 
-// Hardware converter v_cvt_scalef32_pk_fp4_f32 (scale operand 1.0): two fp32 -> one byte,
-// lo -> low nibble.  Enabled only after tools/probe verified it against the oracle on device.
+// Hardware converter v_cvt_scalef32_pk_fp4_f32: two fp32 -> one byte, lo -> low nibble.  Enabled only after tools/probe verified
+// it against the oracle on device (scale operand 1.0).  [r3] The scale operand DIVIDES by a power of two exactly, before the
+// rounding: cvt(y, 2^-sh) == cvt(ldexp(y, sh), 1.0) on 220 000 pairs incl. every rounding tie of the e2m1 grid, saturating values
+// and products in the fp32 denormal range (tests/native/cvt_scale_probe.hip, profiles/cvt_scale_probe_r3.txt) -- so a
+// power-of-two block scale costs no instruction of its own.
 template <int BYTE>
-__device__ __forceinline__ uint32_t e2m1_pack2_hw(uint32_t old, float lo, float hi) {
-  return __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(old, lo, hi, 1.0f, BYTE);
+__device__ __forceinline__ uint32_t e2m1_pack2_hw(uint32_t old, float lo, float hi, float scale = 1.0f) {
+  return __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(old, lo, hi, scale, BYTE);
 }
 
+// 8 values -> one dword.  `scale` (a power of two; HWCVT only) divides the values inside the convert.
 template <bool HWCVT>
-__device__ __forceinline__ uint32_t e2m1_pack8(const float* t) {   // 8 values -> one dword
+__device__ __forceinline__ uint32_t e2m1_pack8(const float* t, float scale = 1.0f) {
   if (HWCVT) {
     uint32_t r = 0;
-    r = e2m1_pack2_hw<0>(r, t[0], t[1]);
-    r = e2m1_pack2_hw<1>(r, t[2], t[3]);
-    r = e2m1_pack2_hw<2>(r, t[4], t[5]);
-    r = e2m1_pack2_hw<3>(r, t[6], t[7]);
+    r = e2m1_pack2_hw<0>(r, t[0], t[1], scale);
+    r = e2m1_pack2_hw<1>(r, t[2], t[3], scale);
+    r = e2m1_pack2_hw<2>(r, t[4], t[5], scale);
+    r = e2m1_pack2_hw<3>(r, t[6], t[7], scale);
     return r;
   } else {
     uint32_t r = 0;
 #pragma unroll
     for (int i = 0; i < 8; ++i) r |= e2m1_encode_sw(t[i]) << (4 * i);
     return r;
+  }
+}
+
+// t[0..N) = a[0..N) * s as N/2 v_pk_mul_f32 (4 cycles per wave for two products, the same issue cost as one v_mul_f32:
+// tests/native/valu_probe.hip; the streaming quantisers are VALU-issue-bound at small rotation sizes)
+typedef float v2f __attribute__((ext_vector_type(2)));
+template <int N, typename V>
+__device__ __forceinline__ void scale_pk(const V& a, int a0, float s, float* t) {
+#pragma unroll
+  for (int i = 0; i < N; i += 2) {
+    const v2f r = v2f{a[a0 + i], a[a0 + i + 1]} * v2f{s, s};
+    t[i] = r[0];
+    t[i + 1] = r[1];
   }
 }
 
@@ -288,13 +305,27 @@ __global__ __launch_bounds__(256) void fused_quantize_kernel(const QuantParams p
         const int sh = 127 - (int)e8;                                 // y / 2^(e8-127) == ldexp(y, sh)
         float t[16];
         uint32_t mbits = 0;
+        float cs = 1.0f;   // scale operand of the hardware convert
         if (METHOD == METHOD_ABSMAX && !MASK) {
           // (y * 2^sh) * 3 == y * (3 * 2^sh): the power-of-two scaling is exact, so one multiply by the pre-scaled
           // constant rounds exactly like the reference's two steps (scale >= 1e-8 keeps 3 * 2^sh finite; results in the
           // denormal range quantise to 0 either way)
-          const float f3 = ldexpf(3.0f, sh);
+          scale_pk<16>(acc, 0, ldexpf(3.0f, sh), t);
+        } else if (HWCVT) {
+          // [r3] y / 2^(e8-127) happens inside the convert (see e2m1_pack2_hw): no v_ldexp_f32 per element.  The clip test
+          // |y * 2^sh| < 6 is |y| < 6 * 2^-sh (power-of-two scaling of either side is exact).
+          cs = __uint_as_float(e8 << 23);   // e8 >= 100: scale >= 1e-8
+          if (MASK) {
+            const float lim = 6.0f * cs;
 #pragma unroll
-          for (int r = 0; r < 16; ++r) t[r] = acc[r] * f3;
+            for (int r = 0; r < 16; ++r) mbits |= (fabsf(acc[r]) < lim ? 1u : 0u) << (8 * (r >> 2) + 4 * half + (r & 3));
+          }
+          if (METHOD == METHOD_ABSMAX) {
+            scale_pk<16>(acc, 0, 3.0f, t);
+          } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) t[r] = acc[r];
+          }
         } else {
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
@@ -305,8 +336,8 @@ __global__ __launch_bounds__(256) void fused_quantize_kernel(const QuantParams p
           }
         }
         // bytes: q-th group of 4 values -> group bytes 4q + 2 half, 4q + 2 half + 1
-        const uint32_t P = e2m1_pack8<HWCVT>(t);       // halfwords H[0+half], H[2+half]
-        const uint32_t Q = e2m1_pack8<HWCVT>(t + 8);   // halfwords H[4+half], H[6+half]
+        const uint32_t P = e2m1_pack8<HWCVT>(t, cs);       // halfwords H[0+half], H[2+half]
+        const uint32_t Q = e2m1_pack8<HWCVT>(t + 8, cs);   // halfwords H[4+half], H[6+half]
         auto sw = __builtin_amdgcn_permlane32_swap(P, Q, false, false);
         const uint32_t X = sw[0], Y = sw[1];
         // half 0: X = own P, Y = partner P ; half 1: X = partner Q, Y = own Q
@@ -361,8 +392,7 @@ __global__ __launch_bounds__(256) void fused_quantize_kernel(const QuantParams p
             out_scale = (sq > 0.f) ? __frcp_rn(sq) : 0.0f;
           }
           float t[8];
-#pragma unroll
-          for (int r = 0; r < 8; ++r) t[r] = v8[r] * out_scale;
+          scale_pk<8>(v8, 0, out_scale, t);
           // 8 values = bytes {0,1,4,5} + 2*half of the 8-byte group: halfwords H[half], H[2+half]
           const uint32_t P = e2m1_pack8<HWCVT>(t);
           auto sw = __builtin_amdgcn_permlane32_swap(P, P, false, false);

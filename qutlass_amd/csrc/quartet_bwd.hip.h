@@ -33,16 +33,42 @@ struct BwdTParams {
   uint8_t* out_sf;          // e8m0 (B, M, N/32)
   int B, N, M;
   int tiles_m;              // ceil(M / 64); B * (N/32) * tiles_m < 2^31 (host-checked): the kernel indexes tiles in 32 bits
+  int m_fast;               // tile order inside a batch: 1 = m-tiles fastest, 0 = n-blocks (of 8 scale groups) fastest
 };
 
 // One wave = one [32 n][64 m] tile = one scale group for 64 output rows; the 8 waves of a workgroup take 8 consecutive
 // scale groups (n0 .. n0 + 255) of the SAME 64 rows m, so the workgroup's output is one whole 128-byte line of e2m1 and
 // 8 scale bytes per row: staged through LDS and stored as full lines (written per wave it was 16 bytes of each of 32
 // lines per store instruction, and single scale bytes 128 bytes apart).
+//
+// [r3] Instruction diet.  The first version was bound by instruction ISSUE, not by memory: at 8192^2 its 32 wave tiles per SIMD cost ~230
+// vector instructions each (PMC: SQ_ACTIVE_INST_VALU = 16 of its 23-32 us; tests/native/valu_probe.hip has the per-instruction costs), and when
+// those were halved the kernel did not move -- the address arithmetic had gone to the SCALAR unit, which a CU has ONE of for its four SIMDs
+// (~300 scalar instructions per tile and wave, every one of the 8 waves repeating the same tile decode with its three integer divisions,
+// twice).  Both are cut now:
+//   * tile coordinates advance incrementally (carry-propagating adds, no division in the loop) and are computed once per tile; every address
+//     is a wave-uniform 64-bit base + a per-lane 32-bit offset computed ONCE (buffer loads / stores; rows and columns past the tensor fall
+//     off the descriptor) -- the per-lane 64-bit multiplies of the first version were ~25 vector instructions per tile;
+//   * the X^T operand comes out of the LDS tile with ds_read_b64_tr_b16 (4 reads per 32 rows instead of 16 two-byte
+//     reads + 8 v_perm_b32);
+//   * no division per group: the e8m0 byte is the exponent field of amax (T) or of amax / alpha (QT), and for two
+//     positive normal floats the exponent of RN(a / b) is the exponent field of the INTEGER bits(a) - bits(b) + bits(1.0)
+//     (the mantissa borrow is exactly the "a's mantissa < b's" case; RN cannot carry the quotient of two 24-bit
+//     mantissas up to the next power of two: the largest quotient below 2 is 2 - 2^-23, itself representable);
+//     the multiplier 3 / scale (T) resp. 3 / (scale * alpha) (QT) is RN(3 / alpha) * 2^-E exactly, so the elements are
+//     multiplied by the kernel-wide constant (v_pk_mul_f32, two per instruction) and 2^-E is the scale operand of the
+//     convert (quantize.hip.h: e2m1_pack2_hw).  Zero / denormal / huge amax or alpha (the reference's 3/0 = inf,
+//     0 * inf = NaN -> code 7 behaviour for all-zero groups included) take the original division path, per wave.
+// A ring of 2-4 prefetched tiles per wave (more bytes in flight) was measured and is SLOWER (QT 8192^2: 23 -> 28 us): not latency-bound.
 template <bool QT, bool HWCVT>
 __global__ __launch_bounds__(512) void bwd_quant_t_kernel(const BwdTParams p) {
-  constexpr int LROW = 64 * 2 + 16;  // LDS row stride (bytes): 16-byte aligned rows (ds_write_b128); the two lane halves read rows
-                                     // 8 apart = 288 dwords = bank offset 32, so their 64-byte column runs never collide
+#ifndef QAMD_BWD_LROW_QT
+#define QAMD_BWD_LROW_QT 144
+#endif
+  // LDS row stride (bytes) of the [32 n][64 m] bf16 tile.  T: 192 -- its staging writes are whole 128-byte rows (conflict-free at any stride) and
+  // the tr reads want the stride = 16 or 48 dwords (mod 64).  QT: a lane pair writes the 128-byte row as 2 x 4 ds_write_b128 and 4 rows per 8-lane
+  // group: conflict-free needs stride = 4 (mod 16) dwords, which the tr reads cannot have at the same time -- 144 keeps the writes clean.
+  constexpr int LROW = QT ? QAMD_BWD_LROW_QT : 192;
   constexpr int HROW = 32 * 2 + 16;
   constexpr int OROW = 128 + 16;     // staged output row: 8 groups x 16 bytes + pad
   __shared__ __attribute__((aligned(16))) char tile_s[8][32 * LROW];
@@ -57,48 +83,72 @@ __global__ __launch_bounds__(512) void bwd_quant_t_kernel(const BwdTParams p) {
   const float alpha = QT ? *p.alpha : 1.0f;
   const int G = p.N >> 5;
   const int ngb = (G + 7) >> 3;                       // blocks of 8 scale groups
-  const int ntw = p.B * p.tiles_m * ngb;              // workgroup tiles (host-checked < 2^31)
-  // workgroup tile tw -> (b, tm, gb), gb fastest; 32-bit arithmetic: 64-bit div/mod is ~100 SALU ops each
-  auto decode = [&](int tw, int& b, int& m0, int& g0) __attribute__((always_inline)) {
-    const unsigned q1 = (unsigned)tw / (unsigned)ngb;
-    g0 = (int)((unsigned)tw - q1 * (unsigned)ngb) * 8;
-    b = (int)(q1 / (unsigned)p.tiles_m);
-    m0 = (int)(q1 - (unsigned)b * (unsigned)p.tiles_m) * 64;
+  // Tile coordinates (b, o, i), all wave-uniform: i = the fast index inside a batch (m_fast: the m-tile, else the block of 8 scale groups), o the
+  // other one.  A workgroup walks tiles blockIdx.x, + gridDim.x, ...: the step is decomposed once, the walk is two carry-propagating adds.
+  // The two 64-bit tile origins ride along: `in` = element index of the tile's first input element for wave 0, (b N + 256 gb) M + 64 tm, and
+  // `grp` = index of its first output scale group, (b M + 64 tm) G + 8 gb -- both linear in (b, o, i), so a step is one add and a carry a second.
+  const int n_i = p.m_fast ? p.tiles_m : ngb, n_o = p.m_fast ? ngb : p.tiles_m;
+  const int64_t in_b = (int64_t)p.N * p.M, in_tm = 64, in_gb = 256ll * p.M, gr_b = (int64_t)p.M * G, gr_tm = 64ll * G, gr_gb = 8;
+  const int64_t in_i = p.m_fast ? in_tm : in_gb, in_o = p.m_fast ? in_gb : in_tm, gr_i = p.m_fast ? gr_tm : gr_gb, gr_o = p.m_fast ? gr_gb : gr_tm;
+  struct Tile { int b, o, i; int64_t in, grp; };
+  auto split = [&](unsigned t) __attribute__((always_inline)) {
+    const unsigned q = t / (unsigned)n_i;
+    Tile r{(int)(q / (unsigned)n_o), (int)(q % (unsigned)n_o), (int)(t % (unsigned)n_i), 0, 0};
+    r.in = r.b * in_b + r.o * in_o + r.i * in_i;
+    r.grp = r.b * gr_b + r.o * gr_o + r.i * gr_i;
+    return r;
+  };
+  const Tile step = split(gridDim.x);
+  const int64_t in_c1 = in_o - n_i * in_i, in_c2 = in_b - n_o * in_o, gr_c1 = gr_o - n_i * gr_i, gr_c2 = gr_b - n_o * gr_o;
+  auto advance = [&](Tile t) __attribute__((always_inline)) {
+    t.i += step.i;
+    const bool c1 = t.i >= n_i;
+    t.i -= c1 ? n_i : 0;
+    t.o += step.o + (c1 ? 1 : 0);
+    const bool c2 = t.o >= n_o;
+    t.o -= c2 ? n_o : 0;
+    t.b += step.b + (c2 ? 1 : 0);
+    t.in += step.in + (c1 ? in_c1 : 0) + (c2 ? in_c2 : 0);
+    t.grp += step.grp + (c1 ? gr_c1 : 0) + (c2 ? gr_c2 : 0);
+    return t;
   };
 
-  // global -> registers for one tile (software pipeline: the next tile's loads are in flight while this one is
-  // rotated and quantised).  T: lane -> row lane/8 (+8 per pass), 16-byte chunk lane%8 (8 m): one pass = 8 rows x 128 B.
+  // ---- per-lane offsets, computed once -------------------------------------------------------------------------
+  // T : lane -> row lane/8 (+8 per pass, a wave-uniform soffset), 16-byte chunk lane%8 (8 m): one pass = 8 rows x 128 B.
   // QT: lane -> row lane/2, 16-byte half (32 codes = one input scale group) + its e8m0 byte.
+  const uint32_t rowb = QT ? (uint32_t)p.M >> 1 : (uint32_t)p.M * 2u;   // input row stride in bytes (host-checked: 32 rows < 2^31 bytes)
+  const int lcol = QT ? (lane & 1) * 32 : (lane & 7) * 8;               // first m of the lane's chunk inside the tile
+  const uint32_t ld_off = QT ? (uint32_t)(lane >> 1) * rowb + (uint32_t)(lane & 1) * 16u : (uint32_t)(lane >> 3) * rowb + (uint32_t)(lane & 7) * 16u;
+  const uint32_t lds_off = QT ? (uint32_t)(lane >> 1) * ((uint32_t)p.M >> 5) + (uint32_t)(lane & 1) : 0u;
+  const uint32_t st_off = (uint32_t)(tid >> 3) * (uint32_t)G * 16u + (uint32_t)(tid & 7) * 16u;   // output piece: row tid/8, group tid%8
+  const uint32_t OOB = 0x80000000u;                                     // past every descriptor below (their extents are < 2^31)
+
+  // global -> registers for one tile (software pipeline: the next tile's loads are in flight while this one is rotated and quantised)
+  // the wave's own 32 input rows start 32 wave rows below the tile origin
+  const char* xw = QT ? (const char*)p.xq + (int64_t)wave * 32 * (p.M >> 1) : (const char*)p.x + (int64_t)wave * 32 * p.M * 2;
+  const char* sw = QT ? (const char*)p.xs + (int64_t)wave * 32 * (p.M >> 5) : nullptr;
   v4i ld[QT ? 1 : 4];
-  uint32_t ld_e = 0;
-  auto load_tile = [&](int tw) __attribute__((always_inline)) {
-    int b, m0, g0;
-    decode(tw, b, m0, g0);
-    const int g = g0 + wave;
-    const bool live = tw < ntw && g < G;
-    const int n0 = g * 32;
+  uint8_t ld_e = 0;   // (kept as the loaded byte and widened at its use: widened here, the zero-extension lands behind the load at the loop
+                      //  latch, and with it the wait for the load just issued)
+  auto load_tile = [&](const Tile t) __attribute__((always_inline)) {
+    const int m0 = (p.m_fast ? t.i : t.o) * 64, g = (p.m_fast ? t.o : t.i) * 8 + wave;
+    const bool live = t.b < p.B && g < G;
+    const uint32_t voff = (m0 + lcol < p.M) ? ld_off : OOB;           // M % 8 (T) / % 32 (QT) == 0: a chunk is in or out as a whole
     if (!QT) {
+      const __amdgpu_buffer_rsrc_t r = make_rsrc(xw + t.in * 2, live ? 32u * rowb : 0u);
 #pragma unroll
-      for (int ps = 0; ps < 4; ++ps) {
-        const int r = ps * 8 + (lane >> 3), c = (lane & 7) * 8;
-        ld[ps] = v4i{0, 0, 0, 0};
-        if (live && m0 + c < p.M)   // M % 8 == 0 (host-checked): a chunk is in or out as a whole
-          ld[ps] = *(const v4i*)(p.x + ((int64_t)b * p.N + n0 + r) * p.M + m0 + c);
-      }
+      for (int ps = 0; ps < 4; ++ps) ld[ps] = __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)(ps * 8 * rowb), 0);
     } else {
-      const int r = lane >> 1, c = (lane & 1) * 32;
-      ld[0] = v4i{0, 0, 0, 0};
-      ld_e = 127;
-      if (live && m0 + c < p.M) {     // M % 32 == 0 (host-checked)
-        const int64_t rowi = (int64_t)b * p.N + n0 + r;
-        ld[0] = *(const v4i*)(p.xq + rowi * (p.M >> 1) + ((m0 + c) >> 1));
-        ld_e = p.xs[rowi * (p.M >> 5) + ((m0 + c) >> 5)];
-      }
+      const __amdgpu_buffer_rsrc_t r = make_rsrc(xw + (t.in >> 1), live ? 32u * rowb : 0u);
+      const __amdgpu_buffer_rsrc_t re = make_rsrc(sw + (t.in >> 5), live ? 32u * ((uint32_t)p.M >> 5) : 0u);
+      ld[0] = __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, 0, 0);
+      ld_e = __builtin_amdgcn_raw_buffer_load_b8(re, (int)((m0 + lcol < p.M) ? lds_off : OOB), 0, 0);   // dropped lanes read 0: their codes are 0 too
     }
   };
+  Tile cur = split(blockIdx.x);
   // [r2] T: the first tile's loads are issued BEFORE the rotation matrix is staged (the two memory round trips overlap: 13.7 -> 12.9 us
   // cold at 4096^2).  QT keeps them after it: its tile is 1/4 of the bytes and hoisting measured +4 % warm (profiles/ab_stream_ops_r2.txt)
-  if (!QT) load_tile(blockIdx.x);
+  if (!QT) load_tile(cur);
   {   // hT[j][k] = h[k][j]; [r2] both loads of a thread before the first LDS write (the loop form waited for each load in turn)
     uint16_t hv[2];
 #pragma unroll
@@ -113,10 +163,20 @@ __global__ __launch_bounds__(512) void bwd_quant_t_kernel(const BwdTParams p) {
   v8bf hf[2];   // H^T operand of the two K = 16 MFMAs (runtime matrix, loaded once)
 #pragma unroll
   for (int kc = 0; kc < 2; ++kc) hf[kc] = *(const v8bf*)(hT + row * HROW + (kc * 16 + half * 8) * 2);
-  if (QT) load_tile(blockIdx.x);
-  for (int tw = blockIdx.x; tw < ntw; tw += gridDim.x) {   // uniform over the workgroup: barriers inside are safe
-    int b, m0, g0;
-    decode(tw, b, m0, g0);
+  if (QT) load_tile(cur);
+
+  // kernel-wide constants of the division-free scale path (see the header comment)
+  const uint32_t alpha_bits = __float_as_uint(alpha);
+  const bool alpha_fast = !QT || (alpha_bits >= 0x30800000u && alpha_bits <= 0x4e800000u);   // 2^-30 <= alpha <= 2^30, positive, finite
+  const uint32_t Kexp = QT ? alpha_bits - 0x3f800000u : 0u;             // bits(amax) - Kexp: exponent field = that of RN(amax / alpha)
+  const float c3 = QT ? 3.0f / alpha : 3.0f;                            // RN(3 / alpha): the multiplier's mantissa
+  // transposing LDS read: the 16 lanes of a group supply the four 8-byte pieces of each of 4 consecutive n rows of a 16-column block and
+  // receive one column each (lane%16), 4 n values -- half a K = 16 MFMA operand
+  const char* tr_ptr = ts + (8 * half + ((lane & 15) >> 2)) * LROW + (((lane & 31) >> 4) * 16 + (lane & 3) * 4) * 2;
+
+  while (cur.b < p.B) {   // uniform over the workgroup: barriers inside are safe
+    const int m0 = (p.m_fast ? cur.i : cur.o) * 64, g0 = (p.m_fast ? cur.o : cur.i) * 8;
+    const int64_t grp0 = cur.grp;
 
     // ---- stage the [32 n][64 m] bf16 tile in LDS ---------------------------------------------------------------
     if (!QT) {
@@ -127,7 +187,8 @@ __global__ __launch_bounds__(512) void bwd_quant_t_kernel(const BwdTParams p) {
       }
     } else {
       const int r = lane >> 1, c = (lane & 1) * 32;
-      const float sc = __uint_as_float(ld_e ? (ld_e << 23) : 0x00400000u);   // 2^(e-127); e = 0 -> 2^-127 (denormal)
+      const uint32_t e = ld_e;
+      const float sc = __uint_as_float(e ? (e << 23) : 0x00400000u);   // 2^(e-127); e = 0 -> 2^-127 (denormal)
       v4i* d = (v4i*)(ts + r * LROW + c * 2);
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
@@ -140,7 +201,8 @@ __global__ __launch_bounds__(512) void bwd_quant_t_kernel(const BwdTParams p) {
         d[q] = o;
       }
     }
-    load_tile(tw + gridDim.x);   // next tile's rows: in flight during the rotation / quantisation below
+    cur = advance(cur);
+    load_tile(cur);   // next tile's rows: in flight during the rotation / quantisation below
     __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): the wave's own LDS writes landed (wave-private tile)
     __builtin_amdgcn_wave_barrier();
 
@@ -153,9 +215,11 @@ __global__ __launch_bounds__(512) void bwd_quant_t_kernel(const BwdTParams p) {
       for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 #pragma unroll
       for (int kc = 0; kc < 2; ++kc) {
-        v8u16 xv;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) xv[i] = *(const uint16_t*)(ts + (kc * 16 + half * 8 + i) * LROW + mloc * 2);
+        typedef short v4s_ __attribute__((ext_vector_type(4)));
+        typedef __attribute__((address_space(3))) v4s_* lds_v4s_t;
+        const v4s_ lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s_t)(tr_ptr + (16 * kc) * LROW + mh * 64));
+        const v4s_ hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s_t)(tr_ptr + (16 * kc + 4) * LROW + mh * 64));
+        const v8u16 xv = {(uint16_t)lo[0], (uint16_t)lo[1], (uint16_t)lo[2], (uint16_t)lo[3], (uint16_t)hi[0], (uint16_t)hi[1], (uint16_t)hi[2], (uint16_t)hi[3]};
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(hf[kc], __builtin_bit_cast(v8bf, xv), acc, 0, 0, 0);
       }
       // acc[4q+e] = y[m][8q + 4 half + e]   (quartet_bwd_sm120.cu:304-323 / :407-426)
@@ -163,15 +227,31 @@ __global__ __launch_bounds__(512) void bwd_quant_t_kernel(const BwdTParams p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) amax = fmaxf(amax, fabsf(acc[r]));
       amax = xhalf_max(amax);
-      float scale = QT ? amax / alpha : amax;
-      const uint32_t sb = __float_as_uint(scale) & 0x7f800000u;
-      scale = __uint_as_float(sb);
-      const float mult = QT ? 3.0f / (scale * alpha) : 3.0f / scale;
+      // e8m0 byte + multiplier.  Fast path (see the header comment): amax in [2^-60, 2^60] and alpha in [2^-30, 2^30].
+      const uint32_t ab = __float_as_uint(amax);
+      uint32_t sb = (ab - Kexp) & 0x7f800000u;
+      float mfac = c3, cs = __uint_as_float(sb);
+      const bool fast = HWCVT && alpha_fast && ab >= 0x21800000u && ab <= 0x5d800000u;
+      const bool slow_wave = __builtin_amdgcn_ballot_w64(!fast) != 0;
+      if (slow_wave) {   // wave-uniform: the reference's arithmetic as written (quartet_bwd_sm120.cu:304-323)
+        float scale = QT ? amax / alpha : amax;
+        const uint32_t sbs = __float_as_uint(scale) & 0x7f800000u;
+        scale = __uint_as_float(sbs);
+        const float mult = QT ? 3.0f / (scale * alpha) : 3.0f / scale;
+        sb = fast ? sb : sbs;
+        mfac = fast ? mfac : mult;
+        cs = fast ? cs : 1.0f;
+      }
       float tq[16];
+      scale_pk<16>(acc, 0, mfac, tq);   // (software encoder, !HWCVT: never the fast path, cs == 1 and unused)
+      if (slow_wave) {
+        // 0 * inf (all-zero group: 3 / 0 = inf) and inf * 0 are NaN, which cvt.rn.satfinite.e2m1x2 encodes as +6 whatever its sign; the
+        // gfx950 convert keeps the NaN's sign bit, and v_pk_mul_f32 hands back a NEGATIVE quiet NaN here (codes 0xF): make it the positive one
 #pragma unroll
-      for (int r = 0; r < 16; ++r) tq[r] = acc[r] * mult;
-      const uint32_t P = e2m1_pack8<HWCVT>(tq);
-      const uint32_t Q = e2m1_pack8<HWCVT>(tq + 8);
+        for (int r = 0; r < 16; ++r) tq[r] = (tq[r] != tq[r]) ? __uint_as_float(0x7fc00000u) : tq[r];
+      }
+      const uint32_t P = e2m1_pack8<HWCVT>(tq, cs);
+      const uint32_t Q = e2m1_pack8<HWCVT>(tq + 8, cs);
       auto sw = __builtin_amdgcn_permlane32_swap(P, Q, false, false);
       const uint32_t X = sw[0], Y = sw[1];
       v2i o;
@@ -182,14 +262,13 @@ __global__ __launch_bounds__(512) void bwd_quant_t_kernel(const BwdTParams p) {
     }
     __syncthreads();   // the workgroup's [64 m][8 groups] output tile is staged (and every wave is done with its bf16 tile)
     {
-      const int r = tid >> 3, pc = tid & 7;            // 512 pieces of 16 bytes: row r, group g0 + pc
-      const int m = m0 + r, g = g0 + pc;
-      if (m < p.M && g < G) {
-        const int64_t grp = ((int64_t)b * p.M + m) * G + g;
-        *(v4i*)(p.out + grp * 16) = *(const v4i*)(out_s + r * OROW + pc * 16);
-      }
+      // 512 pieces of 16 bytes: row tid/8, group g0 + tid%8.  Rows past M fall off the descriptor (its extent is the tile's valid rows).
+      const int rows = min(64, p.M - m0);
+      const __amdgpu_buffer_rsrc_t ro = make_rsrc(p.out + grp0 * 16, (uint32_t)rows * (uint32_t)G * 16u - (uint32_t)g0 * 16u);
+      const uint32_t so = (g0 + (tid & 7) < G) ? st_off : OOB;
+      __builtin_amdgcn_raw_buffer_store_b128(*(const v4i*)(out_s + (tid >> 3) * OROW + (tid & 7) * 16), ro, (int)so, 0, 0);
       if (tid < 64 && m0 + tid < p.M) {
-        uint8_t* dst = p.out_sf + ((int64_t)b * p.M + m0 + tid) * G + g0;
+        uint8_t* dst = p.out_sf + grp0 + (int64_t)tid * G;
         if ((G & 7) == 0) {
           *(v2i*)dst = *(const v2i*)(sf_s + tid * 8);   // 8-byte aligned: G % 8 == 0 and g0 % 8 == 0
         } else {
@@ -301,7 +380,15 @@ __global__ __launch_bounds__(256) void mxfp4_transpose_mxfp8_kernel(const TrPara
   __shared__ __attribute__((aligned(16))) char ts_all[4][32 * LROW];
   const int tid = threadIdx.x, lane = tid & 63, wave = uniform(tid >> 6);
   const int tiles_n = p.n / NC;
-  const int ti = blockIdx.x / tiles_n, tj = blockIdx.x % tiles_n;
+  // [r3] NC = 128: a tile reads 64 of the 128 bytes of each of its input lines, the tile next to it (tj ^ 1) the other 64.  Workgroup ids go round
+  // the 8 XCDs, so the two landed on different XCDs and each L2 fetched the whole line: FETCH_SIZE 82 MB for 35.6 MB of input at 8192^2
+  // (profiles/pmc_stream_ops_r3.txt).  Pairs now sit on one XCD, one dispatch slot apart (tiles_n is even: n % 256 == 0).
+  unsigned t = blockIdx.x;
+  if (NC == 128 && t < (gridDim.x & ~15u)) {
+    const unsigned x = t & 7u, k = t >> 3;
+    t = 2u * ((k >> 1) * 8u + x) + (k & 1u);
+  }
+  const int ti = (int)(t / (unsigned)tiles_n), tj = (int)(t % (unsigned)tiles_n);
   const int r0 = ti * 128 + wave * 32, c0 = tj * NC;
   char* ts = ts_all[wave];
 #pragma unroll

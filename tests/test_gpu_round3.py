@@ -374,3 +374,53 @@ def test_fused_quantize_matmul_wrapper_dispatch_and_errors(q):
         torch.ops.qutlass_amd.fusedQuantizeMatmulMxf4(x, _hadamard(64), w_q, w_sf, alpha, 1)
     with pytest.raises(ValueError):
         q.fused_quantize_matmul_mxf4_bf16_tn(x, h, w_q, w_sf, alpha, method="nope")
+
+
+# ------------------------------------------------------------------------------------------------
+# [r3] division-free scales of backward_t_bf16 / backward_qt_bf16 (quartet_bwd.hip.h): the e8m0 byte comes from an integer
+# subtraction of float bit patterns and the multiplier from RN(3 / alpha) * 2^-E.  Identity rotation => y is the operand itself, so
+# amax is exactly (1 | 1.5) * 2^e and alpha values AT, one ulp above and one ulp below those mantissas hit the borrow boundary of the
+# exponent arithmetic; zero groups (the reference's 3/0 = inf, 0 * inf = NaN -> code 7), scales outside [2^-60, 2^60] and alpha
+# outside [2^-30, 2^30] take the division path.  Everything must equal the oracle's divisions byte for byte
+# (quartet_bwd_sm120.cu:304-323 / :407-426).
+# ------------------------------------------------------------------------------------------------
+def _f32(x):
+    return float(np.float32(x))
+
+
+@pytest.mark.parametrize("alpha", [1.0, 3.0, 1.5, _f32(np.nextafter(np.float32(1.5), np.float32(2))), _f32(np.nextafter(np.float32(1.5), np.float32(1))),
+                                   _f32(np.nextafter(np.float32(2.0), np.float32(1))), 0.37, 1e-3, 777.25, 2.0 ** -31, 2.0 ** 31, 1e-12])
+def test_backward_qt_division_free_scales_equal_the_divisions(q, alpha):
+    rng = np.random.default_rng(int(abs(np.log2(alpha)) * 1000) + 5)
+    N, M = 256, 192
+    eye = torch.eye(32, dtype=torch.bfloat16, device=DEV)
+    codes = rng.integers(0, 256, size=(1, N, M // 2), dtype=np.uint8)
+    scales = rng.integers(100, 150, size=(1, N, M // 32), dtype=np.uint8)
+    codes[0, 32:64, :] = 0                      # all-zero groups for every m: amax = 0
+    codes[0, 64:96, 16:32] = 0x88               # negative zeros
+    scales[0, 96:128, :] = rng.integers(10, 60, size=(32, M // 32))     # amax far below 2^-60 (values stay normal bf16 numbers)
+    scales[0, 128:160, :] = rng.integers(200, 254, size=(32, M // 32))  # far above 2^60
+    xq, xs = torch.from_numpy(codes).to(DEV), torch.from_numpy(scales).to(DEV).view(torch.float8_e8m0fnu)
+    for h in (eye, _hadamard(32)):
+        e2m1, e8m0 = q.backward_qt_bf16(xq, xs, h, torch.tensor([alpha], device=DEV))
+        rq, rs = oracle.backward_qt_bf16(codes, scales, _np(h), alpha, acc_model=1)
+        assert np.array_equal(_np(e8m0), rs), (alpha, int((_np(e8m0) != rs).sum()))
+        eq = oracle.codes_equal_mod_zero_sign(_np(e2m1).reshape(rq.shape), rq)
+        assert int((~eq).sum()) <= (0 if h is eye else 1e-4 * eq.size), (alpha, int((~eq).sum()))
+
+
+def test_backward_t_division_free_scales_equal_the_divisions(q):
+    rng = np.random.default_rng(77)
+    N, M = 256, 200
+    x = (rng.standard_normal((2, N, M)) * 25.0).astype(np.float32)
+    x[0, 32:64, :] = 0.0                                   # zero groups: scale 0 -> NaN -> code 7
+    x[0, 64:96, :] *= 1e-25                                # amax below 2^-60
+    x[0, 96:128, :] *= 1e25                                # above 2^60
+    x[1, 0:32, :] = np.ldexp(rng.choice([1.0, 1.5, -1.0, 0.5], size=(32, M)), rng.integers(-70, 70, size=(1, M)))   # exact powers of two / 1.5 * 2^e per column
+    xt = torch.from_numpy(x).to(torch.bfloat16).to(DEV)
+    for h in (torch.eye(32, dtype=torch.bfloat16, device=DEV), _hadamard(32)):
+        e2m1, e8m0 = q.backward_t_bf16(xt, h)
+        rq, rs = oracle.backward_t_bf16(_np(xt), _np(h), acc_model=1)
+        assert np.array_equal(_np(e8m0), rs), int((_np(e8m0) != rs).sum())
+        eq = oracle.codes_equal_mod_zero_sign(_np(e2m1).reshape(rq.shape), rq)
+        assert int((~eq).sum()) <= 1e-4 * eq.size, int((~eq).sum())

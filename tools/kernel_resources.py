@@ -17,6 +17,8 @@ from concurrent.futures import ThreadPoolExecutor
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "qutlass_amd", "csrc", "capi.hip")
+sys.path.insert(0, ROOT)
+from qutlass_amd.build import TU_FLAGS  # noqa: E402  (per-unit compiler flags of the product build)
 FIELDS = {"TotalSGPRs": "sgpr", "VGPRs": "vgpr", "AGPRs": "agpr", "ScratchSize [bytes/lane]": "scratch", "Occupancy [waves/SIMD]": "occ",
           "SGPRs Spill": "sgpr_spill", "VGPRs Spill": "vgpr_spill", "LDS Size [bytes/block]": "lds"}
 
@@ -30,7 +32,7 @@ def demangle(names):
 def unit(tu: int, lab: bool):
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", f"-DQAMD_TU={tu}", "--cuda-device-only",
-           "-Rpass-analysis=kernel-resource-usage", "-c", SRC, "-o", os.devnull] + (["-DQAMD_BENCH=1"] if lab else [])
+           "-Rpass-analysis=kernel-resource-usage", "-c", SRC, "-o", os.devnull] + (["-DQAMD_BENCH=1"] if lab else []) + TU_FLAGS.get(tu, [])
     err = subprocess.run(cmd, capture_output=True, text=True).stderr
     kernels, cur = {}, None
     for line in err.splitlines():
