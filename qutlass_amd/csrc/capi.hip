@@ -1131,9 +1131,6 @@ int qutlass_amd_backward_t_bf16(const void* x, const void* h, int64_t B, int64_t
   BwdTParams p{};
   p.x = (const uint16_t*)x; p.h = (const uint16_t*)h; p.out = (uint8_t*)out_e2m1; p.out_sf = (uint8_t*)out_e8m0;
   p.B = (int)B; p.N = (int)N; p.M = (int)M; p.tiles_m = (int)cdiv(M, 64);
-  // [r3] m fastest: the workgroups that run together read whole input rows (every tile takes full 128-byte lines of 256 rows 2 M bytes apart;
-  // with the n-blocks fastest the resident set touched 2 KB of each of 8192 rows: 8192^2 cold 42.1 -> 37.6 us, 4096^2 12.9 -> 10.6; tools/ab_multi.py)
-  p.m_fast = 1;
   if (B * (N / 32) * p.tiles_m >= (1ll << 31) - 65536) return fail(QAMD_ERR_INVALID, "%s: tensor too large", name);
   const int64_t ntw = B * p.tiles_m * cdiv(N / 32, 8);   // workgroup tiles: 8 scale groups (256 n) x 64 m
   const int grid = (int)std::min<int64_t>(ntw, chip_cus() * 2);   // several tiles per workgroup: the kernel prefetches the next tile
@@ -1153,17 +1150,14 @@ int qutlass_amd_backward_qt_bf16(const void* x_e2m1, const void* x_e8m0, const v
   p.xq = (const uint8_t*)x_e2m1; p.xs = (const uint8_t*)x_e8m0; p.h = (const uint16_t*)h; p.alpha = alpha;
   p.out = (uint8_t*)out_e2m1; p.out_sf = (uint8_t*)out_e8m0;
   p.B = (int)B; p.N = (int)N; p.M = (int)M; p.tiles_m = (int)cdiv(M, 64);
-  // n-blocks fastest: a tile reads 32 of the 128 bytes of each input line, and the four m-tiles that share the lines must run on the same XCD
-  // at about the same time to share them in its L2 -- they are N / 256 tiles apart, i.e. on the same XCD (workgroup id mod 8) whenever N is a
-  // multiple of 2048; m fastest puts them on four XCDs and costs a quarter more time (8192^2: 24.5 -> 31.4 us, tools/ab_multi.py)
-  p.m_fast = 0;
   if (B * (N / 32) * p.tiles_m >= (1ll << 31) - 65536) return fail(QAMD_ERR_INVALID, "%s: tensor too large", name);
-  const int64_t ntw = B * p.tiles_m * cdiv(N / 32, 8);
+  // virtual tiles: units of 4 sibling m-tiles (bwd_quant_t_kernel's tile order); the grid is a multiple of 32 workgroups (4 siblings x 8 XCDs)
+  const int64_t ntw = B * cdiv(p.tiles_m, 4) * 4 * cdiv(N / 32, 8);
   // 49 KB of LDS per workgroup: three fit a CU.  A round of three per CU takes ~1.24x a round of two (8192^2: 6 rounds 20.7 us against 8 rounds
   // 22.2 us; 4096^2, 2 rounds either way: 9.3 against 8.5 us): three when that wins the round count
   const int64_t cu = chip_cus();
   const int per_cu = 1.24 * (double)cdiv(ntw, 3 * cu) < (double)cdiv(ntw, 2 * cu) ? 3 : 2;
-  const int grid = (int)std::min<int64_t>(ntw, cu * per_cu);
+  const int grid = (int)std::max<int64_t>(32, std::min<int64_t>(cdiv(ntw, 32) * 32, cu * per_cu / 32 * 32));
   if (g_hw_fp4_cvt.load()) hipLaunchKernelGGL((bwd_quant_t_kernel<true, true>), dim3(grid), dim3(512), 0, (hipStream_t)stream, p);
   else hipLaunchKernelGGL((bwd_quant_t_kernel<true, false>), dim3(grid), dim3(512), 0, (hipStream_t)stream, p);
   return check_launch("bwd_quant_t_kernel");

@@ -33,7 +33,6 @@ struct BwdTParams {
   uint8_t* out_sf;          // e8m0 (B, M, N/32)
   int B, N, M;
   int tiles_m;              // ceil(M / 64); B * (N/32) * tiles_m < 2^31 (host-checked): the kernel indexes tiles in 32 bits
-  int m_fast;               // tile order inside a batch: 1 = m-tiles fastest, 0 = n-blocks (of 8 scale groups) fastest
 };
 
 // One wave = one [32 n][64 m] tile = one scale group for 64 output rows; the 8 waves of a workgroup take 8 consecutive
@@ -83,22 +82,30 @@ __global__ __launch_bounds__(512) void bwd_quant_t_kernel(const BwdTParams p) {
   const float alpha = QT ? *p.alpha : 1.0f;
   const int G = p.N >> 5;
   const int ngb = (G + 7) >> 3;                       // blocks of 8 scale groups
-  // Tile coordinates (b, o, i), all wave-uniform: i = the fast index inside a batch (m_fast: the m-tile, else the block of 8 scale groups), o the
-  // other one.  A workgroup walks tiles blockIdx.x, + gridDim.x, ...: the step is decomposed once, the walk is two carry-propagating adds.
-  // The two 64-bit tile origins ride along: `in` = element index of the tile's first input element for wave 0, (b N + 256 gb) M + 64 tm, and
-  // `grp` = index of its first output scale group, (b M + 64 tm) G + 8 gb -- both linear in (b, o, i), so a step is one add and a carry a second.
-  const int n_i = p.m_fast ? p.tiles_m : ngb, n_o = p.m_fast ? ngb : p.tiles_m;
-  const int64_t in_b = (int64_t)p.N * p.M, in_tm = 64, in_gb = 256ll * p.M, gr_b = (int64_t)p.M * G, gr_tm = 64ll * G, gr_gb = 8;
-  const int64_t in_i = p.m_fast ? in_tm : in_gb, in_o = p.m_fast ? in_gb : in_tm, gr_i = p.m_fast ? gr_tm : gr_gb, gr_o = p.m_fast ? gr_gb : gr_tm;
+  // Tile order: m fastest.  T -- the workgroups that run together then read whole input rows (every tile takes full 128-byte lines of 256 rows
+  // 2 M bytes apart; with the n-blocks fastest the resident set touched 2 KB of each of 8192 rows: 8192^2 cold 42.1 -> 37.6 us).  QT -- a tile
+  // reads 32 of the 128 bytes of each of its input lines, so the SIB = 4 m-tiles that share the lines are dispatched as one unit: workgroup ids go
+  // round the 8 XCDs, and ids 32 j + 8 s + x (s = 0..3) -- same XCD x, one dispatch window -- take the four siblings of unit 8 j + x; the XCD's L2
+  // then fetches each line once (with plain m-fastest order the siblings sat on four XCDs: 24.5 -> 31.4 us at 8192^2), and the units that run
+  // together spread over all line columns, i.e. all L2 / HBM channels (n-blocks fastest kept them on four columns).  The host makes
+  // gridDim.x a multiple of 32 for QT.
+  // Unit coordinates (b, o, i), all wave-uniform: i = m-tile (T) / quad of m-tiles (QT), o = block of 8 scale groups.  A workgroup walks units
+  // u0, u0 + step, ...: the step is decomposed once, the walk is two carry-propagating adds.  The two 64-bit tile origins ride along: `in` =
+  // element index of the tile's first input element for wave 0, (b N + 256 gb) M + 64 tm, and `grp` = index of its first output scale group,
+  // (b M + 64 tm) G + 8 gb -- both linear in (b, o, i), so a step is one add and a carry a second.
+  constexpr int SIB = QT ? 4 : 1;
+  const int sib = QT ? (int)(blockIdx.x & 31u) >> 3 : 0;
+  const int n_i = (p.tiles_m + SIB - 1) / SIB, n_o = ngb;
+  const int64_t in_b = (int64_t)p.N * p.M, in_i = 64 * SIB, in_o = 256ll * p.M, gr_b = (int64_t)p.M * G, gr_i = 64ll * SIB * G, gr_o = 8;
   struct Tile { int b, o, i; int64_t in, grp; };
-  auto split = [&](unsigned t) __attribute__((always_inline)) {
-    const unsigned q = t / (unsigned)n_i;
-    Tile r{(int)(q / (unsigned)n_o), (int)(q % (unsigned)n_o), (int)(t % (unsigned)n_i), 0, 0};
+  auto split = [&](unsigned u) __attribute__((always_inline)) {
+    const unsigned q = u / (unsigned)n_i;
+    Tile r{(int)(q / (unsigned)n_o), (int)(q % (unsigned)n_o), (int)(u % (unsigned)n_i), 0, 0};
     r.in = r.b * in_b + r.o * in_o + r.i * in_i;
     r.grp = r.b * gr_b + r.o * gr_o + r.i * gr_i;
     return r;
   };
-  const Tile step = split(gridDim.x);
+  const Tile step = split(QT ? gridDim.x >> 2 : gridDim.x);
   const int64_t in_c1 = in_o - n_i * in_i, in_c2 = in_b - n_o * in_o, gr_c1 = gr_o - n_i * gr_i, gr_c2 = gr_b - n_o * gr_o;
   auto advance = [&](Tile t) __attribute__((always_inline)) {
     t.i += step.i;
@@ -131,7 +138,7 @@ __global__ __launch_bounds__(512) void bwd_quant_t_kernel(const BwdTParams p) {
   uint8_t ld_e = 0;   // (kept as the loaded byte and widened at its use: widened here, the zero-extension lands behind the load at the loop
                       //  latch, and with it the wait for the load just issued)
   auto load_tile = [&](const Tile t) __attribute__((always_inline)) {
-    const int m0 = (p.m_fast ? t.i : t.o) * 64, g = (p.m_fast ? t.o : t.i) * 8 + wave;
+    const int m0 = (t.i * SIB + sib) * 64, g = t.o * 8 + wave;
     const bool live = t.b < p.B && g < G;
     const uint32_t voff = (m0 + lcol < p.M) ? ld_off : OOB;           // M % 8 (T) / % 32 (QT) == 0: a chunk is in or out as a whole
     if (!QT) {
@@ -145,7 +152,9 @@ __global__ __launch_bounds__(512) void bwd_quant_t_kernel(const BwdTParams p) {
       ld_e = __builtin_amdgcn_raw_buffer_load_b8(re, (int)((m0 + lcol < p.M) ? lds_off : OOB), 0, 0);   // dropped lanes read 0: their codes are 0 too
     }
   };
-  Tile cur = split(blockIdx.x);
+  Tile cur = split(QT ? (blockIdx.x >> 5) * 8u + (blockIdx.x & 7u) : blockIdx.x);
+  cur.in += sib * 64;                    // this workgroup's sibling: the same m-tile of every unit it walks
+  cur.grp += (int64_t)sib * 64 * G;
   // [r2] T: the first tile's loads are issued BEFORE the rotation matrix is staged (the two memory round trips overlap: 13.7 -> 12.9 us
   // cold at 4096^2).  QT keeps them after it: its tile is 1/4 of the bytes and hoisting measured +4 % warm (profiles/ab_stream_ops_r2.txt)
   if (!QT) load_tile(cur);
@@ -175,8 +184,13 @@ __global__ __launch_bounds__(512) void bwd_quant_t_kernel(const BwdTParams p) {
   const char* tr_ptr = ts + (8 * half + ((lane & 15) >> 2)) * LROW + (((lane & 31) >> 4) * 16 + (lane & 3) * 4) * 2;
 
   while (cur.b < p.B) {   // uniform over the workgroup: barriers inside are safe
-    const int m0 = (p.m_fast ? cur.i : cur.o) * 64, g0 = (p.m_fast ? cur.o : cur.i) * 8;
+    const int m0 = (cur.i * SIB + sib) * 64, g0 = cur.o * 8;
     const int64_t grp0 = cur.grp;
+    if (QT && m0 >= p.M) {   // a sibling past the last m-tile (tiles_m not a multiple of 4): nothing staged, nothing stored
+      cur = advance(cur);
+      load_tile(cur);
+      continue;
+    }
 
     // ---- stage the [32 n][64 m] bf16 tile in LDS ---------------------------------------------------------------
     if (!QT) {

@@ -424,3 +424,18 @@ def test_backward_t_division_free_scales_equal_the_divisions(q):
         assert np.array_equal(_np(e8m0), rs), int((_np(e8m0) != rs).sum())
         eq = oracle.codes_equal_mod_zero_sign(_np(e2m1).reshape(rq.shape), rq)
         assert int((~eq).sum()) <= 1e-4 * eq.size, int((~eq).sum())
+
+
+@pytest.mark.parametrize("B,N,M", [(2, 512, 320), (1, 96, 64), (3, 32, 1056), (1, 2080, 160)])
+def test_backward_qt_sibling_tile_units_cover_ragged_shapes(q, B, N, M):
+    """bwd_quant_t_kernel<QT> walks units of 4 sibling m-tiles (quartet_bwd.hip.h): m-tile counts that are not multiples of 4, group counts
+    that are not multiples of 8, batches, and grids padded to 32 workgroups must all produce the oracle's bytes."""
+    rng = np.random.default_rng(B * 1000 + N + M)
+    codes = rng.integers(0, 256, size=(B, N, M // 2), dtype=np.uint8)
+    scales = rng.integers(110, 140, size=(B, N, M // 32), dtype=np.uint8)
+    h = _hadamard(32)
+    e2m1, e8m0 = q.backward_qt_bf16(torch.from_numpy(codes).to(DEV), torch.from_numpy(scales).to(DEV).view(torch.float8_e8m0fnu), h, torch.tensor([3.0], device=DEV))
+    rq, rs = oracle.backward_qt_bf16(codes, scales, _np(h), 3.0, acc_model=1)
+    assert np.array_equal(_np(e8m0), rs), int((_np(e8m0) != rs).sum())
+    eq = oracle.codes_equal_mod_zero_sign(_np(e2m1).reshape(rq.shape), rq)
+    assert int((~eq).sum()) <= 1e-4 * eq.size, int((~eq).sum())

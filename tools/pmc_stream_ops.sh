@@ -30,3 +30,4 @@ run tcc2 "WRITE_SIZE"
 run tcc3 "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum"
 run tcp1 "TCP_TCC_READ_REQ_sum TCP_TA_DATA_STALL_CYCLES_sum TA_BUSY_avr TCP_PENDING_STALL_CYCLES_sum"
 cd $R; python tools/rocprof_summary.py $OUT/*/p_results.db 2>&1 | grep -E "qamd|calls|dispatches|==" | grep -v "vectorized\|distribution\|rocclr" > $OUT/summary.txt; cut -c1-160 $OUT/summary.txt
+rm -rf $OUT/sq1 $OUT/sq2 $OUT/sq3 $OUT/tcc1 $OUT/tcc2 $OUT/tcc3 $OUT/tcp1   # the result databases are ~10 MB each: keep the summary and the logs only
