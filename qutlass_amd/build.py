@@ -66,8 +66,16 @@ def _compile_units(out: str, num_tu: int, extra: list, verbose: bool) -> None:
         cmds = [base + TU_FLAGS.get(i, []) + [f"-DQAMD_TU={i}", "-c", SRC, "-o", o] for i, o in zip(range(1, num_tu + 1), objs)]
         if verbose:
             print(" ".join(cmds[0]), f"   (x{num_tu}: QAMD_TU=1..{num_tu}, in parallel)")
+        def run(cmd):
+            rc = subprocess.run(cmd).returncode
+            if rc != 0 and any(f in cmd for fl in TU_FLAGS.values() for f in fl):   # a compiler without the per-unit flag: build that unit plainly
+                plain = [a for a in cmd if not any(a == f for fl in TU_FLAGS.values() for f in fl)]
+                print("qutlass_amd.build: retrying without the per-unit compiler flags:", " ".join(plain[-6:]))
+                rc = subprocess.run(plain).returncode
+            return rc
+
         with ThreadPoolExecutor(max_workers=min(num_tu, os.cpu_count() or 1)) as ex:
-            for rc, cmd in zip(ex.map(lambda c: subprocess.run(c).returncode, cmds), cmds):
+            for rc, cmd in zip(ex.map(run, cmds), cmds):
                 if rc != 0:
                     raise subprocess.CalledProcessError(rc, cmd)
         # -Bsymbolic: the product and the lab library export the same C names and may live in one process
