@@ -199,58 +199,65 @@ __global__ __launch_bounds__(C::THREADS) void gemm_nvf4_kernel(const NvGemmParam
 
   // A stage is 16 k-steps of 16 elements: step s = (j, u) with chunk j = s / 4 (scale column tile jj = j / 2, byte pair
   // jl = j % 2) and dword u = s % 4.  Software pipeline with TWO fragment register sets: the converts of step s + 1 write
-  // set (s + 1) & 1 while the MFMAs of step s read set s & 1, so the scheduler is free to run one step's MFMAs under the
-  // next step's converts.  (An explicit "1 MFMA : n VALU" sched_group_barrier pattern gave the same ISA shape but cost
-  // 150 s of compile time for the five tile configurations; not kept.)  Measured: 8192^3 with zero-filled operands (not
-  // power limited) 762 -> 691 us; random operands unchanged (power cap); small tiles unchanged -- they are bound by the
-  // VALU itself (8 packed-f16 converts / multiplies per 8 elements at ~6 cycles each, tests/native/ubench.hip "valu": 512
-  // of them per stage and wave of a 128x128 tile = 1.6 us).
-  auto compute_stage = [&](int buf) {
-    const char* st = smem + buf * C::STAGE_BYTES;
-    h2_t sa[2][MT][2], sb[2][NT][2];     // [jj & 1][.][jl]
-    v4i ca[2][MT], cb[2][NT];            // [j & 1]
-    h8_t fa[2][MT], fb[2][NT];           // [s & 1]
-    auto load_scales = [&](const int jj) __attribute__((always_inline)) {
+  // set (s + 1) & 1 while the MFMAs of step s read set s & 1.
+  //
+  // [r3] Who issues when.  A 32x32x16 f16 MFMA holds the matrix pipe for 32 cycles and the 4-5 converts / multiplies that belong to it issue in
+  // 16-20 of them -- but only if they sit BETWEEN the MFMAs in program order: with one wave per SIMD (the 256-row tiles) there is no second wave
+  // to fill the shadow, and the scheduler's own order was runs of 4-7 MFMAs followed by runs of 16-24 converts, i.e. the two units took turns
+  // (13 100 cycles per stage = 8192 of MFMA + 5000 of VALU; zero-filled operands at 2.4 GHz and random ones at the power-limited 1.95 GHz took
+  // the same CYCLES).  For those tiles (FENCE) every MFMA is followed by its share of the next step's dequantisation and a scheduling fence;
+  // the second scale column tile of a stage is converted two row sets per step in the shadows of steps 1..4.  8192^3: 784 -> 736 us, -5 ... -8 % on
+  // every shape that runs 256-row tiles, bit-identical (tools/ab_nvf4.py).  Also measured: the stage hand-off moved INTO the stage (after step 8
+  // nobody reads the stage's LDS buffer any more, so wait + barrier + re-issue at step 11 and the next stage's first scales / first step in the
+  // shadows of steps 11..15, i.e. nothing exposed at the top of a stage): correct, and no faster (0.949 against 0.938 of the old time) -- the
+  // kernel is at the socket power limit once the two units overlap; not kept.
+  // The smaller tiles run several workgroups per CU, whose waves fill each other's shadows, and lose 5 % to a fixed order: they keep the
+  // plain loop.
+  constexpr bool FENCE = BM >= 256;
+  constexpr int NSLOT = MT * NT, NH = 2 * (MT + NT);
+  h2_t sa[2][MT][2], sb[2][NT][2];     // [jj & 1][.][jl]
+  v4i ca[2][MT], cb[2][NT];            // [j & 1]
+  h8_t fa[2][MT], fb[2][NT];           // [s & 1]
+  auto load_scale1 = [&](const char* st, const int jj, const int f) __attribute__((always_inline)) {   // one row set's dword of 4 e4m3 scales -> f16 pairs
+    if (f < MT) e4m3x4_to_f16(*(const uint32_t*)(st + rdSA[f] + jj * 512), sa[jj & 1][f][0], sa[jj & 1][f][1]);
+    else e4m3x4_to_f16(*(const uint32_t*)(st + rdSB[f - MT] + jj * 512), sb[jj & 1][f - MT][0], sb[jj & 1][f - MT][1]);
+  };
+  auto load_scales = [&](const char* st, const int jj) __attribute__((always_inline)) {
 #pragma unroll
-      for (int t = 0; t < MT; ++t) e4m3x4_to_f16(*(const uint32_t*)(st + rdSA[t] + jj * 512), sa[jj & 1][t][0], sa[jj & 1][t][1]);
+    for (int f = 0; f < MT + NT; ++f) load_scale1(st, jj, f);
+  };
+  auto load_chunks = [&](const char* st, const int j) __attribute__((always_inline)) {
 #pragma unroll
-      for (int t = 0; t < NT; ++t) e4m3x4_to_f16(*(const uint32_t*)(st + rdSB[t] + jj * 512), sb[jj & 1][t][0], sb[jj & 1][t][1]);
-    };
-    auto load_chunks = [&](const int j) __attribute__((always_inline)) {
+    for (int t = 0; t < MT; ++t) ca[j & 1][t] = *(const v4i*)(st + rdA[j] + t * 32 * C::ROWB);
 #pragma unroll
-      for (int t = 0; t < MT; ++t) ca[j & 1][t] = *(const v4i*)(st + rdA[j] + t * 32 * C::ROWB);
-#pragma unroll
-      for (int t = 0; t < NT; ++t) cb[j & 1][t] = *(const v4i*)(st + rdB[j] + t * 32 * C::ROWB);
-    };
-    auto dq_step = [&](const int s) __attribute__((always_inline)) {
-      const int j = s >> 2, u = s & 3, jj = j >> 1, jl = j & 1;
-#pragma unroll
-      for (int t = 0; t < MT; ++t) {
-        const _Float16 sc = sa[jj & 1][t][jl][u >> 1];
-        fa[s & 1][t] = dq8((uint32_t)ca[j & 1][t][u], h2_t{sc, sc});
-      }
-#pragma unroll
-      for (int t = 0; t < NT; ++t) {
-        const _Float16 sc = sb[jj & 1][t][jl][u >> 1];
-        fb[s & 1][t] = dq8((uint32_t)cb[j & 1][t][u], h2_t{sc, sc});
-      }
-    };
-    load_scales(0);
-    load_chunks(0);
-    dq_step(0);
-#pragma unroll
-    for (int s = 0; s < 16; ++s) {
-      if (s + 1 < 16) {
-        if (s == 1) load_scales(1);                                        // second scale column tile: used from step 8
-        if ((s & 3) == 0 && (s >> 2) + 1 < 4) load_chunks((s >> 2) + 1);   // raw chunk of j + 1: one chunk (4 steps) ahead
-        dq_step(s + 1);
-      }
-#pragma unroll
-      for (int m = 0; m < MT; ++m)
-#pragma unroll
-        for (int n = 0; n < NT; ++n)
-          acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb[s & 1][n], fa[s & 1][m], acc[m][n], 0, 0, 0);
+    for (int t = 0; t < NT; ++t) cb[j & 1][t] = *(const v4i*)(st + rdB[j] + t * 32 * C::ROWB);
+  };
+  // half of one fragment of step s: dword bytes 2 hh, 2 hh + 1 -> elements 4 hh .. 4 hh + 3 (2 converts + 2 packed multiplies)
+  auto dq_half = [&](const int s, const int f, const int hh) __attribute__((always_inline)) {
+    const int j = s >> 2, u = s & 3, jj = j >> 1, jl = j & 1;
+    const bool isA = f < MT;
+    const int t = isA ? f : f - MT;
+    const _Float16 sc = isA ? sa[jj & 1][t][jl][u >> 1] : sb[jj & 1][t][jl][u >> 1];
+    const uint32_t w = (uint32_t)(isA ? ca[j & 1][t][u] : cb[j & 1][t][u]);
+    const h2_t s2 = {sc, sc};
+    h2_t lo, hi;
+    if (hh == 0) {
+      lo = __builtin_amdgcn_cvt_scalef32_pk_f16_fp4(w, 1.0f, 0) * s2;
+      hi = __builtin_amdgcn_cvt_scalef32_pk_f16_fp4(w, 1.0f, 1) * s2;
+    } else {
+      lo = __builtin_amdgcn_cvt_scalef32_pk_f16_fp4(w, 1.0f, 2) * s2;
+      hi = __builtin_amdgcn_cvt_scalef32_pk_f16_fp4(w, 1.0f, 3) * s2;
     }
+    h8_t& d = isA ? fa[s & 1][t] : fb[s & 1][t];
+    d[4 * hh + 0] = lo[0]; d[4 * hh + 1] = lo[1]; d[4 * hh + 2] = hi[0]; d[4 * hh + 3] = hi[1];
+  };
+  auto dq_step = [&](const int s) __attribute__((always_inline)) {
+#pragma unroll
+    for (int f = 0; f < MT + NT; ++f) { dq_half(s, f, 0); dq_half(s, f, 1); }
+  };
+  auto mfma_slot = [&](const int s, const int i) __attribute__((always_inline)) {
+    const int m = i / NT, n = i % NT;
+    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb[s & 1][n], fa[s & 1][m], acc[m][n], 0, 0, 0);
   };
 
   issue_stage(0, 0);
@@ -258,7 +265,35 @@ __global__ __launch_bounds__(C::THREADS) void gemm_nvf4_kernel(const NvGemmParam
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (kt + 1 < KT) issue_stage(kt + 1, (kt + 1) & 1);
-    compute_stage(kt & 1);
+    const char* st = smem + (kt & 1) * C::STAGE_BYTES;
+    load_scales(st, 0);
+    load_chunks(st, 0);
+    dq_step(0);
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+      if (s + 1 < 16) {
+        if (!FENCE && s == 1) load_scales(st, 1);                              // second scale column tile: used from step 8
+        if ((s & 3) == 0 && (s >> 2) + 1 < 4) load_chunks(st, (s >> 2) + 1);   // raw chunk of j + 1: one chunk (4 steps) ahead
+        if (!FENCE) dq_step(s + 1);
+      }
+#pragma unroll
+      for (int i = 0; i < NSLOT; ++i) {
+        mfma_slot(s, i);
+        if (FENCE) {
+          if (s + 1 < 16) {
+#pragma unroll
+            for (int h = i * NH / NSLOT; h < (i + 1) * NH / NSLOT; ++h) dq_half(s + 1, h >> 1, h & 1);
+          }
+          // this stage's second scale column tile (needed by the dequantisation of step 8, which runs in the shadows of step 7): two row sets
+          // per step in steps 1..4 instead of one burst of ~80 instructions
+          if (s >= 1 && s <= 4 && (i == NSLOT / 2 - 1 || i == NSLOT - 1)) {
+            const int f = 2 * (s - 1) + (i == NSLOT - 1 ? 1 : 0);
+            if (f < MT + NT) load_scale1(st, 1, f);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    }
   }
 
   const float alpha = *p.alpha;
