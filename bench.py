@@ -157,27 +157,34 @@ class PowerSampler:
                 pass
 
 
-def event_us(fn, iters, warm=5, min_ms=30.0):
+def event_us(fn, iters, warm=5, min_ms=30.0, sampler=None, tag=None, timed_ms=60.0):
     """average device microseconds per call: back-to-back launches bracketed by HIP events on the current stream, after `warm` calls
-    and at least `min_ms` of the same load (clock ramp)"""
+    and at least `min_ms` of the same load (clock ramp).  With a PowerSampler the timed loop is stretched to >= `timed_ms` (the firmware
+    refreshes its power / clock table every ~12 ms) and bracketed by marks `tag`:0 / `tag`:1."""
     for _ in range(warm):
         fn()
     torch.cuda.synchronize()
-    t0 = time.perf_counter()
+    t0, n = time.perf_counter(), 0
     while (time.perf_counter() - t0) * 1e3 < min_ms:
         for _ in range(10):
             fn()
         torch.cuda.synchronize()
+        n += 10
+    if sampler is not None and tag:
+        iters = max(iters, int(timed_ms * 1e-3 / max((time.perf_counter() - t0) / n, 1e-7)) + 1)
+        sampler.mark(tag + ":0")
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(iters):
         fn()
     e1.record()
     torch.cuda.synchronize()
+    if sampler is not None and tag:
+        sampler.mark(tag + ":1")
     return e0.elapsed_time(e1) * 1e3 / iters
 
 
-def side_configs(q, dev, h32, alpha):
+def side_configs(q, dev, h32, alpha, sampler=None):
     """BASELINE.json configs[2..4] at full size (synthetic operands, resident in HBM; parity of every one of them is what
     tests/test_gpu_baseline_configs.py checks).  Peaks: MI355X_MICROARCH.md dense figures for the MFMA the path computes on --
     FP4 10066, FP8 5033, f16 2516 TFLOP/s (NVFP4 keeps the reference's exact e4m3-per-16 semantics on the f16 MFMA)."""
@@ -185,10 +192,14 @@ def side_configs(q, dev, h32, alpha):
 
     out = {}
 
-    def put(name, us, flops, peak, **extra):
+    def put(name, fn, iters, flops, peak, warm=5, **extra):
+        us = event_us(fn, iters, warm=warm, sampler=sampler if (sampler is not None and sampler.ok) else None, tag=name)
         tf = flops / us * 1e-6
         out[name] = {"us": round(us, 2), "TFLOP/s": round(tf, 1), "roofline": {"bound": "mfma", "achieved": round(tf, 1), "peak": peak, "unit": "TFLOP/s",
                                                                               "frac": round(tf / peak, 4)}, **extra}
+        if sampler is not None and sampler.ok:   # socket power / shader clock while this config ran (which of them sit at the power limit)
+            w = sampler.window(name + ":0", name + ":1")
+            out[name]["power_w"], out[name]["sclk_mhz"] = w["power_w"], w["sclk_mhz"]
 
     # C3: fusedQuantizeMx(H32, abs_max) + MXFP4 GEMM, Llama-3-8B FFN M=4096 N=14336 K=4096
     m, n, k = 4096, 14336, 4096
@@ -199,7 +210,7 @@ def side_configs(q, dev, h32, alpha):
     x_q, x_s = q.fusedQuantizeMx(x, h32, method="abs_max")
     x_sf = to_blocked(x_s)
     fl = 2.0 * m * n * k
-    put("C3_gemm", event_us(lambda: q.matmul_mxf4_bf16_tn(x_q, w_q, x_sf, w_sf, alpha), 100), fl, FP4_DENSE_PEAK_TFLOPS, workload="matmul_mxf4_bf16_tn 4096x14336x4096")
+    put("C3_gemm", lambda: q.matmul_mxf4_bf16_tn(x_q, w_q, x_sf, w_sf, alpha), 100, fl, FP4_DENSE_PEAK_TFLOPS, workload="matmul_mxf4_bf16_tn 4096x14336x4096")
 
     def step3():   # the reference's activation path: three launches (qutlass/__init__.py:149-180, utils.py:160-193)
         a_q, a_s = q.fusedQuantizeMx(x, h32, method="abs_max")
@@ -209,8 +220,8 @@ def side_configs(q, dev, h32, alpha):
         a_q, a_sb = q.fusedQuantizeMxBlocked(x, h32, method="abs_max")
         return q.matmul_mxf4_bf16_tn(a_q, w_q, a_sb, w_sf, alpha)
 
-    put("C3_step", event_us(step3, 100), fl, FP4_DENSE_PEAK_TFLOPS, workload="fusedQuantizeMx(H32, abs_max) + to_blocked + GEMM, weights pre-quantised (3 launches)")
-    put("C3_step_blocked", event_us(step2, 100), fl, FP4_DENSE_PEAK_TFLOPS, workload="fusedQuantizeMxBlocked(H32, abs_max) + GEMM (2 launches; extension)")
+    put("C3_step", step3, 100, fl, FP4_DENSE_PEAK_TFLOPS, workload="fusedQuantizeMx(H32, abs_max) + to_blocked + GEMM, weights pre-quantised (3 launches)")
+    put("C3_step_blocked", step2, 100, fl, FP4_DENSE_PEAK_TFLOPS, workload="fusedQuantizeMxBlocked(H32, abs_max) + GEMM (2 launches; extension)")
     del x, w, w_q, w_s, x_q, x_s, w_sf, x_sf
     # C4: NVFP4 8192^3
     m = n = k = 8192
@@ -223,7 +234,7 @@ def side_configs(q, dev, h32, alpha):
     b_q, b_s = q.fusedQuantizeNv(a, h16, gs)
     del a
     a_sf, b_sf = to_blocked(a_s), to_blocked(b_s)
-    put("C4", event_us(lambda: q.matmul_nvf4_bf16_tn(a_q, b_q, a_sf, b_sf, alpha), 40, warm=3), 2.0 * m * n * k, 2516.0,
+    put("C4", lambda: q.matmul_nvf4_bf16_tn(a_q, b_q, a_sf, b_sf, alpha), 40, 2.0 * m * n * k, 2516.0, warm=3,
         workload="matmul_nvf4_bf16_tn 8192^3 (exact e4m3-per-16 semantics on the f16 MFMA: peak = the 16-bit dense peak)")
     del a_q, b_q, a_s, b_s, a_sf, b_sf
     # C5: MXFP8 4096^3 TN and NN
@@ -233,8 +244,8 @@ def side_configs(q, dev, h32, alpha):
     s8a = to_blocked(torch.randint(120, 131, (m, k // 32), dtype=torch.uint8, device=dev).view(torch.float8_e8m0fnu))
     s8b = to_blocked(torch.randint(120, 131, (n, k // 32), dtype=torch.uint8, device=dev).view(torch.float8_e8m0fnu))
     a8t = a8.view(torch.uint8).T.contiguous().view(torch.float8_e4m3fn)
-    put("C5_tn", event_us(lambda: q.matmul_mxf8_bf16_tn(a8, b8, s8a, s8b, alpha), 200), 2.0 * m * n * k, 5033.0, workload="matmul_mxf8_bf16_tn 4096^3")
-    put("C5_nn", event_us(lambda: q.matmul_mxf8_bf16_nn(a8t, b8, s8a, s8b, alpha), 200), 2.0 * m * n * k, 5033.0, workload="matmul_mxf8_bf16_nn 4096^3 (A stored (K, M))")
+    put("C5_tn", lambda: q.matmul_mxf8_bf16_tn(a8, b8, s8a, s8b, alpha), 200, 2.0 * m * n * k, 5033.0, workload="matmul_mxf8_bf16_tn 4096^3")
+    put("C5_nn", lambda: q.matmul_mxf8_bf16_nn(a8t, b8, s8a, s8b, alpha), 200, 2.0 * m * n * k, 5033.0, workload="matmul_mxf8_bf16_nn 4096^3 (A stored (K, M))")
     return out
 
 
@@ -465,7 +476,6 @@ def main():
     # socket power / shader clock during the timed region (and over the longer window that also holds the per-launch pass: the
     # firmware refreshes its table every ~12 ms, the K-step region of the default run lasts ~70 ms)
     if sampler:
-        sampler.stop()
         if sampler.ok and sampler.samples:
             result["power"] = {"timed_region": sampler.window("timed_start", "timed_end"), "timed_region_plus_per_launch_pass": sampler.window("timed_start", "per_launch_end"),
                                "source": "librocm_smi64 rsmi_dev_power_get / rsmi_dev_gpu_clk_freq_get(SYS), host thread, 2 ms period"}
@@ -494,9 +504,11 @@ def main():
         result["roofline"]["traffic_source"] = note
         if not args.no_configs:
             try:
-                result["configs"] = side_configs(qutlass_amd, dev, h, alpha)
+                result["configs"] = side_configs(qutlass_amd, dev, h, alpha, sampler)
             except Exception as e:   # noqa: BLE001 -- side measurements must not cost the headline line
                 result["configs"] = {"error": f"{type(e).__name__}: {e}"}
+    if sampler:
+        sampler.stop()
 
     if rank == 0:
         if not args.no_cpu_baseline and world == 1:

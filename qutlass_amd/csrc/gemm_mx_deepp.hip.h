@@ -201,43 +201,75 @@ __device__ __forceinline__ void gemm_mx_deepp(char* smem, const GemmParams& p, c
     constexpr int BUF = decltype(bufc)::value;
     constexpr bool FIRST = decltype(firstc)::value;
     constexpr bool EARLY = decltype(earlyc)::value;
-    read_slice(BUF, 2); fence();
-    mfma_all(0, BUF, FIRST); fence();
-    read_slice(BUF, 3); fence();
-    mfma_all(1, BUF, false); fence();
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // own DMA of the next stage landed; own reads of this buffer done
-    __builtin_amdgcn_s_barrier();
-    fence();
-    read_scales(BUF ^ 1, BUF ^ 1);
-    read_slice(BUF ^ 1, 0);
-    dma_prep(ktl, dvalid);
-    fence();
-    int idx = 0;
-#pragma unroll
-    for (int m = 0; m < MT; ++m)
-#pragma unroll
-      for (int n = 0; n < NT; ++n) {
-        mfma1(2, BUF, m, n, false);
-        dma_item(d, ktl, BUF, idx);
-        if (idx == 0) dma_item(d, ktl, BUF, 16);
-        fence();
-        ++idx;
-      }
-    read_slice(BUF ^ 1, 1); fence();
-    if constexpr (EARLY) {
-      int e = 0;
+    // [r3] ONE fragment read behind each MFMA instead of a burst of 8 in front of 16 MFMAs.  With one wave per SIMD the wave's own program order
+    // is all that can put a read into an MFMA's shadow: after a run of MFMAs the matrix pipe drains while the 8 reads issue -- 82 cycles per 8
+    // MFMAs (tests/native/ubench.hip "uinter": 8 MFMA + 6 reads in bursts 350 cycles, interleaved 276, MFMAs alone 268; on quantised-Gaussian
+    // operands, where the clock is held back electrically, 187.5 -> 175.9 ns, and with the LDS-DMA in the mix 200.8 -> 189.3 ns = -6 %;
+    // 200.8 ns x 8 = the 1.62 us this stage took).  QAMD_DEEPP_BURST restores the round-2 order (A/B).
+    // (the slice's two base addresses are made opaque once: folded into every read, buffer offset + row-set offset exceed the 16-bit DS offset
+    //  field and cost a v_add per read -- and, at 256 + 241 registers, spills)
+    typedef __attribute__((address_space(3))) const v4i* lds_v4i_t;
+    uint32_t rbA = 0, rbB = 0;   // 32-bit LDS addresses
+    auto read_base = [&](const int buf, const int j) __attribute__((always_inline)) {
+      rbA = (uint32_t)(uintptr_t)(lds_ptr_t)(smem + buf * STAGE + cx.rdA[j]);
+      rbB = rbA + (uint32_t)cx.rdBd;
+      asm volatile("" : "+v"(rbA), "+v"(rbB));
+    };
+    auto read_frag = [&](const int j, const int i) __attribute__((always_inline)) {
+      if (i < MT) fa[j][i] = *(lds_v4i_t)(uintptr_t)(rbA + (uint32_t)(i * 32 * C::ROWB));
+      else fb[j][i - MT] = *(lds_v4i_t)(uintptr_t)(rbB + (uint32_t)((i - MT) * 32 * C::ROWB));
+    };
+    auto read_scale1 = [&](const int buf, const int set, const int i) __attribute__((always_inline)) {
+      const char* st = smem + buf * STAGE;
+      if (i < MT) sa[set][i] = *(const int*)(st + cx.rdSA[i]);
+      else sb[set][i - MT] = *(const int*)(st + cx.rdSB[i - MT]);
+    };
+#ifdef QAMD_DEEPP_BURST
+    constexpr bool IL = false;
+#else
+    constexpr bool IL = true;
+#endif
+    static_assert(MT + NT <= MT * NT / 2, "a fragment read behind each of the first MT + NT MFMAs, a scale read behind each of the next");
+    // group G: the MT x NT MFMAs of k-slice js, each followed by `extra(i)`
+    auto group = [&](const int js, const bool zero_c, auto extra) __attribute__((always_inline)) {
+      int i = 0;
 #pragma unroll
       for (int m = 0; m < MT; ++m)
 #pragma unroll
         for (int n = 0; n < NT; ++n) {
-          mfma1(3, BUF, m, n, false);
-          early_store(e / 8, (e / 4) % 2, e % 4);   // pairs (m = 0, 1) x (h = 0, 1), four passes each
+          mfma1(js, BUF, m, n, zero_c);
+          extra(i);
           fence();
-          ++e;
+          ++i;
         }
-    } else {
-      mfma_all(3, BUF, false); fence();
+    };
+    if (!IL) { read_slice(BUF, 2); fence(); } else read_base(BUF, 2);
+    group(0, FIRST, [&](const int i) __attribute__((always_inline)) { if (IL && i < MT + NT) read_frag(2, i); });
+    if (!IL) { read_slice(BUF, 3); fence(); } else read_base(BUF, 3);
+    group(1, false, [&](const int i) __attribute__((always_inline)) { if (IL && i < MT + NT) read_frag(3, i); });
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // own DMA of the next stage landed; own reads of this buffer done
+    __builtin_amdgcn_s_barrier();
+    fence();
+    if (!IL) {
+      read_scales(BUF ^ 1, BUF ^ 1);
+      read_slice(BUF ^ 1, 0);
     }
+    dma_prep(ktl, dvalid);
+    if (IL) read_base(BUF ^ 1, 0);
+    fence();
+    group(2, false, [&](const int i) __attribute__((always_inline)) {
+      dma_item(d, ktl, BUF, i);
+      if (i == 0) dma_item(d, ktl, BUF, 16);
+      if (IL) {   // the next stage's slice 0 (set 0 went dead with group 0) and its scale dwords
+        if (i < MT + NT) read_frag(0, i);
+        else if (i < 2 * (MT + NT)) read_scale1(BUF ^ 1, BUF ^ 1, i - (MT + NT));
+      }
+    });
+    if (!IL) { read_slice(BUF ^ 1, 1); fence(); } else read_base(BUF ^ 1, 1);
+    group(3, false, [&](const int i) __attribute__((always_inline)) {
+      if (IL && i < MT + NT) read_frag(1, i);
+      if constexpr (EARLY) early_store(i / 8, (i / 4) % 2, i % 4);   // pairs (m = 0, 1) x (h = 0, 1), four passes each
+    });
     if constexpr (FIRST) pin_acc();
   };
 

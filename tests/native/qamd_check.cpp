@@ -455,6 +455,7 @@ extern void run_probe();   // probe.hip
 extern void run_ubench();  // ubench.hip
 extern void run_valu_rates();  // ubench.hip
 extern void run_ubench_steady();  // ubench.hip
+extern void run_ubench_interleave();  // ubench.hip
 extern void run_ubench_power(const char* csv_path);  // ubench.hip
 extern void run_store_patterns();  // ubench.hip
 extern "C" void qutlass_amd_debug_set_trace_buffer(void*);
@@ -518,6 +519,7 @@ int main(int argc, char** argv) {
   if (argc > 1 && want("ubench")) run_ubench();
   if (argc > 1 && want("valu")) run_valu_rates();
   if (argc > 1 && want("usteady")) run_ubench_steady();
+  if (argc > 1 && want("uinter")) run_ubench_interleave();
   if (want("probe")) run_probe();
   if (argc > 1 && want("stores")) run_store_patterns();
   if (argc > 1 && want("power")) run_ubench_power("gpurun_out/power_trace_ubench_r2.csv");

@@ -162,6 +162,24 @@ __global__ __launch_bounds__(THREADS) void ub_kernel(const char* g, uint32_t gby
       if (MODE == 11 && ph == 0) { dma2(it + 1); dma1(it + 1); fence(); }
       if (ph == 2) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); fence(); }
     }
+    if (MODE == 13 || MODE == 14) {   // [r3] the same work as modes 2 / 4, but ONE fragment read (and, 14, one LDS-DMA) behind each MFMA instead of bursts of 8 + 6 (+ 2)
+      auto half = [&](const int cur, const int oth, const int off, const int itx) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const v4i a = fa[cur][i >> 1], b = fb[cur][i & 1];
+          acc[i] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(v8i{b[0], b[1], b[2], b[3], 0, 0, 0, 0}, v8i{a[0], a[1], a[2], a[3], 0, 0, 0, 0}, acc[i], 4, 4, 0, scale, 0, scale);
+          if (i < 4) fa[oth][i] = *(const v4i*)(smem + addr(off) + i * 4096);
+          else if (i < 6) fb[oth][i - 4] = *(const v4i*)(smem + 32768 + addr(off) + (i - 4) * 4096);
+          else if (MODE == 14) {
+            const int v = lane * 16 + (itx & 63) * 2048 + wave * 131072 + (i - 6) * 1024;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)(smem + 65536 + wave * 2048 + (i - 6) * 1024), 16, v, 0, 0, 0);
+          }
+          fence();
+        }
+      };
+      half(0, 1, off0, it);
+      half(1, 0, off1, it + 1);
+    }
     if (MODE == 7) {
       mfma8(0); fence(); reads(1, off0); keep(0); fence(); dma2(it); fence();
       mfma8(1); fence(); reads(0, off1); keep(1); fence(); dma2(it + 1); fence();
@@ -418,6 +436,27 @@ void run_ubench_steady() {   // MFMA-only ceilings in the steady state (after ~1
   }
   g_steady_warm = 0;
   hipFree(g); hipFree(out); hipFree(cyc);
+}
+
+std::vector<uint32_t> gaussian_e2m1_image(size_t bytes, uint32_t seed);
+void run_ubench_interleave() {   // [r3] bursts vs one-behind-each-MFMA, ONE wave per SIMD (256 threads, the GEMM's occupancy), steady state
+  const uint32_t gbytes = 64u << 20;
+  char* g; float* out; uint32_t* cyc; uint32_t* fill;
+  HIP_OK(hipMalloc(&g, gbytes)); HIP_OK(hipMemset(g, 0x22, gbytes));
+  HIP_OK(hipMalloc(&out, 256 * 512 * 4)); HIP_OK(hipMalloc(&cyc, 64)); HIP_OK(hipMalloc(&fill, 65536));
+  std::vector<uint32_t> gauss = gaussian_e2m1_image(65536, 7);
+  HIP_OK(hipMemcpy(fill, gauss.data(), 65536, hipMemcpyHostToDevice));
+  g_steady_warm = 40;
+  for (int cls : {0, 2, 0, 2}) {
+    g_fill = cls == 2 ? fill : nullptr; g_fill_name = cls == 2 ? "[gaussian codes]  " : nullptr; g_random_fill = 0;
+    run_one<0, 256>("MFMA x8 only", g, gbytes, out, cyc, 256);
+    run_one<2, 256>("bursts: 8 MFMA ; 6 reads -> other set", g, gbytes, out, cyc, 256);
+    run_one<13, 256>("interleaved: MFMA, read, MFMA, read, ...", g, gbytes, out, cyc, 256);
+    run_one<4, 256>("bursts: 8 MFMA ; 6 reads ; 2 LDS-DMA", g, gbytes, out, cyc, 256);
+    run_one<14, 256>("interleaved: ... + LDS-DMA behind MFMA 7, 8", g, gbytes, out, cyc, 256);
+  }
+  g_steady_warm = 0; g_fill = nullptr; g_fill_name = nullptr;
+  hipFree(g); hipFree(out); hipFree(cyc); hipFree(fill);
 }
 
 void run_valu_rates() {
