@@ -323,17 +323,18 @@ __global__ __launch_bounds__(256) void bwd_square_double_mxfp8_kernel(const SqPa
   // lane -> row lane/16 (+4 per pass), 16-byte chunk lane%16 (8 columns); column block j = (lane%16)/4
   const int lr = lane >> 4, lc = (lane & 15) * 8;
   v4i v[8];
-  float amax = 0.f;
+  // [r3] block maximum on the packed bf16 bit patterns (sign stripped, v_pk_max_u16: 2 instructions per dword instead of 3; NaN inputs excepted, the order
+  // of the patterns is the order of the magnitudes)
+  typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+  u16x2 mx = {0, 0};
 #pragma unroll
   for (int ps = 0; ps < 8; ++ps) {
     const int row = r0 + ps * 4 + lr;
     v[ps] = row < p.m ? *(const v4i*)(p.x + (int64_t)row * p.n + c0 + lc) : v4i{0, 0, 0, 0};
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const uint32_t w = (uint32_t)v[ps][q];
-      amax = fmaxf(amax, fmaxf(fabsf(__uint_as_float(w << 16)), fabsf(__uint_as_float(w & 0xffff0000u))));
-    }
+    for (int q = 0; q < 4; ++q) mx = __builtin_elementwise_max(mx, __builtin_bit_cast(u16x2, (uint32_t)v[ps][q] & 0x7fff7fffu));
   }
+  float amax = __uint_as_float((uint32_t)(mx[0] > mx[1] ? mx[0] : mx[1]) << 16);
   // reduce over the lanes of the same column block: lane = 16 a + 4 j + c  ->  xor 1, 2 (c) and 16, 32 (a)
   amax = fmaxf(amax, __shfl_xor(amax, 1));
   amax = fmaxf(amax, __shfl_xor(amax, 2));
@@ -387,7 +388,8 @@ struct TrParams {
 // so its duration is ONE workgroup's load -> transpose -> store latency chain, and smaller tiles shorten it)
 template <int NC>
 __global__ __launch_bounds__(256) void mxfp4_transpose_mxfp8_kernel(const TrParams p) {
-  constexpr int LROW = NC * 2 + 16;    // bf16 row of NC columns + pad
+  constexpr int LROW = NC * 2 + 64;    // bf16 row of NC columns + pad: 16 dwords (mod 64), so the 4 rows x 32 bytes that each of the two 16-lane groups of a
+                                       // half wave gathers with ds_read_b64_tr_b16 fall on 64 different banks
   constexpr int LPR = NC / 32;         // lanes per input row (16 bytes = 32 codes = one input scale group each)
   constexpr int RPP = 64 / LPR;        // rows per load pass
   constexpr int CPL = NC / 64;         // columns per lane
@@ -426,21 +428,31 @@ __global__ __launch_bounds__(256) void mxfp4_transpose_mxfp8_kernel(const TrPara
   }
   __builtin_amdgcn_s_waitcnt(0xc07f);
   __builtin_amdgcn_wave_barrier();
-  // columns lane, lane + 64, ... (consecutive lanes = consecutive 2-byte LDS addresses)
+  // Columns lane, lane + 64, ...  [r3] The lane's 32 m values of a column come out of the tile with 8 transposing reads (ds_read_b64_tr_b16: the 16
+  // lanes of a group supply the 8-byte pieces of 4 rows x 16 columns and receive one column each, rows 2i, 2i + 1 already paired in a register)
+  // instead of 32 two-byte reads + 16 packs -- PMC had the LDS instruction issue busy 17 of the kernel's 23 us at 8192^2 -- and the block
+  // maximum is taken on the packed bf16 bit patterns (sign stripped, v_pk_max_u16: for non-NaN values the order of the patterns is the order of
+  // the magnitudes; an e8m0 byte of 255 in the input, i.e. inf / NaN operands, is outside what the op is defined for).
+  typedef short v4s_ __attribute__((ext_vector_type(4)));
+  typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+  typedef __attribute__((address_space(3))) v4s_* lds_v4s_t;
+  const char* tr_ptr = ts + ((lane & 15) >> 2) * LROW + ((lane >> 4) * 16 + (lane & 3) * 4) * 2;
   v4i oq[CPL][2];
   uint8_t oe[CPL];
 #pragma unroll
   for (int cc = 0; cc < CPL; ++cc) {
-    const int col = cc * 64 + lane;
     uint32_t pr[16];   // pr[i] = bf16 of rows 2i (low half) and 2i+1 (high half)
-    float amax = 0.f;
+    u16x2 mx = {0, 0};
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const uint32_t a = *(const uint16_t*)(ts + (2 * i) * LROW + col * 2);
-      const uint32_t b = *(const uint16_t*)(ts + (2 * i + 1) * LROW + col * 2);
-      pr[i] = a | (b << 16);
-      amax = fmaxf(amax, fmaxf(fabsf(__uint_as_float(a << 16)), fabsf(__uint_as_float(b << 16))));
+    for (int q = 0; q < 8; ++q) {
+      const v4s_ t4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s_t)(tr_ptr + 4 * q * LROW + cc * 128));
+      const v2i w2 = __builtin_bit_cast(v2i, t4);
+      pr[2 * q] = (uint32_t)w2[0];
+      pr[2 * q + 1] = (uint32_t)w2[1];
+      mx = __builtin_elementwise_max(mx, __builtin_bit_cast(u16x2, pr[2 * q] & 0x7fff7fffu));
+      mx = __builtin_elementwise_max(mx, __builtin_bit_cast(u16x2, pr[2 * q + 1] & 0x7fff7fffu));
     }
+    const float amax = __uint_as_float((uint32_t)(mx[0] > mx[1] ? mx[0] : mx[1]) << 16);
     const uint32_t e = e8m0_shift7(amax);
     const float qs = e8m0_scale(e);
     v4i o[2];
