@@ -183,6 +183,16 @@ def test_fuzz_backward_ops(q):
         assert np.array_equal(_np(e8m0), rs), (it, B, N, M)
         eq = oracle.codes_equal_mod_zero_sign(_np(e2m1).reshape(rq.shape), rq)
         assert int((~eq).sum()) <= max(2, 1e-3 * eq.size), (it, B, N, M)
+    for it in range(8):   # [r3] backward_qt_bf16: ragged unit counts (m-tiles not a multiple of 4, groups not a multiple of 8), random alpha
+        B, N, M = int(rng.integers(1, 3)), int(rng.integers(1, 20)) * 32, int(rng.integers(1, 24)) * 32
+        alpha = float(np.float32(rng.uniform(0.05, 20.0)))
+        xq = torch.from_numpy(rng.integers(0, 256, size=(B, N, M // 2), dtype=np.uint8)).to(DEV)
+        xs = torch.from_numpy(rng.integers(112, 142, size=(B, N, M // 32), dtype=np.uint8)).to(DEV)
+        e2m1, e8m0 = q.backward_qt_bf16(xq, xs.view(torch.float8_e8m0fnu), h, torch.tensor([alpha], device=DEV))
+        rq, rs = oracle.backward_qt_bf16(_np(xq), _np(xs), _np(h), alpha, acc_model=1)
+        assert np.array_equal(_np(e8m0), rs), (it, B, N, M, alpha)
+        eq = oracle.codes_equal_mod_zero_sign(_np(e2m1).reshape(rq.shape), rq)
+        assert int((~eq).sum()) <= max(2, 1e-3 * eq.size), (it, B, N, M, alpha)
     for it in range(6):
         m, n = int(rng.integers(1, 5)) * 128, int(rng.integers(1, 5)) * 128
         x = torch.from_numpy(rng.standard_normal((m, n)).astype(np.float32) * float(rng.choice([1e-3, 1.0, 500.0]))).to(torch.bfloat16).to(DEV)
