@@ -1248,6 +1248,10 @@ int qutlass_amd_debug_gemm_plan(int ebits, int64_t M, int64_t N, int64_t K, int6
   return rc == QAMD_OK ? n : -1;
 }
 
+// debug only (not declared in the public header): the tile configuration matmul_nvf4_bf16_tn's auto rule picks for an M x N output
+// (gemm_nvf4.hip.h: nvf4_auto_cfg; 256 CUs assumed, no GPU touched)
+int qutlass_amd_debug_nvf4_plan(int64_t M, int64_t N) { return (M > 0 && N > 0) ? qamd::nvf4_auto_cfg(M, N, 256) : -2; }
+
 #if QAMD_BENCH
 // lab library only: device buffer for ABL_TRACE / ABL_CLOCK builds
 void qutlass_amd_debug_set_trace_buffer(void* p) { g_dbg.store((uint32_t*)p); }

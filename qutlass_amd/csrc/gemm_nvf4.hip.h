@@ -679,6 +679,28 @@ bool launch_nvf4_ablation(NvGemmParams p, hipStream_t s, int variant);
 #endif
 #endif   // QAMD_BENCH
 
+// Tile configuration of the auto rule (no GPU touched; also behind qutlass_amd_debug_nvf4_plan for the CPU tests):
+//   -1 split-K skinny kernel, 0: 256x256, 1: 128x128, 2: 128x64, 3: 64x64, 4: 256x128 on four waves of 128x64
+inline int nvf4_auto_cfg(int64_t M, int64_t N, int cus) {
+  const int64_t want = cus * 3 / 4;
+  auto tiles = [&](int bm, int bn) { return ((M + bm - 1) / bm) * ((N + bn - 1) / bn); };
+  if (M <= 64 || (M <= 128 && tiles(64, 64) < want)) return -1;
+  const bool small = M <= 128 || N <= 128 || tiles(256, 256) < want;
+  int cfg = small ? 1 : 0;
+  if (cfg == 0) {
+    const int64_t t256 = tiles(256, 256), t128 = tiles(128, 128);
+    const double e256 = (double)t256 / (double)((t256 + cus - 1) / cus * cus), e128 = (double)t128 / (double)((t128 + 2 * cus - 1) / (2 * cus) * (2 * cus));
+    if (e256 < 0.85 * e128) cfg = 1;
+  }
+  if (cfg == 1 && tiles(128, 128) < want) cfg = (tiles(128, 64) >= want) ? 2 : 3;
+  if (cfg == 1 && M >= 256) {
+    const int64_t t4 = tiles(256, 128), t128 = tiles(128, 128);
+    const double e4 = (double)t4 / (double)((t4 + cus - 1) / cus * cus), e128 = (double)t128 / (double)((t128 + 2 * cus - 1) / (2 * cus) * (2 * cus));
+    if (1.06 * e4 > e128 && t4 >= want) cfg = 4;
+  }
+  return cfg;
+}
+
 #if QAMD_TU == 0 || QAMD_TU == 4
 // Returns hipErrorInvalidValue for a variant this build does not know (the product library knows only 0 = auto).
 // cus: compute units of the device (capi.hip chip_cus): every occupancy threshold below derives from it
@@ -710,25 +732,19 @@ inline hipError_t launch_nvf4_gemm(NvGemmParams p, hipStream_t s, int variant = 
     auto tiles = [&](int bm, int bn) { return (int64_t)((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn); };
     int cfg = small ? 1 : 0;                                  // 0: 256x256, 1: 128x128, 2: 128x64, 3: 64x64
     if (variant == 0 || variant == 1) {
+      // (nvf4_auto_cfg above)
       // [r2] wave quantisation of the 256x256 grid (one workgroup per CU, 256 slots per round): 288 tiles run two rounds at 56 %
       // occupancy.  128x128 tiles (two per CU, 512 slots) sustain 0.85 of the big tile's rate (2048 x 8192 x 8192: 249 vs 213 us)
       // but quantise four times finer: take them when that more than pays (3072 x 6144 x 4096: 197 -> 152 us;
       // profiles/native_r2_nvwave.log)
-      if (cfg == 0) {
-        const int64_t t256 = tiles(256, 256), t128 = tiles(128, 128);
-        const double e256 = (double)t256 / (double)((t256 + cus - 1) / cus * cus), e128 = (double)t128 / (double)((t128 + 2 * cus - 1) / (2 * cus) * (2 * cus));
-        if (e256 < 0.85 * e128) cfg = 1;
-      }
-      if (cfg == 1 && tiles(128, 128) < want) cfg = (tiles(128, 64) >= want) ? 2 : 3;
       // [r3] where 128x128 tiles would run, the 256x128 tile on FOUR waves of 128x64 (one workgroup per CU) dequantises 0.75 fragments per MFMA
       // instead of 1 and runs 5-6.5 % faster when its rounds are as full (2048 x 4096 x 4096: 66.4 -> 63.1 us, x 8192: 128.2 -> 120.2, x 14336:
-      // 221.1 -> 207.7, 1536 x 4096 x 4096: 59.1 -> 56.2; profiles/native_r3_nvhalf.log) -- take it when 1.06 x its round occupancy beats that
-      // of the 128x128 grid (two workgroups per CU: 2 cus slots per round)
-      if (cfg == 1 && p.M >= 256) {
-        const int64_t t4 = tiles(256, 128), t128 = tiles(128, 128);
-        const double e4 = (double)t4 / (double)((t4 + cus - 1) / cus * cus), e128 = (double)t128 / (double)((t128 + 2 * cus - 1) / (2 * cus) * (2 * cus));
-        if (1.06 * e4 > e128) cfg = 4;
-      }
+      // 221.1 -> 207.7, 1536 x 4096 x 4096: 59.1 -> 56.2; profiles/native_r3_nvhalf.log) -- taken when 1.06 x its round occupancy beats that
+      // of the 128x128 grid (two workgroups per CU: 2 cus slots per round) AND the 256x128 grid itself gives >= 3/4 of the CUs a tile:
+      // 1024 x 4096 is 128 such tiles -- half the chip idle, 54.7 us where the 256 tiles of 128x128 (one per CU) take 35.5; the occupancy
+      // ratio alone (0.5 against 0.5 of the two-per-CU slots) does not see that (found in the batch sweep, M = 1024 slower than M = 512)
+      const int a = nvf4_auto_cfg(p.M, p.N, cus);
+      if (a >= 0) cfg = a;
     }
     if (variant == 5) cfg = 1;
     if (variant == 6) cfg = 2;

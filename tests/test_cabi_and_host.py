@@ -110,6 +110,22 @@ def test_split_k_workspace_plan_is_a_pure_host_function(lib):
     assert lib.qutlass_amd_matmul_mxf8_bf16_tn_ws(None, dummy, dummy, dummy, dummy, dummy, 128, 128, 128, None, 0, None) == QAMD_ERR_INVALID
 
 
+def test_nvf4_tile_rule(lib):
+    """matmul_nvf4_bf16_tn's tile choice (gemm_nvf4.hip.h: nvf4_auto_cfg) through the debug entry: -1 skinny split-K, 0 256x256, 1 128x128,
+    2 128x64, 3 64x64, 4 256x128 on four waves.  [r3] The 256x128 tile is for half-chip outputs whose 256x128 grid still covers the chip
+    (2048 x 4096: 256 tiles); 1024 x 4096 (128 such tiles, half the CUs idle: 54.7 us against 35.5) must stay on 128x128 tiles."""
+    import ctypes
+
+    f = lib.qutlass_amd_debug_nvf4_plan   # debug entry, deliberately not in the public header
+    f.restype, f.argtypes = ctypes.c_int, [ctypes.c_int64, ctypes.c_int64]
+    assert f(8192, 8192) == 0 and f(4096, 4096) == 0 and f(4096, 14336) == 0
+    assert f(2048, 4096) == 4 and f(1536, 4096) == 4 and f(2048, 6144) == 0      # 384 tiles of 256x256 = 1.5 rounds: stays big (95 vs 113.5 us)
+    assert f(1024, 4096) == 1 and f(512, 6144) == 1 and f(1024, 6144) == 4       # 1024 x 6144: 192 tiles of 256x128
+    assert f(3072, 6144) == 4 and f(4096, 5120) == 4                            # 288 / 320 big tiles = two rounds at 56 / 63 %: the finer grids (197 -> 152 us with 128x128)
+    assert f(512, 4096) == 2 and f(256, 4096) in (2, 3) and f(64, 4096) == -1 and f(1, 4096) == -1
+    assert f(0, 4096) == -2
+
+
 def test_auto_dispatch_rules_dry_run(lib):
     """The tile / schedule choice of the MX GEMMs (DESIGN.md sections 3.3, 3.7, 3.8) through the library's dry-run hook:
     the real dispatch code runs, launches are recorded instead of issued.  (variant, N of the launch, K splits)."""

@@ -13,6 +13,8 @@ def main():
     alpha = torch.tensor([1.0], device=dev)
     P = lambda t: ctypes.c_void_p(t.data_ptr()); I = ctypes.c_int64; st = ctypes.c_void_p(0)
     shapes = [(8192, 8192, 8192), (4096, 4096, 4096), (4096, 14336, 4096), (2048, 4096, 4096), (1024, 4096, 4096), (2048, 4096, 14336), (512, 4096, 4096), (128, 4096, 4096), (4096, 5120, 4096)]
+    if len(sys.argv) > 3 and sys.argv[3] == "mid":   # the mid-batch shapes of the Llama-3-8B sweep
+        shapes = [(m, n, k) for (n, k) in ((4096, 4096), (6144, 4096), (4096, 14336)) for m in (256, 512, 1024, 2048)]
     print("%-22s %10s %10s %8s  same bytes" % ("M x N x K", "old us", "new us", "ratio"))
     for (m, n, k) in shapes:
         torch.manual_seed(m + n + k)
