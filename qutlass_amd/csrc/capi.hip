@@ -657,7 +657,12 @@ int gemm_mx(const char* name, const void* A, const void* B, const void* A_sf, co
     // bound: N = 28672, K = 4096, M = 32: 12.6 us with 448 tiles of 64x64 vs 14.3 us with 224 of 64x128)
     if (M <= 64) variant = (tiles(64, 128) >= cus * 3 / 2) ? 28 : 29;
     else if (N <= 64) variant = (tiles(128, 64) >= want) ? 27 : 29;
-    else if (tiles(256, 256) >= want) {
+    // [r3] ... or more than HALF of them with K >= 8 stages: the smaller tiles then no longer fit one round (128x128: two per CU, 256x128: one per CU --
+    // both hold exactly cus / 2 tiles' worth of 256x256 output), and a second, part-filled round costs more than idle CUs do:
+    // 2560 x 4096 x 4096 (160 tiles) 34.6 -> 28.8 us, 1536 x 6144 x 4096 33.2 -> 28.3, 2048 x 5120 x 5120 42.2 -> 35.3, MXFP8 2560 x 4096 x 4096
+    // 49.3 -> 39.4, K = 14336 likewise (146.9 -> 120.9); at exactly half (2048 x 4096: 128 tiles) the small tiles tie or win
+    // (tools/calib_tiles.py, profiles/calib_tiles_r3.txt; found by tools/dip_scan.py: a LARGER batch ran faster)
+    else if (tiles(256, 256) >= want || (2 * tiles(256, 256) > cus && cdiv(K * EBITS / 8, 128) >= 8)) {
       // the persistent deep schedule (one workgroup per CU walks the tiles, epilogue folded into the last K stage), fp4 and
       // fp8; its epilogue addresses a tile with 32-bit byte offsets, so absurdly wide outputs stay with 256x128 simple tiles
       const int big = ldd < (1ll << 22) ? 90 : 25;
@@ -698,6 +703,11 @@ int gemm_mx(const char* name, const void* A, const void* B, const void* A_sf, co
       const int64_t KTs = cdiv(K * EBITS / 8, 128);
       // (MXFP8 likewise: 2048 x 4096 x 4096 34.9 -> 32.7 us, x 8192 63.2 -> 57.1 us; K = 2048 = 16 stages: -2 %, stays)
       variant = (M >= 256 && KTs >= 32 && tiles(256, 128) >= want) ? 58 : 24;
+      // [r3] ... and, at the same K, whenever the 128x128 grid no longer fits one tile per CU while the 256x128 grid still does: the CUs that hold
+      // two 128x128 tiles set the kernel's time.  MXFP8 768 x 6144 x 4096 28.3 -> 23.5 us, 1024 x 5120 x 5120 36.9 -> 29.6, 1024 x 5120 x 25600
+      // 145.3 -> 120.8; MXFP4 1024 x 5120 x 25600 83.5 -> 75.2.  Not below 32 stages: MXFP4 2048 x 4096 x 4096 23.6 against 26.6 on the 256x128 tile
+      // (profiles/calib_tiles_r3.txt)
+      if (M >= 256 && KTs >= 32 && tiles(128, 128) > cus && tiles(256, 128) <= cus) variant = 58;
     }
     else if (tiles(128, 64) >= want || tiles(64, 128) >= want) variant = (N >= M) ? 27 : 28;
     else variant = 29;
@@ -1250,7 +1260,7 @@ int qutlass_amd_debug_gemm_plan(int ebits, int64_t M, int64_t N, int64_t K, int6
 
 // debug only (not declared in the public header): the tile configuration matmul_nvf4_bf16_tn's auto rule picks for an M x N output
 // (gemm_nvf4.hip.h: nvf4_auto_cfg; 256 CUs assumed, no GPU touched)
-int qutlass_amd_debug_nvf4_plan(int64_t M, int64_t N) { return (M > 0 && N > 0) ? qamd::nvf4_auto_cfg(M, N, 256) : -2; }
+int qutlass_amd_debug_nvf4_plan(int64_t M, int64_t N, int64_t K) { return (M > 0 && N > 0 && K > 0) ? qamd::nvf4_auto_cfg(M, N, K, 256) : -2; }
 
 #if QAMD_BENCH
 // lab library only: device buffer for ABL_TRACE / ABL_CLOCK builds

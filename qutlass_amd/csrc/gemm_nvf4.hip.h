@@ -10,6 +10,9 @@
 // not the FP4 peak.  Data movement (LDS-DMA stages, swizzle, swapped operand roles, LDS-staged
 // whole-line epilogue, XCD-aware raster) is identical to gemm_mx.hip.h.
 #pragma once
+#include <algorithm>
+#include <cmath>
+
 #include "common.hip.h"
 
 namespace qamd {
@@ -681,23 +684,40 @@ bool launch_nvf4_ablation(NvGemmParams p, hipStream_t s, int variant);
 
 // Tile configuration of the auto rule (no GPU touched; also behind qutlass_amd_debug_nvf4_plan for the CPU tests):
 //   -1 split-K skinny kernel, 0: 256x256, 1: 128x128, 2: 128x64, 3: 64x64, 4: 256x128 on four waves of 128x64
-inline int nvf4_auto_cfg(int64_t M, int64_t N, int cus) {
+// [r3] Where 128x128 tiles fill the chip, the three large configurations are priced round by round -- a per-tile kernel runs
+// ceil(tiles / slots) rounds, and what a part-filled last round costs decides most shapes that are not powers of two.  Round times in us at
+// K = 4096 (tools/calib_tiles.py, profiles/calib_tiles_r3.txt: every candidate forced on 70 shapes), scaled with K:
+//   256x256 (one per CU)   81 while <= 3/4 of the CUs have a tile, 101 for a full round (the part's electrical limit)
+//   256x128 (one per CU)   51 ... 59.8 likewise
+//   128x128 (two per CU)   a full round of 2 x CUs tiles 64.7; a remainder of <= CUs tiles runs one per CU: 34 ... 37; one tile more: 55 ... 64.7
+// The rule before: the 256x128 tile whenever its round occupancy beat that of the 128x128 grid -- 2560 x 4096 x 4096 ran 106 us (two rounds of
+// 256x128) where 160 tiles of 256x256 take 84.5; 1024 x 4096 ran on 128 tiles, 54.7 us against 35.5.
+inline int nvf4_auto_cfg(int64_t M, int64_t N, int64_t K, int cus) {
   const int64_t want = cus * 3 / 4;
   auto tiles = [&](int bm, int bn) { return ((M + bm - 1) / bm) * ((N + bn - 1) / bn); };
   if (M <= 64 || (M <= 128 && tiles(64, 64) < want)) return -1;
-  const bool small = M <= 128 || N <= 128 || tiles(256, 256) < want;
-  int cfg = small ? 1 : 0;
-  if (cfg == 0) {
-    const int64_t t256 = tiles(256, 256), t128 = tiles(128, 128);
-    const double e256 = (double)t256 / (double)((t256 + cus - 1) / cus * cus), e128 = (double)t128 / (double)((t128 + 2 * cus - 1) / (2 * cus) * (2 * cus));
-    if (e256 < 0.85 * e128) cfg = 1;
+  if (M <= 128 || N <= 128 || tiles(128, 128) < want) {
+    if (tiles(128, 128) >= want) return 1;
+    return tiles(128, 64) >= want ? 2 : 3;
   }
-  if (cfg == 1 && tiles(128, 128) < want) cfg = (tiles(128, 64) >= want) ? 2 : 3;
-  if (cfg == 1 && M >= 256) {
-    const int64_t t4 = tiles(256, 128), t128 = tiles(128, 128);
-    const double e4 = (double)t4 / (double)((t4 + cus - 1) / cus * cus), e128 = (double)t128 / (double)((t128 + 2 * cus - 1) / (2 * cus) * (2 * cus));
-    if (1.06 * e4 > e128 && t4 >= want) cfg = 4;
-  }
+  const double sk = (double)std::max<int64_t>(K, 256) / 4096.0, fix = 5.0;   // per round: `fix` us of prologue / epilogue + a part proportional to K
+  auto rt = [&](double t16) { return fix + (t16 - fix) * sk; };
+  auto ramp = [&](double lo, double hi, double o) { return lo + (hi - lo) * std::min(1.0, std::max(0.0, (o - 0.75) / 0.25)); };
+  const double c = (double)cus;
+  // 256x256
+  const int64_t t0 = tiles(256, 256), r0 = (t0 - 1) / cus, l0 = t0 - r0 * cus;
+  const double T0 = r0 * rt(101.0) + rt(ramp(81.0, 101.0, l0 / c));
+  // 256x128 on four waves
+  const int64_t t4 = tiles(256, 128), r4 = (t4 - 1) / cus, l4 = t4 - r4 * cus;
+  const double T4 = r4 * rt(59.8) + rt(ramp(51.0, 59.8, l4 / c));
+  // 128x128, two per CU
+  const int64_t t1 = tiles(128, 128), r1 = t1 / (2 * cus), l1 = t1 - r1 * 2 * cus;
+  double T1 = r1 * rt(64.7);
+  if (l1 > 0) T1 += l1 <= cus ? rt(34.0 + 3.0 * l1 / c) : rt(55.0 + 9.7 * (double)(l1 - cus) / c);   // (the CUs that hold two tiles set the time: a small spill costs almost the full pair round)
+  int cfg = 0;
+  double best = T0;
+  if (M >= 256 && T4 < best * 0.985) { cfg = 4; best = T4; }   // (ties go to the larger tile)
+  if (T1 < best * 0.985) cfg = 1;
   return cfg;
 }
 
@@ -727,23 +747,13 @@ inline hipError_t launch_nvf4_gemm(NvGemmParams p, hipStream_t s, int variant = 
     return hipSuccess;
   }
 #endif
-  if (variant <= 1 || variant == 4 || (variant >= 5 && variant <= 9) || variant == 40) {
+  if (variant <= 1 || variant == 4 || (variant >= 5 && variant <= 9) || variant == 40 || variant == 41) {
     // tile choice by occupancy (as for the MX kernels): the largest tile that gives >= 192 workgroups
     auto tiles = [&](int bm, int bn) { return (int64_t)((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn); };
     int cfg = small ? 1 : 0;                                  // 0: 256x256, 1: 128x128, 2: 128x64, 3: 64x64
     if (variant == 0 || variant == 1) {
-      // (nvf4_auto_cfg above)
-      // [r2] wave quantisation of the 256x256 grid (one workgroup per CU, 256 slots per round): 288 tiles run two rounds at 56 %
-      // occupancy.  128x128 tiles (two per CU, 512 slots) sustain 0.85 of the big tile's rate (2048 x 8192 x 8192: 249 vs 213 us)
-      // but quantise four times finer: take them when that more than pays (3072 x 6144 x 4096: 197 -> 152 us;
-      // profiles/native_r2_nvwave.log)
-      // [r3] where 128x128 tiles would run, the 256x128 tile on FOUR waves of 128x64 (one workgroup per CU) dequantises 0.75 fragments per MFMA
-      // instead of 1 and runs 5-6.5 % faster when its rounds are as full (2048 x 4096 x 4096: 66.4 -> 63.1 us, x 8192: 128.2 -> 120.2, x 14336:
-      // 221.1 -> 207.7, 1536 x 4096 x 4096: 59.1 -> 56.2; profiles/native_r3_nvhalf.log) -- taken when 1.06 x its round occupancy beats that
-      // of the 128x128 grid (two workgroups per CU: 2 cus slots per round) AND the 256x128 grid itself gives >= 3/4 of the CUs a tile:
-      // 1024 x 4096 is 128 such tiles -- half the chip idle, 54.7 us where the 256 tiles of 128x128 (one per CU) take 35.5; the occupancy
-      // ratio alone (0.5 against 0.5 of the two-per-CU slots) does not see that (found in the batch sweep, M = 1024 slower than M = 512)
-      const int a = nvf4_auto_cfg(p.M, p.N, cus);
+      // the round-by-round pricing of nvf4_auto_cfg above ([r2] wave quantisation of the 256x256 grid, [r3] the 256x128 four-wave tile and the cost model)
+      const int a = nvf4_auto_cfg(p.M, p.N, p.K, cus);
       if (a >= 0) cfg = a;
     }
     if (variant == 5) cfg = 1;
@@ -751,6 +761,7 @@ inline hipError_t launch_nvf4_gemm(NvGemmParams p, hipStream_t s, int variant = 
     if (variant == 7) cfg = 3;
 #if QAMD_BENCH
     if (variant == 40) cfg = 4;   // lab: force the 256x128 tile on four waves of 128x64
+    if (variant == 41) cfg = 0;   //      force the 256x256 tile (tools/calib_tiles.py)
     if (variant == 8) cfg = 8;    // lab: 128x128 tile on 2 waves of 128x64 (A dequantised by 2 waves, B by 1)
     if (variant == 9) cfg = 9;    //      128x128 tile on 2 waves of 64x128
 #endif

@@ -112,18 +112,24 @@ def test_split_k_workspace_plan_is_a_pure_host_function(lib):
 
 def test_nvf4_tile_rule(lib):
     """matmul_nvf4_bf16_tn's tile choice (gemm_nvf4.hip.h: nvf4_auto_cfg) through the debug entry: -1 skinny split-K, 0 256x256, 1 128x128,
-    2 128x64, 3 64x64, 4 256x128 on four waves.  [r3] The 256x128 tile is for half-chip outputs whose 256x128 grid still covers the chip
-    (2048 x 4096: 256 tiles); 1024 x 4096 (128 such tiles, half the CUs idle: 54.7 us against 35.5) must stay on 128x128 tiles."""
+    2 128x64, 3 64x64, 4 256x128 on four waves.  [r3] Among {0, 4, 1} a round-based cost model picks (full rounds x the tile's time + the
+    last round priced by how much of the chip it fills); the expectations below are the measured winners of profiles/calib_tiles_r3.txt
+    (256 CUs): 2560 x 4096 has 160 tiles of 256x256 in one round (84.5 us) against 106 / 88 for the finer grids; 3072 x 6144 has 288 big
+    tiles = two rounds (175 us) against 148 on 128x128; 1024 x 4096 (128 tiles of 256x128, half the CUs idle: 52 us) stays on 128x128 (36)."""
     import ctypes
 
     f = lib.qutlass_amd_debug_nvf4_plan   # debug entry, deliberately not in the public header
-    f.restype, f.argtypes = ctypes.c_int, [ctypes.c_int64, ctypes.c_int64]
-    assert f(8192, 8192) == 0 and f(4096, 4096) == 0 and f(4096, 14336) == 0
-    assert f(2048, 4096) == 4 and f(1536, 4096) == 4 and f(2048, 6144) == 0      # 384 tiles of 256x256 = 1.5 rounds: stays big (95 vs 113.5 us)
-    assert f(1024, 4096) == 1 and f(512, 6144) == 1 and f(1024, 6144) == 4       # 1024 x 6144: 192 tiles of 256x128
-    assert f(3072, 6144) == 4 and f(4096, 5120) == 4                            # 288 / 320 big tiles = two rounds at 56 / 63 %: the finer grids (197 -> 152 us with 128x128)
-    assert f(512, 4096) == 2 and f(256, 4096) in (2, 3) and f(64, 4096) == -1 and f(1, 4096) == -1
-    assert f(0, 4096) == -2
+    f.restype, f.argtypes = ctypes.c_int, [ctypes.c_int64] * 3
+    K = 4096
+    assert f(8192, 8192, 8192) == 0 and f(4096, 4096, K) == 0 and f(4096, 14336, K) == 0
+    assert f(2048, 4096, K) == 4 and f(1536, 4096, K) == 4 and f(1024, 6144, K) == 4        # 256 / 192 / 192 tiles of 256x128: one round
+    assert f(2560, 4096, K) == 0 and f(3072, 4096, K) == 0 and f(2048, 6144, K) == 0       # 160 / 192 / 192 tiles of 256x256: one round
+    assert f(1024, 4096, K) == 1 and f(512, 6144, K) == 1                                   # the 256x128 grid would leave half the chip idle
+    assert f(3072, 6144, K) == 1 and f(4096, 5120, 5120) == 1 and f(5120, 4096, K) == 1     # 288 / 320 / 320 big tiles: two rounds at 56 / 63 %
+    assert f(6144, 4096, K) == 0 and f(4096, 6144, K) == 0                                  # 384 big tiles = 1.5 rounds: 128x128 is no better (180 vs 188)
+    assert f(4096, 5120, 512) == 0 and f(8192, 4096, 14336) == 0
+    assert f(512, 4096, K) == 2 and f(256, 4096, K) in (2, 3) and f(64, 4096, K) == -1 and f(1, 4096, K) == -1
+    assert f(0, 4096, K) == -2 and f(4096, 4096, 0) == -2
 
 
 def test_auto_dispatch_rules_dry_run(lib):
@@ -180,6 +186,10 @@ def test_auto_dispatch_rules_dry_run(lib):
     # [r3] half-chip outputs with a long K (>= 32 stages of 128 bytes): 256x128 tiles on four waves of 128x64 (3-deep ring), fp4 and fp8, M >= 256
     assert plan(4, 2048, 4096, 8192) == [(58, 4096, 1)] and plan(4, 1024, 8192, 14336) == [(58, 8192, 1)]
     assert plan(8, 2048, 4096, 4096) == [(58, 4096, 1)] and plan(8, 2048, 4096, 2048) == [(24, 4096, 1)] and plan(4, 2048, 4096, 7168) == [(24, 4096, 1)]
+    # [r3] ... and whenever the 128x128 grid spills past one tile per CU while the 256x128 grid still fits (fp8 768 x 6144: 288 / 144 tiles, 28.3 -> 23.5 us)
+    assert plan(8, 768, 6144, 4096) == [(58, 6144, 1)] and plan(4, 1024, 5120, 25600) == [(58, 5120, 1)] and plan(8, 1024, 4096, 4096) != [(58, 4096, 1)]
+    # [r3] more than half a round of 256x256 tiles and >= 8 K stages: the persistent big tile already wins (2560 x 4096 x 4096: 160 tiles, 34.6 -> 28.8 us)
+    assert plan(4, 2560, 4096, 4096) == [(DEEPP, 4096, 1)] and plan(4, 3072, 4096, 4096) == [(DEEPP, 4096, 1)] and plan(4, 2560, 4096, 1024) == [(24, 4096, 1)]
     # an A operand of >= 2 GiB (262400 x 16384 fp4 = 2.15 GB) runs as two row ranges of whole 256-row tiles
     assert plan(4, 262400, 256, 16384) == [(DEEPP, 256, 1), (RING64, 256, 1)]   # 261888 rows, then the last 512
     # ... and a B operand of >= 2 GiB (262400 x 16384 fp4 weight) as two column ranges of whole 256-column tiles writing one D

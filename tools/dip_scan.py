@@ -1,0 +1,61 @@
+"""Scan the GEMM ops for wave-quantisation / tile-rule blind spots: for every (N, K) of the reference's benchmark models and a fine grid of batch
+sizes M, time the GEMM alone (C ABI, random operand bytes) and flag every place where a LARGER batch runs FASTER, or the TFLOP/s fall by more
+than 12 % from one M to the next.      python tools/dip_scan.py [mxf4|nvf4|mxf8 ...] > gpurun_out/dip_scan.txt"""
+import ctypes, os, sys
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+lib = ctypes.CDLL(os.path.join(ROOT, "qutlass_amd", "libqutlass_amd.so"), mode=ctypes.RTLD_LOCAL)
+NK = [(4096, 4096), (6144, 4096), (28672, 4096), (4096, 14336), (8192, 8192), (57344, 8192), (8192, 28672), (5120, 5120), (51200, 5120), (5120, 25600), (24576, 4096), (4096, 12288)]
+MS = [64, 96, 128, 192, 256, 384, 512, 768, 1024, 1536, 2048, 3072, 4096, 6144, 8192]
+P = lambda t: ctypes.c_void_p(t.data_ptr()); I = ctypes.c_int64; st = ctypes.c_void_p(0)
+
+
+def main():
+    fmts = sys.argv[1:] or ["mxf4", "nvf4", "mxf8"]
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev).manual_seed(0)
+    alpha = torch.ones(1, device=dev)
+    flagged = 0
+    for fmt in fmts:
+        epb = 1 if fmt == "mxf8" else 2          # elements per byte
+        gs = 16 if fmt == "nvf4" else 32
+        fn = {"mxf4": lib.qutlass_amd_matmul_mxf4_bf16_tn, "nvf4": lib.qutlass_amd_matmul_nvf4_bf16_tn, "mxf8": lib.qutlass_amd_matmul_mxf8_bf16_tn}[fmt]
+        for (n, k) in NK:
+            pad = lambda r: (r + 127) // 128 * 128
+            b = torch.randint(0, 256, (n, k // epb), dtype=torch.uint8, device=dev, generator=g)
+            sb = torch.randint(118, 126, (pad(n) * ((k // gs + 3) // 4 * 4),), dtype=torch.uint8, device=dev, generator=g)
+            prev = None
+            row = []
+            for m in MS:
+                a = torch.randint(0, 256, (m, k // epb), dtype=torch.uint8, device=dev, generator=g)
+                if fmt == "mxf8":
+                    a &= 0x77; 
+                sa = torch.randint(118, 126, (pad(m) * ((k // gs + 3) // 4 * 4),), dtype=torch.uint8, device=dev, generator=g)
+                d = torch.empty(m, n, dtype=torch.bfloat16, device=dev)
+                call = lambda: fn(P(a), P(b), P(sa), P(sb), P(alpha), P(d), I(m), I(n), I(k), st)
+                assert call() == 0, (fmt, m, n, k)
+                fl = 2.0 * m * n * k
+                reps = max(10, min(400, int(25e-3 / max(fl / 3e15, 4e-6))))
+                best = 1e9
+                for _ in range(2):
+                    for _ in range(max(3, reps // 4)): call()
+                    torch.cuda.synchronize()
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    for _ in range(reps): call()
+                    e1.record(); torch.cuda.synchronize()
+                    best = min(best, e0.elapsed_time(e1) * 1e3 / reps)
+                tf = fl / best * 1e-6
+                flag = ""
+                if prev is not None:
+                    if best < prev[0] * 0.98: flag = "  <-- FASTER than the smaller batch (%.1f us at M = %d)" % (prev[0], prev[2])
+                    elif tf < prev[1] * 0.88: flag = "  <-- TFLOP/s fall %.0f %%" % (100 * (1 - tf / prev[1]))
+                if flag: flagged += 1
+                print("%s N=%-6d K=%-6d M=%-5d %9.2f us %8.1f TFLOP/s%s" % (fmt, n, k, m, best, tf, flag), flush=True)
+                prev = (best, tf, m)
+            del b, sb
+    print("flagged:", flagged)
+
+
+main()
