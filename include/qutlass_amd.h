@@ -94,6 +94,18 @@ int qutlass_amd_matmul_mxf8_bf16_tn_ws(const void* A, const void* B, const void*
                                        void* workspace, int64_t workspace_bytes, void* stream);
 
 /*
+ * [r3] The NVFP4 GEMM with caller-owned scratch: split-K for outputs of a few dozen 128x128 tiles with a long K (e.g. M = 256, N = 4096,
+ * K = 14336), where the single pass can only fill the chip with 64x64 tiles whose 32x32 wave tiles dequantise two operand fragments per MFMA.
+ * Same contract as the MX entries above: fp32 partials in workspace[z][M][N], summed in fixed z order by a second kernel (alpha, bf16);
+ * qutlass_amd_nvf4_splitk_workspace_bytes(M, N, K) returns the bytes the planned split needs, 0 when the shape does not split; a NULL or
+ * smaller workspace silently runs the single-pass kernel (= qutlass_amd_matmul_nvf4_bf16_tn).
+ */
+int64_t qutlass_amd_nvf4_splitk_workspace_bytes(int64_t M, int64_t N, int64_t K);
+int qutlass_amd_matmul_nvf4_bf16_tn_ws(const void* A, const void* B, const void* A_sf, const void* B_sf,
+                                       const float* alpha, void* D, int64_t M, int64_t N, int64_t K,
+                                       void* workspace, int64_t workspace_bytes, void* stream);
+
+/*
  * MXFP8 NN: A is stored (K, M) row-major (the reference's ColumnMajor A), B (N, K); A_sf is still the
  * to_blocked layout of the (M, K/32) scale matrix.  K % 32 == 0, M % 16 == 0 (the reference's
  * AlignmentA = 16 on the contiguous M axis, gemm.cu:400).

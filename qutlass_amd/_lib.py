@@ -30,6 +30,8 @@ SYMBOLS = {
     "qutlass_amd_gemm_splitk_workspace_bytes": (_i64, [_i32, _i64, _i64, _i64]),
     "qutlass_amd_matmul_mxf4_bf16_tn_ws": (_i32, _GEMM_ARGS[:-1] + [_vp, _i64, _vp]),
     "qutlass_amd_matmul_mxf8_bf16_tn_ws": (_i32, _GEMM_ARGS[:-1] + [_vp, _i64, _vp]),
+    "qutlass_amd_nvf4_splitk_workspace_bytes": (_i64, [_i64, _i64, _i64]),
+    "qutlass_amd_matmul_nvf4_bf16_tn_ws": (_i32, _GEMM_ARGS[:-1] + [_vp, _i64, _vp]),
     "qutlass_amd_fused_quantize_mx": (_i32, [_vp, _vp, _i32, _i64, _i32, _vp, _vp, _vp, _vp]),
     "qutlass_amd_fused_quantize_nv": (_i32, [_vp, _vp, _i32, _i64, _i32, _vp, _vp, _vp, _vp]),
     "qutlass_amd_fused_quantize_mx_blocked": (_i32, [_vp, _vp, _i32, _i64, _i64, _i32, _vp, _vp, _vp, _vp]),

@@ -467,11 +467,11 @@ extern template int launch_gemm<GemmCfg<256, 256, 2, 2, 8, true>, 6>(GemmParams,
 
 // NVFP4 launches live in their own unit
 #if QAMD_DEF(4)
-int launch_nvf4_host(const NvGemmParams& p, hipStream_t s, int variant) {
-  return launch_nvf4_gemm(p, s, variant, chip_cus()) == hipSuccess ? 0 : 1;
+int launch_nvf4_host(const NvGemmParams& p, hipStream_t s, int variant, int* splits_out) {
+  return launch_nvf4_gemm(p, s, variant, chip_cus(), splits_out) == hipSuccess ? 0 : 1;
 }
 #else
-int launch_nvf4_host(const NvGemmParams& p, hipStream_t s, int variant);
+int launch_nvf4_host(const NvGemmParams& p, hipStream_t s, int variant, int* splits_out);
 #endif
 
 #if QAMD_DEF(1)
@@ -972,8 +972,18 @@ int qutlass_amd_matmul_mxf8_bf16_nn_fmt(const void* A, const void* B, const void
 }
 
 // ldd: row stride of D in elements when the call covers a column range of a wider output (0 = N)
+// [r3] split-K scratch of matmul_nvf4_bf16_tn: bytes for the fp32 partials ws[splits][M][N] of the planned split, 0 when the shape does not split
+static int64_t nvf4_ws_bytes(int64_t M, int64_t N, int64_t K) {
+  if (M <= 0 || N <= 0 || K < 32 || N % 4 || N * (K / 2) >= (1ll << 31) || M * (K / 2) >= (1ll << 31)) return 0;
+#if QAMD_BENCH
+  if (opt_nvf4_variant() >= 100) return 8 * M * N * 4;   // lab: room for any forced split
+#endif
+  const qamd::NvPlan pl = qamd::nvf4_plan(M, N, K, chip_cus(), true);
+  return pl.splits > 1 ? (int64_t)pl.splits * M * N * 4 : 0;
+}
+
 static int nvf4_impl(const void* A, const void* B, const void* A_sf, const void* B_sf, const float* alpha, void* D, int64_t M, int64_t N,
-                     int64_t K, int64_t ldd, void* stream) {
+                     int64_t K, int64_t ldd, void* stream, void* ws = nullptr, int64_t ws_bytes = 0) {
   const char* name = "matmul_nvf4_bf16_tn";
   if (!A || !B || !A_sf || !B_sf || !alpha || !D) return fail(QAMD_ERR_INVALID, "%s: null pointer argument", name);
   if (M <= 0 || N <= 0) return fail(QAMD_ERR_INVALID, "%s: M and N must be positive", name);
@@ -1009,13 +1019,38 @@ static int nvf4_impl(const void* A, const void* B, const void* A_sf, const void*
   p.a_bytes = (uint32_t)(M * rowbytes); p.b_bytes = (uint32_t)(N * rowbytes);
   p.sfa_bytes = (uint32_t)(cdiv(M, 128) * CB * 512); p.sfb_bytes = (uint32_t)(cdiv(N, 128) * CB * 512);
   p.dbg = opt_dbg();
-  if (launch_nvf4_host(p, (hipStream_t)stream, opt_nvf4_variant())) return fail(QAMD_ERR_INVALID, "%s: unknown nvf4_variant %d", name, opt_nvf4_variant());
-  return check_launch(name);
+  // split-K only with caller scratch of the size nvf4_ws_bytes reports for this very shape (a smaller or absent workspace runs the single pass)
+  const int64_t need = ws ? nvf4_ws_bytes(M, N, K) : 0;
+  p.ws = (need > 0 && ws_bytes >= need && ldd == N) ? (float*)ws : nullptr;
+  p.splits = 1; p.kt_per = 0;
+  int splits = 1;
+  if (launch_nvf4_host(p, (hipStream_t)stream, opt_nvf4_variant(), &splits)) return fail(QAMD_ERR_INVALID, "%s: unknown nvf4_variant %d", name, opt_nvf4_variant());
+  if (int rc = check_launch(name)) return rc;
+  if (splits <= 1) return QAMD_OK;
+  if ((int64_t)splits * M * N * 4 > ws_bytes) return fail(QAMD_ERR_INVALID, "%s: internal: split count %d exceeds the workspace", name, splits);
+  // second launch: sum the K ranges in fixed z order, alpha, bf16 (deterministic; gemm_mx.hip.h)
+  const int64_t quads = M * (N / 4);
+  const int grid = (int)std::min<int64_t>(cdiv(quads, 256), 2048);
+  switch (splits) {
+#define QAMD_RED(S_) case S_: hipLaunchKernelGGL(splitk_reduce_kernel<S_>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const float*)ws, (uint16_t*)D, alpha, (int)M, (int)N, (int)ldd); break;
+    QAMD_RED(2) QAMD_RED(3) QAMD_RED(4) QAMD_RED(5) QAMD_RED(6) QAMD_RED(7) QAMD_RED(8)
+#undef QAMD_RED
+    default: return fail(QAMD_ERR_INVALID, "%s: unsupported split count %d", name, splits);
+  }
+  return check_launch("splitk_reduce_kernel");
 }
 
 int qutlass_amd_matmul_nvf4_bf16_tn(const void* A, const void* B, const void* A_sf, const void* B_sf,
                                     const float* alpha, void* D, int64_t M, int64_t N, int64_t K, void* stream) {
   return nvf4_impl(A, B, A_sf, B_sf, alpha, D, M, N, K, 0, stream);
+}
+
+int64_t qutlass_amd_nvf4_splitk_workspace_bytes(int64_t M, int64_t N, int64_t K) { return nvf4_ws_bytes(M, N, K); }
+
+int qutlass_amd_matmul_nvf4_bf16_tn_ws(const void* A, const void* B, const void* A_sf, const void* B_sf, const float* alpha, void* D, int64_t M,
+                                       int64_t N, int64_t K, void* workspace, int64_t workspace_bytes, void* stream) {
+  if (workspace_bytes < 0 || (workspace_bytes > 0 && !workspace)) return fail(QAMD_ERR_INVALID, "matmul_nvf4_bf16_tn: invalid workspace");
+  return nvf4_impl(A, B, A_sf, B_sf, alpha, D, M, N, K, 0, stream, workspace, workspace_bytes);
 }
 
 // sf_rows / k: logical 2-D shape of x (rows of k elements) for the blocked-scale variants; k == 0: flat scales (the reference's contract)
@@ -1258,9 +1293,14 @@ int qutlass_amd_debug_gemm_plan(int ebits, int64_t M, int64_t N, int64_t K, int6
   return rc == QAMD_OK ? n : -1;
 }
 
-// debug only (not declared in the public header): the tile configuration matmul_nvf4_bf16_tn's auto rule picks for an M x N output
-// (gemm_nvf4.hip.h: nvf4_auto_cfg; 256 CUs assumed, no GPU touched)
-int qutlass_amd_debug_nvf4_plan(int64_t M, int64_t N, int64_t K) { return (M > 0 && N > 0 && K > 0) ? qamd::nvf4_auto_cfg(M, N, K, 256) : -2; }
+// debug only (not declared in the public header): what matmul_nvf4_bf16_tn's rule picks for an M x N x K problem (gemm_nvf4.hip.h: nvf4_plan; 256 CUs assumed,
+// no GPU touched): the tile configuration (-1 skinny, 0 256x256, 1 128x128, 2 128x64, 3 64x64, 4 256x128), plus 256 x the number of K ranges when may_split
+// (= the caller passes a workspace) and the shape splits
+int qutlass_amd_debug_nvf4_plan(int64_t M, int64_t N, int64_t K, int may_split) {
+  if (M <= 0 || N <= 0 || K <= 0) return -2;
+  const qamd::NvPlan pl = qamd::nvf4_plan(M, N, K, 256, may_split != 0);
+  return pl.splits > 1 ? pl.cfg + 256 * pl.splits : pl.cfg;
+}
 
 #if QAMD_BENCH
 // lab library only: device buffer for ABL_TRACE / ABL_CLOCK builds

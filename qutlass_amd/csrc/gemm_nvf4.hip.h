@@ -32,6 +32,9 @@ struct NvGemmParams {
   int tiles_m, tiles_n;
   uint32_t a_bytes, b_bytes, sfa_bytes, sfb_bytes;
   uint32_t* dbg;   // bench only: block 0 writes {shader cycles, 100 MHz ticks} of its K loop
+  float* ws;       // [r3] split-K: fp32 partials ws[z][M][N] (caller scratch, capi.hip nvf4_impl); null = single pass
+  int splits;      //      K ranges per tile (1 = single pass); the launch has tiles x splits workgroups, range z = blockIdx.x / tiles
+  int kt_per;      //      K stages (of 256 elements) per range: even, so that a range starts on LDS buffer 0
 };
 
 template <int BM_, int BN_, int WAVES_M_, int WAVES_N_>
@@ -74,7 +77,10 @@ __device__ __forceinline__ h8_t dq8(uint32_t w, h2_t s) {
   return h8_t{a[0], a[1], b[0], b[1], c[0], c[1], d[0], d[1]};
 }
 
-template <class C>
+// SPLIT: the workgroup walks K stages [z kt_per, (z + 1) kt_per) of its tile only and stores the raw fp32 accumulators to ws[z] (splitk_reduce_kernel sums
+// the ranges in z order, applies alpha and rounds: gemm_mx.hip.h).  For outputs of a few dozen 128x128 tiles and a long K, where the only other way to
+// give every CU work is 64x64 tiles whose 32x32 wave tiles dequantise two fragments per MFMA.
+template <class C, bool SPLIT = false>
 __global__ __launch_bounds__(C::THREADS) void gemm_nvf4_kernel(const NvGemmParams p) {
   constexpr int BM = C::BM, BN = C::BN, MT = C::MT, NT = C::NT;
   __shared__ __attribute__((aligned(16))) char smem[C::LDS_BYTES];
@@ -86,9 +92,10 @@ __global__ __launch_bounds__(C::THREADS) void gemm_nvf4_kernel(const NvGemmParam
   const int i32 = lane & 31, g = lane >> 5;
 
   int tile_m, tile_n;
+  const int nb = p.tiles_m * p.tiles_n;
+  const int z = SPLIT ? (int)blockIdx.x / nb : 0;
   {
-    const int nb = p.tiles_m * p.tiles_n;
-    const int b2 = xcd_remap(blockIdx.x, nb);
+    const int b2 = xcd_remap((int)blockIdx.x - z * nb, nb);
     constexpr int GM = 4;
     const int group = GM * p.tiles_n;
     const int gid = b2 / group;
@@ -263,11 +270,12 @@ __global__ __launch_bounds__(C::THREADS) void gemm_nvf4_kernel(const NvGemmParam
     acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb[s & 1][n], fa[s & 1][m], acc[m][n], 0, 0, 0);
   };
 
-  issue_stage(0, 0);
-  for (int kt = 0; kt < KT; ++kt) {
+  const int kt_begin = SPLIT ? z * p.kt_per : 0, kt_end = SPLIT ? min(KT, kt_begin + p.kt_per) : KT;   // (kt_per is even: a range starts on buffer 0)
+  issue_stage(kt_begin, 0);
+  for (int kt = kt_begin; kt < kt_end; ++kt) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (kt + 1 < KT) issue_stage(kt + 1, (kt + 1) & 1);
+    if (kt + 1 < kt_end) issue_stage(kt + 1, (kt + 1) & 1);
     const char* st = smem + (kt & 1) * C::STAGE_BYTES;
     load_scales(st, 0);
     load_chunks(st, 0);
@@ -299,6 +307,24 @@ __global__ __launch_bounds__(C::THREADS) void gemm_nvf4_kernel(const NvGemmParam
     }
   }
 
+  if constexpr (SPLIT) {   // raw fp32 partial of this K range: a lane owns 4 consecutive columns per q -> 16-byte stores (layout of gemm_mx.hip.h epilogue_partial)
+    float* base = p.ws + (size_t)z * p.M * p.N;
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      const int grow = m0 + wave_m * C::WTM + 32 * m + i32;
+#pragma unroll
+      for (int n = 0; n < NT; ++n)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int gcol = n0 + wave_n * C::WTN + 32 * n + 8 * q + 4 * g;
+          if (grow < p.M && gcol < p.N) {
+            const v4f v = {acc[m][n][4 * q + 0], acc[m][n][4 * q + 1], acc[m][n][4 * q + 2], acc[m][n][4 * q + 3]};
+            *(v4f*)(base + (size_t)grow * p.N + gcol) = v;
+          }
+        }
+    }
+    return;
+  }
   const float alpha = *p.alpha;
   __syncthreads();
   // the epilogue re-derives lane / thread id (v_mbcnt) instead of keeping them live across the K loop: with 256 accumulators
@@ -692,14 +718,9 @@ bool launch_nvf4_ablation(NvGemmParams p, hipStream_t s, int variant);
 //   128x128 (two per CU)   a full round of 2 x CUs tiles 64.7; a remainder of <= CUs tiles runs one per CU: 34 ... 37; one tile more: 55 ... 64.7
 // The rule before: the 256x128 tile whenever its round occupancy beat that of the 128x128 grid -- 2560 x 4096 x 4096 ran 106 us (two rounds of
 // 256x128) where 160 tiles of 256x256 take 84.5; 1024 x 4096 ran on 128 tiles, 54.7 us against 35.5.
-inline int nvf4_auto_cfg(int64_t M, int64_t N, int64_t K, int cus) {
-  const int64_t want = cus * 3 / 4;
+// (outputs of >= 3/4 x CUs tiles of 128x128 with M, N > 128; below that: nvf4_plan)
+inline int nvf4_big_cfg(int64_t M, int64_t N, int64_t K, int cus, double* t_us = nullptr) {
   auto tiles = [&](int bm, int bn) { return ((M + bm - 1) / bm) * ((N + bn - 1) / bn); };
-  if (M <= 64 || (M <= 128 && tiles(64, 64) < want)) return -1;
-  if (M <= 128 || N <= 128 || tiles(128, 128) < want) {
-    if (tiles(128, 128) >= want) return 1;
-    return tiles(128, 64) >= want ? 2 : 3;
-  }
   const double sk = (double)std::max<int64_t>(K, 256) / 4096.0, fix = 5.0;   // per round: `fix` us of prologue / epilogue + a part proportional to K
   auto rt = [&](double t16) { return fix + (t16 - fix) * sk; };
   auto ramp = [&](double lo, double hi, double o) { return lo + (hi - lo) * std::min(1.0, std::max(0.0, (o - 0.75) / 0.25)); };
@@ -717,15 +738,71 @@ inline int nvf4_auto_cfg(int64_t M, int64_t N, int64_t K, int cus) {
   int cfg = 0;
   double best = T0;
   if (M >= 256 && T4 < best * 0.985) { cfg = 4; best = T4; }   // (ties go to the larger tile)
-  if (T1 < best * 0.985) cfg = 1;
+  if (T1 < best * 0.985) { cfg = 1; best = T1; }
+  if (t_us) *t_us = best;
   return cfg;
+}
+
+// [r3] The whole rule: tile configuration + number of K ranges (split-K needs caller scratch: may_split).  Shared by the launcher, by
+// qutlass_amd_nvf4_splitk_workspace_bytes and by the CPU tests' debug entry (capi.hip); no GPU touched.
+//
+// Small and mid-size outputs are priced by a second model, fitted (least squares on log time, rms 7 %) to tools/calib_nv_small.py: 132 shapes
+// M = 16 ... 1024 x the (N, K) of the reference's benchmark models x {skinny, 64x64, 128x64, 128x128 tiles} x {1, 2, 4, 8} K ranges
+// (profiles/calib_nv_small_r3.txt):
+//   tile kernels  a + g b kt / 16 [+ reduce pass]   kt = K stages (256 elements) per workgroup, g = 1 while every CU holds at most one workgroup,
+//                                                   else ceil(workgroups / CUs) x e (several workgroups on a CU overlap each other: e < 1)
+//                 128x128: a 4.1 b 29.2 e 0.91    128x64: a 3.2 b 20.3 e 0.85    64x64: a 3.6 b 13.8 e 0.78   (us; b per 16 stages = K 4096)
+//   reduce pass   2.9 us + (S + 1) M N 4 bytes at 4.4 TB/s, and a split must win by 5 %; a K range is never shorter than 4 stages
+//   skinny        5.0 + 4.4 ceil(workgroups of 32x32 / CUs) K / 4096, priced 5 % low (the fit overestimates it at K = 4096), M <= 128 only; always for M <= 32
+// Against the calibration the chosen candidates sum to 10 353 us (best measured candidate per shape: 10 288; the occupancy thresholds this replaces:
+// 11 057), e.g. 256 x 4096 x 14336 54.7 -> 39.2 us (128x128 tiles, 4 K ranges), 128 x 8192 x 28672 107 -> 67, 64 x 28672 x 4096 36.7 -> 26.6 (64x64 tiles
+// instead of the skinny kernel), 512 x 5120 x 5120 47.0 -> 41.1 (160 tiles of 128x128 instead of 320 of 128x64, which put two on 64 CUs).
+struct NvPlan { int cfg, splits, kt_per; };   // cfg as above (-1 skinny); splits = K ranges actually launched (none empty), kt_per = stages per range (even)
+inline NvPlan nvf4_plan(int64_t M, int64_t N, int64_t K, int cus, bool may_split) {
+  if (M <= 32) return {-1, 1, 0};
+  auto tiles = [&](int bm, int bn) { return ((M + bm - 1) / bm) * ((N + bn - 1) / bn); };
+  const int KT = (int)((K / 2 + 127) / 128);
+  static constexpr int BM[3] = {128, 128, 64}, BN[3] = {128, 64, 64};
+  static constexpr double A[3] = {4.107, 3.241, 3.616}, B[3] = {29.172, 20.30, 13.831}, E[3] = {0.906, 0.853, 0.776};
+  NvPlan best = {1, 1, 0};
+  double best_t = 1e30;
+  for (int c = 0; c < 3; ++c)
+    for (int S = 1; S <= (may_split && N % 4 == 0 ? 8 : 1); S *= 2) {
+      const int kt = 2 * ((KT + 2 * S - 1) / (2 * S)), S2 = (KT + kt - 1) / kt;
+      if (S > 1 && (kt < 4 || S2 < 2)) continue;
+      const double n = (double)(tiles(BM[c], BN[c]) * S2) / cus;
+      const double g = n <= 1.0 ? 1.0 : std::ceil(n) * E[c];
+      double t = A[c] + g * B[c] * kt / 16.0;
+      if (S2 > 1) t = (t + 2.897 + (double)(S2 + 1) * M * N * 4.0 / 4.409e6) * 1.05;
+      if (t < best_t) { best_t = t; best = {c + 1, S2, S2 > 1 ? kt : 0}; }
+    }
+  if (M <= 128) {
+    const double wg = (double)(((M + 31) / 32) * ((N + 31) / 32));
+    if (0.95 * (4.96 + 4.40 * std::ceil(wg / cus) * K / 4096.0) < best_t) return {-1, 1, 0};
+  }
+  if (M > 128 && N > 128 && tiles(128, 128) >= cus * 3 / 4) {   // the large-output model above; a split only where it beats that model's time by 5 %
+    double tb;
+    const int cb = nvf4_big_cfg(M, N, K, cus, &tb);
+    if (!(best.splits > 1 && best_t < tb * 0.95)) return {cb, 1, 0};
+  }
+  return best;
 }
 
 #if QAMD_TU == 0 || QAMD_TU == 4
 // Returns hipErrorInvalidValue for a variant this build does not know (the product library knows only 0 = auto).
 // cus: compute units of the device (capi.hip chip_cus): every occupancy threshold below derives from it
-inline hipError_t launch_nvf4_gemm(NvGemmParams p, hipStream_t s, int variant = 0, int cus = 256) {
+// *splits_out (when given): the number of K ranges the launch wrote to p.ws -- the caller then runs splitk_reduce_kernel; 1 = D is final
+inline hipError_t launch_nvf4_gemm(NvGemmParams p, hipStream_t s, int variant = 0, int cus = 256, int* splits_out = nullptr) {
   const int64_t want = cus * 3 / 4;
+  if (splits_out) *splits_out = 1;
+  int force_split = 0;
+#if QAMD_BENCH
+  if (variant >= 100 && variant < 140) {   // lab: 100 + 10 cfg + S = tile cfg (1 128x128, 2 128x64, 3 64x64) with S K ranges (tools/calib_nv_small.py)
+    force_split = variant % 10;
+    variant = 4 + (variant - 100) / 10;    // 5 / 6 / 7 force the tile below
+    if (force_split < 2 || variant < 5 || variant > 7) return hipErrorInvalidValue;
+  }
+#endif
 #if !QAMD_BENCH
   if (variant != 0) return hipErrorInvalidValue;
 #endif
@@ -733,8 +810,8 @@ inline hipError_t launch_nvf4_gemm(NvGemmParams p, hipStream_t s, int variant = 
   const bool small = p.M <= 128 || p.N <= 128 || (int64_t)((p.M + 255) / 256) * ((p.N + 255) / 256) < want;
   // small batch: split-K kernel for M <= 64, and up to M = 128 while even 64x64 tiles would leave CUs idle (measured,
   // M = 128, K = 4096: N = 4096 11.8 us vs 17.3 us for 64x64 tiles; N = 14336 35.6 us vs 25.2 us for 128x64 tiles)
-  const int64_t tiles64 = (int64_t)((p.M + 63) / 64) * ((p.N + 63) / 64);
-  if (variant == 3 || (variant == 0 && (p.M <= 64 || (p.M <= 128 && tiles64 < want)))) {
+  const NvPlan plan = nvf4_plan(p.M, p.N, p.K, cus, p.ws != nullptr);
+  if (variant == 3 || (variant == 0 && plan.cfg < 0)) {
     hipLaunchKernelGGL((gemm_nvf4_skinny_kernel<8>), dim3((p.N + 31) / 32, (p.M + 31) / 32), dim3(512), 0, s, p);
     return hipSuccess;
   }
@@ -752,9 +829,8 @@ inline hipError_t launch_nvf4_gemm(NvGemmParams p, hipStream_t s, int variant = 
     auto tiles = [&](int bm, int bn) { return (int64_t)((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn); };
     int cfg = small ? 1 : 0;                                  // 0: 256x256, 1: 128x128, 2: 128x64, 3: 64x64
     if (variant == 0 || variant == 1) {
-      // the round-by-round pricing of nvf4_auto_cfg above ([r2] wave quantisation of the 256x256 grid, [r3] the 256x128 four-wave tile and the cost model)
-      const int a = nvf4_auto_cfg(p.M, p.N, p.K, cus);
-      if (a >= 0) cfg = a;
+      // the pricing of nvf4_plan above ([r2] wave quantisation of the 256x256 grid, [r3] the 256x128 four-wave tile and the cost model)
+      if (plan.cfg >= 0) cfg = plan.cfg;
     }
     if (variant == 5) cfg = 1;
     if (variant == 6) cfg = 2;
@@ -765,6 +841,25 @@ inline hipError_t launch_nvf4_gemm(NvGemmParams p, hipStream_t s, int variant = 
     if (variant == 8) cfg = 8;    // lab: 128x128 tile on 2 waves of 128x64 (A dequantised by 2 waves, B by 1)
     if (variant == 9) cfg = 9;    //      128x128 tile on 2 waves of 64x128
 #endif
+    // [r3] split-K (caller scratch in p.ws, capi.hip checks its size against nvf4_plan): K ranges of an even number of 256-element stages, none empty
+    int splits = 1;
+    if (p.ws && p.N % 4 == 0) {
+      splits = force_split ? force_split : (variant == 0 ? plan.splits : 1);
+      const int KT = (p.K / 2 + 127) / 128;
+      p.kt_per = 2 * ((KT + 2 * splits - 1) / (2 * splits));
+      splits = (KT + p.kt_per - 1) / p.kt_per;
+    }
+    p.splits = splits;
+    if (splits <= 1) p.ws = nullptr;
+    if (splits_out) *splits_out = splits;
+#define QAMD_NV_LAUNCH_SPLIT(BM_, BN_, WM_, WN_)                                                               \
+    if (splits > 1) {                                                                                          \
+      using C = NvCfg<BM_, BN_, WM_, WN_>;                                                                     \
+      p.tiles_m = (p.M + C::BM - 1) / C::BM;                                                                   \
+      p.tiles_n = (p.N + C::BN - 1) / C::BN;                                                                   \
+      hipLaunchKernelGGL((gemm_nvf4_kernel<C, true>), dim3(p.tiles_m * p.tiles_n * splits), dim3(C::THREADS), 0, s, p); \
+      return hipSuccess;                                                                                       \
+    }
 #define QAMD_NV_LAUNCH(BM_, BN_, WM_, WN_)                                                                     \
     {                                                                                                          \
       using C = NvCfg<BM_, BN_, WM_, WN_>;                                                                     \
@@ -783,10 +878,12 @@ inline hipError_t launch_nvf4_gemm(NvGemmParams p, hipStream_t s, int variant = 
     if (cfg == 8) QAMD_NV_LAUNCH(128, 128, 1, 2)
     if (cfg == 9) QAMD_NV_LAUNCH(128, 128, 2, 1)
 #endif
-    if (cfg == 1) QAMD_NV_LAUNCH(128, 128, 2, 2)
-    if (cfg == 2) QAMD_NV_LAUNCH(128, 64, 2, 2)
+    if (cfg == 1) { QAMD_NV_LAUNCH_SPLIT(128, 128, 2, 2) QAMD_NV_LAUNCH(128, 128, 2, 2) }
+    if (cfg == 2) { QAMD_NV_LAUNCH_SPLIT(128, 64, 2, 2) QAMD_NV_LAUNCH(128, 64, 2, 2) }
+    QAMD_NV_LAUNCH_SPLIT(64, 64, 2, 2)
     QAMD_NV_LAUNCH(64, 64, 2, 2)
 #undef QAMD_NV_LAUNCH
+#undef QAMD_NV_LAUNCH_SPLIT
   }
 #if QAMD_BENCH
   if (variant >= 10 && launch_nvf4_ablation(p, s, variant)) return hipSuccess;

@@ -154,7 +154,13 @@ Tensor matmul(const Tensor& A, const Tensor& B, const Tensor& A_sf, const Tensor
                                                    a_e5m2 ? QAMD_FP8_E5M2 : QAMD_FP8_E4M3, QAMD_FP8_E4M3, wp, ws_bytes, s)
              : qutlass_amd_matmul_mxf4_bf16_tn_ws(A.data_ptr(), B.data_ptr(), A_sf.data_ptr(), B_sf.data_ptr(), al, out.data_ptr(), M, N, K, wp, ws_bytes, s);
   }
-  else if (G == Gemm::NVF4) rc = qutlass_amd_matmul_nvf4_bf16_tn(A.data_ptr(), B.data_ptr(), A_sf.data_ptr(), B_sf.data_ptr(), al, out.data_ptr(), M, N, K, s);
+  else if (G == Gemm::NVF4) {
+    // [r3] the same for NVFP4: outputs of a few dozen 128x128 tiles with a long K split K (M = 256, N = 4096, K = 14336: 54.7 -> 39.2 us)
+    const int64_t ws_bytes = qutlass_amd_nvf4_splitk_workspace_bytes(M, N, K);
+    Tensor ws = ws_bytes > 0 ? torch::stable::new_empty(A, {ws_bytes}, ScalarType::Byte) : Tensor();
+    rc = qutlass_amd_matmul_nvf4_bf16_tn_ws(A.data_ptr(), B.data_ptr(), A_sf.data_ptr(), B_sf.data_ptr(), al, out.data_ptr(), M, N, K,
+                                            ws_bytes > 0 ? ws.data_ptr() : nullptr, ws_bytes, s);
+  }
   else {
     // scratch for the (K, M) -> (M, K) re-layout of small problems, from torch's stream-ordered caching allocator; shapes
     // that read the (K, M) operand in place need none (0 bytes: nothing is allocated)

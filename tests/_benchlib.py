@@ -28,6 +28,8 @@ _SIGS = {
     "qutlass_amd_gemm_splitk_workspace_bytes": (_i64, [_i32, _i64, _i64, _i64]),
     "qutlass_amd_matmul_mxf4_bf16_tn_ws": (_i32, _GEMM[:-1] + [_vp, _i64, _vp]),
     "qutlass_amd_matmul_mxf8_bf16_tn_ws": (_i32, _GEMM[:-1] + [_vp, _i64, _vp]),
+    "qutlass_amd_nvf4_splitk_workspace_bytes": (_i64, [_i64, _i64, _i64]),
+    "qutlass_amd_matmul_nvf4_bf16_tn_ws": (_i32, _GEMM[:-1] + [_vp, _i64, _vp]),
     "qutlass_amd_mxfp4_transpose_mxfp8": (_i32, [_vp, _vp, _i64, _i64, _vp, _vp, _vp]),
     "qutlass_amd_last_error": (ctypes.c_char_p, []),
     "qutlass_amd_version": (ctypes.c_char_p, []),
@@ -116,7 +118,13 @@ def _plain(entry: str, a, b, a_sf, b_sf, alpha):
 
 
 def matmul_nvf4_bf16_tn(a, b, a_sf, b_sf, alpha):
-    return _plain("qutlass_amd_matmul_nvf4_bf16_tn", a, b, a_sf, b_sf, alpha)
+    lib = load()
+    m, n, k = a.shape[0], b.shape[0], b.shape[1] * 2
+    out = torch.empty(m, n, dtype=torch.bfloat16, device=a.device)
+    ws_bytes = lib.qutlass_amd_nvf4_splitk_workspace_bytes(m, n, k)
+    ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=a.device)
+    _check(lib.qutlass_amd_matmul_nvf4_bf16_tn_ws(_p(a), _p(b), _p(a_sf), _p(b_sf), _p(alpha), _p(out), m, n, k, _p(ws) if ws_bytes else None, ws_bytes, _stream()))
+    return out
 
 
 def matmul_ada_mxf4_bf16_tn(a, b, a_sf, b_sf, alpha):

@@ -111,25 +111,49 @@ def test_split_k_workspace_plan_is_a_pure_host_function(lib):
 
 
 def test_nvf4_tile_rule(lib):
-    """matmul_nvf4_bf16_tn's tile choice (gemm_nvf4.hip.h: nvf4_auto_cfg) through the debug entry: -1 skinny split-K, 0 256x256, 1 128x128,
-    2 128x64, 3 64x64, 4 256x128 on four waves.  [r3] Among {0, 4, 1} a round-based cost model picks (full rounds x the tile's time + the
-    last round priced by how much of the chip it fills); the expectations below are the measured winners of profiles/calib_tiles_r3.txt
-    (256 CUs): 2560 x 4096 has 160 tiles of 256x256 in one round (84.5 us) against 106 / 88 for the finer grids; 3072 x 6144 has 288 big
-    tiles = two rounds (175 us) against 148 on 128x128; 1024 x 4096 (128 tiles of 256x128, half the CUs idle: 52 us) stays on 128x128 (36)."""
+    """matmul_nvf4_bf16_tn's tile choice (gemm_nvf4.hip.h: nvf4_plan) through the debug entry: -1 skinny split-K, 0 256x256, 1 128x128,
+    2 128x64, 3 64x64, 4 256x128 on four waves, + 256 x K ranges when the caller brings a workspace and the shape splits.  [r3] Two fitted
+    cost models pick (large outputs: full rounds x the tile's time + the last round priced by its fill; small ones: per-tile time by
+    workgroups per CU, K stages per workgroup and the reduce pass); the expectations below are the measured winners of
+    profiles/calib_tiles_r3.txt and profiles/calib_nv_small_r3.txt (256 CUs): 2560 x 4096 has 160 tiles of 256x256 in one round (84.5 us)
+    against 106 / 88 for the finer grids; 3072 x 6144 has 288 big tiles = two rounds (175 us) against 148 on 128x128; 1024 x 4096 (128 tiles
+    of 256x128, half the CUs idle: 52 us) stays on 128x128 (36); 256 x 4096 x 14336 runs 64 tiles of 128x128 in 4 K ranges (39.2 us) instead
+    of 256 tiles of 64x64 (54.7)."""
     import ctypes
 
+    from qutlass_amd._lib import QAMD_ERR_INVALID
+
     f = lib.qutlass_amd_debug_nvf4_plan   # debug entry, deliberately not in the public header
-    f.restype, f.argtypes = ctypes.c_int, [ctypes.c_int64] * 3
+    f.restype, f.argtypes = ctypes.c_int, [ctypes.c_int64] * 3 + [ctypes.c_int]
     K = 4096
-    assert f(8192, 8192, 8192) == 0 and f(4096, 4096, K) == 0 and f(4096, 14336, K) == 0
-    assert f(2048, 4096, K) == 4 and f(1536, 4096, K) == 4 and f(1024, 6144, K) == 4        # 256 / 192 / 192 tiles of 256x128: one round
-    assert f(2560, 4096, K) == 0 and f(3072, 4096, K) == 0 and f(2048, 6144, K) == 0       # 160 / 192 / 192 tiles of 256x256: one round
-    assert f(1024, 4096, K) == 1 and f(512, 6144, K) == 1                                   # the 256x128 grid would leave half the chip idle
-    assert f(3072, 6144, K) == 1 and f(4096, 5120, 5120) == 1 and f(5120, 4096, K) == 1     # 288 / 320 / 320 big tiles: two rounds at 56 / 63 %
-    assert f(6144, 4096, K) == 0 and f(4096, 6144, K) == 0                                  # 384 big tiles = 1.5 rounds: 128x128 is no better (180 vs 188)
-    assert f(4096, 5120, 512) == 0 and f(8192, 4096, 14336) == 0
-    assert f(512, 4096, K) == 2 and f(256, 4096, K) in (2, 3) and f(64, 4096, K) == -1 and f(1, 4096, K) == -1
-    assert f(0, 4096, K) == -2 and f(4096, 4096, 0) == -2
+    for ws in (0, 1):   # large outputs never split
+        assert f(8192, 8192, 8192, ws) == 0 and f(4096, 4096, K, ws) == 0 and f(4096, 14336, K, ws) == 0
+        assert f(2048, 4096, K, ws) == 4 and f(1536, 4096, K, ws) == 4 and f(1024, 6144, K, ws) == 4        # 256 / 192 / 192 tiles of 256x128: one round
+        assert f(2560, 4096, K, ws) == 0 and f(3072, 4096, K, ws) == 0 and f(2048, 6144, K, ws) == 0       # 160 / 192 / 192 tiles of 256x256: one round
+        assert f(1024, 4096, K, ws) == 1 and f(512, 6144, K, ws) == 1                                       # the 256x128 grid would leave half the chip idle
+        assert f(3072, 6144, K, ws) == 1 and f(4096, 5120, 5120, ws) == 1 and f(5120, 4096, K, ws) == 1     # 288 / 320 / 320 big tiles: two rounds at 56 / 63 %
+        assert f(6144, 4096, K, ws) == 0 and f(4096, 6144, K, ws) == 0                                      # 384 big tiles = 1.5 rounds: 128x128 is no better (180 vs 188)
+        assert f(4096, 5120, 512, ws) == 0 and f(8192, 4096, 14336, ws) == 0
+        # small outputs at K = 4096 (16 stages): nothing to split
+        assert f(512, 4096, K, ws) == 2 and f(256, 4096, K, ws) == 3 and f(64, 4096, K, ws) == -1 and f(1, 4096, K, ws) == -1 and f(96, 4096, K, ws) == -1
+        assert f(32, 28672, K, ws) == -1 and f(64, 28672, K, ws) == 3       # 64 rows against a wide weight: 448 tiles of 64x64 (26.6 us) beat the skinny kernel (36.7)
+        assert f(512, 5120, 5120, ws) == 1 and f(384, 5120, 5120, ws) == 2  # 160 tiles of 128x128 (41.1 us) against 320 of 128x64 (47.0); 240 of 128x64 fit one per CU
+        assert f(0, 4096, K, ws) == -2 and f(4096, 4096, 0, ws) == -2
+    # long K, few tiles: K ranges (only with a workspace)
+    assert f(256, 4096, 14336, 0) == 3 and f(256, 4096, 14336, 1) == 1 + 256 * 4      # 64 tiles of 128x128 x 4 ranges of 14 stages
+    assert f(128, 4096, 14336, 0) == -1 and f(128, 4096, 14336, 1) == 1 + 256 * 7     # 32 tiles x 7 ranges of 8 stages (8 asked for; 56 stages)
+    assert f(768, 4096, 14336, 0) == 1 and f(768, 4096, 14336, 1) == 1 + 256 * 4      # 192 tiles: 768 workgroups balance better than 192 (94.7 vs 108.3 us)
+    assert f(1024, 5120, 25600, 0) == 4 and f(1024, 5120, 25600, 1) == 1 + 256 * 4    # 320 tiles of 128x128 x 4 (252 us) against 160 of 256x128 (300)
+    assert f(64, 8192, 28672, 0) == -1 and f(64, 8192, 28672, 1) == 3 + 256 * 4       # 128 tiles of 64x64 x 4 (49.9 us) against the skinny kernel (69.5)
+    assert f(1024, 4096, 14336, 1) == 1 and f(256, 2048, 2048, 1) == 3                # a full round already / K too short (8 stages)
+    # the workspace query describes the same plan: ranges x M x N fp32
+    g = lib.qutlass_amd_nvf4_splitk_workspace_bytes
+    assert g(256, 4096, 14336) == 4 * 256 * 4096 * 4 and g(128, 4096, 14336) == 7 * 128 * 4096 * 4 and g(200, 4104, 14368) == 8 * 200 * 4104 * 4
+    assert g(4096, 4096, 4096) == 0 and g(256, 4096, 4096) == 0 and g(16, 4096, 14336) == 0 and g(0, 4096, 4096) == 0 and g(256, 4096, 0) == 0
+    dummy = ctypes.c_void_p(0x1000)
+    h = lib.qutlass_amd_matmul_nvf4_bf16_tn_ws
+    assert h(dummy, dummy, dummy, dummy, dummy, dummy, 128, 128, 128, None, 64, None) == QAMD_ERR_INVALID and "invalid workspace" in lib.qutlass_amd_last_error().decode()
+    assert h(dummy, dummy, dummy, dummy, dummy, dummy, 128, 128, 48, None, 0, None) == QAMD_ERR_INVALID and "multiple of 32" in lib.qutlass_amd_last_error().decode()
 
 
 def test_auto_dispatch_rules_dry_run(lib):

@@ -115,6 +115,21 @@ def test_fuzz_matmul_nvf4_and_mxf8(q):
         out = q.matmul_nvf4_bf16_tn(a, b, to_blocked(sa.view(e4)), to_blocked(sb.view(e4)), alpha)
         ref = oracle.gemm_blockscaled(oracle.KIND_NVFP4, _np(a), _np(b), oracle.to_blocked(_np(sa)), oracle.to_blocked(_np(sb)), 1.0, m, n, k)
         assert np.array_equal(_np(out), ref), (it, m, n, k, int((_np(out) != ref).sum()))
+    # [r3] long K against small outputs: the NVFP4 split-K path (ranges of an even number of 256-element stages + the reduce pass), K tails included
+    nsplit = 0
+    for it in range(8):
+        m, n = int(rng.choice([40, 100, 136, 200])), int(rng.integers(8, 48)) * 8
+        k = int(rng.integers(96, 224)) * 32
+        a, b = _rand_codes(rng, m, k // 2), _rand_codes(rng, n, k // 2)
+        sa = torch.from_numpy(rng.integers(0x30, 0x48, size=(m, k // 16), dtype=np.uint8)).to(DEV)
+        sb = torch.from_numpy(rng.integers(0x30, 0x48, size=(n, k // 16), dtype=np.uint8)).to(DEV)
+        alpha = torch.tensor([0.25], device=DEV)
+        e4 = torch.float8_e4m3fn
+        nsplit += q._lib.load().qutlass_amd_nvf4_splitk_workspace_bytes(m, n, k) > 0
+        out = q.matmul_nvf4_bf16_tn(a, b, to_blocked(sa.view(e4)), to_blocked(sb.view(e4)), alpha)
+        ref = oracle.gemm_blockscaled(oracle.KIND_NVFP4, _np(a), _np(b), oracle.to_blocked(_np(sa)), oracle.to_blocked(_np(sb)), 0.25, m, n, k)
+        assert np.array_equal(_np(out), ref), ("nvf4 split", it, m, n, k, int((_np(out) != ref).sum()))
+    assert nsplit >= 2, nsplit
     for it in range(16):
         m, n = int(rng.choice([16, 48, 128, 144, 272])), int(rng.integers(1, 50)) * 8
         k = int(rng.integers(1, 20)) * 32

@@ -1,5 +1,5 @@
 """Scan the GEMM ops for wave-quantisation / tile-rule blind spots: for every (N, K) of the reference's benchmark models and a fine grid of batch
-sizes M, time the GEMM alone (C ABI, random operand bytes) and flag every place where a LARGER batch runs FASTER, or the TFLOP/s fall by more
+sizes M, time the GEMM alone (C ABI entries with caller scratch, random operand bytes) and flag every place where a LARGER batch runs FASTER, or the TFLOP/s fall by more
 than 12 % from one M to the next.      python tools/dip_scan.py [mxf4|nvf4|mxf8 ...] > gpurun_out/dip_scan.txt"""
 import ctypes, os, sys
 import torch
@@ -20,7 +20,11 @@ def main():
     for fmt in fmts:
         epb = 1 if fmt == "mxf8" else 2          # elements per byte
         gs = 16 if fmt == "nvf4" else 32
-        fn = {"mxf4": lib.qutlass_amd_matmul_mxf4_bf16_tn, "nvf4": lib.qutlass_amd_matmul_nvf4_bf16_tn, "mxf8": lib.qutlass_amd_matmul_mxf8_bf16_tn}[fmt]
+        # the entries with caller scratch (what the torch ops call): split-K where the plan wants it
+        fn = {"mxf4": lib.qutlass_amd_matmul_mxf4_bf16_tn_ws, "nvf4": lib.qutlass_amd_matmul_nvf4_bf16_tn_ws, "mxf8": lib.qutlass_amd_matmul_mxf8_bf16_tn_ws}[fmt]
+        lib.qutlass_amd_gemm_splitk_workspace_bytes.restype = lib.qutlass_amd_nvf4_splitk_workspace_bytes.restype = ctypes.c_int64
+        ws_need = (lambda m, n, k: lib.qutlass_amd_nvf4_splitk_workspace_bytes(I(m), I(n), I(k))) if fmt == "nvf4" else \
+                  (lambda m, n, k: lib.qutlass_amd_gemm_splitk_workspace_bytes(8 if fmt == "mxf8" else 4, I(m), I(n), I(k)))
         for (n, k) in NK:
             pad = lambda r: (r + 127) // 128 * 128
             b = torch.randint(0, 256, (n, k // epb), dtype=torch.uint8, device=dev, generator=g)
@@ -33,7 +37,9 @@ def main():
                     a &= 0x77; 
                 sa = torch.randint(118, 126, (pad(m) * ((k // gs + 3) // 4 * 4),), dtype=torch.uint8, device=dev, generator=g)
                 d = torch.empty(m, n, dtype=torch.bfloat16, device=dev)
-                call = lambda: fn(P(a), P(b), P(sa), P(sb), P(alpha), P(d), I(m), I(n), I(k), st)
+                wsb = ws_need(m, n, k)
+                ws = torch.empty(max(wsb, 16), dtype=torch.uint8, device=dev)
+                call = lambda: fn(P(a), P(b), P(sa), P(sb), P(alpha), P(d), I(m), I(n), I(k), P(ws) if wsb else ctypes.c_void_p(0), I(wsb), st)
                 assert call() == 0, (fmt, m, n, k)
                 fl = 2.0 * m * n * k
                 reps = max(10, min(400, int(25e-3 / max(fl / 3e15, 4e-6))))
