@@ -802,7 +802,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 enum { SCHED_LOCKSTEP = 0, SCHED_PINGPONG = 1, SCHED_QUEUE = 2, SCHED_SIMPLE = 3, SCHED_DEEP = 4, SCHED_REGSTAGE = 5, SCHED_DEEP_NN = 6, SCHED_RING = 7, SCHED_RING_RM = 8, SCHED_RINGP = 9, SCHED_RINGP_RM = 10 };
 // pipelined schedule on a 2-deep ring: sized for two workgroups per CU, i.e. (4-wave configurations) two waves per SIMD = 256 registers
 template <class C, int SCHED>
-constexpr int gemm_min_waves_per_eu() { return ((SCHED == 9 || SCHED == 10) && C::NSTAGE == 2 && C::NWAVES == 4) ? 2 : 1; }
+constexpr int gemm_min_waves_per_eu() { return ((SCHED == 9 || SCHED == 10) && C::NSTAGE == 2 && C::NWAVES == 4 && C::BM * C::BN <= 128 * 128) ? 2 : 1; }
 template <class C, int SCHED>
 __global__ __launch_bounds__(C::THREADS, (gemm_min_waves_per_eu<C, SCHED>())) void gemm_mx_kernel(const GemmParams p) {
   __shared__ __attribute__((aligned(16))) char smem[C::LDS_BYTES];
