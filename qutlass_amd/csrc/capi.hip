@@ -500,14 +500,15 @@ inline int64_t splitk_ws_bytes(int variant, int64_t M, int64_t N, int splits) {
   return splitk_partial_bytes(M, N, splits);
 #endif
 }
+// the round-1/2 rule: thresholds on the tile counts (fitted on sweeps of the in-stream C++ harness, profiles/native_r1_ring.log, native_r2_tilesplit.log)
 template <int EBITS>
-SmallPlan plan_small(int64_t M, int64_t N, int64_t K) {
+SmallPlan plan_small_rule(int64_t M, int64_t N, int64_t K, bool may_split) {
   const int64_t cus = chip_cus();
   const int64_t T64 = cdiv(M, 64) * cdiv(N, 64), T128 = cdiv(M, 128) * cdiv(N, 128);
   if (T64 <= cus) {
     const int64_t KT = cdiv(K * EBITS / 8, 128);
     int64_t S = 1;
-    if (T64 < cus && KT >= opt_splitk_min_kt()) {                                       // shorter K: the reduce pass costs more than it saves
+    if (may_split && T64 < cus && KT >= opt_splitk_min_kt()) {                          // shorter K: the reduce pass costs more than it saves
       const int64_t wg = opt_splitk_wg() > 0 ? opt_splitk_wg() : cus;
       S = std::min<int64_t>(std::min<int64_t>(8, wg / T64), KT / 8);   // up to one workgroup per CU, >= 8 stages per split
       if (S < 1) S = 1;
@@ -523,6 +524,53 @@ SmallPlan plan_small(int64_t M, int64_t N, int64_t K) {
   if (T64 <= 2 * cus) return {N >= M ? 72 : 71, 1};
   if (M > 64 && N > 64 && T128 <= cus) return {73, 1};
   return {0, 1};
+}
+
+// [r3] ... corrected by a fitted cost model where that rule leaves a long K to too few, too small tiles: it only ever splits 64x64 tiles, so 96 x 5120 x 25600
+// ran 160 tiles of 64x64 unsplit (27.5 us; MXFP8 50.3) where 40 tiles of 128x128 in 4 K ranges take 19.5 (30.4).  tools/calib_mx_small.py timed the ring schedule
+// on 64x64 / 64x128 / 128x128 tiles with 1 / 2 / 4 / 8 K ranges on 132 shapes per format (profiles/calib_mx_small_r3.txt); least squares on log time (rms 14 % /
+// 18 %, measurements >= 13 us only -- below that the Python caller of the calibration is the bound) give, per tile kernel,
+//     a + g b kt / 16 [+ r0 + (S + 1) M N 4 bytes / bw for the reduce pass]      kt = 128-byte K stages per workgroup, g = 1 while workgroups <= CUs, else
+//                                                                                ceil(workgroups / CUs) e
+// The model is a CORRECTION, not the rule: it replaces the rule's choice only where its own prediction for that choice is more than 8 % above its best candidate
+// and the best candidate takes >= 12 us (K ranges of >= 4 stages).  Against the calibration: 23 of 264 shapes change, MXFP4 96 / 128 x 8192 x 28672 32.4 / 34.1 ->
+// 28.2 / 30.5 us, x 5120 x 25600 27.5 / 28.0 -> 19.5 / 21.1; MXFP8 192 / 256 x 4096 x 14336 30.9 / 31.5 -> 23.0 / 25.3, 96 ... 384 x 5120 x 25600 50 ... 68 -> 30 ... 54,
+// 96 ... 256 x 8192 x 28672 59 ... 84 -> 44 ... 70; three shapes lose 2 - 4 % (MXFP8 16 / 32 x 8192 x 8192, MXFP4 64 x 8192 x 28672).
+template <int EBITS>
+SmallPlan plan_small(int64_t M, int64_t N, int64_t K, bool may_split = true) {
+  const SmallPlan cur = plan_small_rule<EBITS>(M, N, K, may_split);
+  if (cur.variant != 70 && cur.variant != 72 && cur.variant != 73) return cur;      // (71: M > N, not calibrated)
+  const int64_t cus = chip_cus();
+  //                                   64x64  64x128 128x128
+  static constexpr double A4[3] = {6.07, 6.04, 6.30}, B4[3] = {3.41, 4.80, 6.58}, E4[3] = {0.99, 1.2, 1.2};
+  static constexpr double A8[3] = {3.31, 3.79, 2.91}, B8[3] = {3.87, 4.83, 6.41}, E8[3] = {0.90, 1.2, 1.2};
+  const double* A = EBITS == 4 ? A4 : A8;
+  const double* B = EBITS == 4 ? B4 : B8;
+  const double* E = EBITS == 4 ? E4 : E8;
+  const double r0 = EBITS == 4 ? 1.39 : 3.86, bw = EBITS == 4 ? 2.63e6 : 2.79e6;
+  static constexpr int VAR[3] = {70, 72, 73}, BM[3] = {64, 64, 128}, BN[3] = {64, 128, 128};
+  const int64_t KT = cdiv(K * EBITS / 8, 128);
+  auto price = [&](int c, int S, int* s2) {
+    const int64_t per = cdiv(KT, S), S2 = cdiv(KT, per);
+    const double n = (double)(cdiv(M, BM[c]) * cdiv(N, BN[c]) * S2) / (double)cus;
+    double t = A[c] + (n <= 1.0 ? 1.0 : std::ceil(n) * E[c]) * B[c] * (double)per / 16.0;
+    if (S2 > 1) t += r0 + (double)(S2 + 1) * (double)M * (double)N * 4.0 / bw;
+    *s2 = (int)S2;
+    return t;
+  };
+  int s2;
+  const int ccur = cur.variant == 70 ? 0 : cur.variant == 72 ? 1 : 2;
+  const double t_cur = price(ccur, cur.splits, &s2);
+  SmallPlan best = cur;
+  double t_best = t_cur;
+  for (int c = 0; c < 3; ++c)
+    for (int S = 1; S <= (may_split && N % 4 == 0 ? 8 : 1); S *= 2) {
+      if (S > 1 && cdiv(KT, S) < 4) continue;
+      const double t = price(c, S, &s2);
+      if (S > 1 && s2 < 2) continue;
+      if (t < t_best) { t_best = t; best = {VAR[c], s2}; }
+    }
+  return (t_best >= 12.0 && t_best < 0.92 * t_cur) ? best : cur;
 }
 
 // a_fmt (MXFP8 only): QAMD_FP8_E4M3 / QAMD_FP8_E5M2 element format of A
@@ -586,7 +634,9 @@ int gemm_mx(const char* name, const void* A, const void* B, const void* A_sf, co
   int variant = opt_gemm_variant();
   if (variant >= 61 && variant <= 66) variant = 0;   // these select the NN operand path only (matmul_mxf8_bf16_nn)
   // ring schedule + optional split-K (needs caller scratch; "pp_flags" bit 7 turns split-K off, bit 8 the ring rule)
-  const SmallPlan pl = plan_small<EBITS>(M, N, K);
+  // the plan with K ranges needs the caller's scratch; without it (or with too little) the best single-pass plan
+  SmallPlan pl = plan_small<EBITS>(M, N, K, true);
+  if (pl.variant && pl.splits > 1 && !(ws && ws_bytes >= splitk_ws_bytes(pl.variant, M, N, pl.splits) && !(opt_pp_flags() & 128))) pl = plan_small<EBITS>(M, N, K, false);
   auto ring_launch = [&](int v, int splits) -> int {
     {   // every split non-empty (a forced count may not divide the K stages)
       const int64_t KT = cdiv(K * EBITS / 8, 128);
@@ -657,6 +707,9 @@ int gemm_mx(const char* name, const void* A, const void* B, const void* A_sf, co
     // bound: N = 28672, K = 4096, M = 32: 12.6 us with 448 tiles of 64x64 vs 14.3 us with 224 of 64x128)
     if (M <= 64) variant = (tiles(64, 128) >= cus * 3 / 2) ? 28 : 29;
     else if (N <= 64) variant = (tiles(128, 64) >= want) ? 27 : 29;
+    // [r3] at most 128 rows against a wide weight (more 128x128 tiles than CUs): the 256-row persistent tile would be half empty -- 128x128 tiles, two workgroups
+    // per CU (96 x 57344 x 8192: 52.4 -> 42.7 us, 128 x 51200 x 5120: 32.7 -> 26.8, MXFP8 96 x 57344 x 8192 113.5 -> 100.3; profiles/calib_mx_small_r3.txt)
+    else if (M <= 128 && tiles(128, 128) >= want) variant = 24;
     // [r3] ... or more than HALF of them with K >= 8 stages: the smaller tiles then no longer fit one round (128x128: two per CU, 256x128: one per CU --
     // both hold exactly cus / 2 tiles' worth of 256x256 output), and a second, part-filled round costs more than idle CUs do:
     // 2560 x 4096 x 4096 (160 tiles) 34.6 -> 28.8 us, 1536 x 6144 x 4096 33.2 -> 28.3, 2048 x 5120 x 5120 42.2 -> 35.3, MXFP8 2560 x 4096 x 4096

@@ -100,9 +100,14 @@ def test_split_k_workspace_plan_is_a_pure_host_function(lib):
     assert ws(4, 64, 4096, 4096) == 0            # 16 stages: too short to pay for the reduction
     assert ws(4, 64, 4096, 8192) == layout(64, 4096, 4) and ws(8, 64, 4096, 4096) == layout(64, 4096, 4)   # 32 stages (fp8: K = 4096)
     assert ws(4, 4096, 4096, 4096) == 0 and ws(4, 0, 4096, 4096) == 0 and ws(5, 64, 4096, 14336) == 0
-    for m, n, k in [(8, 512, 28672), (40, 1032, 14464), (128, 2048, 57344), (1, 64, 12288)]:
+    for m, n, k in [(8, 512, 28672), (40, 1032, 14464), (1, 64, 12288)]:
         b = ws(4, m, n, k)
         assert b == layout(m, n, splits(4, m, n, k)) and 2 <= splits(4, m, n, k) <= 8, (m, n, k, b)
+    # [r3] where that rule leaves a long K to too few, too small tiles, the fitted model of capi.hip (plan_small) corrects it -- larger tiles, more K ranges
+    # (measured: profiles/calib_mx_small_r3.txt): 96 x 5120 x 25600 ran 160 unsplit 64x64 tiles (27.5 us), now 40 tiles of 128x128 in 4 ranges (19.5 us)
+    assert splits(4, 96, 5120, 25600) == 0 and ws(4, 96, 5120, 25600) == layout(96, 5120, 4)
+    assert splits(8, 192, 4096, 14336) == 0 and ws(8, 192, 4096, 14336) == layout(192, 4096, 4)        # MXFP8: 30.9 -> 23.0 us
+    assert splits(4, 128, 2048, 57344) == 4 and ws(4, 128, 2048, 57344) == layout(128, 2048, 8)       # 32 tiles of 64x128 x 8 instead of 64 of 64x64 x 4
     dummy = ctypes.c_void_p(0x1000)
     g = lib.qutlass_amd_matmul_mxf4_bf16_tn_ws
     assert g(dummy, dummy, dummy, dummy, dummy, dummy, 128, 128, 96, None, 0, None) == QAMD_ERR_INVALID
@@ -214,6 +219,10 @@ def test_auto_dispatch_rules_dry_run(lib):
     assert plan(8, 768, 6144, 4096) == [(58, 6144, 1)] and plan(4, 1024, 5120, 25600) == [(58, 5120, 1)] and plan(8, 1024, 4096, 4096) != [(58, 4096, 1)]
     # [r3] more than half a round of 256x256 tiles and >= 8 K stages: the persistent big tile already wins (2560 x 4096 x 4096: 160 tiles, 34.6 -> 28.8 us)
     assert plan(4, 2560, 4096, 4096) == [(DEEPP, 4096, 1)] and plan(4, 3072, 4096, 4096) == [(DEEPP, 4096, 1)] and plan(4, 2560, 4096, 1024) == [(24, 4096, 1)]
+    # [r3] the fitted model's corrections of the small-output rule (long K, few tiles: larger ring tiles x more K ranges; only with scratch) and the wide-weight rule
+    assert plan(4, 96, 5120, 25600, big) == [(RING128, 5120, 4)] and plan(4, 96, 5120, 25600) == [(RING64, 5120, 1)]
+    assert plan(8, 192, 4096, 14336, big) == [(RING128, 4096, 4)] and plan(4, 128, 2048, 57344, big) == [(RING64x128, 2048, 8)]
+    assert plan(4, 96, 57344, 8192) == [(24, 57344, 1)] and plan(8, 128, 51200, 5120) == [(24, 51200, 1)] and plan(4, 192, 57344, 8192) == [(DEEPP, 57344, 1)]
     # an A operand of >= 2 GiB (262400 x 16384 fp4 = 2.15 GB) runs as two row ranges of whole 256-row tiles
     assert plan(4, 262400, 256, 16384) == [(DEEPP, 256, 1), (RING64, 256, 1)]   # 261888 rows, then the last 512
     # ... and a B operand of >= 2 GiB (262400 x 16384 fp4 weight) as two column ranges of whole 256-column tiles writing one D

@@ -260,6 +260,27 @@ def test_split_k_small_output_long_k(q, m, n, k):
     assert np.array_equal(_np(out)[rows], ref)
 
 
+@pytest.mark.parametrize("m,n,k", [(96, 5120, 25600), (128, 8192, 28672), (100, 2056, 57344)])
+def test_split_k_model_corrected_plans(q, m, n, k):
+    """[r3] Where the tile-count rule would leave a long K to unsplit (or twice-split) 64x64 tiles, capi.hip's fitted model picks 128x128 / 64x128 ring tiles with
+    4 - 8 K ranges (reference counterpart: the tile / split heuristics inside CUTLASS' kernel selection, gemm.cu:195-222).  Same contract as every split: on
+    quantised data all partial sums are exact, so the result equals the single-pass launch (split-K off, "pp_flags" bit 7) and the oracle, bit for bit."""
+    from qutlass_amd.utils import to_blocked
+
+    a_q, a_s, b_q, b_s, out = _pipeline(q, m, n, k, "abs_max", seed=m + k)
+    t64 = -(-m // 64) * -(-n // 64)
+    ws = q._lib.load().qutlass_amd_gemm_splitk_workspace_bytes(4, m, n, k)
+    assert ws % (m * n * 4) == 0 and ws // (m * n * 4) >= 4 and (t64 >= 128 or ws // (m * n * 4) == 8)   # more ranges than 256 / (64x64 tiles) allows
+    asf, bsf, al = to_blocked(a_s), to_blocked(b_s), torch.tensor([1.0], device=DEV)
+    with lab.forced(pp_flags=1 | 128):
+        single = lab.matmul_mxf4_bf16_tn(a_q, b_q, asf, bsf, al)
+    assert torch.equal(out, single)
+    rows = sorted({0, m // 3, m - 1})
+    sfa = oracle.to_blocked(np.ascontiguousarray(np.concatenate([_np(a_s)[rows], np.zeros((128 - len(rows), k // 32), np.uint8)])))
+    ref = oracle.gemm_blockscaled(oracle.KIND_MXFP4, np.ascontiguousarray(_np(a_q)[rows]), _np(b_q), sfa, oracle.to_blocked(_np(b_s)), 1.0, len(rows), n, k)
+    assert np.array_equal(_np(out)[rows], ref)
+
+
 def test_matmul_mxf4_largest_sweep_shape_row_samples(q):
     """M = 65536 is the top of the reference's benchmark sweep (benchmarks/bench_mxfp4_sm100.py:176-194): tile offsets
     approach 2^31 bytes.  Random codes, scales within 3 binades (exact regime) -> sampled rows must match the oracle bit
