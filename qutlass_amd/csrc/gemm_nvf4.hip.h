@@ -80,7 +80,7 @@ __device__ __forceinline__ h8_t dq8(uint32_t w, h2_t s) {
 // SPLIT: the workgroup walks K stages [z kt_per, (z + 1) kt_per) of its tile only and stores the raw fp32 accumulators to ws[z] (splitk_reduce_kernel sums
 // the ranges in z order, applies alpha and rounds: gemm_mx.hip.h).  For outputs of a few dozen 128x128 tiles and a long K, where the only other way to
 // give every CU work is 64x64 tiles whose 32x32 wave tiles dequantise two fragments per MFMA.
-template <class C, bool SPLIT = false>
+template <class C, bool SPLIT = false, bool FENCED = false>
 __global__ __launch_bounds__(C::THREADS) void gemm_nvf4_kernel(const NvGemmParams p) {
   constexpr int BM = C::BM, BN = C::BN, MT = C::MT, NT = C::NT;
   __shared__ __attribute__((aligned(16))) char smem[C::LDS_BYTES];
@@ -223,7 +223,7 @@ __global__ __launch_bounds__(C::THREADS) void gemm_nvf4_kernel(const NvGemmParam
   // kernel is at the socket power limit once the two units overlap; not kept.
   // The smaller tiles run several workgroups per CU, whose waves fill each other's shadows, and lose 5 % to a fixed order: they keep the
   // plain loop.
-  constexpr bool FENCE = BM >= 256;
+  constexpr bool FENCE = BM >= 256 || FENCED;   // FENCED: lab, the fixed order for a smaller tile (one workgroup per CU after a K split)
   constexpr int NSLOT = MT * NT, NH = 2 * (MT + NT);
   h2_t sa[2][MT][2], sb[2][NT][2];     // [jj & 1][.][jl]
   v4i ca[2][MT], cb[2][NT];            // [j & 1]
@@ -797,10 +797,12 @@ inline hipError_t launch_nvf4_gemm(NvGemmParams p, hipStream_t s, int variant = 
   if (splits_out) *splits_out = 1;
   int force_split = 0;
 #if QAMD_BENCH
+  bool fenced = false;
+  if (variant >= 150 && variant < 160) { fenced = true; variant -= 40; }   // lab: 150 + S = 128x128 tiles, S K ranges (1 = none), fixed MFMA / dequantisation order
   if (variant >= 100 && variant < 140) {   // lab: 100 + 10 cfg + S = tile cfg (1 128x128, 2 128x64, 3 64x64) with S K ranges (tools/calib_nv_small.py)
     force_split = variant % 10;
     variant = 4 + (variant - 100) / 10;    // 5 / 6 / 7 force the tile below
-    if (force_split < 2 || variant < 5 || variant > 7) return hipErrorInvalidValue;
+    if ((force_split < 2 && !fenced) || force_split < 1 || variant < 5 || variant > 7) return hipErrorInvalidValue;
   }
 #endif
 #if !QAMD_BENCH
@@ -877,6 +879,16 @@ inline hipError_t launch_nvf4_gemm(NvGemmParams p, hipStream_t s, int variant = 
 #if QAMD_BENCH
     if (cfg == 8) QAMD_NV_LAUNCH(128, 128, 1, 2)
     if (cfg == 9) QAMD_NV_LAUNCH(128, 128, 2, 1)
+#endif
+#if QAMD_BENCH
+    if (cfg == 1 && fenced) {
+      using C = NvCfg<128, 128, 2, 2>;
+      p.tiles_m = (p.M + C::BM - 1) / C::BM;
+      p.tiles_n = (p.N + C::BN - 1) / C::BN;
+      if (splits > 1) hipLaunchKernelGGL((gemm_nvf4_kernel<C, true, true>), dim3(p.tiles_m * p.tiles_n * splits), dim3(C::THREADS), 0, s, p);
+      else hipLaunchKernelGGL((gemm_nvf4_kernel<C, false, true>), dim3(p.tiles_m * p.tiles_n), dim3(C::THREADS), 0, s, p);
+      return hipSuccess;
+    }
 #endif
     if (cfg == 1) { QAMD_NV_LAUNCH_SPLIT(128, 128, 2, 2) QAMD_NV_LAUNCH(128, 128, 2, 2) }
     if (cfg == 2) { QAMD_NV_LAUNCH_SPLIT(128, 64, 2, 2) QAMD_NV_LAUNCH(128, 64, 2, 2) }
