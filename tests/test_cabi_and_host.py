@@ -161,6 +161,34 @@ def test_nvf4_tile_rule(lib):
     assert h(dummy, dummy, dummy, dummy, dummy, dummy, 128, 128, 48, None, 0, None) == QAMD_ERR_INVALID and "multiple of 32" in lib.qutlass_amd_last_error().decode()
 
 
+def test_split_plans_are_consistent_over_a_shape_grid(lib):
+    """Invariants of the two split planners over 5 000 shapes (no GPU): a plan without caller scratch never splits; the workspace queries return
+    ranges x M x N fp32 with 2 ... 8 ranges or 0; the launch plan the dry-run hook records uses exactly the ranges the query sized the scratch for."""
+    import ctypes
+
+    nv = lib.qutlass_amd_debug_nvf4_plan
+    nv.restype, nv.argtypes = ctypes.c_int, [ctypes.c_int64] * 3 + [ctypes.c_int]
+    nv_ws, mx_ws = lib.qutlass_amd_nvf4_splitk_workspace_bytes, lib.qutlass_amd_gemm_splitk_workspace_bytes
+    dry = lib.qutlass_amd_debug_gemm_plan
+    dry.restype = ctypes.c_int
+    dry.argtypes = [ctypes.c_int] + [ctypes.c_int64] * 4 + [ctypes.POINTER(ctypes.c_int), ctypes.c_int]
+    out = (ctypes.c_int * 24)()
+    rng = __import__("numpy").random.default_rng(11)
+    for _ in range(5000):
+        m = int(rng.choice([1, 7, 33, 64, 96, 128, 200, 256, 384, 512, 1000, 2048]))
+        n = int(rng.integers(1, 2048)) * 8
+        k = int(rng.integers(1, 256)) * 128
+        r0, r1 = nv(m, n, k, 0), nv(m, n, k, 1)
+        assert -1 <= r0 <= 4 and (r1 < 256 or (1 <= r1 % 256 <= 3 and 2 <= r1 // 256 <= 8)), (m, n, k, r0, r1)
+        b = nv_ws(m, n, k)
+        assert b == (r1 // 256 if r1 >= 256 else 0) * m * n * 4, (m, n, k, r1, b)
+        for ebits in (4, 8):
+            b = mx_ws(ebits, m, n, k)
+            assert b % (m * n * 4) == 0 and b // (m * n * 4) in (0, 2, 3, 4, 5, 6, 7, 8), (ebits, m, n, k, b)
+            assert dry(ebits, m, n, k, 0, out, 8) >= 1 and out[2] == 1                      # no scratch: one pass
+            assert dry(ebits, m, n, k, 1 << 40, out, 8) >= 1 and out[2] == max(1, b // (m * n * 4)), (ebits, m, n, k, out[0], out[2], b)
+
+
 def test_auto_dispatch_rules_dry_run(lib):
     """The tile / schedule choice of the MX GEMMs (DESIGN.md sections 3.3, 3.7, 3.8) through the library's dry-run hook:
     the real dispatch code runs, launches are recorded instead of issued.  (variant, N of the launch, K splits)."""
