@@ -479,6 +479,32 @@ def _mxfp8_close(got_bits, want_bits):
     return np.abs(got - want) <= tol
 
 
+@pytest.mark.parametrize("m,n,k", [(192, 4096, 14336), (384, 4096, 14336), (96, 5120, 12800), (64, 4096, 4096)])
+def test_matmul_mxf8_split_k_plans_vs_single_pass_and_oracle(q, m, n, k):
+    """[r3] MXFP8 outputs whose plan splits K -- the round-2 rule (64x64 ring tiles, last shape) and the round-3 corrections (128x128 ring tiles in 2 - 4 ranges): the
+    split result against the forced single pass (an fp32 sum in another order: the oracle's tolerance between them, equal on almost every element) and against the
+    oracle on sampled rows (tests/mxfp8_test.py tolerance class)."""
+    from qutlass_amd.utils import to_blocked
+
+    g = torch.Generator(device="cpu").manual_seed(m + n + k)
+    x = (torch.randn(m, k, generator=g) * 4).to(torch.float8_e4m3fn).to(DEV)
+    y = (torch.randn(n, k, generator=g) * 4).to(torch.float8_e4m3fn).to(DEV)
+    sa = torch.randint(120, 131, (m, k // 32), dtype=torch.uint8, generator=g).to(DEV)
+    sb = torch.randint(120, 131, (n, k // 32), dtype=torch.uint8, generator=g).to(DEV)
+    e8, al = torch.float8_e8m0fnu, torch.tensor([1.0], device=DEV)
+    ws = q._lib.load().qutlass_amd_gemm_splitk_workspace_bytes(8, m, n, k)
+    assert ws >= 2 * m * n * 4
+    out = q.matmul_mxf8_bf16_tn(x, y, to_blocked(sa.view(e8)), to_blocked(sb.view(e8)), al)
+    with lab.forced(pp_flags=1 | 128):
+        single = lab.matmul_mxf8_bf16_tn(x, y, to_blocked(sa.view(e8)), to_blocked(sb.view(e8)), al)
+    assert _mxfp8_close(_np(out), _np(single)).all()
+    assert float((out.view(torch.int16) == single.view(torch.int16)).float().mean()) > 0.98
+    rows = sorted({0, m // 2, m - 1})
+    sfa = oracle.to_blocked(np.ascontiguousarray(np.concatenate([_np(sa)[rows], np.zeros((128 - len(rows), k // 32), np.uint8)])))
+    ref = oracle.gemm_blockscaled(oracle.KIND_MXFP8_TN, np.ascontiguousarray(_np(x)[rows]), _np(y), sfa, oracle.to_blocked(_np(sb)), 1.0, len(rows), n, k)
+    assert _mxfp8_close(_np(out)[rows], ref).all()
+
+
 @pytest.mark.parametrize("variant", [0, 20, 30, 70, 73, 90])   # auto, 8-wave simple, 4-wave deep (per tile), ring 64x64 / 128x128, persistent deep
 def test_matmul_mxf8_large_tiles_vs_oracle(q, variant):
     from qutlass_amd.utils import to_blocked
