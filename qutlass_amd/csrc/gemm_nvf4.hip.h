@@ -798,6 +798,11 @@ inline hipError_t launch_nvf4_gemm(NvGemmParams p, hipStream_t s, int variant = 
   int force_split = 0;
 #if QAMD_BENCH
   bool fenced = false;
+  if (variant >= 160 && variant < 170) {   // lab: 160 + S = 128x128 tiles on TWO waves of 128x64 (6 fragment dequantisations per 8 MFMAs), S K ranges
+    force_split = variant - 160;
+    variant = 8;
+    if (force_split < 1) return hipErrorInvalidValue;
+  }
   if (variant >= 150 && variant < 160) { fenced = true; variant -= 40; }   // lab: 150 + S = 128x128 tiles, S K ranges (1 = none), fixed MFMA / dequantisation order
   if (variant >= 100 && variant < 140) {   // lab: 100 + 10 cfg + S = tile cfg (1 128x128, 2 128x64, 3 64x64) with S K ranges (tools/calib_nv_small.py)
     force_split = variant % 10;
@@ -877,7 +882,7 @@ inline hipError_t launch_nvf4_gemm(NvGemmParams p, hipStream_t s, int variant = 
     // [r3] 256x128 on four waves of 128x64: 6 fragment dequantisations per 8 MFMAs (0.75 per MFMA) against 4 per 4 for the 64x64 wave tiles of the 128x128 tile
     if (cfg == 4) QAMD_NV_LAUNCH(256, 128, 2, 2)
 #if QAMD_BENCH
-    if (cfg == 8) QAMD_NV_LAUNCH(128, 128, 1, 2)
+    if (cfg == 8) { QAMD_NV_LAUNCH_SPLIT(128, 128, 1, 2) QAMD_NV_LAUNCH(128, 128, 1, 2) }
     if (cfg == 9) QAMD_NV_LAUNCH(128, 128, 2, 1)
 #endif
 #if QAMD_BENCH

@@ -8,6 +8,9 @@ sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, ROOT)
 import _benchlib as lab
 
 # (M, N, K, [candidates])   0 = the plan (auto), 3 skinny, 5 / 6 / 7 = 128x128 / 128x64 / 64x64 single pass, 110 + S / 120 + S / 130 + S = those tiles with S K ranges
+CASES2W = [(256, 4096, 14336, [0, 114, 164, 168]), (128, 4096, 14336, [0, 118, 168]), (192, 4096, 14336, [0, 114, 168]), (96, 8192, 28672, [0, 118, 168, 164]), (256, 5120, 25600, [0, 118, 168]),
+           (512, 5120, 25600, [0, 114, 164, 168]), (768, 4096, 14336, [0, 114, 162, 164]), (1024, 4096, 4096, [0, 5, 161, 162]), (512, 4096, 4096, [0, 6, 161, 162]), (256, 8192, 8192, [0, 112, 162, 164]),
+           (2048, 4096, 4096, [0, 5, 161]), (1024, 4096, 14336, [0, 5, 161, 162])]
 CASES = [(64, 28672, 4096, [0, 3, 7]), (64, 14336, 4096, [0, 3, 7]), (64, 8192, 28672, [0, 3, 134, 7]), (64, 5120, 25600, [0, 3, 134]), (128, 4096, 14336, [0, 3, 118, 7]),
          (96, 4096, 14336, [0, 3, 118]), (256, 4096, 14336, [0, 7, 114, 112]), (192, 4096, 14336, [0, 7, 114]), (512, 5120, 5120, [0, 5, 6, 114]), (256, 5120, 5120, [0, 6, 7, 114]),
          (96, 8192, 8192, [0, 3, 7, 114]), (128, 8192, 8192, [0, 7, 114]), (64, 4096, 4096, [0, 3, 7, 134]), (128, 4096, 4096, [0, 3, 7]), (256, 4096, 4096, [0, 7, 6, 112]),
@@ -20,7 +23,7 @@ def main():
     g = torch.Generator(device=dev).manual_seed(0)
     alpha = torch.ones(1, device=dev)
     pad = lambda r: (r + 127) // 128 * 128
-    for (m, n, k, cands) in CASES:
+    for (m, n, k, cands) in (CASES2W if "2w" in sys.argv[1:] else CASES):
         a = torch.randint(0, 256, (m, k // 2), dtype=torch.uint8, device=dev, generator=g)
         b = torch.randint(0, 256, (n, k // 2), dtype=torch.uint8, device=dev, generator=g)
         sa = torch.randint(0x30, 0x48, (pad(m) * ((k // 16 + 3) // 4 * 4),), dtype=torch.uint8, device=dev, generator=g)
@@ -51,7 +54,7 @@ def main():
                     del gr
                 except Exception as e:
                     res.append((v, float("nan")))
-        nm = lambda v: NAME[v] if v in NAME else "%s/%d" % ({11: "128x128", 12: "128x64", 13: "64x64"}[v // 10], v % 10)
+        nm = lambda v: NAME[v] if v in NAME else "%s/%d" % ({11: "128x128", 12: "128x64", 13: "64x64", 16: "2wave128x128"}[v // 10], v % 10)
         plan = res[0][1]
         print("%5d %6d %6d | " % (m, n, k) + "  ".join("%s %.2f" % (nm(v), t) for v, t in res) + "   | best other / plan = %.3f" % (min(t for v, t in res[1:]) / plan), flush=True)
 
