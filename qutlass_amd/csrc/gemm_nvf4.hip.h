@@ -752,7 +752,7 @@ inline int nvf4_big_cfg(int64_t M, int64_t N, int64_t K, int cus, double* t_us =
 //   tile kernels  a + g b kt / 16 [+ reduce pass]   kt = K stages (256 elements) per workgroup, g = 1 while every CU holds at most one workgroup,
 //                                                   else ceil(workgroups / CUs) x e (several workgroups on a CU overlap each other: e < 1)
 //                 128x128: a 4.1 b 29.2 e 0.91    128x64: a 3.2 b 20.3 e 0.85    64x64: a 3.6 b 13.8 e 0.78   (us; b per 16 stages = K 4096)
-//   reduce pass   2.9 us + (S + 1) M N 4 bytes at 4.4 TB/s, and a split must win by 5 %; a K range is never shorter than 4 stages
+//   reduce pass   2.9 us + (S + 1) M N 4 bytes at 4.4 TB/s, and a split must win by 2 % (5 % against the large-output model); a K range is never shorter than 4 stages
 //   skinny        5.0 + 4.4 ceil(workgroups of 32x32 / CUs) K / 4096, priced 5 % low (the fit overestimates it at K = 4096), M <= 128 only; always for M <= 32
 // Against the calibration the chosen candidates sum to 10 353 us (best measured candidate per shape: 10 288; the occupancy thresholds this replaces:
 // 11 057), e.g. 256 x 4096 x 14336 54.7 -> 39.2 us (128x128 tiles, 4 K ranges), 128 x 8192 x 28672 107 -> 67, 64 x 28672 x 4096 36.7 -> 26.6 (64x64 tiles
@@ -773,7 +773,7 @@ inline NvPlan nvf4_plan(int64_t M, int64_t N, int64_t K, int cus, bool may_split
       const double n = (double)(tiles(BM[c], BN[c]) * S2) / cus;
       const double g = n <= 1.0 ? 1.0 : std::ceil(n) * E[c];
       double t = A[c] + g * B[c] * kt / 16.0;
-      if (S2 > 1) t = (t + 2.897 + (double)(S2 + 1) * M * N * 4.0 / 4.409e6) * 1.05;
+      if (S2 > 1) t = (t + 2.897 + (double)(S2 + 1) * M * N * 4.0 / 4.409e6) * 1.02;
       if (t < best_t) { best_t = t; best = {c + 1, S2, S2 > 1 ? kt : 0}; }
     }
   if (M <= 128) {

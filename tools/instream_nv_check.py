@@ -12,7 +12,7 @@ CASES2W = [(256, 4096, 14336, [0, 114, 164, 168]), (128, 4096, 14336, [0, 118, 1
            (512, 5120, 25600, [0, 114, 164, 168]), (768, 4096, 14336, [0, 114, 162, 164]), (1024, 4096, 4096, [0, 5, 161, 162]), (512, 4096, 4096, [0, 6, 161, 162]), (256, 8192, 8192, [0, 112, 162, 164]),
            (2048, 4096, 4096, [0, 5, 161]), (1024, 4096, 14336, [0, 5, 161, 162])]
 CASES = [(64, 28672, 4096, [0, 3, 7]), (64, 14336, 4096, [0, 3, 7]), (64, 8192, 28672, [0, 3, 134, 7]), (64, 5120, 25600, [0, 3, 134]), (128, 4096, 14336, [0, 3, 118, 7]),
-         (96, 4096, 14336, [0, 3, 118]), (256, 4096, 14336, [0, 7, 114, 112]), (192, 4096, 14336, [0, 7, 114]), (512, 5120, 5120, [0, 5, 6, 114]), (256, 5120, 5120, [0, 6, 7, 114]),
+         (96, 4096, 14336, [0, 3, 118]), (256, 4096, 14336, [0, 7, 114, 112]), (192, 4096, 14336, [0, 7, 114]), (512, 5120, 5120, [0, 5, 6, 114]), (256, 5120, 5120, [0, 6, 7, 114]), (256, 8192, 8192, [0, 6, 112, 114]),
          (96, 8192, 8192, [0, 3, 7, 114]), (128, 8192, 8192, [0, 7, 114]), (64, 4096, 4096, [0, 3, 7, 134]), (128, 4096, 4096, [0, 3, 7]), (256, 4096, 4096, [0, 7, 6, 112]),
          (512, 4096, 4096, [0, 6, 5, 7]), (768, 4096, 14336, [0, 5, 114]), (1024, 5120, 25600, [0, 40, 114])]
 NAME = {0: "plan", 3: "skinny", 5: "128x128", 6: "128x64", 7: "64x64", 40: "256x128"}
