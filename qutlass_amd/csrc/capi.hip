@@ -681,7 +681,11 @@ int gemm_mx(const char* name, const void* A, const void* B, const void* A_sf, co
   // 128 tiles on, the 64x64 ring kernel streams the weight through full-line LDS-DMA and wins (N = 14336, K = 4096: 6.9 us
   // vs 9.7 us; N = 57344, K = 8192: 36 us vs 58-74 us), as does ring + split-K over caller scratch for a long K
   // (N = 4096, K = 14336, M = 16: 11.6 us vs 14.8 us).  profiles/native_r1_skinny_shapes.log, native_r1_ring.log
-  if (EBITS == 4 && (variant == 60 || (variant >= 44 && variant <= 49) || (variant == 0 && M <= 32 && cdiv(N, 64) < chip_cus() / 2 && !can_split))) {
+  // [r3] re-measured GPU-only (HIP-graph replays, tools/calib_mx_small.py with CALIB_MS=1,4,8,16,24,32; profiles/calib_mx_decode_graph_r3.txt): the split-K kernel's time
+  // grows with M (N = K = 4096: 4.65 us at M = 1, 5.4 at 16, 6.1 at 32) while the 3-deep ring stays at 5.0 -- it keeps M <= 8 (now including N = 8192: 8.9 us against
+  // the ring's 10.8 at K = 8192) and M <= 24 only against small weights (N <= 2048: 3.7 against 3.9 us)
+  const bool skinny_auto = variant == 0 && !can_split && ((M <= 8 && cdiv(N, 64) <= chip_cus() / 2) || (M <= 24 && cdiv(N, 64) <= chip_cus() / 8));
+  if (EBITS == 4 && (variant == 60 || (variant >= 44 && variant <= 49) || skinny_auto)) {
     if (dry_record(variant ? variant : 60, p.N, 1)) return 0;
     SkinnyParams q;
     q.A = p.A; q.B = p.B; q.SFA = p.SFA; q.SFB = p.SFB; q.alpha = alpha; q.D = p.D; q.M = p.M; q.N = p.N; q.K = p.K;

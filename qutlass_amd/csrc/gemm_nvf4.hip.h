@@ -753,7 +753,8 @@ inline int nvf4_big_cfg(int64_t M, int64_t N, int64_t K, int cus, double* t_us =
 //                                                   else ceil(workgroups / CUs) x e (several workgroups on a CU overlap each other: e < 1)
 //                 128x128: a 4.1 b 29.2 e 0.91    128x64: a 3.2 b 20.3 e 0.85    64x64: a 3.6 b 13.8 e 0.78   (us; b per 16 stages = K 4096)
 //   reduce pass   2.9 us + (S + 1) M N 4 bytes at 4.4 TB/s, and a split must win by 2 % (5 % against the large-output model); a K range is never shorter than 4 stages
-//   skinny        5.0 + 4.4 ceil(workgroups of 32x32 / CUs) K / 4096, priced 5 % low (the fit overestimates it at K = 4096), M <= 128 only; always for M <= 32
+//   skinny        2.5 + 4.7 ceil(workgroups of 32x32 / CUs) K / 4096 (refitted on the GPU-only re-take of the calibration, rms 6 %: profiles/calib_nv_small_r3_graph.txt), M <= 256
+//                 only; always for M <= 32
 // Against the calibration the chosen candidates sum to 10 353 us (best measured candidate per shape: 10 288; the occupancy thresholds this replaces:
 // 11 057), e.g. 256 x 4096 x 14336 54.7 -> 39.2 us (128x128 tiles, 4 K ranges), 128 x 8192 x 28672 107 -> 67, 64 x 28672 x 4096 36.7 -> 26.6 (64x64 tiles
 // instead of the skinny kernel), 512 x 5120 x 5120 47.0 -> 41.1 (160 tiles of 128x128 instead of 320 of 128x64, which put two on 64 CUs).
@@ -776,9 +777,9 @@ inline NvPlan nvf4_plan(int64_t M, int64_t N, int64_t K, int cus, bool may_split
       if (S2 > 1) t = (t + 2.897 + (double)(S2 + 1) * M * N * 4.0 / 4.409e6) * 1.02;
       if (t < best_t) { best_t = t; best = {c + 1, S2, S2 > 1 ? kt : 0}; }
     }
-  if (M <= 128) {
+  if (M <= 256) {
     const double wg = (double)(((M + 31) / 32) * ((N + 31) / 32));
-    if (0.95 * (4.96 + 4.40 * std::ceil(wg / cus) * K / 4096.0) < best_t) return {-1, 1, 0};
+    if (2.53 + 4.66 * std::ceil(wg / cus) * K / 4096.0 < best_t) return {-1, 1, 0};
   }
   if (M > 128 && N > 128 && tiles(128, 128) >= cus * 3 / 4) {   // the large-output model above; a split only where it beats that model's time by 5 %
     double tb;

@@ -150,7 +150,9 @@ def test_nvf4_tile_rule(lib):
     assert f(768, 4096, 14336, 0) == 1 and f(768, 4096, 14336, 1) == 1 + 256 * 4      # 192 tiles: 768 workgroups balance better than 192 (94.7 vs 108.3 us)
     assert f(1024, 5120, 25600, 0) == 4 and f(1024, 5120, 25600, 1) == 1 + 256 * 4    # 320 tiles of 128x128 x 4 (252 us) against 160 of 256x128 (300)
     assert f(64, 8192, 28672, 0) == -1 and f(64, 8192, 28672, 1) == 3 + 256 * 4       # 128 tiles of 64x64 x 4 (49.9 us) against the skinny kernel (69.5)
-    assert f(1024, 4096, 14336, 1) == 1 and f(256, 2048, 2048, 1) == 3                # a full round already / K too short (8 stages)
+    assert f(1024, 4096, 14336, 1) == 1 and f(256, 2048, 2048, 1) == -1 and f(384, 2048, 2048, 1) == 3   # a full round already / K too short (8 stages): the skinny
+    # kernel up to 256 rows where its 32x32 workgroups still fit two per CU (GPU-only timing: 7.4 us against 9.6 on 64x64 tiles), 64x64 tiles beyond
+    assert f(192, 4096, 4096, 1) == -1 and f(256, 4096, 4096, 1) == 3
     # the workspace query describes the same plan: ranges x M x N fp32
     g = lib.qutlass_amd_nvf4_splitk_workspace_bytes
     assert g(256, 4096, 14336) == 4 * 256 * 4096 * 4 and g(128, 4096, 14336) == 7 * 128 * 4096 * 4 and g(200, 4104, 14368) == 8 * 200 * 4104 * 4
@@ -223,7 +225,9 @@ def test_auto_dispatch_rules_dry_run(lib):
     assert plan(8, 4096, 4096, 4096) == [(DEEPP, 4096, 1)]
     assert plan(4, 256, 1 << 22, 128) == [(25, 1 << 22, 1)]          # absurdly wide output: 32-bit tile offsets of the persistent epilogue do not reach
     # decode: LDS-free split-K kernel while the weight has fewer than 128 64-row tiles, ring kernel beyond, 64x128 tiles for huge N
-    assert plan(4, 1, 4096, 4096) == [(SKINNY, 4096, 1)] and plan(4, 32, 4096, 4096) == [(SKINNY, 4096, 1)]
+    # [r3] re-measured GPU-only: the split-K kernel up to M = 8 (N <= 8192), up to M = 24 only against small weights (N <= 2048); the ring stays flat in M beyond
+    assert plan(4, 1, 4096, 4096) == [(SKINNY, 4096, 1)] and plan(4, 8, 4096, 4096) == [(SKINNY, 4096, 1)] and plan(4, 8, 8192, 8192) == [(SKINNY, 8192, 1)]
+    assert plan(4, 16, 4096, 4096) == [(RING64, 4096, 1)] and plan(4, 32, 4096, 4096) == [(RING64, 4096, 1)] and plan(4, 24, 2048, 2048) == [(SKINNY, 2048, 1)]
     assert plan(4, 16, 14336, 4096) == [(RING64, 14336, 1)]
     assert plan(4, 16, 57344, 8192) == [(28, 57344, 1)]
     assert plan(8, 16, 4096, 4096) == [(RING64, 4096, 1)]            # no fp8 skinny kernel

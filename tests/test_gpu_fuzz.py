@@ -115,8 +115,8 @@ def test_fuzz_matmul_nvf4_and_mxf8(q):
         out = q.matmul_nvf4_bf16_tn(a, b, to_blocked(sa.view(e4)), to_blocked(sb.view(e4)), alpha)
         ref = oracle.gemm_blockscaled(oracle.KIND_NVFP4, _np(a), _np(b), oracle.to_blocked(_np(sa)), oracle.to_blocked(_np(sb)), 1.0, m, n, k)
         assert np.array_equal(_np(out), ref), (it, m, n, k, int((_np(out) != ref).sum()))
-    # [r3] long K against small outputs: the NVFP4 split-K path (ranges of an even number of 256-element stages + the reduce pass), K tails included
-    nsplit = 0
+    # [r3] long K against small outputs: the NVFP4 split-K path (ranges of an even number of 256-element stages + the reduce pass), K tails included -- the plan's own
+    # choice (which at these widths is mostly the small-batch kernel) AND a forced tile x split of the lab build, both against the full oracle
     for it in range(8):
         m, n = int(rng.choice([40, 100, 136, 200])), int(rng.integers(8, 48)) * 8
         k = int(rng.integers(96, 224)) * 32
@@ -125,11 +125,13 @@ def test_fuzz_matmul_nvf4_and_mxf8(q):
         sb = torch.from_numpy(rng.integers(0x30, 0x48, size=(n, k // 16), dtype=np.uint8)).to(DEV)
         alpha = torch.tensor([0.25], device=DEV)
         e4 = torch.float8_e4m3fn
-        nsplit += q._lib.load().qutlass_amd_nvf4_splitk_workspace_bytes(m, n, k) > 0
-        out = q.matmul_nvf4_bf16_tn(a, b, to_blocked(sa.view(e4)), to_blocked(sb.view(e4)), alpha)
         ref = oracle.gemm_blockscaled(oracle.KIND_NVFP4, _np(a), _np(b), oracle.to_blocked(_np(sa)), oracle.to_blocked(_np(sb)), 0.25, m, n, k)
-        assert np.array_equal(_np(out), ref), ("nvf4 split", it, m, n, k, int((_np(out) != ref).sum()))
-    assert nsplit >= 2, nsplit
+        out = q.matmul_nvf4_bf16_tn(a, b, to_blocked(sa.view(e4)), to_blocked(sb.view(e4)), alpha)
+        assert np.array_equal(_np(out), ref), ("nvf4 long K", it, m, n, k, int((_np(out) != ref).sum()))
+        forced = int(rng.choice([112, 114, 118, 122, 124, 132, 134]))   # 128x128 / 128x64 / 64x64 tiles x 2 / 4 / 8 K ranges
+        with lab.forced(nvf4_variant=forced):
+            out = lab.matmul_nvf4_bf16_tn(a, b, to_blocked(sa.view(e4)), to_blocked(sb.view(e4)), alpha)
+        assert np.array_equal(_np(out), ref), ("nvf4 split", forced, it, m, n, k, int((_np(out) != ref).sum()))
     for it in range(16):
         m, n = int(rng.choice([16, 48, 128, 144, 272])), int(rng.integers(1, 50)) * 8
         k = int(rng.integers(1, 20)) * 32

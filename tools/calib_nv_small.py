@@ -6,9 +6,14 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, ROOT)
 import _benchlib as lab
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+from _timing import graph_us, stream_us
+
+GRAPH = "--stream" not in sys.argv   # default: GPU-only timing through HIP-graph replays; --stream = the Python-in-the-loop protocol of the first calibrations
 
 NK = [(4096, 4096), (6144, 4096), (28672, 4096), (4096, 14336), (8192, 8192), (57344, 8192), (8192, 28672), (5120, 5120), (51200, 5120), (5120, 25600), (2048, 2048), (14336, 4096)]
-MS = [16, 32, 64, 96, 128, 192, 256, 384, 512, 768, 1024]
+MS = [m for m in [16, 32, 64, 96, 128, 192, 256, 384, 512, 768, 1024] if m <= int(os.environ.get("CALIB_MAX_M", "1024"))]
+if os.environ.get("CALIB_MS"): MS = [int(v) for v in os.environ["CALIB_MS"].split(",")]   # e.g. CALIB_MS=1,4,8,16,32 for the decode end
 CAND = [("auto", 0), ("skinny", 3), ("64x64", 7), ("128x64", 6), ("128x128", 5), ("256x128", 40), ("128x128/2", 112), ("128x128/4", 114), ("128x128/8", 118), ("128x64/2", 122),
         ("128x64/4", 124), ("64x64/2", 132), ("64x64/4", 134)]
 
@@ -38,15 +43,7 @@ def main():
                         call = lambda: lab.matmul_nvf4_bf16_tn(a, b, sa, sb, alpha)
                         if var >= 100:   # split-K against the single pass: equal up to the bf16 rounding of a differently ordered fp32 sum
                             worst = max(worst, float(((call().float() - ref).abs() / (ref.abs() + 1.0)).max()))
-                        for _ in range(max(3, reps // 4)): call()
-                        torch.cuda.synchronize()
-                        best = 1e9
-                        for _ in range(2):
-                            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                            e0.record()
-                            for _ in range(reps): call()
-                            e1.record(); torch.cuda.synchronize()
-                            best = min(best, e0.elapsed_time(e1) * 1e3 / reps)
+                        best = graph_us(call, n=max(8, min(40, int(2.5e3 / max(fl / 1.0e15 * 1e6, 5.0))))) if GRAPH else stream_us(call, reps)
                         res.append(best)
                 except Exception:
                     res.append(float("nan"))

@@ -11,4 +11,4 @@ d=json.loads(open('gpurun_out/r3_last/bench.json').read().strip().splitlines()[-
 print('value', d['value'], 'ms_per_step', d['ms_per_step'], 'frac', r['frac'], 'kernel_us', r['kernel_us'], 'cpu', d['cpu_baseline']['value'])
 for k,v in (d.get('configs') or {}).items(): print(k, v.get('us'), v.get('roofline',{}).get('frac'))
 PY
-timeout 300 python tools/instream_nv_check.py > $O/instream_nv_check.txt 2> $O/nv.err; echo "nv rc=$?"; grep -E "^ +256 +(5120 +5120|8192 +8192)|^ +256 +4096 +14336" $O/instream_nv_check.txt
+CALIB_MS=1,8,16,32 timeout 300 python tools/calib_mx_small.py mxf4 > $O/calib_mx_decode_graph_after.txt 2> $O/mx.err; echo "mx rc=$?"; grep -E "^mxf4 +(16|32) +(4096|5120|6144|8192) +(4096|5120|8192) " $O/calib_mx_decode_graph_after.txt | cut -c1-60; grep -E "^mxf4 +(1|8) +8192 +8192 " $O/calib_mx_decode_graph_after.txt | cut -c1-60
