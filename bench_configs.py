@@ -215,7 +215,7 @@ def main():
         xa_sf = to_blocked(xa_s)
         wq, wsf = w_q[:nn], to_blocked(w_s.view(torch.uint8).reshape(-1)[: nn * 128].reshape(nn, 128).view(torch.float8_e8m0fnu))
         wbytes = nn * 4096 // 2 + nn * 128 + mm * 4096 // 2 + 2 * mm * nn
-        for var, tag in ((0, "auto: LDS-free split-K (N < 8192) / 64x64 ring"), (2, "128x128 lockstep"), (24, "128x128 simple")):
+        for var, tag in ((0, "auto: LDS-free split-K (M <= 8) / 64x64 ring"), (2, "128x128 lockstep"), (24, "128x128 simple")):
             impl = q if var == 0 else lab
             with lab.forced(gemm_variant=var):
                 us = time_us(lambda: impl.matmul_mxf4_bf16_tn(xa_q, wq, xa_sf, wsf, alpha), args.iters)
