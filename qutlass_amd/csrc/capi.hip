@@ -571,9 +571,11 @@ SmallPlan plan_small(int64_t M, int64_t N, int64_t K, bool may_split = true) {
       if (t < t_best) { t_best = t; best = {VAR[c], s2}; }
     }
   SmallPlan res = (t_best >= 12.0 && t_best < 0.92 * t_cur) ? best : cur;
-  // MXFP8 with a long K (>= 96 stages) on 64x128 tiles, single pass: 128x128 tiles in two K ranges while those still fit one per CU -- the guard above leaves these alone
-  // (the fit is coarse there), the measurement does not: 384 / 512 x 4096 x 14336 37.9 / 40.7 -> 31.8 / 35.8 us in GPU-only timing (profiles/instream_mx_plan_check_r3.txt)
-  if (EBITS == 8 && may_split && N % 4 == 0 && res.variant == 72 && res.splits == 1 && KT >= 96 && 2 * cdiv(M, 128) * cdiv(N, 128) <= cus) res = {73, 2};
+  // A long K (>= 96 stages) on 64x128 tiles, single pass: 128x128 tiles in two K ranges while those still fit one per CU -- the guard above leaves these alone (the fit
+  // is coarse there), the GPU-only measurement does not: all ten such shapes of the calibration grid gain 8 ... 25 % (MXFP8 384 / 512 x 4096 x 14336 38.6 / 43.0 -> 32.1 /
+  // 36.1 us, MXFP4 256 x 8192 x 28672 46.1 -> 42.2, 384 x 5120 x 25600 41.0 -> 36.2), every shape with fewer stages ties or loses
+  // (profiles/calib_mx_small_r3_graph_m192_1024.txt, profiles/instream_mx_plan_check_r3.txt)
+  if (may_split && N % 4 == 0 && res.variant == 72 && res.splits == 1 && KT >= 96 && 2 * cdiv(M, 128) * cdiv(N, 128) <= cus) res = {73, 2};
   return res;
 }
 

@@ -255,6 +255,7 @@ def test_auto_dispatch_rules_dry_run(lib):
     assert plan(4, 96, 5120, 25600, big) == [(RING128, 5120, 4)] and plan(4, 96, 5120, 25600) == [(RING64, 5120, 1)]
     assert plan(8, 192, 4096, 14336, big) == [(RING128, 4096, 4)] and plan(4, 128, 2048, 57344, big) == [(RING64x128, 2048, 8)]
     assert plan(8, 384, 4096, 14336, big) == [(RING128, 4096, 2)] and plan(8, 384, 4096, 14336) == [(RING64x128, 4096, 1)] and plan(4, 384, 4096, 14336, big) == [(RING64x128, 4096, 1)]
+    assert plan(4, 256, 8192, 28672, big) == [(RING128, 8192, 2)] and plan(4, 384, 5120, 25600, big) == [(RING128, 5120, 2)] and plan(4, 256, 8192, 8192, big) == [(RING64x128, 8192, 1)]
     assert plan(4, 96, 57344, 8192) == [(24, 57344, 1)] and plan(8, 128, 51200, 5120) == [(24, 51200, 1)] and plan(4, 192, 57344, 8192) == [(DEEPP, 57344, 1)]
     # an A operand of >= 2 GiB (262400 x 16384 fp4 = 2.15 GB) runs as two row ranges of whole 256-row tiles
     assert plan(4, 262400, 256, 16384) == [(DEEPP, 256, 1), (RING64, 256, 1)]   # 261888 rows, then the last 512
