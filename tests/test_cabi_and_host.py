@@ -191,6 +191,32 @@ def test_split_plans_are_consistent_over_a_shape_grid(lib):
             assert dry(ebits, m, n, k, 1 << 40, out, 8) >= 1 and out[2] == max(1, b // (m * n * 4)), (ebits, m, n, k, out[0], out[2], b)
 
 
+def test_plan_model_constants_reproduce_from_the_committed_calibration():
+    """The constants of the two fitted dispatch models (gemm_nvf4.hip.h: nvf4_plan, capi.hip: plan_small) are what tools/fit_plan_models.py finds in the
+    committed calibration data (profiles/calib_nv_small_r3.txt, calib_nv_small_r3_graph.txt, calib_mx_small_r3.txt) -- provenance of the numbers, no GPU."""
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("fit_plan_models", os.path.join(ROOT, "tools", "fit_plan_models.py"))
+    fit = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fit)
+    nv_src = open(os.path.join(ROOT, "qutlass_amd", "csrc", "gemm_nvf4.hip.h")).read()
+    mx_src = open(os.path.join(ROOT, "qutlass_amd", "csrc", "capi.hip")).read()
+    arr = lambda src, name: [float(v) for v in re.search(r"\b%s\[3\] = \{([^}]*)\}" % name, src).group(1).split(",")]
+    close = lambda got, want, tol=0.012: all(abs(g - w) <= tol * max(abs(w), 1.0) for g, w in zip(got, want))
+    a, b, e, r0, bw, rms = fit.fit_nv()
+    body = nv_src[nv_src.index("inline NvPlan nvf4_plan"):]
+    assert close(arr(body, "A"), a) and close(arr(body, "B"), b) and close(arr(body, "E"), e) and rms < 0.08
+    assert "2.897" in body and "4.409e6" in body and abs(r0 - 2.897) < 0.01 and abs(bw - 4.409) < 0.01
+    s0, s1, rms = fit.fit_nv_skinny()
+    assert "2.53 + 4.66" in body and abs(s0 - 2.53) < 0.01 and abs(s1 - 4.66) < 0.01 and rms < 0.07
+    mx = fit.fit_mx()
+    for fmt, tag in (("mxf4", "4"), ("mxf8", "8")):
+        a, b, e, r0, bw, rms = mx[fmt]
+        assert close(arr(mx_src, "A" + tag), a) and close(arr(mx_src, "B" + tag), b) and close(arr(mx_src, "E" + tag), e), fmt
+    assert "r0 = EBITS == 4 ? 1.39 : 3.86, bw = EBITS == 4 ? 2.63e6 : 2.79e6" in mx_src
+    assert abs(mx["mxf4"][3] - 1.39) < 0.01 and abs(mx["mxf8"][3] - 3.86) < 0.01 and abs(mx["mxf4"][4] - 2.63) < 0.01 and abs(mx["mxf8"][4] - 2.79) < 0.01
+
+
 def test_auto_dispatch_rules_dry_run(lib):
     """The tile / schedule choice of the MX GEMMs (DESIGN.md sections 3.3, 3.7, 3.8) through the library's dry-run hook:
     the real dispatch code runs, launches are recorded instead of issued.  (variant, N of the launch, K splits)."""
