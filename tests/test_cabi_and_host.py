@@ -273,6 +273,55 @@ def test_mx_large_output_rules_against_the_committed_calibration(lib):
         assert cnt >= 55 and chosen <= 1.02 * best, (fmt, cnt, chosen, best)
 
 
+def test_small_output_plans_against_the_gpu_only_calibrations(lib):
+    """nvf4_plan and plan_small (with caller scratch) through the real C++, on the GPU-only re-takes of the small-output calibrations (HIP-graph replays; 132 shapes
+    per format, M = 16 ... 1024): wherever the planned (tile, K ranges) is one of the measured candidates, the plans sum to within 1.5 % (NVFP4) / 2.5 % (MXFP4, MXFP8)
+    of the best measured candidate of each shape."""
+    import math
+
+    def rows(path):
+        names = None
+        for line in open(os.path.join(ROOT, "profiles", path)):
+            if line.startswith("#"):
+                names = line.split("|")[1].split()
+                continue
+            head, vals = line.split("|")[:2]
+            h = head.split()
+            yield h[0], int(h[1]), int(h[2]), int(h[3]), dict(zip(names, (float(v) for v in vals.split())))
+
+    nv = lib.qutlass_amd_debug_nvf4_plan
+    nv.restype, nv.argtypes = ctypes.c_int, [ctypes.c_int64] * 3 + [ctypes.c_int]
+    name = {-1: "skinny", 1: "128x128", 2: "128x64", 3: "64x64", 4: "256x128"}
+    chosen = best = 0.0
+    cnt = 0
+    for _, m, n, k, d in rows("calib_nv_small_r3_graph.txt"):
+        r = nv(m, n, k, 1)
+        cfg, s = (r % 256, r // 256) if r >= 256 else (r, 1)
+        col = name.get(cfg, "") + ("/%d" % s if s > 1 else "")
+        if col in d and not math.isnan(d[col]):
+            chosen += d[col]
+            best += min(v for v in d.values() if not math.isnan(v))
+            cnt += 1
+    assert cnt >= 90 and chosen <= 1.015 * best, (cnt, chosen, best)
+
+    dry = lib.qutlass_amd_debug_gemm_plan
+    dry.restype = ctypes.c_int
+    dry.argtypes = [ctypes.c_int] + [ctypes.c_int64] * 4 + [ctypes.POINTER(ctypes.c_int), ctypes.c_int]
+    out = (ctypes.c_int * 24)()
+    mxname = {60: "skinny", 70: "r64", 72: "r64x128", 73: "r128", 24: "p128", 58: "256x128"}
+    tot = {"mxf4": [0.0, 0.0, 0], "mxf8": [0.0, 0.0, 0]}
+    for path in ("calib_mx_small_r3_graph_m128.txt", "calib_mx_small_r3_graph_m192_1024.txt"):
+        for fmt, m, n, k, d in rows(path):
+            assert dry(4 if fmt == "mxf4" else 8, m, n, k, 1 << 40, out, 8) == 1
+            col = mxname.get(out[0], "") + ("/%d" % out[2] if out[2] > 1 else "")
+            if col in d and not math.isnan(d[col]):
+                tot[fmt][0] += d[col]
+                tot[fmt][1] += min(v for v in d.values() if not math.isnan(v))
+                tot[fmt][2] += 1
+    for fmt, (c, b, cnt) in tot.items():
+        assert cnt >= 70 and c <= 1.025 * b, (fmt, cnt, c, b)
+
+
 def test_auto_dispatch_rules_dry_run(lib):
     """The tile / schedule choice of the MX GEMMs (DESIGN.md sections 3.3, 3.7, 3.8) through the library's dry-run hook:
     the real dispatch code runs, launches are recorded instead of issued.  (variant, N of the launch, K splits)."""
