@@ -6,6 +6,10 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, ROOT)
 import _benchlib as lab
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+from _timing import graph_us, stream_us
+
+GRAPH = "--stream" not in sys.argv   # default: GPU-only timing through HIP-graph replays (tools/_timing.py); --stream = the Python-in-the-loop protocol of profiles/calib_tiles_r3.txt
 
 NK = [(4096, 4096), (6144, 4096), (5120, 5120), (4096, 14336), (8192, 8192), (5120, 25600), (28672, 4096)]
 MS = [512, 768, 1024, 1536, 2048, 2560, 3072, 4096, 5120, 6144, 8192]
@@ -18,7 +22,7 @@ def main():
     g = torch.Generator(device=dev).manual_seed(0)
     alpha = torch.ones(1, device=dev)
     pad = lambda r: (r + 127) // 128 * 128
-    for fmt in (sys.argv[1:] or ["mxf4", "mxf8", "nvf4"]):
+    for fmt in ([a for a in sys.argv[1:] if not a.startswith("--")] or ["mxf4", "mxf8", "nvf4"]):
         epb, gs = (1, 32) if fmt == "mxf8" else (2, 16 if fmt == "nvf4" else 32)
         fn = {"mxf4": lab.matmul_mxf4_bf16_tn, "mxf8": lab.matmul_mxf8_bf16_tn, "nvf4": lab.matmul_nvf4_bf16_tn}[fmt]
         opt = "nvf4_variant" if fmt == "nvf4" else "gemm_variant"
@@ -38,13 +42,7 @@ def main():
                     try:
                         with lab.forced(**{opt: var}):
                             call = lambda: fn(a, b, sa, sb, alpha)
-                            for _ in range(max(3, reps // 4)): call()
-                            torch.cuda.synchronize()
-                            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                            e0.record()
-                            for _ in range(reps): call()
-                            e1.record(); torch.cuda.synchronize()
-                            res.append(e0.elapsed_time(e1) * 1e3 / reps)
+                            res.append(graph_us(call, n=max(4, min(40, int(2.5e3 / max(fl / 1.0e15 * 1e6, 5.0))))) if GRAPH else stream_us(call, reps))
                     except Exception as e:   # a variant the lab dispatch rejects for this shape
                         res.append(float("nan"))
                 print("%s %5d %6d %6d | %s" % (fmt, m, n, k, " ".join("%8.2f" % r for r in res)), flush=True)

@@ -1,5 +1,5 @@
 """Scan the GEMM ops for wave-quantisation / tile-rule blind spots: for every (N, K) of the reference's benchmark models and a fine grid of batch
-sizes M, time the GEMM alone (C ABI entries with caller scratch, random operand bytes) and flag every place where a LARGER batch runs FASTER, or the TFLOP/s fall by more
+sizes M, time the GEMM alone (C ABI entries with caller scratch, random operand bytes; GPU-only timing through HIP-graph replays) and flag every place where a LARGER batch runs FASTER, or the TFLOP/s fall by more
 than 12 % from one M to the next.      python tools/dip_scan.py [mxf4|nvf4|mxf8 ...] > gpurun_out/dip_scan.txt"""
 import ctypes, os, sys
 import torch
@@ -8,7 +8,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 lib = ctypes.CDLL(os.path.join(ROOT, "qutlass_amd", "libqutlass_amd.so"), mode=ctypes.RTLD_LOCAL)
 NK = [(4096, 4096), (6144, 4096), (28672, 4096), (4096, 14336), (8192, 8192), (57344, 8192), (8192, 28672), (5120, 5120), (51200, 5120), (5120, 25600), (24576, 4096), (4096, 12288)]
 MS = [64, 96, 128, 192, 256, 384, 512, 768, 1024, 1536, 2048, 3072, 4096, 6144, 8192]
-P = lambda t: ctypes.c_void_p(t.data_ptr()); I = ctypes.c_int64; st = ctypes.c_void_p(0)
+P = lambda t: ctypes.c_void_p(t.data_ptr()); I = ctypes.c_int64
+ST = lambda: ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)   # the stream of the moment: the capturing one inside graph_us
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+from _timing import graph_us
 
 
 def main():
@@ -39,19 +42,10 @@ def main():
                 d = torch.empty(m, n, dtype=torch.bfloat16, device=dev)
                 wsb = ws_need(m, n, k)
                 ws = torch.empty(max(wsb, 16), dtype=torch.uint8, device=dev)
-                call = lambda: fn(P(a), P(b), P(sa), P(sb), P(alpha), P(d), I(m), I(n), I(k), P(ws) if wsb else ctypes.c_void_p(0), I(wsb), st)
+                call = lambda: fn(P(a), P(b), P(sa), P(sb), P(alpha), P(d), I(m), I(n), I(k), P(ws) if wsb else ctypes.c_void_p(0), I(wsb), ST())
                 assert call() == 0, (fmt, m, n, k)
                 fl = 2.0 * m * n * k
-                reps = max(10, min(400, int(25e-3 / max(fl / 3e15, 4e-6))))
-                best = 1e9
-                for _ in range(2):
-                    for _ in range(max(3, reps // 4)): call()
-                    torch.cuda.synchronize()
-                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                    e0.record()
-                    for _ in range(reps): call()
-                    e1.record(); torch.cuda.synchronize()
-                    best = min(best, e0.elapsed_time(e1) * 1e3 / reps)
+                best = graph_us(call, n=max(4, min(40, int(2.5e3 / max(fl / 3.0e15 * 1e6, 5.0)))))   # GPU-only: HIP-graph replays (tools/_timing.py)
                 tf = fl / best * 1e-6
                 flag = ""
                 if prev is not None:
