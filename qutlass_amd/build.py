@@ -40,8 +40,8 @@ def needs_build() -> bool:
     return _stale(OUT, _kernel_sources()) or _stale(EXT_OUT, [EXT_SRC, HEADER, OUT])
 
 
-NUM_TU = 5         # translation units of csrc/capi.hip in the product build (QAMD_TU = 1..5; see the top of that file)
-NUM_TU_BENCH = 7   # the lab build adds the ablation units 6 and 7
+UNITS = [1, 2, 3, 4, 5, 8]              # translation units of csrc/capi.hip in the product build (QAMD_TU values; see the top of that file)
+UNITS_BENCH = [1, 2, 3, 4, 5, 6, 7, 8]  # the lab build adds the ablation units 6 and 7
 # Per-unit compiler flags.  Unit 5 holds the fused_quantize_kernel family and nothing else: its rotation MFMAs take their
 # accumulators in VGPRs -- LLVM's default put them in AGPRs and copied all 16 back with v_accvgpr_read_b32 per 1024-element tile,
 # a fifth of the VALU instructions of a kernel that is VALU-issue-bound at R = 32.  The GEMM units must keep
@@ -49,7 +49,7 @@ NUM_TU_BENCH = 7   # the lab build adds the ablation units 6 and 7
 TU_FLAGS = {5: ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
 
 
-def _compile_units(out: str, num_tu: int, extra: list, verbose: bool) -> None:
+def _compile_units(out: str, units: list, extra: list, verbose: bool) -> None:
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     base = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden"] + extra
     if os.environ.get("QAMD_SINGLE_TU"):
@@ -62,10 +62,10 @@ def _compile_units(out: str, num_tu: int, extra: list, verbose: bool) -> None:
     from concurrent.futures import ThreadPoolExecutor
 
     with tempfile.TemporaryDirectory(prefix="qamd_build_") as tmp:
-        objs = [os.path.join(tmp, f"capi_tu{i}.o") for i in range(1, num_tu + 1)]
-        cmds = [base + TU_FLAGS.get(i, []) + [f"-DQAMD_TU={i}", "-c", SRC, "-o", o] for i, o in zip(range(1, num_tu + 1), objs)]
+        objs = [os.path.join(tmp, f"capi_tu{i}.o") for i in units]
+        cmds = [base + TU_FLAGS.get(i, []) + [f"-DQAMD_TU={i}", "-c", SRC, "-o", o] for i, o in zip(units, objs)]
         if verbose:
-            print(" ".join(cmds[0]), f"   (x{num_tu}: QAMD_TU=1..{num_tu}, in parallel)")
+            print(" ".join(cmds[0]), f"   (x{len(units)}: QAMD_TU={units}, in parallel)")
         def run(cmd):
             rc = subprocess.run(cmd).returncode
             if rc != 0 and any(f in cmd for fl in TU_FLAGS.values() for f in fl):   # a compiler without the per-unit flag: build that unit plainly
@@ -74,7 +74,7 @@ def _compile_units(out: str, num_tu: int, extra: list, verbose: bool) -> None:
                 rc = subprocess.run(plain).returncode
             return rc
 
-        with ThreadPoolExecutor(max_workers=min(num_tu, os.cpu_count() or 1)) as ex:
+        with ThreadPoolExecutor(max_workers=min(len(units), os.cpu_count() or 1)) as ex:
             for rc, cmd in zip(ex.map(run, cmds), cmds):
                 if rc != 0:
                     raise subprocess.CalledProcessError(rc, cmd)
@@ -89,14 +89,14 @@ def build_kernels(force: bool = False, verbose: bool = False) -> str:
     """csrc/capi.hip is compiled once per QAMD_TU value, in parallel (each unit instantiates one kernel family), and the
     objects are linked into libqutlass_amd.so.  QAMD_SINGLE_TU=1 in the environment compiles it as one unit instead."""
     if force or _stale(OUT, _kernel_sources()):
-        _compile_units(OUT, NUM_TU, [], verbose)
+        _compile_units(OUT, UNITS, [], verbose)
     return OUT
 
 
 def build_bench_lib(force: bool = False, verbose: bool = False) -> str:
     """The lab library (test / bench infrastructure, see the module docstring)."""
     if force or _stale(BENCH_OUT, _kernel_sources()):
-        _compile_units(BENCH_OUT, NUM_TU_BENCH, ["-DQAMD_BENCH=1"], verbose)
+        _compile_units(BENCH_OUT, UNITS_BENCH, ["-DQAMD_BENCH=1"], verbose)
     return BENCH_OUT
 
 

@@ -14,6 +14,7 @@
 #include "gemm_mx_skinny.hip.h"
 #include "gemm_mx_fusedq.hip.h"
 #include "gemm_nvf4.hip.h"
+#include "gemm_nvf4_pk.hip.h"
 #include "quantize.hip.h"
 #include "to_blocked.hip.h"
 #include "transpose_u8.hip.h"
@@ -35,6 +36,7 @@ using namespace qamd;
 //   1  C entry points, dispatch rules, small kernels      2  MXFP4 tile / schedule variants      3  MXFP8 variants
 //   4  NVFP4 kernels + MXFP8 with an e5m2 A operand        5  fused quantizers
 //   6  MXFP4 ablations (100+, 200+, 300+; lab only)       7  NVFP4 v2 ablations (gemm_nvf4.hip.h; lab only)
+//   8  the persistent NVFP4 kernel (gemm_nvf4_pk.hip.h)
 #ifndef QAMD_TU
 #define QAMD_TU 0
 #endif
@@ -1040,9 +1042,16 @@ static int64_t nvf4_ws_bytes(int64_t M, int64_t N, int64_t K) {
   if (M <= 0 || N <= 0 || K < 32 || N % 4 || N * (K / 2) >= (1ll << 31) || M * (K / 2) >= (1ll << 31)) return 0;
 #if QAMD_BENCH
   if (opt_nvf4_variant() >= 100) return 8 * M * N * 4;   // lab: room for any forced split
+  if (opt_nvf4_variant() >= 42 && opt_nvf4_variant() <= 45) return qamd::nvpk_ws_bytes(chip_cus());   // lab: forced persistent kernel
 #endif
   const qamd::NvPlan pl = qamd::nvf4_plan(M, N, K, chip_cus(), true);
-  return pl.splits > 1 ? (int64_t)pl.splits * M * N * 4 : 0;
+  if (pl.splits > 1) return (int64_t)pl.splits * M * N * 4;
+  // [r4] 256x256 tiles with a part-filled last round: stream-K parks one fp32 tile per workgroup boundary (gemm_nvf4_pk.hip.h)
+  if (pl.cfg == 0 && qamd::nvpk_shape_ok(M, N, K)) {
+    const qamd::NvPkPlan pk = qamd::nvpk_plan(M, N, K, chip_cus(), true);
+    if (pk.sk_tiles > 0) return qamd::nvpk_ws_bytes(pk.grid);
+  }
+  return 0;
 }
 
 static int nvf4_impl(const void* A, const void* B, const void* A_sf, const void* B_sf, const float* alpha, void* D, int64_t M, int64_t N,
@@ -1086,6 +1095,7 @@ static int nvf4_impl(const void* A, const void* B, const void* A_sf, const void*
   const int64_t need = ws ? nvf4_ws_bytes(M, N, K) : 0;
   p.ws = (need > 0 && ws_bytes >= need && ldd == N) ? (float*)ws : nullptr;
   p.splits = 1; p.kt_per = 0;
+  p.sk_tiles = 0; p.sk_ws = nullptr; p.sk_flags = nullptr; p.sk_tag = next_launch_tag();
   int splits = 1;
   if (launch_nvf4_host(p, (hipStream_t)stream, opt_nvf4_variant(), &splits)) return fail(QAMD_ERR_INVALID, "%s: unknown nvf4_variant %d", name, opt_nvf4_variant());
   if (int rc = check_launch(name)) return rc;
@@ -1113,6 +1123,7 @@ int64_t qutlass_amd_nvf4_splitk_workspace_bytes(int64_t M, int64_t N, int64_t K)
 int qutlass_amd_matmul_nvf4_bf16_tn_ws(const void* A, const void* B, const void* A_sf, const void* B_sf, const float* alpha, void* D, int64_t M,
                                        int64_t N, int64_t K, void* workspace, int64_t workspace_bytes, void* stream) {
   if (workspace_bytes < 0 || (workspace_bytes > 0 && !workspace)) return fail(QAMD_ERR_INVALID, "matmul_nvf4_bf16_tn: invalid workspace");
+  if ((uintptr_t)workspace % 16) return fail(QAMD_ERR_INVALID, "matmul_nvf4_bf16_tn: the workspace must be 16-byte aligned");
   return nvf4_impl(A, B, A_sf, B_sf, alpha, D, M, N, K, 0, stream, workspace, workspace_bytes);
 }
 
@@ -1363,6 +1374,31 @@ int qutlass_amd_debug_nvf4_plan(int64_t M, int64_t N, int64_t K, int may_split) 
   if (M <= 0 || N <= 0 || K <= 0) return -2;
   const qamd::NvPlan pl = qamd::nvf4_plan(M, N, K, 256, may_split != 0);
   return pl.splits > 1 ? pl.cfg + 256 * pl.splits : pl.cfg;
+}
+
+// [r4] the persistent NVFP4 kernel's plan on a 256-CU part: out[0] = workgroups, out[1] = tiles in the stream-K region (0: whole tiles only),
+// out[2] = K stages per tile; returns 0 when the shape does not run the persistent kernel (tile configuration other than 256x256, K % 256, K < 512)
+int qutlass_amd_debug_nvf4_pk_plan(int64_t M, int64_t N, int64_t K, int may_sk, int* out) {
+  if (!out || M <= 0 || N <= 0 || K < 32) return 0;
+  const qamd::NvPlan pl = qamd::nvf4_plan(M, N, K, 256, may_sk != 0);
+  if (pl.cfg != 0 || !qamd::nvpk_shape_ok(M, N, K)) return 0;
+  const qamd::NvPkPlan pk = qamd::nvpk_plan(M, N, K, 256, may_sk != 0);
+  out[0] = pk.grid; out[1] = pk.sk_tiles; out[2] = (int)(K / 256);
+  return 1;
+}
+// the units workgroup w of `grid` walks over T tiles (the last sk_tiles as a stream of K stages), KT stages per tile: 5 ints per unit
+// {tile, first stage, end stage, mode, slot} into out[0 .. 5 cap); returns the number of units (the device kernel runs the same NvPkWalk)
+int qutlass_amd_debug_nvf4_pk_units(int w, int grid, int T, int sk_tiles, int KT, int* out, int cap) {
+  if (!out || grid <= 0 || w < 0 || w >= grid || KT < 2 || sk_tiles < 0 || sk_tiles > T) return -1;
+  qamd::NvPkWalk walk(w, grid, T, sk_tiles, KT);
+  int n = 0;
+  for (;;) {
+    const qamd::NvPkUnit u = walk.next();
+    if (u.mode < 0) break;
+    if (n < cap) { out[5 * n] = u.tile; out[5 * n + 1] = u.kb; out[5 * n + 2] = u.ke; out[5 * n + 3] = u.mode; out[5 * n + 4] = u.slot; }
+    ++n;
+  }
+  return n;
 }
 
 #if QAMD_BENCH

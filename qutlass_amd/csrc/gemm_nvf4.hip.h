@@ -35,6 +35,11 @@ struct NvGemmParams {
   float* ws;       // [r3] split-K: fp32 partials ws[z][M][N] (caller scratch, capi.hip nvf4_impl); null = single pass
   int splits;      //      K ranges per tile (1 = single pass); the launch has tiles x splits workgroups, range z = blockIdx.x / tiles
   int kt_per;      //      K stages (of 256 elements) per range: even, so that a range starts on LDS buffer 0
+  // [r4] persistent kernel (gemm_nvf4_pk.hip.h): stream-K over the last sk_tiles tiles of the raster (0 = none: whole tiles only)
+  int sk_tiles;
+  float* sk_ws;                  //      parked fp32 accumulators, 256 KiB per range boundary (slot = workgroup index, 1 .. grid - 1)
+  unsigned long long* sk_flags;  //      one arrival flag per slot; == sk_tag: parked (the consumer resets it to 0)
+  unsigned long long sk_tag;     //      per-launch number (capi.hip next_launch_tag): the flags need no initialisation
 };
 
 template <int BM_, int BN_, int WAVES_M_, int WAVES_N_>
@@ -789,6 +794,26 @@ inline NvPlan nvf4_plan(int64_t M, int64_t N, int64_t K, int cus, bool may_split
   return best;
 }
 
+// [r4] the persistent 256x256 kernel with stream-K over a part-filled last round (gemm_nvf4_pk.hip.h; its own translation unit)
+struct NvPkPlan { int grid, sk_tiles; };
+inline bool nvpk_shape_ok(int64_t M, int64_t N, int64_t K) { return M > 0 && N > 0 && K % 256 == 0 && K >= 512; }
+// Workgroups and stream-K region for T tiles of 256x256 on `cus` CUs.
+//   T a multiple of cus, or no scratch, or less than one round: whole tiles only, BALANCED rounds (R = ceil(T / cus) tiles per workgroup on
+//     ceil(T / R) workgroups rounded up to a multiple of 8 -- the rule of the MX persistent kernels, capi.hip deepp_grid)
+//   otherwise: one workgroup per CU; the full rounds but the last as whole tiles, the last cus + T % cus tiles as an evenly split stream of K stages
+//     (every workgroup walks (cus + T % cus) KT / cus stages: at most one cut tile at each end of its range)
+inline NvPkPlan nvpk_plan(int64_t M, int64_t N, int64_t K, int cus, bool may_sk) {
+  const int64_t T = ((M + 255) / 256) * ((N + 255) / 256);
+  if (may_sk && T > cus && T % cus != 0 && (T % cus) * 8 <= (int64_t)cus * 7) return {cus, (int)(cus + T % cus)};
+  const int64_t rounds = (T + cus - 1) / cus;
+  const int64_t g = ((T + rounds - 1) / rounds + 7) / 8 * 8;
+  return {(int)std::min<int64_t>(std::min<int64_t>(g, cus), T), 0};
+}
+constexpr int64_t NVPK_PART_BYTES = 256 * 256 * 4;   // one parked tile of fp32 accumulators
+// scratch of a stream-K launch on `grid` workgroups: a parked tile per range boundary, then the arrival flags
+inline int64_t nvpk_ws_bytes(int grid) { return (int64_t)grid * NVPK_PART_BYTES + (int64_t)grid * 8; }
+hipError_t launch_nvf4_pk(NvGemmParams p, hipStream_t s, int grid, bool trace);
+
 #if QAMD_TU == 0 || QAMD_TU == 4
 // Returns hipErrorInvalidValue for a variant this build does not know (the product library knows only 0 = auto).
 // cus: compute units of the device (capi.hip chip_cus): every occupancy threshold below derives from it
@@ -832,6 +857,14 @@ inline hipError_t launch_nvf4_gemm(NvGemmParams p, hipStream_t s, int variant = 
     return hipSuccess;
   }
 #endif
+#if QAMD_BENCH
+  // lab: 42 = the persistent 256x256 kernel, whole tiles in balanced rounds; 43 = with stream-K over the last round (needs scratch); 44 / 45 = 42 / 43 + stage trace
+  const bool pk_forced = variant >= 42 && variant <= 45;
+  const bool pk_sk = variant == 43 || variant == 45, pk_trace = variant == 44 || variant == 45;
+  if (pk_forced) variant = 41;
+#else
+  constexpr bool pk_forced = false, pk_trace = false;
+#endif
   if (variant <= 1 || variant == 4 || (variant >= 5 && variant <= 9) || variant == 40 || variant == 41) {
     // tile choice by occupancy (as for the MX kernels): the largest tile that gives >= 192 workgroups
     auto tiles = [&](int bm, int bn) { return (int64_t)((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn); };
@@ -860,6 +893,22 @@ inline hipError_t launch_nvf4_gemm(NvGemmParams p, hipStream_t s, int variant = 
     p.splits = splits;
     if (splits <= 1) p.ws = nullptr;
     if (splits_out) *splits_out = splits;
+    // [r4] 256x256 tiles: the persistent kernel (lab: variant 41 keeps the per-tile kernel for A/B runs)
+    if (cfg == 0 && nvpk_shape_ok(p.M, p.N, p.K) && (variant <= 1 || pk_forced)) {
+      void* scratch = p.ws;   // (splits == 1 for this configuration: the caller's scratch is free for parked tiles; capi.hip checked its size)
+#if QAMD_BENCH
+      const bool may_sk = scratch != nullptr && (!pk_forced || pk_sk);
+#else
+      const bool may_sk = scratch != nullptr;
+#endif
+      const NvPkPlan pl = nvpk_plan(p.M, p.N, p.K, cus, may_sk);
+      p.sk_tiles = pl.sk_tiles;
+      p.sk_ws = (float*)scratch;
+      p.sk_flags = (unsigned long long*)((char*)scratch + (int64_t)pl.grid * NVPK_PART_BYTES);
+      p.ws = nullptr;
+      return launch_nvf4_pk(p, s, pl.grid, pk_trace);
+    }
+    if (cfg == 0) p.ws = nullptr;
 #define QAMD_NV_LAUNCH_SPLIT(BM_, BN_, WM_, WN_)                                                               \
     if (splits > 1) {                                                                                          \
       using C = NvCfg<BM_, BN_, WM_, WN_>;                                                                     \

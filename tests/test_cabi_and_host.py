@@ -171,6 +171,8 @@ def test_split_plans_are_consistent_over_a_shape_grid(lib):
     nv = lib.qutlass_amd_debug_nvf4_plan
     nv.restype, nv.argtypes = ctypes.c_int, [ctypes.c_int64] * 3 + [ctypes.c_int]
     nv_ws, mx_ws = lib.qutlass_amd_nvf4_splitk_workspace_bytes, lib.qutlass_amd_gemm_splitk_workspace_bytes
+    pk = lib.qutlass_amd_debug_nvf4_pk_plan
+    pk.restype, pk.argtypes = ctypes.c_int, [ctypes.c_int64] * 3 + [ctypes.c_int, ctypes.POINTER(ctypes.c_int)]
     dry = lib.qutlass_amd_debug_gemm_plan
     dry.restype = ctypes.c_int
     dry.argtypes = [ctypes.c_int] + [ctypes.c_int64] * 4 + [ctypes.POINTER(ctypes.c_int), ctypes.c_int]
@@ -183,12 +185,79 @@ def test_split_plans_are_consistent_over_a_shape_grid(lib):
         r0, r1 = nv(m, n, k, 0), nv(m, n, k, 1)
         assert -1 <= r0 <= 4 and (r1 < 256 or (1 <= r1 % 256 <= 3 and 2 <= r1 // 256 <= 8)), (m, n, k, r0, r1)
         b = nv_ws(m, n, k)
-        assert b == (r1 // 256 if r1 >= 256 else 0) * m * n * 4, (m, n, k, r1, b)
+        pk_out = (ctypes.c_int * 3)()
+        if r1 == 0 and pk(m, n, k, 1, pk_out) and pk_out[1] > 0:   # [r4] 256x256 tiles, part-filled last round: one parked fp32 tile + flag per workgroup
+            assert b == pk_out[0] * (256 * 256 * 4 + 8), (m, n, k, r1, b)
+        else:
+            assert b == (r1 // 256 if r1 >= 256 else 0) * m * n * 4, (m, n, k, r1, b)
         for ebits in (4, 8):
             b = mx_ws(ebits, m, n, k)
             assert b % (m * n * 4) == 0 and b // (m * n * 4) in (0, 2, 3, 4, 5, 6, 7, 8), (ebits, m, n, k, b)
             assert dry(ebits, m, n, k, 0, out, 8) >= 1 and out[2] == 1                      # no scratch: one pass
             assert dry(ebits, m, n, k, 1 << 40, out, 8) >= 1 and out[2] == max(1, b // (m * n * 4)), (ebits, m, n, k, out[0], out[2], b)
+
+
+def test_nvf4_persistent_walk_covers_every_stage_once(lib):
+    """[r4] gemm_nvf4_pk.hip.h: the unit walk of the persistent NVFP4 kernel, replayed on the CPU through the debug entry (the device kernel runs the
+    same NvPkWalk): every K stage of every tile is computed by exactly one unit; a cut tile has exactly one parking unit (its LAST stages) and one
+    adding unit (its FIRST stages) that name the same scratch slot, the parking workgroup is the next one in walk order and parks before any of its
+    whole tiles; no unit is shorter than two stages; balanced-round plans hold whole tiles only.  (Reference counterpart: the CUTLASS tile
+    scheduler behind qutlass/csrc/gemm.cu:73-75.)"""
+    import ctypes
+
+    units = lib.qutlass_amd_debug_nvf4_pk_units
+    units.restype, units.argtypes = ctypes.c_int, [ctypes.c_int] * 5 + [ctypes.POINTER(ctypes.c_int), ctypes.c_int]
+    pk = lib.qutlass_amd_debug_nvf4_pk_plan
+    pk.restype, pk.argtypes = ctypes.c_int, [ctypes.c_int64] * 3 + [ctypes.c_int, ctypes.POINTER(ctypes.c_int)]
+    out3 = (ctypes.c_int * 3)()
+    buf = (ctypes.c_int * (5 * 64))()
+
+    def walk_all(grid, T, sk, KT):
+        seen = {}
+        parks, adds = {}, {}
+        for w in range(grid):
+            n = units(w, grid, T, sk, KT, buf, 64)
+            assert 1 <= n <= 64, (grid, T, sk, KT, w, n)
+            us = [tuple(buf[5 * i:5 * i + 5]) for i in range(n)]
+            first_whole = next((i for i, u in enumerate(us) if u[3] == 0 and u[0] >= T - sk), len(us))
+            for i, (tile, kb, ke, mode, slot) in enumerate(us):
+                assert 0 <= tile < T and 0 <= kb < ke <= KT and ke - kb >= 2 and mode in (0, 1, 2)
+                assert (mode == 0) == (kb == 0 and ke == KT) and (mode != 1 or ke == KT) and (mode != 2 or kb == 0)
+                for k in range(kb, ke):
+                    assert (tile, k) not in seen, ("stage computed twice", grid, T, sk, KT, tile, k)
+                    seen[(tile, k)] = w
+                if mode == 1:
+                    assert slot == w and tile not in parks and i <= first_whole
+                    parks[tile] = (w, slot, kb)
+                if mode == 2:
+                    assert slot == w + 1 and tile not in adds and i == n - 1
+                    adds[tile] = (w, slot, ke)
+        assert len(seen) == T * KT, ("stages missing", grid, T, sk, KT, len(seen))
+        assert parks.keys() == adds.keys()
+        for t in parks:
+            assert parks[t][1] == adds[t][1] and parks[t][0] == adds[t][0] + 1 and parks[t][2] == adds[t][2]
+        return len(parks)
+
+    # the plan of real shapes on 256 CUs: Llama / Qwen weights at the batch sizes the dip scan flags
+    for (m, n, k) in [(6144, 4096, 4096), (4096, 5120, 5120), (8192, 8192, 8192), (4096, 28672, 4096), (3072, 28672, 8192), (4096, 14336, 4096), (5120, 4096, 4096)]:
+        for may_sk in (0, 1):
+            if not pk(m, n, k, may_sk, out3):
+                continue
+            grid, sk, KT = out3[0], out3[1], out3[2]
+            T = ((m + 255) // 256) * ((n + 255) // 256)
+            assert grid <= 256 and (sk == 0 or (may_sk and grid == 256 and sk == 256 + T % 256 and T > 256))
+            cuts = walk_all(grid, T, sk, KT)
+            assert (cuts > 0) == (sk > 0) or sk == 0
+    assert pk(6144, 4096, 4096, 1, out3) and (out3[0], out3[1]) == (256, 384)      # 384 tiles = 1.5 rounds: every workgroup walks 24 of the 6144 stages
+    assert pk(6144, 4096, 4096, 0, out3) and (out3[0], out3[1]) == (192, 0)        # no scratch: 192 workgroups x 2 whole tiles
+    assert pk(8192, 8192, 8192, 1, out3) and (out3[0], out3[1]) == (256, 0)        # 1024 tiles = 4 full rounds: nothing to cut
+    assert not pk(4096, 4096, 4096 + 128, 1, out3) and not pk(4096, 4096, 256, 1, out3)   # K % 256 / K < 512: the per-tile kernels
+    # synthetic sweeps: every remainder, short and long K
+    for KT in (2, 3, 5, 16, 33):
+        for grid in (8, 24, 256):
+            for T in list(range(grid + 1, 2 * grid + 1, max(1, grid // 8))) + [3 * grid + 5, 7 * grid - 1]:
+                walk_all(grid, T, grid + T % grid if T % grid else 0, KT)
+                walk_all(grid, T, 0, KT)
 
 
 def test_plan_model_constants_reproduce_from_the_committed_calibration():

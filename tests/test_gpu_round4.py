@@ -1,0 +1,158 @@
+"""Round-4 GPU parity tests (Python surface -> torch ops -> C ABI -> HIP kernels), against the pinned CPU oracle.
+
+  * the persistent NVFP4 kernel (gemm_nvf4_pk.hip.h; reference: matmul_host_nvf4_bf16_tn + the CUTLASS tile scheduler,
+    qutlass/csrc/gemm.cu:250-326, :73-75): whole-tile rounds, balanced rounds, and stream-K over a part-filled last round
+    (tiles cut along K, the fp32 partial parked in scratch and added by the owner of the rest of the tile) must return the bytes
+    of the per-tile kernels and of the oracle -- ragged M / N, two-stage K (every boundary snaps to a tile), long K, alpha != 1.
+  * every finite non-negative e4m3 scale byte through the hardware fp8 -> f16 convert the persistent kernel uses
+    (tests/nvfp4_test.py:196-203 dequantises with `scales.float()`; fused_quantize_nv never emits a sign bit or a NaN).
+  * stream-K scratch hygiene: a captured graph replayed (same launch tag, same scratch) returns the same bytes every time.
+Nothing here reads /root/reference.
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import oracle  # noqa: E402  (the checker)
+import _benchlib as lab  # noqa: E402  (LAB build: forced schedules)
+
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def q():
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    import qutlass_amd
+
+    return qutlass_amd
+
+
+def _np(t: torch.Tensor) -> np.ndarray:
+    t = t.detach().cpu().contiguous()
+    if t.dtype == torch.bfloat16:
+        return t.view(torch.uint16).numpy()
+    if t.element_size() == 1:
+        return t.view(torch.uint8).numpy()
+    return t.numpy()
+
+
+def _nv_operands(m, n, k, seed, lo=0x38, hi=0x48):
+    """random e2m1 codes; e4m3 scales in [lo, hi) (default [1, 4), all mantissas: every partial sum stays exact in fp32, so any summation
+    order and the fp64 oracle agree bit for bit)"""
+    from qutlass_amd.utils import to_blocked
+
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    a = torch.randint(0, 256, (m, k // 2), dtype=torch.uint8, generator=g)
+    b = torch.randint(0, 256, (n, k // 2), dtype=torch.uint8, generator=g)
+    sa = torch.randint(lo, hi, (-(-m // 128) * 128, k // 16), dtype=torch.uint8, generator=g)
+    sb = torch.randint(lo, hi, (-(-n // 128) * 128, k // 16), dtype=torch.uint8, generator=g)
+    sa_b = to_blocked(sa.to(DEV).view(torch.float8_e4m3fn))
+    sb_b = to_blocked(sb.to(DEV).view(torch.float8_e4m3fn))
+    return a.to(DEV), b.to(DEV), sa, sb, sa_b, sb_b
+
+
+def _oracle_rows(a, b, sa, sb, alpha, rows, n, k):
+    pad = np.zeros((128 - len(rows), k // 16), np.uint8)
+    return oracle.gemm_blockscaled(oracle.KIND_NVFP4, np.ascontiguousarray(_np(a)[rows]), _np(b), oracle.to_blocked(np.concatenate([np.ascontiguousarray(sa.numpy()[rows]), pad])),
+                                   oracle.to_blocked(sb.numpy()), alpha, len(rows), n, k)
+
+
+# (M, N, K): tiles of 256x256 on 256 CUs
+#   4096 x 4096            256 tiles = one exact round (whole tiles, one per workgroup)
+#   6144 x 4096            384 = 1.5 rounds: stream-K, every workgroup walks 1.5 tiles
+#   4096 x 5120, K = 512   320 tiles of TWO stages: every range boundary snaps to a tile (stream-K region without a cut)
+#   4360 x 5128 (ragged)   18 x 21 = 378 tiles, partial edge tiles in both dimensions, K = 1536 (6 stages)
+#   8192 x 4608            576 = 2.25 rounds: one data-parallel round + a stream-K region of 320 tiles
+#   2560 x 4096            160 tiles < one round: balanced (160 workgroups), no scratch needed
+PK_SHAPES = [(4096, 4096, 1024), (6144, 4096, 1024), (4096, 5120, 512), (4360, 5128, 1536), (8192, 4608, 768), (2560, 4096, 1024), (6144, 4096, 4096)]
+
+
+@pytest.mark.parametrize("m,n,k", PK_SHAPES)
+def test_matmul_nvf4_persistent_kernel_equals_per_tile_kernels_and_oracle(q, m, n, k):
+    a, b, sa, sb, sa_b, sb_b = _nv_operands(m, n, k, m + n + k)
+    al = torch.tensor([0.5], device=DEV)
+    lib = q._lib.load()
+    import ctypes
+
+    pk = lib.qutlass_amd_debug_nvf4_pk_plan
+    pk.restype, pk.argtypes = ctypes.c_int, [ctypes.c_int64] * 3 + [ctypes.c_int, ctypes.POINTER(ctypes.c_int)]
+    plan = (ctypes.c_int * 3)()
+    if pk(m, n, k, 1, plan) and plan[1] > 0:   # the auto rule runs 256x256 tiles with a part-filled last round: scratch for one parked tile per workgroup
+        assert lib.qutlass_amd_nvf4_splitk_workspace_bytes(m, n, k) == plan[0] * (256 * 256 * 4 + 8)
+    out = q.matmul_nvf4_bf16_tn(a, b, sa_b, sb_b, al)                        # product: torch op, scratch from the allocator -> stream-K where planned
+    outs = {}
+    for v in (41, 42, 43, 5):   # per-tile 256x256 kernel (round 3) / persistent, whole tiles / persistent + stream-K / 128x128 tiles
+        with lab.forced(nvf4_variant=v):
+            outs[v] = lab.matmul_nvf4_bf16_tn(a, b, sa_b, sb_b, al)
+    for v, o in outs.items():
+        assert torch.equal(out.view(torch.int16), o.view(torch.int16)), (v, int((out.view(torch.int16) != o.view(torch.int16)).sum()))
+    # the plain C entry (no scratch): balanced whole-tile rounds
+    plain = torch.empty_like(out)
+    assert lib.qutlass_amd_matmul_nvf4_bf16_tn(a.data_ptr(), b.data_ptr(), sa_b.data_ptr(), sb_b.data_ptr(), al.data_ptr(), plain.data_ptr(), m, n, k,
+                                               torch.cuda.current_stream().cuda_stream) == 0
+    assert torch.equal(out.view(torch.int16), plain.view(torch.int16))
+    rows = sorted({0, 255, 256, m // 2, m - 257 if m > 600 else 1, m - 1})
+    ref = _oracle_rows(a, b, sa, sb, 0.5, rows, n, k)
+    assert np.array_equal(_np(out)[rows].view(np.uint16), ref.view(np.uint16))
+
+
+def test_matmul_nvf4_persistent_kernel_every_e4m3_scale_byte(q):
+    """Row r of A carries scale byte r % 127 (0x00 .. 0x7e: zero, the subnormals, every normal up to 448) in ALL its groups, B's scales are 1.0:
+    each output is (scale) x (an exactly representable sum), so the kernel's hardware e4m3 -> f16 convert is compared with the oracle's decode
+    bit for bit for every byte the quantizer can emit."""
+    from qutlass_amd.utils import to_blocked
+
+    m, n, k = 4096, 4096, 512
+    g = torch.Generator(device="cpu").manual_seed(7)
+    a = torch.randint(0, 256, (m, k // 2), dtype=torch.uint8, generator=g).to(DEV)
+    b = torch.randint(0, 256, (n, k // 2), dtype=torch.uint8, generator=g).to(DEV)
+    sa = (torch.arange(m, dtype=torch.int32) % 127).to(torch.uint8).view(m, 1).repeat(1, k // 16).contiguous()
+    sb = torch.full((n, k // 16), 0x38, dtype=torch.uint8)
+    sa_b = to_blocked(sa.to(DEV).view(torch.float8_e4m3fn))
+    sb_b = to_blocked(sb.to(DEV).view(torch.float8_e4m3fn))
+    al = torch.tensor([1.0], device=DEV)
+    with lab.forced(nvf4_variant=42):
+        out = lab.matmul_nvf4_bf16_tn(a, b, sa_b, sb_b, al)
+    with lab.forced(nvf4_variant=5):
+        old = lab.matmul_nvf4_bf16_tn(a, b, sa_b, sb_b, al)
+    assert torch.equal(out.view(torch.int16), old.view(torch.int16))
+    rows = list(range(0, 127)) + [4095]
+    ref = _oracle_rows(a, b, sa, sb, 1.0, rows, n, k)
+    assert np.array_equal(_np(out)[rows].view(np.uint16), ref.view(np.uint16))
+
+
+def test_matmul_nvf4_stream_k_graph_replay_and_general_data(q):
+    """(1) The arrival flags of the stream-K scratch carry a per-launch tag and are reset by their consumer: a captured graph (same tag, same scratch
+    on every replay) must return the same bytes each time.  (2) Scales over six binades (sums no longer exact in fp32): the persistent kernel stays
+    deterministic and within the north-star tolerance (1e-2 relative) of the oracle; the cut tiles' summation order (own part + parked part) differs
+    from the single pass by at most an fp32 rounding."""
+    m, n, k = 6144, 4096, 2048
+    a, b, sa, sb, sa_b, sb_b = _nv_operands(m, n, k, 99, lo=0x20, hi=0x50)
+    al = torch.tensor([1.0], device=DEV)
+    ref_out = q.matmul_nvf4_bf16_tn(a, b, sa_b, sb_b, al)
+    torch.cuda.synchronize()
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        for _ in range(2):
+            q.matmul_nvf4_bf16_tn(a, b, sa_b, sb_b, al)
+    torch.cuda.synchronize()
+    gr = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(gr):
+        o1 = q.matmul_nvf4_bf16_tn(a, b, sa_b, sb_b, al)
+        o2 = q.matmul_nvf4_bf16_tn(a, b, sa_b, sb_b, al)
+    for _ in range(3):
+        o1.zero_(); o2.zero_()
+        gr.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(o1.view(torch.int16), ref_out.view(torch.int16)) and torch.equal(o2.view(torch.int16), ref_out.view(torch.int16))
+    rows = [0, 300, 3071, 6143]
+    got = ref_out[rows].float().cpu().numpy()
+    ref = torch.from_numpy(np.ascontiguousarray(_oracle_rows(a, b, sa, sb, 1.0, rows, n, k)).view(np.int16)).view(torch.bfloat16).float().numpy()
+    denom = np.maximum(np.abs(ref), np.abs(ref).mean())
+    assert float(np.max(np.abs(got - ref) / denom)) <= 1e-2
+    with lab.forced(nvf4_variant=41):
+        per_tile = lab.matmul_nvf4_bf16_tn(a, b, sa_b, sb_b, al)
+    d = (ref_out.float() - per_tile.float()).abs() / per_tile.float().abs().clamp_min(float(per_tile.float().abs().mean()))
+    assert float(d.max()) <= 2.0 ** -7      # at most one bf16 ulp where a cut tile's fp32 rounding moved a tie

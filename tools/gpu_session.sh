@@ -1,0 +1,49 @@
+#!/bin/bash
+# ONE parametrised GPU session script (replaces the per-session tools/gpu_r*.sh of rounds 2-3):
+#     gpurun --timeout 1500 -- 'bash tools/gpu_session.sh <name> <step> [<step> ...]'
+# writes everything under gpurun_out/<name>/ and prints a one-line verdict per step.  Steps:
+#   tests4    tests/test_gpu_round4.py (fail-fast)            suite     the whole -m gpu suite
+#   smoke     __graft_entry__.smoke()                         bench     bench.py (driver protocol) + a summary of its JSON line
+#   pmc       tools/pmc_bench.sh (kernel-trace + FETCH_SIZE / WRITE_SIZE passes of the bench command + a fresh-traffic bench line)
+#   abnv      tools/ab_nvpk.py --trace (persistent NVFP4 kernel vs per-tile kernel vs torch bf16; stage trace)
+#   vendor    tools/vendor_ab.py (hipBLASLt block-scaled GEMM through torch beside ours, power / clock)
+#   profnv    rocprofv3 --kernel-trace --stats + SQ busy counters of the NVFP4 GEMM at 8192^3 and 4096 x 28672 x 4096
+#   dip       tools/dip_scan.py (8 % threshold)               sweeps    benchmarks/bench_mxfp4_mi355x.py for MXFP4 (fused) and NVFP4, Llama-3-8B
+#   configs   bench_configs.py                                abmx      tools/ab_mxsk.py (MX persistent kernels: balanced / heterogeneous / stream-K)
+#   stream    tools/ab_stream_ops.py-style timing of the streaming ops (bench_configs.py --only stream)
+cd ${GRAFT_REPO_ROOT:-.}
+NAME=${1:?session name}; shift
+O=gpurun_out/$NAME; mkdir -p $O
+export TMPDIR=/tmp
+for step in "$@"; do
+  t0=$(date +%s)
+  case $step in
+    tests4) timeout 900 python -m pytest tests/test_gpu_round4.py -x -q > $O/pytest_round4.log 2>&1; echo "tests4 rc=$?"; tail -3 $O/pytest_round4.log ;;
+    suite)  timeout 1500 python -m pytest tests -m gpu -q > $O/pytest_gpu.log 2>&1; echo "suite rc=$?"; tail -3 $O/pytest_gpu.log ;;
+    smoke)  timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; echo "smoke rc=$?"; tail -1 $O/smoke.log ;;
+    bench)  timeout 900 python bench.py > $O/bench.json 2> $O/bench.err; echo "bench rc=$?"
+            python - $O/bench.json <<'PY'
+import json, sys
+d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1]); r = d['roofline']
+print('value', d['value'], 'ms_per_step', d['ms_per_step'], 'frac', r['frac'], 'kernel_us', r.get('kernel_us'), 'cpu', d['cpu_baseline']['value'])
+print('power', d.get('power', {}).get('timed_region'))
+for k, v in (d.get('configs') or {}).items(): print(' ', k, v if 'us' not in v else (v['us'], v['roofline']['frac']))
+PY
+            ;;
+    pmc)    bash tools/pmc_bench.sh $O/pmc_bench > $O/pmc_bench.log 2>&1; echo "pmc rc=$?"; head -20 $O/pmc_bench/summary.txt; cat $O/pmc_bench/traffic.json ;;
+    abnv)   timeout 900 python tools/ab_nvpk.py --trace --shapes all > $O/ab_nvpk.txt 2> $O/ab_nvpk.err; echo "abnv rc=$?"; cat $O/ab_nvpk.txt; tail -3 $O/ab_nvpk.err ;;
+    vendor) timeout 600 python tools/vendor_ab.py > $O/vendor_ab.txt 2> $O/vendor_ab.err; echo "vendor rc=$?"; cat $O/vendor_ab.txt; tail -3 $O/vendor_ab.err ;;
+    profnv) R=$(pwd); (cd /tmp && rocprofv3 --kernel-trace --stats -d $R/$O/prof_nv_trace -o p -- python $R/tools/ab_nvpk.py --shapes prof > $R/$O/prof_nv_trace.log 2>&1
+              rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES -d $R/$O/prof_nv_pmc -o p -- python $R/tools/ab_nvpk.py --shapes prof > $R/$O/prof_nv_pmc.log 2>&1)
+            python tools/rocprof_summary.py $O/prof_nv_trace/p_results.db $O/prof_nv_pmc/p_results.db > $O/prof_nv_summary.txt 2>&1; echo "profnv rc=$?"; head -40 $O/prof_nv_summary.txt ;;
+    dip)    timeout 900 python tools/dip_scan.py > $O/dip_scan.txt 2> $O/dip_scan.err; echo "dip rc=$?"; tail -2 $O/dip_scan.txt ;;
+    sweeps) timeout 900 python benchmarks/bench_mxfp4_mi355x.py --model Llama-3-8B --fused --vendor --max-batch 8192 --reps 30 > $O/bench_sweep_mxfp4_Llama-3-8B.txt 2> $O/sweeps.err; echo "sweep mxfp4 rc=$?"
+            timeout 900 python benchmarks/bench_mxfp4_mi355x.py --format nvfp4 --had 16 --model Llama-3-8B --max-batch 8192 --reps 30 > $O/bench_sweep_nvfp4_Llama-3-8B.txt 2>> $O/sweeps.err; echo "sweep nvfp4 rc=$?"
+            cat $O/bench_sweep_nvfp4_Llama-3-8B.txt ;;
+    configs) timeout 900 python bench_configs.py > $O/bench_configs.jsonl 2> $O/bench_configs.err; echo "configs rc=$?"; tail -30 $O/bench_configs.jsonl | cut -c1-240 ;;
+    abmx)   timeout 900 python tools/ab_mxsk.py > $O/ab_mxsk.txt 2> $O/ab_mxsk.err; echo "abmx rc=$?"; cat $O/ab_mxsk.txt; tail -3 $O/ab_mxsk.err ;;
+    *) echo "unknown step $step" ;;
+  esac
+  echo "[$step: $(( $(date +%s) - t0 )) s]"
+done
+find $O -name "*.db" -size +8M -delete
