@@ -156,3 +156,45 @@ def test_matmul_nvf4_stream_k_graph_replay_and_general_data(q):
         per_tile = lab.matmul_nvf4_bf16_tn(a, b, sa_b, sb_b, al)
     d = (ref_out.float() - per_tile.float()).abs() / per_tile.float().abs().clamp_min(float(per_tile.float().abs().mean()))
     assert float(d.max()) <= 2.0 ** -7      # at most one bf16 ulp where a cut tile's fp32 rounding moved a tie
+
+
+@pytest.mark.parametrize("dev_index", [0, 1])
+def test_pipeline_on_a_second_device_and_a_side_stream(q, dev_index):
+    """quantize -> swizzle -> GEMM on cuda:<dev_index> and a non-default stream while the CURRENT device is cuda:0: exercises the DeviceGuard of every
+    op (csrc/torch_ext.cpp; reference: include/common.h:40-45) and the per-device CU cache (capi.hip chip_cus).  MXFP4, NVFP4 and MXFP8 against the
+    oracle.  Skips the second parametrisation on a single-GPU box (the driver's 8-GPU replica run is the other user of these paths)."""
+    if dev_index >= torch.cuda.device_count():
+        pytest.skip("needs a second GPU")
+    from qutlass_amd.utils import to_blocked
+
+    dev = torch.device(f"cuda:{dev_index}")
+    torch.cuda.set_device(0)
+    m, n, k = 384, 512, 1024
+    g = torch.Generator(device="cpu").manual_seed(5 + dev_index)
+    x = (torch.randn(m, k, generator=g) * 25).to(torch.bfloat16).to(dev)
+    w = (torch.randn(n, k, generator=g) * 25).to(torch.bfloat16).to(dev)
+    h = torch.ones(1, 1)
+    while h.shape[0] < 32:
+        h = torch.cat([torch.cat([h, h], 1), torch.cat([h, -h], 1)], 0)
+    h = (h * 32 ** -0.5).to(torch.bfloat16).to(dev)
+    alpha = torch.tensor([1.0], device=dev)
+    side = torch.cuda.Stream(device=dev)
+    side.wait_stream(torch.cuda.current_stream(dev))
+    with torch.cuda.stream(side):
+        xq, xs = q.fusedQuantizeMx(x, h, method="abs_max")
+        wq, ws = q.fusedQuantizeMx(w, h, method="abs_max")
+        out = q.matmul_mxf4_bf16_tn(xq, wq, to_blocked(xs), to_blocked(ws), alpha)
+        gs = torch.tensor([1.0], device=dev)
+        h16 = torch.eye(16, dtype=torch.bfloat16, device=dev)
+        xq4, xs4 = q.fusedQuantizeNv(x, h16, gs)
+        wq4, ws4 = q.fusedQuantizeNv(w, h16, gs)
+        out4 = q.matmul_nvf4_bf16_tn(xq4, wq4, to_blocked(xs4), to_blocked(ws4), alpha)
+    side.synchronize()
+    assert out.device == dev and out4.device == dev and torch.cuda.current_device() == 0
+    hb = _np(h)
+    rq, rs, _ = oracle.fused_quantize_mx(_np(x), hb, oracle.ABS_MAX)
+    assert np.array_equal(_np(xs).reshape(-1)[: rs.size], rs)
+    ref = oracle.gemm_blockscaled(oracle.KIND_MXFP4, _np(xq), _np(wq), _np(to_blocked(xs)), _np(to_blocked(ws)), 1.0, m, n, k)
+    assert np.array_equal(_np(out).view(np.uint16), ref.view(np.uint16))
+    ref4 = oracle.gemm_blockscaled(oracle.KIND_NVFP4, _np(xq4), _np(wq4), _np(to_blocked(xs4)), _np(to_blocked(ws4)), 1.0, m, n, k)
+    assert np.array_equal(_np(out4).view(np.uint16), ref4.view(np.uint16))
