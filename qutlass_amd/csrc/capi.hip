@@ -1046,12 +1046,7 @@ static int64_t nvf4_ws_bytes(int64_t M, int64_t N, int64_t K) {
 #endif
   const qamd::NvPlan pl = qamd::nvf4_plan(M, N, K, chip_cus(), true);
   if (pl.splits > 1) return (int64_t)pl.splits * M * N * 4;
-  // [r4] 256x256 tiles with a part-filled last round: stream-K parks one fp32 tile per workgroup boundary (gemm_nvf4_pk.hip.h)
-  if (pl.cfg == 0 && qamd::nvpk_shape_ok(M, N, K)) {
-    const qamd::NvPkPlan pk = qamd::nvpk_plan(M, N, K, chip_cus(), true);
-    if (pk.sk_tiles > 0) return qamd::nvpk_ws_bytes(pk.grid);
-  }
-  return 0;
+  return 0;   // (256x256 tiles run the persistent kernel in balanced whole-tile rounds: no scratch; its stream-K form is lab-only, gemm_nvf4_pk.hip.h)
 }
 
 static int nvf4_impl(const void* A, const void* B, const void* A_sf, const void* B_sf, const float* alpha, void* D, int64_t M, int64_t N,
@@ -1382,7 +1377,7 @@ int qutlass_amd_debug_nvf4_pk_plan(int64_t M, int64_t N, int64_t K, int may_sk, 
   if (!out || M <= 0 || N <= 0 || K < 32) return 0;
   const qamd::NvPlan pl = qamd::nvf4_plan(M, N, K, 256, may_sk != 0);
   if (pl.cfg != 0 || !qamd::nvpk_shape_ok(M, N, K)) return 0;
-  const qamd::NvPkPlan pk = qamd::nvpk_plan(M, N, K, 256, may_sk != 0);
+  const qamd::NvPkPlan pk = qamd::nvpk_plan(M, N, K, 256, may_sk != 0);   // may_sk: what the LAB's stream-K variant would walk (the product never cuts tiles)
   out[0] = pk.grid; out[1] = pk.sk_tiles; out[2] = (int)(K / 256);
   return 1;
 }

@@ -897,9 +897,9 @@ inline hipError_t launch_nvf4_gemm(NvGemmParams p, hipStream_t s, int variant = 
     if (cfg == 0 && nvpk_shape_ok(p.M, p.N, p.K) && (variant <= 1 || pk_forced)) {
       void* scratch = p.ws;   // (splits == 1 for this configuration: the caller's scratch is free for parked tiles; capi.hip checked its size)
 #if QAMD_BENCH
-      const bool may_sk = scratch != nullptr && (!pk_forced || pk_sk);
+      const bool may_sk = scratch != nullptr && pk_sk;   // stream-K: lab only (variants 43 / 45); measured equal to balanced rounds for this power-bound kernel
 #else
-      const bool may_sk = scratch != nullptr;
+      const bool may_sk = false;
 #endif
       const NvPkPlan pl = nvpk_plan(p.M, p.N, p.K, cus, may_sk);
       p.sk_tiles = pl.sk_tiles;

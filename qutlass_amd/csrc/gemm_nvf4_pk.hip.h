@@ -84,7 +84,12 @@ struct NvPkWalk {
 };
 
 // TRACE (lab): workgroup 0 / wave 0 writes the shader clock and the 100 MHz wall clock at every stage start to p.dbg.
-template <bool TRACE = false>
+// SK: the stream-K form (units that park / add partial tiles).  The PRODUCT instantiates SK = false only: measured on MI355X
+// (profiles/ab_nvpk_r4a_first_version.txt, variants 42 / 43) the NVFP4 kernel is so firmly at the socket power limit that 192 workgroups x 2 whole
+// tiles take exactly as long as 256 workgroups x 1.5 tiles (162.04 vs 162.05 us at 6144 x 4096 x 4096; within 0.3 % on all 15 shapes) -- balanced
+// rounds already are the partial-round scheduler here.  The stream-K form stays in the lab build, under the parity tests, as the template for
+// kernels that are NOT energy-proportional in the idle CUs.
+template <bool TRACE = false, bool SK = false>
 __global__ __launch_bounds__(256) void gemm_nvf4_pk_kernel(const NvGemmParams p) {
   // (device pass only: on the host pass the generic lambdas below instantiate target builtins, clang marks the kernel specialisation invalid
   //  and emits no launch stub for it -- "undefined symbol __device_stub__gemm_nvf4_pk_kernel" at load time)
@@ -104,7 +109,7 @@ __global__ __launch_bounds__(256) void gemm_nvf4_pk_kernel(const NvGemmParams p)
   const int KT = rowbytes >> 7;            // stages of 256 K-elements (K % 256 == 0)
   const int CB = p.K >> 6;                 // scale column tiles (4 groups of 16) per row
   const int T = p.tiles_m * p.tiles_n;
-  const int Tsk = p.sk_tiles, Tdp = T - Tsk;
+  const int Tsk = SK ? p.sk_tiles : 0;
 
   auto fence = [&]() __attribute__((always_inline)) { __builtin_amdgcn_sched_barrier(0); };
 
@@ -272,84 +277,84 @@ __global__ __launch_bounds__(256) void gemm_nvf4_pk_kernel(const NvGemmParams p)
     });
   };
 
-  // ---- epilogue pieces -----------------------------------------------------------------------------------------------------------
+  // ---- epilogue -------------------------------------------------------------------------------------------------------------------
+  // One 32x32 accumulator tile at a time through the wave's 4-KiB scratch, as RAW fp32: four ds_write_b128 straight from the accumulator
+  // registers (row i32 = 128 B, 16-byte chunk 2 q + g stored at chunk ^ (row & 7): the 8 lanes of a write group hit 8 chunks), read back
+  // row-major (lane -> row 8 pass + lane / 8, columns 4 (lane % 8) .. + 3), then alpha, v_cvt_pk_bf16_f32 and one 8-byte store per pass:
+  // a wave instruction covers 8 rows x 64 B of D.  The tile's accumulators are zeroed for the next unit by ONE MFMA on zero operands
+  // (16 registers per instruction in the otherwise idle matrix pipe, instead of 16 v_accvgpr_write).  Tile t + 1 is written and read
+  // while tile t's read-back is converted (LDS executes a wave's instructions in order: the overwrite of the scratch cannot pass the
+  // read before it).  [first version, profiles/ab_nvpk_r4a_first_version.txt: bf16 pairs written from VGPRs -- 32 v_accvgpr_read + 32
+  // multiplies + 16 converts + 16 selects per pair, 256 v_accvgpr_write to zero: 14 600 cycles per tile, 8 % of a K = 4096 tile]
+  // The three kinds of unit differ only in what happens to the read-back registers (no branch arm touches the accumulators: an if / else
+  // whose arms all read them makes SimplifyCFG hoist 256 v_accvgpr_read in front of the branch and spill):
+  //   mode 2  the parked LAST K stages of the cut tile (slot rW, same layout) are added, own part first, before alpha
+  //   mode 1  the raw sums are parked in slot rW for the workgroup that owns the rest of the tile (nothing goes to D)
   char* scr = smem + NvPkCfg::OFF_SCR + wave * NvPkCfg::SCR_PER_WAVE;
-  // write: lane (row i32, half g) holds 4 consecutive columns 32 nn + 8 q + 4 g of tile nn of the pair = 8-byte granule 8 nn + 2 q + g of the
-  // 128-byte row, stored at granule ^ (row & 15) (two rows per bank group instead of 32)
-  const int scrW = i32 * 128 + (((g ^ (i32 & 1)) | (i32 & 14)) << 3);
-  // read back row-major: lane -> row 8 pass + lane / 8, 16-byte chunk c = lane % 8 (stored at chunk c ^ ((row & 15) >> 1), halves swapped in odd rows)
+  const int scrW = i32 * 128 + (((i32 & 6) | (g ^ (i32 & 1))) << 4);   // chunk (2 q + g) ^ (row & 7) = this ^ (q << 5)
   const int rrl = lane >> 3, ccl = lane & 7;
-  const int scrR = rrl * 128 + ((ccl ^ (rrl >> 1)) << 4);
-  const bool swp = (rrl & 1) != 0;
+  const int scrR = rrl * 128 + ((ccl ^ rrl) << 4);                      // + 1024 per pass
+  const int partLane = wave * 65536 + lane * 16;                        // parked tile: ((wave 16 + tile) 4 + pass) 1024 + lane 16
   __amdgpu_buffer_rsrc_t rD = make_rsrc(p.D, 0);
   int stLane = 0, colLim = 0;
   auto set_out_tile = [&](int m0, int n0) __attribute__((always_inline)) {   // rows >= M fall off the descriptor, columns >= N are pushed out per lane
     const int64_t left = ((int64_t)(p.M - m0) * p.ldd - n0) * 2;
     rD = make_rsrc(p.D + ((int64_t)m0 * p.ldd + n0), (uint32_t)(left > 0x7fffffffll ? 0x7fffffffll : left));
-    stLane = ((wave_m * 128 + rrl) * p.ldd + wave_n * 128 + 8 * ccl) * 2;
+    stLane = ((wave_m * 128 + rrl) * p.ldd + wave_n * 128 + 4 * ccl) * 2;
     asm volatile("" : "+v"(stLane));
-    colLim = p.N - n0 - wave_n * 128 - 8 * ccl;
+    colLim = p.N - n0 - wave_n * 128 - 4 * ccl;   // column 32 n + 4 ccl of the wave tile exists iff 32 n < colLim
   };
-  // parked partials: slot = 256 KiB, a wave instruction covers 1 KiB: ((wave 16 + tile) 4 + q) 1024 + lane 16.  Write-through stores /
-  // sc0 sc1 loads meet at the memory-side coherence point (the protocol of gemm_mx.hip.h epilogue_splitk_fused).
-  const int partLane = wave * 65536 + lane * 16;
-  // ONE epilogue for the three kinds of unit.  An if / else whose arms all start by reading the 256 accumulators makes SimplifyCFG hoist those
-  // reads in front of the branch (256 v_accvgpr_read, 200-300 spilled registers, accumulator tuples shuffled between the arms); here a pair of
-  // 32x32 tiles is read ONCE into pinned registers, and the mode only guards what happens to those registers:
-  //   mode 2  the parked LAST K stages of the cut tile (slot rW) are added, own part first, before alpha
-  //   mode 1  the raw fp32 sums are parked in slot rW for the workgroup that owns the rest of the tile; rD is empty, so the bf16 stores are dropped
-  //   D       alpha, bf16, whole 128-byte lines through the wave's LDS scratch
-  auto epilogue = [&](const float alpha, const int mode, const __amdgpu_buffer_rsrc_t rW) __attribute__((always_inline)) {
+  h8_t hz = {};
+  asm volatile("" : "+v"(hz));   // opaque zeros: the zeroing MFMA must stay an MFMA
+  v4f rb[2][4];                  // read-back of tile t in rb[t & 1]
+  auto ep_issue = [&](const int t) __attribute__((always_inline)) {
+    const int m = t / NT, n = t % NT;
 #pragma unroll
-    for (int m = 0; m < MT; ++m)
+    for (int qq = 0; qq < 4; ++qq)
+      *(v4f*)(scr + (scrW ^ (qq << 5))) = v4f{acc[m][n][4 * qq + 0], acc[m][n][4 * qq + 1], acc[m][n][4 * qq + 2], acc[m][n][4 * qq + 3]};
+    asm volatile("" : "+v"(hz));   // (a fresh opaque value per tile: 16 identical MFMAs are otherwise merged into one + 240 v_accvgpr_mov)
+    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(hz, hz, v16f{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
 #pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        v4f x[2][4];
+    for (int ps = 0; ps < 4; ++ps) rb[t & 1][ps] = *(const v4f*)(scr + scrR + ps * 1024);
+  };
+  auto ep_consume = [&](const int t, const float alpha, const int mode, const __amdgpu_buffer_rsrc_t rW) __attribute__((always_inline)) {
+    const int m = t / NT, n = t % NT;
+    v4f x[4];
 #pragma unroll
-        for (int nn = 0; nn < 2; ++nn)
+    for (int ps = 0; ps < 4; ++ps) x[ps] = rb[t & 1][ps];
+    if constexpr (SK) {   // (the product instantiation walks whole tiles only: no branch, no merge copies in its epilogue)
+      if (mode == 2) {
+        v4f add[4];
 #pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const v16f& a = acc[m][2 * h + nn];
-            x[nn][q] = v4f{a[4 * q + 0], a[4 * q + 1], a[4 * q + 2], a[4 * q + 3]};
-            asm volatile("" : "+v"(x[nn][q]));
-          }
-        if (mode == 2) {
-          v4f add[2][4];
+        for (int ps = 0; ps < 4; ++ps) add[ps] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rW, partLane, (t * 4 + ps) * 1024, 17));
 #pragma unroll
-          for (int nn = 0; nn < 2; ++nn)
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-              add[nn][q] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rW, partLane, ((m * NT + 2 * h + nn) * 4 + q) * 1024, 17));
-#pragma unroll
-          for (int nn = 0; nn < 2; ++nn)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) x[nn][q] += add[nn][q];
-        }
-        if (mode == 1) {
-#pragma unroll
-          for (int nn = 0; nn < 2; ++nn)
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-              __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, x[nn][q]), rW, partLane, ((m * NT + 2 * h + nn) * 4 + q) * 1024, 17);
-        }
-#pragma unroll
-        for (int nn = 0; nn < 2; ++nn)
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            v2i o;
-            o[0] = (int)pack_bf16x2(x[nn][q][0] * alpha, x[nn][q][1] * alpha);
-            o[1] = (int)pack_bf16x2(x[nn][q][2] * alpha, x[nn][q][3] * alpha);
-            *(v2i*)(scr + (scrW ^ (nn * 64 + q * 16))) = o;
-          }
-#pragma unroll
-        for (int ps = 0; ps < 4; ++ps) {
-          v4i v = *(const v4i*)(scr + ((scrR + ps * 1024) ^ ((ps & 1) ? 64 : 0)));
-          if (swp) v = v4i{v[2], v[3], v[0], v[1]};
-          // (the wave-uniform part of the address travels in the scalar offset: as part of the vector offset it costs a register per store)
-          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, v), rD, (64 * h < colLim) ? stLane : (int)0x80000000, ((32 * m + 8 * ps) * p.ldd + 64 * h) * 2, 0);
-        }
-        fence();   // one pair's temporaries at a time: the K loop's registers (next stage's first fragments, chunks, scales) stay live across the epilogue
+        for (int ps = 0; ps < 4; ++ps) x[ps] += add[ps];
       }
+      if (mode == 1) {
+#pragma unroll
+        for (int ps = 0; ps < 4; ++ps) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, x[ps]), rW, partLane, (t * 4 + ps) * 1024, 17);
+      }
+    }
+#pragma unroll
+    for (int ps = 0; ps < 4; ++ps) {
+      v2i o;
+      o[0] = (int)pack_bf16x2(x[ps][0] * alpha, x[ps][1] * alpha);
+      o[1] = (int)pack_bf16x2(x[ps][2] * alpha, x[ps][3] * alpha);
+      // (the wave-uniform part of the address travels in the scalar offset: as part of the vector offset it costs a register per store)
+      __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2i, o), rD, (32 * n < colLim) ? stLane : (int)0x80000000, ((32 * m + 8 * ps) * p.ldd + 32 * n) * 2, 0);
+    }
+  };
+  auto epilogue = [&](const float alpha, const int mode, const __amdgpu_buffer_rsrc_t rW) __attribute__((always_inline)) {
+    ep_issue(0);
+    fence();
+#pragma unroll
+    for (int t = 1; t < 16; ++t) {
+      ep_issue(t);
+      ep_consume(t - 1, alpha, mode, rW);
+      fence();   // two tiles' temporaries at most: the K loop's registers (next stage's first fragments, chunks, scales) stay live across the epilogue
+    }
+    ep_consume(15, alpha, mode, rW);
+    fence();
   };
 
   // ---- prologue: the first two stages in flight; stage 0 landed -> its scale dwords, first chunk, first pairs, step 0 ----------
@@ -395,15 +400,15 @@ __global__ __launch_bounds__(256) void gemm_nvf4_pk_kernel(const NvGemmParams p)
       int m0, n0;
       decode(cur.tile, m0, n0);
       set_out_tile(m0, n0);
-      if (cur.mode == 1) rD = make_rsrc(p.D, 0);
       const float* slotp = p.sk_ws + (size_t)cur.slot * NvPkCfg::PART_FLOATS;
-      if (cur.mode == 2) {   // the other part was parked at the start of its owner's walk; wait for the flag all the same
+      if (SK && cur.mode == 2) {   // the other part was parked at the start of its owner's walk; wait for the flag all the same
         if (tid == 0)
           while (__hip_atomic_load(p.sk_flags + cur.slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != p.sk_tag) __builtin_amdgcn_s_sleep(4);
         __syncthreads();
       }
-      epilogue(alpha, cur.mode, make_rsrc(slotp, cur.mode != 0 ? NvPkCfg::PART_FLOATS * 4 : 0u));
-      if (cur.mode != 0) {
+      if (SK && cur.mode == 1) rD = make_rsrc(p.D, 0);   // parking: nothing goes to D (empty descriptor: the bf16 stores are dropped)
+      epilogue(alpha, cur.mode, make_rsrc(slotp, (SK && cur.mode != 0) ? NvPkCfg::PART_FLOATS * 4 : 0u));
+      if (SK && cur.mode != 0) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // park: acknowledged by the coherence point; add: every wave's loads of the slot have returned
         __syncthreads();
         // (the consumer resets the flag: a replayed graph -- same tag -- starts clean)
@@ -414,7 +419,6 @@ __global__ __launch_bounds__(256) void gemm_nvf4_pk_kernel(const NvGemmParams p)
     dc = dn;
     nxt = next_unit();
     dn = make_desc(nxt);
-    zero_acc();
   }
   trace();
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -427,17 +431,24 @@ __global__ __launch_bounds__(256) void gemm_nvf4_pk_kernel(const NvGemmParams p)
 // ---- host side: nvpk_plan / nvpk_ws_bytes live in gemm_nvf4.hip.h (no GPU touched: launcher, workspace query, CPU tests) ----------------
 static_assert(NVPK_PART_BYTES == NvPkCfg::PART_FLOATS * 4, "parked tile");
 #if QAMD_TU == 0 || QAMD_TU == 8
-// p.sk_tiles / sk_ws / sk_flags / sk_tag set by the caller (capi.hip nvf4_impl); trace: lab build only
+// p.sk_tiles / sk_ws / sk_flags / sk_tag set by the caller (capi.hip nvf4_impl); stream-K and trace: lab build only
 hipError_t launch_nvf4_pk(NvGemmParams p, hipStream_t s, int grid, bool trace) {
   p.tiles_m = (p.M + 255) / 256;
   p.tiles_n = (p.N + 255) / 256;
 #if QAMD_BENCH
-  if (trace) {
-    hipLaunchKernelGGL((gemm_nvf4_pk_kernel<true>), dim3(grid), dim3(256), 0, s, p);
+  if (p.sk_tiles > 0) {
+    if (trace) hipLaunchKernelGGL((gemm_nvf4_pk_kernel<true, true>), dim3(grid), dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((gemm_nvf4_pk_kernel<false, true>), dim3(grid), dim3(256), 0, s, p);
     return hipSuccess;
   }
+  if (trace) {
+    hipLaunchKernelGGL((gemm_nvf4_pk_kernel<true, false>), dim3(grid), dim3(256), 0, s, p);
+    return hipSuccess;
+  }
+#else
+  if (p.sk_tiles > 0) return hipErrorInvalidValue;
 #endif
-  hipLaunchKernelGGL((gemm_nvf4_pk_kernel<false>), dim3(grid), dim3(256), 0, s, p);
+  hipLaunchKernelGGL((gemm_nvf4_pk_kernel<false, false>), dim3(grid), dim3(256), 0, s, p);
   return hipSuccess;
 }
 #endif

@@ -171,8 +171,6 @@ def test_split_plans_are_consistent_over_a_shape_grid(lib):
     nv = lib.qutlass_amd_debug_nvf4_plan
     nv.restype, nv.argtypes = ctypes.c_int, [ctypes.c_int64] * 3 + [ctypes.c_int]
     nv_ws, mx_ws = lib.qutlass_amd_nvf4_splitk_workspace_bytes, lib.qutlass_amd_gemm_splitk_workspace_bytes
-    pk = lib.qutlass_amd_debug_nvf4_pk_plan
-    pk.restype, pk.argtypes = ctypes.c_int, [ctypes.c_int64] * 3 + [ctypes.c_int, ctypes.POINTER(ctypes.c_int)]
     dry = lib.qutlass_amd_debug_gemm_plan
     dry.restype = ctypes.c_int
     dry.argtypes = [ctypes.c_int] + [ctypes.c_int64] * 4 + [ctypes.POINTER(ctypes.c_int), ctypes.c_int]
@@ -185,11 +183,7 @@ def test_split_plans_are_consistent_over_a_shape_grid(lib):
         r0, r1 = nv(m, n, k, 0), nv(m, n, k, 1)
         assert -1 <= r0 <= 4 and (r1 < 256 or (1 <= r1 % 256 <= 3 and 2 <= r1 // 256 <= 8)), (m, n, k, r0, r1)
         b = nv_ws(m, n, k)
-        pk_out = (ctypes.c_int * 3)()
-        if r1 == 0 and pk(m, n, k, 1, pk_out) and pk_out[1] > 0:   # [r4] 256x256 tiles, part-filled last round: one parked fp32 tile + flag per workgroup
-            assert b == pk_out[0] * (256 * 256 * 4 + 8), (m, n, k, r1, b)
-        else:
-            assert b == (r1 // 256 if r1 >= 256 else 0) * m * n * 4, (m, n, k, r1, b)
+        assert b == (r1 // 256 if r1 >= 256 else 0) * m * n * 4, (m, n, k, r1, b)   # (256x256 tiles: the persistent kernel's balanced rounds need no scratch)
         for ebits in (4, 8):
             b = mx_ws(ebits, m, n, k)
             assert b % (m * n * 4) == 0 and b // (m * n * 4) in (0, 2, 3, 4, 5, 6, 7, 8), (ebits, m, n, k, b)

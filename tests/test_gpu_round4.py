@@ -74,14 +74,7 @@ def test_matmul_nvf4_persistent_kernel_equals_per_tile_kernels_and_oracle(q, m, 
     a, b, sa, sb, sa_b, sb_b = _nv_operands(m, n, k, m + n + k)
     al = torch.tensor([0.5], device=DEV)
     lib = q._lib.load()
-    import ctypes
-
-    pk = lib.qutlass_amd_debug_nvf4_pk_plan
-    pk.restype, pk.argtypes = ctypes.c_int, [ctypes.c_int64] * 3 + [ctypes.c_int, ctypes.POINTER(ctypes.c_int)]
-    plan = (ctypes.c_int * 3)()
-    if pk(m, n, k, 1, plan) and plan[1] > 0:   # the auto rule runs 256x256 tiles with a part-filled last round: scratch for one parked tile per workgroup
-        assert lib.qutlass_amd_nvf4_splitk_workspace_bytes(m, n, k) == plan[0] * (256 * 256 * 4 + 8)
-    out = q.matmul_nvf4_bf16_tn(a, b, sa_b, sb_b, al)                        # product: torch op, scratch from the allocator -> stream-K where planned
+    out = q.matmul_nvf4_bf16_tn(a, b, sa_b, sb_b, al)                        # product: the auto rule (persistent kernel in balanced whole-tile rounds where it picks 256x256 tiles)
     outs = {}
     for v in (41, 42, 43, 5):   # per-tile 256x256 kernel (round 3) / persistent, whole tiles / persistent + stream-K / 128x128 tiles
         with lab.forced(nvf4_variant=v):
@@ -131,22 +124,25 @@ def test_matmul_nvf4_stream_k_graph_replay_and_general_data(q):
     m, n, k = 6144, 4096, 2048
     a, b, sa, sb, sa_b, sb_b = _nv_operands(m, n, k, 99, lo=0x20, hi=0x50)
     al = torch.tensor([1.0], device=DEV)
-    ref_out = q.matmul_nvf4_bf16_tn(a, b, sa_b, sb_b, al)
-    torch.cuda.synchronize()
-    s = torch.cuda.Stream()
-    with torch.cuda.stream(s):
-        for _ in range(2):
-            q.matmul_nvf4_bf16_tn(a, b, sa_b, sb_b, al)
-    torch.cuda.synchronize()
-    gr = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(gr):
-        o1 = q.matmul_nvf4_bf16_tn(a, b, sa_b, sb_b, al)
-        o2 = q.matmul_nvf4_bf16_tn(a, b, sa_b, sb_b, al)
-    for _ in range(3):
-        o1.zero_(); o2.zero_()
-        gr.replay()
+    with lab.forced(nvf4_variant=43):   # the stream-K form (lab build: the product walks whole tiles only)
+        ref_out = lab.matmul_nvf4_bf16_tn(a, b, sa_b, sb_b, al)
         torch.cuda.synchronize()
-        assert torch.equal(o1.view(torch.int16), ref_out.view(torch.int16)) and torch.equal(o2.view(torch.int16), ref_out.view(torch.int16))
+        s = torch.cuda.Stream()
+        with torch.cuda.stream(s):
+            for _ in range(2):
+                lab.matmul_nvf4_bf16_tn(a, b, sa_b, sb_b, al)
+        torch.cuda.synchronize()
+        gr = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gr):
+            o1 = lab.matmul_nvf4_bf16_tn(a, b, sa_b, sb_b, al)
+            o2 = lab.matmul_nvf4_bf16_tn(a, b, sa_b, sb_b, al)
+        for _ in range(3):
+            o1.zero_(); o2.zero_()
+            gr.replay()
+            torch.cuda.synchronize()
+            assert torch.equal(o1.view(torch.int16), ref_out.view(torch.int16)) and torch.equal(o2.view(torch.int16), ref_out.view(torch.int16))
+    prod = q.matmul_nvf4_bf16_tn(a, b, sa_b, sb_b, al)
+    assert torch.equal(prod.view(torch.int16), q.matmul_nvf4_bf16_tn(a, b, sa_b, sb_b, al).view(torch.int16))   # the product path: deterministic
     rows = [0, 300, 3071, 6143]
     got = ref_out[rows].float().cpu().numpy()
     ref = torch.from_numpy(np.ascontiguousarray(_oracle_rows(a, b, sa, sb, 1.0, rows, n, k)).view(np.int16)).view(torch.bfloat16).float().numpy()

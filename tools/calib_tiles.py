@@ -14,7 +14,7 @@ GRAPH = "--stream" not in sys.argv   # default: GPU-only timing through HIP-grap
 NK = [(4096, 4096), (6144, 4096), (5120, 5120), (4096, 14336), (8192, 8192), (5120, 25600), (28672, 4096)]
 MS = [512, 768, 1024, 1536, 2048, 2560, 3072, 4096, 5120, 6144, 8192]
 CAND = {"mxf4": [("auto", 0), ("p256", 90), ("het", 98), ("128", 24), ("256x128", 58), ("r128", 73)], "mxf8": [("auto", 0), ("p256", 90), ("het", 98), ("128", 24), ("256x128", 58)],
-        "nvf4": [("auto", 0), ("256", 41), ("256x128", 40), ("128", 5)]}
+        "nvf4": [("auto", 0), ("pk256", 42), ("256x128", 40), ("128", 5)]}   # [r4] pk256 = the persistent 256x256 kernel (41 = the per-tile one it replaced)
 
 
 def main():

@@ -10,6 +10,7 @@
 #   profnv    rocprofv3 --kernel-trace --stats + SQ busy counters of the NVFP4 GEMM at 8192^3 and 4096 x 28672 x 4096
 #   dip       tools/dip_scan.py (8 % threshold)               sweeps    benchmarks/bench_mxfp4_mi355x.py for MXFP4 (fused) and NVFP4, Llama-3-8B
 #   configs   bench_configs.py                                abmx      tools/ab_mxsk.py (MX persistent kernels: balanced / heterogeneous / stream-K)
+#   calibnv   tools/calib_tiles.py nvf4 (forced tile candidates on the training grid of the NVFP4 tile rule)
 #   stream    tools/ab_stream_ops.py-style timing of the streaming ops (bench_configs.py --only stream)
 cd ${GRAFT_REPO_ROOT:-.}
 NAME=${1:?session name}; shift
@@ -41,6 +42,7 @@ PY
             timeout 900 python benchmarks/bench_mxfp4_mi355x.py --format nvfp4 --had 16 --model Llama-3-8B --max-batch 8192 --reps 30 > $O/bench_sweep_nvfp4_Llama-3-8B.txt 2>> $O/sweeps.err; echo "sweep nvfp4 rc=$?"
             cat $O/bench_sweep_nvfp4_Llama-3-8B.txt ;;
     configs) timeout 900 python bench_configs.py > $O/bench_configs.jsonl 2> $O/bench_configs.err; echo "configs rc=$?"; tail -30 $O/bench_configs.jsonl | cut -c1-240 ;;
+    calibnv) timeout 900 python tools/calib_tiles.py nvf4 > $O/calib_tiles_nvf4.txt 2> $O/calib_tiles_nvf4.err; echo "calibnv rc=$?"; tail -5 $O/calib_tiles_nvf4.txt ;;
     abmx)   timeout 900 python tools/ab_mxsk.py > $O/ab_mxsk.txt 2> $O/ab_mxsk.err; echo "abmx rc=$?"; cat $O/ab_mxsk.txt; tail -3 $O/ab_mxsk.err ;;
     *) echo "unknown step $step" ;;
   esac
