@@ -713,6 +713,26 @@ bool launch_nvf4_ablation(NvGemmParams p, hipStream_t s, int variant);
 #endif
 #endif   // QAMD_BENCH
 
+// [r4] the persistent 256x256 kernel with stream-K over a part-filled last round (gemm_nvf4_pk.hip.h; its own translation unit)
+struct NvPkPlan { int grid, sk_tiles; };
+inline bool nvpk_shape_ok(int64_t M, int64_t N, int64_t K) { return M > 0 && N > 0 && K % 256 == 0 && K >= 512; }
+// Workgroups and stream-K region for T tiles of 256x256 on `cus` CUs.
+//   T a multiple of cus, or no scratch, or less than one round: whole tiles only, BALANCED rounds (R = ceil(T / cus) tiles per workgroup on
+//     ceil(T / R) workgroups rounded up to a multiple of 8 -- the rule of the MX persistent kernels, capi.hip deepp_grid)
+//   otherwise: one workgroup per CU; the full rounds but the last as whole tiles, the last cus + T % cus tiles as an evenly split stream of K stages
+//     (every workgroup walks (cus + T % cus) KT / cus stages: at most one cut tile at each end of its range)
+inline NvPkPlan nvpk_plan(int64_t M, int64_t N, int64_t K, int cus, bool may_sk) {
+  const int64_t T = ((M + 255) / 256) * ((N + 255) / 256);
+  if (may_sk && T > cus && T % cus != 0 && (T % cus) * 8 <= (int64_t)cus * 7) return {cus, (int)(cus + T % cus)};
+  const int64_t rounds = (T + cus - 1) / cus;
+  const int64_t g = ((T + rounds - 1) / rounds + 7) / 8 * 8;
+  return {(int)std::min<int64_t>(std::min<int64_t>(g, cus), T), 0};
+}
+constexpr int64_t NVPK_PART_BYTES = 256 * 256 * 4;   // one parked tile of fp32 accumulators
+// scratch of a stream-K launch on `grid` workgroups: a parked tile per range boundary, then the arrival flags
+inline int64_t nvpk_ws_bytes(int grid) { return (int64_t)grid * NVPK_PART_BYTES + (int64_t)grid * 8; }
+hipError_t launch_nvf4_pk(NvGemmParams p, hipStream_t s, int grid, bool trace);
+
 // Tile configuration of the auto rule (no GPU touched; also behind qutlass_amd_debug_nvf4_plan for the CPU tests):
 //   -1 split-K skinny kernel, 0: 256x256, 1: 128x128, 2: 128x64, 3: 64x64, 4: 256x128 on four waves of 128x64
 // [r3] Where 128x128 tiles fill the chip, the three large configurations are priced round by round -- a per-tile kernel runs
@@ -732,7 +752,22 @@ inline int nvf4_big_cfg(int64_t M, int64_t N, int64_t K, int cus, double* t_us =
   const double c = (double)cus;
   // 256x256
   const int64_t t0 = tiles(256, 256), r0 = (t0 - 1) / cus, l0 = t0 - r0 * cus;
-  const double T0 = r0 * rt(101.0) + rt(ramp(81.0, 101.0, l0 / c));
+  double T0 = r0 * rt(101.0) + rt(ramp(81.0, 101.0, l0 / c));   // the per-tile kernel (K % 256 != 0 or K < 512)
+  // [r4] K % 256 == 0: the persistent kernel (gemm_nvf4_pk.hip.h) in balanced rounds -- R = ceil(tiles / CUs) tiles per workgroup on G = ceil(tiles / R)
+  // workgroups.  A tile costs 5 us + 5.5 us per K stage with every CU busy and less while CUs idle (socket power limit: the busy ones clock higher),
+  // f(G / CUs) through (0, .70) (.5, .73) (.625, .76) (.75, .84) (.875, .91) (1, 1); 3.5 us per launch.  Fitted to the forced-variant calibration
+  // profiles/calib_tiles_nvf4_r4b.txt (64 shapes of this regime: the modelled time is within 3.4 % of the measured one, and the modelled choice is the
+  // best measured candidate on all 64 -- 14 226 us against 14 525 for the round-3 rule on the same shapes, e.g. 6144 x 4096 x 14336 588 -> 529 us).
+  if (nvpk_shape_ok(M, N, K)) {
+    const int64_t R = (t0 + cus - 1) / cus;
+    const int64_t G = std::min<int64_t>(std::min<int64_t>(((t0 + R - 1) / R + 7) / 8 * 8, cus), t0);
+    static constexpr double X[6] = {0.0, 0.5, 0.625, 0.75, 0.875, 1.0}, Y[6] = {0.70, 0.73, 0.76, 0.84, 0.91, 1.0};
+    const double o = (double)G / c;
+    double f = 1.0;
+    for (int i = 0; i < 5; ++i)
+      if (o <= X[i + 1]) { f = Y[i] + (Y[i + 1] - Y[i]) * (o - X[i]) / (X[i + 1] - X[i]); break; }
+    T0 = 3.5 + (double)R * (5.0 + 5.5 * (double)K / 256.0) * f;
+  }
   // 256x128 on four waves
   const int64_t t4 = tiles(256, 128), r4 = (t4 - 1) / cus, l4 = t4 - r4 * cus;
   const double T4 = r4 * rt(59.8) + rt(ramp(51.0, 59.8, l4 / c));
@@ -793,26 +828,6 @@ inline NvPlan nvf4_plan(int64_t M, int64_t N, int64_t K, int cus, bool may_split
   }
   return best;
 }
-
-// [r4] the persistent 256x256 kernel with stream-K over a part-filled last round (gemm_nvf4_pk.hip.h; its own translation unit)
-struct NvPkPlan { int grid, sk_tiles; };
-inline bool nvpk_shape_ok(int64_t M, int64_t N, int64_t K) { return M > 0 && N > 0 && K % 256 == 0 && K >= 512; }
-// Workgroups and stream-K region for T tiles of 256x256 on `cus` CUs.
-//   T a multiple of cus, or no scratch, or less than one round: whole tiles only, BALANCED rounds (R = ceil(T / cus) tiles per workgroup on
-//     ceil(T / R) workgroups rounded up to a multiple of 8 -- the rule of the MX persistent kernels, capi.hip deepp_grid)
-//   otherwise: one workgroup per CU; the full rounds but the last as whole tiles, the last cus + T % cus tiles as an evenly split stream of K stages
-//     (every workgroup walks (cus + T % cus) KT / cus stages: at most one cut tile at each end of its range)
-inline NvPkPlan nvpk_plan(int64_t M, int64_t N, int64_t K, int cus, bool may_sk) {
-  const int64_t T = ((M + 255) / 256) * ((N + 255) / 256);
-  if (may_sk && T > cus && T % cus != 0 && (T % cus) * 8 <= (int64_t)cus * 7) return {cus, (int)(cus + T % cus)};
-  const int64_t rounds = (T + cus - 1) / cus;
-  const int64_t g = ((T + rounds - 1) / rounds + 7) / 8 * 8;
-  return {(int)std::min<int64_t>(std::min<int64_t>(g, cus), T), 0};
-}
-constexpr int64_t NVPK_PART_BYTES = 256 * 256 * 4;   // one parked tile of fp32 accumulators
-// scratch of a stream-K launch on `grid` workgroups: a parked tile per range boundary, then the arrival flags
-inline int64_t nvpk_ws_bytes(int grid) { return (int64_t)grid * NVPK_PART_BYTES + (int64_t)grid * 8; }
-hipError_t launch_nvf4_pk(NvGemmParams p, hipStream_t s, int grid, bool trace);
 
 #if QAMD_TU == 0 || QAMD_TU == 4
 // Returns hipErrorInvalidValue for a variant this build does not know (the product library knows only 0 = auto).

@@ -136,8 +136,11 @@ def test_nvf4_tile_rule(lib):
         assert f(2048, 4096, K, ws) == 4 and f(1536, 4096, K, ws) == 4 and f(1024, 6144, K, ws) == 4        # 256 / 192 / 192 tiles of 256x128: one round
         assert f(2560, 4096, K, ws) == 0 and f(3072, 4096, K, ws) == 0 and f(2048, 6144, K, ws) == 0       # 160 / 192 / 192 tiles of 256x256: one round
         assert f(1024, 4096, K, ws) == 1 and f(512, 6144, K, ws) == 1                                       # the 256x128 grid would leave half the chip idle
-        assert f(3072, 6144, K, ws) == 1 and f(4096, 5120, 5120, ws) == 1 and f(5120, 4096, K, ws) == 1     # 288 / 320 / 320 big tiles: two rounds at 56 / 63 %
-        assert f(6144, 4096, K, ws) == 0 and f(4096, 6144, K, ws) == 0                                      # 384 big tiles = 1.5 rounds: 128x128 is no better (180 vs 188)
+        # [r4] 288 / 320 / 320 big tiles = 1.1 - 1.25 rounds: the per-tile 256x256 kernel lost these to 128x128 tiles (two rounds at 56 / 63 %); the persistent kernel
+        # walks them in balanced rounds (144 / 160 workgroups x 2 tiles) and wins: 137.6 vs 146.2, 183.3 vs 193.5, 146.3 vs 159.7 us (profiles/calib_tiles_nvf4_r4b.txt)
+        assert f(3072, 6144, K, ws) == 0 and f(4096, 5120, 5120, ws) == 0 and f(5120, 4096, K, ws) == 0
+        assert f(3072, 6144, K + 128, ws) == 1                                                              # K % 256 != 0: the per-tile kernels, the round-3 choice
+        assert f(6144, 4096, K, ws) == 0 and f(4096, 6144, K, ws) == 0                                      # 384 big tiles = 1.5 rounds: 192 workgroups x 2 tiles (161 us; 128x128: 190)
         assert f(4096, 5120, 512, ws) == 0 and f(8192, 4096, 14336, ws) == 0
         # small outputs at K = 4096 (16 stages): nothing to split
         assert f(512, 4096, K, ws) == 2 and f(256, 4096, K, ws) == 3 and f(64, 4096, K, ws) == -1 and f(1, 4096, K, ws) == -1 and f(96, 4096, K, ws) == -1
@@ -292,7 +295,7 @@ def test_nvf4_large_output_rule_against_the_committed_calibration(lib):
     chosen = best = 0.0
     worst = 1.0
     n = 0
-    for line in open(os.path.join(ROOT, "profiles", "calib_tiles_r3.txt")):
+    for line in open(os.path.join(ROOT, "profiles", "calib_tiles_nvf4_r4b.txt")):   # [r4] columns: auto, persistent 256x256, 256x128, 128x128
         if not line.startswith("nvf4"):
             continue
         head, vals = line.split("|")
