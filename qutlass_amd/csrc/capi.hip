@@ -203,6 +203,18 @@ int launch_gemm_deepp(GemmParams p, hipStream_t s) {
   return check_launch("gemm_mx_deepp_kernel");
 }
 
+// [r4] stream-K form of the two persistent kernels (variant 89): one workgroup per CU; p.ws / p.ctr / p.tag / p.sk_tiles set by gemm_mx
+template <class C>
+int launch_gemm_deepp_sk(GemmParams p, hipStream_t s) {
+  p.tiles_m = (int)cdiv(p.M, C::BM);
+  p.tiles_n = (int)cdiv(p.N, C::BN);
+  p.splits = 1;
+  const int grid = chip_cus();
+  if constexpr (C::EBITS == 4) hipLaunchKernelGGL((gemm_mx_deepp_kernel<C, false, 17, 0, true>), dim3(grid), dim3(C::THREADS), 0, s, p);
+  else hipLaunchKernelGGL((gemm_mx_deepp8_kernel<C, 17, false, 0, true>), dim3(grid), dim3(C::THREADS), 0, s, p);
+  return check_launch("gemm_mx_deepp_kernel (stream-K)");
+}
+
 template <class C, bool NN = false, int NNABL = 0>
 int launch_gemm_deepp8(GemmParams p, hipStream_t s) {   // the fp8 twin (gemm_mx_deepp8), write-through output stores; NN: A is (K, M)
   p.tiles_m = (int)cdiv(p.M, C::BM);
@@ -253,9 +265,30 @@ inline bool hetero_wins(int64_t T, int cus) {
   return b < a;
 }
 
+// [r4] Stream-K for T tiles of 256x256 (KTe K stages each) on `cus` CUs, or 0: the number of tiles at the end of the raster that are walked as one stream of
+// K stages cut into `cus` equal ranges (streamk.hip.h): the last full round + the remainder.  Needs caller scratch (sk_ws_bytes(cus)), more than one round
+// of tiles (a tile is then cut at most once) and a remainder.  It pays where balanced rounds / the heterogeneous launch leave CUs idle
+// for longer than the parked tiles cost: in units of one full-chip round, T / cus + ov / t_round against the models of hetero_wins below.
+inline int sk_tiles_for(int ebits, int64_t T, int64_t KTe, int cus) {
+  if (T % cus == 0 || T < cus || KTe < 8) return 0;   // (more than one round: every range is at least a tile long -- a tile is cut at most once, no range is empty)
+  const int64_t r = T / cus, rem = T % cus, R = r + 1;
+  const double bal = (double)R * std::max(0.45 + 0.55 * (double)T / (double)(R * cus), 0.78);
+  double het = 1e30;
+  if (r >= 1) {
+    const int64_t nsmall = 4 * rem, waves = nsmall / cus;
+    const double last = (double)(nsmall % cus) / (double)cus;
+    het = (double)r + 0.05 + 0.38 * (double)waves + (last > 0 ? 0.25 + 0.13 * last : 0.0);
+  }
+  const double t_round = (double)KTe * (ebits == 4 ? 1.85 : 1.55);   // us: a 256x256 tile with every CU busy
+  const double sk = (double)T / (double)cus + 4.0 / t_round;          // parked tiles: ~4 us of exposed stores / loads per launch
+  if (!(sk < 0.97 * std::min(bal, het))) return 0;
+  return (int)(cus + rem);
+}
+
 // Tile/schedule variants (0 = auto; the lab library can force one through the "gemm_variant" option):
 //   PRODUCT (what the auto rules below can pick):
 //     90  persistent deep schedule, 256x256 (fp4: gemm_mx_deepp, fp8: gemm_mx_deepp8)      lab: 30 = the per-tile deep schedule of round 1
+//     89  [r4] 90 as a stream-K walk (tiles of a part-filled round cut along K, fp32 parts parked in caller scratch)
 //     98  heterogeneous launch: 90 over the full rounds + the residual tiles as 128x128 tiles in the same grid     lab: 99 = 3-deep ring for those
 //     24 / 25 / 27 / 28 / 29  pipelined schedule on a 2-deep ring: 128x128, 256x128 (8 waves), 128x64, 64x128, 64x64      58  256x128 on four waves, 3-deep ring
 //     70..73  ring schedule 64x64, 128x64, 64x128, 128x128 (+ split-K)          60  skinny split-K kernel (fp4, M <= 32)
@@ -351,6 +384,7 @@ int dispatch_variant(int v, const GemmParams& p, hipStream_t s, const char* name
 #endif
   }
   if constexpr (EBITS == 8) {
+    if (v == 89) return launch_gemm_deepp_sk<GemmCfg<256, 256, 2, 2, 8, true>>(p, s);
     if (v == 90) return launch_gemm_deepp8<GemmCfg<256, 256, 2, 2, 8, true>>(p, s);   // persistent deep schedule, fp8
     if (v == 98) return launch_gemm_hetero<GemmCfg<256, 256, 2, 2, 8, true>, GemmCfg<128, 128, 2, 2, 8, true, 0, 4>, 17>(p, s);
 #if QAMD_BENCH
@@ -360,6 +394,7 @@ int dispatch_variant(int v, const GemmParams& p, hipStream_t s, const char* name
   if constexpr (EBITS == 4) {
     // persistent deep schedule; output stores write through (sc0 sc1): nothing dirty is left for the end-of-kernel L2
     // write-back (4096^3: 34.6 -> 33.4 .. 34.4 us, never slower; profiles/native_r2_store_policy.log)
+    if (v == 89) return launch_gemm_deepp_sk<GemmCfg<256, 256, 2, 2, 4, false>>(p, s);
     if (v == 90) return launch_gemm_deepp<GemmCfg<256, 256, 2, 2, 4, false>, false, 17>(p, s);
     if (v == 98) return launch_gemm_hetero<GemmCfg<256, 256, 2, 2, 4, false>, GemmCfg<128, 128, 2, 2, 4, false, 0, 4>, 17>(p, s);
 #if QAMD_BENCH
@@ -637,7 +672,7 @@ int gemm_mx(const char* name, const void* A, const void* B, const void* A_sf, co
   p.pp_shift = opt_pp_shift();
   p.pp_flags = opt_pp_flags();
   p.dbg = opt_dbg();
-  p.ws = nullptr; p.splits = 1; p.ctr = nullptr; p.tag = 0;
+  p.ws = nullptr; p.splits = 1; p.ctr = nullptr; p.tag = 0; p.sk_tiles = 0;
   hipStream_t s = (hipStream_t)stream;
   int variant = opt_gemm_variant();
   if (variant >= 61 && variant <= 66) variant = 0;   // these select the NN operand path only (matmul_mxf8_bf16_nn)
@@ -761,6 +796,10 @@ int gemm_mx(const char* name, const void* A, const void* B, const void* A_sf, co
       if (two_launch) hetero_ok = false;
 #endif
       if (hetero_ok && hetero_wins(T, cus)) variant = 98;
+      // [r4] stream-K over the part-filled round (caller scratch: the _ws entries / the torch op): tiles cut along K, fp32 parts parked in the scratch
+      if (big == 90 && a_fmt == 0 && ws && ws_bytes >= sk_ws_bytes(cus) && (uintptr_t)ws % 16 == 0 && !(opt_pp_flags() & 64) && (K * EBITS / 8) % 256 == 0 &&
+          sk_tiles_for(EBITS, T, cdiv(K * EBITS / 8, 128), cus) > 0)
+        variant = 89;
     }
     else if (tiles(128, 128) >= want) {
       // [r3] half-chip outputs (fewer than `want` tiles of 256x256): with a long K (>= 32 stages) the 256x128 tile on four waves wins 5-6 %
@@ -776,6 +815,18 @@ int gemm_mx(const char* name, const void* A, const void* B, const void* A_sf, co
     }
     else if (tiles(128, 64) >= want || tiles(64, 128) >= want) variant = (N >= M) ? 27 : 28;
     else variant = 29;
+  }
+  if (variant == 89) {   // (auto, or forced in the lab build: falls back to the persistent kernel when the shape has nothing to cut or the scratch is missing)
+    const int cus = chip_cus();
+    const int64_t T = cdiv(M, 256) * cdiv(N, 256), KTe = (cdiv(K * EBITS / 8, 128) + 1) / 2 * 2;
+    const bool ok = a_fmt == 0 && ws && ws_bytes >= sk_ws_bytes(cus) && (uintptr_t)ws % 16 == 0 && T % cus != 0 && T > cus && KTe >= 8 && (K * EBITS / 8) % 256 == 0 && ldd < (1ll << 22);
+    if (!ok) variant = 90;
+    else {
+      p.sk_tiles = (int)(cus + T % cus);
+      p.ws = (float*)ws;
+      p.ctr = (unsigned long long*)((char*)ws + (int64_t)cus * SK_PART_BYTES);
+      p.tag = next_launch_tag();
+    }
   }
   return dispatch(variant, p, s);
 }
@@ -869,7 +920,15 @@ int64_t qutlass_amd_gemm_splitk_workspace_bytes(int ebits, int64_t M, int64_t N,
   if (M <= 0 || N <= 0 || K <= 0 || (ebits != 4 && ebits != 8)) return 0;
   const SmallPlan pl = (ebits == 4) ? plan_small<4>(M, N, K) : plan_small<8>(M, N, K);
   int64_t need = (pl.variant && pl.splits > 1) ? splitk_ws_bytes(pl.variant, M, N, pl.splits) : 0;
+  // [r4] outputs the persistent 256x256 kernel takes (gemm_mx's auto rule) with a part-filled round that stream-K fills: a parked tile + flag per CU
+  if (!pl.variant && M > 128 && N > 64) {
+    const int cus = chip_cus();
+    const int64_t T = cdiv(M, 256) * cdiv(N, 256), KT = cdiv(K * ebits / 8, 128);
+    const bool big = T >= cus * 3 / 4 || (2 * T > cus && KT >= 8);
+    if (big && N < (1ll << 22) && (K * ebits / 8) % 256 == 0 && sk_tiles_for(ebits, T, KT, cus) > 0) need = std::max<int64_t>(need, sk_ws_bytes(cus));
+  }
 #if QAMD_BENCH
+  if (opt_gemm_variant() == 89) need = std::max<int64_t>(need, sk_ws_bytes(chip_cus()));   // lab: forced stream-K
   if (opt_splitk_force() > 1) need = std::max<int64_t>(need, splitk_ws_bytes(70, M, N, 8));   // lab: room for any forced tile x split
 #endif
   return need;
@@ -1383,18 +1442,20 @@ int qutlass_amd_debug_nvf4_pk_plan(int64_t M, int64_t N, int64_t K, int may_sk, 
 }
 // the units workgroup w of `grid` walks over T tiles (the last sk_tiles as a stream of K stages), KT stages per tile: 5 ints per unit
 // {tile, first stage, end stage, mode, slot} into out[0 .. 5 cap); returns the number of units (the device kernel runs the same NvPkWalk)
-int qutlass_amd_debug_nvf4_pk_units(int w, int grid, int T, int sk_tiles, int KT, int* out, int cap) {
+// gran: stage granularity of a range boundary (1: NVFP4 kernel, 2: the MX kernels)
+int qutlass_amd_debug_sk_units(int w, int grid, int T, int sk_tiles, int KT, int gran, int* out, int cap) {
   if (!out || grid <= 0 || w < 0 || w >= grid || KT < 2 || sk_tiles < 0 || sk_tiles > T) return -1;
-  qamd::NvPkWalk walk(w, grid, T, sk_tiles, KT);
+  qamd::SkWalk walk(w, grid, T, sk_tiles, KT, 2, gran);
   int n = 0;
   for (;;) {
-    const qamd::NvPkUnit u = walk.next();
+    const qamd::SkUnit u = walk.next();
     if (u.mode < 0) break;
     if (n < cap) { out[5 * n] = u.tile; out[5 * n + 1] = u.kb; out[5 * n + 2] = u.ke; out[5 * n + 3] = u.mode; out[5 * n + 4] = u.slot; }
     ++n;
   }
   return n;
 }
+int qutlass_amd_debug_nvf4_pk_units(int w, int grid, int T, int sk_tiles, int KT, int* out, int cap) { return qutlass_amd_debug_sk_units(w, grid, T, sk_tiles, KT, 1, out, cap); }
 
 #if QAMD_BENCH
 // lab library only: device buffer for ABL_TRACE / ABL_CLOCK builds

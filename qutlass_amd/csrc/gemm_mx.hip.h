@@ -70,6 +70,9 @@ struct GemmParams {
   // initialisation (whatever the memory held counts as "0 arrivals" unless it carries this launch's 56-bit tag).
   unsigned long long* ctr;
   unsigned long long tag;    // (launch number & (2^56 - 1)) << 8
+  // [r4] persistent kernels, stream-K form (gemm_mx_deepp.hip.h, streamk.hip.h): the last sk_tiles tiles of the raster are walked as one stream of K stages
+  // cut into equal ranges; ws = parked fp32 tiles (one 256 KiB slot per range boundary), ctr = one arrival flag per slot (== tag: parked), tag = launch number
+  int sk_tiles;
 };
 
 // ablation bits (bench-only instantiations; 0 in the product path)

@@ -20,6 +20,7 @@
 // Same products, same K order per output as every other schedule: bit-identical results.
 #pragma once
 #include "gemm_mx.hip.h"
+#include "streamk.hip.h"
 
 namespace qamd {
 
@@ -54,7 +55,13 @@ constexpr int deepp_pair_done_at(int s) { return (s >= 3 && s <= 59 && (s - 3) %
 //   bit 1: "spread" ablation (needs two copies of the stage code and spills -- 1.5 KB of scratch, 183 us: not usable, kept for the record): half of the tile's output stores (the pairs of m = 0, 1, zero data) are issued one stage EARLY, threaded
 //          through the second half of stage KTe-2, and the last stage retires only the other half -- what a two-stage
 //          accumulator-stationary window could gain at best by overlapping the 32 MiB store burst with more MFMA work
-template <class C, bool TRACE = false, int ST_AUX = 0, int LAB = 0>
+// SK ([r4], streamk.hip.h): the workgroup walks UNITS -- whole tiles, then its range of the stream-K region: at most one tile whose LAST K stages it
+// computes first and parks (raw fp32 accumulators, accumulator layout, write-through stores + a tagged flag), whole tiles, and at most one tile
+// whose FIRST K stages it computes last, with the accumulators initialised from the part its neighbour parked.  Ranges start and end on even
+// stages, so a unit starts in LDS buffer 0 like a tile and the stage code is shared; the DMA stream runs on across unit boundaries exactly as
+// across tiles.  Every output element is produced by one fixed summation order: deterministic; bit-identical to the single pass wherever the
+// partial sums are exact (the reference's tests), one fp32 rounding apart otherwise.
+template <class C, bool TRACE = false, int ST_AUX = 0, int LAB = 0, bool SK = false>
 __device__ __forceinline__ void gemm_mx_deepp(char* smem, const GemmParams& p, const int bid, const int G, const int ntiles) {
   static_assert(C::EBITS == 4 && C::BM == 256 && C::BN == 256 && C::WAVES_M == 2 && C::WAVES_N == 2 && C::NSTAGE == 2 && C::PPW == 2,
                 "persistent deep schedule: fp4, 256x256 tiles, 4 waves of 128x128");
@@ -90,7 +97,14 @@ __device__ __forceinline__ void gemm_mx_deepp(char* smem, const GemmParams& p, c
     m0 = uniform((first_m + rem % gsz) * C::BM);
     n0 = uniform((rem / gsz) * C::BN);
   };
-  struct Desc { __amdgpu_buffer_rsrc_t a, b, s; };
+  // SK: the stream-K form keeps THREE descriptors for the whole kernel (all of A, all of B, this wave's scale operand) and carries a tile as three
+  // scalar byte offsets that ride in the soffset operand of the DMA (the range check of a raw buffer covers voffset + soffset on gfx950,
+  // profiles/native_r2_soffset_probe.txt; "no tile" = offsets of 2^31).  36 scalar registers of per-tile descriptors (this tile, the next one, the
+  // selected one) become 9: the unit walk's own scalars would otherwise push the kernel's scalar spills into a second VGPR -- and at 255 of 256
+  // vector registers that one register spills a hundred others into the hand-scheduled stages.
+  struct Desc { __amdgpu_buffer_rsrc_t a, b, s; uint32_t ao, bo, so; };
+  const __amdgpu_buffer_rsrc_t skA = make_rsrc(p.A, SK ? p.a_bytes : 0u), skB = make_rsrc(p.B, SK ? p.b_bytes : 0u);
+  const __amdgpu_buffer_rsrc_t skS = cx.sIsB ? make_rsrc(p.SFB, SK ? p.sfb_bytes : 0u) : make_rsrc(p.SFA, SK ? p.sfa_bytes : 0u);
   // operand descriptors of tile t (t >= ntiles: empty descriptors -> every DMA of that "tile" loads zeros)
   auto make_desc = [&](int t) __attribute__((always_inline)) {
     const bool valid = t < ntiles;
@@ -99,9 +113,15 @@ __device__ __forceinline__ void gemm_mx_deepp(char* smem, const GemmParams& p, c
     const uint32_t a_off = (uint32_t)m0 * rowbytes, b_off = (uint32_t)n0 * rowbytes;
     const uint32_t sa_off = (uint32_t)(m0 >> 7) * CB * 512, sb_off = (uint32_t)(n0 >> 7) * CB * 512;
     Desc d;
-    d.a = make_rsrc(p.A + a_off, valid ? p.a_bytes - a_off : 0u);
-    d.b = make_rsrc(p.B + b_off, valid ? p.b_bytes - b_off : 0u);
-    d.s = cx.sIsB ? make_rsrc(p.SFB + sb_off, valid ? p.sfb_bytes - sb_off : 0u) : make_rsrc(p.SFA + sa_off, valid ? p.sfa_bytes - sa_off : 0u);
+    if constexpr (SK) {
+      d.ao = valid ? a_off : 0x80000000u;
+      d.bo = valid ? b_off : 0x80000000u;
+      d.so = valid ? (cx.sIsB ? sb_off : sa_off) : 0x80000000u;
+    } else {
+      d.a = make_rsrc(p.A + a_off, valid ? p.a_bytes - a_off : 0u);
+      d.b = make_rsrc(p.B + b_off, valid ? p.b_bytes - b_off : 0u);
+      d.s = cx.sIsB ? make_rsrc(p.SFB + sb_off, valid ? p.sfb_bytes - sb_off : 0u) : make_rsrc(p.SFA + sa_off, valid ? p.sfa_bytes - sa_off : 0u);
+    }
     return d;
   };
 
@@ -156,6 +176,11 @@ __device__ __forceinline__ void gemm_mx_deepp(char* smem, const GemmParams& p, c
   // does not exist), computed once per stage by dma_prep -- opaque to the optimiser so the selects stay arithmetic.
   int vb0 = 0, vb1 = 0, vbS = 0;
   auto dma_prep = [&](int kt, bool valid) __attribute__((always_inline)) {
+    if constexpr (SK) {   // stream-K form: K is a whole, even number of stages (capi.hip) -- no tail flavour, no padding stage; "no tile" lives in the scalar offsets
+      vb0 = cx.voffAB[0]; vb1 = cx.voffAB[1]; vbS = cx.voffS;
+      asm volatile("" : "+v"(vb0), "+v"(vb1), "+v"(vbS));   // (opaque per stage: as loop invariants the 16 sums vb + q * rstep of dma_item would each claim a register)
+      return;
+    }
     int lastmask = (kt == KT - 1) ? -1 : 0;
     int oobm = (valid && kt < KT) ? 0 : -1;
     int oobs = (valid && kt * C::SCT + cx.colS < CB) ? 0 : -1;
@@ -170,9 +195,13 @@ __device__ __forceinline__ void gemm_mx_deepp(char* smem, const GemmParams& p, c
     if (item < 16) {
       const int t = item & 7, q = wave * 8 + t;
       const int v = ((t & 1) ? vb1 : vb0) + q * cx.rstep;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(item < 8 ? d.a : d.b, (lds_ptr_t)(st + (item < 8 ? 0 : C::OFF_B) + q * 1024), 16, v, kt * C::ROWB, 0, QAMD_DMA_AUX);
+      if constexpr (SK)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(item < 8 ? skA : skB, (lds_ptr_t)(st + (item < 8 ? 0 : C::OFF_B) + q * 1024), 16, v, (int)((item < 8 ? d.ao : d.bo) + (uint32_t)(kt * C::ROWB)), 0, QAMD_DMA_AUX);
+      else
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(item < 8 ? d.a : d.b, (lds_ptr_t)(st + (item < 8 ? 0 : C::OFF_B) + q * 1024), 16, v, kt * C::ROWB, 0, QAMD_DMA_AUX);
     } else {
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(d.s, (lds_ptr_t)(st + C::OFF_S + wave * 1024), 16, vbS, kt * C::SCT * 512, 0, 0);
+      if constexpr (SK) __builtin_amdgcn_raw_ptr_buffer_load_lds(skS, (lds_ptr_t)(st + C::OFF_S + wave * 1024), 16, vbS, (int)(d.so + (uint32_t)(kt * C::SCT * 512)), 0, 0);
+      else __builtin_amdgcn_raw_ptr_buffer_load_lds(d.s, (lds_ptr_t)(st + C::OFF_S + wave * 1024), 16, vbS, kt * C::SCT * 512, 0, 0);
     }
   };
   auto dma_stage = [&](const Desc& d, int kt, bool valid, const int buf) __attribute__((always_inline)) {
@@ -284,6 +313,8 @@ __device__ __forceinline__ void gemm_mx_deepp(char* smem, const GemmParams& p, c
   const int scrR = rrl * 256 + (ccl >> 2) * 128 + ((((2 * ccl) & 7) ^ (rrl & 7)) << 4);   // chunk 2 ccl of that row; chunk 2 ccl + 1 = this ^ 16
   const float alpha = *p.alpha;
   __amdgpu_buffer_rsrc_t rD = make_rsrc(p.D, 0);
+  __amdgpu_buffer_rsrc_t rP = make_rsrc(p.D, 0);          // SK: scratch slot of a parking unit (empty otherwise)
+  const int pkLane = SK ? wave * 65536 + lane * 32 : 0;   // SK: this lane's 32 bytes of a parked pass
   int stLane = 0, colLim = 0;
   // output descriptor of the tile at (m0, n0): base = its first element, range = what is left of D from there (capped at
   // 2 GiB: a tile spans < 2^31 bytes, launch code rejects wider rows), so rows >= M fall out of range by themselves;
@@ -322,8 +353,22 @@ __device__ __forceinline__ void gemm_mx_deepp(char* smem, const GemmParams& p, c
     o[2] = (int)pack_bf16x2(hi[0] * alpha, hi[1] * alpha);
     o[3] = (int)pack_bf16x2(hi[2] * alpha, hi[3] * alpha);
     }
+    if constexpr (SK) {
+      // (stream-K form: the wave-uniform part of the address rides in the scalar offset, recomputed per store -- as vector offsets the 32 sums
+      //  stLane + k ldd are precomputed per tile and stay live across the K loop: ten spilled registers at 255 of 256)
+      int ldd2 = p.ldd * 2;
+      asm volatile("" : "+s"(ldd2));
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, o), rD, (64 * h < colLim) ? stLane : (int)0x80000000, (32 * m + 8 * pass) * ldd2 + 128 * h, ST_AUX);
+    } else {
     const int off = stLane + ((32 * m + 8 * pass) * p.ldd + 64 * h) * 2;
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, o), rD, (64 * h < colLim) ? off : (int)0x80000000, 0, ST_AUX);
+    }
+    if constexpr (SK) {
+      // stream-K: the same read-back registers, raw, to the scratch slot of a unit that PARKS its sums (rP is empty for every other unit: the stores
+      // are dropped by the range check; a parking unit has an empty rD instead).  Row-major pairs: ((wave 8 + pair) 4 + pass) 2 KiB + lane 32 B.
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, lo), rP, pkLane, (((2 * m + h) * 4 + pass) * 2048), 17);
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, hi), rP, pkLane, (((2 * m + h) * 4 + pass) * 2048) + 16, 17);
+    }
   };
 
   // ---- the LAST stage of a tile (buffer 1), accumulator-stationary, with the tile's epilogue, the DMA of the next tile's
@@ -334,7 +379,8 @@ __device__ __forceinline__ void gemm_mx_deepp(char* smem, const GemmParams& p, c
   //   write e+1 | read rows 0-15 e+3 | stores e+5, e+6 | read rows 16-31 e+7 | stores e+9, e+10
   // One scratch and one read-back register set per wave: write(P + 1) at e + 9 follows read(P) at e + 7, read(P + 1) at
   // e + 11 follows the last store of P at e + 10 (within a slot: stores, then write, then read).
-  auto final_stage = [&](const Desc& d, bool dvalid) __attribute__((always_inline)) {
+  // ktn: the stage of the next tile (unit) whose DMA is threaded through here -- its second one: 1, or kb' + 1 of a stream-K unit
+  auto final_stage = [&](const Desc& d, bool dvalid, const int ktn) __attribute__((always_inline)) {
     read_slice(1, 2);
     read_slice(1, 3);
     fence();
@@ -343,7 +389,7 @@ __device__ __forceinline__ void gemm_mx_deepp(char* smem, const GemmParams& p, c
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // next tile's stage 0 landed (buffer 0); all reads of buffer 1 done
     __builtin_amdgcn_s_barrier();
     fence();
-    dma_prep(1, dvalid);
+    dma_prep(ktn, dvalid);
     fence();
     static_for<0, 71>([&](auto sc) __attribute__((always_inline)) {
       constexpr int s = decltype(sc)::value;
@@ -354,7 +400,7 @@ __device__ __forceinline__ void gemm_mx_deepp(char* smem, const GemmParams& p, c
       }
       // DMA of the next tile's stage 1 into buffer 1: the B pieces and the scale piece now, one instruction every third
       // slot; the wave's 8 A pieces land in its own scratch area, so they wait until the last read-back (after the loop)
-      if constexpr (s % 3 == 0 && s / 3 < 9) dma_item(d, 1, 1, 8 + s / 3);
+      if constexpr (s % 3 == 0 && s / 3 < 9) dma_item(d, ktn, 1, 8 + s / 3);
       if constexpr (s == 1) read_scales(0, 0);
       // fragments of the next tile's stage 0, as their registers die: A rows of m after tile (m, 3), B rows of n after (3, n)
       if constexpr (s == 12 || s == 28 || s == 44) { read_fa(0, 0, (s - 12) / 16); read_fa(0, 1, (s - 12) / 16); }
@@ -378,10 +424,131 @@ __device__ __forceinline__ void gemm_mx_deepp(char* smem, const GemmParams& p, c
     // the wave's own A pieces of the next tile's stage 1 overwrite its scratch: its read-backs must have returned first
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
-    for (int i = 0; i < 8; ++i) dma_item(d, 1, 1, i);
+    for (int i = 0; i < 8; ++i) dma_item(d, ktn, 1, i);
     fence();
     if constexpr (LAB & 2) pin_acc();   // the accumulators the ablation does not retire must stay live, or their MFMAs are eliminated
   };
+
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+  using BT = std::integral_constant<bool, true>;
+  using BF = std::integral_constant<bool, false>;
+  if constexpr (SK) {
+    // ---- stream-K walk (see the head of this function).  ONE instruction path for every kind of unit -- at 255 of 256 vector registers every join
+    //      of two differently scheduled code paths (a skipped stage, a first stage with / without zero accumulators, a last stage with / without the
+    //      epilogue) turned into register copies and 100+ spills inside the hand-scheduled stages; the kinds differ in DATA only:
+    //        * the accumulators are set BEFORE the first stage -- 16 MFMAs on zero operands, or, for the unit that owns the FIRST K stages of a cut
+    //          tile, 64 loads of the part its neighbour parked -- and the first stage accumulates like any other;
+    //        * every unit ends with the accumulator-stationary last stage; it retires to D, and, through the same read-back registers, to the
+    //          scratch slot rP, one of which is an empty descriptor (a parking unit writes no D, the others park nothing).
+    SkWalk walk(wg, G, ntiles, p.sk_tiles, KTe, 2, 2);
+    auto next_unit = [&]() __attribute__((always_inline)) {
+      SkUnit u = walk.next();
+      u.tile = uniform(u.tile); u.kb = uniform(u.kb); u.ke = uniform(u.ke); u.mode = uniform(u.mode); u.slot = uniform(u.slot);
+      return u;
+    };
+    auto slot_rsrc = [&](const int slot, const bool on) __attribute__((always_inline)) {
+      return make_rsrc((const char*)p.ws + (size_t)slot * SK_PART_BYTES, on ? (uint32_t)SK_PART_BYTES : 0u);
+    };
+    // accumulators of the unit that starts now: zero (one MFMA per 32x32 tile on zero operands: 16 instructions in the idle matrix pipe instead of
+    // 256 v_accvgpr_write), or the parked part of the cut tile -- row-major pairs (retire_store's layout) gathered into the accumulator layout:
+    // row i32 of pair (m, h), columns 32 nn + 8 q + 4 g  ->  ((wave 8 + pair) 4 + i32 / 8) 2 KiB + ((i32 % 8) 8 + 4 nn + q) 32 B + 16 g
+    auto init_acc = [&](const bool from_slot, const int slot) __attribute__((always_inline)) {
+      v8i z = {};
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+          asm volatile("" : "+v"(z));   // (a fresh opaque value per tile: identical MFMAs are otherwise merged into one + 240 register copies)
+          acc[m][n] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(z, z, v16f{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, 4, 4, 0, 0, 0, 0);
+        }
+      if (from_slot) {   // (parked at the START of its owner's walk: the flag is long set)
+        const int elane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+        if (wave == 0 && elane == 0)
+          while (__hip_atomic_load(p.ctr + slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != p.tag) __builtin_amdgcn_s_sleep(4);
+        __builtin_amdgcn_s_barrier();
+        const __amdgpu_buffer_rsrc_t rW = slot_rsrc(slot, true);
+        const int ei32 = elane & 31, eg = elane >> 5;
+        const int ul = wave * 65536 + (ei32 >> 3) * 2048 + (ei32 & 7) * 256 + eg * 16;
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+          for (int n = 0; n < NT; ++n)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const v4f v = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rW, ul, ((2 * m + n / 2) * 4) * 2048 + (4 * (n & 1) + q) * 32, 17));
+              acc[m][n][4 * q + 0] = v[0]; acc[m][n][4 * q + 1] = v[1]; acc[m][n][4 * q + 2] = v[2]; acc[m][n][4 * q + 3] = v[3];
+            }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (wave == 0 && elane == 0) __hip_atomic_store(p.ctr + slot, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // a replayed graph (same tag) starts clean
+      }
+    };
+    // (the walk runs one unit ahead; of a unit only what the stages need stays in scalar registers: its stage range and kind -- the tile went into
+    //  the offsets / the output descriptors when the unit was fetched, the scratch slot follows from the kind)
+    auto set_out_unit = [&](const int tile, const int mode) __attribute__((always_inline)) {
+      int m0, n0;
+      decode(tile, m0, n0);
+      set_out_tile(m0, n0);
+      if (mode == 1) rD = make_rsrc(p.D, 0);    // parking: nothing goes to D
+      rP = slot_rsrc(wg, mode == 1);            // ... the raw sums go to this workgroup's slot
+    };
+    SkUnit u0 = next_unit();
+    if (u0.mode < 0) return;
+    Desc dcur = make_desc(u0.tile);
+    int kb = u0.kb, ke = u0.ke, mode = u0.mode;
+    set_out_unit(u0.tile, mode);
+    SkUnit u1 = next_unit();
+    Desc dnxt = make_desc(u1.mode >= 0 ? u1.tile : ntiles);
+    int nkb = u1.kb, nke = u1.ke, nmode = u1.mode, ntile = u1.tile;
+    dma_stage(dcur, kb, true, 0);
+    dma_stage(dcur, kb + 1, true, 1);
+    asm volatile("s_waitcnt vmcnt(17)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    fence();
+    read_scales(0, 0);
+    read_slice(0, 0);
+    read_slice(0, 1);
+    fence();
+    while (mode >= 0) {
+      const bool nvalid = nmode >= 0;
+      // the stage two ahead of stage s - 2 of this unit: stage s, or stage kb' + (s - ke) of the next unit
+      auto ahead = [&](const int s, Desc& d, int& kt, bool& valid) __attribute__((always_inline)) {
+        const bool tonext = s >= ke;
+        d.ao = tonext ? dnxt.ao : dcur.ao; d.bo = tonext ? dnxt.bo : dcur.bo; d.so = tonext ? dnxt.so : dcur.so;
+        kt = tonext ? nkb + (s - ke) : s;
+        valid = tonext ? nvalid : true;
+      };
+      Desc d;
+      int ktl;
+      bool dv;
+      init_acc(mode == 2, wg + 1);   // (the part of a cut tile is parked by the NEXT workgroup of the walk, in its own slot)
+      ahead(kb + 2, d, ktl, dv);
+      stage(I0{}, BF{}, d, ktl, dv, BF{});
+      for (int kt = kb + 1; kt + 2 < ke; kt += 2) {
+        ahead(kt + 2, d, ktl, dv);
+        stage(I1{}, BF{}, d, ktl, dv, BF{});
+        ahead(kt + 3, d, ktl, dv);
+        stage(I0{}, BF{}, d, ktl, dv, BF{});
+      }
+      final_stage(dnxt, nvalid, nkb + 1);
+      if (mode == 1) {   // parked: acknowledged by the coherence point, then the flag
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        const int elane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+        if (wave == 0 && elane == 0) __hip_atomic_store(p.ctr + wg, p.tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      // the next unit becomes the current one; fetch the one after it
+      kb = nkb; ke = nke; mode = nmode;
+      dcur = dnxt;
+      if (mode >= 0) set_out_unit(ntile, mode);
+      u1 = next_unit();
+      dnxt = make_desc(u1.mode >= 0 ? u1.tile : ntiles);
+      nkb = u1.kb; nke = u1.ke; nmode = u1.mode; ntile = u1.tile;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    return;
+  }
 
   // ---- prologue: first tile's stages 0 and 1 in flight; stage 0 landed -> first two slices into registers ---------------
   int tile = wg;
@@ -397,10 +564,6 @@ __device__ __forceinline__ void gemm_mx_deepp(char* smem, const GemmParams& p, c
   fence();
   trace();
 
-  using I0 = std::integral_constant<int, 0>;
-  using I1 = std::integral_constant<int, 1>;
-  using BT = std::integral_constant<bool, true>;
-  using BF = std::integral_constant<bool, false>;
   while (tile < ntiles) {
     int m0, n0;
     decode(tile, m0, n0);
@@ -428,7 +591,7 @@ __device__ __forceinline__ void gemm_mx_deepp(char* smem, const GemmParams& p, c
       }
     }
     trace();
-    final_stage(nxt, nvalid);
+    final_stage(nxt, nvalid, 1);
     trace();
     cur = nxt;
     tile = tnext;
@@ -456,8 +619,9 @@ __device__ __forceinline__ void gemm_mx_deepp(char* smem, const GemmParams& p, c
 // -------------------------------------------------------------------------------------------------------------------------
 constexpr int deepp8_pair_done_at(int s) { return (s >= 1 && s <= 29 && (s - 1) % 4 == 0) ? (s - 1) / 4 : -1; }
 
-template <class C, int ST_AUX = 0, bool NN = false, int NNABL = 0>
+template <class C, int ST_AUX = 0, bool NN = false, int NNABL = 0, bool SK = false>
 __device__ __forceinline__ void gemm_mx_deepp8(char* smem, const GemmParams& p, const int bid, const int G, const int ntiles) {
+  static_assert(!(SK && NN), "stream-K: TN only");
   static_assert(C::EBITS == 8 && C::F8SPLIT && C::BM == 256 && C::BN == 256 && C::WAVES_M == 2 && C::WAVES_N == 2 && C::NSTAGE == 2 && C::PPW == 1,
                 "persistent deep schedule (fp8): 256x256 tiles, 4 waves of 128x128, split register layout");
   constexpr int MT = 4, NT = 4;
@@ -496,7 +660,10 @@ __device__ __forceinline__ void gemm_mx_deepp8(char* smem, const GemmParams& p, 
     const int idx = lane & 15, r = idx >> 1, b = (lane >> 4) & 1;
     nnA0 = (16 * g + r) * 256 + (((cx.wave_m * 8 + b) ^ (2 * r)) << 4) + 8 * (idx & 1);
   }
-  struct Desc { __amdgpu_buffer_rsrc_t a, b, s; int mrem; };
+  // (SK: three kernel-wide descriptors + per-tile scalar offsets, as in the fp4 kernel)
+  struct Desc { __amdgpu_buffer_rsrc_t a, b, s; int mrem; uint32_t ao, bo, so; };
+  const __amdgpu_buffer_rsrc_t skA = make_rsrc(p.A, SK ? p.a_bytes : 0u), skB = make_rsrc(p.B, SK ? p.b_bytes : 0u);
+  const __amdgpu_buffer_rsrc_t skS = cx.sIsB ? make_rsrc(p.SFB, SK ? p.sfb_bytes : 0u) : make_rsrc(p.SFA, SK ? p.sfa_bytes : 0u);
   auto make_desc = [&](int t) __attribute__((always_inline)) {
     const bool valid = t < ntiles;
     int m0, n0;
@@ -505,9 +672,15 @@ __device__ __forceinline__ void gemm_mx_deepp8(char* smem, const GemmParams& p, 
     const uint32_t sa_off = (uint32_t)(m0 >> 7) * CB * 512, sb_off = (uint32_t)(n0 >> 7) * CB * 512;
     Desc d;
     d.mrem = p.M - m0;   // NN: columns past M would read the next k-row: those lanes fetch out of range (zeros) instead
-    d.a = make_rsrc(p.A + a_off, valid ? p.a_bytes - a_off : 0u);
-    d.b = make_rsrc(p.B + b_off, valid ? p.b_bytes - b_off : 0u);
-    d.s = cx.sIsB ? make_rsrc(p.SFB + sb_off, valid ? p.sfb_bytes - sb_off : 0u) : make_rsrc(p.SFA + sa_off, valid ? p.sfa_bytes - sa_off : 0u);
+    if constexpr (SK) {
+      d.ao = valid ? a_off : 0x80000000u;
+      d.bo = valid ? b_off : 0x80000000u;
+      d.so = valid ? (cx.sIsB ? sb_off : sa_off) : 0x80000000u;
+    } else {
+      d.a = make_rsrc(p.A + a_off, valid ? p.a_bytes - a_off : 0u);
+      d.b = make_rsrc(p.B + b_off, valid ? p.b_bytes - b_off : 0u);
+      d.s = cx.sIsB ? make_rsrc(p.SFB + sb_off, valid ? p.sfb_bytes - sb_off : 0u) : make_rsrc(p.SFA + sa_off, valid ? p.sfa_bytes - sa_off : 0u);
+    }
     return d;
   };
 
@@ -584,6 +757,11 @@ __device__ __forceinline__ void gemm_mx_deepp8(char* smem, const GemmParams& p, 
   int vb0 = 0, vb1 = 0, vbS = 0, va0 = 0, va1 = 0;
   const int nn_rstep = 4 * p.M, nn_kstep = 128 * p.M;   // NN: bytes between consecutive A pieces / K stages
   auto dma_prep = [&](const Desc& d, int kt, bool valid) __attribute__((always_inline)) {
+    if constexpr (SK) {   // (as in the fp4 kernel)
+      vb0 = cx.voffAB[0]; vb1 = cx.voffAB[1]; vbS = cx.voffS;
+      asm volatile("" : "+v"(vb0), "+v"(vb1), "+v"(vbS));
+      return;
+    }
     int lastmask = (kt == KT - 1) ? -1 : 0;
     int oobm = (valid && kt < KT) ? 0 : -1;
     int oobs = (valid && kt * C::SCT + cx.colS < CB) ? 0 : -1;
@@ -609,9 +787,13 @@ __device__ __forceinline__ void gemm_mx_deepp8(char* smem, const GemmParams& p, 
     } else if (item < 16) {
       const int t = item & 7, q = wave * 8 + t;
       const int v = ((t & 1) ? vb1 : vb0) + q * cx.rstep;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(item < 8 ? d.a : d.b, (lds_ptr_t)(st + (item < 8 ? 0 : C::OFF_B) + q * 1024), 16, v, kt * C::ROWB, 0, QAMD_DMA_AUX);
+      if constexpr (SK)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(item < 8 ? skA : skB, (lds_ptr_t)(st + (item < 8 ? 0 : C::OFF_B) + q * 1024), 16, v, (int)((item < 8 ? d.ao : d.bo) + (uint32_t)(kt * C::ROWB)), 0, QAMD_DMA_AUX);
+      else
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(item < 8 ? d.a : d.b, (lds_ptr_t)(st + (item < 8 ? 0 : C::OFF_B) + q * 1024), 16, v, kt * C::ROWB, 0, QAMD_DMA_AUX);
     } else {
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(d.s, (lds_ptr_t)(st + C::OFF_S + wave * 1024), 16, vbS, kt * C::SCT * 512, 0, 0);
+      if constexpr (SK) __builtin_amdgcn_raw_ptr_buffer_load_lds(skS, (lds_ptr_t)(st + C::OFF_S + wave * 1024), 16, vbS, (int)(d.so + (uint32_t)(kt * C::SCT * 512)), 0, 0);
+      else __builtin_amdgcn_raw_ptr_buffer_load_lds(d.s, (lds_ptr_t)(st + C::OFF_S + wave * 1024), 16, vbS, kt * C::SCT * 512, 0, 0);
     }
   };
   auto dma_stage = [&](const Desc& d, int kt, bool valid, const int buf) __attribute__((always_inline)) {
@@ -675,6 +857,8 @@ __device__ __forceinline__ void gemm_mx_deepp8(char* smem, const GemmParams& p, 
   const int scrR = rrl * 256 + (ccl >> 2) * 128 + ((((2 * ccl) & 7) ^ (rrl & 7)) << 4);
   const float alpha = *p.alpha;
   __amdgpu_buffer_rsrc_t rD = make_rsrc(p.D, 0);
+  __amdgpu_buffer_rsrc_t rP = make_rsrc(p.D, 0);          // SK: scratch slot of a parking unit (empty otherwise)
+  const int pkLane = SK ? wave * 65536 + lane * 32 : 0;   // SK: this lane's 32 bytes of a parked pass
   int stLane = 0, colLim = 0;
   auto set_out_tile = [&](int m0, int n0) __attribute__((always_inline)) {
     const int64_t left = ((int64_t)(p.M - m0) * p.ldd - n0) * 2;
@@ -708,11 +892,21 @@ __device__ __forceinline__ void gemm_mx_deepp8(char* smem, const GemmParams& p, 
     o[1] = (int)pack_bf16x2(lo[2] * alpha, lo[3] * alpha);
     o[2] = (int)pack_bf16x2(hi[0] * alpha, hi[1] * alpha);
     o[3] = (int)pack_bf16x2(hi[2] * alpha, hi[3] * alpha);
+    if constexpr (SK) {   // (scalar offset per store, as in the fp4 kernel)
+      int ldd2 = p.ldd * 2;
+      asm volatile("" : "+s"(ldd2));
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, o), rD, (64 * h < colLim) ? stLane : (int)0x80000000, (32 * m + 8 * pass) * ldd2 + 128 * h, ST_AUX);
+    } else {
     const int off = stLane + ((32 * m + 8 * pass) * p.ldd + 64 * h) * 2;
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, o), rD, (64 * h < colLim) ? off : (int)0x80000000, 0, ST_AUX);
+    }
+    if constexpr (SK) {   // stream-K: the raw read-back to the scratch slot of a parking unit (empty descriptor otherwise), as in the fp4 kernel
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, lo), rP, pkLane, (((2 * m + h) * 4 + pass) * 2048), 17);
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, hi), rP, pkLane, (((2 * m + h) * 4 + pass) * 2048) + 16, 17);
+    }
   };
 
-  auto final_stage = [&](const Desc& d, bool dvalid) __attribute__((always_inline)) {
+  auto final_stage = [&](const Desc& d, bool dvalid, const int ktn) __attribute__((always_inline)) {   // ktn: as in the fp4 kernel
     read_slice(1, 1);
     fence();
     mfma1(0, 1, 0, 0, false); mfma1(0, 1, 0, 1, false);   // slice 0 of tiles 0, 1: covers the latency of R(1)
@@ -721,7 +915,7 @@ __device__ __forceinline__ void gemm_mx_deepp8(char* smem, const GemmParams& p, 
     asm volatile("" ::: "memory");
     __builtin_amdgcn_s_barrier();
     fence();
-    dma_prep(d, 1, dvalid);
+    dma_prep(d, ktn, dvalid);
     fence();
     static_for<0, 37>([&](auto sc) __attribute__((always_inline)) {
       constexpr int s = decltype(sc)::value;
@@ -730,7 +924,7 @@ __device__ __forceinline__ void gemm_mx_deepp8(char* smem, const GemmParams& p, 
         constexpr int j = s < 2 ? 1 : (s - 2) % 2;
         mfma1(j, 1, T / 4, T % 4, false);
       }
-      if constexpr (s % 2 == 0 && s / 2 < 9) dma_item(d, 1, 1, 8 + s / 2);
+      if constexpr (s % 2 == 0 && s / 2 < 9) dma_item(d, ktn, 1, 8 + s / 2);
       if constexpr (s == 1) scales_load(0);
       if constexpr (s == 4) scales_fin(0);
       // slice 0 of the next tile's stage 0, as the registers die: A rows of m after tile (m, 3) (MFMA 8 m + 5), B rows of n after (3, n) (MFMA 23 + 2 n)
@@ -747,9 +941,130 @@ __device__ __forceinline__ void gemm_mx_deepp8(char* smem, const GemmParams& p, 
     __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): the retirement reads of the scratch slice (and NN: the asm fragment reads)
     asm volatile("" ::: "memory");
 #pragma unroll
-    for (int i = 0; i < 8; ++i) dma_item(d, 1, 1, i);
+    for (int i = 0; i < 8; ++i) dma_item(d, ktn, 1, i);
     fence();
   };
+
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+  using BT = std::integral_constant<bool, true>;
+  using BF = std::integral_constant<bool, false>;
+  if constexpr (SK) {
+    // ---- stream-K walk (gemm_mx_deepp above has the comments).  ONE instruction path for every kind of unit -- at 255 of 256 vector registers every join
+    //      of two differently scheduled code paths (a skipped stage, a first stage with / without zero accumulators, a last stage with / without the
+    //      epilogue) turned into register copies and 100+ spills inside the hand-scheduled stages; the kinds differ in DATA only:
+    //        * the accumulators are set BEFORE the first stage -- 16 MFMAs on zero operands, or, for the unit that owns the FIRST K stages of a cut
+    //          tile, 64 loads of the part its neighbour parked -- and the first stage accumulates like any other;
+    //        * every unit ends with the accumulator-stationary last stage; it retires to D, and, through the same read-back registers, to the
+    //          scratch slot rP, one of which is an empty descriptor (a parking unit writes no D, the others park nothing).
+    SkWalk walk(wg, G, ntiles, p.sk_tiles, KTe, 2, 2);
+    auto next_unit = [&]() __attribute__((always_inline)) {
+      SkUnit u = walk.next();
+      u.tile = uniform(u.tile); u.kb = uniform(u.kb); u.ke = uniform(u.ke); u.mode = uniform(u.mode); u.slot = uniform(u.slot);
+      return u;
+    };
+    auto slot_rsrc = [&](const int slot, const bool on) __attribute__((always_inline)) {
+      return make_rsrc((const char*)p.ws + (size_t)slot * SK_PART_BYTES, on ? (uint32_t)SK_PART_BYTES : 0u);
+    };
+    // accumulators of the unit that starts now: zero (one MFMA per 32x32 tile on zero operands: 16 instructions in the idle matrix pipe instead of
+    // 256 v_accvgpr_write), or the parked part of the cut tile -- row-major pairs (retire_store's layout) gathered into the accumulator layout:
+    // row i32 of pair (m, h), columns 32 nn + 8 q + 4 g  ->  ((wave 8 + pair) 4 + i32 / 8) 2 KiB + ((i32 % 8) 8 + 4 nn + q) 32 B + 16 g
+    auto init_acc = [&](const bool from_slot, const int slot) __attribute__((always_inline)) {
+      v8i z = {};
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+          asm volatile("" : "+v"(z));   // (a fresh opaque value per tile: identical MFMAs are otherwise merged into one + 240 register copies)
+          acc[m][n] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(z, z, v16f{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, 0, C::AFMT, 0, 0, 0, 0);
+        }
+      if (from_slot) {   // (parked at the START of its owner's walk: the flag is long set)
+        const int elane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+        if (wave == 0 && elane == 0)
+          while (__hip_atomic_load(p.ctr + slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != p.tag) __builtin_amdgcn_s_sleep(4);
+        __builtin_amdgcn_s_barrier();
+        const __amdgpu_buffer_rsrc_t rW = slot_rsrc(slot, true);
+        const int ei32 = elane & 31, eg = elane >> 5;
+        const int ul = wave * 65536 + (ei32 >> 3) * 2048 + (ei32 & 7) * 256 + eg * 16;
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+          for (int n = 0; n < NT; ++n)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const v4f v = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rW, ul, ((2 * m + n / 2) * 4) * 2048 + (4 * (n & 1) + q) * 32, 17));
+              acc[m][n][4 * q + 0] = v[0]; acc[m][n][4 * q + 1] = v[1]; acc[m][n][4 * q + 2] = v[2]; acc[m][n][4 * q + 3] = v[3];
+            }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (wave == 0 && elane == 0) __hip_atomic_store(p.ctr + slot, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // a replayed graph (same tag) starts clean
+      }
+    };
+    // (the walk runs one unit ahead; of a unit only what the stages need stays in scalar registers: its stage range and kind -- the tile went into
+    //  the offsets / the output descriptors when the unit was fetched, the scratch slot follows from the kind)
+    auto set_out_unit = [&](const int tile, const int mode) __attribute__((always_inline)) {
+      int m0, n0;
+      decode(tile, m0, n0);
+      set_out_tile(m0, n0);
+      if (mode == 1) rD = make_rsrc(p.D, 0);    // parking: nothing goes to D
+      rP = slot_rsrc(wg, mode == 1);            // ... the raw sums go to this workgroup's slot
+    };
+    SkUnit u0 = next_unit();
+    if (u0.mode < 0) return;
+    Desc dcur = make_desc(u0.tile);
+    int kb = u0.kb, ke = u0.ke, mode = u0.mode;
+    set_out_unit(u0.tile, mode);
+    SkUnit u1 = next_unit();
+    Desc dnxt = make_desc(u1.mode >= 0 ? u1.tile : ntiles);
+    int nkb = u1.kb, nke = u1.ke, nmode = u1.mode, ntile = u1.tile;
+    dma_stage(dcur, kb, true, 0);
+    dma_stage(dcur, kb + 1, true, 1);
+    asm volatile("s_waitcnt vmcnt(17)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    fence();
+    read_scales(0, 0);
+    read_slice(0, 0);
+    fence();
+    while (mode >= 0) {
+      const bool nvalid = nmode >= 0;
+      // the stage two ahead of stage s - 2 of this unit: stage s, or stage kb' + (s - ke) of the next unit
+      auto ahead = [&](const int s, Desc& d, int& kt, bool& valid) __attribute__((always_inline)) {
+        const bool tonext = s >= ke;
+        d.ao = tonext ? dnxt.ao : dcur.ao; d.bo = tonext ? dnxt.bo : dcur.bo; d.so = tonext ? dnxt.so : dcur.so;
+        d.mrem = 0;
+        kt = tonext ? nkb + (s - ke) : s;
+        valid = tonext ? nvalid : true;
+      };
+      Desc d;
+      int ktl;
+      bool dv;
+      init_acc(mode == 2, wg + 1);   // (the part of a cut tile is parked by the NEXT workgroup of the walk, in its own slot)
+      ahead(kb + 2, d, ktl, dv);
+      stage(I0{}, BF{}, d, ktl, dv);
+      for (int kt = kb + 1; kt + 2 < ke; kt += 2) {
+        ahead(kt + 2, d, ktl, dv);
+        stage(I1{}, BF{}, d, ktl, dv);
+        ahead(kt + 3, d, ktl, dv);
+        stage(I0{}, BF{}, d, ktl, dv);
+      }
+      final_stage(dnxt, nvalid, nkb + 1);
+      if (mode == 1) {   // parked: acknowledged by the coherence point, then the flag
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        const int elane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+        if (wave == 0 && elane == 0) __hip_atomic_store(p.ctr + wg, p.tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      // the next unit becomes the current one; fetch the one after it
+      kb = nkb; ke = nke; mode = nmode;
+      dcur = dnxt;
+      if (mode >= 0) set_out_unit(ntile, mode);
+      u1 = next_unit();
+      dnxt = make_desc(u1.mode >= 0 ? u1.tile : ntiles);
+      nkb = u1.kb; nke = u1.ke; nmode = u1.mode; ntile = u1.tile;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    return;
+  }
 
   int tile = wg;
   Desc cur = make_desc(tile);
@@ -763,10 +1078,6 @@ __device__ __forceinline__ void gemm_mx_deepp8(char* smem, const GemmParams& p, 
   nn_wait();
   fence();
 
-  using I0 = std::integral_constant<int, 0>;
-  using I1 = std::integral_constant<int, 1>;
-  using BT = std::integral_constant<bool, true>;
-  using BF = std::integral_constant<bool, false>;
   while (tile < ntiles) {
     int m0, n0;
     decode(tile, m0, n0);
@@ -789,23 +1100,23 @@ __device__ __forceinline__ void gemm_mx_deepp8(char* smem, const GemmParams& p, 
       d.mrem = tonext ? nxt.mrem : cur.mrem;
       stage(I0{}, BF{}, d, tonext ? 0 : kt + 3, tonext ? nvalid : true);
     }
-    final_stage(nxt, nvalid);
+    final_stage(nxt, nvalid, 1);
     cur = nxt;
     tile = tnext;
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
-template <class C, int ST_AUX = 0, bool NN = false, int NNABL = 0>
+template <class C, int ST_AUX = 0, bool NN = false, int NNABL = 0, bool SK = false>
 __global__ __launch_bounds__(C::THREADS) void gemm_mx_deepp8_kernel(const GemmParams p) {
   __shared__ __attribute__((aligned(16))) char smem[DeepPCfg<C>::LDS_BYTES];
-  gemm_mx_deepp8<C, ST_AUX, NN, NNABL>(smem, p, (int)blockIdx.x, (int)gridDim.x, p.tiles_m * p.tiles_n);
+  gemm_mx_deepp8<C, ST_AUX, NN, NNABL, SK>(smem, p, (int)blockIdx.x, (int)gridDim.x, p.tiles_m * p.tiles_n);
 }
 
-template <class C, bool TRACE = false, int ST_AUX = 0, int LAB = 0>
+template <class C, bool TRACE = false, int ST_AUX = 0, int LAB = 0, bool SK = false>
 __global__ __launch_bounds__(C::THREADS) void gemm_mx_deepp_kernel(const GemmParams p) {
   __shared__ __attribute__((aligned(16))) char smem[DeepPCfg<C>::LDS_BYTES];
-  gemm_mx_deepp<C, TRACE, ST_AUX, LAB>(smem, p, (int)blockIdx.x, (int)gridDim.x, p.tiles_m * p.tiles_n);
+  gemm_mx_deepp<C, TRACE, ST_AUX, LAB, SK>(smem, p, (int)blockIdx.x, (int)gridDim.x, p.tiles_m * p.tiles_n);
 }
 
 // -------------------------------------------------------------------------------------------------------------------------

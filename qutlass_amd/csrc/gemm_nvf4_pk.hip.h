@@ -25,6 +25,7 @@
 // K % 256 == 0, K >= 512 and N % 8 == 0 (capi.hip checks; other shapes keep the per-tile kernels).
 #pragma once
 #include "gemm_nvf4.hip.h"
+#include "streamk.hip.h"
 
 namespace qamd {
 
@@ -39,49 +40,8 @@ struct NvPkCfg {
   static_assert(LDS_BYTES == 160 * 1024, "LDS budget");
 };
 
-// first stage (in the tile-major stage space of the stream-K region, KT stages per tile) of workgroup w: w / G of the work, moved to
-// the tile boundary when it would leave a part shorter than MINP stages.  Host and device use the same arithmetic (capi.hip sizes
-// the scratch from it; tests/test_cabi_and_host.py walks it through the debug entry).
-__host__ __device__ inline int nvpk_sk_bound(int w, int G, long long Wsk, int KT) {
-  const long long x = ((long long)w * Wsk + G / 2) / G;
-  const int t = (int)(x / KT);
-  int o = (int)(x % KT);
-  if (o < NvPkCfg::MINP) o = 0;
-  else if (o > KT - NvPkCfg::MINP) o = KT;
-  return t * KT + o;
-}
-
-// The units one workgroup walks, in order (host and device: the CPU tests replay every workgroup's walk through qutlass_amd_debug_nvf4_pk_units
-// and check that each K stage of each tile is computed exactly once and that parked / added slots pair up).
-//   mode 0: whole tile   1: the tile's LAST K stages [kb, KT), raw accumulators parked in scratch slot `slot`
-//        2: the tile's FIRST K stages [0, ke), slot `slot` added in the epilogue, D written      -1: none
-struct NvPkUnit { int tile, kb, ke, mode, slot; };
-struct NvPkWalk {
-  int w, G, KT, Tdp, dp, pos, end;
-  // T tiles, the last Tsk of them as a stream of K stages (0: whole tiles only), KT stages per tile, workgroup w of G
-  __host__ __device__ NvPkWalk(int w_, int G_, int T, int Tsk, int KT_) : w(w_), G(G_), KT(KT_), Tdp(T - Tsk), dp(w_), pos(0), end(0) {
-    if (Tsk > 0) {
-      const long long Wsk = (long long)Tsk * KT;
-      pos = nvpk_sk_bound(w, G, Wsk, KT);
-      end = nvpk_sk_bound(w + 1, G, Wsk, KT);
-    }
-  }
-  __host__ __device__ NvPkUnit next() {
-    NvPkUnit u = {0, 0, 0, -1, 0};
-    if (dp < Tdp) {   // whole tiles w, w + G, ... of the data-parallel part
-      u.tile = dp; u.kb = 0; u.ke = KT; u.mode = 0;
-      dp += G;
-    } else if (pos < end) {
-      const int t = pos / KT, kb = pos - t * KT;
-      const int ke = (kb + end - pos < KT) ? kb + end - pos : KT;
-      u.tile = Tdp + t; u.kb = kb; u.ke = ke;
-      u.mode = kb > 0 ? 1 : (ke < KT ? 2 : 0);
-      u.slot = kb > 0 ? w : w + 1;
-      pos += ke - kb;
-    }
-    return u;
-  }
-};
+// (unit walk: streamk.hip.h, minimum part 2 stages, any stage boundary)
+using NvPkUnit = SkUnit;
 
 // TRACE (lab): workgroup 0 / wave 0 writes the shader clock and the 100 MHz wall clock at every stage start to p.dbg.
 // SK: the stream-K form (units that park / add partial tiles).  The PRODUCT instantiates SK = false only: measured on MI355X
@@ -115,7 +75,7 @@ __global__ __launch_bounds__(256) void gemm_nvf4_pk_kernel(const NvGemmParams p)
 
   // ---- units (NvPkWalk, above) ------------------------------------------------------------------------------------------------
   using Unit = NvPkUnit;
-  NvPkWalk walk(w, G, T, Tsk, KT);
+  SkWalk walk(w, G, T, Tsk, KT, NvPkCfg::MINP, 1);
   auto next_unit = [&]() __attribute__((always_inline)) {
     Unit u = walk.next();
     u.tile = uniform(u.tile); u.kb = uniform(u.kb); u.ke = uniform(u.ke); u.mode = uniform(u.mode); u.slot = uniform(u.slot);

@@ -189,9 +189,13 @@ def test_split_plans_are_consistent_over_a_shape_grid(lib):
         assert b == (r1 // 256 if r1 >= 256 else 0) * m * n * 4, (m, n, k, r1, b)   # (256x256 tiles: the persistent kernel's balanced rounds need no scratch)
         for ebits in (4, 8):
             b = mx_ws(ebits, m, n, k)
-            assert b % (m * n * 4) == 0 and b // (m * n * 4) in (0, 2, 3, 4, 5, 6, 7, 8), (ebits, m, n, k, b)
-            assert dry(ebits, m, n, k, 0, out, 8) >= 1 and out[2] == 1                      # no scratch: one pass
-            assert dry(ebits, m, n, k, 1 << 40, out, 8) >= 1 and out[2] == max(1, b // (m * n * 4)), (ebits, m, n, k, out[0], out[2], b)
+            assert dry(ebits, m, n, k, 0, out, 8) >= 1 and out[2] == 1 and out[0] != 89      # no scratch: one pass, no stream-K
+            assert dry(ebits, m, n, k, 1 << 40, out, 8) >= 1
+            if out[0] == 89:   # [r4] stream-K form of the persistent kernel: a parked fp32 tile + an arrival flag per CU
+                assert b == 256 * (256 * 256 * 4 + 8) and out[2] == 1, (ebits, m, n, k, b)
+            else:
+                assert b % (m * n * 4) == 0 and b // (m * n * 4) in (0, 2, 3, 4, 5, 6, 7, 8), (ebits, m, n, k, b)
+                assert out[2] == max(1, b // (m * n * 4)), (ebits, m, n, k, out[0], out[2], b)
 
 
 def test_nvf4_persistent_walk_covers_every_stage_once(lib):
@@ -255,6 +259,38 @@ def test_nvf4_persistent_walk_covers_every_stage_once(lib):
             for T in list(range(grid + 1, 2 * grid + 1, max(1, grid // 8))) + [3 * grid + 5, 7 * grid - 1]:
                 walk_all(grid, T, grid + T % grid if T % grid else 0, KT)
                 walk_all(grid, T, 0, KT)
+    # the MX kernels' walk (gemm_mx_deepp.hip.h): range boundaries on EVEN stages (the stage code is unrolled by LDS-buffer parity)
+    sk = lib.qutlass_amd_debug_sk_units
+    sk.restype, sk.argtypes = ctypes.c_int, [ctypes.c_int] * 6 + [ctypes.POINTER(ctypes.c_int), ctypes.c_int]
+
+    def walk_mx(grid, T, sktiles, KT):
+        seen, parks, adds = {}, {}, {}
+        for w in range(grid):
+            n = sk(w, grid, T, sktiles, KT, 2, buf, 64)
+            assert 0 <= n <= 64
+            us = [tuple(buf[5 * i:5 * i + 5]) for i in range(n)]
+            for i, (tile, kb, ke, mode, slot) in enumerate(us):
+                assert kb % 2 == 0 and ke % 2 == 0 and ke - kb >= 2 and 0 <= kb < ke <= KT
+                for k in range(kb, ke):
+                    assert (tile, k) not in seen
+                    seen[(tile, k)] = w
+                if mode == 1:
+                    assert slot == w and i == 0 or us[i - 1][0] < T - sktiles      # parked before anything else of the stream
+                    parks[tile] = (w, kb)
+                if mode == 2:
+                    assert slot == w + 1 and i == n - 1
+                    adds[tile] = (w, ke)
+        assert len(seen) == T * KT and parks.keys() == adds.keys()
+        for t in parks:
+            assert parks[t][0] == adds[t][0] + 1 and parks[t][1] == adds[t][1]
+        return len(parks)
+
+    # (the planner -- capi.hip sk_tiles_for -- asks for KT >= 8 and MORE than one round of tiles: every range is then at least one tile long -- a tile is
+    #  cut at most once, by two neighbouring workgroups -- and none is empty, which the slot pairing "parked by the next workgroup" relies on)
+    for KT in (8, 16, 32, 224):
+        for (grid, T) in [(256, 384), (256, 320), (256, 257), (256, 511), (256, 576), (256, 1344), (8, 9), (8, 12), (24, 25), (24, 47)]:
+            cuts = walk_mx(grid, T, grid + T % grid, KT)
+            assert cuts > 0
 
 
 def test_plan_model_constants_reproduce_from_the_committed_calibration():

@@ -194,3 +194,105 @@ def test_pipeline_on_a_second_device_and_a_side_stream(q, dev_index):
     assert np.array_equal(_np(out).view(np.uint16), ref.view(np.uint16))
     ref4 = oracle.gemm_blockscaled(oracle.KIND_NVFP4, _np(xq4), _np(wq4), _np(to_blocked(xs4)), _np(to_blocked(ws4)), 1.0, m, n, k)
     assert np.array_equal(_np(out4).view(np.uint16), ref4.view(np.uint16))
+
+
+# ------------------------------------------------------------------------------------------------
+# stream-K form of the MX persistent kernels (gemm_mx_deepp.hip.h, streamk.hip.h; variant 89)
+# ------------------------------------------------------------------------------------------------
+def _rand_mx(m, n, k, seed, fp8=False):
+    """random operands in the exact regime (block exponents within +-3): any K order gives the same fp32 sums for fp4"""
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    if fp8:
+        a = torch.randint(0, 256, (m, k), dtype=torch.uint8, generator=g)
+        b = torch.randint(0, 256, (n, k), dtype=torch.uint8, generator=g)
+        a = torch.where((a & 0x7f) == 0x7f, a & 0x80, a)
+        b = torch.where((b & 0x7f) == 0x7f, b & 0x80, b)
+    else:
+        a = torch.randint(0, 256, (m, k // 2), dtype=torch.uint8, generator=g)
+        b = torch.randint(0, 256, (n, k // 2), dtype=torch.uint8, generator=g)
+    sa = torch.randint(124, 131, (m, k // 32), dtype=torch.uint8, generator=g)
+    sb = torch.randint(124, 131, (n, k // 32), dtype=torch.uint8, generator=g)
+    return a, b, sa, sb
+
+
+def _mx_rows(kind, a, b, sa, sb, alpha, rows, n, k):
+    return oracle.gemm_blockscaled(kind, a[rows].numpy(), b.numpy(), oracle.to_blocked(sa[rows].numpy()), oracle.to_blocked(sb.numpy()), alpha, len(rows), n, k)
+
+
+# tiles of 256x256 on 256 CUs: 384 = 1.5 rounds (every tile of the stream is cut or whole, 24 / 48 stages per workgroup), 320 = 1.25, ragged 378 tiles,
+# 576 = 2.25 rounds (one whole-tile round first), K = 2048 .. 8192 (8 .. 32 stages of fp4, 16 .. 64 of fp8)
+@pytest.mark.parametrize("m,n,k", [(6144, 4096, 4096), (4096, 5120, 2048), (4360, 5128, 2048), (8192, 4608, 2048), (6144, 4096, 8192)])
+def test_stream_k_mxfp4_equals_persistent_kernel_and_oracle(q, m, n, k):
+    from qutlass_amd.utils import to_blocked
+
+    a, b, sa, sb = _rand_mx(m, n, k, seed=m + n + k)
+    ad, bd = a.to(DEV), b.to(DEV)
+    asf = to_blocked(sa.to(DEV).view(torch.float8_e8m0fnu))
+    bsf = to_blocked(sb.to(DEV).view(torch.float8_e8m0fnu))
+    alpha = torch.tensor([0.5], device=DEV)
+    with lab.forced(gemm_variant=89):
+        sk = lab.matmul_mxf4_bf16_tn(ad, bd, asf, bsf, alpha)
+        sk2 = lab.matmul_mxf4_bf16_tn(ad, bd, asf, bsf, alpha)
+    with lab.forced(gemm_variant=90, pp_flags=1 | 64):   # ONE persistent launch over whole tiles (balanced rounds)
+        one = lab.matmul_mxf4_bf16_tn(ad, bd, asf, bsf, alpha)
+    assert torch.equal(sk.view(torch.int16), sk2.view(torch.int16))
+    assert torch.equal(sk.view(torch.int16), one.view(torch.int16)), int((sk.view(torch.int16) != one.view(torch.int16)).sum())
+    got = q.matmul_mxf4_bf16_tn(ad, bd, asf, bsf, alpha)  # the product's own choice (torch op: scratch from the allocator)
+    assert torch.equal(got.view(torch.int16), one.view(torch.int16))
+    rows = sorted({0, 255, 256, m // 2, m - 257, m - 1})
+    ref = _mx_rows(oracle.KIND_MXFP4, a, b, sa, sb, 0.5, rows, n, k)
+    assert np.array_equal(_np(sk)[rows].view(np.uint16), ref.view(np.uint16))
+
+
+@pytest.mark.parametrize("m,n,k", [(6144, 4096, 2048), (4096, 5120, 4096), (4360, 5128, 1024)])
+def test_stream_k_mxfp8_equals_persistent_kernel_and_oracle(q, m, n, k):
+    from qutlass_amd.utils import to_blocked
+
+    a, b, sa, sb = _rand_mx(m, n, k, seed=m + n + k + 1, fp8=True)
+    ad, bd = a.to(DEV).view(torch.float8_e4m3fn), b.to(DEV).view(torch.float8_e4m3fn)
+    asf = to_blocked(sa.to(DEV).view(torch.float8_e8m0fnu))
+    bsf = to_blocked(sb.to(DEV).view(torch.float8_e8m0fnu))
+    alpha = torch.tensor([1.0], device=DEV)
+    with lab.forced(gemm_variant=89):
+        sk = lab.matmul_mxf8_bf16_tn(ad, bd, asf, bsf, alpha)
+        sk2 = lab.matmul_mxf8_bf16_tn(ad, bd, asf, bsf, alpha)
+    with lab.forced(gemm_variant=90, pp_flags=1 | 64):
+        one = lab.matmul_mxf8_bf16_tn(ad, bd, asf, bsf, alpha)
+    assert torch.equal(sk.view(torch.int16), sk2.view(torch.int16))                      # deterministic
+    # e4m3 x e4m3 products are not all exact in fp32 sums: the cut tiles' order (parked last part + first part) may move a bf16 tie
+    d = (sk.float() - one.float()).abs()
+    assert float((d / one.float().abs().clamp_min(float(one.float().abs().mean()))).max()) <= 2.0 ** -7
+    assert float((sk.view(torch.int16) != one.view(torch.int16)).float().mean()) <= 2e-3
+    rows = sorted({0, 255, 256, m // 2, m - 257, m - 1})
+    ref = oracle.bf16_bits_to_f32(_mx_rows(oracle.KIND_MXFP8_TN, a, b, sa, sb, 1.0, rows, n, k)).astype(np.float64)
+    g = oracle.bf16_bits_to_f32(_np(sk)[rows]).astype(np.float64)
+    assert (np.abs(g - ref) <= np.abs(ref) / 128.0 + 1e-4 * np.abs(ref).max()).all()
+
+
+def test_stream_k_mx_graph_replay(q):
+    """the arrival flags carry a per-launch tag and are reset by their consumer: a captured graph (same tag, same scratch) replays to the same bytes"""
+    from qutlass_amd.utils import to_blocked
+
+    m, n, k = 6144, 4096, 4096
+    a, b, sa, sb = _rand_mx(m, n, k, seed=3)
+    ad, bd = a.to(DEV), b.to(DEV)
+    asf = to_blocked(sa.to(DEV).view(torch.float8_e8m0fnu))
+    bsf = to_blocked(sb.to(DEV).view(torch.float8_e8m0fnu))
+    alpha = torch.tensor([1.0], device=DEV)
+    with lab.forced(gemm_variant=89):
+        ref = lab.matmul_mxf4_bf16_tn(ad, bd, asf, bsf, alpha)
+        torch.cuda.synchronize()
+        s = torch.cuda.Stream()
+        with torch.cuda.stream(s):
+            for _ in range(2):
+                lab.matmul_mxf4_bf16_tn(ad, bd, asf, bsf, alpha)
+        torch.cuda.synchronize()
+        gr = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gr):
+            o1 = lab.matmul_mxf4_bf16_tn(ad, bd, asf, bsf, alpha)
+            o2 = lab.matmul_mxf4_bf16_tn(ad, bd, asf, bsf, alpha)
+        for _ in range(3):
+            o1.zero_(); o2.zero_()
+            gr.replay()
+            torch.cuda.synchronize()
+            assert torch.equal(o1.view(torch.int16), ref.view(torch.int16)) and torch.equal(o2.view(torch.int16), ref.view(torch.int16))
