@@ -257,14 +257,11 @@ const char* qutlass_amd_last_error(void);
 const char* qutlass_amd_version(void);
 
 /*
- * The one verification switch of the library (process-wide):
- *   "hw_fp4_cvt"   (default 1) use v_cvt_scalef32_pk_fp4_f32 for the final e2m1 rounding; 0 = software encoder.  Both
- *                  produce the same bits on gfx950 (tests/test_gpu_parity.py runs every quantizer test
- *                  under both values).
- * Returns the previous value, or -1 for an unknown key.  libqutlass_amd.so knows no other key: nothing a caller or another
- * thread does can change which kernel a shape gets.  (The lab build of the same sources, libqutlass_amd_bench.so -- test and
- * bench infrastructure, see INTEGRATION.md -- additionally accepts "gemm_variant", "nvf4_variant", "pp_flags",
- * "splitk_wg", "splitk_min_kt", "splitk_force", "transpose_nc", "quant_wg_per_cu", "pp_shift".)
+ * libqutlass_amd.so has NO options: this entry returns -1 for every key -- nothing a caller or another thread does can change which
+ * kernel a shape gets or what it computes.  (The lab build of the same sources, libqutlass_amd_bench.so -- test and bench
+ * infrastructure, see INTEGRATION.md -- accepts "gemm_variant", "nvf4_variant", "pp_flags", "splitk_wg", "splitk_min_kt",
+ * "splitk_force", "transpose_nc", "quant_wg_per_cu", "pp_shift", "deepp_grid" and "hw_fp4_cvt" (0 = the software e2m1 encoder instead of
+ * v_cvt_scalef32_pk_fp4_f32: same bits, tests/test_gpu_parity.py) and returns the previous value.)
  */
 int qutlass_amd_set_option(const char* key, int value);
 

@@ -24,8 +24,8 @@ using namespace qamd;
 
 // One source, several translation units, two libraries.
 //   libqutlass_amd.so        the PRODUCT: the C ABI of include/qutlass_amd.h and exactly the kernels its dispatch rules can
-//                            reach.  No process-wide switch can change which kernel runs or what it computes; the only
-//                            option is "hw_fp4_cvt" (two encoders that are tested to the same bits).
+//                            reach.  No process-wide switch can change which kernel runs or what it computes: qutlass_amd_set_option
+//                            knows no key ([r4] the "hw_fp4_cvt" encoder switch of rounds 1-3 lives in the lab build only).
 //   libqutlass_amd_bench.so  the LAB (-DQAMD_BENCH=1): the same entry points plus every schedule variant, ablation, trace
 //                            and clock-probe instantiation the design record cites, selectable through
 //                            qutlass_amd_set_option("gemm_variant" / "nvf4_variant" / "pp_flags" / ...).  Only
@@ -49,8 +49,8 @@ namespace qamd_host {
 
 #if QAMD_DEF(1)
 thread_local char g_err[512] = "";
-std::atomic<int> g_hw_fp4_cvt{1};   // device-verified bit-identical to the software encoder (tests/native/probe.hip P2)
 #if QAMD_BENCH
+std::atomic<int> g_hw_fp4_cvt{1};   // lab: 0 = the software e2m1 encoder (device-verified bit-identical to v_cvt_scalef32_pk_fp4_f32, tests/native/probe.hip P2)
 std::atomic<int> g_gemm_variant{0};
 std::atomic<int> g_nvf4_variant{0};
 std::atomic<int> g_splitk_wg{0};        // split-K: target workgroup count ("splitk_wg"; one per CU measured best, profiles/native_r1_splitk_wg.log)
@@ -90,9 +90,8 @@ unsigned long long next_launch_tag() {
 }
 #else
 unsigned long long next_launch_tag();
-extern std::atomic<int> g_hw_fp4_cvt;
 #if QAMD_BENCH
-extern std::atomic<int> g_gemm_variant, g_nvf4_variant, g_splitk_wg, g_splitk_min_kt, g_transpose_nc, g_pp_shift, g_pp_flags, g_quant_wg_per_cu, g_splitk_force, g_deepp_grid;
+extern std::atomic<int> g_hw_fp4_cvt, g_gemm_variant, g_nvf4_variant, g_splitk_wg, g_splitk_min_kt, g_transpose_nc, g_pp_shift, g_pp_flags, g_quant_wg_per_cu, g_splitk_force, g_deepp_grid;
 extern std::atomic<uint32_t*> g_dbg;
 #endif
 int fail(int code, const char* fmt, ...);
@@ -102,6 +101,7 @@ int check_launch(const char* what);
 // Tuning state.  In the product library these are compile-time constants: nothing a caller (or another thread) does can
 // change which kernel a shape gets.  The lab library reads them from qutlass_amd_set_option().
 #if QAMD_BENCH
+inline bool opt_hw_fp4() { return g_hw_fp4_cvt.load() != 0; }
 inline int opt_gemm_variant() { return g_gemm_variant.load(); }
 inline int opt_nvf4_variant() { return g_nvf4_variant.load(); }
 inline int opt_splitk_wg() { return g_splitk_wg.load(); }   // 0 = one workgroup per CU
@@ -114,6 +114,7 @@ inline int opt_splitk_force() { return g_splitk_force.load(); }
 inline int opt_deepp_grid() { return g_deepp_grid.load(); }
 inline uint32_t* opt_dbg() { return g_dbg.load(); }
 #else
+constexpr bool opt_hw_fp4() { return true; }   // the product ships ONE e2m1 encoder: the hardware convert
 constexpr int opt_gemm_variant() { return 0; }
 constexpr int opt_nvf4_variant() { return 0; }
 constexpr int opt_splitk_wg() { return 0; }
@@ -203,7 +204,8 @@ int launch_gemm_deepp(GemmParams p, hipStream_t s) {
   return check_launch("gemm_mx_deepp_kernel");
 }
 
-// [r4] stream-K form of the two persistent kernels (variant 89): one workgroup per CU; p.ws / p.ctr / p.tag / p.sk_tiles set by gemm_mx
+// [r4] stream-K form of the two persistent kernels (lab variant 89): one workgroup per CU; p.ws / p.ctr / p.tag / p.sk_tiles set by gemm_mx
+#if QAMD_BENCH
 template <class C>
 int launch_gemm_deepp_sk(GemmParams p, hipStream_t s) {
   p.tiles_m = (int)cdiv(p.M, C::BM);
@@ -214,6 +216,7 @@ int launch_gemm_deepp_sk(GemmParams p, hipStream_t s) {
   else hipLaunchKernelGGL((gemm_mx_deepp8_kernel<C, 17, false, 0, true>), dim3(grid), dim3(C::THREADS), 0, s, p);
   return check_launch("gemm_mx_deepp_kernel (stream-K)");
 }
+#endif
 
 template <class C, bool NN = false, int NNABL = 0>
 int launch_gemm_deepp8(GemmParams p, hipStream_t s) {   // the fp8 twin (gemm_mx_deepp8), write-through output stores; NN: A is (K, M)
@@ -265,30 +268,14 @@ inline bool hetero_wins(int64_t T, int cus) {
   return b < a;
 }
 
-// [r4] Stream-K for T tiles of 256x256 (KTe K stages each) on `cus` CUs, or 0: the number of tiles at the end of the raster that are walked as one stream of
-// K stages cut into `cus` equal ranges (streamk.hip.h): the last full round + the remainder.  Needs caller scratch (sk_ws_bytes(cus)), more than one round
-// of tiles (a tile is then cut at most once) and a remainder.  It pays where balanced rounds / the heterogeneous launch leave CUs idle
-// for longer than the parked tiles cost: in units of one full-chip round, T / cus + ov / t_round against the models of hetero_wins below.
-inline int sk_tiles_for(int ebits, int64_t T, int64_t KTe, int cus) {
-  if (T % cus == 0 || T < cus || KTe < 8) return 0;   // (more than one round: every range is at least a tile long -- a tile is cut at most once, no range is empty)
-  const int64_t r = T / cus, rem = T % cus, R = r + 1;
-  const double bal = (double)R * std::max(0.45 + 0.55 * (double)T / (double)(R * cus), 0.78);
-  double het = 1e30;
-  if (r >= 1) {
-    const int64_t nsmall = 4 * rem, waves = nsmall / cus;
-    const double last = (double)(nsmall % cus) / (double)cus;
-    het = (double)r + 0.05 + 0.38 * (double)waves + (last > 0 ? 0.25 + 0.13 * last : 0.0);
-  }
-  const double t_round = (double)KTe * (ebits == 4 ? 1.85 : 1.55);   // us: a 256x256 tile with every CU busy
-  const double sk = (double)T / (double)cus + 4.0 / t_round;          // parked tiles: ~4 us of exposed stores / loads per launch
-  if (!(sk < 0.97 * std::min(bal, het))) return 0;
-  return (int)(cus + rem);
-}
-
 // Tile/schedule variants (0 = auto; the lab library can force one through the "gemm_variant" option):
 //   PRODUCT (what the auto rules below can pick):
 //     90  persistent deep schedule, 256x256 (fp4: gemm_mx_deepp, fp8: gemm_mx_deepp8)      lab: 30 = the per-tile deep schedule of round 1
-//     89  [r4] 90 as a stream-K walk (tiles of a part-filled round cut along K, fp32 parts parked in caller scratch)
+//   LAB only, [r4]:  89  = 90 as a stream-K walk (tiles of a part-filled round cut along K, fp32 parts parked in caller scratch).  Correct and
+//     deterministic (tests/test_gpu_round4.py) and NOT adopted: a cut tile moves 256 KiB of fp32 sums through memory twice, and a stream over G + T % G
+//     tiles cuts ~G - gcd tiles -- 128 ... 255 parked tiles = 64 ... 128 MB per launch at ~3.7 TB/s: +18 us at 384 tiles, +34 us at 320 (MXFP4,
+//     K = 4096: 74.8 / 86.1 us against 57.0 balanced / 48.2 heterogeneous); break-even only beyond K ~ 14336, where the heterogeneous launch still
+//     matches or beats it (MXFP8 3072 x 8192 x 28672: 612 us stream-K, 601 heterogeneous, 666 balanced).  profiles/ab_mxsk_r4c.txt
 //     98  heterogeneous launch: 90 over the full rounds + the residual tiles as 128x128 tiles in the same grid     lab: 99 = 3-deep ring for those
 //     24 / 25 / 27 / 28 / 29  pipelined schedule on a 2-deep ring: 128x128, 256x128 (8 waves), 128x64, 64x128, 64x64      58  256x128 on four waves, 3-deep ring
 //     70..73  ring schedule 64x64, 128x64, 64x128, 128x128 (+ split-K)          60  skinny split-K kernel (fp4, M <= 32)
@@ -384,7 +371,9 @@ int dispatch_variant(int v, const GemmParams& p, hipStream_t s, const char* name
 #endif
   }
   if constexpr (EBITS == 8) {
+#if QAMD_BENCH
     if (v == 89) return launch_gemm_deepp_sk<GemmCfg<256, 256, 2, 2, 8, true>>(p, s);
+#endif
     if (v == 90) return launch_gemm_deepp8<GemmCfg<256, 256, 2, 2, 8, true>>(p, s);   // persistent deep schedule, fp8
     if (v == 98) return launch_gemm_hetero<GemmCfg<256, 256, 2, 2, 8, true>, GemmCfg<128, 128, 2, 2, 8, true, 0, 4>, 17>(p, s);
 #if QAMD_BENCH
@@ -394,7 +383,9 @@ int dispatch_variant(int v, const GemmParams& p, hipStream_t s, const char* name
   if constexpr (EBITS == 4) {
     // persistent deep schedule; output stores write through (sc0 sc1): nothing dirty is left for the end-of-kernel L2
     // write-back (4096^3: 34.6 -> 33.4 .. 34.4 us, never slower; profiles/native_r2_store_policy.log)
+#if QAMD_BENCH
     if (v == 89) return launch_gemm_deepp_sk<GemmCfg<256, 256, 2, 2, 4, false>>(p, s);
+#endif
     if (v == 90) return launch_gemm_deepp<GemmCfg<256, 256, 2, 2, 4, false>, false, 17>(p, s);
     if (v == 98) return launch_gemm_hetero<GemmCfg<256, 256, 2, 2, 4, false>, GemmCfg<128, 128, 2, 2, 4, false, 0, 4>, 17>(p, s);
 #if QAMD_BENCH
@@ -796,10 +787,6 @@ int gemm_mx(const char* name, const void* A, const void* B, const void* A_sf, co
       if (two_launch) hetero_ok = false;
 #endif
       if (hetero_ok && hetero_wins(T, cus)) variant = 98;
-      // [r4] stream-K over the part-filled round (caller scratch: the _ws entries / the torch op): tiles cut along K, fp32 parts parked in the scratch
-      if (big == 90 && a_fmt == 0 && ws && ws_bytes >= sk_ws_bytes(cus) && (uintptr_t)ws % 16 == 0 && !(opt_pp_flags() & 64) && (K * EBITS / 8) % 256 == 0 &&
-          sk_tiles_for(EBITS, T, cdiv(K * EBITS / 8, 128), cus) > 0)
-        variant = 89;
     }
     else if (tiles(128, 128) >= want) {
       // [r3] half-chip outputs (fewer than `want` tiles of 256x256): with a long K (>= 32 stages) the 256x128 tile on four waves wins 5-6 %
@@ -816,7 +803,7 @@ int gemm_mx(const char* name, const void* A, const void* B, const void* A_sf, co
     else if (tiles(128, 64) >= want || tiles(64, 128) >= want) variant = (N >= M) ? 27 : 28;
     else variant = 29;
   }
-  if (variant == 89) {   // (auto, or forced in the lab build: falls back to the persistent kernel when the shape has nothing to cut or the scratch is missing)
+  if (variant == 89) {   // (lab: forced stream-K; falls back to the persistent kernel when the shape has nothing to cut or the scratch is missing)
     const int cus = chip_cus();
     const int64_t T = cdiv(M, 256) * cdiv(N, 256), KTe = (cdiv(K * EBITS / 8, 128) + 1) / 2 * 2;
     const bool ok = a_fmt == 0 && ws && ws_bytes >= sk_ws_bytes(cus) && (uintptr_t)ws % 16 == 0 && T % cus != 0 && T > cus && KTe >= 8 && (K * EBITS / 8) % 256 == 0 && ldd < (1ll << 22);
@@ -835,10 +822,11 @@ int gemm_mx(const char* name, const void* A, const void* B, const void* A_sf, co
 
 template <int R, bool NV, int METHOD, bool MASK, bool BLK>
 int launch_quant(const QuantParams& p, hipStream_t s, int grid) {
-  if (g_hw_fp4_cvt.load())
-    hipLaunchKernelGGL((fused_quantize_kernel<R, NV, METHOD, MASK, true, BLK>), dim3(grid), dim3(256), 0, s, p);
+#if QAMD_BENCH
+  if (!opt_hw_fp4()) hipLaunchKernelGGL((fused_quantize_kernel<R, NV, METHOD, MASK, false, BLK>), dim3(grid), dim3(256), 0, s, p);
   else
-    hipLaunchKernelGGL((fused_quantize_kernel<R, NV, METHOD, MASK, false, BLK>), dim3(grid), dim3(256), 0, s, p);
+#endif
+  hipLaunchKernelGGL((fused_quantize_kernel<R, NV, METHOD, MASK, true, BLK>), dim3(grid), dim3(256), 0, s, p);
   return check_launch("fused_quantize_kernel");
 }
 
@@ -920,13 +908,6 @@ int64_t qutlass_amd_gemm_splitk_workspace_bytes(int ebits, int64_t M, int64_t N,
   if (M <= 0 || N <= 0 || K <= 0 || (ebits != 4 && ebits != 8)) return 0;
   const SmallPlan pl = (ebits == 4) ? plan_small<4>(M, N, K) : plan_small<8>(M, N, K);
   int64_t need = (pl.variant && pl.splits > 1) ? splitk_ws_bytes(pl.variant, M, N, pl.splits) : 0;
-  // [r4] outputs the persistent 256x256 kernel takes (gemm_mx's auto rule) with a part-filled round that stream-K fills: a parked tile + flag per CU
-  if (!pl.variant && M > 128 && N > 64) {
-    const int cus = chip_cus();
-    const int64_t T = cdiv(M, 256) * cdiv(N, 256), KT = cdiv(K * ebits / 8, 128);
-    const bool big = T >= cus * 3 / 4 || (2 * T > cus && KT >= 8);
-    if (big && N < (1ll << 22) && (K * ebits / 8) % 256 == 0 && sk_tiles_for(ebits, T, KT, cus) > 0) need = std::max<int64_t>(need, sk_ws_bytes(cus));
-  }
 #if QAMD_BENCH
   if (opt_gemm_variant() == 89) need = std::max<int64_t>(need, sk_ws_bytes(chip_cus()));   // lab: forced stream-K
   if (opt_splitk_force() > 1) need = std::max<int64_t>(need, splitk_ws_bytes(70, M, N, 8));   // lab: room for any forced tile x split
@@ -1277,18 +1258,20 @@ int qutlass_amd_fused_quantize_matmul_mxf4_bf16_tn(const void* x, const void* h,
   p.x_bytes = (uint32_t)(M * K * 2); p.b_bytes = (uint32_t)(N * (K / 2)); p.sfb_bytes = (uint32_t)(cdiv(N, 128) * cdiv(K / 32, 4) * 512);
   const dim3 grid((unsigned)cdiv(N, 32), 1), block(512);
   hipStream_t s = (hipStream_t)stream;
-  const bool hw = g_hw_fp4_cvt.load() != 0;
+  const bool hw = opt_hw_fp4();
   // rows per rotation tile: the smallest of 4 / 8 / 16 / 32 that holds the batch (fewer rows = more scale groups per tile = fewer
   // rotate + quantize chains per K segment, gemm_mx_fusedq.hip.h)
   const int vr = M <= 4 ? 4 : M <= 8 ? 8 : M <= 16 ? 16 : 32;
 #define QAMD_FQ(METH_, HW_, VR_) hipLaunchKernelGGL((gemm_mx_fusedq_kernel<METH_, HW_, VR_>), grid, block, 0, s, p)
 #define QAMD_FQ_VR(METH_, HW_) \
   switch (vr) { case 4: QAMD_FQ(METH_, HW_, 4); break; case 8: QAMD_FQ(METH_, HW_, 8); break; case 16: QAMD_FQ(METH_, HW_, 16); break; default: QAMD_FQ(METH_, HW_, 32); }
-  if (method == QAMD_METHOD_ABSMAX) {
-    if (hw) { QAMD_FQ_VR(METHOD_ABSMAX, true) } else { QAMD_FQ_VR(METHOD_ABSMAX, false) }
-  } else {
-    if (hw) { QAMD_FQ_VR(METHOD_QUEST, true) } else { QAMD_FQ_VR(METHOD_QUEST, false) }
-  }
+#if QAMD_BENCH
+  if (!hw) {
+    if (method == QAMD_METHOD_ABSMAX) { QAMD_FQ_VR(METHOD_ABSMAX, false) } else { QAMD_FQ_VR(METHOD_QUEST, false) }
+  } else
+#endif
+  if (method == QAMD_METHOD_ABSMAX) { QAMD_FQ_VR(METHOD_ABSMAX, true) } else { QAMD_FQ_VR(METHOD_QUEST, true) }
+  (void)hw;
 #undef QAMD_FQ_VR
 #undef QAMD_FQ
   return check_launch("gemm_mx_fusedq_kernel");
@@ -1307,8 +1290,11 @@ int qutlass_amd_backward_t_bf16(const void* x, const void* h, int64_t B, int64_t
   if (B * (N / 32) * p.tiles_m >= (1ll << 31) - 65536) return fail(QAMD_ERR_INVALID, "%s: tensor too large", name);
   const int64_t ntw = B * p.tiles_m * cdiv(N / 32, 8);   // workgroup tiles: 8 scale groups (256 n) x 64 m
   const int grid = (int)std::min<int64_t>(ntw, chip_cus() * 2);   // several tiles per workgroup: the kernel prefetches the next tile
-  if (g_hw_fp4_cvt.load()) hipLaunchKernelGGL((bwd_quant_t_kernel<false, true>), dim3(grid), dim3(512), 0, (hipStream_t)stream, p);
-  else hipLaunchKernelGGL((bwd_quant_t_kernel<false, false>), dim3(grid), dim3(512), 0, (hipStream_t)stream, p);
+#if QAMD_BENCH
+  if (!opt_hw_fp4()) hipLaunchKernelGGL((bwd_quant_t_kernel<false, false>), dim3(grid), dim3(512), 0, (hipStream_t)stream, p);
+  else
+#endif
+  hipLaunchKernelGGL((bwd_quant_t_kernel<false, true>), dim3(grid), dim3(512), 0, (hipStream_t)stream, p);
   return check_launch("bwd_quant_t_kernel");
 }
 
@@ -1331,8 +1317,11 @@ int qutlass_amd_backward_qt_bf16(const void* x_e2m1, const void* x_e8m0, const v
   const int64_t cu = chip_cus();
   const int per_cu = 1.24 * (double)cdiv(ntw, 3 * cu) < (double)cdiv(ntw, 2 * cu) ? 3 : 2;
   const int grid = (int)std::max<int64_t>(32, std::min<int64_t>(cdiv(ntw, 32) * 32, cu * per_cu / 32 * 32));
-  if (g_hw_fp4_cvt.load()) hipLaunchKernelGGL((bwd_quant_t_kernel<true, true>), dim3(grid), dim3(512), 0, (hipStream_t)stream, p);
-  else hipLaunchKernelGGL((bwd_quant_t_kernel<true, false>), dim3(grid), dim3(512), 0, (hipStream_t)stream, p);
+#if QAMD_BENCH
+  if (!opt_hw_fp4()) hipLaunchKernelGGL((bwd_quant_t_kernel<true, false>), dim3(grid), dim3(512), 0, (hipStream_t)stream, p);
+  else
+#endif
+  hipLaunchKernelGGL((bwd_quant_t_kernel<true, true>), dim3(grid), dim3(512), 0, (hipStream_t)stream, p);
   return check_launch("bwd_quant_t_kernel");
 }
 
@@ -1469,13 +1458,14 @@ const char* qutlass_amd_version(void) { return "qutlass_amd 0.2.0 (gfx950, lab b
 const char* qutlass_amd_version(void) { return "qutlass_amd 0.2.0 (gfx950)"; }
 #endif
 
-// Product library: the only option is "hw_fp4_cvt" (hardware v_cvt_scalef32_pk_fp4_f32 vs the software encoder; both
-// produce the same bits, tests/test_gpu_parity.py).  Every other key -- in particular anything that would select a
-// kernel -- returns -1.  The lab library accepts the tuning / variant keys its benches use.
+// Product library: knows NO key (every call returns -1) -- nothing a caller or another thread does can change which kernel runs or what it computes.
+// The lab library accepts the tuning / variant keys its benches use, and "hw_fp4_cvt" (0 = the software e2m1 encoder, bit-identical to the hardware
+// convert the product ships: tests/test_gpu_parity.py runs the quantizer goldens under both through the lab build).
 int qutlass_amd_set_option(const char* key, int value) {
   if (!key) return -1;
-  if (!strcmp(key, "hw_fp4_cvt")) return g_hw_fp4_cvt.exchange(value);
+  (void)value;
 #if QAMD_BENCH
+  if (!strcmp(key, "hw_fp4_cvt")) return g_hw_fp4_cvt.exchange(value);
   if (!strcmp(key, "gemm_variant")) return g_gemm_variant.exchange(value);
   if (!strcmp(key, "nvf4_variant")) return g_nvf4_variant.exchange(value);
   if (!strcmp(key, "transpose_nc")) return g_transpose_nc.exchange(value);

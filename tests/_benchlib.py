@@ -31,6 +31,8 @@ _SIGS = {
     "qutlass_amd_nvf4_splitk_workspace_bytes": (_i64, [_i64, _i64, _i64]),
     "qutlass_amd_matmul_nvf4_bf16_tn_ws": (_i32, _GEMM[:-1] + [_vp, _i64, _vp]),
     "qutlass_amd_mxfp4_transpose_mxfp8": (_i32, [_vp, _vp, _i64, _i64, _vp, _vp, _vp]),
+    "qutlass_amd_fused_quantize_mx": (_i32, [_vp, _vp, _i32, _i64, _i32, _vp, _vp, _vp, _vp]),
+    "qutlass_amd_fused_quantize_matmul_mxf4_bf16_tn": (_i32, [_vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _vp]),
     "qutlass_amd_last_error": (ctypes.c_char_p, []),
     "qutlass_amd_version": (ctypes.c_char_p, []),
     "qutlass_amd_set_option": (_i32, [ctypes.c_char_p, _i32]),
@@ -137,3 +139,27 @@ def mxfp4_transpose_mxfp8(x_fp4, scales, m: int, n: int):
     sf = torch.empty(n, m // 32, dtype=torch.uint8, device=x_fp4.device)
     _check(load().qutlass_amd_mxfp4_transpose_mxfp8(_p(x_fp4), _p(scales), m, n, _p(y), _p(sf), _stream()))
     return y, sf
+
+
+def fused_quantize_mx(x, h, method: str = "quest", return_mask: bool = False):
+    """C-ABI call of the LAB build's fused rotate + quantize (the product op of the same name has no encoder switch): allocations as
+    qutlass_amd.fusedQuantizeMx (qutlass/__init__.py:149-180)."""
+    from qutlass_amd.utils import get_padded_shape_mx
+
+    rows, cols = get_padded_shape_mx(x)
+    e2m1 = torch.empty(*x.shape[:-1], x.size(-1) // 2, dtype=torch.uint8, device=x.device)
+    e8m0 = torch.empty(rows, cols, dtype=torch.float8_e8m0fnu, device=x.device)
+    mask = torch.empty(*x.shape[:-1], x.size(-1) // 8, dtype=torch.uint8, device=x.device) if return_mask else None
+    _check(load().qutlass_amd_fused_quantize_mx(_p(x), _p(h), h.size(0), x.numel(), {"quest": 0, "abs_max": 1}[method], _p(e2m1), _p(e8m0),
+                                               _p(mask) if return_mask else None, _stream()))
+    return (e2m1, e8m0, mask) if return_mask else (e2m1, e8m0)
+
+
+def fused_quantize_matmul_mxf4_bf16_tn(x, h, b, b_sf, alpha, method: str = "quest"):
+    """C-ABI call of the LAB build's one-launch decode path (M <= 32)."""
+    k = x.size(-1)
+    m, n = x.numel() // k, b.size(0)
+    out = torch.empty(m, n, dtype=torch.bfloat16, device=x.device)
+    _check(load().qutlass_amd_fused_quantize_matmul_mxf4_bf16_tn(_p(x), _p(h), h.size(0), {"quest": 0, "abs_max": 1}[method], _p(b), _p(b_sf), _p(alpha), _p(out),
+                                                                m, n, k, _stream()))
+    return out

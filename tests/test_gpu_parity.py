@@ -111,22 +111,29 @@ def _check_mx(q, x, h, method, mask, exact):
 
 @pytest.mark.parametrize("hw", [0, 1])
 def test_fused_quantize_mx_golden(q, golden_dir, hw):
-    q._lib.set_option("hw_fp4_cvt", hw)
+    """hw = 1: the product (torch op -> libqutlass_amd.so, hardware e2m1 convert -- the one encoder it ships).  hw = 0: the software encoder, kept in the
+    LAB build only ([r4]: the product library has no options any more), through the lab library's C ABI: both must reproduce the golden bytes."""
+    if hw:
+        quant = q.fusedQuantizeMx
+    else:
+        quant = lambda x, h, method, return_mask=False: lab.fused_quantize_mx(x, h, method, return_mask)
+        assert lab.set_option("hw_fp4_cvt", 0) == 1
     try:
         g = _load(golden_dir, "quantize_mx.npz")
         for c in range(int(g["ncases"])):
             R, quest = g[f"meta{c}"]
             x, h = _bf16(g[f"x{c}"]), _bf16(g[f"h{c}"])
-            e2m1, e8m0 = q.fusedQuantizeMx(x, h, method="quest" if quest else "abs_max")
+            e2m1, e8m0 = quant(x, h, method="quest" if quest else "abs_max")
             n = x.numel()
             assert np.array_equal(_np(e8m0).reshape(-1)[: n // 32], g[f"e8m0_{c}"].reshape(-1)), c
             eq = oracle.codes_equal_mod_zero_sign(_np(e2m1), g[f"e2m1_{c}"])
             assert eq.all(), (c, int((~eq).sum()))
             if quest and R == 32:
-                _, _, m = q.fusedQuantizeMx(x, h, method="quest", return_mask=True)
+                _, _, m = quant(x, h, method="quest", return_mask=True)
                 assert np.array_equal(_np(m).reshape(-1), g[f"mask{c}"].reshape(-1)), c
     finally:
-        q._lib.set_option("hw_fp4_cvt", 1)
+        lab.set_option("hw_fp4_cvt", 1)
+    assert q._lib.set_option("hw_fp4_cvt", 0) == -1   # the product library knows no key
 
 
 @pytest.mark.parametrize("rot", [32, 64, 128])

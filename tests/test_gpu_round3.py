@@ -331,14 +331,17 @@ def test_fused_quantize_matmul_decode_equals_three_launch_path(q, m, n, k, metho
     x_sf = to_blocked(x_s.view(torch.uint8).reshape(-1)[: m * k // 32].reshape(m, k // 32).view(torch.float8_e8m0fnu))
     want = q.matmul_mxf4_bf16_tn(x_q, w_q, x_sf, w_sf, alpha)
     for hw in (1, 0):
-        q._lib.set_option("hw_fp4_cvt", hw)
-        try:
+        if hw:   # the product
             got = q.fused_quantize_matmul_mxf4_bf16_tn(x, h, w_q, w_sf, alpha, method=method, single_launch=True)
             two = q.fused_quantize_matmul_mxf4_bf16_tn(x, h, w_q, w_sf, alpha, method=method, single_launch=False)   # blocked quantizer + GEMM
             auto = q.fused_quantize_matmul_mxf4_bf16_tn(x, h, w_q, w_sf, alpha, method=method)                      # the measured rule picks one
             assert torch.equal(two.view(torch.int16), want.view(torch.int16)) and torch.equal(auto.view(torch.int16), want.view(torch.int16))
-        finally:
-            q._lib.set_option("hw_fp4_cvt", 1)
+        else:    # the software e2m1 encoder ([r4] lab build only)
+            lab.set_option("hw_fp4_cvt", 0)
+            try:
+                got = lab.fused_quantize_matmul_mxf4_bf16_tn(x, h, w_q, w_sf, alpha, method=method)
+            finally:
+                lab.set_option("hw_fp4_cvt", 1)
         assert got.shape == (m, n) and got.dtype == torch.bfloat16
         assert torch.equal(got.view(torch.int16), want.view(torch.int16)), (hw, int((got.view(torch.int16) != want.view(torch.int16)).sum()))
     # ... and the oracle on the quantised bytes (exact regime: every partial sum is exact in fp32)

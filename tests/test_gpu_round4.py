@@ -197,7 +197,7 @@ def test_pipeline_on_a_second_device_and_a_side_stream(q, dev_index):
 
 
 # ------------------------------------------------------------------------------------------------
-# stream-K form of the MX persistent kernels (gemm_mx_deepp.hip.h, streamk.hip.h; variant 89)
+# stream-K form of the MX persistent kernels (gemm_mx_deepp.hip.h, streamk.hip.h; LAB variant 89: correct, deterministic, measured slower -- see capi.hip)
 # ------------------------------------------------------------------------------------------------
 def _rand_mx(m, n, k, seed, fp8=False):
     """random operands in the exact regime (block exponents within +-3): any K order gives the same fp32 sums for fp4"""
@@ -237,7 +237,7 @@ def test_stream_k_mxfp4_equals_persistent_kernel_and_oracle(q, m, n, k):
         one = lab.matmul_mxf4_bf16_tn(ad, bd, asf, bsf, alpha)
     assert torch.equal(sk.view(torch.int16), sk2.view(torch.int16))
     assert torch.equal(sk.view(torch.int16), one.view(torch.int16)), int((sk.view(torch.int16) != one.view(torch.int16)).sum())
-    got = q.matmul_mxf4_bf16_tn(ad, bd, asf, bsf, alpha)  # the product's own choice (torch op: scratch from the allocator)
+    got = q.matmul_mxf4_bf16_tn(ad, bd, asf, bsf, alpha)  # the product's own choice (balanced rounds or the heterogeneous launch)
     assert torch.equal(got.view(torch.int16), one.view(torch.int16))
     rows = sorted({0, 255, 256, m // 2, m - 257, m - 1})
     ref = _mx_rows(oracle.KIND_MXFP4, a, b, sa, sb, 0.5, rows, n, k)

@@ -2,6 +2,7 @@
 # ONE parametrised GPU session script (replaces the per-session tools/gpu_r*.sh of rounds 2-3):
 #     gpurun --timeout 1500 -- 'bash tools/gpu_session.sh <name> <step> [<step> ...]'
 # writes everything under gpurun_out/<name>/ and prints a one-line verdict per step.  Steps:
+#   testsk    the stream-K parity tests only, short timeout (a wrong flag protocol would hang)
 #   tests4    tests/test_gpu_round4.py (fail-fast)            suite     the whole -m gpu suite
 #   smoke     __graft_entry__.smoke()                         bench     bench.py (driver protocol) + a summary of its JSON line
 #   pmc       tools/pmc_bench.sh (kernel-trace + FETCH_SIZE / WRITE_SIZE passes of the bench command + a fresh-traffic bench line)
@@ -19,6 +20,7 @@ export TMPDIR=/tmp
 for step in "$@"; do
   t0=$(date +%s)
   case $step in
+    testsk) timeout 240 python -m pytest tests/test_gpu_round4.py -x -q -k stream_k > $O/pytest_streamk.log 2>&1; echo "testsk rc=$?"; tail -5 $O/pytest_streamk.log ;;
     tests4) timeout 900 python -m pytest tests/test_gpu_round4.py -x -q > $O/pytest_round4.log 2>&1; echo "tests4 rc=$?"; tail -3 $O/pytest_round4.log ;;
     suite)  timeout 1500 python -m pytest tests -m gpu -q > $O/pytest_gpu.log 2>&1; echo "suite rc=$?"; tail -3 $O/pytest_gpu.log ;;
     smoke)  timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; echo "smoke rc=$?"; tail -1 $O/smoke.log ;;
