@@ -179,6 +179,14 @@ int qutlass_amd_fused_quantize_nv_blocked(const void* x, const void* h, int rot,
                                           void* stream);
 
 /*
+ * EXTENSION: the measured launch-count rule of the activation path y = Q(x h) W^T of one linear layer (reference flow: qutlass/__init__.py:149-180 ->
+ * qutlass/utils.py:160-193 -> qutlass/__init__.py:34-76, three launches): returns 1 where the one-launch decode kernel below wins (M <= 16, R = 32, short K,
+ * a weight of fewer than 32 x CUs rows), else 2 (quantizer with GEMM-ready scales + GEMM).  Pure host arithmetic on the current device's CU count; what
+ * qutlass_amd.fused_quantize_matmul_mxf4_bf16_tn (Python) asks before it launches, so that a C caller gets the same rule.
+ */
+int qutlass_amd_activation_path_launches(int64_t M, int64_t N, int64_t K, int rot);
+
+/*
  * EXTENSION: the whole decode-time activation path in ONE launch, for batches of at most 32 rows:
  *     D[M,N] (bf16) = alpha[0] * Q(x . h) (B . SFB)^T
  * x: (M, K) bf16 activations, h: 32 x 32 bf16 rotation (rot must be 32), method as above; B / B_sf: the MXFP4 weight and its

@@ -143,24 +143,21 @@ def fusedQuantizeNvBlocked(a: torch.Tensor, b: torch.Tensor, global_scale: torch
 
 
 def _decode_single_launch_wins(m: int, n: int, k: int, rot: int) -> bool:
-    """Measured rule (profiles/ab_blocked_quant_r3.txt: N x K = 4096^2, 6144 x 4096, 4096 x 8192, 2048^2, 4096 x 14336, 14336 x 4096).  The
-    one-launch kernel repeats the rotate + quantize chains of its K slices in every workgroup -- ceil(K / 2048) x (1, 2, 4 for
-    M <= 4, 8, 16) chains per wave -- and beats the two launches (which cost ~3 us over the GEMM alone) while that stays short:
-        M <= 4: K <= 8192      M <= 8: K <= 6144      M <= 16: K <= 4096      (and a weight the small-batch GEMM handles: N < 8192)
-    M = 1 / 8 / 16 at N = K = 4096: 5.0 / 6.0 / 7.6 us against 7.2 / 7.9 / 8.3 us for two launches and 9.0 / 9.6 / 10.0 us for the
-    reference's three (GEMM alone 4.6 / 4.9 / 5.3 us); M = 32, or K = 14336, lose (14.2 vs 9.0 us, 12.7 vs 10.7 us)."""
-    if not (0 < m <= 16 and rot == 32 and n < 8192):
-        return False
-    return k <= (8192 if m <= 4 else 6144 if m <= 8 else 4096)
+    """The measured one-launch / two-launch rule of the activation path.  [r4] It lives in the C library now
+    (``qutlass_amd_activation_path_launches``, csrc/capi.hip: thresholds, measurements and the CU-count scaling are documented there), so
+    that a caller of the C ABI gets the same rule; this is the Python face of it."""
+    return _lib.load().qutlass_amd_activation_path_launches(int(m), int(n), int(k), int(rot)) == 1
 
 
 def fused_quantize_matmul_mxf4_bf16_tn(x: torch.Tensor, h: torch.Tensor, b: torch.Tensor, b_sf: torch.Tensor, alpha: torch.Tensor, *,
-                                       method: Literal["quest", "abs_max"] = "abs_max", single_launch: bool | None = None) -> torch.Tensor:
+                                       method: Literal["quest", "abs_max"] = "quest", single_launch: bool | None = None) -> torch.Tensor:
     """EXTENSION: ``matmul_mxf4_bf16_tn(*fusedQuantizeMx(x, h, method=method) -> to_blocked, b, b_sf, alpha)`` -- the activation path of
     one linear layer (qutlass/__init__.py:149-180 -> qutlass/utils.py:160-193 -> qutlass/__init__.py:34-76) in fewer launches, same bits:
       * TWO launches: the quantizer writes GEMM-ready scales (``fusedQuantizeMxBlocked``), then the GEMM;
       * ONE launch for decode batches (csrc/gemm_mx_fusedq.hip.h: the small-batch GEMM rotates and quantises its own A operand),
-        chosen where it measured faster (``_decode_single_launch_wins``); ``single_launch=True / False`` forces either."""
+        chosen where it measured faster (``qutlass_amd_activation_path_launches`` in the C library, calibrated on a 256-CU MI355X and scaled
+        with the CU count); ``single_launch=True / False`` forces either.
+    ``method`` defaults to ``"quest"`` like ``fusedQuantizeMx`` (qutlass/__init__.py:149): swapping the composed calls for this helper keeps the quantizer."""
     if method not in _METHOD_CODE:
         raise ValueError(f"invalid method {method!r}, must be 'quest' or 'abs_max'")
     k = x.size(-1)

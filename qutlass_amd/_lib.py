@@ -37,6 +37,7 @@ SYMBOLS = {
     "qutlass_amd_fused_quantize_mx_blocked": (_i32, [_vp, _vp, _i32, _i64, _i64, _i32, _vp, _vp, _vp, _vp]),
     "qutlass_amd_fused_quantize_nv_blocked": (_i32, [_vp, _vp, _i32, _i64, _i64, _i32, _vp, _vp, _vp, _vp]),
     "qutlass_amd_fused_quantize_matmul_mxf4_bf16_tn": (_i32, [_vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _vp]),
+    "qutlass_amd_activation_path_launches": (_i32, [_i64, _i64, _i64, _i32]),
     "qutlass_amd_to_blocked": (_i32, [_vp, _i64, _i64, _vp, _vp]),
     "qutlass_amd_backward_t_bf16": (_i32, [_vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp]),
     "qutlass_amd_backward_qt_bf16": (_i32, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp]),

@@ -1241,6 +1241,25 @@ int qutlass_amd_fused_quantize_nv_blocked(const void* x, const void* h, int rot,
   return fused_quantize_nv_impl(name, x, h, rot, rows * k, k, method, global_scale, out_e2m1, out_e4m3_blocked, stream);
 }
 
+// How many launches should the activation path y = Q(x h) W^T of one linear layer take (the rule behind qutlass_amd.fused_quantize_matmul_mxf4_bf16_tn;
+// reference flow: qutlass/__init__.py:149-180 -> qutlass/utils.py:160-193 -> qutlass/__init__.py:34-76 = three launches)?
+//   1  ONE launch, qutlass_amd_fused_quantize_matmul_mxf4_bf16_tn (gemm_mx_fusedq.hip.h: the small-batch GEMM rotates and quantises its own A operand).  It repeats
+//      the rotate + quantize chains of its K slices in every workgroup -- ceil(K / 2048) x (1, 2, 4 for M <= 4, 8, 16) chains per wave -- and wins while that stays
+//      short: M <= 4: K <= 8192, M <= 8: K <= 6144, M <= 16: K <= 4096, R = 32, and a weight the small-batch GEMM handles (N < 32 x CUs = 8192 on an MI355X).
+//      M = 1 / 8 / 16 at N = K = 4096: 5.0 / 6.0 / 7.6 us against 7.3 / 7.9 / 8.2 us for two launches and 9.0 / 9.5 / 9.9 for three (GEMM alone 4.6 / 4.9 / 5.3);
+//      M = 32 or K = 14336 lose (14.2 vs 9.0 us, 12.6 vs 10.7 us).
+//   2  TWO launches everywhere else: qutlass_amd_fused_quantize_mx_blocked (scales written in the to_blocked layout) + the GEMM.  The blocked quantizer costs
+//      0.2 ... 0.8 us more than the flat one and saves the 1.9 ... 3.2 us to_blocked launch: 2.2 vs 4.5 us at 256 x 4096, 7.3 vs 10.4 at 4096^2, 27.9 vs 31.4 at
+//      8192^2, 23.4 vs 26.5 at 4096 x 14336 -- device time, every size measured (profiles/ab_blocked_quant_r3y.txt); with the GEMM behind it: 4096 x 14336 x 4096
+//      123.2 vs 124.5 us (profiles/bench_r4c.json).  It never returns 3: the reference's three-launch flow stays available as fusedQuantizeMx + to_blocked + matmul.
+// Thresholds scale with the CU count of the current device.  No GPU work; the dry-run hook describes a 256-CU part.
+int qutlass_amd_activation_path_launches(int64_t M, int64_t N, int64_t K, int rot) {
+  if (M <= 0 || N <= 0 || K <= 0) return 2;
+  const int cus = chip_cus();
+  if (M > 16 || rot != 32 || N >= 32ll * cus || K % 128) return 2;
+  return K <= (M <= 4 ? 8192 : M <= 8 ? 6144 : 4096) ? 1 : 2;
+}
+
 // decode-time activation path in one launch (gemm_mx_fusedq.hip.h): D = alpha * Q(x . h) (B . SFB)^T for M <= 32
 int qutlass_amd_fused_quantize_matmul_mxf4_bf16_tn(const void* x, const void* h, int rot, int method, const void* B, const void* B_sf,
                                                    const float* alpha, void* D, int64_t M, int64_t N, int64_t K, void* stream) {

@@ -57,7 +57,14 @@ def main():
     dev = torch.device("cuda:0")
     which = "all"
     if "--shapes" in sys.argv: which = sys.argv[sys.argv.index("--shapes") + 1]
-    shapes = {"llama": LLAMA, "dip": DIP, "all": LLAMA + DIP}[which]
+    shapes = {"llama": LLAMA, "dip": DIP, "all": LLAMA + DIP, "prof": [(8192, 8192, 8192), (4096, 28672, 4096), (4096, 4096, 4096)]}[which]
+    if which == "prof":   # under rocprofv3: the product's own choice only, plain launches (tools/gpu_session.sh profnv)
+        alpha = torch.ones(1, device=dev)
+        for (m, n, k) in shapes:
+            (a, sa, _), (b, sb, _) = operands(m, n, k, dev)
+            for _ in range(60): q.matmul_nvf4_bf16_tn(a, b, sa, sb, alpha)
+            torch.cuda.synchronize()
+        return
     if "--trace" in sys.argv:
         for s in [(8192, 8192, 8192), (4096, 28672, 4096)]: trace(*s, dev)
     alpha = torch.ones(1, device=dev)
