@@ -363,8 +363,9 @@ def test_fused_quantize_matmul_wrapper_dispatch_and_errors(q):
     x = torch.randn(2, 8, k, dtype=torch.bfloat16, device=DEV)
     got = q.fused_quantize_matmul_mxf4_bf16_tn(x, h, w_q, w_sf, alpha, single_launch=True)
     assert torch.equal(got, q.fused_quantize_matmul_mxf4_bf16_tn(x, h, w_q, w_sf, alpha))
-    a_q, a_sf = q.fusedQuantizeMxBlocked(x, h, method="abs_max")
+    a_q, a_sf = q.fusedQuantizeMxBlocked(x, h)   # [r4] the helper's default method is fusedQuantizeMx's ("quest"), not "abs_max"
     want = q.matmul_mxf4_bf16_tn(a_q.view(-1, k // 2), w_q, a_sf, w_sf, alpha)
+    assert not torch.equal(got, q.fused_quantize_matmul_mxf4_bf16_tn(x, h, w_q, w_sf, alpha, method="abs_max"))
     assert got.shape == (2, 8, n) and torch.equal(got.view(-1, n).view(torch.int16), want.view(torch.int16))
     # M = 48: the default two-launch path, same bits as the reference flow (the one-launch kernel rejects M > 32, below)
     x2 = torch.randn(48, k, dtype=torch.bfloat16, device=DEV)
