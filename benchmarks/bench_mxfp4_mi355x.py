@@ -7,6 +7,9 @@ quantised linear layer vs batch size for the layer shapes of a model, three prov
     <fmt>-native-fused     [r3, --fused] the same result in fewer launches: fusedQuantize*Blocked + GEMM (two launches), and for MXFP4
                            batches of at most 32 rows ONE launch in which the small-batch GEMM quantises its own A operand
     <fmt>-native-noquant   the GEMM alone on pre-quantised activations ("ideal" provider of the reference)
+    mxfp4-vendor-noquant   [r4, --vendor, MXFP4 only] the vendor's block-scaled GEMM on the SAME pre-quantised operands: hipBLASLt through
+                           torch.nn.functional.scaled_mm (1x32 e8m0 blocks, row-major scales) -- the counterpart of the reference's cuDNN / flashinfer
+                           column (benchmarks/bench_mxfp4_sm100.py:27-31, 216-225).  A reported baseline; nothing in the package imports it.
 
 timed as HIP-graph replays (the reference uses triton.testing.do_bench_cudagraph; triton is not used here), median and
 20 / 80 % quantiles over `--reps` replays.  Prints one table per layer and writes CSVs under benchmarks_output/.
@@ -92,6 +95,7 @@ def main():
     ap.add_argument("--max-batch", type=int, default=65536)
     ap.add_argument("--quick", action="store_true", help="batch sizes 1, 16, 256, 4096 only, first two layers")
     ap.add_argument("--fused", action="store_true", help="add the <fmt>-native-fused provider (blocked-scale quantizer / one-launch decode path)")
+    ap.add_argument("--vendor", action="store_true", help="add the mxfp4-vendor-noquant provider (hipBLASLt block-scaled GEMM via torch scaled_mm)")
     ap.add_argument("--layers", type=int, default=0, help="only the first N layers of the model")
     args = ap.parse_args()
 
@@ -106,7 +110,9 @@ def main():
     nv = args.format == "nvfp4"
     quant = (lambda t: q.fusedQuantizeNv(t, h, gs)) if nv else (lambda t: q.fusedQuantizeMx(t, h, method="abs_max"))
     gemm = q.matmul_nvf4_bf16_tn if nv else q.matmul_mxf4_bf16_tn
-    providers = ["torch-bf16", f"{args.format}-native"] + ([f"{args.format}-native-fused"] if args.fused else []) + [f"{args.format}-native-noquant"]
+    vendor = args.vendor and not nv
+    providers = (["torch-bf16", f"{args.format}-native"] + ([f"{args.format}-native-fused"] if args.fused else []) + (["mxfp4-vendor-noquant"] if vendor else [])
+                 + [f"{args.format}-native-noquant"])
     if nv:
         fused = lambda t, wq, wsf: gemm(*(lambda aq, asf: (aq, wq, asf, wsf, alpha))(*q.fusedQuantizeNvBlocked(t, h, gs)))
     else:
@@ -137,10 +143,22 @@ def main():
             }
             if args.fused:
                 fns[providers[2]] = lambda: fused(a, w_q, w_sf)
+            if vendor:   # same e2m1 bytes, the quantizer's own row-major e8m0 scales (the vendor path takes them un-swizzled on ROCm)
+                import torch.nn.functional as F
+                A4, B4 = a_q.view(torch.float4_e2m1fn_x2), w_q.view(torch.float4_e2m1fn_x2)
+                sa_rm = a_s.view(torch.uint8)[:M, : K // 32].contiguous().view(torch.float8_e8m0fnu)
+                sb_rm = w_s.view(torch.uint8)[:N, : K // 32].contiguous().view(torch.float8_e8m0fnu)
+                fns["mxfp4-vendor-noquant"] = lambda: F.scaled_mm(A4, B4.t(), sa_rm, F.ScalingType.BlockWise1x32, sb_rm, F.ScalingType.BlockWise1x32,
+                                                                  F.SwizzleType.NO_SWIZZLE, F.SwizzleType.NO_SWIZZLE, None, torch.bfloat16)
             row = {"batch": M}
             cells = []
             for pname in providers:
-                ms, lo, hi = bench_graph(fns[pname], args.reps)
+                try:
+                    ms, lo, hi = bench_graph(fns[pname], args.reps)
+                except Exception as e:   # (the vendor path rejects some shapes: recorded as nan)
+                    if pname != "mxfp4-vendor-noquant":
+                        raise
+                    ms = lo = hi = float("nan")
                 tf = lambda t: 2.0 * M * N * K * 1e-12 / (t * 1e-3)
                 row[pname], row[pname + "_q20"], row[pname + "_q80"] = tf(ms), tf(hi), tf(lo)
                 cells.append(f"{tf(ms):10.1f} [{tf(hi):8.1f},{tf(lo):8.1f}]")
