@@ -60,6 +60,7 @@ std::atomic<int> g_pp_shift{2};
 std::atomic<int> g_pp_flags{1};
 std::atomic<int> g_quant_wg_per_cu{0};  // 0 = auto
 std::atomic<int> g_deepp_grid{0};       // lab: workgroups of the persistent deep kernels (0 = the balanced-rounds rule)
+std::atomic<int> g_bwd_variant{0};      // lab: 1 = the round-3 backward_t / backward_qt kernel (8 waves meeting at two barriers per tile) instead of the wave-owned-lines one
 std::atomic<int> g_splitk_force{0};     // lab: K splits for a FORCED ring variant ("gemm_variant" 70..73); 0 = the plan's
 std::atomic<uint32_t*> g_dbg{nullptr};
 #endif
@@ -91,7 +92,7 @@ unsigned long long next_launch_tag() {
 #else
 unsigned long long next_launch_tag();
 #if QAMD_BENCH
-extern std::atomic<int> g_hw_fp4_cvt, g_gemm_variant, g_nvf4_variant, g_splitk_wg, g_splitk_min_kt, g_transpose_nc, g_pp_shift, g_pp_flags, g_quant_wg_per_cu, g_splitk_force, g_deepp_grid;
+extern std::atomic<int> g_hw_fp4_cvt, g_gemm_variant, g_nvf4_variant, g_splitk_wg, g_splitk_min_kt, g_transpose_nc, g_pp_shift, g_pp_flags, g_quant_wg_per_cu, g_splitk_force, g_deepp_grid, g_bwd_variant;
 extern std::atomic<uint32_t*> g_dbg;
 #endif
 int fail(int code, const char* fmt, ...);
@@ -112,6 +113,7 @@ inline int opt_pp_flags() { return g_pp_flags.load(); }
 inline int opt_quant_wg_per_cu() { return g_quant_wg_per_cu.load(); }
 inline int opt_splitk_force() { return g_splitk_force.load(); }
 inline int opt_deepp_grid() { return g_deepp_grid.load(); }
+inline int opt_bwd_variant() { return g_bwd_variant.load(); }
 inline uint32_t* opt_dbg() { return g_dbg.load(); }
 #else
 constexpr bool opt_hw_fp4() { return true; }   // the product ships ONE e2m1 encoder: the hardware convert
@@ -125,6 +127,7 @@ constexpr int opt_pp_flags() { return 1; }
 constexpr int opt_quant_wg_per_cu() { return 0; }
 constexpr int opt_splitk_force() { return 0; }
 constexpr int opt_deepp_grid() { return 0; }
+constexpr int opt_bwd_variant() { return 0; }
 constexpr uint32_t* opt_dbg() { return nullptr; }
 #endif
 
@@ -1307,14 +1310,23 @@ int qutlass_amd_backward_t_bf16(const void* x, const void* h, int64_t B, int64_t
   p.x = (const uint16_t*)x; p.h = (const uint16_t*)h; p.out = (uint8_t*)out_e2m1; p.out_sf = (uint8_t*)out_e8m0;
   p.B = (int)B; p.N = (int)N; p.M = (int)M; p.tiles_m = (int)cdiv(M, 64);
   if (B * (N / 32) * p.tiles_m >= (1ll << 31) - 65536) return fail(QAMD_ERR_INVALID, "%s: tensor too large", name);
-  const int64_t ntw = B * p.tiles_m * cdiv(N / 32, 8);   // workgroup tiles: 8 scale groups (256 n) x 64 m
-  const int grid = (int)std::min<int64_t>(ntw, chip_cus() * 2);   // several tiles per workgroup: the kernel prefetches the next tile
+  const int64_t ntw = B * p.tiles_m * cdiv(N / 32, 8);   // units: 8 scale groups (256 n) x 64 m = 64 whole output lines
 #if QAMD_BENCH
-  if (!opt_hw_fp4()) hipLaunchKernelGGL((bwd_quant_t_kernel<false, false>), dim3(grid), dim3(512), 0, (hipStream_t)stream, p);
+  if (opt_bwd_variant() == 1) {   // lab: the round-3 kernel (one unit per workgroup of 8 waves, two barriers per tile)
+    const int grid = (int)std::min<int64_t>(ntw, chip_cus() * 2);
+    if (!opt_hw_fp4()) hipLaunchKernelGGL((bwd_quant_t_kernel<false, false>), dim3(grid), dim3(512), 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL((bwd_quant_t_kernel<false, true>), dim3(grid), dim3(512), 0, (hipStream_t)stream, p);
+    return check_launch("bwd_quant_t_kernel");
+  }
+#endif
+  // [r4] wave-owned output lines (bwd_quant_tw_kernel): a unit per WAVE, four waves per workgroup, 66 KB of LDS -> two workgroups per CU
+  const int gridw = (int)std::min<int64_t>(cdiv(ntw, 4), chip_cus() * 2);
+#if QAMD_BENCH
+  if (!opt_hw_fp4()) hipLaunchKernelGGL((bwd_quant_tw_kernel<false, false>), dim3(gridw), dim3(256), 0, (hipStream_t)stream, p);
   else
 #endif
-  hipLaunchKernelGGL((bwd_quant_t_kernel<false, true>), dim3(grid), dim3(512), 0, (hipStream_t)stream, p);
-  return check_launch("bwd_quant_t_kernel");
+  hipLaunchKernelGGL((bwd_quant_tw_kernel<false, true>), dim3(gridw), dim3(256), 0, (hipStream_t)stream, p);
+  return check_launch("bwd_quant_tw_kernel");
 }
 
 int qutlass_amd_backward_qt_bf16(const void* x_e2m1, const void* x_e8m0, const void* h, const float* alpha, int64_t B,
@@ -1337,11 +1349,21 @@ int qutlass_amd_backward_qt_bf16(const void* x_e2m1, const void* x_e8m0, const v
   const int per_cu = 1.24 * (double)cdiv(ntw, 3 * cu) < (double)cdiv(ntw, 2 * cu) ? 3 : 2;
   const int grid = (int)std::max<int64_t>(32, std::min<int64_t>(cdiv(ntw, 32) * 32, cu * per_cu / 32 * 32));
 #if QAMD_BENCH
-  if (!opt_hw_fp4()) hipLaunchKernelGGL((bwd_quant_t_kernel<true, false>), dim3(grid), dim3(512), 0, (hipStream_t)stream, p);
+  if (opt_bwd_variant() == 1) {   // lab: the round-3 kernel
+    if (!opt_hw_fp4()) hipLaunchKernelGGL((bwd_quant_t_kernel<true, false>), dim3(grid), dim3(512), 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL((bwd_quant_t_kernel<true, true>), dim3(grid), dim3(512), 0, (hipStream_t)stream, p);
+    return check_launch("bwd_quant_t_kernel");
+  }
+#endif
+  (void)grid;
+  // [r4] wave-owned output lines: the four waves of a workgroup take four consecutive m-tiles -- the siblings that share QT's 128-byte input lines
+  const int gridw = (int)std::min<int64_t>(cdiv(B * p.tiles_m * cdiv(N / 32, 8), 4), cu * 2);
+#if QAMD_BENCH
+  if (!opt_hw_fp4()) hipLaunchKernelGGL((bwd_quant_tw_kernel<true, false>), dim3(gridw), dim3(256), 0, (hipStream_t)stream, p);
   else
 #endif
-  hipLaunchKernelGGL((bwd_quant_t_kernel<true, true>), dim3(grid), dim3(512), 0, (hipStream_t)stream, p);
-  return check_launch("bwd_quant_t_kernel");
+  hipLaunchKernelGGL((bwd_quant_tw_kernel<true, true>), dim3(gridw), dim3(256), 0, (hipStream_t)stream, p);
+  return check_launch("bwd_quant_tw_kernel");
 }
 
 int qutlass_amd_backward_bf16_square_double_mxfp8_rows(const void* x, int64_t m, int64_t m_pad, int64_t n, void* y, void* row_scales,
@@ -1492,6 +1514,7 @@ int qutlass_amd_set_option(const char* key, int value) {
   if (!strcmp(key, "splitk_min_kt")) return g_splitk_min_kt.exchange(value);
   if (!strcmp(key, "splitk_force")) return g_splitk_force.exchange(value);
   if (!strcmp(key, "deepp_grid")) return g_deepp_grid.exchange(value);
+  if (!strcmp(key, "bwd_variant")) return g_bwd_variant.exchange(value);
   if (!strcmp(key, "quant_wg_per_cu")) return g_quant_wg_per_cu.exchange(value);
   if (!strcmp(key, "pp_shift")) return g_pp_shift.exchange(value);
   if (!strcmp(key, "pp_flags")) return g_pp_flags.exchange(value);

@@ -32,6 +32,8 @@ _SIGS = {
     "qutlass_amd_matmul_nvf4_bf16_tn_ws": (_i32, _GEMM[:-1] + [_vp, _i64, _vp]),
     "qutlass_amd_mxfp4_transpose_mxfp8": (_i32, [_vp, _vp, _i64, _i64, _vp, _vp, _vp]),
     "qutlass_amd_fused_quantize_mx": (_i32, [_vp, _vp, _i32, _i64, _i32, _vp, _vp, _vp, _vp]),
+    "qutlass_amd_backward_t_bf16": (_i32, [_vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp]),
+    "qutlass_amd_backward_qt_bf16": (_i32, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp]),
     "qutlass_amd_fused_quantize_matmul_mxf4_bf16_tn": (_i32, [_vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _vp]),
     "qutlass_amd_last_error": (ctypes.c_char_p, []),
     "qutlass_amd_version": (ctypes.c_char_p, []),
@@ -163,3 +165,22 @@ def fused_quantize_matmul_mxf4_bf16_tn(x, h, b, b_sf, alpha, method: str = "ques
     _check(load().qutlass_amd_fused_quantize_matmul_mxf4_bf16_tn(_p(x), _p(h), h.size(0), {"quest": 0, "abs_max": 1}[method], _p(b), _p(b_sf), _p(alpha), _p(out),
                                                                 m, n, k, _stream()))
     return out
+
+
+def backward_t_bf16(x, h):
+    """C-ABI call of the LAB build (x: (B, N, M) bf16): e2m1 (B, M, N/2) + e8m0 (B, M, N/32)."""
+    B, N, M = (1, *x.shape) if x.dim() == 2 else x.shape
+    q = torch.empty(B, M, N // 2, dtype=torch.uint8, device=x.device)
+    sf = torch.empty(B, M, N // 32, dtype=torch.uint8, device=x.device)
+    _check(load().qutlass_amd_backward_t_bf16(_p(x), _p(h), B, N, M, _p(q), _p(sf), _stream()))
+    return q, sf
+
+
+def backward_qt_bf16(xq, xs, h, alpha):
+    """C-ABI call of the LAB build (xq: (B, N, M/2) e2m1 bytes, xs: (B, N, M/32) e8m0)."""
+    B, N, M2 = (1, *xq.shape) if xq.dim() == 2 else xq.shape
+    M = M2 * 2
+    q = torch.empty(B, M, N // 2, dtype=torch.uint8, device=xq.device)
+    sf = torch.empty(B, M, N // 32, dtype=torch.uint8, device=xq.device)
+    _check(load().qutlass_amd_backward_qt_bf16(_p(xq), _p(xs), _p(h), _p(alpha), B, N, M, _p(q), _p(sf), _stream()))
+    return q, sf

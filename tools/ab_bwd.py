@@ -1,0 +1,58 @@
+"""backward_t_bf16 / backward_qt_bf16: the wave-owned-lines kernel (bwd_quant_tw_kernel, [r4]) against the round-3 kernel (lab option bwd_variant = 1), one box,
+interleaved, GPU-only timing (HIP-graph replays), warm (one input) and cold (inputs rotated through > 256 MB so the MALL does not hold them); also checks that
+both kernels return the same bytes.      python tools/ab_bwd.py > gpurun_out/ab_bwd.txt"""
+import os, sys
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tools"))
+import _benchlib as lab
+from _timing import graph_us
+
+
+def hadamard(n, dev):
+    h = torch.ones(1, 1)
+    while h.shape[0] < n:
+        h = torch.cat([torch.cat([h, h], 1), torch.cat([h, -h], 1)], 0)
+    return (h * n ** -0.5).to(torch.bfloat16).to(dev)
+
+
+def main():
+    dev = torch.device("cuda:0")
+    h = hadamard(32, dev)
+    alpha = torch.tensor([0.75], device=dev)
+    print("%-28s %6s | %9s %9s %7s | %9s %9s %7s | bytes moved -> new cold TB/s, frac of 8   same" % ("op  (N x M)", "", "old warm", "new warm", "ratio", "old cold", "new cold", "ratio"))
+    for (n, m) in [(4096, 4096), (8192, 8192), (2048, 14336), (8192, 1024)]:
+        for op in ("t", "qt"):
+            nbuf = max(2, int(300e6 / (n * m * (2 if op == "t" else 0.53))) + 1)
+            if op == "t":
+                xs = [torch.randn(n, m, dtype=torch.bfloat16, device=dev) * 3 for _ in range(nbuf)]
+                calls = [(lambda x=x: lab.backward_t_bf16(x, h)) for x in xs]
+                nbytes = n * m * 2 + n * m // 2 + n * m // 32
+            else:
+                g = torch.Generator(device=dev).manual_seed(1)
+                qs = [torch.randint(0, 256, (n, m // 2), dtype=torch.uint8, device=dev, generator=g) for _ in range(nbuf)]
+                ss = [torch.randint(120, 132, (n, m // 32), dtype=torch.uint8, device=dev, generator=g) for _ in range(nbuf)]
+                calls = [(lambda a=a, b=b: lab.backward_qt_bf16(a, b, h, alpha)) for a, b in zip(qs, ss)]
+                nbytes = 2 * (n * m // 2 + n * m // 32)
+            outs = {}
+            t = {}
+            for v in (1, 0):
+                with lab.forced(bwd_variant=v):
+                    outs[v] = calls[0]()
+            same = all(torch.equal(a, b) for a, b in zip(outs[0], outs[1]))
+            state = {"i": 0}
+            def cold():
+                state["i"] = (state["i"] + 1) % nbuf
+                return calls[state["i"]]()
+            for rnd in range(2):
+                for v in (1, 0):
+                    with lab.forced(bwd_variant=v):
+                        t[(v, "w")] = min(t.get((v, "w"), 1e9), graph_us(calls[0], n=20))
+                        t[(v, "c")] = min(t.get((v, "c"), 1e9), graph_us(cold, n=2 * nbuf))
+            tb = nbytes / t[(0, "c")] * 1e-6
+            print("%-28s %6s | %9.2f %9.2f %7.3f | %9.2f %9.2f %7.3f | %6.1f MB -> %5.2f TB/s, %.2f   %s" % (f"backward_{op}_bf16 {n}x{m}", "", t[(1, "w")], t[(0, "w")], t[(0, "w")] / t[(1, "w")],
+                  t[(1, "c")], t[(0, "c")], t[(0, "c")] / t[(1, "c")], nbytes / 1e6, tb, tb / 8.0, same), flush=True)
+            del calls
+
+
+main()

@@ -12,6 +12,7 @@
 #   dip       tools/dip_scan.py (8 % threshold)               sweeps    benchmarks/bench_mxfp4_mi355x.py for MXFP4 (fused) and NVFP4, Llama-3-8B
 #   configs   bench_configs.py                                abmx      tools/ab_mxsk.py (MX persistent kernels: balanced / heterogeneous / stream-K)
 #   calibnv   tools/calib_tiles.py nvf4 (forced tile candidates on the training grid of the NVFP4 tile rule)
+#   abbwd     tools/ab_bwd.py (backward_t / backward_qt: wave-owned-lines kernel vs the round-3 kernel)     testbwd   the GPU tests of the QAT-backward ops
 #   stream    tools/ab_stream_ops.py-style timing of the streaming ops (bench_configs.py --only stream)
 cd ${GRAFT_REPO_ROOT:-.}
 NAME=${1:?session name}; shift
@@ -45,6 +46,8 @@ PY
             cat $O/bench_sweep_nvfp4_Llama-3-8B.txt ;;
     configs) timeout 900 python bench_configs.py > $O/bench_configs.jsonl 2> $O/bench_configs.err; echo "configs rc=$?"; tail -30 $O/bench_configs.jsonl | cut -c1-240 ;;
     calibnv) timeout 900 python tools/calib_tiles.py nvf4 > $O/calib_tiles_nvf4.txt 2> $O/calib_tiles_nvf4.err; echo "calibnv rc=$?"; tail -5 $O/calib_tiles_nvf4.txt ;;
+    abbwd)  timeout 600 python tools/ab_bwd.py > $O/ab_bwd.txt 2> $O/ab_bwd.err; echo "abbwd rc=$?"; cat $O/ab_bwd.txt; tail -3 $O/ab_bwd.err ;;
+    testbwd) timeout 600 python -m pytest tests -m gpu -q -k "backward or quartet or bwd" > $O/pytest_bwd.log 2>&1; echo "testbwd rc=$?"; tail -4 $O/pytest_bwd.log ;;
     abmx)   timeout 900 python tools/ab_mxsk.py > $O/ab_mxsk.txt 2> $O/ab_mxsk.err; echo "abmx rc=$?"; cat $O/ab_mxsk.txt; tail -3 $O/ab_mxsk.err ;;
     *) echo "unknown step $step" ;;
   esac
