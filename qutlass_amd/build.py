@@ -42,7 +42,7 @@ def needs_build() -> bool:
 
 UNITS = [1, 2, 3, 4, 5, 8]              # translation units of csrc/capi.hip in the product build (QAMD_TU values; see the top of that file)
 UNITS_BENCH = [1, 2, 3, 4, 5, 6, 7, 8]  # the lab build adds the ablation units 6 and 7
-# Per-unit compiler flags.  Unit 5 holds the fused_quantize_kernel family and nothing else: its rotation MFMAs take their
+# Per-unit compiler flags.  Unit 5 holds the rotation quantizers (fused_quantize_kernel family, backward_t / backward_qt) and nothing else: their rotation MFMAs take their
 # accumulators in VGPRs -- LLVM's default put them in AGPRs and copied all 16 back with v_accvgpr_read_b32 per 1024-element tile,
 # a fifth of the VALU instructions of a kernel that is VALU-issue-bound at R = 32.  The GEMM units must keep
 # the AGPR form (256 accumulator registers per lane), so this is not a global flag; a QAMD_SINGLE_TU build goes without it.

@@ -870,6 +870,36 @@ QAMD_ROT_BOTH(true, METHOD_ABSMAX, false)
 #undef QAMD_ROT_INST
 #endif
 
+// backward_t_bf16 / backward_qt_bf16 kernels live in unit 5 with the other rotation quantizers (MFMA results straight in VGPRs: a
+// v_accvgpr_read per accumulator register is 32 more VALU issues per tile)
+//   which: 1 = the round-3 kernel (8 waves per unit of 8 groups x 64 m, two barriers per unit); 2 = wave-owned 64-byte segments (units of 4
+//   groups, 12 - 16 waves per CU); 3 = wave-owned 128-byte lines (units of 8 groups, 8 waves per CU).  Product: QT 2, T 3 (bwd_kernel_choice).
+int launch_bwd_quant(const BwdTParams& p, bool qt, int which, bool hw, int grid, hipStream_t s);
+#if QAMD_DEF(5)
+int launch_bwd_quant(const BwdTParams& p, bool qt, int which, bool hw, int grid, hipStream_t s) {
+#define QAMD_BWD_GO(KERN, THREADS) hipLaunchKernelGGL((KERN), dim3(grid), dim3(THREADS), 0, s, p)
+  if (which == 1) {
+#if QAMD_BENCH
+    if (!hw) { if (qt) QAMD_BWD_GO((bwd_quant_t_kernel<true, false>), 512); else QAMD_BWD_GO((bwd_quant_t_kernel<false, false>), 512); return check_launch("bwd_quant_t_kernel"); }
+#endif
+    if (qt) QAMD_BWD_GO((bwd_quant_t_kernel<true, true>), 512); else QAMD_BWD_GO((bwd_quant_t_kernel<false, true>), 512);
+    return check_launch("bwd_quant_t_kernel");
+  }
+#if QAMD_BENCH
+  if (!hw) {
+    if (which == 3) { if (qt) QAMD_BWD_GO((bwd_quant_tw_kernel<true, false, 8>), 256); else QAMD_BWD_GO((bwd_quant_tw_kernel<false, false, 8>), 256); }
+    else            { if (qt) QAMD_BWD_GO((bwd_quant_tw_kernel<true, false, 4>), 256); else QAMD_BWD_GO((bwd_quant_tw_kernel<false, false, 4>), 256); }
+    return check_launch("bwd_quant_tw_kernel");
+  }
+  if (qt && which == 3) { QAMD_BWD_GO((bwd_quant_tw_kernel<true, true, 8>), 256); return check_launch("bwd_quant_tw_kernel"); }
+  if (!qt && which == 2) { QAMD_BWD_GO((bwd_quant_tw_kernel<false, true, 4>), 256); return check_launch("bwd_quant_tw_kernel"); }
+#endif
+  if (qt) QAMD_BWD_GO((bwd_quant_tw_kernel<true, true, 4>), 256); else QAMD_BWD_GO((bwd_quant_tw_kernel<false, true, 8>), 256);
+#undef QAMD_BWD_GO
+  return check_launch("bwd_quant_tw_kernel");
+}
+#endif
+
 #if QAMD_DEF(1)
 int quant_grid(int ntiles, int rot) {
   // 4 waves per workgroup, one 32-row tile per wave per trip.  Small rotations are pure streaming: as many waves as
@@ -1299,6 +1329,19 @@ int qutlass_amd_fused_quantize_matmul_mxf4_bf16_tn(const void* x, const void* h,
   return check_launch("gemm_mx_fusedq_kernel");
 }
 
+// which backward_t / backward_qt kernel (see launch_bwd_quant), from the A/B on one box (profiles/ab_bwd_r4k_variants.txt; nu = units of 8 groups x
+// 64 m): the wave-owned kernels need a few units per wave to amortise their pipeline fill, below that the round-3 kernel (8 waves share a unit)
+// stays.  QT: 64-byte segments with 16 waves per CU (4096^2 cold 10.2 -> 8.5 us, 8192^2 30.9 -> 26.6); T: whole lines with 8 waves per CU
+// (8192^2 cold 38.0 -> 36.5, 2048 x 14336 17.7 -> 15.2; the 64-byte form ties with the round-3 kernel there).  In the product build the product
+// kernels are the only instantiations: QT never takes 3, T never 2.  Lab: option "bwd_variant" (low 4 bits) forces 1 / 2 / 3.
+static int bwd_kernel_choice(bool qt, int64_t nu) {
+  const int v = opt_bwd_variant() & 15;
+  if (v >= 1 && v <= 3) return v;
+  const int64_t cu = chip_cus();
+  if (qt) return nu >= 3 * cu ? 2 : 1;
+  return nu >= 6 * cu ? 3 : 1;
+}
+
 int qutlass_amd_backward_t_bf16(const void* x, const void* h, int64_t B, int64_t N, int64_t M, void* out_e2m1,
                                 void* out_e8m0, void* stream) {
   const char* name = "backward_t_bf16";
@@ -1311,22 +1354,11 @@ int qutlass_amd_backward_t_bf16(const void* x, const void* h, int64_t B, int64_t
   p.B = (int)B; p.N = (int)N; p.M = (int)M; p.tiles_m = (int)cdiv(M, 64);
   if (B * (N / 32) * p.tiles_m >= (1ll << 31) - 65536) return fail(QAMD_ERR_INVALID, "%s: tensor too large", name);
   const int64_t ntw = B * p.tiles_m * cdiv(N / 32, 8);   // units: 8 scale groups (256 n) x 64 m = 64 whole output lines
-#if QAMD_BENCH
-  if (opt_bwd_variant() == 1) {   // lab: the round-3 kernel (one unit per workgroup of 8 waves, two barriers per tile)
-    const int grid = (int)std::min<int64_t>(ntw, chip_cus() * 2);
-    if (!opt_hw_fp4()) hipLaunchKernelGGL((bwd_quant_t_kernel<false, false>), dim3(grid), dim3(512), 0, (hipStream_t)stream, p);
-    else hipLaunchKernelGGL((bwd_quant_t_kernel<false, true>), dim3(grid), dim3(512), 0, (hipStream_t)stream, p);
-    return check_launch("bwd_quant_t_kernel");
-  }
-#endif
-  // [r4] wave-owned output lines (bwd_quant_tw_kernel): a unit per WAVE, four waves per workgroup, 66 KB of LDS -> two workgroups per CU
-  const int gridw = (int)std::min<int64_t>(cdiv(ntw, 4), chip_cus() * 2);
-#if QAMD_BENCH
-  if (!opt_hw_fp4()) hipLaunchKernelGGL((bwd_quant_tw_kernel<false, false>), dim3(gridw), dim3(256), 0, (hipStream_t)stream, p);
-  else
-#endif
-  hipLaunchKernelGGL((bwd_quant_tw_kernel<false, true>), dim3(gridw), dim3(256), 0, (hipStream_t)stream, p);
-  return check_launch("bwd_quant_tw_kernel");
+  const int which = bwd_kernel_choice(false, ntw);
+  p.abl = opt_bwd_variant() >> 4;
+  const int64_t nuw = B * p.tiles_m * cdiv(N / 32, which == 3 ? 8 : 4);   // wave units
+  const int grid = which == 1 ? (int)std::min<int64_t>(ntw, chip_cus() * 2) : (int)std::min<int64_t>(cdiv(nuw, 4), chip_cus() * (which == 3 ? 2 : 3));
+  return launch_bwd_quant(p, false, which, opt_hw_fp4(), grid, (hipStream_t)stream);
 }
 
 int qutlass_amd_backward_qt_bf16(const void* x_e2m1, const void* x_e8m0, const void* h, const float* alpha, int64_t B,
@@ -1348,22 +1380,13 @@ int qutlass_amd_backward_qt_bf16(const void* x_e2m1, const void* x_e8m0, const v
   const int64_t cu = chip_cus();
   const int per_cu = 1.24 * (double)cdiv(ntw, 3 * cu) < (double)cdiv(ntw, 2 * cu) ? 3 : 2;
   const int grid = (int)std::max<int64_t>(32, std::min<int64_t>(cdiv(ntw, 32) * 32, cu * per_cu / 32 * 32));
-#if QAMD_BENCH
-  if (opt_bwd_variant() == 1) {   // lab: the round-3 kernel
-    if (!opt_hw_fp4()) hipLaunchKernelGGL((bwd_quant_t_kernel<true, false>), dim3(grid), dim3(512), 0, (hipStream_t)stream, p);
-    else hipLaunchKernelGGL((bwd_quant_t_kernel<true, true>), dim3(grid), dim3(512), 0, (hipStream_t)stream, p);
-    return check_launch("bwd_quant_t_kernel");
-  }
-#endif
-  (void)grid;
-  // [r4] wave-owned output lines: the four waves of a workgroup take four consecutive m-tiles -- the siblings that share QT's 128-byte input lines
-  const int gridw = (int)std::min<int64_t>(cdiv(B * p.tiles_m * cdiv(N / 32, 8), 4), cu * 2);
-#if QAMD_BENCH
-  if (!opt_hw_fp4()) hipLaunchKernelGGL((bwd_quant_tw_kernel<true, false>), dim3(gridw), dim3(256), 0, (hipStream_t)stream, p);
-  else
-#endif
-  hipLaunchKernelGGL((bwd_quant_tw_kernel<true, true>), dim3(gridw), dim3(256), 0, (hipStream_t)stream, p);
-  return check_launch("bwd_quant_tw_kernel");
+  // [r4] wave-owned output segments: the four waves of a workgroup take four consecutive m-tiles -- the siblings that share QT's 128-byte input lines
+  const int64_t nu = B * p.tiles_m * cdiv(N / 32, 8);
+  const int which = bwd_kernel_choice(true, nu);
+  p.abl = opt_bwd_variant() >> 4;
+  const int64_t nuw = B * p.tiles_m * cdiv(N / 32, which == 3 ? 8 : 4);
+  const int gridw = (int)std::min<int64_t>(cdiv(nuw, 4), cu * (which == 3 ? 2 : 4));
+  return launch_bwd_quant(p, true, which, opt_hw_fp4(), which == 1 ? grid : gridw, (hipStream_t)stream);
 }
 
 int qutlass_amd_backward_bf16_square_double_mxfp8_rows(const void* x, int64_t m, int64_t m_pad, int64_t n, void* y, void* row_scales,

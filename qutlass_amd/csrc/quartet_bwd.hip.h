@@ -33,7 +33,13 @@ struct BwdTParams {
   uint8_t* out_sf;          // e8m0 (B, M, N/32)
   int B, N, M;
   int tiles_m;              // ceil(M / 64); B * (N/32) * tiles_m < 2^31 (host-checked): the kernel indexes tiles in 32 bits
+  int abl;                  // lab build only (bwd_quant_tw_kernel): leave out 1 = the global loads, 2 = the unit stores, 4 = MFMA + quantisation, 8 = staging
 };
+#if QAMD_BENCH
+#define QAMD_BWD_ABL(b) (p.abl & (b))
+#else
+#define QAMD_BWD_ABL(b) false
+#endif
 
 // One wave = one [32 n][64 m] tile = one scale group for 64 output rows; the 8 waves of a workgroup take 8 consecutive
 // scale groups (n0 .. n0 + 255) of the SAME 64 rows m, so the workgroup's output is one whole 128-byte line of e2m1 and
@@ -297,22 +303,22 @@ __global__ __launch_bounds__(512) void bwd_quant_t_kernel(const BwdTParams p) {
 // ----------------------------------------------------------------------------------------------------------------
 // [r4] bwd_quant_tw_kernel: the same arithmetic with WAVE-OWNED output lines -- no workgroup barrier in the tile loop.
 //
-// The kernel above spreads the 8 scale groups of an output line over the 8 waves of a workgroup and meets twice per tile at a barrier (stage the
-// workgroup's output tile, free it again): every tile costs the slowest wave's load -> LDS -> transposing read -> MFMA -> reduce -> pack chain
-// plus two barrier round trips, and the op with the FEWEST bytes (QT: 72 MB at 8192^2, 30.6 us = 0.29 of 8 TB/s) took as long as its bf16-input
-// sibling (T: 170 MB, 37 us) -- latency-, not byte-bound.  Here ONE WAVE walks the 8 scale groups (256 n) of its 64 output rows itself, one
-// [32 n][64 m] tile after the other with the next tile's rows in flight, collects its 64 x 128 bytes of e2m1 + 64 x 8 scale bytes in a private LDS
-// area and stores whole 128-byte lines.  Waves never wait for each other (4 per workgroup only share the staged H^T); the four sibling m-tiles
-// that share QT's 128-byte input lines are the four waves of one workgroup.
-template <bool QT, bool HWCVT>
+// The kernel above spreads the 8 scale groups of an output line over the 8 waves of a workgroup and meets twice per unit at a barrier (stage the
+// workgroup's output tile, free it again).  Here ONE WAVE walks NG scale groups (32 NG n) of its 64 output rows itself, one [32 n][64 m] tile after
+// the other with the next tile's rows in flight, collects its 64 x 16 NG bytes of e2m1 + 64 x NG scale bytes in a private LDS area and stores whole
+// 128-byte (NG = 8) or 64-byte (NG = 4) line segments.  Waves never wait for each other; the four sibling m-tiles that share QT's 128-byte input
+// lines are the four waves of one workgroup.  What bounds it is instruction issue, not bytes (a wave issues one instruction per 4 cycles:
+// ~145 VALU + the LDS round trips per 2048-element tile), so the walk keeps its addresses incrementally (one 64-bit add per tile, the divisions
+// once per unit) and the LDS footprint is cut to 10 - 11.5 KB per wave: NG = 4 fits 16 (QT) / 12 (T) waves on a CU.
+template <bool QT, bool HWCVT, int NG>
 __global__ __launch_bounds__(256) void bwd_quant_tw_kernel(const BwdTParams p) {
   constexpr int LROW = QT ? QAMD_BWD_LROW_QT : 192;
   constexpr int HROW = 32 * 2 + 16;
-  constexpr int OROW = 128 + 16;
+  constexpr int OROW = NG * 16 + 16;
+  static_assert(32 * HROW <= 32 * LROW, "the staged H^T borrows the first wave's tile area");
   __shared__ __attribute__((aligned(16))) char tile_s[4][32 * LROW];
   __shared__ __attribute__((aligned(16))) char out_s[4][64 * OROW];
-  __shared__ __attribute__((aligned(16))) uint8_t sf_s[4][64 * 8];
-  __shared__ __attribute__((aligned(16))) char hT[32 * HROW];
+  __shared__ __attribute__((aligned(16))) uint8_t sf_s[4][64 * NG];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = uniform(tid >> 6);
   const int row = lane & 31, half = lane >> 5;
@@ -321,10 +327,12 @@ __global__ __launch_bounds__(256) void bwd_quant_tw_kernel(const BwdTParams p) {
   uint8_t* ss = sf_s[wave];
   const float alpha = QT ? *p.alpha : 1.0f;
   const int G = p.N >> 5;
-  const int n_o = (G + 7) >> 3, n_i = p.tiles_m;
+  const int n_o = (G + NG - 1) / NG, n_i = p.tiles_m;
   const uint32_t OOB = 0x80000000u;
 
-  {   // hT[j][k] = h[k][j]
+  v8bf hf[2];
+  {   // hT[j][k] = h[k][j], staged in the first wave's tile area and read once
+    char* hT = tile_s[0];
     uint16_t hv[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) hv[i] = p.h[i * 256 + tid];
@@ -333,11 +341,11 @@ __global__ __launch_bounds__(256) void bwd_quant_tw_kernel(const BwdTParams p) {
       const int idx = i * 256 + tid, k = idx >> 5, j = idx & 31;
       *(uint16_t*)(hT + j * HROW + k * 2) = hv[i];
     }
-  }
-  __syncthreads();
-  v8bf hf[2];
+    __syncthreads();
 #pragma unroll
-  for (int kc = 0; kc < 2; ++kc) hf[kc] = *(const v8bf*)(hT + row * HROW + (kc * 16 + half * 8) * 2);
+    for (int kc = 0; kc < 2; ++kc) hf[kc] = *(const v8bf*)(hT + row * HROW + (kc * 16 + half * 8) * 2);
+    __syncthreads();
+  }
 
   const uint32_t rowb = QT ? (uint32_t)p.M >> 1 : (uint32_t)p.M * 2u;   // input row stride in bytes
   const int lcol = QT ? (lane & 1) * 32 : (lane & 7) * 8;
@@ -349,134 +357,186 @@ __global__ __launch_bounds__(256) void bwd_quant_tw_kernel(const BwdTParams p) {
   const float c3 = QT ? 3.0f / alpha : 3.0f;
   const char* tr_ptr = ts + (8 * half + ((lane & 15) >> 2)) * LROW + (((lane & 31) >> 4) * 16 + (lane & 3) * 4) * 2;
 
-  v4i ld[QT ? 1 : 4];
-  uint8_t ld_e = 0;
-  // rows of scale group g (32 n) of batch b, columns m0 .. m0 + 63: in flight while the previous tile is rotated and quantised
-  auto load_tile = [&](const int b, const int g, const int m0, const bool live) __attribute__((always_inline)) {
-    const int64_t e0 = ((int64_t)b * p.N + (int64_t)g * 32) * p.M + m0;          // element index of the tile's first input element
+  // the wave's walk: units (b, block of NG groups o, m-tile i), i fastest (< 2^31: host-checked), tiles k = 0 .. ng-1 inside a unit.  The cursor
+  // L is one tile ahead of the arithmetic (its rows are in flight); e0 = element index of the tile's first input element, advanced by 32 rows
+  // per tile and recomputed once per unit.
+  const uint32_t U = (uint32_t)((int64_t)p.B * n_o * n_i);
+  const uint32_t stride = gridDim.x * 4u;
+  const int64_t estep = (int64_t)32 * p.M;
+  struct Cur { uint32_t u; int k, ng, b, g0, m0; int64_t e0; };
+  auto decode = [&](Cur& c) __attribute__((always_inline)) {
+    c.k = 0;
+    if (c.u >= U) { c.ng = 0; c.b = 0; c.g0 = 0; c.m0 = 0; c.e0 = 0; return; }
+    uint32_t i = c.u % (uint32_t)n_i, q = c.u / (uint32_t)n_i;
+    uint32_t o = q % (uint32_t)n_o;
+    q /= (uint32_t)n_o;
+    c.b = uniform((int)q);
+    c.m0 = uniform((int)i * 64);
+    c.g0 = uniform((int)o * NG);
+    c.ng = uniform(min(NG, G - c.g0));
+    c.e0 = ((int64_t)c.b * p.N + (int64_t)c.g0 * 32) * p.M + c.m0;
+  };
+  // (A register ring with the unit's NG tiles in flight instead of one, non-temporal loads / stores and a group-block-fastest unit order were
+  // measured and dropped: profiles/ab_bwd_r4k_variants.txt, ab_bwd_abl_r4l_nt_order.txt.)
+  constexpr int SLOTS = 1;
+  v4i ld[SLOTS][QT ? 1 : 4];
+  uint8_t ld_e[SLOTS] = {};
+  auto load_tile = [&](const int s, const bool live_in, const int m0, const int64_t e0) __attribute__((always_inline)) {
+    const bool live = live_in && !QAMD_BWD_ABL(1);
     const uint32_t voff = (live && m0 + lcol < p.M) ? ld_off : OOB;
     if (!QT) {
       const __amdgpu_buffer_rsrc_t r = make_rsrc((const char*)p.x + e0 * 2, live ? 32u * rowb : 0u);
 #pragma unroll
-      for (int ps = 0; ps < 4; ++ps) ld[ps] = __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)(ps * 8 * rowb), 0);
+      for (int ps = 0; ps < 4; ++ps) ld[s][ps] = __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)(ps * 8 * rowb), 0);
     } else {
       const __amdgpu_buffer_rsrc_t r = make_rsrc((const char*)p.xq + (e0 >> 1), live ? 32u * rowb : 0u);
       const __amdgpu_buffer_rsrc_t re = make_rsrc((const char*)p.xs + (e0 >> 5), live ? 32u * ((uint32_t)p.M >> 5) : 0u);
-      ld[0] = __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, 0, 0);
-      ld_e = __builtin_amdgcn_raw_buffer_load_b8(re, (int)((live && m0 + lcol < p.M) ? lds_off : OOB), 0, 0);
+      ld[s][0] = __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, 0, 0);
+      ld_e[s] = __builtin_amdgcn_raw_buffer_load_b8(re, (int)((live && m0 + lcol < p.M) ? lds_off : OOB), 0, 0);
     }
   };
-
-  const int64_t U = (int64_t)p.B * n_o * n_i;        // units: (b, block of 8 groups o, m-tile i), i fastest (< 2^31: host-checked)
-  const int64_t stride = (int64_t)gridDim.x * 4;
-  for (int64_t u = (int64_t)blockIdx.x * 4 + wave; u < U; u += stride) {
-    const int i = (int)(u % n_i);
-    const int64_t q = u / n_i;
-    const int o = (int)(q % n_o), b = (int)(q / n_o);
-    const int m0 = uniform(i * 64), g0 = uniform(o * 8);
-    const int ng = uniform(min(8, G - g0));
-    load_tile(b, g0, m0, true);
-    for (int k = 0; k < ng; ++k) {
-      // ---- stage the [32 n][64 m] bf16 tile in the wave's LDS area -------------------------------------------------
-      if (!QT) {
+  // ---- stage the [32 n][64 m] bf16 tile of slot s in the wave's LDS area ------------------------------------------
+  auto stage = [&](const int s) __attribute__((always_inline)) {
+    if (QAMD_BWD_ABL(8)) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else if (!QT) {
 #pragma unroll
-        for (int ps = 0; ps < 4; ++ps) {
-          const int r = ps * 8 + (lane >> 3), c = (lane & 7) * 8;
-          *(v4i*)(ts + r * LROW + c * 2) = ld[ps];
-        }
-      } else {
-        const int r = lane >> 1, c = (lane & 1) * 32;
-        const uint32_t e = ld_e;
-        const float sc = __uint_as_float(e ? (e << 23) : 0x00400000u);
-        v4i* d = (v4i*)(ts + r * LROW + c * 2);
-#pragma unroll
-        for (int qq = 0; qq < 4; ++qq) {
-          const uint32_t w = (uint32_t)ld[0][qq];
-          v4i ov;
-          ov[0] = __builtin_bit_cast(int, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp4(w, sc, 0));
-          ov[1] = __builtin_bit_cast(int, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp4(w, sc, 1));
-          ov[2] = __builtin_bit_cast(int, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp4(w, sc, 2));
-          ov[3] = __builtin_bit_cast(int, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp4(w, sc, 3));
-          d[qq] = ov;
-        }
+      for (int ps = 0; ps < 4; ++ps) {
+        const int r = ps * 8 + (lane >> 3), c = (lane & 7) * 8;
+        *(v4i*)(ts + r * LROW + c * 2) = ld[s][ps];
       }
-      load_tile(b, g0 + k + 1, m0, k + 1 < ng);   // next group's rows (nothing past the block: the next unit loads its own first tile)
-      __builtin_amdgcn_s_waitcnt(0xc07f);         // lgkmcnt(0): the wave's own LDS writes landed
-      __builtin_amdgcn_wave_barrier();
+    } else {
+      const int r = lane >> 1, c = (lane & 1) * 32;
+      const uint32_t e = ld_e[s];
+      const float sc = __uint_as_float(e ? (e << 23) : 0x00400000u);
+      v4i* d = (v4i*)(ts + r * LROW + c * 2);
 #pragma unroll
-      for (int mh = 0; mh < 2; ++mh) {
-        const int mloc = mh * 32 + row;
-        v16f acc;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-#pragma unroll
-        for (int kc = 0; kc < 2; ++kc) {
-          typedef short v4s_ __attribute__((ext_vector_type(4)));
-          typedef __attribute__((address_space(3))) v4s_* lds_v4s_t;
-          const v4s_ lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s_t)(tr_ptr + (16 * kc) * LROW + mh * 64));
-          const v4s_ hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s_t)(tr_ptr + (16 * kc + 4) * LROW + mh * 64));
-          const v8u16 xv = {(uint16_t)lo[0], (uint16_t)lo[1], (uint16_t)lo[2], (uint16_t)lo[3], (uint16_t)hi[0], (uint16_t)hi[1], (uint16_t)hi[2], (uint16_t)hi[3]};
-          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(hf[kc], __builtin_bit_cast(v8bf, xv), acc, 0, 0, 0);
-        }
-        float amax = 0.f;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) amax = fmaxf(amax, fabsf(acc[r]));
-        amax = xhalf_max(amax);
-        const uint32_t ab = __float_as_uint(amax);
-        uint32_t sb = (ab - Kexp) & 0x7f800000u;
-        float mfac = c3, cs = __uint_as_float(sb);
-        const bool fast = HWCVT && alpha_fast && ab >= 0x21800000u && ab <= 0x5d800000u;
-        const bool slow_wave = __builtin_amdgcn_ballot_w64(!fast) != 0;
-        if (slow_wave) {   // wave-uniform: the reference's arithmetic as written (quartet_bwd_sm120.cu:304-323)
-          float scale = QT ? amax / alpha : amax;
-          const uint32_t sbs = __float_as_uint(scale) & 0x7f800000u;
-          scale = __uint_as_float(sbs);
-          const float mult = QT ? 3.0f / (scale * alpha) : 3.0f / scale;
-          sb = fast ? sb : sbs;
-          mfac = fast ? mfac : mult;
-          cs = fast ? cs : 1.0f;
-        }
-        float tq[16];
-        scale_pk<16>(acc, 0, mfac, tq);
-        if (slow_wave) {
-#pragma unroll
-          for (int r = 0; r < 16; ++r) tq[r] = (tq[r] != tq[r]) ? __uint_as_float(0x7fc00000u) : tq[r];
-        }
-        const uint32_t P = e2m1_pack8<HWCVT>(tq, cs);
-        const uint32_t Q = e2m1_pack8<HWCVT>(tq + 8, cs);
-        auto sw = __builtin_amdgcn_permlane32_swap(P, Q, false, false);
-        const uint32_t X = sw[0], Y = sw[1];
-        v2i ov;
-        ov[0] = (int)((X & 0xffffu) | (Y << 16));
-        ov[1] = (int)((X >> 16) | (Y & 0xffff0000u));
-        *(v2i*)(os + mloc * OROW + k * 16 + half * 8) = ov;
-        if (half == 0) ss[mloc * 8 + k] = (uint8_t)(sb >> 23);
+      for (int qq = 0; qq < 4; ++qq) {
+        const uint32_t w = (uint32_t)ld[s][0][qq];
+        v4i ov;
+        ov[0] = __builtin_bit_cast(int, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp4(w, sc, 0));
+        ov[1] = __builtin_bit_cast(int, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp4(w, sc, 1));
+        ov[2] = __builtin_bit_cast(int, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp4(w, sc, 2));
+        ov[3] = __builtin_bit_cast(int, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp4(w, sc, 3));
+        d[qq] = ov;
       }
-      __builtin_amdgcn_wave_barrier();   // (the transposing reads of this tile were consumed: the next group may be staged)
     }
-    // ---- the wave's 64 output rows: whole 128-byte lines + 8 scale bytes per row -------------------------------------------
+  };
+  // ---- rotate + quantise the staged tile = scale group k of the unit --------------------------------------------------
+  auto compute = [&](const int k) __attribute__((always_inline)) {
+    __builtin_amdgcn_s_waitcnt(0xc07f);         // lgkmcnt(0): the wave's own LDS writes landed
+    __builtin_amdgcn_wave_barrier();
+    if (!QAMD_BWD_ABL(4)) {
+    // both 32-row halves of the tile: the MFMAs and the amax reductions first, ONE wave-uniform decision for the pair, then a straight-line arm
+    // for both (two independent chains the scheduler can interleave -- a branch per half ends the scheduling region four times per tile)
+    v16f acc[2];
+    float amax[2];
+#pragma unroll
+    for (int mh = 0; mh < 2; ++mh) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mh][r] = 0.f;
+#pragma unroll
+      for (int kc = 0; kc < 2; ++kc) {
+        typedef short v4s_ __attribute__((ext_vector_type(4)));
+        typedef __attribute__((address_space(3))) v4s_* lds_v4s_t;
+        const v4s_ lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s_t)(tr_ptr + (16 * kc) * LROW + mh * 64));
+        const v4s_ hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s_t)(tr_ptr + (16 * kc + 4) * LROW + mh * 64));
+        const v8u16 xv = {(uint16_t)lo[0], (uint16_t)lo[1], (uint16_t)lo[2], (uint16_t)lo[3], (uint16_t)hi[0], (uint16_t)hi[1], (uint16_t)hi[2], (uint16_t)hi[3]};
+        acc[mh] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(hf[kc], __builtin_bit_cast(v8bf, xv), acc[mh], 0, 0, 0);
+      }
+    }
+    bool fast[2];
+#pragma unroll
+    for (int mh = 0; mh < 2; ++mh) {
+      float m0_ = fmaxf(fmaxf(fabsf(acc[mh][0]), fabsf(acc[mh][1])), fmaxf(fabsf(acc[mh][2]), fabsf(acc[mh][3])));
+      float m1_ = fmaxf(fmaxf(fabsf(acc[mh][4]), fabsf(acc[mh][5])), fmaxf(fabsf(acc[mh][6]), fabsf(acc[mh][7])));
+      float m2_ = fmaxf(fmaxf(fabsf(acc[mh][8]), fabsf(acc[mh][9])), fmaxf(fabsf(acc[mh][10]), fabsf(acc[mh][11])));
+      float m3_ = fmaxf(fmaxf(fabsf(acc[mh][12]), fabsf(acc[mh][13])), fmaxf(fabsf(acc[mh][14]), fabsf(acc[mh][15])));
+      amax[mh] = xhalf_max(fmaxf(fmaxf(fmaxf(m0_, m1_), fmaxf(m2_, m3_)), 0.f));   // (the 0: sixteen NaNs -- inf - inf under the rotation -- reduce to 0 as in the reference's chain from 0)
+      const uint32_t ab = __float_as_uint(amax[mh]);
+      fast[mh] = HWCVT && alpha_fast && ab >= 0x21800000u && ab <= 0x5d800000u;
+    }
+    const bool slow_wave = __builtin_amdgcn_ballot_w64(!(fast[0] && fast[1])) != 0;
+    auto emit = [&](const int mh, auto slow_c) __attribute__((always_inline)) {
+      constexpr bool SLOW = decltype(slow_c)::value;
+      const int mloc = mh * 32 + row;
+      const uint32_t ab = __float_as_uint(amax[mh]);
+      uint32_t sb = (ab - Kexp) & 0x7f800000u;
+      float mfac = c3, cs = __uint_as_float(sb);
+      if (SLOW) {   // the reference's arithmetic as written (quartet_bwd_sm120.cu:304-323) for the lanes outside the fast range
+        float scale = QT ? amax[mh] / alpha : amax[mh];
+        const uint32_t sbs = __float_as_uint(scale) & 0x7f800000u;
+        scale = __uint_as_float(sbs);
+        const float mult = QT ? 3.0f / (scale * alpha) : 3.0f / scale;
+        sb = fast[mh] ? sb : sbs;
+        mfac = fast[mh] ? mfac : mult;
+        cs = fast[mh] ? cs : 1.0f;
+      }
+      float tq[16];
+      scale_pk<16>(acc[mh], 0, mfac, tq);
+      if (SLOW) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) tq[r] = (tq[r] != tq[r]) ? __uint_as_float(0x7fc00000u) : tq[r];
+      }
+      const uint32_t P = e2m1_pack8<HWCVT>(tq, cs);
+      const uint32_t Q = e2m1_pack8<HWCVT>(tq + 8, cs);
+      auto sw = __builtin_amdgcn_permlane32_swap(P, Q, false, false);
+      const uint32_t X = sw[0], Y = sw[1];
+      v2i ov;
+      ov[0] = (int)((X & 0xffffu) | (Y << 16));
+      ov[1] = (int)((X >> 16) | (Y & 0xffff0000u));
+      *(v2i*)(os + mloc * OROW + k * 16 + half * 8) = ov;
+      if (half == 0) ss[mloc * NG + k] = (uint8_t)(sb >> 23);
+    };
+    if (!slow_wave) {
+      emit(0, std::false_type{});
+      emit(1, std::false_type{});
+    } else {
+      emit(0, std::true_type{});
+      emit(1, std::true_type{});
+    }
+    }
+    __builtin_amdgcn_wave_barrier();   // (the transposing reads of this tile were consumed: the next group may be staged)
+  };
+  // ---- the wave's 64 output rows: 16 NG-byte line segments + NG scale bytes per row --------------------------------------
+  auto store_unit = [&](const int b, const int g0, const int m0, const int ng) __attribute__((always_inline)) {
+    if (QAMD_BWD_ABL(2)) return;
     __builtin_amdgcn_s_waitcnt(0xc07f);
     __builtin_amdgcn_wave_barrier();
-    {
-      const int rows = min(64, p.M - m0);
-      const int64_t grp0 = ((int64_t)b * p.M + m0) * G + g0;    // first output scale group of the unit
-      const __amdgpu_buffer_rsrc_t ro = make_rsrc(p.out + grp0 * 16, (uint32_t)rows * (uint32_t)G * 16u - (uint32_t)g0 * 16u);
+    const int rows = min(64, p.M - m0);
+    const int64_t grp0 = ((int64_t)b * p.M + m0) * G + g0;    // first output scale group of the unit
+    const __amdgpu_buffer_rsrc_t ro = make_rsrc(p.out + grp0 * 16, (uint32_t)rows * (uint32_t)G * 16u - (uint32_t)g0 * 16u);
 #pragma unroll
-      for (int it = 0; it < 8; ++it) {
-        const int pc = it * 64 + lane, r = pc >> 3, kk = pc & 7;
-        const uint32_t so = (kk < ng) ? (uint32_t)r * (uint32_t)G * 16u + (uint32_t)kk * 16u : OOB;
-        __builtin_amdgcn_raw_buffer_store_b128(*(const v4i*)(os + r * OROW + kk * 16), ro, (int)so, 0, 0);
-      }
-      if (lane < rows) {
-        uint8_t* dst = p.out_sf + grp0 + (int64_t)lane * G;
-        if ((G & 7) == 0) {
-          *(v2i*)dst = *(const v2i*)(ss + lane * 8);
-        } else {
-          for (int kk = 0; kk < ng; ++kk) dst[kk] = ss[lane * 8 + kk];
-        }
+    for (int it = 0; it < NG; ++it) {
+      const int pc = it * 64 + lane, r = pc / NG, kk = pc % NG;
+      const uint32_t so = (kk < ng) ? (uint32_t)r * (uint32_t)G * 16u + (uint32_t)kk * 16u : OOB;
+      __builtin_amdgcn_raw_buffer_store_b128(*(const v4i*)(os + r * OROW + kk * 16), ro, (int)so, 0, 0);
+    }
+    if (lane < rows) {
+      uint8_t* dst = p.out_sf + grp0 + (int64_t)lane * G;
+      if ((G & (NG - 1)) == 0) {
+        if (NG == 8) *(v2i*)dst = *(const v2i*)(ss + lane * NG);
+        else *(uint32_t*)dst = *(const uint32_t*)(ss + lane * NG);
+      } else {
+        for (int kk = 0; kk < ng; ++kk) dst[kk] = ss[lane * NG + kk];
       }
     }
     __builtin_amdgcn_wave_barrier();   // the LDS reads above are issued before the next unit's writes (in-order LDS): only the compiler needs the fence
+  };
+
+  Cur L;
+  L.u = uniform((int)(blockIdx.x * 4u + (uint32_t)wave));
+  decode(L);
+  load_tile(0, L.u < U, L.m0, L.e0);
+  while (L.u < U) {
+    const int k = L.k, ng = L.ng, b = L.b, g0 = L.g0, m0 = L.m0;
+    stage(0);
+    // the registers are free again: the next tile of the walk (this unit's next group, or the first group of the wave's next unit)
+    if (L.k + 1 < L.ng) { L.k += 1; L.e0 += estep; }
+    else { L.u += stride; decode(L); }
+    load_tile(0, L.u < U, L.m0, L.e0);
+    compute(k);
+    if (k + 1 == ng) store_unit(b, g0, m0, ng);
   }
 }
 

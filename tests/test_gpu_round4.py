@@ -296,3 +296,69 @@ def test_stream_k_mx_graph_replay(q):
             gr.replay()
             torch.cuda.synchronize()
             assert torch.equal(o1.view(torch.int16), ref.view(torch.int16)) and torch.equal(o2.view(torch.int16), ref.view(torch.int16))
+
+
+# ------------------------------------------------------------------------------------------------
+# [r4] backward_t_bf16 / backward_qt_bf16: wave-owned output lines (bwd_quant_tw_kernel, quartet_bwd.hip.h).  Three kernels sit behind one entry
+# point (capi.hip: bwd_kernel_choice): 1 = the round-3 kernel (small tensors), 2 = units of 4 scale groups (QT), 3 = units of 8 (T).  Each is
+# forced through the LAB build on ragged shapes against the oracle (quartet_bwd_sm120.cu:304-323 / :407-426), and the product rule is checked
+# against the round-3 kernel, byte for byte, on tensors large enough to take the new kernels.
+# ------------------------------------------------------------------------------------------------
+def _hadamard32():
+    h = torch.ones(1, 1)
+    while h.shape[0] < 32:
+        h = torch.cat([torch.cat([h, h], 1), torch.cat([h, -h], 1)], 0)
+    return (h * 32 ** -0.5).to(torch.bfloat16).to(DEV)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("variant", [1, 2, 3])
+@pytest.mark.parametrize("B,N,M", [(2, 512, 320), (1, 96, 64), (3, 32, 1056), (1, 2080, 160), (1, 416, 8 * 37)])
+def test_backward_wave_owned_kernels_equal_the_oracle_on_ragged_shapes(q, variant, B, N, M):
+    """group counts that are not multiples of 4 / 8, m-tile counts that are not multiples of 4, a last m-tile of 8 .. 56 rows, batches: every kernel
+    behind backward_t_bf16 / backward_qt_bf16 returns the oracle's scale bytes exactly and its codes up to the reference's own tolerance."""
+    rng = np.random.default_rng(B * 1000 + N + M + variant)
+    h = _hadamard32()
+    with lab.forced(bwd_variant=variant):
+        x = torch.from_numpy(rng.standard_normal((B, N, M)).astype(np.float32) * 20.0).to(torch.bfloat16).to(DEV)
+        e2m1, e8m0 = lab.backward_t_bf16(x, h)
+        rq, rs = oracle.backward_t_bf16(_np(x), _np(h), acc_model=1)
+        assert np.array_equal(_np(e8m0), rs), int((_np(e8m0) != rs).sum())
+        eq = oracle.codes_equal_mod_zero_sign(_np(e2m1).reshape(rq.shape), rq)
+        assert int((~eq).sum()) <= 1e-4 * eq.size, int((~eq).sum())
+        if M % 32 == 0:
+            codes = rng.integers(0, 256, size=(B, N, M // 2), dtype=np.uint8)
+            scales = rng.integers(110, 140, size=(B, N, M // 32), dtype=np.uint8)
+            scales[:, : min(N, 32), :] = 0            # e8m0 byte 0 (2^-127: the dequantised operand is a bf16 denormal)
+            codes[:, -32:, : M // 4] = 0              # all-zero groups: the reference's 0 * inf = NaN -> code 7 path
+            e2m1, e8m0 = lab.backward_qt_bf16(torch.from_numpy(codes).to(DEV), torch.from_numpy(scales).to(DEV), h, torch.tensor([3.0], device=DEV))
+            rq, rs = oracle.backward_qt_bf16(codes, scales, _np(h), 3.0, acc_model=1)
+            assert np.array_equal(_np(e8m0), rs), int((_np(e8m0) != rs).sum())
+            eq = oracle.codes_equal_mod_zero_sign(_np(e2m1).reshape(rq.shape), rq)
+            assert int((~eq).sum()) <= 1e-4 * eq.size, int((~eq).sum())
+
+
+@pytest.mark.gpu
+def test_backward_product_rule_takes_the_wave_owned_kernels_and_equals_the_round3_kernel(q):
+    """tensors above the thresholds of bwd_kernel_choice (QT: 3 units per CU, T: 6), ragged in M and in the group count: the PRODUCT library's bytes
+    (whatever kernel its rule picks) equal the round-3 kernel's, forced through the lab build -- and equal the lab build's own rule."""
+    g = torch.Generator(device=DEV).manual_seed(5)
+    h = _hadamard32()
+    B, N, M = 1, 4096 + 96, 6152                       # T: 131 groups (not a multiple of 8), 97 m-tiles, the last one of 8 rows
+    x = torch.randn(B, N, M, dtype=torch.bfloat16, device=DEV, generator=g) * 7.0
+    pq, ps = q.backward_t_bf16(x, h)
+    with lab.forced(bwd_variant=1):
+        oq, osf = lab.backward_t_bf16(x, h)
+    aq, asf = lab.backward_t_bf16(x, h)
+    assert torch.equal(pq.view(torch.uint8).reshape(oq.shape), oq) and torch.equal(ps.view(torch.uint8).reshape(osf.shape), osf)
+    assert torch.equal(aq, oq) and torch.equal(asf, osf)
+    M = 6144 + 32                                      # QT: M a multiple of 32
+    xq = torch.randint(0, 256, (B, N, M // 2), dtype=torch.uint8, device=DEV, generator=g)
+    xs = torch.randint(118, 134, (B, N, M // 32), dtype=torch.uint8, device=DEV, generator=g)
+    alpha = torch.tensor([0.61], device=DEV)
+    pq, ps = q.backward_qt_bf16(xq, xs.view(torch.float8_e8m0fnu), h, alpha)
+    with lab.forced(bwd_variant=1):
+        oq, osf = lab.backward_qt_bf16(xq, xs, h, alpha)
+    aq, asf = lab.backward_qt_bf16(xq, xs, h, alpha)
+    assert torch.equal(pq.view(torch.uint8).reshape(oq.shape), oq) and torch.equal(ps.view(torch.uint8).reshape(osf.shape), osf)
+    assert torch.equal(aq, oq) and torch.equal(asf, osf)
