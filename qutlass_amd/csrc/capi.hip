@@ -1421,12 +1421,28 @@ int qutlass_amd_mxfp4_transpose_mxfp8_rows(const void* x_fp4, const void* scales
   TrParams p;
   p.xq = (const uint8_t*)x_fp4; p.xs = (const uint8_t*)scales; p.y = (uint8_t*)y; p.out_sf = (uint8_t*)out_e8m0;
   p.m = (int)m; p.n = (int)n; p.m_pad = (int)m_pad;
+  // [r4] A wave-owned-lines form of this op (mxfp4_transpose_mxfp8_tw_kernel: persistent waves, no workgroup barrier, whole 128-byte lines or
+  // 64-byte segments) is byte-identical and NOT faster (8192^2 cold 30.7 / 35.0 us against 28.4, warm 21.4 / 22.5 against 21.2;
+  // profiles/ab_transpose_r4o.txt): the one-shot kernel stays the product, the other lives in the lab build (option "transpose_nc" = 4 / 2).
 #if QAMD_BENCH
-  if (opt_transpose_nc() == 256)
+  const int64_t cu = chip_cus();
+  const int tw = (m_pad < (1ll << 25) && (opt_transpose_nc() == 4 || opt_transpose_nc() == 2)) ? opt_transpose_nc() : 0;   // (64 output rows within one buffer window)
+  if (opt_transpose_nc() == 256) {
     hipLaunchKernelGGL(mxfp4_transpose_mxfp8_kernel<256>, dim3((unsigned)((m_pad / 128) * (n / 256))), dim3(256), 0, (hipStream_t)stream, p);
-  else
+    return check_launch("mxfp4_transpose_mxfp8_kernel");
+  }
+  if (tw == 4) {
+    const int64_t units = (m_pad / 128) * (n / 64);
+    hipLaunchKernelGGL(mxfp4_transpose_mxfp8_tw_kernel<4>, dim3((unsigned)std::min<int64_t>(cdiv(units, 4), cu * 2)), dim3(256), 0, (hipStream_t)stream, p);
+    return check_launch("mxfp4_transpose_mxfp8_tw_kernel");
+  }
+  if (tw == 2) {
+    const int64_t units = (m_pad / 64) * (n / 64);
+    hipLaunchKernelGGL(mxfp4_transpose_mxfp8_tw_kernel<2>, dim3((unsigned)std::min<int64_t>(cdiv(units, 4), cu * 3)), dim3(256), 0, (hipStream_t)stream, p);
+    return check_launch("mxfp4_transpose_mxfp8_tw_kernel");
+  }
 #endif
-    hipLaunchKernelGGL(mxfp4_transpose_mxfp8_kernel<128>, dim3((unsigned)((m_pad / 128) * (n / 128))), dim3(256), 0, (hipStream_t)stream, p);
+  hipLaunchKernelGGL(mxfp4_transpose_mxfp8_kernel<128>, dim3((unsigned)((m_pad / 128) * (n / 128))), dim3(256), 0, (hipStream_t)stream, p);
   return check_launch("mxfp4_transpose_mxfp8_kernel");
 }
 

@@ -741,4 +741,130 @@ __global__ __launch_bounds__(256) void mxfp4_transpose_mxfp8_kernel(const TrPara
   if (tid < NC) *(uint32_t*)(p.out_sf + (int64_t)(c0 + tid) * (p.m_pad >> 5) + (m0 >> 5)) = *(const uint32_t*)(es + tid * 4);
 }
 
+// ----------------------------------------------------------------------------------------------------------------
+// [r4] mxfp4_transpose_mxfp8_tw_kernel: the transposer with WAVE-OWNED output lines (the layout of bwd_quant_tw_kernel above).
+//
+// The kernel above is one shot per workgroup: load 128 m x NC n, two workgroup barriers, store -- 4096 workgroups in four rounds at 8192^2, each
+// a serial load -> LDS -> transpose -> barrier -> stage -> barrier -> store chain.  Here a wave walks units of [32 MCH m] x [64 n]: one chunk of
+// 32 m rows x 64 n (32 input bytes per row; the four waves of a workgroup are the four 64-column blocks of the same 128-byte input lines)
+// after the other with the next chunk's rows in flight, dequantises it into a private bf16 tile, takes each of its 64 columns out with
+// transposing reads (lane = column), requantises the 32 m values of the column to e4m3 + one e8m0 byte, and collects 64 n x 32 MCH bytes in a
+// private output area that leaves as whole 128-byte lines (MCH = 4) or 64-byte segments (MCH = 2).  No workgroup barrier anywhere.
+template <int MCH>
+__global__ __launch_bounds__(256) void mxfp4_transpose_mxfp8_tw_kernel(const TrParams p) {
+  constexpr int LROW = 64 * 2 + 64;    // as above (NC = 64): the transposing reads of a half wave fall on 64 different banks
+  constexpr int OROW = MCH * 32 + 16;
+  __shared__ __attribute__((aligned(16))) char tile_s[4][32 * LROW];
+  __shared__ __attribute__((aligned(16))) char out_s[4][64 * OROW];
+  __shared__ __attribute__((aligned(16))) uint8_t es_s[4][64 * MCH];
+  const int tid = threadIdx.x, lane = tid & 63, wave = uniform(tid >> 6);
+  char* ts = tile_s[wave];
+  char* os = out_s[wave];
+  uint8_t* es = es_s[wave];
+  const uint32_t OOB = 0x80000000u;
+  const uint32_t rowb = (uint32_t)p.n >> 1, srow = (uint32_t)p.n >> 5;     // input row strides in bytes: codes, scales
+  const uint32_t n_j = (uint32_t)p.n >> 6, n_i = (uint32_t)p.m_pad / (32u * MCH);
+  const uint32_t U = n_i * n_j, stride = gridDim.x * 4u;
+  const uint32_t ld_off = (uint32_t)(lane >> 1) * rowb + (uint32_t)(lane & 1) * 16u;
+  const uint32_t lds_off = (uint32_t)(lane >> 1) * srow + (uint32_t)(lane & 1);
+
+  typedef short v4s_ __attribute__((ext_vector_type(4)));
+  typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+  typedef __attribute__((address_space(3))) v4s_* lds_v4s_t;
+  const char* tr_ptr = ts + ((lane & 15) >> 2) * LROW + ((lane >> 4) * 16 + (lane & 3) * 4) * 2;
+
+  // the walk: units u = (ti, tj), tj fastest (the workgroup's four waves = four neighbouring column blocks), chunks ch = 0 .. MCH-1 inside a unit
+  struct Cur { uint32_t u; int ch, row0, c0; };
+  auto decode = [&](Cur& c) __attribute__((always_inline)) {
+    c.ch = 0;
+    if (c.u >= U) { c.row0 = 0; c.c0 = 0; return; }
+    const uint32_t tj = c.u % n_j, ti = c.u / n_j;
+    c.row0 = uniform((int)(ti * 32u * MCH));
+    c.c0 = uniform((int)(tj * 64u));
+  };
+  v4i ld;
+  uint8_t ld_e = 0;
+  auto load_chunk = [&](const Cur& c) __attribute__((always_inline)) {
+    const int rows_live = c.u < U ? max(0, min(32, p.m - c.row0)) : 0;     // rows m .. m_pad-1 of the padded problem: zero codes
+    const int64_t roff = (int64_t)c.row0;
+    const __amdgpu_buffer_rsrc_t r = make_rsrc(p.xq + roff * rowb + (c.c0 >> 1), (uint32_t)rows_live * rowb);
+    const __amdgpu_buffer_rsrc_t re = make_rsrc(p.xs + roff * srow + (c.c0 >> 5), (uint32_t)rows_live * srow);
+    ld = __builtin_amdgcn_raw_buffer_load_b128(r, (int)(rows_live ? ld_off : OOB), 0, 0);
+    ld_e = __builtin_amdgcn_raw_buffer_load_b8(re, (int)(rows_live ? lds_off : OOB), 0, 0);
+  };
+  Cur L;
+  L.u = uniform((int)(blockIdx.x * 4u + (uint32_t)wave));
+  decode(L);
+  load_chunk(L);
+  while (L.u < U) {
+    const int ch = L.ch, row0 = L.row0, c0 = L.c0;
+    {   // ---- dequantise the chunk into the wave's bf16 tile: lane = (row lane / 2, 32 codes = one input scale group)
+      const int r = lane >> 1, c = (lane & 1) * 32;
+      const float sc = e8m0_scale(ld_e);
+      v4i* d = (v4i*)(ts + r * LROW + c * 2);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const uint32_t w = (uint32_t)ld[q];
+        v4i o;
+        o[0] = __builtin_bit_cast(int, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp4(w, sc, 0));
+        o[1] = __builtin_bit_cast(int, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp4(w, sc, 1));
+        o[2] = __builtin_bit_cast(int, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp4(w, sc, 2));
+        o[3] = __builtin_bit_cast(int, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp4(w, sc, 3));
+        d[q] = o;
+      }
+    }
+    // the registers are free again: the next chunk of the walk
+    if (L.ch + 1 < MCH) { L.ch += 1; L.row0 += 32; }
+    else { L.u += stride; decode(L); }
+    load_chunk(L);
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+    {   // ---- column `lane` of the tile: 32 m values as 16 packed pairs, block maximum on the bf16 bit patterns, e4m3 + e8m0 (as above)
+      uint32_t pr[16];
+      u16x2 mx = {0, 0};
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const v4s_ t4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s_t)(tr_ptr + 4 * q * LROW));
+        const v2i w2 = __builtin_bit_cast(v2i, t4);
+        pr[2 * q] = (uint32_t)w2[0];
+        pr[2 * q + 1] = (uint32_t)w2[1];
+        mx = __builtin_elementwise_max(mx, __builtin_bit_cast(u16x2, pr[2 * q] & 0x7fff7fffu));
+        mx = __builtin_elementwise_max(mx, __builtin_bit_cast(u16x2, pr[2 * q + 1] & 0x7fff7fffu));
+      }
+      const float amax = __uint_as_float((uint32_t)(mx[0] > mx[1] ? mx[0] : mx[1]) << 16);
+      const uint32_t e = e8m0_shift7(amax);
+      const float qs = e8m0_scale(e);
+      v4i o[2];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        i16x2 w = {0, 0};
+        w = __builtin_amdgcn_cvt_scalef32_pk_fp8_bf16(w, __builtin_bit_cast(bf16x2, pr[2 * q]), qs, false);
+        w = __builtin_amdgcn_cvt_scalef32_pk_fp8_bf16(w, __builtin_bit_cast(bf16x2, pr[2 * q + 1]), qs, true);
+        o[q >> 2][q & 3] = __builtin_bit_cast(int, w);
+      }
+      *(v4i*)(os + lane * OROW + ch * 32) = o[0];
+      *(v4i*)(os + lane * OROW + ch * 32 + 16) = o[1];
+      es[lane * MCH + ch] = (uint8_t)e;
+    }
+    __builtin_amdgcn_wave_barrier();   // (the transposing reads of this chunk were consumed: the next one may be staged)
+    if (ch + 1 < MCH) continue;
+    // ---- the wave's 64 output rows n: 32 MCH bytes each + MCH scale bytes ---------------------------------------------
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+    {
+      const int m0 = row0 - 32 * (MCH - 1);
+      const __amdgpu_buffer_rsrc_t ro = make_rsrc(p.y + (int64_t)c0 * p.m_pad + m0, 64u * (uint32_t)p.m_pad - (uint32_t)m0);
+#pragma unroll
+      for (int it = 0; it < MCH * 2; ++it) {
+        const int piece = it * 64 + lane, rown = piece / (MCH * 2), pc = piece % (MCH * 2);
+        __builtin_amdgcn_raw_buffer_store_b128(*(const v4i*)(os + rown * OROW + pc * 16), ro, (int)((uint32_t)rown * (uint32_t)p.m_pad + (uint32_t)pc * 16u), 0, 0);
+      }
+      uint8_t* dst = p.out_sf + (int64_t)(c0 + lane) * (p.m_pad >> 5) + (m0 >> 5);
+      if (MCH == 4) *(uint32_t*)dst = *(const uint32_t*)(es + lane * 4);
+      else *(uint16_t*)dst = *(const uint16_t*)(es + lane * 2);
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
 }  // namespace qamd

@@ -31,6 +31,7 @@ _SIGS = {
     "qutlass_amd_nvf4_splitk_workspace_bytes": (_i64, [_i64, _i64, _i64]),
     "qutlass_amd_matmul_nvf4_bf16_tn_ws": (_i32, _GEMM[:-1] + [_vp, _i64, _vp]),
     "qutlass_amd_mxfp4_transpose_mxfp8": (_i32, [_vp, _vp, _i64, _i64, _vp, _vp, _vp]),
+    "qutlass_amd_mxfp4_transpose_mxfp8_rows": (_i32, [_vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp]),
     "qutlass_amd_fused_quantize_mx": (_i32, [_vp, _vp, _i32, _i64, _i32, _vp, _vp, _vp, _vp]),
     "qutlass_amd_backward_t_bf16": (_i32, [_vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp]),
     "qutlass_amd_backward_qt_bf16": (_i32, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp]),
@@ -140,6 +141,14 @@ def mxfp4_transpose_mxfp8(x_fp4, scales, m: int, n: int):
     y = torch.empty(n, m, dtype=torch.uint8, device=x_fp4.device)
     sf = torch.empty(n, m // 32, dtype=torch.uint8, device=x_fp4.device)
     _check(load().qutlass_amd_mxfp4_transpose_mxfp8(_p(x_fp4), _p(scales), m, n, _p(y), _p(sf), _stream()))
+    return y, sf
+
+
+def mxfp4_transpose_mxfp8_rows(x_fp4, scales, m: int, m_pad: int, n: int):
+    """C-ABI call of the lab build, row-padded form: rows m .. m_pad-1 count as zero codes (m_pad % 128 == 0, n % 256 == 0)."""
+    y = torch.empty(n, m_pad, dtype=torch.uint8, device=x_fp4.device)
+    sf = torch.empty(n, m_pad // 32, dtype=torch.uint8, device=x_fp4.device)
+    _check(load().qutlass_amd_mxfp4_transpose_mxfp8_rows(_p(x_fp4), _p(scales), m, m_pad, n, _p(y), _p(sf), _stream()))
     return y, sf
 
 

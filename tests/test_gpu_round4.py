@@ -361,3 +361,25 @@ def test_backward_product_rule_takes_the_wave_owned_kernels_and_equals_the_round
     aq, asf = lab.backward_qt_bf16(xq, xs, h, alpha)
     assert torch.equal(pq.view(torch.uint8).reshape(oq.shape), oq) and torch.equal(ps.view(torch.uint8).reshape(osf.shape), osf)
     assert torch.equal(aq, oq) and torch.equal(asf, osf)
+
+
+# ------------------------------------------------------------------------------------------------
+# [r4] mxfp4_transpose_mxfp8 with wave-owned output lines (mxfp4_transpose_mxfp8_tw_kernel): both unit shapes against the oracle
+# (quartet_bwd_sm120.cu mxfp4_transpose_mxfp8 kernel; oracle.mxfp4_transpose_mxfp8) and against the one-shot kernel, incl. padded rows.
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("variant", [4, 2, 128])
+@pytest.mark.parametrize("m,m_pad,n", [(128, 128, 256), (384, 384, 768), (200, 256, 512), (1, 128, 256), (129, 256, 1280), (2048, 2048, 2304)])
+def test_transposer_wave_owned_kernels_equal_the_oracle(q, variant, m, m_pad, n):
+    rng = np.random.default_rng(m * 7 + n + variant)
+    codes = rng.integers(0, 256, size=(m, n // 2), dtype=np.uint8)
+    scales = rng.integers(117, 137, size=(m, n // 32), dtype=np.uint8)
+    if m >= 64:
+        codes[32:64, : n // 4] = 0                      # an all-zero block along m for a quarter of the columns (amax = 0 -> e8m0 127)
+    with lab.forced(transpose_nc=variant):
+        y, sf = lab.mxfp4_transpose_mxfp8_rows(torch.from_numpy(codes).to(DEV), torch.from_numpy(scales).to(DEV), m, m_pad, n)
+    pc = np.zeros((m_pad, n // 2), np.uint8); pc[:m] = codes
+    ps = np.full((m_pad, n // 32), 127, np.uint8); ps[:m] = scales
+    ry, rs = oracle.mxfp4_transpose_mxfp8(pc, ps)
+    assert np.array_equal(_np(sf), np.asarray(rs).reshape(_np(sf).shape)), int((_np(sf) != np.asarray(rs).reshape(_np(sf).shape)).sum())
+    assert np.array_equal(_np(y), np.asarray(ry).reshape(_np(y).shape)), int((_np(y) != np.asarray(ry).reshape(_np(y).shape)).sum())
