@@ -82,8 +82,16 @@ int qutlass_amd_matmul_mxf8_bf16_tn(const void* A, const void* B, const void* A_
  * alpha and rounds to bf16 (deterministic; identical to the single-pass result whenever the fp32 partial sums are
  * exact, which is the regime the reference's equality tests run in).  qutlass_amd_gemm_splitk_workspace_bytes(ebits = 4
  * or 8, M, N, K) returns the bytes the split needs, 0 when the shape does not split; a NULL or smaller workspace
- * silently runs the single-pass kernel.  The workspace is used on `stream` for the duration of the call's kernels.
+ * silently runs the single-pass kernel.  The workspace is used on `stream` for the duration of the call's kernels and must be
+ * 16-byte aligned (the partials are written as 16-byte vectors; a misaligned pointer is rejected with QAMD_ERR_INVALID).
  * (The reference allocates and frees a CUTLASS workspace inside every call, gemm.cu:160-162.)
+ *
+ * Reproducibility.  Every entry point is deterministic: the same call on the same device returns the same bytes, run after run and
+ * under HIP-graph replay.  It is NOT bit-stable ACROSS entry points or devices for general data: whether a shape splits K depends on
+ * whether a workspace was passed and on the device's CU count (the plans scale with it), and a split sums the fp32 partials in a
+ * different order than the single pass -- the bf16 output can differ in its last bit.  Exact-regime operands (every partial sum
+ * exactly representable: the regime of the reference's own equality tests) give identical bytes on every path.  For one summation
+ * order everywhere call the entries without `_ws`.
  */
 int64_t qutlass_amd_gemm_splitk_workspace_bytes(int ebits, int64_t M, int64_t N, int64_t K);
 int qutlass_amd_matmul_mxf4_bf16_tn_ws(const void* A, const void* B, const void* A_sf, const void* B_sf,
@@ -199,6 +207,18 @@ int qutlass_amd_fused_quantize_matmul_mxf4_bf16_tn(const void* x, const void* h,
                                                    int64_t K, void* stream);
 
 /* ---- QAT-backward data preparation ------------------------------------- */
+
+/*
+ * Input contract of the four ops below (and of the forward quantizers): FINITE operands.  What the reference's kernels do with NaN / inf
+ * follows from the order of its fmaxf chains and is not a documented behaviour; here
+ *   - backward_t_bf16 / backward_qt_bf16 reproduce the reference's arithmetic for the cases its own data can reach (all-zero groups:
+ *     3 / 0 = inf, 0 * inf = NaN -> code 7; scales outside the division-free range take the reference's divisions), tests pin them;
+ *   - backward_bf16_square_double_mxfp8 and mxfp4_transpose_mxfp8 take the block maximum on sign-stripped bf16 bit patterns: a NaN or inf
+ *     element (or an input e8m0 byte of 255) becomes the block maximum, where an fmaxf chain would have skipped a NaN;
+ *   - an input e8m0 byte of 0 (2^-127: the dequantised bf16 operand is a denormal) is outside what the MFMA rotation reproduces exactly
+ *     (the matrix core flushes bf16 denormals); the forward quantizers never emit it for a non-zero group.
+ * All four are deterministic and bit-stable across devices (no plan depends on the CU count in a way that changes arithmetic order).
+ */
 
 /*
  * x: bf16 (B, N, M) row-major; h: bf16 32 x 32.  For every (b, m) and every 32-group g along N:

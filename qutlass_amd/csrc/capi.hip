@@ -950,11 +950,13 @@ int64_t qutlass_amd_gemm_splitk_workspace_bytes(int ebits, int64_t M, int64_t N,
 
 int qutlass_amd_matmul_mxf4_bf16_tn_ws(const void* A, const void* B, const void* A_sf, const void* B_sf, const float* alpha, void* D,
                                        int64_t M, int64_t N, int64_t K, void* workspace, int64_t workspace_bytes, void* stream) {
+  if (workspace && (uintptr_t)workspace % 16) return fail(QAMD_ERR_INVALID, "matmul_mxf4_bf16_tn: the workspace must be 16-byte aligned");   // v4f partials
   return gemm_mx<4>("matmul_mxf4_bf16_tn", A, B, A_sf, B_sf, alpha, D, M, N, K, stream, workspace, workspace_bytes);
 }
 
 int qutlass_amd_matmul_mxf8_bf16_tn_ws(const void* A, const void* B, const void* A_sf, const void* B_sf, const float* alpha, void* D,
                                        int64_t M, int64_t N, int64_t K, void* workspace, int64_t workspace_bytes, void* stream) {
+  if (workspace && (uintptr_t)workspace % 16) return fail(QAMD_ERR_INVALID, "matmul_mxf8_bf16_tn: the workspace must be 16-byte aligned");   // v4f partials
   return gemm_mx<8>("matmul_mxf8_bf16_tn", A, B, A_sf, B_sf, alpha, D, M, N, K, stream, workspace, workspace_bytes);
 }
 
