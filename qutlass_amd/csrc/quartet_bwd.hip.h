@@ -524,8 +524,13 @@ __global__ __launch_bounds__(256) void bwd_quant_tw_kernel(const BwdTParams p) {
     __builtin_amdgcn_wave_barrier();   // the LDS reads above are issued before the next unit's writes (in-order LDS): only the compiler needs the fence
   };
 
+  // (QT reads every e8m0 line once per XCD -- FETCH_SIZE 50.3 MB for 35.7 MB of input at 8192^2 -- because a row block's m-tiles go round the 8 XCDs with
+  // the workgroup ids.  Giving each XCD whole row blocks, as a contiguous eighth of the walk or block by block, brings FETCH_SIZE to 36.0 MB and is
+  // SLOWER, 26.6 -> 31.8 / 31.2 us cold: the two 64-byte halves of an output line then come from different L2s and WRITE_SIZE grows from 37.8 to
+  // 52.8 / 58.2 MB.  profiles/pmc_stream_ops_r4.txt, ab_bwd_r4s_xcd_eighths.txt, ab_bwd_r4t_xcd_rowblocks.txt.)
+  const uint32_t wg = blockIdx.x;
   Cur L;
-  L.u = uniform((int)(blockIdx.x * 4u + (uint32_t)wave));
+  L.u = uniform((int)(wg * 4u + (uint32_t)wave));
   decode(L);
   load_tile(0, L.u < U, L.m0, L.e0);
   while (L.u < U) {
@@ -645,6 +650,9 @@ __global__ __launch_bounds__(256) void mxfp4_transpose_mxfp8_kernel(const TrPara
   // [r3] NC = 128: a tile reads 64 of the 128 bytes of each of its input lines, the tile next to it (tj ^ 1) the other 64.  Workgroup ids go round
   // the 8 XCDs, so the two landed on different XCDs and each L2 fetched the whole line: FETCH_SIZE 82 MB for 35.6 MB of input at 8192^2
   // (profiles/pmc_stream_ops_r3.txt).  Pairs now sit on one XCD, one dispatch slot apart (tiles_n is even: n % 256 == 0).
+  // ([r4] The e8m0 lines of the input rows are still fetched once per XCD (FETCH_SIZE 50.3 MB for 35.7 MB at 8192^2); keeping a row block on one XCD
+  // removes that and costs more on the write side -- the 4 scale bytes a tile writes per output row share their line with 31 other row blocks, which then
+  // sit on 8 different L2s: WRITE_SIZE 69.4 -> 85.8 MB, 28.4 -> 28.9 / 29.2 us cold.  profiles/ab_transpose_r4{s,t}_*.txt, pmc_stream_ops_r4.txt.)
   unsigned t = blockIdx.x;
   if (NC == 128 && t < (gridDim.x & ~15u)) {
     const unsigned x = t & 7u, k = t >> 3;

@@ -47,6 +47,7 @@ PY
     configs) timeout 900 python bench_configs.py > $O/bench_configs.jsonl 2> $O/bench_configs.err; echo "configs rc=$?"; tail -30 $O/bench_configs.jsonl | cut -c1-240 ;;
     calibnv) timeout 900 python tools/calib_tiles.py nvf4 > $O/calib_tiles_nvf4.txt 2> $O/calib_tiles_nvf4.err; echo "calibnv rc=$?"; tail -5 $O/calib_tiles_nvf4.txt ;;
     abbwd)  timeout 600 python tools/ab_bwd.py > $O/ab_bwd.txt 2> $O/ab_bwd.err; echo "abbwd rc=$?"; cat $O/ab_bwd.txt; tail -3 $O/ab_bwd.err ;;
+    pmcstream) timeout 900 bash tools/pmc_stream_ops.sh qutlass_amd/libqutlass_amd.so $O/pmc_stream 8192 > $O/pmc_stream.log 2>&1; echo "pmcstream rc=$?"; tail -120 $O/pmc_stream.log ;;
     hbm)    timeout 600 python tools/hbm_ceilings.py > $O/hbm_ceilings.txt 2> $O/hbm_ceilings.err; echo "hbm rc=$?"; cat $O/hbm_ceilings.txt; tail -3 $O/hbm_ceilings.err ;;
     abtr)   timeout 600 python tools/ab_transpose.py > $O/ab_transpose.txt 2> $O/ab_transpose.err; echo "abtr rc=$?"; cat $O/ab_transpose.txt; tail -3 $O/ab_transpose.err ;;
     ablbwd) timeout 600 python tools/ab_bwd_abl.py > $O/ab_bwd_abl.txt 2> $O/ab_bwd_abl.err; echo "ablbwd rc=$?"; cat $O/ab_bwd_abl.txt; tail -3 $O/ab_bwd_abl.err ;;
