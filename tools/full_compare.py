@@ -1,0 +1,89 @@
+#!/usr/bin/env python3
+"""BASELINE.json configs[1], [2], [4] compared IN FULL ("C3/C5 full-size checks are sampled rows"; configs[3] has tools/full_compare_c4.py):
+every output of the GPU GEMM against the reference's own test method restated in oracle/dequant_matmul.py (tests/mxfp4_test.py:84-120: dequantise both
+operands, a_dq @ b_dq.T in fp64 on the host cores, cast to bf16, `out.equal(ref)`), not sampled rows.  MXFP4 is held to bit equality; MXFP8 products
+carry 8 significant bits, the fp32 accumulation order shows in the last place, and the tool reports the histogram of bf16-ulp distances (the
+reference's own MXFP8 test uses a tolerance, tests/mxfp8_test.py:88-96).  Test infrastructure; prints one JSON line per config.
+
+    python tools/full_compare.py [C2 C3 C5] > gpurun_out/full_compare.jsonl       (about a minute of host time on the GPU box)
+"""
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+
+
+def hadamard(n, device):
+    h = torch.ones(1, 1)
+    while h.shape[0] < n:
+        h = torch.cat([torch.cat([h, h], 1), torch.cat([h, -h], 1)], 0)
+    return (h * n ** -0.5).to(torch.bfloat16).to(device)
+
+
+def ulp_hist(got, ref):
+    """bf16 bit patterns as sign-magnitude integers -> |distance| histogram {0: n0, 1: n1, 2: n2, '>2': n}"""
+    def key(t):
+        v = t.view(torch.int16).to(torch.int32)
+        return torch.where(v < 0, -(v & 0x7fff), v)
+    d = (key(got) - key(ref)).abs()
+    return {"0": int((d == 0).sum()), "1": int((d == 1).sum()), "2": int((d == 2).sum()), ">2": int((d > 2).sum())}
+
+
+def main():
+    import qutlass_amd as q
+    from oracle import dequant_matmul as dm
+    from qutlass_amd.utils import to_blocked
+
+    which = [a for a in sys.argv[1:] if a in ("C2", "C3", "C5")] or ["C2", "C3", "C5"]
+    dev = torch.device("cuda", 0)
+    torch.set_num_threads(os.cpu_count() or 1)
+    h32 = hadamard(32, dev)
+    one = torch.tensor([1.0], device=dev)
+    rc = 0
+    for cfg in which:
+        torch.manual_seed({"C2": 2, "C3": 3, "C5": 5}[cfg])
+        m, n, k = (4096, 14336, 4096) if cfg == "C3" else (4096, 4096, 4096)
+        a = torch.randn(m, k, dtype=torch.bfloat16, device=dev) * 25.0
+        b = torch.randn(n, k, dtype=torch.bfloat16, device=dev) * 25.0
+        if cfg in ("C2", "C3"):
+            a_q, a_s = q.fusedQuantizeMx(a, h32, method="abs_max")
+            b_q, b_s = q.fusedQuantizeMx(b, h32, method="abs_max")
+            out = q.matmul_mxf4_bf16_tn(a_q, b_q, to_blocked(a_s), to_blocked(b_s), one)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            ref = dm.dequant_matmul_mxfp4(a_q.cpu(), a_s.cpu(), b_q.cpu(), b_s.cpu(), 1.0, torch.float64)
+            t1 = time.perf_counter()
+            got = out.cpu()
+            neq = int((got.view(torch.int16) != ref.view(torch.int16)).sum())
+            print(json.dumps({"config": f"{cfg} matmul_mxf4_bf16_tn {m}x{n}x{k}, operands = fusedQuantizeMx(H32, abs_max) of randn*25", "outputs_compared": m * n,
+                              "bit_mismatches_vs_fp64_dequant_matmul_oracle": neq, "equal": neq == 0, "oracle": "oracle/dequant_matmul.py dequant_matmul_mxfp4 (fp64, host cores)",
+                              "oracle_seconds": round(t1 - t0, 1), "host_threads": torch.get_num_threads()}), flush=True)
+            rc |= int(neq != 0)
+        else:
+            # MXFP8: the square-block quantiser of the QAT backward gives e4m3 data + e8m0 row scales for both operands (qutlass/__init__.py:282-297)
+            a_q, a_s, _ = q.backward_bf16_square_double_mxfp8(a)
+            b_q, b_s, _ = q.backward_bf16_square_double_mxfp8(b)
+            out = q.matmul_mxf8_bf16_tn(a_q, b_q, to_blocked(a_s), to_blocked(b_s), one)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            def dq(xq, xs):
+                x = xq.cpu().view(torch.float8_e4m3fn).to(torch.float64)
+                e = xs.cpu().view(torch.uint8).to(torch.float64)[: x.shape[0], : x.shape[1] // 32]
+                return x * torch.pow(torch.tensor(2.0, dtype=torch.float64), e - 127.0).repeat_interleave(32, dim=1)
+            ref = (dq(a_q, a_s) @ dq(b_q, b_s).T).to(torch.bfloat16)
+            t1 = time.perf_counter()
+            hist = ulp_hist(out.cpu(), ref)
+            print(json.dumps({"config": f"{cfg} matmul_mxf8_bf16_tn {m}x{n}x{k}, operands = backward_bf16_square_double_mxfp8 of randn*25 (e4m3 + e8m0 per 32)", "outputs_compared": m * n,
+                              "bf16_ulp_distance_histogram_vs_fp64_dequant_matmul": hist, "within_1_ulp": hist["2"] + hist[">2"] == 0,
+                              "oracle_seconds": round(t1 - t0, 1), "host_threads": torch.get_num_threads()}), flush=True)
+            rc |= int(hist["2"] + hist[">2"] != 0)
+        del a, b
+    return rc
+
+
+if __name__ == "__main__":
+    sys.exit(main())

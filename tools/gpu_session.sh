@@ -13,7 +13,10 @@
 #   configs   bench_configs.py                                abmx      tools/ab_mxsk.py (MX persistent kernels: balanced / heterogeneous / stream-K)
 #   calibnv   tools/calib_tiles.py nvf4 (forced tile candidates on the training grid of the NVFP4 tile rule)
 #   abbwd     tools/ab_bwd.py (backward_t / backward_qt: wave-owned-lines kernel vs the round-3 kernel)     testbwd   the GPU tests of the QAT-backward ops
-#   stream    tools/ab_stream_ops.py-style timing of the streaming ops (bench_configs.py --only stream)
+#   ablbwd    tools/ab_bwd_abl.py (where the time of the wave-owned backward kernel goes: loads / stores / arithmetic left out in turn)
+#   abtr      tools/ab_transpose.py (mxfp4_transpose_mxfp8: one-shot kernel vs the wave-owned-lines kernels)
+#   pmcstream tools/pmc_stream_ops.sh (SQ / TCC counters of the streaming ops at 8192^2)            hbm   tools/hbm_ceilings.py (trivial kernels at the ops' read : write mixes)
+#   fullcmp   tools/full_compare.py (configs C2, C3, C5: every output against the fp64 dequant-matmul oracle)
 cd ${GRAFT_REPO_ROOT:-.}
 NAME=${1:?session name}; shift
 O=gpurun_out/$NAME; mkdir -p $O
@@ -47,6 +50,7 @@ PY
     configs) timeout 900 python bench_configs.py > $O/bench_configs.jsonl 2> $O/bench_configs.err; echo "configs rc=$?"; tail -30 $O/bench_configs.jsonl | cut -c1-240 ;;
     calibnv) timeout 900 python tools/calib_tiles.py nvf4 > $O/calib_tiles_nvf4.txt 2> $O/calib_tiles_nvf4.err; echo "calibnv rc=$?"; tail -5 $O/calib_tiles_nvf4.txt ;;
     abbwd)  timeout 600 python tools/ab_bwd.py > $O/ab_bwd.txt 2> $O/ab_bwd.err; echo "abbwd rc=$?"; cat $O/ab_bwd.txt; tail -3 $O/ab_bwd.err ;;
+    fullcmp) timeout 900 python tools/full_compare.py > $O/full_compare.jsonl 2> $O/full_compare.err; echo "fullcmp rc=$?"; cat $O/full_compare.jsonl; tail -3 $O/full_compare.err ;;
     pmcstream) timeout 900 bash tools/pmc_stream_ops.sh qutlass_amd/libqutlass_amd.so $O/pmc_stream 8192 > $O/pmc_stream.log 2>&1; echo "pmcstream rc=$?"; tail -120 $O/pmc_stream.log ;;
     hbm)    timeout 600 python tools/hbm_ceilings.py > $O/hbm_ceilings.txt 2> $O/hbm_ceilings.err; echo "hbm rc=$?"; cat $O/hbm_ceilings.txt; tail -3 $O/hbm_ceilings.err ;;
     abtr)   timeout 600 python tools/ab_transpose.py > $O/ab_transpose.txt 2> $O/ab_transpose.err; echo "abtr rc=$?"; cat $O/ab_transpose.txt; tail -3 $O/ab_transpose.err ;;
