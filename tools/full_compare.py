@@ -2,8 +2,8 @@
 """BASELINE.json configs[1], [2], [4] compared IN FULL ("C3/C5 full-size checks are sampled rows"; configs[3] has tools/full_compare_c4.py):
 every output of the GPU GEMM against the reference's own test method restated in oracle/dequant_matmul.py (tests/mxfp4_test.py:84-120: dequantise both
 operands, a_dq @ b_dq.T in fp64 on the host cores, cast to bf16, `out.equal(ref)`), not sampled rows.  MXFP4 is held to bit equality; MXFP8 products
-carry 8 significant bits, the fp32 accumulation order shows in the last place, and the tool reports the histogram of bf16-ulp distances (the
-reference's own MXFP8 test uses a tolerance, tests/mxfp8_test.py:88-96).  Test infrastructure; prints one JSON line per config.
+carry 8 significant bits, the fp32 accumulation order shows in the last place (and in many ulps of outputs that cancel to near zero): the tool applies the
+reference's own criterion (assert_close atol = rtol = 1e-1, tests/mxfp8_test.py:75), an error bound in units of sum |a_k b_k|, and prints the bf16-ulp histogram.  Test infrastructure; prints one JSON line per config.
 
     python tools/full_compare.py [C2 C3 C5] > gpurun_out/full_compare.jsonl       (about a minute of host time on the GPU box)
 """
@@ -74,13 +74,22 @@ def main():
                 x = xq.cpu().view(torch.float8_e4m3fn).to(torch.float64)
                 e = xs.cpu().view(torch.uint8).to(torch.float64)[: x.shape[0], : x.shape[1] // 32]
                 return x * torch.pow(torch.tensor(2.0, dtype=torch.float64), e - 127.0).repeat_interleave(32, dim=1)
-            ref = (dq(a_q, a_s) @ dq(b_q, b_s).T).to(torch.bfloat16)
+            ad, bd = dq(a_q, a_s), dq(b_q, b_s)
+            ref64 = ad @ bd.T
+            mass = ad.abs() @ bd.abs().T            # sum_k |a_k b_k|: what fp32 accumulation error scales with (cancelling outputs have many ulps of it)
             t1 = time.perf_counter()
-            hist = ulp_hist(out.cpu(), ref)
+            got = out.cpu()
+            ref = ref64.to(torch.bfloat16)
+            hist = ulp_hist(got, ref)
+            err = (got.to(torch.float64) - ref64).abs()
+            viol = int((err > 1e-1 + 1e-1 * ref64.abs()).sum())           # the reference's criterion: assert_close(atol=1e-1, rtol=1e-1), tests/mxfp8_test.py:75
+            beyond = int((err > 2.0 ** -8 * ref64.abs() + 2.0 ** -20 * mass).sum())   # half a bf16 ulp of the result + 4096 fp32 roundings of the mass (2^-24 each, x 16)
             print(json.dumps({"config": f"{cfg} matmul_mxf8_bf16_tn {m}x{n}x{k}, operands = backward_bf16_square_double_mxfp8 of randn*25 (e4m3 + e8m0 per 32)", "outputs_compared": m * n,
-                              "bf16_ulp_distance_histogram_vs_fp64_dequant_matmul": hist, "within_1_ulp": hist["2"] + hist[">2"] == 0,
+                              "violations_of_the_reference_tolerance_atol_rtol_1e-1": viol,
+                              "outputs_beyond_half_bf16_ulp_plus_2^-20_of_sum_abs_products": beyond, "max_abs_err_over_sum_abs_products": float((err / mass.clamp_min(1e-300)).max()),
+                              "bf16_ulp_distance_histogram_vs_fp64_dequant_matmul": hist,
                               "oracle_seconds": round(t1 - t0, 1), "host_threads": torch.get_num_threads()}), flush=True)
-            rc |= int(hist["2"] + hist[">2"] != 0)
+            rc |= int(viol != 0 or beyond != 0)
         del a, b
     return rc
 
