@@ -330,23 +330,7 @@ __global__ __launch_bounds__(256) void bwd_quant_tw_kernel(const BwdTParams p) {
   const int n_o = (G + NG - 1) / NG, n_i = p.tiles_m;
   const uint32_t OOB = 0x80000000u;
 
-  v8bf hf[2];
-  {   // hT[j][k] = h[k][j], staged in the first wave's tile area and read once
-    char* hT = tile_s[0];
-    uint16_t hv[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) hv[i] = p.h[i * 256 + tid];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int idx = i * 256 + tid, k = idx >> 5, j = idx & 31;
-      *(uint16_t*)(hT + j * HROW + k * 2) = hv[i];
-    }
-    __syncthreads();
-#pragma unroll
-    for (int kc = 0; kc < 2; ++kc) hf[kc] = *(const v8bf*)(hT + row * HROW + (kc * 16 + half * 8) * 2);
-    __syncthreads();
-  }
-
+  v8bf hf[2];     // H^T fragments of the lane: filled below, after the first tile's loads are out
   const uint32_t rowb = QT ? (uint32_t)p.M >> 1 : (uint32_t)p.M * 2u;   // input row stride in bytes
   const int lcol = QT ? (lane & 1) * 32 : (lane & 7) * 8;
   const uint32_t ld_off = QT ? (uint32_t)(lane >> 1) * rowb + (uint32_t)(lane & 1) * 16u : (uint32_t)(lane >> 3) * rowb + (uint32_t)(lane & 7) * 16u;
@@ -533,6 +517,23 @@ __global__ __launch_bounds__(256) void bwd_quant_tw_kernel(const BwdTParams p) {
   L.u = uniform((int)(wg * 4u + (uint32_t)wave));
   decode(L);
   load_tile(0, L.u < U, L.m0, L.e0);
+  // (the first tile's rows are in flight while H is staged: the two memory round trips overlap, as in fused_quantize_kernel)
+  {   // hT[j][k] = h[k][j], staged in the first wave's tile area and read once
+    char* hT = tile_s[0];
+    uint16_t hv[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) hv[i] = p.h[i * 256 + tid];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int idx = i * 256 + tid, k = idx >> 5, j = idx & 31;
+      *(uint16_t*)(hT + j * HROW + k * 2) = hv[i];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kc = 0; kc < 2; ++kc) hf[kc] = *(const v8bf*)(hT + row * HROW + (kc * 16 + half * 8) * 2);
+    __syncthreads();
+  }
+
   while (L.u < U) {
     const int k = L.k, ng = L.ng, b = L.b, g0 = L.g0, m0 = L.m0;
     stage(0);
