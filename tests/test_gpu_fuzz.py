@@ -267,3 +267,38 @@ def test_fuzz_persistent_deep_kernels(q):
             got = oracle.bf16_bits_to_f32(_np(out[ri])).astype(np.float64)
             want = oracle.bf16_bits_to_f32(ref).astype(np.float64)
             assert (np.abs(got - want) <= np.abs(want) / 128.0 + 1e-4 * np.abs(want).max()).all(), (it, m, n, k, e5)
+
+
+def test_fuzz_round4_kernels(q):
+    """[r4] The kernels that only large tensors reach through the product rules, forced through the lab build on small random shapes:
+    the persistent NVFP4 kernel (nvf4_variant 42: ragged M / N, any K % 256 == 0, 1-3 tiles per workgroup; sampled rows against the oracle)
+    and the wave-owned backward quantizers (bwd_variant 2 / 3: must return the bytes of the product path, which the test above holds to the oracle)."""
+    from qutlass_amd.utils import to_blocked
+
+    rng = np.random.default_rng(108 + 1000 * SEED)
+    e4 = torch.float8_e4m3fn
+    for it in range(6):
+        m, n = int(rng.integers(1, 700)), int(rng.integers(1, 90)) * 8
+        k = int(rng.integers(2, 8)) * 256
+        a, b = _rand_codes(rng, m, k // 2), _rand_codes(rng, n, k // 2)
+        sa = torch.from_numpy(rng.integers(0x30, 0x48, size=(m, k // 16), dtype=np.uint8)).to(DEV)
+        sb = torch.from_numpy(rng.integers(0x30, 0x48, size=(n, k // 16), dtype=np.uint8)).to(DEV)
+        al = float(rng.choice([1.0, 0.5, 0.1875]))
+        with lab.forced(nvf4_variant=42):
+            out = lab.matmul_nvf4_bf16_tn(a, b, to_blocked(sa.view(e4)), to_blocked(sb.view(e4)), torch.tensor([al], device=DEV))
+        rows = sorted(set([0, m - 1, min(m - 1, 255), min(m - 1, 256)] + [int(r) for r in rng.integers(0, m, 12)]))
+        ref = oracle.gemm_blockscaled(oracle.KIND_NVFP4, _np(a)[rows], _np(b), oracle.to_blocked(_np(sa)[rows]), oracle.to_blocked(_np(sb)), al, len(rows), n, k)
+        assert np.array_equal(_np(out)[rows], ref), ("nvf4 persistent", it, m, n, k, int((_np(out)[rows] != ref).sum()))
+    h = _hadamard(32)
+    for it in range(8):
+        B, N, M = int(rng.integers(1, 3)), int(rng.integers(1, 24)) * 32, int(rng.integers(1, 30)) * 32
+        x = torch.from_numpy(rng.standard_normal((B, N, M)).astype(np.float32) * 25.0).to(torch.bfloat16).to(DEV)
+        xq = torch.from_numpy(rng.integers(0, 256, size=(B, N, M // 2), dtype=np.uint8)).to(DEV)
+        xs = torch.from_numpy(rng.integers(112, 142, size=(B, N, M // 32), dtype=np.uint8)).to(DEV)
+        alpha = torch.tensor([float(np.float32(rng.uniform(0.05, 20.0)))], device=DEV)
+        t0, q0 = q.backward_t_bf16(x, h), q.backward_qt_bf16(xq, xs.view(torch.float8_e8m0fnu), h, alpha)
+        for v in (2, 3):
+            with lab.forced(bwd_variant=v):
+                t1, q1 = lab.backward_t_bf16(x, h), lab.backward_qt_bf16(xq, xs, h, alpha)
+            for got, want in zip(t1 + q1, t0 + q0):
+                assert torch.equal(got.reshape(-1), want.view(torch.uint8).reshape(-1)), ("bwd", v, it, B, N, M)
