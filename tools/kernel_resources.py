@@ -18,7 +18,7 @@ from concurrent.futures import ThreadPoolExecutor
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "qutlass_amd", "csrc", "capi.hip")
 sys.path.insert(0, ROOT)
-from qutlass_amd.build import TU_FLAGS  # noqa: E402  (per-unit compiler flags of the product build)
+from qutlass_amd.build import TU_FLAGS, UNITS, UNITS_BENCH  # noqa: E402  (translation units and per-unit compiler flags of the build)
 FIELDS = {"TotalSGPRs": "sgpr", "VGPRs": "vgpr", "AGPRs": "agpr", "ScratchSize [bytes/lane]": "scratch", "Occupancy [waves/SIMD]": "occ",
           "SGPRs Spill": "sgpr_spill", "VGPRs Spill": "vgpr_spill", "LDS Size [bytes/block]": "lds"}
 
@@ -48,9 +48,9 @@ def unit(tu: int, lab: bool):
 
 
 def collect(lab: bool = False):
-    n = 7 if lab else 5
-    with ThreadPoolExecutor(max_workers=min(n, os.cpu_count() or 1)) as ex:
-        parts = list(ex.map(lambda t: unit(t, lab), range(1, n + 1)))
+    units = UNITS_BENCH if lab else UNITS          # the translation units of the build itself (qutlass_amd/build.py): unit 8 = the persistent NVFP4 kernel
+    with ThreadPoolExecutor(max_workers=min(len(units), os.cpu_count() or 1)) as ex:
+        parts = list(ex.map(lambda t: unit(t, lab), units))
     allk = {}
     for p in parts:
         allk.update(p)
