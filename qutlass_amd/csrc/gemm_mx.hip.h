@@ -138,10 +138,13 @@ struct GemmCtx {
   v16f acc[MT][NT];
   v8i fa[KSL][MT], fb[KSL][NT];   // only the slices a schedule keeps live are materialised
   int sa[MT], sb[NT];
+  float alpha_k;   // [r4] alpha[0], fetched by the constructor: loaded where the epilogue starts, its memory round trip sat on the critical path of every
+                   // per-tile workgroup (a 5-20 us kernel paid ~0.5 us for one scalar)
 
   // bid: linear tile id (the workgroup id of a plain launch).  fm0 / fn0 >= 0: the tile's origin is given instead (residual
   // tiles of a heterogeneous launch, gemm_mx_deepp.hip.h: any 128-aligned origin inside the output).
   __device__ __forceinline__ GemmCtx(char* smem_, const GemmParams& p_, int bid = (int)blockIdx.x, int fm0 = -1, int fn0 = -1) : smem(smem_), p(p_) {
+    alpha_k = *p.alpha;     // (issued here: the ISA keeps the s_load in the prologue, tools/kernel_resources.py-style check in tests)
     tid = threadIdx.x;
     lane = tid & 63;
     wave = uniform(tid >> 6);
@@ -390,7 +393,7 @@ struct GemmCtx {
   //      other sectors of each 128-byte line follow from the same wave within a few instructions (L2 merges them).
   //      No LDS, no barrier: the stage buffers stay free for the next tile of a persistent loop.
   __device__ __forceinline__ void epilogue_direct() {
-    const float alpha = *p.alpha;
+    const float alpha = alpha_k;
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
       const int grow = m0 + wave_m * C::WTM + 32 * m + i32;
@@ -485,7 +488,7 @@ struct GemmCtx {
     const int arrived = uniform(*(volatile int*)smem);
     if (arrived != p.splits) return;
     // ---- last arrival: D tile = bf16(alpha * sum_z partial[z]) ----------------------------------------------------------
-    const float alpha = *p.alpha;
+    const float alpha = alpha_k;
     constexpr int QPR = C::BN / 4;                 // float4 per tile row
     constexpr int RPP = C::THREADS / QPR;          // rows per pass
     constexpr int NPASS = C::BM / RPP;
@@ -539,7 +542,7 @@ struct GemmCtx {
       if (s == 123456.789f) p.D[tid] = 1;
       return;
     }
-    const float alpha = *p.alpha;
+    const float alpha = alpha_k;
     __syncthreads();
 #pragma unroll
     for (int m = 0; m < MT; ++m)
@@ -753,6 +756,7 @@ __device__ __forceinline__ void gemm_mx_ringp(char* smem, const GemmParams& p, i
 
 #pragma unroll
   for (int s = 0; s < D - 1; ++s) issue(kt0 + s, s);
+  asm volatile("" :: "s"(cx.alpha_k));   // alpha is waited for HERE, behind the first stages' DMA (left alone, its load is sunk to the epilogue)
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 2) * LPS) : "memory");   // stage kt0 landed
   __builtin_amdgcn_s_barrier();
   fence();

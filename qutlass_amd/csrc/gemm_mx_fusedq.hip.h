@@ -45,6 +45,7 @@ __global__ __launch_bounds__(NWAVES * 64) void gemm_mx_fusedq_kernel(const Fused
   constexpr int NPASS = 8 / GPS;        // rotation tiles per 256-element segment
   constexpr int CROW = 8 * 16 + 16;     // staged code row: 8 groups x 16 bytes + pad
   __shared__ __attribute__((aligned(16))) float part[NWAVES][32][33];
+  const float alpha_k = *p.alpha;     // [r4] fetched here, not behind the K loop: the decode kernels last 4-6 us and this is a memory round trip
   constexpr int HROW = 32 * 2 + 16;   // padded H^T row stride (bytes), as in quantize.hip.h
   __shared__ __attribute__((aligned(16))) char hT[32 * HROW];
   __shared__ __attribute__((aligned(16))) char cs_all[NWAVES][VR * CROW];      // codes of one segment: [row][group][16]
@@ -98,6 +99,7 @@ __global__ __launch_bounds__(NWAVES * 64) void gemm_mx_fusedq_kernel(const Fused
   int s = wave;
   load_b(s);
   load_x(s);
+  asm volatile("" :: "s"(alpha_k));   // alpha is waited for HERE, behind the first loads (left alone, its load is sunk below the K loop)
 
   // ---- H^T image in LDS (hT[j][k] = h[k][j]), then this lane's two MFMA fragments into registers -----------------------------
   if (tid < 256) {
@@ -209,7 +211,7 @@ __global__ __launch_bounds__(NWAVES * 64) void gemm_mx_fusedq_kernel(const Fused
 #pragma unroll
     for (int e = 0; e < 4; ++e) part[wave][i32][8 * q + 4 * g + e] = acc[4 * q + e];
   __syncthreads();
-  const float alpha = *p.alpha;
+  const float alpha = alpha_k;
   for (int idx = tid; idx < 32 * 8; idx += NWAVES * 64) {
     const int m = idx >> 3, nq = (idx & 7) * 4;
     float sm[4] = {0.f, 0.f, 0.f, 0.f};

@@ -33,6 +33,7 @@ struct SkinnyParams {
 template <bool SWZ, int NWAVES, int SEG = 2, bool MAP2 = false>   // SEG: 128-byte row segments (256 K elements) per wave per trip
 __global__ __launch_bounds__(NWAVES * 64) void gemm_mx_skinny_kernel(const SkinnyParams p) {
   __shared__ __attribute__((aligned(16))) float part[NWAVES][32][33];
+  const float alpha_k = *p.alpha;     // [r4] fetched here, not behind the K loop: the decode kernels last 4-6 us and this is a memory round trip
 
   const int tid = threadIdx.x, lane = tid & 63, wave = uniform(tid >> 6);
   const int i32 = lane & 31, g = lane >> 5;
@@ -103,6 +104,7 @@ __global__ __launch_bounds__(NWAVES * 64) void gemm_mx_skinny_kernel(const Skinn
         sb[u][1] = sb[u][0];
       }
     }
+    asm volatile("" :: "s"(alpha_k));   // alpha is waited for HERE, behind the operand loads just issued (left alone, its load is sunk below the loop)
 #pragma unroll
     for (int u = 0; u < SEG; ++u) {
 #pragma unroll
@@ -131,7 +133,7 @@ __global__ __launch_bounds__(NWAVES * 64) void gemm_mx_skinny_kernel(const Skinn
 #pragma unroll
     for (int e = 0; e < 4; ++e) part[wave][i32][8 * q + 4 * g + e] = acc[4 * q + e];
   __syncthreads();
-  const float alpha = *p.alpha;
+  const float alpha = alpha_k;
   for (int idx = tid; idx < 32 * 8; idx += NWAVES * 64) {   // 32 rows x 8 quads of 4 columns
     const int m = idx >> 3, nq = (idx & 7) * 4;
     float s[4] = {0.f, 0.f, 0.f, 0.f};

@@ -89,6 +89,7 @@ template <class C, bool SPLIT = false, bool FENCED = false>
 __global__ __launch_bounds__(C::THREADS) void gemm_nvf4_kernel(const NvGemmParams p) {
   constexpr int BM = C::BM, BN = C::BN, MT = C::MT, NT = C::NT;
   __shared__ __attribute__((aligned(16))) char smem[C::LDS_BYTES];
+  const float alpha_k = SPLIT ? 1.0f : *p.alpha;       // [r4] fetched here, not where the epilogue starts (a memory round trip on every workgroup's critical path)
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -277,6 +278,7 @@ __global__ __launch_bounds__(C::THREADS) void gemm_nvf4_kernel(const NvGemmParam
 
   const int kt_begin = SPLIT ? z * p.kt_per : 0, kt_end = SPLIT ? min(KT, kt_begin + p.kt_per) : KT;   // (kt_per is even: a range starts on buffer 0)
   issue_stage(kt_begin, 0);
+  asm volatile("" :: "s"(alpha_k));   // alpha is waited for HERE, behind the first stage's DMA (left alone, its load is sunk to the epilogue)
   for (int kt = kt_begin; kt < kt_end; ++kt) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -330,7 +332,7 @@ __global__ __launch_bounds__(C::THREADS) void gemm_nvf4_kernel(const NvGemmParam
     }
     return;
   }
-  const float alpha = *p.alpha;
+  const float alpha = alpha_k;
   __syncthreads();
   // the epilogue re-derives lane / thread id (v_mbcnt) instead of keeping them live across the K loop: with 256 accumulators
   // + two fragment sets the 256x256 tile is at the 256-VGPR limit and the three id registers were spilled to scratch
@@ -405,6 +407,7 @@ template <class C>
 __global__ __launch_bounds__(C::THREADS) void gemm_nvf4_lds_kernel(const NvGemmParams p) {
   constexpr int BM = C::BM, BN = C::BN, MT = C::MT, NT = C::NT;
   __shared__ __attribute__((aligned(16))) char smem[C::LDS_BYTES];
+  const float alpha_k = *p.alpha;     // [r4] fetched here, not where the epilogue starts
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -538,6 +541,7 @@ __global__ __launch_bounds__(C::THREADS) void gemm_nvf4_lds_kernel(const NvGemmP
   NvPacked P0, P1;
   load_stage(0, P0);
   load_stage(1, P1);
+  asm volatile("" :: "s"(alpha_k));   // alpha is waited for HERE, behind the first loads
   asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
   convert_part(P0, 0, 0, 0, 8);
   load_stage(2, P0);
@@ -557,7 +561,7 @@ __global__ __launch_bounds__(C::THREADS) void gemm_nvf4_lds_kernel(const NvGemmP
     p.dbg[2] = (uint32_t)KT;
   }
 
-  const float alpha = *p.alpha;
+  const float alpha = alpha_k;
 #pragma unroll
   for (int m = 0; m < MT; ++m)
 #pragma unroll
@@ -598,6 +602,7 @@ __global__ __launch_bounds__(C::THREADS) void gemm_nvf4_lds_kernel(const NvGemmP
 template <int NWAVES>
 __global__ __launch_bounds__(NWAVES * 64) void gemm_nvf4_skinny_kernel(const NvGemmParams p) {
   __shared__ __attribute__((aligned(16))) float part[NWAVES][32][33];
+  const float alpha_k = *p.alpha;     // [r4] fetched here, not behind the K loop (decode shapes: a 5-10 us kernel)
   const int tid = threadIdx.x, lane = tid & 63, wave = uniform(tid >> 6);
   const int i32 = lane & 31, g = lane >> 5;
   const int n0 = blockIdx.x * 32, m0 = blockIdx.y * 32;
@@ -637,6 +642,7 @@ __global__ __launch_bounds__(NWAVES * 64) void gemm_nvf4_skinny_kernel(const NvG
       da[jj] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rSA, soffA + so, 0, 0);
       db[jj] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rSB, soffB + so, 0, 0);
     }
+    asm volatile("" :: "s"(alpha_k));   // alpha is waited for HERE, behind the operand loads just issued (left alone, its load is sunk below the loop)
 #pragma unroll
     for (int jj = 0; jj < 2; ++jj) {
       // groups past K inside the last tile (K % 64 == 32): mask their scale bytes
@@ -664,7 +670,7 @@ __global__ __launch_bounds__(NWAVES * 64) void gemm_nvf4_skinny_kernel(const NvG
 #pragma unroll
     for (int e = 0; e < 4; ++e) part[wave][i32][8 * q + 4 * g + e] = acc[4 * q + e];
   __syncthreads();
-  const float alpha = *p.alpha;
+  const float alpha = alpha_k;
   for (int idx = tid; idx < 32 * 8; idx += NWAVES * 64) {
     const int m = idx >> 3, nq = (idx & 7) * 4;
     float sum[4] = {0.f, 0.f, 0.f, 0.f};
