@@ -511,7 +511,9 @@ __global__ __launch_bounds__(256) void bwd_quant_tw_kernel(const BwdTParams p) {
   // (QT reads every e8m0 line once per XCD -- FETCH_SIZE 50.3 MB for 35.7 MB of input at 8192^2 -- because a row block's m-tiles go round the 8 XCDs with
   // the workgroup ids.  Giving each XCD whole row blocks, as a contiguous eighth of the walk or block by block, brings FETCH_SIZE to 36.0 MB and is
   // SLOWER, 26.6 -> 31.8 / 31.2 us cold: the two 64-byte halves of an output line then come from different L2s and WRITE_SIZE grows from 37.8 to
-  // 52.8 / 58.2 MB.  profiles/pmc_stream_ops_r4.txt, ab_bwd_r4s_xcd_eighths.txt, ab_bwd_r4t_xcd_rowblocks.txt.)
+  // 52.8 / 58.2 MB.  A third order that keeps the line-sharing workgroups AND the two group blocks of an output line together in one XCD's dispatch
+  // order leaves cold loads where they were (14.1 us: not byte-bound) and slows the stores (12.2 -> 13.4 us).  profiles/pmc_stream_ops_r4.txt,
+  // ab_bwd_r4s_xcd_eighths.txt, ab_bwd_r4t_xcd_rowblocks.txt, ab_bwd_abl_r4aa_superblock_order.txt.)
   const uint32_t wg = blockIdx.x;
   Cur L;
   L.u = uniform((int)(wg * 4u + (uint32_t)wave));
