@@ -1401,8 +1401,20 @@ int qutlass_amd_backward_bf16_square_double_mxfp8_rows(const void* x, int64_t m,
   if (m_pad >= (1ll << 31) || n >= (1ll << 31) || (m_pad / 128) * (n / 128) >= (1ll << 31)) return fail(QAMD_ERR_INVALID, "%s: tensor too large", name);
   SqParams p;
   p.x = (const uint16_t*)x; p.y = (uint8_t*)y; p.row_sf = (uint8_t*)row_scales; p.col_sf = (uint8_t*)col_scales;
-  p.m = (int)m; p.n = (int)n; p.m_pad = (int)m_pad;
-  hipLaunchKernelGGL(bwd_square_double_mxfp8_kernel<>, dim3((unsigned)((m_pad / 128) * (n / 128))), dim3(256), 0, (hipStream_t)stream, p);
+  p.m = (int)m; p.n = (int)n; p.m_pad = (int)m_pad; p.abl = opt_bwd_variant() >> 4;
+  // [r4] 512 columns per workgroup (16 waves: the row scales leave as 16-byte pieces) when that still gives every CU a workgroup; lab: option
+  // "transpose_nc" = 1 forces the 4-wave form, 4 / 8 the 512- / 1024-column forms
+  {
+    const int64_t rb = m_pad / 128, cu = chip_cus();
+    int ct = (n % 512 == 0 && rb * (n / 512) >= cu) ? 4 : 1;   // (1024 columns, two tiles per wave: slower again except warm at 8192^2 -- profiles/ab_sq_abl_r4ae.txt)
+#if QAMD_BENCH
+    if (opt_transpose_nc() == 1) ct = 1;
+    if ((opt_transpose_nc() == 8 && n % 1024 == 0) || (opt_transpose_nc() == 4 && n % 512 == 0)) ct = opt_transpose_nc();
+    if (ct == 8) { hipLaunchKernelGGL((bwd_square_double_mxfp8_kernel<4, 2>), dim3((unsigned)(rb * (n / 1024))), dim3(1024), 0, (hipStream_t)stream, p); return check_launch("bwd_square_double_mxfp8_kernel"); }
+#endif
+    if (ct == 4) hipLaunchKernelGGL((bwd_square_double_mxfp8_kernel<4, 1>), dim3((unsigned)(rb * (n / 512))), dim3(1024), 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL((bwd_square_double_mxfp8_kernel<1, 1>), dim3((unsigned)(rb * (n / 128))), dim3(256), 0, (hipStream_t)stream, p);
+  }
   return check_launch("bwd_square_double_mxfp8_kernel");
 }
 

@@ -559,6 +559,7 @@ struct SqParams {
   int m, n;            // m: rows of x that exist; n a multiple of 128 (host-checked)
   int m_pad;           // rows of the outputs, a multiple of 128 >= m: rows m .. m_pad-1 are treated as zeros IN the kernel ([r3]: the
                        // reference pads x with torch.nn.functional.pad first, qutlass/__init__.py:288-290 -- a full extra copy of the operand)
+  int abl;             // lab build only: leave out 1 = the row-scale stores, 2 = the column-scale stores, 4 = the data stores
 };
 
 // exponent byte of encode_e8m0_shiftm8 (quartet_bwd_sm120.cu:503-509): amax is a bf16 value held in fp32
@@ -567,59 +568,82 @@ __device__ __forceinline__ uint32_t e8m0_shift7(float amax) {
 }
 __device__ __forceinline__ float e8m0_scale(uint32_t e) { return __uint_as_float(e ? (e << 23) : 0x00400000u); }
 
-template <int UNIT = 0>   // (a template only so that the kernel is emitted by the one translation unit that launches it)
-__global__ __launch_bounds__(256) void bwd_square_double_mxfp8_kernel(const SqParams p) {
-  __shared__ uint8_t es[4][4];   // [wave = row block][column block]
-  const int tid = threadIdx.x, lane = tid & 63, wave = uniform(tid >> 6);
-  const int tiles_n = p.n >> 7;
+// [r4] WC = column tiles per workgroup (4 WC waves): the row scales of a workgroup leave as 4 WC contiguous bytes per row.  The 4 MB of scale bytes cost the
+// WC = 1 form 15 % of its time as 4-byte stores into as many different lines (8192^2 cold 46.8 us, 40.1 without them, the row scales 4.9 of the 6.8:
+// profiles/ab_sq_abl_r4ab.txt); walking a 4-wave workgroup along n instead (row dwords collected in registers) lost more in occupancy than it saved
+// (profiles/ab_sq_abl_r4ac_walk.txt).
+template <int WC = 1, int TPW = 1>   // WC column tiles side by side (4 waves each), TPW tiles per wave one after the other: 128 WC TPW columns per workgroup
+__global__ __launch_bounds__(256 * WC) void bwd_square_double_mxfp8_kernel(const SqParams p) {
+  constexpr int CT = WC * TPW;                                     // column tiles per workgroup
+  static_assert(CT == 1 || CT == 4 || CT == 8, "row pieces of 4, 16 or 32 bytes");
+  __shared__ __attribute__((aligned(16))) uint8_t es[4][4 * CT];   // [row block][column block]
+  const int tid = threadIdx.x, lane = tid & 63, wv = uniform(tid >> 6), wave = wv & 3, wcol = wv >> 2;
+  const int tiles_n = p.n / (128 * CT);
   const int ti = blockIdx.x / tiles_n, tj = blockIdx.x % tiles_n;
-  const int r0 = ti * 128 + wave * 32, c0 = tj * 128;
+  const int r0 = ti * 128 + wave * 32;
   // lane -> row lane/16 (+4 per pass), 16-byte chunk lane%16 (8 columns); column block j = (lane%16)/4
   const int lr = lane >> 4, lc = (lane & 15) * 8;
-  v4i v[8];
   // [r3] block maximum on the packed bf16 bit patterns (sign stripped, v_pk_max_u16: 2 instructions per dword instead of 3; NaN inputs excepted, the order
   // of the patterns is the order of the magnitudes)
   typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
-  u16x2 mx = {0, 0};
+  v4i v[TPW][8];
 #pragma unroll
-  for (int ps = 0; ps < 8; ++ps) {
-    const int row = r0 + ps * 4 + lr;
-    v[ps] = row < p.m ? *(const v4i*)(p.x + (int64_t)row * p.n + c0 + lc) : v4i{0, 0, 0, 0};
+  for (int tp = 0; tp < TPW; ++tp) {      // all loads of the wave first
+    const int c0 = (tj * CT + wcol * TPW + tp) * 128;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) mx = __builtin_elementwise_max(mx, __builtin_bit_cast(u16x2, (uint32_t)v[ps][q] & 0x7fff7fffu));
+    for (int ps = 0; ps < 8; ++ps) {
+      const int row = r0 + ps * 4 + lr;
+      v[tp][ps] = row < p.m ? *(const v4i*)(p.x + (int64_t)row * p.n + c0 + lc) : v4i{0, 0, 0, 0};
+    }
   }
-  float amax = __uint_as_float((uint32_t)(mx[0] > mx[1] ? mx[0] : mx[1]) << 16);
-  // reduce over the lanes of the same column block: lane = 16 a + 4 j + c  ->  xor 1, 2 (c) and 16, 32 (a)
-  amax = fmaxf(amax, __shfl_xor(amax, 1));
-  amax = fmaxf(amax, __shfl_xor(amax, 2));
-  amax = fmaxf(amax, __shfl_xor(amax, 16));
-  amax = xhalf_max(amax);
-  const uint32_t e = e8m0_shift7(amax);
-  const float qs = e8m0_scale(e);
 #pragma unroll
-  for (int ps = 0; ps < 8; ++ps) {
-    // (hipcc 7.2 folds the four conversions of one v4i into two when the sources are vector elements: it selects the
-    //  same source register for both halves -- keep the sources as opaque scalars)
-    int s0 = v[ps][0], s1 = v[ps][1], s2 = v[ps][2], s3 = v[ps][3];
-    asm volatile("" : "+v"(s0), "+v"(s1), "+v"(s2), "+v"(s3));
-    i16x2 lo = {0, 0}, hi = {0, 0};
-    lo = __builtin_amdgcn_cvt_scalef32_pk_fp8_bf16(lo, __builtin_bit_cast(bf16x2, s0), qs, false);
-    lo = __builtin_amdgcn_cvt_scalef32_pk_fp8_bf16(lo, __builtin_bit_cast(bf16x2, s1), qs, true);
-    hi = __builtin_amdgcn_cvt_scalef32_pk_fp8_bf16(hi, __builtin_bit_cast(bf16x2, s2), qs, false);
-    hi = __builtin_amdgcn_cvt_scalef32_pk_fp8_bf16(hi, __builtin_bit_cast(bf16x2, s3), qs, true);
-    const v2i o = {__builtin_bit_cast(int, lo), __builtin_bit_cast(int, hi)};
-    *(v2i*)(p.y + (int64_t)(r0 + ps * 4 + lr) * p.n + c0 + lc) = o;
+  for (int tp = 0; tp < TPW; ++tp) {
+    const int ct = wcol * TPW + tp, c0 = (tj * CT + ct) * 128;
+    u16x2 mx = {0, 0};
+#pragma unroll
+    for (int ps = 0; ps < 8; ++ps)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) mx = __builtin_elementwise_max(mx, __builtin_bit_cast(u16x2, (uint32_t)v[tp][ps][q] & 0x7fff7fffu));
+    float amax = __uint_as_float((uint32_t)(mx[0] > mx[1] ? mx[0] : mx[1]) << 16);
+    // reduce over the lanes of the same column block: lane = 16 a + 4 j + c  ->  xor 1, 2 (c) and 16, 32 (a)
+    amax = fmaxf(amax, __shfl_xor(amax, 1));
+    amax = fmaxf(amax, __shfl_xor(amax, 2));
+    amax = fmaxf(amax, __shfl_xor(amax, 16));
+    amax = xhalf_max(amax);
+    const uint32_t e = e8m0_shift7(amax);
+    const float qs = e8m0_scale(e);
+#pragma unroll
+    for (int ps = 0; ps < 8; ++ps) {
+      // (hipcc 7.2 folds the four conversions of one v4i into two when the sources are vector elements: it selects the
+      //  same source register for both halves -- keep the sources as opaque scalars)
+      int s0 = v[tp][ps][0], s1 = v[tp][ps][1], s2 = v[tp][ps][2], s3 = v[tp][ps][3];
+      asm volatile("" : "+v"(s0), "+v"(s1), "+v"(s2), "+v"(s3));
+      i16x2 lo = {0, 0}, hi = {0, 0};
+      lo = __builtin_amdgcn_cvt_scalef32_pk_fp8_bf16(lo, __builtin_bit_cast(bf16x2, s0), qs, false);
+      lo = __builtin_amdgcn_cvt_scalef32_pk_fp8_bf16(lo, __builtin_bit_cast(bf16x2, s1), qs, true);
+      hi = __builtin_amdgcn_cvt_scalef32_pk_fp8_bf16(hi, __builtin_bit_cast(bf16x2, s2), qs, false);
+      hi = __builtin_amdgcn_cvt_scalef32_pk_fp8_bf16(hi, __builtin_bit_cast(bf16x2, s3), qs, true);
+      const v2i o = {__builtin_bit_cast(int, lo), __builtin_bit_cast(int, hi)};
+      if (!QAMD_BWD_ABL(4)) *(v2i*)(p.y + (int64_t)(r0 + ps * 4 + lr) * p.n + c0 + lc) = o;
+    }
+    // scales: lanes 0, 4, 8, 12 hold the exponents of column blocks 0..3 of this wave's row block
+    const uint32_t e0 = __shfl(e, 0), e1 = __shfl(e, 4), e2 = __shfl(e, 8), e3 = __shfl(e, 12);
+    const uint32_t packed = e0 | (e1 << 8) | (e2 << 16) | (e3 << 24);
+    if (CT == 1 && lane < 32 && !QAMD_BWD_ABL(1)) *(uint32_t*)(p.row_sf + (int64_t)(r0 + lane) * (p.n >> 5) + tj * 4) = packed;
+    if (lane == 0) *(uint32_t*)&es[wave][4 * ct] = packed;
   }
-  // scales: lanes 0, 4, 8, 12 hold the exponents of column blocks 0..3 of this wave's row block
-  const uint32_t e0 = __shfl(e, 0), e1 = __shfl(e, 4), e2 = __shfl(e, 8), e3 = __shfl(e, 12);
-  const uint32_t packed = e0 | (e1 << 8) | (e2 << 16) | (e3 << 24);
-  if (lane < 32) *(uint32_t*)(p.row_sf + (int64_t)(r0 + lane) * (p.n >> 5) + tj * 4) = packed;
-  if (lane == 0) *(uint32_t*)&es[wave][0] = packed;
   __syncthreads();
-  if (tid < 128) {   // column c0 + tid: the four row blocks of this workgroup are 4 consecutive bytes
-    const int j = tid >> 5;
-    const uint32_t col = es[0][j] | (es[1][j] << 8) | (es[2][j] << 16) | (es[3][j] << 24);
-    *(uint32_t*)(p.col_sf + (int64_t)(c0 + tid) * (p.m_pad >> 5) + ti * 4) = col;
+  if (CT > 1 && tid < 128 && !QAMD_BWD_ABL(1)) {   // row ti * 128 + tid: the 4 CT column blocks of this workgroup are 4 CT consecutive bytes
+    uint8_t* dst = p.row_sf + (int64_t)(ti * 128 + tid) * (p.n >> 5) + tj * 4 * CT;
+#pragma unroll
+    for (int q = 0; q < CT / 4; ++q) *(v4i*)(dst + 16 * q) = *(const v4i*)&es[tid >> 5][16 * q];
+  }
+  if (!QAMD_BWD_ABL(2)) {
+    for (int idx = tid; idx < 128 * CT; idx += 256 * WC) {   // column tj * 128 CT + idx: the four row blocks of this workgroup are 4 consecutive bytes
+      const int j = idx >> 5;
+      const uint32_t col = es[0][j] | (es[1][j] << 8) | (es[2][j] << 16) | (es[3][j] << 24);
+      *(uint32_t*)(p.col_sf + (int64_t)(tj * 128 * CT + idx) * (p.m_pad >> 5) + ti * 4) = col;
+    }
   }
 }
 

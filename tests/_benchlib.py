@@ -31,6 +31,7 @@ _SIGS = {
     "qutlass_amd_nvf4_splitk_workspace_bytes": (_i64, [_i64, _i64, _i64]),
     "qutlass_amd_matmul_nvf4_bf16_tn_ws": (_i32, _GEMM[:-1] + [_vp, _i64, _vp]),
     "qutlass_amd_mxfp4_transpose_mxfp8": (_i32, [_vp, _vp, _i64, _i64, _vp, _vp, _vp]),
+    "qutlass_amd_backward_bf16_square_double_mxfp8": (_i32, [_vp, _i64, _i64, _vp, _vp, _vp, _vp]),
     "qutlass_amd_mxfp4_transpose_mxfp8_rows": (_i32, [_vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp]),
     "qutlass_amd_fused_quantize_mx": (_i32, [_vp, _vp, _i32, _i64, _i32, _vp, _vp, _vp, _vp]),
     "qutlass_amd_backward_t_bf16": (_i32, [_vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp]),
@@ -142,6 +143,16 @@ def mxfp4_transpose_mxfp8(x_fp4, scales, m: int, n: int):
     sf = torch.empty(n, m // 32, dtype=torch.uint8, device=x_fp4.device)
     _check(load().qutlass_amd_mxfp4_transpose_mxfp8(_p(x_fp4), _p(scales), m, n, _p(y), _p(sf), _stream()))
     return y, sf
+
+
+def backward_bf16_square_double_mxfp8(x):
+    """C-ABI call of the lab build (x: (m, n) bf16, m % 128 == 0, n % 128 == 0): e4m3 (m, n), row scales (m, n/32), column scales (n, m/32)."""
+    m, n = x.shape
+    y = torch.empty(m, n, dtype=torch.uint8, device=x.device)
+    rs = torch.empty(m, n // 32, dtype=torch.uint8, device=x.device)
+    cs = torch.empty(n, m // 32, dtype=torch.uint8, device=x.device)
+    _check(load().qutlass_amd_backward_bf16_square_double_mxfp8(_p(x), m, n, _p(y), _p(rs), _p(cs), _stream()))
+    return y, rs, cs
 
 
 def mxfp4_transpose_mxfp8_rows(x_fp4, scales, m: int, m_pad: int, n: int):

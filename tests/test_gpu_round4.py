@@ -383,3 +383,34 @@ def test_transposer_wave_owned_kernels_equal_the_oracle(q, variant, m, m_pad, n)
     ry, rs = oracle.mxfp4_transpose_mxfp8(pc, ps)
     assert np.array_equal(_np(sf), np.asarray(rs).reshape(_np(sf).shape)), int((_np(sf) != np.asarray(rs).reshape(_np(sf).shape)).sum())
     assert np.array_equal(_np(y), np.asarray(ry).reshape(_np(y).shape)), int((_np(y) != np.asarray(ry).reshape(_np(y).shape)).sum())
+
+
+# ------------------------------------------------------------------------------------------------
+# [r4] backward_bf16_square_double_mxfp8 with 512 columns per workgroup (16 waves: 16-byte row-scale pieces) -- and the lab's 1024-column form --
+# against the oracle (quartet_bwd_sm120.cu:511-621) and the 4-wave form, incl. tensors large enough for the product rule to take it.
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("variant", [1, 4, 8])
+@pytest.mark.parametrize("m,n", [(128, 1024), (384, 2048), (256, 3072), (1024, 5120)])
+def test_square_double_wide_workgroups_equal_the_oracle(q, variant, m, n):
+    if variant == 8 and n % 1024:
+        pytest.skip("1024-column workgroups need n % 1024 == 0")
+    rng = np.random.default_rng(m + n + variant)
+    x = torch.from_numpy(rng.standard_normal((m, n)).astype(np.float32) * float(rng.choice([1e-3, 1.0, 300.0]))).to(torch.bfloat16).to(DEV)
+    x[32:64, 128:256] = 0          # an all-zero 32 x 32 block row: shared exponent 127
+    with lab.forced(transpose_nc=variant):
+        y, rs, cs = lab.backward_bf16_square_double_mxfp8(x)
+    ry, rrs, rcs = oracle.backward_bf16_square_double_mxfp8(_np(x))
+    assert np.array_equal(_np(y), ry) and np.array_equal(_np(rs), rrs) and np.array_equal(_np(cs), rcs)
+
+
+@pytest.mark.gpu
+def test_square_double_product_rule_takes_the_wide_form_and_equals_the_four_wave_form(q):
+    g = torch.Generator(device=DEV).manual_seed(9)
+    x = torch.randn(4000, 4608, dtype=torch.bfloat16, device=DEV, generator=g) * 11.0      # 32 row blocks (the last one padded in the kernel) x 9 wide tiles = 288 workgroups
+    py, prs, pcs = q.backward_bf16_square_double_mxfp8(x)                                    # product library, its own rule, in-kernel row padding
+    xp = torch.zeros(4096, 4608, dtype=torch.bfloat16, device=DEV)
+    xp[:4000] = x
+    with lab.forced(transpose_nc=1):
+        oy, ors, ocs = lab.backward_bf16_square_double_mxfp8(xp)
+    assert torch.equal(py.view(torch.uint8), oy) and torch.equal(prs.view(torch.uint8), ors) and torch.equal(pcs.view(torch.uint8), ocs)

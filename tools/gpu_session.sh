@@ -47,6 +47,7 @@ PY
     sweeps) timeout 900 python benchmarks/bench_mxfp4_mi355x.py --model Llama-3-8B --fused --vendor --max-batch 8192 --reps 30 > $O/bench_sweep_mxfp4_Llama-3-8B.txt 2> $O/sweeps.err; echo "sweep mxfp4 rc=$?"
             timeout 900 python benchmarks/bench_mxfp4_mi355x.py --format nvfp4 --had 16 --model Llama-3-8B --max-batch 8192 --reps 30 > $O/bench_sweep_nvfp4_Llama-3-8B.txt 2>> $O/sweeps.err; echo "sweep nvfp4 rc=$?"
             cat $O/bench_sweep_nvfp4_Llama-3-8B.txt ;;
+    absq)   timeout 600 python tools/ab_sq_abl.py > $O/ab_sq_abl.txt 2> $O/ab_sq_abl.err; echo "absq rc=$?"; cat $O/ab_sq_abl.txt; tail -3 $O/ab_sq_abl.err ;;
     ablib)  timeout 900 python tools/ab_lib_shapes.py build/exp/libqamd_base.so qutlass_amd/libqutlass_amd.so > $O/ab_lib_shapes.txt 2> $O/ab_lib_shapes.err; echo "ablib rc=$?"; cat $O/ab_lib_shapes.txt; tail -3 $O/ab_lib_shapes.err ;;
     configs) timeout 900 python bench_configs.py > $O/bench_configs.jsonl 2> $O/bench_configs.err; echo "configs rc=$?"; tail -30 $O/bench_configs.jsonl | cut -c1-240 ;;
     calibnv) timeout 900 python tools/calib_tiles.py nvf4 > $O/calib_tiles_nvf4.txt 2> $O/calib_tiles_nvf4.err; echo "calibnv rc=$?"; tail -5 $O/calib_tiles_nvf4.txt ;;
@@ -56,7 +57,7 @@ PY
     hbm)    timeout 600 python tools/hbm_ceilings.py > $O/hbm_ceilings.txt 2> $O/hbm_ceilings.err; echo "hbm rc=$?"; cat $O/hbm_ceilings.txt; tail -3 $O/hbm_ceilings.err ;;
     abtr)   timeout 600 python tools/ab_transpose.py > $O/ab_transpose.txt 2> $O/ab_transpose.err; echo "abtr rc=$?"; cat $O/ab_transpose.txt; tail -3 $O/ab_transpose.err ;;
     ablbwd) timeout 600 python tools/ab_bwd_abl.py > $O/ab_bwd_abl.txt 2> $O/ab_bwd_abl.err; echo "ablbwd rc=$?"; cat $O/ab_bwd_abl.txt; tail -3 $O/ab_bwd_abl.err ;;
-    testbwd) timeout 600 python -m pytest tests -m gpu -q -k "backward or quartet or bwd or transpos" > $O/pytest_bwd.log 2>&1; echo "testbwd rc=$?"; tail -4 $O/pytest_bwd.log ;;
+    testbwd) timeout 600 python -m pytest tests -m gpu -q -k "backward or quartet or bwd or transpos or square" > $O/pytest_bwd.log 2>&1; echo "testbwd rc=$?"; tail -4 $O/pytest_bwd.log ;;
     abmx)   timeout 900 python tools/ab_mxsk.py > $O/ab_mxsk.txt 2> $O/ab_mxsk.err; echo "abmx rc=$?"; cat $O/ab_mxsk.txt; tail -3 $O/ab_mxsk.err ;;
     *) echo "unknown step $step" ;;
   esac
