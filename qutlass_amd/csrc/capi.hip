@@ -1434,7 +1434,7 @@ int qutlass_amd_mxfp4_transpose_mxfp8_rows(const void* x_fp4, const void* scales
   if (m_pad >= (1ll << 31) || n >= (1ll << 31) || (m_pad / 128) * (n / 128) >= (1ll << 31)) return fail(QAMD_ERR_INVALID, "%s: tensor too large", name);
   TrParams p;
   p.xq = (const uint8_t*)x_fp4; p.xs = (const uint8_t*)scales; p.y = (uint8_t*)y; p.out_sf = (uint8_t*)out_e8m0;
-  p.m = (int)m; p.n = (int)n; p.m_pad = (int)m_pad;
+  p.m = (int)m; p.n = (int)n; p.m_pad = (int)m_pad; p.abl = opt_bwd_variant() >> 4;
   // [r4] A wave-owned-lines form of this op (mxfp4_transpose_mxfp8_tw_kernel: persistent waves, no workgroup barrier, whole 128-byte lines or
   // 64-byte segments) is byte-identical and NOT faster (8192^2 cold 30.7 / 35.0 us against 28.4, warm 21.4 / 22.5 against 21.2;
   // profiles/ab_transpose_r4o.txt): the one-shot kernel stays the product, the other lives in the lab build (option "transpose_nc" = 4 / 2).

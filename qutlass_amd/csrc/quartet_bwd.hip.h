@@ -33,7 +33,7 @@ struct BwdTParams {
   uint8_t* out_sf;          // e8m0 (B, M, N/32)
   int B, N, M;
   int tiles_m;              // ceil(M / 64); B * (N/32) * tiles_m < 2^31 (host-checked): the kernel indexes tiles in 32 bits
-  int abl;                  // lab build only (bwd_quant_tw_kernel): leave out 1 = the global loads, 2 = the unit stores, 4 = MFMA + quantisation, 8 = staging
+  int abl;                  // lab build only (bwd_quant_tw_kernel): leave out 1 = the global loads, 2 = the unit stores, 4 = MFMA + quantisation, 8 = staging, 16 = the scale-byte stores
 };
 #if QAMD_BENCH
 #define QAMD_BWD_ABL(b) (p.abl & (b))
@@ -496,7 +496,7 @@ __global__ __launch_bounds__(256) void bwd_quant_tw_kernel(const BwdTParams p) {
       const uint32_t so = (kk < ng) ? (uint32_t)r * (uint32_t)G * 16u + (uint32_t)kk * 16u : OOB;
       __builtin_amdgcn_raw_buffer_store_b128(*(const v4i*)(os + r * OROW + kk * 16), ro, (int)so, 0, 0);
     }
-    if (lane < rows) {
+    if (lane < rows && !QAMD_BWD_ABL(16)) {
       uint8_t* dst = p.out_sf + grp0 + (int64_t)lane * G;
       if ((G & (NG - 1)) == 0) {
         if (NG == 8) *(v2i*)dst = *(const v2i*)(ss + lane * NG);
@@ -660,6 +660,7 @@ struct TrParams {
   int m_pad;           // row extent of the outputs (y is (n, m_pad)), a multiple of 128 >= m: rows m .. m_pad-1 count as zero codes with
                        // unit scales IN the kernel ([r3]: the reference pads x_fp4 with a copy and writes 1.0 into the caller's scale
                        // tensor first, qutlass/__init__.py:299-307 "TODO: padding in kernel")
+  int abl;             // lab build only: 1 = leave out the scale stores
 };
 
 // NC = columns (n) per workgroup: 256, or 128 (half the LDS, 4 workgroups per CU: the kernel is one round of workgroups,
@@ -773,7 +774,7 @@ __global__ __launch_bounds__(256) void mxfp4_transpose_mxfp8_kernel(const TrPara
     const v4i v = *(const v4i*)(os + row * OROW + ch * 16);
     *(v4i*)(p.y + (int64_t)(c0 + row) * p.m_pad + m0 + ch * 16) = v;
   }
-  if (tid < NC) *(uint32_t*)(p.out_sf + (int64_t)(c0 + tid) * (p.m_pad >> 5) + (m0 >> 5)) = *(const uint32_t*)(es + tid * 4);
+  if (tid < NC && !QAMD_BWD_ABL(1)) *(uint32_t*)(p.out_sf + (int64_t)(c0 + tid) * (p.m_pad >> 5) + (m0 >> 5)) = *(const uint32_t*)(es + tid * 4);
 }
 
 // ----------------------------------------------------------------------------------------------------------------
