@@ -142,7 +142,12 @@ __global__ __launch_bounds__(256) void fused_quantize_kernel(const QuantParams p
   constexpr int RP = (R < 32) ? 32 : R;         // rotation padded to one MFMA j-tile (R=16: block-diag)
   constexpr int KC = RP / 16;                   // 16-wide k chunks per row
   constexpr int JT = RP / 32;                   // 32-wide j tiles per row = MX groups per row
-  constexpr int HROW = RP * 2 + 16;             // padded H^T row stride in LDS (bytes)
+  // [r4] R >= 64: H sits in LDS as it is in memory (row k, column j; staged with 16-byte copies) and the MFMA fragments come out of it with
+  // transposing reads (ds_read_b64_tr_b16, the addressing of quartet_bwd.hip.h) -- the transposed image cost every thread R*R/256 two-byte loads
+  // and as many two-byte LDS writes before the first tile could be rotated (R = 128: ~2 us of a 10 us kernel at 4096^2).  Row stride = 16 or 48
+  // dwords (mod 64) keeps the transposing reads of a half wave on 64 different banks.
+  constexpr bool HTR = RP >= 64;
+  constexpr int HROW = HTR ? RP * 2 + 64 : RP * 2 + 16;   // H (HTR) / H^T row stride in LDS (bytes)
   __shared__ __attribute__((aligned(16))) char hT[RP * HROW];
   // R >= 64: a tile's rows are 128 / 256 bytes apart, and a load in MFMA layout (lane = row, 16 bytes) touches 32 lines
   // for 32 bytes each -- every line four to eight times over the tile's loads, from an L1 that the other waves' tiles
@@ -215,14 +220,26 @@ __global__ __launch_bounds__(256) void fused_quantize_kernel(const QuantParams p
     // 16-row input).  Consecutive lanes take consecutive j: 2-byte loads coalesce to whole lines, and the transposed
     // writes hT[j][k] land HROW = 2 RP + 16 bytes apart, 16 distinct banks per 16 lanes.  (16-byte loads with 8
     // transposed 2-byte writes each were tried: the writes of a wave then fall on 2 banks, 15.7 us.)
-    constexpr int NE = RP * RP / 256;
-    uint16_t hv[NE];
+    if constexpr (HTR) {
+      constexpr int NCH = RP * RP / 8 / 256, CPRH = RP / 8;          // 16-byte chunks per thread, chunks per row of h
+      v4i hc[NCH];
 #pragma unroll
-    for (int i = 0; i < NE; ++i) hv[i] = p.h[i * 256 + tid];           // idx = i * 256 + tid = k * RP + j, R == RP here
+      for (int i = 0; i < NCH; ++i) hc[i] = *(const v4i*)(p.h + (i * 256 + tid) * 8);
 #pragma unroll
-    for (int i = 0; i < NE; ++i) {
-      const int idx = i * 256 + tid, k = idx / RP, j = idx % RP;
-      *(uint16_t*)(hT + j * HROW + k * 2) = hv[i];
+      for (int i = 0; i < NCH; ++i) {
+        const int c = i * 256 + tid;
+        *(v4i*)(hT + (c / CPRH) * HROW + (c % CPRH) * 16) = hc[i];
+      }
+    } else {
+      constexpr int NE = RP * RP / 256;
+      uint16_t hv[NE];
+#pragma unroll
+      for (int i = 0; i < NE; ++i) hv[i] = p.h[i * 256 + tid];           // idx = i * 256 + tid = k * RP + j, R == RP here
+#pragma unroll
+      for (int i = 0; i < NE; ++i) {
+        const int idx = i * 256 + tid, k = idx / RP, j = idx % RP;
+        *(uint16_t*)(hT + j * HROW + k * 2) = hv[i];
+      }
     }
   }
   __syncthreads();
@@ -281,7 +298,18 @@ __global__ __launch_bounds__(256) void fused_quantize_kernel(const QuantParams p
       for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 #pragma unroll
       for (int kc = 0; kc < KC; ++kc) {
-        const v8bf hf = *(const v8bf*)(hT + hoist_guard + (jt * 32 + row) * HROW + (kc * 16 + half * 8) * 2);
+        v8bf hf;
+        if constexpr (HTR) {   // column j = 32 jt + row of h, rows k = 16 kc + 8 half .. + 7: two transposing reads of 4 rows each
+          typedef short v4s_ __attribute__((ext_vector_type(4)));
+          typedef __attribute__((address_space(3))) v4s_* lds_v4s_t;
+          const char* tp = hT + hoist_guard + (8 * half + ((lane & 15) >> 2) + 16 * kc) * HROW + (((lane & 31) >> 4) * 16 + (lane & 3) * 4) * 2 + jt * 64;
+          const v4s_ lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s_t)tp);
+          const v4s_ hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s_t)(tp + 4 * HROW));
+          const v8u16 hv8 = {(uint16_t)lo[0], (uint16_t)lo[1], (uint16_t)lo[2], (uint16_t)lo[3], (uint16_t)hi[0], (uint16_t)hi[1], (uint16_t)hi[2], (uint16_t)hi[3]};
+          hf = __builtin_bit_cast(v8bf, hv8);
+        } else {
+          hf = *(const v8bf*)(hT + hoist_guard + (jt * 32 + row) * HROW + (kc * 16 + half * 8) * 2);
+        }
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(hf, xf[kc], acc, 0, 0, 0);
       }
       // acc[4q+e] = y[r_abs][32 jt + 8q + 4 half + e]
