@@ -905,6 +905,7 @@ int quant_grid(int ntiles, int rot) {
   // 4 waves per workgroup, one 32-row tile per wave per trip.  Small rotations are pure streaming: as many waves as
   // fit (8 workgroups per CU; 8192^2 NV runs at 6.26 TB/s).  R = 128 tiles are 8 KiB with 32 MFMAs each: fewer, longer
   // waves let the software pipeline (next tile's loads in flight during this tile's MFMAs) overlap (13.2 vs 14.6 us).
+  // ([r4] One 12-wave workgroup per CU sharing one H image -- three waves per SIMD instead of two -- measured slower: 4096^2 8.9 -> 10.8 us warm.)
   int per_cu = opt_quant_wg_per_cu();
   if (per_cu <= 0) per_cu = rot >= 128 ? 2 : (rot >= 64 ? 4 : 8);
   int g = (ntiles + 3) / 4;
