@@ -55,7 +55,7 @@ std::atomic<int> g_gemm_variant{0};
 std::atomic<int> g_nvf4_variant{0};
 std::atomic<int> g_splitk_wg{0};        // split-K: target workgroup count ("splitk_wg"; one per CU measured best, profiles/native_r1_splitk_wg.log)
 std::atomic<int> g_splitk_min_kt{32};   // split-K: minimum number of 128-byte K stages ("splitk_min_kt"; 16 loses at K = 4096, 48 leaves K = 8192 .. 11008 unsplit)
-std::atomic<int> g_transpose_nc{128};   // mxfp4_transpose_mxfp8: n columns per workgroup (128 or 256)
+std::atomic<int> g_transpose_nc{0};     // lab: kernel forcing of mxfp4_transpose_mxfp8 (128 / 256 / 3 / 4 / 2) and backward_bf16_square_double_mxfp8 (1 / 4 / 8); 0 = the product rules
 std::atomic<int> g_pp_shift{2};
 std::atomic<int> g_pp_flags{1};
 std::atomic<int> g_quant_wg_per_cu{0};  // 0 = auto
@@ -121,7 +121,7 @@ constexpr int opt_gemm_variant() { return 0; }
 constexpr int opt_nvf4_variant() { return 0; }
 constexpr int opt_splitk_wg() { return 0; }
 constexpr int opt_splitk_min_kt() { return 32; }
-constexpr int opt_transpose_nc() { return 128; }
+constexpr int opt_transpose_nc() { return 0; }
 constexpr int opt_pp_shift() { return 2; }
 constexpr int opt_pp_flags() { return 1; }
 constexpr int opt_quant_wg_per_cu() { return 0; }
@@ -1457,7 +1457,15 @@ int qutlass_amd_mxfp4_transpose_mxfp8_rows(const void* x_fp4, const void* scales
     return check_launch("mxfp4_transpose_mxfp8_tw_kernel");
   }
 #endif
-  hipLaunchKernelGGL(mxfp4_transpose_mxfp8_kernel<128>, dim3((unsigned)((m_pad / 128) * (n / 128))), dim3(256), 0, (hipStream_t)stream, p);
+  // [r4] 256 rows per workgroup (8 waves, 8-byte scale pieces per output row instead of 4) is byte-identical and slower -- the two workgroup barriers then
+  // wait for eight waves: 8192^2 cold 28.6 -> 31.5 us (profiles/ab_transpose_r4ak_8wave.txt); lab only: option "transpose_nc" = 3
+#if QAMD_BENCH
+  if (opt_transpose_nc() == 3 && m_pad % 256 == 0) {
+    hipLaunchKernelGGL((mxfp4_transpose_mxfp8_kernel<128, 256>), dim3((unsigned)((m_pad / 256) * (n / 128))), dim3(512), 0, (hipStream_t)stream, p);
+    return check_launch("mxfp4_transpose_mxfp8_kernel");
+  }
+#endif
+  hipLaunchKernelGGL((mxfp4_transpose_mxfp8_kernel<128, 128>), dim3((unsigned)((m_pad / 128) * (n / 128))), dim3(256), 0, (hipStream_t)stream, p);
   return check_launch("mxfp4_transpose_mxfp8_kernel");
 }
 

@@ -665,14 +665,17 @@ struct TrParams {
 
 // NC = columns (n) per workgroup: 256, or 128 (half the LDS, 4 workgroups per CU: the kernel is one round of workgroups,
 // so its duration is ONE workgroup's load -> transpose -> store latency chain, and smaller tiles shorten it)
-template <int NC>
-__global__ __launch_bounds__(256) void mxfp4_transpose_mxfp8_kernel(const TrParams p) {
+// [r4] MR = rows (m) per workgroup, MR / 32 waves: 256 doubles the scale piece a workgroup writes per output row (8 bytes instead of 4: the 4-byte pieces cost
+// 8 % at 8192^2, profiles/ab_sf_stores_r4ah.txt) at the same LDS per wave.
+template <int NC, int MR = 128>
+__global__ __launch_bounds__(MR * 2) void mxfp4_transpose_mxfp8_kernel(const TrParams p) {
+  constexpr int NWV = MR / 32, NTH = MR * 2;      // waves, threads
   constexpr int LROW = NC * 2 + 64;    // bf16 row of NC columns + pad: 16 dwords (mod 64), so the 4 rows x 32 bytes that each of the two 16-lane groups of a
                                        // half wave gathers with ds_read_b64_tr_b16 fall on 64 different banks
   constexpr int LPR = NC / 32;         // lanes per input row (16 bytes = 32 codes = one input scale group each)
   constexpr int RPP = 64 / LPR;        // rows per load pass
   constexpr int CPL = NC / 64;         // columns per lane
-  __shared__ __attribute__((aligned(16))) char ts_all[4][32 * LROW];
+  __shared__ __attribute__((aligned(16))) char ts_all[NWV][32 * LROW];
   const int tid = threadIdx.x, lane = tid & 63, wave = uniform(tid >> 6);
   const int tiles_n = p.n / NC;
   // [r3] NC = 128: a tile reads 64 of the 128 bytes of each of its input lines, the tile next to it (tj ^ 1) the other 64.  Workgroup ids go round
@@ -687,7 +690,7 @@ __global__ __launch_bounds__(256) void mxfp4_transpose_mxfp8_kernel(const TrPara
     t = 2u * ((k >> 1) * 8u + x) + (k & 1u);
   }
   const int ti = (int)(t / (unsigned)tiles_n), tj = (int)(t % (unsigned)tiles_n);
-  const int r0 = ti * 128 + wave * 32, c0 = tj * NC;
+  const int r0 = ti * MR + wave * 32, c0 = tj * NC;
   char* ts = ts_all[wave];
 #pragma unroll
   for (int ps = 0; ps < 32 / RPP; ++ps) {
@@ -755,26 +758,30 @@ __global__ __launch_bounds__(256) void mxfp4_transpose_mxfp8_kernel(const TrPara
   // [NC n][128 m] fp8 tile and its [NC][4] scale bytes in LDS (the bf16 staging area is dead by now) and write whole
   // lines / one dword of scales per output row.
   __syncthreads();
-  constexpr int OROW = 128 + 16;                       // staged output row: 128 m bytes + pad
+  constexpr int OROW = MR + 16;                        // staged output row: MR m bytes + pad
   char* os = &ts_all[0][0];
-  uint8_t* es = (uint8_t*)os + NC * OROW;              // [NC][4]
-  static_assert(NC * OROW + NC * 4 <= 4 * 32 * LROW, "output staging fits the bf16 staging area");
+  uint8_t* es = (uint8_t*)os + NC * OROW;              // [NC][NWV]
+  static_assert(NC * OROW + NC * NWV <= NWV * 32 * LROW, "output staging fits the bf16 staging area");
 #pragma unroll
   for (int cc = 0; cc < CPL; ++cc) {
     const int col = cc * 64 + lane;
     *(v4i*)(os + col * OROW + wave * 32) = oq[cc][0];
     *(v4i*)(os + col * OROW + wave * 32 + 16) = oq[cc][1];
-    es[col * 4 + wave] = oe[cc];
+    es[col * NWV + wave] = oe[cc];
   }
   __syncthreads();
-  const int m0 = ti * 128;
+  const int m0 = ti * MR;
 #pragma unroll
-  for (int ps = 0; ps < NC / 32; ++ps) {               // NC * 8 16-byte pieces: row = piece / 8, chunk = piece % 8
-    const int piece = ps * 256 + tid, row = piece >> 3, ch = piece & 7;
+  for (int ps = 0; ps < NC / 32; ++ps) {               // NC * MR / 16 16-byte pieces: row = piece / (MR / 16), chunk = piece % (MR / 16)
+    const int piece = ps * NTH + tid, row = piece / (MR / 16), ch = piece % (MR / 16);
     const v4i v = *(const v4i*)(os + row * OROW + ch * 16);
     *(v4i*)(p.y + (int64_t)(c0 + row) * p.m_pad + m0 + ch * 16) = v;
   }
-  if (tid < NC && !QAMD_BWD_ABL(1)) *(uint32_t*)(p.out_sf + (int64_t)(c0 + tid) * (p.m_pad >> 5) + (m0 >> 5)) = *(const uint32_t*)(es + tid * 4);
+  if (tid < NC && !QAMD_BWD_ABL(1)) {
+    uint8_t* dst = p.out_sf + (int64_t)(c0 + tid) * (p.m_pad >> 5) + (m0 >> 5);
+    if (MR == 128) *(uint32_t*)dst = *(const uint32_t*)(es + tid * 4);
+    else *(v2i*)dst = *(const v2i*)(es + tid * 8);
+  }
 }
 
 // ----------------------------------------------------------------------------------------------------------------

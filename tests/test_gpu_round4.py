@@ -368,8 +368,8 @@ def test_backward_product_rule_takes_the_wave_owned_kernels_and_equals_the_round
 # (quartet_bwd_sm120.cu mxfp4_transpose_mxfp8 kernel; oracle.mxfp4_transpose_mxfp8) and against the one-shot kernel, incl. padded rows.
 # ------------------------------------------------------------------------------------------------
 @pytest.mark.gpu
-@pytest.mark.parametrize("variant", [4, 2, 128])
-@pytest.mark.parametrize("m,m_pad,n", [(128, 128, 256), (384, 384, 768), (200, 256, 512), (1, 128, 256), (129, 256, 1280), (2048, 2048, 2304)])
+@pytest.mark.parametrize("variant", [4, 2, 128, 3, 0])     # wave-owned lines / segments (lab), 4-wave one-shot, 8-wave one-shot (256 rows), the product rule
+@pytest.mark.parametrize("m,m_pad,n", [(128, 128, 256), (384, 384, 768), (200, 256, 512), (1, 128, 256), (129, 256, 1280), (2048, 2048, 2304), (3000, 3072, 5632)])
 def test_transposer_wave_owned_kernels_equal_the_oracle(q, variant, m, m_pad, n):
     rng = np.random.default_rng(m * 7 + n + variant)
     codes = rng.integers(0, 256, size=(m, n // 2), dtype=np.uint8)
