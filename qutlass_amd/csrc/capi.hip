@@ -1337,13 +1337,17 @@ int qutlass_amd_fused_quantize_matmul_mxf4_bf16_tn(const void* x, const void* h,
 // stays.  QT: 64-byte segments with 16 waves per CU (4096^2 cold 10.2 -> 8.5 us, 8192^2 30.9 -> 26.6); T: whole lines with 8 waves per CU
 // (8192^2 cold 38.0 -> 36.5, 2048 x 14336 17.7 -> 15.2; the 64-byte form ties with the round-3 kernel there).  In the product build the product
 // kernels are the only instantiations: QT never takes 3, T never 2.  Lab: option "bwd_variant" (low 4 bits) forces 1 / 2 / 3.
-static int bwd_kernel_choice(bool qt, int64_t nu) {
-  const int v = opt_bwd_variant() & 15;
-  if (v >= 1 && v <= 3) return v;
-  const int64_t cu = chip_cus();
+static int bwd_kernel_rule(bool qt, int64_t nu, int64_t cu) {
   if (qt) return nu >= 3 * cu ? 2 : 1;
   return nu >= 6 * cu ? 3 : 1;
 }
+static int bwd_kernel_choice(bool qt, int64_t nu) {
+  const int v = opt_bwd_variant() & 15;
+  if (v >= 1 && v <= 3) return v;
+  return bwd_kernel_rule(qt, nu, chip_cus());
+}
+// column tiles (of 128) per workgroup of backward_bf16_square_double_mxfp8: 4 (16 waves, 16-byte row-scale pieces) when n allows and every CU still gets a workgroup
+static int sq_column_tiles_rule(int64_t m_pad, int64_t n, int64_t cu) { return (n % 512 == 0 && (m_pad / 128) * (n / 512) >= cu) ? 4 : 1; }
 
 int qutlass_amd_backward_t_bf16(const void* x, const void* h, int64_t B, int64_t N, int64_t M, void* out_e2m1,
                                 void* out_e8m0, void* stream) {
@@ -1407,7 +1411,7 @@ int qutlass_amd_backward_bf16_square_double_mxfp8_rows(const void* x, int64_t m,
   // "transpose_nc" = 1 forces the 4-wave form, 4 / 8 the 512- / 1024-column forms
   {
     const int64_t rb = m_pad / 128, cu = chip_cus();
-    int ct = (n % 512 == 0 && rb * (n / 512) >= cu) ? 4 : 1;   // (1024 columns, two tiles per wave: slower again except warm at 8192^2 -- profiles/ab_sq_abl_r4ae.txt)
+    int ct = sq_column_tiles_rule(m_pad, n, cu);   // (1024 columns, two tiles per wave: slower again except warm at 8192^2 -- profiles/ab_sq_abl_r4ae.txt)
 #if QAMD_BENCH
     if (opt_transpose_nc() == 1) ct = 1;
     if ((opt_transpose_nc() == 8 && n % 1024 == 0) || (opt_transpose_nc() == 4 && n % 512 == 0)) ct = opt_transpose_nc();
@@ -1511,6 +1515,18 @@ int qutlass_amd_debug_gemm_plan(int ebits, int64_t M, int64_t N, int64_t K, int6
   for (int i = 0; i < n && i < 8 && i < cap; ++i) { out[3 * i] = t_dry.rec[i][0]; out[3 * i + 1] = t_dry.rec[i][1]; out[3 * i + 2] = t_dry.rec[i][2]; }
   t_dry = DryRun{};
   return rc == QAMD_OK ? n : -1;
+}
+
+// [r4] debug only (not declared in the public header): the kernel rules of the QAT-backward data-prep ops on a 256-CU part, no GPU touched.
+//   op 0 / 1: backward_t_bf16 / backward_qt_bf16 (a, b, c) = (B, N, M) -> 1 = the round-3 kernel, 2 = wave-owned 64-byte segments, 3 = wave-owned 128-byte lines
+//   op 2: backward_bf16_square_double_mxfp8 (a, b) = (m_pad, n) -> column tiles per workgroup (1 or 4)
+int qutlass_amd_debug_stream_plan(int op, int64_t a, int64_t b, int64_t c) {
+  if (op == 0 || op == 1) {
+    if (a <= 0 || b <= 0 || c <= 0 || b % 32) return -1;
+    return bwd_kernel_rule(op == 1, a * cdiv(c, 64) * cdiv(b / 32, 8), 256);
+  }
+  if (op == 2) return (a <= 0 || b <= 0 || a % 128 || b % 128) ? -1 : sq_column_tiles_rule(a, b, 256);
+  return -1;
 }
 
 // debug only (not declared in the public header): what matmul_nvf4_bf16_tn's rule picks for an M x N x K problem (gemm_nvf4.hip.h: nvf4_plan; 256 CUs assumed,

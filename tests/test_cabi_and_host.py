@@ -681,3 +681,21 @@ def test_in_tree_binaries_are_not_older_than_their_sources():
 
     assert not build.needs_build(), "libqutlass_amd.so / qutlass/_CUDA.abi3.so are older than their sources: run __graft_entry__.build()"
     assert not build._stale(build.BENCH_OUT, build._kernel_sources()), "libqutlass_amd_bench.so is older than its sources"
+
+
+def test_backward_op_kernel_rules(lib):
+    """[r4] Which kernel backward_t_bf16 / backward_qt_bf16 / backward_bf16_square_double_mxfp8 launch (capi.hip: bwd_kernel_rule, sq_column_tiles_rule), through
+    the dry-run hook (256-CU part): the thresholds of the one-box A/Bs, profiles/ab_bwd_r4m.txt and ab_sq_abl_r4ae.txt."""
+    f = lib.qutlass_amd_debug_stream_plan
+    f.restype = ctypes.c_int
+    f.argtypes = [ctypes.c_int, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64]
+    # backward_t (op 0): wave-owned 128-byte lines from 6 units (8 groups x 64 m) per CU on, the round-3 kernel below
+    assert f(0, 1, 8192, 8192) == 3 and f(0, 1, 2048, 14336) == 3 and f(0, 1, 4096, 4096) == 1 and f(0, 1, 8192, 1024) == 1 and f(0, 4, 4096, 4096) == 3
+    # backward_qt (op 1): wave-owned 64-byte segments from 3 units per CU on
+    assert f(1, 1, 8192, 8192) == 2 and f(1, 1, 4096, 4096) == 2 and f(1, 1, 2048, 14336) == 2 and f(1, 1, 8192, 1024) == 1 and f(1, 1, 256, 192) == 1
+    # never the other op's kernel (the product library only holds QT x 4 groups and T x 8 groups)
+    for shp in [(1, 32, 8), (2, 512, 320), (1, 16384, 16384)]:
+        assert f(0, *shp) in (1, 3) and f(1, *shp) in (1, 2)
+    # square_double (op 2): 16-wave workgroups of 128 x 512 when n % 512 == 0 and that still gives every CU a workgroup
+    assert f(2, 8192, 8192, 0) == 4 and f(2, 4096, 4096, 0) == 4 and f(2, 1024, 4096, 0) == 1 and f(2, 4096, 4224, 0) == 1 and f(2, 16384, 512, 0) == 1 and f(2, 32768, 512, 0) == 4
+    assert f(0, 1, 100, 64) == -1 and f(2, 100, 128, 0) == -1 and f(9, 1, 1, 1) == -1
