@@ -195,7 +195,7 @@ __global__ __launch_bounds__(256) void gemm_nvf4_pk_kernel(const NvGemmParams p)
         for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
   };
 
-  int trace_n = 0;
+  int trace_n = 0, ho_n = 0;
   auto trace = [&]() __attribute__((always_inline)) {
     if constexpr (TRACE) {
       if (blockIdx.x == 0 && wave == 0 && p.dbg && trace_n < 120) {
@@ -217,8 +217,15 @@ __global__ __launch_bounds__(256) void gemm_nvf4_pk_kernel(const NvGemmParams p)
         constexpr int i = decltype(ic)::value;
         if constexpr (s == 10 && i == 0) {
           // hand-off: nobody reads this buffer any more (its last chunk was read at step 8); own DMA of the next stage landed
+          uint32_t hc0 = 0;
+          if constexpr (TRACE) hc0 = (uint32_t)__builtin_readcyclecounter();
           asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
           __builtin_amdgcn_s_barrier();
+          if constexpr (TRACE) {   // (lab) cycles spent waiting at the hand-off: dbg[1024 + 2 j] = before the wait, dbg[1025 + 2 j] = behind the barrier
+            const uint32_t hc1 = (uint32_t)__builtin_readcyclecounter();
+            if (blockIdx.x == 0 && wave == 0 && p.dbg && ho_n < 120 && lane == 0) { p.dbg[1024 + 2 * ho_n] = hc0; p.dbg[1025 + 2 * ho_n] = hc1; }
+            ++ho_n;
+          }
           fence();
         }
         mfma1(s, i);
@@ -230,8 +237,9 @@ __global__ __launch_bounds__(256) void gemm_nvf4_pk_kernel(const NvGemmParams p)
         if constexpr (s == 4 && i < 8) cvt_pair(2, i);
         if constexpr (s == 8 && i < 8) cvt_pair(3, i);
         if constexpr (s == 14 && i < 8) cvt_pair(0, i);                                    // next stage's first pairs
-        if constexpr (s == 10) dma_item(d2, kt2, bo, i);
-        if constexpr (s == 11 && i < 2) dma_item(d2, kt2, bo, 16 + i);
+        // the 18 DMA items of the stage two ahead, three per k-step behind the hand-off (all sixteen in step 10 cost that step's MFMAs their slots:
+        // a stage took ~700 cycles more in steps 10 .. 15 than in steps 0 .. 9, profiles/trace_nvpk_r4al.txt)
+        if constexpr (s >= 10 && (i == 2 || i == 7 || i == 12)) dma_item(d2, kt2, bo, (s - 10) * 3 + (i == 2 ? 0 : (i == 7 ? 1 : 2)));
         fence();
       });
     });

@@ -10,15 +10,20 @@ SHAPES = [(1, 4096, 4096), (8, 4096, 4096), (16, 4096, 14336), (32, 14336, 4096)
           (1024, 4096, 4096), (1024, 6144, 4096), (2048, 4096, 4096), (512, 28672, 4096)]
 
 
+BIG = [(4096, 4096, 4096), (8192, 8192, 8192), (4096, 28672, 4096), (8192, 4096, 14336), (2048, 28672, 4096)]
+
+
 def main():
-    libs = [ctypes.CDLL(p, mode=ctypes.RTLD_LOCAL) for p in sys.argv[1:3]]
+    libs = [ctypes.CDLL(p, mode=ctypes.RTLD_LOCAL) for p in [a for a in sys.argv[1:] if not a.startswith("--")][:2]]
     dev = torch.device("cuda:0")
     g = torch.Generator(device=dev).manual_seed(0)
     P = lambda t: ctypes.c_void_p(t.data_ptr())
     I = ctypes.c_int64
     print("%-6s %-22s %10s %10s %8s   same bytes" % ("fmt", "M x N x K", "old us", "new us", "new/old"))
+    fmts = [a[6:] for a in sys.argv if a.startswith("--fmt=")]
     for fmt, entry, gs, fp8 in (("mxf4", "qutlass_amd_matmul_mxf4_bf16_tn", 32, False), ("mxf8", "qutlass_amd_matmul_mxf8_bf16_tn", 32, True), ("nvf4", "qutlass_amd_matmul_nvf4_bf16_tn", 16, False)):
-        for (m, n, k) in SHAPES:
+        if fmts and fmt not in fmts: continue
+        for (m, n, k) in (BIG if "--big" in sys.argv else SHAPES):
             kb = k if fp8 else k // 2
             if fp8:
                 a = (torch.randn(m, k, device=dev, generator=g) * 2).to(torch.float8_e4m3fn).view(torch.uint8)

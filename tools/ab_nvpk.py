@@ -51,13 +51,19 @@ def trace(m, n, k, dev):
     steady_w = [int(dw[i]) for i in range(len(dw)) if (i + 1) % kt != 0 and i % kt != 0 and i >= 2]
     if steady:
         print(f"#   steady stages: median {sorted(steady)[len(steady) // 2]} cycles, {sorted(steady_w)[len(steady_w) // 2] * 10} ns; MFMA-bound 8192 cycles", flush=True)
+    ho = t[1024:1024 + 2 * min(cnt, 120)].astype("int64")
+    wait = [int((ho[2 * j + 1] - ho[2 * j]) % (1 << 32)) for j in range(len(ho) // 2) if ho[2 * j] or ho[2 * j + 1]]
+    into = [int((ho[2 * j] - cyc[j]) % (1 << 32)) for j in range(min(len(ho) // 2, len(cyc))) if ho[2 * j]]
+    if wait:
+        print(f"#   hand-off (s_waitcnt vmcnt(0) lgkmcnt(0) + s_barrier at k-step 10): median {sorted(wait)[len(wait) // 2]} cycles, min {min(wait)}, max {max(wait)}; "
+              f"reached {sorted(into)[len(into) // 2]} cycles into the stage (10 k-steps of 16 MFMAs = 5120 at best)", flush=True)
 
 
 def main():
     dev = torch.device("cuda:0")
     which = "all"
     if "--shapes" in sys.argv: which = sys.argv[sys.argv.index("--shapes") + 1]
-    shapes = {"llama": LLAMA, "dip": DIP, "all": LLAMA + DIP, "prof": [(8192, 8192, 8192), (4096, 28672, 4096), (4096, 4096, 4096)]}[which]
+    shapes = {"none": [], "llama": LLAMA, "dip": DIP, "all": LLAMA + DIP, "prof": [(8192, 8192, 8192), (4096, 28672, 4096), (4096, 4096, 4096)]}[which]
     if which == "prof":   # under rocprofv3: the product's own choice only, plain launches (tools/gpu_session.sh profnv)
         alpha = torch.ones(1, device=dev)
         for (m, n, k) in shapes:
