@@ -282,10 +282,13 @@ __global__ __launch_bounds__(C::THREADS) void gemm_nvf4_kernel(const NvGemmParam
   for (int kt = kt_begin; kt < kt_end; ++kt) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (kt + 1 < kt_end) issue_stage(kt + 1, (kt + 1) & 1);
     const char* st = smem + (kt & 1) * C::STAGE_BYTES;
+    // [r4] FENCE tiles (one workgroup per CU): this stage's first LDS reads go out BEFORE the next stage's DMA burst (8-14 instructions of ~16 cycles each
+    // that the first MFMA of the stage was waiting behind)
+    if (!FENCE && kt + 1 < kt_end) issue_stage(kt + 1, (kt + 1) & 1);
     load_scales(st, 0);
     load_chunks(st, 0);
+    if (FENCE && kt + 1 < kt_end) issue_stage(kt + 1, (kt + 1) & 1);
     dq_step(0);
 #pragma unroll
     for (int s = 0; s < 16; ++s) {
