@@ -61,7 +61,7 @@ constexpr int deepp_pair_done_at(int s) { return (s >= 3 && s <= 59 && (s - 3) %
 // stages, so a unit starts in LDS buffer 0 like a tile and the stage code is shared; the DMA stream runs on across unit boundaries exactly as
 // across tiles.  Every output element is produced by one fixed summation order: deterministic; bit-identical to the single pass wherever the
 // partial sums are exact (the reference's tests), one fp32 rounding apart otherwise.
-template <class C, bool TRACE = false, int ST_AUX = 0, int LAB = 0, bool SK = false>
+template <class C, bool TRACE = false, int ST_AUX = 0, int LAB = 0, bool SK = false, bool DMA_SPREAD = true>
 __device__ __forceinline__ void gemm_mx_deepp(char* smem, const GemmParams& p, const int bid, const int G, const int ntiles) {
   static_assert(C::EBITS == 4 && C::BM == 256 && C::BN == 256 && C::WAVES_M == 2 && C::WAVES_N == 2 && C::NSTAGE == 2 && C::PPW == 2,
                 "persistent deep schedule: fp4, 256x256 tiles, 4 waves of 128x128");
@@ -286,9 +286,11 @@ __device__ __forceinline__ void gemm_mx_deepp(char* smem, const GemmParams& p, c
     dma_prep(ktl, dvalid);
     if (IL) read_base(BUF ^ 1, 0);
     fence();
+    // [r4] the stage's 17 DMA items ride in the slots that have no fragment read: second half of group 2 (items 0 .. 7 + the scale piece) and second half
+    // of group 3 (items 8 .. 15) -- all 17 behind the first 16 MFMAs after the hand-off put three auxiliary instructions into each of eight slots
     group(2, false, [&](const int i) __attribute__((always_inline)) {
-      dma_item(d, ktl, BUF, i);
-      if (i == 0) dma_item(d, ktl, BUF, 16);
+      if (!DMA_SPREAD) { dma_item(d, ktl, BUF, i); if (i == 0) dma_item(d, ktl, BUF, 16); }
+      else if (i >= 8) { dma_item(d, ktl, BUF, i - 8); if (i == 8) dma_item(d, ktl, BUF, 16); }
       if (IL) {   // the next stage's slice 0 (set 0 went dead with group 0) and its scale dwords
         if (i < MT + NT) read_frag(0, i);
         else if (i < 2 * (MT + NT)) read_scale1(BUF ^ 1, BUF ^ 1, i - (MT + NT));
@@ -297,6 +299,7 @@ __device__ __forceinline__ void gemm_mx_deepp(char* smem, const GemmParams& p, c
     if (!IL) { read_slice(BUF ^ 1, 1); fence(); } else read_base(BUF ^ 1, 1);
     group(3, false, [&](const int i) __attribute__((always_inline)) {
       if (IL && i < MT + NT) read_frag(1, i);
+      if (DMA_SPREAD && i >= 8) dma_item(d, ktl, BUF, i);
       if constexpr (EARLY) early_store(i / 8, (i / 4) % 2, i % 4);   // pairs (m = 0, 1) x (h = 0, 1), four passes each
     });
     if constexpr (FIRST) pin_acc();
@@ -1143,7 +1146,8 @@ __global__ __launch_bounds__(256) void gemm_mx_hetero_kernel(const GemmParams p,
   __shared__ __attribute__((aligned(16))) char smem[LDS];
   const int b = (int)blockIdx.x;
   if (b < g_big) {
-    if constexpr (CB::EBITS == 4) gemm_mx_deepp<CB, false, ST_AUX>(smem, p, b, g_big, t_main);
+    // (DMA_SPREAD = false here: with the residual-tile path in the same kernel the spread order costs this kernel one spilled register)
+    if constexpr (CB::EBITS == 4) gemm_mx_deepp<CB, false, ST_AUX, 0, false, false>(smem, p, b, g_big, t_main);
     else gemm_mx_deepp8<CB, ST_AUX>(smem, p, b, g_big, t_main);
     return;
   }
