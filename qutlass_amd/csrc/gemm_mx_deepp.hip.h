@@ -61,7 +61,7 @@ constexpr int deepp_pair_done_at(int s) { return (s >= 3 && s <= 59 && (s - 3) %
 // stages, so a unit starts in LDS buffer 0 like a tile and the stage code is shared; the DMA stream runs on across unit boundaries exactly as
 // across tiles.  Every output element is produced by one fixed summation order: deterministic; bit-identical to the single pass wherever the
 // partial sums are exact (the reference's tests), one fp32 rounding apart otherwise.
-template <class C, bool TRACE = false, int ST_AUX = 0, int LAB = 0, bool SK = false, bool DMA_SPREAD = true>
+template <class C, bool TRACE = false, int ST_AUX = 0, int LAB = 0, bool SK = false, int DMA_SPREAD = 1>
 __device__ __forceinline__ void gemm_mx_deepp(char* smem, const GemmParams& p, const int bid, const int G, const int ntiles) {
   static_assert(C::EBITS == 4 && C::BM == 256 && C::BN == 256 && C::WAVES_M == 2 && C::WAVES_N == 2 && C::NSTAGE == 2 && C::PPW == 2,
                 "persistent deep schedule: fp4, 256x256 tiles, 4 waves of 128x128");
@@ -299,6 +299,8 @@ __device__ __forceinline__ void gemm_mx_deepp(char* smem, const GemmParams& p, c
     if (!IL) { read_slice(BUF ^ 1, 1); fence(); } else read_base(BUF ^ 1, 1);
     group(3, false, [&](const int i) __attribute__((always_inline)) {
       if (IL && i < MT + NT) read_frag(1, i);
+      if (DMA_SPREAD == 2 && i == 8) dma_prep(ktl, dvalid);   // (2: the piece offsets are recomputed here instead of staying live through this group's fragment reads -- one register less,
+                                                               //  which the heterogeneous kernel needs; costs the plain kernel ~1 %, profiles/ab_lib_gemm_r4at_reprep.txt)
       if (DMA_SPREAD && i >= 8) dma_item(d, ktl, BUF, i);
       if constexpr (EARLY) early_store(i / 8, (i / 4) % 2, i % 4);   // pairs (m = 0, 1) x (h = 0, 1), four passes each
     });
@@ -1146,8 +1148,8 @@ __global__ __launch_bounds__(256) void gemm_mx_hetero_kernel(const GemmParams p,
   __shared__ __attribute__((aligned(16))) char smem[LDS];
   const int b = (int)blockIdx.x;
   if (b < g_big) {
-    // (DMA_SPREAD = false here: with the residual-tile path in the same kernel the spread order costs this kernel one spilled register)
-    if constexpr (CB::EBITS == 4) gemm_mx_deepp<CB, false, ST_AUX, 0, false, false>(smem, p, b, g_big, t_main);
+    // (DMA_SPREAD = 2: with the residual-tile path in the same kernel the spread order alone costs this kernel one spilled register)
+    if constexpr (CB::EBITS == 4) gemm_mx_deepp<CB, false, ST_AUX, 0, false, 2>(smem, p, b, g_big, t_main);
     else gemm_mx_deepp8<CB, ST_AUX>(smem, p, b, g_big, t_main);
     return;
   }

@@ -10,7 +10,7 @@ SHAPES = [(1, 4096, 4096), (8, 4096, 4096), (16, 4096, 14336), (32, 14336, 4096)
           (1024, 4096, 4096), (1024, 6144, 4096), (2048, 4096, 4096), (512, 28672, 4096)]
 
 
-BIG = [(4096, 4096, 4096), (8192, 8192, 8192), (4096, 28672, 4096), (8192, 4096, 14336), (2048, 28672, 4096)]
+BIG = [(4096, 4096, 4096), (8192, 8192, 8192), (4096, 28672, 4096), (8192, 4096, 14336), (2048, 28672, 4096), (5120, 4096, 4096), (3072, 6144, 4096), (4096, 11008, 4096), (4096, 14336, 4096)]
 
 
 def main():
