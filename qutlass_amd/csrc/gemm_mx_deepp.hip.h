@@ -253,6 +253,9 @@ __device__ __forceinline__ void gemm_mx_deepp(char* smem, const GemmParams& p, c
       if (i < MT) sa[set][i] = *(const int*)(st + cx.rdSA[i]);
       else sb[set][i - MT] = *(const int*)(st + cx.rdSB[i - MT]);
     };
+#ifndef QAMD_DEEPP_EARLYPREP
+#define QAMD_DEEPP_EARLYPREP 1
+#endif
 #ifdef QAMD_DEEPP_BURST
     constexpr bool IL = false;
 #else
@@ -275,7 +278,13 @@ __device__ __forceinline__ void gemm_mx_deepp(char* smem, const GemmParams& p, c
     if (!IL) { read_slice(BUF, 2); fence(); } else read_base(BUF, 2);
     group(0, FIRST, [&](const int i) __attribute__((always_inline)) { if (IL && i < MT + NT) read_frag(2, i); });
     if (!IL) { read_slice(BUF, 3); fence(); } else read_base(BUF, 3);
-    group(1, false, [&](const int i) __attribute__((always_inline)) { if (IL && i < MT + NT) read_frag(3, i); });
+    // [r4] EARLYPREP: the stage's DMA offsets and the next slice's base addresses are computed in the shadow of group 1's last MFMAs instead of between the
+    // barrier and group 2's first MFMA (neither depends on the hand-off)
+    group(1, false, [&](const int i) __attribute__((always_inline)) {
+      if (IL && i < MT + NT) read_frag(3, i);
+      if (QAMD_DEEPP_EARLYPREP && IL && i == 12) dma_prep(ktl, dvalid);
+      if (QAMD_DEEPP_EARLYPREP && IL && i == 14) read_base(BUF ^ 1, 0);
+    });
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // own DMA of the next stage landed; own reads of this buffer done
     __builtin_amdgcn_s_barrier();
     fence();
@@ -283,9 +292,11 @@ __device__ __forceinline__ void gemm_mx_deepp(char* smem, const GemmParams& p, c
       read_scales(BUF ^ 1, BUF ^ 1);
       read_slice(BUF ^ 1, 0);
     }
-    dma_prep(ktl, dvalid);
-    if (IL) read_base(BUF ^ 1, 0);
-    fence();
+    if (!(QAMD_DEEPP_EARLYPREP && IL)) {
+      dma_prep(ktl, dvalid);
+      if (IL) read_base(BUF ^ 1, 0);
+      fence();
+    }
     // [r4] the stage's 17 DMA items ride in the slots that have no fragment read: second half of group 2 (items 0 .. 7 + the scale piece) and second half
     // of group 3 (items 8 .. 15) -- all 17 behind the first 16 MFMAs after the hand-off put three auxiliary instructions into each of eight slots
     group(2, false, [&](const int i) __attribute__((always_inline)) {
