@@ -838,6 +838,7 @@ __device__ __forceinline__ void gemm_mx_deepp8(char* smem, const GemmParams& p, 
         mfma1(0, BUF, m, n, FIRST);
         if (idx < 4) read_fa(BUF, 1, idx);
         else if (idx < 8) read_fb(BUF, 1, idx - 4);
+        if (idx == 12) dma_prep(d, ktl, dvalid);   // [r4] behind an MFMA, not between the barrier and the second group (it does not depend on the hand-off)
         fence();
         ++idx;
       }
@@ -846,7 +847,6 @@ __device__ __forceinline__ void gemm_mx_deepp8(char* smem, const GemmParams& p, 
     __builtin_amdgcn_s_barrier();
     fence();
     scales_load(BUF ^ 1);
-    dma_prep(d, ktl, dvalid);
     fence();
     idx = 0;
 #pragma unroll
@@ -854,7 +854,7 @@ __device__ __forceinline__ void gemm_mx_deepp8(char* smem, const GemmParams& p, 
 #pragma unroll
       for (int n = 0; n < NT; ++n) {
         mfma1(1, BUF, m, n, false);
-        dma_item(d, ktl, BUF, idx);
+        dma_item(d, ktl, BUF, idx);   // ([r4] two items in each of the eight slots without a fragment read, the fp4 kernel's gain, costs this one 3-6 %: 64-cycle MFMAs)
         if (idx == 0) dma_item(d, ktl, BUF, 16);
         if (idx < 4) read_fa(BUF ^ 1, 0, idx);
         else if (idx < 8) read_fb(BUF ^ 1, 0, idx - 4);
