@@ -61,6 +61,9 @@ constexpr int deepp_pair_done_at(int s) { return (s >= 3 && s <= 59 && (s - 3) %
 // stages, so a unit starts in LDS buffer 0 like a tile and the stage code is shared; the DMA stream runs on across unit boundaries exactly as
 // across tiles.  Every output element is produced by one fixed summation order: deterministic; bit-identical to the single pass wherever the
 // partial sums are exact (the reference's tests), one fp32 rounding apart otherwise.
+#ifndef QAMD_DEEPP_PEEL
+#define QAMD_DEEPP_PEEL 1
+#endif
 template <class C, bool TRACE = false, int ST_AUX = 0, int LAB = 0, bool SK = false, int DMA_SPREAD = 1>
 __device__ __forceinline__ void gemm_mx_deepp(char* smem, const GemmParams& p, const int bid, const int G, const int ntiles) {
   static_assert(C::EBITS == 4 && C::BM == 256 && C::BN == 256 && C::WAVES_M == 2 && C::WAVES_N == 2 && C::NSTAGE == 2 && C::PPW == 2,
@@ -594,16 +597,30 @@ __device__ __forceinline__ void gemm_mx_deepp(char* smem, const GemmParams& p, c
       d.a = tonext ? nxt.a : cur.a; d.b = tonext ? nxt.b : cur.b; d.s = tonext ? nxt.s : cur.s;
       stage(I0{}, BT{}, d, tonext ? 0 : 2, tonext ? nvalid : true, BF{});
     }
-    for (int kt = 1; kt + 2 < KTe; kt += 2) {
-      stage(I1{}, BF{}, cur, kt + 2, true, BF{});
-      const bool tonext = kt + 3 == KTe;
-      Desc d;
-      d.a = tonext ? nxt.a : cur.a; d.b = tonext ? nxt.b : cur.b; d.s = tonext ? nxt.s : cur.s;
-      if constexpr (LAB & 2) {
-        if (tonext) stage(I0{}, BF{}, d, 0, nvalid, BT{});
-        else stage(I0{}, BF{}, d, kt + 3, true, BF{});
-      } else {
-        stage(I0{}, BF{}, d, tonext ? 0 : kt + 3, tonext ? nvalid : true, BF{});
+    if constexpr ((LAB & 2) || !QAMD_DEEPP_PEEL) {
+      for (int kt = 1; kt + 2 < KTe; kt += 2) {
+        stage(I1{}, BF{}, cur, kt + 2, true, BF{});
+        const bool tonext = kt + 3 == KTe;
+        Desc d;
+        d.a = tonext ? nxt.a : cur.a; d.b = tonext ? nxt.b : cur.b; d.s = tonext ? nxt.s : cur.s;
+        if constexpr (LAB & 2) {
+          if (tonext) stage(I0{}, BF{}, d, 0, nvalid, BT{});
+          else stage(I0{}, BF{}, d, kt + 3, true, BF{});
+        } else {
+          stage(I0{}, BF{}, d, tonext ? 0 : kt + 3, tonext ? nvalid : true, BF{});
+        }
+      }
+    } else {
+      // [r4] only the LAST pair of stages issues DMA for the next tile: peeled, so that the loop body no longer selects three descriptors between its
+      // two stages (12 s_cselect + compares = 21 scalar instructions in one MFMA slot, by the ISA's slot accounting)
+      int kt = 1;
+      for (; kt + 4 < KTe; kt += 2) {
+        stage(I1{}, BF{}, cur, kt + 2, true, BF{});
+        stage(I0{}, BF{}, cur, kt + 3, true, BF{});
+      }
+      if (kt + 2 < KTe) {
+        stage(I1{}, BF{}, cur, kt + 2, true, BF{});
+        stage(I0{}, BF{}, nxt, 0, nvalid, BF{});
       }
     }
     trace();
