@@ -17,6 +17,10 @@
 #   abtr      tools/ab_transpose.py (mxfp4_transpose_mxfp8: one-shot kernel vs the wave-owned-lines kernels)
 #   pmcstream tools/pmc_stream_ops.sh (SQ / TCC counters of the streaming ops at 8192^2)            hbm   tools/hbm_ceilings.py (trivial kernels at the ops' read : write mixes)
 #   fullcmp   tools/full_compare.py (configs C2, C3, C5: every output against the fp64 dequant-matmul oracle)
+#   absq / absf   tools/ab_sq_abl.py / ab_sf_stores.py (what the scale-byte stores of the transposing ops cost; square_double workgroup shapes)
+#   testq     the GPU tests of the quantizers            tracenv   stage + hand-off trace of the persistent NVFP4 kernel (lab variant 44)
+#   ablib / ablibnv / ablibmx / ablibmid   two BUILDS of the library side by side (tools/ab_lib_shapes.py, ab_lib_gemm.py): copy the old one to
+#             build/exp/libqamd_base.so first (or set AB_OLD / AB_NEW / AB_FMT); small + mid-size shapes, NVFP4 large, MXFP4 / MXFP8 large + headline
 cd ${GRAFT_REPO_ROOT:-.}
 NAME=${1:?session name}; shift
 O=gpurun_out/$NAME; mkdir -p $O
