@@ -201,6 +201,7 @@ template <class C, bool TRACE = false, int ST_AUX = 0, int LAB = 0>
 int launch_gemm_deepp(GemmParams p, hipStream_t s) {
   p.tiles_m = (int)cdiv(p.M, C::BM);
   p.tiles_n = (int)cdiv(p.N, C::BN);
+  p.raster_magic = raster_magic(p.tiles_n);
   p.ws = nullptr; p.splits = 1; p.ctr = nullptr; p.tag = 0;
   const int grid = deepp_grid(p.tiles_m * p.tiles_n);
   hipLaunchKernelGGL((gemm_mx_deepp_kernel<C, TRACE, ST_AUX, LAB>), dim3(grid), dim3(C::THREADS), 0, s, p);
@@ -213,6 +214,7 @@ template <class C>
 int launch_gemm_deepp_sk(GemmParams p, hipStream_t s) {
   p.tiles_m = (int)cdiv(p.M, C::BM);
   p.tiles_n = (int)cdiv(p.N, C::BN);
+  p.raster_magic = raster_magic(p.tiles_n);
   p.splits = 1;
   const int grid = chip_cus();
   if constexpr (C::EBITS == 4) hipLaunchKernelGGL((gemm_mx_deepp_kernel<C, false, 17, 0, true>), dim3(grid), dim3(C::THREADS), 0, s, p);
@@ -225,6 +227,7 @@ template <class C, bool NN = false, int NNABL = 0>
 int launch_gemm_deepp8(GemmParams p, hipStream_t s) {   // the fp8 twin (gemm_mx_deepp8), write-through output stores; NN: A is (K, M)
   p.tiles_m = (int)cdiv(p.M, C::BM);
   p.tiles_n = (int)cdiv(p.N, C::BN);
+  p.raster_magic = raster_magic(p.tiles_n);
   p.ws = nullptr; p.splits = 1; p.ctr = nullptr; p.tag = 0;
   const int grid = deepp_grid(p.tiles_m * p.tiles_n);
   hipLaunchKernelGGL((gemm_mx_deepp8_kernel<C, 17, NN, NNABL>), dim3(grid), dim3(C::THREADS), 0, s, p);
@@ -237,6 +240,7 @@ template <class CB, class CT, int ST_AUX>
 int launch_gemm_hetero(GemmParams p, hipStream_t s) {
   p.tiles_m = (int)cdiv(p.M, CB::BM);
   p.tiles_n = (int)cdiv(p.N, CB::BN);
+  p.raster_magic = raster_magic(p.tiles_n);
   p.ws = nullptr; p.splits = 1; p.ctr = nullptr; p.tag = 0;
   const int T = p.tiles_m * p.tiles_n;
   const int forced = opt_deepp_grid();
@@ -1527,6 +1531,15 @@ int qutlass_amd_debug_stream_plan(int op, int64_t a, int64_t b, int64_t c) {
   }
   if (op == 2) return (a <= 0 || b <= 0 || a % 128 || b % 128) ? -1 : sq_column_tiles_rule(a, b, 256);
   return -1;
+}
+
+// [r4] debug only (not declared in the public header): the grouped-raster decode of the persistent kernels (common.hip.h raster_decode, the SAME function the
+// device runs, with the host's raster_magic) for tiles [t0, t0 + n) of a tiles_m x tiles_n grid: out[2 i] = tile row, out[2 i + 1] = tile column.  No GPU touched.
+int qutlass_amd_debug_raster_decode(int tiles_m, int tiles_n, int t0, int n, int* out) {
+  if (!out || tiles_m <= 0 || tiles_n <= 0 || t0 < 0 || n < 0) return -1;
+  const uint32_t magic = qamd::raster_magic(tiles_n);
+  for (int i = 0; i < n; ++i) qamd::raster_decode(t0 + i, tiles_m, tiles_n, magic, out[2 * i], out[2 * i + 1]);
+  return n;
 }
 
 // debug only (not declared in the public header): what matmul_nvf4_bf16_tn's rule picks for an M x N x K problem (gemm_nvf4.hip.h: nvf4_plan; 256 CUs assumed,

@@ -51,6 +51,29 @@ __device__ __forceinline__ int xcd_remap(int b, int nb) {
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
 }
 
+// Grouped raster of the persistent kernels: tile t -> (tile row, tile column); groups of 4 tile rows, walked column by column (row fastest) inside a
+// group, the last group has tiles_m % 4 rows.  magic = raster_magic(tiles_n) = ceil(2^32 / (4 tiles_n)), worked out by the host: t / group is then one
+// s_mul_hi (exact or one too high for every t < 2^31: fixed up from the sign of the remainder), and the division by the group's row count (1 .. 4) is a
+// shift or the constant reciprocal of 3 -- about 20 scalar instructions where the two 32-bit divisions took ~90, per decode; a persistent workgroup
+// decodes twice before its first MFMA ([r4] profiles/ab_lib_gemm_r4bc_magic_decode.txt).
+inline uint32_t raster_magic(int tiles_n) {
+  const unsigned long long d = 4ull * (unsigned long long)tiles_n;
+  return (uint32_t)(((1ull << 32) + d - 1) / d);
+}
+__host__ __device__ __forceinline__ uint32_t mulhi_u32(uint32_t a, uint32_t b) { return (uint32_t)(((unsigned long long)a * b) >> 32); }
+// (host-callable so that tests/test_cabi_and_host.py can sweep it against the plain divisions through qutlass_amd_debug_raster_decode)
+__host__ __device__ __forceinline__ void raster_decode(int t, int tiles_m, int tiles_n, uint32_t magic, int& tile_m, int& tile_n) {
+  const int group = 4 * tiles_n;
+  int gid = (int)mulhi_u32((uint32_t)t, magic);
+  int rem = t - gid * group;
+  if (rem < 0) { gid -= 1; rem += group; }
+  const int first_m = gid * 4;
+  const int left = tiles_m - first_m, gsz = left < 4 ? left : 4;
+  const int q = gsz == 3 ? (int)(mulhi_u32((uint32_t)rem, 0xAAAAAAABu) >> 1) : rem >> (gsz >> 1);
+  tile_m = first_m + (rem - q * gsz);
+  tile_n = q;
+}
+
 // compile-time loop: f(std::integral_constant<int, I>{}) for I in [I0, N)
 template <int I, int N, class F>
 __device__ __forceinline__ void static_for(F&& f) {

@@ -59,6 +59,7 @@ struct GemmParams {
   int M, N, K;           // K in elements
   int ldd;               // row stride of D in elements (= N unless the launch covers a column range of a wider D)
   int tiles_m, tiles_n;  // grid = tiles_m * tiles_n
+  uint32_t raster_magic; // persistent kernels: raster_magic(tiles_n) (common.hip.h), set by their launchers
   uint32_t a_bytes, b_bytes, sfa_bytes, sfb_bytes;
   int pp_shift;          // ping-pong: wave group = (wave >> pp_shift) & 1
   int pp_flags;          // bit0: s_setprio around MFMA blocks

@@ -92,13 +92,10 @@ __device__ __forceinline__ void gemm_mx_deepp(char* smem, const GemmParams& p, c
 
   // ---- tile -> (m0, n0): rounds of G tiles, each round XCD-contiguous, grouped raster of 4 tile rows --------------------
   auto decode = [&](int t, int& m0, int& n0) __attribute__((always_inline)) {
-    constexpr int GM = 4;
-    const int group = GM * p.tiles_n;
-    const int gid = t / group, first_m = gid * GM;
-    const int gsz = min(p.tiles_m - first_m, GM);
-    const int rem = t - gid * group;
-    m0 = uniform((first_m + rem % gsz) * C::BM);
-    n0 = uniform((rem / gsz) * C::BN);
+    int tm, tn;
+    raster_decode(t, p.tiles_m, p.tiles_n, p.raster_magic, tm, tn);
+    m0 = uniform(tm * C::BM);
+    n0 = uniform(tn * C::BN);
   };
   // SK: the stream-K form keeps THREE descriptors for the whole kernel (all of A, all of B, this wave's scale operand) and carries a tile as three
   // scalar byte offsets that ride in the soffset operand of the DMA (the range check of a raw buffer covers voffset + soffset on gfx950,
@@ -666,13 +663,10 @@ __device__ __forceinline__ void gemm_mx_deepp8(char* smem, const GemmParams& p, 
   auto fence = [&]() __attribute__((always_inline)) { __builtin_amdgcn_sched_barrier(0); };
 
   auto decode = [&](int t, int& m0, int& n0) __attribute__((always_inline)) {
-    constexpr int GM = 4;
-    const int group = GM * p.tiles_n;
-    const int gid = t / group, first_m = gid * GM;
-    const int gsz = min(p.tiles_m - first_m, GM);
-    const int rem = t - gid * group;
-    m0 = uniform((first_m + rem % gsz) * C::BM);
-    n0 = uniform((rem / gsz) * C::BN);
+    int tm, tn;
+    raster_decode(t, p.tiles_m, p.tiles_n, p.raster_magic, tm, tn);
+    m0 = uniform(tm * C::BM);
+    n0 = uniform(tn * C::BN);
   };
   // ---- NN: A handed over as (K, M) row-major (matmul_host_mxf8_bf16_nn, gemm.cu:388-434) ---------------------------------
   // The A stage is DMAed as it lies in memory: [128 k][256 m] bytes (piece q = k-rows 4q .. 4q+3 = 1 KiB, lane = row l/16,
@@ -1187,10 +1181,10 @@ __global__ __launch_bounds__(256) void gemm_mx_hetero_kernel(const GemmParams p,
   int j = (b - g_big + (g_big & 7)) % nsmall;
   j = xcd_remap(j, nsmall);
   const int t = t_main + (j >> 2);
-  constexpr int GM = 4;   // the grouped raster of the persistent kernel (decode)
-  const int group = GM * p.tiles_n, gid = t / group, first_m = gid * GM, gsz = min(p.tiles_m - first_m, GM), rem = t - gid * group;
-  const int m0 = uniform((first_m + rem % gsz) * CB::BM + ((j >> 1) & 1) * 128);
-  const int n0 = uniform((rem / gsz) * CB::BN + (j & 1) * 128);
+  int tm, tn;             // the grouped raster of the persistent kernel (decode)
+  raster_decode(t, p.tiles_m, p.tiles_n, p.raster_magic, tm, tn);
+  const int m0 = uniform(tm * CB::BM + ((j >> 1) & 1) * 128);
+  const int n0 = uniform(tn * CB::BN + (j & 1) * 128);
   if (m0 >= p.M || n0 >= p.N) return;   // quarter of a partial edge tile that lies outside the output
   gemm_mx_ringp<CT>(smem, p, 0, m0, n0);
 #endif

@@ -30,6 +30,7 @@ struct NvGemmParams {
   int M, N, K;
   int ldd;         // row stride of D in elements (= N unless the launch covers a column range of a wider D: operands >= 2 GiB, capi.hip)
   int tiles_m, tiles_n;
+  uint32_t raster_magic;   // persistent kernel (gemm_nvf4_pk.hip.h): raster_magic(tiles_n) of common.hip.h, set by launch_nvf4_pk
   uint32_t a_bytes, b_bytes, sfa_bytes, sfb_bytes;
   uint32_t* dbg;   // bench only: block 0 writes {shader cycles, 100 MHz ticks} of its K loop
   float* ws;       // [r3] split-K: fp32 partials ws[z][M][N] (caller scratch, capi.hip nvf4_impl); null = single pass

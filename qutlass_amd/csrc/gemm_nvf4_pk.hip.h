@@ -82,13 +82,10 @@ __global__ __launch_bounds__(256) void gemm_nvf4_pk_kernel(const NvGemmParams p)
     return u;
   };
   auto decode = [&](int t, int& m0, int& n0) __attribute__((always_inline)) {   // grouped raster of 4 tile rows (as gemm_nvf4_kernel)
-    constexpr int GM = 4;
-    const int group = GM * p.tiles_n;
-    const int gid = t / group, first_m = gid * GM;
-    const int gsz = min(p.tiles_m - first_m, GM);
-    const int rem = t - gid * group;
-    m0 = uniform((first_m + rem % gsz) * 256);
-    n0 = uniform((rem / gsz) * 256);
+    int tm, tn;
+    raster_decode(t, p.tiles_m, p.tiles_n, p.raster_magic, tm, tn);
+    m0 = uniform(tm * 256);
+    n0 = uniform(tn * 256);
   };
   struct Desc { __amdgpu_buffer_rsrc_t a, b, sa, sb; };
   auto make_desc = [&](const Unit& u) __attribute__((always_inline)) {   // (no unit: empty descriptors, every DMA of it loads zeros)
@@ -403,6 +400,7 @@ static_assert(NVPK_PART_BYTES == NvPkCfg::PART_FLOATS * 4, "parked tile");
 hipError_t launch_nvf4_pk(NvGemmParams p, hipStream_t s, int grid, bool trace) {
   p.tiles_m = (p.M + 255) / 256;
   p.tiles_n = (p.N + 255) / 256;
+  p.raster_magic = raster_magic(p.tiles_n);
 #if QAMD_BENCH
   if (p.sk_tiles > 0) {
     if (trace) hipLaunchKernelGGL((gemm_nvf4_pk_kernel<true, true>), dim3(grid), dim3(256), 0, s, p);

@@ -2,6 +2,7 @@
 argument validation of the C entry points (no launches), the Python host mirror of the reference
 interface (names, signatures, error behaviour), and the padded-shape helpers."""
 import ctypes
+import numpy as np
 import inspect
 import os
 import re
@@ -699,3 +700,41 @@ def test_backward_op_kernel_rules(lib):
     # square_double (op 2): 16-wave workgroups of 128 x 512 when n % 512 == 0 and that still gives every CU a workgroup
     assert f(2, 8192, 8192, 0) == 4 and f(2, 4096, 4096, 0) == 4 and f(2, 1024, 4096, 0) == 1 and f(2, 4096, 4224, 0) == 1 and f(2, 16384, 512, 0) == 1 and f(2, 32768, 512, 0) == 4
     assert f(0, 1, 100, 64) == -1 and f(2, 100, 128, 0) == -1 and f(9, 1, 1, 1) == -1
+
+
+def test_raster_decode_matches_the_divisions(lib):
+    """[r4] The persistent kernels turn a tile id into (tile row, tile column) with a host-made reciprocal instead of two integer divisions (common.hip.h
+    raster_decode: ~20 scalar instructions instead of ~90, twice before a workgroup's first MFMA).  The same function, run on the host through the debug hook,
+    against the plain formula: groups of 4 tile rows walked column by column, the last group with tiles_m % 4 rows -- every tile of small grids, the ends of
+    large ones (where the reciprocal's estimate is one too high and the fix-up has to act), and ids past the grid (the kernels decode min(t, T - 1) only, but
+    garbage there must still not trap)."""
+    f = lib.qutlass_amd_debug_raster_decode
+    f.restype = ctypes.c_int
+    f.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_int)]
+
+    def ref(t, tm, tn):
+        group = 4 * tn
+        gid, rem = divmod(t, group)
+        gsz = min(tm - 4 * gid, 4)
+        return 4 * gid + rem % gsz, rem // gsz
+
+    def check(tm, tn, t0, n):
+        out = (ctypes.c_int * (2 * n))()
+        assert f(tm, tn, t0, n, out) == n
+        got = np.frombuffer(out, dtype=np.int32).reshape(n, 2)
+        for i in range(n):
+            assert tuple(got[i]) == ref(t0 + i, tm, tn), (tm, tn, t0 + i, tuple(got[i]), ref(t0 + i, tm, tn))
+
+    for tm in range(1, 10):
+        for tn in (1, 2, 3, 5, 7, 16, 33):
+            check(tm, tn, 0, tm * tn)
+    seen = set()
+    for tm, tn in [(16, 16), (32, 32), (16, 112), (17, 3), (64, 56), (3, 1000), (1023, 1021), (4099, 4093), (32768, 32768), (46340, 46340), (7, 500000)]:
+        T = tm * tn
+        assert T < 2**31
+        for t0 in {0, max(0, T // 2 - 300), max(0, T - 600)}:
+            n = min(600, T - t0)
+            check(tm, tn, t0, n)
+            seen.add((tm, tn))
+    assert len(seen) == 11
+    assert f(0, 4, 0, 1, (ctypes.c_int * 2)()) == -1
