@@ -170,6 +170,8 @@ def _sample(m, count, seed):
     (4000, 5000, 640, 98),       # ragged edges: quarter tiles partly and wholly outside the output; K tail (KT = 3 -> 4)
     (4100, 4360, 768, 98),       # 306 tiles; the last tile row is 4 rows tall
     (8192, 5120, 256, 98),       # two full rounds + 128 residual tiles, KT = 1
+    (2800, 6152, 384, 98),       # 11 x 25 tiles: the last group of the raster is three tile rows tall ([r4] raster_decode's division by 3)
+    (2800, 6152, 384, 0),
 ])
 def test_hetero_launch_mxfp4_bit_exact(q, m, n, k, forced):
     from qutlass_amd.utils import to_blocked

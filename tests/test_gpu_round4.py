@@ -66,7 +66,8 @@ def _oracle_rows(a, b, sa, sb, alpha, rows, n, k):
 #   4360 x 5128 (ragged)   18 x 21 = 378 tiles, partial edge tiles in both dimensions, K = 1536 (6 stages)
 #   8192 x 4608            576 = 2.25 rounds: one data-parallel round + a stream-K region of 320 tiles
 #   2560 x 4096            160 tiles < one round: balanced (160 workgroups), no scratch needed
-PK_SHAPES = [(4096, 4096, 1024), (6144, 4096, 1024), (4096, 5120, 512), (4360, 5128, 1536), (8192, 4608, 768), (2560, 4096, 1024), (6144, 4096, 4096)]
+#   2800 x 6152            11 x 25 tiles: the last group of the raster is THREE tile rows tall (raster_decode's division by 3, common.hip.h)
+PK_SHAPES = [(4096, 4096, 1024), (6144, 4096, 1024), (4096, 5120, 512), (4360, 5128, 1536), (8192, 4608, 768), (2560, 4096, 1024), (6144, 4096, 4096), (2800, 6152, 512)]
 
 
 @pytest.mark.parametrize("m,n,k", PK_SHAPES)
