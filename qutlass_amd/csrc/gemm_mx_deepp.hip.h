@@ -61,6 +61,12 @@ constexpr int deepp_pair_done_at(int s) { return (s >= 3 && s <= 59 && (s - 3) %
 // stages, so a unit starts in LDS buffer 0 like a tile and the stage code is shared; the DMA stream runs on across unit boundaries exactly as
 // across tiles.  Every output element is produced by one fixed summation order: deterministic; bit-identical to the single pass wherever the
 // partial sums are exact (the reference's tests), one fp32 rounding apart otherwise.
+#ifndef QAMD_DEEPP_SOFF
+#define QAMD_DEEPP_SOFF 1
+#endif
+#ifndef QAMD_KERNARG_EARLY
+#define QAMD_KERNARG_EARLY 1
+#endif
 #ifndef QAMD_DEEPP_PEEL
 #define QAMD_DEEPP_PEEL 1
 #endif
@@ -369,9 +375,10 @@ __device__ __forceinline__ void gemm_mx_deepp(char* smem, const GemmParams& p, c
     o[2] = (int)pack_bf16x2(hi[0] * alpha, hi[1] * alpha);
     o[3] = (int)pack_bf16x2(hi[2] * alpha, hi[3] * alpha);
     }
-    if constexpr (SK) {
-      // (stream-K form: the wave-uniform part of the address rides in the scalar offset, recomputed per store -- as vector offsets the 32 sums
-      //  stLane + k ldd are precomputed per tile and stay live across the K loop: ten spilled registers at 255 of 256)
+    if constexpr (SK || QAMD_DEEPP_SOFF) {
+      // (the wave-uniform part of the address rides in the scalar offset, recomputed per store -- as vector offsets the 32 sums stLane + k ldd are
+      //  precomputed per tile and stay live across the K loop: ten spilled registers in the stream-K form, and in the plain kernel the 20 registers
+      //  whose absence kept the scalar argument loads from being requested in one round, QAMD_KERNARG_EARLY; [r4] same speed by itself, profiles/ab_lib_gemm_r4bh_*)
       int ldd2 = p.ldd * 2;
       asm volatile("" : "+s"(ldd2));
       __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, o), rD, (64 * h < colLim) ? stLane : (int)0x80000000, (32 * m + 8 * pass) * ldd2 + 128 * h, ST_AUX);
@@ -1143,6 +1150,10 @@ __global__ __launch_bounds__(C::THREADS) void gemm_mx_deepp8_kernel(const GemmPa
 template <class C, bool TRACE = false, int ST_AUX = 0, int LAB = 0, bool SK = false>
 __global__ __launch_bounds__(C::THREADS) void gemm_mx_deepp_kernel(const GemmParams p) {
   __shared__ __attribute__((aligned(16))) char smem[DeepPCfg<C>::LDS_BYTES];
+#if QAMD_KERNARG_EARLY
+  // every argument the prologue needs is asked for HERE: the scalar loads leave together and are waited for once (left alone they arrive in four dependent rounds)
+  asm volatile("" :: "s"(p.A), "s"(p.D), "s"(p.K), "s"(p.b_bytes), "s"((int)gridDim.x));
+#endif
   gemm_mx_deepp<C, TRACE, ST_AUX, LAB, SK>(smem, p, (int)blockIdx.x, (int)gridDim.x, p.tiles_m * p.tiles_n);
 }
 
@@ -1168,10 +1179,14 @@ __global__ __launch_bounds__(256) void gemm_mx_hetero_kernel(const GemmParams p,
   // marks a __device__ specialisation whose body holds target builtins as invalid for every later host-side reference)
 #if defined(__HIP_DEVICE_COMPILE__)
   __shared__ __attribute__((aligned(16))) char smem[LDS];
+#if QAMD_KERNARG_EARLY
+  asm volatile("" :: "s"(p.A), "s"(p.D), "s"(p.K), "s"(p.b_bytes), "s"(g_big), "s"(t_main));   // (all scalar argument loads in one round, as in gemm_mx_deepp_kernel)
+#endif
   const int b = (int)blockIdx.x;
   if (b < g_big) {
-    // (DMA_SPREAD = 2: with the residual-tile path in the same kernel the spread order alone costs this kernel one spilled register)
-    if constexpr (CB::EBITS == 4) gemm_mx_deepp<CB, false, ST_AUX, 0, false, 2>(smem, p, b, g_big, t_main);
+    // (DMA_SPREAD = 1 since the output stores carry their row offsets as scalars (QAMD_DEEPP_SOFF): before that, with the residual-tile path in the same kernel,
+    //  the spread order alone cost this kernel one spilled register and the piece offsets were recomputed mid-stage, DMA_SPREAD = 2)
+    if constexpr (CB::EBITS == 4) gemm_mx_deepp<CB, false, ST_AUX, 0, false, 1>(smem, p, b, g_big, t_main);
     else gemm_mx_deepp8<CB, ST_AUX>(smem, p, b, g_big, t_main);
     return;
   }
