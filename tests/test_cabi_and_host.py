@@ -738,3 +738,20 @@ def test_raster_decode_matches_the_divisions(lib):
             seen.add((tm, tn))
     assert len(seen) == 11
     assert f(0, 4, 0, 1, (ctypes.c_int * 2)()) == -1
+
+
+def test_headline_kernel_prologue_stays_short():
+    """[r4] The instructions a persistent workgroup runs ahead of its first MFMA are exposed one for one at 4096^3 (624 -> 555 of them were worth 1.1 %, DESIGN.md 7;
+    profiles/ab_lib_gemm_r4bc_magic_decode.txt, ab_lib_gemm_r4bh_scalar_store_offsets_early_kernargs.txt).  Read off the ISA of the product build's headline
+    kernel (hipcc -S of translation unit 2, ~15 s): the kernel arguments arrive in ONE scalar-load round before the first LDS-DMA, no integer division is left in
+    the tile decode, the first MFMA comes within 580 instructions, and the kernel keeps the registers the scalar store offsets freed (236 of 256)."""
+    import sys
+
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from isa_prologue import prologue
+
+    r = prologue(2, "gemm_mx_deepp_kernelINS_7GemmCfgILi256ELi256ELi2ELi2ELi4ELb0ELi0ELi2ELi0EEELb0ELi17ELi0ELb0")
+    assert r["vgpr_spills"] == 0
+    assert r["waits_before_dma"] == 1, r
+    assert r["first_dma"] <= 225 and r["first_mfma"] <= 580, r
+    assert r["arch_vgprs"] <= 240, r
