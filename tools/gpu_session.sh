@@ -19,6 +19,7 @@
 #   fullcmp   tools/full_compare.py (configs C2, C3, C5: every output against the fp64 dequant-matmul oracle)
 #   absq / absf   tools/ab_sq_abl.py / ab_sf_stores.py (what the scale-byte stores of the transposing ops cost; square_double workgroup shapes)
 #   testq     the GPU tests of the quantizers            tracenv   stage + hand-off trace of the persistent NVFP4 kernel (lab variant 44)
+#   contention   tools/final_stage_contention.py (stage trace of the persistent MXFP4 kernel at 8 / 64 / 256 workgroups, same work per workgroup: is the final stage's cost the chip-wide store burst?)
 #   ablib / ablibnv / ablibmx / ablibmid   two BUILDS of the library side by side (tools/ab_lib_shapes.py, ab_lib_gemm.py): copy the old one to
 #             build/exp/libqamd_base.so first (or set AB_OLD / AB_NEW / AB_FMT); small + mid-size shapes, NVFP4 large, MXFP4 / MXFP8 large + headline
 cd ${GRAFT_REPO_ROOT:-.}
@@ -68,6 +69,7 @@ PY
     abtr)   timeout 600 python tools/ab_transpose.py > $O/ab_transpose.txt 2> $O/ab_transpose.err; echo "abtr rc=$?"; cat $O/ab_transpose.txt; tail -3 $O/ab_transpose.err ;;
     ablbwd) timeout 600 python tools/ab_bwd_abl.py > $O/ab_bwd_abl.txt 2> $O/ab_bwd_abl.err; echo "ablbwd rc=$?"; cat $O/ab_bwd_abl.txt; tail -3 $O/ab_bwd_abl.err ;;
     testbwd) timeout 600 python -m pytest tests -m gpu -q -k "backward or quartet or bwd or transpos or square" > $O/pytest_bwd.log 2>&1; echo "testbwd rc=$?"; tail -4 $O/pytest_bwd.log ;;
+    contention) timeout 300 python tools/final_stage_contention.py > $O/final_stage_contention.txt 2> $O/final_stage_contention.err; echo "contention rc=$?"; cat $O/final_stage_contention.txt; tail -3 $O/final_stage_contention.err ;;
     abmx)   timeout 900 python tools/ab_mxsk.py > $O/ab_mxsk.txt 2> $O/ab_mxsk.err; echo "abmx rc=$?"; cat $O/ab_mxsk.txt; tail -3 $O/ab_mxsk.err ;;
     *) echo "unknown step $step" ;;
   esac
