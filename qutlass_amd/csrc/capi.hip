@@ -177,6 +177,7 @@ template <class C, int PP>
 int launch_gemm(GemmParams p, hipStream_t s) {
   p.tiles_m = (int)cdiv(p.M, C::BM);
   p.tiles_n = (int)cdiv(p.N, C::BN);
+  p.raster_magic = raster_magic(p.tiles_n);
   if (PP != 7 && PP != 9) { p.ws = nullptr; p.splits = 1; p.ctr = nullptr; p.tag = 0; }   // only the (blocked-scale) ring schedules know about split-K
   hipLaunchKernelGGL((gemm_mx_kernel<C, PP>), dim3(p.tiles_m * p.tiles_n, p.splits), dim3(C::THREADS), 0, s, p);
   return check_launch("gemm_mx_kernel");

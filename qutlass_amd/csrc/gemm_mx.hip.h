@@ -49,6 +49,9 @@
 
 namespace qamd {
 
+#ifndef QAMD_CTX_MAGIC_DECODE
+#define QAMD_CTX_MAGIC_DECODE 0
+#endif
 struct GemmParams {
   const uint8_t* A;
   const uint8_t* B;
@@ -159,6 +162,11 @@ struct GemmCtx {
     {
       const int nb = p.tiles_m * p.tiles_n;
       const int b2 = xcd_remap(bid, nb);
+#if QAMD_CTX_MAGIC_DECODE
+      // the division-free decode of the persistent kernels (common.hip.h; p.raster_magic is set by every launcher of a GemmCtx kernel).  NOT the product's choice yet:
+      // prepared at the end of round 4 (no GPU minutes left to validate it); ISA: two 32-bit divisions less at the top of every per-tile workgroup
+      raster_decode(b2, p.tiles_m, p.tiles_n, p.raster_magic, tile_m, tile_n);
+#else
       constexpr int GM = 4;
       const int group = GM * p.tiles_n;
       const int gid = b2 / group;
@@ -166,6 +174,7 @@ struct GemmCtx {
       const int gsz = min(p.tiles_m - first_m, GM);
       tile_m = first_m + (b2 % group) % gsz;
       tile_n = (b2 % group) / gsz;
+#endif
     }
     m0 = tile_m * C::BM;
     n0 = tile_n * C::BN;

@@ -20,6 +20,9 @@ namespace qamd {
 typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
 typedef _Float16 h8_t __attribute__((ext_vector_type(8)));
 
+#ifndef QAMD_CTX_MAGIC_DECODE
+#define QAMD_CTX_MAGIC_DECODE 0
+#endif
 struct NvGemmParams {
   const uint8_t* A;
   const uint8_t* B;
@@ -103,6 +106,9 @@ __global__ __launch_bounds__(C::THREADS) void gemm_nvf4_kernel(const NvGemmParam
   const int z = SPLIT ? (int)blockIdx.x / nb : 0;
   {
     const int b2 = xcd_remap((int)blockIdx.x - z * nb, nb);
+#if QAMD_CTX_MAGIC_DECODE   // (prepared at the end of round 4, not the product's choice yet: gemm_mx.hip.h GemmCtx)
+    raster_decode(b2, p.tiles_m, p.tiles_n, p.raster_magic, tile_m, tile_n);
+#else
     constexpr int GM = 4;
     const int group = GM * p.tiles_n;
     const int gid = b2 / group;
@@ -110,6 +116,7 @@ __global__ __launch_bounds__(C::THREADS) void gemm_nvf4_kernel(const NvGemmParam
     const int gsz = min(p.tiles_m - first_m, GM);
     tile_m = first_m + (b2 % group) % gsz;
     tile_n = (b2 % group) / gsz;
+#endif
   }
   const int m0 = tile_m * BM, n0 = tile_n * BN;
   const int rowbytes = p.K >> 1;
@@ -423,6 +430,9 @@ __global__ __launch_bounds__(C::THREADS) void gemm_nvf4_lds_kernel(const NvGemmP
   {
     const int nb = p.tiles_m * p.tiles_n;
     const int b2 = xcd_remap(blockIdx.x, nb);
+#if QAMD_CTX_MAGIC_DECODE
+    raster_decode(b2, p.tiles_m, p.tiles_n, p.raster_magic, tile_m, tile_n);
+#else
     constexpr int GM = 4;
     const int group = GM * p.tiles_n;
     const int gid = b2 / group;
@@ -430,6 +440,7 @@ __global__ __launch_bounds__(C::THREADS) void gemm_nvf4_lds_kernel(const NvGemmP
     const int gsz = min(p.tiles_m - first_m, GM);
     tile_m = first_m + (b2 % group) % gsz;
     tile_n = (b2 % group) / gsz;
+#endif
   }
   const int m0 = tile_m * BM, n0 = tile_n * BN;
   const int rowbytes = p.K >> 1;
@@ -711,6 +722,7 @@ bool launch_nvf4_ablation(NvGemmParams p, hipStream_t s, int variant) {
     using C = NvLdsCfg<256, 256, 2, 4, b>;                                                                     \
     p.tiles_m = (p.M + C::BM - 1) / C::BM;                                                                     \
     p.tiles_n = (p.N + C::BN - 1) / C::BN;                                                                     \
+    p.raster_magic = raster_magic(p.tiles_n);          \
     hipLaunchKernelGGL((gemm_nvf4_lds_kernel<C>), dim3(p.tiles_m * p.tiles_n), dim3(C::THREADS), 0, s, p);     \
     return true;                                                                                               \
   }
@@ -878,6 +890,7 @@ inline hipError_t launch_nvf4_gemm(NvGemmParams p, hipStream_t s, int variant = 
     using C = NvCfg<256, 256, 2, 4>;
     p.tiles_m = (p.M + C::BM - 1) / C::BM;
     p.tiles_n = (p.N + C::BN - 1) / C::BN;
+    p.raster_magic = raster_magic(p.tiles_n);
     hipLaunchKernelGGL((gemm_nvf4_kernel<C>), dim3(p.tiles_m * p.tiles_n), dim3(C::THREADS), 0, s, p);
     return hipSuccess;
   }
@@ -939,6 +952,7 @@ inline hipError_t launch_nvf4_gemm(NvGemmParams p, hipStream_t s, int variant = 
       using C = NvCfg<BM_, BN_, WM_, WN_>;                                                                     \
       p.tiles_m = (p.M + C::BM - 1) / C::BM;                                                                   \
       p.tiles_n = (p.N + C::BN - 1) / C::BN;                                                                   \
+      p.raster_magic = raster_magic(p.tiles_n);          \
       hipLaunchKernelGGL((gemm_nvf4_kernel<C, true>), dim3(p.tiles_m * p.tiles_n * splits), dim3(C::THREADS), 0, s, p); \
       return hipSuccess;                                                                                       \
     }
@@ -947,6 +961,7 @@ inline hipError_t launch_nvf4_gemm(NvGemmParams p, hipStream_t s, int variant = 
       using C = NvCfg<BM_, BN_, WM_, WN_>;                                                                     \
       p.tiles_m = (p.M + C::BM - 1) / C::BM;                                                                   \
       p.tiles_n = (p.N + C::BN - 1) / C::BN;                                                                   \
+      p.raster_magic = raster_magic(p.tiles_n);          \
       hipLaunchKernelGGL((gemm_nvf4_kernel<C>), dim3(p.tiles_m * p.tiles_n), dim3(C::THREADS), 0, s, p);       \
       return hipSuccess;                                                                                       \
     }
@@ -965,6 +980,7 @@ inline hipError_t launch_nvf4_gemm(NvGemmParams p, hipStream_t s, int variant = 
       using C = NvCfg<128, 128, 2, 2>;
       p.tiles_m = (p.M + C::BM - 1) / C::BM;
       p.tiles_n = (p.N + C::BN - 1) / C::BN;
+      p.raster_magic = raster_magic(p.tiles_n);
       if (splits > 1) hipLaunchKernelGGL((gemm_nvf4_kernel<C, true, true>), dim3(p.tiles_m * p.tiles_n * splits), dim3(C::THREADS), 0, s, p);
       else hipLaunchKernelGGL((gemm_nvf4_kernel<C, false, true>), dim3(p.tiles_m * p.tiles_n), dim3(C::THREADS), 0, s, p);
       return hipSuccess;
@@ -984,11 +1000,13 @@ inline hipError_t launch_nvf4_gemm(NvGemmParams p, hipStream_t s, int variant = 
     using C = NvLdsCfg<128, 128, 2, 2>;
     p.tiles_m = (p.M + C::BM - 1) / C::BM;
     p.tiles_n = (p.N + C::BN - 1) / C::BN;
+    p.raster_magic = raster_magic(p.tiles_n);
     hipLaunchKernelGGL((gemm_nvf4_lds_kernel<C>), dim3(p.tiles_m * p.tiles_n), dim3(C::THREADS), 0, s, p);
   } else {
     using C = NvLdsCfg<256, 256, 2, 4>;
     p.tiles_m = (p.M + C::BM - 1) / C::BM;
     p.tiles_n = (p.N + C::BN - 1) / C::BN;
+    p.raster_magic = raster_magic(p.tiles_n);
     hipLaunchKernelGGL((gemm_nvf4_lds_kernel<C>), dim3(p.tiles_m * p.tiles_n), dim3(C::THREADS), 0, s, p);
   }
   return hipSuccess;
