@@ -52,6 +52,9 @@ namespace qamd {
 #ifndef QAMD_CTX_MAGIC_DECODE
 #define QAMD_CTX_MAGIC_DECODE 0
 #endif
+#ifndef QAMD_RING_KERNARG_EARLY
+#define QAMD_RING_KERNARG_EARLY 0
+#endif
 struct GemmParams {
   const uint8_t* A;
   const uint8_t* B;
@@ -827,6 +830,11 @@ __global__ __launch_bounds__(C::THREADS, (gemm_min_waves_per_eu<C, SCHED>())) vo
   // 100 MHz wall-clock duration, i.e. the clock the chip actually ran at under this kernel's power draw
   const bool clk = (C::ABL & ABL_CLOCK) && p.dbg && blockIdx.x == 0 && threadIdx.x == 0;
   const uint64_t c0 = clk ? __builtin_readcyclecounter() : 0, r0 = clk ? __builtin_amdgcn_s_memrealtime() : 0;
+#if QAMD_RING_KERNARG_EARLY
+  // every scalar argument asked for at entry: ONE scalar-load round ahead of the first LDS-DMA instead of two (what gemm_mx_deepp_kernel does since round 4).
+  // Prepared at the end of round 4, not measured yet -- build with tools/build_variant.py ... -DQAMD_RING_KERNARG_EARLY=1 and A/B the mid-size shapes.
+  asm volatile("" :: "s"(p.A), "s"(p.D), "s"(p.K), "s"(p.b_bytes), "s"(p.ws), "s"(p.splits), "s"(p.ctr), "s"(p.tag));
+#endif
   if constexpr (SCHED == SCHED_RINGP_RM) gemm_mx_ringp<C, true>(smem, p);
   else if constexpr (SCHED == SCHED_RINGP) gemm_mx_ringp<C>(smem, p);
 #if QAMD_BENCH   // gemm_mx_lab.hip.h
