@@ -52,14 +52,14 @@ PY
     sweeps) timeout 900 python benchmarks/bench_mxfp4_mi355x.py --model Llama-3-8B --fused --vendor --max-batch 8192 --reps 30 > $O/bench_sweep_mxfp4_Llama-3-8B.txt 2> $O/sweeps.err; echo "sweep mxfp4 rc=$?"
             timeout 900 python benchmarks/bench_mxfp4_mi355x.py --format nvfp4 --had 16 --model Llama-3-8B --max-batch 8192 --reps 30 > $O/bench_sweep_nvfp4_Llama-3-8B.txt 2>> $O/sweeps.err; echo "sweep nvfp4 rc=$?"
             cat $O/bench_sweep_nvfp4_Llama-3-8B.txt ;;
-    ablibmid) timeout 900 python tools/ab_lib_shapes.py build/exp/libqamd_base.so qutlass_amd/libqutlass_amd.so --fmt=mxf4 --fmt=mxf8 > $O/ab_lib_mid.txt 2> $O/ab_lib_mid.err; echo "ablibmid rc=$?"; cat $O/ab_lib_mid.txt; tail -2 $O/ab_lib_mid.err ;;
+    ablibmid) timeout 900 python tools/ab_lib_shapes.py ${AB_OLD:-build/exp/libqamd_base.so} ${AB_NEW:-qutlass_amd/libqutlass_amd.so} --fmt=mxf4 --fmt=mxf8 > $O/ab_lib_mid.txt 2> $O/ab_lib_mid.err; echo "ablibmid rc=$?"; cat $O/ab_lib_mid.txt; tail -2 $O/ab_lib_mid.err ;;
     ablibmx) timeout 900 python tools/ab_lib_gemm.py ${AB_OLD:-build/exp/libqamd_base.so} ${AB_NEW:-qutlass_amd/libqutlass_amd.so} > $O/ab_lib_gemm.txt 2> $O/ab_lib_gemm.err; echo "ablibmx rc=$?"; cat $O/ab_lib_gemm.txt; timeout 900 python tools/ab_lib_shapes.py ${AB_OLD:-build/exp/libqamd_base.so} ${AB_NEW:-qutlass_amd/libqutlass_amd.so} --big --fmt=${AB_FMT:-mxf4} > $O/ab_lib_mx.txt 2>> $O/ab_lib_gemm.err; cat $O/ab_lib_mx.txt; tail -3 $O/ab_lib_gemm.err ;;
-    ablibnv) timeout 900 python tools/ab_lib_shapes.py build/exp/libqamd_base.so qutlass_amd/libqutlass_amd.so --big --fmt=nvf4 > $O/ab_lib_nv.txt 2> $O/ab_lib_nv.err; timeout 900 python tools/ab_lib_shapes.py build/exp/libqamd_base.so qutlass_amd/libqutlass_amd.so --fmt=nvf4 >> $O/ab_lib_nv.txt 2>> $O/ab_lib_nv.err; echo "ablibnv rc=$?"; cat $O/ab_lib_nv.txt; tail -3 $O/ab_lib_nv.err ;;
+    ablibnv) timeout 900 python tools/ab_lib_shapes.py ${AB_OLD:-build/exp/libqamd_base.so} ${AB_NEW:-qutlass_amd/libqutlass_amd.so} --big --fmt=nvf4 > $O/ab_lib_nv.txt 2> $O/ab_lib_nv.err; timeout 900 python tools/ab_lib_shapes.py ${AB_OLD:-build/exp/libqamd_base.so} ${AB_NEW:-qutlass_amd/libqutlass_amd.so} --fmt=nvf4 >> $O/ab_lib_nv.txt 2>> $O/ab_lib_nv.err; echo "ablibnv rc=$?"; cat $O/ab_lib_nv.txt; tail -3 $O/ab_lib_nv.err ;;
     tracenv) timeout 600 python tools/ab_nvpk.py --trace --shapes none > $O/trace_nvpk.txt 2> $O/trace_nvpk.err; echo "tracenv rc=$?"; cat $O/trace_nvpk.txt; tail -3 $O/trace_nvpk.err ;;
     testq)  timeout 900 python -m pytest tests -m gpu -q -k "quantize or fuzz or Quantize or quest or golden" > $O/pytest_quant.log 2>&1; echo "testq rc=$?"; tail -4 $O/pytest_quant.log ;;
     absf)   timeout 600 python tools/ab_sf_stores.py > $O/ab_sf_stores.txt 2> $O/ab_sf_stores.err; echo "absf rc=$?"; cat $O/ab_sf_stores.txt; tail -3 $O/ab_sf_stores.err ;;
     absq)   timeout 600 python tools/ab_sq_abl.py > $O/ab_sq_abl.txt 2> $O/ab_sq_abl.err; echo "absq rc=$?"; cat $O/ab_sq_abl.txt; tail -3 $O/ab_sq_abl.err ;;
-    ablib)  timeout 900 python tools/ab_lib_shapes.py build/exp/libqamd_base.so qutlass_amd/libqutlass_amd.so > $O/ab_lib_shapes.txt 2> $O/ab_lib_shapes.err; echo "ablib rc=$?"; cat $O/ab_lib_shapes.txt; tail -3 $O/ab_lib_shapes.err ;;
+    ablib)  timeout 900 python tools/ab_lib_shapes.py ${AB_OLD:-build/exp/libqamd_base.so} ${AB_NEW:-qutlass_amd/libqutlass_amd.so} > $O/ab_lib_shapes.txt 2> $O/ab_lib_shapes.err; echo "ablib rc=$?"; cat $O/ab_lib_shapes.txt; tail -3 $O/ab_lib_shapes.err ;;
     configs) timeout 900 python bench_configs.py > $O/bench_configs.jsonl 2> $O/bench_configs.err; echo "configs rc=$?"; tail -30 $O/bench_configs.jsonl | cut -c1-240 ;;
     calibnv) timeout 900 python tools/calib_tiles.py nvf4 > $O/calib_tiles_nvf4.txt 2> $O/calib_tiles_nvf4.err; echo "calibnv rc=$?"; tail -5 $O/calib_tiles_nvf4.txt ;;
     abbwd)  timeout 600 python tools/ab_bwd.py > $O/ab_bwd.txt 2> $O/ab_bwd.err; echo "abbwd rc=$?"; cat $O/ab_bwd.txt; tail -3 $O/ab_bwd.err ;;
