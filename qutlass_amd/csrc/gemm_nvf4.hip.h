@@ -23,6 +23,9 @@ typedef _Float16 h8_t __attribute__((ext_vector_type(8)));
 #ifndef QAMD_CTX_MAGIC_DECODE
 #define QAMD_CTX_MAGIC_DECODE 0
 #endif
+#ifndef QAMD_NV_KERNARG_EARLY
+#define QAMD_NV_KERNARG_EARLY 0
+#endif
 struct NvGemmParams {
   const uint8_t* A;
   const uint8_t* B;
@@ -93,6 +96,9 @@ template <class C, bool SPLIT = false, bool FENCED = false>
 __global__ __launch_bounds__(C::THREADS) void gemm_nvf4_kernel(const NvGemmParams p) {
   constexpr int BM = C::BM, BN = C::BN, MT = C::MT, NT = C::NT;
   __shared__ __attribute__((aligned(16))) char smem[C::LDS_BYTES];
+#if QAMD_NV_KERNARG_EARLY   // one scalar-load round for the kernel arguments (as gemm_mx_deepp_kernel); prepared at the end of round 4, off in the product, not measured yet
+  asm volatile("" :: "s"(p.A), "s"(p.D), "s"(p.K), "s"(p.b_bytes), "s"(p.ws), "s"(p.splits), "s"(p.kt_per));
+#endif
   const float alpha_k = SPLIT ? 1.0f : *p.alpha;       // [r4] fetched here, not where the epilogue starts (a memory round trip on every workgroup's critical path)
 
   const int tid = threadIdx.x;

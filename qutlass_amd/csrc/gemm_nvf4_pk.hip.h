@@ -57,6 +57,9 @@ __global__ __launch_bounds__(256) void gemm_nvf4_pk_kernel(const NvGemmParams p)
   using C = NvPkCfg::C;
   constexpr int MT = 4, NT = 4, STAGE = NvPkCfg::STAGE;
   __shared__ __attribute__((aligned(16))) char smem[NvPkCfg::LDS_BYTES];
+#if QAMD_NV_KERNARG_EARLY   // (gemm_nvf4.hip.h: the four scalar-load rounds ahead of this kernel's first DMA become one; off in the product, not measured yet)
+  asm volatile("" :: "s"(p.A), "s"(p.D), "s"(p.K), "s"(p.b_bytes), "s"(p.raster_magic), "s"(p.sk_tiles), "s"(p.sk_ws), "s"(p.sk_tag), "s"((int)gridDim.x));
+#endif
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;

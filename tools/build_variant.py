@@ -6,7 +6,8 @@
     gpurun -- 'AB_OLD=qutlass_amd/libqutlass_amd.so AB_NEW=build/exp/libqamd_magic.so bash tools/gpu_session.sh <name> ablibmx'
 
 (build/ is git-ignored and travels to the GPU box with the snapshot.)  Compile-time switches that exist for this: QAMD_CTX_MAGIC_DECODE (per-tile MX / NVFP4 kernels
-decode their tile without integer divisions, prepared at the end of round 4), QAMD_DEEPP_SOFF, QAMD_KERNARG_EARLY, QAMD_DEEPP_PEEL, QAMD_DEEPP_EARLYPREP (gemm_mx_deepp.hip.h)."""
+decode their tile without integer divisions, prepared at the end of round 4), QAMD_RING_KERNARG_EARLY / QAMD_NV_KERNARG_EARLY (one scalar-load round for the kernel
+arguments in the per-tile MX kernels / the NVFP4 kernels, likewise prepared and unmeasured), QAMD_DEEPP_SOFF, QAMD_KERNARG_EARLY, QAMD_DEEPP_PEEL, QAMD_DEEPP_EARLYPREP (gemm_mx_deepp.hip.h)."""
 import os
 import sys
 
