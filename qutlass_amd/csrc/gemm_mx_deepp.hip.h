@@ -67,6 +67,9 @@ constexpr int deepp_pair_done_at(int s) { return (s >= 3 && s <= 59 && (s - 3) %
 #ifndef QAMD_KERNARG_EARLY
 #define QAMD_KERNARG_EARLY 1
 #endif
+#ifndef QAMD_DEEPP_RB2
+#define QAMD_DEEPP_RB2 0
+#endif
 #ifndef QAMD_DEEPP_PEEL
 #define QAMD_DEEPP_PEEL 1
 #endif
@@ -356,16 +359,23 @@ __device__ __forceinline__ void gemm_mx_deepp(char* smem, const GemmParams& p, c
         *(v4f*)(scr + (scrW ^ (q << 5)) + nn * 128) =
             v4f{acc[m][2 * h + nn][4 * q + 0], acc[m][2 * h + nn][4 * q + 1], acc[m][2 * h + nn][4 * q + 2], acc[m][2 * h + nn][4 * q + 3]};
   };
-  v4f rb[2][2];
+  // RB2 ([r4], behind QAMD_DEEPP_RB2, OFF: DO NOT ENABLE AS IT IS): a read-back register set per HALF of a pair (32 registers instead of 16; they exist since the
+  // store offsets became scalar), so that a half is read SIX slots ahead of its stores instead of two.  Why: the stage trace (profiles/final_stage_contention_r4.txt)
+  // puts the final stage at ~8 400 cycles on an idle chip, and the stores of a half wait for an LDS round trip that was issued 64 cycles earlier.  The one run it got
+  // (the last 2.6 GPU seconds of round 4, profiles/ab_lib_rb2_r4bj.txt): 1 % SLOWER and the output differs from the product's -- the ISA reads correct (order, registers
+  // and s_waitcnt values checked by hand for the first pairs), the static count of outstanding LDS operations reaches 24 where the product build stays at 16 (the
+  // lgkmcnt field has 4 bits).  Unexplained; the first thing to look at with a GPU in hand.
+  constexpr bool RB2 = QAMD_DEEPP_RB2 && !SK;
+  v4f rb[RB2 ? 4 : 2][2];
   auto retire_read = [&](const int half) __attribute__((always_inline)) {   // rows 16 half .. + 15: passes 2 half, 2 half + 1
 #pragma unroll
     for (int ps = 0; ps < 2; ++ps) {
-      rb[ps][0] = *(const v4f*)(scr + scrR + (2 * half + ps) * 2048);
-      rb[ps][1] = *(const v4f*)(scr + (scrR ^ 16) + (2 * half + ps) * 2048);
+      rb[RB2 ? 2 * half + ps : ps][0] = *(const v4f*)(scr + scrR + (2 * half + ps) * 2048);
+      rb[RB2 ? 2 * half + ps : ps][1] = *(const v4f*)(scr + (scrR ^ 16) + (2 * half + ps) * 2048);
     }
   };
   auto retire_store = [&](const int m, const int h, const int pass) __attribute__((always_inline)) {
-    const v4f lo = rb[pass & 1][0], hi = rb[pass & 1][1];
+    const v4f lo = rb[RB2 ? pass : pass & 1][0], hi = rb[RB2 ? pass : pass & 1][1];
     v4i o;
     if constexpr (LAB & 1) {
       o[0] = (int)pack_bf16x2(lo[0], lo[1]); o[1] = (int)pack_bf16x2(lo[2], lo[3]); o[2] = (int)pack_bf16x2(hi[0], hi[1]); o[3] = (int)pack_bf16x2(hi[2], hi[3]);
@@ -414,7 +424,7 @@ __device__ __forceinline__ void gemm_mx_deepp(char* smem, const GemmParams& p, c
     fence();
     dma_prep(ktn, dvalid);
     fence();
-    static_for<0, 71>([&](auto sc) __attribute__((always_inline)) {
+    static_for<0, RB2 ? 73 : 71>([&](auto sc) __attribute__((always_inline)) {
       constexpr int s = decltype(sc)::value;
       if constexpr (s < 60) {
         constexpr int T = s < 2 ? 0 : s < 4 ? 1 : 2 + (s - 4) / 4;
@@ -430,7 +440,10 @@ __device__ __forceinline__ void gemm_mx_deepp(char* smem, const GemmParams& p, c
       if constexpr (s == 48 || s == 52 || s == 56) { read_fb(0, 0, (s - 48) / 4); read_fb(0, 1, (s - 48) / 4); }
       if constexpr (s == 60) { read_fa(0, 0, 3); read_fa(0, 1, 3); read_fb(0, 0, 3); read_fb(0, 1, 3); }
       // retirement items due in this slot (pair P final at e = 8 P + 3)
-      constexpr int d1 = s - 1, d3 = s - 3, d5 = s - 5, d6 = s - 6, d7 = s - 7, d9 = s - 9, d10 = s - 10;
+      // pair P (final at e = 8 P + 3):   write e+1 | read rows 0-15 e+3 | stores e+5, e+6 | read rows 16-31 e+7 | stores e+9, e+10
+      // RB2:                            write e+1 | read rows 0-15 e+3 | read rows 16-31 e+5 | stores e+9, e+10 (set A) | stores e+11, e+12 (set B);
+      //                                 pair P + 1 reads into set A at e+11 (after P's stores from it, same slot order: stores first) and into set B at e+13
+      constexpr int d1 = s - 1, d3 = s - 3, d5 = s - (RB2 ? 9 : 5), d6 = s - (RB2 ? 10 : 6), d7 = s - (RB2 ? 5 : 7), d9 = s - (RB2 ? 11 : 9), d10 = s - (RB2 ? 12 : 10);
       constexpr int PMIN = (LAB & 6) ? 4 : 0;   // ablations: the pairs of m = 0, 1 are not retired here (bit 1: "stored" one stage earlier; bit 2: never)
       if constexpr ((LAB & 4) && deepp_pair_done_at(d1) >= 0 && deepp_pair_done_at(d1) < 4) {   // ... but their accumulators (and MFMAs) stay alive
         asm volatile("" ::"a"(acc[deepp_pair_done_at(d1) / 2][2 * (deepp_pair_done_at(d1) % 2)]), "a"(acc[deepp_pair_done_at(d1) / 2][2 * (deepp_pair_done_at(d1) % 2) + 1]));

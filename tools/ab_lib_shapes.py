@@ -1,5 +1,5 @@
 """A/B of two builds of libqutlass_amd.so on small / mid-size GEMM shapes of all three formats (same box, interleaved, GPU-only timing through HIP-graph
-replays of the C-ABI call):      python tools/ab_lib_shapes.py old.so new.so > gpurun_out/ab_lib_shapes.txt"""
+replays of the C-ABI call):      python tools/ab_lib_shapes.py old.so new.so [--big | --shapes=MxNxK,...] [--fmt=mxf4 ...] > gpurun_out/ab_lib_shapes.txt"""
 import ctypes, os, sys
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -23,7 +23,8 @@ def main():
     fmts = [a[6:] for a in sys.argv if a.startswith("--fmt=")]
     for fmt, entry, gs, fp8 in (("mxf4", "qutlass_amd_matmul_mxf4_bf16_tn", 32, False), ("mxf8", "qutlass_amd_matmul_mxf8_bf16_tn", 32, True), ("nvf4", "qutlass_amd_matmul_nvf4_bf16_tn", 16, False)):
         if fmts and fmt not in fmts: continue
-        for (m, n, k) in (BIG if "--big" in sys.argv else SHAPES):
+        custom = [tuple(int(v) for v in x.split("x")) for a in sys.argv if a.startswith("--shapes=") for x in a[9:].split(",")]   # --shapes=4096x4096x4096,4100x4360x768
+        for (m, n, k) in (custom or (BIG if "--big" in sys.argv else SHAPES)):
             kb = k if fp8 else k // 2
             if fp8:
                 a = (torch.randn(m, k, device=dev, generator=g) * 2).to(torch.float8_e4m3fn).view(torch.uint8)
