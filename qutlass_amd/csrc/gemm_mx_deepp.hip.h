@@ -352,6 +352,7 @@ __device__ __forceinline__ void gemm_mx_deepp(char* smem, const GemmParams& p, c
     if constexpr (LAB & 2) { est_rD = rD; est_lane = stLane; est_colLim = colLim; }
   };
   auto retire_write = [&](const int m, const int h) __attribute__((always_inline)) {
+    if constexpr (QAMD_DEEPP_RB2 == 2 && !SK) asm volatile("s_waitcnt lgkmcnt(7)" ::: "memory");   // (RB2 = 2: never more than 15 LDS operations outstanding -- the lgkmcnt field has 4 bits)
 #pragma unroll
     for (int nn = 0; nn < 2; ++nn)
 #pragma unroll
@@ -359,15 +360,17 @@ __device__ __forceinline__ void gemm_mx_deepp(char* smem, const GemmParams& p, c
         *(v4f*)(scr + (scrW ^ (q << 5)) + nn * 128) =
             v4f{acc[m][2 * h + nn][4 * q + 0], acc[m][2 * h + nn][4 * q + 1], acc[m][2 * h + nn][4 * q + 2], acc[m][2 * h + nn][4 * q + 3]};
   };
-  // RB2 ([r4], behind QAMD_DEEPP_RB2, OFF: DO NOT ENABLE AS IT IS): a read-back register set per HALF of a pair (32 registers instead of 16; they exist since the
+  // RB2 ([r4], behind QAMD_DEEPP_RB2 = 1 / 2, OFF: DO NOT ENABLE AS IT IS): a read-back register set per HALF of a pair (32 registers instead of 16; they exist since the
   // store offsets became scalar), so that a half is read SIX slots ahead of its stores instead of two.  Why: the stage trace (profiles/final_stage_contention_r4.txt)
   // puts the final stage at ~8 400 cycles on an idle chip, and the stores of a half wait for an LDS round trip that was issued 64 cycles earlier.  The one run it got
   // (the last 2.6 GPU seconds of round 4, profiles/ab_lib_rb2_r4bj.txt): 1 % SLOWER and the output differs from the product's -- the ISA reads correct (order, registers
   // and s_waitcnt values checked by hand for the first pairs), the static count of outstanding LDS operations reaches 24 where the product build stays at 16 (the
-  // lgkmcnt field has 4 bits).  Unexplained; the first thing to look at with a GPU in hand.
+  // lgkmcnt field has 4 bits).  Unexplained; the first thing to look at with a GPU in hand: QAMD_DEEPP_RB2 = 2 is the same schedule with explicit waits that keep the
+  // static count at 15 or below -- if THAT is bit-identical, the counter overflow is the cause (and the compiler's clamp to lgkmcnt(14) is not enough on this part).
   constexpr bool RB2 = QAMD_DEEPP_RB2 && !SK;
   v4f rb[RB2 ? 4 : 2][2];
   auto retire_read = [&](const int half) __attribute__((always_inline)) {   // rows 16 half .. + 15: passes 2 half, 2 half + 1
+    if constexpr (QAMD_DEEPP_RB2 == 2 && !SK) asm volatile("s_waitcnt lgkmcnt(11)" ::: "memory");
 #pragma unroll
     for (int ps = 0; ps < 2; ++ps) {
       rb[RB2 ? 2 * half + ps : ps][0] = *(const v4f*)(scr + scrR + (2 * half + ps) * 2048);
@@ -436,6 +439,7 @@ __device__ __forceinline__ void gemm_mx_deepp(char* smem, const GemmParams& p, c
       if constexpr (s % 3 == 0 && s / 3 < 9) dma_item(d, ktn, 1, 8 + s / 3);
       if constexpr (s == 1) read_scales(0, 0);
       // fragments of the next tile's stage 0, as their registers die: A rows of m after tile (m, 3), B rows of n after (3, n)
+      if constexpr (QAMD_DEEPP_RB2 == 2 && !SK && (s == 12 || s == 28 || s == 44 || s == 48 || s == 52 || s == 56 || s == 60)) asm volatile("s_waitcnt lgkmcnt(11)" ::: "memory");
       if constexpr (s == 12 || s == 28 || s == 44) { read_fa(0, 0, (s - 12) / 16); read_fa(0, 1, (s - 12) / 16); }
       if constexpr (s == 48 || s == 52 || s == 56) { read_fb(0, 0, (s - 48) / 4); read_fb(0, 1, (s - 48) / 4); }
       if constexpr (s == 60) { read_fa(0, 0, 3); read_fa(0, 1, 3); read_fb(0, 0, 3); read_fb(0, 1, 3); }
