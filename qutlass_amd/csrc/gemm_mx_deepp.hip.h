@@ -364,9 +364,9 @@ __device__ __forceinline__ void gemm_mx_deepp(char* smem, const GemmParams& p, c
   // store offsets became scalar), so that a half is read SIX slots ahead of its stores instead of two.  Why: the stage trace (profiles/final_stage_contention_r4.txt)
   // puts the final stage at ~8 400 cycles on an idle chip, and the stores of a half wait for an LDS round trip that was issued 64 cycles earlier.  The one run it got
   // (the last 2.6 GPU seconds of round 4, profiles/ab_lib_rb2_r4bj.txt): 1 % SLOWER and the output differs from the product's -- the ISA reads correct (order, registers
-  // and s_waitcnt values checked by hand for the first pairs), the static count of outstanding LDS operations reaches 24 where the product build stays at 16 (the
-  // lgkmcnt field has 4 bits).  Unexplained; the first thing to look at with a GPU in hand: QAMD_DEEPP_RB2 = 2 is the same schedule with explicit waits that keep the
-  // static count at 15 or below -- if THAT is bit-identical, the counter overflow is the cause (and the compiler's clamp to lgkmcnt(14) is not enough on this part).
+  // and s_waitcnt values checked by hand for the first and the last pairs).  Unexplained; the first thing to look at with a GPU in hand.  (The static count of
+  // outstanding LDS operations reaches 24 in this schedule and the lgkmcnt field has 4 bits -- but the validated K loop reaches 22 by the same count,
+  // tools/lgkm_pressure.py, so that alone is not it.  QAMD_DEEPP_RB2 = 2 is the same schedule with explicit waits keeping the count at 16: one more data point.)
   constexpr bool RB2 = QAMD_DEEPP_RB2 && !SK;
   v4f rb[RB2 ? 4 : 2][2];
   auto retire_read = [&](const int half) __attribute__((always_inline)) {   // rows 16 half .. + 15: passes 2 half, 2 half + 1
