@@ -360,13 +360,15 @@ __device__ __forceinline__ void gemm_mx_deepp(char* smem, const GemmParams& p, c
         *(v4f*)(scr + (scrW ^ (q << 5)) + nn * 128) =
             v4f{acc[m][2 * h + nn][4 * q + 0], acc[m][2 * h + nn][4 * q + 1], acc[m][2 * h + nn][4 * q + 2], acc[m][2 * h + nn][4 * q + 3]};
   };
-  // RB2 ([r4], behind QAMD_DEEPP_RB2 = 1 / 2, OFF: DO NOT ENABLE AS IT IS): a read-back register set per HALF of a pair (32 registers instead of 16; they exist since the
+  // RB2 ([r4], behind QAMD_DEEPP_RB2 = 1 / 2 / 3, OFF: DO NOT ENABLE AS IT IS): a read-back register set per HALF of a pair (32 registers instead of 16; they exist since the
   // store offsets became scalar), so that a half is read SIX slots ahead of its stores instead of two.  Why: the stage trace (profiles/final_stage_contention_r4.txt)
   // puts the final stage at ~8 400 cycles on an idle chip, and the stores of a half wait for an LDS round trip that was issued 64 cycles earlier.  The one run it got
   // (the last 2.6 GPU seconds of round 4, profiles/ab_lib_rb2_r4bj.txt): 1 % SLOWER and the output differs from the product's -- the ISA reads correct (order, registers
-  // and s_waitcnt values checked by hand for the first and the last pairs).  Unexplained; the first thing to look at with a GPU in hand.  (The static count of
-  // outstanding LDS operations reaches 24 in this schedule and the lgkmcnt field has 4 bits -- but the validated K loop reaches 22 by the same count,
-  // tools/lgkm_pressure.py, so that alone is not it.  QAMD_DEEPP_RB2 = 2 is the same schedule with explicit waits keeping the count at 16: one more data point.)
+  // and s_waitcnt values checked by hand for the first and the last pairs; the read -> store data flow of the two ISAs is identical).  Found afterwards, on the CPU:
+  // RB2 = 1 has a VALU write of a store's data registers DIRECTLY behind the (scalar-offset, 16-byte) store -- a hazard the compiler only guards for stores without a
+  // scalar offset; the product never gets closer than one instruction in between (tools/store_data_hazard.py, a CPU test now).  RB2 = 3 = the same schedule with
+  // `s_nop 1` behind every store: the variant to try first with a GPU in hand.  (RB2 = 2: explicit lgkmcnt waits instead -- the static count of outstanding LDS
+  // operations reaches 24 here and the field has 4 bits, but the validated K loop reaches 22 by the same count, tools/lgkm_pressure.py.)
   constexpr bool RB2 = QAMD_DEEPP_RB2 && !SK;
   v4f rb[RB2 ? 4 : 2][2];
   auto retire_read = [&](const int half) __attribute__((always_inline)) {   // rows 16 half .. + 15: passes 2 half, 2 half + 1
@@ -395,6 +397,9 @@ __device__ __forceinline__ void gemm_mx_deepp(char* smem, const GemmParams& p, c
       int ldd2 = p.ldd * 2;
       asm volatile("" : "+s"(ldd2));
       __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, o), rD, (64 * h < colLim) ? stLane : (int)0x80000000, (32 * m + 8 * pass) * ldd2 + 128 * h, ST_AUX);
+      // (RB2 = 3: two wait states behind the store before anything may overwrite its data registers -- the compiler guards that hazard only for stores WITHOUT a scalar
+      //  offset, and RB2 = 1 had a packed multiply of the next pass directly behind the store: tools/store_data_hazard.py, the likely cause of its wrong output)
+      if constexpr (QAMD_DEEPP_RB2 == 3 && !SK) asm volatile("s_nop 1" ::: "memory");
     } else {
     const int off = stLane + ((32 * m + 8 * pass) * p.ldd + 64 * h) * 2;
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, o), rD, (64 * h < colLim) ? off : (int)0x80000000, 0, ST_AUX);
