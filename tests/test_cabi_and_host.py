@@ -761,7 +761,7 @@ def test_no_valu_write_directly_behind_a_scalar_offset_store():
     """[r4] One pattern the compiler does not guard on gfx950, by the evidence of round 4 (tools/store_data_hazard.py has the story): a buffer_store_dwordx3/x4 whose
     soffset is an SGPR, followed ONE instruction later by a VALU write of its data registers.  A schedule that had it (QAMD_DEEPP_RB2) produced output that differed
     from the product's although the two ISAs agree in order, registers, wait counts and read -> store data flow.  The product's closest case has one instruction in
-    between (bit-exact over the GPU suite, the fuzz seeds and 27 whole-output comparisons against the build before it); distance 1 must not appear in any kernel."""
+    between (bit-exact over the GPU suite, fuzz seeds 61-68 and 27 whole-output comparisons against the build before it); distance 1 must not appear in any kernel."""
     import subprocess
     import sys
 

@@ -7,7 +7,7 @@
 LLVM's hazard recogniser inserts wait states between a > 64-bit VMEM store and a VALU write of its data registers (2 on gfx940-family parts) -- but only when the
 store's soffset is not a register (GCNHazardRecognizer::createsVALUHazard).  The QAMD_DEEPP_RB2 schedule put such a write DIRECTLY behind stores with a scalar offset;
 its output differed from the product's although order, registers, wait counts and the whole read -> store data flow of the two ISAs are identical.  The product's
-closest case has one instruction in between and is bit-exact over 473 GPU tests, 30 fuzz seeds and the whole-matrix compares.  So: distance 1 is treated as a bug.
+closest case has one instruction in between and is bit-exact over 473 GPU tests, the fuzz seeds 61-68 and 27 whole-output comparisons against the build before it.  So: distance 1 is treated as a bug.
 
     python tools/store_data_hazard.py [--lab]       # exit status 1 if any kernel of the build has a distance-1 case; prints the closest case per kernel otherwise
 CPU only (hipcc -S of every translation unit of the build, in parallel)."""
