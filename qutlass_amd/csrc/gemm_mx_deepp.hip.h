@@ -95,6 +95,17 @@ __device__ __forceinline__ void gemm_mx_deepp(char* smem, const GemmParams& p, c
       ++trace_n;
     }
   };
+  // (TRACE only) marks INSIDE the final stage: shader cycles at slot 0, 8, 16 ... 64 and behind the last slot of the first four final stages workgroup 0 runs,
+  // dbg[1024 + 16 f + k] -- is the stage's time spread evenly (a throughput bound: LDS bytes, instruction issue) or does it pile up somewhere (tools/final_stage_contention.py)
+  int fs_n = 0;
+  auto trace_fs = [&](const int k) __attribute__((always_inline)) {
+    if constexpr (TRACE) {
+      if (blockIdx.x == 0 && wave == 0 && p.dbg && fs_n < 4) {
+        const uint32_t c = (uint32_t)__builtin_readcyclecounter();
+        if (lane == 0) p.dbg[1024 + 16 * fs_n + k] = c;
+      }
+    }
+  };
   trace();
   uint32_t wg_t0 = 0;
   if constexpr (TRACE) wg_t0 = (uint32_t)__builtin_amdgcn_s_memrealtime();
@@ -464,10 +475,12 @@ __device__ __forceinline__ void gemm_mx_deepp(char* smem, const GemmParams& p, c
       if constexpr (deepp_pair_done_at(d1) >= PMIN) retire_write(deepp_pair_done_at(d1) / 2, deepp_pair_done_at(d1) % 2);
       if constexpr (deepp_pair_done_at(d3) >= PMIN) retire_read(0);
       if constexpr (deepp_pair_done_at(d7) >= PMIN) retire_read(1);
+      if constexpr (TRACE && s % 8 == 0 && s <= 64) trace_fs(s / 8);
       fence();
     });
     // the wave's own A pieces of the next tile's stage 1 overwrite its scratch: its read-backs must have returned first
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if constexpr (TRACE) { trace_fs(9); ++fs_n; }
 #pragma unroll
     for (int i = 0; i < 8; ++i) dma_item(d, ktn, 1, i);
     fence();

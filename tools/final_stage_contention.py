@@ -9,7 +9,8 @@ memory side), de-phasing the workgroups would recover most of it on multi-round 
 This tool answers that with the stage trace of workgroup 0 (lab variant 91: gemm_mx_deepp with TRACE, marks = {entry, first stage read, then per tile: end of the K loop, end of
 the final stage}) at three grid sizes with the SAME work per workgroup (two tiles of 256 x 256 x K each): 8, 64 and 256 workgroups.
     python tools/final_stage_contention.py > gpurun_out/final_stage_contention.txt
-Reads: if `final` grows from 8 to 256 workgroups while `kloop` does not, the burst is the cost.  (Written at the end of round 4 with the GPU budget spent: NOT YET RUN.)"""
+Reads: if `final` grows from 8 to 256 workgroups while `kloop` does not, the burst is the cost (round 4: it does not -- 8 400 cycles with 8 workgroups).  The per-8-slot marks inside the
+final stage (added after that run, not yet run themselves) say whether the time is spread evenly (a throughput bound) or piles up behind particular slots."""
 import os
 import sys
 
@@ -55,13 +56,16 @@ def trace(grid, k, dev):
                 cyc = t[2:2 + 2 * cnt:2].astype("int64"); wall = t[3:3 + 2 * cnt:2].astype("int64")
                 dc = (cyc[1:] - cyc[:-1]) % (1 << 32); dw = ((wall[1:] - wall[:-1]) % (1 << 32)) * 10
                 # marks: 0 entry, 1 first stage in registers, then (end of K loop, end of final stage) per tile
-                rows.append((cnt, [int(x) for x in dc], [int(x) for x in dw]))
+                fs = t[1024:1024 + 64].astype("int64").reshape(4, 16)[:, :10]   # marks inside the first four final stages: slots 0, 8 ... 64, end
+                rows.append((cnt, [int(x) for x in dc], [int(x) for x in dw], [[int((fs[f][k + 1] - fs[f][k]) % (1 << 32)) for k in range(9)] for f in range(4) if fs[f][0]]))
         finally:
             lab.load().qutlass_amd_debug_set_trace_buffer(None)
     rows.sort(key=lambda r: sum(r[2]))
-    cnt, dc, dw = rows[len(rows) // 2]
+    cnt, dc, dw, fsd = rows[len(rows) // 2]
     names = ["prologue"] + [f"tile{i // 2} {'kloop' if i % 2 == 0 else 'final'}" for i in range(len(dc) - 1)]
     print(f"grid {grid:3d} ({m} x {n} x {k}, {tiles} tiles, {cnt} marks): " + " | ".join(f"{nm} {c} cyc {w} ns" for nm, c, w in zip(names, dc, dw)), flush=True)
+    for f, d in enumerate(fsd):
+        print(f"          final stage {f}: cycles per 8 MFMA slots (256 at best) " + " ".join(str(x) for x in d[:8]) + f" | behind the last slot {d[8]}", flush=True)
     return dict(zip(names, dw))
 
 
