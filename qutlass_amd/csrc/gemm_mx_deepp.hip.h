@@ -41,6 +41,33 @@ struct DeepPCfg {
 // final: e(P) = 8 P + 3; inverse (-1: none)
 constexpr int deepp_pair_done_at(int s) { return (s >= 3 && s <= 59 && (s - 3) % 8 == 0) ? (s - 3) / 8 : -1; }
 
+// [r5] MFMA order of the last stage (final_stage16).  Rounds 2-4 ran it tile by tile: the four k-slices of an accumulator tile back to back, with the stage's other
+// instructions threaded between them.  That is the one thing the matrix pipe does badly: an MFMA whose accumulator is the result of the MFMA right before it is fed
+// from inside the pipe ONLY when it follows immediately; with anything in between it waits for the write-back -- ~110-130 cycles per MFMA instead of 32, whatever the
+// retirement looked like (profiles/final_stage_contention_r4.txt and ..._r5a_*: ~8 400-9 000 cycles per stage with the fp32 retirement AND with the bf16-first one).
+// Here the tiles go in BLOCKS of IL (row-major order), k-slice-major inside a block, so two MFMAs on one accumulator are IL slots apart -- the K loop's order on a
+// smaller window.  Slices 0 and 1 of block 0 run before the hand-off (their fragments are in registers; they cover the LDS latency of slices 2, 3).
+//   NS post-hand-off slot s -> k-slice fs_j, tile fs_T;  fs_F(T) = the slot of tile T's last MFMA
+#ifndef QAMD_DEEPP_FS_IL
+#define QAMD_DEEPP_FS_IL 4
+#endif
+// (lab, timing only -- the output is wrong: what the parts of the last stage cost, read off the stage trace of tools/final_stage_contention.py.
+//  bit 0: no retirement at all; bit 1: a piece is its 4 accumulator reads only; bit 2: a piece without its ds_write_b64; bit 3: no read-back / stores;
+//  bit 4: no next-tile DMA / fragment / scale reads inside the stage)
+#ifndef QAMD_FS_ABL
+#define QAMD_FS_ABL 0
+#endif
+#ifndef QAMD_FS_BURST
+#define QAMD_FS_BURST 0
+#endif
+constexpr int fs_T(int IL, int s) { return s < 2 * IL ? s % IL : IL * (1 + (s - 2 * IL) / (4 * IL)) + (s - 2 * IL) % IL; }
+constexpr int fs_j(int IL, int s) { return s < 2 * IL ? 2 + s / IL : ((s - 2 * IL) % (4 * IL)) / IL; }
+constexpr int fs_F(int IL, int T) { return 4 * IL * (T / IL) + IL + T % IL; }
+// the MXFP8 twin: two k-slices per tile, slice 0 of block 0 before the hand-off
+constexpr int fs8_T(int IL, int s) { return s < IL ? s : IL * (1 + (s - IL) / (2 * IL)) + (s - IL) % IL; }
+constexpr int fs8_j(int IL, int s) { return s < IL ? 1 : ((s - IL) % (2 * IL)) / IL; }
+constexpr int fs8_F(int IL, int T) { return 2 * IL * (T / IL) + T % IL; }
+
 
 // TRACE (lab build only): workgroup 0, wave 0 writes {shader cycles, 100 MHz wall ticks} pairs to p.dbg at: kernel entry,
 // first stage landed, entry of the last stage of every tile, end of that stage, kernel exit (after the last store ack).
@@ -72,6 +99,14 @@ constexpr int deepp_pair_done_at(int s) { return (s >= 3 && s <= 59 && (s - 3) %
 #endif
 #ifndef QAMD_DEEPP_PEEL
 #define QAMD_DEEPP_PEEL 1
+#endif
+// [r5] retirement of the last stage: 0 = fp32 through the scratch (rounds 2-4), 1 = bf16 BEFORE the transposition (retire16 below),
+// 2 = 1 + an alpha == 1 arm without the multiply (x * 1.0f == x: same bytes; spills -- kept for the record), 3 = 1 with v_pk_mul_f32 (lab A/B)
+#ifndef QAMD_DEEPP_RETIRE
+#define QAMD_DEEPP_RETIRE 0
+#endif
+#ifndef QAMD_DEEPP8_RETIRE   // the same for the MXFP8 twin (gemm_mx_deepp8): 0 = fp32 through the scratch, 1 = bf16 first
+#define QAMD_DEEPP8_RETIRE 0
 #endif
 template <class C, bool TRACE = false, int ST_AUX = 0, int LAB = 0, bool SK = false, int DMA_SPREAD = 1>
 __device__ __forceinline__ void gemm_mx_deepp(char* smem, const GemmParams& p, const int bid, const int G, const int ntiles) {
@@ -475,16 +510,152 @@ __device__ __forceinline__ void gemm_mx_deepp(char* smem, const GemmParams& p, c
       if constexpr (deepp_pair_done_at(d1) >= PMIN) retire_write(deepp_pair_done_at(d1) / 2, deepp_pair_done_at(d1) % 2);
       if constexpr (deepp_pair_done_at(d3) >= PMIN) retire_read(0);
       if constexpr (deepp_pair_done_at(d7) >= PMIN) retire_read(1);
-      if constexpr (TRACE && s % 8 == 0 && s <= 64) trace_fs(s / 8);
+      if constexpr (TRACE && s % 8 == 0 && s <= 64 + 8 * QAMD_FS_BURST * 6) trace_fs(s / 8);
+#ifdef QAMD_FS_TRACE_SLOTS   // (lab) a mark behind EVERY slot of the first two last stages: dbg[2048 + 128 f + s]
+      if constexpr (TRACE) {
+        if (blockIdx.x == 0 && wave == 0 && p.dbg && fs_n < 2) {
+          const uint32_t c = (uint32_t)__builtin_readcyclecounter();
+          if (lane == 0) p.dbg[2048 + 128 * fs_n + s] = c;
+        }
+      }
+#endif
       fence();
     });
     // the wave's own A pieces of the next tile's stage 1 overwrite its scratch: its read-backs must have returned first
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    if constexpr (TRACE) { trace_fs(9); ++fs_n; }
+    if constexpr (TRACE) { trace_fs(15); ++fs_n; }
 #pragma unroll
     for (int i = 0; i < 8; ++i) dma_item(d, ktn, 1, i);
     fence();
     if constexpr (LAB & 2) pin_acc();   // the accumulators the ablation does not retire must stay live, or their MFMAs are eliminated
+  };
+
+  // ---- [r5] the last stage with the bf16-first retirement ("retire16").  What the round-4 trace said about the fp32 form above (profiles/final_stage_contention_r4.txt):
+  //      ~8 400 cycles per tile against 2 048 of MFMA, on an idle chip -- 512 KiB per tile through LDS as ds_write_b128 (13 cycles of store-data path each:
+  //      3 300 cycles per tile by themselves) and three dependent LDS round trips per pair through ONE scratch and ONE read-back register set.  Here a lane
+  //      converts its accumulator values BEFORE they go to LDS: 4 consecutive columns -> v_accvgpr_read x 4, (alpha) v_mul_f32 x 4, v_cvt_pk_bf16_f32 x 2 ->
+  //      ONE ds_write_b64.  A pair of tiles is then 32 rows x 128 B = 4 KiB: the wave's 8-KiB slice holds TWO pairs (pair P in half P & 1), so the writes of
+  //      pair P + 1 never wait for the read-back of pair P, a read-back is ONE ds_read_b128 per 8 rows x 128 B and goes to the store untouched (no VALU
+  //      between LDS and the store, no read-back -> convert -> store chain), and the bytes through LDS halve (256 KiB per tile, ds_write_b64: 6 cycles each).
+  //      The price is VALU issue: 10 vector instructions per piece, one piece per MFMA slot.
+  //   piece pi = 4 T + q (tile T = 4 m + n in MFMA order, q = the lane's 4 columns 8 q + 4 g .. + 3 of the tile) rides in slot pi + 3 (tile T >= 2 is final
+  //   after slot 4 T - 1, tiles 0 / 1 after slots 1 / 3); pair P = tiles 2 P, 2 P + 1 is read back in slots 8 P + 11 / + 12 and stored in 8 P + 15 .. + 18
+  //   (the last pair: + 13 .. + 16); pair P + 2 writes the same half from slot 8 P + 19 on (LDS operations of a wave execute in order).
+  //   LDS layout of a half: 16 row pairs x 256 B; row r, tile nn, quarter q, lane half g at
+  //       (r >> 1) 256 + nn 128 + (r & 1) 64 + (q ^ ((r >> 1) & 3)) 16 + (g ^ ((r >> 3) & 1)) 8
+  //   -- the 16 lanes of a ds_write_b64 group (rows r .. r + 15, same nn / q / g) hit 16 different 8-byte slots of the 128-byte bank window, and the 16 lanes of
+  //   a ds_read_b128 group 16 different 16-byte chunks of the 256-byte window.  Rows with bit 3 set have their 8-byte halves swapped; a read-back pass covers rows
+  //   8 p + lane / 8, so that is a property of the PASS: odd passes fetch their two halves separately, in the right register order.
+  const int r16w = (i32 >> 1) * 256 + (i32 & 1) * 64 + ((g ^ ((i32 >> 3) & 1)) << 3);
+  const int r16x = ((i32 >> 1) & 3) << 4;
+  const int r16r = (rrl >> 1) * 256 + (ccl >> 2) * 128 + (rrl & 1) * 64 + (((ccl & 3) ^ (rrl >> 1)) << 4);
+  v4i rbh[4];
+  auto final_stage16 = [&](const Desc& d, bool dvalid, const int ktn, auto a1c) __attribute__((always_inline)) {
+    constexpr bool A1 = decltype(a1c)::value;   // alpha == 1: no multiply
+    // D: the slot of the first piece.  QAMD_FS_BURST: the whole retirement BEHIND the MFMAs instead of threaded through them (nothing issues in the shadow of this MFMA with one
+    // wave per SIMD, and a v_accvgpr_read_b32 costs 9.5 cycles while MFMAs run against ~4 when none does: profiles/final_stage_ablation_r5c.txt)
+    constexpr int IL = QAMD_DEEPP_FS_IL, NMF = 64 - 2 * IL, D = QAMD_FS_BURST ? NMF + 1 : IL + 3, NS = 70 + D;
+    static_assert(IL == 1 || IL == 2 || IL == 4, "block of the last stage: 1, 2 or 4 tiles");
+    read_slice(1, 2);
+    read_slice(1, 3);
+    fence();
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int t = 0; t < IL; ++t) mfma1(j, 1, t / 4, t % 4, false);
+    fence();
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // next tile's stage 0 landed (buffer 0); all reads of buffer 1 done
+    __builtin_amdgcn_s_barrier();
+    fence();
+    dma_prep(ktn, dvalid);
+    int wq[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) wq[q] = r16w + (r16x ^ (q << 4));
+    // (odd passes: the second half through its own, opaque base address -- two adjacent 8-byte loads are otherwise merged into one ds_read_b128 + four v_mov_b32
+    //  behind an s_waitcnt lgkmcnt(0) right where the read was issued)
+    int r16r8 = r16r + 8;
+    asm volatile("" : "+v"(r16r8));
+    int ldd2 = p.ldd * 2;
+    asm volatile("" : "+s"(ldd2));
+    fence();
+    auto piece = [&](const int pi) __attribute__((always_inline)) {
+      const int T = pi >> 2, q = pi & 3, m = T >> 2, n = T & 3;
+      float x0 = acc[m][n][4 * q + 0], x1 = acc[m][n][4 * q + 1], x2 = acc[m][n][4 * q + 2], x3 = acc[m][n][4 * q + 3];
+      if constexpr ((QAMD_FS_ABL & 2) != 0) { asm volatile("" ::"v"(x0), "v"(x1), "v"(x2), "v"(x3)); return; }
+      if constexpr (!A1 && QAMD_DEEPP_RETIRE == 3) {   // (lab A/B: what the compiler makes of it -- two v_pk_mul_f32)
+        x0 *= alpha; x1 *= alpha; x2 *= alpha; x3 *= alpha;
+      } else if constexpr (!A1) {   // (plain v_mul_f32: the compiler would pack these into v_pk_mul_f32)
+        asm("v_mul_f32 %0, %1, %2" : "=v"(x0) : "s"(alpha), "v"(x0));
+        asm("v_mul_f32 %0, %1, %2" : "=v"(x1) : "s"(alpha), "v"(x1));
+        asm("v_mul_f32 %0, %1, %2" : "=v"(x2) : "s"(alpha), "v"(x2));
+        asm("v_mul_f32 %0, %1, %2" : "=v"(x3) : "s"(alpha), "v"(x3));
+      }
+      if constexpr ((QAMD_FS_ABL & 4) != 0) { asm volatile("" ::"v"(pack_bf16x2(x0, x1)), "v"(pack_bf16x2(x2, x3))); return; }
+      *(v2i*)(scr + ((T >> 1) & 1) * 4096 + (T & 1) * 128 + wq[q]) = v2i{(int)pack_bf16x2(x0, x1), (int)pack_bf16x2(x2, x3)};
+    };
+    auto readback = [&](const int P, const int pass) __attribute__((always_inline)) {
+      const int o = (P & 1) * 4096 + pass * 1024;
+      if (pass & 1) {
+        const v2i lo = *(const v2i*)(scr + o + r16r8), hi = *(const v2i*)(scr + o + r16r);
+        rbh[pass] = v4i{lo[0], lo[1], hi[0], hi[1]};
+      } else {
+        rbh[pass] = *(const v4i*)(scr + o + r16r);
+      }
+    };
+    // (a wait state behind every store: on gfx950 a VALU write of the data registers of a 16-byte buffer store DIRECTLY behind it corrupts the store also when the store
+    //  carries an SGPR offset -- tests/native/store_hazard_probe.hip, profiles/store_hazard_probe_r5.txt; the compiler guards only stores WITHOUT one.  The read-back
+    //  registers are recycled as conversion temporaries, so this is not hypothetical here; tools/store_data_hazard.py scans the ISA, a CPU test)
+    auto store16 = [&](const int P, const int pass) __attribute__((always_inline)) {
+      const int m = P >> 1, h = P & 1;
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, rbh[pass]), rD, (64 * h < colLim) ? stLane : (int)0x80000000, (32 * m + 8 * pass) * ldd2 + 128 * h, ST_AUX);
+      asm volatile("s_nop 0" : "+v"(rbh[pass]) :: "memory");   // (the data registers stay claimed up to here: nothing else can be allocated into them, i.e. written, before the wait state)
+    };
+    static_for<0, NS>([&](auto sc) __attribute__((always_inline)) {
+      constexpr int s = decltype(sc)::value;
+      if constexpr (s < NMF) {
+        mfma1(fs_j(IL, s), 1, fs_T(IL, s) / 4, fs_T(IL, s) % 4, false);
+        fence();   // the MFMA FIRST in its slot: left to the scheduler it drifts to the end of some slots and the start of others (3 .. 27 instructions between two MFMAs)
+      }
+      // DMA of the next tile's stage 1 into buffer 1 (B pieces + the scale piece; the wave's A pieces land in its scratch: after the loop), the next tile's
+      // stage-0 scales, and its stage-0 fragments as their registers die: A rows of m behind the last MFMA of tile (m, 3), B rows of n behind that of tile (3, n)
+      constexpr bool AUX = (QAMD_FS_ABL & 16) == 0, RETIRE = (QAMD_FS_ABL & 1) == 0, BACK = (QAMD_FS_ABL & 9) == 0;
+      if constexpr (AUX && s % 3 == 0 && s / 3 < 9) dma_item(d, ktn, 1, 8 + s / 3);
+      if constexpr (AUX && s == 1) read_scales(0, 0);
+      static_for<0, 4>([&](auto mc) __attribute__((always_inline)) {
+        constexpr int m = decltype(mc)::value;
+        if constexpr (AUX && s == fs_F(IL, 4 * m + 3) + 1) { read_fa(0, 0, m); read_fa(0, 1, m); }
+        if constexpr (AUX && s == fs_F(IL, 12 + m) + 1) { read_fb(0, 0, m); read_fb(0, 1, m); }
+      });
+      // pair P = tiles 2 P, 2 P + 1: pieces 8 P .. 8 P + 7 in slots 8 P + D .. + 7, read back in 8 P + D + 8 / + 9, stored in + 12 .. + 15 (the last pair: + 10 .. + 13)
+      if constexpr (BACK && s >= D + 12 && (s - D - 12) / 8 < 7 && (s - D - 12) % 8 < 4) store16((s - D - 12) / 8, (s - D - 12) % 8);
+      if constexpr (BACK && s >= D + 66) store16(7, s - D - 66);
+      if constexpr (RETIRE && s >= D && s < D + 64) piece(s - D);
+      if constexpr (BACK && s >= D + 8 && (s - D - 8) % 8 == 0 && (s - D - 8) / 8 < 8) { readback((s - D - 8) / 8, 0); readback((s - D - 8) / 8, 1); }
+      if constexpr (BACK && s >= D + 9 && (s - D - 9) % 8 == 0 && (s - D - 9) / 8 < 8) { readback((s - D - 9) / 8, 2); readback((s - D - 9) / 8, 3); }
+      if constexpr (TRACE && s % 8 == 0 && s <= 64 + 8 * QAMD_FS_BURST * 6) trace_fs(s / 8);
+#ifdef QAMD_FS_TRACE_SLOTS   // (lab) a mark behind EVERY slot of the first two last stages: dbg[2048 + 128 f + s]
+      if constexpr (TRACE) {
+        if (blockIdx.x == 0 && wave == 0 && p.dbg && fs_n < 2) {
+          const uint32_t c = (uint32_t)__builtin_readcyclecounter();
+          if (lane == 0) p.dbg[2048 + 128 * fs_n + s] = c;
+        }
+      }
+#endif
+      fence();
+    });
+    // the wave's own A pieces of the next tile's stage 1 overwrite its scratch: its read-backs must have returned first
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if constexpr (TRACE) { trace_fs(15); ++fs_n; }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) dma_item(d, ktn, 1, i);
+    fence();
+  };
+  constexpr int RET16 = (SK || LAB) ? 0 : QAMD_DEEPP_RETIRE;
+  // (RET16 == 2: the alpha == 1 arm is a second copy of the whole tile walk, entered once per workgroup -- a branch per tile around two copies of the last stage
+  //  makes the register allocator join two hand-scheduled stages and spills 128 registers)
+  auto last_stage = [&](const Desc& d, bool dvalid, const int ktn, auto a1c) __attribute__((always_inline)) {
+    if constexpr (RET16 != 0) final_stage16(d, dvalid, ktn, a1c);
+    else final_stage(d, dvalid, ktn);
   };
 
   using I0 = std::integral_constant<int, 0>;
@@ -622,6 +793,7 @@ __device__ __forceinline__ void gemm_mx_deepp(char* smem, const GemmParams& p, c
   fence();
   trace();
 
+  auto walk = [&](auto a1c) __attribute__((always_inline)) {
   while (tile < ntiles) {
     int m0, n0;
     decode(tile, m0, n0);
@@ -663,10 +835,17 @@ __device__ __forceinline__ void gemm_mx_deepp(char* smem, const GemmParams& p, c
       }
     }
     trace();
-    final_stage(nxt, nvalid, 1);
+    last_stage(nxt, nvalid, 1, a1c);
     trace();
     cur = nxt;
     tile = tnext;
+  }
+  };
+  if constexpr (RET16 == 2) {
+    if (alpha == 1.0f) walk(std::true_type{});
+    else walk(std::false_type{});
+  } else {
+    walk(std::false_type{});
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   trace();
@@ -1014,6 +1193,92 @@ __device__ __forceinline__ void gemm_mx_deepp8(char* smem, const GemmParams& p, 
     fence();
   };
 
+  // ---- [r5] the last stage with the bf16-first retirement (final_stage16 of the fp4 kernel has the layout and the reasons).  An fp8 MFMA is 64 cycles, so the
+  //      64 pieces of a tile ride two per slot: piece pi = 4 T + q in slot pi / 2 + 1 (tile T >= 2 is final after slot 2 T - 1, tiles 0 / 1 after slots 0 / 1); pair P is
+  //      read back in slots 4 P + 5 / + 6 and stored in 4 P + 7 / + 8; pair P + 2 writes the same half of the scratch from slot 4 P + 9 on.
+  const int r16w = (i32 >> 1) * 256 + (i32 & 1) * 64 + ((g ^ ((i32 >> 3) & 1)) << 3);
+  const int r16x = ((i32 >> 1) & 3) << 4;
+  const int r16r = (rrl >> 1) * 256 + (ccl >> 2) * 128 + (rrl & 1) * 64 + (((ccl & 3) ^ (rrl >> 1)) << 4);
+  v4i rbh[4];
+  auto final_stage16 = [&](const Desc& d, bool dvalid, const int ktn) __attribute__((always_inline)) {
+    // MFMA order: blocks of IL tiles, k-slice-major inside a block (fs8_* above; why: the comment at fs_T).  Two pieces per 64-cycle slot: piece pi = 4 T + q in slot
+    // pi / 2 + D; pair P: pieces in slots 4 P + D .. + 3, read back in 4 P + D + 4 / + 5, stored in + 6 / + 7.
+    constexpr int IL = QAMD_DEEPP_FS_IL, NMF = 32 - IL, D = IL / 2 + 2, NS = 36 + D;
+    static_assert(IL == 1 || IL == 2 || IL == 4, "block of the last stage: 1, 2 or 4 tiles");
+    read_slice(1, 1);
+    fence();
+#pragma unroll
+    for (int t = 0; t < IL; ++t) mfma1(0, 1, t / 4, t % 4, false);   // slice 0 of block 0: covers the latency of R(1)
+    fence();
+    __builtin_amdgcn_s_waitcnt(0x0070);   // vmcnt(0) lgkmcnt(0), as a builtin: the compiler's wait-count scoreboard sees it
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    fence();
+    dma_prep(d, ktn, dvalid);
+    int wq[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) wq[q] = r16w + (r16x ^ (q << 4));
+    int r16r8 = r16r + 8;   // (odd passes fetch their swapped halves through a second, opaque base: two adjacent 8-byte loads would be merged into one ds_read_b128 + v_mov_b32 x 4)
+    asm volatile("" : "+v"(r16r8));
+    int ldd2 = p.ldd * 2;
+    asm volatile("" : "+s"(ldd2));
+    fence();
+    auto piece = [&](const int pi) __attribute__((always_inline)) {
+      const int T = pi >> 2, q = pi & 3, m = T >> 2, n = T & 3;
+      float x0 = acc[m][n][4 * q + 0], x1 = acc[m][n][4 * q + 1], x2 = acc[m][n][4 * q + 2], x3 = acc[m][n][4 * q + 3];
+      asm("v_mul_f32 %0, %1, %2" : "=v"(x0) : "s"(alpha), "v"(x0));
+      asm("v_mul_f32 %0, %1, %2" : "=v"(x1) : "s"(alpha), "v"(x1));
+      asm("v_mul_f32 %0, %1, %2" : "=v"(x2) : "s"(alpha), "v"(x2));
+      asm("v_mul_f32 %0, %1, %2" : "=v"(x3) : "s"(alpha), "v"(x3));
+      *(v2i*)(scr + ((T >> 1) & 1) * 4096 + (T & 1) * 128 + wq[q]) = v2i{(int)pack_bf16x2(x0, x1), (int)pack_bf16x2(x2, x3)};
+    };
+    auto readback = [&](const int P, const int pass) __attribute__((always_inline)) {
+      const int o = (P & 1) * 4096 + pass * 1024;
+      if (pass & 1) {
+        const v2i lo = *(const v2i*)(scr + o + r16r8), hi = *(const v2i*)(scr + o + r16r);
+        rbh[pass] = v4i{lo[0], lo[1], hi[0], hi[1]};
+      } else {
+        rbh[pass] = *(const v4i*)(scr + o + r16r);
+      }
+    };
+    auto store16 = [&](const int P, const int pass) __attribute__((always_inline)) {   // (+ a wait state: see the fp4 kernel's store16)
+      const int m = P >> 1, h = P & 1;
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, rbh[pass]), rD, (64 * h < colLim) ? stLane : (int)0x80000000, (32 * m + 8 * pass) * ldd2 + 128 * h, ST_AUX);
+      asm volatile("s_nop 0" : "+v"(rbh[pass]) :: "memory");   // (the data registers stay claimed up to here: nothing else can be allocated into them, i.e. written, before the wait state)
+    };
+    static_for<0, NS>([&](auto sc) __attribute__((always_inline)) {
+      constexpr int s = decltype(sc)::value;
+      if constexpr (s < NMF) {
+        mfma1(fs8_j(IL, s), 1, fs8_T(IL, s) / 4, fs8_T(IL, s) % 4, false);
+        fence();
+      }
+      if constexpr (s % 2 == 0 && s / 2 < 9) dma_item(d, ktn, 1, 8 + s / 2);
+      if constexpr (s == 1) scales_load(0);
+      if constexpr (s == 4) scales_fin(0);
+      // slice 0 of the next tile's stage 0, as the registers die: A rows of m behind the last MFMA of tile (m, 3), B rows of n behind that of tile (3, n)
+      static_for<0, 4>([&](auto mc) __attribute__((always_inline)) {
+        constexpr int m = decltype(mc)::value;
+        if constexpr (s == fs8_F(IL, 4 * m + 3) + 1) read_fa(0, 0, m);
+        if constexpr (s == fs8_F(IL, 12 + m) + 1) read_fb(0, 0, m);
+      });
+      if constexpr (s >= D + 6 && (s - D - 6) % 4 == 0 && (s - D - 6) / 4 < 8) { store16((s - D - 6) / 4, 0); store16((s - D - 6) / 4, 1); }
+      if constexpr (s >= D + 7 && (s - D - 7) % 4 == 0 && (s - D - 7) / 4 < 8) { store16((s - D - 7) / 4, 2); store16((s - D - 7) / 4, 3); }
+      if constexpr (s >= D && s < D + 32) { piece(2 * (s - D)); piece(2 * (s - D) + 1); }
+      if constexpr (s >= D + 4 && (s - D - 4) % 4 == 0 && (s - D - 4) / 4 < 8) { readback((s - D - 4) / 4, 0); readback((s - D - 4) / 4, 1); }
+      if constexpr (s >= D + 5 && (s - D - 5) % 4 == 0 && (s - D - 5) / 4 < 8) { readback((s - D - 5) / 4, 2); readback((s - D - 5) / 4, 3); }
+      fence();
+    });
+    __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): the retirement reads of the scratch slice (and NN: the asm fragment reads)
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int i = 0; i < 8; ++i) dma_item(d, ktn, 1, i);
+    fence();
+  };
+  auto last_stage = [&](const Desc& d, bool dvalid, const int ktn) __attribute__((always_inline)) {
+    if constexpr (!SK && QAMD_DEEPP8_RETIRE != 0) final_stage16(d, dvalid, ktn);
+    else final_stage(d, dvalid, ktn);
+  };
+
   using I0 = std::integral_constant<int, 0>;
   using I1 = std::integral_constant<int, 1>;
   using BT = std::integral_constant<bool, true>;
@@ -1169,7 +1434,7 @@ __device__ __forceinline__ void gemm_mx_deepp8(char* smem, const GemmParams& p, 
       d.mrem = tonext ? nxt.mrem : cur.mrem;
       stage(I0{}, BF{}, d, tonext ? 0 : kt + 3, tonext ? nvalid : true);
     }
-    final_stage(nxt, nvalid, 1);
+    last_stage(nxt, nvalid, 1);
     cur = nxt;
     tile = tnext;
   }

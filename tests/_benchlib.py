@@ -16,7 +16,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), "qutlass_amd", "libqutlass_amd_bench.so")
+LIB_PATH = os.environ.get("QAMD_LAB_LIB") or os.path.join(os.path.dirname(_HERE), "qutlass_amd", "libqutlass_amd_bench.so")   # (QAMD_LAB_LIB: a side build of the lab library, tools/build_variant.py --lab)
 
 _vp, _i64, _i32 = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int
 _GEMM = [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _vp]

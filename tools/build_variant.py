@@ -21,7 +21,12 @@ def main():
         sys.exit(__doc__)
     out = os.path.abspath(sys.argv[1])
     os.makedirs(os.path.dirname(out), exist_ok=True)
-    build._compile_units(out, build.UNITS, sys.argv[2:], verbose=True)
+    flags = [a for a in sys.argv[2:] if a != "--lab"]
+    if "--lab" in sys.argv:   # the LAB library with extra flags (stage traces need its TRACE instantiations): QAMD_LAB_LIB=<out> python tools/final_stage_contention.py
+        units = [int(u) for u in os.environ.get("QAMD_UNITS", "").split(",") if u] or build.UNITS_BENCH
+        build._compile_units(out, units, ["-DQAMD_BENCH=1"] + flags, verbose=True)
+    else:
+        build._compile_units(out, build.UNITS, flags, verbose=True)
     print("built", out)
 
 

@@ -56,16 +56,25 @@ def trace(grid, k, dev):
                 cyc = t[2:2 + 2 * cnt:2].astype("int64"); wall = t[3:3 + 2 * cnt:2].astype("int64")
                 dc = (cyc[1:] - cyc[:-1]) % (1 << 32); dw = ((wall[1:] - wall[:-1]) % (1 << 32)) * 10
                 # marks: 0 entry, 1 first stage in registers, then (end of K loop, end of final stage) per tile
-                fs = t[1024:1024 + 64].astype("int64").reshape(4, 16)[:, :10]   # marks inside the first four final stages: slots 0, 8 ... 64, end
-                rows.append((cnt, [int(x) for x in dc], [int(x) for x in dw], [[int((fs[f][k + 1] - fs[f][k]) % (1 << 32)) for k in range(9)] for f in range(4) if fs[f][0]]))
+                fs = t[1024:1024 + 64].astype("int64").reshape(4, 16)   # marks inside the first four final stages: slots 0, 8 ... (mark k = slot 8 k), mark 15 = the end
+                def deltas(r):
+                    ks = [k for k in range(15) if r[k]] + [15]
+                    return [int((r[b] - r[a]) % (1 << 32)) for a, b in zip(ks[:-1], ks[1:])]
+                rows.append((cnt, [int(x) for x in dc], [int(x) for x in dw], [deltas(fs[f]) for f in range(4) if fs[f][0]]))
         finally:
             lab.load().qutlass_amd_debug_set_trace_buffer(None)
     rows.sort(key=lambda r: sum(r[2]))
     cnt, dc, dw, fsd = rows[len(rows) // 2]
     names = ["prologue"] + [f"tile{i // 2} {'kloop' if i % 2 == 0 else 'final'}" for i in range(len(dc) - 1)]
     print(f"grid {grid:3d} ({m} x {n} x {k}, {tiles} tiles, {cnt} marks): " + " | ".join(f"{nm} {c} cyc {w} ns" for nm, c, w in zip(names, dc, dw)), flush=True)
+    if os.environ.get("QAMD_FS_TRACE_SLOTS"):   # a lab side build with -DQAMD_FS_TRACE_SLOTS: cycles of every slot of the first two last stages
+        t = buf.cpu().numpy().astype("int64")
+        for f in range(2):
+            m = t[2048 + 128 * f:2048 + 128 * f + 128]
+            n = int((m != 0).sum())
+            print(f"          final stage {f}, cycles per slot: " + " ".join(str(int((m[i + 1] - m[i]) % (1 << 32))) for i in range(n - 1)), flush=True)
     for f, d in enumerate(fsd):
-        print(f"          final stage {f}: cycles per 8 MFMA slots (256 at best) " + " ".join(str(x) for x in d[:8]) + f" | behind the last slot {d[8]}", flush=True)
+        print(f"          final stage {f}: cycles per 8 slots (256 at best with an MFMA in each) " + " ".join(str(x) for x in d[:-1]) + f" | behind the last mark {d[-1]}", flush=True)
     return dict(zip(names, dw))
 
 

@@ -71,6 +71,20 @@ PY
     testbwd) timeout 600 python -m pytest tests -m gpu -q -k "backward or quartet or bwd or transpos or square" > $O/pytest_bwd.log 2>&1; echo "testbwd rc=$?"; tail -4 $O/pytest_bwd.log ;;
     contention) timeout 300 python tools/final_stage_contention.py > $O/final_stage_contention.txt 2> $O/final_stage_contention.err; echo "contention rc=$?"; cat $O/final_stage_contention.txt; tail -3 $O/final_stage_contention.err ;;
     abmx)   timeout 900 python tools/ab_mxsk.py > $O/ab_mxsk.txt 2> $O/ab_mxsk.err; echo "abmx rc=$?"; cat $O/ab_mxsk.txt; tail -3 $O/ab_mxsk.err ;;
+    hazard) (cd tests/native && hipcc --offload-arch=gfx950 -O2 store_hazard_probe.hip -o store_hazard_probe 2>/dev/null); timeout 120 tests/native/store_hazard_probe > $O/store_hazard_probe.txt 2>&1; echo "hazard rc=$?"; cat $O/store_hazard_probe.txt ;;
+    libdiff) # [r5] where do two builds disagree: LD_PAIRS="old.so:new.so:fmt ..." (tools/lib_diff.py)
+            for pr in ${LD_PAIRS:-build/exp/libqamd_base.so:qutlass_amd/libqutlass_amd.so:mxf4}; do IFS=: read a b f <<< "$pr"
+              echo "== $a vs $b ($f)" >> $O/lib_diff.txt; timeout 300 python tools/lib_diff.py $a $b --fmt=$f >> $O/lib_diff.txt 2>> $O/lib_diff.err; done
+            echo "libdiff rc=$?"; cat $O/lib_diff.txt; tail -3 $O/lib_diff.err ;;
+    abpairs) # [r5] timing of pairs of builds on chosen shapes: AB_PAIRS="old.so:new.so:fmt:shapes ..." (tools/ab_lib_shapes.py)
+            for pr in $AB_PAIRS; do IFS=: read a b f sh <<< "$pr"
+              echo "== $a vs $b" >> $O/ab_pairs.txt; timeout 600 python tools/ab_lib_shapes.py $a $b --fmt=$f --shapes=$sh >> $O/ab_pairs.txt 2>> $O/ab_pairs.err; done
+            echo "abpairs rc=$?"; cat $O/ab_pairs.txt; tail -3 $O/ab_pairs.err ;;
+    pmcgemm) # [r5] SQ / TCC / GRBM counter passes of ONE lab variant of the MXFP4 GEMM at 4096^3 (PMC_VARIANT, default 90 = the product's persistent kernel)
+            (cd tests/native && bash build.sh > /dev/null 2>&1); timeout 900 bash tools/pmc_gemm.sh ${PMC_VARIANT:-90} $O/pmc_gemm > $O/pmc_gemm.log 2>&1; echo "pmcgemm rc=$?"; cat $O/pmc_gemm/summary.txt | cut -c1-200 | head -120 ;;
+    contabl) # [r5] the stage trace under side builds of the lab library (CONT_LIBS="a.so b.so ..."; tools/build_variant.py --lab -DQAMD_FS_ABL=...)
+            for l in $CONT_LIBS; do echo "== $l" >> $O/contention_abl.txt; QAMD_LAB_LIB=$l timeout 300 python tools/final_stage_contention.py 2>> $O/contention_abl.err | grep -A2 "^grid" | grep -v "^--" >> $O/contention_abl.txt; done
+            echo "contabl rc=$?"; cat $O/contention_abl.txt; tail -3 $O/contention_abl.err ;;
     *) echo "unknown step $step" ;;
   esac
   echo "[$step: $(( $(date +%s) - t0 )) s]"

@@ -5,9 +5,11 @@
     v_... v[a..b] ...                                           <- a VALU write of the store's DATA registers one instruction later
 
 LLVM's hazard recogniser inserts wait states between a > 64-bit VMEM store and a VALU write of its data registers (2 on gfx940-family parts) -- but only when the
-store's soffset is not a register (GCNHazardRecognizer::createsVALUHazard).  The QAMD_DEEPP_RB2 schedule put such a write DIRECTLY behind stores with a scalar offset;
-its output differed from the product's although order, registers, wait counts and the whole read -> store data flow of the two ISAs are identical.  The product's
-closest case has one instruction in between and is bit-exact over 473 GPU tests, the fuzz seeds 61-68 and 27 whole-output comparisons against the build before it.  So: distance 1 is treated as a bug.
+store's soffset is not a register (GCNHazardRecognizer::createsVALUHazard).  [r5] SETTLED ON THE DEVICE (tests/native/store_hazard_probe.hip, profiles/store_hazard_probe_r5.txt,
+2.1e9 stored words per case): with an SGPR soffset a VALU write DIRECTLY behind the store corrupts it (v_mov_b32: 3.3e6 wrong words, v_pk_mul_f32: 1.2e8), ONE wait state
+(any instruction in between) is enough; without an SGPR soffset two are needed (what the compiler inserts); an LDS read returning into the data registers is harmless.
+The round-4 QAMD_DEEPP_RB2 = 1 variant had exactly this pattern on one store per pair, and its wrong outputs are exactly that store's elements (tools/lib_diff.py,
+profiles/lib_diff_r5a_rb2_and_bf16_first.txt: always pair 6, pass 1, elements 2-3 of the lane's 16 bytes).  So: distance 1 (directly behind) is a bug, distance >= 2 is safe.
 
     python tools/store_data_hazard.py [--lab]       # exit status 1 if any kernel of the build has a distance-1 case; prints the closest case per kernel otherwise
 CPU only (hipcc -S of every translation unit of the build, in parallel)."""
