@@ -636,7 +636,8 @@ void orc_mxfp4_transpose_mxfp8(const uint8_t* x_fp4, const uint8_t* scales, int6
         const uint8_t byte = x_fp4[row * (n / 2) + col / 2];
         const uint8_t code = (col & 1) ? (byte >> 4) : (byte & 0xF);
         const uint8_t se = scales[row * (n / 32) + col / 32];
-        const float s_in = bf16_to_f32(se ? (uint16_t)((uint16_t)se << 7) : (uint16_t)0x0040);
+        /* __nv_cvt_e8m0_to_bf16raw (:658-660): 0 -> 2^-127 (bits 0x0040), 0xFF -> NaN (the e8m0 NaN), else 2^(se-127) */
+        const float s_in = se == 0xFF ? NAN : bf16_to_f32(se ? (uint16_t)((uint16_t)se << 7) : (uint16_t)0x0040);
         v[k] = bf16_to_f32(f32_to_bf16_rne(orc_e2m1_decode(code) * s_in));
         amax = fmaxf(amax, fabsf(v[k]));
       }

@@ -167,7 +167,7 @@ __global__ __launch_bounds__(NWAVES * 64) void gemm_mx_fusedq_kernel(const Fused
 #pragma unroll
         for (int r = 0; r < 16; ++r) t[r] = ldexpf(y[r], sh);
       }
-      const uint32_t P = e2m1_pack8<HWCVT>(t), Q = e2m1_pack8<HWCVT>(t + 8);
+      const uint32_t P = e2m1_pack8<HWCVT, true>(t), Q = e2m1_pack8<HWCVT, true>(t + 8);   // (NaN -> 0x7 like the stand-alone quantizer: quantize.hip.h nan_to_pinf)
       auto sw = __builtin_amdgcn_permlane32_swap(P, Q, false, false);
       const uint32_t X = sw[0], Y = sw[1];
       v2i o;   // bytes 8 g .. 8 g + 7 of the group's 16 code bytes

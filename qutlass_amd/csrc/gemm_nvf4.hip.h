@@ -69,15 +69,13 @@ struct NvCfg {
   static constexpr int SPW = (NSIA + NSIB + NWAVES - 1) / NWAVES;   // 1-KiB scale pieces per wave (2 for the 4-wave config)
 };
 
-// 4 e4m3 scale bytes (one dword of the blocked layout) -> two packed-f16 pairs, exact:
-// f16 bits = (byte & 0x7f) << 7 is the same significand at exponent bias 15 instead of 7 (+8), so
-// multiplying by 2^8 (and letting f16 subnormals through) gives the e4m3 value.
+// 4 e4m3 scale bytes (one dword of the blocked layout) -> two packed-f16 pairs, exact: the hardware convert (OCP e4m3fn: sign honoured, 0x7f / 0xff = NaN), two
+// instructions.  [r5] Rounds 1-4 built the f16 bits with integer operations here ((byte & 0x7f) << 7, times 2^8): the same value for every byte the quantizer emits,
+// but the sign bit was dropped and 0x7f decoded to 480 where the persistent kernel (v_cvt_scalef32_pk_f16_fp8 since round 4) and the oracle say NaN -- one call
+// could change meaning with the shape-dependent dispatch (tests/test_gpu_round5.py::test_matmul_nvf4_nan_scale_bytes_decode_the_same_in_every_kernel).
 __device__ __forceinline__ void e4m3x4_to_f16(uint32_t d, h2_t& s01, h2_t& s23) {
-  const uint32_t lo = ((d & 0x7fu) << 7) | ((d & 0x7f00u) << 15);
-  const uint32_t hi = (((d >> 16) & 0x7fu) << 7) | (((d >> 16) & 0x7f00u) << 15);
-  const h2_t k = {(_Float16)256.0f, (_Float16)256.0f};
-  s01 = __builtin_bit_cast(h2_t, lo) * k;
-  s23 = __builtin_bit_cast(h2_t, hi) * k;
+  s01 = __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(d, 1.0f, false);
+  s23 = __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(d, 1.0f, true);
 }
 
 // one dword = 8 e2m1 (element 2b = low nibble of byte b) -> 8 f16 scaled by s (broadcast pair)

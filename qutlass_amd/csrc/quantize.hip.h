@@ -65,11 +65,34 @@ __device__ __forceinline__ uint32_t e2m1_pack2_hw(uint32_t old, float lo, float 
   return __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(old, lo, hi, scale, BYTE);
 }
 
-// 8 values -> one dword.  `scale` (a power of two; HWCVT only) divides the values inside the convert.
-template <bool HWCVT>
+// [r5] NaN -> +inf in one instruction (v_min_f32 returns its non-NaN operand; every other value, +-inf included, passes unchanged).  The reference's convert,
+// cvt.rn.satfinite.e2m1x2.f32, maps a NaN of EITHER sign to +6 = 0x7 (epilogue_quant.h:77-97; oracle orc_e2m1_encode); v_cvt_scalef32_pk_fp4_f32 keeps the NaN's
+// sign (0x7 or 0xf) -- and the NaNs an MFMA rotation makes of a NaN / inf activation come out negative (tests/test_gpu_round5.py, tools/dbg_special_quant.py).
+#ifndef QAMD_Q_NANFIX
+#define QAMD_Q_NANFIX 1
+#endif
+__device__ __forceinline__ float nan_to_pinf(float v) {
+#if QAMD_Q_NANFIX
+  float r;
+  asm("v_min_f32 %0, 0x7f800000, %1" : "=v"(r) : "v"(v));
+  return r;
+#else
+  return v;
+#endif
+}
+
+// 8 values -> one dword.  `scale` (a power of two; HWCVT only) divides the values inside the convert.  NANFIX: the forward quantizers' exact NaN code (above).
+template <bool HWCVT, bool NANFIX = false>
 __device__ __forceinline__ uint32_t e2m1_pack8(const float* t, float scale = 1.0f) {
   if (HWCVT) {
     uint32_t r = 0;
+    if constexpr (NANFIX) {
+      r = e2m1_pack2_hw<0>(r, nan_to_pinf(t[0]), nan_to_pinf(t[1]), scale);
+      r = e2m1_pack2_hw<1>(r, nan_to_pinf(t[2]), nan_to_pinf(t[3]), scale);
+      r = e2m1_pack2_hw<2>(r, nan_to_pinf(t[4]), nan_to_pinf(t[5]), scale);
+      r = e2m1_pack2_hw<3>(r, nan_to_pinf(t[6]), nan_to_pinf(t[7]), scale);
+      return r;
+    }
     r = e2m1_pack2_hw<0>(r, t[0], t[1], scale);
     r = e2m1_pack2_hw<1>(r, t[2], t[3], scale);
     r = e2m1_pack2_hw<2>(r, t[4], t[5], scale);
@@ -125,6 +148,7 @@ __device__ __forceinline__ uint32_t e4m3_encode_pos(float a) {
 }
 __device__ __forceinline__ float e4m3_decode_pos(uint32_t b) {
   const uint32_t e = b >> 3, m = b & 7;
+  if (b == 0x7Fu) return __uint_as_float(0x7fc00000u);   // [r5] the format's NaN (a NaN group statistic): `SF > 0` is then false and the group's multiplier 0, as in the reference
   return e ? __uint_as_float(((e + 120u) << 23) | (m << 20)) : (float)m * 0.001953125f;
 }
 
@@ -310,7 +334,17 @@ __global__ __launch_bounds__(256) void fused_quantize_kernel(const QuantParams p
         } else {
           hf = *(const v8bf*)(hT + hoist_guard + (jt * 32 + row) * HROW + (kc * 16 + half * 8) * 2);
         }
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(hf, xf[kc], acc, 0, 0, 0);
+        if constexpr (R < 32) {
+          // [r5] R = 16: the two 16-element rows that share this 32-wide tile get an accumulator EACH.  Summed into one (rounds 1-4), the zero blocks of
+          // blockdiag(h, h) met the OTHER row's inputs -- 0 x NaN / 0 x inf = NaN: one non-finite activation poisoned its neighbour's whole group, which the
+          // reference's per-row GEMM cannot do (tests/test_gpu_round5.py).  Step kc feeds columns j = 16 kc .. + 15 only = registers 8 kc .. + 7 of a lane.
+          const v16f z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+          const v16f part = __builtin_amdgcn_mfma_f32_32x32x16_bf16(hf, xf[kc], z, 0, 0, 0);
+#pragma unroll
+          for (int r = 0; r < 8; ++r) acc[8 * kc + r] = part[8 * kc + r];
+        } else {
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(hf, xf[kc], acc, 0, 0, 0);
+        }
       }
       // acc[4q+e] = y[r_abs][32 jt + 8q + 4 half + e]
       const int64_t grp32 = r_abs * JT + jt;   // 32-element group index in the flat output
@@ -318,12 +352,17 @@ __global__ __launch_bounds__(256) void fused_quantize_kernel(const QuantParams p
       if (!NV) {
         // ------------------------------ MX: e8m0 per 32 ----------------------------------------
         float scale;
+        // nan_risk: the group may hold NaNs.  A NaN activation makes ALL outputs of its rotation NaN (0 x NaN included), an inf makes them +-inf or NaN: the
+        // maximum (which ignores NaNs) is then exactly 0 or inf, the variance NaN or inf -- conditions that are free to test and (all-zero groups aside) never
+        // true on real activations.  Only such groups pay for the NaN -> 0x7 fix-up below (1-5 % of the kernel when done unconditionally, profiles/ab_stream_r5n_*).
+        bool nan_risk;
         if (METHOD == METHOD_ABSMAX) {
           float m = 0.f;
 #pragma unroll
           for (int r = 0; r < 16; ++r) m = fmaxf(m, fabsf(acc[r]));
           m = xhalf_max(m);
           scale = m + 1e-8f;
+          nan_risk = m == 0.f;
         } else {
           float s1 = 0.f, s2 = 0.f;
 #pragma unroll
@@ -337,9 +376,23 @@ __global__ __launch_bounds__(256) void fused_quantize_kernel(const QuantParams p
           const float var = fmaf(-mean, mean, s2 * 0.03125f);
           scale = 1.0f;
           if (var >= 0.f) scale = (float)((double)sqrtf(var) * (2.92247856 / 6.) + 1e-8);
+          nan_risk = !(var >= 0.f);
         }
         const uint32_t e8 = (__float_as_uint(scale) >> 23) & 0xffu;   // floor to 2^e, keep exponent
-        const int sh = 127 - (int)e8;                                 // y / 2^(e8-127) == ldexp(y, sh)
+        int sh = 127 - (int)e8;                                       // y / 2^(e8-127) == ldexp(y, sh)
+        // [r5] an infinite scale (a group that holds +-inf, or whose sum of squares overflows): the reference divides by it -- finite / inf = 0, inf / inf = NaN -> 0x7
+        // (epilogue_quant.h:546-550, :565-569).  Neither the pre-scaled multiply (inf * 2^-128 = inf -> +-6) nor the convert's own scale operand (2^128 = inf:
+        // every code comes out 7) does that, so this rare arm multiplies by 0 first (0 or NaN, the same two outcomes) and converts with unit scale.
+        const bool inf_scale = e8 == 255u;
+        if (__builtin_expect(inf_scale, 0)) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[r] = acc[r] * 0.0f;
+          sh = 0;
+        }
+        if (__builtin_expect(inf_scale || nan_risk, 0)) {   // NaN -> +inf -> code 0x7 (nan_to_pinf above; a NaN never passes the clip test either way)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[r] = nan_to_pinf(acc[r]);
+        }
         float t[16];
         uint32_t mbits = 0;
         float cs = 1.0f;   // scale operand of the hardware convert
@@ -351,7 +404,7 @@ __global__ __launch_bounds__(256) void fused_quantize_kernel(const QuantParams p
         } else if (HWCVT) {
           // [r3] y / 2^(e8-127) happens inside the convert (see e2m1_pack2_hw): no v_ldexp_f32 per element.  The clip test
           // |y * 2^sh| < 6 is |y| < 6 * 2^-sh (power-of-two scaling of either side is exact).
-          cs = __uint_as_float(e8 << 23);   // e8 >= 100: scale >= 1e-8
+          cs = inf_scale ? 1.0f : __uint_as_float(e8 << 23);   // e8 >= 100: scale >= 1e-8
           if (MASK) {
             const float lim = 6.0f * cs;
 #pragma unroll
@@ -400,11 +453,13 @@ __global__ __launch_bounds__(256) void fused_quantize_kernel(const QuantParams p
           for (int r = 0; r < 8; ++r) v8[r] = acc[sub * 8 + r];
           float out_scale;
           uint32_t sfb;
+          bool nan_risk;   // (as in the MX arm)
           if (METHOD == METHOD_ABSMAX) {
             float m = 0.f;
 #pragma unroll
             for (int r = 0; r < 8; ++r) m = fmaxf(m, fabsf(v8[r]));
             m = xhalf_max(m);
+            nan_risk = m == 0.f || !(m < __builtin_inff());
             float sf = gscale * (m * (1.0f / 6.0f));
             sfb = e4m3_encode_pos(sf);
             sf = e4m3_decode_pos(sfb);
@@ -422,7 +477,9 @@ __global__ __launch_bounds__(256) void fused_quantize_kernel(const QuantParams p
             // var < 0 can only come from fp32 rounding on a (nearly) constant group; the reference takes sqrt of it and
             // carries a NaN scale (epilogue_quant.h:1631-1680 has no guard).  Clamped here, as the MX path does: the group
             // quantises to scale 0 / zero codes instead of a NaN scale byte.  (Deviation noted in DESIGN.md section 4.)
-            const float var = fmaxf(fmaf(-mean, mean, s2 * 0.0625f), 0.f);
+            const float vraw = fmaf(-mean, mean, s2 * 0.0625f);
+            const float var = vraw < 0.f ? 0.f : vraw;   // ([r5] not fmaxf: a NaN variance -- NaN / inf activations -- stays NaN and becomes the scale byte 0x7f, as in the reference)
+            nan_risk = !(vraw >= 0.f);
             const float sc = (float)((double)sqrtf(var) * (2.92247856 / 6.) + 1e-8);
             sfb = e4m3_encode_pos(sc);
             const float sq = e4m3_decode_pos(sfb);
@@ -430,6 +487,10 @@ __global__ __launch_bounds__(256) void fused_quantize_kernel(const QuantParams p
           }
           float t[8];
           scale_pk<8>(v8, 0, out_scale, t);
+          if (__builtin_expect(nan_risk, 0)) {
+#pragma unroll
+            for (int r = 0; r < 8; ++r) t[r] = nan_to_pinf(t[r]);
+          }
           // 8 values = bytes {0,1,4,5} + 2*half of the 8-byte group: halfwords H[half], H[2+half]
           const uint32_t P = e2m1_pack8<HWCVT>(t);
           auto sw = __builtin_amdgcn_permlane32_swap(P, P, false, false);

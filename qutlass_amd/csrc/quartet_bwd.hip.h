@@ -65,6 +65,15 @@ struct BwdTParams {
 //     convert (quantize.hip.h: e2m1_pack2_hw).  Zero / denormal / huge amax or alpha (the reference's 3/0 = inf,
 //     0 * inf = NaN -> code 7 behaviour for all-zero groups included) take the original division path, per wave.
 // A ring of 2-4 prefetched tiles per wave (more bytes in flight) was measured and is SLOWER (QT 8192^2: 23 -> 28 us): not latency-bound.
+
+// [r5] QT operands under an input scale byte of 255: the reference multiplies the decoded code by the bf16 +inf (bits 255 << 7): +-inf, or NaN for a zero code.  The
+// hardware convert with an infinite scale operand returns NaN for EVERY code, so such a group (never produced by the quantizers) is decoded with unit scale and
+// patched: nonzero -> +-inf, zero -> NaN.  w2 = two bf16 of cvt_scalef32_pk_bf16_fp4(w, 1.0, k).
+__device__ __forceinline__ uint32_t qt_times_inf(uint32_t w2) {
+  const uint32_t lo = w2 & 0xffffu, hi = w2 >> 16;
+  const uint32_t l = (lo & 0x7fffu) ? ((lo & 0x8000u) | 0x7f80u) : 0x7fc0u, h = (hi & 0x7fffu) ? ((hi & 0x8000u) | 0x7f80u) : 0x7fc0u;
+  return l | (h << 16);
+}
 template <bool QT, bool HWCVT>
 __global__ __launch_bounds__(512) void bwd_quant_t_kernel(const BwdTParams p) {
 #ifndef QAMD_BWD_LROW_QT
@@ -208,7 +217,9 @@ __global__ __launch_bounds__(512) void bwd_quant_t_kernel(const BwdTParams p) {
     } else {
       const int r = lane >> 1, c = (lane & 1) * 32;
       const uint32_t e = ld_e;
-      const float sc = __uint_as_float(e ? (e << 23) : 0x00400000u);   // 2^(e-127); e = 0 -> 2^-127 (denormal)
+      // [r5] the reference builds the scale as the bf16 with bits e << 7 (quartet_bwd_sm120.cu:369-371): byte 0 is 0.0 (NOT 2^-127: the operand is zero whatever
+      // its code), byte 255 is +inf (operand +-inf, 0 x inf = NaN) -- the same two special values come out of e << 23 in fp32
+      const float sc = e == 255u ? 1.0f : __uint_as_float(e << 23);
       v4i* d = (v4i*)(ts + r * LROW + c * 2);
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
@@ -218,6 +229,10 @@ __global__ __launch_bounds__(512) void bwd_quant_t_kernel(const BwdTParams p) {
         o[1] = __builtin_bit_cast(int, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp4(w, sc, 1));
         o[2] = __builtin_bit_cast(int, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp4(w, sc, 2));
         o[3] = __builtin_bit_cast(int, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp4(w, sc, 3));
+        if (__builtin_expect(e == 255u, 0)) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) o[k] = (int)qt_times_inf((uint32_t)o[k]);
+        }
         d[q] = o;
       }
     }
@@ -392,7 +407,7 @@ __global__ __launch_bounds__(256) void bwd_quant_tw_kernel(const BwdTParams p) {
     } else {
       const int r = lane >> 1, c = (lane & 1) * 32;
       const uint32_t e = ld_e[s];
-      const float sc = __uint_as_float(e ? (e << 23) : 0x00400000u);
+      const float sc = e == 255u ? 1.0f : __uint_as_float(e << 23);   // (byte 0 -> 0.0: the bf16 with bits e << 7, as the reference builds it; byte 255 = +inf: qt_times_inf)
       v4i* d = (v4i*)(ts + r * LROW + c * 2);
 #pragma unroll
       for (int qq = 0; qq < 4; ++qq) {
@@ -402,6 +417,10 @@ __global__ __launch_bounds__(256) void bwd_quant_tw_kernel(const BwdTParams p) {
         ov[1] = __builtin_bit_cast(int, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp4(w, sc, 1));
         ov[2] = __builtin_bit_cast(int, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp4(w, sc, 2));
         ov[3] = __builtin_bit_cast(int, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp4(w, sc, 3));
+        if (__builtin_expect(e == 255u, 0)) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) ov[k] = (int)qt_times_inf((uint32_t)ov[k]);
+        }
         d[qq] = ov;
       }
     }
@@ -692,13 +711,19 @@ __global__ __launch_bounds__(MR * 2) void mxfp4_transpose_mxfp8_kernel(const TrP
   const int ti = (int)(t / (unsigned)tiles_n), tj = (int)(t % (unsigned)tiles_n);
   const int r0 = ti * MR + wave * 32, c0 = tj * NC;
   char* ts = ts_all[wave];
+  bool nan_in = false;
 #pragma unroll
   for (int ps = 0; ps < 32 / RPP; ++ps) {
     const int r = ps * RPP + lane / LPR, c = (lane % LPR) * 32;
     const int64_t rowi = r0 + r;
     const bool live = rowi < p.m;
     const v4i v = live ? *(const v4i*)(p.xq + rowi * (p.n >> 1) + ((c0 + c) >> 1)) : v4i{0, 0, 0, 0};
-    const float sc = live ? e8m0_scale(p.xs[rowi * (p.n >> 5) + ((c0 + c) >> 5)]) : 1.0f;
+    const uint32_t se = live ? p.xs[rowi * (p.n >> 5) + ((c0 + c) >> 5)] : 127u;
+    // [r5] input scale byte 255 is NaN (`__nv_cvt_e8m0_to_bf16raw`, quartet_bwd_sm120.cu:658-660): all 32 operands of the group become NaN, which the reference's
+    // fmaxf block maximum ignores and its e4m3 convert turns into 0x7f.  The bit-pattern maximum below cannot ignore a NaN, so a wave that has seen such a byte
+    // takes the exact arm there (wave-uniform, never taken on the quantizers' own outputs).
+    nan_in |= se == 255u;
+    const float sc = se == 255u ? __uint_as_float(0x7fc00000u) : e8m0_scale(se);
     v4i* d = (v4i*)(ts + r * LROW + c * 2);
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -713,11 +738,12 @@ __global__ __launch_bounds__(MR * 2) void mxfp4_transpose_mxfp8_kernel(const TrP
   }
   __builtin_amdgcn_s_waitcnt(0xc07f);
   __builtin_amdgcn_wave_barrier();
+  const bool wave_nan = __builtin_amdgcn_ballot_w64(nan_in) != 0;
   // Columns lane, lane + 64, ...  [r3] The lane's 32 m values of a column come out of the tile with 8 transposing reads (ds_read_b64_tr_b16: the 16
   // lanes of a group supply the 8-byte pieces of 4 rows x 16 columns and receive one column each, rows 2i, 2i + 1 already paired in a register)
   // instead of 32 two-byte reads + 16 packs -- PMC had the LDS instruction issue busy 17 of the kernel's 23 us at 8192^2 -- and the block
   // maximum is taken on the packed bf16 bit patterns (sign stripped, v_pk_max_u16: for non-NaN values the order of the patterns is the order of
-  // the magnitudes; an e8m0 byte of 255 in the input, i.e. inf / NaN operands, is outside what the op is defined for).
+  // the magnitudes; [r5] a wave that met an input scale byte of 255 = NaN operands takes the exact arm, `wave_nan`).
   typedef short v4s_ __attribute__((ext_vector_type(4)));
   typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
   typedef __attribute__((address_space(3))) v4s_* lds_v4s_t;
@@ -737,7 +763,20 @@ __global__ __launch_bounds__(MR * 2) void mxfp4_transpose_mxfp8_kernel(const TrP
       mx = __builtin_elementwise_max(mx, __builtin_bit_cast(u16x2, pr[2 * q] & 0x7fff7fffu));
       mx = __builtin_elementwise_max(mx, __builtin_bit_cast(u16x2, pr[2 * q + 1] & 0x7fff7fffu));
     }
-    const float amax = __uint_as_float((uint32_t)(mx[0] > mx[1] ? mx[0] : mx[1]) << 16);
+    float amax = __uint_as_float((uint32_t)(mx[0] > mx[1] ? mx[0] : mx[1]) << 16);
+    uint32_t nanrows = 0;   // bit r: row r of this column's block is NaN
+    if (wave_nan) {   // the maximum over the NON-NaN magnitudes (fmaxf semantics); the NaN rows are written as 0x7f below, whatever the convert makes of their sign
+      uint32_t m16 = 0;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        uint32_t lo16 = pr[i] & 0x7fffu, hi16 = (pr[i] >> 16) & 0x7fffu;
+        const bool nl = lo16 > 0x7f80u, nh = hi16 > 0x7f80u;
+        nanrows |= (nl ? 1u : 0u) << (2 * i) | (nh ? 1u : 0u) << (2 * i + 1);
+        lo16 = nl ? 0u : lo16; hi16 = nh ? 0u : hi16;
+        m16 = max(m16, max(lo16, hi16));
+      }
+      amax = __uint_as_float(m16 << 16);
+    }
     const uint32_t e = e8m0_shift7(amax);
     const float qs = e8m0_scale(e);
     v4i o[2];
@@ -747,6 +786,16 @@ __global__ __launch_bounds__(MR * 2) void mxfp4_transpose_mxfp8_kernel(const TrP
       w = __builtin_amdgcn_cvt_scalef32_pk_fp8_bf16(w, __builtin_bit_cast(bf16x2, pr[2 * q]), qs, false);
       w = __builtin_amdgcn_cvt_scalef32_pk_fp8_bf16(w, __builtin_bit_cast(bf16x2, pr[2 * q + 1]), qs, true);
       o[q >> 2][q & 3] = __builtin_bit_cast(int, w);
+    }
+    if (wave_nan && nanrows) {   // byte r of the lane's 32 output bytes = row r
+#pragma unroll
+      for (int d = 0; d < 8; ++d) {
+        uint32_t v = (uint32_t)o[d >> 2][d & 3];
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+          if ((nanrows >> (4 * d + b)) & 1u) v = (v & ~(0xffu << (8 * b))) | (0x7fu << (8 * b));
+        o[d >> 2][d & 3] = (int)v;
+      }
     }
     oq[cc][0] = o[0];
     oq[cc][1] = o[1];
