@@ -38,6 +38,77 @@ def register_torch_ops() -> None:
         )
     torch.ops.load_library(EXT_PATH)
     _registered = True
+    _register_fakes()
+
+
+def _register_fakes() -> None:
+    """Shape-only ("fake" / meta) kernels for every op of the extension, so that callers can be traced: `torch.compile(fullgraph=True)`, `make_fx`,
+    `torch.export` under FakeTensorMode.  The reference's default `to_blocked` is plain torch written to be compiled through
+    (qutlass/utils.py:160-193); here it is a custom op, and without a fake kernel a compiled caller graph-breaks or fails.  The 14 `_qutlass_C` ops get
+    one too (beyond the reference, whose ops have none).  Outputs mirror csrc/torch_ext.cpp: GEMMs allocate (M, N) bf16; the quantizers return their
+    OUT / OUT_sf (/ OUT_mask) arguments -- the fake hands back fresh tensors of the same metadata (a fake kernel must not alias its inputs);
+    the backward data-prep ops return nothing (they fill caller-provided tensors, as in bindings.cpp:429-494)."""
+    rf = torch.library.register_fake
+
+    def gemm_tn(A, B, A_sf, B_sf, alpha):
+        return A.new_empty((A.size(0), B.size(0)), dtype=torch.bfloat16)
+
+    for name in ("matmul_mxf4_bf16_tn", "matmul_nvf4_bf16_tn", "matmul_ada_mxf4_bf16_tn", "matmul_mxf8_bf16_tn"):
+        rf(f"_qutlass_C::{name}")(gemm_tn)
+
+    @rf("_qutlass_C::matmul_mxf8_bf16_nn")
+    def _(A, B, A_sf, B_sf, alpha):   # A is (K, M) (bindings.cpp:185-214)
+        return A.new_empty((A.size(1), B.size(0)), dtype=torch.bfloat16)
+
+    def quant2(A, R, OUT, OUT_sf):
+        return torch.empty_like(OUT), torch.empty_like(OUT_sf)
+
+    for name in ("fusedQuantizeMxQuest", "fusedQuantizeMxAbsMax"):
+        rf(f"_qutlass_C::{name}")(quant2)
+
+    @rf("_qutlass_C::fusedQuantizeMxQuestWithMask")
+    def _(A, R, OUT, OUT_sf, OUT_mask):
+        return torch.empty_like(OUT), torch.empty_like(OUT_sf), torch.empty_like(OUT_mask)
+
+    def quant_nv(A, R, OUT, OUT_sf, global_scale):
+        return torch.empty_like(OUT), torch.empty_like(OUT_sf)
+
+    for name in ("fusedQuantizeNvQuest", "fusedQuantizeNvAbsMax"):
+        rf(f"_qutlass_C::{name}")(quant_nv)
+
+    @rf("_qutlass_C::backward_t_bf16")
+    def _(x, h, xh_e2m1, xh_e8m0):
+        return None
+
+    @rf("_qutlass_C::backward_qt_bf16")
+    def _(x_e2m1, x_e8m0, h, alpha, xh_e2m1, xh_e8m0):
+        return None
+
+    @rf("_qutlass_C::backward_bf16_square_double_mxfp8")
+    def _(x_bf16, x_fp8, row_scales, column_scales):
+        return None
+
+    @rf("_qutlass_C::mxfp4_transpose_mxfp8")
+    def _(x_fp4, scales, x_fp8, shared_exps):
+        return None
+
+    @rf("qutlass_amd::to_blocked")
+    def _(input_matrix):
+        rows, cols = input_matrix.shape
+        return input_matrix.new_empty(((rows + 127) // 128 * 128) * ((cols + 3) // 4 * 4))
+
+    @rf("qutlass_amd::fusedQuantizeMxBlocked")
+    def _(A, R, OUT, OUT_sf, method):
+        return torch.empty_like(OUT), torch.empty_like(OUT_sf)
+
+    @rf("qutlass_amd::fusedQuantizeNvBlocked")
+    def _(A, R, OUT, OUT_sf, global_scale, method):
+        return torch.empty_like(OUT), torch.empty_like(OUT_sf)
+
+    @rf("qutlass_amd::fusedQuantizeMatmulMxf4")
+    def _(X, R, B, B_sf, alpha, method):
+        k = X.size(-1)
+        return X.new_empty((X.numel() // k if k else 0, B.size(0)), dtype=torch.bfloat16)
 
 
 def to_blocked(input_matrix: torch.Tensor) -> torch.Tensor:

@@ -1,0 +1,80 @@
+"""Shape-only (fake / meta) kernels of the torch ops (qutlass_amd/ops.py `_register_fakes`): a caller of the operator surface traces under FakeTensorMode -- no GPU needed,
+the fake tensors only CLAIM to live on one.  The reference's default `to_blocked` is plain torch meant to be compiled through (qutlass/utils.py:160-193); a custom op
+needs a fake kernel to keep that property.  The GPU half (compiled == eager, bit for bit) is in tests/test_gpu_round5.py."""
+import pytest
+import torch
+from torch._subclasses.fake_tensor import FakeTensorMode
+from torch.fx.experimental.proxy_tensor import make_fx
+
+import qutlass_amd as q
+from qutlass_amd.utils import to_blocked
+
+DEV = "cuda"
+
+
+def _targets(gm):
+    return [str(n.target) for n in gm.graph.nodes if n.op == "call_function"]
+
+
+def test_every_op_of_the_extension_has_a_fake_kernel():
+    q.ops.register_torch_ops()
+    names = [f"_qutlass_C::{n}" for n in ("matmul_mxf4_bf16_tn", "matmul_nvf4_bf16_tn", "matmul_ada_mxf4_bf16_tn", "matmul_mxf8_bf16_tn", "matmul_mxf8_bf16_nn",
+                                          "fusedQuantizeMxQuest", "fusedQuantizeMxAbsMax", "fusedQuantizeMxQuestWithMask", "fusedQuantizeNvQuest", "fusedQuantizeNvAbsMax",
+                                          "backward_t_bf16", "backward_qt_bf16", "backward_bf16_square_double_mxfp8", "mxfp4_transpose_mxfp8")]
+    names += [f"qutlass_amd::{n}" for n in ("to_blocked", "fusedQuantizeMxBlocked", "fusedQuantizeNvBlocked", "fusedQuantizeMatmulMxf4")]
+    for name in names:   # (torch.library.register_fake keeps its kernels in this registry; the fake-tensor machinery looks them up there)
+        assert torch._library.simple_registry.singleton.find(name).fake_impl.kernel is not None, name
+
+
+def test_to_blocked_traces_with_fullgraph():
+    with FakeTensorMode():
+        s = torch.empty(300, 10, dtype=torch.float8_e8m0fnu, device=DEV)
+        out = torch.compile(lambda t: to_blocked(t), backend="eager", fullgraph=True)(s)
+        assert out.shape == (384 * 12,) and out.dtype == torch.float8_e8m0fnu and out.device.type == "cuda"
+
+
+def test_quantize_swizzle_gemm_traces_under_fake_tensors():
+    def layer(x, h, wq, wsf, alpha):          # the forward path of a quantized linear layer: Q(x h) W^T
+        xq, xs = q.fusedQuantizeMx(x, h, method="abs_max")
+        return q.matmul_mxf4_bf16_tn(xq.view(-1, xq.size(-1)), wq, to_blocked(xs), wsf, alpha)
+
+    def layer_nv(x, h, gs, wq, wsf, alpha):
+        xq, xs = q.fusedQuantizeNv(x, h, gs)
+        return q.matmul_nvf4_bf16_tn(xq.view(-1, xq.size(-1)), wq, to_blocked(xs), wsf, alpha)
+
+    with FakeTensorMode():
+        x = torch.empty(4, 64, 512, dtype=torch.bfloat16, device=DEV)
+        h = torch.empty(32, 32, dtype=torch.bfloat16, device=DEV)
+        wq = torch.empty(384, 256, dtype=torch.uint8, device=DEV)
+        wsf = torch.empty(384 * 16, dtype=torch.float8_e8m0fnu, device=DEV)
+        alpha = torch.empty(1, device=DEV)
+        out = torch.compile(layer, backend="eager", fullgraph=True)(x, h, wq, wsf, alpha)
+        assert out.shape == (256, 384) and out.dtype == torch.bfloat16
+        gm = make_fx(layer)(x, h, wq, wsf, alpha)
+        t = _targets(gm)
+        assert "_qutlass_C.fusedQuantizeMxAbsMax.default" in t and "qutlass_amd.to_blocked.default" in t and "_qutlass_C.matmul_mxf4_bf16_tn.default" in t
+        h16 = torch.empty(16, 16, dtype=torch.bfloat16, device=DEV)
+        wsf_nv = torch.empty(384 * 32, dtype=torch.float8_e4m3fn, device=DEV)
+        out = torch.compile(layer_nv, backend="eager", fullgraph=True)(x, h16, torch.empty(1, device=DEV), wq, wsf_nv, alpha)
+        assert out.shape == (256, 384)
+
+
+def test_remaining_ops_trace_under_fake_tensors():
+    with FakeTensorMode():
+        h = torch.empty(32, 32, dtype=torch.bfloat16, device=DEV)
+        alpha = torch.empty(1, device=DEV)
+        a8 = torch.empty(512, 256, dtype=torch.float8_e4m3fn, device=DEV)       # (K, M) for the NN op
+        b8 = torch.empty(384, 512, dtype=torch.float8_e4m3fn, device=DEV)
+        sf = torch.empty(4096, dtype=torch.float8_e8m0fnu, device=DEV)
+        assert torch.compile(q.matmul_mxf8_bf16_nn, backend="eager", fullgraph=True)(a8, b8, sf, sf, alpha).shape == (256, 384)
+        assert torch.compile(q.matmul_mxf8_bf16_tn, backend="eager", fullgraph=True)(b8, b8, sf, sf, alpha).shape == (384, 384)
+        x = torch.empty(2, 128, 256, dtype=torch.bfloat16, device=DEV)
+        e2m1, e8m0 = torch.compile(q.backward_t_bf16, backend="eager", fullgraph=True)(x, h)
+        assert e2m1.shape == (2, 256, 64) and e8m0.shape == (2, 256, 4)
+        y, rs, cs = torch.compile(q.backward_bf16_square_double_mxfp8, backend="eager", fullgraph=True)(torch.empty(200, 256, dtype=torch.bfloat16, device=DEV))
+        assert y.shape == (256, 256) and rs.shape == (256, 8) and cs.shape == (256, 8)
+        yt, st = torch.compile(q.mxfp4_transpose_mxfp8, backend="eager", fullgraph=True)(torch.empty(128, 128, dtype=torch.uint8, device=DEV),
+                                                                                       torch.empty(128, 8, dtype=torch.float8_e8m0fnu, device=DEV))
+        assert yt.shape == (256, 256) and st.shape == (256, 8)
+        out = q.fusedQuantizeMx(torch.empty(64, 128, dtype=torch.bfloat16, device=DEV), h, method="quest", return_mask=True)
+        assert len(out) == 3 and out[2].shape[-1] == 128 // 8

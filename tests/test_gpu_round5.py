@@ -180,3 +180,28 @@ def test_mxfp4_transpose_mxfp8_with_e8m0_bytes_0_and_255(q, m, n):
     ry, rs = oracle.mxfp4_transpose_mxfp8(pc, ps)
     assert np.array_equal(_np(sf).reshape(-1), np.asarray(rs).reshape(-1)), int((_np(sf).reshape(-1) != np.asarray(rs).reshape(-1)).sum())
     assert np.array_equal(_np(y).reshape(-1), np.asarray(ry).reshape(-1)), int((_np(y).reshape(-1) != np.asarray(ry).reshape(-1)).sum())
+
+
+# ------------------------------------------------------------------------------------------------
+# fake kernels: a compiled caller (AOT autograd over the fake kernels of qutlass_amd/ops.py, eager execution of the graph) returns the eager bytes
+# ------------------------------------------------------------------------------------------------
+def test_compiled_quantize_swizzle_gemm_equals_eager(q):
+    from qutlass_amd.utils import to_blocked
+
+    def layer(x, h, wq, wsf, alpha):
+        xq, xs = q.fusedQuantizeMx(x, h, method="abs_max")
+        return q.matmul_mxf4_bf16_tn(xq.view(-1, xq.size(-1)), wq, to_blocked(xs), wsf, alpha)
+
+    g = torch.Generator(device=DEV).manual_seed(3)
+    x = torch.randn(2, 160, 512, dtype=torch.bfloat16, device=DEV, generator=g) * 5
+    w = torch.randn(384, 512, dtype=torch.bfloat16, device=DEV, generator=g)
+    h = _hadamard(32)
+    wq, ws = q.fusedQuantizeMx(w, h, method="abs_max")
+    wsf = to_blocked(ws)
+    alpha = torch.tensor([0.5], device=DEV)
+    eager = layer(x, h, wq, wsf, alpha)
+    for backend in ("eager", "aot_eager"):
+        out = torch.compile(layer, backend=backend, fullgraph=True)(x, h, wq, wsf, alpha)
+        assert torch.equal(out.view(torch.int16), eager.view(torch.int16)), backend
+    sb = torch.compile(lambda t: to_blocked(t), backend="aot_eager", fullgraph=True)(ws)
+    assert torch.equal(sb.view(torch.uint8), wsf.view(torch.uint8))
