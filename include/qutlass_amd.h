@@ -157,6 +157,9 @@ int qutlass_amd_matmul_mxf8_bf16_nn_fmt(const void* A, const void* B, const void
  * out_e2m1: numel/2 bytes; out_e8m0: numel/32 bytes written FLAT in group order (the caller's
  * (padded_rows, padded_cols) buffer keeps its padding untouched, as in the reference);
  * out_mask: NULL, or numel/8 bytes (one u32 per 32-group; quest + rot 32 only).
+ * Alignment: h must be 16-byte aligned for rot >= 64 (QAMD_ERR_INVALID otherwise; the kernel stages it with 16-byte loads).
+ * Non-finite activations follow the reference's arithmetic: NaN -> code 0x7 whatever its sign, +-inf -> +-6 or, under an
+ * infinite group scale (e8m0 byte 255), 0 / NaN as x / inf gives (tests/test_gpu_round5.py).
  * Replaces fusedQuantizeMx{Quest,AbsMax}{,Had64,Had128}_host (fused_quantize_mx.cu:107-207) and
  * fusedQuantizeMxQuestWithMask_host (fused_quantize_mx_mask.cu:107-123); bindings.cpp:218-333.
  */

@@ -142,11 +142,16 @@ def fusedQuantizeNvBlocked(a: torch.Tensor, b: torch.Tensor, global_scale: torch
     return torch.ops.qutlass_amd.fusedQuantizeNvBlocked(a, b, xh_e2m1, xh_e4m3, global_scale, _METHOD_CODE[method])
 
 
-def _decode_single_launch_wins(m: int, n: int, k: int, rot: int) -> bool:
+def _decode_single_launch_wins(m: int, n: int, k: int, rot: int, device: torch.device | None = None) -> bool:
     """The measured one-launch / two-launch rule of the activation path.  [r4] It lives in the C library now
     (``qutlass_amd_activation_path_launches``, csrc/capi.hip: thresholds, measurements and the CU-count scaling are documented there), so
-    that a caller of the C ABI gets the same rule; this is the Python face of it."""
-    return _lib.load().qutlass_amd_activation_path_launches(int(m), int(n), int(k), int(rot)) == 1
+    that a caller of the C ABI gets the same rule; this is the Python face of it.  The rule scales with the CU count of HIP's CURRENT device, so it is asked
+    with the operand's device current (a mixed or partitioned node would otherwise be judged by device 0)."""
+    ask = lambda: _lib.load().qutlass_amd_activation_path_launches(int(m), int(n), int(k), int(rot)) == 1
+    if device is not None and device.type == "cuda" and torch.cuda.is_available():
+        with torch.cuda.device(device):
+            return ask()
+    return ask()
 
 
 def fused_quantize_matmul_mxf4_bf16_tn(x: torch.Tensor, h: torch.Tensor, b: torch.Tensor, b_sf: torch.Tensor, alpha: torch.Tensor, *,
@@ -163,7 +168,7 @@ def fused_quantize_matmul_mxf4_bf16_tn(x: torch.Tensor, h: torch.Tensor, b: torc
     k = x.size(-1)
     m = x.numel() // k if k else 0
     if single_launch is None:
-        single_launch = _decode_single_launch_wins(m, b.size(0), k, h.size(0))
+        single_launch = _decode_single_launch_wins(m, b.size(0), k, h.size(0), x.device)
     if single_launch:
         out = torch.ops.qutlass_amd.fusedQuantizeMatmulMxf4(x, h, b, b_sf, alpha, _METHOD_CODE[method])
         return out.view(*x.shape[:-1], b.size(0))

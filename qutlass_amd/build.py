@@ -24,20 +24,26 @@ EXT_OUT = os.path.join(os.path.dirname(_HERE), "qutlass", "_CUDA.abi3.so")
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "qutlass_amd.h")
 
 
+def _header() -> str:
+    """include/qutlass_amd.h: next to the package in the source tree, inside it (qutlass_amd/include/) in an installed copy (setup.py ships it as package data)."""
+    inpkg = os.path.join(_HERE, "include", "qutlass_amd.h")
+    return HEADER if os.path.exists(HEADER) or not os.path.exists(inpkg) else inpkg
+
+
 def _kernel_sources():
     d = os.path.join(_HERE, "csrc")
-    return [os.path.join(d, f) for f in sorted(os.listdir(d)) if f != "torch_ext.cpp"] + [HEADER]
+    return [os.path.join(d, f) for f in sorted(os.listdir(d)) if f != "torch_ext.cpp"] + [_header()]
 
 
 def _stale(out, sources) -> bool:
     if not os.path.exists(out):
         return True
     t = os.path.getmtime(out)
-    return any(os.path.getmtime(s) > t for s in sources)
+    return any(os.path.exists(s) and os.path.getmtime(s) > t for s in sources)   # (a source that an installed copy does not carry cannot be newer than its build)
 
 
 def needs_build() -> bool:
-    return _stale(OUT, _kernel_sources()) or _stale(EXT_OUT, [EXT_SRC, HEADER, OUT])
+    return _stale(OUT, _kernel_sources()) or _stale(EXT_OUT, [EXT_SRC, _header(), OUT])
 
 
 UNITS = [1, 2, 3, 4, 5, 8]              # translation units of csrc/capi.hip in the product build (QAMD_TU values; see the top of that file)
@@ -101,7 +107,7 @@ def build_bench_lib(force: bool = False, verbose: bool = False) -> str:
 
 
 def build_extension(force: bool = False, verbose: bool = False) -> str:
-    if force or _stale(EXT_OUT, [EXT_SRC, HEADER, OUT]):
+    if force or _stale(EXT_OUT, [EXT_SRC, _header(), OUT]):
         import sysconfig
 
         import torch

@@ -1214,6 +1214,9 @@ static int fused_quantize_mx_impl(const char* name, const void* x, const void* h
   if (method != QAMD_METHOD_QUEST && method != QAMD_METHOD_ABSMAX) return fail(QAMD_ERR_INVALID, "%s: invalid method %d", name, method);
   if (out_mask && method != QAMD_METHOD_QUEST) return fail(QAMD_ERR_INVALID, "%s: the clip mask is only defined for method quest", name);
   if (k && (k % rot || numel % k)) return fail(QAMD_ERR_INVALID, "%s: the row length %lld must be a multiple of the rotation size %d and divide numel", name, (long long)k, rot);
+  // (rot >= 64 stages H with 16-byte vector loads, quantize.hip.h: an offset view of a larger tensor may be 2-byte aligned only -- rejected rather than left to
+  //  the device's unaligned-access mode; torch allocations are 256-byte aligned)
+  if (rot >= 64 && (uintptr_t)h % 16) return fail(QAMD_ERR_INVALID, "%s: the rotation matrix must be 16-byte aligned for rotation sizes >= 64", name);
   QuantParams p;
   p.x = (const uint16_t*)x; p.h = (const uint16_t*)h; p.out = (uint8_t*)out_e2m1; p.out_sf = (uint8_t*)out_e8m0;
   p.out_mask = (uint32_t*)out_mask; p.global_scale = nullptr; p.numel = numel;
@@ -1254,6 +1257,7 @@ static int fused_quantize_nv_impl(const char* name, const void* x, const void* h
   if (method != QAMD_METHOD_QUEST && method != QAMD_METHOD_ABSMAX) return fail(QAMD_ERR_INVALID, "%s: invalid method %d", name, method);
   const int rp = rot < 32 ? 32 : rot;
   if (k && (k % rp || numel % k)) return fail(QAMD_ERR_INVALID, "%s: the row length %lld must be a multiple of %d and divide numel", name, (long long)k, rp);
+  if (rot >= 64 && (uintptr_t)h % 16) return fail(QAMD_ERR_INVALID, "%s: the rotation matrix must be 16-byte aligned for rotation sizes >= 64", name);
   QuantParams p;
   p.x = (const uint16_t*)x; p.h = (const uint16_t*)h; p.out = (uint8_t*)out_e2m1; p.out_sf = (uint8_t*)out_e4m3;
   p.out_mask = nullptr; p.global_scale = global_scale; p.numel = numel;

@@ -22,6 +22,11 @@ def _native_build():
 class BuildPy(build_py):
     def run(self):
         _native_build()
+        # the C header travels inside the package (qutlass_amd/include/): qutlass_amd.build looks for it there when the source tree is gone
+        import shutil
+        dst = os.path.join(ROOT, "qutlass_amd", "include")
+        os.makedirs(dst, exist_ok=True)
+        shutil.copy2(os.path.join(ROOT, "include", "qutlass_amd.h"), os.path.join(dst, "qutlass_amd.h"))
         super().run()
 
 
@@ -31,12 +36,25 @@ class Develop(develop):
         super().run()
 
 
+try:   # PEP 660 editable installs (`pip install -e .` with a recent pip / setuptools) do not run `develop`: hook the command they do run
+    from setuptools.command.editable_wheel import editable_wheel
+
+    class EditableWheel(editable_wheel):
+        def run(self):
+            _native_build()
+            super().run()
+
+    _EXTRA_CMDS = {"editable_wheel": EditableWheel}
+except ImportError:   # an old setuptools: `develop` is the editable path
+    _EXTRA_CMDS = {}
+
+
 setup(
     name="qutlass-amd",
     version="0.2.0",
     packages=["qutlass_amd", "qutlass"],
-    package_data={"qutlass_amd": ["libqutlass_amd.so", "csrc/*"], "qutlass": ["_CUDA.abi3.so"]},
+    package_data={"qutlass_amd": ["libqutlass_amd.so", "csrc/*", "include/*.h"], "qutlass": ["_CUDA.abi3.so"]},
     include_package_data=False,
     zip_safe=False,
-    cmdclass={"build_py": BuildPy, "develop": Develop},
+    cmdclass={"build_py": BuildPy, "develop": Develop, **_EXTRA_CMDS},
 )

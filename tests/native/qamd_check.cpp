@@ -18,6 +18,15 @@
 
 #include "../../include/qutlass_amd.h"
 #include "smi_sampler.h"
+
+// the software e2m1 encoder exists in the LAB library only (the product's qutlass_amd_set_option knows no key and returns -1): a case labelled "hw=0" that silently
+// ran the hardware encoder would prove nothing -- stop instead
+static void set_hw_fp4_cvt(int v) {
+  if (qutlass_amd_set_option("hw_fp4_cvt", v) < 0) {
+    fprintf(stderr, "qamd_check: this library has no hw_fp4_cvt option -- link libqutlass_amd_bench.so (tests/native/build.sh)\n");
+    exit(2);
+  }
+}
 extern std::vector<uint32_t> gaussian_e2m1_image(size_t bytes, uint32_t seed);  // ubench.hip
 
 extern "C" {
@@ -333,7 +342,7 @@ static void check_quant_mx(int R, int method, bool mask, int hwcvt, int64_t nume
   dx.up(x); dh.up(h);
   HIP_OK(hipMemset(dq.p, 0xEE, numel / 2));
   HIP_OK(hipMemset(ds.p, 0xEE, numel / 32));
-  qutlass_amd_set_option("hw_fp4_cvt", hwcvt);
+  set_hw_fp4_cvt(hwcvt);
   Q_OK(qutlass_amd_fused_quantize_mx(dx.p, dh.p, R, numel, method, dq.p, ds.p, mask ? dm.p : nullptr, nullptr));
   HIP_OK(hipDeviceSynchronize());
   auto q = dq.down();
@@ -378,7 +387,7 @@ static void check_quant_nv(int R, int method, int hwcvt, int64_t numel, float gs
   DBuf<uint8_t> dq(numel / 2), ds(numel / 16);
   DBuf<float> dg(1);
   dx.up(x); dh.up(h); dg.up({gs});
-  qutlass_amd_set_option("hw_fp4_cvt", hwcvt);
+  set_hw_fp4_cvt(hwcvt);
   Q_OK(qutlass_amd_fused_quantize_nv(dx.p, dh.p, R, numel, method, dg.p, dq.p, ds.p, nullptr));
   HIP_OK(hipDeviceSynchronize());
   auto q = dq.down();
@@ -410,7 +419,7 @@ static void bench_quant(int R, int method, bool mask, int hwcvt, int64_t rows, i
   DBuf<uint32_t> dm(numel / 32);
   DBuf<float> dg(1);
   dx.up(x); dh.up(h); dg.up({1.0f});
-  qutlass_amd_set_option("hw_fp4_cvt", hwcvt);
+  set_hw_fp4_cvt(hwcvt);
   double us;
   if (nv) us = time_us([&] { Q_OK(qutlass_amd_fused_quantize_nv(dx.p, dh.p, R, numel, method, dg.p, dq.p, ds.p, nullptr)); }, 5, 50);
   else us = time_us([&] { Q_OK(qutlass_amd_fused_quantize_mx(dx.p, dh.p, R, numel, method, dq.p, ds.p, mask ? dm.p : nullptr, nullptr)); }, 5, 50);

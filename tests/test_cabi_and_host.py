@@ -68,6 +68,12 @@ def test_c_abi_rejects_bad_arguments_without_launching(lib):
     assert "divisible" in err()
     assert q(dummy, dummy, 32, 4096, 1, dummy, dummy, dummy, None) == QAMD_ERR_INVALID  # mask + abs_max
     assert lib.qutlass_amd_fused_quantize_nv(dummy, dummy, 8, 4096, 1, dummy, dummy, dummy, None) == QAMD_ERR_INVALID
+    # [r5] rotation sizes >= 64 stage H with 16-byte vector loads: a rotation matrix that is not 16-byte aligned (an offset view) is rejected
+    odd = ctypes.c_void_p(0x1002)
+    assert q(dummy, odd, 64, 4096, 1, dummy, dummy, None, None) == QAMD_ERR_INVALID
+    assert "16-byte aligned" in err()
+    assert lib.qutlass_amd_fused_quantize_nv(dummy, odd, 128, 4096, 1, dummy, dummy, dummy, None) == QAMD_ERR_INVALID
+    assert "16-byte aligned" in err()
     assert lib.qutlass_amd_to_blocked(dummy, 0, 4, dummy, None) == QAMD_ERR_INVALID
     assert lib.qutlass_amd_set_option(b"no_such_option", 1) == -1
     # the PRODUCT library has no kernel-selecting state: these keys exist only in the lab build (libqutlass_amd_bench.so)
