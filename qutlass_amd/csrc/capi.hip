@@ -11,6 +11,9 @@
 #include "../../include/qutlass_amd.h"
 #include "gemm_mx.hip.h"
 #include "gemm_mx_deepp.hip.h"
+#if QAMD_BENCH
+#include "gemm_mx_deepp_lab.hip.h"   // the lab copy (namespace qamd::labk): traces, ablations, stream-K, retirement experiments
+#endif
 #include "gemm_mx_skinny.hip.h"
 #include "gemm_mx_fusedq.hip.h"
 #include "gemm_nvf4.hip.h"
@@ -205,7 +208,15 @@ int launch_gemm_deepp(GemmParams p, hipStream_t s) {
   p.raster_magic = raster_magic(p.tiles_n);
   p.ws = nullptr; p.splits = 1; p.ctr = nullptr; p.tag = 0;
   const int grid = deepp_grid(p.tiles_m * p.tiles_n);
-  hipLaunchKernelGGL((gemm_mx_deepp_kernel<C, TRACE, ST_AUX, LAB>), dim3(grid), dim3(C::THREADS), 0, s, p);
+#if QAMD_BENCH
+  if constexpr (TRACE || LAB != 0) {   // stage traces and result-changing ablations: the lab copy of the kernel
+    hipLaunchKernelGGL((labk::gemm_mx_deepp_kernel<C, TRACE, ST_AUX, LAB>), dim3(grid), dim3(C::THREADS), 0, s, p);
+    return check_launch("labk::gemm_mx_deepp_kernel");
+  }
+#else
+  static_assert(!TRACE && LAB == 0, "traces / ablations: lab build only");
+#endif
+  hipLaunchKernelGGL((gemm_mx_deepp_kernel<C, ST_AUX>), dim3(grid), dim3(C::THREADS), 0, s, p);
   return check_launch("gemm_mx_deepp_kernel");
 }
 
@@ -218,8 +229,8 @@ int launch_gemm_deepp_sk(GemmParams p, hipStream_t s) {
   p.raster_magic = raster_magic(p.tiles_n);
   p.splits = 1;
   const int grid = chip_cus();
-  if constexpr (C::EBITS == 4) hipLaunchKernelGGL((gemm_mx_deepp_kernel<C, false, 17, 0, true>), dim3(grid), dim3(C::THREADS), 0, s, p);
-  else hipLaunchKernelGGL((gemm_mx_deepp8_kernel<C, 17, false, 0, true>), dim3(grid), dim3(C::THREADS), 0, s, p);
+  if constexpr (C::EBITS == 4) hipLaunchKernelGGL((labk::gemm_mx_deepp_kernel<C, false, 17, 0, true>), dim3(grid), dim3(C::THREADS), 0, s, p);
+  else hipLaunchKernelGGL((labk::gemm_mx_deepp8_kernel<C, 17, false, 0, true>), dim3(grid), dim3(C::THREADS), 0, s, p);
   return check_launch("gemm_mx_deepp_kernel (stream-K)");
 }
 #endif
@@ -231,7 +242,15 @@ int launch_gemm_deepp8(GemmParams p, hipStream_t s) {   // the fp8 twin (gemm_mx
   p.raster_magic = raster_magic(p.tiles_n);
   p.ws = nullptr; p.splits = 1; p.ctr = nullptr; p.tag = 0;
   const int grid = deepp_grid(p.tiles_m * p.tiles_n);
-  hipLaunchKernelGGL((gemm_mx_deepp8_kernel<C, 17, NN, NNABL>), dim3(grid), dim3(C::THREADS), 0, s, p);
+#if QAMD_BENCH
+  if constexpr (NNABL != 0) {   // the NN-operand ablations: the lab copy of the kernel
+    hipLaunchKernelGGL((labk::gemm_mx_deepp8_kernel<C, 17, NN, NNABL>), dim3(grid), dim3(C::THREADS), 0, s, p);
+    return check_launch("labk::gemm_mx_deepp8_kernel");
+  }
+#else
+  static_assert(NNABL == 0, "ablations: lab build only");
+#endif
+  hipLaunchKernelGGL((gemm_mx_deepp8_kernel<C, 17, NN>), dim3(grid), dim3(C::THREADS), 0, s, p);
   return check_launch("gemm_mx_deepp8_kernel");
 }
 

@@ -3,7 +3,7 @@
 inside the K loop, and which are only parked across it for the final stage / the next tile.
 
     python tools/register_map.py <translation unit> <substring of the mangled kernel name> [--lab]
-    python tools/register_map.py 2 gemm_mx_deepp_kernelINS_7GemmCfgILi256ELi256ELi2ELi2ELi4ELb0ELi0ELi2ELi0EEELb0ELi17ELi0ELb0
+    python tools/register_map.py 2 gemm_mx_deepp_kernelINS_7GemmCfgILi256ELi256ELi2ELi2ELi4ELb0ELi0ELi2ELi0EEELi17E
 
 The K loop is taken to be the basic block with the most MFMAs that ends in a backward branch to itself.  Classes (a register counts once, first match):
   accumulator   destination / C operand of an MFMA                       fragment      A / B operand of an MFMA (written by ds_read_b128)

@@ -6,7 +6,7 @@ With ONE wave per SIMD (the 256 x 256 GEMM tiles) a wave issues at most one inst
 clustered LDS-DMA items of round 4 were found (17 of them behind the first 16 MFMAs after the hand-off, 21 scalar selects between two stages).
 
     python tools/slot_accounting.py <translation unit 1..8> <substring of the mangled kernel name> [--budget 7] [--lab]
-    python tools/slot_accounting.py 2 gemm_mx_deepp_kernelINS_7GemmCfgILi256ELi256ELi2ELi2ELi4ELb0ELi0ELi2ELi0EEELb0ELi17ELi0ELb0
+    python tools/slot_accounting.py 2 gemm_mx_deepp_kernelINS_7GemmCfgILi256ELi256ELi2ELi2ELi4ELb0ELi0ELi2ELi0EEELi17E
     python tools/slot_accounting.py 8 gemm_nvf4_pk_kernelILb0ELb0
 
 Prints, per basic-block run of MFMAs, the slots over budget and the excess in issue slots (x 4 = cycles).  CPU only (hipcc -S)."""
