@@ -214,6 +214,10 @@ __device__ __forceinline__ void gemm_mx_deepp(char* smem, const GemmParams& p, c
       if (i == 12) dma_prep(ktl, dvalid);
       if (i == 14) read_base(BUF ^ 1, 0);
     });
+    // ([r5] With the whole chip streaming every wave waits ~300 - 440 cycles here for its own pieces (tools/handoff_trace.py, profiles/handoff_trace_r5q.txt; 8 cycles with 8
+    //  workgroups).  Splitting the hand-off in two -- refill issued 12 slots earlier behind its own barrier, `vmcnt(12)` here -- removes that wait and makes the kernel 1 - 3 %
+    //  SLOWER, same bytes: the launch sits at the socket power limit, and cycles the matrix pipe idles come back as clock (profiles/ab_lib_r5r_two_handoffs_per_stage_negative.txt;
+    //  the variant lives in the lab copy, QAMD_DEEPP_SPLITB).)
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // own DMA of the next stage landed; own reads of this buffer done
     __builtin_amdgcn_s_barrier();
     fence();

@@ -74,6 +74,9 @@ constexpr int fs8_F(int IL, int T) { return 2 * IL * (T / IL) + T % IL; }
 // stages, so a unit starts in LDS buffer 0 like a tile and the stage code is shared; the DMA stream runs on across unit boundaries exactly as
 // across tiles.  Every output element is produced by one fixed summation order: deterministic; bit-identical to the single pass wherever the
 // partial sums are exact (the reference's tests), one fp32 rounding apart otherwise.
+#ifndef QAMD_DEEPP_SPLITB
+#define QAMD_DEEPP_SPLITB 0
+#endif
 #ifndef QAMD_DEEPP_SOFF
 #define QAMD_DEEPP_SOFF 1
 #endif
@@ -106,7 +109,7 @@ __device__ __forceinline__ void gemm_mx_deepp(char* smem, const GemmParams& p, c
   const int wg = xcd_remap(bid, G);
 
   auto fence = [&]() __attribute__((always_inline)) { __builtin_amdgcn_sched_barrier(0); };
-  int trace_n = 0;
+  int trace_n = 0, ho_n = 0;
   auto trace = [&]() __attribute__((always_inline)) {
     if constexpr (TRACE) {
       if (blockIdx.x == 0 && wave == 0 && p.dbg && trace_n < 30) {
@@ -316,6 +319,44 @@ __device__ __forceinline__ void gemm_mx_deepp(char* smem, const GemmParams& p, c
           ++i;
         }
     };
+#if QAMD_DEEPP_SPLITB   // [r5] two hand-offs per K stage (measured: 1 - 3 % slower, profiles/ab_lib_r5r_two_handoffs_per_stage_negative.txt)
+    // [r5] TWO hand-offs per stage instead of one.  The single barrier of rounds 2-4 (behind group 1) served two purposes: "everybody is done READING this buffer,
+    // its refill may start" and "everybody's pieces of the NEXT stage have landed, its fragments may be read".  Tied together, the refill of buffer BUF was issued in
+    // slots 40 .. 63 and had to be in LDS by slot 32 of the next stage: 33 .. 56 slots = 1.2 - 2.1 kcycles of lead, and with the whole chip streaming that is not enough --
+    // every wave sat ~300 - 440 cycles in `s_waitcnt vmcnt(0)` per stage (tools/handoff_trace.py, profiles/handoff_trace_r5q.txt: 8 cycles with 8 workgroups).
+    //   * both remaining slices (2, 3) are read behind group 0 (their registers are free: slice 3's last use was group 3 of the previous stage);
+    //   * hand-off A (slot 20): own reads back, barrier -> the refill starts NOW: 12 pieces behind group 1's MFMAs, 5 behind the first of group 2;
+    //   * hand-off B (slot 32): `s_waitcnt vmcnt(12)` -- everything but the 12 pieces just issued, i.e. all of the next stage (loads return in order) -- and barrier.
+    // Lead of a piece: 60 .. 76 slots.  Same products in the same order: bit-identical.
+    read_base(BUF, 2);
+    group(0, FIRST, [&](const int i) __attribute__((always_inline)) {
+      if (i < MT + NT) read_frag(2, i);
+      if (i == MT + NT - 1) read_base(BUF, 3);
+      if (i >= MT + NT) read_frag(3, i - (MT + NT));
+    });
+    group(1, false, [&](const int i) __attribute__((always_inline)) {
+      if (i == 0) dma_prep(ktl, dvalid);
+      if (i == 2) read_base(BUF ^ 1, 0);
+      if (i == 3) {   // hand-off A
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+      }
+      if (i >= 4) dma_item(d, ktl, BUF, i - 4);
+    });
+    asm volatile("s_waitcnt vmcnt(12)" ::: "memory");   // hand-off B: own pieces of the next stage landed (the 12 just issued stay in flight)
+    __builtin_amdgcn_s_barrier();
+    fence();
+    group(2, false, [&](const int i) __attribute__((always_inline)) {
+      if (i < 5) dma_item(d, ktl, BUF, 12 + i);
+      // the next stage's slice 0 (set 0 went dead with group 0) and its scale dwords
+      if (i < MT + NT) read_frag(0, i);
+      else if (i < 2 * (MT + NT)) read_scale1(BUF ^ 1, BUF ^ 1, i - (MT + NT));
+    });
+    read_base(BUF ^ 1, 1);
+    group(3, false, [&](const int i) __attribute__((always_inline)) {
+      if (i < MT + NT) read_frag(1, i);
+    });
+#else
     if (!IL) { read_slice(BUF, 2); fence(); } else read_base(BUF, 2);
     group(0, FIRST, [&](const int i) __attribute__((always_inline)) { if (IL && i < MT + NT) read_frag(2, i); });
     if (!IL) { read_slice(BUF, 3); fence(); } else read_base(BUF, 3);
@@ -326,8 +367,28 @@ __device__ __forceinline__ void gemm_mx_deepp(char* smem, const GemmParams& p, c
       if (QAMD_DEEPP_EARLYPREP && IL && i == 12) dma_prep(ktl, dvalid);
       if (QAMD_DEEPP_EARLYPREP && IL && i == 14) read_base(BUF ^ 1, 0);
     });
+    // (TRACE, [r5]: what does the hand-off cost?  Shader clock before the two waits and behind each: dbg[3072 + 4 k] = before, + 1 = LDS reads back (lgkmcnt),
+    //  + 2 = own DMA landed (vmcnt), + 3 = behind the barrier; workgroup 0, every wave: dbg[3072 + 1024 wave + ...], the first 60 hand-offs.  s_memtime answers through
+    //  lgkmcnt, so the first mark is asked for early and costs nothing extra; the later ones add a few cycles each.)
+    if constexpr (TRACE) {
+      if (blockIdx.x == 0 && p.dbg && ho_n < 60) {
+        const uint32_t t0 = (uint32_t)__builtin_readcyclecounter();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        const uint32_t t1 = (uint32_t)__builtin_readcyclecounter();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const uint32_t t2 = (uint32_t)__builtin_readcyclecounter();
+        __builtin_amdgcn_s_barrier();
+        const uint32_t t3 = (uint32_t)__builtin_readcyclecounter();
+        if (lane == 0) { uint32_t* q = p.dbg + 3072 + 1024 * wave + 4 * ho_n; q[0] = t0; q[1] = t1; q[2] = t2; q[3] = t3; }
+        ++ho_n;
+      } else {
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+      }
+    } else {
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // own DMA of the next stage landed; own reads of this buffer done
     __builtin_amdgcn_s_barrier();
+    }
     fence();
     if (!IL) {
       read_scales(BUF ^ 1, BUF ^ 1);
@@ -356,6 +417,7 @@ __device__ __forceinline__ void gemm_mx_deepp(char* smem, const GemmParams& p, c
       if (DMA_SPREAD && i >= 8) dma_item(d, ktl, BUF, i);
       if constexpr (EARLY) early_store(i / 8, (i / 4) % 2, i % 4);   // pairs (m = 0, 1) x (h = 0, 1), four passes each
     });
+#endif
     if constexpr (FIRST) pin_acc();
   };
 

@@ -39,7 +39,7 @@ def trace(grid, k, dev):
     m = tiles // 16 * 256
     (a, sa), (b, sb) = operands(m, n, k, dev)
     alpha = torch.ones(1, device=dev)
-    buf = torch.zeros(4096, dtype=torch.int32, device=dev)
+    buf = torch.zeros(8192, dtype=torch.int32, device=dev)   # (the lab kernel also stamps its hand-offs at dbg[3072 ..], tools/handoff_trace.py)
     rows = []
     with lab.forced(gemm_variant=91, deepp_grid=grid):
         for _ in range(20):                    # clock ramp
