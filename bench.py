@@ -497,6 +497,11 @@ def main():
             "parallelism": f"replicas x{world}" if world > 1 else "single GPU",
             "clock_ramp": f"{ramp_steps} untimed steps (~{args.ramp_ms:.0f} ms) before the {args.warmup} warmup steps",
             "pct_of_fp4_peak": round(100.0 * value / world / FP4_DENSE_PEAK_TFLOPS, 2),
+            # `value` is the wall clock of the timed region: barrier + synchronize, K launches, synchronize + barrier.  With few steps the first launch after the barrier
+            # and the final synchronize add a fixed ~40 us (7 % at K = 20); the launch-to-launch duration of the kernel itself is roofline.kernel_us
+            "timed_region": "wall clock around the K steps incl. the first launch after the barrier and the final synchronize (a fixed ~40 us: 7 % at 20 steps); "
+                            "kernel-only duration: roofline.kernel_us",
+            "wall_minus_kernel_us_per_step": round((wall / args.steps - kernel_ms * 1e-3) * 1e6, 3),
         },
         "roofline": {
             "bound": "mfma",

@@ -20,6 +20,8 @@
 #define MFMB "v_mfma_scale_f32_32x32x64_f8f6f4 a[48:63], v[24:27], v[28:31], a[48:63], v18, v18 op_sel_hi:[0,0,0] cbsz:4 blgp:4\n"
 #define X4(s) s s s s
 #define X16(s) X4(X4(s))
+#define X64(s) X4(X16(s))
+#define X256(s) X4(X64(s))
 
 template <int V>
 __global__ __launch_bounds__(256) void k(uint32_t* out, float alpha, int trips) {
@@ -51,6 +53,12 @@ __global__ __launch_bounds__(256) void k(uint32_t* out, float alpha, int trips) 
     if constexpr (V == 16) BODY(MFMA W128A MFMB W128A);
     if constexpr (V == 17) BODY(MFMA R128 MFMB R128);
     if constexpr (V == 18) BODY(MFMA MOV MOV MFMB MOV MOV);      //   + 8 v_mov_b32 behind each
+    // code size: the same piece, 256 copies in a row = 2 816 instructions = 22 KB of straight-line code per trip (the last stage of gemm_mx_deepp is ~1 200 instructions
+    // executed once per tile) -- does instruction supply hold the issue rate of the 16-copy loop?
+#define BODYN(xn, seq) asm volatile(xn(seq) ::[al] "s"(alpha), [la] "v"(la) : "v10", "v11", "v12", "v13", "v14", "v15", "v20", "v21", "v22", "v23", "a0", "a1", "a2", "a3", "a16", "a17", "a18", "a19", "memory")
+    if constexpr (V == 19) BODYN(X256, AR MUL CVT W64);
+    if constexpr (V == 20) BODYN(X64, MFMA AR MUL CVT W64 MFMB AR2 MUL CVT W64);
+    if constexpr (V == 21) BODYN(X256, MOV);
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   const uint64_t t1 = __builtin_readcyclecounter();
@@ -59,7 +67,7 @@ __global__ __launch_bounds__(256) void k(uint32_t* out, float alpha, int trips) 
 
 static uint32_t* d_out;
 template <int V>
-static void run(const char* what, int grid) {
+static void run(const char* what, int grid, double scale = 1.0) {
   const int trips = 200;
   std::vector<uint32_t> c;
   for (int rep = 0; rep < 5; ++rep) {
@@ -69,7 +77,7 @@ static void run(const char* what, int grid) {
     c.push_back(h);
   }
   std::sort(c.begin(), c.end());
-  printf("%-100s %7.1f cycles\n", what, c[2] / (16.0 * trips));
+  printf("%-100s %7.1f cycles\n", what, c[2] / (16.0 * trips) / scale);
 }
 
 int main(int argc, char** argv) {
@@ -95,5 +103,8 @@ int main(int argc, char** argv) {
   run<15>("2 MFMAs, a piece behind each", grid);
   run<16>("2 MFMAs, a ds_write_b128 from AGPRs behind each", grid);
   run<17>("2 MFMAs, a ds_read_b128 behind each", grid);
+  run<19>("piece, 256 copies straight-line (22 KB of code per trip)", grid, 16.0);
+  run<21>("4 v_mov_b32, 256 copies straight-line (8 KB of code per trip)", grid, 16.0);
+  run<20>("2 MFMAs + a piece behind each, 64 copies straight-line (15 KB per trip; per PAIR)", grid, 4.0);
   return 0;
 }
