@@ -22,6 +22,9 @@
 #include "to_blocked.hip.h"
 #include "transpose_u8.hip.h"
 #include "quartet_bwd.hip.h"
+#if QAMD_BENCH
+#include "quartet_bwd_lab.hip.h"     // backward_qt_bf16's whole-line panel kernel (built, bit-identical, not faster)
+#endif
 
 using namespace qamd;
 
@@ -902,6 +905,23 @@ int launch_bwd_quant(const BwdTParams& p, bool qt, int which, bool hw, int grid,
 #if QAMD_DEF(5)
 int launch_bwd_quant(const BwdTParams& p, bool qt, int which, bool hw, int grid, hipStream_t s) {
 #define QAMD_BWD_GO(KERN, THREADS) hipLaunchKernelGGL((KERN), dim3(grid), dim3(THREADS), 0, s, p)
+  if (which >= 5 && which <= 8) {   // [r5] QT only: the wave-owned kernel with the input fetched as whole lines into a ring shared by the workgroup's four m-tiles
+#if QAMD_BENCH
+    if (which == 6) { QAMD_BWD_GO((bwd_qt_ring_kernel<true, 8, 4, true>), 256); return check_launch("bwd_qt_ring_kernel"); }
+    if (which == 7) { QAMD_BWD_GO((bwd_qt_ring_kernel<true, 8, 4, false>), 256); return check_launch("bwd_qt_ring_kernel"); }
+    if (which == 8) { QAMD_BWD_GO((bwd_qt_ring_kernel<true, 4, 3, true>), 256); return check_launch("bwd_qt_ring_kernel"); }
+    if (!hw) { QAMD_BWD_GO((bwd_qt_ring_kernel<false, 4, 3, false>), 256); return check_launch("bwd_qt_ring_kernel"); }
+#endif
+    QAMD_BWD_GO((bwd_qt_ring_kernel<true, 4, 3, false>), 256);
+    return check_launch("bwd_qt_ring_kernel");
+  }
+#if QAMD_BENCH
+  if (which == 4) {   // QT only: whole-line panels ([256 n][256 m] per workgroup), quartet_bwd_lab.hip.h
+    if (!hw) { QAMD_BWD_GO((bwd_qt_panel_kernel<false>), 512); return check_launch("bwd_qt_panel_kernel"); }
+    QAMD_BWD_GO((bwd_qt_panel_kernel<true>), 512);
+    return check_launch("bwd_qt_panel_kernel");
+  }
+#endif
   if (which == 1) {
 #if QAMD_BENCH
     if (!hw) { if (qt) QAMD_BWD_GO((bwd_quant_t_kernel<true, false>), 512); else QAMD_BWD_GO((bwd_quant_t_kernel<false, false>), 512); return check_launch("bwd_quant_t_kernel"); }
@@ -1365,14 +1385,17 @@ int qutlass_amd_fused_quantize_matmul_mxf4_bf16_tn(const void* x, const void* h,
 // stays.  QT: 64-byte segments with 16 waves per CU (4096^2 cold 10.2 -> 8.5 us, 8192^2 30.9 -> 26.6); T: whole lines with 8 waves per CU
 // (8192^2 cold 38.0 -> 36.5, 2048 x 14336 17.7 -> 15.2; the 64-byte form ties with the round-3 kernel there).  In the product build the product
 // kernels are the only instantiations: QT never takes 3, T never 2.  Lab: option "bwd_variant" (low 4 bits) forces 1 / 2 / 3.
-static int bwd_kernel_rule(bool qt, int64_t nu, int64_t cu) {
-  if (qt) return nu >= 3 * cu ? 2 : 1;
+// [r5] QT, large inputs with M % 128 == 0: 5 = the wave-owned kernel fed through a shared whole-line ring (bwd_qt_ring_kernel).  Cold it wins from ~12 units per CU
+// (profiles/ab_bwd_r5x_ring_threshold.txt: 14336 x 4096 22.1 -> 20.6 us, 8192^2 26.1 -> 22.4, 8192 x 16384 55.1 -> 43.5; 11008 x 4096 ties, 6144^2 15.1 -> 15.5), warm
+// (input in the MALL) the plain kernel stays ahead until ~32 per CU -- the rule goes by the cold numbers, as every streaming-op figure of the design record does.
+static int bwd_kernel_rule(bool qt, int64_t nu, int64_t cu, bool ring_ok = false) {
+  if (qt) return (ring_ok && nu >= 12 * cu) ? 5 : nu >= 3 * cu ? 2 : 1;
   return nu >= 6 * cu ? 3 : 1;
 }
-static int bwd_kernel_choice(bool qt, int64_t nu) {
+static int bwd_kernel_choice(bool qt, int64_t nu, bool ring_ok = false) {
   const int v = opt_bwd_variant() & 15;
-  if (v >= 1 && v <= 3) return v;
-  return bwd_kernel_rule(qt, nu, chip_cus());
+  if (v >= 1 && v <= 8) return v;
+  return bwd_kernel_rule(qt, nu, chip_cus(), ring_ok);
 }
 // column tiles (of 128) per workgroup of backward_bf16_square_double_mxfp8: 4 (16 waves, 16-byte row-scale pieces) when n allows and every CU still gets a workgroup
 static int sq_column_tiles_rule(int64_t m_pad, int64_t n, int64_t cu) { return (n % 512 == 0 && (m_pad / 128) * (n / 512) >= cu) ? 4 : 1; }
@@ -1389,7 +1412,8 @@ int qutlass_amd_backward_t_bf16(const void* x, const void* h, int64_t B, int64_t
   p.B = (int)B; p.N = (int)N; p.M = (int)M; p.tiles_m = (int)cdiv(M, 64);
   if (B * (N / 32) * p.tiles_m >= (1ll << 31) - 65536) return fail(QAMD_ERR_INVALID, "%s: tensor too large", name);
   const int64_t ntw = B * p.tiles_m * cdiv(N / 32, 8);   // units: 8 scale groups (256 n) x 64 m = 64 whole output lines
-  const int which = bwd_kernel_choice(false, ntw);
+  const int which0 = bwd_kernel_choice(false, ntw);
+  const int which = which0 >= 4 ? bwd_kernel_rule(false, ntw, chip_cus()) : which0;   // (4 .. 8 = QT-only kernels)
   p.abl = opt_bwd_variant() >> 4;
   const int64_t nuw = B * p.tiles_m * cdiv(N / 32, which == 3 ? 8 : 4);   // wave units
   const int grid = which == 1 ? (int)std::min<int64_t>(ntw, chip_cus() * 2) : (int)std::min<int64_t>(cdiv(nuw, 4), chip_cus() * (which == 3 ? 2 : 3));
@@ -1417,10 +1441,21 @@ int qutlass_amd_backward_qt_bf16(const void* x_e2m1, const void* x_e8m0, const v
   const int grid = (int)std::max<int64_t>(32, std::min<int64_t>(cdiv(ntw, 32) * 32, cu * per_cu / 32 * 32));
   // [r4] wave-owned output segments: the four waves of a workgroup take four consecutive m-tiles -- the siblings that share QT's 128-byte input lines
   const int64_t nu = B * p.tiles_m * cdiv(N / 32, 8);
-  const int which = bwd_kernel_choice(true, nu);
+  const int which = bwd_kernel_choice(true, nu, M % 128 == 0);
   p.abl = opt_bwd_variant() >> 4;
   const int64_t nuw = B * p.tiles_m * cdiv(N / 32, which == 3 ? 8 : 4);
   const int gridw = (int)std::min<int64_t>(cdiv(nuw, 4), cu * (which == 3 ? 2 : 4));
+  if (which >= 5) {   // [r5] ring kernels: units of NG groups x 256 m
+    if (M % 128) return fail(QAMD_ERR_INVALID, "%s: the ring kernel needs M %% 128 == 0", name);
+    const int ng = (which == 6 || which == 7) ? 8 : 4;
+    const int64_t ur = B * cdiv(M, 256) * cdiv(N / 32, ng);
+    return launch_bwd_quant(p, true, which, opt_hw_fp4(), (int)std::min<int64_t>(ur, cu * (ng == 8 ? 2 : 3) / 8 * 8), (hipStream_t)stream);
+  }
+  if (which == 4) {   // [r5] panel kernel: units of 8 groups x 256 m, two workgroups per CU (persistent grids step by a multiple of the 8 XCDs)
+    if (M % 128) return fail(QAMD_ERR_INVALID, "%s: the panel kernel needs M %% 128 == 0", name);
+    const int64_t up = B * cdiv(M, 256) * cdiv(N / 32, 8);
+    return launch_bwd_quant(p, true, 4, opt_hw_fp4(), (int)std::min<int64_t>(up, cu * 2 / 8 * 8), (hipStream_t)stream);
+  }
   return launch_bwd_quant(p, true, which, opt_hw_fp4(), which == 1 ? grid : gridw, (hipStream_t)stream);
 }
 
@@ -1546,12 +1581,12 @@ int qutlass_amd_debug_gemm_plan(int ebits, int64_t M, int64_t N, int64_t K, int6
 }
 
 // [r4] debug only (not declared in the public header): the kernel rules of the QAT-backward data-prep ops on a 256-CU part, no GPU touched.
-//   op 0 / 1: backward_t_bf16 / backward_qt_bf16 (a, b, c) = (B, N, M) -> 1 = the round-3 kernel, 2 = wave-owned 64-byte segments, 3 = wave-owned 128-byte lines
+//   op 0 / 1: backward_t_bf16 / backward_qt_bf16 (a, b, c) = (B, N, M) -> 1 = the round-3 kernel, 2 = wave-owned 64-byte segments, 3 = wave-owned 128-byte lines, 5 = [r5] QT: 2 fed through the shared whole-line ring
 //   op 2: backward_bf16_square_double_mxfp8 (a, b) = (m_pad, n) -> column tiles per workgroup (1 or 4)
 int qutlass_amd_debug_stream_plan(int op, int64_t a, int64_t b, int64_t c) {
   if (op == 0 || op == 1) {
     if (a <= 0 || b <= 0 || c <= 0 || b % 32) return -1;
-    return bwd_kernel_rule(op == 1, a * cdiv(c, 64) * cdiv(b / 32, 8), 256);
+    return bwd_kernel_rule(op == 1, a * cdiv(c, 64) * cdiv(b / 32, 8), 256, op == 1 && c % 128 == 0);
   }
   if (op == 2) return (a <= 0 || b <= 0 || a % 128 || b % 128) ? -1 : sq_column_tiles_rule(a, b, 256);
   return -1;

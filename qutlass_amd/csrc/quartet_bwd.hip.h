@@ -451,11 +451,12 @@ __global__ __launch_bounds__(256) void bwd_quant_tw_kernel(const BwdTParams p) {
     bool fast[2];
 #pragma unroll
     for (int mh = 0; mh < 2; ++mh) {
-      float m0_ = fmaxf(fmaxf(fabsf(acc[mh][0]), fabsf(acc[mh][1])), fmaxf(fabsf(acc[mh][2]), fabsf(acc[mh][3])));
-      float m1_ = fmaxf(fmaxf(fabsf(acc[mh][4]), fabsf(acc[mh][5])), fmaxf(fabsf(acc[mh][6]), fabsf(acc[mh][7])));
-      float m2_ = fmaxf(fmaxf(fabsf(acc[mh][8]), fabsf(acc[mh][9])), fmaxf(fabsf(acc[mh][10]), fabsf(acc[mh][11])));
-      float m3_ = fmaxf(fmaxf(fabsf(acc[mh][12]), fabsf(acc[mh][13])), fmaxf(fabsf(acc[mh][14]), fabsf(acc[mh][15])));
-      amax[mh] = xhalf_max(fmaxf(fmaxf(fmaxf(m0_, m1_), fmaxf(m2_, m3_)), 0.f));   // (the 0: sixteen NaNs -- inf - inf under the rotation -- reduce to 0 as in the reference's chain from 0)
+      // [r5] the reference's chain from 0 (sixteen NaNs -- inf - inf under the rotation -- reduce to 0), written as the chain: it compiles to 8 v_max3_f32 with |x| operands.
+      // The balanced tree that stood here cost 23 instructions per half: every leaf |x| was first quieted by a v_max_f32 |x|, |x| of its own (llvm.maxnum on a maybe-sNaN).
+      float am = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) am = fmaxf(am, fabsf(acc[mh][r]));
+      amax[mh] = xhalf_max(am);
       const uint32_t ab = __float_as_uint(amax[mh]);
       fast[mh] = HWCVT && alpha_fast && ab >= 0x21800000u && ab <= 0x5d800000u;
     }
@@ -564,6 +565,249 @@ __global__ __launch_bounds__(256) void bwd_quant_tw_kernel(const BwdTParams p) {
     load_tile(0, L.u < U, L.m0, L.e0);
     compute(k);
     if (k + 1 == ng) store_unit(b, g0, m0, ng);
+  }
+}
+
+// ----------------------------------------------------------------------------------------------------------------
+// [r5] bwd_qt_ring_kernel: bwd_quant_tw_kernel<QT> with the INPUT read as whole 128-byte lines.
+//
+// The four waves of a workgroup are the four m-tiles that share QT's e2m1 lines; in bwd_quant_tw_kernel each of them loads its own 32 bytes of every line (a load
+// instruction that touches 32 lines for 1 KiB; tests/native/xpose_traffic_ubench.hip: that access shape alone costs 32 us at 8192^2 cold against 17 with whole lines).
+// Here the workgroup fetches a step -- scale group k of the unit, [32 n][256 m] = 32 lines + 32 x 8 scale bytes -- cooperatively: wave w issues ONE LDS-DMA piece of 8
+// whole lines (wave 0 a dword piece for the scale bytes as well) into a ring of R slots, R - 1 steps ahead of the arithmetic; a step starts with s_waitcnt vmcnt (own
+// piece) + one s_barrier of the four waves (all pieces; and the slot of the step before is free for the piece issued next), then every wave takes its 32-byte quarter of
+// each row + the scale byte out of the slot (16-byte chunks XOR-swizzled by 2 (row % 4): 8 lanes = 4 rows x 2 chunks hit 8 different chunks) and goes on exactly as
+// bwd_quant_tw_kernel: bf16 tile, transposing reads, MFMAs, division-free scales, wave-owned output segments.  Needs M % 128 == 0.
+template <bool HWCVT, int NG, int R, bool XR>
+__global__ __launch_bounds__(256) void bwd_qt_ring_kernel(const BwdTParams p) {
+  constexpr int LROW = QAMD_BWD_LROW_QT;
+  constexpr int HROW = 32 * 2 + 16;
+  constexpr int OROW = NG * 16 + 16;
+  constexpr int SLOT = 4096 + 256;
+  static_assert(32 * HROW <= 32 * LROW, "the staged H^T borrows the first wave's tile area");
+  __shared__ __attribute__((aligned(16))) char tile_s[4][32 * LROW];
+  __shared__ __attribute__((aligned(16))) char out_s[4][64 * OROW];
+  __shared__ __attribute__((aligned(16))) uint8_t sf_s[4][64 * NG];
+  __shared__ __attribute__((aligned(16))) char ring_s[R][SLOT];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = uniform(tid >> 6);
+  const int row = lane & 31, half = lane >> 5;
+  char* ts = tile_s[wave];
+  char* os = out_s[wave];
+  uint8_t* ss = sf_s[wave];
+  const float alpha = *p.alpha;
+  const int G = p.N >> 5;
+  const int n_o = (G + NG - 1) / NG, n_iq = (p.tiles_m + 3) >> 2;
+  const uint32_t OOB = 0x80000000u;
+  const uint32_t rowb = (uint32_t)p.M >> 1, srowb = (uint32_t)p.M >> 5;
+  const uint32_t alpha_bits = __float_as_uint(alpha);
+  const bool alpha_fast = alpha_bits >= 0x30800000u && alpha_bits <= 0x4e800000u;
+  const uint32_t Kexp = alpha_bits - 0x3f800000u;
+  const float c3 = 3.0f / alpha;
+  const char* tr_ptr = ts + (8 * half + ((lane & 15) >> 2)) * LROW + (((lane & 31) >> 4) * 16 + (lane & 3) * 4) * 2;
+
+  // ---- the workgroup's walk: units (b, block of NG groups o, quad of m-tiles i), i fastest; steps k = 0 .. ng - 1 inside a unit.  XR: workgroup id 128 q + 8 j + x
+  // takes unit 128 q + 16 x + j -- the 16 quads along m that share the 128-byte lines of input scale bytes on ONE XCD.
+  const uint32_t U = (uint32_t)((int64_t)p.B * n_o * n_iq), U128 = U & ~127u;
+  struct Cur { uint32_t u; int k, ng, b, g0, mq0; int64_t e0; };
+  auto decode = [&](Cur& c) __attribute__((always_inline)) {
+    c.k = 0;
+    if (c.u >= U) { c.ng = 0; c.b = 0; c.g0 = 0; c.mq0 = 0; c.e0 = 0; return; }
+    const uint32_t u = (XR && c.u < U128) ? (c.u & ~127u) + ((c.u & 7u) << 4) + ((c.u & 127u) >> 3) : c.u;
+    uint32_t i = u % (uint32_t)n_iq, q = u / (uint32_t)n_iq;
+    uint32_t o = q % (uint32_t)n_o;
+    q /= (uint32_t)n_o;
+    c.b = uniform((int)q);
+    c.mq0 = uniform((int)i * 256);
+    c.g0 = uniform((int)o * NG);
+    c.ng = uniform(min(NG, G - c.g0));
+    c.e0 = ((int64_t)c.b * p.N + (int64_t)c.g0 * 32) * p.M + c.mq0;
+  };
+  auto advance = [&](Cur& c) __attribute__((always_inline)) {
+    if (c.k + 1 < c.ng) { c.k += 1; c.e0 += (int64_t)32 * p.M; }
+    else { c.u += gridDim.x; decode(c); }
+  };
+  // ---- one step's fetch: wave w -> rows 8 w .. 8 w + 7 (lane / 8), LDS chunk lane % 8 of the row holds input chunk (lane % 8) ^ 2 (row % 4)
+  const int cg = (lane & 7) ^ (((lane >> 3) & 3) << 1);
+  const uint32_t q_off = (uint32_t)(lane >> 3) * rowb + (uint32_t)cg * 16u;
+  const uint32_t e_off = (uint32_t)(lane >> 1) * srowb + (uint32_t)(lane & 1) * 4u;
+  auto fetch = [&](const Cur& f, const int slot) __attribute__((always_inline)) {
+    const __amdgpu_buffer_rsrc_t r = make_rsrc((const char*)p.xq + (f.e0 >> 1) + (int64_t)wave * 8 * rowb, 8u * rowb);
+    dma16(r, ring_s[slot] + wave * 1024, (int)((f.mq0 + 32 * cg < p.M) ? q_off : OOB));   // (dropped chunks land as zeros: code 0 under scale byte 0)
+    if (wave == 0) {
+      const __amdgpu_buffer_rsrc_t re = make_rsrc((const char*)p.xs + (f.e0 >> 5), 32u * srowb);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(re, (lds_ptr_t)(ring_s[slot] + 4096), 4, (int)((f.mq0 + 128 * (lane & 1) < p.M) ? e_off : OOB), 0, 0, 0);
+    }
+  };
+  // the lane's quarter-row out of a slot: row lane / 2, input chunk 2 wave + lane % 2 (one input scale group) + its e8m0 byte
+  const int tr_ = lane >> 1, tc_ = 2 * wave + (lane & 1);
+  const int t_off = tr_ * 128 + ((tc_ ^ ((tr_ & 3) << 1)) << 4), t_eoff = 4096 + tr_ * 8 + tc_;
+  v4i ld;
+  uint32_t ld_e = 0;
+
+  auto stage = [&]() __attribute__((always_inline)) {
+    const int r = lane >> 1, c = (lane & 1) * 32;
+    const uint32_t e = ld_e;
+    const float sc = e == 255u ? 1.0f : __uint_as_float(e << 23);   // (byte 0 -> 0.0, byte 255 = +inf: see bwd_quant_t_kernel)
+    v4i* d = (v4i*)(ts + r * LROW + c * 2);
+#pragma unroll
+    for (int qq = 0; qq < 4; ++qq) {
+      const uint32_t w = (uint32_t)ld[qq];
+      v4i ov;
+      ov[0] = __builtin_bit_cast(int, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp4(w, sc, 0));
+      ov[1] = __builtin_bit_cast(int, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp4(w, sc, 1));
+      ov[2] = __builtin_bit_cast(int, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp4(w, sc, 2));
+      ov[3] = __builtin_bit_cast(int, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp4(w, sc, 3));
+      if (__builtin_expect(e == 255u, 0)) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) ov[k] = (int)qt_times_inf((uint32_t)ov[k]);
+      }
+      d[qq] = ov;
+    }
+  };
+  v8bf hf[2];
+  auto compute = [&](const int k) __attribute__((always_inline)) {
+    __builtin_amdgcn_s_waitcnt(0xc07f);         // lgkmcnt(0): the wave's own LDS writes landed
+    __builtin_amdgcn_wave_barrier();
+    v16f acc[2];
+    float amax[2];
+#pragma unroll
+    for (int mh = 0; mh < 2; ++mh) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mh][r] = 0.f;
+#pragma unroll
+      for (int kc = 0; kc < 2; ++kc) {
+        typedef short v4s_ __attribute__((ext_vector_type(4)));
+        typedef __attribute__((address_space(3))) v4s_* lds_v4s_t;
+        const v4s_ lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s_t)(tr_ptr + (16 * kc) * LROW + mh * 64));
+        const v4s_ hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s_t)(tr_ptr + (16 * kc + 4) * LROW + mh * 64));
+        const v8u16 xv = {(uint16_t)lo[0], (uint16_t)lo[1], (uint16_t)lo[2], (uint16_t)lo[3], (uint16_t)hi[0], (uint16_t)hi[1], (uint16_t)hi[2], (uint16_t)hi[3]};
+        acc[mh] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(hf[kc], __builtin_bit_cast(v8bf, xv), acc[mh], 0, 0, 0);
+      }
+    }
+    bool fast[2];
+#pragma unroll
+    for (int mh = 0; mh < 2; ++mh) {
+      float am = 0.f;   // (the reference's chain from 0: 8 v_max3_f32 with |x| operands)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) am = fmaxf(am, fabsf(acc[mh][r]));
+      amax[mh] = xhalf_max(am);
+      const uint32_t ab = __float_as_uint(amax[mh]);
+      fast[mh] = HWCVT && alpha_fast && ab >= 0x21800000u && ab <= 0x5d800000u;
+    }
+    const bool slow_wave = __builtin_amdgcn_ballot_w64(!(fast[0] && fast[1])) != 0;
+    auto emit = [&](const int mh, auto slow_c) __attribute__((always_inline)) {
+      constexpr bool SLOW = decltype(slow_c)::value;
+      const int mloc = mh * 32 + row;
+      const uint32_t ab = __float_as_uint(amax[mh]);
+      uint32_t sb = (ab - Kexp) & 0x7f800000u;
+      float mfac = c3, cs = __uint_as_float(sb);
+      if (SLOW) {   // the reference's arithmetic as written (quartet_bwd_sm120.cu:407-426) for the lanes outside the fast range
+        float scale = amax[mh] / alpha;
+        const uint32_t sbs = __float_as_uint(scale) & 0x7f800000u;
+        scale = __uint_as_float(sbs);
+        const float mult = 3.0f / (scale * alpha);
+        sb = fast[mh] ? sb : sbs;
+        mfac = fast[mh] ? mfac : mult;
+        cs = fast[mh] ? cs : 1.0f;
+      }
+      float tq[16];
+      scale_pk<16>(acc[mh], 0, mfac, tq);
+      if (SLOW) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) tq[r] = (tq[r] != tq[r]) ? __uint_as_float(0x7fc00000u) : tq[r];
+      }
+      const uint32_t P = e2m1_pack8<HWCVT>(tq, cs);
+      const uint32_t Q = e2m1_pack8<HWCVT>(tq + 8, cs);
+      auto sw = __builtin_amdgcn_permlane32_swap(P, Q, false, false);
+      const uint32_t X = sw[0], Y = sw[1];
+      v2i ov;
+      ov[0] = (int)((X & 0xffffu) | (Y << 16));
+      ov[1] = (int)((X >> 16) | (Y & 0xffff0000u));
+      *(v2i*)(os + mloc * OROW + k * 16 + half * 8) = ov;
+      if (half == 0) ss[mloc * NG + k] = (uint8_t)(sb >> 23);
+    };
+    if (!slow_wave) {
+      emit(0, std::false_type{});
+      emit(1, std::false_type{});
+    } else {
+      emit(0, std::true_type{});
+      emit(1, std::true_type{});
+    }
+    __builtin_amdgcn_wave_barrier();
+  };
+  auto store_unit = [&](const int b, const int g0, const int m0, const int ng) __attribute__((always_inline)) {
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+    const int rows = min(64, p.M - m0);
+    const int64_t grp0 = ((int64_t)b * p.M + m0) * G + g0;
+    const __amdgpu_buffer_rsrc_t ro = make_rsrc(p.out + grp0 * 16, (uint32_t)rows * (uint32_t)G * 16u - (uint32_t)g0 * 16u);
+#pragma unroll
+    for (int it = 0; it < NG; ++it) {
+      const int pc = it * 64 + lane, r = pc / NG, kk = pc % NG;
+      const uint32_t so = (kk < ng) ? (uint32_t)r * (uint32_t)G * 16u + (uint32_t)kk * 16u : OOB;
+      __builtin_amdgcn_raw_buffer_store_b128(*(const v4i*)(os + r * OROW + kk * 16), ro, (int)so, 0, 0);
+    }
+    if (lane < rows) {
+      uint8_t* dst = p.out_sf + grp0 + (int64_t)lane * G;
+      if ((G & (NG - 1)) == 0) {
+        if (NG == 8) *(v2i*)dst = *(const v2i*)(ss + lane * NG);
+        else *(uint32_t*)dst = *(const uint32_t*)(ss + lane * NG);
+      } else {
+        for (int kk = 0; kk < ng; ++kk) dst[kk] = ss[lane * NG + kk];
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+  };
+
+  Cur C, F;
+  C.u = F.u = blockIdx.x;
+  decode(C);
+  decode(F);
+  int fs = 0, cs = 0, inflight = 0;   // slot of the next fetch / of the current step; steps fetched and not yet taken
+#pragma unroll
+  for (int i = 0; i < R - 1; ++i) {
+    if (F.u < U) { fetch(F, fs); advance(F); fs = fs + 1 == R ? 0 : fs + 1; ++inflight; }
+  }
+  {   // hT[j][k] = h[k][j], staged in the first wave's tile area and read once
+    char* hT = tile_s[0];
+    uint16_t hv[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) hv[i] = p.h[i * 256 + tid];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int idx = i * 256 + tid, k = idx >> 5, j = idx & 31;
+      *(uint16_t*)(hT + j * HROW + k * 2) = hv[i];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kc = 0; kc < 2; ++kc) hf[kc] = *(const v8bf*)(hT + row * HROW + (kc * 16 + half * 8) * 2);
+    __syncthreads();
+  }
+  while (C.u < U) {   // uniform over the workgroup
+    // own piece of this step landed: the pieces of the R - 2 later steps may stay in flight (VMEM returns in order; stores issued in between only make the wait longer);
+    // at the tail of the walk fewer pieces follow, so everything is waited for
+    if (inflight == R - 1 && R > 2) {
+      if (wave == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (R - 2)) : "memory");
+      else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(R - 2) : "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    asm volatile("s_barrier" ::: "memory");   // all four pieces are in the slot; every wave is done with the slot of the step before
+    --inflight;
+    if (F.u < U) { fetch(F, fs); advance(F); fs = fs + 1 == R ? 0 : fs + 1; ++inflight; }
+    const int m0 = C.mq0 + 64 * wave;
+    if (m0 < p.M) {
+      // (inline asm: behind a plain LDS read of the ring the compiler waits for EVERY LDS-DMA in flight -- it cannot tell the slots apart -- i.e. for the piece issued two
+      //  lines up, a whole memory round trip per step)
+      const uint32_t slot_a = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)(ring_s[cs]);
+      asm volatile("ds_read_b128 %0, %2\n\tds_read_u8 %1, %3\n\ts_waitcnt lgkmcnt(0)" : "=&v"(ld), "=&v"(ld_e) : "v"(slot_a + (uint32_t)t_off), "v"(slot_a + (uint32_t)t_eoff) : "memory");
+      stage();
+      compute(C.k);
+      if (C.k + 1 == C.ng) store_unit(C.b, C.g0, m0, C.ng);
+    }
+    cs = cs + 1 == R ? 0 : cs + 1;
+    advance(C);
   }
 }
 

@@ -698,11 +698,13 @@ def test_backward_op_kernel_rules(lib):
     f.argtypes = [ctypes.c_int, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64]
     # backward_t (op 0): wave-owned 128-byte lines from 6 units (8 groups x 64 m) per CU on, the round-3 kernel below
     assert f(0, 1, 8192, 8192) == 3 and f(0, 1, 2048, 14336) == 3 and f(0, 1, 4096, 4096) == 1 and f(0, 1, 8192, 1024) == 1 and f(0, 4, 4096, 4096) == 3
-    # backward_qt (op 1): wave-owned 64-byte segments from 3 units per CU on
-    assert f(1, 1, 8192, 8192) == 2 and f(1, 1, 4096, 4096) == 2 and f(1, 1, 2048, 14336) == 2 and f(1, 1, 8192, 1024) == 1 and f(1, 1, 256, 192) == 1
+    # backward_qt (op 1): wave-owned 64-byte segments from 3 units per CU on; [r5] from 12 units per CU on, with M % 128 == 0, the same kernel fed through the
+    # shared whole-line ring (profiles/ab_bwd_r5x_ring_threshold.txt)
+    assert f(1, 1, 8192, 8192) == 5 and f(1, 1, 4096, 4096) == 2 and f(1, 1, 2048, 14336) == 2 and f(1, 1, 8192, 1024) == 1 and f(1, 1, 256, 192) == 1
+    assert f(1, 1, 14336, 4096) == 5 and f(1, 1, 11008, 4096) == 2 and f(1, 1, 6144, 6144) == 2 and f(1, 1, 8192, 8192 + 64) == 2 and f(1, 2, 8192, 4096) == 5
     # never the other op's kernel (the product library only holds QT x 4 groups and T x 8 groups)
     for shp in [(1, 32, 8), (2, 512, 320), (1, 16384, 16384)]:
-        assert f(0, *shp) in (1, 3) and f(1, *shp) in (1, 2)
+        assert f(0, *shp) in (1, 3) and f(1, *shp) in (1, 2, 5)
     # square_double (op 2): 16-wave workgroups of 128 x 512 when n % 512 == 0 and that still gives every CU a workgroup
     assert f(2, 8192, 8192, 0) == 4 and f(2, 4096, 4096, 0) == 4 and f(2, 1024, 4096, 0) == 1 and f(2, 4096, 4224, 0) == 1 and f(2, 16384, 512, 0) == 1 and f(2, 32768, 512, 0) == 4
     assert f(0, 1, 100, 64) == -1 and f(2, 100, 128, 0) == -1 and f(9, 1, 1, 1) == -1
@@ -810,7 +812,7 @@ def test_product_build_does_not_see_the_lab_sources():
     import subprocess
     from qutlass_amd import build
     src = os.path.join(ROOT, "qutlass_amd", "csrc", "capi.hip")
-    lab_headers = ("gemm_mx_deepp_lab.hip.h", "gemm_mx_lab.hip.h")
+    lab_headers = ("gemm_mx_deepp_lab.hip.h", "gemm_mx_lab.hip.h", "quartet_bwd_lab.hip.h")
     def deps(unit, extra):   # the files the preprocessor read (its line markers): one unit is enough per build -- every unit includes the same headers
         import tempfile
         with tempfile.TemporaryDirectory() as td:

@@ -205,3 +205,52 @@ def test_compiled_quantize_swizzle_gemm_equals_eager(q):
         assert torch.equal(out.view(torch.int16), eager.view(torch.int16)), backend
     sb = torch.compile(lambda t: to_blocked(t), backend="aot_eager", fullgraph=True)(ws)
     assert torch.equal(sb.view(torch.uint8), wsf.view(torch.uint8))
+
+
+# ------------------------------------------------------------------------------------------------
+# [r5] backward_qt_bf16 with whole-line input: bwd_qt_ring_kernel (product: 12 units per CU and more with M % 128 == 0; lab variants 5-8) and the lab-only panel
+# kernel (variant 4) -- quartet_bwd_sm120.cu:327-430.  Forced through the LAB build on ragged / batched shapes against the oracle, and the product rule at a size that
+# takes the ring kernel against the round-3 kernel byte for byte.
+# ------------------------------------------------------------------------------------------------
+import _benchlib as lab  # noqa: E402  (the LAB library: test infrastructure)
+
+
+@pytest.mark.parametrize("variant", [4, 5, 6, 7, 8])
+@pytest.mark.parametrize("B,N,M", [(1, 256, 256), (2, 288, 640), (1, 32, 128), (3, 1056, 1152), (1, 2080, 384)])
+def test_backward_qt_whole_line_kernels_equal_the_oracle(q, variant, B, N, M):
+    """group counts that are not multiples of 4 / 8, M % 256 in {0, 128}, fewer rows than a workgroup takes, batches; input scale bytes 0 and 255 included"""
+    rng = np.random.default_rng(B * 1000 + N + M + variant)
+    h = _hadamard(32)
+    codes = rng.integers(0, 256, size=(B, N, M // 2), dtype=np.uint8)
+    scales = rng.integers(110, 140, size=(B, N, M // 32), dtype=np.uint8)
+    codes[:, -32:, : M // 4] = 0                  # all-zero groups: the reference's 0 * inf = NaN -> code 7 path
+    scales[:, 0, 0] = 0
+    scales[:, N // 2, -1] = 255
+    with lab.forced(bwd_variant=variant):
+        e2m1, e8m0 = lab.backward_qt_bf16(torch.from_numpy(codes).to(DEV), torch.from_numpy(scales).to(DEV), h, torch.tensor([3.0], device=DEV))
+    rq, rs = oracle.backward_qt_bf16(codes, scales, _np(h), 3.0, acc_model=1)
+    assert np.array_equal(_np(e8m0), rs), int((_np(e8m0) != rs).sum())
+    eq = oracle.codes_equal_mod_zero_sign(_np(e2m1).reshape(rq.shape), rq)
+    assert int((~eq).sum()) <= 1e-4 * eq.size, int((~eq).sum())
+
+
+def test_backward_qt_product_rule_takes_the_ring_kernel_and_equals_the_round3_kernel(q):
+    """8192 x 4224 x 2 batches = 16.5 units per CU with M % 128 == 0: the PRODUCT library launches bwd_qt_ring_kernel (test_backward_op_kernel_rules pins the rule on
+    the CPU); its bytes equal the round-3 kernel's and the wave-owned kernel's, general rotation matrix, 131 + 1 groups (not a multiple of 4)."""
+    g = torch.Generator(device=DEV).manual_seed(11)
+    h = (torch.randn(32, 32, device=DEV, generator=g) * 0.2).to(torch.bfloat16)
+    B, N, M = 2, 4096 + 128, 8192 + 128
+    xq = torch.randint(0, 256, (B, N, M // 2), dtype=torch.uint8, device=DEV, generator=g)
+    xs = torch.randint(116, 136, (B, N, M // 32), dtype=torch.uint8, device=DEV, generator=g)
+    alpha = torch.tensor([0.61], device=DEV)
+    lib = q._lib.load()
+    import ctypes
+    f = lib.qutlass_amd_debug_stream_plan
+    f.restype = ctypes.c_int
+    f.argtypes = [ctypes.c_int, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64]
+    assert f(1, B, N, M) == 5
+    pq, ps = q.backward_qt_bf16(xq, xs.view(torch.float8_e8m0fnu), h, alpha)
+    for v in (1, 2):
+        with lab.forced(bwd_variant=v):
+            oq, osf = lab.backward_qt_bf16(xq, xs, h, alpha)
+        assert torch.equal(pq.view(torch.uint8).reshape(oq.shape), oq) and torch.equal(ps.view(torch.uint8).reshape(osf.shape), osf), v

@@ -16,18 +16,25 @@ def hadamard(n, dev):
     return (h * n ** -0.5).to(torch.bfloat16).to(dev)
 
 
-VARS = [0, 1, 2, 3]
-NAMES = {0: "the product rule", 1: "round-3 kernel (8 waves per unit, 2 barriers per unit)", 2: "wave-owned 64-byte segments (units of 4 groups, 12-16 waves per CU)", 3: "wave-owned 128-byte lines (units of 8 groups, 8 waves per CU)"}
+VARS = [0, 1, 2, 3, 4, 5, 6, 7, 8]
+NAMES = {5: "[r5] QT: v2 with the input through a shared whole-line ring (NG 4, 3 slots)", 6: "[r5] QT: ring, NG 8, 4 slots, 16 quads per XCD", 7: "[r5] QT: ring, NG 8, 4 slots", 8: "[r5] QT: ring, NG 4, 3 slots, 16 quads per XCD", 0: "the product rule", 1: "round-3 kernel (8 waves per unit, 2 barriers per unit)", 2: "wave-owned 64-byte segments (units of 4 groups, 12-16 waves per CU)", 4: "[r5] QT only: whole-line panels, [256 n][256 m] per workgroup (T: the product rule)", 3: "wave-owned 128-byte lines (units of 8 groups, 8 waves per CU)"}
 
 
 def main():
+    global VARS
+    if os.environ.get("AB_BWD_VARS"):
+        VARS = [int(v) for v in os.environ["AB_BWD_VARS"].split(",")]
+    shapes = [(4096, 4096), (8192, 8192), (2048, 14336), (8192, 1024)]
+    if os.environ.get("AB_BWD_SHAPES"):
+        shapes = [tuple(int(d) for d in sh.split("x")) for sh in os.environ["AB_BWD_SHAPES"].split(",")]
+    ops = os.environ.get("AB_BWD_OPS", "t,qt").split(",")
     dev = torch.device("cuda:0")
     h = hadamard(32, dev)
     alpha = torch.tensor([0.75], device=dev)
     print("variants (lab option bwd_variant): " + ", ".join(f"{v}={NAMES[v]}" for v in VARS))
     print("%-30s | warm us: %s | cold us: %s |" % ("op  (N x M)", " ".join("%7s" % ("v%d" % v) for v in VARS), " ".join("%7s" % ("v%d" % v) for v in VARS)))
-    for (n, m) in [(4096, 4096), (8192, 8192), (2048, 14336), (8192, 1024)]:
-        for op in ("t", "qt"):
+    for (n, m) in shapes:
+        for op in ops:
             nbuf = max(2, int(300e6 / (n * m * (2 if op == "t" else 0.53))) + 1)
             if op == "t":
                 xs = [torch.randn(n, m, dtype=torch.bfloat16, device=dev) * 3 for _ in range(nbuf)]

@@ -72,6 +72,8 @@ PY
     contention) timeout 300 python tools/final_stage_contention.py > $O/final_stage_contention.txt 2> $O/final_stage_contention.err; echo "contention rc=$?"; cat $O/final_stage_contention.txt; tail -3 $O/final_stage_contention.err ;;
     abmx)   timeout 900 python tools/ab_mxsk.py > $O/ab_mxsk.txt 2> $O/ab_mxsk.err; echo "abmx rc=$?"; cat $O/ab_mxsk.txt; tail -3 $O/ab_mxsk.err ;;
     hazard) (cd tests/native && hipcc --offload-arch=gfx950 -O2 store_hazard_probe.hip -o store_hazard_probe 2>/dev/null); timeout 120 tests/native/store_hazard_probe > $O/store_hazard_probe.txt 2>&1; echo "hazard rc=$?"; cat $O/store_hazard_probe.txt ;;
+    xposeub) (cd tests/native && hipcc --offload-arch=gfx950 -O3 -w xpose_traffic_ubench.hip -o xpose_traffic_ubench); timeout 300 tests/native/xpose_traffic_ubench > $O/xpose_traffic_ubench.txt 2>&1; echo "xposeub rc=$?"; cat $O/xpose_traffic_ubench.txt ;;
+    qtpanel) timeout 600 python tools/check_qt_panel.py > $O/check_qt_panel.txt 2>&1; echo "qtpanel rc=$?"; tail -15 $O/check_qt_panel.txt ;;
     libdiff) # [r5] where do two builds disagree: LD_PAIRS="old.so:new.so:fmt ..." (tools/lib_diff.py)
             for pr in ${LD_PAIRS:-build/exp/libqamd_base.so:qutlass_amd/libqutlass_amd.so:mxf4}; do IFS=: read a b f <<< "$pr"
               echo "== $a vs $b ($f)" >> $O/lib_diff.txt; timeout 300 python tools/lib_diff.py $a $b --fmt=$f >> $O/lib_diff.txt 2>> $O/lib_diff.err; done
