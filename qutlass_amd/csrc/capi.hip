@@ -212,6 +212,12 @@ int launch_gemm_deepp(GemmParams p, hipStream_t s) {
   p.ws = nullptr; p.splits = 1; p.ctr = nullptr; p.tag = 0;
   const int grid = deepp_grid(p.tiles_m * p.tiles_n);
 #if QAMD_BENCH
+#ifdef QAMD_ROUTE_LABK   // side builds for schedule A/Bs (tools/build_variant.py --lab ... -DQAMD_ROUTE_LABK): the plain entry runs the LAB copy of the kernel, no ablation
+  if constexpr (!TRACE && LAB == 0) {
+    hipLaunchKernelGGL((labk::gemm_mx_deepp_kernel<C, false, ST_AUX, 8>), dim3(grid), dim3(C::THREADS), 0, s, p);
+    return check_launch("labk::gemm_mx_deepp_kernel");
+  }
+#endif
   if constexpr (TRACE || LAB != 0) {   // stage traces and result-changing ablations: the lab copy of the kernel
     hipLaunchKernelGGL((labk::gemm_mx_deepp_kernel<C, TRACE, ST_AUX, LAB>), dim3(grid), dim3(C::THREADS), 0, s, p);
     return check_launch("labk::gemm_mx_deepp_kernel");

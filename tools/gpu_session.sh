@@ -74,6 +74,7 @@ PY
     hazard) (cd tests/native && hipcc --offload-arch=gfx950 -O2 store_hazard_probe.hip -o store_hazard_probe 2>/dev/null); timeout 120 tests/native/store_hazard_probe > $O/store_hazard_probe.txt 2>&1; echo "hazard rc=$?"; cat $O/store_hazard_probe.txt ;;
     xposeub) (cd tests/native && hipcc --offload-arch=gfx950 -O3 -w xpose_traffic_ubench.hip -o xpose_traffic_ubench); timeout 300 tests/native/xpose_traffic_ubench > $O/xpose_traffic_ubench.txt 2>&1; echo "xposeub rc=$?"; cat $O/xpose_traffic_ubench.txt ;;
     qtpanel) timeout 600 python tools/check_qt_panel.py > $O/check_qt_panel.txt 2>&1; echo "qtpanel rc=$?"; tail -15 $O/check_qt_panel.txt ;;
+    powerdata) timeout 600 python tools/power_data_probe.py > $O/power_data_probe.txt 2> $O/power_data_probe.err; echo "powerdata rc=$?"; cat $O/power_data_probe.txt; tail -3 $O/power_data_probe.err ;;
     libdiff) # [r5] where do two builds disagree: LD_PAIRS="old.so:new.so:fmt ..." (tools/lib_diff.py)
             for pr in ${LD_PAIRS:-build/exp/libqamd_base.so:qutlass_amd/libqutlass_amd.so:mxf4}; do IFS=: read a b f <<< "$pr"
               echo "== $a vs $b ($f)" >> $O/lib_diff.txt; timeout 300 python tools/lib_diff.py $a $b --fmt=$f >> $O/lib_diff.txt 2>> $O/lib_diff.err; done
