@@ -527,6 +527,24 @@ def main():
                                "source": "librocm_smi64 rsmi_dev_power_get / rsmi_dev_gpu_clk_freq_get(SYS), host thread, 2 ms period"}
         else:
             result["power"] = None
+    # [r5] the same kernel, same shape, ALL-ZERO operands under unit scales (nothing toggles in the matrix pipe, the clock stays up): what the SCHEDULE delivers without the
+    # socket's power cap.  A reported side figure, after the timed region, never `value` / `roofline.frac` (tools/power_data_probe.py has the longer form).
+    if rank == 0 and world == 1 and not args.no_configs:
+        try:
+            zq_a, zq_b = torch.zeros_like(a_q), torch.zeros_like(b_q)
+            one_a = torch.full_like(a_sf.view(torch.uint8), 127).view(a_sf.dtype)
+            one_b = torch.full_like(b_sf.view(torch.uint8), 127).view(b_sf.dtype)
+            zus, zhow = graph_us(lambda: qutlass_amd.matmul_mxf4_bf16_tn(zq_a, zq_b, one_a, one_b, alpha), sampler=sampler if (sampler and sampler.ok) else None, tag="zero_operands")
+            ztf = flop_per_step / zus * 1e-6
+            result["roofline"]["same_kernel_on_zero_operands"] = {"kernel_us": round(zus, 3), "achieved": round(ztf, 2), "frac": round(ztf / FP4_DENSE_PEAK_TFLOPS, 4), "timing": zhow,
+                                                                   "note": "all-zero e2m1 codes, every scale 2^0: identical instruction stream, no data-dependent power -- the schedule at the clock the "
+                                                                           "peak is quoted for; the gap to roofline.frac is the socket power cap under the bench operands"}
+            if sampler and sampler.ok:
+                zw = sampler.window("zero_operands:0", "zero_operands:1")
+                result["roofline"]["same_kernel_on_zero_operands"].update({"power_w": zw["power_w"], "sclk_mhz": zw["sclk_mhz"]})
+            del zq_a, zq_b, one_a, one_b
+        except Exception as e:   # noqa: BLE001 -- a side measurement must not cost the headline line
+            result["roofline"]["same_kernel_on_zero_operands"] = {"error": f"{type(e).__name__}: {e}"}
     # HBM-side bytes per launch of this kernel: fresh PMC passes (see fresh_traffic), rank 0 of a single-GPU run only
     if rank == 0 and world == 1:
         tj, note = None, "skipped (--no-pmc)"
