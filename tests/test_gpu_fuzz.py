@@ -291,13 +291,13 @@ def test_fuzz_round4_kernels(q):
         assert np.array_equal(_np(out)[rows], ref), ("nvf4 persistent", it, m, n, k, int((_np(out)[rows] != ref).sum()))
     h = _hadamard(32)
     for it in range(8):
-        B, N, M = int(rng.integers(1, 3)), int(rng.integers(1, 24)) * 32, int(rng.integers(1, 30)) * 32
+        B, N, M = int(rng.integers(1, 3)), int(rng.integers(1, 24)) * 32, int(rng.integers(1, 30)) * 32 if it % 2 else int(rng.integers(1, 9)) * 128
         x = torch.from_numpy(rng.standard_normal((B, N, M)).astype(np.float32) * 25.0).to(torch.bfloat16).to(DEV)
         xq = torch.from_numpy(rng.integers(0, 256, size=(B, N, M // 2), dtype=np.uint8)).to(DEV)
         xs = torch.from_numpy(rng.integers(112, 142, size=(B, N, M // 32), dtype=np.uint8)).to(DEV)
         alpha = torch.tensor([float(np.float32(rng.uniform(0.05, 20.0)))], device=DEV)
         t0, q0 = q.backward_t_bf16(x, h), q.backward_qt_bf16(xq, xs.view(torch.float8_e8m0fnu), h, alpha)
-        for v in (2, 3):
+        for v in (2, 3) + ((5, 4) if M % 128 == 0 else ()):   # [r5] 5 = the ring kernel (product for large inputs), 4 = the lab's panel kernel: QT only (T takes its product rule)
             with lab.forced(bwd_variant=v):
                 t1, q1 = lab.backward_t_bf16(x, h), lab.backward_qt_bf16(xq, xs, h, alpha)
             for got, want in zip(t1 + q1, t0 + q0):
