@@ -1538,6 +1538,16 @@ int qutlass_amd_mxfp4_transpose_mxfp8_rows(const void* x_fp4, const void* scales
     return check_launch("mxfp4_transpose_mxfp8_kernel");
   }
 #endif
+#if QAMD_BENCH
+  if (opt_transpose_nc() >= 5 && opt_transpose_nc() <= 8) {   // [r5] the persistent form with the next tile's rows in flight: 5 / 6 / 7 / 8 = 4 / 3 / 2 / 6 workgroups' worth of grid per CU
+    const int64_t tiles = (m_pad / 128) * (n / 128);
+    const int per_cu = opt_transpose_nc() == 5 ? 4 : opt_transpose_nc() == 6 ? 3 : opt_transpose_nc() == 7 ? 2 : 6;
+    int64_t grid = std::min<int64_t>(tiles, chip_cus() * per_cu);
+    if (grid < tiles) grid = grid / 16 * 16;
+    hipLaunchKernelGGL((mxfp4_transpose_mxfp8_pp_kernel<128, 128>), dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, p);
+    return check_launch("mxfp4_transpose_mxfp8_pp_kernel");
+  }
+#endif
   hipLaunchKernelGGL((mxfp4_transpose_mxfp8_kernel<128, 128>), dim3((unsigned)((m_pad / 128) * (n / 128))), dim3(256), 0, (hipStream_t)stream, p);
   return check_launch("mxfp4_transpose_mxfp8_kernel");
 }

@@ -249,4 +249,186 @@ __global__ __launch_bounds__(512) void bwd_qt_panel_kernel(const BwdTParams p) {
 }
 
 
+// ----------------------------------------------------------------------------------------------------------------
+// [r5] The same tile, PERSISTENT: a workgroup walks tiles t, t + grid, ... with the NEXT tile's rows (2 x 16 bytes + 2 scale bytes per lane) in flight while this one is
+// transposed, requantised and stored -- the one-shot form exposes a cold memory round trip per tile to every wave (60 % of its wave cycles wait; cold - warm = 7 us at
+// 8192^2).  Bare barriers (s_waitcnt lgkmcnt(0) + s_barrier): __syncthreads() is s_waitcnt vmcnt(0) first, i.e. it would wait for the prefetch.
+// MEASURED (profiles/ab_transpose_r5ac_persistent_prefetch.txt), byte-identical: 8192^2 cold 29.4 us against 28.3, warm 21.1 against 21.1; 2048 x 14336 / 14336 x 2048 cold
+// 12.5-12.8 against 13.8-13.9; 16384 x 8192 warm 43.5 against 37.8.  Hiding the load latency buys nothing at 8192^2: cold - warm stays 7-8 us with the prefetch, i.e. the cold
+// penalty is bandwidth (scattered 128-byte lines written while the input streams in), not exposed latency.  Kept here as the record.
+template <int NC, int MR = 128>
+__global__ __launch_bounds__(MR * 2) void mxfp4_transpose_mxfp8_pp_kernel(const TrParams p) {
+  constexpr int NWV = MR / 32, NTH = MR * 2;      // waves, threads
+  constexpr int LROW = NC * 2 + 64;    // bf16 row of NC columns + pad: 16 dwords (mod 64), so the 4 rows x 32 bytes that each of the two 16-lane groups of a
+                                       // half wave gathers with ds_read_b64_tr_b16 fall on 64 different banks
+  constexpr int LPR = NC / 32;         // lanes per input row (16 bytes = 32 codes = one input scale group each)
+  constexpr int RPP = 64 / LPR;        // rows per load pass
+  constexpr int CPL = NC / 64;         // columns per lane
+  __shared__ __attribute__((aligned(16))) char ts_all[NWV][32 * LROW];
+  const int tid = threadIdx.x, lane = tid & 63, wave = uniform(tid >> 6);
+  const int tiles_n = p.n / NC;
+  // [r3] NC = 128: a tile reads 64 of the 128 bytes of each of its input lines, the tile next to it (tj ^ 1) the other 64.  Workgroup ids go round
+  // the 8 XCDs, so the two landed on different XCDs and each L2 fetched the whole line: FETCH_SIZE 82 MB for 35.6 MB of input at 8192^2
+  // (profiles/pmc_stream_ops_r3.txt).  Pairs now sit on one XCD, one dispatch slot apart (tiles_n is even: n % 256 == 0).
+  // ([r4] The e8m0 lines of the input rows are still fetched once per XCD (FETCH_SIZE 50.3 MB for 35.7 MB at 8192^2); keeping a row block on one XCD
+  // removes that and costs more on the write side -- the 4 scale bytes a tile writes per output row share their line with 31 other row blocks, which then
+  // sit on 8 different L2s: WRITE_SIZE 69.4 -> 85.8 MB, 28.4 -> 28.9 / 29.2 us cold.  profiles/ab_transpose_r4{s,t}_*.txt, pmc_stream_ops_r4.txt.)
+  const unsigned ntiles = (unsigned)(p.m_pad / MR) * (unsigned)tiles_n;
+  constexpr int NPS = 32 / RPP;
+  struct Tile { int r0, c0, m0; };
+  auto decode = [&](unsigned t) __attribute__((always_inline)) {
+    if (NC == 128 && t < (ntiles & ~15u)) {   // (the pairing of the one-shot kernel: the two tiles that share input lines on one XCD; gridDim.x % 16 == 0 keeps a workgroup's XCD)
+      const unsigned x = t & 7u, k = t >> 3;
+      t = 2u * ((k >> 1) * 8u + x) + (k & 1u);
+    }
+    const int ti = (int)(t / (unsigned)tiles_n), tj = (int)(t % (unsigned)tiles_n);
+    return Tile{ti * MR + wave * 32, tj * NC, ti * MR};
+  };
+  v4i vld[NPS];
+  uint32_t sld[NPS];
+  auto load = [&](unsigned t) __attribute__((always_inline)) {
+    if (t >= ntiles) return;
+    const Tile tl = decode(t);
+#pragma unroll
+    for (int ps = 0; ps < NPS; ++ps) {
+      const int r = ps * RPP + lane / LPR, c = (lane % LPR) * 32;
+      const int64_t rowi = tl.r0 + r;
+      const bool live = rowi < p.m;
+      vld[ps] = live ? *(const v4i*)(p.xq + rowi * (p.n >> 1) + ((tl.c0 + c) >> 1)) : v4i{0, 0, 0, 0};
+      sld[ps] = live ? p.xs[rowi * (p.n >> 5) + ((tl.c0 + c) >> 5)] : 127u;
+    }
+  };
+  char* ts = ts_all[wave];
+  load(blockIdx.x);
+  for (unsigned tcur = blockIdx.x; tcur < ntiles; tcur += gridDim.x) {
+  const Tile tl = decode(tcur);
+  const int c0 = tl.c0;
+  bool nan_in = false;
+  v4i vcur[NPS];
+  uint32_t scur[NPS];
+#pragma unroll
+  for (int ps = 0; ps < NPS; ++ps) { vcur[ps] = vld[ps]; scur[ps] = sld[ps]; }
+  load(tcur + gridDim.x);   // the next tile's rows: in flight until the next trip
+#pragma unroll
+  for (int ps = 0; ps < NPS; ++ps) {
+    const int r = ps * RPP + lane / LPR, c = (lane % LPR) * 32;
+    const v4i v = vcur[ps];
+    const uint32_t se = scur[ps];
+    // [r5] input scale byte 255 is NaN (`__nv_cvt_e8m0_to_bf16raw`, quartet_bwd_sm120.cu:658-660): all 32 operands of the group become NaN, which the reference's
+    // fmaxf block maximum ignores and its e4m3 convert turns into 0x7f.  The bit-pattern maximum below cannot ignore a NaN, so a wave that has seen such a byte
+    // takes the exact arm there (wave-uniform, never taken on the quantizers' own outputs).
+    nan_in |= se == 255u;
+    const float sc = se == 255u ? __uint_as_float(0x7fc00000u) : e8m0_scale(se);
+    v4i* d = (v4i*)(ts + r * LROW + c * 2);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const uint32_t w = (uint32_t)v[q];
+      v4i o;
+      o[0] = __builtin_bit_cast(int, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp4(w, sc, 0));
+      o[1] = __builtin_bit_cast(int, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp4(w, sc, 1));
+      o[2] = __builtin_bit_cast(int, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp4(w, sc, 2));
+      o[3] = __builtin_bit_cast(int, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp4(w, sc, 3));
+      d[q] = o;
+    }
+  }
+  __builtin_amdgcn_s_waitcnt(0xc07f);
+  __builtin_amdgcn_wave_barrier();
+  const bool wave_nan = __builtin_amdgcn_ballot_w64(nan_in) != 0;
+  // Columns lane, lane + 64, ...  [r3] The lane's 32 m values of a column come out of the tile with 8 transposing reads (ds_read_b64_tr_b16: the 16
+  // lanes of a group supply the 8-byte pieces of 4 rows x 16 columns and receive one column each, rows 2i, 2i + 1 already paired in a register)
+  // instead of 32 two-byte reads + 16 packs -- PMC had the LDS instruction issue busy 17 of the kernel's 23 us at 8192^2 -- and the block
+  // maximum is taken on the packed bf16 bit patterns (sign stripped, v_pk_max_u16: for non-NaN values the order of the patterns is the order of
+  // the magnitudes; [r5] a wave that met an input scale byte of 255 = NaN operands takes the exact arm, `wave_nan`).
+  typedef short v4s_ __attribute__((ext_vector_type(4)));
+  typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+  typedef __attribute__((address_space(3))) v4s_* lds_v4s_t;
+  const char* tr_ptr = ts + ((lane & 15) >> 2) * LROW + ((lane >> 4) * 16 + (lane & 3) * 4) * 2;
+  v4i oq[CPL][2];
+  uint8_t oe[CPL];
+#pragma unroll
+  for (int cc = 0; cc < CPL; ++cc) {
+    uint32_t pr[16];   // pr[i] = bf16 of rows 2i (low half) and 2i+1 (high half)
+    u16x2 mx = {0, 0};
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const v4s_ t4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s_t)(tr_ptr + 4 * q * LROW + cc * 128));
+      const v2i w2 = __builtin_bit_cast(v2i, t4);
+      pr[2 * q] = (uint32_t)w2[0];
+      pr[2 * q + 1] = (uint32_t)w2[1];
+      mx = __builtin_elementwise_max(mx, __builtin_bit_cast(u16x2, pr[2 * q] & 0x7fff7fffu));
+      mx = __builtin_elementwise_max(mx, __builtin_bit_cast(u16x2, pr[2 * q + 1] & 0x7fff7fffu));
+    }
+    float amax = __uint_as_float((uint32_t)(mx[0] > mx[1] ? mx[0] : mx[1]) << 16);
+    uint32_t nanrows = 0;   // bit r: row r of this column's block is NaN
+    if (wave_nan) {   // the maximum over the NON-NaN magnitudes (fmaxf semantics); the NaN rows are written as 0x7f below, whatever the convert makes of their sign
+      uint32_t m16 = 0;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        uint32_t lo16 = pr[i] & 0x7fffu, hi16 = (pr[i] >> 16) & 0x7fffu;
+        const bool nl = lo16 > 0x7f80u, nh = hi16 > 0x7f80u;
+        nanrows |= (nl ? 1u : 0u) << (2 * i) | (nh ? 1u : 0u) << (2 * i + 1);
+        lo16 = nl ? 0u : lo16; hi16 = nh ? 0u : hi16;
+        m16 = max(m16, max(lo16, hi16));
+      }
+      amax = __uint_as_float(m16 << 16);
+    }
+    const uint32_t e = e8m0_shift7(amax);
+    const float qs = e8m0_scale(e);
+    v4i o[2];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      i16x2 w = {0, 0};
+      w = __builtin_amdgcn_cvt_scalef32_pk_fp8_bf16(w, __builtin_bit_cast(bf16x2, pr[2 * q]), qs, false);
+      w = __builtin_amdgcn_cvt_scalef32_pk_fp8_bf16(w, __builtin_bit_cast(bf16x2, pr[2 * q + 1]), qs, true);
+      o[q >> 2][q & 3] = __builtin_bit_cast(int, w);
+    }
+    if (wave_nan && nanrows) {   // byte r of the lane's 32 output bytes = row r
+#pragma unroll
+      for (int d = 0; d < 8; ++d) {
+        uint32_t v = (uint32_t)o[d >> 2][d & 3];
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+          if ((nanrows >> (4 * d + b)) & 1u) v = (v & ~(0xffu << (8 * b))) | (0x7fu << (8 * b));
+        o[d >> 2][d & 3] = (int)v;
+      }
+    }
+    oq[cc][0] = o[0];
+    oq[cc][1] = o[1];
+    oe[cc] = (uint8_t)e;
+  }
+  // The lane's 32 output bytes per column are a quarter of a 128-byte output line (the other three quarters belong to
+  // the other waves) and its scale byte sits 128 bytes from its neighbour's: written straight from here that is 64
+  // partial lines per store instruction (14.2 us for 4096^2, 23 % of the HBM roofline).  Stage the workgroup's
+  // [NC n][128 m] fp8 tile and its [NC][4] scale bytes in LDS (the bf16 staging area is dead by now) and write whole
+  // lines / one dword of scales per output row.
+  asm volatile("s_waitcnt lgkmcnt(0)\n s_barrier" ::: "memory");
+  constexpr int OROW = MR + 16;                        // staged output row: MR m bytes + pad
+  char* os = &ts_all[0][0];
+  uint8_t* es = (uint8_t*)os + NC * OROW;              // [NC][NWV]
+  static_assert(NC * OROW + NC * NWV <= NWV * 32 * LROW, "output staging fits the bf16 staging area");
+#pragma unroll
+  for (int cc = 0; cc < CPL; ++cc) {
+    const int col = cc * 64 + lane;
+    *(v4i*)(os + col * OROW + wave * 32) = oq[cc][0];
+    *(v4i*)(os + col * OROW + wave * 32 + 16) = oq[cc][1];
+    es[col * NWV + wave] = oe[cc];
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)\n s_barrier" ::: "memory");
+  const int m0 = tl.m0;
+#pragma unroll
+  for (int ps = 0; ps < NC / 32; ++ps) {               // NC * MR / 16 16-byte pieces: row = piece / (MR / 16), chunk = piece % (MR / 16)
+    const int piece = ps * NTH + tid, row = piece / (MR / 16), ch = piece % (MR / 16);
+    const v4i v = *(const v4i*)(os + row * OROW + ch * 16);
+    *(v4i*)(p.y + (int64_t)(c0 + row) * p.m_pad + m0 + ch * 16) = v;
+  }
+  if (tid < NC && !QAMD_BWD_ABL(1)) {
+    uint8_t* dst = p.out_sf + (int64_t)(c0 + tid) * (p.m_pad >> 5) + (m0 >> 5);
+    if (MR == 128) *(uint32_t*)dst = *(const uint32_t*)(es + tid * 4);
+    else *(v2i*)dst = *(const v2i*)(es + tid * 8);
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)\n s_barrier" ::: "memory");   // the staged tile has been read (the stores took their data): the area is the next tile's bf16 staging
+  }
+}
+
+
 }  // namespace qamd

@@ -8,8 +8,8 @@ sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, ROOT); sys.p
 import _benchlib as lab
 from _timing import graph_us
 
-VARS = [0, 128, 3, 256, 4, 2]
-NAMES = {0: "the product rule", 128: "one-shot 128 m x 128 n (round 3)", 3: "one-shot 256 m x 128 n (8 waves)", 256: "one-shot 128 m x 256 n", 4: "wave-owned 128-byte lines", 2: "wave-owned 64-byte segments"}
+VARS = [int(v) for v in os.environ.get("AB_TR_VARS", "0,128,256,4,5,6,7,8").split(",")]
+NAMES = {5: "[r5] persistent one-shot tile, next tile prefetched, 4 workgroups per CU", 6: "[r5] the same, 3 per CU", 7: "[r5] 2 per CU", 8: "[r5] 6 per CU (4 resident)", 0: "the product rule", 128: "one-shot 128 m x 128 n (round 3)", 3: "one-shot 256 m x 128 n (8 waves)", 256: "one-shot 128 m x 256 n", 4: "wave-owned 128-byte lines", 2: "wave-owned 64-byte segments"}
 
 
 def main():
