@@ -19,6 +19,10 @@ def main():
     g = torch.Generator(device=dev).manual_seed(0)
     alpha = torch.ones(1, device=dev)
     pad = lambda r: (r + 127) // 128 * 128
+    if os.environ.get("AB_SK_SHAPES"):   # "MxNxK,..." for the formats named on the command line
+        for f_ in SHAPES:
+            SHAPES[f_] = [tuple(int(d) for d in sh.split("x")) for sh in os.environ["AB_SK_SHAPES"].split(",")]
+    print("# operands: %s" % ("all-zero codes under unit scales" if os.environ.get("AB_DATA") == "zero" else "random bytes"))
     for fmt in ([a for a in sys.argv[1:]] or ["mxf4", "mxf8"]):
         epb = 1 if fmt == "mxf8" else 2
         fn = lab.matmul_mxf4_bf16_tn if fmt == "mxf4" else lab.matmul_mxf8_bf16_tn
@@ -28,8 +32,12 @@ def main():
             b = torch.randint(0, 256, (n, k // epb), dtype=torch.uint8, device=dev, generator=g)
             if fmt == "mxf8":
                 a &= 0x77; b &= 0x77
+            if os.environ.get("AB_DATA") == "zero":   # nothing toggles in the matrix pipe: the clock stays up, the times are the schedules' in cycles (tools/power_data_probe.py)
+                a.zero_(); b.zero_()
             sa = torch.randint(118, 126, (pad(m) * ((k // 32 + 3) // 4 * 4),), dtype=torch.uint8, device=dev, generator=g)
             sb = torch.randint(118, 126, (pad(n) * ((k // 32 + 3) // 4 * 4),), dtype=torch.uint8, device=dev, generator=g)
+            if os.environ.get("AB_DATA") == "zero":
+                sa.fill_(127); sb.fill_(127)
             t = {}
             nrep = max(4, min(40, int(3000 / max(1.0, 2.0 * m * n * k / 3.5e9))))
             for rnd in range(2):
