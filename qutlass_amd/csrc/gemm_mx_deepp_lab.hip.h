@@ -698,7 +698,7 @@ __device__ __forceinline__ void gemm_mx_deepp(char* smem, const GemmParams& p, c
     for (int i = 0; i < 8; ++i) dma_item(d, ktn, 1, i);
     fence();
   };
-  constexpr int RET16 = (SK || LAB) ? 0 : QAMD_DEEPP_RETIRE;
+  constexpr int RET16 = (SK || (LAB & 7)) ? 0 : QAMD_DEEPP_RETIRE;   // (LAB = 8: the plain entry routed to this copy, QAMD_ROUTE_LABK -- no ablation)
   // (RET16 == 2: the alpha == 1 arm is a second copy of the whole tile walk, entered once per workgroup -- a branch per tile around two copies of the last stage
   //  makes the register allocator join two hand-scheduled stages and spills 128 registers)
   auto last_stage = [&](const Desc& d, bool dvalid, const int ktn, auto a1c) __attribute__((always_inline)) {
