@@ -1,13 +1,16 @@
 #!/usr/bin/env python3
-"""Build the PRODUCT translation units of the kernel library with extra compiler flags into a side file, for two-library A/Bs on one box
-(tools/ab_lib_gemm.py, tools/ab_lib_shapes.py; gpu_session.sh steps ablib* with AB_OLD / AB_NEW):
+"""Build the kernel library with extra compiler flags into a side file, for several-library A/Bs on one box (tools/ab_lib_gemm.py, tools/ab_lib_shapes.py;
+gpu_session.sh steps ablib* / abpairs with AB_OLD / AB_NEW / AB_PAIRS):
 
-    python tools/build_variant.py build/exp/libqamd_magic.so -DQAMD_CTX_MAGIC_DECODE=1
-    gpurun -- 'AB_OLD=qutlass_amd/libqutlass_amd.so AB_NEW=build/exp/libqamd_magic.so bash tools/gpu_session.sh <name> ablibmx'
+    python tools/build_variant.py build/exp/libqamd_magic.so -DQAMD_CTX_MAGIC_DECODE=1                          # the PRODUCT units + flags
+    python tools/build_variant.py build/exp/lab_splitb.so --lab -DQAMD_ROUTE_LABK -DQAMD_DEEPP_SPLITB=1         # the LAB units + flags
+    gpurun -- 'AB_DATA=zero python tools/ab_lib_gemm.py qutlass_amd/libqutlass_amd.so build/exp/lab_base.so build/exp/lab_splitb.so'
 
-(build/ is git-ignored and travels to the GPU box with the snapshot.)  Compile-time switches that exist for this: QAMD_CTX_MAGIC_DECODE (per-tile MX / NVFP4 kernels
-decode their tile without integer divisions, prepared at the end of round 4), QAMD_RING_KERNARG_EARLY / QAMD_NV_KERNARG_EARLY (one scalar-load round for the kernel
-arguments in the per-tile MX kernels / the NVFP4 kernels, likewise prepared and unmeasured), QAMD_DEEPP_SOFF, QAMD_KERNARG_EARLY, QAMD_DEEPP_PEEL, QAMD_DEEPP_EARLYPREP (gemm_mx_deepp.hip.h)."""
+(build/ is git-ignored and travels to the GPU box with the snapshot.)  Product switches that exist for this: QAMD_CTX_MAGIC_DECODE, QAMD_RING_KERNARG_EARLY /
+QAMD_NV_KERNARG_EARLY (per-tile MX / NVFP4 kernels).  The persistent kernels' experiments ([r5]) live in the lab copy (csrc/gemm_mx_deepp_lab.hip.h: QAMD_DEEPP_SPLITB,
+QAMD_DEEPP_RETIRE, QAMD_DEEPP8_RETIRE, QAMD_DEEPP_FS_IL, QAMD_FS_BURST, QAMD_FS_ABL, QAMD_DEEPP_RB2, QAMD_DEEPP_SOFF, QAMD_KERNARG_EARLY, QAMD_DEEPP_PEEL,
+QAMD_DEEPP_EARLYPREP): `--lab -DQAMD_ROUTE_LABK` makes the plain matmul_mxf4_bf16_tn entry of a lab build run that copy (a `lab_base.so` built with the routing flag alone
+is the control).  `AB_DATA=zero` times the schedules in cycles (no data-dependent power: tools/power_data_probe.py)."""
 import os
 import sys
 
