@@ -75,6 +75,7 @@ PY
     xposeub) (cd tests/native && hipcc --offload-arch=gfx950 -O3 -w xpose_traffic_ubench.hip -o xpose_traffic_ubench); timeout 300 tests/native/xpose_traffic_ubench > $O/xpose_traffic_ubench.txt 2>&1; echo "xposeub rc=$?"; cat $O/xpose_traffic_ubench.txt ;;
     qtpanel) timeout 600 python tools/check_qt_panel.py > $O/check_qt_panel.txt 2>&1; echo "qtpanel rc=$?"; tail -15 $O/check_qt_panel.txt ;;
     powerdata) timeout 600 python tools/power_data_probe.py > $O/power_data_probe.txt 2> $O/power_data_probe.err; echo "powerdata rc=$?"; cat $O/power_data_probe.txt; tail -3 $O/power_data_probe.err ;;
+    abvar) timeout 600 python tools/ab_gemm_variants.py > $O/ab_gemm_variants.txt 2> $O/ab_gemm_variants.err; echo "abvar rc=$?"; cat $O/ab_gemm_variants.txt; tail -3 $O/ab_gemm_variants.err ;;
     libdiff) # [r5] where do two builds disagree: LD_PAIRS="old.so:new.so:fmt ..." (tools/lib_diff.py)
             for pr in ${LD_PAIRS:-build/exp/libqamd_base.so:qutlass_amd/libqutlass_amd.so:mxf4}; do IFS=: read a b f <<< "$pr"
               echo "== $a vs $b ($f)" >> $O/lib_diff.txt; timeout 300 python tools/lib_diff.py $a $b --fmt=$f >> $O/lib_diff.txt 2>> $O/lib_diff.err; done
