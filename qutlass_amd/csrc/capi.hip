@@ -1447,7 +1447,8 @@ int qutlass_amd_backward_qt_bf16(const void* x_e2m1, const void* x_e8m0, const v
   const int grid = (int)std::max<int64_t>(32, std::min<int64_t>(cdiv(ntw, 32) * 32, cu * per_cu / 32 * 32));
   // [r4] wave-owned output segments: the four waves of a workgroup take four consecutive m-tiles -- the siblings that share QT's 128-byte input lines
   const int64_t nu = B * p.tiles_m * cdiv(N / 32, 8);
-  const int which = bwd_kernel_choice(true, nu, M % 128 == 0);
+  // (the ring kernel fetches by LDS-DMA: 16-byte pieces of the codes, dword pieces of the scale bytes -- an offset view that breaks either alignment takes the other kernels)
+  const int which = bwd_kernel_choice(true, nu, M % 128 == 0 && (uintptr_t)x_e2m1 % 16 == 0 && (uintptr_t)x_e8m0 % 4 == 0);
   p.abl = opt_bwd_variant() >> 4;
   const int64_t nuw = B * p.tiles_m * cdiv(N / 32, which == 3 ? 8 : 4);
   const int gridw = (int)std::min<int64_t>(cdiv(nuw, 4), cu * (which == 3 ? 2 : 4));

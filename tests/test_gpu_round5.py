@@ -254,3 +254,22 @@ def test_backward_qt_product_rule_takes_the_ring_kernel_and_equals_the_round3_ke
         with lab.forced(bwd_variant=v):
             oq, osf = lab.backward_qt_bf16(xq, xs, h, alpha)
         assert torch.equal(pq.view(torch.uint8).reshape(oq.shape), oq) and torch.equal(ps.view(torch.uint8).reshape(osf.shape), osf), v
+
+
+def test_backward_qt_scale_tensor_at_an_odd_address_takes_the_other_kernels(q):
+    """the ring kernel fetches the scale bytes as dword LDS-DMA pieces: an e8m0 operand that is a view at an odd byte offset must not take it (capi.hip checks the
+    alignment) and must give the same bytes as the aligned copy"""
+    g = torch.Generator(device=DEV).manual_seed(13)
+    h = _hadamard(32)
+    B, N, M = 1, 8192, 8192
+    xq = torch.randint(0, 256, (B, N, M // 2), dtype=torch.uint8, device=DEV, generator=g)
+    xs = torch.randint(116, 136, (B, N, M // 32), dtype=torch.uint8, device=DEV, generator=g)
+    buf = torch.empty(xs.numel() + 16, dtype=torch.uint8, device=DEV)
+    odd = buf[1:1 + xs.numel()].view(xs.shape)
+    odd.copy_(xs)
+    assert odd.data_ptr() % 4 == 1
+    alpha = torch.tensor([1.25], device=DEV)
+    want = q.backward_qt_bf16(xq, xs.view(torch.float8_e8m0fnu), h, alpha)
+    got = q.backward_qt_bf16(xq, odd.view(torch.float8_e8m0fnu), h, alpha)
+    for a_, b_ in zip(got, want):
+        assert torch.equal(a_.view(torch.uint8), b_.view(torch.uint8))
