@@ -86,6 +86,10 @@ int qutlass_amd_matmul_mxf8_bf16_tn(const void* A, const void* B, const void* A_
  * 16-byte aligned (the partials are written as 16-byte vectors; a misaligned pointer is rejected with QAMD_ERR_INVALID).
  * (The reference allocates and frees a CUTLASS workspace inside every call, gemm.cu:160-162.)
  *
+ * Alignment.  A, B, both scale operands and D of the matmul_{mxf4,mxf8,nvf4}_bf16_* entries must be 16-byte aligned (QAMD_ERR_INVALID otherwise): operands are
+ * fetched as 16-byte pieces, the output leaves as 16-byte stores.  Tensors that torch allocates, and row ranges of them, are.  (The reference's CUTLASS kernels
+ * require 128-bit alignment through their TMA descriptors, gemm.cu:90-143.)
+ *
  * Reproducibility.  Every entry point is deterministic: the same call on the same device returns the same bytes, run after run and
  * under HIP-graph replay.  It is NOT bit-stable ACROSS entry points or devices for general data: whether a shape splits K depends on
  * whether a workspace was passed and on the device's CU count (the plans scale with it), and a split sums the fp32 partials in a

@@ -654,6 +654,9 @@ int gemm_mx(const char* name, const void* A, const void* B, const void* A_sf, co
     return dispatch_variant<EBITS, EBITS == 8>(v, q, st, name);
   };
   if (!A || !B || !A_sf || !B_sf || !alpha || !D) return fail(QAMD_ERR_INVALID, "%s: null pointer argument", name);
+  // [r5] operands are fetched as 16-byte LDS-DMA pieces and the output leaves as 16-byte stores (the reference's CUTLASS kernels ask for 128-bit alignment as well, via TMA)
+  if (((uintptr_t)A | (uintptr_t)B | (uintptr_t)A_sf | (uintptr_t)B_sf | (uintptr_t)D) % 16)
+    return fail(QAMD_ERR_INVALID, "%s: A, B, the scale operands and D must be 16-byte aligned", name);
   if (M <= 0 || N <= 0) return fail(QAMD_ERR_INVALID, "%s: M and N must be positive (got M=%lld N=%lld)", name, (long long)M, (long long)N);
   const int kalign = (EBITS == 4) ? 128 : 32;
   if (K < 32 || K % kalign) return fail(QAMD_ERR_INVALID, "%s: K must be a positive multiple of %d (got %lld)", name, kalign, (long long)K);
@@ -1179,6 +1182,8 @@ static int nvf4_impl(const void* A, const void* B, const void* A_sf, const void*
                      int64_t K, int64_t ldd, void* stream, void* ws = nullptr, int64_t ws_bytes = 0) {
   const char* name = "matmul_nvf4_bf16_tn";
   if (!A || !B || !A_sf || !B_sf || !alpha || !D) return fail(QAMD_ERR_INVALID, "%s: null pointer argument", name);
+  if (((uintptr_t)A | (uintptr_t)B | (uintptr_t)A_sf | (uintptr_t)B_sf | (uintptr_t)D) % 16)   // [r5] as in gemm_mx
+    return fail(QAMD_ERR_INVALID, "%s: A, B, the scale operands and D must be 16-byte aligned", name);
   if (M <= 0 || N <= 0) return fail(QAMD_ERR_INVALID, "%s: M and N must be positive", name);
   if (K < 16 || K % 32) return fail(QAMD_ERR_INVALID, "%s: K must be a positive multiple of 32 (got %lld)", name, (long long)K);
   if (N % 8) return fail(QAMD_ERR_INVALID, "%s: N must be a multiple of 8 (got %lld)", name, (long long)N);
@@ -1584,7 +1589,7 @@ int qutlass_amd_to_blocked(const void* in, int64_t rows, int64_t cols, void* out
 // out[3 * i + {0, 1, 2}] = {gemm_variant, N of the launch, K splits} of launch i; returns the number of launches (the split-K
 // reduce pass is implied by splits > 1), or -1 when the arguments are rejected.  No GPU is touched.
 int qutlass_amd_debug_gemm_plan(int ebits, int64_t M, int64_t N, int64_t K, int64_t workspace_bytes, int* out, int cap) {
-  static char dummy[16];
+  alignas(16) static char dummy[16];
   t_dry = DryRun{};
   t_dry.on = true;
   void* ws = workspace_bytes > 0 ? (void*)dummy : nullptr;

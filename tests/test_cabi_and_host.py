@@ -74,6 +74,14 @@ def test_c_abi_rejects_bad_arguments_without_launching(lib):
     assert "16-byte aligned" in err()
     assert lib.qutlass_amd_fused_quantize_nv(dummy, odd, 128, 4096, 1, dummy, dummy, dummy, None) == QAMD_ERR_INVALID
     assert "16-byte aligned" in err()
+    # [r5] GEMM operands / output: fetched and stored as 16-byte pieces (the reference's CUTLASS kernels ask for 128-bit alignment too)
+    al = ctypes.c_void_p(0x1000)
+    for k_ in range(5):
+        args = [al] * 6
+        args[k_ if k_ < 4 else 5] = odd
+        assert g(*args, 128, 128, 128, None) == QAMD_ERR_INVALID and "16-byte aligned" in err(), k_
+        assert lib.qutlass_amd_matmul_mxf8_bf16_tn(*args, 128, 128, 128, None) == QAMD_ERR_INVALID and "16-byte aligned" in err(), k_
+        assert lib.qutlass_amd_matmul_nvf4_bf16_tn(*args, 128, 128, 128, None) == QAMD_ERR_INVALID and "16-byte aligned" in err(), k_
     assert lib.qutlass_amd_to_blocked(dummy, 0, 4, dummy, None) == QAMD_ERR_INVALID
     assert lib.qutlass_amd_set_option(b"no_such_option", 1) == -1
     # the PRODUCT library has no kernel-selecting state: these keys exist only in the lab build (libqutlass_amd_bench.so)
