@@ -106,31 +106,45 @@ def build_bench_lib(force: bool = False, verbose: bool = False) -> str:
     return BENCH_OUT
 
 
-def build_extension(force: bool = False, verbose: bool = False) -> str:
+def build_extension(force: bool = False, verbose: bool = False, minimal: bool = False, out: str | None = None) -> str:
+    """minimal: the reference's QUTLASS_MINIMAL_BUILD (bindings.cpp:254, :428, :508, :537) -- an op library with the inference ops only (no clip-mask quantizer, no
+    QAT-backward data prep, no Python module entry: load it with torch.ops.load_library, or point QUTLASS_AMD_OP_LIBRARY at it).  Written to `out`
+    (default qutlass/_CUDA_minimal.so), never over the full library."""
+    if minimal:
+        return _build_extension_to(out or os.path.join(os.path.dirname(EXT_OUT), "_CUDA_minimal.so"), ["-DQUTLASS_MINIMAL_BUILD"], verbose)
     if force or _stale(EXT_OUT, [EXT_SRC, _header(), OUT]):
-        import sysconfig
-
-        import torch
-
-        tdir = os.path.dirname(torch.__file__)
-        inc, lib = os.path.join(tdir, "include"), os.path.join(tdir, "lib")
-        # Py_LIMITED_API: the module only needs PyModule_Create (abi3); the ops themselves use the LibTorch stable ABI
-        cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden", "-DUSE_ROCM", "-DTORCH_TARGET_VERSION=0x020a000000000000",
-               "-DPy_LIMITED_API=0x03090000", EXT_SRC, "-I" + inc, "-I" + sysconfig.get_paths()["include"], "-o", EXT_OUT,
-               "-L" + lib, "-ltorch", "-ltorch_cpu", "-lc10", "-ltorch_hip",
-               "-L" + _HERE, "-lqutlass_amd", "-Wl,-rpath,$ORIGIN/../qutlass_amd", "-Wl,-rpath," + lib]
-        if verbose:
-            print(" ".join(cmd))
-        subprocess.check_call(cmd)
+        _build_extension_to(EXT_OUT, [], verbose)
         stale = os.path.join(_HERE, "_C.so")   # the round-1 name of the extension
         if os.path.exists(stale):
             os.remove(stale)
     return EXT_OUT
 
 
+def _build_extension_to(ext_out: str, defines: list, verbose: bool) -> str:
+    import sysconfig
+
+    import torch
+
+    tdir = os.path.dirname(torch.__file__)
+    inc, lib = os.path.join(tdir, "include"), os.path.join(tdir, "lib")
+    # Py_LIMITED_API: the module only needs PyModule_Create (abi3); the ops themselves use the LibTorch stable ABI
+    rpaths = ["-Wl,-rpath,$ORIGIN/../qutlass_amd", "-Wl,-rpath," + lib]
+    if os.path.dirname(os.path.abspath(ext_out)) != os.path.dirname(EXT_OUT):   # a copy outside the tree finds the kernel library by its absolute path
+        rpaths.insert(0, "-Wl,-rpath," + _HERE)
+    cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden", "-DUSE_ROCM", "-DTORCH_TARGET_VERSION=0x020a000000000000",
+           "-DPy_LIMITED_API=0x03090000", EXT_SRC, "-I" + inc, "-I" + sysconfig.get_paths()["include"], "-o", ext_out,
+           "-L" + lib, "-ltorch", "-ltorch_cpu", "-lc10", "-ltorch_hip", "-L" + _HERE, "-lqutlass_amd"] + rpaths + defines
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return ext_out
+
+
 def build(force: bool = False, verbose: bool = False) -> str:
     build_kernels(force, verbose)
     build_extension(force, verbose)
+    if os.environ.get("QUTLASS_MINIMAL_BUILD"):   # in addition, never instead: the trimmed op library next to the full one
+        build_extension(verbose=verbose, minimal=True)
     return OUT
 
 

@@ -412,13 +412,15 @@ STABLE_TORCH_LIBRARY_FRAGMENT(_qutlass_C, m) {
   m.def("matmul_mxf8_bf16_nn(Tensor A, Tensor B, Tensor A_sf, Tensor B_sf, Tensor alpha) -> Tensor");
   m.def("fusedQuantizeMxQuest(Tensor A, Tensor R, Tensor OUT, Tensor OUT_sf) -> (Tensor, Tensor)");
   m.def("fusedQuantizeMxAbsMax(Tensor A, Tensor R, Tensor OUT, Tensor OUT_sf) -> (Tensor, Tensor)");
-  m.def("fusedQuantizeMxQuestWithMask(Tensor A, Tensor R, Tensor OUT, Tensor OUT_sf, Tensor OUT_mask) -> (Tensor, Tensor, Tensor)");
   m.def("fusedQuantizeNvQuest(Tensor A, Tensor R, Tensor OUT, Tensor OUT_sf, Tensor global_scale) -> (Tensor, Tensor)");
   m.def("fusedQuantizeNvAbsMax(Tensor A, Tensor R, Tensor OUT, Tensor OUT_sf, Tensor global_scale) -> (Tensor, Tensor)");
+#ifndef QUTLASS_MINIMAL_BUILD   // the reference's trimmed build (bindings.cpp:254, :428, :508): inference ops only -- no clip-mask quantizer, no QAT-backward data prep
+  m.def("fusedQuantizeMxQuestWithMask(Tensor A, Tensor R, Tensor OUT, Tensor OUT_sf, Tensor OUT_mask) -> (Tensor, Tensor, Tensor)");
   m.def("backward_t_bf16(Tensor x, Tensor h, Tensor xh_e2m1, Tensor xh_e8m0) -> ()");
   m.def("backward_qt_bf16(Tensor x_e2m1, Tensor x_e8m0, Tensor h, Tensor alpha, Tensor xh_e2m1, Tensor xh_e8m0) -> ()");
   m.def("backward_bf16_square_double_mxfp8(Tensor x_bf16, Tensor x_fp8, Tensor row_scales, Tensor column_scales) -> ()");
   m.def("mxfp4_transpose_mxfp8(Tensor x_fp4, Tensor scales, Tensor x_fp8, Tensor shared_exps) -> ()");
+#endif
 }
 
 STABLE_TORCH_LIBRARY_FRAGMENT(qutlass_amd, m) {
@@ -437,13 +439,15 @@ STABLE_TORCH_LIBRARY_IMPL(_qutlass_C, CUDA, m) {
   m.impl("matmul_mxf8_bf16_nn", TORCH_BOX(&matmul_mxf8_bf16_nn));
   m.impl("fusedQuantizeMxQuest", TORCH_BOX(&fusedQuantizeMxQuest));
   m.impl("fusedQuantizeMxAbsMax", TORCH_BOX(&fusedQuantizeMxAbsMax));
-  m.impl("fusedQuantizeMxQuestWithMask", TORCH_BOX(&fusedQuantizeMxQuestWithMask));
   m.impl("fusedQuantizeNvQuest", TORCH_BOX(&fusedQuantizeNvQuest));
   m.impl("fusedQuantizeNvAbsMax", TORCH_BOX(&fusedQuantizeNvAbsMax));
+#ifndef QUTLASS_MINIMAL_BUILD
+  m.impl("fusedQuantizeMxQuestWithMask", TORCH_BOX(&fusedQuantizeMxQuestWithMask));
   m.impl("backward_t_bf16", TORCH_BOX(&backward_t_bf16));
   m.impl("backward_qt_bf16", TORCH_BOX(&backward_qt_bf16));
   m.impl("backward_bf16_square_double_mxfp8", TORCH_BOX(&backward_bf16_square_double_mxfp8));
   m.impl("mxfp4_transpose_mxfp8", TORCH_BOX(&mxfp4_transpose_mxfp8));
+#endif
 }
 STABLE_TORCH_LIBRARY_IMPL(qutlass_amd, CUDA, m) {
   m.impl("to_blocked", TORCH_BOX(&to_blocked));
@@ -454,7 +458,10 @@ STABLE_TORCH_LIBRARY_IMPL(qutlass_amd, CUDA, m) {
 
 // `import qutlass._CUDA` (reference: include/registration.h REGISTER_EXTENSION(_CUDA), bindings.cpp:537-540): an empty module
 // whose only purpose is that loading it runs the registrations above.
+// (QUTLASS_MINIMAL_BUILD drops it with the reference, bindings.cpp:537-540: such a library is loaded with torch.ops.load_library, not imported.)
+#ifndef QUTLASS_MINIMAL_BUILD
 extern "C" __attribute__((visibility("default"))) PyObject* PyInit__CUDA(void) {
   static struct PyModuleDef module = {PyModuleDef_HEAD_INIT, "_CUDA", nullptr, 0, nullptr};
   return PyModule_Create(&module);
 }
+#endif

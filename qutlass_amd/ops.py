@@ -16,7 +16,8 @@ import torch
 from . import _lib
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-EXT_PATH = os.path.join(os.path.dirname(_HERE), "qutlass", "_CUDA.abi3.so")
+# QUTLASS_AMD_OP_LIBRARY: another build of the op library, e.g. the trimmed one (qutlass_amd.build.build_extension(minimal=True), the reference's QUTLASS_MINIMAL_BUILD)
+EXT_PATH = os.environ.get("QUTLASS_AMD_OP_LIBRARY") or os.path.join(os.path.dirname(_HERE), "qutlass", "_CUDA.abi3.so")
 
 _registered = False
 
@@ -48,7 +49,11 @@ def _register_fakes() -> None:
     one too (beyond the reference, whose ops have none).  Outputs mirror csrc/torch_ext.cpp: GEMMs allocate (M, N) bf16; the quantizers return their
     OUT / OUT_sf (/ OUT_mask) arguments -- the fake hands back fresh tensors of the same metadata (a fake kernel must not alias its inputs);
     the backward data-prep ops return nothing (they fill caller-provided tensors, as in bindings.cpp:429-494)."""
-    rf = torch.library.register_fake
+    def rf(qualname):   # (a trimmed op library -- QUTLASS_MINIMAL_BUILD -- does not define the training-only ops: nothing to register for them)
+        ns, op = qualname.split("::")
+        if hasattr(getattr(torch.ops, ns), op):
+            return torch.library.register_fake(qualname)
+        return lambda fn: fn
 
     def gemm_tn(A, B, A_sf, B_sf, alpha):
         return A.new_empty((A.size(0), B.size(0)), dtype=torch.bfloat16)
