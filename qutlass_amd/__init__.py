@@ -21,12 +21,14 @@ import torch
 from . import _lib, ops
 from .utils import ceil_div, get_padded_shape_mx, get_padded_shape_nv, pad_to_block, to_blocked  # noqa: F401
 
-__version__ = "0.1.0"
+__version__ = "0.2.0"
 
 _lib.load()                 # fail loudly at import time if the HIP library is missing
 ops.register_torch_ops()    # torch.ops._qutlass_C.<op>  (reference: bindings.cpp:498-535)
 
 qutlass_CUDA = torch.ops._qutlass_C
+_ops_amd = torch.ops.qutlass_amd   # extensions + the mutation-declaring twins of the reference's output-filling ops
+_METHOD_CODE = {"quest": 0, "abs_max": 1}
 
 _FLASHINFER_MSG = (
     "flashinfer backend requested but not installed. flashinfer/cuDNN is an NVIDIA-only backend and is "
@@ -87,16 +89,21 @@ def fusedQuantizeMx(a: torch.Tensor, b: torch.Tensor, *, method: Literal["quest"
     xh_e2m1 = torch.empty(*a.shape[:-1], a.size(-1) // 2, dtype=torch.uint8, device=a.device)
     xh_e8m0 = torch.empty(padded_rows, padded_cols, dtype=torch.float8_e8m0fnu, device=a.device)
 
+    # (the op calls go through the mutation-declaring twins of `_qutlass_C.fusedQuantizeMx*` -- same kernels, same checks; see ops.py / torch_ext.cpp:
+    #  the reference's schemas hide the writes from torch.compile)
     if method == "quest":
         if return_mask:
             clip_mask = torch.empty(*a.shape[:-1], a.size(-1) // 8, dtype=torch.uint8, device=a.device)
-            return qutlass_CUDA.fusedQuantizeMxQuestWithMask(a, b, xh_e2m1, xh_e8m0, clip_mask)
+            _ops_amd.fusedQuantizeMxMask_(a, b, xh_e2m1, xh_e8m0, clip_mask)
+            return xh_e2m1, xh_e8m0, clip_mask
         else:
-            return qutlass_CUDA.fusedQuantizeMxQuest(a, b, xh_e2m1, xh_e8m0)
+            _ops_amd.fusedQuantizeMx_(a, b, xh_e2m1, xh_e8m0, 0)
+            return xh_e2m1, xh_e8m0
     elif method == "abs_max":
         if return_mask:
             raise ValueError("return_mask is only supported for method 'quest'")
-        return qutlass_CUDA.fusedQuantizeMxAbsMax(a, b, xh_e2m1, xh_e8m0)
+        _ops_amd.fusedQuantizeMx_(a, b, xh_e2m1, xh_e8m0, 1)
+        return xh_e2m1, xh_e8m0
     else:
         raise ValueError(f"invalid method {method!r}, must be 'quest' or 'abs_max'")
 
@@ -108,15 +115,10 @@ def fusedQuantizeNv(a: torch.Tensor, b: torch.Tensor, global_scale: torch.Tensor
     xh_e2m1 = torch.empty(*a.shape[:-1], a.size(-1) // 2, dtype=torch.uint8, device=a.device)
     xh_e4m3 = torch.empty(padded_rows, padded_cols, dtype=torch.float8_e4m3fn, device=a.device)
 
-    if method == "quest":
-        return qutlass_CUDA.fusedQuantizeNvQuest(a, b, xh_e2m1, xh_e4m3, global_scale)
-    elif method == "abs_max":
-        return qutlass_CUDA.fusedQuantizeNvAbsMax(a, b, xh_e2m1, xh_e4m3, global_scale)
-    else:
+    if method not in _METHOD_CODE:
         raise ValueError(f"invalid method {method!r}, must be 'quest' or 'abs_max'")
-
-
-_METHOD_CODE = {"quest": 0, "abs_max": 1}
+    _ops_amd.fusedQuantizeNv_(a, b, xh_e2m1, xh_e4m3, global_scale, _METHOD_CODE[method])
+    return xh_e2m1, xh_e4m3
 
 
 def fusedQuantizeMxBlocked(a: torch.Tensor, b: torch.Tensor, *, method: Literal["quest", "abs_max"] = "quest") -> tuple[torch.Tensor, torch.Tensor]:
@@ -128,7 +130,8 @@ def fusedQuantizeMxBlocked(a: torch.Tensor, b: torch.Tensor, *, method: Literal[
     padded_rows, padded_cols = get_padded_shape_mx(a)
     xh_e2m1 = torch.empty(*a.shape[:-1], a.size(-1) // 2, dtype=torch.uint8, device=a.device)
     xh_e8m0 = torch.empty(padded_rows * padded_cols, dtype=torch.float8_e8m0fnu, device=a.device)
-    return torch.ops.qutlass_amd.fusedQuantizeMxBlocked(a, b, xh_e2m1, xh_e8m0, _METHOD_CODE[method])
+    _ops_amd.fusedQuantizeMxBlocked(a, b, xh_e2m1, xh_e8m0, _METHOD_CODE[method])
+    return xh_e2m1, xh_e8m0
 
 
 def fusedQuantizeNvBlocked(a: torch.Tensor, b: torch.Tensor, global_scale: torch.Tensor, *,
@@ -139,7 +142,8 @@ def fusedQuantizeNvBlocked(a: torch.Tensor, b: torch.Tensor, global_scale: torch
     padded_rows, padded_cols = get_padded_shape_nv(a)
     xh_e2m1 = torch.empty(*a.shape[:-1], a.size(-1) // 2, dtype=torch.uint8, device=a.device)
     xh_e4m3 = torch.empty(padded_rows * padded_cols, dtype=torch.float8_e4m3fn, device=a.device)
-    return torch.ops.qutlass_amd.fusedQuantizeNvBlocked(a, b, xh_e2m1, xh_e4m3, global_scale, _METHOD_CODE[method])
+    _ops_amd.fusedQuantizeNvBlocked(a, b, xh_e2m1, xh_e4m3, global_scale, _METHOD_CODE[method])
+    return xh_e2m1, xh_e4m3
 
 
 def _decode_single_launch_wins(m: int, n: int, k: int, rot: int, device: torch.device | None = None) -> bool:
@@ -187,7 +191,7 @@ def backward_t_bf16(x: torch.Tensor, h: torch.Tensor, xh_e2m1: torch.Tensor = No
     assert x.dtype == h.dtype == torch.bfloat16
     assert xh_e2m1.dtype == torch.float4_e2m1fn_x2 and xh_e8m0.dtype == torch.float8_e8m0fnu
     assert x.is_contiguous() and h.is_contiguous() and xh_e2m1.is_contiguous() and xh_e8m0.is_contiguous()
-    qutlass_CUDA.backward_t_bf16(x, h, xh_e2m1, xh_e8m0)
+    _ops_amd.backward_t_bf16_(x, h, xh_e2m1, xh_e8m0)
     return xh_e2m1, xh_e8m0
 
 
@@ -202,7 +206,7 @@ def backward_qt_bf16(x_e2m1: torch.Tensor, x_e8m0: torch.Tensor, h: torch.Tensor
                               dtype=torch.float8_e8m0fnu, device=h.device)
     assert (x_e2m1.is_contiguous() and x_e8m0.is_contiguous() and h.is_contiguous()
             and xh_e2m1.is_contiguous() and xh_e8m0.is_contiguous())
-    qutlass_CUDA.backward_qt_bf16(x_e2m1, x_e8m0, h, alpha, xh_e2m1, xh_e8m0)
+    _ops_amd.backward_qt_bf16_(x_e2m1, x_e8m0, h, alpha, xh_e2m1, xh_e8m0)
     return xh_e2m1, xh_e8m0
 
 
@@ -214,7 +218,7 @@ def backward_bf16_square_double_mxfp8(x_bf16: torch.Tensor) -> tuple[torch.Tenso
     x_fp8 = torch.empty(m_pad, n, device=x_bf16.device, dtype=torch.float8_e4m3fn)
     row_scales = torch.empty(m_pad, n // 32, device=x_bf16.device, dtype=torch.float8_e8m0fnu)
     column_scales = torch.empty(n, m_pad // 32, device=x_bf16.device, dtype=torch.float8_e8m0fnu)
-    qutlass_CUDA.backward_bf16_square_double_mxfp8(x_bf16, x_fp8, row_scales, column_scales)
+    _ops_amd.backward_bf16_square_double_mxfp8_(x_bf16, x_fp8, row_scales, column_scales)
     return x_fp8, row_scales, column_scales
 
 
@@ -226,7 +230,7 @@ def mxfp4_transpose_mxfp8(x_fp4: torch.Tensor, scales: torch.Tensor) -> tuple[to
     m_pad = ceil_div(m, 256) * 256
     x_fp8 = torch.empty(x_fp4.shape[1] * 2, m_pad, device=x_fp4.device, dtype=torch.float8_e4m3fn)
     shared_exps = torch.empty(x_fp4.shape[1] * 2, m_pad // 32, device=x_fp4.device, dtype=torch.float8_e8m0fnu)
-    qutlass_CUDA.mxfp4_transpose_mxfp8(x_fp4, scales, x_fp8, shared_exps)
+    _ops_amd.mxfp4_transpose_mxfp8_(x_fp4, scales, x_fp8, shared_exps)
     return x_fp8, shared_exps
 
 

@@ -1461,12 +1461,12 @@ int qutlass_amd_backward_qt_bf16(const void* x_e2m1, const void* x_e8m0, const v
     if (M % 128) return fail(QAMD_ERR_INVALID, "%s: the ring kernel needs M %% 128 == 0", name);
     const int ng = (which == 6 || which == 7) ? 8 : 4;
     const int64_t ur = B * cdiv(M, 256) * cdiv(N / 32, ng);
-    return launch_bwd_quant(p, true, which, opt_hw_fp4(), (int)std::min<int64_t>(ur, cu * (ng == 8 ? 2 : 3) / 8 * 8), (hipStream_t)stream);
+    return launch_bwd_quant(p, true, which, opt_hw_fp4(), (int)std::min<int64_t>(ur, std::max<int64_t>(8, cu * (ng == 8 ? 2 : 3) / 8 * 8)), (hipStream_t)stream);   // (>= 8: a part with fewer than 3 visible CUs must not get an empty grid)
   }
   if (which == 4) {   // [r5] panel kernel: units of 8 groups x 256 m, two workgroups per CU (persistent grids step by a multiple of the 8 XCDs)
     if (M % 128) return fail(QAMD_ERR_INVALID, "%s: the panel kernel needs M %% 128 == 0", name);
     const int64_t up = B * cdiv(M, 256) * cdiv(N / 32, 8);
-    return launch_bwd_quant(p, true, 4, opt_hw_fp4(), (int)std::min<int64_t>(up, cu * 2 / 8 * 8), (hipStream_t)stream);
+    return launch_bwd_quant(p, true, 4, opt_hw_fp4(), (int)std::min<int64_t>(up, std::max<int64_t>(8, cu * 2 / 8 * 8)), (hipStream_t)stream);
   }
   return launch_bwd_quant(p, true, which, opt_hw_fp4(), which == 1 ? grid : gridw, (hipStream_t)stream);
 }

@@ -133,6 +133,32 @@ __device__ __forceinline__ uint32_t xhalf_or(uint32_t v) {
   return r[0] | r[1];
 }
 
+// [r6] Quest sums of one group in the REFERENCE's order: one thread adds elements 0, 1, 2, ... in turn (epilogue_quant.h:521-528 MX, :1621-1628 NV; nvcc contracts
+// `c_sum2 += c_val * c_val` into an fma).  The kernel's own order (a lane's values, then the partner half) gives sums that differ from those in the last bits -- which
+// decides the SIGN of the variance of a (nearly) constant group, i.e. whether the reference takes its `var >= 0` arm (MX: scale 1.0 otherwise) or stores a NaN scale
+// byte (NV).  Such groups (variance below 2^-10 of the mean square, NaN included; never on real activations) are re-summed here; NQ quads per lane, a lane holds
+// elements 8 q + 4 half + e of the group (v_permlane32_swap of a value with itself leaves {half 0's, half 1's} in both lanes).
+template <int NQ, typename V>
+__device__ __forceinline__ void quest_sums_in_reference_order(const V& a, int a0, float& s1, float& s2) {
+  s1 = 0.f;
+  s2 = 0.f;
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) {
+    float lo[4], hi[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const uint32_t b = __float_as_uint(a[a0 + 4 * q + e]);
+      auto r = __builtin_amdgcn_permlane32_swap(b, b, false, false);
+      lo[e] = __uint_as_float(r[0]);
+      hi[e] = __uint_as_float(r[1]);
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { s1 += lo[e]; s2 = fmaf(lo[e], lo[e], s2); }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { s1 += hi[e]; s2 = fmaf(hi[e], hi[e], s2); }
+  }
+}
+
 // OCP e4m3fn encode of a non-negative finite fp32, RNE, saturating at 448 (oracle: orc_e4m3_encode).
 __device__ __forceinline__ uint32_t e4m3_encode_pos(float a) {
   if (!(a < 448.0f)) return (a != a) ? 0x7Fu : 0x7Eu;
@@ -372,8 +398,13 @@ __global__ __launch_bounds__(256) void fused_quantize_kernel(const QuantParams p
           }
           s1 = xhalf_add(s1);
           s2 = xhalf_add(s2);
-          const float mean = s1 * 0.03125f;
-          const float var = fmaf(-mean, mean, s2 * 0.03125f);
+          float mean = s1 * 0.03125f;
+          float var = fmaf(-mean, mean, s2 * 0.03125f);
+          if (__builtin_expect(!(var > s2 * (0.03125f * 0.0009765625f)), 0)) {   // [r6] sign of the variance at stake: the reference's summation order
+            quest_sums_in_reference_order<4>(acc, 0, s1, s2);
+            mean = s1 * 0.03125f;
+            var = fmaf(-mean, mean, s2 * 0.03125f);
+          }
           scale = 1.0f;
           if (var >= 0.f) scale = (float)((double)sqrtf(var) * (2.92247856 / 6.) + 1e-8);
           nan_risk = !(var >= 0.f);
@@ -473,13 +504,17 @@ __global__ __launch_bounds__(256) void fused_quantize_kernel(const QuantParams p
             }
             s1 = xhalf_add(s1);
             s2 = xhalf_add(s2);
-            const float mean = s1 * 0.0625f;
-            // var < 0 can only come from fp32 rounding on a (nearly) constant group; the reference takes sqrt of it and
-            // carries a NaN scale (epilogue_quant.h:1631-1680 has no guard).  Clamped here, as the MX path does: the group
-            // quantises to scale 0 / zero codes instead of a NaN scale byte.  (Deviation noted in DESIGN.md section 4.)
-            const float vraw = fmaf(-mean, mean, s2 * 0.0625f);
-            const float var = vraw < 0.f ? 0.f : vraw;   // ([r5] not fmaxf: a NaN variance -- NaN / inf activations -- stays NaN and becomes the scale byte 0x7f, as in the reference)
-            nan_risk = !(vraw >= 0.f);
+            float mean = s1 * 0.0625f;
+            // var < 0 can only come from fp32 rounding on a (nearly) constant group.  [r6] The reference takes sqrt of it and stores the NaN it
+            // gets as the scale byte 0x7f (epilogue_quant.h:1631-1640: no guard; `scale_q > 0` is then false, the multiplier 0 and every code +-0):
+            // so does this kernel -- rounds 1-5 clamped the variance at 0.  A NaN variance (NaN / inf activations) takes the same path.
+            float var = fmaf(-mean, mean, s2 * 0.0625f);
+            if (__builtin_expect(!(var > s2 * (0.0625f * 0.0009765625f)), 0)) {   // whether it is negative depends on the order of the additions: the reference's
+              quest_sums_in_reference_order<2>(v8, 0, s1, s2);
+              mean = s1 * 0.0625f;
+              var = fmaf(-mean, mean, s2 * 0.0625f);
+            }
+            nan_risk = !(var >= 0.f);
             const float sc = (float)((double)sqrtf(var) * (2.92247856 / 6.) + 1e-8);
             sfb = e4m3_encode_pos(sc);
             const float sq = e4m3_decode_pos(sfb);

@@ -218,12 +218,14 @@ __global__ __launch_bounds__(512) void bwd_quant_t_kernel(const BwdTParams p) {
       const int r = lane >> 1, c = (lane & 1) * 32;
       const uint32_t e = ld_e;
       // [r5] the reference builds the scale as the bf16 with bits e << 7 (quartet_bwd_sm120.cu:369-371): byte 0 is 0.0 (NOT 2^-127: the operand is zero whatever
-      // its code), byte 255 is +inf (operand +-inf, 0 x inf = NaN) -- the same two special values come out of e << 23 in fp32
+      // its code), byte 255 is +inf (operand +-inf, 0 x inf = NaN).  [r6] v_cvt_scalef32_pk_bf16_fp4 reads only the EXPONENT of its scale operand
+      // (tests/native/cvt_mant_probe.hip), so 0.0f acts as 2^-127 there: for byte 0 the magnitudes of the code word are cleared instead (sign nibbles
+      // kept: code x 0.0 = +-0.0), which makes a tile whose rows all carry scale byte 0 come out with amax 0 as in the reference
       const float sc = e == 255u ? 1.0f : __uint_as_float(e << 23);
       v4i* d = (v4i*)(ts + r * LROW + c * 2);
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const uint32_t w = (uint32_t)ld[0][q];
+        const uint32_t w = e ? (uint32_t)ld[0][q] : ((uint32_t)ld[0][q] & 0x88888888u);   // [r6] scale byte 0: +-0 (see sc above)
         v4i o;
         o[0] = __builtin_bit_cast(int, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp4(w, sc, 0));
         o[1] = __builtin_bit_cast(int, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp4(w, sc, 1));
@@ -411,7 +413,7 @@ __global__ __launch_bounds__(256) void bwd_quant_tw_kernel(const BwdTParams p) {
       v4i* d = (v4i*)(ts + r * LROW + c * 2);
 #pragma unroll
       for (int qq = 0; qq < 4; ++qq) {
-        const uint32_t w = (uint32_t)ld[s][0][qq];
+        const uint32_t w = e ? (uint32_t)ld[s][0][qq] : ((uint32_t)ld[s][0][qq] & 0x88888888u);
         v4i ov;
         ov[0] = __builtin_bit_cast(int, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp4(w, sc, 0));
         ov[1] = __builtin_bit_cast(int, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp4(w, sc, 1));
@@ -652,7 +654,7 @@ __global__ __launch_bounds__(256) void bwd_qt_ring_kernel(const BwdTParams p) {
     v4i* d = (v4i*)(ts + r * LROW + c * 2);
 #pragma unroll
     for (int qq = 0; qq < 4; ++qq) {
-      const uint32_t w = (uint32_t)ld[qq];
+      const uint32_t w = e ? (uint32_t)ld[qq] : ((uint32_t)ld[qq] & 0x88888888u);
       v4i ov;
       ov[0] = __builtin_bit_cast(int, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp4(w, sc, 0));
       ov[1] = __builtin_bit_cast(int, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp4(w, sc, 1));

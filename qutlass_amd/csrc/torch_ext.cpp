@@ -259,9 +259,27 @@ std::tuple<Tensor, Tensor> fusedQuantizeNvAbsMax(const Tensor& A, const Tensor& 
   return {OUT, OUT_sf};
 }
 
+// ---- in-place twins of the reference's output-filling ops, schemas with the mutation declared (`Tensor(a!)`) ------------------------
+// The reference's schemas (bindings.cpp:504-513, kept verbatim above) declare neither that the quantizers write OUT / OUT_sf and return
+// aliases of them, nor that the QAT-backward ops fill their last arguments.  Eager dispatch does not care; AOTAutograd / inductor do: an
+// undeclared write is dead code to them (the call is removed, or OUT's storage reused while the returned alias is live).  The Python
+// wrappers (qutlass_amd/__init__.py) therefore call these twins -- same checks, same C-ABI call -- and hand the caller the tensors they
+// allocated; the `_qutlass_C` ops stay for callers that use them directly (eager), WITHOUT fake kernels, so tracing them fails loudly.
+void fusedQuantizeMx_(const Tensor& A, const Tensor& R, Tensor OUT, Tensor OUT_sf, int64_t method) {
+  STD_TORCH_CHECK(method == QAMD_METHOD_QUEST || method == QAMD_METHOD_ABSMAX, "method must be 0 (quest) or 1 (abs_max)");
+  quantize_mx(method == QAMD_METHOD_QUEST ? "fusedQuantizeMxQuest" : "fusedQuantizeMxAbsMax", A, R, OUT, OUT_sf, nullptr, (int)method);
+}
+void fusedQuantizeMxMask_(const Tensor& A, const Tensor& R, Tensor OUT, Tensor OUT_sf, Tensor OUT_mask) {
+  quantize_mx("fusedQuantizeMxQuestWithMask", A, R, OUT, OUT_sf, &OUT_mask, QAMD_METHOD_QUEST);
+}
+void fusedQuantizeNv_(const Tensor& A, const Tensor& R, Tensor OUT, Tensor OUT_sf, const Tensor& global_scale, int64_t method) {
+  STD_TORCH_CHECK(method == QAMD_METHOD_QUEST || method == QAMD_METHOD_ABSMAX, "method must be 0 (quest) or 1 (abs_max)");
+  quantize_nv(method == QAMD_METHOD_QUEST ? "fusedQuantizeNvQuest" : "fusedQuantizeNvAbsMax", A, R, OUT, OUT_sf, global_scale, (int)method);
+}
+
 // ---- EXTENSION: quantizers that emit GEMM-ready (to_blocked-layout) scales: one launch instead of quantize + to_blocked ----------
 // A is (.., K); OUT_sf must hold the padded blocked matrix of the (numel / K, K / gs) scales.  method: 0 quest, 1 abs_max.
-std::tuple<Tensor, Tensor> fusedQuantizeMxBlocked(const Tensor& A, const Tensor& R, Tensor OUT, Tensor OUT_sf, int64_t method) {
+void fusedQuantizeMxBlocked(const Tensor& A, const Tensor& R, Tensor OUT, Tensor OUT_sf, int64_t method) {
   const char* op = "fusedQuantizeMxBlocked";
   require_contiguous(op, {{A, "A"}, {R, "B"}, {OUT, "OUT"}, {OUT_sf, "OUT_sf"}});
   require_gpu(op, {{A, "A"}, {R, "B"}, {OUT, "OUT"}, {OUT_sf, "OUT_sf"}});
@@ -277,10 +295,9 @@ std::tuple<Tensor, Tensor> fusedQuantizeMxBlocked(const Tensor& A, const Tensor&
   const torch::stable::accelerator::DeviceGuard guard(A.get_device_index());
   check_rc(qutlass_amd_fused_quantize_mx_blocked(A.data_ptr(), R.data_ptr(), (int)rot, rows, k, (int)method, OUT.data_ptr(), OUT_sf.data_ptr(), nullptr,
                                                  current_stream(A)));
-  return {OUT, OUT_sf};
 }
 
-std::tuple<Tensor, Tensor> fusedQuantizeNvBlocked(const Tensor& A, const Tensor& R, Tensor OUT, Tensor OUT_sf, const Tensor& gscale, int64_t method) {
+void fusedQuantizeNvBlocked(const Tensor& A, const Tensor& R, Tensor OUT, Tensor OUT_sf, const Tensor& gscale, int64_t method) {
   const char* op = "fusedQuantizeNvBlocked";
   require_contiguous(op, {{A, "A"}, {R, "B"}, {OUT, "OUT"}, {OUT_sf, "OUT_sf"}});
   require_gpu(op, {{A, "A"}, {R, "B"}, {OUT, "OUT"}, {OUT_sf, "OUT_sf"}, {gscale, "global_scale"}});
@@ -298,7 +315,6 @@ std::tuple<Tensor, Tensor> fusedQuantizeNvBlocked(const Tensor& A, const Tensor&
   const torch::stable::accelerator::DeviceGuard guard(A.get_device_index());
   check_rc(qutlass_amd_fused_quantize_nv_blocked(A.data_ptr(), R.data_ptr(), (int)rot, rows, k, (int)method, static_cast<const float*>(gscale.data_ptr()),
                                                  OUT.data_ptr(), OUT_sf.data_ptr(), current_stream(A)));
-  return {OUT, OUT_sf};
 }
 
 // ---- EXTENSION: rotate + quantize + MXFP4 GEMM in one launch for decode batches (M <= 32) ---------------------------------------
@@ -425,8 +441,18 @@ STABLE_TORCH_LIBRARY_FRAGMENT(_qutlass_C, m) {
 
 STABLE_TORCH_LIBRARY_FRAGMENT(qutlass_amd, m) {
   m.def("to_blocked(Tensor input_matrix) -> Tensor");
-  m.def("fusedQuantizeMxBlocked(Tensor A, Tensor R, Tensor OUT, Tensor OUT_sf, int method) -> (Tensor, Tensor)");
-  m.def("fusedQuantizeNvBlocked(Tensor A, Tensor R, Tensor OUT, Tensor OUT_sf, Tensor global_scale, int method) -> (Tensor, Tensor)");
+  // every op that fills caller tensors says so: `Tensor(a!)`, no aliasing return (see the note above fusedQuantizeMx_)
+  m.def("fusedQuantizeMxBlocked(Tensor A, Tensor R, Tensor(a!) OUT, Tensor(b!) OUT_sf, int method) -> ()");
+  m.def("fusedQuantizeNvBlocked(Tensor A, Tensor R, Tensor(a!) OUT, Tensor(b!) OUT_sf, Tensor global_scale, int method) -> ()");
+  m.def("fusedQuantizeMx_(Tensor A, Tensor R, Tensor(a!) OUT, Tensor(b!) OUT_sf, int method) -> ()");
+  m.def("fusedQuantizeNv_(Tensor A, Tensor R, Tensor(a!) OUT, Tensor(b!) OUT_sf, Tensor global_scale, int method) -> ()");
+#ifndef QUTLASS_MINIMAL_BUILD
+  m.def("fusedQuantizeMxMask_(Tensor A, Tensor R, Tensor(a!) OUT, Tensor(b!) OUT_sf, Tensor(c!) OUT_mask) -> ()");
+  m.def("backward_t_bf16_(Tensor x, Tensor h, Tensor(a!) xh_e2m1, Tensor(b!) xh_e8m0) -> ()");
+  m.def("backward_qt_bf16_(Tensor x_e2m1, Tensor x_e8m0, Tensor h, Tensor alpha, Tensor(a!) xh_e2m1, Tensor(b!) xh_e8m0) -> ()");
+  m.def("backward_bf16_square_double_mxfp8_(Tensor x_bf16, Tensor(a!) x_fp8, Tensor(b!) row_scales, Tensor(c!) column_scales) -> ()");
+  m.def("mxfp4_transpose_mxfp8_(Tensor x_fp4, Tensor scales, Tensor(a!) x_fp8, Tensor(b!) shared_exps) -> ()");
+#endif
   m.def("fusedQuantizeMatmulMxf4(Tensor X, Tensor R, Tensor B, Tensor B_sf, Tensor alpha, int method) -> Tensor");
 }
 
@@ -453,6 +479,15 @@ STABLE_TORCH_LIBRARY_IMPL(qutlass_amd, CUDA, m) {
   m.impl("to_blocked", TORCH_BOX(&to_blocked));
   m.impl("fusedQuantizeMxBlocked", TORCH_BOX(&fusedQuantizeMxBlocked));
   m.impl("fusedQuantizeNvBlocked", TORCH_BOX(&fusedQuantizeNvBlocked));
+  m.impl("fusedQuantizeMx_", TORCH_BOX(&fusedQuantizeMx_));
+  m.impl("fusedQuantizeNv_", TORCH_BOX(&fusedQuantizeNv_));
+#ifndef QUTLASS_MINIMAL_BUILD
+  m.impl("fusedQuantizeMxMask_", TORCH_BOX(&fusedQuantizeMxMask_));
+  m.impl("backward_t_bf16_", TORCH_BOX(&backward_t_bf16));
+  m.impl("backward_qt_bf16_", TORCH_BOX(&backward_qt_bf16));
+  m.impl("backward_bf16_square_double_mxfp8_", TORCH_BOX(&backward_bf16_square_double_mxfp8));
+  m.impl("mxfp4_transpose_mxfp8_", TORCH_BOX(&mxfp4_transpose_mxfp8));
+#endif
   m.impl("fusedQuantizeMatmulMxf4", TORCH_BOX(&fusedQuantizeMatmulMxf4));
 }
 

@@ -38,17 +38,16 @@ def register_torch_ops() -> None:
             "qutlass_amd has no CPU / eager fallback."
         )
     torch.ops.load_library(EXT_PATH)
-    _registered = True
     _register_fakes()
+    _registered = True   # only once the fake kernels are in place: a failed registration is retried (and raises again) on the next call
 
 
 def _register_fakes() -> None:
     """Shape-only ("fake" / meta) kernels for every op of the extension, so that callers can be traced: `torch.compile(fullgraph=True)`, `make_fx`,
     `torch.export` under FakeTensorMode.  The reference's default `to_blocked` is plain torch written to be compiled through
     (qutlass/utils.py:160-193); here it is a custom op, and without a fake kernel a compiled caller graph-breaks or fails.  The 14 `_qutlass_C` ops get
-    one too (beyond the reference, whose ops have none).  Outputs mirror csrc/torch_ext.cpp: GEMMs allocate (M, N) bf16; the quantizers return their
-    OUT / OUT_sf (/ OUT_mask) arguments -- the fake hands back fresh tensors of the same metadata (a fake kernel must not alias its inputs);
-    the backward data-prep ops return nothing (they fill caller-provided tensors, as in bindings.cpp:429-494)."""
+    one where the schema tells the truth (the five GEMMs: they allocate (M, N) bf16); the ops that fill caller tensors are traced through their
+    mutation-declaring twins in the `qutlass_amd` namespace (csrc/torch_ext.cpp), which return nothing."""
     def rf(qualname):   # (a trimmed op library -- QUTLASS_MINIMAL_BUILD -- does not define the training-only ops: nothing to register for them)
         ns, op = qualname.split("::")
         if hasattr(getattr(torch.ops, ns), op):
@@ -65,50 +64,21 @@ def _register_fakes() -> None:
     def _(A, B, A_sf, B_sf, alpha):   # A is (K, M) (bindings.cpp:185-214)
         return A.new_empty((A.size(1), B.size(0)), dtype=torch.bfloat16)
 
-    def quant2(A, R, OUT, OUT_sf):
-        return torch.empty_like(OUT), torch.empty_like(OUT_sf)
-
-    for name in ("fusedQuantizeMxQuest", "fusedQuantizeMxAbsMax"):
-        rf(f"_qutlass_C::{name}")(quant2)
-
-    @rf("_qutlass_C::fusedQuantizeMxQuestWithMask")
-    def _(A, R, OUT, OUT_sf, OUT_mask):
-        return torch.empty_like(OUT), torch.empty_like(OUT_sf), torch.empty_like(OUT_mask)
-
-    def quant_nv(A, R, OUT, OUT_sf, global_scale):
-        return torch.empty_like(OUT), torch.empty_like(OUT_sf)
-
-    for name in ("fusedQuantizeNvQuest", "fusedQuantizeNvAbsMax"):
-        rf(f"_qutlass_C::{name}")(quant_nv)
-
-    @rf("_qutlass_C::backward_t_bf16")
-    def _(x, h, xh_e2m1, xh_e8m0):
+    # The reference's output-filling ops -- the five quantizers and the four QAT-backward data-prep ops of `_qutlass_C` -- get NO fake kernel: their
+    # schemas (bindings.cpp:504-513, kept verbatim) declare neither the writes nor the aliasing returns, so a traced graph would treat the call as
+    # dead code (AOTAutograd drops a `-> ()` op without declared mutation; inductor reuses OUT's storage while the returned alias is live).  Tracing
+    # them fails loudly instead; the Python wrappers call the `qutlass_amd::*_` twins below, whose schemas declare `Tensor(a!)` and return nothing.
+    def fills(*args):
         return None
 
-    @rf("_qutlass_C::backward_qt_bf16")
-    def _(x_e2m1, x_e8m0, h, alpha, xh_e2m1, xh_e8m0):
-        return None
-
-    @rf("_qutlass_C::backward_bf16_square_double_mxfp8")
-    def _(x_bf16, x_fp8, row_scales, column_scales):
-        return None
-
-    @rf("_qutlass_C::mxfp4_transpose_mxfp8")
-    def _(x_fp4, scales, x_fp8, shared_exps):
-        return None
+    for name in ("fusedQuantizeMx_", "fusedQuantizeNv_", "fusedQuantizeMxMask_", "fusedQuantizeMxBlocked", "fusedQuantizeNvBlocked",
+                 "backward_t_bf16_", "backward_qt_bf16_", "backward_bf16_square_double_mxfp8_", "mxfp4_transpose_mxfp8_"):
+        rf(f"qutlass_amd::{name}")(fills)
 
     @rf("qutlass_amd::to_blocked")
     def _(input_matrix):
         rows, cols = input_matrix.shape
         return input_matrix.new_empty(((rows + 127) // 128 * 128) * ((cols + 3) // 4 * 4))
-
-    @rf("qutlass_amd::fusedQuantizeMxBlocked")
-    def _(A, R, OUT, OUT_sf, method):
-        return torch.empty_like(OUT), torch.empty_like(OUT_sf)
-
-    @rf("qutlass_amd::fusedQuantizeNvBlocked")
-    def _(A, R, OUT, OUT_sf, global_scale, method):
-        return torch.empty_like(OUT), torch.empty_like(OUT_sf)
 
     @rf("qutlass_amd::fusedQuantizeMatmulMxf4")
     def _(X, R, B, B_sf, alpha, method):

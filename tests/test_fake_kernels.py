@@ -16,14 +16,87 @@ def _targets(gm):
     return [str(n.target) for n in gm.graph.nodes if n.op == "call_function"]
 
 
-def test_every_op_of_the_extension_has_a_fake_kernel():
+FILL_OPS = ("fusedQuantizeMxQuest", "fusedQuantizeMxAbsMax", "fusedQuantizeMxQuestWithMask", "fusedQuantizeNvQuest", "fusedQuantizeNvAbsMax",
+            "backward_t_bf16", "backward_qt_bf16", "backward_bf16_square_double_mxfp8", "mxfp4_transpose_mxfp8")
+TWINS = ("fusedQuantizeMx_", "fusedQuantizeNv_", "fusedQuantizeMxMask_", "fusedQuantizeMxBlocked", "fusedQuantizeNvBlocked",
+         "backward_t_bf16_", "backward_qt_bf16_", "backward_bf16_square_double_mxfp8_", "mxfp4_transpose_mxfp8_")
+
+
+def _fake_of(name):   # (torch.library.register_fake keeps its kernels in this registry; the fake-tensor machinery looks them up there)
+    return torch._library.simple_registry.singleton.find(name).fake_impl.kernel
+
+
+def test_fake_kernels_exist_exactly_where_the_schema_tells_the_truth():
+    """[r6, ADVICE r5] The five GEMMs and every `qutlass_amd` op have a fake kernel.  The reference's nine output-filling `_qutlass_C` ops have NONE: their schemas
+    (bindings.cpp:504-513, verbatim) hide the writes, so a traced graph would drop or mis-schedule the call -- tracing them must fail loudly.  Their twins declare
+    every written argument `Tensor(a!)` and return nothing."""
     q.ops.register_torch_ops()
-    names = [f"_qutlass_C::{n}" for n in ("matmul_mxf4_bf16_tn", "matmul_nvf4_bf16_tn", "matmul_ada_mxf4_bf16_tn", "matmul_mxf8_bf16_tn", "matmul_mxf8_bf16_nn",
-                                          "fusedQuantizeMxQuest", "fusedQuantizeMxAbsMax", "fusedQuantizeMxQuestWithMask", "fusedQuantizeNvQuest", "fusedQuantizeNvAbsMax",
-                                          "backward_t_bf16", "backward_qt_bf16", "backward_bf16_square_double_mxfp8", "mxfp4_transpose_mxfp8")]
-    names += [f"qutlass_amd::{n}" for n in ("to_blocked", "fusedQuantizeMxBlocked", "fusedQuantizeNvBlocked", "fusedQuantizeMatmulMxf4")]
-    for name in names:   # (torch.library.register_fake keeps its kernels in this registry; the fake-tensor machinery looks them up there)
-        assert torch._library.simple_registry.singleton.find(name).fake_impl.kernel is not None, name
+    for n in ("matmul_mxf4_bf16_tn", "matmul_nvf4_bf16_tn", "matmul_ada_mxf4_bf16_tn", "matmul_mxf8_bf16_tn", "matmul_mxf8_bf16_nn"):
+        assert _fake_of(f"_qutlass_C::{n}") is not None, n
+    for n in ("to_blocked", "fusedQuantizeMatmulMxf4") + TWINS:
+        assert _fake_of(f"qutlass_amd::{n}") is not None, n
+    for n in FILL_OPS:
+        assert _fake_of(f"_qutlass_C::{n}") is None, n
+        schema = getattr(torch.ops._qutlass_C, n).default._schema
+        assert not any(a.alias_info is not None and a.alias_info.is_write for a in schema.arguments), n   # the reference's schema, untouched
+    for n in TWINS:
+        schema = getattr(torch.ops.qutlass_amd, n).default._schema
+        written = [a.name for a in schema.arguments if a.alias_info is not None and a.alias_info.is_write]
+        assert len(written) >= 2 and len(schema.returns) == 0, (n, str(schema))
+    with FakeTensorMode():   # and tracing a hidden-write op raises instead of producing a wrong graph
+        x = torch.empty(64, 128, dtype=torch.bfloat16, device=DEV)
+        h = torch.empty(32, 32, dtype=torch.bfloat16, device=DEV)
+        with pytest.raises(Exception):
+            torch.ops._qutlass_C.fusedQuantizeMxAbsMax(x, h, torch.empty(64, 64, dtype=torch.uint8, device=DEV), torch.empty(128, 4, dtype=torch.float8_e8m0fnu, device=DEV))
+
+
+def _aot_graphs(fn, *args):
+    """Forward graphs AOTAutograd hands to a backend (functionalised, dead code eliminated) -- what `aot_eager` / inductor would run."""
+    from torch._dynamo.backends.common import aot_autograd
+    graphs = []
+
+    def capture(gm, example_inputs):
+        graphs.append(gm)
+        return gm.forward
+
+    torch._dynamo.reset()
+    try:   # CPU tensors: tracing never looks at the device, and the run after it has no kernel to call (CUDA key only) -- the graphs exist by then
+        torch.compile(fn, backend=aot_autograd(fw_compiler=capture), fullgraph=True)(*args)
+    except (NotImplementedError, RuntimeError) as e:
+        assert graphs and ("CPU" in str(e) or "backend" in str(e)), e
+    return graphs
+
+
+def test_output_filling_ops_survive_aot_functionalisation():
+    """[r6, ADVICE r5 high x2] After AOTAutograd's functionalisation + dead-code elimination the quantizer / backward calls are still in the graph (as
+    `auto_functionalized` nodes of the mutation-declaring twins) and the values returned to the caller come out of them -- with the round-5 fakes the backward
+    calls were removed (the wrappers returned uninitialised torch.empty buffers) and the quantizers' outputs were not tied to the call."""
+    def fwd(x, h):
+        xq, xs = q.fusedQuantizeMx(x, h, method="abs_max")
+        return xq, to_blocked(xs)
+
+    def bwd(x, h):
+        return q.backward_t_bf16(x, h)
+
+    def sq(x):
+        return q.backward_bf16_square_double_mxfp8(x)
+
+    if True:
+        h = torch.zeros(32, 32, dtype=torch.bfloat16)
+        for fn, args, twin in ((fwd, (torch.zeros(64, 128, dtype=torch.bfloat16), h), "fusedQuantizeMx_"),
+                               (bwd, (torch.zeros(2, 128, 256, dtype=torch.bfloat16), h), "backward_t_bf16_"),
+                               (sq, (torch.zeros(200, 256, dtype=torch.bfloat16),), "backward_bf16_square_double_mxfp8_")):
+            (gm,) = _aot_graphs(fn, *args)
+            calls = [n for n in gm.graph.nodes if n.op == "call_function" and twin in str(n.args[:1]) + str(n.target)]
+            assert calls, (twin, gm.code)
+            outs = [a for a in gm.graph.output_node().args[0] if a is not None]
+            def feeds(node, seen=None):   # does `node` depend on the op call?
+                seen = seen if seen is not None else set()
+                if node in calls:
+                    return True
+                seen.add(node)
+                return any(feeds(i, seen) for i in node.all_input_nodes if i not in seen)
+            assert all(feeds(o) for o in outs), (twin, gm.code)
 
 
 def test_to_blocked_traces_with_fullgraph():
@@ -52,7 +125,7 @@ def test_quantize_swizzle_gemm_traces_under_fake_tensors():
         assert out.shape == (256, 384) and out.dtype == torch.bfloat16
         gm = make_fx(layer)(x, h, wq, wsf, alpha)
         t = _targets(gm)
-        assert "_qutlass_C.fusedQuantizeMxAbsMax.default" in t and "qutlass_amd.to_blocked.default" in t and "_qutlass_C.matmul_mxf4_bf16_tn.default" in t
+        assert "qutlass_amd.fusedQuantizeMx_.default" in t and "qutlass_amd.to_blocked.default" in t and "_qutlass_C.matmul_mxf4_bf16_tn.default" in t
         h16 = torch.empty(16, 16, dtype=torch.bfloat16, device=DEV)
         wsf_nv = torch.empty(384 * 32, dtype=torch.float8_e4m3fn, device=DEV)
         out = torch.compile(layer_nv, backend="eager", fullgraph=True)(x, h16, torch.empty(1, device=DEV), wq, wsf_nv, alpha)
