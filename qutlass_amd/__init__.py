@@ -80,43 +80,50 @@ def matmul_mxf8_bf16_nn(a: torch.Tensor, b: torch.Tensor, block_scale_a: torch.T
     return qutlass_CUDA.matmul_mxf8_bf16_nn(a, b, block_scale_a, block_scale_b, alpha)
 
 
+def _alloc_mx(a: torch.Tensor, blocked: bool = False):
+    padded_rows, padded_cols = get_padded_shape_mx(a)
+    xh_e2m1 = torch.empty(*a.shape[:-1], a.size(-1) // 2, dtype=torch.uint8, device=a.device)
+    sf_shape = (padded_rows * padded_cols,) if blocked else (padded_rows, padded_cols)
+    return xh_e2m1, torch.empty(*sf_shape, dtype=torch.float8_e8m0fnu, device=a.device)
+
+
+def _alloc_nv(a: torch.Tensor, blocked: bool = False):
+    padded_rows, padded_cols = get_padded_shape_nv(a)
+    xh_e2m1 = torch.empty(*a.shape[:-1], a.size(-1) // 2, dtype=torch.uint8, device=a.device)
+    sf_shape = (padded_rows * padded_cols,) if blocked else (padded_rows, padded_cols)
+    return xh_e2m1, torch.empty(*sf_shape, dtype=torch.float8_e4m3fn, device=a.device)
+
+
 def fusedQuantizeMx(a: torch.Tensor, b: torch.Tensor, *, method: Literal["quest", "abs_max"] = "quest",
                     return_mask: bool = False):
     """qutlass/__init__.py:149-180: allocate packed e2m1 + (padded_rows, padded_cols) e8m0 [+ clip mask]
     and run the fused rotate+quantize kernel.  As in the reference the scale buffer is written flat
-    (first numel/32 bytes) and its padding is left uninitialised."""
-    padded_rows, padded_cols = get_padded_shape_mx(a)
-    xh_e2m1 = torch.empty(*a.shape[:-1], a.size(-1) // 2, dtype=torch.uint8, device=a.device)
-    xh_e8m0 = torch.empty(padded_rows, padded_cols, dtype=torch.float8_e8m0fnu, device=a.device)
-
-    # (the op calls go through the mutation-declaring twins of `_qutlass_C.fusedQuantizeMx*` -- same kernels, same checks; see ops.py / torch_ext.cpp:
-    #  the reference's schemas hide the writes from torch.compile)
-    if method == "quest":
-        if return_mask:
-            clip_mask = torch.empty(*a.shape[:-1], a.size(-1) // 8, dtype=torch.uint8, device=a.device)
-            _ops_amd.fusedQuantizeMxMask_(a, b, xh_e2m1, xh_e8m0, clip_mask)
-            return xh_e2m1, xh_e8m0, clip_mask
-        else:
-            _ops_amd.fusedQuantizeMx_(a, b, xh_e2m1, xh_e8m0, 0)
-            return xh_e2m1, xh_e8m0
-    elif method == "abs_max":
-        if return_mask:
-            raise ValueError("return_mask is only supported for method 'quest'")
-        _ops_amd.fusedQuantizeMx_(a, b, xh_e2m1, xh_e8m0, 1)
-        return xh_e2m1, xh_e8m0
-    else:
+    (first numel/32 bytes) and its padding is left uninitialised.
+    (The op calls go through `qutlass_amd::` twins of `_qutlass_C.fusedQuantizeMx*` -- same kernels, same checks: the reference's schemas hide the writes from
+    torch.compile.  Eager: the in-place twin on tensors allocated here; under torch.compile: the functional form, see ops.py.)"""
+    if method not in _METHOD_CODE:
         raise ValueError(f"invalid method {method!r}, must be 'quest' or 'abs_max'")
+    if return_mask and method != "quest":
+        raise ValueError("return_mask is only supported for method 'quest'")
+    if torch.compiler.is_compiling():
+        return _ops_amd.quantize_mx_mask(a, b) if return_mask else _ops_amd.quantize_mx(a, b, _METHOD_CODE[method])
+    xh_e2m1, xh_e8m0 = _alloc_mx(a)
+    if return_mask:
+        clip_mask = torch.empty(*a.shape[:-1], a.size(-1) // 8, dtype=torch.uint8, device=a.device)
+        _ops_amd.fusedQuantizeMxMask_(a, b, xh_e2m1, xh_e8m0, clip_mask)
+        return xh_e2m1, xh_e8m0, clip_mask
+    _ops_amd.fusedQuantizeMx_(a, b, xh_e2m1, xh_e8m0, _METHOD_CODE[method])
+    return xh_e2m1, xh_e8m0
 
 
 def fusedQuantizeNv(a: torch.Tensor, b: torch.Tensor, global_scale: torch.Tensor, *,
                     method: Literal["quest", "abs_max"] = "abs_max") -> tuple[torch.Tensor, torch.Tensor]:
     """qutlass/__init__.py:183-203."""
-    padded_rows, padded_cols = get_padded_shape_nv(a)
-    xh_e2m1 = torch.empty(*a.shape[:-1], a.size(-1) // 2, dtype=torch.uint8, device=a.device)
-    xh_e4m3 = torch.empty(padded_rows, padded_cols, dtype=torch.float8_e4m3fn, device=a.device)
-
     if method not in _METHOD_CODE:
         raise ValueError(f"invalid method {method!r}, must be 'quest' or 'abs_max'")
+    if torch.compiler.is_compiling():
+        return _ops_amd.quantize_nv(a, b, global_scale, _METHOD_CODE[method])
+    xh_e2m1, xh_e4m3 = _alloc_nv(a)
     _ops_amd.fusedQuantizeNv_(a, b, xh_e2m1, xh_e4m3, global_scale, _METHOD_CODE[method])
     return xh_e2m1, xh_e4m3
 
@@ -127,9 +134,9 @@ def fusedQuantizeMxBlocked(a: torch.Tensor, b: torch.Tensor, *, method: Literal[
     one launch instead of two on the activation path (qutlass/__init__.py:149-180 + qutlass/utils.py:160-193)."""
     if method not in _METHOD_CODE:
         raise ValueError(f"invalid method {method!r}, must be 'quest' or 'abs_max'")
-    padded_rows, padded_cols = get_padded_shape_mx(a)
-    xh_e2m1 = torch.empty(*a.shape[:-1], a.size(-1) // 2, dtype=torch.uint8, device=a.device)
-    xh_e8m0 = torch.empty(padded_rows * padded_cols, dtype=torch.float8_e8m0fnu, device=a.device)
+    if torch.compiler.is_compiling():
+        return _ops_amd.quantize_mx_blocked(a, b, _METHOD_CODE[method])
+    xh_e2m1, xh_e8m0 = _alloc_mx(a, blocked=True)
     _ops_amd.fusedQuantizeMxBlocked(a, b, xh_e2m1, xh_e8m0, _METHOD_CODE[method])
     return xh_e2m1, xh_e8m0
 
@@ -139,9 +146,9 @@ def fusedQuantizeNvBlocked(a: torch.Tensor, b: torch.Tensor, global_scale: torch
     """EXTENSION: ``fusedQuantizeNv`` with the e4m3 scales written directly in the ``to_blocked`` layout (see fusedQuantizeMxBlocked)."""
     if method not in _METHOD_CODE:
         raise ValueError(f"invalid method {method!r}, must be 'quest' or 'abs_max'")
-    padded_rows, padded_cols = get_padded_shape_nv(a)
-    xh_e2m1 = torch.empty(*a.shape[:-1], a.size(-1) // 2, dtype=torch.uint8, device=a.device)
-    xh_e4m3 = torch.empty(padded_rows * padded_cols, dtype=torch.float8_e4m3fn, device=a.device)
+    if torch.compiler.is_compiling():
+        return _ops_amd.quantize_nv_blocked(a, b, global_scale, _METHOD_CODE[method])
+    xh_e2m1, xh_e4m3 = _alloc_nv(a, blocked=True)
     _ops_amd.fusedQuantizeNvBlocked(a, b, xh_e2m1, xh_e4m3, global_scale, _METHOD_CODE[method])
     return xh_e2m1, xh_e4m3
 
@@ -184,6 +191,9 @@ def backward_t_bf16(x: torch.Tensor, h: torch.Tensor, xh_e2m1: torch.Tensor = No
                     xh_e8m0: torch.Tensor = None) -> tuple[torch.Tensor, torch.Tensor]:
     """qutlass/__init__.py:206-243: abs-max MXFP4 of x^T (last two dims swapped) rotated per 32 along the old
     second-to-last dim.  Outputs (.., M, N/2) float4_e2m1fn_x2 and (.., M, N/32) e8m0 for x of shape (.., N, M)."""
+    if xh_e2m1 is None and xh_e8m0 is None and torch.compiler.is_compiling():
+        assert x.dtype == h.dtype == torch.bfloat16 and x.is_contiguous() and h.is_contiguous()
+        return _ops_amd.backward_t(x, h)
     if xh_e2m1 is None:
         xh_e2m1 = torch.empty(*x.shape[:-2], x.size(-1), x.size(-2) // 2, dtype=torch.float4_e2m1fn_x2, device=h.device)
     if xh_e8m0 is None:
@@ -198,6 +208,9 @@ def backward_t_bf16(x: torch.Tensor, h: torch.Tensor, xh_e2m1: torch.Tensor = No
 def backward_qt_bf16(x_e2m1: torch.Tensor, x_e8m0: torch.Tensor, h: torch.Tensor, alpha: torch.Tensor,
                      xh_e2m1: torch.Tensor = None, xh_e8m0: torch.Tensor = None) -> tuple[torch.Tensor, torch.Tensor]:
     """qutlass/__init__.py:246-286: the same on an MXFP4 operand (x_e2m1 (.., N, M/2), x_e8m0 (.., N, M/32))."""
+    if xh_e2m1 is None and xh_e8m0 is None and torch.compiler.is_compiling():
+        assert x_e2m1.is_contiguous() and x_e8m0.is_contiguous() and h.is_contiguous()
+        return _ops_amd.backward_qt(x_e2m1, x_e8m0, h, alpha)
     if xh_e2m1 is None:
         xh_e2m1 = torch.empty(*x_e2m1.shape[:-2], x_e2m1.size(-1) * 2, x_e2m1.size(-2) // 2,
                               dtype=torch.float4_e2m1fn_x2, device=h.device)
@@ -213,6 +226,8 @@ def backward_qt_bf16(x_e2m1: torch.Tensor, x_e8m0: torch.Tensor, h: torch.Tensor
 def backward_bf16_square_double_mxfp8(x_bf16: torch.Tensor) -> tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
     """qutlass/__init__.py:288-297: e4m3 with one e8m0 per 32 x 32 block, returned row-wise (m_pad, n/32) and column-wise
     (n, m_pad/32), m_pad = rows rounded up to 128.  The missing rows are zeros INSIDE the kernel: no padded copy of x."""
+    if torch.compiler.is_compiling():
+        return _ops_amd.square_double_mxfp8(x_bf16)
     m, n = x_bf16.shape
     m_pad = ceil_div(m, 128) * 128
     x_fp8 = torch.empty(m_pad, n, device=x_bf16.device, dtype=torch.float8_e4m3fn)
@@ -226,6 +241,8 @@ def mxfp4_transpose_mxfp8(x_fp4: torch.Tensor, scales: torch.Tensor) -> tuple[to
     """qutlass/__init__.py:299-315: MXFP4 (m, n/2) + e8m0 (m, n/32) -> transposed e4m3 (n, m_pad) + e8m0 (n, m_pad/32), m_pad = rows
     rounded up to 256 as in the reference.  The padding rows (zero codes, unit scales) exist only inside the kernel: x_fp4 is
     not copied and `scales` is not written (the reference's own "TODO: padding in kernel")."""
+    if torch.compiler.is_compiling():
+        return _ops_amd.transpose_mxfp8(x_fp4, scales)
     m = x_fp4.shape[0]
     m_pad = ceil_div(m, 256) * 256
     x_fp8 = torch.empty(x_fp4.shape[1] * 2, m_pad, device=x_fp4.device, dtype=torch.float8_e4m3fn)

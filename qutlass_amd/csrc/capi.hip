@@ -11,6 +11,7 @@
 #include "../../include/qutlass_amd.h"
 #include "gemm_mx.hip.h"
 #include "gemm_mx_deepp.hip.h"
+#include "gemm_mx_duo.hip.h"
 #if QAMD_BENCH
 #include "gemm_mx_deepp_lab.hip.h"   // the lab copy (namespace qamd::labk): traces, ablations, stream-K, retirement experiments
 #endif
@@ -229,6 +230,18 @@ int launch_gemm_deepp(GemmParams p, hipStream_t s) {
   return check_launch("gemm_mx_deepp_kernel");
 }
 
+// [r6] the 8-wave persistent schedule (gemm_mx_duo.hip.h): same grid rule, 144 KiB of static LDS.  RET: retirement placement (0 burst, 1 behind the last k-slice)
+template <class C, int ST_AUX = 17, int RET = 0, bool TRACE = false>
+int launch_gemm_duo(GemmParams p, hipStream_t s) {
+  p.tiles_m = (int)cdiv(p.M, C::BM);
+  p.tiles_n = (int)cdiv(p.N, C::BN);
+  p.raster_magic = raster_magic(p.tiles_n);
+  p.ws = nullptr; p.splits = 1; p.ctr = nullptr; p.tag = 0;
+  const int grid = deepp_grid(p.tiles_m * p.tiles_n);
+  hipLaunchKernelGGL((gemm_mx_duo_kernel<C, ST_AUX, RET, TRACE>), dim3(grid), dim3(C::THREADS), 0, s, p);
+  return check_launch("gemm_mx_duo_kernel");
+}
+
 // [r4] stream-K form of the two persistent kernels (lab variant 89): one workgroup per CU; p.ws / p.ctr / p.tag / p.sk_tiles set by gemm_mx
 #if QAMD_BENCH
 template <class C>
@@ -426,6 +439,10 @@ int dispatch_variant(int v, const GemmParams& p, hipStream_t s, const char* name
     if (v == 98) return launch_gemm_hetero<GemmCfg<256, 256, 2, 2, 4, false>, GemmCfg<128, 128, 2, 2, 4, false, 0, 4>, 17>(p, s);
 #if QAMD_BENCH
     if (v == 99) return launch_gemm_hetero<GemmCfg<256, 256, 2, 2, 4, false>, GemmCfg<128, 128, 2, 2, 4, false, 0, 3>, 17>(p, s);
+    // [r6] 8-wave persistent schedule (gemm_mx_duo.hip.h): 88 burst retirement, 87 retirement behind the last k-slice, 86 = 88 with stage stamps
+    if (v == 88) return launch_gemm_duo<GemmCfg<256, 256, 2, 4, 4, false>, 17, 0>(p, s);
+    if (v == 87) return launch_gemm_duo<GemmCfg<256, 256, 2, 4, 4, false>, 17, 1>(p, s);
+    if (v == 86) return launch_gemm_duo<GemmCfg<256, 256, 2, 4, 4, false>, 17, 0, true>(p, s);
     if (v == 298) return launch_gemm_hetero<GemmCfg<256, 256, 2, 2, 4, false>, GemmCfg<128, 128, 2, 2, 4, false, 128, 4>, 17>(p, s);   // residual tiles with ABL_READS_FIRST
     if (v == 91) return launch_gemm_deepp<GemmCfg<256, 256, 2, 2, 4, false>, true, 17>(p, s);   //   + phase timestamps of workgroup 0 (qutlass_amd_debug_set_trace_buffer)
     if (v == 92) return launch_gemm_deepp<GemmCfg<256, 256, 2, 2, 4, false>, false, 2>(p, s);       //   output stores nt

@@ -83,7 +83,11 @@ __device__ __forceinline__ void gemm_mx_deepp(char* smem, const GemmParams& p, c
   // ---- registers -------------------------------------------------------------------------------------------------------
   v16f acc[MT][NT];
   v4i fa[4][MT] = {}, fb[4][NT] = {};
-  int sa[2][MT], sb[2][NT];
+  // [r6] the scale dwords of a stage, one 16-byte LDS read per operand: a lane's four row fragments (rows 32 t + i32 of the wave's 128) have their dwords in ONE 16-byte
+  // line of the to_blocked image (32 lanes x 16 B: conflict-free).  Rounds 3-5 read them as eight ds_read_b32 at a 16-byte lane stride -- a 4-way bank conflict each,
+  // which is what SQ_LDS_BANK_CONFLICT counted in the K loop (192 cycles per stage and CU = 22 % of the LDS-active cycles, profiles/rocprof_pmc_gemm_r5a_mxfp4_4096.txt).
+  static_assert(MT == 4 && NT == 4, "one ds_read_b128 = the scale dwords of the wave's four row fragments");
+  v4i sa[2], sb[2];
 
   auto read_slice = [&](const int buf, const int j) __attribute__((always_inline)) {
     const char* st = smem + buf * STAGE;
@@ -100,10 +104,8 @@ __device__ __forceinline__ void gemm_mx_deepp(char* smem, const GemmParams& p, c
   };
   auto read_scales = [&](const int buf, const int set) __attribute__((always_inline)) {
     const char* st = smem + buf * STAGE;
-#pragma unroll
-    for (int t = 0; t < MT; ++t) sa[set][t] = *(const int*)(st + cx.rdSA[t]);
-#pragma unroll
-    for (int t = 0; t < NT; ++t) sb[set][t] = *(const int*)(st + cx.rdSB[t]);
+    sa[set] = *(const v4i*)(st + cx.rdSA[0]);
+    sb[set] = *(const v4i*)(st + cx.rdSB[0]);
   };
   // one scaled FP4 MFMA: acc[m][n] (+)= B-fragment n x A-fragment m of k-slice j (op_sel byte j of the scale dwords of set sset)
   auto mfma1 = [&](const int j, const int sset, const int m, const int n, const bool zero_c) __attribute__((always_inline)) {
@@ -185,12 +187,12 @@ __device__ __forceinline__ void gemm_mx_deepp(char* smem, const GemmParams& p, c
       if (i < MT) fa[j][i] = *(lds_v4i_t)(uintptr_t)(rbA + (uint32_t)(i * 32 * C::ROWB));
       else fb[j][i - MT] = *(lds_v4i_t)(uintptr_t)(rbB + (uint32_t)((i - MT) * 32 * C::ROWB));
     };
-    auto read_scale1 = [&](const int buf, const int set, const int i) __attribute__((always_inline)) {
+    auto read_scale1 = [&](const int buf, const int set, const int i) __attribute__((always_inline)) {   // i = 0: the A operand's dwords, 1: B's
       const char* st = smem + buf * STAGE;
-      if (i < MT) sa[set][i] = *(const int*)(st + cx.rdSA[i]);
-      else sb[set][i - MT] = *(const int*)(st + cx.rdSB[i - MT]);
+      if (i == 0) sa[set] = *(const v4i*)(st + cx.rdSA[0]);
+      else sb[set] = *(const v4i*)(st + cx.rdSB[0]);
     };
-    static_assert(MT + NT <= MT * NT / 2, "a fragment read behind each of the first MT + NT MFMAs, a scale read behind each of the next");
+    static_assert(MT + NT <= MT * NT / 2, "a fragment read behind each of the first MT + NT MFMAs, the two scale reads behind the next two");
     // group G: the MT x NT MFMAs of k-slice js, each followed by `extra(i)`
     auto group = [&](const int js, const bool zero_c, auto extra) __attribute__((always_inline)) {
       int i = 0;
@@ -228,7 +230,7 @@ __device__ __forceinline__ void gemm_mx_deepp(char* smem, const GemmParams& p, c
       else if (i >= 8) { dma_item(d, ktl, BUF, i - 8); if (i == 8) dma_item(d, ktl, BUF, 16); }
       // the next stage's slice 0 (set 0 went dead with group 0) and its scale dwords
       if (i < MT + NT) read_frag(0, i);
-      else if (i < 2 * (MT + NT)) read_scale1(BUF ^ 1, BUF ^ 1, i - (MT + NT));
+      else if (i < MT + NT + 2) read_scale1(BUF ^ 1, BUF ^ 1, i - (MT + NT));
     });
     read_base(BUF ^ 1, 1);
     group(3, false, [&](const int i) __attribute__((always_inline)) {

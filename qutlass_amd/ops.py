@@ -39,6 +39,7 @@ def register_torch_ops() -> None:
         )
     torch.ops.load_library(EXT_PATH)
     _register_fakes()
+    _define_functional_ops()
     _registered = True   # only once the fake kernels are in place: a failed registration is retried (and raises again) on the next call
 
 
@@ -84,6 +85,129 @@ def _register_fakes() -> None:
     def _(X, R, B, B_sf, alpha, method):
         k = X.size(-1)
         return X.new_empty((X.numel() // k if k else 0, B.size(0)), dtype=torch.bfloat16)
+
+
+def _define_functional_ops() -> None:
+    """FUNCTIONAL forms of the output-filling ops (`qutlass_amd::quantize_mx` ...: allocate, call the in-place twin, return fresh tensors), defined in Python with
+    `torch.library.custom_op`.  The wrappers of qutlass_amd/__init__.py call them only while a graph is being compiled (`torch.compiler.is_compiling()`): inductor (torch
+    2.10) refuses every node that touches a `float8_e8m0fnu` tensor except views / cat / clone / `_scaled_mm` (torch/_inductor/lowering.py `unsupported_input_tensor`), so
+    the `auto_functionalized` wrapper of a mutating op with an e8m0 argument is never decomposed and compilation dies ("auto_functionalized_v2 was not removed") -- while a
+    functional op with e8m0 results is simply called as an extern kernel.  Eager callers keep the direct C++ path (a Python custom op costs ~10 us per call)."""
+    if hasattr(torch.ops.qutlass_amd, "quantize_mx"):
+        return
+    from torch.library import custom_op
+
+    amd = torch.ops.qutlass_amd
+    have_training_ops = hasattr(amd, "backward_t_bf16_")
+
+    def _mx(a, blocked=False):
+        rows, cols = a.numel() // a.size(-1), a.size(-1) // 32
+        pr, pc = (rows + 127) // 128 * 128, (cols + 3) // 4 * 4
+        return (a.new_empty((*a.shape[:-1], a.size(-1) // 2), dtype=torch.uint8),
+                a.new_empty((pr * pc,) if blocked else (pr, pc), dtype=torch.float8_e8m0fnu))
+
+    def _nv(a, blocked=False):
+        rows, cols = a.numel() // a.size(-1), a.size(-1) // 16
+        pr, pc = (rows + 127) // 128 * 128, (cols + 3) // 4 * 4
+        return (a.new_empty((*a.shape[:-1], a.size(-1) // 2), dtype=torch.uint8),
+                a.new_empty((pr * pc,) if blocked else (pr, pc), dtype=torch.float8_e4m3fn))
+
+    @custom_op("qutlass_amd::quantize_mx", mutates_args=(), schema="(Tensor A, Tensor R, int method) -> (Tensor, Tensor)")
+    def quantize_mx(A, R, method):
+        o = _mx(A)
+        amd.fusedQuantizeMx_(A, R, o[0], o[1], method)
+        return o
+
+    quantize_mx.register_fake(lambda A, R, method: _mx(A))
+
+    @custom_op("qutlass_amd::quantize_nv", mutates_args=(), schema="(Tensor A, Tensor R, Tensor global_scale, int method) -> (Tensor, Tensor)")
+    def quantize_nv(A, R, global_scale, method):
+        o = _nv(A)
+        amd.fusedQuantizeNv_(A, R, o[0], o[1], global_scale, method)
+        return o
+
+    quantize_nv.register_fake(lambda A, R, global_scale, method: _nv(A))
+
+    @custom_op("qutlass_amd::quantize_mx_blocked", mutates_args=(), schema="(Tensor A, Tensor R, int method) -> (Tensor, Tensor)")
+    def quantize_mx_blocked(A, R, method):
+        o = _mx(A, True)
+        amd.fusedQuantizeMxBlocked(A, R, o[0], o[1], method)
+        return o
+
+    quantize_mx_blocked.register_fake(lambda A, R, method: _mx(A, True))
+
+    @custom_op("qutlass_amd::quantize_nv_blocked", mutates_args=(), schema="(Tensor A, Tensor R, Tensor global_scale, int method) -> (Tensor, Tensor)")
+    def quantize_nv_blocked(A, R, global_scale, method):
+        o = _nv(A, True)
+        amd.fusedQuantizeNvBlocked(A, R, o[0], o[1], global_scale, method)
+        return o
+
+    quantize_nv_blocked.register_fake(lambda A, R, global_scale, method: _nv(A, True))
+
+    if not have_training_ops:   # QUTLASS_MINIMAL_BUILD: inference ops only
+        return
+
+    def _mask(a):
+        return _mx(a) + (a.new_empty((*a.shape[:-1], a.size(-1) // 8), dtype=torch.uint8),)
+
+    @custom_op("qutlass_amd::quantize_mx_mask", mutates_args=(), schema="(Tensor A, Tensor R) -> (Tensor, Tensor, Tensor)")
+    def quantize_mx_mask(A, R):
+        o = _mask(A)
+        amd.fusedQuantizeMxMask_(A, R, o[0], o[1], o[2])
+        return o
+
+    quantize_mx_mask.register_fake(lambda A, R: _mask(A))
+
+    def _bt(x):   # (.., N, M) -> (.., M, N/2) e2m1x2, (.., M, N/32) e8m0
+        return (x.new_empty((*x.shape[:-2], x.size(-1), x.size(-2) // 2), dtype=torch.float4_e2m1fn_x2),
+                x.new_empty((*x.shape[:-2], x.size(-1), x.size(-2) // 32), dtype=torch.float8_e8m0fnu))
+
+    @custom_op("qutlass_amd::backward_t", mutates_args=(), schema="(Tensor x, Tensor h) -> (Tensor, Tensor)")
+    def backward_t(x, h):
+        o = _bt(x)
+        amd.backward_t_bf16_(x, h, o[0], o[1])
+        return o
+
+    backward_t.register_fake(lambda x, h: _bt(x))
+
+    def _bqt(c, s):
+        return (c.new_empty((*c.shape[:-2], c.size(-1) * 2, c.size(-2) // 2), dtype=torch.float4_e2m1fn_x2),
+                c.new_empty((*s.shape[:-2], s.size(-1) * 32, s.size(-2) // 32), dtype=torch.float8_e8m0fnu))
+
+    @custom_op("qutlass_amd::backward_qt", mutates_args=(), schema="(Tensor x_e2m1, Tensor x_e8m0, Tensor h, Tensor alpha) -> (Tensor, Tensor)")
+    def backward_qt(x_e2m1, x_e8m0, h, alpha):
+        o = _bqt(x_e2m1, x_e8m0)
+        amd.backward_qt_bf16_(x_e2m1, x_e8m0, h, alpha, o[0], o[1])
+        return o
+
+    backward_qt.register_fake(lambda x_e2m1, x_e8m0, h, alpha: _bqt(x_e2m1, x_e8m0))
+
+    def _sq(x):
+        m, n = x.shape
+        mp = (m + 127) // 128 * 128
+        return (x.new_empty((mp, n), dtype=torch.float8_e4m3fn), x.new_empty((mp, n // 32), dtype=torch.float8_e8m0fnu),
+                x.new_empty((n, mp // 32), dtype=torch.float8_e8m0fnu))
+
+    @custom_op("qutlass_amd::square_double_mxfp8", mutates_args=(), schema="(Tensor x_bf16) -> (Tensor, Tensor, Tensor)")
+    def square_double_mxfp8(x_bf16):
+        o = _sq(x_bf16)
+        amd.backward_bf16_square_double_mxfp8_(x_bf16, o[0], o[1], o[2])
+        return o
+
+    square_double_mxfp8.register_fake(lambda x_bf16: _sq(x_bf16))
+
+    def _tr(x, s):
+        m, n = x.shape[0], x.shape[1] * 2
+        mp = (m + 255) // 256 * 256
+        return x.new_empty((n, mp), dtype=torch.float8_e4m3fn), x.new_empty((n, mp // 32), dtype=torch.float8_e8m0fnu)
+
+    @custom_op("qutlass_amd::transpose_mxfp8", mutates_args=(), schema="(Tensor x_fp4, Tensor scales) -> (Tensor, Tensor)")
+    def transpose_mxfp8(x_fp4, scales):
+        o = _tr(x_fp4, scales)
+        amd.mxfp4_transpose_mxfp8_(x_fp4, scales, o[0], o[1])
+        return o
+
+    transpose_mxfp8.register_fake(lambda x_fp4, scales: _tr(x_fp4, scales))
 
 
 def to_blocked(input_matrix: torch.Tensor) -> torch.Tensor:

@@ -1,8 +1,9 @@
 """Round-6 GPU parity tests (nothing here reads /root/reference).
 
-  * Quest on (nearly) CONSTANT groups: the sign of the fp32 variance decides the reference's arm -- MX: `if (var >= 0)` else scale 1.0 (epilogue_quant.h:531-535); NV: no
+  * Quest on CONSTANT groups: the sign of the fp32 variance decides the reference's arm -- MX: `if (var >= 0)` else scale 1.0 (epilogue_quant.h:531-535); NV: no
     guard at all, sqrt of the negative variance is stored as the NaN scale byte 0x7f and every code of the group becomes +-0 (epilogue_quant.h:1631-1640).  The kernel
-    re-sums such groups in the reference's order (quantize.hip.h `quest_sums_in_reference_order`), so scale bytes are compared EXACTLY against the oracle's sequential sums.
+    re-sums such groups in the reference's order (quantize.hip.h `quest_sums_in_reference_order`): with a rotation that is exact (c I) the scale bytes are compared
+    EXACTLY against the oracle's sequential sums; with a Hadamard rotation only the kind of disagreement is checked.
   * `backward_qt_bf16` on a tile whose 32 rows ALL carry scale byte 0 (operands 0.0 whatever their codes, quartet_bwd_sm120.cu:369-375): amax 0 -> scale 2^-127 ... as the oracle.
   * compiled callers: `aot_eager` and `inductor` graphs of the quantize -> swizzle -> GEMM layer and of the QAT-backward data-prep ops return the eager bytes (the wrappers
     call ops whose schemas declare what they write).
@@ -42,9 +43,27 @@ def _hadamard(n: int) -> torch.Tensor:
     return (h * n ** -0.5).to(torch.bfloat16).to(DEV)
 
 
+def constant_groups(n: int, rot: int, seed: int) -> torch.Tensor:
+    """n rotation groups of ONE repeated bf16 value each; in the second half of them a tenth of the elements have the last mantissa bit flipped (also built by the CPU half,
+    tests/test_round6_cpu.py).  Rotated by c I with c = 1.7109375 every output is x c EXACTLY (one product per output, 16 significant bits), so kernel and oracle see the
+    same y -- and y^2 has 32 significant bits, so every `fma(y, y, s2)` rounds: the sums depend on the order of the additions and the fp32 variance of such a group is
+    rounding noise around 0, negative for about a third of them."""
+    rng = np.random.default_rng(seed)
+    a = rng.standard_normal(n).astype(np.float32) * 8
+    bits = torch.from_numpy(np.repeat(a[:, None], rot, 1)).to(torch.bfloat16).view(torch.int16).numpy().copy()
+    flip = rng.random((n, rot)) < 0.1
+    flip[: n // 2] = False
+    return torch.from_numpy(bits ^ flip.astype(np.int16)).view(torch.bfloat16)
+
+
+def scaled_identity(rot: int) -> torch.Tensor:
+    return (torch.eye(rot) * 1.7109375).to(torch.bfloat16).to(DEV)
+
+
 def nearly_constant_groups(n: int, rot: int, seed: int) -> torch.Tensor:
-    """n rotation groups (a, a 2^-k, 0, ..., 0), k = 9 .. 14: rotated by a Hadamard matrix every output is +-(a +- a 2^-k) / sqrt(rot) -- a group whose spread is at the
-    rounding noise of its fp32 sum of squares (also used by the CPU half, tests/test_round6_cpu.py)."""
+    """n rotation groups (a, a 2^-k, 0, ..., 0), k = 9 .. 14: rotated by a Hadamard matrix every output is +-(a +- a 2^-k) / sqrt(rot) -- nearly constant, with long mantissas.
+    Here the rotation itself rounds (the matrix pipe's accumulation is not the oracle's, nor the reference's tensor core's): which of these groups get a negative variance
+    cannot be pinned, only that the two outcomes are the ones a vanishing variance has."""
     rng = np.random.default_rng(seed)
     x = np.zeros((n, rot), np.float32)
     a = rng.standard_normal(n).astype(np.float32) * 8
@@ -54,44 +73,61 @@ def nearly_constant_groups(n: int, rot: int, seed: int) -> torch.Tensor:
 
 
 @pytest.mark.parametrize("rot", [16, 32, 64, 128])
-def test_fused_quantize_nv_quest_nearly_constant_groups_nan_scale_byte(q, rot):
-    x = nearly_constant_groups(4096, rot, 6).to(DEV)
-    h = _hadamard(rot)
+def test_fused_quantize_nv_quest_constant_groups_nan_scale_byte_exact(q, rot):
+    x = constant_groups(4096, rot, 3).to(DEV)
+    h = scaled_identity(rot)
     gs = torch.tensor([1.0], device=DEV)
     e2m1, e4m3 = q.fusedQuantizeNv(x, h, gs, method="quest")
     rq, rs = oracle.fused_quantize_nv(_np(x), _np(h), 1.0, oracle.QUEST)
     rs = np.asarray(rs).reshape(-1)
     got_s = _np(e4m3).reshape(-1)[: rs.size]
-    if rot == 32:   # (1 / sqrt(32) is not a bf16: long mantissas, about a fifth of these groups come out with a negative variance)
-        assert int((rs == 0x7F).sum()) > 500
+    assert int((rs == 0x7F).sum()) > rs.size // 8          # the reference's NaN scale byte (epilogue_quant.h:1631-1640), about a quarter of these groups
     bad = np.nonzero(got_s != rs)[0]
     assert bad.size == 0, f"{bad.size} e4m3 scale bytes differ, first groups {bad[:8]}: got {got_s[bad[:8]]}, oracle {rs[bad[:8]]}"
     got_q = _np(e2m1).reshape(-1, 8)
-    nan_groups = rs == 0x7F
-    assert not (got_q[nan_groups] & 0x77).any(), "a group with a NaN scale byte holds codes other than +-0"
+    assert not (got_q[rs == 0x7F] & 0x77).any(), "a group with a NaN scale byte holds codes other than +-0"
     eq = oracle.codes_equal_mod_zero_sign(_np(e2m1), rq)
     assert int((~eq).sum()) <= 2, f"{int((~eq).sum())} code bytes differ"
 
 
 @pytest.mark.parametrize("rot", [32, 64, 128])
 @pytest.mark.parametrize("mask", [False, True])
-def test_fused_quantize_mx_quest_nearly_constant_groups(q, rot, mask):
+def test_fused_quantize_mx_quest_constant_groups_exact(q, rot, mask):
     if mask and rot != 32:
         pytest.skip("the clip-mask quantizer takes rotation 32 only (fused_quantize_mx_mask.cu:107-123)")
-    x = nearly_constant_groups(4096, rot, 7).to(DEV)
-    h = _hadamard(rot)
+    x = constant_groups(4096, rot, 4).to(DEV)
+    h = scaled_identity(rot)
     out = q.fusedQuantizeMx(x, h, method="quest", return_mask=mask)
     rq, rs, rm = oracle.fused_quantize_mx(_np(x), _np(h), oracle.QUEST, with_mask=mask)
     rs = np.asarray(rs).reshape(-1)
     got_s = _np(out[1]).reshape(-1)[: rs.size]
-    if rot == 32:
-        assert int((rs == 127).sum()) > 500   # the `var < 0` arm: scale 1.0
+    assert int((rs == 127).sum()) > rs.size // 8           # the `var < 0` arm: scale 1.0 (epilogue_quant.h:531-535)
+    _, rs_lane, _ = oracle.fused_quantize_mx(_np(x), _np(h), oracle.QUEST, acc_model=2)
+    assert int((np.asarray(rs_lane).reshape(-1) != rs).sum()) > rs.size // 8   # ... and the kernel's natural lane order would get a third of them wrong
     bad = np.nonzero(got_s != rs)[0]
     assert bad.size == 0, f"{bad.size} e8m0 bytes differ, first groups {bad[:8]}: got {got_s[bad[:8]]}, oracle {rs[bad[:8]]}"
     eq = oracle.codes_equal_mod_zero_sign(_np(out[0]), rq)
     assert eq.all(), f"{int((~eq).sum())} code bytes differ"
     if mask:
         assert np.array_equal(_np(out[2]).reshape(-1), np.asarray(rm).reshape(-1))
+
+
+@pytest.mark.parametrize("rot", [16, 32, 64])
+def test_fused_quantize_nv_quest_nearly_constant_rotated_groups(q, rot):
+    """Hadamard-rotated near-constant groups: kernel and oracle may disagree on the SIGN of a vanishing variance (the rotation's own rounding), never on anything else: a
+    differing scale byte is 0x7f (NaN: negative variance) on one side and the byte of sqrt(~0) * c + 1e-8 -- 0 or 1 -- on the other."""
+    x = nearly_constant_groups(4096, rot, 6).to(DEV)
+    h = _hadamard(rot)
+    gs = torch.tensor([1.0], device=DEV)
+    e2m1, e4m3 = q.fusedQuantizeNv(x, h, gs, method="quest")
+    _, rs = oracle.fused_quantize_nv(_np(x), _np(h), 1.0, oracle.QUEST)
+    rs = np.asarray(rs).reshape(-1)
+    got_s = _np(e4m3).reshape(-1)[: rs.size]
+    bad = got_s != rs
+    assert set(np.unique(np.stack([got_s[bad], rs[bad]])).tolist()) <= {0, 1, 0x7F}, (got_s[bad][:8], rs[bad][:8])   # (1 = 2^-9, the smallest e4m3: a variance of a few ulps)
+    if rot == 32:   # (1 / sqrt(32) is not a bf16: long mantissas -- about a fifth of these groups get a negative variance, on either side)
+        assert int((got_s == 0x7F).sum()) > 500 and int((rs == 0x7F).sum()) > 500
+    assert not (_np(e2m1).reshape(-1, 8)[got_s == 0x7F] & 0x77).any()
 
 
 @pytest.mark.parametrize("B,N,M", [(1, 96, 64), (1, 4096 + 96, 6144 + 32), (2, 512, 1024)])   # round-3 kernel / wave-owned lines / the ring kernel (M % 128 == 0)
@@ -167,3 +203,49 @@ def test_compiled_callers_return_the_eager_bytes(q):
                 av = a.view(torch.uint8) if a.element_size() == 1 else a.view(torch.int16)
                 bv = b.view(torch.uint8) if b.element_size() == 1 else b.view(torch.int16)
                 assert torch.equal(av, bv), (fn.__name__, backend, i)
+
+
+# ------------------------------------------------------------------------------------------------
+# [r6] the 8-wave persistent MXFP4 kernel (csrc/gemm_mx_duo.hip.h; qutlass/csrc/gemm.cu:174-248): same products, same K order -> the SAME bits as the 4-wave
+# persistent kernel and every other schedule, on full tiles, ragged edges, K tails, odd stage counts, one tile and several tiles per workgroup
+# ------------------------------------------------------------------------------------------------
+import _benchlib as lab  # noqa: E402  (the LAB library: test infrastructure)
+
+
+def _mx_operands(m, n, k, seed):
+    g = torch.Generator(device=DEV).manual_seed(seed)
+    a = torch.randint(0, 256, (m, k // 2), dtype=torch.uint8, device=DEV, generator=g)
+    b = torch.randint(0, 256, (n, k // 2), dtype=torch.uint8, device=DEV, generator=g)
+    pad = lambda r: (r + 127) // 128 * 128
+    cb = (k // 32 + 3) // 4 * 4
+    sa = torch.randint(121, 130, (pad(m) * cb,), dtype=torch.uint8, device=DEV, generator=g)
+    sb = torch.randint(121, 130, (pad(n) * cb,), dtype=torch.uint8, device=DEV, generator=g)
+    return a, b, sa, sb
+
+
+DUO_SHAPES = [(256, 256, 512), (512, 768, 256), (4096, 4096, 4096), (1000, 1288, 1408), (2048, 6400, 1280), (264, 8, 3968), (8192, 8192, 768), (300, 520, 11008)]
+
+
+@pytest.mark.parametrize("variant", [88, 87])
+@pytest.mark.parametrize("m,n,k", DUO_SHAPES)
+def test_duo_kernel_equals_the_4wave_persistent_kernel(variant, m, n, k):
+    a, b, sa, sb = _mx_operands(m, n, k, m + n + k)
+    alpha = torch.tensor([0.75], device=DEV)
+    with lab.forced(gemm_variant=90):
+        ref = lab.matmul_mxf4_bf16_tn(a, b, sa, sb, alpha)
+    with lab.forced(gemm_variant=variant):
+        got = lab.matmul_mxf4_bf16_tn(a, b, sa, sb, alpha)
+    torch.cuda.synchronize()
+    bad = (got.view(torch.int16) != ref.view(torch.int16))
+    assert not bad.any(), f"{int(bad.sum())} of {bad.numel()} outputs differ, first at {bad.nonzero()[0].tolist()}"
+
+
+@pytest.mark.parametrize("variant", [88, 87])
+def test_duo_kernel_against_the_oracle(variant):
+    m, n, k = 320, 264, 1408      # edges in M and N, a K tail (5.5 stages of 256), an odd number of stages
+    a, b, sa, sb = _mx_operands(m, n, k, 5)
+    alpha = torch.tensor([1.0], device=DEV)
+    with lab.forced(gemm_variant=variant):
+        got = lab.matmul_mxf4_bf16_tn(a, b, sa, sb, alpha)
+    ref = oracle.gemm_blockscaled(oracle.KIND_MXFP4, _np(a), _np(b), _np(sa), _np(sb), 1.0, m, n, k)
+    assert np.array_equal(_np(got), ref), int((_np(got) != ref).sum())
