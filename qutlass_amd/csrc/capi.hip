@@ -16,6 +16,7 @@
 #include "gemm_mx_deepp_lab.hip.h"   // the lab copy (namespace qamd::labk): traces, ablations, stream-K, retirement experiments
 #endif
 #include "gemm_mx_skinny.hip.h"
+#include "gemm_mx_ks.hip.h"
 #include "gemm_mx_fusedq.hip.h"
 #include "gemm_nvf4.hip.h"
 #include "gemm_nvf4_pk.hip.h"
@@ -242,6 +243,17 @@ int launch_gemm_duo(GemmParams p, hipStream_t s) {
   return check_launch("gemm_mx_duo_kernel");
 }
 
+// [r6] small-batch kernel with the K split inside the workgroup (gemm_mx_ks.hip.h): one 32x32 / 32x64 / 64x32 tile per workgroup of four waves
+template <int TM, int TN, int D = 8>
+int launch_gemm_ks(GemmParams p, hipStream_t s) {
+  using C = KsCfg<TM, TN, D>;
+  p.tiles_m = (int)cdiv(p.M, TM);
+  p.tiles_n = (int)cdiv(p.N, TN);
+  p.ws = nullptr; p.splits = 1; p.ctr = nullptr; p.tag = 0;
+  hipLaunchKernelGGL((gemm_mx_ks_kernel<C>), dim3(p.tiles_m * p.tiles_n), dim3(256), 0, s, p);
+  return check_launch("gemm_mx_ks_kernel");
+}
+
 // [r4] stream-K form of the two persistent kernels (lab variant 89): one workgroup per CU; p.ws / p.ctr / p.tag / p.sk_tiles set by gemm_mx
 #if QAMD_BENCH
 template <class C>
@@ -437,8 +449,24 @@ int dispatch_variant(int v, const GemmParams& p, hipStream_t s, const char* name
 #endif
     if (v == 90) return launch_gemm_deepp<GemmCfg<256, 256, 2, 2, 4, false>, false, 17>(p, s);
     if (v == 98) return launch_gemm_hetero<GemmCfg<256, 256, 2, 2, 4, false>, GemmCfg<128, 128, 2, 2, 4, false, 0, 4>, 17>(p, s);
+    // [r6] K split inside the workgroup (gemm_mx_ks.hip.h): 561 = 32x32 tiles, 562 = 32x64.  Ring depth by the K stage count: a short K pays for a deep ring's prologue
+    // (4096^2 weights, M <= 64: 4.16 us 4-deep, 4.47 us 8-deep), a long one needs the stages in flight (8192^2: 9.4 us 4-deep, 7.4 us 6-deep; profiles/calib_ks_r6*.txt)
+    if (v == 561 || v == 562) {
+      const bool deep = cdiv(p.K, 256) > 24;
+      if (v == 561) return deep ? launch_gemm_ks<32, 32, 6>(p, s) : launch_gemm_ks<32, 32, 4>(p, s);
+      return deep ? launch_gemm_ks<32, 64, 6>(p, s) : launch_gemm_ks<32, 64, 4>(p, s);
+    }
 #if QAMD_BENCH
     if (v == 99) return launch_gemm_hetero<GemmCfg<256, 256, 2, 2, 4, false>, GemmCfg<128, 128, 2, 2, 4, false, 0, 3>, 17>(p, s);
+    // [r6] lab: the other tiles / ring depths of the in-workgroup K-split kernel (563 = 64x32, 564 = 64x64; 565 - 567 = 32x32 with a 4 / 8 / 6-deep ring)
+    if (v == 563 || v == 564) {
+      const bool deep = cdiv(p.K, 256) > 24;
+      if (v == 563) return deep ? launch_gemm_ks<64, 32, 6>(p, s) : launch_gemm_ks<64, 32, 4>(p, s);
+      return deep ? launch_gemm_ks<64, 64, 6>(p, s) : launch_gemm_ks<64, 64, 4>(p, s);
+    }
+    if (v == 565) return launch_gemm_ks<32, 32, 4>(p, s);
+    if (v == 566) return launch_gemm_ks<32, 32, 8>(p, s);
+    if (v == 567) return launch_gemm_ks<32, 32, 6>(p, s);
     // [r6] 8-wave persistent schedule (gemm_mx_duo.hip.h): 88 burst retirement, 87 retirement behind the last k-slice, 86 = 88 with stage stamps
     if (v == 88) return launch_gemm_duo<GemmCfg<256, 256, 2, 4, 4, false>, 17, 0>(p, s);
     if (v == 87) return launch_gemm_duo<GemmCfg<256, 256, 2, 4, 4, false>, 17, 1>(p, s);
@@ -660,6 +688,23 @@ SmallPlan plan_small(int64_t M, int64_t N, int64_t K, bool may_split = true) {
   return res;
 }
 
+// [r6] When does the in-workgroup K-split kernel (gemm_mx_ks.hip.h, one 32x32 tile per workgroup of four waves) take an MXFP4 shape?  Measured against the plans below on
+// M = 1 ... 256 x 14 (N, K) (tools/calib_ks.py, profiles/calib_ks_r6g.txt; GPU-only timing, both sides with caller scratch):
+//   * the tiles must fit one per CU (two workgroups on a CU share its LDS-DMA path: +40 ... +100 %), and
+//   * with a long K (> 24 stages of 256) they must also fill more than half the chip: below that the split-K plans, which spread K over more CUs, are ahead
+//     (N = 4096, K = 14336: M <= 16 8.1-9.1 us split against 9.2-9.4; M = 64 11.4 against 9.8).
+// Where it applies it is 11 ... 30 % faster (N = K = 4096: M <= 64 4.9-5.3 -> 4.1-4.5 us; 8192^2: M <= 32 8.8-11.1 -> 7.4-7.8 us), M = 1 ... 8 included (the LDS-free
+// split-K kernel: 4.55-4.92 us at N = K = 4096).  32x64 tiles: only where 32x32 tiles just overflow the chip and 32x64 nearly fill it (N = 14336: -6 %).
+// Returns the variant (561 / 562) or 0.
+inline int ks_plan(int64_t M, int64_t N, int64_t K) {
+  const int64_t cus = chip_cus(), KT = cdiv(K, 256);
+  const int64_t T32 = cdiv(M, 32) * cdiv(N, 32);
+  if (T32 <= cus && (KT <= 24 || (2 * T32 > cus && KT <= 64))) return 561;   // (K > 16384 was not calibrated, and a split-K plan on larger tiles moves fewer bytes per CU there)
+  const int64_t T64 = cdiv(M, 32) * cdiv(N, 64);
+  if (M <= 32 && T32 > cus && T64 <= cus && 8 * T64 >= 7 * cus && KT <= 24) return 562;
+  return 0;
+}
+
 // a_fmt (MXFP8 only): QAMD_FP8_E4M3 / QAMD_FP8_E5M2 element format of A
 template <int EBITS>
 int gemm_mx(const char* name, const void* A, const void* B, const void* A_sf, const void* B_sf,
@@ -770,6 +815,10 @@ int gemm_mx(const char* name, const void* A, const void* B, const void* A_sf, co
   // [r3] re-measured GPU-only (HIP-graph replays, tools/calib_mx_small.py with CALIB_MS=1,4,8,16,24,32; profiles/calib_mx_decode_graph_r3.txt): the split-K kernel's time
   // grows with M (N = K = 4096: 4.65 us at M = 1, 5.4 at 16, 6.1 at 32) while the 3-deep ring stays at 5.0 -- it keeps M <= 8 (now including N = 8192: 8.9 us against
   // the ring's 10.8 at K = 8192) and M <= 24 only against small weights (N <= 2048: 3.7 against 3.9 us)
+  // [r6] small batches against a weight that fills the chip with 32x32 tiles: the in-workgroup K-split kernel (gemm_mx_ks.hip.h; ks_plan above)
+  if (EBITS == 4 && variant == 0 && !(p.pp_flags & 256)) {
+    if (const int kv = ks_plan(M, N, K)) return dispatch(kv, p, s);
+  }
   const bool skinny_auto = variant == 0 && !can_split && ((M <= 8 && cdiv(N, 64) <= chip_cus() / 2) || (M <= 24 && cdiv(N, 64) <= chip_cus() / 8));
   if (EBITS == 4 && (variant == 60 || (variant >= 44 && variant <= 49) || skinny_auto)) {
     if (dry_record(variant ? variant : 60, p.N, 1)) return 0;
@@ -1012,6 +1061,7 @@ int64_t qutlass_amd_gemm_splitk_workspace_bytes(int ebits, int64_t M, int64_t N,
   if (M <= 0 || N <= 0 || K <= 0 || (ebits != 4 && ebits != 8)) return 0;
   const SmallPlan pl = (ebits == 4) ? plan_small<4>(M, N, K) : plan_small<8>(M, N, K);
   int64_t need = (pl.variant && pl.splits > 1) ? splitk_ws_bytes(pl.variant, M, N, pl.splits) : 0;
+  if (ebits == 4 && opt_gemm_variant() == 0 && !(opt_pp_flags() & 256) && ks_plan(M, N, K)) need = 0;   // [r6] the in-workgroup K-split kernel takes the shape: no scratch
 #if QAMD_BENCH
   if (opt_gemm_variant() == 89) need = std::max<int64_t>(need, sk_ws_bytes(chip_cus()));   // lab: forced stream-K
   if (opt_splitk_force() > 1) need = std::max<int64_t>(need, splitk_ws_bytes(70, M, N, 8));   // lab: room for any forced tile x split

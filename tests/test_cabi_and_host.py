@@ -107,13 +107,15 @@ def test_split_k_workspace_plan_is_a_pure_host_function(lib):
     def layout(m, n, s):   # [s][m][n] fp32 partials
         return s * m * n * 4
 
-    # Llama-3-8B down-proj, batch 64: 64 tiles, KT = 56 stages -> 4 splits of 14 stages (one workgroup per CU)
-    assert splits(4, 64, 4096, 14336) == 4 and ws(4, 64, 4096, 14336) == layout(64, 4096, 4) == 4 * 64 * 4096 * 4
+    # Llama-3-8B down-proj, batch 64: 64 tiles, KT = 56 stages -> 4 splits of 14 stages (one workgroup per CU).  [r6] MXFP4 shapes whose 32x32 tiles fill the chip one
+    # per CU go to the in-workgroup K-split kernel instead (capi.hip ks_plan: no scratch): the MXFP8 twin of this shape still shows the split plan
+    assert splits(4, 64, 4096, 14336) == 4 and ws(4, 64, 4096, 14336) == 0
+    assert splits(8, 64, 4096, 7168) == 4 and ws(8, 64, 4096, 7168) == layout(64, 4096, 4) == 4 * 64 * 4096 * 4
     assert ws(4, 16, 4096, 14336) == layout(16, 4096, splits(4, 16, 4096, 14336))
     assert ws(4, 128, 4096, 14336) == layout(128, 4096, 2)   # 128 tiles: 2 splits
     assert ws(4, 256, 4096, 14336) == 0 and ws(4, 192, 4096, 14336) == 0   # more than 128 tiles: no split
     assert ws(4, 64, 4096, 4096) == 0            # 16 stages: too short to pay for the reduction
-    assert ws(4, 64, 4096, 8192) == layout(64, 4096, 4) and ws(8, 64, 4096, 4096) == layout(64, 4096, 4)   # 32 stages (fp8: K = 4096)
+    assert ws(4, 64, 4096, 8192) == 0 and ws(4, 16, 4096, 8192) == layout(16, 4096, 4) and ws(8, 64, 4096, 4096) == layout(64, 4096, 4)   # 32 stages (fp8: K = 4096); [r6] fp4, M = 64: ks_plan
     assert ws(4, 4096, 4096, 4096) == 0 and ws(4, 0, 4096, 4096) == 0 and ws(5, 64, 4096, 14336) == 0
     for m, n, k in [(8, 512, 28672), (40, 1032, 14464), (1, 64, 12288)]:
         b = ws(4, m, n, k)
@@ -448,6 +450,7 @@ def test_auto_dispatch_rules_dry_run(lib):
         return None if cnt < 0 else [(out[3 * i], out[3 * i + 1], out[3 * i + 2]) for i in range(cnt)]
 
     DEEPP, DEEP, SKINNY, RING64, RING64x128, RING128 = 90, 30, 60, 70, 72, 73
+    KS32, KS32x64 = 561, 562   # [r6] in-workgroup K-split kernel (csrc/gemm_mx_ks.hip.h), 32x32 / 32x64 tiles: MXFP4 shapes whose 32x32 tiles fit one per CU (capi.hip ks_plan)
     big = 1 << 30
     # headline and the other BASELINE configs: 256x256 tiles, the persistent deep schedule (fp4 and fp8);
     # C3 = 3.5 rounds of tiles -> one persistent launch with balanced rounds (224 workgroups x 4 tiles); 1.25 rounds (320 tiles) ->
@@ -470,16 +473,21 @@ def test_auto_dispatch_rules_dry_run(lib):
     assert plan(4, 256, 1 << 22, 128) == [(25, 1 << 22, 1)]          # absurdly wide output: 32-bit tile offsets of the persistent epilogue do not reach
     # decode: LDS-free split-K kernel while the weight has fewer than 128 64-row tiles, ring kernel beyond, 64x128 tiles for huge N
     # [r3] re-measured GPU-only: the split-K kernel up to M = 8 (N <= 8192), up to M = 24 only against small weights (N <= 2048); the ring stays flat in M beyond
-    assert plan(4, 1, 4096, 4096) == [(SKINNY, 4096, 1)] and plan(4, 8, 4096, 4096) == [(SKINNY, 4096, 1)] and plan(4, 8, 8192, 8192) == [(SKINNY, 8192, 1)]
-    assert plan(4, 16, 4096, 4096) == [(RING64, 4096, 1)] and plan(4, 32, 4096, 4096) == [(RING64, 4096, 1)] and plan(4, 24, 2048, 2048) == [(SKINNY, 2048, 1)]
-    assert plan(4, 16, 14336, 4096) == [(RING64, 14336, 1)]
+    # [r6] ... where the in-workgroup K-split kernel does not take the shape: it does whenever the 32x32 tiles fit one per CU and K <= 24 stages of 256 (or they fill
+    # more than half the chip and K <= 16384) -- N = K = 4096: M = 1 ... 64 4.5-5.3 -> 4.1-4.5 us; 32x64 tiles where 32x32 just overflow (N = 14336)
+    assert plan(4, 1, 4096, 4096) == [(KS32, 4096, 1)] and plan(4, 8, 4096, 4096) == [(KS32, 4096, 1)] and plan(4, 8, 8192, 8192) == [(KS32, 8192, 1)]
+    assert plan(4, 16, 4096, 4096) == [(KS32, 4096, 1)] and plan(4, 32, 4096, 4096) == [(KS32, 4096, 1)] and plan(4, 24, 2048, 2048) == [(KS32, 2048, 1)]
+    assert plan(4, 16, 14336, 4096) == [(KS32x64, 14336, 1)]
+    assert plan(4, 1, 4096, 14336) == [(SKINNY, 4096, 1)] and plan(4, 8, 4096, 11008) == [(SKINNY, 4096, 1)]     # long K, half the chip: the split-K kernels keep it
+    assert plan(4, 16, 11008, 4096) == [(RING64, 11008, 1)] and plan(4, 96, 4096, 4096) == [(RING64, 4096, 1)]  # 32x32 tiles would sit two on a CU
     assert plan(4, 16, 57344, 8192) == [(28, 57344, 1)]
     assert plan(8, 16, 4096, 4096) == [(RING64, 4096, 1)]            # no fp8 skinny kernel
     # small outputs: ring schedule; split-K only with caller scratch, <= 128 tiles and >= 32 K stages
-    assert plan(4, 64, 4096, 4096) == [(RING64, 4096, 1)] == plan(4, 64, 4096, 4096, big)
-    assert plan(4, 64, 4096, 14336) == [(RING64, 4096, 1)]
-    assert plan(4, 64, 4096, 14336, big) == [(RING64, 4096, 4)]
-    assert plan(4, 64, 4096, 14336, 64 * 4096 * 4 * 4 - 1) == [(RING64, 4096, 1)]   # scratch one byte short: single pass
+    assert plan(4, 64, 4096, 4096) == [(KS32, 4096, 1)] == plan(4, 64, 4096, 4096, big)
+    assert plan(4, 64, 4096, 14336) == [(KS32, 4096, 1)] == plan(4, 64, 4096, 14336, big)   # [r6] 256 tiles of 32x32, 56 stages: 11.4 us (4 K ranges + reduce) -> 9.8
+    assert plan(8, 64, 4096, 7168) == [(RING64, 4096, 1)]
+    assert plan(8, 64, 4096, 7168, big) == [(RING64, 4096, 4)]
+    assert plan(8, 64, 4096, 7168, 64 * 4096 * 4 * 4 - 1) == [(RING64, 4096, 1)]   # scratch one byte short: single pass
     assert plan(4, 16, 4096, 14336, big) == [(RING64, 4096, 4)]       # beats the skinny kernel when it may split
     assert plan(4, 128, 4096, 14336, big) == [(RING64, 4096, 2)]
     assert plan(4, 128, 4096, 8192, big) == [(RING64, 4096, 1)]       # a two-way split needs >= 48 K stages to pay for its reduce pass

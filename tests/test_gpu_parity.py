@@ -254,7 +254,9 @@ def test_split_k_small_output_long_k(q, m, n, k):
 
     a_q, a_s, b_q, b_s, out = _pipeline(q, m, n, k, "abs_max", seed=m + k)
     expect_split = q._lib.load().qutlass_amd_gemm_splitk_workspace_bytes(4, m, n, k)
-    assert (expect_split > 0) == (k >= 32 * 256 and -(-m // 64) * -(-n // 64) <= 128)
+    t32, kt = -(-m // 32) * -(-n // 32), -(-k // 256)
+    takes_ks = t32 <= 256 and (kt <= 24 or (2 * t32 > 256 and kt <= 64))   # [r6] capi.hip ks_plan: the in-workgroup K-split kernel (no scratch) takes the shape
+    assert (expect_split > 0) == (k >= 32 * 256 and -(-m // 64) * -(-n // 64) <= 128 and not takes_ks)
     asf, bsf, al = to_blocked(a_s), to_blocked(b_s), torch.tensor([1.0], device=DEV)
     with lab.forced(pp_flags=1 | 128):
         single = lab.matmul_mxf4_bf16_tn(a_q, b_q, asf, bsf, al)

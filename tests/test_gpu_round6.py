@@ -249,3 +249,50 @@ def test_duo_kernel_against_the_oracle(variant):
         got = lab.matmul_mxf4_bf16_tn(a, b, sa, sb, alpha)
     ref = oracle.gemm_blockscaled(oracle.KIND_MXFP4, _np(a), _np(b), _np(sa), _np(sb), 1.0, m, n, k)
     assert np.array_equal(_np(got), ref), int((_np(got) != ref).sum())
+
+
+# ------------------------------------------------------------------------------------------------
+# [r6] the in-workgroup K-split kernel (csrc/gemm_mx_ks.hip.h; qutlass/csrc/gemm.cu:195-222, gemm_ada.cu:127-129): every tile / ring depth against the oracle on
+# ragged shapes (M, N not multiples of the tile, K tails of half a stage, fewer stages than the ring is deep), and the product's rule (capi.hip ks_plan) on the
+# shapes it takes -- operands in the exact regime (scale exponents within +-2: every partial sum is exact, any summation order gives the same bits)
+# ------------------------------------------------------------------------------------------------
+def _mx_operands_exact(m, n, k, seed):
+    a, b, sa, sb = _mx_operands(m, n, k, seed)
+    g = torch.Generator(device=DEV).manual_seed(seed + 1)
+    sa = torch.randint(125, 129, sa.shape, dtype=torch.uint8, device=DEV, generator=g)
+    sb = torch.randint(125, 129, sb.shape, dtype=torch.uint8, device=DEV, generator=g)
+    return a, b, sa, sb
+
+
+KS_SHAPES = [(1, 8, 128), (9, 40, 384), (33, 104, 1408), (64, 264, 4096), (100, 72, 640), (31, 4096, 4096), (64, 2048, 8192), (130, 520, 256)]
+
+
+@pytest.mark.parametrize("variant", [561, 562, 563, 564, 565, 566, 567])
+@pytest.mark.parametrize("m,n,k", KS_SHAPES)
+def test_ks_kernel_against_the_oracle(variant, m, n, k):
+    a, b, sa, sb = _mx_operands_exact(m, n, k, m * 7 + n + k)
+    alpha = torch.tensor([0.5], device=DEV)
+    with lab.forced(gemm_variant=variant):
+        got = lab.matmul_mxf4_bf16_tn(a, b, sa, sb, alpha)
+    ref = oracle.gemm_blockscaled(oracle.KIND_MXFP4, _np(a), _np(b), _np(sa), _np(sb), 0.5, m, n, k)
+    bad = _np(got) != ref
+    assert not bad.any(), f"{int(bad.sum())} of {bad.size} outputs differ, first at {np.argwhere(bad)[0].tolist()}"
+
+
+@pytest.mark.parametrize("m,n,k", [(1, 4096, 4096), (8, 8192, 4096), (48, 4096, 4096), (64, 4096, 14336), (16, 14336, 4096), (200, 1024, 2048)])
+def test_product_rule_takes_the_ks_kernel_and_matches_the_oracle(q, m, n, k):
+    """shapes capi.hip's ks_plan sends to the new kernel (tests/test_cabi_and_host.py pins the plan on the CPU), through the product library and the torch op"""
+    a, b, sa, sb = _mx_operands_exact(m, n, k, m + n + k)
+    alpha = torch.tensor([1.0], device=DEV)
+    got = q.matmul_mxf4_bf16_tn(a, b, sa.view(torch.float8_e8m0fnu), sb.view(torch.float8_e8m0fnu), alpha)
+    rows = np.unique(np.linspace(0, m - 1, min(m, 24)).astype(np.int64))
+    cb = (k // 32 + 3) // 4 * 4
+    # the oracle on a sample of rows (their scale rows gathered out of the blocked image)
+    a_rows = _np(a)[rows]
+    sa_img = _np(sa).reshape(-1)
+    def blocked_row(img, r):   # (qutlass/utils.py:60-64) byte (r, c) of the to_blocked image
+        c = np.arange(k // 32)
+        return img[((r // 128) * (cb // 4) + c // 4) * 512 + (r % 32) * 16 + ((r % 128) // 32) * 4 + c % 4]
+    sa_rm = np.stack([blocked_row(sa_img, int(r)) for r in rows])
+    ref = oracle.gemm_blockscaled(oracle.KIND_MXFP4, a_rows, _np(b), oracle.to_blocked(sa_rm), _np(sb), 1.0, len(rows), n, k)
+    assert np.array_equal(_np(got)[rows], ref)
