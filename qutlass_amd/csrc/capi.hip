@@ -227,6 +227,11 @@ int launch_gemm_deepp(GemmParams p, hipStream_t s) {
 #else
   static_assert(!TRACE && LAB == 0, "traces / ablations: lab build only");
 #endif
+  // [r6] an odd number (>= 3) of K stages: the kernel form without the empty stage (gemm_mx_deepp.hip.h ODD)
+  if (const int64_t kt = cdiv((int64_t)p.K * C::EBITS / 8, 128); (kt & 1) && kt >= 3) {
+    hipLaunchKernelGGL((gemm_mx_deepp_kernel<C, ST_AUX, true>), dim3(grid), dim3(C::THREADS), 0, s, p);
+    return check_launch("gemm_mx_deepp_kernel (odd stage count)");
+  }
   hipLaunchKernelGGL((gemm_mx_deepp_kernel<C, ST_AUX>), dim3(grid), dim3(C::THREADS), 0, s, p);
   return check_launch("gemm_mx_deepp_kernel");
 }

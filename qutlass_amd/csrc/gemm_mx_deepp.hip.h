@@ -46,7 +46,10 @@ constexpr int deepp_pair_done_at(int s) { return (s >= 3 && s <= 59 && (s - 3) %
 // file) gives the persistent workgroups the full rounds and runs the residual tiles as 128x128 tiles on other workgroups.
 // DMA_SPREAD: 1 = the product; 2 recomputes the piece offsets mid-stage (one register less; kept for the heterogeneous kernel should it need it again).
 // (Stage traces, timing ablations, the stream-K walk and the retirement experiments of rounds 4-5 live in gemm_mx_deepp_lab.hip.h, lab build only.)
-template <class C, int ST_AUX = 0, int DMA_SPREAD = 1>
+// [r6] ODD: for an ODD number of K stages (>= 3) the tile walk runs without the empty stage -- a tile then starts in the buffer its predecessor's last stage did not use,
+// so consecutive tiles of a workgroup alternate their starting buffer and the last stage exists for either buffer (the tile loop is unrolled twice).  Chosen by the host
+// (K / 256 is known there): the even kernel is unchanged.  K = 11008 (43 stages, qutlass's own test list tests/mxfp4_test.py:194-199): one stage of 44 saved.
+template <class C, int ST_AUX = 0, int DMA_SPREAD = 1, bool ODD = false>
 __device__ __forceinline__ void gemm_mx_deepp(char* smem, const GemmParams& p, const int bid, const int G, const int ntiles) {
   static_assert(C::EBITS == 4 && C::BM == 256 && C::BN == 256 && C::WAVES_M == 2 && C::WAVES_N == 2 && C::NSTAGE == 2 && C::PPW == 2,
                 "persistent deep schedule: fp4, 256x256 tiles, 4 waves of 128x128");
@@ -54,7 +57,7 @@ __device__ __forceinline__ void gemm_mx_deepp(char* smem, const GemmParams& p, c
   constexpr int STAGE = C::STAGE_BYTES, OFF_SCR = DeepPCfg<C>::OFF_SCR;
   GemmCtx<C> cx(smem, p);   // per-lane offsets / LDS addresses; its tile coordinates and descriptors are NOT used here
   const int lane = cx.lane, wave = cx.wave, i32 = cx.i32, g = cx.g;
-  const int KT = cx.KT, KTe = (KT + 1) & ~1, CB = cx.CB, rowbytes = cx.rowbytes;
+  const int KT = cx.KT, KTe = ODD ? KT : (KT + 1) & ~1, CB = cx.CB, rowbytes = cx.rowbytes;
   const int wg = xcd_remap(bid, G);
 
   auto fence = [&]() __attribute__((always_inline)) { __builtin_amdgcn_sched_barrier(0); };
@@ -247,7 +250,7 @@ __device__ __forceinline__ void gemm_mx_deepp(char* smem, const GemmParams& p, c
   //      (c & 8) | ((c & 7) ^ (r & 7)): the 8 lanes of a ds_write_b128 group hit 8 different chunks, the 16 lanes of a
   //      ds_read_b128 group 16 different ones).  Read-back is row-major: lane -> row 8 p + l / 8, columns 8 (l % 8) .. + 7, so
   //      8 lanes cover one whole 128-byte line of D and a wave instruction stores 8 rows x 128 B.
-  char* scr = smem + OFF_SCR + wave * DeepPCfg<C>::SCR_PER_WAVE;
+  char* scr = smem + OFF_SCR + wave * DeepPCfg<C>::SCR_PER_WAVE;   // (the last stage's buffer; ODD: re-pointed per tile by final_stage)
   const int scrW = i32 * 256 + ((((i32 & 6) << 4)) | ((g ^ (i32 & 1)) << 4));   // chunk (2q + g) ^ (row & 7) = this ^ (q << 5); + 128 n'
   const int rrl = lane >> 3, ccl = lane & 7;                                     // read-back: row rrl (+ 8 per pass), columns 8 ccl .. + 7
   const int scrR = rrl * 256 + (ccl >> 2) * 128 + ((((2 * ccl) & 7) ^ (rrl & 7)) << 4);   // chunk 2 ccl of that row; chunk 2 ccl + 1 = this ^ 16
@@ -308,11 +311,13 @@ __device__ __forceinline__ void gemm_mx_deepp(char* smem, const GemmParams& p, c
   // ~5 other instructions hide behind a 32-cycle MFMA; the retirement adds ~7 per slot, its ds_write_b128 from the accumulator registers cost 52 cycles of LDS store path
   // each with four waves writing, and with 256 workgroups the 32 MiB store burst back-pressures the stage by another ~2 us.  Measured and NOT faster (lab copy of this
   // file): bf16 before the transposition (twice the vector instructions: +3 %), block-of-4 MFMA order (no change), the whole retirement behind the MFMAs (+4.5 %).
-  auto final_stage = [&](const Desc& d, bool dvalid, const int ktn) __attribute__((always_inline)) {
-    read_slice(1, 2);
-    read_slice(1, 3);
+  auto final_stage = [&](auto fbc, const Desc& d, bool dvalid, const int ktn) __attribute__((always_inline)) {
+    constexpr int FB = decltype(fbc)::value;   // the buffer this stage lives in (1 unless ODD); the next tile starts in the other one
+    if constexpr (ODD) scr = smem + FB * STAGE + wave * DeepPCfg<C>::SCR_PER_WAVE;
+    read_slice(FB, 2);
+    read_slice(FB, 3);
     fence();
-    mfma1(0, 1, 0, 0, false); mfma1(1, 1, 0, 0, false); mfma1(0, 1, 0, 1, false); mfma1(1, 1, 0, 1, false);
+    mfma1(0, FB, 0, 0, false); mfma1(1, FB, 0, 0, false); mfma1(0, FB, 0, 1, false); mfma1(1, FB, 0, 1, false);
     fence();
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // next tile's stage 0 landed (buffer 0); all reads of buffer 1 done
     __builtin_amdgcn_s_barrier();
@@ -324,16 +329,16 @@ __device__ __forceinline__ void gemm_mx_deepp(char* smem, const GemmParams& p, c
       if constexpr (s < 60) {
         constexpr int T = s < 2 ? 0 : s < 4 ? 1 : 2 + (s - 4) / 4;
         constexpr int j = s < 4 ? 2 + (s & 1) : (s - 4) % 4;
-        mfma1(j, 1, T / 4, T % 4, false);
+        mfma1(j, FB, T / 4, T % 4, false);
       }
       // DMA of the next tile's stage 1 into buffer 1: the B pieces and the scale piece now, one instruction every third
       // slot; the wave's 8 A pieces land in its own scratch area, so they wait until the last read-back (after the loop)
-      if constexpr (s % 3 == 0 && s / 3 < 9) dma_item(d, ktn, 1, 8 + s / 3);
-      if constexpr (s == 1) read_scales(0, 0);
+      if constexpr (s % 3 == 0 && s / 3 < 9) dma_item(d, ktn, FB, 8 + s / 3);
+      if constexpr (s == 1) read_scales(FB ^ 1, FB ^ 1);
       // fragments of the next tile's stage 0, as their registers die: A rows of m after tile (m, 3), B rows of n after (3, n)
-      if constexpr (s == 12 || s == 28 || s == 44) { read_fa(0, 0, (s - 12) / 16); read_fa(0, 1, (s - 12) / 16); }
-      if constexpr (s == 48 || s == 52 || s == 56) { read_fb(0, 0, (s - 48) / 4); read_fb(0, 1, (s - 48) / 4); }
-      if constexpr (s == 60) { read_fa(0, 0, 3); read_fa(0, 1, 3); read_fb(0, 0, 3); read_fb(0, 1, 3); }
+      if constexpr (s == 12 || s == 28 || s == 44) { read_fa(FB ^ 1, 0, (s - 12) / 16); read_fa(FB ^ 1, 1, (s - 12) / 16); }
+      if constexpr (s == 48 || s == 52 || s == 56) { read_fb(FB ^ 1, 0, (s - 48) / 4); read_fb(FB ^ 1, 1, (s - 48) / 4); }
+      if constexpr (s == 60) { read_fa(FB ^ 1, 0, 3); read_fa(FB ^ 1, 1, 3); read_fb(FB ^ 1, 0, 3); read_fb(FB ^ 1, 1, 3); }
       // retirement items due in this slot; pair P (final at e = 8 P + 3):   write e+1 | read rows 0-15 e+3 | stores e+5, e+6 | read rows 16-31 e+7 | stores e+9, e+10
       constexpr int d1 = s - 1, d3 = s - 3, d5 = s - 5, d6 = s - 6, d7 = s - 7, d9 = s - 9, d10 = s - 10;
       if constexpr (deepp_pair_done_at(d5) >= 0) retire_store(deepp_pair_done_at(d5) / 2, deepp_pair_done_at(d5) % 2, 0);
@@ -348,7 +353,7 @@ __device__ __forceinline__ void gemm_mx_deepp(char* smem, const GemmParams& p, c
     // the wave's own A pieces of the next tile's stage 1 overwrite its scratch: its read-backs must have returned first
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
-    for (int i = 0; i < 8; ++i) dma_item(d, ktn, 1, i);
+    for (int i = 0; i < 8; ++i) dma_item(d, ktn, FB, i);
     fence();
   };
 
@@ -370,6 +375,7 @@ __device__ __forceinline__ void gemm_mx_deepp(char* smem, const GemmParams& p, c
   read_slice(0, 1);
   fence();
 
+  if constexpr (!ODD) {
   while (tile < ntiles) {
     int m0, n0;
     decode(tile, m0, n0);
@@ -395,9 +401,38 @@ __device__ __forceinline__ void gemm_mx_deepp(char* smem, const GemmParams& p, c
       stage(I1{}, BF{}, cur, kt + 2, true);
       stage(I0{}, BF{}, nxt, 0, nvalid);
     }
-    final_stage(nxt, nvalid, 1);
+    final_stage(I1{}, nxt, nvalid, 1);
     cur = nxt;
     tile = tnext;
+  }
+  } else {
+    // ODD (KT = 3, 5, 7, ...): a tile whose first stage sits in buffer P ends in buffer P (its last stage has an even index); the next tile starts in P ^ 1.
+    // Stage kt of a tile issues the DMA of stage kt + 2 -- stage KT - 2 that of the next tile's stage 0, the last stage that of its stage 1, each into its own buffer.
+    auto tile_body = [&](auto pc) __attribute__((always_inline)) {
+      using P0 = decltype(pc);
+      using P1 = std::integral_constant<int, P0::value ^ 1>;
+      int m0, n0;
+      decode(tile, m0, n0);
+      set_out_tile(m0, n0);
+      const int tnext = tile + G;
+      const Desc nxt = make_desc(tnext);
+      const bool nvalid = tnext < ntiles;
+      stage(P0{}, BT{}, cur, 2, true);
+      int kt = 1;
+      for (; kt + 2 <= KT - 2; kt += 2) {
+        stage(P1{}, BF{}, cur, kt + 2, true);
+        stage(P0{}, BF{}, cur, kt + 3, true);
+      }
+      stage(P1{}, BF{}, nxt, 0, nvalid);   // stage KT - 2
+      final_stage(P0{}, nxt, nvalid, 1);
+      cur = nxt;
+      tile = tnext;
+    };
+    while (tile < ntiles) {
+      tile_body(I0{});
+      if (tile >= ntiles) break;
+      tile_body(I1{});
+    }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
@@ -757,12 +792,12 @@ __global__ __launch_bounds__(C::THREADS) void gemm_mx_deepp8_kernel(const GemmPa
   gemm_mx_deepp8<C, ST_AUX, NN>(smem, p, (int)blockIdx.x, (int)gridDim.x, p.tiles_m * p.tiles_n);
 }
 
-template <class C, int ST_AUX = 0>
+template <class C, int ST_AUX = 0, bool ODD = false>
 __global__ __launch_bounds__(C::THREADS) void gemm_mx_deepp_kernel(const GemmParams p) {
   __shared__ __attribute__((aligned(16))) char smem[DeepPCfg<C>::LDS_BYTES];
   // every argument the prologue needs is asked for HERE: the scalar loads leave together and are waited for once (left alone they arrive in four dependent rounds)
   asm volatile("" :: "s"(p.A), "s"(p.D), "s"(p.K), "s"(p.b_bytes), "s"((int)gridDim.x));
-  gemm_mx_deepp<C, ST_AUX>(smem, p, (int)blockIdx.x, (int)gridDim.x, p.tiles_m * p.tiles_n);
+  gemm_mx_deepp<C, ST_AUX, 1, ODD>(smem, p, (int)blockIdx.x, (int)gridDim.x, p.tiles_m * p.tiles_n);
 }
 
 // -------------------------------------------------------------------------------------------------------------------------

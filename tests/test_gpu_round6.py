@@ -296,3 +296,29 @@ def test_product_rule_takes_the_ks_kernel_and_matches_the_oracle(q, m, n, k):
     sa_rm = np.stack([blocked_row(sa_img, int(r)) for r in rows])
     ref = oracle.gemm_blockscaled(oracle.KIND_MXFP4, a_rows, _np(b), oracle.to_blocked(sa_rm), _np(sb), 1.0, len(rows), n, k)
     assert np.array_equal(_np(got)[rows], ref)
+
+
+# ------------------------------------------------------------------------------------------------
+# [r6] an ODD number of K stages in the persistent 4-wave kernel (gemm_mx_deepp.hip.h ODD; K = 11008 is in the reference's own shape list, tests/mxfp4_test.py:194-199):
+# no empty stage any more -- tiles alternate their starting LDS buffer, so the walk is forced onto FEW workgroups (lab option deepp_grid) to make every workgroup
+# run tiles of both parities, and compared with the ring kernel (another schedule, same K order) and the oracle
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("m,n,k,grid", [(512, 768, 768, 2), (512, 768, 1280, 1), (700, 520, 3840, 3), (1024, 1024, 11008, 5), (4096, 4096, 3840, 0), (256, 256, 11008 + 128, 1)])
+def test_persistent_kernel_with_an_odd_number_of_k_stages(m, n, k, grid):
+    a, b, sa, sb = _mx_operands(m, n, k, m + n + k)
+    alpha = torch.tensor([0.75], device=DEV)
+    with lab.forced(gemm_variant=73):
+        ref = lab.matmul_mxf4_bf16_tn(a, b, sa, sb, alpha)
+    with lab.forced(gemm_variant=90, deepp_grid=grid):
+        got = lab.matmul_mxf4_bf16_tn(a, b, sa, sb, alpha)
+    torch.cuda.synchronize()
+    bad = got.view(torch.int16) != ref.view(torch.int16)
+    assert not bad.any(), f"{int(bad.sum())} of {bad.numel()} outputs differ, first at {bad.nonzero()[0].tolist()}"
+    if m * n <= 1 << 20:
+        a2, b2, sa2, sb2 = _mx_operands_exact(m, n, k, 3)
+        with lab.forced(gemm_variant=90, deepp_grid=grid):
+            got2 = lab.matmul_mxf4_bf16_tn(a2, b2, sa2, sb2, alpha)
+        rows = slice(0, min(m, 40))
+        cb = (k // 32 + 3) // 4 * 4
+        ref2 = oracle.gemm_blockscaled(oracle.KIND_MXFP4, _np(a2), _np(b2), _np(sa2), _np(sb2), 0.75, m, n, k)
+        assert np.array_equal(_np(got2), ref2)
