@@ -310,6 +310,12 @@ int launch_gemm_hetero(GemmParams p, hipStream_t s) {
     if constexpr (CB::EBITS == 4) return launch_gemm_deepp<CB, false, ST_AUX>(p, s);
     else return launch_gemm_deepp8<CB>(p, s);
   }
+  if constexpr (CB::EBITS == 4) {   // [r6] odd number of K stages: the persistent workgroups run without the empty stage
+    if (const int64_t kt = cdiv((int64_t)p.K, 256); (kt & 1) && kt >= 3) {
+      hipLaunchKernelGGL((gemm_mx_hetero_kernel<CB, CT, ST_AUX, true>), dim3(g_big + nsmall), dim3(256), 0, s, p, g_big, t_main);
+      return check_launch("gemm_mx_hetero_kernel (odd stage count)");
+    }
+  }
   hipLaunchKernelGGL((gemm_mx_hetero_kernel<CB, CT, ST_AUX>), dim3(g_big + nsmall), dim3(256), 0, s, p, g_big, t_main);
   return check_launch("gemm_mx_hetero_kernel");
 }

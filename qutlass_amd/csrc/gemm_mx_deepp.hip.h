@@ -813,7 +813,7 @@ __global__ __launch_bounds__(C::THREADS) void gemm_mx_deepp_kernel(const GemmPar
 // exactly one workgroup in the same K order, so the result is bit-identical to every other schedule.
 // Reference counterpart: the M-bucketed tile choice + CUTLASS tile scheduler of qutlass/csrc/gemm.cu:195-222.
 // -------------------------------------------------------------------------------------------------------------------------
-template <class CB, class CT, int ST_AUX = 0>
+template <class CB, class CT, int ST_AUX = 0, bool ODD = false>   // ODD: the persistent workgroups' form for an odd number of K stages (fp4 only)
 __global__ __launch_bounds__(256) void gemm_mx_hetero_kernel(const GemmParams p, const int g_big, const int t_main) {
   static_assert(CB::THREADS == 256 && CT::THREADS == 256 && CT::BM == 128 && CT::BN == 128 && CB::EBITS == CT::EBITS && CB::AFMT == CT::AFMT, "tile pair");
   constexpr int LDS = DeepPCfg<CB>::LDS_BYTES > CT::LDS_BYTES ? DeepPCfg<CB>::LDS_BYTES : CT::LDS_BYTES;
@@ -825,7 +825,7 @@ __global__ __launch_bounds__(256) void gemm_mx_hetero_kernel(const GemmParams p,
   asm volatile("" :: "s"(p.A), "s"(p.D), "s"(p.K), "s"(p.b_bytes), "s"(g_big), "s"(t_main));   // (all scalar argument loads in one round, as in gemm_mx_deepp_kernel)
   const int b = (int)blockIdx.x;
   if (b < g_big) {
-    if constexpr (CB::EBITS == 4) gemm_mx_deepp<CB, ST_AUX>(smem, p, b, g_big, t_main);
+    if constexpr (CB::EBITS == 4) gemm_mx_deepp<CB, ST_AUX, 1, ODD>(smem, p, b, g_big, t_main);
     else gemm_mx_deepp8<CB, ST_AUX>(smem, p, b, g_big, t_main);
     return;
   }

@@ -303,7 +303,8 @@ def test_product_rule_takes_the_ks_kernel_and_matches_the_oracle(q, m, n, k):
 # no empty stage any more -- tiles alternate their starting LDS buffer, so the walk is forced onto FEW workgroups (lab option deepp_grid) to make every workgroup
 # run tiles of both parities, and compared with the ring kernel (another schedule, same K order) and the oracle
 # ------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("m,n,k,grid", [(512, 768, 768, 2), (512, 768, 1280, 1), (700, 520, 3840, 3), (1024, 1024, 11008, 5), (4096, 4096, 3840, 0), (256, 256, 11008 + 128, 1)])
+@pytest.mark.parametrize("m,n,k,grid", [(512, 768, 768, 2), (512, 768, 1280, 1), (700, 520, 3840, 3), (1024, 1024, 11008, 5), (4096, 4096, 3840, 0), (256, 256, 11008 + 128, 1),
+                                         (4096, 5120, 1280, 0), (2304, 1024, 768, 8)])   # (the last two with variant 98 too: the heterogeneous launch)
 def test_persistent_kernel_with_an_odd_number_of_k_stages(m, n, k, grid):
     a, b, sa, sb = _mx_operands(m, n, k, m + n + k)
     alpha = torch.tensor([0.75], device=DEV)
@@ -314,6 +315,10 @@ def test_persistent_kernel_with_an_odd_number_of_k_stages(m, n, k, grid):
     torch.cuda.synchronize()
     bad = got.view(torch.int16) != ref.view(torch.int16)
     assert not bad.any(), f"{int(bad.sum())} of {bad.numel()} outputs differ, first at {bad.nonzero()[0].tolist()}"
+    if (m, n) in ((4096, 5120), (2304, 1024)):   # persistent workgroups + residual quarter tiles in one grid
+        with lab.forced(gemm_variant=98, deepp_grid=grid):
+            het = lab.matmul_mxf4_bf16_tn(a, b, sa, sb, alpha)
+        assert torch.equal(het.view(torch.int16), ref.view(torch.int16))
     if m * n <= 1 << 20:
         a2, b2, sa2, sb2 = _mx_operands_exact(m, n, k, 3)
         with lab.forced(gemm_variant=90, deepp_grid=grid):
