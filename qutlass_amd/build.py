@@ -30,9 +30,14 @@ def _header() -> str:
     return HEADER if os.path.exists(HEADER) or not os.path.exists(inpkg) else inpkg
 
 
-def _kernel_sources():
+def _kernel_sources(lab: bool = False):
+    """sources of libqutlass_amd.so; lab: + csrc/lab/ (read by the -DQAMD_BENCH=1 build only; an installed copy does not carry that directory)"""
     d = os.path.join(_HERE, "csrc")
-    return [os.path.join(d, f) for f in sorted(os.listdir(d)) if f != "torch_ext.cpp"] + [_header()]
+    out = [os.path.join(d, f) for f in sorted(os.listdir(d)) if f != "torch_ext.cpp" and os.path.isfile(os.path.join(d, f))] + [_header()]
+    ld = os.path.join(d, "lab")
+    if lab and os.path.isdir(ld):
+        out += [os.path.join(ld, f) for f in sorted(os.listdir(ld))]
+    return out
 
 
 def _stale(out, sources) -> bool:
@@ -101,7 +106,7 @@ def build_kernels(force: bool = False, verbose: bool = False) -> str:
 
 def build_bench_lib(force: bool = False, verbose: bool = False) -> str:
     """The lab library (test / bench infrastructure, see the module docstring)."""
-    if force or _stale(BENCH_OUT, _kernel_sources()):
+    if force or _stale(BENCH_OUT, _kernel_sources(lab=True)):
         _compile_units(BENCH_OUT, UNITS_BENCH, ["-DQAMD_BENCH=1"], verbose)
     return BENCH_OUT
 

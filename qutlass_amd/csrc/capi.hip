@@ -11,9 +11,9 @@
 #include "../../include/qutlass_amd.h"
 #include "gemm_mx.hip.h"
 #include "gemm_mx_deepp.hip.h"
-#include "gemm_mx_duo.hip.h"
-#if QAMD_BENCH
-#include "gemm_mx_deepp_lab.hip.h"   // the lab copy (namespace qamd::labk): traces, ablations, stream-K, retirement experiments
+#if QAMD_BENCH   // csrc/lab/: sources of the LAB library only -- not read by the product build, not shipped by setup.py
+#include "lab/gemm_mx_duo.hip.h"         // [r6] the 8-wave persistent kernel (built, bit-identical, slower under the power cap: DESIGN.md section 7)
+#include "lab/gemm_mx_deepp_lab.hip.h"   // the lab copy (namespace qamd::labk): traces, ablations, stream-K, retirement experiments
 #endif
 #include "gemm_mx_skinny.hip.h"
 #include "gemm_mx_ks.hip.h"
@@ -25,7 +25,7 @@
 #include "transpose_u8.hip.h"
 #include "quartet_bwd.hip.h"
 #if QAMD_BENCH
-#include "quartet_bwd_lab.hip.h"     // backward_qt_bf16's whole-line panel kernel (built, bit-identical, not faster)
+#include "lab/quartet_bwd_lab.hip.h"     // backward_qt_bf16's whole-line panel kernel (built, bit-identical, not faster)
 #endif
 
 using namespace qamd;
@@ -236,7 +236,8 @@ int launch_gemm_deepp(GemmParams p, hipStream_t s) {
   return check_launch("gemm_mx_deepp_kernel");
 }
 
-// [r6] the 8-wave persistent schedule (gemm_mx_duo.hip.h): same grid rule, 144 KiB of static LDS.  RET: retirement placement (0 burst, 1 behind the last k-slice)
+#if QAMD_BENCH
+// [r6] the 8-wave persistent schedule (lab/gemm_mx_duo.hip.h): same grid rule, 144 KiB of static LDS.  RET: retirement placement (0 burst, 1 behind the last k-slice)
 template <class C, int ST_AUX = 17, int RET = 0, bool TRACE = false>
 int launch_gemm_duo(GemmParams p, hipStream_t s) {
   p.tiles_m = (int)cdiv(p.M, C::BM);
@@ -247,6 +248,7 @@ int launch_gemm_duo(GemmParams p, hipStream_t s) {
   hipLaunchKernelGGL((gemm_mx_duo_kernel<C, ST_AUX, RET, TRACE>), dim3(grid), dim3(C::THREADS), 0, s, p);
   return check_launch("gemm_mx_duo_kernel");
 }
+#endif
 
 // [r6] small-batch kernel with the K split inside the workgroup (gemm_mx_ks.hip.h): one 32x32 / 32x64 / 64x32 tile per workgroup of four waves
 template <int TM, int TN, int D = 8>

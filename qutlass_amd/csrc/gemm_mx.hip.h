@@ -30,7 +30,7 @@
 //                                                  heterogeneous launch
 //                 gemm_mx_deepp / gemm_mx_deepp8   (gemm_mx_deepp.hip.h) persistent 256x256 kernels, fp4 / fp8 (+ the (K, M) operand of matmul_mxf8_bf16_nn)
 //                 gemm_mx_skinny_kernel            (gemm_mx_skinny.hip.h) LDS-free split-K kernel for M <= 32
-//       LAB ONLY  gemm_mx_lab.hip.h (-DQAMD_BENCH=1): lockstep / ping-pong / queue / simple / per-tile deep / regstage / un-pipelined ring -- kept
+//       LAB ONLY  lab/gemm_mx_lab.hip.h (-DQAMD_BENCH=1): lockstep / ping-pong / queue / simple / per-tile deep / regstage / un-pipelined ring -- kept
 //                                                  selectable ("gemm_variant") because their measurements are part of the design record
 #pragma once
 #include <type_traits>
@@ -594,9 +594,9 @@ struct GemmCtx {
 };
 
 // The round-1 / alternative schedules (lockstep, ping-pong, queue, simple, per-tile deep, regstage, un-pipelined ring) live in
-// gemm_mx_lab.hip.h and exist in the lab build only; what follows is what the product library ships.
+// lab/gemm_mx_lab.hip.h and exist in the lab build only; what follows is what the product library ships.
 #if QAMD_BENCH
-#include "gemm_mx_lab.hip.h"
+#include "lab/gemm_mx_lab.hip.h"
 #endif
 
 // ================================================================================================

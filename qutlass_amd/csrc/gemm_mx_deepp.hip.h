@@ -45,7 +45,7 @@ constexpr int deepp_pair_done_at(int s) { return (s >= 3 && s <= 59 && (s - 3) %
 // raster).  A plain launch passes blockIdx.x / gridDim.x / all tiles; the heterogeneous launch (gemm_mx_hetero_kernel, end of this
 // file) gives the persistent workgroups the full rounds and runs the residual tiles as 128x128 tiles on other workgroups.
 // DMA_SPREAD: 1 = the product; 2 recomputes the piece offsets mid-stage (one register less; kept for the heterogeneous kernel should it need it again).
-// (Stage traces, timing ablations, the stream-K walk and the retirement experiments of rounds 4-5 live in gemm_mx_deepp_lab.hip.h, lab build only.)
+// (Stage traces, timing ablations, the stream-K walk and the retirement experiments of rounds 4-5 live in lab/gemm_mx_deepp_lab.hip.h, lab build only.)
 // [r6] ODD: for an ODD number of K stages (>= 3) the tile walk runs without the empty stage -- a tile then starts in the buffer its predecessor's last stage did not use,
 // so consecutive tiles of a workgroup alternate their starting buffer and the last stage exists for either buffer (the tile loop is unrolled twice).  Chosen by the host
 // (K / 256 is known there): the even kernel is unchanged.  K = 11008 (43 stages, qutlass's own test list tests/mxfp4_test.py:194-199): one stage of 44 saved.

@@ -4,8 +4,8 @@
 // QAMD_FS_ABL), the NN-operand ablations of the fp8 twin.  The PRODUCT header carries none of this: an experiment edits this file and cannot change a byte of
 // libqutlass_amd.so (tests/test_cabi_and_host.py::test_product_build_does_not_see_the_lab_sources).  History and measurements: docs/history.md, profiles/.
 #pragma once
-#include "gemm_mx.hip.h"
-#include "streamk.hip.h"
+#include "../gemm_mx.hip.h"
+#include "../streamk.hip.h"
 
 namespace qamd {
 namespace labk {

@@ -23,7 +23,7 @@
 //     whichever is done first.
 // Same products, same K order per output as every other schedule: bit-identical results (tests/test_gpu_round6.py, tools/full_compare.py).
 #pragma once
-#include "gemm_mx.hip.h"
+#include "../gemm_mx.hip.h"
 
 namespace qamd {
 

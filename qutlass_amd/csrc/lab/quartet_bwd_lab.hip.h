@@ -1,7 +1,7 @@
 // LAB ONLY (-DQAMD_BENCH=1): QAT-backward kernels that were built, are bit-identical to the product kernels and are NOT faster.  The product translation units do not read
 // this file (tests/test_cabi_and_host.py: test_product_build_does_not_see_the_lab_sources).
 #pragma once
-#include "quartet_bwd.hip.h"
+#include "../quartet_bwd.hip.h"
 
 namespace qamd {
 

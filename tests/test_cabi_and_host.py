@@ -822,13 +822,13 @@ def test_xcd_tile_blocks_fetch_within_six_percent_of_the_whole_tile_optimum(lib)
 
 
 def test_product_build_does_not_see_the_lab_sources():
-    """[r5] The experiments on the persistent kernels (stage traces, ablations, stream-K, the retirement variants) live in csrc/gemm_mx_deepp_lab.hip.h and csrc/gemm_mx_lab.hip.h;
+    """[r5] The experiments on the persistent kernels (stage traces, ablations, stream-K, the retirement variants) live in csrc/lab/ (gemm_mx_deepp_lab.hip.h, gemm_mx_lab.hip.h, ...);
     the product translation units must not even read them, so a lab-only edit cannot change a byte of libqutlass_amd.so.  Checked on the preprocessor's
     own file list (hipcc -E of the product build): none of the lab headers is a dependency -- and the lab build does read them."""
     import subprocess
     from qutlass_amd import build
     src = os.path.join(ROOT, "qutlass_amd", "csrc", "capi.hip")
-    lab_headers = ("gemm_mx_deepp_lab.hip.h", "gemm_mx_lab.hip.h", "quartet_bwd_lab.hip.h")
+    lab_headers = ("gemm_mx_deepp_lab.hip.h", "gemm_mx_lab.hip.h", "quartet_bwd_lab.hip.h", "gemm_mx_duo.hip.h")   # [r6] all under csrc/lab/, which setup.py does not ship
     def deps(unit, extra):   # the files the preprocessor read (its line markers): one unit is enough per build -- every unit includes the same headers
         import tempfile
         with tempfile.TemporaryDirectory() as td:

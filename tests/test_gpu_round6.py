@@ -206,7 +206,7 @@ def test_compiled_callers_return_the_eager_bytes(q):
 
 
 # ------------------------------------------------------------------------------------------------
-# [r6] the 8-wave persistent MXFP4 kernel (csrc/gemm_mx_duo.hip.h; qutlass/csrc/gemm.cu:174-248): same products, same K order -> the SAME bits as the 4-wave
+# [r6] the 8-wave persistent MXFP4 kernel (csrc/lab/gemm_mx_duo.hip.h, LAB library only; qutlass/csrc/gemm.cu:174-248): same products, same K order -> the SAME bits as the 4-wave
 # persistent kernel and every other schedule, on full tiles, ragged edges, K tails, odd stage counts, one tile and several tiles per workgroup
 # ------------------------------------------------------------------------------------------------
 import _benchlib as lab  # noqa: E402  (the LAB library: test infrastructure)

@@ -7,7 +7,7 @@ gpu_session.sh steps ablib* / abpairs with AB_OLD / AB_NEW / AB_PAIRS):
     gpurun -- 'AB_DATA=zero python tools/ab_lib_gemm.py qutlass_amd/libqutlass_amd.so build/exp/lab_base.so build/exp/lab_splitb.so'
 
 (build/ is git-ignored and travels to the GPU box with the snapshot.)  Product switches that exist for this: QAMD_CTX_MAGIC_DECODE, QAMD_RING_KERNARG_EARLY /
-QAMD_NV_KERNARG_EARLY (per-tile MX / NVFP4 kernels).  The persistent kernels' experiments ([r5]) live in the lab copy (csrc/gemm_mx_deepp_lab.hip.h: QAMD_DEEPP_SPLITB,
+QAMD_NV_KERNARG_EARLY (per-tile MX / NVFP4 kernels).  The persistent kernels' experiments ([r5]) live in the lab copy (csrc/lab/gemm_mx_deepp_lab.hip.h: QAMD_DEEPP_SPLITB,
 QAMD_DEEPP_RETIRE, QAMD_DEEPP8_RETIRE, QAMD_DEEPP_FS_IL, QAMD_FS_BURST, QAMD_FS_ABL, QAMD_DEEPP_RB2, QAMD_DEEPP_SOFF, QAMD_KERNARG_EARLY, QAMD_DEEPP_PEEL,
 QAMD_DEEPP_EARLYPREP): `--lab -DQAMD_ROUTE_LABK` makes the plain matmul_mxf4_bf16_tn entry of a lab build run that copy (a `lab_base.so` built with the routing flag alone
 is the control).  `AB_DATA=zero` times the schedules in cycles (no data-dependent power: tools/power_data_probe.py)."""

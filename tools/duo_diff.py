@@ -1,4 +1,4 @@
-"""Where does a lab variant of the MXFP4 GEMM disagree with the product's persistent kernel?  (debugging aid for csrc/gemm_mx_duo.hip.h)
+"""Where does a lab variant of the MXFP4 GEMM disagree with the product's persistent kernel?  (debugging aid for csrc/lab/gemm_mx_duo.hip.h)
     python tools/duo_diff.py 88 256x256x512"""
 import os, sys
 import torch
