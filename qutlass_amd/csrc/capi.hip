@@ -227,12 +227,14 @@ int launch_gemm_deepp(GemmParams p, hipStream_t s) {
 #else
   static_assert(!TRACE && LAB == 0, "traces / ablations: lab build only");
 #endif
-  // [r6] an odd number (>= 3) of K stages: the kernel form without the empty stage (gemm_mx_deepp.hip.h ODD)
-  if (const int64_t kt = cdiv((int64_t)p.K * C::EBITS / 8, 128); (kt & 1) && kt >= 3) {
-    hipLaunchKernelGGL((gemm_mx_deepp_kernel<C, ST_AUX, true>), dim3(grid), dim3(C::THREADS), 0, s, p);
-    return check_launch("gemm_mx_deepp_kernel (odd stage count)");
-  }
-  hipLaunchKernelGGL((gemm_mx_deepp_kernel<C, ST_AUX>), dim3(grid), dim3(C::THREADS), 0, s, p);
+  // [r6] two host-side choices of the kernel form (gemm_mx_deepp.hip.h): ODD -- an odd number (>= 3) of K stages runs without the empty stage; ONETILE -- every workgroup
+  // walks exactly one tile (grid == tile count), so nothing is prefetched for a next tile
+  const int64_t kt = cdiv((int64_t)p.K * C::EBITS / 8, 128);
+  const bool odd = (kt & 1) && kt >= 3, one = grid == p.tiles_m * p.tiles_n;
+  if (odd && one) hipLaunchKernelGGL((gemm_mx_deepp_kernel<C, ST_AUX, true, true>), dim3(grid), dim3(C::THREADS), 0, s, p);
+  else if (odd) hipLaunchKernelGGL((gemm_mx_deepp_kernel<C, ST_AUX, true, false>), dim3(grid), dim3(C::THREADS), 0, s, p);
+  else if (one) hipLaunchKernelGGL((gemm_mx_deepp_kernel<C, ST_AUX, false, true>), dim3(grid), dim3(C::THREADS), 0, s, p);
+  else hipLaunchKernelGGL((gemm_mx_deepp_kernel<C, ST_AUX>), dim3(grid), dim3(C::THREADS), 0, s, p);
   return check_launch("gemm_mx_deepp_kernel");
 }
 

@@ -49,7 +49,11 @@ constexpr int deepp_pair_done_at(int s) { return (s >= 3 && s <= 59 && (s - 3) %
 // [r6] ODD: for an ODD number of K stages (>= 3) the tile walk runs without the empty stage -- a tile then starts in the buffer its predecessor's last stage did not use,
 // so consecutive tiles of a workgroup alternate their starting buffer and the last stage exists for either buffer (the tile loop is unrolled twice).  Chosen by the host
 // (K / 256 is known there): the even kernel is unchanged.  K = 11008 (43 stages, qutlass's own test list tests/mxfp4_test.py:194-199): one stage of 44 saved.
-template <class C, int ST_AUX = 0, int DMA_SPREAD = 1, bool ODD = false>
+// [r6] ONETILE: every workgroup walks exactly one tile (grid == tile count: 4096^3 on 256 CUs) -- chosen by the host.  Nothing follows a tile then, so everything the
+// walk does FOR THE NEXT TILE is compiled out: the 17 LDS-DMA items of "its stage 0" (stage KT - 2) and "its stage 1" (last stage) -- out-of-range descriptors, zero fill,
+// but each still takes its issue slot and its pass through the address unit -- and the 34 LDS reads of "its first fragments" in the last stage.  (As a run-time arm of
+// the one kernel the second copy of the last stage cost 107 spilled registers; as its own instantiation the kernel needs 176 + 256.)
+template <class C, int ST_AUX = 0, int DMA_SPREAD = 1, bool ODD = false, bool ONETILE = false>
 __device__ __forceinline__ void gemm_mx_deepp(char* smem, const GemmParams& p, const int bid, const int G, const int ntiles) {
   static_assert(C::EBITS == 4 && C::BM == 256 && C::BN == 256 && C::WAVES_M == 2 && C::WAVES_N == 2 && C::NSTAGE == 2 && C::PPW == 2,
                 "persistent deep schedule: fp4, 256x256 tiles, 4 waves of 128x128");
@@ -169,9 +173,10 @@ __device__ __forceinline__ void gemm_mx_deepp(char* smem, const GemmParams& p, c
 
   // ---- one K stage (not the last of its tile).  Entry: fragment sets 0, 1 and scale set BUF hold slices 0, 1 of this
   //      stage; exit: the same for the next stage (other buffer).  The DMA threaded through M(2) is stage (d, ktl).
-  auto stage = [&](auto bufc, auto firstc, const Desc& d, int ktl, bool dvalid) __attribute__((always_inline)) {
+  auto stage = [&](auto bufc, auto firstc, const Desc& d, int ktl, bool dvalid, auto dmac) __attribute__((always_inline)) {
     constexpr int BUF = decltype(bufc)::value;
     constexpr bool FIRST = decltype(firstc)::value;
+    constexpr bool DMA = decltype(dmac)::value;   // false (ONETILE, stage KT - 2): the stage's DMA would be the next tile's stage 0
     // [r3] ONE fragment read behind each MFMA instead of a burst of 8 in front of 16 MFMAs.  With one wave per SIMD the wave's own program order
     // is all that can put a read into an MFMA's shadow: after a run of MFMAs the matrix pipe drains while the 8 reads issue -- 82 cycles per 8
     // MFMAs (tests/native/ubench.hip "uinter": 8 MFMA + 6 reads in bursts 350 cycles, interleaved 276, MFMAs alone 268; on quantised-Gaussian
@@ -216,7 +221,7 @@ __device__ __forceinline__ void gemm_mx_deepp(char* smem, const GemmParams& p, c
     // barrier and group 2's first MFMA (neither depends on the hand-off)
     group(1, false, [&](const int i) __attribute__((always_inline)) {
       if (i < MT + NT) read_frag(3, i);
-      if (i == 12) dma_prep(ktl, dvalid);
+      if (DMA && i == 12) dma_prep(ktl, dvalid);
       if (i == 14) read_base(BUF ^ 1, 0);
     });
     // ([r5] With the whole chip streaming every wave waits ~300 - 440 cycles here for its own pieces (tools/handoff_trace.py, profiles/handoff_trace_r5q.txt; 8 cycles with 8
@@ -229,7 +234,8 @@ __device__ __forceinline__ void gemm_mx_deepp(char* smem, const GemmParams& p, c
     // [r4] the stage's 17 DMA items ride in the slots that have no fragment read: second half of group 2 (items 0 .. 7 + the scale piece) and second half
     // of group 3 (items 8 .. 15) -- all 17 behind the first 16 MFMAs after the hand-off put three auxiliary instructions into each of eight slots
     group(2, false, [&](const int i) __attribute__((always_inline)) {
-      if (!DMA_SPREAD) { dma_item(d, ktl, BUF, i); if (i == 0) dma_item(d, ktl, BUF, 16); }
+      if (!DMA) {}
+      else if (!DMA_SPREAD) { dma_item(d, ktl, BUF, i); if (i == 0) dma_item(d, ktl, BUF, 16); }
       else if (i >= 8) { dma_item(d, ktl, BUF, i - 8); if (i == 8) dma_item(d, ktl, BUF, 16); }
       // the next stage's slice 0 (set 0 went dead with group 0) and its scale dwords
       if (i < MT + NT) read_frag(0, i);
@@ -238,9 +244,9 @@ __device__ __forceinline__ void gemm_mx_deepp(char* smem, const GemmParams& p, c
     read_base(BUF ^ 1, 1);
     group(3, false, [&](const int i) __attribute__((always_inline)) {
       if (i < MT + NT) read_frag(1, i);
-      if (DMA_SPREAD == 2 && i == 8) dma_prep(ktl, dvalid);   // (2: the piece offsets are recomputed here instead of staying live through this group's fragment reads -- one register less,
+      if (DMA && DMA_SPREAD == 2 && i == 8) dma_prep(ktl, dvalid);   // (2: the piece offsets are recomputed here instead of staying live through this group's fragment reads -- one register less,
                                                                //  which the heterogeneous kernel needs; costs the plain kernel ~1 %, profiles/ab_lib_gemm_r4at_reprep.txt)
-      if (DMA_SPREAD && i >= 8) dma_item(d, ktl, BUF, i);
+      if (DMA && DMA_SPREAD && i >= 8) dma_item(d, ktl, BUF, i);
     });
     if constexpr (FIRST) pin_acc();
   };
@@ -286,6 +292,8 @@ __device__ __forceinline__ void gemm_mx_deepp(char* smem, const GemmParams& p, c
   //  which the compiler does not guard -- tests/native/store_hazard_probe.hip, profiles/store_hazard_probe_r5.txt; tools/store_data_hazard.py scans the ISA, a CPU test)
   auto retire_store = [&](const int m, const int h, const int pass) __attribute__((always_inline)) {
     const v4f lo = rb[pass & 1][0], hi = rb[pass & 1][1];
+    // ([r6] measured and not adopted: eight plain v_mul_f32 kept apart from the converts instead of the v_pk_mul_f32 pairs the vectoriser makes of these -- same time on
+    //  zero and random operands, profiles/ab_lib_r6k_onetile_and_scalar_multiplies.txt)
     v4i o;
     o[0] = (int)pack_bf16x2(lo[0] * alpha, lo[1] * alpha);
     o[1] = (int)pack_bf16x2(lo[2] * alpha, lo[3] * alpha);
@@ -311,8 +319,10 @@ __device__ __forceinline__ void gemm_mx_deepp(char* smem, const GemmParams& p, c
   // ~5 other instructions hide behind a 32-cycle MFMA; the retirement adds ~7 per slot, its ds_write_b128 from the accumulator registers cost 52 cycles of LDS store path
   // each with four waves writing, and with 256 workgroups the 32 MiB store burst back-pressures the stage by another ~2 us.  Measured and NOT faster (lab copy of this
   // file): bf16 before the transposition (twice the vector instructions: +3 %), block-of-4 MFMA order (no change), the whole retirement behind the MFMAs (+4.5 %).
-  auto final_stage = [&](auto fbc, const Desc& d, bool dvalid, const int ktn) __attribute__((always_inline)) {
+  // NEXT = false (ONETILE kernels): no next tile -- its stage-1 DMA and the reads of its first fragments are left out.
+  auto final_stage = [&](auto fbc, auto nextc, const Desc& d, bool dvalid, const int ktn) __attribute__((always_inline)) {
     constexpr int FB = decltype(fbc)::value;   // the buffer this stage lives in (1 unless ODD); the next tile starts in the other one
+    constexpr bool NEXT = decltype(nextc)::value;
     if constexpr (ODD) scr = smem + FB * STAGE + wave * DeepPCfg<C>::SCR_PER_WAVE;
     read_slice(FB, 2);
     read_slice(FB, 3);
@@ -322,7 +332,7 @@ __device__ __forceinline__ void gemm_mx_deepp(char* smem, const GemmParams& p, c
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // next tile's stage 0 landed (buffer 0); all reads of buffer 1 done
     __builtin_amdgcn_s_barrier();
     fence();
-    dma_prep(ktn, dvalid);
+    if constexpr (NEXT) dma_prep(ktn, dvalid);
     fence();
     static_for<0, 71>([&](auto sc) __attribute__((always_inline)) {
       constexpr int s = decltype(sc)::value;
@@ -333,12 +343,12 @@ __device__ __forceinline__ void gemm_mx_deepp(char* smem, const GemmParams& p, c
       }
       // DMA of the next tile's stage 1 into buffer 1: the B pieces and the scale piece now, one instruction every third
       // slot; the wave's 8 A pieces land in its own scratch area, so they wait until the last read-back (after the loop)
-      if constexpr (s % 3 == 0 && s / 3 < 9) dma_item(d, ktn, FB, 8 + s / 3);
-      if constexpr (s == 1) read_scales(FB ^ 1, FB ^ 1);
+      if constexpr (NEXT && s % 3 == 0 && s / 3 < 9) dma_item(d, ktn, FB, 8 + s / 3);
+      if constexpr (NEXT && s == 1) read_scales(FB ^ 1, FB ^ 1);
       // fragments of the next tile's stage 0, as their registers die: A rows of m after tile (m, 3), B rows of n after (3, n)
-      if constexpr (s == 12 || s == 28 || s == 44) { read_fa(FB ^ 1, 0, (s - 12) / 16); read_fa(FB ^ 1, 1, (s - 12) / 16); }
-      if constexpr (s == 48 || s == 52 || s == 56) { read_fb(FB ^ 1, 0, (s - 48) / 4); read_fb(FB ^ 1, 1, (s - 48) / 4); }
-      if constexpr (s == 60) { read_fa(FB ^ 1, 0, 3); read_fa(FB ^ 1, 1, 3); read_fb(FB ^ 1, 0, 3); read_fb(FB ^ 1, 1, 3); }
+      if constexpr (NEXT && (s == 12 || s == 28 || s == 44)) { read_fa(FB ^ 1, 0, (s - 12) / 16); read_fa(FB ^ 1, 1, (s - 12) / 16); }
+      if constexpr (NEXT && (s == 48 || s == 52 || s == 56)) { read_fb(FB ^ 1, 0, (s - 48) / 4); read_fb(FB ^ 1, 1, (s - 48) / 4); }
+      if constexpr (NEXT && s == 60) { read_fa(FB ^ 1, 0, 3); read_fa(FB ^ 1, 1, 3); read_fb(FB ^ 1, 0, 3); read_fb(FB ^ 1, 1, 3); }
       // retirement items due in this slot; pair P (final at e = 8 P + 3):   write e+1 | read rows 0-15 e+3 | stores e+5, e+6 | read rows 16-31 e+7 | stores e+9, e+10
       constexpr int d1 = s - 1, d3 = s - 3, d5 = s - 5, d6 = s - 6, d7 = s - 7, d9 = s - 9, d10 = s - 10;
       if constexpr (deepp_pair_done_at(d5) >= 0) retire_store(deepp_pair_done_at(d5) / 2, deepp_pair_done_at(d5) % 2, 0);
@@ -351,9 +361,11 @@ __device__ __forceinline__ void gemm_mx_deepp(char* smem, const GemmParams& p, c
       fence();
     });
     // the wave's own A pieces of the next tile's stage 1 overwrite its scratch: its read-backs must have returned first
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if constexpr (NEXT) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
-    for (int i = 0; i < 8; ++i) dma_item(d, ktn, FB, i);
+      for (int i = 0; i < 8; ++i) dma_item(d, ktn, FB, i);
+    }
     fence();
   };
 
@@ -361,6 +373,7 @@ __device__ __forceinline__ void gemm_mx_deepp(char* smem, const GemmParams& p, c
   using I1 = std::integral_constant<int, 1>;
   using BT = std::integral_constant<bool, true>;
   using BF = std::integral_constant<bool, false>;
+  using NXT = std::integral_constant<bool, !ONETILE>;   // is there a next tile to prefetch for?
 
   // ---- prologue: first tile's stages 0 and 1 in flight; stage 0 landed -> first two slices into registers ---------------
   int tile = wg;
@@ -388,20 +401,20 @@ __device__ __forceinline__ void gemm_mx_deepp(char* smem, const GemmParams& p, c
       const bool tonext = KTe == 2;
       Desc d;
       d.a = tonext ? nxt.a : cur.a; d.b = tonext ? nxt.b : cur.b; d.s = tonext ? nxt.s : cur.s;
-      stage(I0{}, BT{}, d, tonext ? 0 : 2, tonext ? nvalid : true);
+      stage(I0{}, BT{}, d, tonext ? 0 : 2, tonext ? nvalid : true, BT{});   // (ONETILE with K <= 512: a zero-fill DMA, harmless)
     }
     // [r4] only the LAST pair of stages issues DMA for the next tile: peeled, so that the loop body does not select three descriptors between its
     // two stages (12 s_cselect + compares = 21 scalar instructions in one MFMA slot, by the ISA's slot accounting)
     int kt = 1;
     for (; kt + 4 < KTe; kt += 2) {
-      stage(I1{}, BF{}, cur, kt + 2, true);
-      stage(I0{}, BF{}, cur, kt + 3, true);
+      stage(I1{}, BF{}, cur, kt + 2, true, BT{});
+      stage(I0{}, BF{}, cur, kt + 3, true, BT{});
     }
     if (kt + 2 < KTe) {
-      stage(I1{}, BF{}, cur, kt + 2, true);
-      stage(I0{}, BF{}, nxt, 0, nvalid);
+      stage(I1{}, BF{}, cur, kt + 2, true, BT{});
+      stage(I0{}, BF{}, nxt, 0, nvalid, NXT{});
     }
-    final_stage(I1{}, nxt, nvalid, 1);
+    final_stage(I1{}, NXT{}, nxt, nvalid, 1);
     cur = nxt;
     tile = tnext;
   }
@@ -417,14 +430,14 @@ __device__ __forceinline__ void gemm_mx_deepp(char* smem, const GemmParams& p, c
       const int tnext = tile + G;
       const Desc nxt = make_desc(tnext);
       const bool nvalid = tnext < ntiles;
-      stage(P0{}, BT{}, cur, 2, true);
+      stage(P0{}, BT{}, cur, 2, true, BT{});
       int kt = 1;
       for (; kt + 2 <= KT - 2; kt += 2) {
-        stage(P1{}, BF{}, cur, kt + 2, true);
-        stage(P0{}, BF{}, cur, kt + 3, true);
+        stage(P1{}, BF{}, cur, kt + 2, true, BT{});
+        stage(P0{}, BF{}, cur, kt + 3, true, BT{});
       }
-      stage(P1{}, BF{}, nxt, 0, nvalid);   // stage KT - 2
-      final_stage(P0{}, nxt, nvalid, 1);
+      stage(P1{}, BF{}, nxt, 0, nvalid, NXT{});   // stage KT - 2
+      final_stage(P0{}, NXT{}, nxt, nvalid, 1);
       cur = nxt;
       tile = tnext;
     };
@@ -792,12 +805,12 @@ __global__ __launch_bounds__(C::THREADS) void gemm_mx_deepp8_kernel(const GemmPa
   gemm_mx_deepp8<C, ST_AUX, NN>(smem, p, (int)blockIdx.x, (int)gridDim.x, p.tiles_m * p.tiles_n);
 }
 
-template <class C, int ST_AUX = 0, bool ODD = false>
+template <class C, int ST_AUX = 0, bool ODD = false, bool ONETILE = false>
 __global__ __launch_bounds__(C::THREADS) void gemm_mx_deepp_kernel(const GemmParams p) {
   __shared__ __attribute__((aligned(16))) char smem[DeepPCfg<C>::LDS_BYTES];
   // every argument the prologue needs is asked for HERE: the scalar loads leave together and are waited for once (left alone they arrive in four dependent rounds)
   asm volatile("" :: "s"(p.A), "s"(p.D), "s"(p.K), "s"(p.b_bytes), "s"((int)gridDim.x));
-  gemm_mx_deepp<C, ST_AUX, 1, ODD>(smem, p, (int)blockIdx.x, (int)gridDim.x, p.tiles_m * p.tiles_n);
+  gemm_mx_deepp<C, ST_AUX, 1, ODD, ONETILE>(smem, p, (int)blockIdx.x, (int)gridDim.x, p.tiles_m * p.tiles_n);
 }
 
 // -------------------------------------------------------------------------------------------------------------------------

@@ -1502,7 +1502,7 @@ __global__ __launch_bounds__(C::THREADS) void gemm_mx_deepp_kernel(const GemmPar
   // every argument the prologue needs is asked for HERE: the scalar loads leave together and are waited for once (left alone they arrive in four dependent rounds)
   asm volatile("" :: "s"(p.A), "s"(p.D), "s"(p.K), "s"(p.b_bytes), "s"((int)gridDim.x));
 #endif
-  gemm_mx_deepp<C, TRACE, ST_AUX, LAB, SK>(smem, p, (int)blockIdx.x, (int)gridDim.x, p.tiles_m * p.tiles_n);
+  labk::gemm_mx_deepp<C, TRACE, ST_AUX, LAB, SK>(smem, p, (int)blockIdx.x, (int)gridDim.x, p.tiles_m * p.tiles_n);
 }
 
 // -------------------------------------------------------------------------------------------------------------------------
