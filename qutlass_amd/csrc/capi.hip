@@ -293,7 +293,8 @@ int launch_gemm_deepp8(GemmParams p, hipStream_t s) {   // the fp8 twin (gemm_mx
 #else
   static_assert(NNABL == 0, "ablations: lab build only");
 #endif
-  hipLaunchKernelGGL((gemm_mx_deepp8_kernel<C, 17, NN>), dim3(grid), dim3(C::THREADS), 0, s, p);
+  if (grid == p.tiles_m * p.tiles_n) hipLaunchKernelGGL((gemm_mx_deepp8_kernel<C, 17, NN, true>), dim3(grid), dim3(C::THREADS), 0, s, p);   // [r6] one tile per workgroup
+  else hipLaunchKernelGGL((gemm_mx_deepp8_kernel<C, 17, NN>), dim3(grid), dim3(C::THREADS), 0, s, p);
   return check_launch("gemm_mx_deepp8_kernel");
 }
 

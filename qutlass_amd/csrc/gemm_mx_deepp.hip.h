@@ -461,7 +461,9 @@ __device__ __forceinline__ void gemm_mx_deepp(char* smem, const GemmParams& p, c
 // -------------------------------------------------------------------------------------------------------------------------
 constexpr int deepp8_pair_done_at(int s) { return (s >= 1 && s <= 29 && (s - 1) % 4 == 0) ? (s - 1) / 4 : -1; }
 
-template <class C, int ST_AUX = 0, bool NN = false>
+// [r6] ONETILE (chosen by the host when every workgroup walks exactly one tile, 4096^3): the last stage leaves out what it does for a next tile -- 17 LDS-DMA items and
+// the reads of its first fragments -- as in the fp4 kernel.
+template <class C, int ST_AUX = 0, bool NN = false, bool ONETILE = false>
 __device__ __forceinline__ void gemm_mx_deepp8(char* smem, const GemmParams& p, const int bid, const int G, const int ntiles) {
   static_assert(C::EBITS == 8 && C::F8SPLIT && C::BM == 256 && C::BN == 256 && C::WAVES_M == 2 && C::WAVES_N == 2 && C::NSTAGE == 2 && C::PPW == 1,
                 "persistent deep schedule (fp8): 256x256 tiles, 4 waves of 128x128, split register layout");
@@ -723,7 +725,7 @@ __device__ __forceinline__ void gemm_mx_deepp8(char* smem, const GemmParams& p, 
     asm volatile("" ::: "memory");
     __builtin_amdgcn_s_barrier();
     fence();
-    dma_prep(d, ktn, dvalid);
+    if constexpr (!ONETILE) dma_prep(d, ktn, dvalid);
     fence();
     static_for<0, 37>([&](auto sc) __attribute__((always_inline)) {
       constexpr int s = decltype(sc)::value;
@@ -732,13 +734,13 @@ __device__ __forceinline__ void gemm_mx_deepp8(char* smem, const GemmParams& p, 
         constexpr int j = s < 2 ? 1 : (s - 2) % 2;
         mfma1(j, 1, T / 4, T % 4, false);
       }
-      if constexpr (s % 2 == 0 && s / 2 < 9) dma_item(d, ktn, 1, 8 + s / 2);
-      if constexpr (s == 1) scales_load(0);
-      if constexpr (s == 4) scales_fin(0);
+      if constexpr (!ONETILE && s % 2 == 0 && s / 2 < 9) dma_item(d, ktn, 1, 8 + s / 2);
+      if constexpr (!ONETILE && s == 1) scales_load(0);
+      if constexpr (!ONETILE && s == 4) scales_fin(0);
       // slice 0 of the next tile's stage 0, as the registers die: A rows of m after tile (m, 3) (MFMA 8 m + 5), B rows of n after (3, n) (MFMA 23 + 2 n)
-      if constexpr (s == 6 || s == 14 || s == 22) read_fa(0, 0, (s - 6) / 8);
-      if constexpr (s == 24 || s == 26 || s == 28) read_fb(0, 0, (s - 24) / 2);
-      if constexpr (s == 30) { read_fa(0, 0, 3); read_fb(0, 0, 3); }
+      if constexpr (!ONETILE && (s == 6 || s == 14 || s == 22)) read_fa(0, 0, (s - 6) / 8);
+      if constexpr (!ONETILE && (s == 24 || s == 26 || s == 28)) read_fb(0, 0, (s - 24) / 2);
+      if constexpr (!ONETILE && s == 30) { read_fa(0, 0, 3); read_fb(0, 0, 3); }
       constexpr int P4 = deepp8_pair_done_at(s - 4), P6 = deepp8_pair_done_at(s - 6), P1 = deepp8_pair_done_at(s - 1), P2 = deepp8_pair_done_at(s - 2);
       if constexpr (P6 >= 0) { retire_store(P6 / 2, P6 % 2, 2); retire_store(P6 / 2, P6 % 2, 3); }
       if constexpr (P4 >= 0) { retire_store(P4 / 2, P4 % 2, 0); retire_store(P4 / 2, P4 % 2, 1); retire_read(1); }
@@ -748,8 +750,10 @@ __device__ __forceinline__ void gemm_mx_deepp8(char* smem, const GemmParams& p, 
     });
     __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): the retirement reads of the scratch slice (and NN: the asm fragment reads)
     asm volatile("" ::: "memory");
+    if constexpr (!ONETILE) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) dma_item(d, ktn, 1, i);
+      for (int i = 0; i < 8; ++i) dma_item(d, ktn, 1, i);
+    }
     fence();
   };
 
@@ -799,10 +803,10 @@ __device__ __forceinline__ void gemm_mx_deepp8(char* smem, const GemmParams& p, 
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
-template <class C, int ST_AUX = 0, bool NN = false>
+template <class C, int ST_AUX = 0, bool NN = false, bool ONETILE = false>
 __global__ __launch_bounds__(C::THREADS) void gemm_mx_deepp8_kernel(const GemmParams p) {
   __shared__ __attribute__((aligned(16))) char smem[DeepPCfg<C>::LDS_BYTES];
-  gemm_mx_deepp8<C, ST_AUX, NN>(smem, p, (int)blockIdx.x, (int)gridDim.x, p.tiles_m * p.tiles_n);
+  gemm_mx_deepp8<C, ST_AUX, NN, ONETILE>(smem, p, (int)blockIdx.x, (int)gridDim.x, p.tiles_m * p.tiles_n);
 }
 
 template <class C, int ST_AUX = 0, bool ODD = false, bool ONETILE = false>
