@@ -241,6 +241,8 @@ def side_configs(q, dev, h32, alpha, sampler=None):
         if sampler is not None and sampler.ok:   # socket power / shader clock while this config ran (which of them sit at the power limit)
             w = sampler.window(name + ":0", name + ":1")
             out[name]["power_w"], out[name]["sclk_mhz"] = w["power_w"], w["sclk_mhz"]
+            if w["power_w"]:   # [r6] joules per step: the launch sits at the socket power limit, so energy is what sets its time (profiles/energy_ubench_r6p.txt)
+                out[name]["energy_mj"] = round(w["power_w"] * us * 1e-3, 2)
 
     # C3: fusedQuantizeMx(H32, abs_max) + MXFP4 GEMM, Llama-3-8B FFN M=4096 N=14336 K=4096
     m, n, k = 4096, 14336, 4096
@@ -525,6 +527,12 @@ def main():
         if sampler.ok and sampler.samples:
             result["power"] = {"timed_region": sampler.window("timed_start", "timed_end"), "timed_region_plus_per_launch_pass": sampler.window("timed_start", "per_launch_end"),
                                "source": "librocm_smi64 rsmi_dev_power_get / rsmi_dev_gpu_clk_freq_get(SYS), host thread, 2 ms period"}
+            # [r6] joules per launch = mean socket power x the kernel's duration (the wider window when the K-step region was too short for a sample)
+            pw = result["power"]["timed_region"]["power_w"] or result["power"]["timed_region_plus_per_launch_pass"]["power_w"]
+            if pw:
+                result["roofline"]["energy_mj_per_launch"] = round(pw * kernel_ms, 2)
+                result["roofline"]["energy_note"] = ("socket W x kernel_us; ~0.30 kW of it is the idle socket.  Priced piece by piece in profiles/energy_ubench_r6p.txt: "
+                                                     "20.3 mJ for the MFMAs of 137.4 GFLOP on this data + 10-13 mJ of operand fill above idle")
         else:
             result["power"] = None
     # [r5] the same kernel, same shape, ALL-ZERO operands under unit scales (nothing toggles in the matrix pipe, the clock stays up): what the SCHEDULE delivers without the
@@ -542,6 +550,8 @@ def main():
             if sampler and sampler.ok:
                 zw = sampler.window("zero_operands:0", "zero_operands:1")
                 result["roofline"]["same_kernel_on_zero_operands"].update({"power_w": zw["power_w"], "sclk_mhz": zw["sclk_mhz"]})
+                if zw["power_w"]:
+                    result["roofline"]["same_kernel_on_zero_operands"]["energy_mj_per_launch"] = round(zw["power_w"] * zus * 1e-3, 2)
             del zq_a, zq_b, one_a, one_b
         except Exception as e:   # noqa: BLE001 -- a side measurement must not cost the headline line
             result["roofline"]["same_kernel_on_zero_operands"] = {"error": f"{type(e).__name__}: {e}"}
