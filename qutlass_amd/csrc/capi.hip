@@ -1026,6 +1026,10 @@ int launch_bwd_quant(const BwdTParams& p, bool qt, int which, bool hw, int grid,
     else            { if (qt) QAMD_BWD_GO((bwd_quant_tw_kernel<true, false, 4>), 256); else QAMD_BWD_GO((bwd_quant_tw_kernel<false, false, 4>), 256); }
     return check_launch("bwd_quant_tw_kernel");
   }
+  if (which == 9) {   // [r6] lab: units of 2 groups (32-byte output segments, twice the waves of variant 2) -- latency against write efficiency at small inputs
+    if (qt) QAMD_BWD_GO((bwd_quant_tw_kernel<true, true, 2>), 256); else QAMD_BWD_GO((bwd_quant_tw_kernel<false, true, 2>), 256);
+    return check_launch("bwd_quant_tw_kernel");
+  }
   if (qt && which == 3) { QAMD_BWD_GO((bwd_quant_tw_kernel<true, true, 8>), 256); return check_launch("bwd_quant_tw_kernel"); }
   if (!qt && which == 2) { QAMD_BWD_GO((bwd_quant_tw_kernel<false, true, 4>), 256); return check_launch("bwd_quant_tw_kernel"); }
 #endif
@@ -1488,7 +1492,7 @@ static int bwd_kernel_rule(bool qt, int64_t nu, int64_t cu, bool ring_ok = false
 }
 static int bwd_kernel_choice(bool qt, int64_t nu, bool ring_ok = false) {
   const int v = opt_bwd_variant() & 15;
-  if (v >= 1 && v <= 8) return v;
+  if (v >= 1 && v <= 9) return v;
   return bwd_kernel_rule(qt, nu, chip_cus(), ring_ok);
 }
 // column tiles (of 128) per workgroup of backward_bf16_square_double_mxfp8: 4 (16 waves, 16-byte row-scale pieces) when n allows and every CU still gets a workgroup
@@ -1507,10 +1511,10 @@ int qutlass_amd_backward_t_bf16(const void* x, const void* h, int64_t B, int64_t
   if (B * (N / 32) * p.tiles_m >= (1ll << 31) - 65536) return fail(QAMD_ERR_INVALID, "%s: tensor too large", name);
   const int64_t ntw = B * p.tiles_m * cdiv(N / 32, 8);   // units: 8 scale groups (256 n) x 64 m = 64 whole output lines
   const int which0 = bwd_kernel_choice(false, ntw);
-  const int which = which0 >= 4 ? bwd_kernel_rule(false, ntw, chip_cus()) : which0;   // (4 .. 8 = QT-only kernels)
+  const int which = (which0 >= 4 && which0 != 9) ? bwd_kernel_rule(false, ntw, chip_cus()) : which0;   // (4 .. 8 = QT-only kernels)
   p.abl = opt_bwd_variant() >> 4;
-  const int64_t nuw = B * p.tiles_m * cdiv(N / 32, which == 3 ? 8 : 4);   // wave units
-  const int grid = which == 1 ? (int)std::min<int64_t>(ntw, chip_cus() * 2) : (int)std::min<int64_t>(cdiv(nuw, 4), chip_cus() * (which == 3 ? 2 : 3));
+  const int64_t nuw = B * p.tiles_m * cdiv(N / 32, which == 3 ? 8 : which == 9 ? 2 : 4);   // wave units
+  const int grid = which == 1 ? (int)std::min<int64_t>(ntw, chip_cus() * 2) : (int)std::min<int64_t>(cdiv(nuw, 4), chip_cus() * (which == 3 ? 2 : which == 9 ? 4 : 3));
   return launch_bwd_quant(p, false, which, opt_hw_fp4(), grid, (hipStream_t)stream);
 }
 
@@ -1538,9 +1542,9 @@ int qutlass_amd_backward_qt_bf16(const void* x_e2m1, const void* x_e8m0, const v
   // (the ring kernel fetches by LDS-DMA: 16-byte pieces of the codes, dword pieces of the scale bytes -- an offset view that breaks either alignment takes the other kernels)
   const int which = bwd_kernel_choice(true, nu, M % 128 == 0 && (uintptr_t)x_e2m1 % 16 == 0 && (uintptr_t)x_e8m0 % 4 == 0);
   p.abl = opt_bwd_variant() >> 4;
-  const int64_t nuw = B * p.tiles_m * cdiv(N / 32, which == 3 ? 8 : 4);
-  const int gridw = (int)std::min<int64_t>(cdiv(nuw, 4), cu * (which == 3 ? 2 : 4));
-  if (which >= 5) {   // [r5] ring kernels: units of NG groups x 256 m
+  const int64_t nuw = B * p.tiles_m * cdiv(N / 32, which == 3 ? 8 : which == 9 ? 2 : 4);
+  const int gridw = (int)std::min<int64_t>(cdiv(nuw, 4), cu * (which == 3 ? 2 : which == 9 ? 5 : 4));
+  if (which >= 5 && which <= 8) {   // [r5] ring kernels: units of NG groups x 256 m
     if (M % 128) return fail(QAMD_ERR_INVALID, "%s: the ring kernel needs M %% 128 == 0", name);
     const int ng = (which == 6 || which == 7) ? 8 : 4;
     const int64_t ur = B * cdiv(M, 256) * cdiv(N / 32, ng);

@@ -522,6 +522,7 @@ __global__ __launch_bounds__(256) void bwd_quant_tw_kernel(const BwdTParams p) {
       uint8_t* dst = p.out_sf + grp0 + (int64_t)lane * G;
       if ((G & (NG - 1)) == 0) {
         if (NG == 8) *(v2i*)dst = *(const v2i*)(ss + lane * NG);
+        else if (NG == 2) *(uint16_t*)dst = *(const uint16_t*)(ss + lane * NG);
         else *(uint32_t*)dst = *(const uint32_t*)(ss + lane * NG);
       } else {
         for (int kk = 0; kk < ng; ++kk) dst[kk] = ss[lane * NG + kk];

@@ -16,8 +16,8 @@ def hadamard(n, dev):
     return (h * n ** -0.5).to(torch.bfloat16).to(dev)
 
 
-VARS = [0, 1, 2, 3, 4, 5, 6, 7, 8]
-NAMES = {5: "[r5] QT: v2 with the input through a shared whole-line ring (NG 4, 3 slots)", 6: "[r5] QT: ring, NG 8, 4 slots, 16 quads per XCD", 7: "[r5] QT: ring, NG 8, 4 slots", 8: "[r5] QT: ring, NG 4, 3 slots, 16 quads per XCD", 0: "the product rule", 1: "round-3 kernel (8 waves per unit, 2 barriers per unit)", 2: "wave-owned 64-byte segments (units of 4 groups, 12-16 waves per CU)", 4: "[r5] QT only: whole-line panels, [256 n][256 m] per workgroup (T: the product rule)", 3: "wave-owned 128-byte lines (units of 8 groups, 8 waves per CU)"}
+VARS = [0, 1, 2, 3, 4, 5, 6, 7, 8, 9]
+NAMES = {9: "[r6] wave-owned 32-byte segments (units of 2 groups, up to 20 waves per CU)", 5: "[r5] QT: v2 with the input through a shared whole-line ring (NG 4, 3 slots)", 6: "[r5] QT: ring, NG 8, 4 slots, 16 quads per XCD", 7: "[r5] QT: ring, NG 8, 4 slots", 8: "[r5] QT: ring, NG 4, 3 slots, 16 quads per XCD", 0: "the product rule", 1: "round-3 kernel (8 waves per unit, 2 barriers per unit)", 2: "wave-owned 64-byte segments (units of 4 groups, 12-16 waves per CU)", 4: "[r5] QT only: whole-line panels, [256 n][256 m] per workgroup (T: the product rule)", 3: "wave-owned 128-byte lines (units of 8 groups, 8 waves per CU)"}
 
 
 def main():
