@@ -17,6 +17,7 @@
 #endif
 #include "gemm_mx_skinny.hip.h"
 #include "gemm_mx_ks.hip.h"
+#include "gemm_mx_os.hip.h"
 #include "gemm_mx_fusedq.hip.h"
 #include "gemm_nvf4.hip.h"
 #include "gemm_nvf4_pk.hip.h"
@@ -263,6 +264,25 @@ int launch_gemm_ks(GemmParams p, hipStream_t s) {
   return check_launch("gemm_mx_ks_kernel");
 }
 
+// [r6] small-batch kernel that requests a 32x32 tile's whole K extent up front (gemm_mx_os.hip.h): K <= 4096, wave w owns stages w, w + 4, ...
+// (RM: row-major scale operands -- matmul_ada_mxf4_bf16_tn)
+template <bool RM = false>
+int launch_gemm_os(GemmParams p, hipStream_t s) {
+  p.tiles_m = (int)cdiv(p.M, 32);
+  p.tiles_n = (int)cdiv(p.N, 32);
+  p.ws = nullptr; p.splits = 1; p.ctr = nullptr; p.tag = 0;
+  const int64_t KT = cdiv(p.K, 256);
+  const dim3 grid(p.tiles_m * p.tiles_n), block(256);
+  if (KT <= 4) hipLaunchKernelGGL((gemm_mx_os_kernel<OsCfg<1>, RM>), grid, block, 0, s, p);
+  else if (KT <= 8) hipLaunchKernelGGL((gemm_mx_os_kernel<OsCfg<2>, RM>), grid, block, 0, s, p);
+  else if (KT <= 12) hipLaunchKernelGGL((gemm_mx_os_kernel<OsCfg<3>, RM>), grid, block, 0, s, p);
+  else if (KT <= 16) hipLaunchKernelGGL((gemm_mx_os_kernel<OsCfg<4>, RM>), grid, block, 0, s, p);
+  else return fail(QAMD_ERR_INVALID, "gemm_mx_os_kernel: K = %lld exceeds the 16 stages the tile holds in LDS", (long long)p.K);
+  return check_launch("gemm_mx_os_kernel");
+}
+// does the one-shot kernel take the shape?  32x32 tiles one per CU at most, K <= 16 stages of 256
+inline bool os_fits(int64_t M, int64_t N, int64_t K) { return cdiv(M, 32) * cdiv(N, 32) <= chip_cus() && cdiv(K, 256) <= 16; }
+
 // [r4] stream-K form of the two persistent kernels (lab variant 89): one workgroup per CU; p.ws / p.ctr / p.tag / p.sk_tiles set by gemm_mx
 #if QAMD_BENCH
 template <class C>
@@ -472,6 +492,7 @@ int dispatch_variant(int v, const GemmParams& p, hipStream_t s, const char* name
       if (v == 561) return deep ? launch_gemm_ks<32, 32, 6>(p, s) : launch_gemm_ks<32, 32, 4>(p, s);
       return deep ? launch_gemm_ks<32, 64, 6>(p, s) : launch_gemm_ks<32, 64, 4>(p, s);
     }
+    if (v == 568) return launch_gemm_os<false>(p, s);   // [r6] 32x32 tiles, the whole K extent (<= 16 stages) requested up front (gemm_mx_os.hip.h)
 #if QAMD_BENCH
     if (v == 99) return launch_gemm_hetero<GemmCfg<256, 256, 2, 2, 4, false>, GemmCfg<128, 128, 2, 2, 4, false, 0, 3>, 17>(p, s);
     // [r6] lab: the other tiles / ring depths of the in-workgroup K-split kernel (563 = 64x32, 564 = 64x64; 565 - 567 = 32x32 with a 4 / 8 / 6-deep ring)
@@ -711,10 +732,13 @@ SmallPlan plan_small(int64_t M, int64_t N, int64_t K, bool may_split = true) {
 //     (N = 4096, K = 14336: M <= 16 8.1-9.1 us split against 9.2-9.4; M = 64 11.4 against 9.8).
 // Where it applies it is 11 ... 30 % faster (N = K = 4096: M <= 64 4.9-5.3 -> 4.1-4.5 us; 8192^2: M <= 32 8.8-11.1 -> 7.4-7.8 us), M = 1 ... 8 included (the LDS-free
 // split-K kernel: 4.55-4.92 us at N = K = 4096).  32x64 tiles: only where 32x32 tiles just overflow the chip and 32x64 nearly fill it (N = 14336: -6 %).
-// Returns the variant (561 / 562) or 0.
+// Returns the variant (568 / 561 / 562) or 0.
 inline int ks_plan(int64_t M, int64_t N, int64_t K) {
   const int64_t cus = chip_cus(), KT = cdiv(K, 256);
   const int64_t T32 = cdiv(M, 32) * cdiv(N, 32);
+  // [r6] K <= 4096: the tile's whole K extent fits the LDS -- the one-shot kernel (gemm_mx_os.hip.h), no ring and no barrier in the K walk: N = K = 4096, M = 1 ... 64
+  // 4.05-4.39 -> 3.34-3.67 us, N = K = 2048 3.15-3.26 -> 2.62-2.77 (profiles/calib_os_r6q.txt); past one tile per CU the ring plans below keep the shape
+  if (os_fits(M, N, K)) return 568;
   if (T32 <= cus && (KT <= 24 || (2 * T32 > cus && KT <= 64))) return 561;   // (K > 16384 was not calibrated, and a split-K plan on larger tiles moves fewer bytes per CU there)
   const int64_t T64 = cdiv(M, 32) * cdiv(N, 64);
   if (M <= 32 && T32 > cus && T64 <= cus && 8 * T64 >= 7 * cus && KT <= 24) return 562;
@@ -1136,7 +1160,9 @@ static int ada_impl(const void* A, const void* B, const void* A_sf, const void* 
                                      //  8 x 8192 x 28672: 27.9 us vs 34.2 us on 128 workgroups of the ring kernel)
   const int cus = chip_cus();
   const bool ring = forced == 70 || (forced != 60 && (M > 32 || T64 >= cus || (T64 >= cus / 2 && K < 16384)));
-  if (ring) {
+  // [r6] K <= 4096 and at most one 32x32 tile per CU: the one-shot kernel with row-major scale pieces (gemm_mx_os.hip.h; "gemm_variant" 568 forces it where it fits)
+  const bool oneshot = os_fits(M, N, K) && (forced == 568 || forced == 0);
+  if (ring || oneshot) {
     GemmParams p;
     p.A = (const uint8_t*)A; p.B = (const uint8_t*)B; p.SFA = (const uint8_t*)A_sf; p.SFB = (const uint8_t*)B_sf;
     p.alpha = alpha; p.D = (uint16_t*)D; p.M = (int)M; p.N = (int)N; p.K = (int)K; p.ldd = (int)ldd;
@@ -1144,6 +1170,7 @@ static int ada_impl(const void* A, const void* B, const void* A_sf, const void* 
     p.sfa_bytes = (uint32_t)(M * KB); p.sfb_bytes = (uint32_t)(N * KB);   // row-major (rows, K/32), un-swizzled
     p.pp_shift = opt_pp_shift(); p.pp_flags = opt_pp_flags(); p.dbg = opt_dbg();
     p.ws = nullptr; p.splits = 1; p.ctr = nullptr; p.tag = 0;
+    if (oneshot) return launch_gemm_os<true>(p, (hipStream_t)stream);
 #if QAMD_BENCH
     if (opt_gemm_variant() == 178) return launch_gemm<GemmCfg<64, 64, 2, 2, 4, false, 0, 3>, 8>(p, (hipStream_t)stream);   // round-1 ring schedule
 #endif

@@ -1,0 +1,146 @@
+// Small-batch MXFP4 GEMM for gfx950, "one shot": a 32x32 output tile per workgroup of four waves whose WHOLE K extent is requested from memory before the first MFMA.
+// Replaces the M-bucketed small tiles of qutlass/csrc/gemm.cu:195-222 and the small-batch kernel of qutlass/csrc/gemm_ada.cu:127-129 for M <= 64 against weights of
+// K <= 4096 (the decode shapes of the reference's own sweep, README.md:121-123), where gemm_mx_ks.hip.h was the plan until now.
+//
+// Why ([r6]).  gemm_mx_ks walks the K stages through a 4-deep ring with one barrier of the four waves per stage: three stages of 8 KiB in flight per
+// workgroup and ~250 cycles per stage for ONE MFMA per wave -- at N = K = 4096 the 16 stages stream the 8.4 MB of weights at 4.8 TB/s (4.07 us per call, of which
+// ~2.3 are launch + first round trip + cross-wave sum + store).  A 32x32 tile with K <= 4096 is (32 + 32) rows x 2 KiB + 8 KiB of scale dwords = 136 KiB: it fits
+// the LDS whole.  So there is no ring: wave w owns K stages w, w + 4, w + 8, ... -- issues every LDS-DMA piece of them up front (<= 40 per wave, all in flight), and
+// takes each stage as it lands (s_waitcnt vmcnt counts its own pieces down; nobody else touches them: no barrier until the cross-wave sum).
+//
+// Data path per stage = gemm_mx_ks's (128 B per row, pieces of 8 rows x 128 B with the 16-byte chunk XOR-swizzled by row at the SOURCE; rows past M / N and chunks
+// past K fall off the buffer descriptor and read zeros), except the scales: ONE dword piece per operand and stage -- lane l fetches the dword of row l % 32 in column
+// tile 2 kt + l / 32 of the to_blocked image (bytes = K-blocks 4 (l / 32) .. + 3 of the stage), which is exactly the dword lane l's MFMAs take their scale byte from.
+// Results: each wave sums its stages' four k-slices in K order into one accumulator; the four partial sums are added as ((w0 + w1) + w2) + w3 in fp32 -- bit-identical
+// to the other schedules wherever partial sums are exact (the reference's test regime), one fp32 rounding apart otherwise, like every split-K plan here.
+#pragma once
+#include "gemm_mx.hip.h"
+
+namespace qamd {
+
+template <int SPW_>   // K stages per wave: the kernel covers K <= 1024 SPW
+struct OsCfg {
+  static constexpr int TM = 32, TN = 32, ROWB = 128, SPW = SPW_, KTMAX = 4 * SPW_;
+  static constexpr int OFF_B = TM * ROWB, OFF_S = (TM + TN) * ROWB, STAGE = OFF_S + 512;   // + 256 B of scale dwords per operand
+  static constexpr int LPS = 10;                                                            // LDS-DMA instructions per stage: 4 A pieces, 4 B pieces, 2 scale pieces
+  static constexpr int RED = 4 * 4096;                                                      // cross-wave sum: [wave] 32 x 32 fp32
+  static constexpr int LDS_BYTES = KTMAX * STAGE > RED ? KTMAX * STAGE : RED;
+  static_assert(SPW >= 1 && SPW * LPS <= 63, "vmcnt immediate");
+  static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
+};
+
+// RM: the scale operands are row-major (rows, K / 32) as matmul_ada_mxf4_bf16_tn hands them over (qutlass/csrc/gemm_ada.cu) instead of the to_blocked image
+template <class C, bool RM = false>
+__global__ __launch_bounds__(256) void gemm_mx_os_kernel(const GemmParams p) {
+  constexpr int SPW = C::SPW, LPS = C::LPS;
+  __shared__ __attribute__((aligned(16))) char smem[C::LDS_BYTES];
+  asm volatile("" :: "s"(p.A), "s"(p.D), "s"(p.K), "s"(p.b_bytes), "s"(p.alpha));   // all scalar argument loads in one round
+  const float alpha = *p.alpha;
+  const int tid = threadIdx.x, lane = tid & 63, wave = uniform(tid >> 6), i32 = lane & 31, g = lane >> 5;
+  // tile: workgroups that share a B row tile are neighbours (and stay on one XCD: xcd_remap)
+  const int nb = p.tiles_m * p.tiles_n;
+  const int b2 = xcd_remap((int)blockIdx.x, nb);
+  const int m0 = uniform((b2 % p.tiles_m) * C::TM), n0 = uniform((b2 / p.tiles_m) * C::TN);
+  const int rowbytes = p.K >> 1, KT = (rowbytes + C::ROWB - 1) / C::ROWB, CB = (p.K / 32 + 3) >> 2;
+  const int tailbytes = rowbytes - (KT - 1) * C::ROWB;   // bytes per row of the last stage
+
+  // ---- LDS-DMA sources --------------------------------------------------------------------------------------------------------------
+  const uint32_t a_off = (uint32_t)m0 * rowbytes, b_off = (uint32_t)n0 * rowbytes;
+  const __amdgpu_buffer_rsrc_t rA = make_rsrc(p.A + a_off, p.a_bytes - a_off), rB = make_rsrc(p.B + b_off, p.b_bytes - b_off);
+  // piece qq of an operand tile = rows 8 qq .. + 7; lane -> row 8 qq + (l >> 3), physical chunk l & 7 = logical chunk ^ ((row >> 1) & 7): only the parity of qq matters
+  int vP[2], chP[2];
+#pragma unroll
+  for (int par = 0; par < 2; ++par) {
+    chP[par] = (lane & 7) ^ (((lane >> 4) + 4 * par) & 7);
+    vP[par] = (lane >> 3) * rowbytes + (chP[par] << 4);
+  }
+  const int rstep = 8 * rowbytes;
+  // scale dwords: row (m0 | n0) + i32 of column tile 2 kt + g -- byte ((r % 32) * 16 + ((r % 128) / 32) * 4) of the 512-byte tile (qutlass/utils.py:60-64)
+  // (RM: row r's eight scale bytes of stage kt are bytes 8 kt .. + 7 of its K / 32 -- the lane's dword is bytes 8 kt + 4 g .. + 3; rows past M / N lie past the descriptor)
+  const int KB = p.K >> 5;
+  const uint32_t sa_off = RM ? (uint32_t)m0 * KB : (uint32_t)(m0 >> 7) * CB * 512, sb_off = RM ? (uint32_t)n0 * KB : (uint32_t)(n0 >> 7) * CB * 512;
+  const __amdgpu_buffer_rsrc_t rSA = make_rsrc(p.SFA + sa_off, p.sfa_bytes - sa_off), rSB = make_rsrc(p.SFB + sb_off, p.sfb_bytes - sb_off);
+  const int vSA = RM ? i32 * KB + 4 * g : g * 512 + i32 * 16 + ((m0 & 127) >> 5) * 4, vSB = RM ? i32 * KB + 4 * g : g * 512 + i32 * 16 + ((n0 & 127) >> 5) * 4;
+
+  auto issue = [&](const int kt) __attribute__((always_inline)) {   // stage kt into its own LDS area (kt >= KT: every piece out of range -> zeros)
+    char* st = smem + kt * C::STAGE;
+    int tail = (kt == KT - 1) ? tailbytes : C::ROWB;
+    int oob = (kt < KT) ? 0 : -1;
+    asm volatile("" : "+v"(tail), "+v"(oob));
+    const int soff = kt * C::ROWB;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      const bool isB = t >= 4;
+      const int qq = t & 3, par = qq & 1;
+      const int o = oob | ((chP[par] << 4) < tail ? 0 : -1);
+      const int v = ((vP[par] + qq * rstep) & ~o) | ((int)0x80000000 & o);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(isB ? rB : rA, (lds_ptr_t)(st + (isB ? C::OFF_B : 0) + qq * 1024), 16, v, soff, 0, 0);
+    }
+    // a column tile past the operand's last one would read the next row tile's bytes (RM: K-blocks past K / 32 the next row's)
+    const int os = (kt < KT && (RM ? 8 * kt + 4 * g < KB : 2 * kt + g < CB)) ? 0 : -1;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rSA, (lds_ptr_t)(st + C::OFF_S), 4, (vSA & ~os) | ((int)0x80000000 & os), RM ? kt * 8 : kt * 1024, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rSB, (lds_ptr_t)(st + C::OFF_S + 256), 4, (vSB & ~os) | ((int)0x80000000 & os), RM ? kt * 8 : kt * 1024, 0, 0);
+  };
+
+  // ---- everything this wave will ever read, requested now -------------------------------------------------------------------------------
+#pragma unroll
+  for (int j = 0; j < SPW; ++j) issue(wave + 4 * j);
+
+  // row i32 of the tile, logical chunk 4 g + js (lane half g owns K-blocks 4 g .. 4 g + 3 of the stage), physical chunk ^ ((row >> 1) & 7)
+  const int sw = (i32 >> 1) & 7;
+  v16f acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  auto fence = [&]() __attribute__((always_inline)) { __builtin_amdgcn_sched_barrier(0); };
+
+  static_for<0, SPW>([&](auto jc) __attribute__((always_inline)) {
+    constexpr int j = decltype(jc)::value;
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((SPW - 1 - j) * LPS) : "memory");   // this wave's stage j landed (its later stages may still be in flight)
+    fence();
+    const char* st = smem + (wave + 4 * j) * C::STAGE;
+    v4i fa[4], fb[4];
+#pragma unroll
+    for (int js = 0; js < 4; ++js) {
+      const int off = i32 * C::ROWB + (((4 * g + js) ^ sw) << 4);
+      fa[js] = *(const v4i*)(st + off);
+      fb[js] = *(const v4i*)(st + C::OFF_B + off);
+    }
+    const int sa = *(const int*)(st + C::OFF_S + lane * 4), sb = *(const int*)(st + C::OFF_S + 256 + lane * 4);
+    fence();   // all ten reads issued before the first MFMA (left alone, the compiler reads one k-slice at a time into the same registers: four exposed LDS round trips)
+#pragma unroll
+    for (int js = 0; js < 4; ++js) {
+      const v4i a = fa[js], b = fb[js];
+      const v8i A8 = {a[0], a[1], a[2], a[3], 0, 0, 0, 0}, B8 = {b[0], b[1], b[2], b[3], 0, 0, 0, 0};
+      if (js == 0) acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(B8, A8, acc, 4, 4, 0, sb, 0, sa);
+      if (js == 1) acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(B8, A8, acc, 4, 4, 1, sb, 1, sa);
+      if (js == 2) acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(B8, A8, acc, 4, 4, 2, sb, 2, sa);
+      if (js == 3) acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(B8, A8, acc, 4, 4, 3, sb, 3, sa);
+    }
+    fence();
+  });
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();   // every wave's reads of the stage areas are done: they become the sum's scratch
+  fence();
+
+  // ---- cross-wave sum: [wave][row][8 chunks of 4 fp32], chunk ^ (row & 7) (the 8 lanes of a ds_write_b128 group hit 8 chunks) ------------------------
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+    *(v4f*)(smem + (wave * 32 + i32) * 128 + (((2 * q + g) ^ (i32 & 7)) << 4)) = v4f{acc[4 * q + 0], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]};
+  __syncthreads();
+  const int rr = tid >> 3, cq = tid & 7;   // row of the 32 x 32 tile, chunk of 4 columns
+  v4f s[4];
+#pragma unroll
+  for (int w = 0; w < 4; ++w) s[w] = *(const v4f*)(smem + (w * 32 + rr) * 128 + ((cq ^ (rr & 7)) << 4));
+  v4f t;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) t[e] = ((s[0][e] + s[1][e]) + s[2][e]) + s[3][e];
+  const int row = m0 + rr, col = n0 + 4 * cq;
+  if (row < p.M && col < p.N) {
+    v2i o;
+    o[0] = (int)pack_bf16x2(t[0] * alpha, t[1] * alpha);
+    o[1] = (int)pack_bf16x2(t[2] * alpha, t[3] * alpha);
+    *(v2i*)(p.D + (size_t)row * p.ldd + col) = o;
+  }
+}
+
+}  // namespace qamd

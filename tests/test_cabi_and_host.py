@@ -475,15 +475,18 @@ def test_auto_dispatch_rules_dry_run(lib):
     # [r3] re-measured GPU-only: the split-K kernel up to M = 8 (N <= 8192), up to M = 24 only against small weights (N <= 2048); the ring stays flat in M beyond
     # [r6] ... where the in-workgroup K-split kernel does not take the shape: it does whenever the 32x32 tiles fit one per CU and K <= 24 stages of 256 (or they fill
     # more than half the chip and K <= 16384) -- N = K = 4096: M = 1 ... 64 4.5-5.3 -> 4.1-4.5 us; 32x64 tiles where 32x32 just overflow (N = 14336)
-    assert plan(4, 1, 4096, 4096) == [(KS32, 4096, 1)] and plan(4, 8, 4096, 4096) == [(KS32, 4096, 1)] and plan(4, 8, 8192, 8192) == [(KS32, 8192, 1)]
-    assert plan(4, 16, 4096, 4096) == [(KS32, 4096, 1)] and plan(4, 32, 4096, 4096) == [(KS32, 4096, 1)] and plan(4, 24, 2048, 2048) == [(KS32, 2048, 1)]
+    # [r6] ... and with K <= 4096 (16 stages) the tile's whole K extent fits the LDS: the one-shot kernel (csrc/gemm_mx_os.hip.h), N = K = 4096, M = 1 ... 64 4.05-4.39 -> 3.34-3.67 us
+    OS32 = 568
+    assert plan(4, 1, 4096, 4096) == [(OS32, 4096, 1)] and plan(4, 8, 4096, 4096) == [(OS32, 4096, 1)] and plan(4, 8, 8192, 8192) == [(KS32, 8192, 1)]
+    assert plan(4, 16, 4096, 4096) == [(OS32, 4096, 1)] and plan(4, 32, 4096, 4096) == [(OS32, 4096, 1)] and plan(4, 24, 2048, 2048) == [(OS32, 2048, 1)]
+    assert plan(4, 32, 8192, 4096) == [(OS32, 8192, 1)] and plan(4, 33, 8192, 4096) != [(OS32, 8192, 1)] and plan(4, 16, 4096, 4224) == [(KS32, 4096, 1)]   # one tile per CU at most; 17 stages: the ring
     assert plan(4, 16, 14336, 4096) == [(KS32x64, 14336, 1)]
     assert plan(4, 1, 4096, 14336) == [(SKINNY, 4096, 1)] and plan(4, 8, 4096, 11008) == [(SKINNY, 4096, 1)]     # long K, half the chip: the split-K kernels keep it
     assert plan(4, 16, 11008, 4096) == [(RING64, 11008, 1)] and plan(4, 96, 4096, 4096) == [(RING64, 4096, 1)]  # 32x32 tiles would sit two on a CU
     assert plan(4, 16, 57344, 8192) == [(28, 57344, 1)]
     assert plan(8, 16, 4096, 4096) == [(RING64, 4096, 1)]            # no fp8 skinny kernel
     # small outputs: ring schedule; split-K only with caller scratch, <= 128 tiles and >= 32 K stages
-    assert plan(4, 64, 4096, 4096) == [(KS32, 4096, 1)] == plan(4, 64, 4096, 4096, big)
+    assert plan(4, 64, 4096, 4096) == [(OS32, 4096, 1)] == plan(4, 64, 4096, 4096, big)
     assert plan(4, 64, 4096, 14336) == [(KS32, 4096, 1)] == plan(4, 64, 4096, 14336, big)   # [r6] 256 tiles of 32x32, 56 stages: 11.4 us (4 K ranges + reduce) -> 9.8
     assert plan(8, 64, 4096, 7168) == [(RING64, 4096, 1)]
     assert plan(8, 64, 4096, 7168, big) == [(RING64, 4096, 4)]

@@ -267,9 +267,11 @@ def _mx_operands_exact(m, n, k, seed):
 KS_SHAPES = [(1, 8, 128), (9, 40, 384), (33, 104, 1408), (64, 264, 4096), (100, 72, 640), (31, 4096, 4096), (64, 2048, 8192), (130, 520, 256)]
 
 
-@pytest.mark.parametrize("variant", [561, 562, 563, 564, 565, 566, 567])
-@pytest.mark.parametrize("m,n,k", KS_SHAPES)
+@pytest.mark.parametrize("variant", [561, 562, 563, 564, 565, 566, 567, 568])
+@pytest.mark.parametrize("m,n,k", KS_SHAPES + [(5, 72, 1024), (40, 200, 2944), (64, 96, 3072)])
 def test_ks_kernel_against_the_oracle(variant, m, n, k):
+    if variant == 568 and k > 4096:
+        pytest.skip("the one-shot kernel (gemm_mx_os.hip.h) holds at most 16 K stages in LDS")
     a, b, sa, sb = _mx_operands_exact(m, n, k, m * 7 + n + k)
     alpha = torch.tensor([0.5], device=DEV)
     with lab.forced(gemm_variant=variant):
@@ -277,6 +279,28 @@ def test_ks_kernel_against_the_oracle(variant, m, n, k):
     ref = oracle.gemm_blockscaled(oracle.KIND_MXFP4, _np(a), _np(b), _np(sa), _np(sb), 0.5, m, n, k)
     bad = _np(got) != ref
     assert not bad.any(), f"{int(bad.sum())} of {bad.size} outputs differ, first at {np.argwhere(bad)[0].tolist()}"
+
+
+@pytest.mark.parametrize("m,n,k", [(1, 8, 128), (5, 72, 1024), (33, 104, 1408), (40, 200, 2944), (64, 96, 3072), (31, 264, 4096), (17, 8192, 3968)])
+def test_one_shot_kernel_with_row_major_scales_against_the_oracle(q, m, n, k):
+    """matmul_ada_mxf4_bf16_tn (qutlass/csrc/gemm_ada.cu; row-major scale operands) on shapes the product sends to the one-shot kernel (csrc/gemm_mx_os.hip.h, RM form):
+    ragged M / N, K tails of half a stage, 1 ... 16 stages; the same operands through the blocked-scale entry (one-shot kernel, blocked form) and the 64x64 ring kernel."""
+    g = torch.Generator(device=DEV).manual_seed(m * 11 + n + k)
+    a = torch.randint(0, 256, (m, k // 2), dtype=torch.uint8, device=DEV, generator=g)
+    b = torch.randint(0, 256, (n, k // 2), dtype=torch.uint8, device=DEV, generator=g)
+    sa = torch.randint(125, 129, (m, k // 32), dtype=torch.uint8, device=DEV, generator=g)
+    sb = torch.randint(125, 129, (n, k // 32), dtype=torch.uint8, device=DEV, generator=g)
+    alpha = torch.tensor([0.5], device=DEV)
+    e8 = torch.float8_e8m0fnu
+    got = q.matmul_ada_mxf4_bf16_tn(a, b, sa.view(e8), sb.view(e8), alpha)
+    sa_b, sb_b = oracle.to_blocked(_np(sa)), oracle.to_blocked(_np(sb))
+    ref = oracle.gemm_blockscaled(oracle.KIND_MXFP4, _np(a), _np(b), sa_b, sb_b, 0.5, m, n, k)
+    bad = _np(got) != ref
+    assert not bad.any(), f"{int(bad.sum())} of {bad.size} outputs differ, first at {np.argwhere(bad)[0].tolist()}"
+    tsa, tsb = torch.from_numpy(sa_b).to(DEV), torch.from_numpy(sb_b).to(DEV)
+    assert np.array_equal(_np(q.matmul_mxf4_bf16_tn(a, b, tsa.view(e8), tsb.view(e8), alpha)), ref)
+    with lab.forced(gemm_variant=70):   # the ring kernel with row-major scale fetch, the plan before this kernel
+        assert np.array_equal(_np(lab.matmul_ada_mxf4_bf16_tn(a, b, sa, sb, alpha)), ref)
 
 
 @pytest.mark.parametrize("m,n,k", [(1, 4096, 4096), (8, 8192, 4096), (48, 4096, 4096), (64, 4096, 14336), (16, 14336, 4096), (200, 1024, 2048)])

@@ -1,0 +1,23 @@
+import os, sys
+ROOT = os.environ.get("GRAFT_REPO_ROOT", "/root/repo")
+sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tools"))
+import torch
+import _benchlib as lab
+from _timing import graph_us
+dev = torch.device("cuda:0")
+g = torch.Generator(device=dev).manual_seed(0)
+alpha = torch.ones(1, device=dev)
+print("# matmul_ada_mxf4_bf16_tn (row-major scales), us per launch (HIP-graph replays): forced 60 = LDS-free split-K kernel, 70 = 64x64 ring, 568 = one-shot, 0 = the product rule")
+for (n, k) in ((4096, 4096), (2048, 2048), (8192, 4096), (1024, 4096), (6144, 4096)):
+    for m in (1, 8, 16, 32, 64):
+        a = torch.randint(0, 256, (m, k // 2), dtype=torch.uint8, device=dev, generator=g)
+        b = torch.randint(0, 256, (n, k // 2), dtype=torch.uint8, device=dev, generator=g)
+        sa = torch.randint(125, 129, (m, k // 32), dtype=torch.uint8, device=dev, generator=g)
+        sb = torch.randint(125, 129, (n, k // 32), dtype=torch.uint8, device=dev, generator=g)
+        t, outs = {}, {}
+        for v in (60, 70, 568, 0):
+            with lab.forced(gemm_variant=v):
+                outs[v] = lab.matmul_ada_mxf4_bf16_tn(a, b, sa, sb, alpha)
+                t[v] = min(graph_us(lambda: lab.matmul_ada_mxf4_bf16_tn(a, b, sa, sb, alpha), n=40) for _ in range(3))
+        eq = all(torch.equal(outs[v].view(torch.int16), outs[60].view(torch.int16)) for v in (70, 568, 0))
+        print("N=%-6d K=%-6d M=%-4d | %s | %s" % (n, k, m, " ".join("%d: %6.2f" % (v, t[v]) for v in (60, 70, 568, 0)), "equal" if eq else "DIFFER"), flush=True)
