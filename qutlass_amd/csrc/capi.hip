@@ -277,11 +277,20 @@ int launch_gemm_os(GemmParams p, hipStream_t s) {
   else if (KT <= 8) hipLaunchKernelGGL((gemm_mx_os_kernel<OsCfg<2>, RM>), grid, block, 0, s, p);
   else if (KT <= 12) hipLaunchKernelGGL((gemm_mx_os_kernel<OsCfg<3>, RM>), grid, block, 0, s, p);
   else if (KT <= 16) hipLaunchKernelGGL((gemm_mx_os_kernel<OsCfg<4>, RM>), grid, block, 0, s, p);
-  else return fail(QAMD_ERR_INVALID, "gemm_mx_os_kernel: K = %lld exceeds the 16 stages the tile holds in LDS", (long long)p.K);
+  else hipLaunchKernelGGL((gemm_mx_os_kernel<OsCfg<4>, RM, true>), grid, block, 0, s, p);   // wave-owned rings of four slots
   return check_launch("gemm_mx_os_kernel");
 }
-// does the one-shot kernel take the shape?  32x32 tiles one per CU at most, K <= 16 stages of 256
-inline bool os_fits(int64_t M, int64_t N, int64_t K) { return cdiv(M, 32) * cdiv(N, 32) <= chip_cus() && cdiv(K, 256) <= 16; }
+// Does the one-shot kernel take the shape?  32x32 tiles, one per CU at most; K <= 16 stages of 256: always.  Longer K (wave-owned rings): up to 32 stages when the tiles
+// fill a quarter of the chip, up to 64 stages (K = 16384) when they fill half of it (N = 1024, K = 14336: 32 workgroups take 7.4 us where the split-K plans take
+// 5.7-6.9); the blocked-scale op also keeps M < 8 with more than 32 stages on the LDS-free split-K kernel (4096 x 11008, M = 1: 6.07 vs 6.40 us).  ada: matmul_ada_mxf4_bf16_tn (row-major scales: its other kernels are
+// 25-45 % slower on every such shape).  profiles/calib_os_r6q.txt, calib_osring_r6q.txt, calib_ada_r6q.txt
+inline bool os_fits(int64_t M, int64_t N, int64_t K, bool ada = false) {
+  const int64_t cus = chip_cus(), T32 = cdiv(M, 32) * cdiv(N, 32), KT = cdiv(K, 256);
+  if (T32 > cus) return false;
+  if (KT <= 16) return true;
+  if (KT <= 32) return 4 * T32 >= cus;
+  return KT <= 64 && 2 * T32 >= cus && (ada || M >= 8);   // (measured with 128 and 256 tiles only: fewer tiles against K > 8192 stay with the split plans)
+}
 
 // [r4] stream-K form of the two persistent kernels (lab variant 89): one workgroup per CU; p.ws / p.ctr / p.tag / p.sk_tiles set by gemm_mx
 #if QAMD_BENCH
@@ -737,7 +746,8 @@ inline int ks_plan(int64_t M, int64_t N, int64_t K) {
   const int64_t cus = chip_cus(), KT = cdiv(K, 256);
   const int64_t T32 = cdiv(M, 32) * cdiv(N, 32);
   // [r6] K <= 4096: the tile's whole K extent fits the LDS -- the one-shot kernel (gemm_mx_os.hip.h), no ring and no barrier in the K walk: N = K = 4096, M = 1 ... 64
-  // 4.05-4.39 -> 3.34-3.67 us, N = K = 2048 3.15-3.26 -> 2.62-2.77 (profiles/calib_os_r6q.txt); past one tile per CU the ring plans below keep the shape
+  // 4.05-4.39 -> 3.34-3.67 us, N = K = 2048 3.15-3.26 -> 2.62-2.77 (profiles/calib_os_r6q.txt); its wave-owned-ring form for longer K where os_fits says so
+  // (4096 x 8192, M <= 32: 5.8-7.1 -> 5.5-5.7 us); past one tile per CU the ring plans below keep the shape
   if (os_fits(M, N, K)) return 568;
   if (T32 <= cus && (KT <= 24 || (2 * T32 > cus && KT <= 64))) return 561;   // (K > 16384 was not calibrated, and a split-K plan on larger tiles moves fewer bytes per CU there)
   const int64_t T64 = cdiv(M, 32) * cdiv(N, 64);
@@ -1161,7 +1171,7 @@ static int ada_impl(const void* A, const void* B, const void* A_sf, const void* 
   const int cus = chip_cus();
   const bool ring = forced == 70 || (forced != 60 && (M > 32 || T64 >= cus || (T64 >= cus / 2 && K < 16384)));
   // [r6] K <= 4096 and at most one 32x32 tile per CU: the one-shot kernel with row-major scale pieces (gemm_mx_os.hip.h; "gemm_variant" 568 forces it where it fits)
-  const bool oneshot = os_fits(M, N, K) && (forced == 568 || forced == 0);
+  const bool oneshot = forced == 568 ? cdiv(M, 32) * cdiv(N, 32) <= 4 * cus : (forced == 0 && os_fits(M, N, K, true));
   if (ring || oneshot) {
     GemmParams p;
     p.A = (const uint8_t*)A; p.B = (const uint8_t*)B; p.SFA = (const uint8_t*)A_sf; p.SFB = (const uint8_t*)B_sf;

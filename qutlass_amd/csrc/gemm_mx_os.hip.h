@@ -11,6 +11,8 @@
 // Data path per stage = gemm_mx_ks's (128 B per row, pieces of 8 rows x 128 B with the 16-byte chunk XOR-swizzled by row at the SOURCE; rows past M / N and chunks
 // past K fall off the buffer descriptor and read zeros), except the scales: ONE dword piece per operand and stage -- lane l fetches the dword of row l % 32 in column
 // tile 2 kt + l / 32 of the to_blocked image (bytes = K-blocks 4 (l / 32) .. + 3 of the stage), which is exactly the dword lane l's MFMAs take their scale byte from.
+// RING ([r6], K > 4096): the same wave-owned stages through wave-owned SLOTS -- SPW per wave; as soon as a wave's reads of stage j have returned it requests its stage
+// j + SPW into the slot just freed (the only consumer of a slot is the wave that filled it: still no barrier), so SPW - 1 of its stages are always in flight.
 // Results: each wave sums its stages' four k-slices in K order into one accumulator; the four partial sums are added as ((w0 + w1) + w2) + w3 in fp32 -- bit-identical
 // to the other schedules wherever partial sums are exact (the reference's test regime), one fp32 rounding apart otherwise, like every split-K plan here.
 #pragma once
@@ -30,7 +32,8 @@ struct OsCfg {
 };
 
 // RM: the scale operands are row-major (rows, K / 32) as matmul_ada_mxf4_bf16_tn hands them over (qutlass/csrc/gemm_ada.cu) instead of the to_blocked image
-template <class C, bool RM = false>
+// RING: any K -- the wave's SPW slots are refilled as they are consumed (false: K <= 1024 SPW, every stage has a slot of its own)
+template <class C, bool RM = false, bool RING = false>
 __global__ __launch_bounds__(256) void gemm_mx_os_kernel(const GemmParams p) {
   constexpr int SPW = C::SPW, LPS = C::LPS;
   __shared__ __attribute__((aligned(16))) char smem[C::LDS_BYTES];
@@ -62,8 +65,8 @@ __global__ __launch_bounds__(256) void gemm_mx_os_kernel(const GemmParams p) {
   const __amdgpu_buffer_rsrc_t rSA = make_rsrc(p.SFA + sa_off, p.sfa_bytes - sa_off), rSB = make_rsrc(p.SFB + sb_off, p.sfb_bytes - sb_off);
   const int vSA = RM ? i32 * KB + 4 * g : g * 512 + i32 * 16 + ((m0 & 127) >> 5) * 4, vSB = RM ? i32 * KB + 4 * g : g * 512 + i32 * 16 + ((n0 & 127) >> 5) * 4;
 
-  auto issue = [&](const int kt) __attribute__((always_inline)) {   // stage kt into its own LDS area (kt >= KT: every piece out of range -> zeros)
-    char* st = smem + kt * C::STAGE;
+  auto issue = [&](const int kt, const int slot) __attribute__((always_inline)) {   // stage kt into slot `slot` of this wave (kt >= KT: every piece out of range -> zeros)
+    char* st = smem + (wave * SPW + slot) * C::STAGE;
     int tail = (kt == KT - 1) ? tailbytes : C::ROWB;
     int oob = (kt < KT) ? 0 : -1;
     asm volatile("" : "+v"(tail), "+v"(oob));
@@ -82,9 +85,9 @@ __global__ __launch_bounds__(256) void gemm_mx_os_kernel(const GemmParams p) {
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rSB, (lds_ptr_t)(st + C::OFF_S + 256), 4, (vSB & ~os) | ((int)0x80000000 & os), RM ? kt * 8 : kt * 1024, 0, 0);
   };
 
-  // ---- everything this wave will ever read, requested now -------------------------------------------------------------------------------
+  // ---- everything this wave will ever read (RING: its first SPW stages), requested now ---------------------------------------------------------
 #pragma unroll
-  for (int j = 0; j < SPW; ++j) issue(wave + 4 * j);
+  for (int j = 0; j < SPW; ++j) issue(wave + 4 * j, j);
 
   // row i32 of the tile, logical chunk 4 g + js (lane half g owns K-blocks 4 g .. 4 g + 3 of the stage), physical chunk ^ ((row >> 1) & 7)
   const int sw = (i32 >> 1) & 7;
@@ -93,11 +96,9 @@ __global__ __launch_bounds__(256) void gemm_mx_os_kernel(const GemmParams p) {
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
   auto fence = [&]() __attribute__((always_inline)) { __builtin_amdgcn_sched_barrier(0); };
 
-  static_for<0, SPW>([&](auto jc) __attribute__((always_inline)) {
-    constexpr int j = decltype(jc)::value;
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((SPW - 1 - j) * LPS) : "memory");   // this wave's stage j landed (its later stages may still be in flight)
-    fence();
-    const char* st = smem + (wave + 4 * j) * C::STAGE;
+  // one stage out of slot u; RING: kt_next (>= KT: zeros) is requested into the slot as soon as the reads have returned
+  auto consume = [&](const int u, const int kt_next) __attribute__((always_inline)) {
+    const char* st = smem + (wave * SPW + u) * C::STAGE;
     v4i fa[4], fb[4];
 #pragma unroll
     for (int js = 0; js < 4; ++js) {
@@ -107,6 +108,11 @@ __global__ __launch_bounds__(256) void gemm_mx_os_kernel(const GemmParams p) {
     }
     const int sa = *(const int*)(st + C::OFF_S + lane * 4), sb = *(const int*)(st + C::OFF_S + 256 + lane * 4);
     fence();   // all ten reads issued before the first MFMA (left alone, the compiler reads one k-slice at a time into the same registers: four exposed LDS round trips)
+    if constexpr (RING) {
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[0]), "+v"(fa[1]), "+v"(fa[2]), "+v"(fa[3]), "+v"(fb[0]), "+v"(fb[1]), "+v"(fb[2]), "+v"(fb[3]) :: "memory");   // the slot is free
+      issue(kt_next, u);
+      fence();
+    }
 #pragma unroll
     for (int js = 0; js < 4; ++js) {
       const v4i a = fa[js], b = fb[js];
@@ -117,7 +123,28 @@ __global__ __launch_bounds__(256) void gemm_mx_os_kernel(const GemmParams p) {
       if (js == 3) acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(B8, A8, acc, 4, 4, 3, sb, 3, sa);
     }
     fence();
-  });
+  };
+  if constexpr (!RING) {
+    static_for<0, SPW>([&](auto jc) __attribute__((always_inline)) {
+      constexpr int j = decltype(jc)::value;
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"((SPW - 1 - j) * LPS) : "memory");   // this wave's stage j landed (its later stages may still be in flight)
+      fence();
+      consume(j, 0);
+    });
+  } else {
+    // the wave's stages kt = wave + 4 j, j = 0, 1, ...: slot j % SPW; behind the wait for stage j exactly the SPW - 1 stages after it are outstanding (the refills
+    // past K are zero-fill pieces: the count stays the same to the end)
+    for (int kt = wave; kt < KT; kt += 4 * SPW) {
+      static_for<0, SPW>([&](auto uc) __attribute__((always_inline)) {
+        constexpr int u = decltype(uc)::value;
+        if (u == 0 || kt + 4 * u < KT) {
+          asm volatile("s_waitcnt vmcnt(%0)" ::"n"((SPW - 1) * LPS) : "memory");
+          fence();
+          consume(u, kt + 4 * u + 4 * SPW);
+        }
+      });
+    }
+  }
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();   // every wave's reads of the stage areas are done: they become the sum's scratch
   fence();

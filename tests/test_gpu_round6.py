@@ -268,10 +268,8 @@ KS_SHAPES = [(1, 8, 128), (9, 40, 384), (33, 104, 1408), (64, 264, 4096), (100, 
 
 
 @pytest.mark.parametrize("variant", [561, 562, 563, 564, 565, 566, 567, 568])
-@pytest.mark.parametrize("m,n,k", KS_SHAPES + [(5, 72, 1024), (40, 200, 2944), (64, 96, 3072)])
+@pytest.mark.parametrize("m,n,k", KS_SHAPES + [(5, 72, 1024), (40, 200, 2944), (64, 96, 3072), (9, 136, 4224), (33, 72, 11008), (3, 40, 14336), (64, 64, 4352)])   # (568: one shot up to K = 4096, wave-owned rings beyond)
 def test_ks_kernel_against_the_oracle(variant, m, n, k):
-    if variant == 568 and k > 4096:
-        pytest.skip("the one-shot kernel (gemm_mx_os.hip.h) holds at most 16 K stages in LDS")
     a, b, sa, sb = _mx_operands_exact(m, n, k, m * 7 + n + k)
     alpha = torch.tensor([0.5], device=DEV)
     with lab.forced(gemm_variant=variant):
@@ -281,7 +279,7 @@ def test_ks_kernel_against_the_oracle(variant, m, n, k):
     assert not bad.any(), f"{int(bad.sum())} of {bad.size} outputs differ, first at {np.argwhere(bad)[0].tolist()}"
 
 
-@pytest.mark.parametrize("m,n,k", [(1, 8, 128), (5, 72, 1024), (33, 104, 1408), (40, 200, 2944), (64, 96, 3072), (31, 264, 4096), (17, 8192, 3968)])
+@pytest.mark.parametrize("m,n,k", [(1, 8, 128), (5, 72, 1024), (33, 104, 1408), (40, 200, 2944), (64, 96, 3072), (31, 264, 4096), (17, 8192, 3968), (9, 136, 4224), (33, 72, 11008), (3, 40, 14336)])
 def test_one_shot_kernel_with_row_major_scales_against_the_oracle(q, m, n, k):
     """matmul_ada_mxf4_bf16_tn (qutlass/csrc/gemm_ada.cu; row-major scale operands) on shapes the product sends to the one-shot kernel (csrc/gemm_mx_os.hip.h, RM form):
     ragged M / N, K tails of half a stage, 1 ... 16 stages; the same operands through the blocked-scale entry (one-shot kernel, blocked form) and the 64x64 ring kernel."""
@@ -300,6 +298,8 @@ def test_one_shot_kernel_with_row_major_scales_against_the_oracle(q, m, n, k):
     tsa, tsb = torch.from_numpy(sa_b).to(DEV), torch.from_numpy(sb_b).to(DEV)
     assert np.array_equal(_np(q.matmul_mxf4_bf16_tn(a, b, tsa.view(e8), tsb.view(e8), alpha)), ref)
     with lab.forced(gemm_variant=70):   # the ring kernel with row-major scale fetch, the plan before this kernel
+        assert np.array_equal(_np(lab.matmul_ada_mxf4_bf16_tn(a, b, sa, sb, alpha)), ref)
+    with lab.forced(gemm_variant=568):  # ... and the kernel itself where the product rule does not send the shape to it
         assert np.array_equal(_np(lab.matmul_ada_mxf4_bf16_tn(a, b, sa, sb, alpha)), ref)
 
 

@@ -1,3 +1,5 @@
+"""matmul_ada_mxf4_bf16_tn (row-major scale operands) on decode shapes: the LDS-free split-K kernel (60), the 64x64 ring (70), the one-shot / wave-owned-ring kernel (568,
+csrc/gemm_mx_os.hip.h) and the product rule (0), GPU-only timing (HIP-graph replays) + equality of the four results.   ADA_NK=4096x8192,... python tools/calib_ada.py"""
 import os, sys
 ROOT = os.environ.get("GRAFT_REPO_ROOT", "/root/repo")
 sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tools"))
@@ -8,7 +10,8 @@ dev = torch.device("cuda:0")
 g = torch.Generator(device=dev).manual_seed(0)
 alpha = torch.ones(1, device=dev)
 print("# matmul_ada_mxf4_bf16_tn (row-major scales), us per launch (HIP-graph replays): forced 60 = LDS-free split-K kernel, 70 = 64x64 ring, 568 = one-shot, 0 = the product rule")
-for (n, k) in ((4096, 4096), (2048, 2048), (8192, 4096), (1024, 4096), (6144, 4096)):
+NK = [tuple(int(d) for d in x.split("x")) for x in os.environ.get("ADA_NK", "4096x4096,2048x2048,8192x4096,1024x4096,6144x4096").split(",")]
+for (n, k) in NK:
     for m in (1, 8, 16, 32, 64):
         a = torch.randint(0, 256, (m, k // 2), dtype=torch.uint8, device=dev, generator=g)
         b = torch.randint(0, 256, (n, k // 2), dtype=torch.uint8, device=dev, generator=g)
