@@ -265,31 +265,35 @@ int launch_gemm_ks(GemmParams p, hipStream_t s) {
 }
 
 // [r6] small-batch kernel that requests a 32x32 tile's whole K extent up front (gemm_mx_os.hip.h): K <= 4096, wave w owns stages w, w + 4, ...
-// (RM: row-major scale operands -- matmul_ada_mxf4_bf16_tn)
-template <bool RM = false>
+// (RM: row-major scale operands -- matmul_ada_mxf4_bf16_tn; TN: columns per workgroup, 32 or 16)
+template <bool RM = false, int TN = 32>
 int launch_gemm_os(GemmParams p, hipStream_t s) {
   p.tiles_m = (int)cdiv(p.M, 32);
-  p.tiles_n = (int)cdiv(p.N, 32);
+  p.tiles_n = (int)cdiv(p.N, TN);
   p.ws = nullptr; p.splits = 1; p.ctr = nullptr; p.tag = 0;
   const int64_t KT = cdiv(p.K, 256);
   const dim3 grid(p.tiles_m * p.tiles_n), block(256);
-  if (KT <= 4) hipLaunchKernelGGL((gemm_mx_os_kernel<OsCfg<1>, RM>), grid, block, 0, s, p);
-  else if (KT <= 8) hipLaunchKernelGGL((gemm_mx_os_kernel<OsCfg<2>, RM>), grid, block, 0, s, p);
-  else if (KT <= 12) hipLaunchKernelGGL((gemm_mx_os_kernel<OsCfg<3>, RM>), grid, block, 0, s, p);
-  else if (KT <= 16) hipLaunchKernelGGL((gemm_mx_os_kernel<OsCfg<4>, RM>), grid, block, 0, s, p);
-  else hipLaunchKernelGGL((gemm_mx_os_kernel<OsCfg<4>, RM, true>), grid, block, 0, s, p);   // wave-owned rings of four slots
+  if (KT <= 4) hipLaunchKernelGGL((gemm_mx_os_kernel<OsCfg<1, TN>, RM>), grid, block, 0, s, p);
+  else if (KT <= 8) hipLaunchKernelGGL((gemm_mx_os_kernel<OsCfg<2, TN>, RM>), grid, block, 0, s, p);
+  else if (KT <= 12) hipLaunchKernelGGL((gemm_mx_os_kernel<OsCfg<3, TN>, RM>), grid, block, 0, s, p);
+  else if (KT <= 16) hipLaunchKernelGGL((gemm_mx_os_kernel<OsCfg<4, TN>, RM>), grid, block, 0, s, p);
+  else hipLaunchKernelGGL((gemm_mx_os_kernel<OsCfg<4, TN>, RM, true>), grid, block, 0, s, p);   // wave-owned rings of four slots
   return check_launch("gemm_mx_os_kernel");
 }
-// Does the one-shot kernel take the shape?  32x32 tiles, one per CU at most; K <= 16 stages of 256: always.  Longer K (wave-owned rings): up to 32 stages when the tiles
-// fill a quarter of the chip, up to 64 stages (K = 16384) when they fill half of it (N = 1024, K = 14336: 32 workgroups take 7.4 us where the split-K plans take
-// 5.7-6.9); the blocked-scale op also keeps M < 8 with more than 32 stages on the LDS-free split-K kernel (4096 x 11008, M = 1: 6.07 vs 6.40 us).  ada: matmul_ada_mxf4_bf16_tn (row-major scales: its other kernels are
-// 25-45 % slower on every such shape).  profiles/calib_os_r6q.txt, calib_osring_r6q.txt, calib_ada_r6q.txt
-inline bool os_fits(int64_t M, int64_t N, int64_t K, bool ada = false) {
-  const int64_t cus = chip_cus(), T32 = cdiv(M, 32) * cdiv(N, 32), KT = cdiv(K, 256);
-  if (T32 > cus) return false;
-  if (KT <= 16) return true;
-  if (KT <= 32) return 4 * T32 >= cus;
-  return KT <= 64 && 2 * T32 >= cus && (ada || M >= 8);   // (measured with 128 and 256 tiles only: fewer tiles against K > 8192 stay with the split plans)
+// Does the one-shot kernel take the shape, and with how many columns per workgroup?  Returns 0 (no), 32 or 16.  32x32 tiles, one per CU at most; 16 columns per
+// workgroup whenever that still leaves one workgroup per CU (N = 4096, M <= 32: 256 workgroups pulling half the bytes each -- 3.34 -> 3.22 us at K = 4096, 7.8 -> 6.9 at
+// K = 14336).  K <= 16 stages of 256: always.  Longer K (wave-owned rings): up to 32 stages when the tiles fill a quarter of the chip, up to 64 stages (K = 16384) when
+// they fill half of it (N = 1024, K = 14336: 32 workgroups take 7.4 us where the split-K plans take 5.7-6.9); with 32 columns per workgroup the blocked-scale op also keeps
+// M < 8 against more than 32 stages on the LDS-free split-K kernel (4096 x 11008, M = 1: 6.07 vs 6.40 us).  ada: matmul_ada_mxf4_bf16_tn (row-major scales: its other
+// kernels are 25-45 % slower on every such shape).  profiles/calib_os_r6q.txt, calib_osring_r6q.txt, calib_ada_r6q.txt, calib_os16_r6s.txt
+inline int os_plan(int64_t M, int64_t N, int64_t K, bool ada = false) {
+  const int64_t cus = chip_cus(), T32 = cdiv(M, 32) * cdiv(N, 32), T16 = cdiv(M, 32) * cdiv(N, 16), KT = cdiv(K, 256);
+  if (T32 > cus) return 0;
+  const int tn = T16 <= cus ? 16 : 32;
+  if (KT <= 16) return tn;
+  if (KT <= 32) return 4 * T32 >= cus ? tn : 0;
+  if (KT > 64 || 2 * T32 < cus) return 0;   // (measured with 128 and 256 tiles only: fewer tiles against K > 8192 stay with the split plans)
+  return (ada || M >= 8 || tn == 16) ? tn : 0;
 }
 
 // [r4] stream-K form of the two persistent kernels (lab variant 89): one workgroup per CU; p.ws / p.ctr / p.tag / p.sk_tiles set by gemm_mx
@@ -501,7 +505,8 @@ int dispatch_variant(int v, const GemmParams& p, hipStream_t s, const char* name
       if (v == 561) return deep ? launch_gemm_ks<32, 32, 6>(p, s) : launch_gemm_ks<32, 32, 4>(p, s);
       return deep ? launch_gemm_ks<32, 64, 6>(p, s) : launch_gemm_ks<32, 64, 4>(p, s);
     }
-    if (v == 568) return launch_gemm_os<false>(p, s);   // [r6] 32x32 tiles, the whole K extent (<= 16 stages) requested up front (gemm_mx_os.hip.h)
+    if (v == 568) return launch_gemm_os<false>(p, s);
+    if (v == 569) return launch_gemm_os<false, 16>(p, s);   // [r6] the same with 16 columns per workgroup   // [r6] 32x32 tiles, the whole K extent (<= 16 stages) requested up front (gemm_mx_os.hip.h)
 #if QAMD_BENCH
     if (v == 99) return launch_gemm_hetero<GemmCfg<256, 256, 2, 2, 4, false>, GemmCfg<128, 128, 2, 2, 4, false, 0, 3>, 17>(p, s);
     // [r6] lab: the other tiles / ring depths of the in-workgroup K-split kernel (563 = 64x32, 564 = 64x64; 565 - 567 = 32x32 with a 4 / 8 / 6-deep ring)
@@ -741,14 +746,14 @@ SmallPlan plan_small(int64_t M, int64_t N, int64_t K, bool may_split = true) {
 //     (N = 4096, K = 14336: M <= 16 8.1-9.1 us split against 9.2-9.4; M = 64 11.4 against 9.8).
 // Where it applies it is 11 ... 30 % faster (N = K = 4096: M <= 64 4.9-5.3 -> 4.1-4.5 us; 8192^2: M <= 32 8.8-11.1 -> 7.4-7.8 us), M = 1 ... 8 included (the LDS-free
 // split-K kernel: 4.55-4.92 us at N = K = 4096).  32x64 tiles: only where 32x32 tiles just overflow the chip and 32x64 nearly fill it (N = 14336: -6 %).
-// Returns the variant (568 / 561 / 562) or 0.
+// Returns the variant (568 / 569 / 561 / 562) or 0.
 inline int ks_plan(int64_t M, int64_t N, int64_t K) {
   const int64_t cus = chip_cus(), KT = cdiv(K, 256);
   const int64_t T32 = cdiv(M, 32) * cdiv(N, 32);
   // [r6] K <= 4096: the tile's whole K extent fits the LDS -- the one-shot kernel (gemm_mx_os.hip.h), no ring and no barrier in the K walk: N = K = 4096, M = 1 ... 64
-  // 4.05-4.39 -> 3.34-3.67 us, N = K = 2048 3.15-3.26 -> 2.62-2.77 (profiles/calib_os_r6q.txt); its wave-owned-ring form for longer K where os_fits says so
+  // 4.05-4.39 -> 3.34-3.67 us, N = K = 2048 3.15-3.26 -> 2.62-2.77 (profiles/calib_os_r6q.txt); its wave-owned-ring form for longer K and 16 columns per workgroup where os_plan says so
   // (4096 x 8192, M <= 32: 5.8-7.1 -> 5.5-5.7 us); past one tile per CU the ring plans below keep the shape
-  if (os_fits(M, N, K)) return 568;
+  if (const int tn = os_plan(M, N, K)) return tn == 16 ? 569 : 568;
   if (T32 <= cus && (KT <= 24 || (2 * T32 > cus && KT <= 64))) return 561;   // (K > 16384 was not calibrated, and a split-K plan on larger tiles moves fewer bytes per CU there)
   const int64_t T64 = cdiv(M, 32) * cdiv(N, 64);
   if (M <= 32 && T32 > cus && T64 <= cus && 8 * T64 >= 7 * cus && KT <= 24) return 562;
@@ -1171,7 +1176,9 @@ static int ada_impl(const void* A, const void* B, const void* A_sf, const void* 
   const int cus = chip_cus();
   const bool ring = forced == 70 || (forced != 60 && (M > 32 || T64 >= cus || (T64 >= cus / 2 && K < 16384)));
   // [r6] K <= 4096 and at most one 32x32 tile per CU: the one-shot kernel with row-major scale pieces (gemm_mx_os.hip.h; "gemm_variant" 568 forces it where it fits)
-  const bool oneshot = forced == 568 ? cdiv(M, 32) * cdiv(N, 32) <= 4 * cus : (forced == 0 && os_fits(M, N, K, true));
+  const int os_tn = forced == 0 ? os_plan(M, N, K, true) : 0;
+  const bool os16 = forced == 569 || os_tn == 16;   // 16 columns per workgroup
+  const bool oneshot = (forced == 568 || forced == 569) ? cdiv(M, 32) * cdiv(N, 32) <= 4 * cus : os_tn != 0;
   if (ring || oneshot) {
     GemmParams p;
     p.A = (const uint8_t*)A; p.B = (const uint8_t*)B; p.SFA = (const uint8_t*)A_sf; p.SFB = (const uint8_t*)B_sf;
@@ -1180,7 +1187,7 @@ static int ada_impl(const void* A, const void* B, const void* A_sf, const void* 
     p.sfa_bytes = (uint32_t)(M * KB); p.sfb_bytes = (uint32_t)(N * KB);   // row-major (rows, K/32), un-swizzled
     p.pp_shift = opt_pp_shift(); p.pp_flags = opt_pp_flags(); p.dbg = opt_dbg();
     p.ws = nullptr; p.splits = 1; p.ctr = nullptr; p.tag = 0;
-    if (oneshot) return launch_gemm_os<true>(p, (hipStream_t)stream);
+    if (oneshot) return os16 ? launch_gemm_os<true, 16>(p, (hipStream_t)stream) : launch_gemm_os<true>(p, (hipStream_t)stream);
 #if QAMD_BENCH
     if (opt_gemm_variant() == 178) return launch_gemm<GemmCfg<64, 64, 2, 2, 4, false, 0, 3>, 8>(p, (hipStream_t)stream);   // round-1 ring schedule
 #endif

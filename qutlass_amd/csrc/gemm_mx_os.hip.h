@@ -20,11 +20,16 @@
 
 namespace qamd {
 
-template <int SPW_>   // K stages per wave: the kernel covers K <= 1024 SPW
+// TN = 16 ([r6]): the workgroup owns 16 output columns -- only B rows 0 .. 15 of the tile are fetched (rows 16 .. 31 of the MFMA's B fragment read whatever the LDS
+// holds: they only feed output columns 16 .. 31, which are not stored), so a weight of N columns spreads over N / 16 workgroups: N = 4096 fills 256 CUs instead of 128
+// and every CU pulls half the bytes through its LDS-DMA path.
+template <int SPW_, int TN_ = 32>   // K stages per wave: the kernel covers K <= 1024 SPW (RING: any K)
 struct OsCfg {
-  static constexpr int TM = 32, TN = 32, ROWB = 128, SPW = SPW_, KTMAX = 4 * SPW_;
-  static constexpr int OFF_B = TM * ROWB, OFF_S = (TM + TN) * ROWB, STAGE = OFF_S + 512;   // + 256 B of scale dwords per operand
-  static constexpr int LPS = 10;                                                            // LDS-DMA instructions per stage: 4 A pieces, 4 B pieces, 2 scale pieces
+  static constexpr int TM = 32, TN = TN_, ROWB = 128, SPW = SPW_, KTMAX = 4 * SPW_;
+  static constexpr int OFF_B = TM * ROWB, OFF_S = (TM + 32) * ROWB, STAGE = OFF_S + 512;   // + 256 B of scale dwords per operand (the B area keeps 32 rows: the fragment reads span them)
+  static constexpr int NPB = TN / 8;                                                        // B pieces per stage
+  static constexpr int LPS = 4 + NPB + 2;                                                   // LDS-DMA instructions per stage: 4 A pieces, 4 / 2 B pieces, 2 scale pieces
+  static_assert(TN == 32 || TN == 16, "tile width");
   static constexpr int RED = 4 * 4096;                                                      // cross-wave sum: [wave] 32 x 32 fp32
   static constexpr int LDS_BYTES = KTMAX * STAGE > RED ? KTMAX * STAGE : RED;
   static_assert(SPW >= 1 && SPW * LPS <= 63, "vmcnt immediate");
@@ -63,7 +68,8 @@ __global__ __launch_bounds__(256) void gemm_mx_os_kernel(const GemmParams p) {
   const int KB = p.K >> 5;
   const uint32_t sa_off = RM ? (uint32_t)m0 * KB : (uint32_t)(m0 >> 7) * CB * 512, sb_off = RM ? (uint32_t)n0 * KB : (uint32_t)(n0 >> 7) * CB * 512;
   const __amdgpu_buffer_rsrc_t rSA = make_rsrc(p.SFA + sa_off, p.sfa_bytes - sa_off), rSB = make_rsrc(p.SFB + sb_off, p.sfb_bytes - sb_off);
-  const int vSA = RM ? i32 * KB + 4 * g : g * 512 + i32 * 16 + ((m0 & 127) >> 5) * 4, vSB = RM ? i32 * KB + 4 * g : g * 512 + i32 * 16 + ((n0 & 127) >> 5) * 4;
+  const int rowB = (n0 & 127) + i32;   // row of the 128-row scale tile (TN = 16: n0 is a multiple of 16 only; lanes past the 16 rows fetch some row's dword -- unused)
+  const int vSA = RM ? i32 * KB + 4 * g : g * 512 + i32 * 16 + ((m0 & 127) >> 5) * 4, vSB = RM ? i32 * KB + 4 * g : g * 512 + (rowB & 31) * 16 + ((rowB & 127) >> 5) * 4;
 
   auto issue = [&](const int kt, const int slot) __attribute__((always_inline)) {   // stage kt into slot `slot` of this wave (kt >= KT: every piece out of range -> zeros)
     char* st = smem + (wave * SPW + slot) * C::STAGE;
@@ -72,7 +78,7 @@ __global__ __launch_bounds__(256) void gemm_mx_os_kernel(const GemmParams p) {
     asm volatile("" : "+v"(tail), "+v"(oob));
     const int soff = kt * C::ROWB;
 #pragma unroll
-    for (int t = 0; t < 8; ++t) {
+    for (int t = 0; t < 4 + C::NPB; ++t) {
       const bool isB = t >= 4;
       const int qq = t & 3, par = qq & 1;
       const int o = oob | ((chP[par] << 4) < tail ? 0 : -1);
@@ -162,7 +168,7 @@ __global__ __launch_bounds__(256) void gemm_mx_os_kernel(const GemmParams p) {
 #pragma unroll
   for (int e = 0; e < 4; ++e) t[e] = ((s[0][e] + s[1][e]) + s[2][e]) + s[3][e];
   const int row = m0 + rr, col = n0 + 4 * cq;
-  if (row < p.M && col < p.N) {
+  if (row < p.M && col < p.N && 4 * cq < C::TN) {
     v2i o;
     o[0] = (int)pack_bf16x2(t[0] * alpha, t[1] * alpha);
     o[1] = (int)pack_bf16x2(t[2] * alpha, t[3] * alpha);

@@ -111,8 +111,8 @@ def test_split_k_workspace_plan_is_a_pure_host_function(lib):
     # per CU go to the in-workgroup K-split kernel instead (capi.hip ks_plan: no scratch): the MXFP8 twin of this shape still shows the split plan
     assert splits(4, 64, 4096, 14336) == 4 and ws(4, 64, 4096, 14336) == 0
     assert splits(8, 64, 4096, 7168) == 4 and ws(8, 64, 4096, 7168) == layout(64, 4096, 4) == 4 * 64 * 4096 * 4
-    assert splits(4, 16, 4096, 14336) == 4 and ws(4, 16, 4096, 14336) == 0   # [r6] the wave-owned-ring form of the one-shot kernel takes it (capi.hip os_fits): no scratch
-    assert ws(4, 4, 4096, 14336) == layout(4, 4096, splits(4, 4, 4096, 14336))    # ... M < 8 with more than 32 stages stays with the split plans
+    assert splits(4, 16, 4096, 14336) == 4 and ws(4, 16, 4096, 14336) == 0   # [r6] the wave-owned-ring form of the one-shot kernel takes it (capi.hip os_plan): no scratch
+    assert ws(4, 4, 2048, 14336) == layout(4, 2048, splits(4, 4, 2048, 14336))    # ... a quarter of the chip against 56 stages stays with the split plans
     assert ws(4, 128, 4096, 14336) == layout(128, 4096, 2)   # 128 tiles: 2 splits
     assert ws(4, 256, 4096, 14336) == 0 and ws(4, 192, 4096, 14336) == 0   # more than 128 tiles: no split
     assert ws(4, 64, 4096, 4096) == 0            # 16 stages: too short to pay for the reduction
@@ -477,17 +477,18 @@ def test_auto_dispatch_rules_dry_run(lib):
     # [r6] ... where the in-workgroup K-split kernel does not take the shape: it does whenever the 32x32 tiles fit one per CU and K <= 24 stages of 256 (or they fill
     # more than half the chip and K <= 16384) -- N = K = 4096: M = 1 ... 64 4.5-5.3 -> 4.1-4.5 us; 32x64 tiles where 32x32 just overflow (N = 14336)
     # [r6] ... and with K <= 4096 (16 stages) the tile's whole K extent fits the LDS: the one-shot kernel (csrc/gemm_mx_os.hip.h), N = K = 4096, M = 1 ... 64 4.05-4.39 -> 3.34-3.67 us
-    OS32 = 568
-    assert plan(4, 1, 4096, 4096) == [(OS32, 4096, 1)] and plan(4, 8, 4096, 4096) == [(OS32, 4096, 1)] and plan(4, 8, 8192, 8192) == [(OS32, 8192, 1)]
-    assert plan(4, 16, 4096, 4096) == [(OS32, 4096, 1)] and plan(4, 32, 4096, 4096) == [(OS32, 4096, 1)] and plan(4, 24, 2048, 2048) == [(OS32, 2048, 1)]
+    OS32, OS16 = 568, 569   # 32 / 16 output columns per workgroup: 16 whenever that still leaves at most one workgroup per CU (N = 4096, M <= 32: 256 workgroups)
+    assert plan(4, 1, 4096, 4096) == [(OS16, 4096, 1)] and plan(4, 8, 4096, 4096) == [(OS16, 4096, 1)] and plan(4, 8, 8192, 8192) == [(OS32, 8192, 1)]
+    assert plan(4, 16, 4096, 4096) == [(OS16, 4096, 1)] and plan(4, 32, 4096, 4096) == [(OS16, 4096, 1)] and plan(4, 24, 2048, 2048) == [(OS16, 2048, 1)]
     assert plan(4, 32, 8192, 4096) == [(OS32, 8192, 1)] and plan(4, 33, 8192, 4096) != [(OS32, 8192, 1)]   # one tile per CU at most
-    # longer K: the same kernel on wave-owned rings where the tiles fill a quarter of the chip (M < 8 with more than 32 stages stays on the LDS-free split-K kernel)
-    assert plan(4, 16, 4096, 4224) == [(OS32, 4096, 1)] and plan(4, 16, 4096, 8192) == [(OS32, 4096, 1)] and plan(4, 1, 4096, 8192) == [(OS32, 4096, 1)]
+    # longer K: the same kernel on wave-owned rings where the tiles fill a quarter of the chip (M < 8 with more than 32 stages stays on the LDS-free split-K kernel
+    # unless the 16-column form applies)
+    assert plan(4, 16, 4096, 4224) == [(OS16, 4096, 1)] and plan(4, 16, 4096, 8192) == [(OS16, 4096, 1)] and plan(4, 1, 4096, 8192) == [(OS16, 4096, 1)]
     assert plan(4, 1, 8192, 14336) == [(KS32, 8192, 1)] and plan(4, 16, 1024, 5120) == [(KS32, 1024, 1)]   # what the K-split ring kernel keeps
-    assert plan(4, 16, 1024, 14336) != [(OS32, 1024, 1)] and plan(4, 8, 4096, 14336, big) == [(OS32, 4096, 1)] and plan(4, 16, 4096, 32768) != [(OS32, 4096, 1)]
+    assert plan(4, 16, 1024, 14336) != [(OS32, 1024, 1)] and plan(4, 8, 4096, 14336, big) == [(OS16, 4096, 1)] and plan(4, 16, 4096, 32768) != [(OS32, 4096, 1)]
     assert plan(4, 16, 14336, 4096) == [(KS32x64, 14336, 1)]
-    assert plan(4, 1, 4096, 14336) == [(SKINNY, 4096, 1)] and plan(4, 4, 4096, 11008) == [(SKINNY, 4096, 1)]     # long K, half the chip, M < 8: the split-K kernels keep it
-    assert plan(4, 8, 4096, 11008) == [(OS32, 4096, 1)]
+    assert plan(4, 1, 4096, 14336) == [(OS16, 4096, 1)] and plan(4, 8, 4096, 11008) == [(OS16, 4096, 1)]     # [r6] (rounds 3-5: the LDS-free split-K kernel, 7.6-7.8 us; 16-column wave-owned rings 6.9)
+    assert plan(4, 4, 8192, 11008) == [(KS32, 8192, 1)] and plan(4, 4, 2048, 11008) == [(SKINNY, 2048, 1)]     # long K, M < 8, no room for 16-column workgroups / too few tiles: the split-K kernels keep it
     assert plan(4, 16, 11008, 4096) == [(RING64, 11008, 1)] and plan(4, 96, 4096, 4096) == [(RING64, 4096, 1)]  # 32x32 tiles would sit two on a CU
     assert plan(4, 16, 57344, 8192) == [(28, 57344, 1)]
     assert plan(8, 16, 4096, 4096) == [(RING64, 4096, 1)]            # no fp8 skinny kernel
@@ -497,7 +498,7 @@ def test_auto_dispatch_rules_dry_run(lib):
     assert plan(8, 64, 4096, 7168) == [(RING64, 4096, 1)]
     assert plan(8, 64, 4096, 7168, big) == [(RING64, 4096, 4)]
     assert plan(8, 64, 4096, 7168, 64 * 4096 * 4 * 4 - 1) == [(RING64, 4096, 1)]   # scratch one byte short: single pass
-    assert plan(4, 16, 4096, 14336, big) == [(OS32, 4096, 1)]         # [r6] (rounds 3-5: 64x64 tiles x 4 K ranges, 8.85 us; wave-owned rings 8.0)
+    assert plan(4, 16, 4096, 14336, big) == [(OS16, 4096, 1)]         # [r6] (rounds 3-5: 64x64 tiles x 4 K ranges, 8.85 us; wave-owned rings 8.0)
     assert plan(4, 128, 4096, 14336, big) == [(RING64, 4096, 2)]
     assert plan(4, 128, 4096, 8192, big) == [(RING64, 4096, 1)]       # a two-way split needs >= 48 K stages to pay for its reduce pass
     assert plan(4, 256, 4096, 14336, big) == [(RING64, 4096, 1)]
@@ -519,7 +520,7 @@ def test_auto_dispatch_rules_dry_run(lib):
     assert plan(4, 256, 8192, 28672, big) == [(RING128, 8192, 2)] and plan(4, 384, 5120, 25600, big) == [(RING128, 5120, 2)] and plan(4, 256, 8192, 8192, big) == [(RING64x128, 8192, 1)]
     assert plan(4, 96, 57344, 8192) == [(24, 57344, 1)] and plan(8, 128, 51200, 5120) == [(24, 51200, 1)] and plan(4, 192, 57344, 8192) == [(DEEPP, 57344, 1)]
     # an A operand of >= 2 GiB (262400 x 16384 fp4 = 2.15 GB) runs as two row ranges of whole 256-row tiles
-    assert plan(4, 262400, 256, 16384) == [(DEEPP, 256, 1), (OS32, 256, 1)]   # 261888 rows, then the last 512 (128 tiles of 32x32, 64 stages: wave-owned rings; rounds 3-5: 64x64 ring tiles)
+    assert plan(4, 262400, 256, 16384) == [(DEEPP, 256, 1), (OS16, 256, 1)]   # 261888 rows, then the last 512 (256 workgroups of 32x16, 64 stages: wave-owned rings; rounds 3-5: 64x64 ring tiles)
     # ... and a B operand of >= 2 GiB (262400 x 16384 fp4 weight) as two column ranges of whole 256-column tiles writing one D
     assert plan(4, 16, 262400, 16384) == [(28, 261888, 1), (SKINNY, 512, 1)]   # [r3] the split-K kernel writes a column range too (row stride ldd)
     assert plan(4, 4096, 262400, 16384) == [(DEEPP, 261888, 1), (71, 512, 1)]

@@ -267,7 +267,7 @@ def _mx_operands_exact(m, n, k, seed):
 KS_SHAPES = [(1, 8, 128), (9, 40, 384), (33, 104, 1408), (64, 264, 4096), (100, 72, 640), (31, 4096, 4096), (64, 2048, 8192), (130, 520, 256)]
 
 
-@pytest.mark.parametrize("variant", [561, 562, 563, 564, 565, 566, 567, 568])
+@pytest.mark.parametrize("variant", [561, 562, 563, 564, 565, 566, 567, 568, 569])
 @pytest.mark.parametrize("m,n,k", KS_SHAPES + [(5, 72, 1024), (40, 200, 2944), (64, 96, 3072), (9, 136, 4224), (33, 72, 11008), (3, 40, 14336), (64, 64, 4352)])   # (568: one shot up to K = 4096, wave-owned rings beyond)
 def test_ks_kernel_against_the_oracle(variant, m, n, k):
     a, b, sa, sb = _mx_operands_exact(m, n, k, m * 7 + n + k)
@@ -299,8 +299,9 @@ def test_one_shot_kernel_with_row_major_scales_against_the_oracle(q, m, n, k):
     assert np.array_equal(_np(q.matmul_mxf4_bf16_tn(a, b, tsa.view(e8), tsb.view(e8), alpha)), ref)
     with lab.forced(gemm_variant=70):   # the ring kernel with row-major scale fetch, the plan before this kernel
         assert np.array_equal(_np(lab.matmul_ada_mxf4_bf16_tn(a, b, sa, sb, alpha)), ref)
-    with lab.forced(gemm_variant=568):  # ... and the kernel itself where the product rule does not send the shape to it
-        assert np.array_equal(_np(lab.matmul_ada_mxf4_bf16_tn(a, b, sa, sb, alpha)), ref)
+    for v in (568, 569):   # ... and the kernel itself (32 / 16 columns per workgroup) where the product rule does not send the shape to it
+        with lab.forced(gemm_variant=v):
+            assert np.array_equal(_np(lab.matmul_ada_mxf4_bf16_tn(a, b, sa, sb, alpha)), ref), v
 
 
 @pytest.mark.parametrize("m,n,k", [(1, 4096, 4096), (8, 8192, 4096), (48, 4096, 4096), (64, 4096, 14336), (16, 14336, 4096), (200, 1024, 2048)])

@@ -18,9 +18,9 @@ for (n, k) in NK:
         sa = torch.randint(125, 129, (m, k // 32), dtype=torch.uint8, device=dev, generator=g)
         sb = torch.randint(125, 129, (n, k // 32), dtype=torch.uint8, device=dev, generator=g)
         t, outs = {}, {}
-        for v in (60, 70, 568, 0):
+        for v in (60, 70, 568, 569, 0):
             with lab.forced(gemm_variant=v):
                 outs[v] = lab.matmul_ada_mxf4_bf16_tn(a, b, sa, sb, alpha)
                 t[v] = min(graph_us(lambda: lab.matmul_ada_mxf4_bf16_tn(a, b, sa, sb, alpha), n=40) for _ in range(3))
-        eq = all(torch.equal(outs[v].view(torch.int16), outs[60].view(torch.int16)) for v in (70, 568, 0))
-        print("N=%-6d K=%-6d M=%-4d | %s | %s" % (n, k, m, " ".join("%d: %6.2f" % (v, t[v]) for v in (60, 70, 568, 0)), "equal" if eq else "DIFFER"), flush=True)
+        eq = all(torch.equal(outs[v].view(torch.int16), outs[60].view(torch.int16)) for v in (70, 568, 569, 0))
+        print("N=%-6d K=%-6d M=%-4d | %s | %s" % (n, k, m, " ".join("%d: %6.2f" % (v, t[v]) for v in (60, 70, 568, 569, 0)), "equal" if eq else "DIFFER"), flush=True)
