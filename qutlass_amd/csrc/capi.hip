@@ -21,6 +21,7 @@
 #include "gemm_mx_fusedq.hip.h"
 #include "gemm_nvf4.hip.h"
 #include "gemm_nvf4_pk.hip.h"
+#include "gemm_nvf4_os.hip.h"
 #include "quantize.hip.h"
 #include "to_blocked.hip.h"
 #include "transpose_u8.hip.h"

@@ -1,0 +1,204 @@
+// Small-batch NVFP4 GEMM for gfx950 on wave-owned K stages: the NVFP4 twin of gemm_mx_os.hip.h.  Replaces matmul_host_nvf4_bf16_tn's M-bucketed small tiles
+// (qutlass/csrc/gemm.cu:250-326) for batches of at most a few dozen rows, where gemm_nvf4_skinny_kernel (gemm_nvf4.hip.h) was the plan: N = K = 4096, M = 1 ... 64
+// took 5.6-7.3 us there against 3.2-3.7 us for the same bytes in MXFP4.
+//
+// One 32x32 (or 32x16) output tile per workgroup of EIGHT waves, two per SIMD -- the e2m1 -> f16 dequantisation is ~20 vector instructions per MFMA, and with two
+// waves on a SIMD one wave's converts run beside the other's MFMAs.  Wave w owns K stages w, w + 8, w + 16, ... (256 elements = 128 B per row each): it issues the
+// LDS-DMA pieces of its stages itself and is their only reader, so the K walk has no workgroup barrier; s_waitcnt vmcnt counts the wave's own pieces down.
+// K <= 4096: all 16 stages have an LDS area of their own and are requested before the first MFMA; longer K (RING): each wave refills the two slots it owns as it
+// consumes them.  Data path per stage: the pieces of gemm_mx_os (8 rows x 128 B, 16-byte chunk XOR-swizzled by row at the source; rows past M / N and chunks past K
+// fall off the buffer descriptor), and the e4m3 scales as TWO dword pieces per operand: lane (row i32, half g) fetches the dwords of column tiles 4 kt + 2 g and
+// 4 kt + 2 g + 1 of the to_blocked image -- the eight scale groups of the 64 bytes its fragments cover.
+// Arithmetic = gemm_nvf4_skinny_kernel's: cvt(e2m1) x e4m3 scale in f16 (both exact), v_mfma_f32_32x32x16_f16, fp32 sums; each wave sums its stages in K order, the
+// eight partial sums are added in wave order in fp32 -- bit-identical to the other kernels wherever partial sums are exact (the reference's test regime).
+#pragma once
+#include "gemm_nvf4.hip.h"
+
+namespace qamd {
+
+template <int SPW_, int TN_ = 32>   // stages (one shot) / slots (RING) per wave
+struct NvOsCfg {
+  static constexpr int NW = 8, TM = 32, TN = TN_, ROWB = 128, SPW = SPW_, NSLOT = NW * SPW_;
+  static constexpr int OFF_B = TM * ROWB, OFF_S = (TM + 32) * ROWB, STAGE = OFF_S + 1024;   // + four 256-byte scale pieces: A tiles (jj = 0, 1), B tiles (jj = 0, 1)
+  static constexpr int NPB = TN / 8;
+  static constexpr int LPS = 4 + NPB + 4;
+  static constexpr int RED = NW * 4096;
+  static constexpr int LDS_BYTES = NSLOT * STAGE > RED ? NSLOT * STAGE : RED;
+  static_assert(TN == 32 || TN == 16, "tile width");
+  static_assert(SPW >= 1 && SPW * LPS <= 63, "vmcnt immediate");
+  static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
+};
+
+template <class C, bool RING = false>
+__global__ __launch_bounds__(512) void gemm_nvf4_os_kernel(const NvGemmParams p) {
+  constexpr int SPW = C::SPW, LPS = C::LPS, NW = C::NW;
+  __shared__ __attribute__((aligned(16))) char smem[C::LDS_BYTES];
+  asm volatile("" :: "s"(p.A), "s"(p.D), "s"(p.K), "s"(p.b_bytes), "s"(p.alpha));   // all scalar argument loads in one round
+  const float alpha = *p.alpha;
+  const int tid = threadIdx.x, lane = tid & 63, wave = uniform(tid >> 6), i32 = lane & 31, g = lane >> 5;
+  const int nb = p.tiles_m * p.tiles_n;
+  const int b2 = xcd_remap((int)blockIdx.x, nb);
+  const int m0 = uniform((b2 % p.tiles_m) * C::TM), n0 = uniform((b2 / p.tiles_m) * C::TN);
+  const int rowbytes = p.K >> 1, KT = (rowbytes + C::ROWB - 1) / C::ROWB;
+  const int G16 = p.K >> 4, CB = (G16 + 3) >> 2;   // scale groups per row, column tiles of 4 groups
+  const int tailbytes = rowbytes - (KT - 1) * C::ROWB;
+
+  // ---- LDS-DMA sources (gemm_mx_os.hip.h) ------------------------------------------------------------------------------------------------
+  const uint32_t a_off = (uint32_t)m0 * rowbytes, b_off = (uint32_t)n0 * rowbytes;
+  const __amdgpu_buffer_rsrc_t rA = make_rsrc(p.A + a_off, p.a_bytes - a_off), rB = make_rsrc(p.B + b_off, p.b_bytes - b_off);
+  int vP[2], chP[2];
+#pragma unroll
+  for (int par = 0; par < 2; ++par) {
+    chP[par] = (lane & 7) ^ (((lane >> 4) + 4 * par) & 7);
+    vP[par] = (lane >> 3) * rowbytes + (chP[par] << 4);
+  }
+  const int rstep = 8 * rowbytes;
+  const uint32_t sa_off = (uint32_t)(m0 >> 7) * CB * 512, sb_off = (uint32_t)(n0 >> 7) * CB * 512;
+  const __amdgpu_buffer_rsrc_t rSA = make_rsrc(p.SFA + sa_off, p.sfa_bytes - sa_off), rSB = make_rsrc(p.SFB + sb_off, p.sfb_bytes - sb_off);
+  const int rowB = (n0 & 127) + i32;   // (TN = 16: n0 is a multiple of 16 only; lanes past the 16 rows fetch some row's dword -- unused)
+  const int vSA = 2 * g * 512 + i32 * 16 + ((m0 & 127) >> 5) * 4, vSB = 2 * g * 512 + (rowB & 31) * 16 + ((rowB & 127) >> 5) * 4;
+
+  auto issue = [&](const int kt, const int slot) __attribute__((always_inline)) {   // stage kt into slot `slot` of this wave (kt >= KT: every piece out of range -> zeros)
+    char* st = smem + (wave * SPW + slot) * C::STAGE;
+    int tail = (kt == KT - 1) ? tailbytes : C::ROWB;
+    int oob = (kt < KT) ? 0 : -1;
+    asm volatile("" : "+v"(tail), "+v"(oob));
+    const int soff = kt * C::ROWB;
+#pragma unroll
+    for (int t = 0; t < 4 + C::NPB; ++t) {
+      const bool isB = t >= 4;
+      const int qq = t & 3, par = qq & 1;
+      const int o = oob | ((chP[par] << 4) < tail ? 0 : -1);
+      const int v = ((vP[par] + qq * rstep) & ~o) | ((int)0x80000000 & o);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(isB ? rB : rA, (lds_ptr_t)(st + (isB ? C::OFF_B : 0) + qq * 1024), 16, v, soff, 0, 0);
+    }
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj) {
+      const int os = (kt < KT && 4 * kt + 2 * g + jj < CB) ? 0 : -1;   // a column tile past the operand's last one would read the next row tile's bytes
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rSA, (lds_ptr_t)(st + C::OFF_S + jj * 256), 4, ((vSA + jj * 512) & ~os) | ((int)0x80000000 & os), kt * 2048, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rSB, (lds_ptr_t)(st + C::OFF_S + 512 + jj * 256), 4, ((vSB + jj * 512) & ~os) | ((int)0x80000000 & os), kt * 2048, 0, 0);
+    }
+  };
+
+#pragma unroll
+  for (int j = 0; j < SPW; ++j) issue(wave + NW * j, j);
+
+  const int sw = (i32 >> 1) & 7;
+  v16f acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  auto fence = [&]() __attribute__((always_inline)) { __builtin_amdgcn_sched_barrier(0); };
+
+  // one stage (kt) out of slot u; RING: kt_next (>= KT: zeros) is requested into the slot as soon as the reads have returned
+  auto consume = [&](const int kt, const int u, const int kt_next) __attribute__((always_inline)) {
+    const char* st = smem + (wave * SPW + u) * C::STAGE;
+    v4i ca[4], cb[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int off = i32 * C::ROWB + (((4 * g + j) ^ sw) << 4);
+      ca[j] = *(const v4i*)(st + off);
+      cb[j] = *(const v4i*)(st + C::OFF_B + off);
+    }
+    uint32_t da[2], db[2];
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj) {
+      da[jj] = *(const uint32_t*)(st + C::OFF_S + jj * 256 + lane * 4);
+      db[jj] = *(const uint32_t*)(st + C::OFF_S + 512 + jj * 256 + lane * 4);
+    }
+    fence();
+    if constexpr (RING) {
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ca[0]), "+v"(ca[1]), "+v"(ca[2]), "+v"(ca[3]), "+v"(cb[0]), "+v"(cb[1]), "+v"(cb[2]), "+v"(cb[3]), "+v"(da[0]), "+v"(da[1]), "+v"(db[0]), "+v"(db[1]) :: "memory");   // the slot is free
+      issue(kt_next, u);
+      fence();
+    }
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj) {
+      // groups past K inside the last column tile (K % 64 == 32): their scale bytes are layout padding -- masked to 0 (0 x 0, never NaN)
+      const int valid = G16 - 4 * (4 * kt + 2 * g + jj);
+      const uint32_t smask = valid >= 4 ? 0xffffffffu : (valid <= 0 ? 0u : ((1u << (8 * valid)) - 1u));
+      h2_t sa[2], sb[2];
+      e4m3x4_to_f16(da[jj] & smask, sa[0], sa[1]);
+      e4m3x4_to_f16(db[jj] & smask, sb[0], sb[1]);
+#pragma unroll
+      for (int jl = 0; jl < 2; ++jl) {
+        const int j = 2 * jj + jl;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const _Float16 xa = sa[jl][q >> 1], xb = sb[jl][q >> 1];
+          const h8_t fa = dq8((uint32_t)ca[j][q], h2_t{xa, xa});
+          const h8_t fb = dq8((uint32_t)cb[j][q], h2_t{xb, xb});
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb, fa, acc, 0, 0, 0);
+        }
+      }
+    }
+    fence();
+  };
+  if constexpr (!RING) {
+    static_for<0, SPW>([&](auto jc) __attribute__((always_inline)) {
+      constexpr int j = decltype(jc)::value;
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"((SPW - 1 - j) * LPS) : "memory");
+      fence();
+      consume(wave + NW * j, j, 0);
+    });
+  } else {
+    for (int kt = wave; kt < KT; kt += NW * SPW) {
+      static_for<0, SPW>([&](auto uc) __attribute__((always_inline)) {
+        constexpr int u = decltype(uc)::value;
+        if (u == 0 || kt + NW * u < KT) {
+          asm volatile("s_waitcnt vmcnt(%0)" ::"n"((SPW - 1) * LPS) : "memory");
+          fence();
+          consume(kt + NW * u, u, kt + NW * u + NW * SPW);
+        }
+      });
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();   // every wave's reads of the stage areas are done: they become the sum's scratch
+  fence();
+
+  // ---- cross-wave sum: [wave][row][8 chunks of 4 fp32], chunk ^ (row & 7) -------------------------------------------------------------------
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+    *(v4f*)(smem + (wave * 32 + i32) * 128 + (((2 * q + g) ^ (i32 & 7)) << 4)) = v4f{acc[4 * q + 0], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]};
+  __syncthreads();
+  if (tid < 256) {
+    const int rr = tid >> 3, cq = tid & 7;   // row of the 32 x 32 tile, chunk of 4 columns
+    v4f t = *(const v4f*)(smem + rr * 128 + ((cq ^ (rr & 7)) << 4));
+#pragma unroll
+    for (int w = 1; w < NW; ++w) {
+      const v4f s = *(const v4f*)(smem + (w * 32 + rr) * 128 + ((cq ^ (rr & 7)) << 4));
+#pragma unroll
+      for (int e = 0; e < 4; ++e) t[e] += s[e];
+    }
+    const int row = m0 + rr, col = n0 + 4 * cq;
+    if (row < p.M && col < p.N && 4 * cq < C::TN) {
+      v2i o;
+      o[0] = (int)pack_bf16x2(t[0] * alpha, t[1] * alpha);
+      o[1] = (int)pack_bf16x2(t[2] * alpha, t[3] * alpha);
+      *(v2i*)(p.D + (size_t)row * p.ldd + col) = o;
+    }
+  }
+}
+
+#if QAMD_TU == 0 || QAMD_TU == 4
+// (not inline: the NVFP4 unit of capi.hip emits it; declared in gemm_nvf4.hip.h for launch_nvf4_gemm)
+// [r6] the wave-owned small-batch kernel (gemm_nvf4_os.hip.h): K <= 2048 one stage per wave, K <= 4096 two, longer K two refilled slots per wave
+hipError_t launch_nvf4_os(NvGemmParams p, hipStream_t s, int tn) {
+  p.tiles_m = (p.M + 31) / 32;
+  p.tiles_n = (p.N + tn - 1) / tn;
+  const int KT = (p.K / 2 + 127) / 128;
+  const dim3 grid(p.tiles_m * p.tiles_n), block(512);
+#define QAMD_NVOS(SPW_, RING_)                                                                                                      \
+  do {                                                                                                                              \
+    if (tn == 16) hipLaunchKernelGGL((gemm_nvf4_os_kernel<NvOsCfg<SPW_, 16>, RING_>), grid, block, 0, s, p);                           \
+    else hipLaunchKernelGGL((gemm_nvf4_os_kernel<NvOsCfg<SPW_, 32>, RING_>), grid, block, 0, s, p);                                     \
+  } while (0)
+  if (KT <= 8) QAMD_NVOS(1, false);
+  else if (KT <= 16) QAMD_NVOS(2, false);
+  else QAMD_NVOS(2, true);
+#undef QAMD_NVOS
+  return hipSuccess;
+}
+#endif
+
+}  // namespace qamd

@@ -352,3 +352,30 @@ def test_persistent_kernel_with_an_odd_number_of_k_stages(m, n, k, grid):
         cb = (k // 32 + 3) // 4 * 4
         ref2 = oracle.gemm_blockscaled(oracle.KIND_MXFP4, _np(a2), _np(b2), _np(sa2), _np(sb2), 0.75, m, n, k)
         assert np.array_equal(_np(got2), ref2)
+
+
+# ------------------------------------------------------------------------------------------------
+# [r6] the wave-owned small-batch NVFP4 kernel (csrc/gemm_nvf4_os.hip.h; qutlass/csrc/gemm.cu:250-326): 32 / 16 columns per workgroup (lab variants 46 / 47), one shot
+# (K <= 4096) and wave-owned rings (longer K), ragged M / N, K tails of half a stage and of half a column tile (K % 64 == 32), against the oracle; scale bytes in the
+# exact regime (e4m3 0x30 ... 0x47: every partial sum exact, any summation order gives the same bits) -- and the product rule on the shapes it sends there
+# ------------------------------------------------------------------------------------------------
+NVOS_SHAPES = [(1, 8, 32), (5, 72, 1024), (33, 104, 1440), (40, 200, 2944), (64, 96, 3104), (31, 264, 4096), (17, 4096, 3968), (9, 136, 4224), (33, 72, 11040), (3, 40, 14336)]
+
+
+@pytest.mark.parametrize("variant", [46, 47, 0])
+@pytest.mark.parametrize("m,n,k", NVOS_SHAPES)
+def test_nvf4_wave_owned_kernel_against_the_oracle(variant, m, n, k):
+    from qutlass_amd.utils import to_blocked
+
+    rng = np.random.default_rng(m * 13 + n + k)
+    a = torch.from_numpy(rng.integers(0, 256, size=(m, k // 2), dtype=np.uint8)).to(DEV)
+    b = torch.from_numpy(rng.integers(0, 256, size=(n, k // 2), dtype=np.uint8)).to(DEV)
+    sa = torch.from_numpy(rng.integers(0x30, 0x48, size=(m, k // 16), dtype=np.uint8)).to(DEV)
+    sb = torch.from_numpy(rng.integers(0x30, 0x48, size=(n, k // 16), dtype=np.uint8)).to(DEV)
+    alpha = torch.tensor([0.5], device=DEV)
+    e4 = torch.float8_e4m3fn
+    with lab.forced(nvf4_variant=variant):
+        got = lab.matmul_nvf4_bf16_tn(a, b, to_blocked(sa.view(e4)), to_blocked(sb.view(e4)), alpha)
+    ref = oracle.gemm_blockscaled(oracle.KIND_NVFP4, _np(a), _np(b), oracle.to_blocked(_np(sa)), oracle.to_blocked(_np(sb)), 0.5, m, n, k)
+    bad = _np(got) != ref
+    assert not bad.any(), f"{int(bad.sum())} of {bad.size} outputs differ, first at {np.argwhere(bad)[0].tolist()}"
