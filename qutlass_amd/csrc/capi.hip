@@ -265,20 +265,22 @@ int launch_gemm_ks(GemmParams p, hipStream_t s) {
   return check_launch("gemm_mx_ks_kernel");
 }
 
-// [r6] small-batch kernel that requests a 32x32 tile's whole K extent up front (gemm_mx_os.hip.h): K <= 4096, wave w owns stages w, w + 4, ...
-// (RM: row-major scale operands -- matmul_ada_mxf4_bf16_tn; TN: columns per workgroup, 32 or 16)
-template <bool RM = false, int TN = 32>
+// [r6] small-batch kernel whose waves own K stages (gemm_mx_os.hip.h): wave w owns stages w, w + 4, ...; the tile's whole K extent requested up front while it fits the
+// LDS (16 stages of 128 bytes per row for a 32-row tile, 12 for a 64-row tile), wave-owned rings beyond
+// (RM: row-major scale operands -- matmul_ada_mxf4_bf16_tn; TN: columns per workgroup, 32 or 16; EBITS 8: MXFP8, AFMT 1: e5m2 A operand; TM: rows per workgroup, 32 or 64)
+template <bool RM = false, int TN = 32, int EBITS = 4, int TM = 32, int AFMT = 0>
 int launch_gemm_os(GemmParams p, hipStream_t s) {
-  p.tiles_m = (int)cdiv(p.M, 32);
+  p.tiles_m = (int)cdiv(p.M, TM);
   p.tiles_n = (int)cdiv(p.N, TN);
   p.ws = nullptr; p.splits = 1; p.ctr = nullptr; p.tag = 0;
-  const int64_t KT = cdiv(p.K, 256);
+  const int64_t KT = cdiv((int64_t)p.K * EBITS / 8, 128);
   const dim3 grid(p.tiles_m * p.tiles_n), block(256);
-  if (KT <= 4) hipLaunchKernelGGL((gemm_mx_os_kernel<OsCfg<1, TN>, RM>), grid, block, 0, s, p);
-  else if (KT <= 8) hipLaunchKernelGGL((gemm_mx_os_kernel<OsCfg<2, TN>, RM>), grid, block, 0, s, p);
-  else if (KT <= 12) hipLaunchKernelGGL((gemm_mx_os_kernel<OsCfg<3, TN>, RM>), grid, block, 0, s, p);
-  else if (KT <= 16) hipLaunchKernelGGL((gemm_mx_os_kernel<OsCfg<4, TN>, RM>), grid, block, 0, s, p);
-  else hipLaunchKernelGGL((gemm_mx_os_kernel<OsCfg<4, TN>, RM, true>), grid, block, 0, s, p);   // wave-owned rings of four slots
+  constexpr int SMAX = TM == 32 ? 4 : 3;   // slots per wave that fit the LDS
+  if (KT <= 4) hipLaunchKernelGGL((gemm_mx_os_kernel<OsCfg<1, TN, EBITS, TM, AFMT>, RM>), grid, block, 0, s, p);
+  else if (KT <= 8) hipLaunchKernelGGL((gemm_mx_os_kernel<OsCfg<2, TN, EBITS, TM, AFMT>, RM>), grid, block, 0, s, p);
+  else if (KT <= 12) hipLaunchKernelGGL((gemm_mx_os_kernel<OsCfg<3, TN, EBITS, TM, AFMT>, RM>), grid, block, 0, s, p);
+  else if (KT <= 4 * SMAX) hipLaunchKernelGGL((gemm_mx_os_kernel<OsCfg<SMAX, TN, EBITS, TM, AFMT>, RM>), grid, block, 0, s, p);
+  else hipLaunchKernelGGL((gemm_mx_os_kernel<OsCfg<SMAX, TN, EBITS, TM, AFMT>, RM, true>), grid, block, 0, s, p);   // wave-owned rings of SMAX slots
   return check_launch("gemm_mx_os_kernel");
 }
 // Does the one-shot kernel take the shape, and with how many columns per workgroup?  Returns 0 (no), 32 or 16.  32x32 tiles, one per CU at most; 16 columns per
@@ -295,6 +297,43 @@ inline int os_plan(int64_t M, int64_t N, int64_t K, bool ada = false) {
   if (KT <= 32) return 4 * T32 >= cus ? tn : 0;
   if (KT > 64 || 2 * T32 < cus) return 0;   // (measured with 128 and 256 tiles only: fewer tiles against K > 8192 stay with the split plans)
   return (ada || M >= 8 || tn == 16) ? tn : 0;
+}
+
+// [r6, third session] ... and its 64-row form (variant 570: two m-tiles per stage owner) for MXFP4 batches whose 32x32 tiles no longer fit one per CU while 64x32 tiles do
+// (M = 65 ... 128 at N = 4096, M = 33 ... 64 at N = 8192).  A 64x32 tile's K extent fits the LDS up to 12 stages (K <= 3072) -- there it is the one-shot kernel and wins
+// 8-13 % (4096 x 2048, M = 96 / 128: 4.10 / 4.14 -> 3.57 / 3.63 us; 2048^2, M = 160 ... 256: 4.07-4.22 -> 3.51-3.70).  Beyond, the wave-owned rings hold three stages per
+// wave and a fourth costs a second memory round trip: K = 4096 ... 6144 lose 0-8 % against the 64x64 ring tiles (N = K = 4096, M = 128: 5.20 vs 5.60 us) and stay there; from
+// ~40 stages on the round trips overlap and it wins again (4096 x 11008, M = 96 / 128: 12.05 / 12.59 -> 9.19 / 9.73; x 14336: 13.5 / 14.1 -> 11.7 / 12.4; 8192^2, M = 64,
+// 32 stages on every CU: 11.65 -> 9.66).  profiles/calib_os2_fp4_r7.txt
+// ada: matmul_ada_mxf4_bf16_tn has no scratch argument, so no split-K plan competes -- every measured K wins there (4096 x 4096, M = 96 / 128: 6.5 / 6.7 -> 6.0 / 6.3 us;
+// x 8192: 10.1 -> 8.9; x 14336: 20.9 / 22.6 -> 14.4 / 15.3; profiles/calib_ada_570_r7.txt)
+inline bool os64_plan(int64_t M, int64_t N, int64_t K, bool ada = false) {
+  const int64_t cus = chip_cus(), T32 = cdiv(M, 32) * cdiv(N, 32), T64 = cdiv(M, 64) * cdiv(N, 32), KT = cdiv(K, 256);
+  if (T32 <= cus || T64 > cus) return false;
+  if (ada) return KT <= 64;
+  return KT <= 12 || (KT >= 40 && KT <= 64) || (KT >= 32 && KT < 40 && T64 == cus && M <= 64);   // (the last: 8192^2, M = 64; 4096 x 8192, M = 128 -- two tile rows -- loses 3 %)
+}
+// [r6, third session] The same kernel on MXFP8 operands (EBITS = 8: a stage is 128 elements, so K = 4096 is 32 stages and the one-shot form ends at K = 2048): returns the
+// variant (568 = 32x32 tiles, 569 = 32x16, 570 = 64x32) or 0.  Measured against the plans below -- 64x64 ring tiles, split-K with caller scratch -- on M = 1 ... 256 x 21
+// (N, K) (tools/calib_os2.py, profiles/calib_os2_fp8_r7.txt): N = K = 4096, M = 1 ... 32 5.9-7.0 -> 4.8-5.4 us, M = 64 8.6 -> 6.4; 8192 x 4096, M <= 32 10.3-10.7 -> 6.0-7.0;
+// N = K = 2048, M <= 128 4.8-5.1 -> 3.1-3.5; 4096 x 14336, M <= 32 13.2-15.0 -> 10.9-12.6.
+//   * 32-row tiles, one per CU at most (G workgroups; 16 columns per workgroup when that still fits): always up to 40 stages (K <= 5120); up to 64 stages when they fill
+//     3/4 of the chip (N = 1024 / 2048 against K = 8192 on 64 / 128 workgroups: 7-20 % behind the split-K plans); up to 128 stages for one m-tile or a weight of N >= 4096
+//     (2048 x 14336, M = 64: a tie); up to 256 stages (K = 32768) for one m-tile.
+//   * 64-row tiles where the 32-row ones overflow the chip: 17 ... 128 stages (4096 x 8192, M = 96 / 128: 15.6 / 14.8 -> 12.0 / 12.5 us; 8192 x 4096, M = 64: 11.3 -> 9.3;
+//     K <= 2048 ties, K = 28672 loses 13 %).
+inline int os8_plan(int64_t M, int64_t N, int64_t K) {
+  const int64_t cus = chip_cus(), T32 = cdiv(M, 32) * cdiv(N, 32), T16 = cdiv(M, 32) * cdiv(N, 16), T64 = cdiv(M, 64) * cdiv(N, 32), KT = cdiv(K, 128);
+  if (T32 <= cus) {
+    const int v = T16 <= cus ? 569 : 568;
+    const int64_t G = T16 <= cus ? T16 : T32;
+    if (KT <= 40) return v;
+    if (4 * G < 3 * cus) return 0;
+    if (KT <= 64) return v;
+    if (KT <= 128) return (M <= 32 || N >= 4096) ? v : 0;
+    return (KT <= 256 && M <= 32) ? v : 0;
+  }
+  return (T64 <= cus && KT > 16 && KT <= 128) ? 570 : 0;
 }
 
 // [r4] stream-K form of the two persistent kernels (lab variant 89): one workgroup per CU; p.ws / p.ctr / p.tag / p.sk_tiles set by gemm_mx
@@ -486,6 +525,10 @@ int dispatch_variant(int v, const GemmParams& p, hipStream_t s, const char* name
     if (v == 89) return launch_gemm_deepp_sk<GemmCfg<256, 256, 2, 2, 8, true>>(p, s);
 #endif
     if (v == 90) return launch_gemm_deepp8<GemmCfg<256, 256, 2, 2, 8, true>>(p, s);   // persistent deep schedule, fp8
+    // [r6] small batches on wave-owned K stages (gemm_mx_os.hip.h, EBITS = 8): 32x32 / 32x16 / 64x32 tiles
+    if (v == 568) return launch_gemm_os<false, 32, 8>(p, s);
+    if (v == 569) return launch_gemm_os<false, 16, 8>(p, s);
+    if (v == 570) return launch_gemm_os<false, 32, 8, 64>(p, s);
     if (v == 98) return launch_gemm_hetero<GemmCfg<256, 256, 2, 2, 8, true>, GemmCfg<128, 128, 2, 2, 8, true, 0, 4>, 17>(p, s);
 #if QAMD_BENCH
     if (v == 30) return launch_gemm<GemmCfg<256, 256, 2, 2, 8, true>, 4>(p, s);   // per-tile deep schedule (round 1)
@@ -506,8 +549,9 @@ int dispatch_variant(int v, const GemmParams& p, hipStream_t s, const char* name
       if (v == 561) return deep ? launch_gemm_ks<32, 32, 6>(p, s) : launch_gemm_ks<32, 32, 4>(p, s);
       return deep ? launch_gemm_ks<32, 64, 6>(p, s) : launch_gemm_ks<32, 64, 4>(p, s);
     }
-    if (v == 568) return launch_gemm_os<false>(p, s);
-    if (v == 569) return launch_gemm_os<false, 16>(p, s);   // [r6] the same with 16 columns per workgroup   // [r6] 32x32 tiles, the whole K extent (<= 16 stages) requested up front (gemm_mx_os.hip.h)
+    if (v == 568) return launch_gemm_os<false>(p, s);       // [r6] 32x32 tiles on wave-owned K stages (gemm_mx_os.hip.h): one shot up to 16 stages, wave-owned rings beyond
+    if (v == 569) return launch_gemm_os<false, 16>(p, s);   // [r6] the same with 16 columns per workgroup
+    if (v == 570) return launch_gemm_os<false, 32, 4, 64>(p, s);   // [r6] 64x32 tiles (two m-tiles per stage owner)
 #if QAMD_BENCH
     if (v == 99) return launch_gemm_hetero<GemmCfg<256, 256, 2, 2, 4, false>, GemmCfg<128, 128, 2, 2, 4, false, 0, 3>, 17>(p, s);
     // [r6] lab: the other tiles / ring depths of the in-workgroup K-split kernel (563 = 64x32, 564 = 64x64; 565 - 567 = 32x32 with a 4 / 8 / 6-deep ring)
@@ -592,6 +636,9 @@ int dispatch_variant_a5(int v, const GemmParams& p, hipStream_t s, const char* n
     case 71: return launch_gemm<GemmCfg<128, 64, 2, 2, 8, true, 0, 3, 1>, 9>(p, s);
     case 72: return launch_gemm<GemmCfg<64, 128, 2, 2, 8, true, 0, 3, 1>, 9>(p, s);
     case 73: return launch_gemm<GemmCfg<128, 128, 2, 2, 8, true, 0, 3, 1>, 9>(p, s);
+    case 568: return launch_gemm_os<false, 32, 8, 32, 1>(p, s);   // [r6] small batches on wave-owned K stages, e5m2 A
+    case 569: return launch_gemm_os<false, 16, 8, 32, 1>(p, s);
+    case 570: return launch_gemm_os<false, 32, 8, 64, 1>(p, s);
   }
   return fail(QAMD_ERR_INVALID, "%s: gemm_variant %d has no e5m2-operand instantiation", name, v);
 }
@@ -747,7 +794,7 @@ SmallPlan plan_small(int64_t M, int64_t N, int64_t K, bool may_split = true) {
 //     (N = 4096, K = 14336: M <= 16 8.1-9.1 us split against 9.2-9.4; M = 64 11.4 against 9.8).
 // Where it applies it is 11 ... 30 % faster (N = K = 4096: M <= 64 4.9-5.3 -> 4.1-4.5 us; 8192^2: M <= 32 8.8-11.1 -> 7.4-7.8 us), M = 1 ... 8 included (the LDS-free
 // split-K kernel: 4.55-4.92 us at N = K = 4096).  32x64 tiles: only where 32x32 tiles just overflow the chip and 32x64 nearly fill it (N = 14336: -6 %).
-// Returns the variant (568 / 569 / 561 / 562) or 0.
+// Returns the variant (568 / 569 / 570 / 561 / 562) or 0.
 inline int ks_plan(int64_t M, int64_t N, int64_t K) {
   const int64_t cus = chip_cus(), KT = cdiv(K, 256);
   const int64_t T32 = cdiv(M, 32) * cdiv(N, 32);
@@ -755,6 +802,7 @@ inline int ks_plan(int64_t M, int64_t N, int64_t K) {
   // 4.05-4.39 -> 3.34-3.67 us, N = K = 2048 3.15-3.26 -> 2.62-2.77 (profiles/calib_os_r6q.txt); its wave-owned-ring form for longer K and 16 columns per workgroup where os_plan says so
   // (4096 x 8192, M <= 32: 5.8-7.1 -> 5.5-5.7 us); past one tile per CU the ring plans below keep the shape
   if (const int tn = os_plan(M, N, K)) return tn == 16 ? 569 : 568;
+  if (os64_plan(M, N, K)) return 570;   // [r6] 64x32 tiles on wave-owned K stages where 32x32 tiles overflow the chip
   if (T32 <= cus && (KT <= 24 || (2 * T32 > cus && KT <= 64))) return 561;   // (K > 16384 was not calibrated, and a split-K plan on larger tiles moves fewer bytes per CU there)
   const int64_t T64 = cdiv(M, 32) * cdiv(N, 64);
   if (M <= 32 && T32 > cus && T64 <= cus && 8 * T64 >= 7 * cus && KT <= 24) return 562;
@@ -874,6 +922,10 @@ int gemm_mx(const char* name, const void* A, const void* B, const void* A_sf, co
   // [r6] small batches against a weight that fills the chip with 32x32 tiles: the in-workgroup K-split kernel (gemm_mx_ks.hip.h; ks_plan above)
   if (EBITS == 4 && variant == 0 && !(p.pp_flags & 256)) {
     if (const int kv = ks_plan(M, N, K)) return dispatch(kv, p, s);
+  }
+  // [r6] MXFP8 small batches (e4m3 and e5m2 A): the wave-owned kernel where os8_plan says so
+  if (EBITS == 8 && variant == 0 && !(p.pp_flags & 256)) {
+    if (const int kv = os8_plan(M, N, K)) return dispatch(kv, p, s);
   }
   const bool skinny_auto = variant == 0 && !can_split && ((M <= 8 && cdiv(N, 64) <= chip_cus() / 2) || (M <= 24 && cdiv(N, 64) <= chip_cus() / 8));
   if (EBITS == 4 && (variant == 60 || (variant >= 44 && variant <= 49) || skinny_auto)) {
@@ -1122,6 +1174,7 @@ int64_t qutlass_amd_gemm_splitk_workspace_bytes(int ebits, int64_t M, int64_t N,
   const SmallPlan pl = (ebits == 4) ? plan_small<4>(M, N, K) : plan_small<8>(M, N, K);
   int64_t need = (pl.variant && pl.splits > 1) ? splitk_ws_bytes(pl.variant, M, N, pl.splits) : 0;
   if (ebits == 4 && opt_gemm_variant() == 0 && !(opt_pp_flags() & 256) && ks_plan(M, N, K)) need = 0;   // [r6] the in-workgroup K-split kernel takes the shape: no scratch
+  if (ebits == 8 && opt_gemm_variant() == 0 && !(opt_pp_flags() & 256) && os8_plan(M, N, K)) need = 0;  // [r6] ... the wave-owned kernel an MXFP8 one
 #if QAMD_BENCH
   if (opt_gemm_variant() == 89) need = std::max<int64_t>(need, sk_ws_bytes(chip_cus()));   // lab: forced stream-K
   if (opt_splitk_force() > 1) need = std::max<int64_t>(need, splitk_ws_bytes(70, M, N, 8));   // lab: room for any forced tile x split
@@ -1179,7 +1232,8 @@ static int ada_impl(const void* A, const void* B, const void* A_sf, const void* 
   // [r6] K <= 4096 and at most one 32x32 tile per CU: the one-shot kernel with row-major scale pieces (gemm_mx_os.hip.h; "gemm_variant" 568 forces it where it fits)
   const int os_tn = forced == 0 ? os_plan(M, N, K, true) : 0;
   const bool os16 = forced == 569 || os_tn == 16;   // 16 columns per workgroup
-  const bool oneshot = (forced == 568 || forced == 569) ? cdiv(M, 32) * cdiv(N, 32) <= 4 * cus : os_tn != 0;
+  const bool os64 = forced == 570 || (forced == 0 && os_tn == 0 && os64_plan(M, N, K, true));   // 64x32 tiles where the 32-row tiles overflow the chip (os64_plan)
+  const bool oneshot = (forced >= 568 && forced <= 570) ? cdiv(M, 32) * cdiv(N, 32) <= 4 * cus : (os_tn != 0 || os64);
   if (ring || oneshot) {
     GemmParams p;
     p.A = (const uint8_t*)A; p.B = (const uint8_t*)B; p.SFA = (const uint8_t*)A_sf; p.SFB = (const uint8_t*)B_sf;
@@ -1188,6 +1242,7 @@ static int ada_impl(const void* A, const void* B, const void* A_sf, const void* 
     p.sfa_bytes = (uint32_t)(M * KB); p.sfb_bytes = (uint32_t)(N * KB);   // row-major (rows, K/32), un-swizzled
     p.pp_shift = opt_pp_shift(); p.pp_flags = opt_pp_flags(); p.dbg = opt_dbg();
     p.ws = nullptr; p.splits = 1; p.ctr = nullptr; p.tag = 0;
+    if (oneshot && os64) return launch_gemm_os<true, 32, 4, 64>(p, (hipStream_t)stream);
     if (oneshot) return os16 ? launch_gemm_os<true, 16>(p, (hipStream_t)stream) : launch_gemm_os<true>(p, (hipStream_t)stream);
 #if QAMD_BENCH
     if (opt_gemm_variant() == 178) return launch_gemm<GemmCfg<64, 64, 2, 2, 4, false, 0, 3>, 8>(p, (hipStream_t)stream);   // round-1 ring schedule

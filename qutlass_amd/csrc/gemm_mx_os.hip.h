@@ -23,24 +23,39 @@ namespace qamd {
 // TN = 16 ([r6]): the workgroup owns 16 output columns -- only B rows 0 .. 15 of the tile are fetched (rows 16 .. 31 of the MFMA's B fragment read whatever the LDS
 // holds: they only feed output columns 16 .. 31, which are not stored), so a weight of N columns spreads over N / 16 workgroups: N = 4096 fills 256 CUs instead of 128
 // and every CU pulls half the bytes through its LDS-DMA path.
-template <int SPW_, int TN_ = 32>   // K stages per wave: the kernel covers K <= 1024 SPW (RING: any K)
+// [r6, third session] Two more axes of the same kernel:
+//   EBITS = 8 -- MXFP8 (qutlass/csrc/gemm.cu:328-386 on small batches): a stage is 128 fp8 elements = ONE column tile of the to_blocked image, two MFMAs of 64;
+//     the hardware's 8-bit fragment is "split" (registers 0-3 of lane half g = bytes 16 g .. + 15 of K-block 2 j, registers 4-7 the same of K-block 2 j + 1, the
+//     scale byte of K-block 2 j + g taken from lane half g), so a lane reads chunks 4 j + 2 u + g and shifts its scale dword right by 8 g (op_sel 2 j).  AFMT = 1: A is
+//     e5m2 (the extension entry qutlass_amd_matmul_mxf8_bf16_tn_fmt).  One scale piece per operand and stage (both lane halves fetch the row's dword; TM = 64: half g
+//     fetches m-tile g's).
+//   TM = 64 -- two m-tiles per workgroup, for batches whose 32x32 tiles no longer fit one per CU (M = 96 ... 128 against N = 4096: 256 tiles of 64x32).  Still wave-owned
+//     K stages: the owner of a stage fetches the tile's 64 A rows and 32 B rows ONCE and runs both m-tiles' MFMAs on them -- no byte is fetched twice.
+template <int SPW_, int TN_ = 32, int EBITS_ = 4, int TM_ = 32, int AFMT_ = 0>   // SPW: K stages per wave -- the kernel covers 4 SPW stages of 128 bytes per row (RING: any K)
 struct OsCfg {
-  static constexpr int TM = 32, TN = TN_, ROWB = 128, SPW = SPW_, KTMAX = 4 * SPW_;
-  static constexpr int OFF_B = TM * ROWB, OFF_S = (TM + 32) * ROWB, STAGE = OFF_S + 512;   // + 256 B of scale dwords per operand (the B area keeps 32 rows: the fragment reads span them)
-  static constexpr int NPB = TN / 8;                                                        // B pieces per stage
-  static constexpr int LPS = 4 + NPB + 2;                                                   // LDS-DMA instructions per stage: 4 A pieces, 4 / 2 B pieces, 2 scale pieces
+  static constexpr int TM = TM_, TN = TN_, EBITS = EBITS_, AFMT = AFMT_, ROWB = 128, SPW = SPW_, KTMAX = 4 * SPW_;
+  static constexpr int MT = TM / 32;                                                        // m-tiles of 32 rows
+  static constexpr int KSL = EBITS == 4 ? 4 : 2;                                            // MFMAs (k-slices of 64) per stage and m-tile
+  static constexpr int NSA = EBITS == 4 ? MT : 1;                                           // A scale pieces per stage
+  static constexpr int OFF_B = TM * ROWB, OFF_S = (TM + 32) * ROWB, OFF_SB = OFF_S + NSA * 256, STAGE = OFF_SB + 256;   // 256 B of scale dwords per piece (the B area keeps 32 rows: the fragment reads span them)
+  static constexpr int NPA = TM / 8, NPB = TN / 8;                                          // A / B pieces per stage
+  static constexpr int LPS = NPA + NPB + NSA + 1;                                           // LDS-DMA instructions per stage
   static_assert(TN == 32 || TN == 16, "tile width");
-  static constexpr int RED = 4 * 4096;                                                      // cross-wave sum: [wave] 32 x 32 fp32
+  static_assert(TM == 32 || TM == 64, "tile height");
+  static_assert(EBITS == 4 || EBITS == 8, "element width");
+  static_assert(AFMT == 0 || (AFMT == 1 && EBITS == 8), "A format: 0 = e2m1 / e4m3, 1 = e5m2 (MXFP8 only)");
+  static constexpr int RED = 4 * TM * 128;                                                  // cross-wave sum: [wave] TM x 32 fp32
   static constexpr int LDS_BYTES = KTMAX * STAGE > RED ? KTMAX * STAGE : RED;
   static_assert(SPW >= 1 && SPW * LPS <= 63, "vmcnt immediate");
   static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
 };
 
 // RM: the scale operands are row-major (rows, K / 32) as matmul_ada_mxf4_bf16_tn hands them over (qutlass/csrc/gemm_ada.cu) instead of the to_blocked image
-// RING: any K -- the wave's SPW slots are refilled as they are consumed (false: K <= 1024 SPW, every stage has a slot of its own)
+// RING: any K -- the wave's SPW slots are refilled as they are consumed (false: at most 4 SPW stages, every stage has a slot of its own)
 template <class C, bool RM = false, bool RING = false>
 __global__ __launch_bounds__(256) void gemm_mx_os_kernel(const GemmParams p) {
-  constexpr int SPW = C::SPW, LPS = C::LPS;
+  constexpr int SPW = C::SPW, LPS = C::LPS, MT = C::MT, KSL = C::KSL, E8 = C::EBITS == 8;
+  static_assert(!(RM && E8), "row-major scales: matmul_ada_mxf4_bf16_tn only");
   __shared__ __attribute__((aligned(16))) char smem[C::LDS_BYTES];
   asm volatile("" :: "s"(p.A), "s"(p.D), "s"(p.K), "s"(p.b_bytes), "s"(p.alpha));   // all scalar argument loads in one round
   const float alpha = *p.alpha;
@@ -49,7 +64,7 @@ __global__ __launch_bounds__(256) void gemm_mx_os_kernel(const GemmParams p) {
   const int nb = p.tiles_m * p.tiles_n;
   const int b2 = xcd_remap((int)blockIdx.x, nb);
   const int m0 = uniform((b2 % p.tiles_m) * C::TM), n0 = uniform((b2 / p.tiles_m) * C::TN);
-  const int rowbytes = p.K >> 1, KT = (rowbytes + C::ROWB - 1) / C::ROWB, CB = (p.K / 32 + 3) >> 2;
+  const int rowbytes = E8 ? p.K : p.K >> 1, KT = (rowbytes + C::ROWB - 1) / C::ROWB, CB = (p.K / 32 + 3) >> 2;
   const int tailbytes = rowbytes - (KT - 1) * C::ROWB;   // bytes per row of the last stage
 
   // ---- LDS-DMA sources --------------------------------------------------------------------------------------------------------------
@@ -63,13 +78,23 @@ __global__ __launch_bounds__(256) void gemm_mx_os_kernel(const GemmParams p) {
     vP[par] = (lane >> 3) * rowbytes + (chP[par] << 4);
   }
   const int rstep = 8 * rowbytes;
-  // scale dwords: row (m0 | n0) + i32 of column tile 2 kt + g -- byte ((r % 32) * 16 + ((r % 128) / 32) * 4) of the 512-byte tile (qutlass/utils.py:60-64)
-  // (RM: row r's eight scale bytes of stage kt are bytes 8 kt .. + 7 of its K / 32 -- the lane's dword is bytes 8 kt + 4 g .. + 3; rows past M / N lie past the descriptor)
+  // scale dwords.  fp4: row (m0 | n0) + i32 of column tile 2 kt + g -- byte ((r % 32) * 16 + ((r % 128) / 32) * 4) of the 512-byte tile (qutlass/utils.py:60-64)
+  // (RM: row r's eight scale bytes of stage kt are bytes 8 kt .. + 7 of its K / 32 -- the lane's dword is bytes 8 kt + 4 g .. + 3; rows past M / N lie past the descriptor).
+  // fp8: the stage is column tile kt; both lane halves fetch the row's dword (TM = 64: lane half g fetches m-tile g's)
   const int KB = p.K >> 5;
   const uint32_t sa_off = RM ? (uint32_t)m0 * KB : (uint32_t)(m0 >> 7) * CB * 512, sb_off = RM ? (uint32_t)n0 * KB : (uint32_t)(n0 >> 7) * CB * 512;
   const __amdgpu_buffer_rsrc_t rSA = make_rsrc(p.SFA + sa_off, p.sfa_bytes - sa_off), rSB = make_rsrc(p.SFB + sb_off, p.sfb_bytes - sb_off);
   const int rowB = (n0 & 127) + i32;   // row of the 128-row scale tile (TN = 16: n0 is a multiple of 16 only; lanes past the 16 rows fetch some row's dword -- unused)
-  const int vSA = RM ? i32 * KB + 4 * g : g * 512 + i32 * 16 + ((m0 & 127) >> 5) * 4, vSB = RM ? i32 * KB + 4 * g : g * 512 + (rowB & 31) * 16 + ((rowB & 127) >> 5) * 4;
+  const int mq = (m0 & 127) >> 5;      // 32-row slab of the 128-row scale tile the A tile starts in
+  const int gcol = E8 ? 0 : g * 512;   // fp4: lane half g takes column tile 2 kt + g
+  int vSA[C::NSA];
+#pragma unroll
+  for (int t = 0; t < C::NSA; ++t) {
+    const int slab = E8 ? (MT == 2 ? g : 0) : t;   // m-tile whose dword this lane fetches with piece t
+    vSA[t] = RM ? (32 * slab + i32) * KB + 4 * g : gcol + i32 * 16 + (mq + slab) * 4;
+  }
+  const int vSB = RM ? i32 * KB + 4 * g : gcol + (rowB & 31) * 16 + ((rowB & 127) >> 5) * 4;
+  constexpr int SCW = E8 ? 512 : 1024;   // scale bytes per stage and 128-row tile
 
   auto issue = [&](const int kt, const int slot) __attribute__((always_inline)) {   // stage kt into slot `slot` of this wave (kt >= KT: every piece out of range -> zeros)
     char* st = smem + (wave * SPW + slot) * C::STAGE;
@@ -78,55 +103,84 @@ __global__ __launch_bounds__(256) void gemm_mx_os_kernel(const GemmParams p) {
     asm volatile("" : "+v"(tail), "+v"(oob));
     const int soff = kt * C::ROWB;
 #pragma unroll
-    for (int t = 0; t < 4 + C::NPB; ++t) {
-      const bool isB = t >= 4;
-      const int qq = t & 3, par = qq & 1;
+    for (int t = 0; t < C::NPA + C::NPB; ++t) {
+      const bool isB = t >= C::NPA;
+      const int qq = isB ? t - C::NPA : t, par = qq & 1;
       const int o = oob | ((chP[par] << 4) < tail ? 0 : -1);
       const int v = ((vP[par] + qq * rstep) & ~o) | ((int)0x80000000 & o);
       __builtin_amdgcn_raw_ptr_buffer_load_lds(isB ? rB : rA, (lds_ptr_t)(st + (isB ? C::OFF_B : 0) + qq * 1024), 16, v, soff, 0, 0);
     }
     // a column tile past the operand's last one would read the next row tile's bytes (RM: K-blocks past K / 32 the next row's)
-    const int os = (kt < KT && (RM ? 8 * kt + 4 * g < KB : 2 * kt + g < CB)) ? 0 : -1;
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rSA, (lds_ptr_t)(st + C::OFF_S), 4, (vSA & ~os) | ((int)0x80000000 & os), RM ? kt * 8 : kt * 1024, 0, 0);
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rSB, (lds_ptr_t)(st + C::OFF_S + 256), 4, (vSB & ~os) | ((int)0x80000000 & os), RM ? kt * 8 : kt * 1024, 0, 0);
+    const int os = (kt < KT && (RM ? 8 * kt + 4 * g < KB : (E8 ? kt : 2 * kt + g) < CB)) ? 0 : -1;
+#pragma unroll
+    for (int t = 0; t < C::NSA; ++t)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rSA, (lds_ptr_t)(st + C::OFF_S + t * 256), 4, (vSA[t] & ~os) | ((int)0x80000000 & os), RM ? kt * 8 : kt * SCW, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rSB, (lds_ptr_t)(st + C::OFF_SB), 4, (vSB & ~os) | ((int)0x80000000 & os), RM ? kt * 8 : kt * SCW, 0, 0);
   };
 
   // ---- everything this wave will ever read (RING: its first SPW stages), requested now ---------------------------------------------------------
 #pragma unroll
   for (int j = 0; j < SPW; ++j) issue(wave + 4 * j, j);
 
-  // row i32 of the tile, logical chunk 4 g + js (lane half g owns K-blocks 4 g .. 4 g + 3 of the stage), physical chunk ^ ((row >> 1) & 7)
+  // row i32 of an m-tile / of the B tile; fp4: logical chunk 4 g + js (lane half g owns K-blocks 4 g .. 4 g + 3 of the stage); fp8: chunks 4 js + 2 u + g (see OsCfg);
+  // physical chunk ^ ((row >> 1) & 7)
   const int sw = (i32 >> 1) & 7;
-  v16f acc;
+  v16f acc[MT];
 #pragma unroll
-  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  for (int t = 0; t < MT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
   auto fence = [&]() __attribute__((always_inline)) { __builtin_amdgcn_sched_barrier(0); };
 
   // one stage out of slot u; RING: kt_next (>= KT: zeros) is requested into the slot as soon as the reads have returned
   auto consume = [&](const int u, const int kt_next) __attribute__((always_inline)) {
     const char* st = smem + (wave * SPW + u) * C::STAGE;
-    v4i fa[4], fb[4];
+    v4i fa[MT][4], fb[4];
 #pragma unroll
-    for (int js = 0; js < 4; ++js) {
-      const int off = i32 * C::ROWB + (((4 * g + js) ^ sw) << 4);
-      fa[js] = *(const v4i*)(st + off);
-      fb[js] = *(const v4i*)(st + C::OFF_B + off);
+    for (int c4 = 0; c4 < 4; ++c4) {   // fp4: c4 = k-slice js; fp8: c4 = 2 js + u
+      const int chunk = E8 ? 4 * (c4 >> 1) + 2 * (c4 & 1) + g : 4 * g + c4;
+      const int off = i32 * C::ROWB + ((chunk ^ sw) << 4);
+#pragma unroll
+      for (int t = 0; t < MT; ++t) fa[t][c4] = *(const v4i*)(st + t * 32 * C::ROWB + off);
+      fb[c4] = *(const v4i*)(st + C::OFF_B + off);
     }
-    const int sa = *(const int*)(st + C::OFF_S + lane * 4), sb = *(const int*)(st + C::OFF_S + 256 + lane * 4);
-    fence();   // all ten reads issued before the first MFMA (left alone, the compiler reads one k-slice at a time into the same registers: four exposed LDS round trips)
+    int sa[MT], sb;
+#pragma unroll
+    for (int t = 0; t < MT; ++t) sa[t] = *(const int*)(st + C::OFF_S + (E8 ? (MT == 2 ? (32 * t + i32) * 4 : lane * 4) : t * 256 + lane * 4));
+    sb = *(const int*)(st + C::OFF_SB + lane * 4);
+    fence();   // every read issued before the first MFMA (left alone, the compiler reads one k-slice at a time into the same registers: four exposed LDS round trips)
     if constexpr (RING) {
-      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[0]), "+v"(fa[1]), "+v"(fa[2]), "+v"(fa[3]), "+v"(fb[0]), "+v"(fb[1]), "+v"(fb[2]), "+v"(fb[3]) :: "memory");   // the slot is free
+      if constexpr (MT == 1)
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[0][0]), "+v"(fa[0][1]), "+v"(fa[0][2]), "+v"(fa[0][3]), "+v"(fb[0]), "+v"(fb[1]), "+v"(fb[2]), "+v"(fb[3]) :: "memory");   // the slot is free
+      else
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[0][0]), "+v"(fa[0][1]), "+v"(fa[0][2]), "+v"(fa[0][3]), "+v"(fa[MT - 1][0]), "+v"(fa[MT - 1][1]), "+v"(fa[MT - 1][2]), "+v"(fa[MT - 1][3]),
+                     "+v"(fb[0]), "+v"(fb[1]), "+v"(fb[2]), "+v"(fb[3]) :: "memory");
       issue(kt_next, u);
       fence();
     }
+    if constexpr (E8) {   // "my" scale byte of K-block 2 js + g down to byte 2 js - ... op_sel 2 js picks it
 #pragma unroll
-    for (int js = 0; js < 4; ++js) {
-      const v4i a = fa[js], b = fb[js];
-      const v8i A8 = {a[0], a[1], a[2], a[3], 0, 0, 0, 0}, B8 = {b[0], b[1], b[2], b[3], 0, 0, 0, 0};
-      if (js == 0) acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(B8, A8, acc, 4, 4, 0, sb, 0, sa);
-      if (js == 1) acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(B8, A8, acc, 4, 4, 1, sb, 1, sa);
-      if (js == 2) acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(B8, A8, acc, 4, 4, 2, sb, 2, sa);
-      if (js == 3) acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(B8, A8, acc, 4, 4, 3, sb, 3, sa);
+      for (int t = 0; t < MT; ++t) sa[t] = (int)((unsigned)sa[t] >> (8 * g));
+      sb = (int)((unsigned)sb >> (8 * g));
+    }
+    // cbsz = format of srcA (the B fragments), blgp = format of srcB (the A fragments): 4 = e2m1, 0 = e4m3, 1 = e5m2
+    constexpr int FMT = E8 ? 0 : 4, FMTA = E8 ? C::AFMT : 4;
+#pragma unroll
+    for (int js = 0; js < KSL; ++js) {
+      const v4i b = E8 ? fb[2 * js] : fb[js];
+      const v4i bh = E8 ? fb[2 * js + 1] : v4i{0, 0, 0, 0};
+      const v8i B8 = {b[0], b[1], b[2], b[3], bh[0], bh[1], bh[2], bh[3]};
+      const int ops = E8 ? 2 * js : js;
+#pragma unroll
+      for (int t = 0; t < MT; ++t) {
+        const v4i a = E8 ? fa[t][2 * js] : fa[t][js];
+        const v4i ah = E8 ? fa[t][2 * js + 1] : v4i{0, 0, 0, 0};
+        const v8i A8 = {a[0], a[1], a[2], a[3], ah[0], ah[1], ah[2], ah[3]};
+        if (ops == 0) acc[t] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(B8, A8, acc[t], FMT, FMTA, 0, sb, 0, sa[t]);
+        if (ops == 1) acc[t] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(B8, A8, acc[t], FMT, FMTA, 1, sb, 1, sa[t]);
+        if (ops == 2) acc[t] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(B8, A8, acc[t], FMT, FMTA, 2, sb, 2, sa[t]);
+        if (ops == 3) acc[t] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(B8, A8, acc[t], FMT, FMTA, 3, sb, 3, sa[t]);
+      }
     }
     fence();
   };
@@ -157,22 +211,28 @@ __global__ __launch_bounds__(256) void gemm_mx_os_kernel(const GemmParams p) {
 
   // ---- cross-wave sum: [wave][row][8 chunks of 4 fp32], chunk ^ (row & 7) (the 8 lanes of a ds_write_b128 group hit 8 chunks) ------------------------
 #pragma unroll
-  for (int q = 0; q < 4; ++q)
-    *(v4f*)(smem + (wave * 32 + i32) * 128 + (((2 * q + g) ^ (i32 & 7)) << 4)) = v4f{acc[4 * q + 0], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]};
+  for (int t = 0; t < MT; ++t)
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      *(v4f*)(smem + (wave * C::TM + 32 * t + i32) * 128 + (((2 * q + g) ^ (i32 & 7)) << 4)) = v4f{acc[t][4 * q + 0], acc[t][4 * q + 1], acc[t][4 * q + 2], acc[t][4 * q + 3]};
   __syncthreads();
-  const int rr = tid >> 3, cq = tid & 7;   // row of the 32 x 32 tile, chunk of 4 columns
-  v4f s[4];
+  const int cq = tid & 7;   // chunk of 4 columns
 #pragma unroll
-  for (int w = 0; w < 4; ++w) s[w] = *(const v4f*)(smem + (w * 32 + rr) * 128 + ((cq ^ (rr & 7)) << 4));
-  v4f t;
+  for (int h = 0; h < MT; ++h) {
+    const int rr = (tid >> 3) + 32 * h;   // row of the tile
+    v4f s[4];
 #pragma unroll
-  for (int e = 0; e < 4; ++e) t[e] = ((s[0][e] + s[1][e]) + s[2][e]) + s[3][e];
-  const int row = m0 + rr, col = n0 + 4 * cq;
-  if (row < p.M && col < p.N && 4 * cq < C::TN) {
-    v2i o;
-    o[0] = (int)pack_bf16x2(t[0] * alpha, t[1] * alpha);
-    o[1] = (int)pack_bf16x2(t[2] * alpha, t[3] * alpha);
-    *(v2i*)(p.D + (size_t)row * p.ldd + col) = o;
+    for (int w = 0; w < 4; ++w) s[w] = *(const v4f*)(smem + (w * C::TM + rr) * 128 + ((cq ^ (rr & 7)) << 4));
+    v4f t;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) t[e] = ((s[0][e] + s[1][e]) + s[2][e]) + s[3][e];
+    const int row = m0 + rr, col = n0 + 4 * cq;
+    if (row < p.M && col < p.N && 4 * cq < C::TN) {
+      v2i o;
+      o[0] = (int)pack_bf16x2(t[0] * alpha, t[1] * alpha);
+      o[1] = (int)pack_bf16x2(t[2] * alpha, t[3] * alpha);
+      *(v2i*)(p.D + (size_t)row * p.ldd + col) = o;
+    }
   }
 }
 

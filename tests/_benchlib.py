@@ -28,6 +28,7 @@ _SIGS = {
     "qutlass_amd_gemm_splitk_workspace_bytes": (_i64, [_i32, _i64, _i64, _i64]),
     "qutlass_amd_matmul_mxf4_bf16_tn_ws": (_i32, _GEMM[:-1] + [_vp, _i64, _vp]),
     "qutlass_amd_matmul_mxf8_bf16_tn_ws": (_i32, _GEMM[:-1] + [_vp, _i64, _vp]),
+    "qutlass_amd_matmul_mxf8_bf16_tn_fmt": (_i32, _GEMM[:-1] + [_i32, _i32, _vp, _i64, _vp]),
     "qutlass_amd_nvf4_splitk_workspace_bytes": (_i64, [_i64, _i64, _i64]),
     "qutlass_amd_matmul_nvf4_bf16_tn_ws": (_i32, _GEMM[:-1] + [_vp, _i64, _vp]),
     "qutlass_amd_mxfp4_transpose_mxfp8": (_i32, [_vp, _vp, _i64, _i64, _vp, _vp, _vp]),
@@ -104,6 +105,14 @@ def matmul_mxf4_bf16_tn(a, b, a_sf, b_sf, alpha):
 
 def matmul_mxf8_bf16_tn(a, b, a_sf, b_sf, alpha):
     return _gemm("qutlass_amd_matmul_mxf8_bf16_tn_ws", 8, a, b, a_sf, b_sf, alpha, True)
+
+
+def matmul_mxf8_bf16_tn_fmt(a, b, a_sf, b_sf, alpha, a_format: int = 1):
+    """the extension entry: A in e5m2 (a_format = 1) or e4m3 (0), B e4m3; no scratch handed over (single-pass plans only)"""
+    m, n, k = a.shape[0], b.shape[0], b.shape[1]
+    out = torch.empty(m, n, dtype=torch.bfloat16, device=a.device)
+    _check(load().qutlass_amd_matmul_mxf8_bf16_tn_fmt(_p(a), _p(b), _p(a_sf), _p(b_sf), _p(alpha), _p(out), m, n, k, a_format, 0, None, 0, _stream()))
+    return out
 
 
 def matmul_mxf8_bf16_nn(a, b, a_sf, b_sf, alpha):

@@ -108,15 +108,16 @@ def test_split_k_workspace_plan_is_a_pure_host_function(lib):
         return s * m * n * 4
 
     # Llama-3-8B down-proj, batch 64: 64 tiles, KT = 56 stages -> 4 splits of 14 stages (one workgroup per CU).  [r6] MXFP4 shapes whose 32x32 tiles fill the chip one
-    # per CU go to the in-workgroup K-split kernel instead (capi.hip ks_plan: no scratch): the MXFP8 twin of this shape still shows the split plan
-    assert splits(4, 64, 4096, 14336) == 4 and ws(4, 64, 4096, 14336) == 0
-    assert splits(8, 64, 4096, 7168) == 4 and ws(8, 64, 4096, 7168) == layout(64, 4096, 4) == 4 * 64 * 4096 * 4
+    # per CU go to the in-workgroup K-split kernel instead (capi.hip ks_plan: no scratch), and MXFP8 ones likewise to the wave-owned kernel (os8_plan) -- the MXFP8 shape
+    # below fills only half the chip with 32x16 tiles against 56 stages and still shows the split plan
+    assert splits(4, 64, 4096, 14336) == 4 and ws(4, 64, 4096, 14336) == 0 and ws(8, 64, 4096, 7168) == 0
+    assert splits(8, 64, 1024, 7168) == 7 and ws(8, 64, 1024, 7168) == layout(64, 1024, 7) == 7 * 64 * 1024 * 4
     assert splits(4, 16, 4096, 14336) == 4 and ws(4, 16, 4096, 14336) == 0   # [r6] the wave-owned-ring form of the one-shot kernel takes it (capi.hip os_plan): no scratch
     assert ws(4, 4, 2048, 14336) == layout(4, 2048, splits(4, 4, 2048, 14336))    # ... a quarter of the chip against 56 stages stays with the split plans
-    assert ws(4, 128, 4096, 14336) == layout(128, 4096, 2)   # 128 tiles: 2 splits
+    assert ws(4, 128, 4096, 14336) == 0 and ws(4, 128, 4096, 28672) == layout(128, 4096, 4)   # [r6] 64x32 tiles on wave-owned rings up to 64 stages (os64_plan), split plans beyond
     assert ws(4, 256, 4096, 14336) == 0 and ws(4, 192, 4096, 14336) == 0   # more than 128 tiles: no split
     assert ws(4, 64, 4096, 4096) == 0            # 16 stages: too short to pay for the reduction
-    assert ws(4, 64, 4096, 8192) == 0 and ws(4, 16, 4096, 8192) == 0 and ws(8, 16, 4096, 4096) == layout(16, 4096, 4) and ws(8, 64, 4096, 4096) == layout(64, 4096, 4)   # 32 stages (fp8: K = 4096); [r6] fp4: ks_plan
+    assert ws(4, 64, 4096, 8192) == 0 and ws(4, 16, 4096, 8192) == 0 and ws(8, 16, 4096, 4096) == 0 and ws(8, 64, 4096, 4096) == 0 and ws(8, 64, 1024, 8192) == layout(64, 1024, 8)   # 32 stages (fp8: K = 4096); [r6] fp4: ks_plan, fp8: os8_plan up to M = 128
     assert ws(4, 4096, 4096, 4096) == 0 and ws(4, 0, 4096, 4096) == 0 and ws(5, 64, 4096, 14336) == 0
     for m, n, k in [(8, 512, 28672), (40, 1032, 14464), (1, 64, 12288)]:
         b = ws(4, m, n, k)
@@ -497,18 +498,30 @@ def test_auto_dispatch_rules_dry_run(lib):
     assert plan(4, 4, 8192, 11008) == [(KS32, 8192, 1)] and plan(4, 4, 2048, 11008) == [(SKINNY, 2048, 1)]     # long K, M < 8, no room for 16-column workgroups / too few tiles: the split-K kernels keep it
     assert plan(4, 16, 11008, 4096) == [(RING64, 11008, 1)] and plan(4, 96, 4096, 4096) == [(RING64, 4096, 1)]  # 32x32 tiles would sit two on a CU
     assert plan(4, 16, 57344, 8192) == [(28, 57344, 1)]
-    assert plan(8, 16, 4096, 4096) == [(RING64, 4096, 1)]            # no fp8 skinny kernel
+    # [r6] MXFP8 small batches: the wave-owned kernel (csrc/gemm_mx_os.hip.h, EBITS = 8; capi.hip os8_plan) -- 32x16 / 32x32 tiles while they fit one per CU, 64x32 where only
+    # those still do; a long K only on (nearly) the whole chip (rounds 1-5: 64x64 ring tiles, N = K = 4096, M = 16: 6.4 -> 5.0 us; 8192 x 4096: 10.6 -> 6.4)
+    OS64 = 570
+    assert plan(8, 16, 4096, 4096) == [(OS16, 4096, 1)] and plan(8, 1, 4096, 4096) == [(OS16, 4096, 1)] and plan(8, 64, 4096, 4096) == [(OS32, 4096, 1)]
+    assert plan(8, 32, 8192, 4096) == [(OS32, 8192, 1)] and plan(8, 64, 8192, 4096) == [(OS64, 8192, 1)] and plan(8, 128, 4096, 4096) == [(OS64, 4096, 1)]
+    assert plan(8, 128, 2048, 2048) == [(OS32, 2048, 1)] and plan(8, 192, 2048, 2048) == [(RING64, 2048, 1)]       # 64-row tiles only with more than 16 stages
+    assert plan(8, 16, 1024, 4096) == [(OS16, 1024, 1)] and plan(8, 16, 1024, 8192, big) != [(OS16, 1024, 1)]     # 64 workgroups against 64 stages: the split-K plans
+    assert plan(8, 16, 4096, 14336, big) == [(OS16, 4096, 1)] and plan(8, 64, 2048, 14336, big) != [(OS16, 2048, 1)] and plan(8, 16, 4096, 28672, big) == [(OS16, 4096, 1)]
+    assert plan(8, 64, 4096, 28672, big) != [(OS32, 4096, 1)] and plan(8, 128, 4096, 28672, big) != [(OS64, 4096, 1)] and plan(8, 16, 14336, 4096) == [(RING64, 14336, 1)]
+    # [r6] ... and MXFP4 batches whose 32x32 tiles overflow the chip while 64x32 tiles fit: one shot up to K = 3072, wave-owned rings from ~40 stages (os64_plan)
+    assert plan(4, 128, 4096, 2048) == [(OS64, 4096, 1)] and plan(4, 128, 4096, 3072) == [(OS64, 4096, 1)] and plan(4, 128, 4096, 4096) == [(RING64, 4096, 1)]
+    assert plan(4, 96, 4096, 11008, big) == [(OS64, 4096, 1)] and plan(4, 128, 4096, 14336) == [(OS64, 4096, 1)] and plan(4, 64, 8192, 8192, big) == [(OS64, 8192, 1)]
+    assert plan(4, 128, 4096, 8192, big) == [(RING64, 4096, 1)] and plan(4, 200, 2048, 2048) == [(OS64, 2048, 1)]
     # small outputs: ring schedule; split-K only with caller scratch, <= 128 tiles and >= 32 K stages
     assert plan(4, 64, 4096, 4096) == [(OS32, 4096, 1)] == plan(4, 64, 4096, 4096, big)
     assert plan(4, 64, 4096, 14336) == [(OS32, 4096, 1)] == plan(4, 64, 4096, 14336, big)   # [r6] 256 tiles of 32x32, 56 stages: 11.4 us (4 K ranges + reduce) -> 9.8 (K-split ring) -> 9.1 (wave-owned rings)
-    assert plan(8, 64, 4096, 7168) == [(RING64, 4096, 1)]
-    assert plan(8, 64, 4096, 7168, big) == [(RING64, 4096, 4)]
-    assert plan(8, 64, 4096, 7168, 64 * 4096 * 4 * 4 - 1) == [(RING64, 4096, 1)]   # scratch one byte short: single pass
+    assert plan(8, 64, 1024, 7168) == [(RING64, 1024, 1)]              # (an MXFP8 shape the wave-owned kernel leaves alone: 128 workgroups of 32x16 against 56 stages)
+    assert plan(8, 64, 1024, 7168, big) == [(RING64, 1024, 7)]
+    assert plan(8, 64, 1024, 7168, 64 * 1024 * 4 * 7 - 1) == [(RING64, 1024, 1)]   # scratch one byte short: single pass
     assert plan(4, 16, 4096, 14336, big) == [(OS16, 4096, 1)]         # [r6] (rounds 3-5: 64x64 tiles x 4 K ranges, 8.85 us; wave-owned rings 8.0)
-    assert plan(4, 128, 4096, 14336, big) == [(RING64, 4096, 2)]
+    assert plan(4, 128, 4096, 28672, big) == [(RING64x128, 4096, 4)]   # (K = 14336: 64x32 tiles on wave-owned rings since round 6, above)
     assert plan(4, 128, 4096, 8192, big) == [(RING64, 4096, 1)]       # a two-way split needs >= 48 K stages to pay for its reduce pass
     assert plan(4, 256, 4096, 14336, big) == [(RING64, 4096, 1)]
-    assert plan(8, 64, 4096, 4096, big) == [(RING64, 4096, 4)]
+    assert plan(8, 64, 1024, 8192, big) == [(RING64, 1024, 8)]
     assert plan(4, 512, 4096, 4096) == [(RING64x128, 4096, 1)]
     assert plan(4, 1024, 4096, 4096) == [(RING128, 4096, 1)] and plan(4, 256, 14336, 4096) == [(RING128, 14336, 1)]
     assert plan(4, 2048, 4096, 4096) == [(24, 4096, 1)]               # 512 tiles of 128x128: two workgroups per CU, pipelined schedule on a 2-deep ring

@@ -267,8 +267,9 @@ def _mx_operands_exact(m, n, k, seed):
 KS_SHAPES = [(1, 8, 128), (9, 40, 384), (33, 104, 1408), (64, 264, 4096), (100, 72, 640), (31, 4096, 4096), (64, 2048, 8192), (130, 520, 256)]
 
 
-@pytest.mark.parametrize("variant", [561, 562, 563, 564, 565, 566, 567, 568, 569])
-@pytest.mark.parametrize("m,n,k", KS_SHAPES + [(5, 72, 1024), (40, 200, 2944), (64, 96, 3072), (9, 136, 4224), (33, 72, 11008), (3, 40, 14336), (64, 64, 4352)])   # (568: one shot up to K = 4096, wave-owned rings beyond)
+@pytest.mark.parametrize("variant", [561, 562, 563, 564, 565, 566, 567, 568, 569, 570])
+@pytest.mark.parametrize("m,n,k", KS_SHAPES + [(5, 72, 1024), (40, 200, 2944), (64, 96, 3072), (9, 136, 4224), (33, 72, 11008), (3, 40, 14336), (64, 64, 4352),
+                                               (128, 4096, 4096), (97, 136, 3328), (160, 72, 5376)])   # (568: one shot up to K = 4096, wave-owned rings beyond; 570: 64x32 tiles, one shot up to K = 3072)
 def test_ks_kernel_against_the_oracle(variant, m, n, k):
     a, b, sa, sb = _mx_operands_exact(m, n, k, m * 7 + n + k)
     alpha = torch.tensor([0.5], device=DEV)
@@ -279,7 +280,8 @@ def test_ks_kernel_against_the_oracle(variant, m, n, k):
     assert not bad.any(), f"{int(bad.sum())} of {bad.size} outputs differ, first at {np.argwhere(bad)[0].tolist()}"
 
 
-@pytest.mark.parametrize("m,n,k", [(1, 8, 128), (5, 72, 1024), (33, 104, 1408), (40, 200, 2944), (64, 96, 3072), (31, 264, 4096), (17, 8192, 3968), (9, 136, 4224), (33, 72, 11008), (3, 40, 14336)])
+@pytest.mark.parametrize("m,n,k", [(1, 8, 128), (5, 72, 1024), (33, 104, 1408), (40, 200, 2944), (64, 96, 3072), (31, 264, 4096), (17, 8192, 3968), (9, 136, 4224), (33, 72, 11008), (3, 40, 14336),
+                                   (128, 4096, 2048), (72, 8192, 1280)])   # (the last two: 64x32 tiles by the product rule, capi.hip os64_plan)
 def test_one_shot_kernel_with_row_major_scales_against_the_oracle(q, m, n, k):
     """matmul_ada_mxf4_bf16_tn (qutlass/csrc/gemm_ada.cu; row-major scale operands) on shapes the product sends to the one-shot kernel (csrc/gemm_mx_os.hip.h, RM form):
     ragged M / N, K tails of half a stage, 1 ... 16 stages; the same operands through the blocked-scale entry (one-shot kernel, blocked form) and the 64x64 ring kernel."""
@@ -299,7 +301,7 @@ def test_one_shot_kernel_with_row_major_scales_against_the_oracle(q, m, n, k):
     assert np.array_equal(_np(q.matmul_mxf4_bf16_tn(a, b, tsa.view(e8), tsb.view(e8), alpha)), ref)
     with lab.forced(gemm_variant=70):   # the ring kernel with row-major scale fetch, the plan before this kernel
         assert np.array_equal(_np(lab.matmul_ada_mxf4_bf16_tn(a, b, sa, sb, alpha)), ref)
-    for v in (568, 569):   # ... and the kernel itself (32 / 16 columns per workgroup) where the product rule does not send the shape to it
+    for v in (568, 569, 570):   # ... and the kernel itself (32 / 16 columns per workgroup, 64-row tiles) where the product rule does not send the shape to it
         with lab.forced(gemm_variant=v):
             assert np.array_equal(_np(lab.matmul_ada_mxf4_bf16_tn(a, b, sa, sb, alpha)), ref), v
 
@@ -379,3 +381,82 @@ def test_nvf4_wave_owned_kernel_against_the_oracle(variant, m, n, k):
     ref = oracle.gemm_blockscaled(oracle.KIND_NVFP4, _np(a), _np(b), oracle.to_blocked(_np(sa)), oracle.to_blocked(_np(sb)), 0.5, m, n, k)
     bad = _np(got) != ref
     assert not bad.any(), f"{int(bad.sum())} of {bad.size} outputs differ, first at {np.argwhere(bad)[0].tolist()}"
+
+
+# ------------------------------------------------------------------------------------------------
+# [r6] the wave-owned small-batch kernel on MXFP8 operands (csrc/gemm_mx_os.hip.h, EBITS = 8; qutlass/csrc/gemm.cu:328-386 on small batches) -- 32x32 / 32x16 / 64x32 tiles
+# (lab variants 568 / 569 / 570), one shot (K <= 2048 / 1536) and wave-owned rings (longer K), ragged M / N, K tails of a quarter stage (K % 128 == 32), e4m3 and e5m2 A
+# operands: (a) within the MXFP8 tolerance class of the fp64 oracle on quantised Gaussian operands (tests/mxfp8_test.py), (b) EXACTLY equal to the oracle on operands whose
+# products and partial sums are all exact in fp32 (codes from {0, +-0.5, +-1, +-1.5, +-2, +-3, +-4}, scale exponents within +-2) -- the second pins every byte's place in
+# the fragment and every scale byte's block
+# ------------------------------------------------------------------------------------------------
+def _mxfp8_close(got_bits, want_bits):
+    got = oracle.bf16_bits_to_f32(got_bits).astype(np.float64)
+    want = oracle.bf16_bits_to_f32(want_bits).astype(np.float64)
+    tol = np.abs(want) / 128.0 + 2e-5 * np.abs(want).max()
+    return np.abs(got - want) <= tol
+
+
+MXF8_OS_SHAPES = [(1, 8, 32), (5, 72, 1024), (33, 104, 1440), (40, 200, 1952), (64, 96, 2048), (31, 264, 4096), (17, 4096, 2016), (9, 136, 4224), (33, 72, 5536), (3, 40, 7168),
+                  (128, 520, 4096), (97, 136, 1536), (100, 72, 1568)]
+
+
+def _exact_fp8_operands(m, n, k, seed, e5m2_a=False):
+    rng = np.random.default_rng(seed)
+    vals = np.array([0.0, 0.5, 1.0, 1.5, 2.0, 3.0, 4.0, -0.5, -1.0, -1.5, -2.0, -3.0, -4.0], np.float32)
+    af = torch.from_numpy(vals[rng.integers(0, len(vals), size=(m, k))])
+    bf = torch.from_numpy(vals[rng.integers(0, len(vals), size=(n, k))])
+    a = af.to(torch.float8_e5m2 if e5m2_a else torch.float8_e4m3fn).view(torch.uint8).to(DEV)
+    b = bf.to(torch.float8_e4m3fn).view(torch.uint8).to(DEV)
+    sa = torch.from_numpy(rng.integers(125, 130, size=(m, k // 32), dtype=np.uint8)).to(DEV)
+    sb = torch.from_numpy(rng.integers(125, 130, size=(n, k // 32), dtype=np.uint8)).to(DEV)
+    return a, b, sa, sb
+
+
+@pytest.mark.parametrize("a5", [False, True])
+@pytest.mark.parametrize("variant", [568, 569, 570, 0])
+@pytest.mark.parametrize("m,n,k", MXF8_OS_SHAPES)
+def test_mxf8_wave_owned_kernel_exact_against_the_oracle(variant, m, n, k, a5):
+    from qutlass_amd.utils import to_blocked
+
+    a, b, sa, sb = _exact_fp8_operands(m, n, k, m * 13 + n + k, a5)
+    alpha = torch.tensor([0.5], device=DEV)
+    e8 = torch.float8_e8m0fnu
+    tsa, tsb = to_blocked(sa.view(e8)).view(torch.uint8), to_blocked(sb.view(e8)).view(torch.uint8)
+    with lab.forced(gemm_variant=variant):
+        got = lab.matmul_mxf8_bf16_tn_fmt(a, b, tsa, tsb, alpha, a_format=1 if a5 else 0)
+    kind = oracle.KIND_MXFP8_TN_A5 if a5 else oracle.KIND_MXFP8_TN
+    ref = oracle.gemm_blockscaled(kind, _np(a), _np(b), oracle.to_blocked(_np(sa)), oracle.to_blocked(_np(sb)), 0.5, m, n, k)
+    bad = _np(got) != ref
+    assert not bad.any(), f"{int(bad.sum())} of {bad.size} outputs differ, first at {np.argwhere(bad)[0].tolist()}"
+
+
+@pytest.mark.parametrize("variant", [568, 569, 570])
+@pytest.mark.parametrize("m,n,k", [(33, 104, 1440), (31, 264, 4096), (128, 520, 4096), (9, 136, 4224)])
+def test_mxf8_wave_owned_kernel_on_quantised_gaussians(variant, m, n, k):
+    from qutlass_amd.utils import to_blocked
+
+    torch.manual_seed(m + n + k)
+    a = torch.randn(m, k, dtype=torch.bfloat16) * 25.0
+    b = torch.randn(n, k, dtype=torch.bfloat16) * 25.0
+    aq, asf = oracle.pseudoquant_mxfp8(_np(a))
+    bq, bsf = oracle.pseudoquant_mxfp8(_np(b))
+    e8 = torch.float8_e8m0fnu
+    with lab.forced(gemm_variant=variant):
+        out = lab.matmul_mxf8_bf16_tn(torch.from_numpy(aq).to(DEV), torch.from_numpy(bq).to(DEV), to_blocked(torch.from_numpy(asf).to(DEV).view(e8)),
+                                      to_blocked(torch.from_numpy(bsf).to(DEV).view(e8)), torch.tensor([1.0], device=DEV))
+    ref = oracle.gemm_blockscaled(oracle.KIND_MXFP8_TN, aq, bq, oracle.to_blocked(asf), oracle.to_blocked(bsf), 1.0, m, n, k)
+    assert _mxfp8_close(_np(out), ref).all()
+
+
+@pytest.mark.parametrize("m,n,k", [(1, 4096, 4096), (16, 4096, 4096), (64, 4096, 4096), (128, 4096, 4096), (32, 8192, 2048), (8, 2048, 8192)])
+def test_product_rule_on_mxf8_small_batches_matches_the_oracle(q, m, n, k):
+    """shapes the product sends to the wave-owned kernel (capi.hip os8_plan; pinned on the CPU in tests/test_cabi_and_host.py), through the product library and the torch op,
+    exact-regime operands: every output element equal to the oracle's"""
+    from qutlass_amd.utils import to_blocked
+
+    a, b, sa, sb = _exact_fp8_operands(m, n, k, m + n + k)
+    e4, e8 = torch.float8_e4m3fn, torch.float8_e8m0fnu
+    got = q.matmul_mxf8_bf16_tn(a.view(e4), b.view(e4), to_blocked(sa.view(e8)), to_blocked(sb.view(e8)), torch.tensor([1.0], device=DEV))
+    ref = oracle.gemm_blockscaled(oracle.KIND_MXFP8_TN, _np(a), _np(b), oracle.to_blocked(_np(sa)), oracle.to_blocked(_np(sb)), 1.0, m, n, k)
+    assert np.array_equal(_np(got), ref)

@@ -12,15 +12,16 @@ alpha = torch.ones(1, device=dev)
 print("# matmul_ada_mxf4_bf16_tn (row-major scales), us per launch (HIP-graph replays): forced 60 = LDS-free split-K kernel, 70 = 64x64 ring, 568 = one-shot, 0 = the product rule")
 NK = [tuple(int(d) for d in x.split("x")) for x in os.environ.get("ADA_NK", "4096x4096,2048x2048,8192x4096,1024x4096,6144x4096").split(",")]
 for (n, k) in NK:
-    for m in (1, 8, 16, 32, 64):
+    for m in [int(v) for v in os.environ.get("ADA_M", "1,8,16,32,64").split(",")]:
         a = torch.randint(0, 256, (m, k // 2), dtype=torch.uint8, device=dev, generator=g)
         b = torch.randint(0, 256, (n, k // 2), dtype=torch.uint8, device=dev, generator=g)
         sa = torch.randint(125, 129, (m, k // 32), dtype=torch.uint8, device=dev, generator=g)
         sb = torch.randint(125, 129, (n, k // 32), dtype=torch.uint8, device=dev, generator=g)
         t, outs = {}, {}
-        for v in (60, 70, 568, 569, 0):
+        VS = [int(v) for v in os.environ.get("ADA_VARIANTS", "60,70,568,569,0").split(",")]   # (570 = 64x32 tiles)
+        for v in VS:
             with lab.forced(gemm_variant=v):
                 outs[v] = lab.matmul_ada_mxf4_bf16_tn(a, b, sa, sb, alpha)
                 t[v] = min(graph_us(lambda: lab.matmul_ada_mxf4_bf16_tn(a, b, sa, sb, alpha), n=40) for _ in range(3))
-        eq = all(torch.equal(outs[v].view(torch.int16), outs[60].view(torch.int16)) for v in (70, 568, 569, 0))
-        print("N=%-6d K=%-6d M=%-4d | %s | %s" % (n, k, m, " ".join("%d: %6.2f" % (v, t[v]) for v in (60, 70, 568, 569, 0)), "equal" if eq else "DIFFER"), flush=True)
+        eq = all(torch.equal(outs[v].view(torch.int16), outs[VS[0]].view(torch.int16)) for v in VS[1:])
+        print("N=%-6d K=%-6d M=%-4d | %s | %s" % (n, k, m, " ".join("%d: %6.2f" % (v, t[v]) for v in VS), "equal" if eq else "DIFFER"), flush=True)
