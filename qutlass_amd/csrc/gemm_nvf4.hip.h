@@ -824,16 +824,23 @@ inline int nvf4_big_cfg(int64_t M, int64_t N, int64_t K, int cus, double* t_us =
 // Against the calibration the chosen candidates sum to 10 353 us (best measured candidate per shape: 10 288; the occupancy thresholds this replaces:
 // 11 057), e.g. 256 x 4096 x 14336 54.7 -> 39.2 us (128x128 tiles, 4 K ranges), 128 x 8192 x 28672 107 -> 67, 64 x 28672 x 4096 36.7 -> 26.6 (64x64 tiles
 // instead of the skinny kernel), 512 x 5120 x 5120 47.0 -> 41.1 (160 tiles of 128x128 instead of 320 of 128x64, which put two on 64 CUs).
-struct NvPlan { int cfg, splits, kt_per; };   // cfg as above (-1 skinny, [r6] -2 / -3 wave-owned small-batch kernel with 32 / 16 columns per workgroup); splits = K ranges actually launched (none empty), kt_per = stages per range (even)
+struct NvPlan { int cfg, splits, kt_per; };   // cfg as above (-1 skinny, [r6] -2 / -3 wave-owned small-batch kernel with 32 / 16 columns per workgroup, -4 its 16x16 decode form); splits = K ranges actually launched (none empty), kt_per = stages per range (even)
 // [r6] Does the wave-owned small-batch kernel (gemm_nvf4_os.hip.h) take the shape?  0 (no) or 32 (columns per workgroup; 16 is lab-only: the kernel is bound by its
 // dequantisation instructions -- ~16 per MFMA -- not by bytes, so spreading the weight over twice the workgroups buys nothing: profiles/calib_nvos_r6u.txt).
 // Measured against the plan before it (skinny / tile kernels / split-K with scratch), M = 1 ... 128:
 //   K <= 4096 (one shot): up to THREE rounds of 32x32 tiles (N = 4096, M = 128: 11.5 -> 9.7 us; 6144 x 4096, M = 128 = 768 tiles: 16.8 -> 13.8; four rounds lose)
 //   longer K (wave-owned rings, <= 64 stages): one tile per CU at most (4096 x 14336, M <= 64: 14.4-20.0 -> 13.4-15.5 us), two rounds up to 32 stages
 //   (4096 x 8192, M = 128: 21.6 -> 18.0), and never fewer than a quarter of the CUs busy (a long K on few tiles stays with the split plans)
+// [r6, third session] 1616 = its decode form, 16x16 tiles on v_mfma_f32_16x16x32_f16 (gemm_nvf4_os16_kernel): the same dequantisation instructions per weight element spread
+// over twice the workgroups.  Whenever the 16x16 tiles fit one per CU it wins at every K and every workgroup count measured (K = 2048 ... 28672, 32 ... 256 workgroups:
+// N = K = 4096, M <= 16: 5.3 -> 3.7-3.9 us; 4096 x 14336: 13.6 -> 9.1-9.7; 1024 x 14336, M = 32: 18.6 -> 8.8; x 28672, M = 16: 30.0 -> 16.4 -- also against the split-K
+// plans); two per CU (N = 6144 / 8192, M <= 16) still 4-8 % ahead at K = 4096 and behind from K = 8192 on.  profiles/calib_nv16_r7.txt
 inline int nv_os_plan(int64_t M, int64_t N, int64_t K, int cus) {
   const int64_t T32 = ((M + 31) / 32) * ((N + 31) / 32), KT = (K / 2 + 127) / 128;
   if (M > 128) return 0;
+  const int64_t G16 = ((M + 15) / 16) * ((N + 15) / 16);
+  if (G16 <= cus && KT <= 128) return 1616;
+  if (M <= 16 && G16 <= 2 * (int64_t)cus && KT <= 16) return 1616;
   // (more than one round only when the last round is at least half full: 260 tiles would pay a second round for 4 of them)
   const bool rounds_ok = T32 <= cus || T32 % cus == 0 || 2 * (T32 % cus) >= cus;
   if (KT <= 16) return (T32 <= 3 * (int64_t)cus && rounds_ok) ? 32 : 0;
@@ -843,7 +850,7 @@ inline int nv_os_plan(int64_t M, int64_t N, int64_t K, int cus) {
 }
 hipError_t launch_nvf4_os(NvGemmParams p, hipStream_t s, int tn);   // capi.hip (the NVFP4 unit)
 inline NvPlan nvf4_plan(int64_t M, int64_t N, int64_t K, int cus, bool may_split) {
-  if (const int tn = nv_os_plan(M, N, K, cus)) return {tn == 16 ? -3 : -2, 1, 0};
+  if (const int tn = nv_os_plan(M, N, K, cus)) return {tn == 1616 ? -4 : tn == 16 ? -3 : -2, 1, 0};
   if (M <= 32) return {-1, 1, 0};
   auto tiles = [&](int bm, int bn) { return ((M + bm - 1) / bm) * ((N + bn - 1) / bn); };
   const int KT = (int)((K / 2 + 127) / 128);
@@ -905,8 +912,9 @@ inline hipError_t launch_nvf4_gemm(NvGemmParams p, hipStream_t s, int variant = 
   const NvPlan plan = nvf4_plan(p.M, p.N, p.K, cus, p.ws != nullptr);
 #if QAMD_BENCH
   if (variant == 46 || variant == 47) return launch_nvf4_os(p, s, variant == 47 ? 16 : 32);   // lab: force the wave-owned small-batch kernel (any K: rings beyond 4096)
+  if (variant == 48) return launch_nvf4_os(p, s, 1616);                                       // lab: ... its 16x16 decode form (any M: rows in tiles of 16)
 #endif
-  if (variant == 0 && plan.cfg <= -2) return launch_nvf4_os(p, s, plan.cfg == -3 ? 16 : 32);
+  if (variant == 0 && plan.cfg <= -2) return launch_nvf4_os(p, s, plan.cfg == -4 ? 1616 : plan.cfg == -3 ? 16 : 32);
   if (variant == 3 || (variant == 0 && plan.cfg < 0)) {
     hipLaunchKernelGGL((gemm_nvf4_skinny_kernel<8>), dim3((p.N + 31) / 32, (p.M + 31) / 32), dim3(512), 0, s, p);
     return hipSuccess;

@@ -180,10 +180,175 @@ __global__ __launch_bounds__(512) void gemm_nvf4_os_kernel(const NvGemmParams p)
   }
 }
 
+// ---- [r6, third session] decode form: a 16x16 output tile per workgroup on v_mfma_f32_16x16x32_f16 -------------------------------------------------------------
+// The 32x32 kernel above is bound by its dequantisation instructions (16 per MFMA: 4 converts + 4 packed multiplies per operand dword), not by bytes, and at M <= 16 half
+// of its A fragment is rows that do not exist.  Here a workgroup owns 16 output columns and 16 rows: a 16x16x32 MFMA takes ONE dword (8 e2m1) per lane and operand, so the
+// instructions per weight element are those of the 32-column kernel while N = 4096 spreads over 256 workgroups instead of 128 -- half the vector work per CU.
+// Lane l = (row r = l & 15, quarter kq = l >> 4) reads the two 16-byte chunks kq and kq + 4 of its row (64 elements of the stage's 256); MFMA (h, d) takes dword d of
+// chunk kq + 4 h from every lane -- a permutation of K inside the stage that A and B share.  Scales: ONE dword piece per operand and stage (lane l fetches row r's dword of
+// column tile 4 kt + kq); the two scale groups of chunk kq + 4 h are bytes 2 (kq & 1), + 1 of column tile 4 kt + 2 h + (kq >> 1).
+template <int SPW_>
+struct NvOs16Cfg {
+  static constexpr int NW = 8, TM = 16, TN = 16, ROWB = 128, SPW = SPW_, NSLOT = NW * SPW_;
+  static constexpr int OFF_B = TM * ROWB, OFF_S = (TM + TN) * ROWB, STAGE = OFF_S + 512;   // + one 256-byte scale piece per operand
+  static constexpr int LPS = 2 + 2 + 2;
+  static constexpr int RED = NW * 1024;
+  static constexpr int LDS_BYTES = NSLOT * STAGE > RED ? NSLOT * STAGE : RED;
+  static_assert(SPW >= 1 && SPW * LPS <= 63, "vmcnt immediate");
+  static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
+};
+
+template <class C, bool RING = false>
+__global__ __launch_bounds__(512) void gemm_nvf4_os16_kernel(const NvGemmParams p) {
+  constexpr int SPW = C::SPW, LPS = C::LPS, NW = C::NW;
+  __shared__ __attribute__((aligned(16))) char smem[C::LDS_BYTES];
+  asm volatile("" :: "s"(p.A), "s"(p.D), "s"(p.K), "s"(p.b_bytes), "s"(p.alpha));   // all scalar argument loads in one round
+  const float alpha = *p.alpha;
+  const int tid = threadIdx.x, lane = tid & 63, wave = uniform(tid >> 6), r16 = lane & 15, kq = lane >> 4;
+  const int nb = p.tiles_m * p.tiles_n;
+  const int b2 = xcd_remap((int)blockIdx.x, nb);
+  const int m0 = uniform((b2 % p.tiles_m) * C::TM), n0 = uniform((b2 / p.tiles_m) * C::TN);
+  const int rowbytes = p.K >> 1, KT = (rowbytes + C::ROWB - 1) / C::ROWB;
+  const int G16 = p.K >> 4, CB = (G16 + 3) >> 2;   // scale groups per row, column tiles of 4 groups
+  const int tailbytes = rowbytes - (KT - 1) * C::ROWB;
+
+  // ---- LDS-DMA sources: pieces of 8 rows x 128 B, chunk ^ ((row >> 1) & 7) at the source (gemm_mx_os.hip.h) ----------------------------------------------
+  const uint32_t a_off = (uint32_t)m0 * rowbytes, b_off = (uint32_t)n0 * rowbytes;
+  const __amdgpu_buffer_rsrc_t rA = make_rsrc(p.A + a_off, p.a_bytes - a_off), rB = make_rsrc(p.B + b_off, p.b_bytes - b_off);
+  int vP[2], chP[2];
+#pragma unroll
+  for (int par = 0; par < 2; ++par) {
+    chP[par] = (lane & 7) ^ (((lane >> 4) + 4 * par) & 7);
+    vP[par] = (lane >> 3) * rowbytes + (chP[par] << 4);
+  }
+  const int rstep = 8 * rowbytes;
+  const uint32_t sa_off = (uint32_t)(m0 >> 7) * CB * 512, sb_off = (uint32_t)(n0 >> 7) * CB * 512;
+  const __amdgpu_buffer_rsrc_t rSA = make_rsrc(p.SFA + sa_off, p.sfa_bytes - sa_off), rSB = make_rsrc(p.SFB + sb_off, p.sfb_bytes - sb_off);
+  const int rowA = (m0 & 127) + r16, rowB = (n0 & 127) + r16;   // rows of the 128-row scale tiles
+  const int vSA = kq * 512 + (rowA & 31) * 16 + (rowA >> 5) * 4, vSB = kq * 512 + (rowB & 31) * 16 + (rowB >> 5) * 4;
+
+  auto issue = [&](const int kt, const int slot) __attribute__((always_inline)) {   // stage kt into slot `slot` of this wave (kt >= KT: every piece out of range -> zeros)
+    char* st = smem + (wave * SPW + slot) * C::STAGE;
+    int tail = (kt == KT - 1) ? tailbytes : C::ROWB;
+    int oob = (kt < KT) ? 0 : -1;
+    asm volatile("" : "+v"(tail), "+v"(oob));
+    const int soff = kt * C::ROWB;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const bool isB = t >= 2;
+      const int qq = t & 1;
+      const int o = oob | ((chP[qq] << 4) < tail ? 0 : -1);
+      const int v = ((vP[qq] + qq * rstep) & ~o) | ((int)0x80000000 & o);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(isB ? rB : rA, (lds_ptr_t)(st + (isB ? C::OFF_B : 0) + qq * 1024), 16, v, soff, 0, 0);
+    }
+    const int os = (kt < KT && 4 * kt + kq < CB) ? 0 : -1;   // a column tile past the operand's last one would read the next row tile's bytes
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rSA, (lds_ptr_t)(st + C::OFF_S), 4, (vSA & ~os) | ((int)0x80000000 & os), kt * 2048, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rSB, (lds_ptr_t)(st + C::OFF_S + 256), 4, (vSB & ~os) | ((int)0x80000000 & os), kt * 2048, 0, 0);
+  };
+
+#pragma unroll
+  for (int j = 0; j < SPW; ++j) issue(wave + NW * j, j);
+
+  const int sw = (r16 >> 1) & 7;
+  v4f acc = {0.f, 0.f, 0.f, 0.f};
+  auto fence = [&]() __attribute__((always_inline)) { __builtin_amdgcn_sched_barrier(0); };
+
+  auto consume = [&](const int kt, const int u, const int kt_next) __attribute__((always_inline)) {
+    const char* st = smem + (wave * SPW + u) * C::STAGE;
+    v4i ca[2], cb[2];
+    uint32_t da[2], db[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int off = r16 * C::ROWB + (((kq + 4 * h) ^ sw) << 4);
+      ca[h] = *(const v4i*)(st + off);
+      cb[h] = *(const v4i*)(st + C::OFF_B + off);
+      da[h] = *(const uint32_t*)(st + C::OFF_S + ((2 * h + (kq >> 1)) * 16 + r16) * 4);
+      db[h] = *(const uint32_t*)(st + C::OFF_S + 256 + ((2 * h + (kq >> 1)) * 16 + r16) * 4);
+    }
+    fence();
+    if constexpr (RING) {
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ca[0]), "+v"(ca[1]), "+v"(cb[0]), "+v"(cb[1]), "+v"(da[0]), "+v"(da[1]), "+v"(db[0]), "+v"(db[1]) :: "memory");   // the slot is free
+      issue(kt_next, u);
+      fence();
+    }
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      // groups past K inside the last column tile (K % 64 == 32): their scale bytes are layout padding -- masked to 0 (0 x 0, never NaN)
+      const int valid = G16 - 4 * (4 * kt + 2 * h + (kq >> 1));
+      const uint32_t smask = valid >= 4 ? 0xffffffffu : (valid <= 0 ? 0u : ((1u << (8 * valid)) - 1u));
+      const h2_t sa = __builtin_amdgcn_cvt_scalef32_pk_f16_fp8((da[h] & smask) >> (16 * (kq & 1)), 1.0f, false);   // the two groups of chunk kq + 4 h
+      const h2_t sb = __builtin_amdgcn_cvt_scalef32_pk_f16_fp8((db[h] & smask) >> (16 * (kq & 1)), 1.0f, false);
+#pragma unroll
+      for (int d = 0; d < 4; ++d) {
+        const _Float16 xa = sa[d >> 1], xb = sb[d >> 1];
+        const h8_t fa = dq8((uint32_t)ca[h][d], h2_t{xa, xa});
+        const h8_t fb = dq8((uint32_t)cb[h][d], h2_t{xb, xb});
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb, fa, acc, 0, 0, 0);
+      }
+    }
+    fence();
+  };
+  if constexpr (!RING) {
+    static_for<0, SPW>([&](auto jc) __attribute__((always_inline)) {
+      constexpr int j = decltype(jc)::value;
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"((SPW - 1 - j) * LPS) : "memory");
+      fence();
+      consume(wave + NW * j, j, 0);
+    });
+  } else {
+    for (int kt = wave; kt < KT; kt += NW * SPW) {
+      static_for<0, SPW>([&](auto uc) __attribute__((always_inline)) {
+        constexpr int u = decltype(uc)::value;
+        if (u == 0 || kt + NW * u < KT) {
+          asm volatile("s_waitcnt vmcnt(%0)" ::"n"((SPW - 1) * LPS) : "memory");
+          fence();
+          consume(kt + NW * u, u, kt + NW * u + NW * SPW);
+        }
+      });
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();   // every wave's reads of the stage areas are done: they become the sum's scratch
+  fence();
+
+  // ---- cross-wave sum: [wave][row m][16 columns] fp32; a lane holds row m = r16, columns 4 kq .. + 3 (srcA = the B fragment) ------------------------------
+  *(v4f*)(smem + (wave * 16 + r16) * 64 + kq * 16) = acc;
+  __syncthreads();
+  if (tid < 64) {
+    const int rr = tid >> 2, cq = tid & 3;
+    v4f t = *(const v4f*)(smem + rr * 64 + cq * 16);
+#pragma unroll
+    for (int w = 1; w < NW; ++w) {
+      const v4f s = *(const v4f*)(smem + (w * 16 + rr) * 64 + cq * 16);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) t[e] += s[e];
+    }
+    const int row = m0 + rr, col = n0 + 4 * cq;
+    if (row < p.M && col < p.N) {
+      v2i o;
+      o[0] = (int)pack_bf16x2(t[0] * alpha, t[1] * alpha);
+      o[1] = (int)pack_bf16x2(t[2] * alpha, t[3] * alpha);
+      *(v2i*)(p.D + (size_t)row * p.ldd + col) = o;
+    }
+  }
+}
+
 #if QAMD_TU == 0 || QAMD_TU == 4
 // (not inline: the NVFP4 unit of capi.hip emits it; declared in gemm_nvf4.hip.h for launch_nvf4_gemm)
 // [r6] the wave-owned small-batch kernel (gemm_nvf4_os.hip.h): K <= 2048 one stage per wave, K <= 4096 two, longer K two refilled slots per wave
 hipError_t launch_nvf4_os(NvGemmParams p, hipStream_t s, int tn) {
+  if (tn == 1616) {   // [r6] the decode form: 16x16 tiles on the 16x16x32 MFMA -- one shot up to K = 8192 (four 4.5-KiB stages per wave), four refilled slots per wave beyond
+    p.tiles_m = (p.M + 15) / 16;
+    p.tiles_n = (p.N + 15) / 16;
+    const int KT = (p.K / 2 + 127) / 128;
+    const dim3 grid(p.tiles_m * p.tiles_n), block(512);
+    if (KT <= 8) hipLaunchKernelGGL((gemm_nvf4_os16_kernel<NvOs16Cfg<1>>), grid, block, 0, s, p);
+    else if (KT <= 16) hipLaunchKernelGGL((gemm_nvf4_os16_kernel<NvOs16Cfg<2>>), grid, block, 0, s, p);
+    else if (KT <= 24) hipLaunchKernelGGL((gemm_nvf4_os16_kernel<NvOs16Cfg<3>>), grid, block, 0, s, p);
+    else if (KT <= 32) hipLaunchKernelGGL((gemm_nvf4_os16_kernel<NvOs16Cfg<4>>), grid, block, 0, s, p);
+    else hipLaunchKernelGGL((gemm_nvf4_os16_kernel<NvOs16Cfg<4>, true>), grid, block, 0, s, p);
+    return hipSuccess;
+  }
   p.tiles_m = (p.M + 31) / 32;
   p.tiles_n = (p.N + tn - 1) / tn;
   const int KT = (p.K / 2 + 127) / 128;
