@@ -824,7 +824,7 @@ inline int nvf4_big_cfg(int64_t M, int64_t N, int64_t K, int cus, double* t_us =
 // Against the calibration the chosen candidates sum to 10 353 us (best measured candidate per shape: 10 288; the occupancy thresholds this replaces:
 // 11 057), e.g. 256 x 4096 x 14336 54.7 -> 39.2 us (128x128 tiles, 4 K ranges), 128 x 8192 x 28672 107 -> 67, 64 x 28672 x 4096 36.7 -> 26.6 (64x64 tiles
 // instead of the skinny kernel), 512 x 5120 x 5120 47.0 -> 41.1 (160 tiles of 128x128 instead of 320 of 128x64, which put two on 64 CUs).
-struct NvPlan { int cfg, splits, kt_per; };   // cfg as above (-1 skinny, [r6] -2 / -3 wave-owned small-batch kernel with 32 / 16 columns per workgroup, -4 its 16x16 decode form); splits = K ranges actually launched (none empty), kt_per = stages per range (even)
+struct NvPlan { int cfg, splits, kt_per; };   // cfg as above (-1 skinny, [r6] -2 / -3 wave-owned small-batch kernel with 32 / 16 columns per workgroup, -4 / -5 its 16x16 / 32x16 decode form); splits = K ranges actually launched (none empty), kt_per = stages per range (even)
 // [r6] Does the wave-owned small-batch kernel (gemm_nvf4_os.hip.h) take the shape?  0 (no) or 32 (columns per workgroup; 16 is lab-only: the kernel is bound by its
 // dequantisation instructions -- ~16 per MFMA -- not by bytes, so spreading the weight over twice the workgroups buys nothing: profiles/calib_nvos_r6u.txt).
 // Measured against the plan before it (skinny / tile kernels / split-K with scratch), M = 1 ... 128:
@@ -841,6 +841,9 @@ inline int nv_os_plan(int64_t M, int64_t N, int64_t K, int cus) {
   const int64_t G16 = ((M + 15) / 16) * ((N + 15) / 16);
   if (G16 <= cus && KT <= 128) return 1616;
   if (M <= 16 && G16 <= 2 * (int64_t)cus && KT <= 16) return 1616;
+  // 3216 = the same with two m-tiles per workgroup (a B dword dequantised once for both): where 32x16 tiles fit one per CU (N = 4096, M = 17 ... 32: K = 4096 5.35 -> 4.75 us,
+  // K = 14336 14.1 -> 11.7, K = 28672 30-36 -> 20)
+  if (((M + 31) / 32) * ((N + 15) / 16) <= cus && KT <= 128) return 3216;
   // (more than one round only when the last round is at least half full: 260 tiles would pay a second round for 4 of them)
   const bool rounds_ok = T32 <= cus || T32 % cus == 0 || 2 * (T32 % cus) >= cus;
   if (KT <= 16) return (T32 <= 3 * (int64_t)cus && rounds_ok) ? 32 : 0;
@@ -850,7 +853,7 @@ inline int nv_os_plan(int64_t M, int64_t N, int64_t K, int cus) {
 }
 hipError_t launch_nvf4_os(NvGemmParams p, hipStream_t s, int tn);   // capi.hip (the NVFP4 unit)
 inline NvPlan nvf4_plan(int64_t M, int64_t N, int64_t K, int cus, bool may_split) {
-  if (const int tn = nv_os_plan(M, N, K, cus)) return {tn == 1616 ? -4 : tn == 16 ? -3 : -2, 1, 0};
+  if (const int tn = nv_os_plan(M, N, K, cus)) return {tn == 3216 ? -5 : tn == 1616 ? -4 : tn == 16 ? -3 : -2, 1, 0};
   if (M <= 32) return {-1, 1, 0};
   auto tiles = [&](int bm, int bn) { return ((M + bm - 1) / bm) * ((N + bn - 1) / bn); };
   const int KT = (int)((K / 2 + 127) / 128);
@@ -913,8 +916,9 @@ inline hipError_t launch_nvf4_gemm(NvGemmParams p, hipStream_t s, int variant = 
 #if QAMD_BENCH
   if (variant == 46 || variant == 47) return launch_nvf4_os(p, s, variant == 47 ? 16 : 32);   // lab: force the wave-owned small-batch kernel (any K: rings beyond 4096)
   if (variant == 48) return launch_nvf4_os(p, s, 1616);                                       // lab: ... its 16x16 decode form (any M: rows in tiles of 16)
+  if (variant == 49) return launch_nvf4_os(p, s, 3216);                                       // lab: ... with two m-tiles per workgroup (32x16)
 #endif
-  if (variant == 0 && plan.cfg <= -2) return launch_nvf4_os(p, s, plan.cfg == -4 ? 1616 : plan.cfg == -3 ? 16 : 32);
+  if (variant == 0 && plan.cfg <= -2) return launch_nvf4_os(p, s, plan.cfg == -5 ? 3216 : plan.cfg == -4 ? 1616 : plan.cfg == -3 ? 16 : 32);
   if (variant == 3 || (variant == 0 && plan.cfg < 0)) {
     hipLaunchKernelGGL((gemm_nvf4_skinny_kernel<8>), dim3((p.N + 31) / 32, (p.M + 31) / 32), dim3(512), 0, s, p);
     return hipSuccess;

@@ -187,20 +187,24 @@ __global__ __launch_bounds__(512) void gemm_nvf4_os_kernel(const NvGemmParams p)
 // Lane l = (row r = l & 15, quarter kq = l >> 4) reads the two 16-byte chunks kq and kq + 4 of its row (64 elements of the stage's 256); MFMA (h, d) takes dword d of
 // chunk kq + 4 h from every lane -- a permutation of K inside the stage that A and B share.  Scales: ONE dword piece per operand and stage (lane l fetches row r's dword of
 // column tile 4 kt + kq); the two scale groups of chunk kq + 4 h are bytes 2 (kq & 1), + 1 of column tile 4 kt + 2 h + (kq >> 1).
-template <int SPW_>
+// MT = 2 (M = 17 ... 32): two m-tiles of 16 rows per workgroup -- a B dword is dequantised once and feeds both m-tiles' MFMAs (12 instead of 16 vector instructions
+// per MFMA), still 16 columns per workgroup.
+template <int SPW_, int MT_ = 1>
 struct NvOs16Cfg {
-  static constexpr int NW = 8, TM = 16, TN = 16, ROWB = 128, SPW = SPW_, NSLOT = NW * SPW_;
-  static constexpr int OFF_B = TM * ROWB, OFF_S = (TM + TN) * ROWB, STAGE = OFF_S + 512;   // + one 256-byte scale piece per operand
-  static constexpr int LPS = 2 + 2 + 2;
-  static constexpr int RED = NW * 1024;
+  static constexpr int NW = 8, MT = MT_, TM = 16 * MT_, TN = 16, ROWB = 128, SPW = SPW_, NSLOT = NW * SPW_;
+  static constexpr int OFF_B = TM * ROWB, OFF_S = (TM + TN) * ROWB, OFF_SB = OFF_S + MT * 256, STAGE = OFF_SB + 256;   // one 256-byte scale piece per m-tile and one for B
+  static constexpr int NPA = 2 * MT;
+  static constexpr int LPS = NPA + 2 + MT + 1;
+  static constexpr int RED = NW * TM * 64;
   static constexpr int LDS_BYTES = NSLOT * STAGE > RED ? NSLOT * STAGE : RED;
+  static_assert(MT == 1 || MT == 2, "m-tiles");
   static_assert(SPW >= 1 && SPW * LPS <= 63, "vmcnt immediate");
   static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
 };
 
 template <class C, bool RING = false>
 __global__ __launch_bounds__(512) void gemm_nvf4_os16_kernel(const NvGemmParams p) {
-  constexpr int SPW = C::SPW, LPS = C::LPS, NW = C::NW;
+  constexpr int SPW = C::SPW, LPS = C::LPS, NW = C::NW, MT = C::MT;
   __shared__ __attribute__((aligned(16))) char smem[C::LDS_BYTES];
   asm volatile("" :: "s"(p.A), "s"(p.D), "s"(p.K), "s"(p.b_bytes), "s"(p.alpha));   // all scalar argument loads in one round
   const float alpha = *p.alpha;
@@ -224,8 +228,14 @@ __global__ __launch_bounds__(512) void gemm_nvf4_os16_kernel(const NvGemmParams 
   const int rstep = 8 * rowbytes;
   const uint32_t sa_off = (uint32_t)(m0 >> 7) * CB * 512, sb_off = (uint32_t)(n0 >> 7) * CB * 512;
   const __amdgpu_buffer_rsrc_t rSA = make_rsrc(p.SFA + sa_off, p.sfa_bytes - sa_off), rSB = make_rsrc(p.SFB + sb_off, p.sfb_bytes - sb_off);
-  const int rowA = (m0 & 127) + r16, rowB = (n0 & 127) + r16;   // rows of the 128-row scale tiles
-  const int vSA = kq * 512 + (rowA & 31) * 16 + (rowA >> 5) * 4, vSB = kq * 512 + (rowB & 31) * 16 + (rowB >> 5) * 4;
+  const int rowB = (n0 & 127) + r16;   // row of the 128-row scale tile
+  int vSA[MT];
+#pragma unroll
+  for (int t = 0; t < MT; ++t) {
+    const int rowA = (m0 & 127) + 16 * t + r16;
+    vSA[t] = kq * 512 + (rowA & 31) * 16 + (rowA >> 5) * 4;
+  }
+  const int vSB = kq * 512 + (rowB & 31) * 16 + (rowB >> 5) * 4;
 
   auto issue = [&](const int kt, const int slot) __attribute__((always_inline)) {   // stage kt into slot `slot` of this wave (kt >= KT: every piece out of range -> zeros)
     char* st = smem + (wave * SPW + slot) * C::STAGE;
@@ -234,40 +244,52 @@ __global__ __launch_bounds__(512) void gemm_nvf4_os16_kernel(const NvGemmParams 
     asm volatile("" : "+v"(tail), "+v"(oob));
     const int soff = kt * C::ROWB;
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      const bool isB = t >= 2;
-      const int qq = t & 1;
-      const int o = oob | ((chP[qq] << 4) < tail ? 0 : -1);
-      const int v = ((vP[qq] + qq * rstep) & ~o) | ((int)0x80000000 & o);
+    for (int t = 0; t < C::NPA + 2; ++t) {
+      const bool isB = t >= C::NPA;
+      const int qq = isB ? t - C::NPA : t, par = qq & 1;
+      const int o = oob | ((chP[par] << 4) < tail ? 0 : -1);
+      const int v = ((vP[par] + qq * rstep) & ~o) | ((int)0x80000000 & o);
       __builtin_amdgcn_raw_ptr_buffer_load_lds(isB ? rB : rA, (lds_ptr_t)(st + (isB ? C::OFF_B : 0) + qq * 1024), 16, v, soff, 0, 0);
     }
     const int os = (kt < KT && 4 * kt + kq < CB) ? 0 : -1;   // a column tile past the operand's last one would read the next row tile's bytes
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rSA, (lds_ptr_t)(st + C::OFF_S), 4, (vSA & ~os) | ((int)0x80000000 & os), kt * 2048, 0, 0);
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rSB, (lds_ptr_t)(st + C::OFF_S + 256), 4, (vSB & ~os) | ((int)0x80000000 & os), kt * 2048, 0, 0);
+#pragma unroll
+    for (int t = 0; t < MT; ++t)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rSA, (lds_ptr_t)(st + C::OFF_S + t * 256), 4, (vSA[t] & ~os) | ((int)0x80000000 & os), kt * 2048, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rSB, (lds_ptr_t)(st + C::OFF_SB), 4, (vSB & ~os) | ((int)0x80000000 & os), kt * 2048, 0, 0);
   };
 
 #pragma unroll
   for (int j = 0; j < SPW; ++j) issue(wave + NW * j, j);
 
   const int sw = (r16 >> 1) & 7;
-  v4f acc = {0.f, 0.f, 0.f, 0.f};
+  v4f acc[MT];
+#pragma unroll
+  for (int t = 0; t < MT; ++t) acc[t] = v4f{0.f, 0.f, 0.f, 0.f};
   auto fence = [&]() __attribute__((always_inline)) { __builtin_amdgcn_sched_barrier(0); };
 
   auto consume = [&](const int kt, const int u, const int kt_next) __attribute__((always_inline)) {
     const char* st = smem + (wave * SPW + u) * C::STAGE;
-    v4i ca[2], cb[2];
-    uint32_t da[2], db[2];
+    v4i ca[MT][2], cb[2];
+    uint32_t da[MT][2], db[2];
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       const int off = r16 * C::ROWB + (((kq + 4 * h) ^ sw) << 4);
-      ca[h] = *(const v4i*)(st + off);
+      const int soff = ((2 * h + (kq >> 1)) * 16 + r16) * 4;
+#pragma unroll
+      for (int t = 0; t < MT; ++t) {
+        ca[t][h] = *(const v4i*)(st + t * 16 * C::ROWB + off);
+        da[t][h] = *(const uint32_t*)(st + C::OFF_S + t * 256 + soff);
+      }
       cb[h] = *(const v4i*)(st + C::OFF_B + off);
-      da[h] = *(const uint32_t*)(st + C::OFF_S + ((2 * h + (kq >> 1)) * 16 + r16) * 4);
-      db[h] = *(const uint32_t*)(st + C::OFF_S + 256 + ((2 * h + (kq >> 1)) * 16 + r16) * 4);
+      db[h] = *(const uint32_t*)(st + C::OFF_SB + soff);
     }
     fence();
     if constexpr (RING) {
-      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ca[0]), "+v"(ca[1]), "+v"(cb[0]), "+v"(cb[1]), "+v"(da[0]), "+v"(da[1]), "+v"(db[0]), "+v"(db[1]) :: "memory");   // the slot is free
+      if constexpr (MT == 1)
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ca[0][0]), "+v"(ca[0][1]), "+v"(cb[0]), "+v"(cb[1]), "+v"(da[0][0]), "+v"(da[0][1]), "+v"(db[0]), "+v"(db[1]) :: "memory");   // the slot is free
+      else
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ca[0][0]), "+v"(ca[0][1]), "+v"(ca[MT - 1][0]), "+v"(ca[MT - 1][1]), "+v"(cb[0]), "+v"(cb[1]), "+v"(da[0][0]), "+v"(da[0][1]),
+                     "+v"(da[MT - 1][0]), "+v"(da[MT - 1][1]), "+v"(db[0]), "+v"(db[1]) :: "memory");
       issue(kt_next, u);
       fence();
     }
@@ -276,14 +298,20 @@ __global__ __launch_bounds__(512) void gemm_nvf4_os16_kernel(const NvGemmParams 
       // groups past K inside the last column tile (K % 64 == 32): their scale bytes are layout padding -- masked to 0 (0 x 0, never NaN)
       const int valid = G16 - 4 * (4 * kt + 2 * h + (kq >> 1));
       const uint32_t smask = valid >= 4 ? 0xffffffffu : (valid <= 0 ? 0u : ((1u << (8 * valid)) - 1u));
-      const h2_t sa = __builtin_amdgcn_cvt_scalef32_pk_f16_fp8((da[h] & smask) >> (16 * (kq & 1)), 1.0f, false);   // the two groups of chunk kq + 4 h
+      h2_t sa[MT];
+#pragma unroll
+      for (int t = 0; t < MT; ++t) sa[t] = __builtin_amdgcn_cvt_scalef32_pk_f16_fp8((da[t][h] & smask) >> (16 * (kq & 1)), 1.0f, false);   // the two groups of chunk kq + 4 h
       const h2_t sb = __builtin_amdgcn_cvt_scalef32_pk_f16_fp8((db[h] & smask) >> (16 * (kq & 1)), 1.0f, false);
 #pragma unroll
       for (int d = 0; d < 4; ++d) {
-        const _Float16 xa = sa[d >> 1], xb = sb[d >> 1];
-        const h8_t fa = dq8((uint32_t)ca[h][d], h2_t{xa, xa});
+        const _Float16 xb = sb[d >> 1];
         const h8_t fb = dq8((uint32_t)cb[h][d], h2_t{xb, xb});
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb, fa, acc, 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < MT; ++t) {
+          const _Float16 xa = sa[t][d >> 1];
+          const h8_t fa = dq8((uint32_t)ca[t][h][d], h2_t{xa, xa});
+          acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb, fa, acc[t], 0, 0, 0);
+        }
       }
     }
     fence();
@@ -311,15 +339,16 @@ __global__ __launch_bounds__(512) void gemm_nvf4_os16_kernel(const NvGemmParams 
   __builtin_amdgcn_s_barrier();   // every wave's reads of the stage areas are done: they become the sum's scratch
   fence();
 
-  // ---- cross-wave sum: [wave][row m][16 columns] fp32; a lane holds row m = r16, columns 4 kq .. + 3 (srcA = the B fragment) ------------------------------
-  *(v4f*)(smem + (wave * 16 + r16) * 64 + kq * 16) = acc;
+  // ---- cross-wave sum: [wave][row m][16 columns] fp32; a lane holds row m = 16 t + r16, columns 4 kq .. + 3 (srcA = the B fragment) -----------------------
+#pragma unroll
+  for (int t = 0; t < MT; ++t) *(v4f*)(smem + (wave * C::TM + 16 * t + r16) * 64 + kq * 16) = acc[t];
   __syncthreads();
-  if (tid < 64) {
+  if (tid < 64 * MT) {
     const int rr = tid >> 2, cq = tid & 3;
     v4f t = *(const v4f*)(smem + rr * 64 + cq * 16);
 #pragma unroll
     for (int w = 1; w < NW; ++w) {
-      const v4f s = *(const v4f*)(smem + (w * 16 + rr) * 64 + cq * 16);
+      const v4f s = *(const v4f*)(smem + (w * C::TM + rr) * 64 + cq * 16);
 #pragma unroll
       for (int e = 0; e < 4; ++e) t[e] += s[e];
     }
@@ -337,11 +366,18 @@ __global__ __launch_bounds__(512) void gemm_nvf4_os16_kernel(const NvGemmParams 
 // (not inline: the NVFP4 unit of capi.hip emits it; declared in gemm_nvf4.hip.h for launch_nvf4_gemm)
 // [r6] the wave-owned small-batch kernel (gemm_nvf4_os.hip.h): K <= 2048 one stage per wave, K <= 4096 two, longer K two refilled slots per wave
 hipError_t launch_nvf4_os(NvGemmParams p, hipStream_t s, int tn) {
-  if (tn == 1616) {   // [r6] the decode form: 16x16 tiles on the 16x16x32 MFMA -- one shot up to K = 8192 (four 4.5-KiB stages per wave), four refilled slots per wave beyond
-    p.tiles_m = (p.M + 15) / 16;
+  if (tn == 1616 || tn == 3216) {   // [r6] the decode form: 16x16 (3216: 32x16) tiles on the 16x16x32 MFMA -- one shot while the tile's K extent fits the LDS (K <= 8192 / 4096), refilled slots beyond
+    const bool two = tn == 3216;
+    p.tiles_m = two ? (p.M + 31) / 32 : (p.M + 15) / 16;
     p.tiles_n = (p.N + 15) / 16;
     const int KT = (p.K / 2 + 127) / 128;
     const dim3 grid(p.tiles_m * p.tiles_n), block(512);
+    if (two) {
+      if (KT <= 8) hipLaunchKernelGGL((gemm_nvf4_os16_kernel<NvOs16Cfg<1, 2>>), grid, block, 0, s, p);
+      else if (KT <= 16) hipLaunchKernelGGL((gemm_nvf4_os16_kernel<NvOs16Cfg<2, 2>>), grid, block, 0, s, p);
+      else hipLaunchKernelGGL((gemm_nvf4_os16_kernel<NvOs16Cfg<2, 2>, true>), grid, block, 0, s, p);
+      return hipSuccess;
+    }
     if (KT <= 8) hipLaunchKernelGGL((gemm_nvf4_os16_kernel<NvOs16Cfg<1>>), grid, block, 0, s, p);
     else if (KT <= 16) hipLaunchKernelGGL((gemm_nvf4_os16_kernel<NvOs16Cfg<2>>), grid, block, 0, s, p);
     else if (KT <= 24) hipLaunchKernelGGL((gemm_nvf4_os16_kernel<NvOs16Cfg<3>>), grid, block, 0, s, p);
