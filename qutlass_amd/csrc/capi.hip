@@ -283,6 +283,22 @@ int launch_gemm_os(GemmParams p, hipStream_t s) {
   else hipLaunchKernelGGL((gemm_mx_os_kernel<OsCfg<SMAX, TN, EBITS, TM, AFMT>, RM, true>), grid, block, 0, s, p);   // wave-owned rings of SMAX slots
   return check_launch("gemm_mx_os_kernel");
 }
+// [r6] its decode form (gemm_mx_os16_kernel: 16x16 tiles on the 16x16x128 MFMA, rows in tiles of 16): one shot up to 32 stages (4.5 KiB each), wave-owned rings of 8 beyond
+template <int EBITS = 4, int AFMT = 0>
+int launch_gemm_os16(GemmParams p, hipStream_t s) {
+  p.tiles_m = (int)cdiv(p.M, 16);
+  p.tiles_n = (int)cdiv(p.N, 16);
+  p.ws = nullptr; p.splits = 1; p.ctr = nullptr; p.tag = 0;
+  const int64_t KT = cdiv((int64_t)p.K * EBITS / 8, 128);
+  const dim3 grid(p.tiles_m * p.tiles_n), block(256);
+  if (KT <= 4) hipLaunchKernelGGL((gemm_mx_os16_kernel<Os16Cfg<1, EBITS, AFMT>>), grid, block, 0, s, p);
+  else if (KT <= 8) hipLaunchKernelGGL((gemm_mx_os16_kernel<Os16Cfg<2, EBITS, AFMT>>), grid, block, 0, s, p);
+  else if (KT <= 16) hipLaunchKernelGGL((gemm_mx_os16_kernel<Os16Cfg<4, EBITS, AFMT>>), grid, block, 0, s, p);
+  else if (KT <= 24) hipLaunchKernelGGL((gemm_mx_os16_kernel<Os16Cfg<6, EBITS, AFMT>>), grid, block, 0, s, p);
+  else if (KT <= 32) hipLaunchKernelGGL((gemm_mx_os16_kernel<Os16Cfg<8, EBITS, AFMT>>), grid, block, 0, s, p);
+  else hipLaunchKernelGGL((gemm_mx_os16_kernel<Os16Cfg<8, EBITS, AFMT>, true>), grid, block, 0, s, p);
+  return check_launch("gemm_mx_os16_kernel");
+}
 // Does the one-shot kernel take the shape, and with how many columns per workgroup?  Returns 0 (no), 32 or 16.  32x32 tiles, one per CU at most; 16 columns per
 // workgroup whenever that still leaves one workgroup per CU (N = 4096, M <= 32: 256 workgroups pulling half the bytes each -- 3.34 -> 3.22 us at K = 4096, 7.8 -> 6.9 at
 // K = 14336).  K <= 16 stages of 256: always.  Longer K (wave-owned rings): up to 32 stages when the tiles fill a quarter of the chip, up to 64 stages (K = 16384) when
@@ -327,9 +343,11 @@ inline int os8_plan(int64_t M, int64_t N, int64_t K) {
   if (T32 <= cus) {
     const int v = T16 <= cus ? 569 : 568;
     const int64_t G = T16 <= cus ? T16 : T32;
-    if (KT <= 40) return v;
+    // decode form (16x16 tiles on the 16x16x128 MFMA) where those fit one per CU, up to 64 stages (N = K = 4096, M <= 16: 4.85-4.98 -> 3.65-3.82 us; K = 14336: +2 ... 4 %)
+    const bool d16 = cdiv(M, 16) * cdiv(N, 16) <= cus;
+    if (KT <= 40) return d16 ? 571 : v;
     if (4 * G < 3 * cus) return 0;
-    if (KT <= 64) return v;
+    if (KT <= 64) return d16 ? 571 : v;
     if (KT <= 128) return (M <= 32 || N >= 4096) ? v : 0;
     return (KT <= 256 && M <= 32) ? v : 0;
   }
@@ -529,6 +547,7 @@ int dispatch_variant(int v, const GemmParams& p, hipStream_t s, const char* name
     if (v == 568) return launch_gemm_os<false, 32, 8>(p, s);
     if (v == 569) return launch_gemm_os<false, 16, 8>(p, s);
     if (v == 570) return launch_gemm_os<false, 32, 8, 64>(p, s);
+    if (v == 571) return launch_gemm_os16<8>(p, s);
     if (v == 98) return launch_gemm_hetero<GemmCfg<256, 256, 2, 2, 8, true>, GemmCfg<128, 128, 2, 2, 8, true, 0, 4>, 17>(p, s);
 #if QAMD_BENCH
     if (v == 30) return launch_gemm<GemmCfg<256, 256, 2, 2, 8, true>, 4>(p, s);   // per-tile deep schedule (round 1)
@@ -552,6 +571,7 @@ int dispatch_variant(int v, const GemmParams& p, hipStream_t s, const char* name
     if (v == 568) return launch_gemm_os<false>(p, s);       // [r6] 32x32 tiles on wave-owned K stages (gemm_mx_os.hip.h): one shot up to 16 stages, wave-owned rings beyond
     if (v == 569) return launch_gemm_os<false, 16>(p, s);   // [r6] the same with 16 columns per workgroup
     if (v == 570) return launch_gemm_os<false, 32, 4, 64>(p, s);   // [r6] 64x32 tiles (two m-tiles per stage owner)
+    if (v == 571) return launch_gemm_os16<4>(p, s);                // [r6] decode form: 16x16 tiles on the 16x16x128 MFMA
 #if QAMD_BENCH
     if (v == 99) return launch_gemm_hetero<GemmCfg<256, 256, 2, 2, 4, false>, GemmCfg<128, 128, 2, 2, 4, false, 0, 3>, 17>(p, s);
     // [r6] lab: the other tiles / ring depths of the in-workgroup K-split kernel (563 = 64x32, 564 = 64x64; 565 - 567 = 32x32 with a 4 / 8 / 6-deep ring)
@@ -639,6 +659,7 @@ int dispatch_variant_a5(int v, const GemmParams& p, hipStream_t s, const char* n
     case 568: return launch_gemm_os<false, 32, 8, 32, 1>(p, s);   // [r6] small batches on wave-owned K stages, e5m2 A
     case 569: return launch_gemm_os<false, 16, 8, 32, 1>(p, s);
     case 570: return launch_gemm_os<false, 32, 8, 64, 1>(p, s);
+    case 571: return launch_gemm_os16<8, 1>(p, s);
   }
   return fail(QAMD_ERR_INVALID, "%s: gemm_variant %d has no e5m2-operand instantiation", name, v);
 }
@@ -794,14 +815,19 @@ SmallPlan plan_small(int64_t M, int64_t N, int64_t K, bool may_split = true) {
 //     (N = 4096, K = 14336: M <= 16 8.1-9.1 us split against 9.2-9.4; M = 64 11.4 against 9.8).
 // Where it applies it is 11 ... 30 % faster (N = K = 4096: M <= 64 4.9-5.3 -> 4.1-4.5 us; 8192^2: M <= 32 8.8-11.1 -> 7.4-7.8 us), M = 1 ... 8 included (the LDS-free
 // split-K kernel: 4.55-4.92 us at N = K = 4096).  32x64 tiles: only where 32x32 tiles just overflow the chip and 32x64 nearly fill it (N = 14336: -6 %).
-// Returns the variant (568 / 569 / 570 / 561 / 562) or 0.
+// Returns the variant (568 / 569 / 570 / 571 / 561 / 562) or 0.
 inline int ks_plan(int64_t M, int64_t N, int64_t K) {
   const int64_t cus = chip_cus(), KT = cdiv(K, 256);
   const int64_t T32 = cdiv(M, 32) * cdiv(N, 32);
   // [r6] K <= 4096: the tile's whole K extent fits the LDS -- the one-shot kernel (gemm_mx_os.hip.h), no ring and no barrier in the K walk: N = K = 4096, M = 1 ... 64
   // 4.05-4.39 -> 3.34-3.67 us, N = K = 2048 3.15-3.26 -> 2.62-2.77 (profiles/calib_os_r6q.txt); its wave-owned-ring form for longer K and 16 columns per workgroup where os_plan says so
   // (4096 x 8192, M <= 32: 5.8-7.1 -> 5.5-5.7 us); past one tile per CU the ring plans below keep the shape
-  if (const int tn = os_plan(M, N, K)) return tn == 16 ? 569 : 568;
+  if (const int tn = os_plan(M, N, K)) {
+    // [r6] decode form (gemm_mx_os16_kernel, 16x16 tiles on the 16x16x128 MFMA) wherever those fit one per CU: a third fewer bytes through each CU's LDS-DMA path
+    // (N = K = 4096, M <= 16: 3.25-3.31 -> 2.86-2.92 us; K = 8192 5.0-5.2 -> 3.7-4.1; K = 14336 6.8-7.0 -> 6.1-6.5; two per CU (N = 8192) lose 9 %; profiles/calib_os16_r7.txt)
+    if (cdiv(M, 16) * cdiv(N, 16) <= cus) return 571;
+    return tn == 16 ? 569 : 568;
+  }
   if (os64_plan(M, N, K)) return 570;   // [r6] 64x32 tiles on wave-owned K stages where 32x32 tiles overflow the chip
   if (T32 <= cus && (KT <= 24 || (2 * T32 > cus && KT <= 64))) return 561;   // (K > 16384 was not calibrated, and a split-K plan on larger tiles moves fewer bytes per CU there)
   const int64_t T64 = cdiv(M, 32) * cdiv(N, 64);

@@ -236,4 +236,159 @@ __global__ __launch_bounds__(256) void gemm_mx_os_kernel(const GemmParams p) {
   }
 }
 
+// ---- [r6, third session] decode form: a 16x16 output tile per workgroup on v_mfma_scale_f32_16x16x128_f8f6f4 ------------------------------------------------
+// At M <= 16 half of the 32-row A tile above is rows that do not exist, and they are fetched all the same (they fall off the descriptor as zeros but still take their
+// LDS-DMA pieces and LDS space): a workgroup of the 32x16 form pulls 48 rows x K / 2 bytes through its CU's LDS-DMA path.  The 16x16x128 MFMA takes 32 K elements per lane
+// (lane l = row l & 15, K-block kq = l >> 4 of the four blocks of an MFMA), so a 16x16 tile needs 32 rows per stage: a third fewer bytes per CU, and a 4.5-KiB stage
+// (one shot up to K = 8192).  Same wave-owned K stages: wave w owns stages w, w + 4, ...; no barrier in the K walk.
+//   fp4: a stage is two MFMAs; MFMA h takes chunk 4 h + kq from lane (r, kq); its scale byte is byte kq of the row's dword of column tile 2 kt + h -- the dword shifted
+//        right by 8 kq, op_sel 0.
+//   fp8: a stage is ONE MFMA; the 8-bit fragment is "split" as in the 32x32x64 form: registers 0-3 = chunk kq, registers 4-7 = chunk 4 + kq, and the scale byte of K-block b
+//        is taken from lane group b -- so lane (r, kq) supplies byte kq of the row's dword of column tile kt (again the dword shifted by 8 kq).
+// One dword scale piece per operand and stage: lane l fetches the dword of row l & 15 in column tile 2 kt + ((l >> 4) & 1) (fp8: kt).
+template <int SPW_, int EBITS_ = 4, int AFMT_ = 0>
+struct Os16Cfg {
+  static constexpr int TM = 16, TN = 16, EBITS = EBITS_, AFMT = AFMT_, ROWB = 128, SPW = SPW_, KTMAX = 4 * SPW_;
+  static constexpr int OFF_B = TM * ROWB, OFF_S = (TM + TN) * ROWB, STAGE = OFF_S + 512;   // + one 256-byte scale piece per operand
+  static constexpr int LPS = 2 + 2 + 2;
+  static constexpr int RED = 4 * 1024;
+  static constexpr int LDS_BYTES = KTMAX * STAGE > RED ? KTMAX * STAGE : RED;
+  static_assert(EBITS == 4 || EBITS == 8, "element width");
+  static_assert(AFMT == 0 || (AFMT == 1 && EBITS == 8), "A format: 0 = e2m1 / e4m3, 1 = e5m2 (MXFP8 only)");
+  static_assert(SPW >= 1 && SPW * LPS <= 63, "vmcnt immediate");
+  static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
+};
+
+template <class C, bool RING = false>
+__global__ __launch_bounds__(256) void gemm_mx_os16_kernel(const GemmParams p) {
+  constexpr int SPW = C::SPW, LPS = C::LPS, E8 = C::EBITS == 8;
+  __shared__ __attribute__((aligned(16))) char smem[C::LDS_BYTES];
+  asm volatile("" :: "s"(p.A), "s"(p.D), "s"(p.K), "s"(p.b_bytes), "s"(p.alpha));   // all scalar argument loads in one round
+  const float alpha = *p.alpha;
+  const int tid = threadIdx.x, lane = tid & 63, wave = uniform(tid >> 6), r16 = lane & 15, kq = lane >> 4;
+  const int nb = p.tiles_m * p.tiles_n;
+  const int b2 = xcd_remap((int)blockIdx.x, nb);
+  const int m0 = uniform((b2 % p.tiles_m) * C::TM), n0 = uniform((b2 / p.tiles_m) * C::TN);
+  const int rowbytes = E8 ? p.K : p.K >> 1, KT = (rowbytes + C::ROWB - 1) / C::ROWB, CB = (p.K / 32 + 3) >> 2;
+  const int tailbytes = rowbytes - (KT - 1) * C::ROWB;
+
+  const uint32_t a_off = (uint32_t)m0 * rowbytes, b_off = (uint32_t)n0 * rowbytes;
+  const __amdgpu_buffer_rsrc_t rA = make_rsrc(p.A + a_off, p.a_bytes - a_off), rB = make_rsrc(p.B + b_off, p.b_bytes - b_off);
+  int vP[2], chP[2];
+#pragma unroll
+  for (int par = 0; par < 2; ++par) {
+    chP[par] = (lane & 7) ^ (((lane >> 4) + 4 * par) & 7);
+    vP[par] = (lane >> 3) * rowbytes + (chP[par] << 4);
+  }
+  const int rstep = 8 * rowbytes;
+  const uint32_t sa_off = (uint32_t)(m0 >> 7) * CB * 512, sb_off = (uint32_t)(n0 >> 7) * CB * 512;
+  const __amdgpu_buffer_rsrc_t rSA = make_rsrc(p.SFA + sa_off, p.sfa_bytes - sa_off), rSB = make_rsrc(p.SFB + sb_off, p.sfb_bytes - sb_off);
+  const int rowA = (m0 & 127) + r16, rowB = (n0 & 127) + r16;   // rows of the 128-row scale tiles
+  const int ctl = E8 ? 0 : (kq & 1);                            // column tile of the stage this lane fetches
+  const int vSA = ctl * 512 + (rowA & 31) * 16 + (rowA >> 5) * 4, vSB = ctl * 512 + (rowB & 31) * 16 + (rowB >> 5) * 4;
+  constexpr int SCW = E8 ? 512 : 1024;   // scale bytes per stage and 128-row tile
+
+  auto issue = [&](const int kt, const int slot) __attribute__((always_inline)) {   // stage kt into slot `slot` of this wave (kt >= KT: every piece out of range -> zeros)
+    char* st = smem + (wave * SPW + slot) * C::STAGE;
+    int tail = (kt == KT - 1) ? tailbytes : C::ROWB;
+    int oob = (kt < KT) ? 0 : -1;
+    asm volatile("" : "+v"(tail), "+v"(oob));
+    const int soff = kt * C::ROWB;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const bool isB = t >= 2;
+      const int qq = t & 1;
+      const int o = oob | ((chP[qq] << 4) < tail ? 0 : -1);
+      const int v = ((vP[qq] + qq * rstep) & ~o) | ((int)0x80000000 & o);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(isB ? rB : rA, (lds_ptr_t)(st + (isB ? C::OFF_B : 0) + qq * 1024), 16, v, soff, 0, 0);
+    }
+    const int os = (kt < KT && (E8 ? kt : 2 * kt + ctl) < CB) ? 0 : -1;   // a column tile past the operand's last one would read the next row tile's bytes
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rSA, (lds_ptr_t)(st + C::OFF_S), 4, (vSA & ~os) | ((int)0x80000000 & os), kt * SCW, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rSB, (lds_ptr_t)(st + C::OFF_S + 256), 4, (vSB & ~os) | ((int)0x80000000 & os), kt * SCW, 0, 0);
+  };
+
+#pragma unroll
+  for (int j = 0; j < SPW; ++j) issue(wave + 4 * j, j);
+
+  const int sw = (r16 >> 1) & 7;
+  v4f acc = {0.f, 0.f, 0.f, 0.f};
+  auto fence = [&]() __attribute__((always_inline)) { __builtin_amdgcn_sched_barrier(0); };
+
+  auto consume = [&](const int u, const int kt_next) __attribute__((always_inline)) {
+    const char* st = smem + (wave * SPW + u) * C::STAGE;
+    v4i fa[2], fb[2];
+    int sa[2], sb[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int off = r16 * C::ROWB + (((4 * h + kq) ^ sw) << 4);
+      fa[h] = *(const v4i*)(st + off);
+      fb[h] = *(const v4i*)(st + C::OFF_B + off);
+      // the lane fetched column tile (kq & 1) into slot lane * 4: row r16 of column tile h sits at (h * 16 + r16) * 4 (lanes 32-63 hold a second copy)
+      sa[h] = *(const int*)(st + C::OFF_S + ((E8 ? 0 : h) * 16 + r16) * 4);
+      sb[h] = *(const int*)(st + C::OFF_S + 256 + ((E8 ? 0 : h) * 16 + r16) * 4);
+    }
+    fence();
+    if constexpr (RING) {
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[0]), "+v"(fa[1]), "+v"(fb[0]), "+v"(fb[1]), "+v"(sa[0]), "+v"(sa[1]), "+v"(sb[0]), "+v"(sb[1]) :: "memory");   // the slot is free
+      issue(kt_next, u);
+      fence();
+    }
+    constexpr int FMT = E8 ? 0 : 4, FMTA = E8 ? C::AFMT : 4;   // cbsz = format of srcA (the B fragment), blgp = format of srcB (the A fragment)
+    if constexpr (E8) {
+      const v8i A8 = {fa[0][0], fa[0][1], fa[0][2], fa[0][3], fa[1][0], fa[1][1], fa[1][2], fa[1][3]};
+      const v8i B8 = {fb[0][0], fb[0][1], fb[0][2], fb[0][3], fb[1][0], fb[1][1], fb[1][2], fb[1][3]};
+      acc = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(B8, A8, acc, FMT, FMTA, 0, (int)((unsigned)sb[0] >> (8 * kq)), 0, (int)((unsigned)sa[0] >> (8 * kq)));
+    } else {
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const v8i A8 = {fa[h][0], fa[h][1], fa[h][2], fa[h][3], 0, 0, 0, 0}, B8 = {fb[h][0], fb[h][1], fb[h][2], fb[h][3], 0, 0, 0, 0};
+        acc = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(B8, A8, acc, FMT, FMTA, 0, (int)((unsigned)sb[h] >> (8 * kq)), 0, (int)((unsigned)sa[h] >> (8 * kq)));
+      }
+    }
+    fence();
+  };
+  if constexpr (!RING) {
+    static_for<0, SPW>([&](auto jc) __attribute__((always_inline)) {
+      constexpr int j = decltype(jc)::value;
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"((SPW - 1 - j) * LPS) : "memory");
+      fence();
+      consume(j, 0);
+    });
+  } else {
+    for (int kt = wave; kt < KT; kt += 4 * SPW) {
+      static_for<0, SPW>([&](auto uc) __attribute__((always_inline)) {
+        constexpr int u = decltype(uc)::value;
+        if (u == 0 || kt + 4 * u < KT) {
+          asm volatile("s_waitcnt vmcnt(%0)" ::"n"((SPW - 1) * LPS) : "memory");
+          fence();
+          consume(u, kt + 4 * u + 4 * SPW);
+        }
+      });
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();   // every wave's reads of the stage areas are done: they become the sum's scratch
+  fence();
+
+  // ---- cross-wave sum: [wave][row m][16 columns] fp32; a lane holds row m = r16, columns 4 kq .. + 3 (srcA = the B fragment) ------------------------------
+  *(v4f*)(smem + (wave * 16 + r16) * 64 + kq * 16) = acc;
+  __syncthreads();
+  if (tid < 64) {
+    const int rr = tid >> 2, cq = tid & 3;
+    v4f s[4];
+#pragma unroll
+    for (int w = 0; w < 4; ++w) s[w] = *(const v4f*)(smem + (w * 16 + rr) * 64 + cq * 16);
+    v4f t;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) t[e] = ((s[0][e] + s[1][e]) + s[2][e]) + s[3][e];
+    const int row = m0 + rr, col = n0 + 4 * cq;
+    if (row < p.M && col < p.N) {
+      v2i o;
+      o[0] = (int)pack_bf16x2(t[0] * alpha, t[1] * alpha);
+      o[1] = (int)pack_bf16x2(t[2] * alpha, t[3] * alpha);
+      *(v2i*)(p.D + (size_t)row * p.ldd + col) = o;
+    }
+  }
+}
+
 }  // namespace qamd

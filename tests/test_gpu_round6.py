@@ -267,7 +267,7 @@ def _mx_operands_exact(m, n, k, seed):
 KS_SHAPES = [(1, 8, 128), (9, 40, 384), (33, 104, 1408), (64, 264, 4096), (100, 72, 640), (31, 4096, 4096), (64, 2048, 8192), (130, 520, 256)]
 
 
-@pytest.mark.parametrize("variant", [561, 562, 563, 564, 565, 566, 567, 568, 569, 570])
+@pytest.mark.parametrize("variant", [561, 562, 563, 564, 565, 566, 567, 568, 569, 570, 571])   # (571: the 16x16 decode form on the 16x16x128 MFMA)
 @pytest.mark.parametrize("m,n,k", KS_SHAPES + [(5, 72, 1024), (40, 200, 2944), (64, 96, 3072), (9, 136, 4224), (33, 72, 11008), (3, 40, 14336), (64, 64, 4352),
                                                (128, 4096, 4096), (97, 136, 3328), (160, 72, 5376)])   # (568: one shot up to K = 4096, wave-owned rings beyond; 570: 64x32 tiles, one shot up to K = 3072)
 def test_ks_kernel_against_the_oracle(variant, m, n, k):
@@ -414,7 +414,7 @@ def _exact_fp8_operands(m, n, k, seed, e5m2_a=False):
 
 
 @pytest.mark.parametrize("a5", [False, True])
-@pytest.mark.parametrize("variant", [568, 569, 570, 0])
+@pytest.mark.parametrize("variant", [568, 569, 570, 571, 0])
 @pytest.mark.parametrize("m,n,k", MXF8_OS_SHAPES)
 def test_mxf8_wave_owned_kernel_exact_against_the_oracle(variant, m, n, k, a5):
     from qutlass_amd.utils import to_blocked
@@ -431,7 +431,7 @@ def test_mxf8_wave_owned_kernel_exact_against_the_oracle(variant, m, n, k, a5):
     assert not bad.any(), f"{int(bad.sum())} of {bad.size} outputs differ, first at {np.argwhere(bad)[0].tolist()}"
 
 
-@pytest.mark.parametrize("variant", [568, 569, 570])
+@pytest.mark.parametrize("variant", [568, 569, 570, 571])
 @pytest.mark.parametrize("m,n,k", [(33, 104, 1440), (31, 264, 4096), (128, 520, 4096), (9, 136, 4224)])
 def test_mxf8_wave_owned_kernel_on_quantised_gaussians(variant, m, n, k):
     from qutlass_amd.utils import to_blocked
