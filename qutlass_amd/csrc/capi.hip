@@ -284,19 +284,19 @@ int launch_gemm_os(GemmParams p, hipStream_t s) {
   return check_launch("gemm_mx_os_kernel");
 }
 // [r6] its decode form (gemm_mx_os16_kernel: 16x16 tiles on the 16x16x128 MFMA, rows in tiles of 16): one shot up to 32 stages (4.5 KiB each), wave-owned rings of 8 beyond
-template <int EBITS = 4, int AFMT = 0>
+template <int EBITS = 4, int AFMT = 0, bool RM = false>
 int launch_gemm_os16(GemmParams p, hipStream_t s) {
   p.tiles_m = (int)cdiv(p.M, 16);
   p.tiles_n = (int)cdiv(p.N, 16);
   p.ws = nullptr; p.splits = 1; p.ctr = nullptr; p.tag = 0;
   const int64_t KT = cdiv((int64_t)p.K * EBITS / 8, 128);
   const dim3 grid(p.tiles_m * p.tiles_n), block(256);
-  if (KT <= 4) hipLaunchKernelGGL((gemm_mx_os16_kernel<Os16Cfg<1, EBITS, AFMT>>), grid, block, 0, s, p);
-  else if (KT <= 8) hipLaunchKernelGGL((gemm_mx_os16_kernel<Os16Cfg<2, EBITS, AFMT>>), grid, block, 0, s, p);
-  else if (KT <= 16) hipLaunchKernelGGL((gemm_mx_os16_kernel<Os16Cfg<4, EBITS, AFMT>>), grid, block, 0, s, p);
-  else if (KT <= 24) hipLaunchKernelGGL((gemm_mx_os16_kernel<Os16Cfg<6, EBITS, AFMT>>), grid, block, 0, s, p);
-  else if (KT <= 32) hipLaunchKernelGGL((gemm_mx_os16_kernel<Os16Cfg<8, EBITS, AFMT>>), grid, block, 0, s, p);
-  else hipLaunchKernelGGL((gemm_mx_os16_kernel<Os16Cfg<8, EBITS, AFMT>, true>), grid, block, 0, s, p);
+  if (KT <= 4) hipLaunchKernelGGL((gemm_mx_os16_kernel<Os16Cfg<1, EBITS, AFMT>, false, RM>), grid, block, 0, s, p);
+  else if (KT <= 8) hipLaunchKernelGGL((gemm_mx_os16_kernel<Os16Cfg<2, EBITS, AFMT>, false, RM>), grid, block, 0, s, p);
+  else if (KT <= 16) hipLaunchKernelGGL((gemm_mx_os16_kernel<Os16Cfg<4, EBITS, AFMT>, false, RM>), grid, block, 0, s, p);
+  else if (KT <= 24) hipLaunchKernelGGL((gemm_mx_os16_kernel<Os16Cfg<6, EBITS, AFMT>, false, RM>), grid, block, 0, s, p);
+  else if (KT <= 32) hipLaunchKernelGGL((gemm_mx_os16_kernel<Os16Cfg<8, EBITS, AFMT>, false, RM>), grid, block, 0, s, p);
+  else hipLaunchKernelGGL((gemm_mx_os16_kernel<Os16Cfg<8, EBITS, AFMT>, true, RM>), grid, block, 0, s, p);
   return check_launch("gemm_mx_os16_kernel");
 }
 // Does the one-shot kernel take the shape, and with how many columns per workgroup?  Returns 0 (no), 32 or 16.  32x32 tiles, one per CU at most; 16 columns per
@@ -1258,6 +1258,16 @@ static int ada_impl(const void* A, const void* B, const void* A_sf, const void* 
   // [r6] K <= 4096 and at most one 32x32 tile per CU: the one-shot kernel with row-major scale pieces (gemm_mx_os.hip.h; "gemm_variant" 568 forces it where it fits)
   const int os_tn = forced == 0 ? os_plan(M, N, K, true) : 0;
   const bool os16 = forced == 569 || os_tn == 16;   // 16 columns per workgroup
+  // [r6] ... its decode form (16x16 tiles on the 16x16x128 MFMA) where those fit one per CU (matmul_mxf4_bf16_tn's rule, ks_plan)
+  if ((forced == 571 && cdiv(M, 16) * cdiv(N, 16) <= 4 * cus) || (os_tn != 0 && cdiv(M, 16) * cdiv(N, 16) <= cus)) {
+    GemmParams p;
+    p.A = (const uint8_t*)A; p.B = (const uint8_t*)B; p.SFA = (const uint8_t*)A_sf; p.SFB = (const uint8_t*)B_sf;
+    p.alpha = alpha; p.D = (uint16_t*)D; p.M = (int)M; p.N = (int)N; p.K = (int)K; p.ldd = (int)ldd;
+    p.a_bytes = (uint32_t)(M * rowbytes); p.b_bytes = (uint32_t)(N * rowbytes);
+    p.sfa_bytes = (uint32_t)(M * KB); p.sfb_bytes = (uint32_t)(N * KB);
+    p.pp_shift = opt_pp_shift(); p.pp_flags = opt_pp_flags(); p.dbg = opt_dbg();
+    return launch_gemm_os16<4, 0, true>(p, (hipStream_t)stream);
+  }
   const bool os64 = forced == 570 || (forced == 0 && os_tn == 0 && os64_plan(M, N, K, true));   // 64x32 tiles where the 32-row tiles overflow the chip (os64_plan)
   const bool oneshot = (forced >= 568 && forced <= 570) ? cdiv(M, 32) * cdiv(N, 32) <= 4 * cus : (os_tn != 0 || os64);
   if (ring || oneshot) {

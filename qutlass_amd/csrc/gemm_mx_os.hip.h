@@ -259,9 +259,11 @@ struct Os16Cfg {
   static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
 };
 
-template <class C, bool RING = false>
+// RM: row-major scale operands (rows, K / 32) -- matmul_ada_mxf4_bf16_tn; the lane's dword (K-blocks 4 c .. 4 c + 3 of its row) holds the same four bytes either way
+template <class C, bool RING = false, bool RM = false>
 __global__ __launch_bounds__(256) void gemm_mx_os16_kernel(const GemmParams p) {
   constexpr int SPW = C::SPW, LPS = C::LPS, E8 = C::EBITS == 8;
+  static_assert(!(RM && E8), "row-major scales: matmul_ada_mxf4_bf16_tn only");
   __shared__ __attribute__((aligned(16))) char smem[C::LDS_BYTES];
   asm volatile("" :: "s"(p.A), "s"(p.D), "s"(p.K), "s"(p.b_bytes), "s"(p.alpha));   // all scalar argument loads in one round
   const float alpha = *p.alpha;
@@ -281,12 +283,13 @@ __global__ __launch_bounds__(256) void gemm_mx_os16_kernel(const GemmParams p) {
     vP[par] = (lane >> 3) * rowbytes + (chP[par] << 4);
   }
   const int rstep = 8 * rowbytes;
-  const uint32_t sa_off = (uint32_t)(m0 >> 7) * CB * 512, sb_off = (uint32_t)(n0 >> 7) * CB * 512;
+  const int KB = p.K >> 5;
+  const uint32_t sa_off = RM ? (uint32_t)m0 * KB : (uint32_t)(m0 >> 7) * CB * 512, sb_off = RM ? (uint32_t)n0 * KB : (uint32_t)(n0 >> 7) * CB * 512;
   const __amdgpu_buffer_rsrc_t rSA = make_rsrc(p.SFA + sa_off, p.sfa_bytes - sa_off), rSB = make_rsrc(p.SFB + sb_off, p.sfb_bytes - sb_off);
   const int rowA = (m0 & 127) + r16, rowB = (n0 & 127) + r16;   // rows of the 128-row scale tiles
   const int ctl = E8 ? 0 : (kq & 1);                            // column tile of the stage this lane fetches
-  const int vSA = ctl * 512 + (rowA & 31) * 16 + (rowA >> 5) * 4, vSB = ctl * 512 + (rowB & 31) * 16 + (rowB >> 5) * 4;
-  constexpr int SCW = E8 ? 512 : 1024;   // scale bytes per stage and 128-row tile
+  const int vSA = RM ? r16 * KB + 4 * ctl : ctl * 512 + (rowA & 31) * 16 + (rowA >> 5) * 4, vSB = RM ? r16 * KB + 4 * ctl : ctl * 512 + (rowB & 31) * 16 + (rowB >> 5) * 4;
+  constexpr int SCW = RM ? 8 : E8 ? 512 : 1024;   // scale bytes per stage and 128-row tile (RM: per row)
 
   auto issue = [&](const int kt, const int slot) __attribute__((always_inline)) {   // stage kt into slot `slot` of this wave (kt >= KT: every piece out of range -> zeros)
     char* st = smem + (wave * SPW + slot) * C::STAGE;
@@ -302,7 +305,7 @@ __global__ __launch_bounds__(256) void gemm_mx_os16_kernel(const GemmParams p) {
       const int v = ((vP[qq] + qq * rstep) & ~o) | ((int)0x80000000 & o);
       __builtin_amdgcn_raw_ptr_buffer_load_lds(isB ? rB : rA, (lds_ptr_t)(st + (isB ? C::OFF_B : 0) + qq * 1024), 16, v, soff, 0, 0);
     }
-    const int os = (kt < KT && (E8 ? kt : 2 * kt + ctl) < CB) ? 0 : -1;   // a column tile past the operand's last one would read the next row tile's bytes
+    const int os = (kt < KT && (RM ? 8 * kt + 4 * ctl < KB : (E8 ? kt : 2 * kt + ctl) < CB)) ? 0 : -1;   // a column tile past the operand's last one would read the next row tile's bytes (RM: the next row's)
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rSA, (lds_ptr_t)(st + C::OFF_S), 4, (vSA & ~os) | ((int)0x80000000 & os), kt * SCW, 0, 0);
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rSB, (lds_ptr_t)(st + C::OFF_S + 256), 4, (vSB & ~os) | ((int)0x80000000 & os), kt * SCW, 0, 0);
   };

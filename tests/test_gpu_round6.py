@@ -301,7 +301,7 @@ def test_one_shot_kernel_with_row_major_scales_against_the_oracle(q, m, n, k):
     assert np.array_equal(_np(q.matmul_mxf4_bf16_tn(a, b, tsa.view(e8), tsb.view(e8), alpha)), ref)
     with lab.forced(gemm_variant=70):   # the ring kernel with row-major scale fetch, the plan before this kernel
         assert np.array_equal(_np(lab.matmul_ada_mxf4_bf16_tn(a, b, sa, sb, alpha)), ref)
-    for v in (568, 569, 570):   # ... and the kernel itself (32 / 16 columns per workgroup, 64-row tiles) where the product rule does not send the shape to it
+    for v in (568, 569, 570, 571):   # ... and the kernel itself (32 / 16 columns per workgroup, 64-row tiles, the 16x16 decode form) where the product rule does not send the shape to it
         with lab.forced(gemm_variant=v):
             assert np.array_equal(_np(lab.matmul_ada_mxf4_bf16_tn(a, b, sa, sb, alpha)), ref), v
 
