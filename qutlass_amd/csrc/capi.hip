@@ -283,21 +283,62 @@ int launch_gemm_os(GemmParams p, hipStream_t s) {
   else hipLaunchKernelGGL((gemm_mx_os_kernel<OsCfg<SMAX, TN, EBITS, TM, AFMT>, RM, true>), grid, block, 0, s, p);   // wave-owned rings of SMAX slots
   return check_launch("gemm_mx_os_kernel");
 }
-// [r6] its decode form (gemm_mx_os16_kernel: 16x16 tiles on the 16x16x128 MFMA, rows in tiles of 16): one shot up to 32 stages (4.5 KiB each), wave-owned rings of 8 beyond
-template <int EBITS = 4, int AFMT = 0, bool RM = false>
+// [r6] its decode form (gemm_mx_os16_kernel: 16 x TN tiles on the 16x16x128 MFMA, rows in tiles of 16): one shot while the tile's K extent fits the LDS (SMAX slots per wave),
+// wave-owned rings of SMAX slots beyond
+template <int EBITS = 4, int AFMT = 0, bool RM = false, int TN = 16>
 int launch_gemm_os16(GemmParams p, hipStream_t s) {
   p.tiles_m = (int)cdiv(p.M, 16);
-  p.tiles_n = (int)cdiv(p.N, 16);
+  p.tiles_n = (int)cdiv(p.N, TN);
   p.ws = nullptr; p.splits = 1; p.ctr = nullptr; p.tag = 0;
   const int64_t KT = cdiv((int64_t)p.K * EBITS / 8, 128);
   const dim3 grid(p.tiles_m * p.tiles_n), block(256);
-  if (KT <= 4) hipLaunchKernelGGL((gemm_mx_os16_kernel<Os16Cfg<1, EBITS, AFMT>, false, RM>), grid, block, 0, s, p);
-  else if (KT <= 8) hipLaunchKernelGGL((gemm_mx_os16_kernel<Os16Cfg<2, EBITS, AFMT>, false, RM>), grid, block, 0, s, p);
-  else if (KT <= 16) hipLaunchKernelGGL((gemm_mx_os16_kernel<Os16Cfg<4, EBITS, AFMT>, false, RM>), grid, block, 0, s, p);
-  else if (KT <= 24) hipLaunchKernelGGL((gemm_mx_os16_kernel<Os16Cfg<6, EBITS, AFMT>, false, RM>), grid, block, 0, s, p);
-  else if (KT <= 32) hipLaunchKernelGGL((gemm_mx_os16_kernel<Os16Cfg<8, EBITS, AFMT>, false, RM>), grid, block, 0, s, p);
-  else hipLaunchKernelGGL((gemm_mx_os16_kernel<Os16Cfg<8, EBITS, AFMT>, true, RM>), grid, block, 0, s, p);
+  constexpr int STAGE = Os16Cfg<1, EBITS, AFMT, TN>::STAGE;
+  constexpr int SFIT = 160 * 1024 / (4 * STAGE), SMAX = SFIT >= 8 ? 8 : SFIT >= 4 ? 4 : SFIT;   // slots per wave that fit the LDS: 8 (TN = 16), 4 (32 ... 56), 3 (64)
+  static_assert(SMAX >= 3, "LDS budget");
+  if (KT <= 4) hipLaunchKernelGGL((gemm_mx_os16_kernel<Os16Cfg<1, EBITS, AFMT, TN>, false, RM>), grid, block, 0, s, p);
+  else if (KT <= 8) hipLaunchKernelGGL((gemm_mx_os16_kernel<Os16Cfg<2, EBITS, AFMT, TN>, false, RM>), grid, block, 0, s, p);
+  else if (KT <= 16 && SMAX >= 4) hipLaunchKernelGGL((gemm_mx_os16_kernel<Os16Cfg<(SMAX >= 4 ? 4 : SMAX), EBITS, AFMT, TN>, false, RM>), grid, block, 0, s, p);
+  else if (KT <= 4 * SMAX) hipLaunchKernelGGL((gemm_mx_os16_kernel<Os16Cfg<SMAX, EBITS, AFMT, TN>, false, RM>), grid, block, 0, s, p);
+  else hipLaunchKernelGGL((gemm_mx_os16_kernel<Os16Cfg<SMAX, EBITS, AFMT, TN>, true, RM>), grid, block, 0, s, p);
   return check_launch("gemm_mx_os16_kernel");
+}
+// columns per workgroup of the decode form for M <= 16: the narrowest of 16 / 32 / 48 / 56 / 64 that leaves at most one workgroup per CU; 0 = none does
+inline int os16_tn(int64_t N) {
+  const int64_t cus = chip_cus();
+  for (int tn : {16, 32, 48, 56, 64})
+    if (cdiv(N, tn) <= cus) return tn;
+  return 0;
+}
+// [r6] M <= 16 against a weight too wide for 16-column workgroups: the decode form with 32 / 48 / 56 / 64 columns per workgroup (variants 572 ... 575) where it was measured ahead
+// (tools/calib_os2.py, profiles/calib_os16w_r7.txt; K in stages of 128 bytes per row).  MXFP4: N = 11008 / 12288 x K = 4096 5.0-5.2 -> 3.8-4.0 us (48 columns: 64 rows per
+// stage where the 32x64 K-split ring kernel fetched 96 and met at a barrier per stage), 14336 x 4096 5.9-6.1 -> 4.6-4.9 (56 columns = exactly 256 workgroups), 12288 x 5120
+// 7.5-8.0 -> 5.6-6.1, 16384 x 4096 -7 %; N = 5120 ... 8192 (32 columns against the 32x32 form's 64 rows per stage) -3 ... -7 % at K = 3072 ... 8192, +3 % at K = 2048.
+// Past the one-shot range the wider forms lose (14336 x 8192: +3 %).  MXFP8: 32 columns -6 ... -12 % at K = 2048 ... 8192, 48 columns -9 % at 11008 x 4096; 14336 x 4096 loses.
+// Returns the variant or 0.
+inline int os16_wide_plan(int ebits, int64_t N, int64_t K) {
+  const int tn = os16_tn(N);
+  const int64_t KT = cdiv(K * ebits / 8, 128);
+  if (ebits == 4) {
+    if (tn == 32) return (KT >= 12 && KT <= 32) ? 572 : 0;
+    if (tn == 48) return (KT >= 8 && KT <= 24) ? 573 : 0;
+    if (tn == 56) return (KT >= 8 && KT <= 16) ? 574 : 0;
+    if (tn == 64) return (KT >= 8 && KT <= 16) ? 575 : 0;
+    return 0;
+  }
+  if (tn == 32) return (KT >= 16 && KT <= 64) ? 572 : 0;
+  if (tn == 48) return (KT >= 16 && KT <= 32) ? 573 : 0;
+  return 0;
+}
+template <int EBITS, int AFMT, bool RM>
+int launch_gemm_os16_tn(int tn, const GemmParams& p, hipStream_t s) {
+  switch (tn) {
+    case 16: return launch_gemm_os16<EBITS, AFMT, RM, 16>(p, s);
+    case 32: return launch_gemm_os16<EBITS, AFMT, RM, 32>(p, s);
+    case 48: return launch_gemm_os16<EBITS, AFMT, RM, 48>(p, s);
+    case 56: return launch_gemm_os16<EBITS, AFMT, RM, 56>(p, s);
+    case 64: return launch_gemm_os16<EBITS, AFMT, RM, 64>(p, s);
+  }
+  return fail(QAMD_ERR_INVALID, "gemm_mx_os16: no column tile of %d", tn);
 }
 // Does the one-shot kernel take the shape, and with how many columns per workgroup?  Returns 0 (no), 32 or 16.  32x32 tiles, one per CU at most; 16 columns per
 // workgroup whenever that still leaves one workgroup per CU (N = 4096, M <= 32: 256 workgroups pulling half the bytes each -- 3.34 -> 3.22 us at K = 4096, 7.8 -> 6.9 at
@@ -340,6 +381,9 @@ inline bool os64_plan(int64_t M, int64_t N, int64_t K, bool ada = false) {
 //     K <= 2048 ties, K = 28672 loses 13 %).
 inline int os8_plan(int64_t M, int64_t N, int64_t K) {
   const int64_t cus = chip_cus(), T32 = cdiv(M, 32) * cdiv(N, 32), T16 = cdiv(M, 32) * cdiv(N, 16), T64 = cdiv(M, 64) * cdiv(N, 32), KT = cdiv(K, 128);
+  if (M <= 16) {   // the decode form with 32 / 48 columns per workgroup
+    if (const int v = os16_wide_plan(8, N, K)) return v;
+  }
   if (T32 <= cus) {
     const int v = T16 <= cus ? 569 : 568;
     const int64_t G = T16 <= cus ? T16 : T32;
@@ -547,7 +591,7 @@ int dispatch_variant(int v, const GemmParams& p, hipStream_t s, const char* name
     if (v == 568) return launch_gemm_os<false, 32, 8>(p, s);
     if (v == 569) return launch_gemm_os<false, 16, 8>(p, s);
     if (v == 570) return launch_gemm_os<false, 32, 8, 64>(p, s);
-    if (v == 571) return launch_gemm_os16<8>(p, s);
+    if (v >= 571 && v <= 575) return launch_gemm_os16_tn<8, 0, false>(v == 571 ? 16 : v == 572 ? 32 : v == 573 ? 48 : v == 574 ? 56 : 64, p, s);
     if (v == 98) return launch_gemm_hetero<GemmCfg<256, 256, 2, 2, 8, true>, GemmCfg<128, 128, 2, 2, 8, true, 0, 4>, 17>(p, s);
 #if QAMD_BENCH
     if (v == 30) return launch_gemm<GemmCfg<256, 256, 2, 2, 8, true>, 4>(p, s);   // per-tile deep schedule (round 1)
@@ -571,7 +615,7 @@ int dispatch_variant(int v, const GemmParams& p, hipStream_t s, const char* name
     if (v == 568) return launch_gemm_os<false>(p, s);       // [r6] 32x32 tiles on wave-owned K stages (gemm_mx_os.hip.h): one shot up to 16 stages, wave-owned rings beyond
     if (v == 569) return launch_gemm_os<false, 16>(p, s);   // [r6] the same with 16 columns per workgroup
     if (v == 570) return launch_gemm_os<false, 32, 4, 64>(p, s);   // [r6] 64x32 tiles (two m-tiles per stage owner)
-    if (v == 571) return launch_gemm_os16<4>(p, s);                // [r6] decode form: 16x16 tiles on the 16x16x128 MFMA
+    if (v >= 571 && v <= 575) return launch_gemm_os16_tn<4, 0, false>(v == 571 ? 16 : v == 572 ? 32 : v == 573 ? 48 : v == 574 ? 56 : 64, p, s);   // [r6] decode form: 16 x (16 / 32 / 48 / 56 / 64) tiles on the 16x16x128 MFMA
 #if QAMD_BENCH
     if (v == 99) return launch_gemm_hetero<GemmCfg<256, 256, 2, 2, 4, false>, GemmCfg<128, 128, 2, 2, 4, false, 0, 3>, 17>(p, s);
     // [r6] lab: the other tiles / ring depths of the in-workgroup K-split kernel (563 = 64x32, 564 = 64x64; 565 - 567 = 32x32 with a 4 / 8 / 6-deep ring)
@@ -659,7 +703,7 @@ int dispatch_variant_a5(int v, const GemmParams& p, hipStream_t s, const char* n
     case 568: return launch_gemm_os<false, 32, 8, 32, 1>(p, s);   // [r6] small batches on wave-owned K stages, e5m2 A
     case 569: return launch_gemm_os<false, 16, 8, 32, 1>(p, s);
     case 570: return launch_gemm_os<false, 32, 8, 64, 1>(p, s);
-    case 571: return launch_gemm_os16<8, 1>(p, s);
+    case 571: case 572: case 573: case 574: case 575: return launch_gemm_os16_tn<8, 1, false>(v == 571 ? 16 : v == 572 ? 32 : v == 573 ? 48 : v == 574 ? 56 : 64, p, s);
   }
   return fail(QAMD_ERR_INVALID, "%s: gemm_variant %d has no e5m2-operand instantiation", name, v);
 }
@@ -822,6 +866,9 @@ inline int ks_plan(int64_t M, int64_t N, int64_t K) {
   // [r6] K <= 4096: the tile's whole K extent fits the LDS -- the one-shot kernel (gemm_mx_os.hip.h), no ring and no barrier in the K walk: N = K = 4096, M = 1 ... 64
   // 4.05-4.39 -> 3.34-3.67 us, N = K = 2048 3.15-3.26 -> 2.62-2.77 (profiles/calib_os_r6q.txt); its wave-owned-ring form for longer K and 16 columns per workgroup where os_plan says so
   // (4096 x 8192, M <= 32: 5.8-7.1 -> 5.5-5.7 us); past one tile per CU the ring plans below keep the shape
+  if (M <= 16) {   // [r6] the decode form with wider column tiles (os16_wide_plan)
+    if (const int v = os16_wide_plan(4, N, K)) return v;
+  }
   if (const int tn = os_plan(M, N, K)) {
     // [r6] decode form (gemm_mx_os16_kernel, 16x16 tiles on the 16x16x128 MFMA) wherever those fit one per CU: a third fewer bytes through each CU's LDS-DMA path
     // (N = K = 4096, M <= 16: 3.25-3.31 -> 2.86-2.92 us; K = 8192 5.0-5.2 -> 3.7-4.1; K = 14336 6.8-7.0 -> 6.1-6.5; two per CU (N = 8192) lose 9 %; profiles/calib_os16_r7.txt)
@@ -1259,14 +1306,17 @@ static int ada_impl(const void* A, const void* B, const void* A_sf, const void* 
   const int os_tn = forced == 0 ? os_plan(M, N, K, true) : 0;
   const bool os16 = forced == 569 || os_tn == 16;   // 16 columns per workgroup
   // [r6] ... its decode form (16x16 tiles on the 16x16x128 MFMA) where those fit one per CU (matmul_mxf4_bf16_tn's rule, ks_plan)
-  if ((forced == 571 && cdiv(M, 16) * cdiv(N, 16) <= 4 * cus) || (os_tn != 0 && cdiv(M, 16) * cdiv(N, 16) <= cus)) {
+  const int ada_tn16 = (forced >= 571 && forced <= 575) ? (forced == 571 ? 16 : forced == 572 ? 32 : forced == 573 ? 48 : forced == 574 ? 56 : 64)
+                       : (os_tn != 0 && cdiv(M, 16) * cdiv(N, 16) <= cus) ? 16
+                       : (forced == 0 && M <= 16 && os16_wide_plan(4, N, K)) ? os16_tn(N) : 0;   // (wider column tiles: matmul_mxf4_bf16_tn's rule)
+  if (ada_tn16) {
     GemmParams p;
     p.A = (const uint8_t*)A; p.B = (const uint8_t*)B; p.SFA = (const uint8_t*)A_sf; p.SFB = (const uint8_t*)B_sf;
     p.alpha = alpha; p.D = (uint16_t*)D; p.M = (int)M; p.N = (int)N; p.K = (int)K; p.ldd = (int)ldd;
     p.a_bytes = (uint32_t)(M * rowbytes); p.b_bytes = (uint32_t)(N * rowbytes);
     p.sfa_bytes = (uint32_t)(M * KB); p.sfb_bytes = (uint32_t)(N * KB);
     p.pp_shift = opt_pp_shift(); p.pp_flags = opt_pp_flags(); p.dbg = opt_dbg();
-    return launch_gemm_os16<4, 0, true>(p, (hipStream_t)stream);
+    return launch_gemm_os16_tn<4, 0, true>(ada_tn16, p, (hipStream_t)stream);
   }
   const bool os64 = forced == 570 || (forced == 0 && os_tn == 0 && os64_plan(M, N, K, true));   // 64x32 tiles where the 32-row tiles overflow the chip (os64_plan)
   const bool oneshot = (forced >= 568 && forced <= 570) ? cdiv(M, 32) * cdiv(N, 32) <= 4 * cus : (os_tn != 0 || os64);

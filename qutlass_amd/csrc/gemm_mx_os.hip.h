@@ -246,13 +246,19 @@ __global__ __launch_bounds__(256) void gemm_mx_os_kernel(const GemmParams p) {
 //   fp8: a stage is ONE MFMA; the 8-bit fragment is "split" as in the 32x32x64 form: registers 0-3 = chunk kq, registers 4-7 = chunk 4 + kq, and the scale byte of K-block b
 //        is taken from lane group b -- so lane (r, kq) supplies byte kq of the row's dword of column tile kt (again the dword shifted by 8 kq).
 // One dword scale piece per operand and stage: lane l fetches the dword of row l & 15 in column tile 2 kt + ((l >> 4) & 1) (fp8: kt).
-template <int SPW_, int EBITS_ = 4, int AFMT_ = 0>
+// TN (third template parameter of the configuration): output columns per workgroup, 16 ... 64 in pieces of 8 rows of B -- the A rows are fetched once for ceil(TN / 16) n-tiles,
+// so a WIDE weight at M <= 16 still runs one workgroup per CU with 16 + TN rows per stage (N = 8192: TN = 32, 48 rows instead of the 32x32 form's 64; N = 14336: TN = 56 = 256
+// workgroups, 72 rows -- the 32x64 K-split ring kernel fetched 96 and met at a barrier per stage).  TN = 56: the fourth n-tile's columns 8 ... 15 read whatever the LDS holds
+// behind the B area -- they only feed output columns that are not stored.
+template <int SPW_, int EBITS_ = 4, int AFMT_ = 0, int TN_ = 16>
 struct Os16Cfg {
-  static constexpr int TM = 16, TN = 16, EBITS = EBITS_, AFMT = AFMT_, ROWB = 128, SPW = SPW_, KTMAX = 4 * SPW_;
-  static constexpr int OFF_B = TM * ROWB, OFF_S = (TM + TN) * ROWB, STAGE = OFF_S + 512;   // + one 256-byte scale piece per operand
-  static constexpr int LPS = 2 + 2 + 2;
-  static constexpr int RED = 4 * 1024;
+  static constexpr int TM = 16, TN = TN_, EBITS = EBITS_, AFMT = AFMT_, ROWB = 128, SPW = SPW_, KTMAX = 4 * SPW_;
+  static constexpr int NT = (TN + 15) / 16, NPB = TN / 8, NSB = (NT + 1) / 2;   // n-tiles (MFMAs per k-slice), B pieces, B scale pieces (one per pair of n-tiles)
+  static constexpr int OFF_B = TM * ROWB, OFF_S = (TM + TN) * ROWB, OFF_SB = OFF_S + 256, STAGE = OFF_SB + NSB * 256;
+  static constexpr int LPS = 2 + NPB + 1 + NSB;
+  static constexpr int RED = 4 * 16 * NT * 64;
   static constexpr int LDS_BYTES = KTMAX * STAGE > RED ? KTMAX * STAGE : RED;
+  static_assert(TN % 8 == 0 && TN >= 16 && TN <= 64, "tile width");
   static_assert(EBITS == 4 || EBITS == 8, "element width");
   static_assert(AFMT == 0 || (AFMT == 1 && EBITS == 8), "A format: 0 = e2m1 / e4m3, 1 = e5m2 (MXFP8 only)");
   static_assert(SPW >= 1 && SPW * LPS <= 63, "vmcnt immediate");
@@ -262,7 +268,7 @@ struct Os16Cfg {
 // RM: row-major scale operands (rows, K / 32) -- matmul_ada_mxf4_bf16_tn; the lane's dword (K-blocks 4 c .. 4 c + 3 of its row) holds the same four bytes either way
 template <class C, bool RING = false, bool RM = false>
 __global__ __launch_bounds__(256) void gemm_mx_os16_kernel(const GemmParams p) {
-  constexpr int SPW = C::SPW, LPS = C::LPS, E8 = C::EBITS == 8;
+  constexpr int SPW = C::SPW, LPS = C::LPS, E8 = C::EBITS == 8, NT = C::NT;
   static_assert(!(RM && E8), "row-major scales: matmul_ada_mxf4_bf16_tn only");
   __shared__ __attribute__((aligned(16))) char smem[C::LDS_BYTES];
   asm volatile("" :: "s"(p.A), "s"(p.D), "s"(p.K), "s"(p.b_bytes), "s"(p.alpha));   // all scalar argument loads in one round
@@ -283,12 +289,20 @@ __global__ __launch_bounds__(256) void gemm_mx_os16_kernel(const GemmParams p) {
     vP[par] = (lane >> 3) * rowbytes + (chP[par] << 4);
   }
   const int rstep = 8 * rowbytes;
+  // scale dwords.  A: lane l fetches row l & 15 of column tile 2 kt + ((l >> 4) & 1) (fp8: kt) -- lanes 32-63 a second copy.  B: one piece per PAIR of n-tiles, lane half
+  // g = l >> 5 fetching n-tile 2 pp + g; the rows of a column tile of 56 may straddle two 128-row scale tiles, so B rows are addressed from the operand's start.
   const int KB = p.K >> 5;
-  const uint32_t sa_off = RM ? (uint32_t)m0 * KB : (uint32_t)(m0 >> 7) * CB * 512, sb_off = RM ? (uint32_t)n0 * KB : (uint32_t)(n0 >> 7) * CB * 512;
-  const __amdgpu_buffer_rsrc_t rSA = make_rsrc(p.SFA + sa_off, p.sfa_bytes - sa_off), rSB = make_rsrc(p.SFB + sb_off, p.sfb_bytes - sb_off);
-  const int rowA = (m0 & 127) + r16, rowB = (n0 & 127) + r16;   // rows of the 128-row scale tiles
-  const int ctl = E8 ? 0 : (kq & 1);                            // column tile of the stage this lane fetches
-  const int vSA = RM ? r16 * KB + 4 * ctl : ctl * 512 + (rowA & 31) * 16 + (rowA >> 5) * 4, vSB = RM ? r16 * KB + 4 * ctl : ctl * 512 + (rowB & 31) * 16 + (rowB >> 5) * 4;
+  const uint32_t sa_off = RM ? (uint32_t)m0 * KB : (uint32_t)(m0 >> 7) * CB * 512;
+  const __amdgpu_buffer_rsrc_t rSA = make_rsrc(p.SFA + sa_off, p.sfa_bytes - sa_off), rSB = make_rsrc(p.SFB, p.sfb_bytes);
+  const int rowA = (m0 & 127) + r16;
+  const int ctl = E8 ? 0 : (kq & 1);   // column tile of the stage this lane fetches
+  const int vSA = RM ? r16 * KB + 4 * ctl : ctl * 512 + (rowA & 31) * 16 + (rowA >> 5) * 4;
+  int vSB[C::NSB];
+#pragma unroll
+  for (int pp = 0; pp < C::NSB; ++pp) {
+    const int nr = n0 + 16 * (2 * pp + (lane >> 5)) + r16;   // B row (an n-tile past TN: rows of the next workgroup's tile or past N -- unused / zeros)
+    vSB[pp] = RM ? nr * KB + 4 * ctl : (nr >> 7) * CB * 512 + ctl * 512 + (nr & 31) * 16 + ((nr & 127) >> 5) * 4;
+  }
   constexpr int SCW = RM ? 8 : E8 ? 512 : 1024;   // scale bytes per stage and 128-row tile (RM: per row)
 
   auto issue = [&](const int kt, const int slot) __attribute__((always_inline)) {   // stage kt into slot `slot` of this wave (kt >= KT: every piece out of range -> zeros)
@@ -298,54 +312,72 @@ __global__ __launch_bounds__(256) void gemm_mx_os16_kernel(const GemmParams p) {
     asm volatile("" : "+v"(tail), "+v"(oob));
     const int soff = kt * C::ROWB;
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
+    for (int t = 0; t < 2 + C::NPB; ++t) {
       const bool isB = t >= 2;
-      const int qq = t & 1;
-      const int o = oob | ((chP[qq] << 4) < tail ? 0 : -1);
-      const int v = ((vP[qq] + qq * rstep) & ~o) | ((int)0x80000000 & o);
+      const int qq = isB ? t - 2 : t, par = qq & 1;
+      const int o = oob | ((chP[par] << 4) < tail ? 0 : -1);
+      const int v = ((vP[par] + qq * rstep) & ~o) | ((int)0x80000000 & o);
       __builtin_amdgcn_raw_ptr_buffer_load_lds(isB ? rB : rA, (lds_ptr_t)(st + (isB ? C::OFF_B : 0) + qq * 1024), 16, v, soff, 0, 0);
     }
     const int os = (kt < KT && (RM ? 8 * kt + 4 * ctl < KB : (E8 ? kt : 2 * kt + ctl) < CB)) ? 0 : -1;   // a column tile past the operand's last one would read the next row tile's bytes (RM: the next row's)
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rSA, (lds_ptr_t)(st + C::OFF_S), 4, (vSA & ~os) | ((int)0x80000000 & os), kt * SCW, 0, 0);
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rSB, (lds_ptr_t)(st + C::OFF_S + 256), 4, (vSB & ~os) | ((int)0x80000000 & os), kt * SCW, 0, 0);
+#pragma unroll
+    for (int pp = 0; pp < C::NSB; ++pp)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rSB, (lds_ptr_t)(st + C::OFF_SB + pp * 256), 4, (vSB[pp] & ~os) | ((int)0x80000000 & os), kt * SCW, 0, 0);
   };
 
 #pragma unroll
   for (int j = 0; j < SPW; ++j) issue(wave + 4 * j, j);
 
   const int sw = (r16 >> 1) & 7;
-  v4f acc = {0.f, 0.f, 0.f, 0.f};
+  v4f acc[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) acc[t] = v4f{0.f, 0.f, 0.f, 0.f};
   auto fence = [&]() __attribute__((always_inline)) { __builtin_amdgcn_sched_barrier(0); };
 
   auto consume = [&](const int u, const int kt_next) __attribute__((always_inline)) {
     const char* st = smem + (wave * SPW + u) * C::STAGE;
-    v4i fa[2], fb[2];
-    int sa[2], sb[2];
+    v4i fa[2], fb[NT][2];
+    int sa[2], sb[NT][2];
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       const int off = r16 * C::ROWB + (((4 * h + kq) ^ sw) << 4);
+      const int hs = E8 ? 0 : h;
       fa[h] = *(const v4i*)(st + off);
-      fb[h] = *(const v4i*)(st + C::OFF_B + off);
-      // the lane fetched column tile (kq & 1) into slot lane * 4: row r16 of column tile h sits at (h * 16 + r16) * 4 (lanes 32-63 hold a second copy)
-      sa[h] = *(const int*)(st + C::OFF_S + ((E8 ? 0 : h) * 16 + r16) * 4);
-      sb[h] = *(const int*)(st + C::OFF_S + 256 + ((E8 ? 0 : h) * 16 + r16) * 4);
+      sa[h] = *(const int*)(st + C::OFF_S + (hs * 16 + r16) * 4);   // the fetching lane (kq & 1 = column tile) put row r16 of column tile h at (h * 16 + r16) * 4
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        fb[t][h] = *(const v4i*)(st + C::OFF_B + t * 16 * C::ROWB + off);
+        sb[t][h] = *(const int*)(st + C::OFF_SB + (t >> 1) * 256 + ((t & 1) * 32 + hs * 16 + r16) * 4);
+      }
     }
     fence();
     if constexpr (RING) {
-      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[0]), "+v"(fa[1]), "+v"(fb[0]), "+v"(fb[1]), "+v"(sa[0]), "+v"(sa[1]), "+v"(sb[0]), "+v"(sb[1]) :: "memory");   // the slot is free
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[0]), "+v"(fa[1]), "+v"(sa[0]), "+v"(sa[1]) :: "memory");   // the slot is free (LDS reads return in order: the A reads were issued ...
+#pragma unroll
+      for (int t = 0; t < NT; ++t) asm volatile("" : "+v"(fb[t][0]), "+v"(fb[t][1]), "+v"(sb[t][0]), "+v"(sb[t][1]));   // ... and every B read is pinned behind the wait)
       issue(kt_next, u);
       fence();
     }
     constexpr int FMT = E8 ? 0 : 4, FMTA = E8 ? C::AFMT : 4;   // cbsz = format of srcA (the B fragment), blgp = format of srcB (the A fragment)
     if constexpr (E8) {
       const v8i A8 = {fa[0][0], fa[0][1], fa[0][2], fa[0][3], fa[1][0], fa[1][1], fa[1][2], fa[1][3]};
-      const v8i B8 = {fb[0][0], fb[0][1], fb[0][2], fb[0][3], fb[1][0], fb[1][1], fb[1][2], fb[1][3]};
-      acc = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(B8, A8, acc, FMT, FMTA, 0, (int)((unsigned)sb[0] >> (8 * kq)), 0, (int)((unsigned)sa[0] >> (8 * kq)));
+      const int xa = (int)((unsigned)sa[0] >> (8 * kq));
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const v8i B8 = {fb[t][0][0], fb[t][0][1], fb[t][0][2], fb[t][0][3], fb[t][1][0], fb[t][1][1], fb[t][1][2], fb[t][1][3]};
+        acc[t] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(B8, A8, acc[t], FMT, FMTA, 0, (int)((unsigned)sb[t][0] >> (8 * kq)), 0, xa);
+      }
     } else {
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
-        const v8i A8 = {fa[h][0], fa[h][1], fa[h][2], fa[h][3], 0, 0, 0, 0}, B8 = {fb[h][0], fb[h][1], fb[h][2], fb[h][3], 0, 0, 0, 0};
-        acc = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(B8, A8, acc, FMT, FMTA, 0, (int)((unsigned)sb[h] >> (8 * kq)), 0, (int)((unsigned)sa[h] >> (8 * kq)));
+        const v8i A8 = {fa[h][0], fa[h][1], fa[h][2], fa[h][3], 0, 0, 0, 0};
+        const int xa = (int)((unsigned)sa[h] >> (8 * kq));
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          const v8i B8 = {fb[t][h][0], fb[t][h][1], fb[t][h][2], fb[t][h][3], 0, 0, 0, 0};
+          acc[t] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(B8, A8, acc[t], FMT, FMTA, 0, (int)((unsigned)sb[t][h] >> (8 * kq)), 0, xa);
+        }
       }
     }
     fence();
@@ -373,23 +405,28 @@ __global__ __launch_bounds__(256) void gemm_mx_os16_kernel(const GemmParams p) {
   __builtin_amdgcn_s_barrier();   // every wave's reads of the stage areas are done: they become the sum's scratch
   fence();
 
-  // ---- cross-wave sum: [wave][row m][16 columns] fp32; a lane holds row m = r16, columns 4 kq .. + 3 (srcA = the B fragment) ------------------------------
-  *(v4f*)(smem + (wave * 16 + r16) * 64 + kq * 16) = acc;
+  // ---- cross-wave sum: [wave][row m][16 NT columns] fp32; a lane holds row m = r16, columns 16 t + 4 kq .. + 3 (srcA = the B fragment) ----------------------
+  constexpr int RROW = 64 * NT;   // bytes per row of a wave's partial tile
+#pragma unroll
+  for (int t = 0; t < NT; ++t) *(v4f*)(smem + (wave * 16 + r16) * RROW + t * 64 + kq * 16) = acc[t];
   __syncthreads();
   if (tid < 64) {
     const int rr = tid >> 2, cq = tid & 3;
-    v4f s[4];
 #pragma unroll
-    for (int w = 0; w < 4; ++w) s[w] = *(const v4f*)(smem + (w * 16 + rr) * 64 + cq * 16);
-    v4f t;
+    for (int t = 0; t < NT; ++t) {
+      v4f s[4];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) t[e] = ((s[0][e] + s[1][e]) + s[2][e]) + s[3][e];
-    const int row = m0 + rr, col = n0 + 4 * cq;
-    if (row < p.M && col < p.N) {
-      v2i o;
-      o[0] = (int)pack_bf16x2(t[0] * alpha, t[1] * alpha);
-      o[1] = (int)pack_bf16x2(t[2] * alpha, t[3] * alpha);
-      *(v2i*)(p.D + (size_t)row * p.ldd + col) = o;
+      for (int w = 0; w < 4; ++w) s[w] = *(const v4f*)(smem + (w * 16 + rr) * RROW + t * 64 + cq * 16);
+      v4f x;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) x[e] = ((s[0][e] + s[1][e]) + s[2][e]) + s[3][e];
+      const int row = m0 + rr, cl = 16 * t + 4 * cq, col = n0 + cl;
+      if (row < p.M && col < p.N && cl < C::TN) {
+        v2i o;
+        o[0] = (int)pack_bf16x2(x[0] * alpha, x[1] * alpha);
+        o[1] = (int)pack_bf16x2(x[2] * alpha, x[3] * alpha);
+        *(v2i*)(p.D + (size_t)row * p.ldd + col) = o;
+      }
     }
   }
 }

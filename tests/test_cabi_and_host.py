@@ -488,7 +488,7 @@ def test_auto_dispatch_rules_dry_run(lib):
     # [r6] ... and with K <= 4096 (16 stages) the tile's whole K extent fits the LDS: the one-shot kernel (csrc/gemm_mx_os.hip.h), N = K = 4096, M = 1 ... 64 4.05-4.39 -> 3.34-3.67 us
     OS32, OS16 = 568, 569   # 32 / 16 output columns per workgroup: 16 whenever that still leaves at most one workgroup per CU (N = 4096, M <= 32: 256 workgroups)
     OSD = 571               # [r6] its decode form: 16x16 tiles on the 16x16x128 MFMA wherever those fit one per CU (N = 4096: M <= 16)
-    assert plan(4, 1, 4096, 4096) == [(OSD, 4096, 1)] and plan(4, 8, 4096, 4096) == [(OSD, 4096, 1)] and plan(4, 8, 8192, 8192) == [(OS32, 8192, 1)]
+    assert plan(4, 1, 4096, 4096) == [(OSD, 4096, 1)] and plan(4, 8, 4096, 4096) == [(OSD, 4096, 1)] and plan(4, 8, 8192, 8192) == [(572, 8192, 1)] and plan(4, 17, 8192, 8192) == [(OS32, 8192, 1)]
     assert plan(4, 16, 4096, 4096) == [(OSD, 4096, 1)] and plan(4, 32, 4096, 4096) == [(OS16, 4096, 1)] and plan(4, 24, 2048, 2048) == [(OSD, 2048, 1)]
     assert plan(4, 32, 8192, 4096) == [(OS32, 8192, 1)] and plan(4, 33, 8192, 4096) != [(OS32, 8192, 1)]   # one tile per CU at most
     # longer K: the same kernel on wave-owned rings where the tiles fill a quarter of the chip (M < 8 with more than 32 stages stays on the LDS-free split-K kernel
@@ -496,10 +496,13 @@ def test_auto_dispatch_rules_dry_run(lib):
     assert plan(4, 16, 4096, 4224) == [(OSD, 4096, 1)] and plan(4, 16, 4096, 8192) == [(OSD, 4096, 1)] and plan(4, 1, 4096, 8192) == [(OSD, 4096, 1)] and plan(4, 17, 4096, 8192) == [(OS16, 4096, 1)]
     assert plan(4, 1, 8192, 14336) == [(KS32, 8192, 1)] and plan(4, 16, 1024, 5120) == [(KS32, 1024, 1)]   # what the K-split ring kernel keeps
     assert plan(4, 16, 1024, 14336) != [(OS32, 1024, 1)] and plan(4, 8, 4096, 14336, big) == [(OSD, 4096, 1)] and plan(4, 16, 4096, 32768) != [(OS32, 4096, 1)]
-    assert plan(4, 16, 14336, 4096) == [(KS32x64, 14336, 1)]
+    # [r6] M <= 16 against wider weights: the decode form with 32 / 48 / 56 / 64 columns per workgroup (variants 572 ... 575; capi.hip os16_wide_plan) inside its one-shot range
+    assert plan(4, 16, 14336, 4096) == [(574, 14336, 1)] and plan(4, 17, 14336, 4096) == [(KS32x64, 14336, 1)] and plan(4, 16, 14336, 8192) != [(574, 14336, 1)]
+    assert plan(4, 1, 12288, 4096) == [(573, 12288, 1)] and plan(4, 8, 12288, 5120) == [(573, 12288, 1)] and plan(4, 8, 16384, 4096) == [(575, 16384, 1)] and plan(4, 8, 6144, 4096) == [(572, 6144, 1)]
+    assert plan(4, 8, 8192, 2048) == [(OS32, 8192, 1)] and plan(8, 8, 8192, 4096) == [(572, 8192, 1)] and plan(8, 16, 11008, 4096) == [(573, 11008, 1)] and plan(8, 8, 8192, 1024) == [(OS32, 8192, 1)]
     assert plan(4, 1, 4096, 14336) == [(OSD, 4096, 1)] and plan(4, 8, 4096, 11008) == [(OSD, 4096, 1)] and plan(4, 32, 4096, 11008) == [(OS16, 4096, 1)]     # [r6] (rounds 3-5: the LDS-free split-K kernel, 7.6-7.8 us; 16-column wave-owned rings 6.9)
     assert plan(4, 4, 8192, 11008) == [(KS32, 8192, 1)] and plan(4, 4, 2048, 11008) == [(SKINNY, 2048, 1)]     # long K, M < 8, no room for 16-column workgroups / too few tiles: the split-K kernels keep it
-    assert plan(4, 16, 11008, 4096) == [(RING64, 11008, 1)] and plan(4, 96, 4096, 4096) == [(RING64, 4096, 1)]  # 32x32 tiles would sit two on a CU
+    assert plan(4, 24, 11008, 4096) == [(RING64, 11008, 1)] and plan(4, 96, 4096, 4096) == [(RING64, 4096, 1)]  # 32x32 tiles would sit two on a CU
     assert plan(4, 16, 57344, 8192) == [(28, 57344, 1)]
     # [r6] MXFP8 small batches: the wave-owned kernel (csrc/gemm_mx_os.hip.h, EBITS = 8; capi.hip os8_plan) -- 32x16 / 32x32 tiles while they fit one per CU, 64x32 where only
     # those still do; a long K only on (nearly) the whole chip (rounds 1-5: 64x64 ring tiles, N = K = 4096, M = 16: 6.4 -> 5.0 us; 8192 x 4096: 10.6 -> 6.4)

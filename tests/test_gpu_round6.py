@@ -267,7 +267,7 @@ def _mx_operands_exact(m, n, k, seed):
 KS_SHAPES = [(1, 8, 128), (9, 40, 384), (33, 104, 1408), (64, 264, 4096), (100, 72, 640), (31, 4096, 4096), (64, 2048, 8192), (130, 520, 256)]
 
 
-@pytest.mark.parametrize("variant", [561, 562, 563, 564, 565, 566, 567, 568, 569, 570, 571])   # (571: the 16x16 decode form on the 16x16x128 MFMA)
+@pytest.mark.parametrize("variant", [561, 562, 563, 564, 565, 566, 567, 568, 569, 570, 571, 572, 573, 574, 575])   # (571 ... 575: the decode form on the 16x16x128 MFMA, 16 / 32 / 48 / 56 / 64 columns per workgroup)
 @pytest.mark.parametrize("m,n,k", KS_SHAPES + [(5, 72, 1024), (40, 200, 2944), (64, 96, 3072), (9, 136, 4224), (33, 72, 11008), (3, 40, 14336), (64, 64, 4352),
                                                (128, 4096, 4096), (97, 136, 3328), (160, 72, 5376)])   # (568: one shot up to K = 4096, wave-owned rings beyond; 570: 64x32 tiles, one shot up to K = 3072)
 def test_ks_kernel_against_the_oracle(variant, m, n, k):
@@ -301,7 +301,7 @@ def test_one_shot_kernel_with_row_major_scales_against_the_oracle(q, m, n, k):
     assert np.array_equal(_np(q.matmul_mxf4_bf16_tn(a, b, tsa.view(e8), tsb.view(e8), alpha)), ref)
     with lab.forced(gemm_variant=70):   # the ring kernel with row-major scale fetch, the plan before this kernel
         assert np.array_equal(_np(lab.matmul_ada_mxf4_bf16_tn(a, b, sa, sb, alpha)), ref)
-    for v in (568, 569, 570, 571):   # ... and the kernel itself (32 / 16 columns per workgroup, 64-row tiles, the 16x16 decode form) where the product rule does not send the shape to it
+    for v in (568, 569, 570, 571, 572, 574, 575):   # ... and the kernel itself (32 / 16 columns per workgroup, 64-row tiles, the 16x16 decode form) where the product rule does not send the shape to it
         with lab.forced(gemm_variant=v):
             assert np.array_equal(_np(lab.matmul_ada_mxf4_bf16_tn(a, b, sa, sb, alpha)), ref), v
 
@@ -414,7 +414,7 @@ def _exact_fp8_operands(m, n, k, seed, e5m2_a=False):
 
 
 @pytest.mark.parametrize("a5", [False, True])
-@pytest.mark.parametrize("variant", [568, 569, 570, 571, 0])
+@pytest.mark.parametrize("variant", [568, 569, 570, 571, 572, 573, 574, 575, 0])
 @pytest.mark.parametrize("m,n,k", MXF8_OS_SHAPES)
 def test_mxf8_wave_owned_kernel_exact_against_the_oracle(variant, m, n, k, a5):
     from qutlass_amd.utils import to_blocked

@@ -40,8 +40,8 @@ def main():
             sb = torch.randint(125, 129, (pad(n) * cb,), dtype=torch.uint8, device=dev, generator=g)
             t, outs = {}, {}
             for v in variants:
-                if v == 571 and ((m + 15) // 16) * ((n + 15) // 16) > 4 * 256:
-                    continue
+                if 571 <= v <= 575 and ((m + 15) // 16) * -(-n // {571: 16, 572: 32, 573: 48, 574: 56, 575: 64}[v]) > 2 * 256:
+                    continue   # (the decode form: at most two workgroups per CU)
                 if v in (568, 569, 570) and ((m + (63 if v == 570 else 31)) // (64 if v == 570 else 32)) * ((n + (15 if v == 569 else 31)) // (16 if v == 569 else 32)) > 4 * 256:
                     continue   # more than four rounds of tiles: not a candidate
                 with lab.forced(gemm_variant=v):
