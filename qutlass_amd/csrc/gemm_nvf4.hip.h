@@ -824,7 +824,7 @@ inline int nvf4_big_cfg(int64_t M, int64_t N, int64_t K, int cus, double* t_us =
 // Against the calibration the chosen candidates sum to 10 353 us (best measured candidate per shape: 10 288; the occupancy thresholds this replaces:
 // 11 057), e.g. 256 x 4096 x 14336 54.7 -> 39.2 us (128x128 tiles, 4 K ranges), 128 x 8192 x 28672 107 -> 67, 64 x 28672 x 4096 36.7 -> 26.6 (64x64 tiles
 // instead of the skinny kernel), 512 x 5120 x 5120 47.0 -> 41.1 (160 tiles of 128x128 instead of 320 of 128x64, which put two on 64 CUs).
-struct NvPlan { int cfg, splits, kt_per; };   // cfg as above (-1 skinny, [r6] -2 / -3 wave-owned small-batch kernel with 32 / 16 columns per workgroup, -4 / -5 its 16x16 / 32x16 decode form); splits = K ranges actually launched (none empty), kt_per = stages per range (even)
+struct NvPlan { int cfg, splits, kt_per; };   // cfg as above (-1 skinny, [r6] -2 / -3 wave-owned small-batch kernel with 32 / 16 columns per workgroup, -4 / -5 its 16x16 / 32x16 decode form, -6 ... -9 the decode form with 32 / 48 / 56 / 56 (8 A rows) columns per workgroup); splits = K ranges actually launched (none empty), kt_per = stages per range (even)
 // [r6] Does the wave-owned small-batch kernel (gemm_nvf4_os.hip.h) take the shape?  0 (no) or 32 (columns per workgroup; 16 is lab-only: the kernel is bound by its
 // dequantisation instructions -- ~16 per MFMA -- not by bytes, so spreading the weight over twice the workgroups buys nothing: profiles/calib_nvos_r6u.txt).
 // Measured against the plan before it (skinny / tile kernels / split-K with scratch), M = 1 ... 128:
@@ -840,7 +840,14 @@ inline int nv_os_plan(int64_t M, int64_t N, int64_t K, int cus) {
   if (M > 128) return 0;
   const int64_t G16 = ((M + 15) / 16) * ((N + 15) / 16);
   if (G16 <= cus && KT <= 128) return 1616;
-  if (M <= 16 && G16 <= 2 * (int64_t)cus && KT <= 16) return 1616;
+  // M <= 16 against a weight too wide for 16-column workgroups: the decode form with 32 / 48 / 56 columns per workgroup, the A dword dequantised once for 2 / 3 / 4 n-tiles
+  // (1632 / 1648 / 1656; 856 = 56 columns with only A rows 0 ... 7 fetched, M <= 8: its 16 stages fit the LDS).  N = 11008 / 12288 x K = 4096: 9.2-10.8 -> 5.8-5.9 us (the
+  // 32x32 kernel ran two rounds of tiles); 12288 x 5120 13.6-14.1 -> 8.7-9.2; 14336 x 4096 9.5-9.8 -> 7.6-7.7 (M <= 8) / 8.0-8.3; x 8192 19.2 -> 15.0; N = 6144 / 8192:
+  // -5 % at K = 4096, -12 % at K = 8192; 5120^2 -12 ... -15 %.  profiles/calib_nv16w_r7.txt
+  if (M <= 16 && KT <= 32) {
+    for (int tn : {32, 48, 56})
+      if ((N + tn - 1) / tn <= cus) return tn == 56 ? ((M <= 8 && KT <= 16) ? 856 : 1656) : 1600 + tn;
+  }
   // 3216 = the same with two m-tiles per workgroup (a B dword dequantised once for both): where 32x16 tiles fit one per CU (N = 4096, M = 17 ... 32: K = 4096 5.35 -> 4.75 us,
   // K = 14336 14.1 -> 11.7, K = 28672 30-36 -> 20)
   if (((M + 31) / 32) * ((N + 15) / 16) <= cus && KT <= 128) return 3216;
@@ -853,7 +860,7 @@ inline int nv_os_plan(int64_t M, int64_t N, int64_t K, int cus) {
 }
 hipError_t launch_nvf4_os(NvGemmParams p, hipStream_t s, int tn);   // capi.hip (the NVFP4 unit)
 inline NvPlan nvf4_plan(int64_t M, int64_t N, int64_t K, int cus, bool may_split) {
-  if (const int tn = nv_os_plan(M, N, K, cus)) return {tn == 3216 ? -5 : tn == 1616 ? -4 : tn == 16 ? -3 : -2, 1, 0};
+  if (const int tn = nv_os_plan(M, N, K, cus)) return {tn == 856 ? -9 : tn == 1656 ? -8 : tn == 1648 ? -7 : tn == 1632 ? -6 : tn == 3216 ? -5 : tn == 1616 ? -4 : tn == 16 ? -3 : -2, 1, 0};
   if (M <= 32) return {-1, 1, 0};
   auto tiles = [&](int bm, int bn) { return ((M + bm - 1) / bm) * ((N + bn - 1) / bn); };
   const int KT = (int)((K / 2 + 127) / 128);
@@ -917,8 +924,9 @@ inline hipError_t launch_nvf4_gemm(NvGemmParams p, hipStream_t s, int variant = 
   if (variant == 46 || variant == 47) return launch_nvf4_os(p, s, variant == 47 ? 16 : 32);   // lab: force the wave-owned small-batch kernel (any K: rings beyond 4096)
   if (variant == 48) return launch_nvf4_os(p, s, 1616);                                       // lab: ... its 16x16 decode form (any M: rows in tiles of 16)
   if (variant == 49) return launch_nvf4_os(p, s, 3216);                                       // lab: ... with two m-tiles per workgroup (32x16)
+  if (variant >= 50 && variant <= 53) return launch_nvf4_os(p, s, variant == 50 ? 1632 : variant == 51 ? 1648 : variant == 52 ? 1656 : 856);   // lab: ... with 32 / 48 / 56 columns per workgroup (53: 56 columns, A rows 0 ... 7 only)
 #endif
-  if (variant == 0 && plan.cfg <= -2) return launch_nvf4_os(p, s, plan.cfg == -5 ? 3216 : plan.cfg == -4 ? 1616 : plan.cfg == -3 ? 16 : 32);
+  if (variant == 0 && plan.cfg <= -2) return launch_nvf4_os(p, s, plan.cfg == -9 ? 856 : plan.cfg == -8 ? 1656 : plan.cfg == -7 ? 1648 : plan.cfg == -6 ? 1632 : plan.cfg == -5 ? 3216 : plan.cfg == -4 ? 1616 : plan.cfg == -3 ? 16 : 32);
   if (variant == 3 || (variant == 0 && plan.cfg < 0)) {
     hipLaunchKernelGGL((gemm_nvf4_skinny_kernel<8>), dim3((p.N + 31) / 32, (p.M + 31) / 32), dim3(512), 0, s, p);
     return hipSuccess;

@@ -189,22 +189,29 @@ __global__ __launch_bounds__(512) void gemm_nvf4_os_kernel(const NvGemmParams p)
 // column tile 4 kt + kq); the two scale groups of chunk kq + 4 h are bytes 2 (kq & 1), + 1 of column tile 4 kt + 2 h + (kq >> 1).
 // MT = 2 (M = 17 ... 32): two m-tiles of 16 rows per workgroup -- a B dword is dequantised once and feeds both m-tiles' MFMAs (12 instead of 16 vector instructions
 // per MFMA), still 16 columns per workgroup.
-template <int SPW_, int MT_ = 1>
+// TN > 16 (MT = 1; M <= 16 against a weight too wide for 16-column workgroups): ceil(TN / 16) n-tiles per workgroup -- the A dword is dequantised once for all of them
+// (TN = 32: 12 vector instructions per MFMA, 48: 10.7, 56: 10) and the weight still runs one workgroup per CU (N = 8192: TN = 32; 12288: 48; 14336: 56 = 256 workgroups
+// where the 32x32 kernel ran two rounds).  TN = 56: the fourth n-tile's columns 8 ... 15 read whatever the LDS holds behind the B area -- they only feed columns that are not
+// stored.  NPA = 1 (M <= 8): only A rows 0 ... 7 are fetched (rows 8 ... 15 of the fragment read the first B rows: finite, and they only feed rows that are not stored) --
+// that KiB per stage is what lets a 56-column tile's 16 stages (K = 4096) fit the LDS.
+template <int SPW_, int MT_ = 1, int TN_ = 16, int NPA_ = 2 * MT_>
 struct NvOs16Cfg {
-  static constexpr int NW = 8, MT = MT_, TM = 16 * MT_, TN = 16, ROWB = 128, SPW = SPW_, NSLOT = NW * SPW_;
-  static constexpr int OFF_B = TM * ROWB, OFF_S = (TM + TN) * ROWB, OFF_SB = OFF_S + MT * 256, STAGE = OFF_SB + 256;   // one 256-byte scale piece per m-tile and one for B
-  static constexpr int NPA = 2 * MT;
-  static constexpr int LPS = NPA + 2 + MT + 1;
-  static constexpr int RED = NW * TM * 64;
+  static constexpr int NW = 8, MT = MT_, TM = 16 * MT_, TN = TN_, ROWB = 128, SPW = SPW_, NSLOT = NW * SPW_;
+  static constexpr int NT = (TN + 15) / 16, NPA = NPA_, NPB = TN / 8;
+  static constexpr int OFF_B = NPA * 1024, OFF_S = OFF_B + TN * ROWB, OFF_SB = OFF_S + MT * 256, STAGE = OFF_SB + NT * 256;   // one 256-byte scale piece per m-tile and per n-tile
+  static constexpr int LPS = NPA + NPB + MT + NT;
+  static constexpr int RED = NW * TM * NT * 64;
   static constexpr int LDS_BYTES = NSLOT * STAGE > RED ? NSLOT * STAGE : RED;
-  static_assert(MT == 1 || MT == 2, "m-tiles");
+  static_assert(MT == 1 || (MT == 2 && TN == 16), "two m-tiles: 16 columns only");
+  static_assert(TN % 8 == 0 && TN >= 16 && TN <= 64, "tile width");
+  static_assert(NPA == 2 * MT || (NPA == 1 && MT == 1), "A pieces");
   static_assert(SPW >= 1 && SPW * LPS <= 63, "vmcnt immediate");
   static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
 };
 
 template <class C, bool RING = false>
 __global__ __launch_bounds__(512) void gemm_nvf4_os16_kernel(const NvGemmParams p) {
-  constexpr int SPW = C::SPW, LPS = C::LPS, NW = C::NW, MT = C::MT;
+  constexpr int SPW = C::SPW, LPS = C::LPS, NW = C::NW, MT = C::MT, NT = C::NT;
   __shared__ __attribute__((aligned(16))) char smem[C::LDS_BYTES];
   asm volatile("" :: "s"(p.A), "s"(p.D), "s"(p.K), "s"(p.b_bytes), "s"(p.alpha));   // all scalar argument loads in one round
   const float alpha = *p.alpha;
@@ -226,16 +233,20 @@ __global__ __launch_bounds__(512) void gemm_nvf4_os16_kernel(const NvGemmParams 
     vP[par] = (lane >> 3) * rowbytes + (chP[par] << 4);
   }
   const int rstep = 8 * rowbytes;
-  const uint32_t sa_off = (uint32_t)(m0 >> 7) * CB * 512, sb_off = (uint32_t)(n0 >> 7) * CB * 512;
-  const __amdgpu_buffer_rsrc_t rSA = make_rsrc(p.SFA + sa_off, p.sfa_bytes - sa_off), rSB = make_rsrc(p.SFB + sb_off, p.sfb_bytes - sb_off);
-  const int rowB = (n0 & 127) + r16;   // row of the 128-row scale tile
-  int vSA[MT];
+  // scale dwords: lane l fetches row l & 15 of column tile 4 kt + (l >> 4); B rows are addressed from the operand's start (a column tile of 56 may straddle two 128-row scale tiles)
+  const uint32_t sa_off = (uint32_t)(m0 >> 7) * CB * 512;
+  const __amdgpu_buffer_rsrc_t rSA = make_rsrc(p.SFA + sa_off, p.sfa_bytes - sa_off), rSB = make_rsrc(p.SFB, p.sfb_bytes);
+  int vSA[MT], vSB[NT];
 #pragma unroll
   for (int t = 0; t < MT; ++t) {
     const int rowA = (m0 & 127) + 16 * t + r16;
     vSA[t] = kq * 512 + (rowA & 31) * 16 + (rowA >> 5) * 4;
   }
-  const int vSB = kq * 512 + (rowB & 31) * 16 + (rowB >> 5) * 4;
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const int nr = n0 + 16 * t + r16;   // (an n-tile past TN: rows of the next workgroup's tile or past N -- unused / zeros)
+    vSB[t] = (nr >> 7) * CB * 512 + kq * 512 + (nr & 31) * 16 + ((nr & 127) >> 5) * 4;
+  }
 
   auto issue = [&](const int kt, const int slot) __attribute__((always_inline)) {   // stage kt into slot `slot` of this wave (kt >= KT: every piece out of range -> zeros)
     char* st = smem + (wave * SPW + slot) * C::STAGE;
@@ -244,7 +255,7 @@ __global__ __launch_bounds__(512) void gemm_nvf4_os16_kernel(const NvGemmParams 
     asm volatile("" : "+v"(tail), "+v"(oob));
     const int soff = kt * C::ROWB;
 #pragma unroll
-    for (int t = 0; t < C::NPA + 2; ++t) {
+    for (int t = 0; t < C::NPA + C::NPB; ++t) {
       const bool isB = t >= C::NPA;
       const int qq = isB ? t - C::NPA : t, par = qq & 1;
       const int o = oob | ((chP[par] << 4) < tail ? 0 : -1);
@@ -255,22 +266,26 @@ __global__ __launch_bounds__(512) void gemm_nvf4_os16_kernel(const NvGemmParams 
 #pragma unroll
     for (int t = 0; t < MT; ++t)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rSA, (lds_ptr_t)(st + C::OFF_S + t * 256), 4, (vSA[t] & ~os) | ((int)0x80000000 & os), kt * 2048, 0, 0);
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rSB, (lds_ptr_t)(st + C::OFF_SB), 4, (vSB & ~os) | ((int)0x80000000 & os), kt * 2048, 0, 0);
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rSB, (lds_ptr_t)(st + C::OFF_SB + t * 256), 4, (vSB[t] & ~os) | ((int)0x80000000 & os), kt * 2048, 0, 0);
   };
 
 #pragma unroll
   for (int j = 0; j < SPW; ++j) issue(wave + NW * j, j);
 
   const int sw = (r16 >> 1) & 7;
-  v4f acc[MT];
+  v4f acc[MT][NT];
 #pragma unroll
-  for (int t = 0; t < MT; ++t) acc[t] = v4f{0.f, 0.f, 0.f, 0.f};
+  for (int t = 0; t < MT; ++t)
+#pragma unroll
+    for (int n = 0; n < NT; ++n) acc[t][n] = v4f{0.f, 0.f, 0.f, 0.f};
   auto fence = [&]() __attribute__((always_inline)) { __builtin_amdgcn_sched_barrier(0); };
 
   auto consume = [&](const int kt, const int u, const int kt_next) __attribute__((always_inline)) {
     const char* st = smem + (wave * SPW + u) * C::STAGE;
-    v4i ca[MT][2], cb[2];
-    uint32_t da[MT][2], db[2];
+    v4i ca[MT][2], cb[NT][2];
+    uint32_t da[MT][2], db[NT][2];
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       const int off = r16 * C::ROWB + (((kq + 4 * h) ^ sw) << 4);
@@ -280,16 +295,19 @@ __global__ __launch_bounds__(512) void gemm_nvf4_os16_kernel(const NvGemmParams 
         ca[t][h] = *(const v4i*)(st + t * 16 * C::ROWB + off);
         da[t][h] = *(const uint32_t*)(st + C::OFF_S + t * 256 + soff);
       }
-      cb[h] = *(const v4i*)(st + C::OFF_B + off);
-      db[h] = *(const uint32_t*)(st + C::OFF_SB + soff);
+#pragma unroll
+      for (int n = 0; n < NT; ++n) {
+        cb[n][h] = *(const v4i*)(st + C::OFF_B + n * 16 * C::ROWB + off);
+        db[n][h] = *(const uint32_t*)(st + C::OFF_SB + n * 256 + soff);
+      }
     }
     fence();
     if constexpr (RING) {
-      if constexpr (MT == 1)
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ca[0][0]), "+v"(ca[0][1]), "+v"(cb[0]), "+v"(cb[1]), "+v"(da[0][0]), "+v"(da[0][1]), "+v"(db[0]), "+v"(db[1]) :: "memory");   // the slot is free
-      else
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ca[0][0]), "+v"(ca[0][1]), "+v"(ca[MT - 1][0]), "+v"(ca[MT - 1][1]), "+v"(cb[0]), "+v"(cb[1]), "+v"(da[0][0]), "+v"(da[0][1]),
-                     "+v"(da[MT - 1][0]), "+v"(da[MT - 1][1]), "+v"(db[0]), "+v"(db[1]) :: "memory");
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the slot is free ...
+#pragma unroll
+      for (int t = 0; t < MT; ++t) asm volatile("" : "+v"(ca[t][0]), "+v"(ca[t][1]), "+v"(da[t][0]), "+v"(da[t][1]));   // ... (every read pinned behind the wait)
+#pragma unroll
+      for (int n = 0; n < NT; ++n) asm volatile("" : "+v"(cb[n][0]), "+v"(cb[n][1]), "+v"(db[n][0]), "+v"(db[n][1]));
       issue(kt_next, u);
       fence();
     }
@@ -298,19 +316,25 @@ __global__ __launch_bounds__(512) void gemm_nvf4_os16_kernel(const NvGemmParams 
       // groups past K inside the last column tile (K % 64 == 32): their scale bytes are layout padding -- masked to 0 (0 x 0, never NaN)
       const int valid = G16 - 4 * (4 * kt + 2 * h + (kq >> 1));
       const uint32_t smask = valid >= 4 ? 0xffffffffu : (valid <= 0 ? 0u : ((1u << (8 * valid)) - 1u));
-      h2_t sa[MT];
+      h2_t sa[MT], sb[NT];
 #pragma unroll
       for (int t = 0; t < MT; ++t) sa[t] = __builtin_amdgcn_cvt_scalef32_pk_f16_fp8((da[t][h] & smask) >> (16 * (kq & 1)), 1.0f, false);   // the two groups of chunk kq + 4 h
-      const h2_t sb = __builtin_amdgcn_cvt_scalef32_pk_f16_fp8((db[h] & smask) >> (16 * (kq & 1)), 1.0f, false);
+#pragma unroll
+      for (int n = 0; n < NT; ++n) sb[n] = __builtin_amdgcn_cvt_scalef32_pk_f16_fp8((db[n][h] & smask) >> (16 * (kq & 1)), 1.0f, false);
 #pragma unroll
       for (int d = 0; d < 4; ++d) {
-        const _Float16 xb = sb[d >> 1];
-        const h8_t fb = dq8((uint32_t)cb[h][d], h2_t{xb, xb});
+        h8_t fa[MT];
 #pragma unroll
         for (int t = 0; t < MT; ++t) {
           const _Float16 xa = sa[t][d >> 1];
-          const h8_t fa = dq8((uint32_t)ca[t][h][d], h2_t{xa, xa});
-          acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb, fa, acc[t], 0, 0, 0);
+          fa[t] = dq8((uint32_t)ca[t][h][d], h2_t{xa, xa});
+        }
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+          const _Float16 xb = sb[n][d >> 1];
+          const h8_t fb = dq8((uint32_t)cb[n][h][d], h2_t{xb, xb});
+#pragma unroll
+          for (int t = 0; t < MT; ++t) acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb, fa[t], acc[t][n], 0, 0, 0);
         }
       }
     }
@@ -339,21 +363,24 @@ __global__ __launch_bounds__(512) void gemm_nvf4_os16_kernel(const NvGemmParams 
   __builtin_amdgcn_s_barrier();   // every wave's reads of the stage areas are done: they become the sum's scratch
   fence();
 
-  // ---- cross-wave sum: [wave][row m][16 columns] fp32; a lane holds row m = 16 t + r16, columns 4 kq .. + 3 (srcA = the B fragment) -----------------------
+  // ---- cross-wave sum: [wave][row m][16 NT columns] fp32; a lane holds row m = 16 t + r16, columns 16 n + 4 kq .. + 3 (srcA = the B fragment) --------------
+  constexpr int RROW = 64 * NT;
 #pragma unroll
-  for (int t = 0; t < MT; ++t) *(v4f*)(smem + (wave * C::TM + 16 * t + r16) * 64 + kq * 16) = acc[t];
+  for (int t = 0; t < MT; ++t)
+#pragma unroll
+    for (int n = 0; n < NT; ++n) *(v4f*)(smem + (wave * C::TM + 16 * t + r16) * RROW + n * 64 + kq * 16) = acc[t][n];
   __syncthreads();
-  if (tid < 64 * MT) {
-    const int rr = tid >> 2, cq = tid & 3;
-    v4f t = *(const v4f*)(smem + rr * 64 + cq * 16);
+  if (tid < 64 * MT * NT) {
+    const int rr = (tid >> 2) % C::TM, n = (tid >> 2) / C::TM, cq = tid & 3;   // row of the tile, n-tile, chunk of 4 columns
+    v4f t = *(const v4f*)(smem + rr * RROW + n * 64 + cq * 16);
 #pragma unroll
     for (int w = 1; w < NW; ++w) {
-      const v4f s = *(const v4f*)(smem + (w * C::TM + rr) * 64 + cq * 16);
+      const v4f s = *(const v4f*)(smem + (w * C::TM + rr) * RROW + n * 64 + cq * 16);
 #pragma unroll
       for (int e = 0; e < 4; ++e) t[e] += s[e];
     }
-    const int row = m0 + rr, col = n0 + 4 * cq;
-    if (row < p.M && col < p.N) {
+    const int row = m0 + rr, cl = 16 * n + 4 * cq, col = n0 + cl;
+    if (row < p.M && col < p.N && cl < C::TN) {
       v2i o;
       o[0] = (int)pack_bf16x2(t[0] * alpha, t[1] * alpha);
       o[1] = (int)pack_bf16x2(t[2] * alpha, t[3] * alpha);
@@ -383,6 +410,28 @@ hipError_t launch_nvf4_os(NvGemmParams p, hipStream_t s, int tn) {
     else if (KT <= 24) hipLaunchKernelGGL((gemm_nvf4_os16_kernel<NvOs16Cfg<3>>), grid, block, 0, s, p);
     else if (KT <= 32) hipLaunchKernelGGL((gemm_nvf4_os16_kernel<NvOs16Cfg<4>>), grid, block, 0, s, p);
     else hipLaunchKernelGGL((gemm_nvf4_os16_kernel<NvOs16Cfg<4>, true>), grid, block, 0, s, p);
+    return hipSuccess;
+  }
+  if (tn == 1632 || tn == 1648 || tn == 1656 || tn == 856) {   // [r6] 16 rows x 32 / 48 / 56 columns per workgroup (856: only A rows 0 ... 7 fetched, M <= 8); K <= 4096 one shot, two refilled slots per wave beyond
+    const int cols = tn == 1632 ? 32 : tn == 1648 ? 48 : 56;
+    p.tiles_m = (p.M + 15) / 16;
+    p.tiles_n = (p.N + cols - 1) / cols;
+    const int KT = (p.K / 2 + 127) / 128;
+    const dim3 grid(p.tiles_m * p.tiles_n), block(512);
+#define QAMD_NVW(TN_, NPA_)                                                                                                         \
+    do {                                                                                                                            \
+      if (KT <= 8) hipLaunchKernelGGL((gemm_nvf4_os16_kernel<NvOs16Cfg<1, 1, TN_, NPA_>>), grid, block, 0, s, p);                    \
+      else if (KT <= 16) hipLaunchKernelGGL((gemm_nvf4_os16_kernel<NvOs16Cfg<2, 1, TN_, NPA_>>), grid, block, 0, s, p);              \
+      else hipLaunchKernelGGL((gemm_nvf4_os16_kernel<NvOs16Cfg<2, 1, TN_, NPA_>, true>), grid, block, 0, s, p);                      \
+    } while (0)
+    if (tn == 1632) QAMD_NVW(32, 2);
+    else if (tn == 1648) QAMD_NVW(48, 2);
+    else if (tn == 856) QAMD_NVW(56, 1);
+    else {   // 56 columns with all 16 A rows: 16 stages do not fit the LDS (164 KiB) -- one shot up to 8 stages, refilled slots beyond
+      if (KT <= 8) hipLaunchKernelGGL((gemm_nvf4_os16_kernel<NvOs16Cfg<1, 1, 56, 2>>), grid, block, 0, s, p);
+      else hipLaunchKernelGGL((gemm_nvf4_os16_kernel<NvOs16Cfg<1, 1, 56, 2>, true>), grid, block, 0, s, p);
+    }
+#undef QAMD_NVW
     return hipSuccess;
   }
   p.tiles_m = (p.M + 31) / 32;

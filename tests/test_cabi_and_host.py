@@ -165,7 +165,10 @@ def test_nvf4_tile_rule(lib):
         # [r6] -2 = the wave-owned small-batch kernel (csrc/gemm_nvf4_os.hip.h): M <= 128 with K <= 4096 up to three rounds of 32x32 tiles (rounds 3-5: the skinny kernel)
         # [r6] -4 = its decode form (16x16 tiles on the 16x16x32 MFMA) wherever those fit one per CU, and two per CU for M <= 16 with K <= 4096
         assert f(512, 4096, K, ws) == 2 and f(256, 4096, K, ws) == 3 and f(64, 4096, K, ws) == -2 and f(1, 4096, K, ws) == -4 and f(96, 4096, K, ws) == -2
-        assert f(16, 4096, K, ws) == -4 and f(17, 4096, K, ws) == -5 and f(32, 4096, K, ws) == -5 and f(33, 4096, K, ws) == -2 and f(32, 6144, K, ws) == -2 and f(64, 1024, K, ws) == -4 and f(128, 512, K, ws) == -4 and f(16, 8192, K, ws) == -4 and f(16, 8208, K, ws) == -1
+        assert f(16, 4096, K, ws) == -4 and f(17, 4096, K, ws) == -5 and f(32, 4096, K, ws) == -5 and f(33, 4096, K, ws) == -2 and f(32, 6144, K, ws) == -2 and f(64, 1024, K, ws) == -4 and f(128, 512, K, ws) == -4 and f(16, 8192, K, ws) == -6 and f(16, 8208, K, ws) == -7
+        # [r6] -6 ... -9: the decode form with 32 / 48 / 56 columns per workgroup (-9: 56 columns, A rows 0 ... 7 only) for M <= 16 against wider weights, K <= 8192
+        assert f(1, 6144, K, ws) == -6 and f(16, 12288, K, ws) == -7 and f(8, 14336, K, ws) == -9 and f(9, 14336, K, ws) == -8 and f(8, 14336, 8192, ws) == -8 and f(17, 12288, K, ws) not in (-6, -7, -8, -9)
+        assert f(8, 16384, K, ws) not in (-6, -7, -8, -9) and f(8, 14336, 14336, ws) not in (-6, -7, -8, -9)
         assert f(128, 4096, K, ws) == -2 and f(128, 6144, K, ws) == -2 and f(128, 8192, K, ws) != -2 and f(32, 14336, K, ws) == -2 and f(64, 14336, K, ws) != -2   # 512 / 768 tiles yes, 1024 / 896 no
         assert f(32, 28672, K, ws) == -1 and f(64, 28672, K, ws) == 3       # 64 rows against a wide weight: 448 tiles of 64x64 (26.6 us) beat the skinny kernel (36.7)
         assert f(512, 5120, 5120, ws) == 1 and f(384, 5120, 5120, ws) == 2  # 160 tiles of 128x128 (41.1 us) against 320 of 128x64 (47.0); 240 of 128x64 fit one per CU
@@ -176,7 +179,7 @@ def test_nvf4_tile_rule(lib):
     # [r6] long K on wave-owned rings: one 32x32 tile per CU at most (two rounds up to 32 stages), at least a quarter of the CUs busy, with or without scratch
     for ws in (0, 1):
         assert f(64, 4096, 14336, ws) == -2 and f(16, 4096, 8192, ws) == -4 and f(128, 4096, 8192, ws) == -2 and f(32, 8192, 8192, ws) == -2 and f(32, 4096, 8192, ws) == -5
-        assert f(16, 1024, 14336, ws) == -4 and f(64, 8192, 14336, ws) != -2 and f(16, 4096, 28672, ws) == -4 and f(32, 4096, 28672, ws) == -5 and f(64, 4096, 28672, ws) not in (-2, -4, -5) and f(16, 8192, 8192, ws) == -2
+        assert f(16, 1024, 14336, ws) == -4 and f(64, 8192, 14336, ws) != -2 and f(16, 4096, 28672, ws) == -4 and f(32, 4096, 28672, ws) == -5 and f(64, 4096, 28672, ws) not in (-2, -4, -5) and f(16, 8192, 8192, ws) == -6
     assert f(768, 4096, 14336, 0) == 1 and f(768, 4096, 14336, 1) == 1 + 256 * 4      # 192 tiles: 768 workgroups balance better than 192 (94.7 vs 108.3 us)
     assert f(1024, 5120, 25600, 0) == 4 and f(1024, 5120, 25600, 1) == 1 + 256 * 4    # 320 tiles of 128x128 x 4 (252 us) against 160 of 256x128 (300)
     assert f(64, 8192, 28672, 0) == -1 and f(64, 8192, 28672, 1) == 3 + 256 * 4       # 128 tiles of 64x64 x 4 (49.9 us) against the skinny kernel (69.5)
@@ -211,7 +214,7 @@ def test_split_plans_are_consistent_over_a_shape_grid(lib):
         n = int(rng.integers(1, 2048)) * 8
         k = int(rng.integers(1, 256)) * 128
         r0, r1 = nv(m, n, k, 0), nv(m, n, k, 1)
-        assert -5 <= r0 <= 4 and (r1 < 256 or (1 <= r1 % 256 <= 3 and 2 <= r1 // 256 <= 8)), (m, n, k, r0, r1)
+        assert -9 <= r0 <= 4 and (r1 < 256 or (1 <= r1 % 256 <= 3 and 2 <= r1 // 256 <= 8)), (m, n, k, r0, r1)
         b = nv_ws(m, n, k)
         assert b == (r1 // 256 if r1 >= 256 else 0) * m * n * 4, (m, n, k, r1, b)   # (256x256 tiles: the persistent kernel's balanced rounds need no scratch)
         for ebits in (4, 8):
