@@ -1613,7 +1613,7 @@ int qutlass_amd_fused_quantize_nv_blocked(const void* x, const void* h, int rot,
 // reference flow: qutlass/__init__.py:149-180 -> qutlass/utils.py:160-193 -> qutlass/__init__.py:34-76 = three launches)?
 //   1  ONE launch, qutlass_amd_fused_quantize_matmul_mxf4_bf16_tn (gemm_mx_fusedq.hip.h: the small-batch GEMM rotates and quantises its own A operand).  It repeats
 //      the rotate + quantize chains of its K slices in every workgroup -- ceil(K / 2048) x (1, 2, 4 for M <= 4, 8, 16) chains per wave -- and wins while that stays
-//      short: M <= 4: K <= 8192, M <= 8: K <= 6144, M <= 16: K <= 4096, R = 32, and a weight the small-batch GEMM handles (N < 32 x CUs = 8192 on an MI355X).
+//      short: [r6] M <= 4: K <= 4096, M <= 8: K <= 2048 (see below), R = 32, and a weight the small-batch GEMM handles (N < 32 x CUs = 8192 on an MI355X).
 //      M = 1 / 8 / 16 at N = K = 4096: 5.0 / 6.0 / 7.6 us against 7.3 / 7.9 / 8.2 us for two launches and 9.0 / 9.5 / 9.9 for three (GEMM alone 4.6 / 4.9 / 5.3);
 //      M = 32 or K = 14336 lose (14.2 vs 9.0 us, 12.6 vs 10.7 us).
 //   2  TWO launches everywhere else: qutlass_amd_fused_quantize_mx_blocked (scales written in the to_blocked layout) + the GEMM.  The blocked quantizer costs
@@ -1625,7 +1625,11 @@ int qutlass_amd_activation_path_launches(int64_t M, int64_t N, int64_t K, int ro
   if (M <= 0 || N <= 0 || K <= 0) return 2;
   const int cus = chip_cus();
   if (M > 16 || rot != 32 || N >= 32ll * cus || K % 128) return 2;
-  return K <= (M <= 4 ? 8192 : M <= 8 ? 6144 : 4096) ? 1 : 2;
+  // [r6] re-taken after the decode forms made the GEMM of the two-launch path faster (N = K = 4096, M <= 16: 4.6-5.3 -> 2.85-3.0 us; tools/calib_actpath.py,
+  // profiles/calib_actpath_r7.txt): two launches now take 5.2-5.7 us at N = K = 4096 where the one-launch kernel takes 5.1 / 5.3 / 6.2 / 8.1 (M = 1 / 4 / 8 / 16), 6.4 against
+  // 8.4-8.8 at 4096 x 8192 -- one launch keeps M <= 4 with K <= 4096 (4096 x 6144: a tie) and M <= 8 with K <= 2048 (3.8-4.4 against 4.6-4.9); rounds 3-5: M <= 4: K <= 8192,
+  // M <= 8: K <= 6144, M <= 16: K <= 4096
+  return K <= (M <= 4 ? 4096 : M <= 8 ? 2048 : 0) ? 1 : 2;
 }
 
 // decode-time activation path in one launch (gemm_mx_fusedq.hip.h): D = alpha * Q(x . h) (B . SFB)^T for M <= 32
