@@ -215,7 +215,7 @@ def main():
         xa_sf = to_blocked(xa_s)
         wq, wsf = w_q[:nn], to_blocked(w_s.view(torch.uint8).reshape(-1)[: nn * 128].reshape(nn, 128).view(torch.float8_e8m0fnu))
         wbytes = nn * 4096 // 2 + nn * 128 + mm * 4096 // 2 + 2 * mm * nn
-        for var, tag in ((0, "auto: one-shot kernel (wave-owned K stages) / 32x64 K-split ring for wide weights"), (2, "128x128 lockstep"), (24, "128x128 simple")):
+        for var, tag in ((0, "auto: decode form (16 x 16 ... 64 tiles, wave-owned K stages) for M <= 16, one-shot 32-row tiles beyond"), (2, "128x128 lockstep"), (24, "128x128 simple")):
             impl = q if var == 0 else lab
             with lab.forced(gemm_variant=var):
                 us = time_us(lambda: impl.matmul_mxf4_bf16_tn(xa_q, wq, xa_sf, wsf, alpha), args.iters)
@@ -229,7 +229,7 @@ def main():
         xa_q, xa_s = q.fusedQuantizeMx(xa, h32, method="abs_max")
         xa_sf = to_blocked(xa_s)
         wbytes = 4096 * 14336 // 2 + 4096 * 448 + mm * 14336 // 2 + 2 * mm * 4096
-        for var, tag in ((0, "auto: one-shot kernel on wave-owned rings / ring tiles, split-K when < 256 tiles"), (29, "64x64 simple (2-stage)")):
+        for var, tag in ((0, "auto: decode form / wave-owned rings / ring tiles, split-K when < 256 tiles"), (29, "64x64 simple (2-stage)")):
             impl = q if var == 0 else lab
             with lab.forced(gemm_variant=var):
                 us = time_us(lambda: impl.matmul_mxf4_bf16_tn(xa_q, w2_q, xa_sf, w2_sf, alpha), args.iters)

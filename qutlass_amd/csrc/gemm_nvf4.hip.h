@@ -880,7 +880,17 @@ inline NvPlan nvf4_plan(int64_t M, int64_t N, int64_t K, int cus, bool may_split
     }
   if (M <= 256) {
     const double wg = (double)(((M + 31) / 32) * ((N + 31) / 32));
-    if (2.53 + 4.66 * std::ceil(wg / cus) * K / 4096.0 < best_t) return {-1, 1, 0};
+    const double t_skinny = 2.53 + 4.66 * std::ceil(wg / cus) * K / 4096.0;
+    // [r6] the wave-owned 32x32 kernel where nv_os_plan's occupancy rule passed the shape on (a part-filled last round, or M = 129 ... 256): up to four rounds of tiles with
+    // K <= 4096 cost 1.75 + 4.05 us per round (N = 4096, M = 64 / 128: 5.7 / 9.8 us; 6144 x 4096, M = 128: 13.85) against 2.53 + 4.66 per round for the split-K kernel --
+    // the dip scan found M = 192 slower than M = 256 at N = K = 4096 (16.8 vs 15.7 us) and M = 96 slower than M = 128 at N = 6144 (16.9 vs 13.9): profiles/dip_scan_r7z.txt
+    const double rounds = std::ceil(wg / cus);
+    // ... and the same on its wave-owned rings up to K = 8192 (+5 % per round: 2048 x 8192, M = 160 ... 256: 19.0-23.1 -> 17.0-17.8 us; 5120^2, M = 64 / 128: 14.1 / 19.9 -> 12.6 / 18.5)
+    if (KT <= 32 && rounds <= 4.0) {   // (four rounds: 6144 x 4096, M = 160: 21.4 -> 17.7 us; where 64x64 tiles fit one round -- N = 4096, M = 256: 15.5 -- their model is lower and they stay)
+      const double t_os = 1.75 + 4.05 * rounds * KT / 16.0 * (KT > 16 ? 1.05 : 1.0);
+      if (t_os < t_skinny && t_os < best_t) return {-2, 1, 0};
+    }
+    if (t_skinny < best_t) return {-1, 1, 0};
   }
   if (M > 128 && N > 128 && tiles(128, 128) >= cus * 3 / 4) {   // the large-output model above; a split only where it beats that model's time by 5 %
     double tb;

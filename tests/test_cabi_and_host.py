@@ -183,9 +183,9 @@ def test_nvf4_tile_rule(lib):
     assert f(768, 4096, 14336, 0) == 1 and f(768, 4096, 14336, 1) == 1 + 256 * 4      # 192 tiles: 768 workgroups balance better than 192 (94.7 vs 108.3 us)
     assert f(1024, 5120, 25600, 0) == 4 and f(1024, 5120, 25600, 1) == 1 + 256 * 4    # 320 tiles of 128x128 x 4 (252 us) against 160 of 256x128 (300)
     assert f(64, 8192, 28672, 0) == -1 and f(64, 8192, 28672, 1) == 3 + 256 * 4       # 128 tiles of 64x64 x 4 (49.9 us) against the skinny kernel (69.5)
-    assert f(1024, 4096, 14336, 1) == 1 and f(256, 2048, 2048, 1) == -1 and f(384, 2048, 2048, 1) == 3   # a full round already / K too short (8 stages): the skinny
+    assert f(1024, 4096, 14336, 1) == 1 and f(256, 2048, 2048, 1) == -2 and f(384, 2048, 2048, 1) == 3   # a full round already / K too short (8 stages): the skinny
     # kernel up to 256 rows where its 32x32 workgroups still fit two per CU (GPU-only timing: 7.4 us against 9.6 on 64x64 tiles), 64x64 tiles beyond
-    assert f(192, 4096, 4096, 1) == -1 and f(256, 4096, 4096, 1) == 3
+    assert f(192, 4096, 4096, 1) == -2 and f(256, 4096, 4096, 1) == 3 and f(96, 6144, 4096, 1) == -2   # [r6] (three rounds of the wave-owned 32x32 kernel: 13.9 us; rounds 3-5: skinny, 16.8)
     # the workspace query describes the same plan: ranges x M x N fp32
     g = lib.qutlass_amd_nvf4_splitk_workspace_bytes
     assert g(256, 4096, 14336) == 4 * 256 * 4096 * 4 and g(128, 4096, 14336) == 7 * 128 * 4096 * 4 and g(200, 4104, 14368) == 8 * 200 * 4104 * 4

@@ -306,7 +306,8 @@ def test_one_shot_kernel_with_row_major_scales_against_the_oracle(q, m, n, k):
             assert np.array_equal(_np(lab.matmul_ada_mxf4_bf16_tn(a, b, sa, sb, alpha)), ref), v
 
 
-@pytest.mark.parametrize("m,n,k", [(1, 4096, 4096), (8, 8192, 4096), (48, 4096, 4096), (64, 4096, 14336), (16, 14336, 4096), (200, 1024, 2048)])
+@pytest.mark.parametrize("m,n,k", [(1, 4096, 4096), (8, 8192, 4096), (48, 4096, 4096), (64, 4096, 14336), (16, 14336, 4096), (200, 1024, 2048),
+                                   (16, 12288, 4096), (9, 11008, 5120), (128, 4096, 2048), (4, 16384, 4096)])   # (the last four: decode forms with 48 / 48 / - / 64 columns, 64-row tiles)
 def test_product_rule_takes_the_ks_kernel_and_matches_the_oracle(q, m, n, k):
     """shapes capi.hip's ks_plan sends to the new kernel (tests/test_cabi_and_host.py pins the plan on the CPU), through the product library and the torch op"""
     a, b, sa, sb = _mx_operands_exact(m, n, k, m + n + k)
@@ -451,7 +452,7 @@ def test_mxf8_wave_owned_kernel_on_quantised_gaussians(variant, m, n, k):
     assert _mxfp8_close(_np(out), ref).all()
 
 
-@pytest.mark.parametrize("m,n,k", [(1, 4096, 4096), (16, 4096, 4096), (64, 4096, 4096), (128, 4096, 4096), (32, 8192, 2048), (8, 2048, 8192)])
+@pytest.mark.parametrize("m,n,k", [(1, 4096, 4096), (16, 4096, 4096), (64, 4096, 4096), (128, 4096, 4096), (32, 8192, 2048), (8, 2048, 8192), (8, 8192, 4096), (16, 11008, 4096)])
 def test_product_rule_on_mxf8_small_batches_matches_the_oracle(q, m, n, k):
     """shapes the product sends to the wave-owned kernel (capi.hip os8_plan; pinned on the CPU in tests/test_cabi_and_host.py), through the product library and the torch op,
     exact-regime operands: every output element equal to the oracle's"""
