@@ -847,6 +847,9 @@ inline int nv_os_plan(int64_t M, int64_t N, int64_t K, int cus) {
   if (M <= 16 && KT <= 32) {
     for (int tn : {32, 48, 56})
       if ((N + tn - 1) / tn <= cus) return tn == 56 ? ((M <= 8 && KT <= 16) ? 856 : 1656) : 1600 + tn;
+    // wider still (the fused up / gate projections, N = 24576 / 28672): 48 columns per workgroup in two or three rounds, K <= 4096 (24576 x 4096: 14.9-15.4 -> 13.2 us,
+    // 28672 x 4096, M = 16: 20.6 -> 17.6; 16384: a tie, left alone)
+    if (KT <= 16 && N >= 20480 && (N + 47) / 48 <= 3 * (int64_t)cus) return 1648;
   }
   // 3216 = the same with two m-tiles per workgroup (a B dword dequantised once for both): where 32x16 tiles fit one per CU (N = 4096, M = 17 ... 32: K = 4096 5.35 -> 4.75 us,
   // K = 14336 14.1 -> 11.7, K = 28672 30-36 -> 20)

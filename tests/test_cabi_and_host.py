@@ -169,6 +169,7 @@ def test_nvf4_tile_rule(lib):
         # [r6] -6 ... -9: the decode form with 32 / 48 / 56 columns per workgroup (-9: 56 columns, A rows 0 ... 7 only) for M <= 16 against wider weights, K <= 8192
         assert f(1, 6144, K, ws) == -6 and f(16, 12288, K, ws) == -7 and f(8, 14336, K, ws) == -9 and f(9, 14336, K, ws) == -8 and f(8, 14336, 8192, ws) == -8 and f(17, 12288, K, ws) not in (-6, -7, -8, -9)
         assert f(8, 16384, K, ws) not in (-6, -7, -8, -9) and f(8, 14336, 14336, ws) not in (-6, -7, -8, -9)
+        assert f(16, 28672, K, ws) == -7 and f(1, 24576, K, ws) == -7 and f(16, 28672, 8192, ws) != -7 and f(17, 28672, K, ws) != -7   # two / three rounds of 48-column workgroups, K <= 4096
         assert f(128, 4096, K, ws) == -2 and f(128, 6144, K, ws) == -2 and f(128, 8192, K, ws) != -2 and f(32, 14336, K, ws) == -2 and f(64, 14336, K, ws) != -2   # 512 / 768 tiles yes, 1024 / 896 no
         assert f(32, 28672, K, ws) == -1 and f(64, 28672, K, ws) == 3       # 64 rows against a wide weight: 448 tiles of 64x64 (26.6 us) beat the skinny kernel (36.7)
         assert f(512, 5120, 5120, ws) == 1 and f(384, 5120, 5120, ws) == 2  # 160 tiles of 128x128 (41.1 us) against 320 of 128x64 (47.0); 240 of 128x64 fit one per CU
