@@ -463,3 +463,45 @@ def test_product_rule_on_mxf8_small_batches_matches_the_oracle(q, m, n, k):
     got = q.matmul_mxf8_bf16_tn(a.view(e4), b.view(e4), to_blocked(sa.view(e8)), to_blocked(sb.view(e8)), torch.tensor([1.0], device=DEV))
     ref = oracle.gemm_blockscaled(oracle.KIND_MXFP8_TN, _np(a), _np(b), oracle.to_blocked(_np(sa)), oracle.to_blocked(_np(sb)), 1.0, m, n, k)
     assert np.array_equal(_np(got), ref)
+
+
+# ------------------------------------------------------------------------------------------------
+# [r6] decode forms through the PRODUCT rules on ragged wide weights: M = 1 ... 16 (17 ... 32 for the NVFP4 32x16 form), N anywhere in 4104 ... 16384 (a multiple of 8, so the last
+# 32 / 48 / 56 / 64-column workgroup is part-filled and its B rows / scale rows fall off the operand), K inside and outside the one-shot range -- exact-regime operands, every
+# output element against the oracle
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("fmt", ["mxf4", "ada", "mxf8", "nvf4"])
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_decode_forms_on_ragged_wide_weights(q, fmt, seed):
+    from qutlass_amd.utils import to_blocked
+
+    rng = np.random.default_rng(1000 * seed + len(fmt))
+    e8, e4 = torch.float8_e8m0fnu, torch.float8_e4m3fn
+    for _ in range(3):
+        m = int(rng.integers(1, 33 if fmt == "nvf4" else 17))
+        n = int(rng.integers(513, 2049)) * 8
+        k = int(rng.choice([1024, 2048, 3072, 4096, 5120, 8192])) if fmt != "mxf8" else int(rng.choice([1024, 2048, 4096, 4128]))
+        alpha = torch.tensor([0.5], device=DEV)
+        if fmt in ("mxf4", "ada"):
+            a = torch.from_numpy(rng.integers(0, 256, size=(m, k // 2), dtype=np.uint8)).to(DEV)
+            b = torch.from_numpy(rng.integers(0, 256, size=(n, k // 2), dtype=np.uint8)).to(DEV)
+            sa = torch.from_numpy(rng.integers(125, 129, size=(m, k // 32), dtype=np.uint8)).to(DEV)
+            sb = torch.from_numpy(rng.integers(125, 129, size=(n, k // 32), dtype=np.uint8)).to(DEV)
+            if fmt == "ada":
+                got = q.matmul_ada_mxf4_bf16_tn(a, b, sa.view(e8), sb.view(e8), alpha)
+            else:
+                got = q.matmul_mxf4_bf16_tn(a, b, to_blocked(sa.view(e8)), to_blocked(sb.view(e8)), alpha)
+            ref = oracle.gemm_blockscaled(oracle.KIND_MXFP4, _np(a), _np(b), oracle.to_blocked(_np(sa)), oracle.to_blocked(_np(sb)), 0.5, m, n, k)
+        elif fmt == "mxf8":
+            a, b, sa, sb = _exact_fp8_operands(m, n, k, int(rng.integers(0, 1 << 30)))
+            got = q.matmul_mxf8_bf16_tn(a.view(e4), b.view(e4), to_blocked(sa.view(e8)), to_blocked(sb.view(e8)), alpha)
+            ref = oracle.gemm_blockscaled(oracle.KIND_MXFP8_TN, _np(a), _np(b), oracle.to_blocked(_np(sa)), oracle.to_blocked(_np(sb)), 0.5, m, n, k)
+        else:
+            a = torch.from_numpy(rng.integers(0, 256, size=(m, k // 2), dtype=np.uint8)).to(DEV)
+            b = torch.from_numpy(rng.integers(0, 256, size=(n, k // 2), dtype=np.uint8)).to(DEV)
+            sa = torch.from_numpy(rng.integers(0x30, 0x48, size=(m, k // 16), dtype=np.uint8)).to(DEV)
+            sb = torch.from_numpy(rng.integers(0x30, 0x48, size=(n, k // 16), dtype=np.uint8)).to(DEV)
+            got = q.matmul_nvf4_bf16_tn(a, b, to_blocked(sa.view(e4)), to_blocked(sb.view(e4)), alpha)
+            ref = oracle.gemm_blockscaled(oracle.KIND_NVFP4, _np(a), _np(b), oracle.to_blocked(_np(sa)), oracle.to_blocked(_np(sb)), 0.5, m, n, k)
+        bad = _np(got) != ref
+        assert not bad.any(), f"{fmt} {m}x{n}x{k}: {int(bad.sum())} of {bad.size} outputs differ, first at {np.argwhere(bad)[0].tolist()}"
