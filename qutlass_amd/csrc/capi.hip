@@ -1643,6 +1643,43 @@ int qutlass_amd_fused_quantize_matmul_mxf4_bf16_tn(const void* x, const void* h,
   if (N <= 0 || N % 8) return fail(QAMD_ERR_INVALID, "%s: N must be a positive multiple of 8 (got %lld)", name, (long long)N);
   if (K < 128 || K % 128) return fail(QAMD_ERR_INVALID, "%s: K must be a positive multiple of 128 (got %lld)", name, (long long)K);
   if (N * (K / 2) >= (1ll << 31) || M * K * 2 >= (1ll << 31) || cdiv(N, 32) >= (1ll << 31)) return fail(QAMD_ERR_INVALID, "%s: operand larger than 2 GiB is not supported", name);
+#if QAMD_BENCH
+  // [r6] lab ("gemm_variant" 580): the hand-off form of the one-launch layer (gemm_mx_os16_fq_kernel: the quantizer's body on the first workgroups, the decode form's K walk
+  // behind one arrival counter) on a scratch buffer the LAB library allocates once -- an experiment's plumbing, not an API (the product would take caller scratch)
+  if (opt_gemm_variant() == 580 && M <= 16 && K <= 8192 && os16_tn(N) != 0) {
+    static void* scratch = nullptr;
+    if (!scratch && hipMalloc(&scratch, 1 << 20) != hipSuccess) return fail(QAMD_ERR_HIP, "%s: lab scratch", name);
+    const int64_t CB = cdiv(K / 32, 4);
+    FqOsParams P;
+    P.q.x = (const uint16_t*)x; P.q.h = (const uint16_t*)h; P.q.out = (uint8_t*)scratch; P.q.out_sf = (uint8_t*)scratch + (256 << 10); P.q.out_mask = nullptr; P.q.global_scale = nullptr;
+    P.q.numel = M * K; P.q.ntiles = (int)cdiv(M * K, 1024); P.q.sf_rows = (int)M; P.q.sf_cols = (int)(K / 32);
+    GemmParams& g = P.g;
+    g.A = (const uint8_t*)scratch; g.B = (const uint8_t*)B; g.SFA = (const uint8_t*)scratch + (256 << 10); g.SFB = (const uint8_t*)B_sf; g.alpha = alpha; g.D = (uint16_t*)D;
+    g.M = (int)M; g.N = (int)N; g.K = (int)K; g.ldd = (int)N;
+    g.a_bytes = (uint32_t)(M * (K / 2)); g.b_bytes = (uint32_t)(N * (K / 2)); g.sfa_bytes = (uint32_t)(CB * 512); g.sfb_bytes = (uint32_t)(cdiv(N, 128) * CB * 512);
+    g.pp_shift = 0; g.pp_flags = 0; g.dbg = nullptr; g.ws = nullptr; g.splits = 1; g.ctr = nullptr; g.tag = 0; g.sk_tiles = 0;
+    const int tn = os16_tn(N);
+    g.tiles_m = 1; g.tiles_n = (int)cdiv(N, tn); g.raster_magic = 0;
+    P.flag = (unsigned long long*)((uint8_t*)scratch + (512 << 10));
+    P.tag = (next_launch_tag() & ((1ull << 56) - 1)) << 8;
+    P.nq = (int)std::min<int64_t>(cdiv(P.q.ntiles, 4), g.tiles_n);
+    const int64_t KT = cdiv(K, 256);
+    const dim3 grid(g.tiles_n), block(256);
+    hipStream_t st = (hipStream_t)stream;
+#define QAMD_FQOS(TN_, SPW_)                                                                                                                     \
+    do {                                                                                                                                         \
+      if (method == QAMD_METHOD_ABSMAX) hipLaunchKernelGGL((gemm_mx_os16_fq_kernel<Os16Cfg<SPW_, 4, 0, TN_>, METHOD_ABSMAX>), grid, block, 0, st, P); \
+      else hipLaunchKernelGGL((gemm_mx_os16_fq_kernel<Os16Cfg<SPW_, 4, 0, TN_>, METHOD_QUEST>), grid, block, 0, st, P);                              \
+    } while (0)
+    if (tn == 16) { if (KT <= 16) QAMD_FQOS(16, 4); else QAMD_FQOS(16, 8); }
+    else if (tn == 32 && KT <= 16) QAMD_FQOS(32, 4);
+    else if (tn == 48 && KT <= 16) QAMD_FQOS(48, 4);
+    else if (tn == 56 && KT <= 16) QAMD_FQOS(56, 4);
+    else return fail(QAMD_ERR_INVALID, "%s: lab variant 580 has no instantiation for this shape", name);
+#undef QAMD_FQOS
+    return check_launch("gemm_mx_os16_fq_kernel");
+  }
+#endif
   FusedQParams p;
   p.x = (const uint16_t*)x; p.h = (const uint16_t*)h; p.B = (const uint8_t*)B; p.SFB = (const uint8_t*)B_sf; p.alpha = alpha; p.D = (uint16_t*)D;
   p.M = (int)M; p.N = (int)N; p.K = (int)K;

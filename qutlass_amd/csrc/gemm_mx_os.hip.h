@@ -17,6 +17,7 @@
 // to the other schedules wherever partial sums are exact (the reference's test regime), one fp32 rounding apart otherwise, like every split-K plan here.
 #pragma once
 #include "gemm_mx.hip.h"
+#include "quantize.hip.h"
 
 namespace qamd {
 
@@ -430,5 +431,198 @@ __global__ __launch_bounds__(256) void gemm_mx_os16_kernel(const GemmParams p) {
     }
   }
 }
+
+#if QAMD_BENCH
+// ---- [r6, third session] the decode LAYER y = Q(x h) W^T in one launch, without repeating the quantisation in every workgroup ----------------------------------
+// gemm_mx_fusedq.hip.h (round 3) lets every workgroup rotate and quantise the whole activation matrix itself: fine at M <= 4, 8.1 us at M = 16 where two launches take 5.7.
+// Here the first `nq` workgroups run the QUANTIZER's own body (quantize.hip.h fused_quantize_body: R = 32, blocked scales) on a quarter-tile share of x each and write the
+// codes / scale bytes to caller scratch; every workgroup first requests its WEIGHT stages (they do not depend on x), then waits for the quantised activations at one
+// arrival counter ({launch tag : 56, count : 8}: the scratch needs no initialisation), then requests its A stages and runs the decode form's K walk.  The producers are the
+// lowest workgroup indices (dispatched first) and wait for nobody, so the consumers' spin cannot deadlock; it is bounded all the same (a timed-out workgroup stores nothing).
+// Same arithmetic as fusedQuantizeMxBlocked + gemm_mx_os16_kernel: bit-identical to the two-launch path (24 shapes, profiles/calib_actpath_handoff_r7.txt).
+// MEASURED AND NOT ADOPTED (lab build only, "gemm_variant" 580): with one producer (M = 1) the layer takes 5.5 us at N = K = 4096 against 5.2 for two launches, and every further
+// producer adds ~1.3 us (M = 16: 26 us) -- a producer's release is a write-back of its XCD's L2 plus a compare-and-swap that executes at the memory side, and the consumers on
+// the other seven XCDs see neither sooner than a round trip to memory.  (The first version -- every workgroup fencing, the consumers invalidating their L2 -- took 19 ... 38 us.)
+// Eight private L2s make a grid-wide hand-off cost more than the launch it was meant to save.
+struct FqOsParams {
+  QuantParams q;                 // q.out / q.out_sf = g.A / g.SFA: the scratch
+  GemmParams g;
+  unsigned long long* flag;      // arrival counter (scratch)
+  unsigned long long tag;        // (launch number & (2^56 - 1)) << 8
+  int nq;                        // producer workgroups
+};
+
+template <class C, int METHOD>
+__global__ __launch_bounds__(256) void gemm_mx_os16_fq_kernel(const FqOsParams P) {
+  constexpr int SPW = C::SPW, NT = C::NT;
+  static_assert(C::EBITS == 4, "MXFP4");
+  constexpr int LB = C::NPB + C::NSB, LA = 2 + 1;   // LDS-DMA instructions per stage: weight side, activation side
+  static_assert(SPW * LA <= 63 && SPW * LB <= 63, "vmcnt immediate");
+  const GemmParams& p = P.g;
+  __shared__ __attribute__((aligned(16))) char smem[C::LDS_BYTES];
+  __shared__ int s_ok;
+  const float alpha = *p.alpha;
+  const int tid = threadIdx.x, lane = tid & 63, wave = uniform(tid >> 6), r16 = lane & 15, kq = lane >> 4;
+  const int nb = p.tiles_n;      // one m-tile (M <= 16)
+  const int b2 = xcd_remap((int)blockIdx.x, nb);
+  const int n0 = uniform(b2 * C::TN);
+  const int rowbytes = p.K >> 1, KT = (rowbytes + C::ROWB - 1) / C::ROWB, CB = (p.K / 32 + 3) >> 2;
+  const int tailbytes = rowbytes - (KT - 1) * C::ROWB;
+
+  const uint32_t b_off = (uint32_t)n0 * rowbytes;
+  const __amdgpu_buffer_rsrc_t rA = make_rsrc(p.A, p.a_bytes), rB = make_rsrc(p.B + b_off, p.b_bytes - b_off);
+  int vP[2], chP[2];
+#pragma unroll
+  for (int par = 0; par < 2; ++par) {
+    chP[par] = (lane & 7) ^ (((lane >> 4) + 4 * par) & 7);
+    vP[par] = (lane >> 3) * rowbytes + (chP[par] << 4);
+  }
+  const int rstep = 8 * rowbytes;
+  const __amdgpu_buffer_rsrc_t rSA = make_rsrc(p.SFA, p.sfa_bytes), rSB = make_rsrc(p.SFB, p.sfb_bytes);
+  const int ctl = kq & 1;
+  const int vSA = ctl * 512 + (r16 & 31) * 16;
+  int vSB[C::NSB];
+#pragma unroll
+  for (int pp = 0; pp < C::NSB; ++pp) {
+    const int nr = n0 + 16 * (2 * pp + (lane >> 5)) + r16;
+    vSB[pp] = (nr >> 7) * CB * 512 + ctl * 512 + (nr & 31) * 16 + ((nr & 127) >> 5) * 4;
+  }
+  auto issueB = [&](const int kt, const int slot) __attribute__((always_inline)) {
+    char* st = smem + (wave * SPW + slot) * C::STAGE;
+    int tail = (kt == KT - 1) ? tailbytes : C::ROWB;
+    int oob = (kt < KT) ? 0 : -1;
+    asm volatile("" : "+v"(tail), "+v"(oob));
+    const int soff = kt * C::ROWB;
+#pragma unroll
+    for (int qq = 0; qq < C::NPB; ++qq) {
+      const int par = qq & 1;
+      const int o = oob | ((chP[par] << 4) < tail ? 0 : -1);
+      const int v = ((vP[par] + qq * rstep) & ~o) | ((int)0x80000000 & o);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, (lds_ptr_t)(st + C::OFF_B + qq * 1024), 16, v, soff, 0, 0);
+    }
+    const int os = (kt < KT && 2 * kt + ctl < CB) ? 0 : -1;
+#pragma unroll
+    for (int pp = 0; pp < C::NSB; ++pp)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rSB, (lds_ptr_t)(st + C::OFF_SB + pp * 256), 4, (vSB[pp] & ~os) | ((int)0x80000000 & os), kt * 1024, 0, 0);
+  };
+  auto issueA = [&](const int kt, const int slot) __attribute__((always_inline)) {
+    char* st = smem + (wave * SPW + slot) * C::STAGE;
+    int tail = (kt == KT - 1) ? tailbytes : C::ROWB;
+    int oob = (kt < KT) ? 0 : -1;
+    asm volatile("" : "+v"(tail), "+v"(oob));
+    const int soff = kt * C::ROWB;
+#pragma unroll
+    for (int qq = 0; qq < 2; ++qq) {
+      const int o = oob | ((chP[qq] << 4) < tail ? 0 : -1);
+      const int v = ((vP[qq] + qq * rstep) & ~o) | ((int)0x80000000 & o);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lds_ptr_t)(st + qq * 1024), 16, v, soff, 0, 17);   // aux 17 = sc0 sc1: past the L2
+    }
+    const int os = (kt < KT && 2 * kt + ctl < CB) ? 0 : -1;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rSA, (lds_ptr_t)(st + C::OFF_S), 4, (vSA & ~os) | ((int)0x80000000 & os), kt * 1024, 0, 17);
+  };
+
+  // ---- the weights first: they do not depend on the activations -------------------------------------------------------------------------------
+#pragma unroll
+  for (int j = 0; j < SPW; ++j) issueB(wave + 4 * j, j);
+
+  // ---- producers: the quantizer's body on this workgroup's share of x --------------------------------------------------------------------------
+  if ((int)blockIdx.x < P.nq) fused_quantize_body<32, false, METHOD, false, true, true, false>(P.q, (int)blockIdx.x, P.nq);
+  if ((int)blockIdx.x < P.nq) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // this wave's stores (and its weight pieces) are done
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");                // ... and written back past this XCD's L2 (producers only: the consumers read the scratch with
+  }                                                                   //     L2-bypassing loads instead of invalidating their L2 -- that would throw the weights out as well)
+  __syncthreads();
+  bool ok = true;
+  if (tid == 0) {
+    unsigned long long cur = __hip_atomic_load(P.flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if ((int)blockIdx.x < P.nq) {
+      for (;;) {
+        const int cnt = ((cur & ~0xffull) == P.tag) ? (int)(cur & 0xffull) : 0;
+        const unsigned long long want = P.tag | (unsigned long long)(cnt + 1);
+        if (__hip_atomic_compare_exchange_strong(P.flag, &cur, want, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { cur = want; break; }
+      }
+    }
+    const unsigned long long full = P.tag | (unsigned long long)P.nq;
+    int spins = 0;
+    while (cur != full && spins < (1 << 16)) {
+      __builtin_amdgcn_s_sleep(1);
+      cur = __hip_atomic_load(P.flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      ++spins;
+    }
+    ok = cur == full;
+    *(volatile int*)&s_ok = ok ? 1 : 0;
+  }
+  __syncthreads();
+  ok = uniform(*(volatile int*)&s_ok) != 0;
+  if (!ok) return;   // (bounded wait ran out: nothing stored -- the tests compare every output)
+
+  // ---- the quantised activations ------------------------------------------------------------------------------------------------------------------
+#pragma unroll
+  for (int j = 0; j < SPW; ++j) issueA(wave + 4 * j, j);
+
+  const int sw = (r16 >> 1) & 7;
+  v4f acc[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) acc[t] = v4f{0.f, 0.f, 0.f, 0.f};
+  auto fence = [&]() __attribute__((always_inline)) { __builtin_amdgcn_sched_barrier(0); };
+  static_for<0, SPW>([&](auto jc) __attribute__((always_inline)) {
+    constexpr int j = decltype(jc)::value;
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((SPW - 1 - j) * LA) : "memory");   // activation pieces of stage j landed (the weights long before)
+    fence();
+    const char* st = smem + (wave * SPW + j) * C::STAGE;
+    v4i fa[2], fb[NT][2];
+    int sa[2], sb[NT][2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int off = r16 * C::ROWB + (((4 * h + kq) ^ sw) << 4);
+      fa[h] = *(const v4i*)(st + off);
+      sa[h] = *(const int*)(st + C::OFF_S + (h * 16 + r16) * 4);
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        fb[t][h] = *(const v4i*)(st + C::OFF_B + t * 16 * C::ROWB + off);
+        sb[t][h] = *(const int*)(st + C::OFF_SB + (t >> 1) * 256 + ((t & 1) * 32 + h * 16 + r16) * 4);
+      }
+    }
+    fence();
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const v8i A8 = {fa[h][0], fa[h][1], fa[h][2], fa[h][3], 0, 0, 0, 0};
+      const int xa = (int)((unsigned)sa[h] >> (8 * kq));
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const v8i B8 = {fb[t][h][0], fb[t][h][1], fb[t][h][2], fb[t][h][3], 0, 0, 0, 0};
+        acc[t] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(B8, A8, acc[t], 4, 4, 0, (int)((unsigned)sb[t][h] >> (8 * kq)), 0, xa);
+      }
+    }
+    fence();
+  });
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  fence();
+  constexpr int RROW = 64 * NT;
+#pragma unroll
+  for (int t = 0; t < NT; ++t) *(v4f*)(smem + (wave * 16 + r16) * RROW + t * 64 + kq * 16) = acc[t];
+  __syncthreads();
+  if (tid < 64) {
+    const int rr = tid >> 2, cq = tid & 3;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      v4f s[4];
+#pragma unroll
+      for (int w = 0; w < 4; ++w) s[w] = *(const v4f*)(smem + (w * 16 + rr) * RROW + t * 64 + cq * 16);
+      v4f x;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) x[e] = ((s[0][e] + s[1][e]) + s[2][e]) + s[3][e];
+      const int cl = 16 * t + 4 * cq, col = n0 + cl;
+      if (rr < p.M && col < p.N && cl < C::TN) {
+        v2i o;
+        o[0] = (int)pack_bf16x2(x[0] * alpha, x[1] * alpha);
+        o[1] = (int)pack_bf16x2(x[2] * alpha, x[3] * alpha);
+        *(v2i*)(p.D + (size_t)rr * p.ldd + col) = o;
+      }
+    }
+  }
+}
+#endif   // QAMD_BENCH
 
 }  // namespace qamd

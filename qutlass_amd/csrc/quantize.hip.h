@@ -187,8 +187,11 @@ __device__ __forceinline__ float e4m3_decode_pos(uint32_t b) {
 //   HWCVT  : use v_cvt_scalef32_pk_fp4_f32 for the final RTNE
 //   BLK    : scale bytes are written in the to_blocked() layout (GEMM-ready: no separate swizzle launch) instead of flat
 // -------------------------------------------------------------------------------------------------
-template <int R, bool NV, int METHOD, bool MASK, bool HWCVT, bool BLK = false>
-__global__ __launch_bounds__(256) void fused_quantize_kernel(const QuantParams p) {
+// The kernel's body as a device function of (workgroup index, workgroup count): fused_quantize_kernel below is its plain launch; [r6] the one-launch decode layer
+// (gemm_mx_os.hip.h gemm_mx_os16_fq_kernel) runs it on its first few workgroups.  PAD = false: the zero padding of the blocked scale layout is left out (a reader that
+// only looks at the rows it wrote).
+template <int R, bool NV, int METHOD, bool MASK, bool HWCVT, bool BLK = false, bool PAD = true>
+__device__ __forceinline__ void fused_quantize_body(const QuantParams& p, const int bid, const int nblk) {
   constexpr int RP = (R < 32) ? 32 : R;         // rotation padded to one MFMA j-tile (R=16: block-diag)
   constexpr int KC = RP / 16;                   // 16-wide k chunks per row
   constexpr int JT = RP / 32;                   // 32-wide j tiles per row = MX groups per row
@@ -215,7 +218,7 @@ __global__ __launch_bounds__(256) void fused_quantize_kernel(const QuantParams p
   const int64_t ngroups = p.numel / (NV ? 16 : 32);
   const __amdgpu_buffer_rsrc_t rx = make_rsrc(p.x, (uint32_t)(p.numel * 2));
 
-  const int wave_global = blockIdx.x * 4 + wave, nwaves = gridDim.x * 4;
+  const int wave_global = bid * 4 + wave, nwaves = nblk * 4;
   v4i xnext[RP / 16];
   // per-lane byte offset inside a tile and the step between a lane's loads: MFMA layout (row, half; 32 bytes apart) or,
   // staged, chunk lane + 64 i of the tile's contiguous 32 * RP * 2 bytes
@@ -230,13 +233,13 @@ __global__ __launch_bounds__(256) void fused_quantize_kernel(const QuantParams p
   }
   const float gscale = NV ? *p.global_scale : 1.0f;
   const uint32_t sfCB = BLK ? ((uint32_t)p.sf_cols + 3u) >> 2 : 0u;
-  if (BLK) {
+  if (BLK && PAD) {
     // zero padding of the blocked layout (rows up to a multiple of 128, columns up to a multiple of 4), as to_blocked writes it
     const uint32_t prow = ((uint32_t)p.sf_rows + 127u) & ~127u, pcol = sfCB * 4u;
     const uint32_t n1 = (prow - (uint32_t)p.sf_rows) * pcol, cpad = pcol - (uint32_t)p.sf_cols, n2 = (uint32_t)p.sf_rows * cpad;
     // padding rows: one dword (the four columns of a column tile) per store; padding columns of real rows: bytes
     const uint32_t nd = n1 >> 2;
-    for (uint32_t i = blockIdx.x * 256u + tid; i < nd + n2; i += gridDim.x * 256u) {
+    for (uint32_t i = (uint32_t)bid * 256u + tid; i < nd + n2; i += (uint32_t)nblk * 256u) {
       if (i < nd) {
         const uint32_t r = (uint32_t)p.sf_rows + i / sfCB, cb = i % sfCB;
         *(uint32_t*)(p.out_sf + blocked_sf_offset(r, 4u * cb, sfCB)) = 0u;
@@ -549,6 +552,11 @@ __global__ __launch_bounds__(256) void fused_quantize_kernel(const QuantParams p
       sf_row += sf_qstep + carry;
     }
   }
+}
+
+template <int R, bool NV, int METHOD, bool MASK, bool HWCVT, bool BLK = false>
+__global__ __launch_bounds__(256) void fused_quantize_kernel(const QuantParams p) {
+  fused_quantize_body<R, NV, METHOD, MASK, HWCVT, BLK>(p, (int)blockIdx.x, (int)gridDim.x);
 }
 
 }  // namespace qamd

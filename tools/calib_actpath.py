@@ -6,6 +6,8 @@ import os, sys
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tools"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import _benchlib as lab   # (only for the lab column: the hand-off form of the one-launch layer, gemm_variant 580)
 import qutlass_amd as q
 from qutlass_amd import _lib
 from qutlass_amd.utils import to_blocked
@@ -35,7 +37,19 @@ for (n, k) in nks:
                 t[name] = min(graph_us(fn, n=40) for _ in range(3))
             except Exception as e:   # the one-launch kernel has shape limits
                 t[name] = float("nan")
+        t["handoff"], eq = float("nan"), ""
+        if os.environ.get("ACT_HANDOFF", "0") == "1" and m <= 16:
+            try:
+                two = q.fused_quantize_matmul_mxf4_bf16_tn(x, h, wq, wsf, alpha, method="abs_max", single_launch=False)
+                with lab.forced(gemm_variant=580):
+                    got = lab.fused_quantize_matmul_mxf4_bf16_tn(x, h, wq, wsf.view(torch.uint8), alpha, method="abs_max")
+                    torch.cuda.synchronize()
+                    eq = "equal" if torch.equal(got.view(torch.int16), two.view(torch.int16)) else "DIFFER (%d)" % int((got.view(torch.int16) != two.view(torch.int16)).sum())
+                    t["handoff"] = min(graph_us(lambda: lab.fused_quantize_matmul_mxf4_bf16_tn(x, h, wq, wsf.view(torch.uint8), alpha, method="abs_max"), n=40) for _ in range(3))
+            except Exception as e:
+                eq = "error: %s" % str(e)[:60]
         aq, asf = q.fusedQuantizeMxBlocked(x, h, method="abs_max")
         t["gemm"] = min(graph_us(lambda: q.matmul_mxf4_bf16_tn(aq, wq, asf, wsf, alpha), n=40) for _ in range(3))
         rule = _lib.load().qutlass_amd_activation_path_launches(m, n, k, 32)
-        print("N=%-6d K=%-6d M=%-3d | %6.2f | %6.2f | %6.2f | %6.2f || %d" % (n, k, m, t["one"], t["two"], t["three"], t["gemm"], rule), flush=True)
+        print("N=%-6d K=%-6d M=%-3d | %6.2f | %6.2f | %6.2f | %6.2f || %d%s" % (n, k, m, t["one"], t["two"], t["three"], t["gemm"], rule,
+              (" || hand-off form (lab) %6.2f %s" % (t["handoff"], eq)) if os.environ.get("ACT_HANDOFF", "0") == "1" else ""), flush=True)
