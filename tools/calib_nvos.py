@@ -1,5 +1,6 @@
 """Small-batch NVFP4 shapes: the product's plan (0) beside the split-K skinny kernel (3) and the wave-owned kernel with 32 / 16 columns per workgroup (46 / 47,
-csrc/gemm_nvf4_os.hip.h), GPU-only timing (HIP-graph replays) + equality of the results (exact-regime scale bytes).   NV_M=1,16 NV_NK=4096x4096,... python tools/calib_nvos.py"""
+csrc/gemm_nvf4_os.hip.h) and its decode forms on the 16x16x32 MFMA (48 = 16x16 tiles, 49 = 32x16, 50 / 51 / 52 = 16 rows x 32 / 48 / 56 columns, 53 = 56 columns with A rows
+0 ... 7 only), GPU-only timing (HIP-graph replays) + equality of the results (exact-regime scale bytes).   NV_VARIANTS=0,46,48 NV_M=1,16 NV_NK=4096x4096,... python tools/calib_nvos.py"""
 import os, sys
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
