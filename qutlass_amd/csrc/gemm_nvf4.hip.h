@@ -824,7 +824,7 @@ inline int nvf4_big_cfg(int64_t M, int64_t N, int64_t K, int cus, double* t_us =
 // Against the calibration the chosen candidates sum to 10 353 us (best measured candidate per shape: 10 288; the occupancy thresholds this replaces:
 // 11 057), e.g. 256 x 4096 x 14336 54.7 -> 39.2 us (128x128 tiles, 4 K ranges), 128 x 8192 x 28672 107 -> 67, 64 x 28672 x 4096 36.7 -> 26.6 (64x64 tiles
 // instead of the skinny kernel), 512 x 5120 x 5120 47.0 -> 41.1 (160 tiles of 128x128 instead of 320 of 128x64, which put two on 64 CUs).
-struct NvPlan { int cfg, splits, kt_per; };   // cfg as above (-1 skinny, [r6] -2 / -3 wave-owned small-batch kernel with 32 / 16 columns per workgroup, -4 / -5 its 16x16 / 32x16 decode form, -6 ... -9 the decode form with 32 / 48 / 56 / 56 (8 A rows) columns per workgroup); splits = K ranges actually launched (none empty), kt_per = stages per range (even)
+struct NvPlan { int cfg, splits, kt_per; };   // cfg as above (-1 skinny, [r6] -2 / -3 wave-owned small-batch kernel with 32 / 16 columns per workgroup, -4 / -5 its 16x16 / 32x16 decode form, -6 ... -9 the decode form with 32 / 48 / 56 / 56 (8 A rows) columns per workgroup, -10 the 32x32-MFMA kernel on 64x32 tiles); splits = K ranges actually launched (none empty), kt_per = stages per range (even)
 // [r6] Does the wave-owned small-batch kernel (gemm_nvf4_os.hip.h) take the shape?  0 (no) or 32 (columns per workgroup; 16 is lab-only: the kernel is bound by its
 // dequantisation instructions -- ~16 per MFMA -- not by bytes, so spreading the weight over twice the workgroups buys nothing: profiles/calib_nvos_r6u.txt).
 // Measured against the plan before it (skinny / tile kernels / split-K with scratch), M = 1 ... 128:
@@ -854,17 +854,17 @@ inline int nv_os_plan(int64_t M, int64_t N, int64_t K, int cus) {
   // 3216 = the same with two m-tiles per workgroup (a B dword dequantised once for both): where 32x16 tiles fit one per CU (N = 4096, M = 17 ... 32: K = 4096 5.35 -> 4.75 us,
   // K = 14336 14.1 -> 11.7, K = 28672 30-36 -> 20)
   if (((M + 31) / 32) * ((N + 15) / 16) <= cus && KT <= 128) return 3216;
-  // (more than one round only when the last round is at least half full: 260 tiles would pay a second round for 4 of them)
-  const bool rounds_ok = T32 <= cus || T32 % cus == 0 || 2 * (T32 % cus) >= cus;
-  if (KT <= 16) return (T32 <= 3 * (int64_t)cus && rounds_ok) ? 32 : 0;
-  if (KT > 64 || 4 * T32 < cus) return 0;
-  if (T32 <= cus) return 32;
-  return (T32 <= 2 * (int64_t)cus && KT <= 32 && rounds_ok) ? 32 : 0;
+  // one round of 32x32 tiles: here; [r6, third session] several rounds (and the 64x32 form) are priced in nvf4_plan against the fitted models of the other kernels
+  if (T32 <= cus && (KT <= 16 || (KT <= 64 && 4 * T32 >= cus))) return 32;
+  return 0;
 }
 hipError_t launch_nvf4_os(NvGemmParams p, hipStream_t s, int tn);   // capi.hip (the NVFP4 unit)
 inline NvPlan nvf4_plan(int64_t M, int64_t N, int64_t K, int cus, bool may_split) {
   if (const int tn = nv_os_plan(M, N, K, cus)) return {tn == 856 ? -9 : tn == 1656 ? -8 : tn == 1648 ? -7 : tn == 1632 ? -6 : tn == 3216 ? -5 : tn == 1616 ? -4 : tn == 16 ? -3 : -2, 1, 0};
-  if (M <= 32) return {-1, 1, 0};
+  if (M <= 32) {   // one m-tile: the wave-owned 32x32 kernel in up to four rounds of tiles (1.75 + 4.05 us per round and 16 stages, K <= 8192) or the split-K kernel (2.53 + 4.66)
+    const int64_t KT0 = (K / 2 + 127) / 128, R0 = (((N + 31) / 32) + cus - 1) / cus;
+    return {(KT0 <= 32 && R0 <= 4) ? -2 : -1, 1, 0};
+  }
   auto tiles = [&](int bm, int bn) { return ((M + bm - 1) / bm) * ((N + bn - 1) / bn); };
   const int KT = (int)((K / 2 + 127) / 128);
   static constexpr int BM[3] = {128, 128, 64}, BN[3] = {128, 64, 64};
@@ -889,10 +889,18 @@ inline NvPlan nvf4_plan(int64_t M, int64_t N, int64_t K, int cus, bool may_split
     // the dip scan found M = 192 slower than M = 256 at N = K = 4096 (16.8 vs 15.7 us) and M = 96 slower than M = 128 at N = 6144 (16.9 vs 13.9): profiles/dip_scan_r7z.txt
     const double rounds = std::ceil(wg / cus);
     // ... and the same on its wave-owned rings up to K = 8192 (+5 % per round: 2048 x 8192, M = 160 ... 256: 19.0-23.1 -> 17.0-17.8 us; 5120^2, M = 64 / 128: 14.1 / 19.9 -> 12.6 / 18.5)
-    if (KT <= 32 && rounds <= 4.0) {   // (four rounds: 6144 x 4096, M = 160: 21.4 -> 17.7 us; where 64x64 tiles fit one round -- N = 4096, M = 256: 15.5 -- their model is lower and they stay)
-      const double t_os = 1.75 + 4.05 * rounds * KT / 16.0 * (KT > 16 ? 1.05 : 1.0);
-      if (t_os < t_skinny && t_os < best_t) return {-2, 1, 0};
+    // (four rounds: 6144 x 4096, M = 160: 21.4 -> 17.7 us; where 64x64 tiles fit one round -- N = 4096, M = 256: 15.5 -- their model is lower and they stay)
+    double t_os = 1e30, t_os64 = 1e30;
+    if (KT <= 32 && rounds <= 4.0) t_os = 1.75 + 4.05 * rounds * KT / 16.0 * (KT > 16 ? 1.05 : 1.0);
+    // ... and its 64x32 form (two m-tiles per workgroup, a B dword dequantised once for both; one slot per wave, refilled behind the stage's dequantisation): 6.6 us per round and
+    // 16 stages up to K = 4096, 5.8 beyond -- N = 4096, M = 96 / 128: 9.6 -> 8.4-8.5 us (ONE round instead of two), x 8192: 17.3-17.8 -> 12.9-13.3; 5120^2, M = 64: 12.6 -> 9.1;
+    // 8192^2, M = 64: 19.5 -> 15.6; two rounds only beyond K = 4096 (N = 4096, M = 256 at K = 4096: 16.1 against 15.5 on 64x64 tiles).  profiles/calib_nv6432_r7.txt
+    {
+      const double rounds64 = std::ceil((double)(((M + 63) / 64) * ((N + 31) / 32)) / cus);
+      if (M > 32 && KT <= 64 && (rounds64 <= 1.0 || (rounds64 <= 2.0 && KT > 16))) t_os64 = 1.75 + (KT <= 16 ? 6.6 : 5.8) * rounds64 * KT / 16.0;
     }
+    if (t_os64 < t_os && t_os64 < t_skinny && t_os64 < best_t) return {-10, 1, 0};
+    if (t_os < t_skinny && t_os < best_t) return {-2, 1, 0};
     if (t_skinny < best_t) return {-1, 1, 0};
   }
   if (M > 128 && N > 128 && tiles(128, 128) >= cus * 3 / 4) {   // the large-output model above; a split only where it beats that model's time by 5 %
@@ -937,9 +945,10 @@ inline hipError_t launch_nvf4_gemm(NvGemmParams p, hipStream_t s, int variant = 
   if (variant == 46 || variant == 47) return launch_nvf4_os(p, s, variant == 47 ? 16 : 32);   // lab: force the wave-owned small-batch kernel (any K: rings beyond 4096)
   if (variant == 48) return launch_nvf4_os(p, s, 1616);                                       // lab: ... its 16x16 decode form (any M: rows in tiles of 16)
   if (variant == 49) return launch_nvf4_os(p, s, 3216);                                       // lab: ... with two m-tiles per workgroup (32x16)
+  if (variant == 54) return launch_nvf4_os(p, s, 6432);                                       // lab: the 32x32-MFMA kernel with two m-tiles per workgroup (64x32 tiles)
   if (variant >= 50 && variant <= 53) return launch_nvf4_os(p, s, variant == 50 ? 1632 : variant == 51 ? 1648 : variant == 52 ? 1656 : 856);   // lab: ... with 32 / 48 / 56 columns per workgroup (53: 56 columns, A rows 0 ... 7 only)
 #endif
-  if (variant == 0 && plan.cfg <= -2) return launch_nvf4_os(p, s, plan.cfg == -9 ? 856 : plan.cfg == -8 ? 1656 : plan.cfg == -7 ? 1648 : plan.cfg == -6 ? 1632 : plan.cfg == -5 ? 3216 : plan.cfg == -4 ? 1616 : plan.cfg == -3 ? 16 : 32);
+  if (variant == 0 && plan.cfg <= -2) return launch_nvf4_os(p, s, plan.cfg == -10 ? 6432 : plan.cfg == -9 ? 856 : plan.cfg == -8 ? 1656 : plan.cfg == -7 ? 1648 : plan.cfg == -6 ? 1632 : plan.cfg == -5 ? 3216 : plan.cfg == -4 ? 1616 : plan.cfg == -3 ? 16 : 32);
   if (variant == 3 || (variant == 0 && plan.cfg < 0)) {
     hipLaunchKernelGGL((gemm_nvf4_skinny_kernel<8>), dim3((p.N + 31) / 32, (p.M + 31) / 32), dim3(512), 0, s, p);
     return hipSuccess;

@@ -16,22 +16,26 @@
 
 namespace qamd {
 
-template <int SPW_, int TN_ = 32>   // stages (one shot) / slots (RING) per wave
+// MT = 2 ([r6, third session]; M = 65 ... 128 and beyond): two m-tiles of 32 rows per workgroup -- a B dword is dequantised once for both (12 instead of 16 vector
+// instructions per MFMA) and a batch of 128 rows against N = 4096 is ONE round of 256 workgroups instead of two.  A 64x32 tile's stage is 13.5 KiB: one slot per wave; beyond
+// K = 2048 the wave refills it as soon as its fragment reads have returned -- the refill's round trip runs behind the stage's ~300 dequantisation instructions.
+template <int SPW_, int TN_ = 32, int MT_ = 1>   // stages (one shot) / slots (RING) per wave
 struct NvOsCfg {
-  static constexpr int NW = 8, TM = 32, TN = TN_, ROWB = 128, SPW = SPW_, NSLOT = NW * SPW_;
-  static constexpr int OFF_B = TM * ROWB, OFF_S = (TM + 32) * ROWB, STAGE = OFF_S + 1024;   // + four 256-byte scale pieces: A tiles (jj = 0, 1), B tiles (jj = 0, 1)
-  static constexpr int NPB = TN / 8;
-  static constexpr int LPS = 4 + NPB + 4;
-  static constexpr int RED = NW * 4096;
+  static constexpr int NW = 8, MT = MT_, TM = 32 * MT_, TN = TN_, ROWB = 128, SPW = SPW_, NSLOT = NW * SPW_;
+  static constexpr int OFF_B = TM * ROWB, OFF_S = (TM + 32) * ROWB, OFF_SB = OFF_S + MT * 512, STAGE = OFF_SB + 512;   // two 256-byte scale pieces (jj = 0, 1) per m-tile and for B
+  static constexpr int NPA = TM / 8, NPB = TN / 8;
+  static constexpr int LPS = NPA + NPB + 2 * MT + 2;
+  static constexpr int RED = NW * TM * 128;
   static constexpr int LDS_BYTES = NSLOT * STAGE > RED ? NSLOT * STAGE : RED;
   static_assert(TN == 32 || TN == 16, "tile width");
+  static_assert(MT == 1 || MT == 2, "m-tiles");
   static_assert(SPW >= 1 && SPW * LPS <= 63, "vmcnt immediate");
   static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
 };
 
 template <class C, bool RING = false>
 __global__ __launch_bounds__(512) void gemm_nvf4_os_kernel(const NvGemmParams p) {
-  constexpr int SPW = C::SPW, LPS = C::LPS, NW = C::NW;
+  constexpr int SPW = C::SPW, LPS = C::LPS, NW = C::NW, MT = C::MT;
   __shared__ __attribute__((aligned(16))) char smem[C::LDS_BYTES];
   asm volatile("" :: "s"(p.A), "s"(p.D), "s"(p.K), "s"(p.b_bytes), "s"(p.alpha));   // all scalar argument loads in one round
   const float alpha = *p.alpha;
@@ -56,7 +60,10 @@ __global__ __launch_bounds__(512) void gemm_nvf4_os_kernel(const NvGemmParams p)
   const uint32_t sa_off = (uint32_t)(m0 >> 7) * CB * 512, sb_off = (uint32_t)(n0 >> 7) * CB * 512;
   const __amdgpu_buffer_rsrc_t rSA = make_rsrc(p.SFA + sa_off, p.sfa_bytes - sa_off), rSB = make_rsrc(p.SFB + sb_off, p.sfb_bytes - sb_off);
   const int rowB = (n0 & 127) + i32;   // (TN = 16: n0 is a multiple of 16 only; lanes past the 16 rows fetch some row's dword -- unused)
-  const int vSA = 2 * g * 512 + i32 * 16 + ((m0 & 127) >> 5) * 4, vSB = 2 * g * 512 + (rowB & 31) * 16 + ((rowB & 127) >> 5) * 4;
+  int vSA[MT];
+#pragma unroll
+  for (int t = 0; t < MT; ++t) vSA[t] = 2 * g * 512 + i32 * 16 + (((m0 & 127) >> 5) + t) * 4;
+  const int vSB = 2 * g * 512 + (rowB & 31) * 16 + ((rowB & 127) >> 5) * 4;
 
   auto issue = [&](const int kt, const int slot) __attribute__((always_inline)) {   // stage kt into slot `slot` of this wave (kt >= KT: every piece out of range -> zeros)
     char* st = smem + (wave * SPW + slot) * C::STAGE;
@@ -65,9 +72,9 @@ __global__ __launch_bounds__(512) void gemm_nvf4_os_kernel(const NvGemmParams p)
     asm volatile("" : "+v"(tail), "+v"(oob));
     const int soff = kt * C::ROWB;
 #pragma unroll
-    for (int t = 0; t < 4 + C::NPB; ++t) {
-      const bool isB = t >= 4;
-      const int qq = t & 3, par = qq & 1;
+    for (int t = 0; t < C::NPA + C::NPB; ++t) {
+      const bool isB = t >= C::NPA;
+      const int qq = isB ? t - C::NPA : t, par = qq & 1;
       const int o = oob | ((chP[par] << 4) < tail ? 0 : -1);
       const int v = ((vP[par] + qq * rstep) & ~o) | ((int)0x80000000 & o);
       __builtin_amdgcn_raw_ptr_buffer_load_lds(isB ? rB : rA, (lds_ptr_t)(st + (isB ? C::OFF_B : 0) + qq * 1024), 16, v, soff, 0, 0);
@@ -75,8 +82,10 @@ __global__ __launch_bounds__(512) void gemm_nvf4_os_kernel(const NvGemmParams p)
 #pragma unroll
     for (int jj = 0; jj < 2; ++jj) {
       const int os = (kt < KT && 4 * kt + 2 * g + jj < CB) ? 0 : -1;   // a column tile past the operand's last one would read the next row tile's bytes
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rSA, (lds_ptr_t)(st + C::OFF_S + jj * 256), 4, ((vSA + jj * 512) & ~os) | ((int)0x80000000 & os), kt * 2048, 0, 0);
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rSB, (lds_ptr_t)(st + C::OFF_S + 512 + jj * 256), 4, ((vSB + jj * 512) & ~os) | ((int)0x80000000 & os), kt * 2048, 0, 0);
+#pragma unroll
+      for (int t = 0; t < MT; ++t)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rSA, (lds_ptr_t)(st + C::OFF_S + t * 512 + jj * 256), 4, ((vSA[t] + jj * 512) & ~os) | ((int)0x80000000 & os), kt * 2048, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rSB, (lds_ptr_t)(st + C::OFF_SB + jj * 256), 4, ((vSB + jj * 512) & ~os) | ((int)0x80000000 & os), kt * 2048, 0, 0);
     }
   };
 
@@ -84,30 +93,37 @@ __global__ __launch_bounds__(512) void gemm_nvf4_os_kernel(const NvGemmParams p)
   for (int j = 0; j < SPW; ++j) issue(wave + NW * j, j);
 
   const int sw = (i32 >> 1) & 7;
-  v16f acc;
+  v16f acc[MT];
 #pragma unroll
-  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  for (int t = 0; t < MT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
   auto fence = [&]() __attribute__((always_inline)) { __builtin_amdgcn_sched_barrier(0); };
 
   // one stage (kt) out of slot u; RING: kt_next (>= KT: zeros) is requested into the slot as soon as the reads have returned
   auto consume = [&](const int kt, const int u, const int kt_next) __attribute__((always_inline)) {
     const char* st = smem + (wave * SPW + u) * C::STAGE;
-    v4i ca[4], cb[4];
+    v4i ca[MT][4], cb[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int off = i32 * C::ROWB + (((4 * g + j) ^ sw) << 4);
-      ca[j] = *(const v4i*)(st + off);
+#pragma unroll
+      for (int t = 0; t < MT; ++t) ca[t][j] = *(const v4i*)(st + t * 32 * C::ROWB + off);
       cb[j] = *(const v4i*)(st + C::OFF_B + off);
     }
-    uint32_t da[2], db[2];
+    uint32_t da[MT][2], db[2];
 #pragma unroll
     for (int jj = 0; jj < 2; ++jj) {
-      da[jj] = *(const uint32_t*)(st + C::OFF_S + jj * 256 + lane * 4);
-      db[jj] = *(const uint32_t*)(st + C::OFF_S + 512 + jj * 256 + lane * 4);
+#pragma unroll
+      for (int t = 0; t < MT; ++t) da[t][jj] = *(const uint32_t*)(st + C::OFF_S + t * 512 + jj * 256 + lane * 4);
+      db[jj] = *(const uint32_t*)(st + C::OFF_SB + jj * 256 + lane * 4);
     }
     fence();
     if constexpr (RING) {
-      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ca[0]), "+v"(ca[1]), "+v"(ca[2]), "+v"(ca[3]), "+v"(cb[0]), "+v"(cb[1]), "+v"(cb[2]), "+v"(cb[3]), "+v"(da[0]), "+v"(da[1]), "+v"(db[0]), "+v"(db[1]) :: "memory");   // the slot is free
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the slot is free ...
+#pragma unroll
+      for (int t = 0; t < MT; ++t) asm volatile("" : "+v"(ca[t][0]), "+v"(ca[t][1]), "+v"(ca[t][2]), "+v"(ca[t][3]), "+v"(da[t][0]), "+v"(da[t][1]));   // ... (every read pinned behind the wait)
+      asm volatile("" : "+v"(cb[0]), "+v"(cb[1]), "+v"(cb[2]), "+v"(cb[3]), "+v"(db[0]), "+v"(db[1]));
       issue(kt_next, u);
       fence();
     }
@@ -116,18 +132,23 @@ __global__ __launch_bounds__(512) void gemm_nvf4_os_kernel(const NvGemmParams p)
       // groups past K inside the last column tile (K % 64 == 32): their scale bytes are layout padding -- masked to 0 (0 x 0, never NaN)
       const int valid = G16 - 4 * (4 * kt + 2 * g + jj);
       const uint32_t smask = valid >= 4 ? 0xffffffffu : (valid <= 0 ? 0u : ((1u << (8 * valid)) - 1u));
-      h2_t sa[2], sb[2];
-      e4m3x4_to_f16(da[jj] & smask, sa[0], sa[1]);
+      h2_t sa[MT][2], sb[2];
+#pragma unroll
+      for (int t = 0; t < MT; ++t) e4m3x4_to_f16(da[t][jj] & smask, sa[t][0], sa[t][1]);
       e4m3x4_to_f16(db[jj] & smask, sb[0], sb[1]);
 #pragma unroll
       for (int jl = 0; jl < 2; ++jl) {
         const int j = 2 * jj + jl;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          const _Float16 xa = sa[jl][q >> 1], xb = sb[jl][q >> 1];
-          const h8_t fa = dq8((uint32_t)ca[j][q], h2_t{xa, xa});
+          const _Float16 xb = sb[jl][q >> 1];
           const h8_t fb = dq8((uint32_t)cb[j][q], h2_t{xb, xb});
-          acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb, fa, acc, 0, 0, 0);
+#pragma unroll
+          for (int t = 0; t < MT; ++t) {
+            const _Float16 xa = sa[t][jl][q >> 1];
+            const h8_t fa = dq8((uint32_t)ca[t][j][q], h2_t{xa, xa});
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb, fa, acc[t], 0, 0, 0);
+          }
         }
       }
     }
@@ -158,15 +179,17 @@ __global__ __launch_bounds__(512) void gemm_nvf4_os_kernel(const NvGemmParams p)
 
   // ---- cross-wave sum: [wave][row][8 chunks of 4 fp32], chunk ^ (row & 7) -------------------------------------------------------------------
 #pragma unroll
-  for (int q = 0; q < 4; ++q)
-    *(v4f*)(smem + (wave * 32 + i32) * 128 + (((2 * q + g) ^ (i32 & 7)) << 4)) = v4f{acc[4 * q + 0], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]};
+  for (int t = 0; t < MT; ++t)
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      *(v4f*)(smem + (wave * C::TM + 32 * t + i32) * 128 + (((2 * q + g) ^ (i32 & 7)) << 4)) = v4f{acc[t][4 * q + 0], acc[t][4 * q + 1], acc[t][4 * q + 2], acc[t][4 * q + 3]};
   __syncthreads();
-  if (tid < 256) {
-    const int rr = tid >> 3, cq = tid & 7;   // row of the 32 x 32 tile, chunk of 4 columns
+  if (tid < 256 * MT) {
+    const int rr = tid >> 3, cq = tid & 7;   // row of the TM x 32 tile, chunk of 4 columns
     v4f t = *(const v4f*)(smem + rr * 128 + ((cq ^ (rr & 7)) << 4));
 #pragma unroll
     for (int w = 1; w < NW; ++w) {
-      const v4f s = *(const v4f*)(smem + (w * 32 + rr) * 128 + ((cq ^ (rr & 7)) << 4));
+      const v4f s = *(const v4f*)(smem + (w * C::TM + rr) * 128 + ((cq ^ (rr & 7)) << 4));
 #pragma unroll
       for (int e = 0; e < 4; ++e) t[e] += s[e];
     }
@@ -432,6 +455,15 @@ hipError_t launch_nvf4_os(NvGemmParams p, hipStream_t s, int tn) {
       else hipLaunchKernelGGL((gemm_nvf4_os16_kernel<NvOs16Cfg<1, 1, 56, 2>, true>), grid, block, 0, s, p);
     }
 #undef QAMD_NVW
+    return hipSuccess;
+  }
+  if (tn == 6432) {   // [r6] two m-tiles per workgroup (64x32 tiles): one slot per wave -- one shot up to K = 2048, refilled beyond
+    p.tiles_m = (p.M + 63) / 64;
+    p.tiles_n = (p.N + 31) / 32;
+    const int KT = (p.K / 2 + 127) / 128;
+    const dim3 grid(p.tiles_m * p.tiles_n), block(512);
+    if (KT <= 8) hipLaunchKernelGGL((gemm_nvf4_os_kernel<NvOsCfg<1, 32, 2>, false>), grid, block, 0, s, p);
+    else hipLaunchKernelGGL((gemm_nvf4_os_kernel<NvOsCfg<1, 32, 2>, true>), grid, block, 0, s, p);
     return hipSuccess;
   }
   p.tiles_m = (p.M + 31) / 32;

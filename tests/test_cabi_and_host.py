@@ -164,32 +164,33 @@ def test_nvf4_tile_rule(lib):
         # small outputs at K = 4096 (16 stages): nothing to split
         # [r6] -2 = the wave-owned small-batch kernel (csrc/gemm_nvf4_os.hip.h): M <= 128 with K <= 4096 up to three rounds of 32x32 tiles (rounds 3-5: the skinny kernel)
         # [r6] -4 = its decode form (16x16 tiles on the 16x16x32 MFMA) wherever those fit one per CU, and two per CU for M <= 16 with K <= 4096
-        assert f(512, 4096, K, ws) == 2 and f(256, 4096, K, ws) == 3 and f(64, 4096, K, ws) == -2 and f(1, 4096, K, ws) == -4 and f(96, 4096, K, ws) == -2
+        assert f(512, 4096, K, ws) == 2 and f(256, 4096, K, ws) == 3 and f(64, 4096, K, ws) == -2 and f(1, 4096, K, ws) == -4 and f(96, 4096, K, ws) == -10
         assert f(16, 4096, K, ws) == -4 and f(17, 4096, K, ws) == -5 and f(32, 4096, K, ws) == -5 and f(33, 4096, K, ws) == -2 and f(32, 6144, K, ws) == -2 and f(64, 1024, K, ws) == -4 and f(128, 512, K, ws) == -4 and f(16, 8192, K, ws) == -6 and f(16, 8208, K, ws) == -7
         # [r6] -6 ... -9: the decode form with 32 / 48 / 56 columns per workgroup (-9: 56 columns, A rows 0 ... 7 only) for M <= 16 against wider weights, K <= 8192
         assert f(1, 6144, K, ws) == -6 and f(16, 12288, K, ws) == -7 and f(8, 14336, K, ws) == -9 and f(9, 14336, K, ws) == -8 and f(8, 14336, 8192, ws) == -8 and f(17, 12288, K, ws) not in (-6, -7, -8, -9)
         assert f(8, 16384, K, ws) not in (-6, -7, -8, -9) and f(8, 14336, 14336, ws) not in (-6, -7, -8, -9)
         assert f(16, 28672, K, ws) == -7 and f(1, 24576, K, ws) == -7 and f(16, 28672, 8192, ws) != -7 and f(17, 28672, K, ws) != -7   # two / three rounds of 48-column workgroups, K <= 4096
-        assert f(128, 4096, K, ws) == -2 and f(128, 6144, K, ws) == -2 and f(128, 8192, K, ws) != -2 and f(32, 14336, K, ws) == -2 and f(64, 14336, K, ws) != -2   # 512 / 768 tiles yes, 1024 / 896 no
-        assert f(32, 28672, K, ws) == -1 and f(64, 28672, K, ws) == 3       # 64 rows against a wide weight: 448 tiles of 64x64 (26.6 us) beat the skinny kernel (36.7)
+        # [r6] -10: the 32x32-MFMA kernel on 64x32 tiles (one round instead of two), priced in nvf4_plan
+        assert f(128, 4096, K, ws) == -10 and f(128, 6144, K, ws) == -2 and f(128, 8192, K, ws) != -2 and f(32, 14336, K, ws) == -2 and f(64, 14336, K, ws) != -2   # 512 / 768 tiles yes, 1024 / 896 no
+        assert f(32, 28672, K, ws) == -2 and f(64, 28672, K, ws) == 3       # 64 rows against a wide weight: 448 tiles of 64x64 (26.6 us) beat the skinny kernel (36.7)
         assert f(512, 5120, 5120, ws) == 1 and f(384, 5120, 5120, ws) == 2  # 160 tiles of 128x128 (41.1 us) against 320 of 128x64 (47.0); 240 of 128x64 fit one per CU
         assert f(0, 4096, K, ws) == -2 and f(4096, 4096, 0, ws) == -2
     # long K, few tiles: K ranges (only with a workspace)
-    assert f(256, 4096, 14336, 0) == 3 and f(256, 4096, 14336, 1) == 1 + 256 * 4      # 64 tiles of 128x128 x 4 ranges of 14 stages
-    assert f(128, 4096, 14336, 0) == -1 and f(128, 4096, 14336, 1) == 1 + 256 * 7     # 32 tiles x 7 ranges of 8 stages (8 asked for; 56 stages)
+    assert f(256, 4096, 14336, 0) == -10 and f(256, 4096, 14336, 1) == 1 + 256 * 4      # 64 tiles of 128x128 x 4 ranges of 14 stages
+    assert f(128, 4096, 14336, 0) == -10 and f(128, 4096, 14336, 1) == -10 and f(128, 2048, 28672, 0) == -1 and f(128, 2048, 28672, 1) == 2 + 256 * 8     # 32 tiles x 7 ranges of 8 stages (8 asked for; 56 stages)
     # [r6] long K on wave-owned rings: one 32x32 tile per CU at most (two rounds up to 32 stages), at least a quarter of the CUs busy, with or without scratch
     for ws in (0, 1):
-        assert f(64, 4096, 14336, ws) == -2 and f(16, 4096, 8192, ws) == -4 and f(128, 4096, 8192, ws) == -2 and f(32, 8192, 8192, ws) == -2 and f(32, 4096, 8192, ws) == -5
+        assert f(64, 4096, 14336, ws) == -2 and f(16, 4096, 8192, ws) == -4 and f(128, 4096, 8192, ws) == -10 and f(32, 8192, 8192, ws) == -2 and f(32, 4096, 8192, ws) == -5
         assert f(16, 1024, 14336, ws) == -4 and f(64, 8192, 14336, ws) != -2 and f(16, 4096, 28672, ws) == -4 and f(32, 4096, 28672, ws) == -5 and f(64, 4096, 28672, ws) not in (-2, -4, -5) and f(16, 8192, 8192, ws) == -6
     assert f(768, 4096, 14336, 0) == 1 and f(768, 4096, 14336, 1) == 1 + 256 * 4      # 192 tiles: 768 workgroups balance better than 192 (94.7 vs 108.3 us)
     assert f(1024, 5120, 25600, 0) == 4 and f(1024, 5120, 25600, 1) == 1 + 256 * 4    # 320 tiles of 128x128 x 4 (252 us) against 160 of 256x128 (300)
     assert f(64, 8192, 28672, 0) == -1 and f(64, 8192, 28672, 1) == 3 + 256 * 4       # 128 tiles of 64x64 x 4 (49.9 us) against the skinny kernel (69.5)
-    assert f(1024, 4096, 14336, 1) == 1 and f(256, 2048, 2048, 1) == -2 and f(384, 2048, 2048, 1) == 3   # a full round already / K too short (8 stages): the skinny
+    assert f(1024, 4096, 14336, 1) == 1 and f(256, 2048, 2048, 1) == -10 and f(384, 2048, 2048, 1) == 3   # a full round already / K too short (8 stages): the skinny
     # kernel up to 256 rows where its 32x32 workgroups still fit two per CU (GPU-only timing: 7.4 us against 9.6 on 64x64 tiles), 64x64 tiles beyond
     assert f(192, 4096, 4096, 1) == -2 and f(256, 4096, 4096, 1) == 3 and f(96, 6144, 4096, 1) == -2   # [r6] (three rounds of the wave-owned 32x32 kernel: 13.9 us; rounds 3-5: skinny, 16.8)
     # the workspace query describes the same plan: ranges x M x N fp32
     g = lib.qutlass_amd_nvf4_splitk_workspace_bytes
-    assert g(256, 4096, 14336) == 4 * 256 * 4096 * 4 and g(128, 4096, 14336) == 7 * 128 * 4096 * 4 and g(200, 4104, 14368) == 8 * 200 * 4104 * 4
+    assert g(256, 4096, 14336) == 4 * 256 * 4096 * 4 and g(128, 4096, 14336) == 0 and g(128, 2048, 28672) == 8 * 128 * 2048 * 4 and g(200, 4104, 14368) == 8 * 200 * 4104 * 4
     assert g(4096, 4096, 4096) == 0 and g(256, 4096, 4096) == 0 and g(16, 4096, 14336) == 0 and g(64, 4096, 14336) == 0 and g(0, 4096, 4096) == 0 and g(256, 4096, 0) == 0
     dummy = ctypes.c_void_p(0x1000)
     h = lib.qutlass_amd_matmul_nvf4_bf16_tn_ws
@@ -215,7 +216,7 @@ def test_split_plans_are_consistent_over_a_shape_grid(lib):
         n = int(rng.integers(1, 2048)) * 8
         k = int(rng.integers(1, 256)) * 128
         r0, r1 = nv(m, n, k, 0), nv(m, n, k, 1)
-        assert -9 <= r0 <= 4 and (r1 < 256 or (1 <= r1 % 256 <= 3 and 2 <= r1 // 256 <= 8)), (m, n, k, r0, r1)
+        assert -10 <= r0 <= 4 and (r1 < 256 or (1 <= r1 % 256 <= 3 and 2 <= r1 // 256 <= 8)), (m, n, k, r0, r1)
         b = nv_ws(m, n, k)
         assert b == (r1 // 256 if r1 >= 256 else 0) * m * n * 4, (m, n, k, r1, b)   # (256x256 tiles: the persistent kernel's balanced rounds need no scratch)
         for ebits in (4, 8):
@@ -431,7 +432,7 @@ def test_small_output_plans_against_the_gpu_only_calibrations(lib):
             chosen += d[col]
             best += min(v for v in d.values() if not math.isnan(v))
             cnt += 1
-    assert cnt >= 75 and chosen <= 1.015 * best, (cnt, chosen, best)   # ([r6] the shapes the wave-owned small-batch kernel takes have no column in the round-3 calibration)
+    assert cnt >= 65 and chosen <= 1.015 * best, (cnt, chosen, best)   # ([r6] the shapes the wave-owned small-batch kernels take -- 32x32 / 64x32 tiles in one to four rounds -- have no column in the round-3 calibration)
 
     dry = lib.qutlass_amd_debug_gemm_plan
     dry.restype = ctypes.c_int

@@ -442,13 +442,15 @@ def test_matmul_nvf4_occupancy_tile_choice_is_bit_identical(q, m, n, k):
     assert np.array_equal(outs[0].numpy()[rows].view(np.uint16), ref.view(np.uint16))
 
 
-@pytest.mark.parametrize("m,n,k", [(256, 4096, 14336), (128, 4096, 14336), (200, 4104, 14368), (64, 8192, 28672), (768, 4096, 14336), (40, 1032, 6144), (100, 2056, 6144), (256, 2048, 2048), (1024, 5120, 25600)])
+@pytest.mark.parametrize("m,n,k", [(256, 4096, 14336), (128, 4096, 14336), (200, 4104, 14368), (64, 8192, 28672), (768, 4096, 14336), (40, 1032, 6144), (100, 2056, 6144), (256, 2048, 2048), (1024, 5120, 25600),
+                                   (128, 2048, 28672)])
 def test_matmul_nvf4_split_k_equals_single_pass_and_oracle(q, m, n, k):
     """[r3] Outputs of a few dozen tiles with a long K: matmul_nvf4_bf16_tn splits K into ranges of an even number of 256-element stages over scratch from the
     caching allocator (qutlass_amd_matmul_nvf4_bf16_tn_ws; reference: the CUTLASS workspace of gemm.cu:290-300) and a second kernel sums the fp32 partials
     in fixed order.  e4m3 scales in [1, 4) keep every partial sum exact in fp32, so the split result must equal the forced single pass on 128x128 tiles bit
     for bit -- ragged M / N, a K tail (14368 = 56 stages + 32 elements), ranges that do not divide the stages (7 of 8, 6 of 8) -- and the oracle on sampled rows.
-    256 x 2048 x 2048 (8 stages) and 40 x 1032 x 6144 (the small-batch kernel's in-workgroup split wins) do not split; the plan is checked against the workspace query."""
+    256 x 2048 x 2048 (8 stages), 40 x 1032 x 6144 and [r6] 128 x 4096 x 14336 / 100 x 2056 x 6144 (the wave-owned small-batch kernels' in-workgroup split wins: 64x32 tiles in one
+    round) do not split; the plan is checked against the workspace query."""
     from qutlass_amd.utils import to_blocked
 
     g = torch.Generator(device="cpu").manual_seed(m + n + k)
@@ -460,7 +462,7 @@ def test_matmul_nvf4_split_k_equals_single_pass_and_oracle(q, m, n, k):
     sb_b = to_blocked(sb.to(DEV).view(torch.float8_e4m3fn))
     al = torch.tensor([0.5], device=DEV)
     ws = q._lib.load().qutlass_amd_nvf4_splitk_workspace_bytes(m, n, k)
-    assert (ws > 0) == ((m, n, k) not in ((256, 2048, 2048), (40, 1032, 6144))) and ws % (m * n * 4) == 0 and 0 <= ws // (m * n * 4) <= 8
+    assert (ws > 0) == ((m, n, k) not in ((256, 2048, 2048), (40, 1032, 6144), (128, 4096, 14336), (100, 2056, 6144))) and ws % (m * n * 4) == 0 and 0 <= ws // (m * n * 4) <= 8
     out = q.matmul_nvf4_bf16_tn(a, b, sa_b, sb_b, al)                       # torch op: workspace from the allocator -> the split path
     with lab.forced(nvf4_variant=5):
         single = lab.matmul_nvf4_bf16_tn(a, b, sa_b, sb_b, al)              # 128x128 tiles, one pass
