@@ -824,7 +824,7 @@ inline int nvf4_big_cfg(int64_t M, int64_t N, int64_t K, int cus, double* t_us =
 // Against the calibration the chosen candidates sum to 10 353 us (best measured candidate per shape: 10 288; the occupancy thresholds this replaces:
 // 11 057), e.g. 256 x 4096 x 14336 54.7 -> 39.2 us (128x128 tiles, 4 K ranges), 128 x 8192 x 28672 107 -> 67, 64 x 28672 x 4096 36.7 -> 26.6 (64x64 tiles
 // instead of the skinny kernel), 512 x 5120 x 5120 47.0 -> 41.1 (160 tiles of 128x128 instead of 320 of 128x64, which put two on 64 CUs).
-struct NvPlan { int cfg, splits, kt_per; };   // cfg as above (-1 skinny, [r6] -2 / -3 wave-owned small-batch kernel with 32 / 16 columns per workgroup, -4 / -5 its 16x16 / 32x16 decode form, -6 ... -9 the decode form with 32 / 48 / 56 / 56 (8 A rows) columns per workgroup, -10 the 32x32-MFMA kernel on 64x32 tiles); splits = K ranges actually launched (none empty), kt_per = stages per range (even)
+struct NvPlan { int cfg, splits, kt_per; };   // cfg as above (-1 skinny, [r6] -2 / -3 wave-owned small-batch kernel with 32 / 16 columns per workgroup, -4 / -5 its 16x16 / 32x16 decode form, -6 ... -9 the decode form with 32 / 48 / 56 / 56 (8 A rows) columns per workgroup, -10 / -11 the 32x32-MFMA kernel on 64x32 / 96x32 tiles); splits = K ranges actually launched (none empty), kt_per = stages per range (even)
 // [r6] Does the wave-owned small-batch kernel (gemm_nvf4_os.hip.h) take the shape?  0 (no) or 32 (columns per workgroup; 16 is lab-only: the kernel is bound by its
 // dequantisation instructions -- ~16 per MFMA -- not by bytes, so spreading the weight over twice the workgroups buys nothing: profiles/calib_nvos_r6u.txt).
 // Measured against the plan before it (skinny / tile kernels / split-K with scratch), M = 1 ... 128:
@@ -881,9 +881,9 @@ inline NvPlan nvf4_plan(int64_t M, int64_t N, int64_t K, int cus, bool may_split
       if (S2 > 1) t = (t + 2.897 + (double)(S2 + 1) * M * N * 4.0 / 4.409e6) * 1.02;
       if (t < best_t) { best_t = t; best = {c + 1, S2, S2 > 1 ? kt : 0}; }
     }
-  if (M <= 256) {
+  if (M <= 384) {
     const double wg = (double)(((M + 31) / 32) * ((N + 31) / 32));
-    const double t_skinny = 2.53 + 4.66 * std::ceil(wg / cus) * K / 4096.0;
+    const double t_skinny = M <= 256 ? 2.53 + 4.66 * std::ceil(wg / cus) * K / 4096.0 : 1e30;
     // [r6] the wave-owned 32x32 kernel where nv_os_plan's occupancy rule passed the shape on (a part-filled last round, or M = 129 ... 256): up to four rounds of tiles with
     // K <= 4096 cost 1.75 + 4.05 us per round (N = 4096, M = 64 / 128: 5.7 / 9.8 us; 6144 x 4096, M = 128: 13.85) against 2.53 + 4.66 per round for the split-K kernel --
     // the dip scan found M = 192 slower than M = 256 at N = K = 4096 (16.8 vs 15.7 us) and M = 96 slower than M = 128 at N = 6144 (16.9 vs 13.9): profiles/dip_scan_r7z.txt
@@ -899,6 +899,15 @@ inline NvPlan nvf4_plan(int64_t M, int64_t N, int64_t K, int cus, bool may_split
       const double rounds64 = std::ceil((double)(((M + 63) / 64) * ((N + 31) / 32)) / cus);
       if (M > 32 && KT <= 64 && (rounds64 <= 1.0 || (rounds64 <= 2.0 && KT > 16))) t_os64 = 1.75 + (KT <= 16 ? 6.6 : 5.8) * rounds64 * KT / 16.0;
     }
+    // ... and three m-tiles per workgroup (96x32 tiles: 10.7 vector instructions per MFMA; 18 KiB per stage, still one slot per wave): 9.2 us per round and 16 stages up to K = 4096,
+    // 8.0 beyond -- N = 4096, M = 160 / 192: 13.6-13.9 -> 10.9-11.1 us (ONE round of 256 workgroups), x 8192: 24 -> 17.8-18.3; 6144 / 8192 x 4096, M = 96: 13.3 / 13.8 -> 10.9 / 11.4;
+    // 8192^2, M = 96: 26 -> 20.2; two rounds: 8192 x 4096, M = 192: 22.2 -> 20.9.  profiles/calib_nv9632_r7.txt
+    double t_os96 = 1e30;
+    {
+      const double rounds96 = std::ceil((double)(((M + 95) / 96) * ((N + 31) / 32)) / cus);
+      if (M > 64 && KT <= 64 && rounds96 <= 2.0) t_os96 = 1.75 + (KT <= 16 ? 9.2 : 8.0) * rounds96 * KT / 16.0;
+    }
+    if (t_os96 < t_os64 && t_os96 < t_os && t_os96 < t_skinny && t_os96 < best_t) return {-11, 1, 0};
     if (t_os64 < t_os && t_os64 < t_skinny && t_os64 < best_t) return {-10, 1, 0};
     if (t_os < t_skinny && t_os < best_t) return {-2, 1, 0};
     if (t_skinny < best_t) return {-1, 1, 0};
@@ -945,10 +954,11 @@ inline hipError_t launch_nvf4_gemm(NvGemmParams p, hipStream_t s, int variant = 
   if (variant == 46 || variant == 47) return launch_nvf4_os(p, s, variant == 47 ? 16 : 32);   // lab: force the wave-owned small-batch kernel (any K: rings beyond 4096)
   if (variant == 48) return launch_nvf4_os(p, s, 1616);                                       // lab: ... its 16x16 decode form (any M: rows in tiles of 16)
   if (variant == 49) return launch_nvf4_os(p, s, 3216);                                       // lab: ... with two m-tiles per workgroup (32x16)
+  if (variant == 55) return launch_nvf4_os(p, s, 9632);                                       // lab: ... with three m-tiles per workgroup (96x32 tiles)
   if (variant == 54) return launch_nvf4_os(p, s, 6432);                                       // lab: the 32x32-MFMA kernel with two m-tiles per workgroup (64x32 tiles)
   if (variant >= 50 && variant <= 53) return launch_nvf4_os(p, s, variant == 50 ? 1632 : variant == 51 ? 1648 : variant == 52 ? 1656 : 856);   // lab: ... with 32 / 48 / 56 columns per workgroup (53: 56 columns, A rows 0 ... 7 only)
 #endif
-  if (variant == 0 && plan.cfg <= -2) return launch_nvf4_os(p, s, plan.cfg == -10 ? 6432 : plan.cfg == -9 ? 856 : plan.cfg == -8 ? 1656 : plan.cfg == -7 ? 1648 : plan.cfg == -6 ? 1632 : plan.cfg == -5 ? 3216 : plan.cfg == -4 ? 1616 : plan.cfg == -3 ? 16 : 32);
+  if (variant == 0 && plan.cfg <= -2) return launch_nvf4_os(p, s, plan.cfg == -11 ? 9632 : plan.cfg == -10 ? 6432 : plan.cfg == -9 ? 856 : plan.cfg == -8 ? 1656 : plan.cfg == -7 ? 1648 : plan.cfg == -6 ? 1632 : plan.cfg == -5 ? 3216 : plan.cfg == -4 ? 1616 : plan.cfg == -3 ? 16 : 32);
   if (variant == 3 || (variant == 0 && plan.cfg < 0)) {
     hipLaunchKernelGGL((gemm_nvf4_skinny_kernel<8>), dim3((p.N + 31) / 32, (p.M + 31) / 32), dim3(512), 0, s, p);
     return hipSuccess;

@@ -28,7 +28,7 @@ struct NvOsCfg {
   static constexpr int RED = NW * TM * 128;
   static constexpr int LDS_BYTES = NSLOT * STAGE > RED ? NSLOT * STAGE : RED;
   static_assert(TN == 32 || TN == 16, "tile width");
-  static_assert(MT == 1 || MT == 2, "m-tiles");
+  static_assert(MT >= 1 && MT <= 3, "m-tiles");   // (MT = 3: 96 rows -- 18 KiB per stage, eight slots = 144 KiB)
   static_assert(SPW >= 1 && SPW * LPS <= 63, "vmcnt immediate");
   static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
 };
@@ -57,12 +57,15 @@ __global__ __launch_bounds__(512) void gemm_nvf4_os_kernel(const NvGemmParams p)
     vP[par] = (lane >> 3) * rowbytes + (chP[par] << 4);
   }
   const int rstep = 8 * rowbytes;
-  const uint32_t sa_off = (uint32_t)(m0 >> 7) * CB * 512, sb_off = (uint32_t)(n0 >> 7) * CB * 512;
-  const __amdgpu_buffer_rsrc_t rSA = make_rsrc(p.SFA + sa_off, p.sfa_bytes - sa_off), rSB = make_rsrc(p.SFB + sb_off, p.sfb_bytes - sb_off);
+  const uint32_t sb_off = (uint32_t)(n0 >> 7) * CB * 512;
+  const __amdgpu_buffer_rsrc_t rSA = make_rsrc(p.SFA, p.sfa_bytes), rSB = make_rsrc(p.SFB + sb_off, p.sfb_bytes - sb_off);
   const int rowB = (n0 & 127) + i32;   // (TN = 16: n0 is a multiple of 16 only; lanes past the 16 rows fetch some row's dword -- unused)
-  int vSA[MT];
+  int vSA[MT];   // A scale rows are addressed from the operand's start: a 96-row tile's m-tiles may lie in two 128-row scale tiles
 #pragma unroll
-  for (int t = 0; t < MT; ++t) vSA[t] = 2 * g * 512 + i32 * 16 + (((m0 & 127) >> 5) + t) * 4;
+  for (int t = 0; t < MT; ++t) {
+    const int rabs = m0 + 32 * t;
+    vSA[t] = (rabs >> 7) * CB * 512 + 2 * g * 512 + i32 * 16 + ((rabs & 127) >> 5) * 4;
+  }
   const int vSB = 2 * g * 512 + (rowB & 31) * 16 + ((rowB & 127) >> 5) * 4;
 
   auto issue = [&](const int kt, const int slot) __attribute__((always_inline)) {   // stage kt into slot `slot` of this wave (kt >= KT: every piece out of range -> zeros)
@@ -184,8 +187,8 @@ __global__ __launch_bounds__(512) void gemm_nvf4_os_kernel(const NvGemmParams p)
     for (int q = 0; q < 4; ++q)
       *(v4f*)(smem + (wave * C::TM + 32 * t + i32) * 128 + (((2 * q + g) ^ (i32 & 7)) << 4)) = v4f{acc[t][4 * q + 0], acc[t][4 * q + 1], acc[t][4 * q + 2], acc[t][4 * q + 3]};
   __syncthreads();
-  if (tid < 256 * MT) {
-    const int rr = tid >> 3, cq = tid & 7;   // row of the TM x 32 tile, chunk of 4 columns
+  for (int it = tid; it < C::TM * 8; it += 512) {
+    const int rr = it >> 3, cq = it & 7;   // row of the TM x 32 tile, chunk of 4 columns
     v4f t = *(const v4f*)(smem + rr * 128 + ((cq ^ (rr & 7)) << 4));
 #pragma unroll
     for (int w = 1; w < NW; ++w) {
@@ -457,11 +460,17 @@ hipError_t launch_nvf4_os(NvGemmParams p, hipStream_t s, int tn) {
 #undef QAMD_NVW
     return hipSuccess;
   }
-  if (tn == 6432) {   // [r6] two m-tiles per workgroup (64x32 tiles): one slot per wave -- one shot up to K = 2048, refilled beyond
-    p.tiles_m = (p.M + 63) / 64;
+  if (tn == 6432 || tn == 9632) {   // [r6] two / three m-tiles per workgroup (64x32 / 96x32 tiles): one slot per wave -- one shot up to K = 2048, refilled beyond
+    const int tm = tn == 9632 ? 96 : 64;
+    p.tiles_m = (p.M + tm - 1) / tm;
     p.tiles_n = (p.N + 31) / 32;
     const int KT = (p.K / 2 + 127) / 128;
     const dim3 grid(p.tiles_m * p.tiles_n), block(512);
+    if (tm == 96) {
+      if (KT <= 8) hipLaunchKernelGGL((gemm_nvf4_os_kernel<NvOsCfg<1, 32, 3>, false>), grid, block, 0, s, p);
+      else hipLaunchKernelGGL((gemm_nvf4_os_kernel<NvOsCfg<1, 32, 3>, true>), grid, block, 0, s, p);
+      return hipSuccess;
+    }
     if (KT <= 8) hipLaunchKernelGGL((gemm_nvf4_os_kernel<NvOsCfg<1, 32, 2>, false>), grid, block, 0, s, p);
     else hipLaunchKernelGGL((gemm_nvf4_os_kernel<NvOsCfg<1, 32, 2>, true>), grid, block, 0, s, p);
     return hipSuccess;

@@ -365,8 +365,8 @@ def test_persistent_kernel_with_an_odd_number_of_k_stages(m, n, k, grid):
 NVOS_SHAPES = [(1, 8, 32), (5, 72, 1024), (33, 104, 1440), (40, 200, 2944), (64, 96, 3104), (31, 264, 4096), (17, 4096, 3968), (9, 136, 4224), (33, 72, 11040), (3, 40, 14336)]
 
 
-@pytest.mark.parametrize("variant", [46, 47, 48, 49, 50, 51, 52, 53, 54, 0])   # (50 ... 52: the decode form with 32 / 48 / 56 columns per workgroup; 53: 56 columns, A rows 0 ... 7 only -- M <= 8; 54: the 32x32-MFMA kernel with two m-tiles per workgroup)   # (48: the 16x16 decode form on v_mfma_f32_16x16x32_f16, one shot up to K = 8192; 49: two m-tiles per workgroup, up to K = 4096)
-@pytest.mark.parametrize("m,n,k", NVOS_SHAPES + [(16, 4096, 4096), (7, 264, 8192), (12, 136, 8480), (8, 14336, 4096), (5, 392, 1056), (16, 616, 2080), (128, 520, 4096), (100, 264, 2080)])
+@pytest.mark.parametrize("variant", [46, 47, 48, 49, 50, 51, 52, 53, 54, 55, 0])   # (50 ... 52: the decode form with 32 / 48 / 56 columns per workgroup; 53: 56 columns, A rows 0 ... 7 only -- M <= 8; 54 / 55: the 32x32-MFMA kernel with two / three m-tiles per workgroup)   # (48: the 16x16 decode form on v_mfma_f32_16x16x32_f16, one shot up to K = 8192; 49: two m-tiles per workgroup, up to K = 4096)
+@pytest.mark.parametrize("m,n,k", NVOS_SHAPES + [(16, 4096, 4096), (7, 264, 8192), (12, 136, 8480), (8, 14336, 4096), (5, 392, 1056), (16, 616, 2080), (128, 520, 4096), (100, 264, 2080), (200, 136, 4128)])
 def test_nvf4_wave_owned_kernel_against_the_oracle(variant, m, n, k):
     from qutlass_amd.utils import to_blocked
 
