@@ -505,3 +505,26 @@ def test_decode_forms_on_ragged_wide_weights(q, fmt, seed):
             ref = oracle.gemm_blockscaled(oracle.KIND_NVFP4, _np(a), _np(b), oracle.to_blocked(_np(sa)), oracle.to_blocked(_np(sb)), 0.5, m, n, k)
         bad = _np(got) != ref
         assert not bad.any(), f"{fmt} {m}x{n}x{k}: {int(bad.sum())} of {bad.size} outputs differ, first at {np.argwhere(bad)[0].tolist()}"
+
+
+@pytest.mark.parametrize("m,n,k", [(300, 2048, 2048), (384, 2056, 2048), (24, 28672, 4096), (160, 4096, 8192), (96, 6144, 4096), (128, 4104, 4128), (192, 4096, 4096), (72, 8192, 2080)])
+def test_nvf4_priced_forms_through_the_product_rule(q, m, n, k):
+    """[r6] shapes nvf4_plan sends to the wave-owned kernel in several rounds of 32x32 tiles or to its 64x32 / 96x32 forms (gemm_nvf4.hip.h: the priced candidates; the CPU half pins
+    the plan), through the product library and the torch op: exact-regime scale bytes, sampled rows against the oracle and every row against the lab library's 128x128 tiles"""
+    from qutlass_amd.utils import to_blocked
+
+    rng = np.random.default_rng(m + n + k)
+    a = torch.from_numpy(rng.integers(0, 256, size=(m, k // 2), dtype=np.uint8)).to(DEV)
+    b = torch.from_numpy(rng.integers(0, 256, size=(n, k // 2), dtype=np.uint8)).to(DEV)
+    sa = torch.from_numpy(rng.integers(0x38, 0x48, size=(m, k // 16), dtype=np.uint8)).to(DEV)
+    sb = torch.from_numpy(rng.integers(0x38, 0x48, size=(n, k // 16), dtype=np.uint8)).to(DEV)
+    e4 = torch.float8_e4m3fn
+    alpha = torch.tensor([0.5], device=DEV)
+    sa_b, sb_b = to_blocked(sa.view(e4)), to_blocked(sb.view(e4))
+    got = q.matmul_nvf4_bf16_tn(a, b, sa_b, sb_b, alpha)
+    with lab.forced(nvf4_variant=5):   # 128x128 tiles, one pass
+        single = lab.matmul_nvf4_bf16_tn(a, b, sa_b, sb_b, alpha)
+    assert torch.equal(got.view(torch.int16), single.view(torch.int16))
+    rows = sorted({0, 31, 32, 63, 64, 95, 96, m // 2, m - 1} & set(range(m)))
+    ref = oracle.gemm_blockscaled(oracle.KIND_NVFP4, np.ascontiguousarray(_np(a)[rows]), _np(b), oracle.to_blocked(np.ascontiguousarray(_np(sa)[rows])), oracle.to_blocked(_np(sb)), 0.5, len(rows), n, k)
+    assert np.array_equal(_np(got)[rows], ref)
